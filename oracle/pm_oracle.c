@@ -1,0 +1,269 @@
+/*
+ * oracle/pm_oracle.c — CPU restatement of the reference's PM gravity path.
+ *
+ * TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library, and only as the checker / CPU
+ * baseline.  The product (concept_amd/, libconcept_gpu.so) never links,
+ * loads or calls it.
+ *
+ * Parity status: PINNED.  oracle/oracle.py drives these functions and
+ * tests/test_oracle_golden.py checks every intermediate against the golden
+ * vectors in tests/golden/*.npz, which were produced by importing the
+ * reference's pure-Python path (tests/golden/make_golden.py).
+ *
+ * Every function cites the reference lines (under /root/reference/src) it
+ * restates.  Plain IEEE double; build with -ffp-contract=off (no FMA
+ * contraction) so the operation order below is the operation order executed.
+ * FFTs are not here: oracle.py uses numpy's pocketfft exactly as the
+ * reference's pure-Python fft() does (mesh.py:4035-4143).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+typedef int64_t i64;
+
+/* set_weights_CIC, mesh.py:5319-5324 */
+static inline i64 set_weights_cic(double x, double *w) {
+    i64 index = (i64)x; /* int(x), x >= 0 here */
+    double dist = x - (double)index;
+    w[0] = 1 - dist;
+    w[1] = dist;
+    return index;
+}
+
+/*
+ * A1  CIC deposit.  interpolate_particles (mesh.py:1512-1636) with the inlined
+ * particle_interpolation_loop_CIC (mesh.py:5101-5155).
+ * offset[d] and scale are computed by the caller exactly as mesh.py:1577-1589
+ * and the R[(1/cellsize)*(1 - machine_eps)] constant of mesh.py:1604.
+ * grid is the ghosted domain grid double[size_i][size_j][size_k].
+ * idx_out (nullable): the three set_weights_CIC indices per particle.
+ */
+void orc_cic_deposit(const double *pos, i64 N, double *grid, i64 size_j, i64 size_k,
+                     const double *offset, double scale, double contribution, i64 *idx_out) {
+    double wx[2], wy[2], wz[2];
+    for (i64 p = 0; p < N; p++) {
+        double x = (pos[3 * p + 0] - offset[0]) * scale;
+        double y = (pos[3 * p + 1] - offset[1]) * scale;
+        double z = (pos[3 * p + 2] - offset[2]) * scale;
+        i64 ii = set_weights_cic(x, wx);
+        i64 jj = set_weights_cic(y, wy);
+        i64 kk = set_weights_cic(z, wz);
+        if (idx_out) {
+            idx_out[3 * p + 0] = ii;
+            idx_out[3 * p + 1] = jj;
+            idx_out[3 * p + 2] = kk;
+        }
+        /* mesh.py:5138-5155 */
+        i64 index_i = ((ii - 1) * size_j + (jj - 1)) * size_k + kk - 1;
+        for (int i = 0; i < 2; i++) {
+            double weight_i = wx[i];
+            weight_i *= contribution; /* apply_factor=True, mesh.py:5145-5146 */
+            index_i += size_j * size_k;
+            i64 index_j = index_i;
+            for (int j = 0; j < 2; j++) {
+                index_j += size_k;
+                i64 index = index_j;
+                double wij = weight_i * wy[j];
+                for (int k = 0; k < 2; k++) {
+                    index += 1;
+                    grid[index] += wij * wz[k];
+                }
+            }
+        }
+    }
+}
+
+/*
+ * A10  CIC gather + kick of one momentum component.
+ * interpolate_domaingrid_to_particles (mesh.py:376-459): value accumulated
+ * over the 8 cells in i,j,k order with weight (wx[i]*wy[j])*wz[k], then
+ * value *= factor (if factor != 1), then mom[3p+dim] += value.
+ */
+void orc_cic_gather_kick(const double *grid, i64 size_j, i64 size_k, const double *pos,
+                         double *mom, i64 N, int dim, const double *offset, double scale,
+                         double factor, i64 *idx_out) {
+    double wx[2], wy[2], wz[2];
+    for (i64 p = 0; p < N; p++) {
+        double x = (pos[3 * p + 0] - offset[0]) * scale;
+        double y = (pos[3 * p + 1] - offset[1]) * scale;
+        double z = (pos[3 * p + 2] - offset[2]) * scale;
+        i64 ii = set_weights_cic(x, wx);
+        i64 jj = set_weights_cic(y, wy);
+        i64 kk = set_weights_cic(z, wz);
+        if (idx_out) {
+            idx_out[3 * p + 0] = ii;
+            idx_out[3 * p + 1] = jj;
+            idx_out[3 * p + 2] = kk;
+        }
+        double value = 0;
+        i64 index_i = ((ii - 1) * size_j + (jj - 1)) * size_k + kk - 1;
+        for (int i = 0; i < 2; i++) {
+            double weight_i = wx[i];
+            index_i += size_j * size_k;
+            i64 index_j = index_i;
+            for (int j = 0; j < 2; j++) {
+                index_j += size_k;
+                i64 index = index_j;
+                double wij = weight_i * wy[j];
+                for (int k = 0; k < 2; k++) {
+                    index += 1;
+                    value += grid[index] * (wij * wz[k]);
+                }
+            }
+        }
+        if (factor != 1) value *= factor;
+        mom[3 * p + dim] += value;
+    }
+}
+
+/*
+ * A2 / A8  communicate_ghosts on ONE rank (communication.py:563-660): all 26
+ * neighbours are the domain itself.  op_add=1: '+=' (ghost values are added
+ * onto the interior cells of the periodic neighbour); op_add=0: '=' (reverse
+ * direction: ghosts are assigned from the opposite interior cells).
+ * The 26 blocks are visited in the reference's i,j,k order so that cells
+ * receiving several contributions are summed in the same order.
+ */
+static void block_range(int d, i64 n, i64 g, i64 *sb, i64 *se, i64 *rb, i64 *re) {
+    if (d == -1) { *sb = 0; *se = g; *rb = n - 2 * g; *re = n - g; }
+    else if (d == 0) { *sb = g; *se = n - g; *rb = g; *re = n - g; }
+    else { *sb = n - g; *se = n; *rb = g; *re = 2 * g; }
+}
+void orc_communicate_ghosts(double *grid, i64 ni, i64 nj, i64 nk, i64 g, int op_add) {
+    for (int i = -1; i < 2; i++) for (int j = -1; j < 2; j++) for (int k = -1; k < 2; k++) {
+        if (i == 0 && j == 0 && k == 0) continue;
+        i64 sbi, sei, rbi, rei, sbj, sej, rbj, rej, sbk, sek, rbk, rek;
+        block_range(i, ni, g, &sbi, &sei, &rbi, &rei);
+        block_range(j, nj, g, &sbj, &sej, &rbj, &rej);
+        block_range(k, nk, g, &sbk, &sek, &rbk, &rek);
+        for (i64 a = 0; a < sei - sbi; a++) for (i64 b = 0; b < sej - sbj; b++)
+            for (i64 c = 0; c < sek - sbk; c++) {
+                i64 s = ((sbi + a) * nj + (sbj + b)) * nk + (sbk + c);
+                i64 r = ((rbi + a) * nj + (rbj + b)) * nk + (rbk + c);
+                if (op_add) grid[r] += grid[s];
+                else grid[s] = grid[r];
+            }
+    }
+}
+
+/*
+ * A3  slab_decompose on one rank (mesh.py:2284-2411): interior of the ghosted
+ * domain grid -> x-slab double[N][N][N+2], padding zeroed (mesh.py:2338-2339).
+ */
+void orc_slab_decompose(const double *grid, i64 N, i64 g, double *slab) {
+    i64 n = N + 2 * g, pad = N + 2;
+    for (i64 i = 0; i < N; i++) for (i64 j = 0; j < N; j++) {
+        const double *src = grid + ((i + g) * n + (j + g)) * n + g;
+        double *dst = slab + (i * N + j) * pad;
+        memcpy(dst, src, sizeof(double) * N);
+        dst[N] = 0; dst[N + 1] = 0;
+    }
+}
+/* A8  domain_decompose on one rank (mesh.py:2138-2244), interior only */
+void orc_domain_decompose(const double *slab, i64 N, i64 g, double *grid) {
+    i64 n = N + 2 * g, pad = N + 2;
+    for (i64 i = 0; i < N; i++) for (i64 j = 0; j < N; j++)
+        memcpy(grid + ((i + g) * n + (j + g)) * n + g, slab + (i * N + j) * pad,
+               sizeof(double) * N);
+}
+
+/*
+ * A5  nullify_modes 'nyquist' (mesh.py:3591-3622) on the transposed slab
+ * double[j][i][N+2] (one rank: j is global).
+ */
+void orc_nullify_nyquist(double *slab, i64 N) {
+    i64 nyq = N / 2, pad = N + 2;
+    for (i64 j = 0; j < N; j++) for (i64 i = 0; i < N; i++) {
+        double *row = slab + (j * N + i) * pad;
+        if (i == nyq || j == nyq) memset(row, 0, sizeof(double) * pad);
+        /* note: the reference leaves k = N (kk = nyquist) of those rows to the
+           third loop, which zeroes it anyway */
+        row[2 * nyq] = 0; row[2 * nyq + 1] = 0;
+    }
+}
+
+/*
+ * A6  Poisson / deconvolution kernel: fourier_loop (mesh.py:2615-2890) inlined
+ * into particle_mesh (interactions.py:2092-2118), one rank, slab in the
+ * transposed layout double[j][i][N+2].  Nyquist planes are skipped (they
+ * were nullified before), the origin is skipped and then nullified.
+ *   C = -boxsize**2*G_Newton/pi               (interactions.py:2105)
+ *   E = -(2*pi/boxsize*scale)**2 or unused    (interactions.py:2112)
+ */
+void orc_kspace_poisson(double *slab, i64 N, int deconv_order, double C, int long_range,
+                        double E, double machine_eps) {
+    const double pi = 3.141592653589793; /* float(np.pi), commons.py:1816 */
+    double pi_over_n = pi / (double)N;
+    i64 nyq = N / 2, pad = N + 2;
+    for (i64 j = 0; j < N; j++) {
+        if (j == nyq) continue;
+        i64 kj = j - (j >= nyq ? N : 0);
+        double dj_n = (double)kj * pi_over_n + machine_eps; /* mesh.py:2775 */
+        double dj_d = sin(dj_n);
+        for (i64 i = 0; i < N; i++) {
+            if (i == nyq) continue;
+            i64 ki = i - (i >= nyq ? N : 0);
+            double di_n = (double)ki * pi_over_n + machine_eps; /* mesh.py:2795 */
+            double di_d = sin(di_n);
+            double dij_n = di_n * dj_n; /* mesh.py:2797 */
+            double dij_d = di_d * dj_d;
+            double *row = slab + (j * N + i) * pad;
+            for (i64 kk = (i == 0 && j == 0) ? 1 : 0; kk < nyq; kk++) {
+                double factor = 1;
+                if (deconv_order) {
+                    double dk_n = (double)kk * pi_over_n + machine_eps;
+                    double dk_d = sin(dk_n);
+                    factor = (dij_n * dk_n) / (dij_d * dk_d); /* mesh.py:2850-2853 */
+                    factor = pow(factor, (double)deconv_order); /* mesh.py:2855 */
+                }
+                factor *= 1.0; /* 1/len(lattice), 'sc' lattice, mesh.py:2856 */
+                i64 k2 = (kj * kj + ki * ki) + kk * kk; /* interactions.py:2096 */
+                if (!long_range) factor *= C / (double)k2; /* interactions.py:2105 */
+                else factor *= C / (double)k2 * exp((double)k2 * E); /* :2110-2113 */
+                row[2 * kk] *= factor;
+                row[2 * kk + 1] *= factor;
+            }
+        }
+    }
+    slab[0] = 0; slab[1] = 0; /* nullify_modes('origin'), mesh.py:3585-3590 */
+}
+
+/*
+ * A9  diff_domaingrid (mesh.py:4874-5030): symmetric finite difference of the
+ * ghosted grid along dim, interior only; orders 2 and 4 (1, 6, 8 are not on
+ * the path's defaults and are rejected by the host).
+ */
+void orc_diff_domaingrid(const double *grid, double *out, i64 ni, i64 nj, i64 nk, i64 g, int dim,
+                         int order, double dx) {
+    i64 step = dim == 0 ? nj * nk : (dim == 1 ? nk : 1);
+    double c2 = (1.0 / 2) / dx, c4a = (2.0 / 3) / dx, c4b = (1.0 / 12) / dx;
+    for (i64 i = g; i < ni - g; i++) for (i64 j = g; j < nj - g; j++)
+        for (i64 k = g; k < nk - g; k++) {
+            i64 ix = (i * nj + j) * nk + k;
+            if (order == 2)
+                out[ix] = c2 * (grid[ix + step] - grid[ix - step]);
+            else
+                out[ix] = c4a * (grid[ix + step] - grid[ix - step])
+                        - c4b * (grid[ix + 2 * step] - grid[ix - 2 * step]);
+        }
+}
+
+/*
+ * A11  Component.drift (species.py:2179-2199) with the pure-Python mod()
+ * (commons.py:5103-5110): np.mod (floored modulo) then x == length -> 0.
+ */
+static inline double np_mod(double a, double b) {
+    double m = fmod(a, b);
+    if (m != 0) { if ((b < 0) != (m < 0)) m += b; }
+    else m = copysign(0.0, b);
+    return m;
+}
+void orc_drift(double *pos, const double *mom, i64 n3, double dt_over_mass, double boxsize) {
+    for (i64 r = 0; r < n3; r++) {
+        double x = np_mod(pos[r] + mom[r] * dt_over_mass, boxsize);
+        if (x == boxsize) x = 0;
+        pos[r] = x;
+    }
+}

@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference); the output .npz
+files are data (inputs + the reference's outputs and intermediates) and are
+what travels.  One reference import per process (its parameters are module
+globals), so every case is generated in its own subprocess:
+
+    python tests/golden/make_golden.py            # all cases
+    python tests/golden/make_golden.py pm_n8_g16  # one case (child mode)
+
+Reference entry points exercised (file:line in /root/reference/src):
+  interactions.gravity            interactions.py:2854
+  interactions.particle_mesh      interactions.py:1985
+  mesh.interpolate_particles      mesh.py:1512      (CIC deposit)
+  mesh.interpolate_domaingrid_to_particles mesh.py:376 (CIC gather-kick)
+  mesh.diff_domaingrid            mesh.py:4874
+  species.Component.drift         species.py:2179
+  gravity.gravity_pairwise_shortrange gravity.py:263 (P3M cases)
+Intermediates are captured by rebinding module globals of the imported
+pure-Python modules (commons.py:1268-1274 binds cimported names as plain
+globals), never by editing reference files.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+
+# name -> dict(method, n (particles per dim or explicit), gridsize, boxsize, ...)
+CASES = {
+    # PM, default differentiation order 2, uniform random particles + random momenta
+    'pm_n8_g16': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=1, dist='uniform',
+                      diff=2, full=True),
+    'pm_n16_g32': dict(method='pm', n=16, gridsize=32, boxsize=100.0, seed=2, dist='uniform',
+                       diff=2, full=True),
+    # boundary stress: particles exactly at 0, at cell centres/edges, next below boxsize
+    'pm_edge_g16': dict(method='pm', n=0, gridsize=16, boxsize=64.0, seed=3, dist='edge',
+                        diff=2, full=True),
+    # differentiation order 4 (the p3m default, commons.py:3209-3237)
+    'pm_n8_g16_d4': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=4, dist='uniform',
+                         diff=4, full=True),
+    # clustered ("Zel'dovich-like" displaced lattice), in/out only
+    'pm_n32_g64': dict(method='pm', n=32, gridsize=64, boxsize=256.0, seed=5, dist='lattice',
+                       diff=2, full=False),
+    # P3M long-range (Gaussian cut-off in the Poisson kernel) + short-range
+    'p3m_n8_g32': dict(method='p3m', n=8, gridsize=32, boxsize=32.0, seed=6, dist='uniform',
+                       diff=4, full=True),
+    'p3m_n12_g36_lattice': dict(method='p3m', n=12, gridsize=36, boxsize=36.0, seed=7,
+                                dist='perfect_lattice', diff=4, full=False),
+    'p3m_n16_g48_clustered': dict(method='p3m', n=16, gridsize=48, boxsize=48.0, seed=8,
+                                  dist='clustered', diff=4, full=False),
+}
+
+
+def make_positions(np, cfg):
+    rng = np.random.default_rng(cfg['seed'])
+    L = cfg['boxsize']
+    n = cfg['n']
+    dist = cfg['dist']
+    if dist == 'uniform':
+        pos = rng.uniform(0, L, size=(n**3, 3))
+    elif dist == 'lattice':
+        g = (np.arange(n) + 0.5)*(L/n)
+        pos = np.stack(np.meshgrid(g, g, g, indexing='ij'), axis=-1).reshape(-1, 3)
+        pos = pos + rng.normal(0, 1.5*L/cfg['gridsize'], size=pos.shape)
+        pos = np.mod(pos, L)
+    elif dist == 'perfect_lattice':
+        g = (np.arange(n) + 0.5)*(L/n)
+        pos = np.stack(np.meshgrid(g, g, g, indexing='ij'), axis=-1).reshape(-1, 3)
+    elif dist == 'clustered':
+        nc = 6
+        centres = rng.uniform(0, L, size=(nc, 3))
+        which = rng.integers(0, nc, size=n**3)
+        pos = centres[which] + rng.normal(0, 0.03*L, size=(n**3, 3))
+        pos = np.mod(pos, L)
+    elif dist == 'edge':
+        N = cfg['gridsize']
+        c = L/N
+        specials = [0.0, np.nextafter(L, 0), c, np.nextafter(c, 0), 0.5*c, np.nextafter(0.5*c, 0),
+                    np.nextafter(0.5*c, L), L - 0.5*c, np.nextafter(L - 0.5*c, L), L/2,
+                    np.nextafter(L/2, 0), 5e-324, 1e-300, 7*c, 7.5*c]
+        pts = []
+        for x in specials:
+            for y in (0.0, np.nextafter(L, 0), 3.3*c):
+                for z in (np.nextafter(L, 0), 0.5*c, 9.99*c):
+                    pts.append((x, y, z))
+                    pts.append((z, x, y))
+                    pts.append((y, z, x))
+        pos = np.array(pts, dtype=np.float64)
+    else:
+        raise ValueError(dist)
+    pos[pos >= L] = 0.0
+    return np.ascontiguousarray(pos, dtype=np.float64)
+
+
+def param_text(cfg):
+    method = cfg['method']
+    txt = f"""
+boxsize = {cfg['boxsize']!r}*Mpc
+potential_options = {{
+    'gridsize': {{'gravity': {{'{method}': {cfg['gridsize']}}}}},
+    'differentiation': {{'matter': {{'gravity': {{'{method}': {cfg['diff']}}}}}}},
+}}
+H0 = 70*km/s/Mpc
+Ωcdm = 0.25
+Ωb = 0.05
+a_begin = 0.5
+enable_class_background = False
+select_forces = {{'matter': {{'gravity': '{method}'}}}}
+"""
+    if method == 'p3m':
+        txt += "shortrange_params = {'gravity': {'subtiling': %r}}\n" % (cfg.get('subtiling', 2),)
+        txt += "select_softening_length = {'matter': '0.03*boxsize/cbrt(N)'}\n"
+    return txt
+
+
+def child(name):
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, 'oracle', 'refharness'))
+    from ref_import import load_reference
+    cfg = CASES[name]
+    ref = load_reference(param_text(cfg), f'/tmp/concept_golden_work/{name}')
+    commons, mesh, interactions, species = ref.commons, ref.mesh, ref.interactions, ref.species
+    L = commons.boxsize
+    assert L == cfg['boxsize']
+    pos = make_positions(np, cfg)
+    N = pos.shape[0]
+    rng = np.random.default_rng(1000 + cfg['seed'])
+    mass = commons.ρ_mbar*L**3/N
+    mom = rng.normal(0, 1.0, size=(N, 3))*mass*0.01
+    comp = species.Component('matter', 'matter', N=N, mass=mass)
+    for d, s in enumerate('xyz'):
+        comp.populate(np.ascontiguousarray(pos[:, d]), 'pos' + s)
+        comp.populate(np.ascontiguousarray(mom[:, d]), 'mom' + s)
+    out = dict(
+        boxsize=L, gridsize=cfg['gridsize'], nghosts=commons.nghosts, G_Newton=commons.G_Newton,
+        mass=mass, N=N, diff_order=cfg['diff'], cell_centered=int(commons.cell_centered),
+        softening_length=comp.softening_length,
+        pos_in=np.array(comp.pos_mv3[:N]).copy(), mom_in=np.array(comp.mom_mv3[:N]).copy(),
+    )
+    # Time-step integrals: plain, distinct numbers so a mixed-up key shows
+    dt = 0.013
+    sdt = {
+        '1': dt,
+        'a**(-2)': dt*3.7,
+        ('a**(-3*w_eff)', 'matter'): dt*1.1,
+        ('a**(-3*w_eff-1)', 'matter'): dt*1.9,
+    }
+    out.update(dt_1=sdt['1'], dt_am2=sdt['a**(-2)'], dt_kick=sdt['a**(-3*w_eff)', 'matter'],
+               dt_dens=sdt['a**(-3*w_eff-1)', 'matter'])
+    # ---- capture hooks (module-global rebinding) ----
+    cap = {}
+    idx_log = []
+    orig_set_weights = mesh.set_weights_CIC
+
+    def set_weights_CIC(x, weights):
+        index = orig_set_weights(x, weights)
+        idx_log.append(index)
+        return index
+    mesh.set_weights_CIC = set_weights_CIC
+
+    orig_interp_particles = mesh.interpolate_particles
+
+    def interpolate_particles(component, gridsize, grid, *a, **k):
+        orig_interp_particles(component, gridsize, grid, *a, **k)
+        cap['grid_deposit'] = np.array(grid).copy()
+        cap['cic_index_deposit'] = np.array(idx_log, dtype=np.int64).reshape(-1, 3)
+        idx_log.clear()
+    mesh.interpolate_particles = interpolate_particles
+
+    orig_upstream = interactions.interpolate_upstream
+
+    def interpolate_upstream(*a, **k):
+        slab = orig_upstream(*a, **k)
+        cap['slab_density_k'] = np.array(slab).copy()
+        return slab
+    interactions.interpolate_upstream = interpolate_upstream
+
+    orig_fft = interactions.fft
+
+    def fft(slab, direction, *a, **k):
+        if direction == 'backward':
+            cap['slab_potential_k'] = np.array(slab).copy()
+        return orig_fft(slab, direction, *a, **k)
+    interactions.fft = fft
+
+    orig_dd = interactions.domain_decompose
+
+    def domain_decompose(*a, **k):
+        grid = orig_dd(*a, **k)
+        cap['grid_potential'] = np.array(grid).copy()
+        return grid
+    interactions.domain_decompose = domain_decompose
+
+    orig_diff = interactions.diff_domaingrid
+    forces = []
+
+    def diff_domaingrid(*a, **k):
+        g = orig_diff(*a, **k)
+        forces.append(np.array(g).copy())
+        return g
+    interactions.diff_domaingrid = diff_domaingrid
+
+    orig_apply = interactions.apply_particle_mesh_force
+    gather_idx = []
+
+    def apply_particle_mesh_force(*a, **k):
+        idx_log.clear()
+        orig_apply(*a, **k)
+        gather_idx.append(np.array(idx_log, dtype=np.int64).reshape(-1, 3))
+        idx_log.clear()
+    interactions.apply_particle_mesh_force = apply_particle_mesh_force
+
+    method = cfg['method']
+    interactions.gravity(method, [comp], [comp], sdt, 'long-range', False)
+    out['mom_after_long'] = np.array(comp.mom_mv3[:N]).copy()
+    out['cic_index_deposit'] = cap['cic_index_deposit']
+    out['cic_index_gather'] = gather_idx[0]
+    assert all(np.array_equal(gather_idx[0], g) for g in gather_idx)
+    if cfg['full']:
+        out['grid_deposit'] = cap['grid_deposit']
+        out['slab_density_k'] = cap['slab_density_k']
+        out['slab_potential_k'] = cap['slab_potential_k']
+        out['grid_potential'] = cap['grid_potential']
+        out['grid_force'] = np.stack(forces)
+    else:
+        # checksums + strided sample of the big grids
+        for key in ('grid_deposit', 'slab_density_k', 'slab_potential_k', 'grid_potential'):
+            a = cap[key]
+            out[key + '_sum'] = a.sum()
+            out[key + '_abssum'] = np.abs(a).sum()
+            out[key + '_sample'] = a.ravel()[::97].copy()
+    mesh.set_weights_CIC = orig_set_weights
+    if method == 'p3m':
+        out['shortrange_scale'] = commons.shortrange_params['gravity']['scale']
+        out['shortrange_range'] = commons.shortrange_params['gravity']['range']
+        out['shortrange_tilesize'] = commons.shortrange_params['gravity']['tilesize']
+        out['shortrange_tablesize'] = commons.shortrange_params['gravity']['tablesize']
+        out['N_rungs'] = commons.N_rungs
+        # Short-range kick: all particles on rung 0, Δmom zeroed
+        # (what main.kick_short() sets up, main.py:1173-1262)
+        nr = commons.N_rungs
+        key2 = ('a**(-3*w_eff₀-3*w_eff₁-1)', 'matter', 'matter')
+        sdt_rungs = {key2: np.zeros(3*nr - 1)}
+        sdt_rungs[key2][:] = dt*2.3*(1 + 0.1*np.arange(3*nr - 1))
+        out['dt_rungs_pair'] = sdt_rungs[key2].copy()
+        comp.nullify_Δ('mom')
+        comp.lowest_active_rung = 0
+        comp.lowest_populated_rung = 0
+        comp.highest_populated_rung = 0
+        interactions.gravity(method, [comp], [comp], sdt_rungs, 'short-range', False)
+        out['dmom_short'] = np.array(comp.Δmom_mv3[:N]).copy()
+        out['pos_after_short'] = np.array(comp.pos_mv3[:N]).copy()  # tile_sort may reorder
+        out['mom_after_short_sorted'] = np.array(comp.mom_mv3[:N]).copy()
+        gravity_mod = ref.gravity
+        (table,) = gravity_mod.shortrange_tables.values()  # one softening -> one cached table
+        out['shortrange_table'] = np.array(table).copy()
+        out['shortrange_table_maxr2'] = gravity_mod.shortrange_table_maxr2
+        tiling = comp.tilings['gravity (tiles)']
+        out['tiling_shape'] = np.array(tiling.shape, dtype=np.int64)
+        sub = comp.tilings['gravity (subtiles)']
+        out['subtiling_shape'] = np.array(sub.shape, dtype=np.int64)
+    # Drift (species.py:2179-2199); universals.a is a_begin
+    pos_before = np.array(comp.pos_mv3[:N]).copy()
+    mom_before = np.array(comp.mom_mv3[:N]).copy()
+    comp.drift(sdt)
+    if method == 'p3m':  # tile_sort reordered the particles
+        out['drift_pos_in'] = pos_before
+        out['drift_mom_in'] = mom_before
+    else:  # drift input is (pos_in, mom_after_long)
+        assert np.array_equal(pos_before, out['pos_in'])
+        assert np.array_equal(mom_before, out['mom_after_long'])
+    out['drift_pos_out'] = np.array(comp.pos_mv3[:N]).copy()
+    out['drift_dt_over_mass'] = sdt['a**(-2)']*commons.universals.a**(
+        3*comp.w_eff(a=commons.universals.a))/comp.mass
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, {k: getattr(v, 'shape', v) for k, v in out.items()})
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] in CASES:
+        child(sys.argv[1])
+        return
+    names = list(CASES)
+    for name in names:
+        print('===', name, flush=True)
+        log = f'/tmp/concept_golden_{name}.log'
+        with open(log, 'w') as f:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), name], stdout=f,
+                               stderr=subprocess.STDOUT)
+        tail = open(log).read().splitlines()[-3:]
+        print('\n'.join(tail))
+        if r.returncode:
+            sys.exit(f'case {name} failed, see {log}')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,95 @@
+"""The CPU oracle against the golden vectors produced by importing the
+reference (tests/golden/make_golden.py).  This is what pins the oracle.
+
+Bars: CIC grid indices bit-exact; PM ('gravity' potential) intermediates and
+momenta bit-exact (same libm sin, same pocketfft); 'gravity long-range'
+(exp in the Poisson kernel: numpy's SIMD exp vs libm, 1 ulp) <= 1e-14 of the
+field rms."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+PM_CASES = ['pm_n8_g16', 'pm_n16_g32', 'pm_edge_g16', 'pm_n8_g16_d4']
+FIELDS = ['grid_deposit', 'slab_density_k', 'slab_potential_k', 'grid_potential', 'grid_force']
+
+
+def run_oracle(g, **kw):
+    pos = g['pos_in'].copy()
+    mom = g['mom_in'].copy()
+    sc = float(g['shortrange_scale']) if 'shortrange_scale' in g else None
+    o = oracle.pm_long_range(
+        pos, mom, mass=float(g['mass']), boxsize=float(g['boxsize']), gridsize=int(g['gridsize']),
+        G_Newton=float(g['G_Newton']), dt_1=float(g['dt_1']), dt_dens=float(g['dt_dens']),
+        dt_kick=float(g['dt_kick']), diff_order=int(g['diff_order']), shortrange_scale=sc, **kw)
+    return o, mom
+
+
+@pytest.mark.parametrize('name', PM_CASES)
+def test_pm_bit_exact(golden, name):
+    g = golden(name)
+    o, mom = run_oracle(g)
+    assert np.array_equal(o['cic_index_deposit'], g['cic_index_deposit'])
+    assert np.array_equal(o['cic_index_gather'], g['cic_index_gather'])
+    for k in FIELDS:
+        assert np.array_equal(o[k], g[k]), k
+    assert np.array_equal(mom, g['mom_after_long'])
+
+
+def test_pm_large_checksums(golden):
+    g = golden('pm_n32_g64')
+    o, mom = run_oracle(g)
+    assert np.array_equal(o['cic_index_deposit'], g['cic_index_deposit'])
+    assert np.array_equal(o['cic_index_gather'], g['cic_index_gather'])
+    for k in ['grid_deposit', 'slab_density_k', 'slab_potential_k', 'grid_potential']:
+        assert np.array_equal(o[k].ravel()[::97], g[k + '_sample']), k
+        assert o[k].sum() == float(g[k + '_sum'])
+    assert np.array_equal(mom, g['mom_after_long'])
+
+
+@pytest.mark.parametrize('name', ['p3m_n8_g32', 'p3m_n12_g36_lattice', 'p3m_n16_g48_clustered'])
+def test_p3m_long_range(golden, name):
+    g = golden(name)
+    o, mom = run_oracle(g)
+    assert np.array_equal(o['cic_index_deposit'], g['cic_index_deposit'])
+    assert np.array_equal(o['cic_index_gather'], g['cic_index_gather'])
+    if 'grid_deposit' in g:
+        assert np.array_equal(o['grid_deposit'], g['grid_deposit'])
+        assert np.array_equal(o['slab_density_k'], g['slab_density_k'])
+        for k in ['slab_potential_k', 'grid_potential', 'grid_force']:
+            rms = np.sqrt((g[k]**2).mean())
+            assert np.abs(o[k] - g[k]).max() <= 1e-14*rms, k
+    kick_ref = g['mom_after_long'] - g['mom_in']
+    kick = mom - g['mom_in']
+    scale = max(np.sqrt((kick_ref**2).mean()), 1e-300)
+    assert np.abs(mom - g['mom_after_long']).max() <= 1e-13*max(scale, np.abs(g['mom_in']).max())
+
+
+@pytest.mark.parametrize('name', PM_CASES + ['pm_n32_g64', 'p3m_n8_g32'])
+def test_drift_bit_exact(golden, name):
+    g = golden(name)
+    pos = (g['drift_pos_in'] if 'drift_pos_in' in g else g['pos_in']).copy()
+    mom = g['drift_mom_in'] if 'drift_mom_in' in g else g['mom_after_long']
+    oracle.drift(pos, mom, float(g['drift_dt_over_mass']), float(g['boxsize']))
+    assert np.array_equal(pos, g['drift_pos_out'])
+    assert (pos >= 0).all() and (pos < float(g['boxsize'])).all()
+
+
+def test_drift_wrap_edge_cases():
+    L = 10.0
+    pos = np.array([0.0, 9.999999999999998, 5.0, 1e-17, 9.5, 0.25], dtype=np.float64)
+    mom = np.array([-1e-17, 1.0, 25.0, -1.0, 0.5, -30.25], dtype=np.float64)
+    ref = np.mod(pos + mom*1.0, L)
+    ref[ref == L] = 0
+    out = oracle.drift(pos.copy(), mom, 1.0, L)
+    assert np.array_equal(out, ref)
+    assert (out >= 0).all() and (out < L).all()
+
+
+def test_fast_build_agrees_to_rounding(golden):
+    """The -ffast-math timing build is the CPU baseline; it must still be the
+    same algorithm (agreement to rounding, not bit-exact)."""
+    g = golden('pm_n16_g32')
+    o, mom = run_oracle(g, fast=True)
+    kick = g['mom_after_long'] - g['mom_in']
+    assert np.abs(mom - g['mom_after_long']).max() <= 1e-10*np.abs(kick).max()
