@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py — PM steps/s and particle-updates/s of the MI355X gravity stepper.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+One "step" = one full PM base step of the reference's time loop
+(main.py:335-358: drift -> long-range kick) on synthetic, HBM-resident
+particles: drift (A11) + tile sort, mesh zero + CIC deposit (A1/A2), rocFFT
+R2C (A4), k-space Poisson kernel (A5/A6), C2R (A8), fused finite-difference +
+CIC gather + kick (A9/A10).  Workload at N=1: BASELINE.json's metric
+configuration, 2^28 (~256M) particles on a 1024^3 mesh, FP64.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant hand-written
+kernel, from HIP events on the stream the kernels run on; `cpu_baseline` is
+the C oracle (oracle/, a port of the reference's algorithm) timed on a
+bounded sample on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+WORKLOADS = {
+    # name: (particles, gridsize)
+    'ns_256M_1024': (2**28, 1024),       # BASELINE.json metric config
+    'c2_256c_512': (256**3, 512),        # configs[1]
+    'c1_128c_256': (128**3, 256),        # configs[0]
+    'tiny': (32**3, 64),
+}
+
+
+def algorithmic_bytes(n_p, n_g):
+    """SURVEY.md §8(d) per-phase algorithmic bytes (FP64), adjusted to what
+    this build's fused kernels must move at minimum (stated in DESIGN.md)."""
+    return {
+        'zero': 8*n_g,
+        'deposit': 24*n_p + 8*n_g,               # read pos, write (accumulate) grid
+        'fft_forward': 48*n_g,                   # 3 passes x (read + write)
+        'kspace': 16*n_g,
+        'fft_backward': 48*n_g,
+        'gather_kick': 24*n_p + 48*n_p + 8*n_g,  # pos, mom RMW, potential once (FD fused)
+        'drift': 48*n_p + 24*n_p,
+        'sort': 2*(48*n_p) + 24*n_p,             # histogram reads pos; scatter moves pos+mom
+    }
+
+
+def cpu_baseline(sample_n=128, sample_grid=256, steps=2):
+    """The oracle (a C port of the reference's algorithm + numpy pocketfft,
+    the reference's own pure-Python FFT) on a bounded sample, 1 thread."""
+    import numpy as np
+    from oracle import oracle
+    oracle.build()
+    n = sample_n**3
+    L = float(sample_grid)
+    rng = np.random.default_rng(7)
+    pos = rng.uniform(0, L, (n, 3))
+    mom = np.zeros((n, 3))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        oracle.drift(pos, mom, 1e-3, L, fast=True)
+        oracle.pm_long_range(pos, mom, mass=1.0, boxsize=L, gridsize=sample_grid, G_Newton=1.0,
+                             dt_1=1e-3, dt_dens=1e-3, dt_kick=1e-3, diff_order=2, fast=True,
+                             want_indices=False)
+    dt = time.perf_counter() - t0
+    return {
+        'value': n*steps/dt, 'unit': 'particle-updates/s', 'cores': 1, 'kind': 'port',
+        'steps_per_sec': steps/dt,
+        'sample': f'{sample_n}^3 particles / {sample_grid}^3 mesh (BASELINE configs[0]), '
+                  f'{steps} PM steps, oracle C port built -O3 -funroll-loops -ffast-math '
+                  f'(reference src/Makefile flags) + numpy pocketfft, {dt:.1f} s wall',
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sort', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from concept_amd.mesh import PotentialMesh
+    if world > 1:
+        from concept_amd import distributed  # noqa: F401
+        sys.exit('bench.py: the multi-GPU domain/slab path is not built yet')
+
+    name = args.workload or 'ns_256M_1024'
+    n_p, N = WORKLOADS[name]
+    L = float(N)  # boxsize in grid units (synthetic)
+    dev = torch.device('cuda', local_rank)
+    mesh = PotentialMesh(N, L, nghosts=2)
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    pos = torch.rand((n_p, 3), dtype=torch.float64, device=dev, generator=gen)
+    pos.mul_(L).clamp_(max=float(torch.nextafter(torch.tensor(L, dtype=torch.float64),
+                                                 torch.tensor(0.0, dtype=torch.float64))))
+    mom = torch.zeros_like(pos)
+    pos2, mom2 = torch.empty_like(pos), torch.empty_like(mom)
+    # step scalars: fixed (enable_Hubble=False semantics)
+    mass = 1.0
+    G = 1.0
+    dt = 1e-4
+    contribution = (dt/dt)*mass*(float(N)**(-3)*(N/L)**3)
+    C = -L**2*G/3.141592653589793
+    kick_factor = mass*(-dt)
+    dt_over_mass = dt/mass
+
+    PHASES = ['drift', 'sort', 'zero', 'deposit', 'fft_forward', 'kspace', 'fft_backward',
+              'gather_kick']
+    if args.no_sort:
+        PHASES.remove('sort')
+    events = []
+
+    def step(record):
+        nonlocal pos, mom, pos2, mom2
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(PHASES) + 1)] \
+            if record else None
+        i = 0
+
+        def mark():
+            nonlocal i
+            if ev is not None:
+                ev[i].record()
+                i += 1
+        mark()
+        mesh.drift(pos, mom, dt_over_mass)
+        mark()
+        if not args.no_sort:
+            mesh.sort_particles(pos, mom, None, pos2, mom2, None)
+            pos, pos2 = pos2, pos
+            mom, mom2 = mom2, mom
+            mark()
+        mesh.zero()
+        mark()
+        mesh.deposit(pos, contribution)
+        mark()
+        mesh.poisson_forward(4, C, False, 0.0, apply_kernel=False)
+        mark()
+        mesh.poisson_kernel(4, C, False, 0.0)
+        mark()
+        mesh.poisson_backward()
+        mark()
+        mesh.gather_kick(pos, mom, 2, kick_factor)
+        mark()
+        if record:
+            events.append(ev)
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        return
+    n_g = N**3
+    alg = algorithmic_bytes(n_p, n_g)
+    phase_ms = {ph: 0.0 for ph in PHASES}
+    for ev in events:
+        for k, ph in enumerate(PHASES):
+            phase_ms[ph] += ev[k].elapsed_time(ev[k + 1])
+    for ph in PHASES:
+        phase_ms[ph] /= len(events)
+    phases = {}
+    for ph in PHASES:
+        gbs = alg[ph]/(phase_ms[ph]*1e-3)/1e9 if phase_ms[ph] > 0 else 0.0
+        phases[ph] = {'ms': round(phase_ms[ph], 4), 'alg_GB': round(alg[ph]/1e9, 3),
+                      'GBps': round(gbs, 1), 'frac_hbm': round(gbs/HBM_PEAK_GBS, 4)}
+    own = ['deposit', 'gather_kick', 'kspace', 'drift'] + ([] if args.no_sort else ['sort'])
+    dom = max(own, key=lambda ph: phase_ms[ph])
+    ach = alg[dom]/(phase_ms[dom]*1e-3)/1e9
+    groups = {
+        'deposit+interp': (alg['deposit'] + alg['gather_kick'],
+                           phase_ms['deposit'] + phase_ms['gather_kick']),
+        'poisson_solve': (alg['fft_forward'] + alg['kspace'] + alg['fft_backward'],
+                          phase_ms['fft_forward'] + phase_ms['kspace'] + phase_ms['fft_backward']),
+    }
+    ms_per_step = elapsed/args.steps*1e3
+    result = {
+        'metric': 'PM particle-updates/sec', 'value': n_p*world*args.steps/elapsed,
+        'unit': 'particle-updates/s', 'steps_per_sec': args.steps/elapsed,
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': f'{name}: {n_p} particles (uniform random, seed 1) / {N}^3 PM mesh, '
+                               'CIC, deconvolution order 4, FD order 2, 1 PM step = drift + '
+                               'tile sort + long-range kick', 'particles': n_p, 'gridsize': N,
+                   'parallelism': f'domains{world}'},
+        'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1),
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach/HBM_PEAK_GBS, 4),
+                     'traffic': None},
+        'roofline_groups': {k: {'alg_GB': round(b/1e9, 2), 'ms': round(ms, 3),
+                                'GBps': round(b/(ms*1e-3)/1e9, 1),
+                                'frac': round(b/(ms*1e-3)/1e9/HBM_PEAK_GBS, 4)}
+                            for k, (b, ms) in groups.items()},
+        'phases': phases,
+    }
+    if not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(result))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,56 @@
+"""Build libconcept_gpu.so (gfx950) in-tree with hipcc.
+
+`python -m concept_amd.build` or `__graft_entry__.build()`.  The .so is
+git-ignored but travels to the GPU box with the repo snapshot."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libconcept_gpu.so')
+SOURCES = ['cg_context.hip', 'cg_mesh_kernels.hip', 'cg_particles.hip']
+HEADERS = [os.path.join(CSRC, 'cg_internal.h'), os.path.join(REPO, 'include', 'concept_gpu.h')]
+
+FLAGS = [
+    '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
+    # the reference's operation order is the parity contract: no FMA contraction
+    '-ffp-contract=off',
+    # hardware FP64 atomic add (global_atomic_add_f64 / ds_add_f64) instead of CAS loops
+    '-munsafe-fp-atomics',
+    '-Wall', '-Wno-unused-result',
+    '-I' + os.path.join(REPO, 'include'), '-I' + CSRC, '-I/opt/rocm/include',
+]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace('.hip', '.o'))
+        if force or _stale(o, [s] + HEADERS + [os.path.abspath(__file__)]):
+            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + [
+            '-L/opt/rocm/lib', '-lrocfft', '-Wl,-rpath,/opt/rocm/lib']
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

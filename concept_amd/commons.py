@@ -1,0 +1,206 @@
+"""concept_amd.commons — the few parameters, units and constants the PM/P3M
+gravity path reads, under the reference's names and defaults.
+
+Mirrors (does not import) the relevant slice of the reference's commons.py:
+  unit system            commons.py:1828-1886, 2040-2110 (default Mpc, Gyr, 1e10 m_sun)
+  G_Newton               commons.py:2130-2134
+  boxsize                commons.py:2956
+  potential_options      commons.py:2958-3237  (gridsize / interpolation / deconvolve /
+                                                interlace / differentiation)
+  shortrange_params      commons.py:3254-3275  (scale, range, tilesize, subtiling, tablesize)
+  select_forces          commons.py:3664-3700
+  select_softening_length commons.py:3867-3872, softening_kernel :3862
+  N_rungs                commons.py:3891
+  cell_centered          commons.py:3926
+  nghosts                commons.py:4411-4432
+A parameter file is Python source executed in a namespace that holds the
+units (commons.py:2001-2140); `load_params` does the same for the names above
+and ignores everything else (I/O, cosmology tables, ... are out of scope).
+"""
+import math
+import types
+
+import numpy as np
+
+machine_ϵ = float(np.finfo(np.float64).eps)  # commons.py:1814
+π = float(np.pi)
+τ = 2*π
+ထ = float('inf')
+
+interpolation_orders = {'NGP': 1, 'CIC': 2, 'TSC': 3, 'PCS': 4}
+
+
+def _unit_relations():
+    r = {'yr': 1.0, 'pc': 1.0, 'm_sun': 1.0}
+    r['kyr'] = 1e+3*r['yr']
+    r['Myr'] = 1e+6*r['yr']
+    r['Gyr'] = 1e+9*r['yr']
+    r['day'] = 1/365.25*r['yr']
+    r['hr'] = 1/24*r['day']
+    r['minutes'] = 1/60*r['hr']
+    r['s'] = 1/60*r['minutes']
+    r['kpc'] = 1e+3*r['pc']
+    r['Mpc'] = 1e+6*r['pc']
+    r['Gpc'] = 1e+9*r['pc']
+    r['AU'] = τ/(60*60*360)*r['pc']
+    r['m'] = 1/149597870700*r['AU']
+    r['km'] = 1e+3*r['m']
+    r['kg'] = 1/1.98841e+30*r['m_sun']
+    r['G_Newton'] = 6.67430e-11*r['m']**3/(r['kg']*r['s']**2)
+    r['light_speed'] = 299792458*r['m']/r['s']
+    return r
+
+
+class Params(types.SimpleNamespace):
+    """All parameters of the path, reference names.  Build with load_params()."""
+
+
+def _make_units(unit_length='Mpc', unit_time='Gyr', unit_mass='10**(10)*m_sun'):
+    rel = _unit_relations()
+    ns = dict(rel)
+    yr = 1/eval(unit_time, {}, ns)
+    pc = 1/eval(unit_length, {}, ns)
+    m_sun = 1/eval(unit_mass, {}, ns)
+    u = {'yr': yr, 'pc': pc, 'm_sun': m_sun}
+    for k in ('kyr', 'Myr', 'Gyr', 'day', 'hr', 'minutes', 's'):
+        u[k] = rel[k]*yr
+    for k in ('kpc', 'Mpc', 'Gpc', 'AU', 'm', 'km'):
+        u[k] = rel[k]*pc
+    u['kg'] = rel['kg']*m_sun
+    G = (rel['G_Newton']/(rel['m']**3/(rel['kg']*rel['s']**2))
+         *u['m']**3/(u['kg']*u['s']**2))
+    c = rel['light_speed']/(rel['m']/rel['s'])*u['m']/u['s']
+    return u, G, c
+
+
+def _method_dict(user, default_pm, default_p3m):
+    """{'gravity': {'pm': x, 'p3m': y}} with reference defaults filled in."""
+    out = {'gravity': {'pm': default_pm, 'p3m': default_p3m}}
+    if isinstance(user, dict):
+        for force, d in user.items():
+            if isinstance(d, dict):
+                out.setdefault(force, {}).update(d)
+            else:
+                out.setdefault(force, {})
+                for m in ('pm', 'p3m'):
+                    out[force][m] = d
+    elif user is not None:
+        for m in ('pm', 'p3m'):
+            out['gravity'][m] = user
+    return out
+
+
+def load_params(source=None, **overrides):
+    """`source`: path to a parameter file, parameter text, a dict, or None.
+    Returns a Params object and makes it the active one (`commons.params`)."""
+    global params
+    units, G_Newton, light_speed = _make_units()
+    user = {}
+    if isinstance(source, dict):
+        user.update(source)
+    elif isinstance(source, str):
+        text = source
+        if '\n' not in source and '=' not in source:
+            with open(source, encoding='utf-8') as f:
+                text = f.read()
+        ns = dict(units)
+        ns.update(π=π, pi=π, τ=τ, ထ=ထ, inf=ထ, sqrt=math.sqrt, cbrt=np.cbrt, h=1.0,
+                  param=types.SimpleNamespace(dir='.', path='.'))
+        lines = text.split('\n')
+        # the reference executes the file repeatedly until all names resolve
+        # (commons.py:2001-2040); two whole-file passes with per-statement
+        # tolerance cover the names this path reads.
+        for _ in range(2):
+            try:
+                exec(text, ns)
+                break
+            except Exception:
+                for ln in lines:
+                    try:
+                        exec(ln, ns)
+                    except Exception:
+                        pass
+        user.update({k: v for k, v in ns.items() if not k.startswith('__')})
+    user.update(overrides)
+    p = Params()
+    p.units = types.SimpleNamespace(**units)
+    p.G_Newton = float(user.get('G_Newton', G_Newton))
+    p.light_speed = light_speed
+    p.boxsize = float(user.get('boxsize', 512*units['Mpc']))
+    po = user.get('potential_options', {})
+    if not isinstance(po, dict):
+        po = {'gridsize': po}
+    p.potential_options = {
+        'gridsize': {'global': _method_dict(po.get('gridsize', {}).get('global')
+                                            if isinstance(po.get('gridsize'), dict)
+                                            and 'global' in po.get('gridsize', {})
+                                            else po.get('gridsize'), -1, -1)},
+        'interpolation': _method_dict(po.get('interpolation'), 'CIC', 'CIC'),
+        'deconvolve': _method_dict(po.get('deconvolve'), (True, True), (True, True)),
+        'interlace': _method_dict(po.get('interlace'), ('sc', 'sc'), ('sc', 'sc')),
+        'differentiation': {'default': _method_dict(None, 2, 4)},
+    }
+    for force, d in p.potential_options['interpolation'].items():
+        for m, v in d.items():
+            if isinstance(v, str):
+                d[m] = interpolation_orders[v.upper()]
+    diff = po.get('differentiation')
+    if isinstance(diff, dict):
+        for name, d in diff.items():
+            p.potential_options['differentiation'][name] = _method_dict(d, 2, 4)
+    # short-range parameters (strings are evaluated per use with the grid size known)
+    sr = {'scale': '1.25*boxsize/gridsize', 'range': '4.5*scale', 'tilesize': 'range',
+          'subtiling': 'automatic', 'tablesize': 2**12}
+    sr.update((user.get('shortrange_params') or {}).get('gravity', {}))
+    p.shortrange_params = {'gravity': sr}
+    p.select_forces = user.get('select_forces', {'particles': {'gravity': 'p3m'}})
+    ssl = user.get('select_softening_length') or {}
+    if not isinstance(ssl, dict):
+        ssl = {'all': ssl}
+    ssl = dict(ssl)
+    ssl.setdefault('default', '0.025*boxsize/cbrt(N)')
+    p.select_softening_length = ssl
+    p.softening_kernel = str(user.get('softening_kernel', 'spline')).lower()
+    p.N_rungs = int(user.get('N_rungs', 8))
+    p.cell_centered = bool(user.get('cell_centered', True))
+    # nghosts (commons.py:4411-4432): default 2 comes from the PCS default of the
+    # power-spectrum options; force interpolation and differentiation orders raise it
+    nghosts = 2
+    for force, d in p.potential_options['interpolation'].items():
+        for m, order in d.items():
+            nghosts = max(nghosts, order//2)
+    for name, d0 in p.potential_options['differentiation'].items():
+        for force, d1 in d0.items():
+            nghosts = max(nghosts, (max(d1.values()) + 1)//2)
+    p.nghosts = int(user.get('nghosts', nghosts))
+    p.user = user
+    params = p
+    return p
+
+
+def resolve_shortrange(p, gridsize):
+    """Numerical shortrange_params['gravity'] for a given P3M grid size
+    (commons.py:3254-3275 evaluates the strings with boxsize/gridsize known)."""
+    sr = p.shortrange_params['gravity']
+    ns = {'boxsize': p.boxsize, 'gridsize': gridsize, **vars(p.units)}
+    out = {}
+    for key in ('scale', 'range', 'tilesize'):
+        v = sr[key]
+        out[key] = float(eval(v, {}, ns)) if isinstance(v, str) else float(v)
+        ns[key] = out[key]
+    out['subtiling'] = sr['subtiling']
+    out['tablesize'] = int(sr['tablesize'])
+    return out
+
+
+def softening_length(p, species, N):
+    """select_softening_length (commons.py:3867-3872)."""
+    expr = p.select_softening_length.get(species, p.select_softening_length.get(
+        'all', p.select_softening_length['default']))
+    if isinstance(expr, str):
+        return float(eval(expr, {}, {'boxsize': p.boxsize, 'N': N, 'cbrt': np.cbrt,
+                                     **vars(p.units)}))
+    return float(expr)
+
+
+params = None

@@ -1,0 +1,296 @@
+// cg_context.hip — context, rocFFT plans, Poisson solve driver, debug fetch.
+// MI355X / gfx950 only.  See include/concept_gpu.h for the reference lines
+// each entry point replaces.
+#include <cmath>
+#include <cstring>
+
+#include "cg_internal.h"
+
+static thread_local std::string g_err;
+
+void cg_set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+extern "C" const char *cg_last_error(void) { return g_err.c_str(); }
+extern "C" int cg_abi_version(void) { return CG_ABI_VERSION; }
+
+static const double kMachineEps = 2.220446049250313e-16;  // np.finfo(float64).eps, commons.py:1814
+static const double kPi = 3.141592653589793;              // float(np.pi), commons.py:1816
+
+// mesh.py:1577-1589 (deposit, -shift) and mesh.py:408-420 (gather, +shift); no
+// interlacing lattice is built yet, so shift = 0 and only cellsize differs.
+static CicGeom make_geom(double cellsize, int nghosts, int cell_centered, const double bgn[3]) {
+    CicGeom g;
+    for (int d = 0; d < 3; d++)
+        g.off[d] = bgn[d] - (1 + kMachineEps) * (nghosts - 0.5 * cell_centered - 0) * cellsize;
+    g.scale = (1 / cellsize) * (1 - kMachineEps);
+    return g;
+}
+
+static int make_plans(cg_ctx *c) {
+    // In-place 3-D R2C / C2R on the padded layout FFTW uses (fft.c:34-73):
+    // real double[N][N][N+2] <-> hermitian complex[N][N][N/2+1], unnormalised
+    // both ways (mesh.py:4015-4022).  rocFFT lengths are fastest-first.
+    const size_t N = (size_t)c->N;
+    size_t lengths[3] = {N, N, N};
+    size_t rstr[3] = {1, N + 2, (N + 2) * N};
+    size_t cstr[3] = {1, N / 2 + 1, (N / 2 + 1) * N};
+    size_t off[1] = {0};
+    rocfft_plan_description d = nullptr;
+    CG_FFT(rocfft_plan_description_create(&d));
+    CG_FFT(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real,
+                                                   rocfft_array_type_hermitian_interleaved, off,
+                                                   off, 3, rstr, (N + 2) * N * N, 3, cstr,
+                                                   (N / 2 + 1) * N * N));
+    CG_FFT(rocfft_plan_create(&c->plan_fwd, rocfft_placement_inplace,
+                              rocfft_transform_type_real_forward, rocfft_precision_double, 3,
+                              lengths, 1, d));
+    CG_FFT(rocfft_plan_description_destroy(d));
+    CG_FFT(rocfft_plan_description_create(&d));
+    CG_FFT(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved,
+                                                   rocfft_array_type_real, off, off, 3, cstr,
+                                                   (N / 2 + 1) * N * N, 3, rstr,
+                                                   (N + 2) * N * N));
+    CG_FFT(rocfft_plan_create(&c->plan_bwd, rocfft_placement_inplace,
+                              rocfft_transform_type_real_inverse, rocfft_precision_double, 3,
+                              lengths, 1, d));
+    CG_FFT(rocfft_plan_description_destroy(d));
+    size_t wf = 0, wb = 0;
+    CG_FFT(rocfft_plan_get_work_buffer_size(c->plan_fwd, &wf));
+    CG_FFT(rocfft_plan_get_work_buffer_size(c->plan_bwd, &wb));
+    c->fft_work_bytes = wf > wb ? wf : wb;
+    if (c->fft_work_bytes) {
+        CG_HIP(hipMalloc(&c->fft_work, c->fft_work_bytes));
+        c->device_bytes += (i64)c->fft_work_bytes;
+    }
+    CG_FFT(rocfft_execution_info_create(&c->info_fwd));
+    CG_FFT(rocfft_execution_info_create(&c->info_bwd));
+    if (c->fft_work_bytes) {
+        CG_FFT(rocfft_execution_info_set_work_buffer(c->info_fwd, c->fft_work, c->fft_work_bytes));
+        CG_FFT(rocfft_execution_info_set_work_buffer(c->info_bwd, c->fft_work, c->fft_work_bytes));
+    }
+    return 0;
+}
+
+static bool g_rocfft_ready = false;
+
+extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
+    CG_CHECK(p && out, "cg_create: null argument");
+    *out = nullptr;
+    CG_CHECK(p->gridsize >= 4 && p->gridsize % 2 == 0,
+             "cg_create: gridsize %lld must be even and >= 4 (mesh.py:1898-1905)",
+             (long long)p->gridsize);
+    CG_CHECK(p->interp_order == 2, "cg_create: interpolation order %d not built (CIC = 2 only)",
+             p->interp_order);
+    CG_CHECK(p->nghosts >= 1 && p->nghosts <= 4, "cg_create: nghosts %d out of range", p->nghosts);
+    CG_CHECK(p->boxsize > 0, "cg_create: boxsize must be positive");
+    CG_CHECK(p->nprocs == 1 && p->rank == 0 && p->subdiv[0] == 1 && p->subdiv[1] == 1 &&
+                 p->subdiv[2] == 1,
+             "cg_create: this context is single-domain; multi-GPU runs shard through "
+             "concept_amd.distributed (nprocs=%d)", p->nprocs);
+    CG_HIP(hipSetDevice(p->device));
+    if (!g_rocfft_ready) {
+        CG_FFT(rocfft_setup());
+        g_rocfft_ready = true;
+    }
+    cg_ctx *c = new cg_ctx();
+    c->p = *p;
+    c->N = p->gridsize;
+    c->pad = c->N + 2;
+    c->mesh_doubles = c->N * c->N * c->pad;
+    auto fail = [&]() {
+        cg_destroy(c);
+        return 1;
+    };
+    if (hipMalloc(&c->mesh, sizeof(double) * c->mesh_doubles) != hipSuccess) {
+        cg_set_error("cg_create: hipMalloc of the %lld^3 mesh (%.2f GB) failed", (long long)c->N,
+                     c->mesh_doubles * 8e-9);
+        return fail();
+    }
+    c->device_bytes += 8 * c->mesh_doubles;
+    // geometry, reference expressions
+    const double bgn[3] = {0, 0, 0};
+    double cellsize_dep = p->boxsize / (double)p->gridsize;             // mesh.py:1577
+    double domain_size_x = p->boxsize / (double)p->subdiv[0];           // communication.py:1777
+    double cellsize_gat = domain_size_x / (double)(p->gridsize / p->subdiv[0]);  // mesh.py:408
+    c->geom_deposit = make_geom(cellsize_dep, p->nghosts, p->cell_centered, bgn);
+    c->geom_gather = make_geom(cellsize_gat, p->nghosts, p->cell_centered, bgn);
+    // k-space tables by array index: k = idx - (idx >= N/2 ? N : 0)
+    // n(k) = k*R[pi/gridsize] + machine_eps, s(k) = sin(n(k))   (mesh.py:2775-2776)
+    {
+        std::vector<double> tn(c->N), ts(c->N);
+        double pi_over_n = kPi / (double)c->N;
+        for (i64 i = 0; i < c->N; i++) {
+            i64 k = i - (i >= c->N / 2 ? c->N : 0);
+            tn[i] = (double)k * pi_over_n + kMachineEps;
+            ts[i] = sin(tn[i]);
+        }
+        if (hipMalloc(&c->ktab_n, 8 * c->N) != hipSuccess ||
+            hipMalloc(&c->ktab_s, 8 * c->N) != hipSuccess ||
+            hipMemcpy(c->ktab_n, tn.data(), 8 * c->N, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->ktab_s, ts.data(), 8 * c->N, hipMemcpyHostToDevice) != hipSuccess) {
+            cg_set_error("cg_create: k-space table upload failed");
+            return fail();
+        }
+    }
+    // tiles: 8x8x8 cells when the grid allows, for the particle order and the
+    // LDS-tiled kernels
+    {
+        int t = 8;
+        while (t > 1 && c->N % t) t /= 2;
+        c->tiles = {t, t, t, (int)(c->N / t), (int)(c->N / t), (int)(c->N / t)};
+        c->ntiles = (i64)c->tiles.ntx * c->tiles.nty * c->tiles.ntz;
+        if (hipMalloc(&c->tile_count, 4 * (c->ntiles + 1)) != hipSuccess ||
+            hipMalloc(&c->tile_offset, 4 * (c->ntiles + 1)) != hipSuccess ||
+            hipMalloc(&c->tile_cursor, 4 * (c->ntiles + 1)) != hipSuccess) {
+            cg_set_error("cg_create: tile table allocation failed");
+            return fail();
+        }
+        c->device_bytes += 12 * (c->ntiles + 1);
+    }
+    if (make_plans(c)) return fail();
+    *out = c;
+    return 0;
+}
+
+extern "C" int cg_destroy(cg_ctx *c) {
+    if (!c) return 0;
+    if (c->plan_fwd) rocfft_plan_destroy(c->plan_fwd);
+    if (c->plan_bwd) rocfft_plan_destroy(c->plan_bwd);
+    if (c->info_fwd) rocfft_execution_info_destroy(c->info_fwd);
+    if (c->info_bwd) rocfft_execution_info_destroy(c->info_bwd);
+    (void)hipFree(c->fft_work);
+    (void)hipFree(c->mesh);
+    (void)hipFree(c->fetch_tmp);
+    (void)hipFree(c->ktab_n);
+    (void)hipFree(c->ktab_s);
+    (void)hipFree(c->tile_count);
+    (void)hipFree(c->tile_offset);
+    (void)hipFree(c->tile_cursor);
+    (void)hipFree(c->scan_tmp);
+    delete c;
+    return 0;
+}
+
+extern "C" int cg_set_stream(cg_ctx *c, void *s) {
+    CG_CHECK(c, "cg_set_stream: null context");
+    c->stream = (hipStream_t)s;
+    return 0;
+}
+
+extern "C" int cg_synchronize(cg_ctx *c) {
+    CG_CHECK(c, "cg_synchronize: null context");
+    CG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int64_t cg_device_bytes(const cg_ctx *c) { return c ? c->device_bytes : 0; }
+
+extern "C" int cg_mesh_zero(cg_ctx *c) {
+    CG_CHECK(c, "cg_mesh_zero: null context");
+    CG_HIP(hipMemsetAsync(c->mesh, 0, sizeof(double) * c->mesh_doubles, c->stream));
+    return 0;
+}
+
+extern "C" int cg_deposit_cic(cg_ctx *c, const double *pos, int64_t n, double contribution) {
+    CG_CHECK(c && (pos || n == 0), "cg_deposit_cic: null argument");
+    CG_CHECK(n >= 0, "cg_deposit_cic: negative particle count");
+    if (n == 0) return 0;
+    return cgk_deposit_cic(c, pos, n, contribution);
+}
+
+extern "C" int cg_poisson_forward(cg_ctx *c, int deconv_order, double C, int long_range, double E,
+                                  int apply_kernel) {
+    CG_CHECK(c, "cg_poisson_forward: null context");
+    CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_poisson_forward: deconv_order %d",
+             deconv_order);
+    CG_FFT(rocfft_execution_info_set_stream(c->info_fwd, c->stream));
+    void *buf[1] = {c->mesh};
+    CG_FFT(rocfft_execute(c->plan_fwd, buf, nullptr, c->info_fwd));
+    if (apply_kernel) return cgk_kspace(c, deconv_order, C, long_range, E);
+    return 0;
+}
+
+extern "C" int cg_poisson_kernel(cg_ctx *c, int deconv_order, double C, int long_range, double E) {
+    CG_CHECK(c, "cg_poisson_kernel: null context");
+    CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_poisson_kernel: deconv_order %d",
+             deconv_order);
+    return cgk_kspace(c, deconv_order, C, long_range, E);
+}
+
+extern "C" int cg_poisson_backward(cg_ctx *c) {
+    CG_CHECK(c, "cg_poisson_backward: null context");
+    CG_FFT(rocfft_execution_info_set_stream(c->info_bwd, c->stream));
+    void *buf[1] = {c->mesh};
+    CG_FFT(rocfft_execute(c->plan_bwd, buf, nullptr, c->info_bwd));
+    return 0;
+}
+
+extern "C" int cg_poisson_solve(cg_ctx *c, int deconv_order, double C, int long_range, double E) {
+    if (cg_poisson_forward(c, deconv_order, C, long_range, E, 1)) return 1;
+    return cg_poisson_backward(c);
+}
+
+extern "C" int cg_gather_kick(cg_ctx *c, const double *pos, double *mom, int64_t n, int diff_order,
+                              double factor) {
+    CG_CHECK(c && ((pos && mom) || n == 0), "cg_gather_kick: null argument");
+    CG_CHECK(diff_order == 2 || diff_order == 4,
+             "cg_gather_kick: differentiation order %d not built (2 and 4 are)", diff_order);
+    CG_CHECK((diff_order + 1) / 2 <= c->p.nghosts,
+             "cg_gather_kick: differentiation order %d needs nghosts >= %d (commons.py:4411-4432)",
+             diff_order, (diff_order + 1) / 2);
+    if (n == 0) return 0;
+    return cgk_gather_kick(c, pos, mom, n, diff_order, factor);
+}
+
+extern "C" int cg_drift(cg_ctx *c, double *pos, const double *mom, int64_t n,
+                        double dt_over_mass) {
+    CG_CHECK(c && ((pos && mom) || n == 0), "cg_drift: null argument");
+    if (n == 0) return 0;
+    c->tiles_valid = false;
+    return cgk_drift(c, pos, mom, n, dt_over_mass);
+}
+
+extern "C" int cg_sort_particles(cg_ctx *c, const double *pos_in, const double *mom_in,
+                                 const int64_t *ids_in, double *pos_out, double *mom_out,
+                                 int64_t *ids_out, int64_t n) {
+    CG_CHECK(c && pos_in && mom_in && pos_out && mom_out, "cg_sort_particles: null argument");
+    CG_CHECK(pos_in != pos_out && mom_in != mom_out, "cg_sort_particles: in/out must not alias");
+    CG_CHECK((ids_in == nullptr) == (ids_out == nullptr),
+             "cg_sort_particles: ids_in and ids_out must both be given or both be null");
+    CG_CHECK(n >= 0 && n < (1ll << 32), "cg_sort_particles: n out of range");
+    if (n == 0) return 0;
+    return cgk_sort(c, pos_in, mom_in, ids_in, pos_out, mom_out, ids_out, n);
+}
+
+extern "C" int cg_cic_indices(cg_ctx *c, const double *pos, int64_t n, int for_gather,
+                              int64_t *idx_out) {
+    CG_CHECK(c && pos && idx_out, "cg_cic_indices: null argument");
+    return cgk_cic_indices(c, pos, n, for_gather, idx_out);
+}
+
+extern "C" int cg_fetch(cg_ctx *c, int which, double *out, int64_t n_doubles) {
+    CG_CHECK(c && out, "cg_fetch: null argument");
+    CG_CHECK(n_doubles == c->mesh_doubles, "cg_fetch: expected %lld doubles, got %lld",
+             (long long)c->mesh_doubles, (long long)n_doubles);
+    if (which == CG_FETCH_MESH_REAL) {
+        CG_HIP(hipStreamSynchronize(c->stream));
+        CG_HIP(hipMemcpy(out, c->mesh, 8 * c->mesh_doubles, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    if (which == CG_FETCH_MESH_FOURIER) {
+        if (!c->fetch_tmp) CG_HIP(hipMalloc(&c->fetch_tmp, 8 * c->mesh_doubles));
+        if (cgk_transpose_fourier(c, c->mesh, c->fetch_tmp)) return 1;
+        CG_HIP(hipStreamSynchronize(c->stream));
+        CG_HIP(hipMemcpy(out, c->fetch_tmp, 8 * c->mesh_doubles, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    cg_set_error("cg_fetch: unknown selector %d", which);
+    return 1;
+}

@@ -1,0 +1,110 @@
+// cg_internal.h — shared declarations of libconcept_gpu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "concept_gpu.h"
+
+typedef int64_t i64;
+
+void cg_set_error(const char *fmt, ...);
+
+#define CG_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            cg_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,     \
+                         __LINE__);                                                           \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+#define CG_FFT(call)                                                                          \
+    do {                                                                                      \
+        rocfft_status s_ = (call);                                                            \
+        if (s_ != rocfft_status_success) {                                                    \
+            cg_set_error("%s failed: rocfft status %d (%s:%d)", #call, (int)s_, __FILE__,     \
+                         __LINE__);                                                           \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+#define CG_CHECK(cond, ...)                                                                   \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            cg_set_error(__VA_ARGS__);                                                        \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+// Geometry of the CIC index map for one domain, computed on the host with
+// the reference's own expressions (mesh.py:1577-1606 deposit, :408-432 gather).
+struct CicGeom {
+    double off[3];  // offset_x/y/z
+    double scale;   // (1/cellsize)*(1 - machine_eps)
+};
+
+// The mesh a particle kernel addresses: periodic (wrap) in every dimension on
+// a single domain.  Cell (i,j,k) of the PERIODIC global mesh lives at
+// base[(i*nj + j)*stride_j + k]; i,j,k are obtained from the reference's
+// ghosted index by subtracting nghosts and wrapping.
+struct MeshView {
+    double *base;
+    i64 n;         // global grid size N
+    i64 stride_i;  // doubles between consecutive i
+    i64 stride_j;  // doubles between consecutive j
+    int nghosts;
+};
+
+// Tile decomposition used for the particle memory order and the LDS-tiled
+// deposit / gather kernels.
+struct TileGeom {
+    int tx, ty, tz;     // tile extent in cells
+    int ntx, nty, ntz;  // tiles per dimension
+};
+
+struct cg_ctx {
+    cg_params p;
+    hipStream_t stream = nullptr;
+    i64 N = 0, pad = 0;          // grid size and padded innermost length N+2
+    double *mesh = nullptr;      // double[N][N][N+2]
+    i64 mesh_doubles = 0;
+    double *fetch_tmp = nullptr; // lazily allocated, for CG_FETCH_MESH_FOURIER
+    // k-space tables: numerator n(k) and denominator sin(n(k)) by array index
+    double *ktab_n = nullptr, *ktab_s = nullptr;
+    // rocFFT
+    rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr;
+    rocfft_execution_info info_fwd = nullptr, info_bwd = nullptr;
+    void *fft_work = nullptr;
+    size_t fft_work_bytes = 0;
+    // particle sort scratch (owned, grown on demand)
+    TileGeom tiles{};
+    unsigned int *tile_count = nullptr;   // [ntiles + 1]
+    unsigned int *tile_offset = nullptr;  // [ntiles + 1] exclusive scan
+    unsigned int *tile_cursor = nullptr;  // [ntiles]
+    void *scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+    i64 ntiles = 0;
+    bool tiles_valid = false;  // tile_offset describes the arrays last sorted
+    i64 sorted_n = -1;
+    const double *sorted_pos = nullptr;
+    CicGeom geom_deposit{}, geom_gather{};
+    i64 device_bytes = 0;
+};
+
+// kernels (cg_mesh_kernels.hip, cg_particles.hip)
+int cgk_deposit_cic(cg_ctx *c, const double *pos, i64 n, double contribution);
+int cgk_kspace(cg_ctx *c, int deconv_order, double C, int long_range, double E);
+int cgk_gather_kick(cg_ctx *c, const double *pos, double *mom, i64 n, int diff_order,
+                    double factor);
+int cgk_drift(cg_ctx *c, double *pos, const double *mom, i64 n, double dt_over_mass);
+int cgk_cic_indices(cg_ctx *c, const double *pos, i64 n, int for_gather, i64 *idx);
+int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst);
+int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
+             double *pos_out, double *mom_out, i64 *ids_out, i64 n);

@@ -1,0 +1,259 @@
+// cg_mesh_kernels.hip — hand-written gfx950 kernels of the PM mesh path:
+// CIC deposit (A1/A2), k-space Poisson kernel (A5/A6), CIC gather + finite
+// difference + kick (A9/A10).  FP64 throughout; compiled with
+// -ffp-contract=off so every expression is evaluated in the reference's
+// operation order (no FMA contraction).
+#include "cg_internal.h"
+
+#define CG_LAUNCH_CHECK()                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) {                                                               \
+            cg_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                           \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// CIC index + weights, set_weights_CIC (mesh.py:5319-5324) under the
+// coordinate map of mesh.py:1604-1606 / :430-432.
+// ---------------------------------------------------------------------------
+struct Cic1 {
+    i64 index;  // reference (ghosted) index of the lower cell
+    double w0, w1;
+};
+__device__ __forceinline__ Cic1 cic1(double pos, double off, double scale) {
+    double x = (pos - off) * scale;
+    Cic1 r;
+    r.index = (i64)x;  // int(x); x > 0 always (mesh.py:1602-1603)
+    double dist = x - (double)r.index;
+    r.w0 = 1 - dist;
+    r.w1 = dist;
+    return r;
+}
+__device__ __forceinline__ i64 wrap(i64 a, i64 n) {
+    // a in [-n, 2n)
+    a = a < 0 ? a + n : a;
+    return a >= n ? a - n : a;
+}
+
+// ---------------------------------------------------------------------------
+// A1/A2 deposit, direct form: one lane per particle, 8 device-scope FP64
+// atomic adds onto the periodic padded mesh.  Index and weight arithmetic is
+// the reference's; only the summation order across particles differs.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_deposit_cic_direct(const double *__restrict__ pos, i64 n,
+                                                            double *__restrict__ mesh, i64 N,
+                                                            i64 pad, int g, CicGeom geo,
+                                                            double contribution) {
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        Cic1 cx = cic1(pos[3 * p + 0], geo.off[0], geo.scale);
+        Cic1 cy = cic1(pos[3 * p + 1], geo.off[1], geo.scale);
+        Cic1 cz = cic1(pos[3 * p + 2], geo.off[2], geo.scale);
+        i64 i0 = wrap(cx.index - g, N), i1 = wrap(cx.index - g + 1, N);
+        i64 j0 = wrap(cy.index - g, N), j1 = wrap(cy.index - g + 1, N);
+        i64 k0 = wrap(cz.index - g, N), k1 = wrap(cz.index - g + 1, N);
+        // mesh.py:5142-5155: ((w_x*contribution)*w_y)*w_z
+        double wi0 = cx.w0 * contribution, wi1 = cx.w1 * contribution;
+        double w00 = wi0 * cy.w0, w01 = wi0 * cy.w1, w10 = wi1 * cy.w0, w11 = wi1 * cy.w1;
+        double *r00 = mesh + (i0 * N + j0) * pad, *r01 = mesh + (i0 * N + j1) * pad;
+        double *r10 = mesh + (i1 * N + j0) * pad, *r11 = mesh + (i1 * N + j1) * pad;
+        unsafeAtomicAdd(r00 + k0, w00 * cz.w0);
+        unsafeAtomicAdd(r00 + k1, w00 * cz.w1);
+        unsafeAtomicAdd(r01 + k0, w01 * cz.w0);
+        unsafeAtomicAdd(r01 + k1, w01 * cz.w1);
+        unsafeAtomicAdd(r10 + k0, w10 * cz.w0);
+        unsafeAtomicAdd(r10 + k1, w10 * cz.w1);
+        unsafeAtomicAdd(r11 + k0, w11 * cz.w0);
+        unsafeAtomicAdd(r11 + k1, w11 * cz.w1);
+    }
+}
+
+int cgk_deposit_cic(cg_ctx *c, const double *pos, i64 n, double contribution) {
+    int block = 256;
+    i64 blocks = (n + block - 1) / block;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_deposit_cic_direct, dim3((unsigned)blocks), dim3(block), 0, c->stream, pos,
+                       n, c->mesh, c->N, c->pad, c->p.nghosts, c->geom_deposit, contribution);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// A5/A6 k-space kernel on rocFFT's natural output layout complex[i][j][kk]
+// (not transposed: on one GPU the transposition FFTW-MPI produces is only a
+// storage order; every mode (ki,kj,kk) gets the reference's factor).
+//   nullify_modes('nyquist')  mesh.py:3591-3622 -> planes ki,kj = -N/2, kk = N/2
+//   factor                    mesh.py:2775-2856, interactions.py:2096-2116
+//   nullify_modes('origin')   interactions.py:2118
+// One lane per complex mode (16 B load + 16 B store, coalesced along kk).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_kspace(double2 *__restrict__ slab, i64 N,
+                                                const double *__restrict__ tab_n,
+                                                const double *__restrict__ tab_s, int deconv_order,
+                                                double C, int long_range, double E) {
+    const i64 nyq = N / 2, nk = N / 2 + 1;
+    i64 row = blockIdx.x;  // i*N + j
+    i64 i = row / N, j = row - i * N;
+    i64 ki = i - (i >= nyq ? N : 0), kj = j - (j >= nyq ? N : 0);
+    bool row_nyq = (i == nyq) || (j == nyq);
+    double ni = tab_n[i], nj = tab_n[j], si = tab_s[i], sj = tab_s[j];
+    double dij_n = ni * nj;  // mesh.py:2797
+    double dij_d = si * sj;  // mesh.py:2798
+    i64 kij2 = kj * kj + ki * ki;  // interactions.py:2096
+    double2 *r = slab + row * nk;
+    for (i64 kk = threadIdx.x; kk < nk; kk += blockDim.x) {
+        double2 v;
+        if (row_nyq || kk == nyq || (kij2 == 0 && kk == 0)) {
+            v.x = 0;
+            v.y = 0;
+        } else {
+            v = r[kk];
+            double factor = 1;
+            if (deconv_order) {
+                double nkk = tab_n[kk], skk = tab_s[kk];
+                factor = (dij_n * nkk) / (dij_d * skk);  // mesh.py:2850-2853
+                double f = factor;
+                for (int o = 1; o < deconv_order; o++) factor *= f;  // factor **= deconv_order
+            }
+            i64 k2 = kij2 + kk * kk;
+            double pk = C / (double)k2;
+            if (long_range) pk = pk * exp((double)k2 * E);  // interactions.py:2110-2113
+            factor *= pk;
+            v.x *= factor;
+            v.y *= factor;
+        }
+        r[kk] = v;
+    }
+}
+
+int cgk_kspace(cg_ctx *c, int deconv_order, double C, int long_range, double E) {
+    i64 rows = c->N * c->N;
+    int block = c->N / 2 + 1 >= 256 ? 256 : (c->N / 2 + 1 > 64 ? 128 : 64);
+    hipLaunchKernelGGL(k_kspace, dim3((unsigned)rows), dim3(block), 0, c->stream,
+                       (double2 *)c->mesh, c->N, c->ktab_n, c->ktab_s, deconv_order, C, long_range,
+                       E);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// complex[i][j][kk] -> the reference's transposed double[j][i][N+2] (debug fetch)
+__global__ void k_transpose_fourier(const double2 *__restrict__ src, double2 *__restrict__ dst,
+                                    i64 N) {
+    i64 nk = N / 2 + 1;
+    i64 row = blockIdx.x;
+    i64 i = row / N, j = row - i * N;
+    for (i64 kk = threadIdx.x; kk < nk; kk += blockDim.x)
+        dst[(j * N + i) * nk + kk] = src[(i * N + j) * nk + kk];
+}
+int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst) {
+    hipLaunchKernelGGL(k_transpose_fourier, dim3((unsigned)(c->N * c->N)), dim3(64), 0, c->stream,
+                       (const double2 *)src, (double2 *)dst, c->N);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// A9/A10 gather + finite difference + kick, direct form: one lane per
+// particle reads the potential stencil straight from the periodic mesh.
+// For each dim the 8 force-cell values are formed exactly as diff_domaingrid
+// forms them (mesh.py:4966-4981) and accumulated in the order of
+// mesh.py:5142-5155 / :445, then value *= factor, mom += value (:456-459).
+// ---------------------------------------------------------------------------
+template <int ORDER>
+__global__ __launch_bounds__(256) void k_gather_kick_direct(const double *__restrict__ pos,
+                                                            double *__restrict__ mom, i64 n,
+                                                            const double *__restrict__ mesh, i64 N,
+                                                            i64 pad, int g, CicGeom geo, double c1,
+                                                            double c2, double factor) {
+    constexpr int H = ORDER / 2;      // stencil half width
+    constexpr int W = 2 + 2 * H;      // cells needed per dimension
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        Cic1 cx = cic1(pos[3 * p + 0], geo.off[0], geo.scale);
+        Cic1 cy = cic1(pos[3 * p + 1], geo.off[1], geo.scale);
+        Cic1 cz = cic1(pos[3 * p + 2], geo.off[2], geo.scale);
+        i64 ix[W], iy[W], iz[W];
+#pragma unroll
+        for (int s = 0; s < W; s++) {
+            ix[s] = wrap(cx.index - g - H + s, N) * N * pad;
+            iy[s] = wrap(cy.index - g - H + s, N) * pad;
+            iz[s] = wrap(cz.index - g - H + s, N);
+        }
+        double wx[2] = {cx.w0, cx.w1}, wy[2] = {cy.w0, cy.w1}, wz[2] = {cz.w0, cz.w1};
+        double val[3] = {0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                double wij = wx[i] * wy[j];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    double w = wij * wz[k];
+                    int a = H + i, b = H + j, cc = H + k;
+                    double fx, fy, fz;
+                    if (ORDER == 2) {
+                        fx = c1 * (mesh[ix[a + 1] + iy[b] + iz[cc]] - mesh[ix[a - 1] + iy[b] + iz[cc]]);
+                        fy = c1 * (mesh[ix[a] + iy[b + 1] + iz[cc]] - mesh[ix[a] + iy[b - 1] + iz[cc]]);
+                        fz = c1 * (mesh[ix[a] + iy[b] + iz[cc + 1]] - mesh[ix[a] + iy[b] + iz[cc - 1]]);
+                    } else {
+                        fx = c1 * (mesh[ix[a + 1] + iy[b] + iz[cc]] - mesh[ix[a - 1] + iy[b] + iz[cc]]) -
+                             c2 * (mesh[ix[a + 2] + iy[b] + iz[cc]] - mesh[ix[a - 2] + iy[b] + iz[cc]]);
+                        fy = c1 * (mesh[ix[a] + iy[b + 1] + iz[cc]] - mesh[ix[a] + iy[b - 1] + iz[cc]]) -
+                             c2 * (mesh[ix[a] + iy[b + 2] + iz[cc]] - mesh[ix[a] + iy[b - 2] + iz[cc]]);
+                        fz = c1 * (mesh[ix[a] + iy[b] + iz[cc + 1]] - mesh[ix[a] + iy[b] + iz[cc - 1]]) -
+                             c2 * (mesh[ix[a] + iy[b] + iz[cc + 2]] - mesh[ix[a] + iy[b] + iz[cc - 2]]);
+                    }
+                    val[0] += fx * w;
+                    val[1] += fy * w;
+                    val[2] += fz * w;
+                }
+            }
+        if (factor != 1) {
+            val[0] *= factor;
+            val[1] *= factor;
+            val[2] *= factor;
+        }
+        mom[3 * p + 0] += val[0];
+        mom[3 * p + 1] += val[1];
+        mom[3 * p + 2] += val[2];
+    }
+}
+
+int cgk_gather_kick(cg_ctx *c, const double *pos, double *mom, i64 n, int diff_order,
+                    double factor) {
+    int block = 256;
+    i64 blocks = (n + block - 1) / block;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    double dx = c->p.boxsize / (double)c->N;  // interactions.py:2133
+    if (diff_order == 2) {
+        double c1 = (1.0 / 2) / dx;  // mesh.py:4967
+        hipLaunchKernelGGL(k_gather_kick_direct<2>, dim3((unsigned)blocks), dim3(block), 0,
+                           c->stream, pos, mom, n, c->mesh, c->N, c->pad, c->p.nghosts,
+                           c->geom_gather, c1, 0.0, factor);
+    } else {
+        double c1 = (2.0 / 3) / dx, c2 = (1.0 / 12) / dx;  // mesh.py:4973-4977
+        hipLaunchKernelGGL(k_gather_kick_direct<4>, dim3((unsigned)blocks), dim3(block), 0,
+                           c->stream, pos, mom, n, c->mesh, c->N, c->pad, c->p.nghosts,
+                           c->geom_gather, c1, c2, factor);
+    }
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// CIC indices as set_weights_CIC returns them (parity tests: bit-exact bar)
+__global__ void k_cic_indices(const double *__restrict__ pos, i64 n, CicGeom geo,
+                              i64 *__restrict__ idx) {
+    i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    for (int d = 0; d < 3; d++) idx[3 * p + d] = cic1(pos[3 * p + d], geo.off[d], geo.scale).index;
+}
+int cgk_cic_indices(cg_ctx *c, const double *pos, i64 n, int for_gather, i64 *idx) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_cic_indices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       pos, n, for_gather ? c->geom_gather : c->geom_deposit, idx);
+    CG_LAUNCH_CHECK();
+    return 0;
+}

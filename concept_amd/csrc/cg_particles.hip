@@ -1,0 +1,147 @@
+// cg_particles.hip — particle-side kernels: drift (A11) and the tile sort
+// that keeps particle memory in mesh-tile order.
+#include <hipcub/hipcub.hpp>
+
+#include "cg_internal.h"
+
+#define CG_LAUNCH_CHECK()                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) {                                                               \
+            cg_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                           \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// A11 drift: pos[r] = mod(pos[r] + mom[r]*dt_over_mass, boxsize) for all 3N
+// reals (species.py:2194-2196).  mod is the reference's pure-Python one
+// (commons.py:5103-5110): numpy floored modulo, then a result that rounded
+// to exactly boxsize becomes 0.  Pure streaming kernel: 2 reads + 1 write of
+// 8 B per real, 16-B vector accesses.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double ref_mod(double x, double L) {
+    if (x > 0 && x < L) return x;  // fmod(x, L) == x, same sign as L
+    double m = fmod(x, L);          // exact
+    if (m != 0) {
+        if (m < 0) m += L;          // npy_divmod: sign fix-up (L > 0)
+    } else {
+        m = 0.0;                    // copysign(0, L)
+    }
+    if (m == L) m = 0;              // commons.py:5108-5109
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_drift(double *__restrict__ pos,
+                                               const double *__restrict__ mom, i64 n3,
+                                               double dt_over_mass, double L) {
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    i64 nv = n3 / 2;
+    double2 *p2 = (double2 *)pos;
+    const double2 *m2 = (const double2 *)mom;
+    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) {
+        double2 p = p2[v], m = m2[v];
+        p.x = ref_mod(p.x + m.x * dt_over_mass, L);
+        p.y = ref_mod(p.y + m.y * dt_over_mass, L);
+        p2[v] = p;
+    }
+    if ((n3 & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+        pos[n3 - 1] = ref_mod(pos[n3 - 1] + mom[n3 - 1] * dt_over_mass, L);
+}
+
+int cgk_drift(cg_ctx *c, double *pos, const double *mom, i64 n, double dt_over_mass) {
+    i64 n3 = 3 * n;
+    CG_CHECK(((uintptr_t)pos % 16 == 0) && ((uintptr_t)mom % 16 == 0),
+             "cg_drift: particle arrays must be 16-byte aligned");
+    i64 blocks = (n3 / 2 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_drift, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, mom, n3,
+                       dt_over_mass, c->p.boxsize);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Tile sort.  Key = the mesh tile that holds the particle's lower CIC cell
+// (the reference's own index map, so the tile of a particle is consistent
+// with the cells the deposit / gather kernels touch).  Counting sort:
+// histogram -> exclusive scan (hipCUB) -> scatter.  Order inside a tile is
+// arbitrary (like the reference's tile_sort, particle order is not part of
+// the contract; ids travel with the particles).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ i64 lower_cell(double pos, double off, double scale, int g, i64 N) {
+    double x = (pos - off) * scale;
+    i64 a = (i64)x - g;
+    a = a < 0 ? a + N : a;
+    return a >= N ? a - N : a;
+}
+__device__ __forceinline__ unsigned tile_of(const double *pos3, const CicGeom &geo, int g, i64 N,
+                                            const TileGeom &t) {
+    unsigned a = (unsigned)lower_cell(pos3[0], geo.off[0], geo.scale, g, N) / t.tx;
+    unsigned b = (unsigned)lower_cell(pos3[1], geo.off[1], geo.scale, g, N) / t.ty;
+    unsigned cc = (unsigned)lower_cell(pos3[2], geo.off[2], geo.scale, g, N) / t.tz;
+    return (a * t.nty + b) * t.ntz + cc;
+}
+
+__global__ __launch_bounds__(256) void k_tile_histogram(const double *__restrict__ pos, i64 n,
+                                                        CicGeom geo, int g, i64 N, TileGeom t,
+                                                        unsigned *__restrict__ count) {
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride)
+        atomicAdd(&count[tile_of(pos + 3 * p, geo, g, N, t)], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_tile_scatter(
+    const double *__restrict__ pos, const double *__restrict__ mom, const i64 *__restrict__ ids,
+    double *__restrict__ pos_out, double *__restrict__ mom_out, i64 *__restrict__ ids_out, i64 n,
+    CicGeom geo, int g, i64 N, TileGeom t, const unsigned *__restrict__ offset,
+    unsigned *__restrict__ cursor) {
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        double x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+        double q[3] = {x, y, z};
+        unsigned tile = tile_of(q, geo, g, N, t);
+        i64 s = (i64)offset[tile] + atomicAdd(&cursor[tile], 1u);
+        pos_out[3 * s] = x;
+        pos_out[3 * s + 1] = y;
+        pos_out[3 * s + 2] = z;
+        mom_out[3 * s] = mom[3 * p];
+        mom_out[3 * s + 1] = mom[3 * p + 1];
+        mom_out[3 * s + 2] = mom[3 * p + 2];
+        if (ids) ids_out[s] = ids[p];
+    }
+}
+
+int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
+             double *pos_out, double *mom_out, i64 *ids_out, i64 n) {
+    i64 nt = c->ntiles;
+    CG_HIP(hipMemsetAsync(c->tile_count, 0, 4 * (nt + 1), c->stream));
+    CG_HIP(hipMemsetAsync(c->tile_cursor, 0, 4 * (nt + 1), c->stream));
+    i64 blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_tile_histogram, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos_in,
+                       n, c->geom_deposit, c->p.nghosts, c->N, c->tiles, c->tile_count);
+    CG_LAUNCH_CHECK();
+    size_t need = 0;
+    CG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, c->tile_count, c->tile_offset,
+                                            (int)(nt + 1), c->stream));
+    if (need > c->scan_tmp_bytes) {
+        CG_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->scan_tmp);
+        c->scan_tmp = nullptr;
+        CG_HIP(hipMalloc(&c->scan_tmp, need));
+        c->scan_tmp_bytes = need;
+    }
+    CG_HIP(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp, need, c->tile_count, c->tile_offset,
+                                            (int)(nt + 1), c->stream));
+    hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos_in,
+                       mom_in, ids_in, pos_out, mom_out, ids_out, n, c->geom_deposit,
+                       c->p.nghosts, c->N, c->tiles, c->tile_offset, c->tile_cursor);
+    CG_LAUNCH_CHECK();
+    c->tiles_valid = true;
+    c->sorted_n = n;
+    c->sorted_pos = pos_out;
+    return 0;
+}

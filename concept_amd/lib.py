@@ -1,0 +1,80 @@
+"""ctypes binding of libconcept_gpu.so (include/concept_gpu.h).
+
+The HIP library IS the product path: there is no CPU or PyTorch fallback.  If
+the shared object is missing or a symbol is absent this module raises at
+import time."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libconcept_gpu.so')
+
+
+class ConceptGPUError(RuntimeError):
+    pass
+
+
+class cg_params(ctypes.Structure):
+    _fields_ = [
+        ('boxsize', ctypes.c_double),
+        ('gridsize', ctypes.c_int64),
+        ('nghosts', ctypes.c_int32),
+        ('cell_centered', ctypes.c_int32),
+        ('interp_order', ctypes.c_int32),
+        ('device', ctypes.c_int32),
+        ('nprocs', ctypes.c_int32),
+        ('rank', ctypes.c_int32),
+        ('subdiv', ctypes.c_int32*3),
+        ('reserved', ctypes.c_int32),
+    ]
+
+
+CG_FETCH_MESH_REAL = 0
+CG_FETCH_MESH_FOURIER = 1
+
+_vp, _i64, _dbl, _int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int
+
+# name -> (restype, argtypes); every symbol include/concept_gpu.h declares
+SYMBOLS = {
+    'cg_last_error': (ctypes.c_char_p, []),
+    'cg_abi_version': (_int, []),
+    'cg_create': (_int, [ctypes.POINTER(cg_params), ctypes.POINTER(_vp)]),
+    'cg_destroy': (_int, [_vp]),
+    'cg_set_stream': (_int, [_vp, _vp]),
+    'cg_synchronize': (_int, [_vp]),
+    'cg_device_bytes': (_i64, [_vp]),
+    'cg_mesh_zero': (_int, [_vp]),
+    'cg_deposit_cic': (_int, [_vp, _vp, _i64, _dbl]),
+    'cg_poisson_solve': (_int, [_vp, _int, _dbl, _int, _dbl]),
+    'cg_poisson_forward': (_int, [_vp, _int, _dbl, _int, _dbl, _int]),
+    'cg_poisson_backward': (_int, [_vp]),
+    'cg_poisson_kernel': (_int, [_vp, _int, _dbl, _int, _dbl]),
+    'cg_gather_kick': (_int, [_vp, _vp, _vp, _i64, _int, _dbl]),
+    'cg_drift': (_int, [_vp, _vp, _vp, _i64, _dbl]),
+    'cg_sort_particles': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    'cg_fetch': (_int, [_vp, _int, _vp, _i64]),
+    'cg_cic_indices': (_int, [_vp, _vp, _i64, _int, _vp]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ConceptGPUError(
+        f'{LIB_PATH} is missing: build it with `python -m concept_amd.build` '
+        '(hipcc --offload-arch=gfx950).  There is no fallback path.')
+_lib = ctypes.CDLL(LIB_PATH)
+for _name, (_res, _args) in SYMBOLS.items():
+    _f = getattr(_lib, _name)  # AttributeError if the .so lacks a declared symbol
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def last_error():
+    return _lib.cg_last_error().decode('utf-8', 'replace')
+
+
+def check(rc):
+    if rc != 0:
+        raise ConceptGPUError(last_error())
+
+
+def raw():
+    return _lib

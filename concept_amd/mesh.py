@@ -1,0 +1,156 @@
+"""concept_amd.mesh — host handle of the GPU potential mesh (a cg_ctx).
+
+Counterpart of the reference's global/upstream/downstream grid buffers and
+FFTW slabs (mesh.py:492-710 interpolate_upstream, :3769-3866 get_fftw_slab,
+communication.py:1666 get_buffer): one persistent mesh per (grid size,
+device), living in HBM, reused across calls."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib
+from .lib import cg_params, check
+
+_L = lib.raw()
+_meshes = {}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class PotentialMesh:
+    def __init__(self, gridsize, boxsize, nghosts=2, cell_centered=True, interp_order=2,
+                 device=None):
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device('cuda', device) if isinstance(device, int) else device
+        self.gridsize = int(gridsize)
+        self.boxsize = float(boxsize)
+        self.nghosts = int(nghosts)
+        p = cg_params()
+        p.boxsize = self.boxsize
+        p.gridsize = self.gridsize
+        p.nghosts = self.nghosts
+        p.cell_centered = int(cell_centered)
+        p.interp_order = int(interp_order)
+        p.device = self.device.index or 0
+        p.nprocs, p.rank = 1, 0
+        p.subdiv[0] = p.subdiv[1] = p.subdiv[2] = 1
+        self._ctx = ctypes.c_void_p()
+        check(_L.cg_create(ctypes.byref(p), ctypes.byref(self._ctx)))
+        self.use_stream(torch.cuda.current_stream(self.device))
+
+    def close(self):
+        if self._ctx:
+            _L.cg_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing -----------------------------------------------------------
+    def use_stream(self, stream):
+        self._stream = stream
+        check(_L.cg_set_stream(self._ctx, ctypes.c_void_p(stream.cuda_stream)))
+
+    def synchronize(self):
+        check(_L.cg_synchronize(self._ctx))
+
+    @property
+    def device_bytes(self):
+        return int(_L.cg_device_bytes(self._ctx))
+
+    @staticmethod
+    def _check_particles(*tensors):
+        n = None
+        for t in tensors:
+            if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous():
+                raise lib.ConceptGPUError('particle arrays must be contiguous float64 CUDA tensors')
+            if t.dim() != 2 or t.shape[1] != 3:
+                raise lib.ConceptGPUError('particle arrays must have shape (N, 3) (AoS xyz)')
+            n = t.shape[0] if n is None else n
+            if t.shape[0] != n:
+                raise lib.ConceptGPUError('particle arrays differ in length')
+        return n
+
+    # -- the path -----------------------------------------------------------
+    def zero(self):
+        check(_L.cg_mesh_zero(self._ctx))
+
+    def deposit(self, pos, contribution):
+        n = self._check_particles(pos)
+        check(_L.cg_deposit_cic(self._ctx, _ptr(pos), n, float(contribution)))
+
+    def poisson_solve(self, deconv_order, C, long_range=False, E=0.0):
+        check(_L.cg_poisson_solve(self._ctx, int(deconv_order), float(C), int(long_range),
+                                  float(E)))
+
+    def poisson_forward(self, deconv_order, C, long_range=False, E=0.0, apply_kernel=True):
+        check(_L.cg_poisson_forward(self._ctx, int(deconv_order), float(C), int(long_range),
+                                    float(E), int(apply_kernel)))
+
+    def poisson_kernel(self, deconv_order, C, long_range=False, E=0.0):
+        check(_L.cg_poisson_kernel(self._ctx, int(deconv_order), float(C), int(long_range),
+                                   float(E)))
+
+    def poisson_backward(self):
+        check(_L.cg_poisson_backward(self._ctx))
+
+    def gather_kick(self, pos, mom, diff_order, factor):
+        n = self._check_particles(pos, mom)
+        check(_L.cg_gather_kick(self._ctx, _ptr(pos), _ptr(mom), n, int(diff_order),
+                                float(factor)))
+
+    def drift(self, pos, mom, dt_over_mass):
+        n = self._check_particles(pos, mom)
+        check(_L.cg_drift(self._ctx, _ptr(pos), _ptr(mom), n, float(dt_over_mass)))
+
+    def sort_particles(self, pos, mom, ids, pos_out, mom_out, ids_out):
+        n = self._check_particles(pos, mom, pos_out, mom_out)
+        check(_L.cg_sort_particles(
+            self._ctx, _ptr(pos), _ptr(mom), _ptr(ids) if ids is not None else None,
+            _ptr(pos_out), _ptr(mom_out), _ptr(ids_out) if ids_out is not None else None, n))
+
+    # -- debug / parity -----------------------------------------------------
+    def fetch(self, which):
+        N = self.gridsize
+        out = np.empty((N, N, N + 2), dtype=np.float64)
+        check(_L.cg_fetch(self._ctx, int(which), out.ctypes.data_as(ctypes.c_void_p), out.size))
+        return out
+
+    def fetch_real(self):
+        return self.fetch(lib.CG_FETCH_MESH_REAL)
+
+    def fetch_fourier(self):
+        return self.fetch(lib.CG_FETCH_MESH_FOURIER)
+
+    def cic_indices(self, pos, for_gather=False):
+        n = self._check_particles(pos)
+        idx = torch.empty((n, 3), dtype=torch.int64, device=pos.device)
+        check(_L.cg_cic_indices(self._ctx, _ptr(pos), n, int(for_gather), _ptr(idx)))
+        return idx
+
+
+def get_mesh(gridsize, boxsize, nghosts=2, cell_centered=True, interp_order=2, device=None):
+    """Persistent mesh per configuration (the reference's named buffers)."""
+    if device is None:
+        device = torch.cuda.current_device()
+    key = (int(gridsize), float(boxsize), int(nghosts), bool(cell_centered), int(interp_order),
+           int(device) if isinstance(device, int) else device.index)
+    m = _meshes.get(key)
+    if m is None:
+        m = _meshes[key] = PotentialMesh(gridsize, boxsize, nghosts, cell_centered, interp_order,
+                                         device)
+    m.use_stream(torch.cuda.current_stream(m.device))
+    return m
+
+
+def free_meshes():
+    for m in _meshes.values():
+        m.close()
+    _meshes.clear()

@@ -1,0 +1,141 @@
+"""concept_amd.species — the GPU-resident particle Component.
+
+Mirrors the slice of the reference's Component the gravity path uses
+(species.py:852-1040 fields, :1911-1925 populate, :2010-2064 AoS double[3N]
+pos/mom/Δmom, :2179-2199 drift, :2253-2266 apply_Δmom, :3717-3741 nullify_Δ,
+:2598-2810 tile_sort), with the particle arrays living in HBM as torch CUDA
+tensors of shape (N, 3), float64 — the reference's own "xyzxyz..." layout."""
+import collections
+
+import numpy as np
+import torch
+
+from . import commons
+from .lib import ConceptGPUError
+from .mesh import get_mesh
+
+PotentialGridsizes = collections.namedtuple('PotentialGridsizes', ('upstream', 'downstream'))
+
+
+class Component:
+    representation = 'particles'
+
+    def __init__(self, name, species, *, N, mass, boltzmann_order=-1, device=None, params=None):
+        if boltzmann_order not in (-1,):
+            raise ConceptGPUError('fluid components (boltzmann_order >= 0) are not on the '
+                                  'GPU path (SURVEY.md §8f)')
+        self.params = p = params or commons.params
+        if p is None:
+            raise ConceptGPUError('no parameters loaded: call concept_amd.commons.load_params()')
+        self.name = name.strip()
+        self.species = species
+        self.N = self.N_local = int(N)
+        self.mass = float(mass)
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.softening_length = commons.softening_length(p, species, self.N)
+        self.pos = torch.zeros((self.N, 3), dtype=torch.float64, device=self.device)
+        self.mom = torch.zeros((self.N, 3), dtype=torch.float64, device=self.device)
+        self.Δmom = None  # allocated on first short-range use
+        self.ids = torch.arange(self.N, dtype=torch.int64, device=self.device)
+        self._scratch = None
+        # rungs: single rung 0 until adaptive rung stepping is built
+        self.use_rungs = False
+        self.lowest_active_rung = 0
+        self.lowest_populated_rung = 0
+        self.highest_populated_rung = 0
+        # forces and potential grid sizes (species.py:1100-1215)
+        self.forces = {}
+        for key in (self.name, species, 'particles', 'all', 'default'):
+            if key in p.select_forces:
+                self.forces = dict(p.select_forces[key])
+                break
+        self.potential_gridsizes = {}
+        self.potential_differentiations = {}
+        for force, method in self.forces.items():
+            methods = [method] + (['pm'] if method == 'p3m' else [])
+            for m in methods:
+                g = p.potential_options['gridsize']['global'].get(force, {}).get(m, -1)
+                if g == -1:
+                    cb = int(round(self.N**(1/3)))
+                    g = 2*cb if m == 'p3m' else cb
+                self.potential_gridsizes.setdefault(force, {})[m] = PotentialGridsizes(g, g)
+                d = None
+                for key in (self.name, species, 'default'):
+                    dd = p.potential_options['differentiation'].get(key)
+                    if dd and m in dd.get(force, {}):
+                        d = dd[force][m]
+                        break
+                self.potential_differentiations.setdefault(force, {})[m] = d
+
+    # -- data in / out ------------------------------------------------------
+    def populate(self, data, var):
+        """populate(array, 'posx'|'posy'|'posz'|'momx'|...) (species.py:1911-1925);
+        also accepts var='pos'/'mom' with an (N, 3) array."""
+        t = torch.as_tensor(np.ascontiguousarray(np.asarray(data, dtype=np.float64)))
+        if var in ('pos', 'mom'):
+            getattr(self, var).copy_(t.reshape(self.N, 3))
+            return
+        prefix, suffix = var[:-1], var[-1]
+        getattr(self, prefix)[:, 'xyz'.index(suffix)] = t.to(self.device)
+
+    def w_eff(self, a=1.0):
+        return 0.0  # matter; decaying species are out of scope
+
+    def host(self, var, original_order=True):
+        """Host copy of 'pos' | 'mom' | 'Δmom', by default in the order the
+        particles were populated in (undoing tile_sort via ids)."""
+        t = getattr(self, var)
+        if original_order:
+            out = torch.empty_like(t)
+            out[self.ids] = t
+            t = out
+        return t.cpu().numpy()
+
+    # -- dynamics -----------------------------------------------------------
+    def _mesh(self):
+        p = self.params
+        g = None
+        for force, d in self.potential_gridsizes.items():
+            for m, gs in d.items():
+                g = gs.upstream
+                break
+            break
+        if g is None:
+            g = max(4, 2*int(round(self.N**(1/3))))
+        return get_mesh(g, p.boxsize, p.nghosts, p.cell_centered, 2, self.device)
+
+    def drift(self, ᔑdt, a_next=-1, a=1.0):
+        """species.py:2179-2199.  `a` is universals.a (only enters through
+        a**(3*w_eff) = 1 for matter)."""
+        Δt_over_mass = ᔑdt['a**(-2)']*a**(3*self.w_eff(a=a))/self.mass
+        self._mesh().drift(self.pos, self.mom, Δt_over_mass)
+
+    def tile_sort(self, mesh=None):
+        """Reorder particle memory into mesh-tile order (the reference's
+        tile_sort, species.py:2598-2810, reorders for the same reason)."""
+        mesh = mesh or self._mesh()
+        if self._scratch is None:
+            self._scratch = (torch.empty_like(self.pos), torch.empty_like(self.mom),
+                             torch.empty_like(self.ids))
+        po, mo, io = self._scratch
+        mesh.sort_particles(self.pos, self.mom, self.ids, po, mo, io)
+        self._scratch = (self.pos, self.mom, self.ids)
+        self.pos, self.mom, self.ids = po, mo, io
+
+    def nullify_Δ(self, specifically=None, only_active=True):
+        if specifically is None:
+            raise ConceptGPUError('You must specify "specifically" when calling '
+                                  'Component.nullify_Δ() for particle components.')
+        if specifically != 'mom':
+            raise ConceptGPUError(f'Component.nullify_Δ(): specifically = {specifically} '
+                                  'not supported')
+        if self.Δmom is None:
+            self.Δmom = torch.zeros_like(self.mom)
+        else:
+            self.Δmom.zero_()
+
+    def apply_Δmom(self, only_active=True):
+        if self.Δmom is not None:
+            self.mom += self.Δmom

@@ -1,0 +1,137 @@
+/*
+ * concept_gpu.h — C ABI of libconcept_gpu.so, the MI355X (gfx950) PM / P3M
+ * gravity hot path of CO*N*CEPT.
+ *
+ * The reference has no FFI for this path: its boundary is the Python-level
+ * interaction registry (interactions.py:2646 register(), :2854 gravity()),
+ * below which everything is Cython-compiled Python plus FFTW glue (fft.c).
+ * This header is the boundary a maintainer would bind from src/gravity.py /
+ * src/interactions.py (ctypes stub in INTEGRATION.md): plain pointers and
+ * sizes, no torch types.  Every entry point names the reference function it
+ * replaces (file:line under reference/src).
+ *
+ * Conventions
+ *  - Every pointer marked DEV is a device (HBM) pointer on the context's
+ *    GPU; HOST pointers are ordinary host memory.
+ *  - Particle arrays are the reference's own layout (species.py:2010-2064):
+ *    AoS double[3*N] "xyzxyz...", FP64.
+ *  - All work is enqueued on the context's HIP stream (cg_set_stream) and is
+ *    asynchronous with respect to the host unless stated otherwise.
+ *  - Return value: 0 on success, non-zero on error with the message available
+ *    from cg_last_error() (the reference's abort(), commons.py:1002-1031,
+ *    becomes an error return; nothing is printed, nothing exits).
+ */
+#ifndef CONCEPT_GPU_H
+#define CONCEPT_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CG_ABI_VERSION 1
+
+typedef struct cg_ctx cg_ctx;
+
+/* Mesh + domain description.  Parameter names follow the reference's
+ * (commons.py:2956 boxsize, :2958-3237 potential_options, :4411-4432 nghosts,
+ * :3926 cell_centered; communication.py:692-741,1765-1836 domain layout). */
+typedef struct cg_params {
+    double  boxsize;
+    int64_t gridsize;      /* global PM grid size N (cubic, even) */
+    int32_t nghosts;       /* ghost layers of a domain grid; reference default 2 */
+    int32_t cell_centered; /* 1 (reference default) */
+    int32_t interp_order;  /* 2 = CIC (the only order built so far) */
+    int32_t device;        /* HIP device ordinal */
+    int32_t nprocs;        /* number of domains (= ranks = GPUs) */
+    int32_t rank;          /* this domain */
+    int32_t subdiv[3];     /* cutout_domains(nprocs), communication.py:692 */
+    int32_t reserved;
+} cg_params;
+
+/* which = selector for cg_fetch (debug / parity tests only) */
+enum {
+    CG_FETCH_MESH_REAL = 0,  /* the local real-space mesh, reference x-slab layout
+                                double[N/P][N][N+2] (mesh.py:1935-1942), padding included */
+    CG_FETCH_MESH_FOURIER = 1 /* the local Fourier slab in the reference's transposed
+                                layout double[j_local][i][N+2] re/im interleaved
+                                (fft.c:55-72, mesh.py:2716-2719) */
+};
+
+const char *cg_last_error(void);
+int cg_abi_version(void);
+
+/* Context: owns the potential mesh, the rocFFT plans and scratch.
+ * Replaces get_fftw_slab()/fftw_setup() (mesh.py:3769-3866, fft.c:105-212)
+ * and the named grid buffers (communication.py:1666 get_buffer). */
+int cg_create(const cg_params *params, cg_ctx **out);
+int cg_destroy(cg_ctx *ctx);
+int cg_set_stream(cg_ctx *ctx, void *hip_stream);
+int cg_synchronize(cg_ctx *ctx);
+/* bytes of HBM owned by the context */
+int64_t cg_device_bytes(const cg_ctx *ctx);
+
+/* --- A1/A2: mass deposition ------------------------------------------------
+ * cg_mesh_zero: get_buffer(..., nullify=True) (mesh.py:600-603).
+ * cg_deposit_cic: interpolate_particles (mesh.py:1512-1636) with the inlined
+ * CIC loop (mesh.py:5101-5155, 5319-5324) for `n` particles, each depositing
+ * `contribution` (mesh.py:1550-1573, computed by the caller).  On a single
+ * domain the ghost fold communicate_ghosts(grid,'+=') (mesh.py:609,
+ * communication.py:563-660) is the periodic wrap and is fused here. */
+int cg_mesh_zero(cg_ctx *ctx);
+int cg_deposit_cic(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, double contribution);
+
+/* --- A3..A8: Poisson solve, in place on the context's mesh -----------------
+ * slab_decompose + fft('forward') + nullify_modes('nyquist') (mesh.py:665-672,
+ * 2284-2411, 4012-4157, 3591-3622; fft.c:240-248), the Poisson/deconvolution
+ * kernel (fourier_loop mesh.py:2615-2890 inlined at interactions.py:2092-2118),
+ * fft('backward') + domain_decompose (interactions.py:2302-2307).
+ *   deconv_order : deconv_order_global (interactions.py:2069-2080), 4 for CIC up+down
+ *   C            : -boxsize**2*G_Newton/pi                (interactions.py:2105)
+ *   long_range,E : potential 'gravity long-range', E = -(2*pi/boxsize*scale)**2
+ *                  (interactions.py:2110-2113) */
+int cg_poisson_solve(cg_ctx *ctx, int deconv_order, double C, int long_range, double E);
+/* The two halves, for tests: density -> Fourier potential, and back. */
+int cg_poisson_forward(cg_ctx *ctx, int deconv_order, double C, int long_range, double E,
+                       int apply_kernel);
+int cg_poisson_backward(cg_ctx *ctx);
+/* Only the k-space kernel (A5/A6) on a mesh that already holds the forward transform. */
+int cg_poisson_kernel(cg_ctx *ctx, int deconv_order, double C, int long_range, double E);
+
+/* --- A9/A10: force differentiation + interpolation + kick ------------------
+ * For dim in 0..2: diff_domaingrid(order 2|4) (mesh.py:4874-5030) and
+ * interpolate_domaingrid_to_particles (mesh.py:376-459) via
+ * apply_particle_mesh_force (interactions.py:2359-2402):
+ *   mom[3p+dim] += factor * sum_8 (w * dphi/dx_dim),  factor = -mass*dt_kick.
+ * The finite difference is evaluated per particle from the potential mesh
+ * (same expression, same order as the reference's force grid cell). */
+int cg_gather_kick(cg_ctx *ctx, const double *pos /*DEV 3n*/, double *mom /*DEV 3n*/, int64_t n,
+                   int diff_order, double factor);
+
+/* --- A11: drift ------------------------------------------------------------
+ * Component.drift (species.py:2179-2199): pos = mod(pos + mom*dt_over_mass, boxsize)
+ * with the reference's mod (commons.py:5103-5135). */
+int cg_drift(cg_ctx *ctx, double *pos /*DEV 3n*/, const double *mom /*DEV 3n*/, int64_t n,
+             double dt_over_mass);
+
+/* --- particle memory order -------------------------------------------------
+ * The reference reorders particle memory for locality (Component.tile_sort,
+ * species.py:2598-2810).  cg_sort_particles bins particles by mesh tile and
+ * permutes pos/mom (and the optional ids) into tile order.  Scratch buffers
+ * are owned by the caller: pos_out/mom_out/ids_out must not alias the inputs. */
+int cg_sort_particles(cg_ctx *ctx, const double *pos_in, const double *mom_in,
+                      const int64_t *ids_in /*nullable*/, double *pos_out, double *mom_out,
+                      int64_t *ids_out /*nullable*/, int64_t n);
+
+/* --- debug fetch (parity tests) -------------------------------------------- */
+int cg_fetch(cg_ctx *ctx, int which, double *out /*HOST*/, int64_t n_doubles);
+/* CIC cell indices exactly as set_weights_CIC returns them for the deposit
+ * (mesh.py:5319-5324 under the offsets of mesh.py:1577-1606) -> int64[3n] DEV */
+int cg_cic_indices(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, int for_gather,
+                   int64_t *idx_out /*DEV 3n*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONCEPT_GPU_H */

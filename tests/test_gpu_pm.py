@@ -1,0 +1,291 @@
+"""GPU parity tests of the PM path (run with -m gpu on an MI355X).
+
+Every test calls the HIP library through its C ABI (concept_amd.lib /
+concept_amd.mesh) and checks against (a) the golden vectors produced by the
+imported reference and (b) the CPU oracle on the same seeded inputs.
+
+Bars: CIC grid indices bit-exact; drift bit-exact; deposited
+density, k-space potential, potential grid and per-particle kick <= 1e-12 of
+the field rms for a single kick (summation order of the scatter and the FFT
+backend differ from the reference's; its own compiled-vs-pure-Python bar is
+1e-10, test/pure_python_pm/analyze.py:125)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+PM_CASES = ['pm_n8_g16', 'pm_n16_g32', 'pm_edge_g16', 'pm_n8_g16_d4']
+
+
+@pytest.fixture(scope='module')
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch
+
+
+def rms(a):
+    return float(np.sqrt((np.asarray(a)**2).mean()))
+
+
+def fold_ghosts(grid, g):
+    """communicate_ghosts(grid, '+=') on one rank + interior, in numpy."""
+    n = grid.shape[0] - 2*g
+    out = np.zeros((n, n, n))
+    idx = (np.arange(grid.shape[0]) - g) % n
+    np.add.at(out, (idx[:, None, None], idx[None, :, None], idx[None, None, :]), grid)
+    return out
+
+
+def setup_case(torch, g):
+    from concept_amd.mesh import PotentialMesh
+    from oracle import oracle
+    L, N = float(g['boxsize']), int(g['gridsize'])
+    mesh = PotentialMesh(N, L, nghosts=int(g['nghosts']))
+    pos = torch.tensor(g['pos_in'], device='cuda')
+    mom = torch.tensor(g['mom_in'], device='cuda')
+    contribution = oracle.deposit_contribution(float(g['mass']), float(g['dt_dens']),
+                                               float(g['dt_1']), N, L)
+    sc = float(g['shortrange_scale']) if 'shortrange_scale' in g else None
+    C, E = oracle.poisson_constants(L, float(g['G_Newton']), sc)
+    return mesh, pos, mom, contribution, C, E, sc is not None
+
+
+@pytest.mark.parametrize('name', PM_CASES + ['pm_n32_g64', 'p3m_n8_g32'])
+def test_cic_indices_bit_exact(torch_cuda, golden, name):
+    g = golden(name)
+    mesh, pos, mom, *_ = setup_case(torch_cuda, g)
+    assert np.array_equal(mesh.cic_indices(pos, False).cpu().numpy(), g['cic_index_deposit'])
+    assert np.array_equal(mesh.cic_indices(pos, True).cpu().numpy(), g['cic_index_gather'])
+
+
+@pytest.mark.parametrize('name', PM_CASES + ['p3m_n8_g32'])
+def test_pm_intermediates(torch_cuda, golden, name):
+    g = golden(name)
+    mesh, pos, mom, contribution, C, E, lr = setup_case(torch_cuda, g)
+    N, ng = int(g['gridsize']), int(g['nghosts'])
+    # A1/A2 deposit (+ fold)
+    mesh.zero()
+    mesh.deposit(pos, contribution)
+    dens = mesh.fetch_real()[:, :, :N]
+    ref = fold_ghosts(g['grid_deposit'], ng)
+    assert np.abs(dens - ref).max() <= TOL*rms(ref)
+    # total mass is conserved to rounding
+    assert abs(dens.sum() - ref.sum()) <= 1e-12*abs(ref.sum())
+    # A4/A5 forward FFT + Nyquist nullification (kernel applied separately below)
+    mesh.poisson_forward(0, 1.0, False, 0.0, apply_kernel=False)
+    dk = mesh.fetch_fourier()
+    refk = g['slab_density_k']
+    nyq = N//2
+    keep = np.ones((N, N, N + 2), dtype=bool)
+    keep[nyq, :, :] = False
+    keep[:, nyq, :] = False
+    keep[:, :, N:] = False
+    assert np.abs(dk - refk)[keep].max() <= TOL*rms(refk)
+    # A6 Poisson kernel: redo from the density
+    mesh.zero()
+    mesh.deposit(pos, contribution)
+    mesh.poisson_forward(4, C, lr, E, apply_kernel=True)
+    pk = mesh.fetch_fourier()
+    refp = g['slab_potential_k']
+    assert np.abs(pk - refp).max() <= TOL*rms(refp)
+    assert pk[0, 0, 0] == 0 and pk[0, 0, 1] == 0
+    assert not pk[nyq].any() and not pk[:, nyq].any() and not pk[:, :, N:].any()
+    # A8 back to real space
+    mesh.poisson_backward()
+    phi = mesh.fetch_real()[:, :, :N]
+    refphi = g['grid_potential'][ng:-ng, ng:-ng, ng:-ng]
+    assert np.abs(phi - refphi).max() <= TOL*rms(refphi)
+
+
+@pytest.mark.parametrize('name', PM_CASES + ['pm_n32_g64', 'p3m_n8_g32', 'p3m_n12_g36_lattice',
+                                             'p3m_n16_g48_clustered'])
+def test_pm_kick_vs_golden_and_oracle(torch_cuda, golden, name):
+    from oracle import oracle
+    g = golden(name)
+    mesh, pos, mom, contribution, C, E, lr = setup_case(torch_cuda, g)
+    mesh.zero()
+    mesh.deposit(pos, contribution)
+    mesh.poisson_solve(4, C, lr, E)
+    mesh.gather_kick(pos, mom, int(g['diff_order']), float(g['mass'])*(-float(g['dt_kick'])))
+    out = mom.cpu().numpy()
+    kick_ref = g['mom_after_long'] - g['mom_in']
+    scale = max(rms(kick_ref), 1e-300)
+    if name == 'p3m_n12_g36_lattice':
+        # perfect lattice: the kick vanishes by symmetry (test/multicomponent K1);
+        # compare against the size of a single-cell force instead
+        scale = float(g['mass'])*float(g['dt_kick'])*float(g['G_Newton'])*float(g['mass'])
+    assert np.abs(out - g['mom_after_long']).max() <= TOL*scale + 4e-16*np.abs(g['mom_in']).max()
+    # and the oracle run here on the same inputs
+    mom_o = g['mom_in'].copy()
+    sc = float(g['shortrange_scale']) if 'shortrange_scale' in g else None
+    oracle.pm_long_range(g['pos_in'].copy(), mom_o, mass=float(g['mass']),
+                         boxsize=float(g['boxsize']), gridsize=int(g['gridsize']),
+                         G_Newton=float(g['G_Newton']), dt_1=float(g['dt_1']),
+                         dt_dens=float(g['dt_dens']), dt_kick=float(g['dt_kick']),
+                         diff_order=int(g['diff_order']), shortrange_scale=sc,
+                         want_indices=False)
+    assert np.abs(out - mom_o).max() <= TOL*scale + 4e-16*np.abs(g['mom_in']).max()
+
+
+@pytest.mark.parametrize('name', PM_CASES + ['pm_n32_g64', 'p3m_n8_g32'])
+def test_drift_bit_exact(torch_cuda, golden, name):
+    torch = torch_cuda
+    g = golden(name)
+    mesh, *_ = setup_case(torch, g)
+    pos = torch.tensor(g['drift_pos_in'] if 'drift_pos_in' in g else g['pos_in'], device='cuda')
+    mom = torch.tensor(g['drift_mom_in'] if 'drift_mom_in' in g else g['mom_after_long'],
+                       device='cuda')
+    mesh.drift(pos, mom, float(g['drift_dt_over_mass']))
+    assert np.array_equal(pos.cpu().numpy(), g['drift_pos_out'])
+
+
+def test_drift_wrap_edges(torch_cuda):
+    torch = torch_cuda
+    from concept_amd.mesh import PotentialMesh
+    from oracle import oracle
+    L = 10.0
+    mesh = PotentialMesh(8, L)
+    pos = np.array([[0.0, 9.999999999999998, 5.0], [1e-17, 9.5, 0.25], [0.0, 0.0, 9.0]])
+    mom = np.array([[-1e-17, 1.0, 25.0], [-1.0, 0.5, -30.25], [-0.0, 10.0, 1.0]])
+    ref = oracle.drift(pos.copy(), mom, 1.0, L)
+    p = torch.tensor(pos, device='cuda')
+    mesh.drift(p, torch.tensor(mom, device='cuda'), 1.0)
+    out = p.cpu().numpy()
+    assert np.array_equal(out, ref)
+    assert (out >= 0).all() and (out < L).all()
+
+
+def test_tile_sort_is_a_permutation_in_tile_order(torch_cuda):
+    torch = torch_cuda
+    from concept_amd.mesh import PotentialMesh
+    L, N, n = 50.0, 32, 20000
+    mesh = PotentialMesh(N, L)
+    rng = np.random.default_rng(3)
+    pos = torch.tensor(rng.uniform(0, L, (n, 3)), device='cuda')
+    mom = torch.tensor(rng.normal(size=(n, 3)), device='cuda')
+    ids = torch.arange(n, device='cuda')
+    po, mo, io = torch.empty_like(pos), torch.empty_like(mom), torch.empty_like(ids)
+    mesh.sort_particles(pos, mom, ids, po, mo, io)
+    torch.cuda.synchronize()
+    assert np.array_equal(np.sort(io.cpu().numpy()), np.arange(n))
+    assert torch.equal(po, pos[io]) and torch.equal(mo, mom[io])
+    idx = mesh.cic_indices(po).cpu().numpy() - 2
+    idx = np.mod(idx, N)//8
+    key = (idx[:, 0]*(N//8) + idx[:, 1])*(N//8) + idx[:, 2]
+    assert (np.diff(key) >= 0).all()
+
+
+def test_empty_and_single_particle(torch_cuda):
+    torch = torch_cuda
+    from concept_amd.mesh import PotentialMesh
+    mesh = PotentialMesh(16, 16.0)
+    empty = torch.zeros((0, 3), dtype=torch.float64, device='cuda')
+    mesh.zero()
+    mesh.deposit(empty, 1.0)
+    mesh.gather_kick(empty, empty.clone(), 2, 1.0)
+    mesh.drift(empty, empty.clone(), 1.0)
+    assert not mesh.fetch_real().any()
+    # one particle at a cell centre deposits all its mass in one cell and feels no self-force
+    pos = torch.tensor([[4.5, 7.5, 11.5]], dtype=torch.float64, device='cuda')
+    mom = torch.zeros_like(pos)
+    mesh.deposit(pos, 2.0)
+    d = mesh.fetch_real()[:, :, :16]
+    assert d[4, 7, 11] == 2.0 and d.sum() == 2.0
+    mesh.poisson_solve(4, -1.0, False, 0.0)
+    mesh.gather_kick(pos, mom, 2, 1.0)
+    assert np.abs(mom.cpu().numpy()).max() < 1e-12
+
+
+def test_errors_are_loud(torch_cuda):
+    torch = torch_cuda
+    from concept_amd.lib import ConceptGPUError
+    from concept_amd.mesh import PotentialMesh
+    with pytest.raises(ConceptGPUError):
+        PotentialMesh(15, 1.0)  # odd grid
+    mesh = PotentialMesh(16, 16.0)
+    pos = torch.zeros((4, 3), dtype=torch.float64, device='cuda')
+    with pytest.raises(ConceptGPUError):
+        mesh.gather_kick(pos, pos.clone(), 3, 1.0)  # odd differentiation order
+    with pytest.raises(ConceptGPUError):
+        mesh.deposit(pos.float(), 1.0)  # wrong dtype
+
+
+def test_gravity_api_pm(torch_cuda, golden):
+    """The boundary itself: gravity('pm', [c], [c], ᔑdt, 'long-range', False)
+    (interactions.py:2854) with the reference's parameter names."""
+    from concept_amd import commons, interactions
+    from concept_amd.species import Component
+    g = golden('pm_n16_g32')
+    commons.load_params({
+        'boxsize': float(g['boxsize']),
+        'potential_options': {'gridsize': {'gravity': {'pm': int(g['gridsize'])}}},
+        'select_forces': {'matter': {'gravity': 'pm'}},
+    })
+    c = Component('matter', 'matter', N=int(g['N']), mass=float(g['mass']))
+    for d, s in enumerate('xyz'):
+        c.populate(g['pos_in'][:, d], 'pos' + s)
+        c.populate(g['mom_in'][:, d], 'mom' + s)
+    sdt = {'1': float(g['dt_1']), 'a**(-2)': float(g['dt_am2']),
+           ('a**(-3*w_eff)', 'matter'): float(g['dt_kick']),
+           ('a**(-3*w_eff-1)', 'matter'): float(g['dt_dens'])}
+    interactions.gravity('pm', [c], [c], sdt, 'long-range', False)
+    kick_ref = g['mom_after_long'] - g['mom_in']
+    assert np.abs(c.host('mom') - g['mom_after_long']).max() <= TOL*rms(kick_ref)
+    assert np.array_equal(c.host('pos'), g['pos_in'])  # gravity must not touch pos
+    # drift through the Component API, then sorting must not change the physics
+    c.drift(sdt)
+    d = np.abs(c.host('pos') - g['drift_pos_out'])
+    d = np.minimum(d, float(g['boxsize']) - d)
+    assert d.max() <= 1e-13*float(g['boxsize'])
+    c.tile_sort()
+    before = c.host('mom')
+    interactions.gravity('pm', [c], [c], sdt, 'long-range', False)
+    c2 = Component('matter', 'matter', N=int(g['N']), mass=float(g['mass']))
+    c2.populate(c.host('pos'), 'pos')
+    c2.populate(before, 'mom')
+    interactions.gravity('pm', [c2], [c2], sdt, 'long-range', False)
+    k = c2.host('mom') - before
+    assert np.abs(c.host('mom') - c2.host('mom')).max() <= TOL*rms(k)
+
+
+def test_full_size_properties(torch_cuda):
+    """BASELINE config-2 size (256^3 particles / 512^3 mesh): size-independent
+    properties — total deposited mass, zero net momentum transfer, linearity
+    of the kick in the supplier mass, and invariance under particle order."""
+    torch = torch_cuda
+    from concept_amd.mesh import PotentialMesh
+    L, N, n = 512.0, 512, 256**3
+    mesh = PotentialMesh(N, L)
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    pos = torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=gen)*L
+    pos.clamp_(max=float(np.nextafter(L, 0)))
+    mom = torch.zeros_like(pos)
+    mesh.zero()
+    mesh.deposit(pos, 1.0)
+    dens = mesh.fetch_real()[:, :, :N]
+    total = dens.sum()
+    assert abs(total - n) <= 1e-9*n
+    mesh.poisson_solve(4, -1.0, False, 0.0)
+    mesh.gather_kick(pos, mom, 2, 1.0)
+    k1 = mom.clone()
+    # Newton's third law on the mesh: net momentum change ~ 0
+    assert float(k1.sum(0).abs().max()) <= 1e-9*float(k1.abs().sum(0).max())
+    # linearity: twice the contribution -> twice the kick
+    mom.zero_()
+    mesh.zero()
+    mesh.deposit(pos, 2.0)
+    mesh.poisson_solve(4, -1.0, False, 0.0)
+    mesh.gather_kick(pos, mom, 2, 1.0)
+    assert float((mom - 2*k1).abs().max()) <= 1e-11*float(k1.abs().max())
+    # order invariance: sort the particles, kick again, compare through ids
+    ids = torch.arange(n, device='cuda')
+    po, mo, io = torch.empty_like(pos), torch.empty_like(mom), torch.empty_like(ids)
+    mom.zero_()
+    mesh.sort_particles(pos, mom, ids, po, mo, io)
+    mesh.zero()
+    mesh.deposit(po, 1.0)
+    mesh.poisson_solve(4, -1.0, False, 0.0)
+    mesh.gather_kick(po, mo, 2, 1.0)
+    assert float((mo - k1[io]).abs().max()) <= 1e-11*float(k1.abs().max())
