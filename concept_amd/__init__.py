@@ -1,7 +1,8 @@
 """concept_amd — MI355X-native PM/P3M gravity stepper behind CO*N*CEPT's
 gravity(method, receivers, suppliers, ᔑdt, interaction_type, printout) API.
 
-Importing the package loads libconcept_gpu.so (concept_amd/lib.py) and fails
-loudly if it has not been built: there is no CPU fallback."""
+Every module of the path (mesh, species, interactions) imports
+concept_amd.lib, which loads libconcept_gpu.so and raises if it has not been
+built (`python -m concept_amd.build`): there is no CPU fallback.  Only
+`concept_amd.build` and `concept_amd.commons` are importable without it."""
 from . import commons  # noqa: F401
-from . import lib  # noqa: F401  (raises if the HIP library is missing)
