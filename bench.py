@@ -51,7 +51,7 @@ def algorithmic_bytes(n_p, n_g):
     }
 
 
-def cpu_baseline(sample_n=128, sample_grid=256, steps=2):
+def cpu_baseline(sample_n=128, sample_grid=256, steps=12):
     """The oracle (a C port of the reference's algorithm + numpy pocketfft,
     the reference's own pure-Python FFT) on a bounded sample, 1 thread."""
     import numpy as np
@@ -85,7 +85,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-sort', action='store_true')
+    ap.add_argument('--no-sort', action='store_true',
+                    help='direct (untiled) kernels on unsorted particles, for A/B')
     args = ap.parse_args()
 
     import torch
@@ -116,6 +117,7 @@ def main():
                                                  torch.tensor(0.0, dtype=torch.float64))))
     mom = torch.zeros_like(pos)
     pos2, mom2 = torch.empty_like(pos), torch.empty_like(mom)
+    table = mesh.new_tile_table()
     # step scalars: fixed (enable_Hubble=False semantics)
     mass = 1.0
     G = 1.0
@@ -125,10 +127,12 @@ def main():
     kick_factor = mass*(-dt)
     dt_over_mass = dt/mass
 
-    PHASES = ['drift', 'sort', 'zero', 'deposit', 'fft_forward', 'kspace', 'fft_backward',
-              'gather_kick']
     if args.no_sort:
-        PHASES.remove('sort')
+        PHASES = ['drift', 'zero', 'deposit', 'fft_forward', 'kspace', 'fft_backward',
+                  'gather_kick']
+    else:  # the tiled deposit assigns the mesh: no zero-fill pass
+        PHASES = ['drift', 'sort', 'deposit', 'fft_forward', 'kspace', 'fft_backward',
+                  'gather_kick']
     events = []
 
     def step(record):
@@ -146,21 +150,27 @@ def main():
         mesh.drift(pos, mom, dt_over_mass)
         mark()
         if not args.no_sort:
-            mesh.sort_particles(pos, mom, None, pos2, mom2, None)
+            mesh.sort_particles(pos, mom, None, pos2, mom2, None, table)
             pos, pos2 = pos2, pos
             mom, mom2 = mom2, mom
             mark()
-        mesh.zero()
-        mark()
-        mesh.deposit(pos, contribution)
-        mark()
+            mesh.deposit_tiled(pos, table, contribution, accumulate=False)
+            mark()
+        else:
+            mesh.zero()
+            mark()
+            mesh.deposit(pos, contribution)
+            mark()
         mesh.poisson_forward(4, C, False, 0.0, apply_kernel=False)
         mark()
         mesh.poisson_kernel(4, C, False, 0.0)
         mark()
         mesh.poisson_backward()
         mark()
-        mesh.gather_kick(pos, mom, 2, kick_factor)
+        if not args.no_sort:
+            mesh.gather_kick_tiled(pos, mom, table, 2, kick_factor)
+        else:
+            mesh.gather_kick(pos, mom, 2, kick_factor)
         mark()
         if record:
             events.append(ev)

@@ -139,20 +139,23 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
             return fail();
         }
     }
-    // tiles: 8x8x8 cells when the grid allows, for the particle order and the
-    // LDS-tiled kernels
+    // tiles: cubic, 16 cells when the grid allows (at least 2 tiles per dimension),
+    // for the particle memory order and the LDS-tiled deposit / gather kernels
     {
-        int t = 8;
-        while (t > 1 && c->N % t) t /= 2;
+        int t = 16;
+        while (t > 2 && (c->N % t || c->N / t < 2)) t /= 2;
+        if (c->N % t) {
+            cg_set_error("cg_create: gridsize %lld is not divisible by 2", (long long)c->N);
+            return fail();
+        }
         c->tiles = {t, t, t, (int)(c->N / t), (int)(c->N / t), (int)(c->N / t)};
         c->ntiles = (i64)c->tiles.ntx * c->tiles.nty * c->tiles.ntz;
         if (hipMalloc(&c->tile_count, 4 * (c->ntiles + 1)) != hipSuccess ||
-            hipMalloc(&c->tile_offset, 4 * (c->ntiles + 1)) != hipSuccess ||
             hipMalloc(&c->tile_cursor, 4 * (c->ntiles + 1)) != hipSuccess) {
             cg_set_error("cg_create: tile table allocation failed");
             return fail();
         }
-        c->device_bytes += 12 * (c->ntiles + 1);
+        c->device_bytes += 8 * (c->ntiles + 1);
     }
     if (make_plans(c)) return fail();
     *out = c;
@@ -171,7 +174,6 @@ extern "C" int cg_destroy(cg_ctx *c) {
     (void)hipFree(c->ktab_n);
     (void)hipFree(c->ktab_s);
     (void)hipFree(c->tile_count);
-    (void)hipFree(c->tile_offset);
     (void)hipFree(c->tile_cursor);
     (void)hipFree(c->scan_tmp);
     delete c;
@@ -253,20 +255,47 @@ extern "C" int cg_drift(cg_ctx *c, double *pos, const double *mom, int64_t n,
                         double dt_over_mass) {
     CG_CHECK(c && ((pos && mom) || n == 0), "cg_drift: null argument");
     if (n == 0) return 0;
-    c->tiles_valid = false;
     return cgk_drift(c, pos, mom, n, dt_over_mass);
+}
+
+extern "C" int cg_tile_info(const cg_ctx *c, int64_t info[3]) {
+    CG_CHECK(c && info, "cg_tile_info: null argument");
+    info[0] = c->tiles.tx;
+    info[1] = c->tiles.ntx;
+    info[2] = c->ntiles;
+    return 0;
+}
+
+extern "C" int cg_deposit_cic_tiled(cg_ctx *c, const double *pos, int64_t n,
+                                    const uint32_t *tile_offset, double contribution,
+                                    int accumulate) {
+    CG_CHECK(c && tile_offset && (pos || n == 0), "cg_deposit_cic_tiled: null argument");
+    CG_CHECK(n >= 0 && n < (1ll << 32), "cg_deposit_cic_tiled: n out of range");
+    return cgk_deposit_cic_tiled(c, pos, n, tile_offset, contribution, accumulate);
+}
+
+extern "C" int cg_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, int64_t n,
+                                    const uint32_t *tile_offset, int diff_order, double factor) {
+    CG_CHECK(c && tile_offset && ((pos && mom) || n == 0), "cg_gather_kick_tiled: null argument");
+    CG_CHECK(diff_order == 2 || diff_order == 4,
+             "cg_gather_kick_tiled: differentiation order %d not built (2 and 4 are)", diff_order);
+    CG_CHECK((diff_order + 1) / 2 <= c->p.nghosts,
+             "cg_gather_kick_tiled: differentiation order %d needs nghosts >= %d "
+             "(commons.py:4411-4432)", diff_order, (diff_order + 1) / 2);
+    if (n == 0) return 0;
+    return cgk_gather_kick_tiled(c, pos, mom, n, tile_offset, diff_order, factor);
 }
 
 extern "C" int cg_sort_particles(cg_ctx *c, const double *pos_in, const double *mom_in,
                                  const int64_t *ids_in, double *pos_out, double *mom_out,
-                                 int64_t *ids_out, int64_t n) {
-    CG_CHECK(c && pos_in && mom_in && pos_out && mom_out, "cg_sort_particles: null argument");
+                                 int64_t *ids_out, int64_t n, uint32_t *tile_offset_out) {
+    CG_CHECK(c && pos_in && mom_in && pos_out && mom_out && tile_offset_out,
+             "cg_sort_particles: null argument");
     CG_CHECK(pos_in != pos_out && mom_in != mom_out, "cg_sort_particles: in/out must not alias");
     CG_CHECK((ids_in == nullptr) == (ids_out == nullptr),
              "cg_sort_particles: ids_in and ids_out must both be given or both be null");
     CG_CHECK(n >= 0 && n < (1ll << 32), "cg_sort_particles: n out of range");
-    if (n == 0) return 0;
-    return cgk_sort(c, pos_in, mom_in, ids_in, pos_out, mom_out, ids_out, n);
+    return cgk_sort(c, pos_in, mom_in, ids_in, pos_out, mom_out, ids_out, n, tile_offset_out);
 }
 
 extern "C" int cg_cic_indices(cg_ctx *c, const double *pos, int64_t n, int for_gather,

@@ -86,14 +86,10 @@ struct cg_ctx {
     // particle sort scratch (owned, grown on demand)
     TileGeom tiles{};
     unsigned int *tile_count = nullptr;   // [ntiles + 1]
-    unsigned int *tile_offset = nullptr;  // [ntiles + 1] exclusive scan
     unsigned int *tile_cursor = nullptr;  // [ntiles]
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     i64 ntiles = 0;
-    bool tiles_valid = false;  // tile_offset describes the arrays last sorted
-    i64 sorted_n = -1;
-    const double *sorted_pos = nullptr;
     CicGeom geom_deposit{}, geom_gather{};
     i64 device_bytes = 0;
 };
@@ -107,4 +103,8 @@ int cgk_drift(cg_ctx *c, double *pos, const double *mom, i64 n, double dt_over_m
 int cgk_cic_indices(cg_ctx *c, const double *pos, i64 n, int for_gather, i64 *idx);
 int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst);
 int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
-             double *pos_out, double *mom_out, i64 *ids_out, i64 n);
+             double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out);
+int cgk_deposit_cic_tiled(cg_ctx *c, const double *pos, i64 n, const unsigned *tile_offset,
+                          double contribution, int accumulate);
+int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
+                          const unsigned *tile_offset, int diff_order, double factor);

@@ -70,6 +70,11 @@ int cgk_drift(cg_ctx *c, double *pos, const double *mom, i64 n, double dt_over_m
 // histogram -> exclusive scan (hipCUB) -> scatter.  Order inside a tile is
 // arbitrary (like the reference's tile_sort, particle order is not part of
 // the contract; ids travel with the particles).
+//
+// Device-scope atomics execute memory-side on MI355X and are the scarce
+// resource here, so both passes aggregate per wavefront: lanes holding a run
+// of equal keys (the common case, the array is nearly sorted from the
+// previous step) elect the run's first lane to issue ONE atomic for the run.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ i64 lower_cell(double pos, double off, double scale, int g, i64 N) {
     double x = (pos - off) * scale;
@@ -77,20 +82,42 @@ __device__ __forceinline__ i64 lower_cell(double pos, double off, double scale, 
     a = a < 0 ? a + N : a;
     return a >= N ? a - N : a;
 }
-__device__ __forceinline__ unsigned tile_of(const double *pos3, const CicGeom &geo, int g, i64 N,
-                                            const TileGeom &t) {
-    unsigned a = (unsigned)lower_cell(pos3[0], geo.off[0], geo.scale, g, N) / t.tx;
-    unsigned b = (unsigned)lower_cell(pos3[1], geo.off[1], geo.scale, g, N) / t.ty;
-    unsigned cc = (unsigned)lower_cell(pos3[2], geo.off[2], geo.scale, g, N) / t.tz;
+__device__ __forceinline__ unsigned tile_of(double x, double y, double z, const CicGeom &geo,
+                                            int g, i64 N, const TileGeom &t) {
+    unsigned a = (unsigned)lower_cell(x, geo.off[0], geo.scale, g, N) / (unsigned)t.tx;
+    unsigned b = (unsigned)lower_cell(y, geo.off[1], geo.scale, g, N) / (unsigned)t.ty;
+    unsigned cc = (unsigned)lower_cell(z, geo.off[2], geo.scale, g, N) / (unsigned)t.tz;
     return (a * t.nty + b) * t.ntz + cc;
 }
+
+// For the calling wave (all 64 lanes active): runs of consecutive lanes with
+// equal key.  Returns the first lane of this lane's run and the run length.
+__device__ __forceinline__ void wave_runs(unsigned key, int lane, int &run_start, int &run_len) {
+    unsigned prev = __shfl_up(key, 1);
+    bool head = (lane == 0) || (key != prev);
+    unsigned long long mask = __ballot(head);
+    unsigned long long below = mask & (~0ull >> (63 - lane));  // heads at lanes <= lane
+    run_start = 63 - __clzll(below);
+    unsigned long long above = (lane == 63) ? 0ull : (mask >> (lane + 1));
+    int next = above ? (lane + 1 + (__ffsll((long long)above) - 1)) : 64;
+    run_len = next - run_start;
+}
+
+constexpr unsigned kNoTile = 0xffffffffu;
 
 __global__ __launch_bounds__(256) void k_tile_histogram(const double *__restrict__ pos, i64 n,
                                                         CicGeom geo, int g, i64 N, TileGeom t,
                                                         unsigned *__restrict__ count) {
     i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride)
-        atomicAdd(&count[tile_of(pos + 3 * p, geo, g, N, t)], 1u);
+    int lane = threadIdx.x & 63;
+    for (i64 base = (i64)blockIdx.x * blockDim.x; base < n; base += stride) {
+        i64 p = base + threadIdx.x;
+        unsigned key = kNoTile;
+        if (p < n) key = tile_of(pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], geo, g, N, t);
+        int rs, rl;
+        wave_runs(key, lane, rs, rl);
+        if (lane == rs && key != kNoTile) atomicAdd(&count[key], (unsigned)rl);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_tile_scatter(
@@ -99,33 +126,50 @@ __global__ __launch_bounds__(256) void k_tile_scatter(
     CicGeom geo, int g, i64 N, TileGeom t, const unsigned *__restrict__ offset,
     unsigned *__restrict__ cursor) {
     i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
-        double x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
-        double q[3] = {x, y, z};
-        unsigned tile = tile_of(q, geo, g, N, t);
-        i64 s = (i64)offset[tile] + atomicAdd(&cursor[tile], 1u);
-        pos_out[3 * s] = x;
-        pos_out[3 * s + 1] = y;
-        pos_out[3 * s + 2] = z;
-        mom_out[3 * s] = mom[3 * p];
-        mom_out[3 * s + 1] = mom[3 * p + 1];
-        mom_out[3 * s + 2] = mom[3 * p + 2];
-        if (ids) ids_out[s] = ids[p];
+    int lane = threadIdx.x & 63;
+    for (i64 base = (i64)blockIdx.x * blockDim.x; base < n; base += stride) {
+        i64 p = base + threadIdx.x;
+        unsigned key = kNoTile;
+        double x = 0, y = 0, z = 0;
+        if (p < n) {
+            x = pos[3 * p];
+            y = pos[3 * p + 1];
+            z = pos[3 * p + 2];
+            key = tile_of(x, y, z, geo, g, N, t);
+        }
+        int rs, rl;
+        wave_runs(key, lane, rs, rl);
+        unsigned first = 0;
+        if (lane == rs && key != kNoTile) first = offset[key] + atomicAdd(&cursor[key], (unsigned)rl);
+        first = __shfl(first, rs);
+        if (p < n) {
+            i64 s = (i64)first + (lane - rs);
+            pos_out[3 * s] = x;
+            pos_out[3 * s + 1] = y;
+            pos_out[3 * s + 2] = z;
+            mom_out[3 * s] = mom[3 * p];
+            mom_out[3 * s + 1] = mom[3 * p + 1];
+            mom_out[3 * s + 2] = mom[3 * p + 2];
+            if (ids) ids_out[s] = ids[p];
+        }
     }
 }
 
 int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
-             double *pos_out, double *mom_out, i64 *ids_out, i64 n) {
+             double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out) {
     i64 nt = c->ntiles;
     CG_HIP(hipMemsetAsync(c->tile_count, 0, 4 * (nt + 1), c->stream));
     CG_HIP(hipMemsetAsync(c->tile_cursor, 0, 4 * (nt + 1), c->stream));
     i64 blocks = (n + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k_tile_histogram, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos_in,
-                       n, c->geom_deposit, c->p.nghosts, c->N, c->tiles, c->tile_count);
-    CG_LAUNCH_CHECK();
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_tile_histogram, dim3((unsigned)blocks), dim3(256), 0, c->stream,
+                           pos_in, n, c->geom_deposit, c->p.nghosts, c->N, c->tiles,
+                           c->tile_count);
+        CG_LAUNCH_CHECK();
+    }
     size_t need = 0;
-    CG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, c->tile_count, c->tile_offset,
+    CG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, c->tile_count, tile_offset_out,
                                             (int)(nt + 1), c->stream));
     if (need > c->scan_tmp_bytes) {
         CG_HIP(hipStreamSynchronize(c->stream));
@@ -134,14 +178,13 @@ int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *i
         CG_HIP(hipMalloc(&c->scan_tmp, need));
         c->scan_tmp_bytes = need;
     }
-    CG_HIP(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp, need, c->tile_count, c->tile_offset,
+    CG_HIP(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp, need, c->tile_count, tile_offset_out,
                                             (int)(nt + 1), c->stream));
-    hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos_in,
-                       mom_in, ids_in, pos_out, mom_out, ids_out, n, c->geom_deposit,
-                       c->p.nghosts, c->N, c->tiles, c->tile_offset, c->tile_cursor);
-    CG_LAUNCH_CHECK();
-    c->tiles_valid = true;
-    c->sorted_n = n;
-    c->sorted_pos = pos_out;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos_in,
+                           mom_in, ids_in, pos_out, mom_out, ids_out, n, c->geom_deposit,
+                           c->p.nghosts, c->N, c->tiles, tile_offset_out, c->tile_cursor);
+        CG_LAUNCH_CHECK();
+    }
     return 0;
 }

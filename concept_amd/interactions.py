@@ -98,15 +98,25 @@ def particle_mesh(receivers, suppliers, gridsize_global, quantity, force, method
     deconv_order_global = (int(bool(deconvolve_upstream)) + int(bool(deconvolve_downstream)))
     deconv_order_global *= interpolation_order
     # interpolate_upstream (mesh.py:492-635): nullified grid, every supplier deposited
-    mesh.zero()
+    # Suppliers whose memory is in exact tile order of this mesh (Component.tile_sort)
+    # take the LDS-tiled kernel; the first of them assigns the mesh (no zero-fill pass).
     fft_factor = float(gridsize_global)**(-3)  # mesh.py:582
-    for supplier in suppliers:
+    ordered = sorted(suppliers, key=lambda s: not (s.tiles_exact and s.tile_mesh is mesh))
+    mesh_started = False
+    for supplier in ordered:
         # mesh.py:1550-1573
         contribution = ᔑdt['a**(-3*w_eff-1)', supplier.name]/ᔑdt['1']
         contribution *= supplier.mass
         contribution_factor = fft_factor*(gridsize_global/boxsize)**3
         contribution *= contribution_factor
-        mesh.deposit(supplier.pos, contribution)
+        if supplier.tiles_exact and supplier.tile_mesh is mesh:
+            mesh.deposit_tiled(supplier.pos, supplier.tile_table, contribution,
+                               accumulate=mesh_started)
+        else:
+            if not mesh_started:
+                mesh.zero()
+            mesh.deposit(supplier.pos, contribution)
+        mesh_started = True
     # interactions.py:2092-2118 and :2302
     C = -boxsize**2*p.G_Newton/π
     if potential == 'gravity':
@@ -122,8 +132,13 @@ def particle_mesh(receivers, suppliers, gridsize_global, quantity, force, method
         if differentiation_order == 0:
             raise ConceptGPUError('Fourier-space differentiation (order 0) is not built '
                                   '(SURVEY.md §8f-3)')
-        mesh.gather_kick(receiver.pos, receiver.mom, differentiation_order,
-                         receiver.mass*(-ᔑdt[key]))
+        factor = receiver.mass*(-ᔑdt[key])
+        if receiver.tile_table is not None and receiver.tile_mesh is mesh:
+            # tile order (possibly drifted since the sort: strays are handled)
+            mesh.gather_kick_tiled(receiver.pos, receiver.mom, receiver.tile_table,
+                                   differentiation_order, factor)
+        else:
+            mesh.gather_kick(receiver.pos, receiver.mom, differentiation_order, factor)
 
 
 register('gravity', ['ppnonperiodic', 'pp', 'p3m', 'pm'], 'gravitational')

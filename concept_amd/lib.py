@@ -45,13 +45,16 @@ SYMBOLS = {
     'cg_device_bytes': (_i64, [_vp]),
     'cg_mesh_zero': (_int, [_vp]),
     'cg_deposit_cic': (_int, [_vp, _vp, _i64, _dbl]),
+    'cg_deposit_cic_tiled': (_int, [_vp, _vp, _i64, _vp, _dbl, _int]),
     'cg_poisson_solve': (_int, [_vp, _int, _dbl, _int, _dbl]),
     'cg_poisson_forward': (_int, [_vp, _int, _dbl, _int, _dbl, _int]),
     'cg_poisson_backward': (_int, [_vp]),
     'cg_poisson_kernel': (_int, [_vp, _int, _dbl, _int, _dbl]),
     'cg_gather_kick': (_int, [_vp, _vp, _vp, _i64, _int, _dbl]),
+    'cg_gather_kick_tiled': (_int, [_vp, _vp, _vp, _i64, _vp, _int, _dbl]),
     'cg_drift': (_int, [_vp, _vp, _vp, _i64, _dbl]),
-    'cg_sort_particles': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    'cg_sort_particles': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'cg_tile_info': (_int, [_vp, ctypes.POINTER(ctypes.c_int64*3)]),
     'cg_fetch': (_int, [_vp, _int, _vp, _i64]),
     'cg_cic_indices': (_int, [_vp, _vp, _i64, _int, _vp]),
 }

@@ -41,6 +41,9 @@ class PotentialMesh:
         self._ctx = ctypes.c_void_p()
         check(_L.cg_create(ctypes.byref(p), ctypes.byref(self._ctx)))
         self.use_stream(torch.cuda.current_stream(self.device))
+        info = (ctypes.c_int64*3)()
+        check(_L.cg_tile_info(self._ctx, ctypes.byref(info)))
+        self.tile_extent, self.tiles_per_dim, self.ntiles = int(info[0]), int(info[1]), int(info[2])
 
     def close(self):
         if self._ctx:
@@ -86,6 +89,13 @@ class PotentialMesh:
         n = self._check_particles(pos)
         check(_L.cg_deposit_cic(self._ctx, _ptr(pos), n, float(contribution)))
 
+    def deposit_tiled(self, pos, tile_offset, contribution, accumulate=False):
+        """`pos` must be in exact tile order (sort_particles on this array)."""
+        n = self._check_particles(pos)
+        self._check_table(tile_offset)
+        check(_L.cg_deposit_cic_tiled(self._ctx, _ptr(pos), n, _ptr(tile_offset),
+                                      float(contribution), int(accumulate)))
+
     def poisson_solve(self, deconv_order, C, long_range=False, E=0.0):
         check(_L.cg_poisson_solve(self._ctx, int(deconv_order), float(C), int(long_range),
                                   float(E)))
@@ -106,15 +116,35 @@ class PotentialMesh:
         check(_L.cg_gather_kick(self._ctx, _ptr(pos), _ptr(mom), n, int(diff_order),
                                 float(factor)))
 
+    def gather_kick_tiled(self, pos, mom, tile_offset, diff_order, factor):
+        n = self._check_particles(pos, mom)
+        self._check_table(tile_offset)
+        check(_L.cg_gather_kick_tiled(self._ctx, _ptr(pos), _ptr(mom), n, _ptr(tile_offset),
+                                      int(diff_order), float(factor)))
+
+    def new_tile_table(self):
+        """uint32[ntiles + 1] on the device (stored as int32 bits)."""
+        return torch.zeros(self.ntiles + 1, dtype=torch.int32, device=self.device)
+
+    def _check_table(self, t):
+        if t.dtype != torch.int32 or not t.is_cuda or t.numel() != self.ntiles + 1:
+            raise lib.ConceptGPUError(
+                f'tile table must be a CUDA int32 tensor of {self.ntiles + 1} entries')
+
     def drift(self, pos, mom, dt_over_mass):
         n = self._check_particles(pos, mom)
         check(_L.cg_drift(self._ctx, _ptr(pos), _ptr(mom), n, float(dt_over_mass)))
 
-    def sort_particles(self, pos, mom, ids, pos_out, mom_out, ids_out):
+    def sort_particles(self, pos, mom, ids, pos_out, mom_out, ids_out, tile_offset=None):
         n = self._check_particles(pos, mom, pos_out, mom_out)
+        if tile_offset is None:
+            tile_offset = self.new_tile_table()
+        self._check_table(tile_offset)
         check(_L.cg_sort_particles(
             self._ctx, _ptr(pos), _ptr(mom), _ptr(ids) if ids is not None else None,
-            _ptr(pos_out), _ptr(mom_out), _ptr(ids_out) if ids_out is not None else None, n))
+            _ptr(pos_out), _ptr(mom_out), _ptr(ids_out) if ids_out is not None else None, n,
+            _ptr(tile_offset)))
+        return tile_offset
 
     # -- debug / parity -----------------------------------------------------
     def fetch(self, which):

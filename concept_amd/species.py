@@ -40,6 +40,11 @@ class Component:
         self.Δmom = None  # allocated on first short-range use
         self.ids = torch.arange(self.N, dtype=torch.int64, device=self.device)
         self._scratch = None
+        # tile order bookkeeping: `tile_table` (first particle of each mesh tile) is
+        # exact right after tile_sort() on `tile_mesh`; a drift makes it approximate
+        self.tile_table = None
+        self.tile_mesh = None
+        self.tiles_exact = False
         # rungs: single rung 0 until adaptive rung stepping is built
         self.use_rungs = False
         self.lowest_active_rung = 0
@@ -74,6 +79,9 @@ class Component:
         """populate(array, 'posx'|'posy'|'posz'|'momx'|...) (species.py:1911-1925);
         also accepts var='pos'/'mom' with an (N, 3) array."""
         t = torch.as_tensor(np.ascontiguousarray(np.asarray(data, dtype=np.float64)))
+        if var.startswith('pos'):
+            self.tile_table = None
+            self.tiles_exact = False
         if var in ('pos', 'mom'):
             getattr(self, var).copy_(t.reshape(self.N, 3))
             return
@@ -111,6 +119,7 @@ class Component:
         a**(3*w_eff) = 1 for matter)."""
         Δt_over_mass = ᔑdt['a**(-2)']*a**(3*self.w_eff(a=a))/self.mass
         self._mesh().drift(self.pos, self.mom, Δt_over_mass)
+        self.tiles_exact = False
 
     def tile_sort(self, mesh=None):
         """Reorder particle memory into mesh-tile order (the reference's
@@ -120,9 +129,15 @@ class Component:
             self._scratch = (torch.empty_like(self.pos), torch.empty_like(self.mom),
                              torch.empty_like(self.ids))
         po, mo, io = self._scratch
-        mesh.sort_particles(self.pos, self.mom, self.ids, po, mo, io)
+        if self.tile_table is None or self.tile_mesh is not mesh:
+            self.tile_table = mesh.new_tile_table()
+        mesh.sort_particles(self.pos, self.mom, self.ids, po, mo, io, self.tile_table)
         self._scratch = (self.pos, self.mom, self.ids)
         self.pos, self.mom, self.ids = po, mo, io
+        self.tile_mesh = mesh
+        self.tiles_exact = True
+        if self.Δmom is not None:
+            self.Δmom = None  # order changed; short-range buffers are rebuilt on use
 
     def nullify_Δ(self, specifically=None, only_active=True):
         if specifically is None:

@@ -81,6 +81,15 @@ int64_t cg_device_bytes(const cg_ctx *ctx);
  * communication.py:563-660) is the periodic wrap and is fused here. */
 int cg_mesh_zero(cg_ctx *ctx);
 int cg_deposit_cic(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, double contribution);
+/* Same deposit for particles in tile order (cg_sort_particles on exactly this
+ * `pos`): one workgroup per mesh tile accumulates its particles in an LDS tile
+ * and writes it out once.  accumulate = 0: the mesh needs no prior
+ * cg_mesh_zero (tile interiors are assigned, tile faces are zeroed here and
+ * summed with atomics); accumulate = 1: added onto the existing mesh
+ * (second and later suppliers of interpolate_upstream, mesh.py:604-608). */
+int cg_deposit_cic_tiled(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n,
+                         const uint32_t *tile_offset /*DEV ntiles+1*/, double contribution,
+                         int accumulate);
 
 /* --- A3..A8: Poisson solve, in place on the context's mesh -----------------
  * slab_decompose + fft('forward') + nullify_modes('nyquist') (mesh.py:665-672,
@@ -108,6 +117,12 @@ int cg_poisson_kernel(cg_ctx *ctx, int deconv_order, double C, int long_range, d
  * (same expression, same order as the reference's force grid cell). */
 int cg_gather_kick(cg_ctx *ctx, const double *pos /*DEV 3n*/, double *mom /*DEV 3n*/, int64_t n,
                    int diff_order, double factor);
+/* Same, for particles in tile order: the potential tile (+ stencil halo) is
+ * staged in LDS once per workgroup.  Particles that have left their tile since
+ * the sort are still handled (straight from the mesh). */
+int cg_gather_kick_tiled(cg_ctx *ctx, const double *pos /*DEV 3n*/, double *mom /*DEV 3n*/,
+                         int64_t n, const uint32_t *tile_offset /*DEV ntiles+1*/, int diff_order,
+                         double factor);
 
 /* --- A11: drift ------------------------------------------------------------
  * Component.drift (species.py:2179-2199): pos = mod(pos + mom*dt_over_mass, boxsize)
@@ -122,7 +137,13 @@ int cg_drift(cg_ctx *ctx, double *pos /*DEV 3n*/, const double *mom /*DEV 3n*/, 
  * are owned by the caller: pos_out/mom_out/ids_out must not alias the inputs. */
 int cg_sort_particles(cg_ctx *ctx, const double *pos_in, const double *mom_in,
                       const int64_t *ids_in /*nullable*/, double *pos_out, double *mom_out,
-                      int64_t *ids_out /*nullable*/, int64_t n);
+                      int64_t *ids_out /*nullable*/, int64_t n,
+                      uint32_t *tile_offset_out /*DEV ntiles+1: first particle of each tile*/);
+/* info[0] = tile extent in cells (cubic), info[1] = tiles per dimension,
+ * info[2] = number of tiles.  Tile t = (ta*nt + tb)*nt + tc holds the particles
+ * whose lower CIC cell (set_weights_CIC index - nghosts, wrapped) lies in
+ * [ta*T, ta*T+T) x [tb*T, ...) x [tc*T, ...). */
+int cg_tile_info(const cg_ctx *ctx, int64_t info[3]);
 
 /* --- debug fetch (parity tests) -------------------------------------------- */
 int cg_fetch(cg_ctx *ctx, int which, double *out /*HOST*/, int64_t n_doubles);
