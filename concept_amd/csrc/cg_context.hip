@@ -39,15 +39,18 @@ static int make_plans(cg_ctx *c) {
     // both ways (mesh.py:4015-4022).  rocFFT lengths are fastest-first.
     const size_t N = (size_t)c->N;
     size_t lengths[3] = {N, N, N};
-    size_t rstr[3] = {1, N + 2, (N + 2) * N};
-    size_t cstr[3] = {1, N / 2 + 1, (N / 2 + 1) * N};
+    // row pitch c->pad >= N + 2 doubles (a multiple of 16 doubles when N is, so that
+    // rows and 16-cell tile rows start on 128-byte lines)
+    const size_t P = (size_t)c->pad;
+    size_t rstr[3] = {1, P, P * N};
+    size_t cstr[3] = {1, P / 2, (P / 2) * N};
     size_t off[1] = {0};
     rocfft_plan_description d = nullptr;
     CG_FFT(rocfft_plan_description_create(&d));
     CG_FFT(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real,
                                                    rocfft_array_type_hermitian_interleaved, off,
-                                                   off, 3, rstr, (N + 2) * N * N, 3, cstr,
-                                                   (N / 2 + 1) * N * N));
+                                                   off, 3, rstr, P * N * N, 3, cstr,
+                                                   (P / 2) * N * N));
     CG_FFT(rocfft_plan_create(&c->plan_fwd, rocfft_placement_inplace,
                               rocfft_transform_type_real_forward, rocfft_precision_double, 3,
                               lengths, 1, d));
@@ -55,8 +58,7 @@ static int make_plans(cg_ctx *c) {
     CG_FFT(rocfft_plan_description_create(&d));
     CG_FFT(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved,
                                                    rocfft_array_type_real, off, off, 3, cstr,
-                                                   (N / 2 + 1) * N * N, 3, rstr,
-                                                   (N + 2) * N * N));
+                                                   (P / 2) * N * N, 3, rstr, P * N * N));
     CG_FFT(rocfft_plan_create(&c->plan_bwd, rocfft_placement_inplace,
                               rocfft_transform_type_real_inverse, rocfft_precision_double, 3,
                               lengths, 1, d));
@@ -102,7 +104,7 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
     cg_ctx *c = new cg_ctx();
     c->p = *p;
     c->N = p->gridsize;
-    c->pad = c->N + 2;
+    c->pad = (c->N % 16 == 0) ? c->N + 16 : c->N + 2;
     c->mesh_doubles = c->N * c->N * c->pad;
     auto fail = [&]() {
         cg_destroy(c);
@@ -150,12 +152,14 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
         }
         c->tiles = {t, t, t, (int)(c->N / t), (int)(c->N / t), (int)(c->N / t)};
         c->ntiles = (i64)c->tiles.ntx * c->tiles.nty * c->tiles.ntz;
-        if (hipMalloc(&c->tile_count, 4 * (c->ntiles + 1)) != hipSuccess ||
-            hipMalloc(&c->tile_cursor, 4 * (c->ntiles + 1)) != hipSuccess) {
+        // 8 buckets per tile (which of the +x/+y/+z neighbour tiles a particle's CIC
+        // cloud reaches), see cg_particles.hip
+        if (hipMalloc(&c->tile_count, 4 * (8 * c->ntiles + 1)) != hipSuccess ||
+            hipMalloc(&c->tile_cursor, 4 * (8 * c->ntiles + 1)) != hipSuccess) {
             cg_set_error("cg_create: tile table allocation failed");
             return fail();
         }
-        c->device_bytes += 8 * (c->ntiles + 1);
+        c->device_bytes += 8 * (8 * c->ntiles + 1);
     }
     if (make_plans(c)) return fail();
     *out = c;
@@ -262,7 +266,7 @@ extern "C" int cg_tile_info(const cg_ctx *c, int64_t info[3]) {
     CG_CHECK(c && info, "cg_tile_info: null argument");
     info[0] = c->tiles.tx;
     info[1] = c->tiles.ntx;
-    info[2] = c->ntiles;
+    info[2] = 8 * c->ntiles + 1;
     return 0;
 }
 
@@ -306,18 +310,21 @@ extern "C" int cg_cic_indices(cg_ctx *c, const double *pos, int64_t n, int for_g
 
 extern "C" int cg_fetch(cg_ctx *c, int which, double *out, int64_t n_doubles) {
     CG_CHECK(c && out, "cg_fetch: null argument");
-    CG_CHECK(n_doubles == c->mesh_doubles, "cg_fetch: expected %lld doubles, got %lld",
-             (long long)c->mesh_doubles, (long long)n_doubles);
+    const i64 ref_doubles = c->N * c->N * (c->N + 2);  // the reference's slab shape
+    CG_CHECK(n_doubles == ref_doubles, "cg_fetch: expected %lld doubles, got %lld",
+             (long long)ref_doubles, (long long)n_doubles);
+    const size_t row = 8 * (size_t)(c->N + 2);
     if (which == CG_FETCH_MESH_REAL) {
         CG_HIP(hipStreamSynchronize(c->stream));
-        CG_HIP(hipMemcpy(out, c->mesh, 8 * c->mesh_doubles, hipMemcpyDeviceToHost));
+        CG_HIP(hipMemcpy2D(out, row, c->mesh, 8 * (size_t)c->pad, row, (size_t)(c->N * c->N),
+                           hipMemcpyDeviceToHost));
         return 0;
     }
     if (which == CG_FETCH_MESH_FOURIER) {
-        if (!c->fetch_tmp) CG_HIP(hipMalloc(&c->fetch_tmp, 8 * c->mesh_doubles));
+        if (!c->fetch_tmp) CG_HIP(hipMalloc(&c->fetch_tmp, 8 * ref_doubles));
         if (cgk_transpose_fourier(c, c->mesh, c->fetch_tmp)) return 1;
         CG_HIP(hipStreamSynchronize(c->stream));
-        CG_HIP(hipMemcpy(out, c->fetch_tmp, 8 * c->mesh_doubles, hipMemcpyDeviceToHost));
+        CG_HIP(hipMemcpy(out, c->fetch_tmp, 8 * ref_doubles, hipMemcpyDeviceToHost));
         return 0;
     }
     cg_set_error("cg_fetch: unknown selector %d", which);

@@ -90,7 +90,7 @@ int cgk_deposit_cic(cg_ctx *c, const double *pos, i64 n, double contribution) {
 //   nullify_modes('origin')   interactions.py:2118
 // One lane per complex mode (16 B load + 16 B store, coalesced along kk).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_kspace(double2 *__restrict__ slab, i64 N,
+__global__ __launch_bounds__(256) void k_kspace(double2 *__restrict__ slab, i64 N, i64 pitch,
                                                 const double *__restrict__ tab_n,
                                                 const double *__restrict__ tab_s, int deconv_order,
                                                 double C, int long_range, double E) {
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_kspace(double2 *__restrict__ slab, i64 
     double dij_n = ni * nj;  // mesh.py:2797
     double dij_d = si * sj;  // mesh.py:2798
     i64 kij2 = kj * kj + ki * ki;  // interactions.py:2096
-    double2 *r = slab + row * nk;
+    double2 *r = slab + row * pitch;
     for (i64 kk = threadIdx.x; kk < nk; kk += blockDim.x) {
         double2 v;
         if (row_nyq || kk == nyq || (kij2 == 0 && kk == 0)) {
@@ -133,24 +133,24 @@ int cgk_kspace(cg_ctx *c, int deconv_order, double C, int long_range, double E) 
     i64 rows = c->N * c->N;
     int block = c->N / 2 + 1 >= 256 ? 256 : (c->N / 2 + 1 > 64 ? 128 : 64);
     hipLaunchKernelGGL(k_kspace, dim3((unsigned)rows), dim3(block), 0, c->stream,
-                       (double2 *)c->mesh, c->N, c->ktab_n, c->ktab_s, deconv_order, C, long_range,
-                       E);
+                       (double2 *)c->mesh, c->N, c->pad / 2, c->ktab_n, c->ktab_s, deconv_order, C,
+                       long_range, E);
     CG_LAUNCH_CHECK();
     return 0;
 }
 
 // complex[i][j][kk] -> the reference's transposed double[j][i][N+2] (debug fetch)
 __global__ void k_transpose_fourier(const double2 *__restrict__ src, double2 *__restrict__ dst,
-                                    i64 N) {
+                                    i64 N, i64 pitch) {
     i64 nk = N / 2 + 1;
     i64 row = blockIdx.x;
     i64 i = row / N, j = row - i * N;
     for (i64 kk = threadIdx.x; kk < nk; kk += blockDim.x)
-        dst[(j * N + i) * nk + kk] = src[(i * N + j) * nk + kk];
+        dst[(j * N + i) * nk + kk] = src[(i * N + j) * pitch + kk];
 }
 int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst) {
     hipLaunchKernelGGL(k_transpose_fourier, dim3((unsigned)(c->N * c->N)), dim3(64), 0, c->stream,
-                       (const double2 *)src, (double2 *)dst, c->N);
+                       (const double2 *)src, (double2 *)dst, c->N, c->pad / 2);
     CG_LAUNCH_CHECK();
     return 0;
 }

@@ -82,12 +82,20 @@ __device__ __forceinline__ i64 lower_cell(double pos, double off, double scale, 
     a = a < 0 ? a + N : a;
     return a >= N ? a - N : a;
 }
+// key = 8*tile + bucket; bucket bit d is set when the lower cell is the last of
+// the tile in dimension d, i.e. the CIC cloud reaches the next tile there
+// (bit 2: x, bit 1: y, bit 0: z).  The pull-deposit of a tile reads its own 8
+// buckets plus the matching boundary buckets of its 7 lower neighbours.
 __device__ __forceinline__ unsigned tile_of(double x, double y, double z, const CicGeom &geo,
                                             int g, i64 N, const TileGeom &t) {
-    unsigned a = (unsigned)lower_cell(x, geo.off[0], geo.scale, g, N) / (unsigned)t.tx;
-    unsigned b = (unsigned)lower_cell(y, geo.off[1], geo.scale, g, N) / (unsigned)t.ty;
-    unsigned cc = (unsigned)lower_cell(z, geo.off[2], geo.scale, g, N) / (unsigned)t.tz;
-    return (a * t.nty + b) * t.ntz + cc;
+    unsigned ca = (unsigned)lower_cell(x, geo.off[0], geo.scale, g, N);
+    unsigned cb = (unsigned)lower_cell(y, geo.off[1], geo.scale, g, N);
+    unsigned cc = (unsigned)lower_cell(z, geo.off[2], geo.scale, g, N);
+    unsigned T = (unsigned)t.tx;
+    unsigned a = ca / T, b = cb / T, c = cc / T;
+    unsigned f = ((ca - a * T == T - 1) ? 4u : 0u) | ((cb - b * T == T - 1) ? 2u : 0u) |
+                 ((cc - c * T == T - 1) ? 1u : 0u);
+    return ((a * t.nty + b) * t.ntz + c) * 8u + f;
 }
 
 // For the calling wave (all 64 lanes active): runs of consecutive lanes with
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256) void k_tile_scatter(
 
 int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
              double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out) {
-    i64 nt = c->ntiles;
+    i64 nt = 8 * c->ntiles;  // table entries (8 buckets per tile)
     CG_HIP(hipMemsetAsync(c->tile_count, 0, 4 * (nt + 1), c->stream));
     CG_HIP(hipMemsetAsync(c->tile_cursor, 0, 4 * (nt + 1), c->stream));
     i64 blocks = (n + 255) / 256;

@@ -3,12 +3,11 @@
 // order (cg_sort_particles).  One 256-lane workgroup per T^3-cell tile.
 //
 // Why tiles: on MI355X device-scope FP64 atomics execute memory-side, one
-// fabric transaction per lane (measured: 2^31 direct atomic adds = 77 ms at
-// 2^28 particles).  Accumulating a tile in LDS (ds_add_f64) and writing it
-// out once turns the scatter into a streaming store of the mesh: tile
-// interiors are exclusively owned by one workgroup and are ASSIGNED with
-// plain stores (no zero-fill pass), only the tile faces — the cells that also
-// receive the neighbouring tiles' halo layer — are summed with atomics.
+// fabric transaction per lane (measured at 2^28 particles / 1024^3: 2^31
+// direct atomic adds = 77 ms; LDS tiles with atomics only on the tile faces
+// = 28 ms).  The deposit therefore uses no global atomics at all: each
+// workgroup accumulates everything its tile receives in LDS (ds_add_f64) and
+// stores the tile once.
 //
 // Arithmetic per particle and per cell is the reference's (see
 // cg_mesh_kernels.hip); only the order in which particles are added to a
@@ -52,101 +51,103 @@ __device__ __forceinline__ unsigned tile_for_block(unsigned b, unsigned ntiles) 
 }
 
 // ---------------------------------------------------------------------------
-// zero the tile faces (planes i, j or k = 0 mod T) ahead of an assigning deposit
-// ---------------------------------------------------------------------------
-__global__ void k_zero_tile_faces(double *__restrict__ mesh, i64 N, i64 pad, int T) {
-    i64 row = blockIdx.x;
-    i64 i = row / N, j = row - i * N;
-    double *r = mesh + row * pad;
-    if (i % T == 0 || j % T == 0) {
-        for (i64 k = threadIdx.x; k < N; k += blockDim.x) r[k] = 0;
-    } else {
-        for (i64 k = (i64)threadIdx.x * T; k < N; k += (i64)blockDim.x * T) r[k] = 0;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// tiled deposit
+// tiled deposit, owner-computes ("pull") form
+//
+// Workgroup of tile t accumulates in LDS every contribution to the T^3 cells
+// it owns: from its own particles (all 8 buckets) and from the particles of
+// its 7 lower neighbour tiles whose CIC cloud reaches into t — exactly the
+// buckets f of neighbour d (d = which dimensions step back one tile) with
+// (f & d) == d, found through the tile table without touching other
+// particles.  Then the tile is written once with plain, line-aligned stores:
+// no global atomics, no zero-fill pass, ~1.2x particle reads (the boundary
+// buckets are re-read from L2 by the neighbour).
 // ---------------------------------------------------------------------------
 template <int T, bool ACCUMULATE>
-__global__ __launch_bounds__(256) void k_deposit_cic_tiled(
-    const double *__restrict__ pos, const unsigned *__restrict__ tile_offset,
+__global__ __launch_bounds__(512) void k_deposit_cic_pull(
+    const double *__restrict__ pos, const unsigned *__restrict__ table,
     double *__restrict__ mesh, i64 N, i64 pad, int g, int nt, unsigned ntiles, CicGeom geo,
     double contribution) {
-    constexpr int E = T + 1;
-    constexpr int NL = E * E * E;
+    constexpr int NL = T * T * T;
     __shared__ double lds[NL];
+    __shared__ unsigned seg_beg[64], seg_end_prefix[65];
     const unsigned tile = tile_for_block(blockIdx.x, ntiles);
     const int tc = tile % nt, tb = (tile / nt) % nt, ta = tile / (nt * nt);
     const i64 T0a = (i64)ta * T, T0b = (i64)tb * T, T0c = (i64)tc * T;
-    for (int idx = threadIdx.x; idx < NL; idx += 256) lds[idx] = 0;
+    for (int idx = threadIdx.x; idx < NL; idx += 512) lds[idx] = 0;
+    if (threadIdx.x < 64) {
+        // segment (d, f): bucket f of the neighbour d steps back
+        int d = threadIdx.x >> 3, f = threadIdx.x & 7;
+        int na = ta - ((d >> 2) & 1), nb = tb - ((d >> 1) & 1), nc = tc - (d & 1);
+        na = na < 0 ? na + nt : na;
+        nb = nb < 0 ? nb + nt : nb;
+        nc = nc < 0 ? nc + nt : nc;
+        unsigned e = ((unsigned)((na * nt + nb) * nt + nc)) * 8u + (unsigned)f;
+        unsigned b0 = table[e], cnt = ((f & d) == d) ? table[e + 1] - b0 : 0u;
+        // inclusive scan of cnt over the 64 lanes of this (first) wave
+        unsigned incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned v = __shfl_up(incl, o);
+            if ((int)threadIdx.x >= o) incl += v;
+        }
+        seg_beg[threadIdx.x] = b0;
+        seg_end_prefix[threadIdx.x + 1] = incl;
+        if (threadIdx.x == 0) seg_end_prefix[0] = 0;
+    }
     __syncthreads();
-    const i64 beg = tile_offset[tile], end = tile_offset[tile + 1];
-    for (i64 p = beg + threadIdx.x; p < end; p += 256) {
+    const unsigned total = seg_end_prefix[64];
+    for (unsigned q = threadIdx.x; q < total; q += 512) {
+        // segment of flat index q: largest s with prefix[s] <= q
+        int s = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+            if (seg_end_prefix[s + step] <= q) s += step;
+        const i64 p = (i64)seg_beg[s] + (q - seg_end_prefix[s]);
         Cic1 cx = cic1(pos[3 * p + 0], geo.off[0], geo.scale);
         Cic1 cy = cic1(pos[3 * p + 1], geo.off[1], geo.scale);
         Cic1 cz = cic1(pos[3 * p + 2], geo.off[2], geo.scale);
         // mesh.py:5142-5155: ((w_x*contribution)*w_y)*w_z
-        double wi0 = cx.w0 * contribution, wi1 = cx.w1 * contribution;
-        double w00 = wi0 * cy.w0, w01 = wi0 * cy.w1, w10 = wi1 * cy.w0, w11 = wi1 * cy.w1;
-        i64 ga = wrap(cx.index - g, N), gb = wrap(cy.index - g, N), gc = wrap(cz.index - g, N);
-        i64 la = ga - T0a, lb = gb - T0b, lc = gc - T0c;
-        if (la >= 0 && la < T && lb >= 0 && lb < T && lc >= 0 && lc < T) {
-            double *l = lds + (la * E + lb) * E + lc;
-            atomicAdd(l, w00 * cz.w0);
-            atomicAdd(l + 1, w00 * cz.w1);
-            atomicAdd(l + E, w01 * cz.w0);
-            atomicAdd(l + E + 1, w01 * cz.w1);
-            atomicAdd(l + E * E, w10 * cz.w0);
-            atomicAdd(l + E * E + 1, w10 * cz.w1);
-            atomicAdd(l + E * E + E, w11 * cz.w0);
-            atomicAdd(l + E * E + E + 1, w11 * cz.w1);
-        } else if (ACCUMULATE) {
-            // a particle outside its tile (array drifted since the sort): still correct
-            // when every cell is summed atomically
-            i64 a1 = wrap(ga + 1, N), b1 = wrap(gb + 1, N), c1 = wrap(gc + 1, N);
-            double *r00 = mesh + (ga * N + gb) * pad, *r01 = mesh + (ga * N + b1) * pad;
-            double *r10 = mesh + (a1 * N + gb) * pad, *r11 = mesh + (a1 * N + b1) * pad;
-            unsafeAtomicAdd(r00 + gc, w00 * cz.w0);
-            unsafeAtomicAdd(r00 + c1, w00 * cz.w1);
-            unsafeAtomicAdd(r01 + gc, w01 * cz.w0);
-            unsafeAtomicAdd(r01 + c1, w01 * cz.w1);
-            unsafeAtomicAdd(r10 + gc, w10 * cz.w0);
-            unsafeAtomicAdd(r10 + c1, w10 * cz.w1);
-            unsafeAtomicAdd(r11 + gc, w11 * cz.w0);
-            unsafeAtomicAdd(r11 + c1, w11 * cz.w1);
-        }
-        // (assign mode requires exact tile order: cg_sort_particles on this array)
+        double wi[2] = {cx.w0 * contribution, cx.w1 * contribution};
+        double wy[2] = {cy.w0, cy.w1}, wz[2] = {cz.w0, cz.w1};
+        // lower cell relative to this tile: -1 .. T-1 (periodic)
+        i64 la = wrap(cx.index - g, N) - T0a, lb = wrap(cy.index - g, N) - T0b,
+            lc = wrap(cz.index - g, N) - T0c;
+        la = la >= T ? la - N : la;
+        lb = lb >= T ? lb - N : lb;
+        lc = lc >= T ? lc - N : lc;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                double wij = wi[i] * wy[j];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    i64 a = la + i, b = lb + j, c = lc + k;
+                    if (a >= 0 && a < T && b >= 0 && b < T && c >= 0 && c < T)
+                        atomicAdd(&lds[(a * T + b) * T + c], wij * wz[k]);
+                }
+            }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < NL; idx += 256) {
-        int c = idx % E, b = (idx / E) % E, a = idx / (E * E);
-        double v = lds[idx];
-        i64 gi = T0a + a, gj = T0b + b, gk = T0c + c;
-        gi = gi >= N ? gi - N : gi;
-        gj = gj >= N ? gj - N : gj;
-        gk = gk >= N ? gk - N : gk;
-        double *dst = mesh + (gi * N + gj) * pad + gk;
-        bool face = (a == 0) | (a == T) | (b == 0) | (b == T) | (c == 0) | (c == T);
-        if (ACCUMULATE || face) {
-            if (v != 0) unsafeAtomicAdd(dst, v);
-        } else {
-            *dst = v;
-        }
+    for (int idx = threadIdx.x; idx < NL; idx += 512) {
+        int c = idx % T, b = (idx / T) % T, a = idx / (T * T);
+        double *dst = mesh + ((T0a + a) * N + (T0b + b)) * pad + (T0c + c);
+        if (ACCUMULATE) *dst += lds[idx];  // cells are exclusively owned: no atomics needed
+        else *dst = lds[idx];
     }
 }
 
 template <int T>
-static int launch_deposit(cg_ctx *c, const double *pos, const unsigned *tile_offset,
+static int launch_deposit(cg_ctx *c, const double *pos, const unsigned *table,
                           double contribution, int accumulate) {
     unsigned nt = (unsigned)c->ntiles;
     if (accumulate)
-        hipLaunchKernelGGL((k_deposit_cic_tiled<T, true>), dim3(nt), dim3(256), 0, c->stream, pos,
-                           tile_offset, c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.ntx, nt,
+        hipLaunchKernelGGL((k_deposit_cic_pull<T, true>), dim3(nt), dim3(512), 0, c->stream, pos,
+                           table, c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.ntx, nt,
                            c->geom_deposit, contribution);
     else
-        hipLaunchKernelGGL((k_deposit_cic_tiled<T, false>), dim3(nt), dim3(256), 0, c->stream, pos,
-                           tile_offset, c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.ntx, nt,
+        hipLaunchKernelGGL((k_deposit_cic_pull<T, false>), dim3(nt), dim3(512), 0, c->stream, pos,
+                           table, c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.ntx, nt,
                            c->geom_deposit, contribution);
     return 0;
 }
@@ -155,11 +156,6 @@ int cgk_deposit_cic_tiled(cg_ctx *c, const double *pos, i64 n, const unsigned *t
                           double contribution, int accumulate) {
     (void)n;
     const int T = c->tiles.tx;
-    if (!accumulate) {
-        hipLaunchKernelGGL(k_zero_tile_faces, dim3((unsigned)(c->N * c->N)), dim3(64), 0,
-                           c->stream, c->mesh, c->N, c->pad, T);
-        CG_LAUNCH_CHECK();
-    }
     switch (T) {
         case 16: launch_deposit<16>(c, pos, tile_offset, contribution, accumulate); break;
         case 8: launch_deposit<8>(c, pos, tile_offset, contribution, accumulate); break;
@@ -192,7 +188,7 @@ __device__ __forceinline__ void force_cell(const P &phi, double c1, double c2, d
 }
 
 template <int ORDER, int T>
-__global__ __launch_bounds__(256) void k_gather_kick_tiled(
+__global__ __launch_bounds__(512) void k_gather_kick_tiled(
     const double *__restrict__ pos, double *__restrict__ mom,
     const unsigned *__restrict__ tile_offset, const double *__restrict__ mesh, i64 N, i64 pad,
     int g, int nt, unsigned ntiles, CicGeom geo, double c1, double c2, double factor) {
@@ -201,17 +197,33 @@ __global__ __launch_bounds__(256) void k_gather_kick_tiled(
     constexpr int NL = E * E * E;
     extern __shared__ double lds[];
     const unsigned tile = tile_for_block(blockIdx.x, ntiles);
-    const i64 beg = tile_offset[tile], end = tile_offset[tile + 1];
+    const i64 beg = tile_offset[8 * tile], end = tile_offset[8 * tile + 8];
     if (beg == end) return;  // uniform for the workgroup
     const int tc = tile % nt, tb = (tile / nt) % nt, ta = tile / (nt * nt);
     const i64 T0a = (i64)ta * T, T0b = (i64)tb * T, T0c = (i64)tc * T;
-    for (int idx = threadIdx.x; idx < NL; idx += 256) {
-        int c = idx % E, b = (idx / E) % E, a = idx / (E * E);
-        i64 gi = wrap(T0a - H + a, N), gj = wrap(T0b - H + b, N), gk = wrap(T0c - H + c, N);
-        lds[idx] = mesh[(gi * N + gj) * pad + gk];
+    {
+        // stage the potential tile + stencil halo: all loads of a lane issued before
+        // the first LDS store, so they overlap instead of paying HBM latency serially
+        constexpr int PER = (NL + 511) / 512;
+        double v[PER];
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            int idx = threadIdx.x + r * 512;
+            if (idx < NL) {
+                int c = idx % E, b = (idx / E) % E, a = idx / (E * E);
+                i64 gi = wrap(T0a - H + a, N), gj = wrap(T0b - H + b, N),
+                    gk = wrap(T0c - H + c, N);
+                v[r] = mesh[(gi * N + gj) * pad + gk];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            int idx = threadIdx.x + r * 512;
+            if (idx < NL) lds[idx] = v[r];
+        }
     }
     __syncthreads();
-    for (i64 p = beg + threadIdx.x; p < end; p += 256) {
+    for (i64 p = beg + threadIdx.x; p < end; p += 512) {
         Cic1 cx = cic1(pos[3 * p + 0], geo.off[0], geo.scale);
         Cic1 cy = cic1(pos[3 * p + 1], geo.off[1], geo.scale);
         Cic1 cz = cic1(pos[3 * p + 2], geo.off[2], geo.scale);
@@ -293,7 +305,7 @@ static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsign
         attr_set = true;
     }
     unsigned nt = (unsigned)c->ntiles;
-    hipLaunchKernelGGL(kern, dim3(nt), dim3(256), lds, c->stream, pos, mom, tile_offset, c->mesh,
+    hipLaunchKernelGGL(kern, dim3(nt), dim3(512), lds, c->stream, pos, mom, tile_offset, c->mesh,
                        c->N, c->pad, c->p.nghosts, c->tiles.ntx, nt, c->geom_gather, c1, c2,
                        factor);
     return 0;

@@ -43,7 +43,9 @@ class PotentialMesh:
         self.use_stream(torch.cuda.current_stream(self.device))
         info = (ctypes.c_int64*3)()
         check(_L.cg_tile_info(self._ctx, ctypes.byref(info)))
-        self.tile_extent, self.tiles_per_dim, self.ntiles = int(info[0]), int(info[1]), int(info[2])
+        self.tile_extent, self.tiles_per_dim, self.table_entries = (
+            int(info[0]), int(info[1]), int(info[2]))
+        self.ntiles = self.tiles_per_dim**3
 
     def close(self):
         if self._ctx:
@@ -123,13 +125,14 @@ class PotentialMesh:
                                       int(diff_order), float(factor)))
 
     def new_tile_table(self):
-        """uint32[ntiles + 1] on the device (stored as int32 bits)."""
-        return torch.zeros(self.ntiles + 1, dtype=torch.int32, device=self.device)
+        """uint32[8*ntiles + 1] on the device (stored as int32 bits): first particle
+        of each (tile, bucket), see include/concept_gpu.h cg_tile_info."""
+        return torch.zeros(self.table_entries, dtype=torch.int32, device=self.device)
 
     def _check_table(self, t):
-        if t.dtype != torch.int32 or not t.is_cuda or t.numel() != self.ntiles + 1:
+        if t.dtype != torch.int32 or not t.is_cuda or t.numel() != self.table_entries:
             raise lib.ConceptGPUError(
-                f'tile table must be a CUDA int32 tensor of {self.ntiles + 1} entries')
+                f'tile table must be a CUDA int32 tensor of {self.table_entries} entries')
 
     def drift(self, pos, mom, dt_over_mass):
         n = self._check_particles(pos, mom)

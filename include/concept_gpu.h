@@ -82,13 +82,14 @@ int64_t cg_device_bytes(const cg_ctx *ctx);
 int cg_mesh_zero(cg_ctx *ctx);
 int cg_deposit_cic(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, double contribution);
 /* Same deposit for particles in tile order (cg_sort_particles on exactly this
- * `pos`): one workgroup per mesh tile accumulates its particles in an LDS tile
- * and writes it out once.  accumulate = 0: the mesh needs no prior
- * cg_mesh_zero (tile interiors are assigned, tile faces are zeroed here and
- * summed with atomics); accumulate = 1: added onto the existing mesh
- * (second and later suppliers of interpolate_upstream, mesh.py:604-608). */
+ * `pos`): one workgroup per mesh tile accumulates, in LDS, its own particles
+ * and the boundary buckets of its 7 lower neighbour tiles, then writes the tile
+ * once with plain stores (no global atomics, no zero-fill pass).
+ * accumulate = 0: the mesh is assigned (no prior cg_mesh_zero needed);
+ * accumulate = 1: added onto the existing mesh (second and later suppliers of
+ * interpolate_upstream, mesh.py:604-608). */
 int cg_deposit_cic_tiled(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n,
-                         const uint32_t *tile_offset /*DEV ntiles+1*/, double contribution,
+                         const uint32_t *tile_offset /*DEV tile table*/, double contribution,
                          int accumulate);
 
 /* --- A3..A8: Poisson solve, in place on the context's mesh -----------------
@@ -121,7 +122,7 @@ int cg_gather_kick(cg_ctx *ctx, const double *pos /*DEV 3n*/, double *mom /*DEV 
  * staged in LDS once per workgroup.  Particles that have left their tile since
  * the sort are still handled (straight from the mesh). */
 int cg_gather_kick_tiled(cg_ctx *ctx, const double *pos /*DEV 3n*/, double *mom /*DEV 3n*/,
-                         int64_t n, const uint32_t *tile_offset /*DEV ntiles+1*/, int diff_order,
+                         int64_t n, const uint32_t *tile_offset /*DEV tile table*/, int diff_order,
                          double factor);
 
 /* --- A11: drift ------------------------------------------------------------
@@ -138,11 +139,15 @@ int cg_drift(cg_ctx *ctx, double *pos /*DEV 3n*/, const double *mom /*DEV 3n*/, 
 int cg_sort_particles(cg_ctx *ctx, const double *pos_in, const double *mom_in,
                       const int64_t *ids_in /*nullable*/, double *pos_out, double *mom_out,
                       int64_t *ids_out /*nullable*/, int64_t n,
-                      uint32_t *tile_offset_out /*DEV ntiles+1: first particle of each tile*/);
-/* info[0] = tile extent in cells (cubic), info[1] = tiles per dimension,
- * info[2] = number of tiles.  Tile t = (ta*nt + tb)*nt + tc holds the particles
- * whose lower CIC cell (set_weights_CIC index - nghosts, wrapped) lies in
- * [ta*T, ta*T+T) x [tb*T, ...) x [tc*T, ...). */
+                      uint32_t *tile_offset_out /*DEV 8*ntiles+1, see cg_tile_info*/);
+/* info[0] = tile extent T in cells (cubic), info[1] = tiles per dimension nt,
+ * info[2] = number of entries of a tile table (8*nt^3 + 1).  Tile
+ * t = (ta*nt + tb)*nt + tc holds the particles whose lower CIC cell
+ * (set_weights_CIC index - nghosts, wrapped) lies in
+ * [ta*T, ta*T+T) x [tb*T, ...) x [tc*T, ...); inside a tile particles are grouped
+ * in 8 buckets f = 4*fx + 2*fy + fz, f? = 1 when that lower cell is the tile's last
+ * in that dimension (the CIC cloud then reaches the next tile).  Table entry
+ * 8*t + f = index of the first particle of bucket f of tile t. */
 int cg_tile_info(const cg_ctx *ctx, int64_t info[3]);
 
 /* --- debug fetch (parity tests) -------------------------------------------- */

@@ -176,10 +176,16 @@ def test_tile_sort_is_a_permutation_in_tile_order(torch_cuda):
     idx = np.mod(idx, N)//T
     key = (idx[:, 0]*nt + idx[:, 1])*nt + idx[:, 2]
     assert (np.diff(key) >= 0).all()
-    # the tile table is the exclusive scan of the tile populations
+    # the tile table (8 buckets per tile) is the exclusive scan of the populations
     tab = table.cpu().numpy().astype(np.int64)
     counts = np.bincount(key, minlength=mesh.ntiles)
-    assert np.array_equal(tab, np.concatenate([[0], np.cumsum(counts)]))
+    assert np.array_equal(tab[::8], np.concatenate([[0], np.cumsum(counts)]))
+    assert (np.diff(tab) >= 0).all() and tab[-1] == n
+    # bucket f = 4*fx + 2*fy + fz, f? = lower cell is the last one of its tile
+    cell = np.mod(mesh.cic_indices(po).cpu().numpy() - 2, N)
+    last = (cell % T == T - 1).astype(np.int64)
+    f = 4*last[:, 0] + 2*last[:, 1] + last[:, 2]
+    assert (np.diff(key*8 + f) >= 0).all()
 
 
 @pytest.mark.parametrize('name', PM_CASES + ['pm_n32_g64', 'p3m_n8_g32', 'p3m_n12_g36_lattice',
@@ -216,8 +222,9 @@ def test_tiled_kernels_vs_golden(torch_cuda, golden, name):
 
 
 def test_tiled_accumulate_and_strays(torch_cuda):
-    """accumulate=1 adds onto an existing mesh; particles that left their tile
-    after the sort (drift without re-sort) are still deposited / kicked right."""
+    """accumulate=1 adds onto an existing mesh (exact tile order required for the
+    deposit); the tiled gather still kicks particles right after they have left
+    their tile (drift without re-sort)."""
     torch = torch_cuda
     from concept_amd.mesh import PotentialMesh
     L, N, n = 64.0, 64, 50000
@@ -227,7 +234,6 @@ def test_tiled_accumulate_and_strays(torch_cuda):
     mom = torch.tensor(rng.normal(0, 3.0, (n, 3)), device='cuda')  # several cells per drift
     po, mo = torch.empty_like(pos), torch.empty_like(mom)
     table = mesh.sort_particles(pos, mom, None, po, mo, None)
-    mesh.drift(po, mo, 1.0)  # now many particles are outside their tile
     # reference: direct kernels
     mesh.zero()
     mesh.deposit(po, 0.7)
@@ -238,6 +244,7 @@ def test_tiled_accumulate_and_strays(torch_cuda):
     mesh.deposit_tiled(po, table, 0.3, accumulate=True)
     out = mesh.fetch_real()[:, :, :N]
     assert np.abs(out - ref).max() <= 1e-13*np.abs(ref).max()
+    mesh.drift(po, mo, 1.0)  # now many particles are outside their tile
     mesh.poisson_solve(4, -1.0, False, 0.0)
     k_direct = torch.zeros_like(mo)
     k_tiled = torch.zeros_like(mo)
