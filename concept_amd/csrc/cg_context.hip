@@ -2,6 +2,7 @@
 // MI355X / gfx950 only.  See include/concept_gpu.h for the reference lines
 // each entry point replaces.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "cg_internal.h"
@@ -161,7 +162,29 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
         }
         c->device_bytes += 8 * (8 * c->ntiles + 1);
     }
-    if (make_plans(c)) return fail();
+    // FFT backend: the hand-written passes for power-of-two grids, rocFFT otherwise
+    // (CONCEPT_GPU_FFT=rocfft forces the library, for A/B measurements)
+    {
+        const char *env = getenv("CONCEPT_GPU_FFT");
+        bool force_rocfft = env && std::string(env) == "rocfft";
+        c->custom_fft = cgk_fft_supported(c->N) && !force_rocfft;
+    }
+    if (c->custom_fft) {
+        std::vector<double> tw(2 * c->N);
+        for (i64 k = 0; k < c->N; k++) {
+            long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)k /
+                            (long double)c->N;
+            tw[2 * k] = (double)cosl(a);
+            tw[2 * k + 1] = (double)sinl(a);
+        }
+        if (hipMalloc(&c->fft_tw, 16 * c->N) != hipSuccess ||
+            hipMemcpy(c->fft_tw, tw.data(), 16 * c->N, hipMemcpyHostToDevice) != hipSuccess) {
+            cg_set_error("cg_create: FFT twiddle upload failed");
+            return fail();
+        }
+    } else if (make_plans(c)) {
+        return fail();
+    }
     *out = c;
     return 0;
 }
@@ -173,6 +196,7 @@ extern "C" int cg_destroy(cg_ctx *c) {
     if (c->info_fwd) rocfft_execution_info_destroy(c->info_fwd);
     if (c->info_bwd) rocfft_execution_info_destroy(c->info_bwd);
     (void)hipFree(c->fft_work);
+    (void)hipFree(c->fft_tw);
     (void)hipFree(c->mesh);
     (void)hipFree(c->fetch_tmp);
     (void)hipFree(c->ktab_n);
@@ -216,9 +240,13 @@ extern "C" int cg_poisson_forward(cg_ctx *c, int deconv_order, double C, int lon
     CG_CHECK(c, "cg_poisson_forward: null context");
     CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_poisson_forward: deconv_order %d",
              deconv_order);
-    CG_FFT(rocfft_execution_info_set_stream(c->info_fwd, c->stream));
-    void *buf[1] = {c->mesh};
-    CG_FFT(rocfft_execute(c->plan_fwd, buf, nullptr, c->info_fwd));
+    if (c->custom_fft) {
+        if (cgk_fft(c, 0, 0, 0.0, 0, 0.0)) return 1;
+    } else {
+        CG_FFT(rocfft_execution_info_set_stream(c->info_fwd, c->stream));
+        void *buf[1] = {c->mesh};
+        CG_FFT(rocfft_execute(c->plan_fwd, buf, nullptr, c->info_fwd));
+    }
     if (apply_kernel) return cgk_kspace(c, deconv_order, C, long_range, E);
     return 0;
 }
@@ -232,6 +260,7 @@ extern "C" int cg_poisson_kernel(cg_ctx *c, int deconv_order, double C, int long
 
 extern "C" int cg_poisson_backward(cg_ctx *c) {
     CG_CHECK(c, "cg_poisson_backward: null context");
+    if (c->custom_fft) return cgk_fft(c, 1, 0, 0.0, 0, 0.0);
     CG_FFT(rocfft_execution_info_set_stream(c->info_bwd, c->stream));
     void *buf[1] = {c->mesh};
     CG_FFT(rocfft_execute(c->plan_bwd, buf, nullptr, c->info_bwd));
@@ -239,6 +268,11 @@ extern "C" int cg_poisson_backward(cg_ctx *c) {
 }
 
 extern "C" int cg_poisson_solve(cg_ctx *c, int deconv_order, double C, int long_range, double E) {
+    CG_CHECK(c, "cg_poisson_solve: null context");
+    CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_poisson_solve: deconv_order %d",
+             deconv_order);
+    // hand-written FFT: the k-space kernel is fused into the x pass (5 passes in all)
+    if (c->custom_fft) return cgk_fft(c, 2, deconv_order, C, long_range, E);
     if (cg_poisson_forward(c, deconv_order, C, long_range, E, 1)) return 1;
     return cg_poisson_backward(c);
 }

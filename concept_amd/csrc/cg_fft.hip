@@ -1,0 +1,335 @@
+// cg_fft.hip — hand-written FP64 3-D real FFT for the Poisson solve on
+// gfx950, power-of-two grid sizes 16..2048.
+//
+// Why not rocFFT here: for 1024^3 doubles its 3-D real plan runs 6 passes over
+// the mesh per transform (3 FFT kernels + 3 transposes/post-process, measured
+// 19.9 ms forward, 22.1 ms backward; its strided 1-D plans are slower still).
+// The mesh is HBM-bound, so the pass count is the cost.  Here every dimension
+// is ONE pass: a workgroup stages whole pencils in LDS (a 1024-point complex
+// pencil is 16 KB), transforms them there (Stockham autosort, radix 4 with a
+// radix-2 tail; inputs held in registers between the read and write halves of
+// a pass so one LDS buffer suffices) and writes them back in place.  The
+// x-pass is fused: forward transform, multiply by the Poisson/deconvolution
+// factor (cg_kspace.h), inverse transform — the k-space field never travels to
+// HBM.  A Poisson solve is 5 passes (z, y, x-fused, y, z) instead of 13.
+//
+// Layout (unchanged): real double[N][N][pad] <-> complex[N][N][pad/2] in
+// place, pad >= N+2, unnormalised both ways (FFTW's convention, fft.c:34-73,
+// mesh.py:4015-4022).
+//   z: real<->half-complex along the contiguous dimension via the packed
+//      half-length complex transform + split/merge step
+//   y, x: complex pencils with stride pad/2 and N*pad/2; 4 adjacent kk per
+//      workgroup (64-byte segments per row)
+#include "cg_internal.h"
+#include "cg_kspace.h"
+
+#define CG_LAUNCH_CHECK()                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) {                                                               \
+            cg_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                           \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) {
+    return make_double2(a.x + b.x, a.y + b.y);
+}
+__device__ __forceinline__ double2 csub(double2 a, double2 b) {
+    return make_double2(a.x - b.x, a.y - b.y);
+}
+__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+
+// ---------------------------------------------------------------------------
+// In-LDS transform of W interleaved pencils of n = 2^LOGN complex points:
+// element m of pencil w lives at lds[m*W + w].  tw[k*tws] = exp(-2 pi i k/n).
+// All NT threads of the workgroup must call it.  Natural order in and out.
+// ---------------------------------------------------------------------------
+template <int LOGN, int W, int NT, bool INV>
+__device__ __forceinline__ void fft_lds(double2 *lds, const double2 *__restrict__ tw, int tws,
+                                        int tid) {
+    constexpr int n = 1 << LOGN;
+    int Ns = 1;
+#pragma unroll 1
+    for (int pass = 0; pass < LOGN / 2; pass++) {
+        // radix 4
+        constexpr int NB = (n / 4) * W;             // butterflies in the workgroup
+        constexpr int B = (NB + NT - 1) / NT;       // per thread
+        double2 v[B][4];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            int f = tid + b * NT;
+            if (NB % NT == 0 || f < NB) {
+                int w = f % W, j = f / W;
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[b][r] = lds[(j + r * (n / 4)) * W + w];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            int f = tid + b * NT;
+            if (NB % NT == 0 || f < NB) {
+                int w = f % W, j = f / W;
+                int k = j & (Ns - 1);
+                double2 x0 = v[b][0], x1 = v[b][1], x2 = v[b][2], x3 = v[b][3];
+                if (Ns > 1) {
+                    // twiddles exp(-+2 pi i k r/(4 Ns)), r = 1..3
+                    double2 t1 = tw[(size_t)k * (n / (4 * Ns)) * tws];
+                    if (INV) t1 = cconj(t1);
+                    double2 t2 = cmul(t1, t1), t3 = cmul(t2, t1);
+                    x1 = cmul(x1, t1);
+                    x2 = cmul(x2, t2);
+                    x3 = cmul(x3, t3);
+                }
+                double2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3),
+                        d = csub(x1, x3);
+                // (x1 - x3) * (-+ i)
+                double2 a3 = INV ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);
+                int j0 = ((j - k) << 2) + k;  // (j/Ns)*Ns*4 + k
+                lds[(j0)*W + w] = cadd(a0, a2);
+                lds[(j0 + Ns) * W + w] = cadd(a1, a3);
+                lds[(j0 + 2 * Ns) * W + w] = csub(a0, a2);
+                lds[(j0 + 3 * Ns) * W + w] = csub(a1, a3);
+            }
+        }
+        __syncthreads();
+        Ns <<= 2;
+    }
+    if (LOGN & 1) {
+        // radix-2 tail, Ns = n/2
+        constexpr int NB = (n / 2) * W;
+        constexpr int B = (NB + NT - 1) / NT;
+        double2 v[B][2];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            int f = tid + b * NT;
+            if (NB % NT == 0 || f < NB) {
+                int w = f % W, j = f / W;
+                v[b][0] = lds[j * W + w];
+                v[b][1] = lds[(j + n / 2) * W + w];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            int f = tid + b * NT;
+            if (NB % NT == 0 || f < NB) {
+                int w = f % W, j = f / W;  // k = j (Ns = n/2)
+                double2 t1 = tw[(size_t)j * tws];
+                if (INV) t1 = cconj(t1);
+                double2 x1 = cmul(v[b][1], t1);
+                lds[j * W + w] = cadd(v[b][0], x1);
+                lds[(j + n / 2) * W + w] = csub(v[b][0], x1);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// z pass, forward: N reals -> N/2+1 complex per (i,j) row, in place.
+// One row per workgroup.  tw[k] = exp(-2 pi i k/N), k < N.
+// ---------------------------------------------------------------------------
+template <int LOGN /* log2 N */, int NT>
+__global__ __launch_bounds__(NT) void k_fft_z_forward(double *__restrict__ mesh, i64 pad,
+                                                      const double2 *__restrict__ tw) {
+    constexpr int N = 1 << LOGN, H = N / 2;
+    __shared__ double2 lds[H];
+    double2 *row = (double2 *)(mesh + (i64)blockIdx.x * pad);
+    const int tid = threadIdx.x;
+    {
+        constexpr int PER = (H + NT - 1) / NT;
+        double2 v[PER];
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            int m = tid + r * NT;
+            if (H % NT == 0 || m < H) v[r] = row[m];  // (x[2m], x[2m+1])
+        }
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            int m = tid + r * NT;
+            if (H % NT == 0 || m < H) lds[m] = v[r];
+        }
+    }
+    __syncthreads();
+    fft_lds<LOGN - 1, 1, NT, false>(lds, tw, 2, tid);
+    // split: X[k] = (Z[k] + conj Z[H-k])/2 - (i/2) w^k (Z[k] - conj Z[H-k]), k = 0..H
+    for (int k = tid; k <= H; k += NT) {
+        double2 zk = lds[k & (H - 1)], zc = cconj(lds[(H - k) & (H - 1)]);
+        double2 s = cadd(zk, zc), d = csub(zk, zc);
+        double2 wd = cmul(tw[k % N], d);  // k = H < N always
+        // -(i/2)*wd = (wd.y/2, -wd.x/2)
+        row[k] = make_double2(0.5 * s.x + 0.5 * wd.y, 0.5 * s.y - 0.5 * wd.x);
+    }
+}
+
+// z pass, backward: N/2+1 complex -> N reals (unnormalised), in place.
+template <int LOGN, int NT>
+__global__ __launch_bounds__(NT) void k_fft_z_backward(double *__restrict__ mesh, i64 pad,
+                                                       const double2 *__restrict__ tw) {
+    constexpr int N = 1 << LOGN, H = N / 2;
+    __shared__ double2 lds[H];
+    double2 *row = (double2 *)(mesh + (i64)blockIdx.x * pad);
+    const int tid = threadIdx.x;
+    // merge: Z[k] = (X[k] + conj X[H-k]) + i conj(w^k) (X[k] - conj X[H-k]), k = 0..H-1
+    for (int k = tid; k < H; k += NT) {
+        double2 xk = row[k], xc = cconj(row[H - k]);
+        double2 s = cadd(xk, xc), d = csub(xk, xc);
+        double2 wd = cmul(cconj(tw[k]), d);
+        // + i*wd = (-wd.y, wd.x)
+        lds[k] = make_double2(s.x - wd.y, s.y + wd.x);
+    }
+    __syncthreads();
+    fft_lds<LOGN - 1, 1, NT, true>(lds, tw, 2, tid);
+    for (int m = tid; m < H; m += NT) row[m] = lds[m];
+}
+
+// ---------------------------------------------------------------------------
+// strided pass (y or x): n = N points with stride `estride` (complex units),
+// W = 4 adjacent kk per workgroup.  MODE 0: forward, 1: backward,
+// 2: forward * k-space factor * backward (the fused Poisson pass).
+// Workgroup -> (outer index o in [0, N), kk block): pencil base =
+// o*ostride + kk0, element m at base + m*estride.
+// For the factor the pencil index m and the outer index o are the two full
+// dimensions (the expression is symmetric in them).
+// ---------------------------------------------------------------------------
+template <int LOGN, int NT, int MODE>
+__global__ __launch_bounds__(NT) void k_fft_strided(double2 *__restrict__ data, i64 estride,
+                                                    i64 ostride, int nkb,
+                                                    const double2 *__restrict__ tw,
+                                                    KspaceParams P) {
+    constexpr int N = 1 << LOGN, W = 4;
+    extern __shared__ double2 lds_dyn[];
+    double2 *lds = lds_dyn;
+    const int tid = threadIdx.x;
+    const i64 o = blockIdx.x / nkb;
+    const int kb = blockIdx.x - (int)o * nkb;
+    const int kk0 = kb * W;
+    const int nk = N / 2 + 1;  // valid kk: 0..N/2
+    double2 *base = data + o * ostride + kk0;
+    constexpr int TOT = N * W;
+    constexpr int PER = (TOT + NT - 1) / NT;
+    {
+        double2 v[PER];
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            int f = tid + r * NT;
+            int w = f % W, m = f / W;
+            bool ok = (TOT % NT == 0 || f < TOT) && (kk0 + w < nk);
+            v[r] = ok ? base[(i64)m * estride + w] : make_double2(0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            int f = tid + r * NT;
+            if (TOT % NT == 0 || f < TOT) lds[f] = v[r];
+        }
+    }
+    __syncthreads();
+    if (MODE == 0 || MODE == 2) fft_lds<LOGN, W, NT, false>(lds, tw, 1, tid);
+    if (MODE == 2) {
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            int f = tid + r * NT;
+            if (TOT % NT == 0 || f < TOT) {
+                int w = f % W, m = f / W;
+                int kk = kk0 + w;
+                if (kk < nk) {
+                    double fac = kspace_factor(P, N, m, o, kk);
+                    double2 x = lds[f];
+                    lds[f] = make_double2(x.x * fac, x.y * fac);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (MODE == 1 || MODE == 2) fft_lds<LOGN, W, NT, true>(lds, tw, 1, tid);
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        int f = tid + r * NT;
+        int w = f % W, m = f / W;
+        if ((TOT % NT == 0 || f < TOT) && (kk0 + w < nk)) base[(i64)m * estride + w] = lds[f];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <int LOGN>
+static int run_z(cg_ctx *c, bool inverse) {
+    constexpr int N = 1 << LOGN;
+    constexpr int NT = (N / 8) < 64 ? 64 : ((N / 8) > 256 ? 256 : (N / 8));
+    unsigned rows = (unsigned)(c->N * c->N);
+    if (!inverse)
+        hipLaunchKernelGGL((k_fft_z_forward<LOGN, NT>), dim3(rows), dim3(NT), 0, c->stream, c->mesh,
+                           c->pad, (const double2 *)c->fft_tw);
+    else
+        hipLaunchKernelGGL((k_fft_z_backward<LOGN, NT>), dim3(rows), dim3(NT), 0, c->stream,
+                           c->mesh, c->pad, (const double2 *)c->fft_tw);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int LOGN, int MODE>
+static int run_strided(cg_ctx *c, int dim /*1 = y, 0 = x*/, const KspaceParams &P) {
+    constexpr int N = 1 << LOGN;
+    constexpr int NT = N >= 256 ? 256 : (N >= 64 ? 64 : 64);
+    const i64 cp = c->pad / 2;
+    const int nkb = (int)((c->N / 2 + 1 + 3) / 4);
+    i64 estride = dim == 1 ? cp : cp * c->N;
+    i64 ostride = dim == 1 ? cp * c->N : cp;
+    size_t lds = sizeof(double2) * N * 4;
+    auto kern = k_fft_strided<LOGN, NT, MODE>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        CG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(c->N * nkb)), dim3(NT), lds, c->stream,
+                       (double2 *)c->mesh, estride, ostride, nkb, (const double2 *)c->fft_tw, P);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int LOGN>
+static int fft3d(cg_ctx *c, int what, const KspaceParams &P) {
+    // what: 0 forward, 1 backward, 2 forward + kernel + backward (fused x pass)
+    if (what == 0) {
+        if (run_z<LOGN>(c, false)) return 1;
+        if (run_strided<LOGN, 0>(c, 1, P)) return 1;
+        return run_strided<LOGN, 0>(c, 0, P);
+    }
+    if (what == 1) {
+        if (run_strided<LOGN, 1>(c, 0, P)) return 1;
+        if (run_strided<LOGN, 1>(c, 1, P)) return 1;
+        return run_z<LOGN>(c, true);
+    }
+    if (run_z<LOGN>(c, false)) return 1;
+    if (run_strided<LOGN, 0>(c, 1, P)) return 1;
+    if (run_strided<LOGN, 2>(c, 0, P)) return 1;
+    if (run_strided<LOGN, 1>(c, 1, P)) return 1;
+    return run_z<LOGN>(c, true);
+}
+
+bool cgk_fft_supported(i64 N) { return N >= 16 && N <= 2048 && (N & (N - 1)) == 0; }
+
+int cgk_fft(cg_ctx *c, int what, int deconv_order, double C, int long_range, double E) {
+    KspaceParams P{c->ktab_n, c->ktab_s, deconv_order, long_range, C, E};
+    switch (c->N) {
+        case 16: return fft3d<4>(c, what, P);
+        case 32: return fft3d<5>(c, what, P);
+        case 64: return fft3d<6>(c, what, P);
+        case 128: return fft3d<7>(c, what, P);
+        case 256: return fft3d<8>(c, what, P);
+        case 512: return fft3d<9>(c, what, P);
+        case 1024: return fft3d<10>(c, what, P);
+        case 2048: return fft3d<11>(c, what, P);
+    }
+    cg_set_error("cgk_fft: grid size %lld not supported by the hand-written FFT", (long long)c->N);
+    return 1;
+}

@@ -83,6 +83,9 @@ struct cg_ctx {
     rocfft_execution_info info_fwd = nullptr, info_bwd = nullptr;
     void *fft_work = nullptr;
     size_t fft_work_bytes = 0;
+    // hand-written FFT (cg_fft.hip): twiddles exp(-2 pi i k/N) as double2[N]
+    bool custom_fft = false;
+    double *fft_tw = nullptr;
     // particle sort scratch (owned, grown on demand)
     TileGeom tiles{};
     unsigned int *tile_count = nullptr;   // [ntiles + 1]
@@ -104,6 +107,9 @@ int cgk_cic_indices(cg_ctx *c, const double *pos, i64 n, int for_gather, i64 *id
 int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst);
 int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
              double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out);
+bool cgk_fft_supported(i64 N);
+// what: 0 forward, 1 backward, 2 forward + Poisson kernel + backward (fused)
+int cgk_fft(cg_ctx *c, int what, int deconv_order, double C, int long_range, double E);
 int cgk_deposit_cic_tiled(cg_ctx *c, const double *pos, i64 n, const unsigned *tile_offset,
                           double contribution, int accumulate);
 int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,

@@ -4,6 +4,7 @@
 // -ffp-contract=off so every expression is evaluated in the reference's
 // operation order (no FMA contraction).
 #include "cg_internal.h"
+#include "cg_kspace.h"
 
 #define CG_LAUNCH_CHECK()                                                                     \
     do {                                                                                      \
@@ -91,37 +92,16 @@ int cgk_deposit_cic(cg_ctx *c, const double *pos, i64 n, double contribution) {
 // One lane per complex mode (16 B load + 16 B store, coalesced along kk).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_kspace(double2 *__restrict__ slab, i64 N, i64 pitch,
-                                                const double *__restrict__ tab_n,
-                                                const double *__restrict__ tab_s, int deconv_order,
-                                                double C, int long_range, double E) {
-    const i64 nyq = N / 2, nk = N / 2 + 1;
+                                                KspaceParams P) {
+    const i64 nk = N / 2 + 1;
     i64 row = blockIdx.x;  // i*N + j
     i64 i = row / N, j = row - i * N;
-    i64 ki = i - (i >= nyq ? N : 0), kj = j - (j >= nyq ? N : 0);
-    bool row_nyq = (i == nyq) || (j == nyq);
-    double ni = tab_n[i], nj = tab_n[j], si = tab_s[i], sj = tab_s[j];
-    double dij_n = ni * nj;  // mesh.py:2797
-    double dij_d = si * sj;  // mesh.py:2798
-    i64 kij2 = kj * kj + ki * ki;  // interactions.py:2096
     double2 *r = slab + row * pitch;
     for (i64 kk = threadIdx.x; kk < nk; kk += blockDim.x) {
-        double2 v;
-        if (row_nyq || kk == nyq || (kij2 == 0 && kk == 0)) {
-            v.x = 0;
-            v.y = 0;
-        } else {
+        double factor = kspace_factor(P, N, i, j, kk);
+        double2 v = make_double2(0, 0);
+        if (factor != 0) {
             v = r[kk];
-            double factor = 1;
-            if (deconv_order) {
-                double nkk = tab_n[kk], skk = tab_s[kk];
-                factor = (dij_n * nkk) / (dij_d * skk);  // mesh.py:2850-2853
-                double f = factor;
-                for (int o = 1; o < deconv_order; o++) factor *= f;  // factor **= deconv_order
-            }
-            i64 k2 = kij2 + kk * kk;
-            double pk = C / (double)k2;
-            if (long_range) pk = pk * exp((double)k2 * E);  // interactions.py:2110-2113
-            factor *= pk;
             v.x *= factor;
             v.y *= factor;
         }
@@ -133,8 +113,8 @@ int cgk_kspace(cg_ctx *c, int deconv_order, double C, int long_range, double E) 
     i64 rows = c->N * c->N;
     int block = c->N / 2 + 1 >= 256 ? 256 : (c->N / 2 + 1 > 64 ? 128 : 64);
     hipLaunchKernelGGL(k_kspace, dim3((unsigned)rows), dim3(block), 0, c->stream,
-                       (double2 *)c->mesh, c->N, c->pad / 2, c->ktab_n, c->ktab_s, deconv_order, C,
-                       long_range, E);
+                       (double2 *)c->mesh, c->N, c->pad / 2,
+                       KspaceParams{c->ktab_n, c->ktab_s, deconv_order, long_range, C, E});
     CG_LAUNCH_CHECK();
     return 0;
 }
