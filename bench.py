@@ -45,6 +45,7 @@ def algorithmic_bytes(n_p, n_g):
         'fft_forward': 48*n_g,                   # 3 passes x (read + write)
         'kspace': 16*n_g,
         'fft_backward': 48*n_g,
+        'poisson': 48*n_g + 16*n_g + 48*n_g,     # A4 + A5-A7 + A8
         'gather_kick': 24*n_p + 48*n_p + 8*n_g,  # pos, mom RMW, potential once (FD fused)
         'drift': 48*n_p + 24*n_p,
         'sort': 2*(48*n_p) + 24*n_p,             # histogram reads pos; scatter moves pos+mom
@@ -85,6 +86,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--split-poisson', action='store_true',
+                    help='time FFT forward / k-space kernel / FFT backward separately (unfused)')
     ap.add_argument('--no-sort', action='store_true',
                     help='direct (untiled) kernels on unsorted particles, for A/B')
     args = ap.parse_args()
@@ -127,12 +130,11 @@ def main():
     kick_factor = mass*(-dt)
     dt_over_mass = dt/mass
 
+    poisson = ['fft_forward', 'kspace', 'fft_backward'] if args.split_poisson else ['poisson']
     if args.no_sort:
-        PHASES = ['drift', 'zero', 'deposit', 'fft_forward', 'kspace', 'fft_backward',
-                  'gather_kick']
+        PHASES = ['drift', 'zero', 'deposit'] + poisson + ['gather_kick']
     else:  # the tiled deposit assigns the mesh: no zero-fill pass
-        PHASES = ['drift', 'sort', 'deposit', 'fft_forward', 'kspace', 'fft_backward',
-                  'gather_kick']
+        PHASES = ['drift', 'sort', 'deposit'] + poisson + ['gather_kick']
     events = []
 
     def step(record):
@@ -161,12 +163,16 @@ def main():
             mark()
             mesh.deposit(pos, contribution)
             mark()
-        mesh.poisson_forward(4, C, False, 0.0, apply_kernel=False)
-        mark()
-        mesh.poisson_kernel(4, C, False, 0.0)
-        mark()
-        mesh.poisson_backward()
-        mark()
+        if args.split_poisson:
+            mesh.poisson_forward(4, C, False, 0.0, apply_kernel=False)
+            mark()
+            mesh.poisson_kernel(4, C, False, 0.0)
+            mark()
+            mesh.poisson_backward()
+            mark()
+        else:  # the product path: k-space kernel fused into the x pass of the FFT
+            mesh.poisson_solve(4, C, False, 0.0)
+            mark()
         if not args.no_sort:
             mesh.gather_kick_tiled(pos, mom, table, 2, kick_factor)
         else:
@@ -214,8 +220,7 @@ def main():
     groups = {
         'deposit+interp': (alg['deposit'] + alg['gather_kick'],
                            phase_ms['deposit'] + phase_ms['gather_kick']),
-        'poisson_solve': (alg['fft_forward'] + alg['kspace'] + alg['fft_backward'],
-                          phase_ms['fft_forward'] + phase_ms['kspace'] + phase_ms['fft_backward']),
+        'poisson_solve': (alg['poisson'], sum(phase_ms[ph] for ph in poisson)),
     }
     ms_per_step = elapsed/args.steps*1e3
     result = {
