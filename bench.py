@@ -214,7 +214,8 @@ def main():
         gbs = alg[ph]/(phase_ms[ph]*1e-3)/1e9 if phase_ms[ph] > 0 else 0.0
         phases[ph] = {'ms': round(phase_ms[ph], 4), 'alg_GB': round(alg[ph]/1e9, 3),
                       'GBps': round(gbs, 1), 'frac_hbm': round(gbs/HBM_PEAK_GBS, 4)}
-    own = ['deposit', 'gather_kick', 'kspace', 'drift'] + ([] if args.no_sort else ['sort'])
+    own = [ph for ph in ('deposit', 'gather_kick', 'kspace', 'poisson', 'drift', 'sort')
+           if ph in phase_ms]
     dom = max(own, key=lambda ph: phase_ms[ph])
     ach = alg[dom]/(phase_ms[dom]*1e-3)/1e9
     groups = {

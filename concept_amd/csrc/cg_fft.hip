@@ -21,7 +21,7 @@
 //   y, x: complex pencils with stride pad/2 and N*pad/2; 4 adjacent kk per
 //      workgroup (64-byte segments per row)
 #include "cg_internal.h"
-#include "cg_kspace.h"
+#include "cg_kspace.h"  // its factor function pins fp-contract off itself
 
 #define CG_LAUNCH_CHECK()                                                                     \
     do {                                                                                      \
@@ -60,6 +60,18 @@ __device__ __forceinline__ void fft_lds(double2 *lds, const double2 *__restrict_
         constexpr int NB = (n / 4) * W;             // butterflies in the workgroup
         constexpr int B = (NB + NT - 1) / NT;       // per thread
         double2 v[B][4];
+        double2 t1s[B];
+        // the pass's twiddles come from global memory (L1/L2 resident table): issue
+        // those loads first so their latency hides behind the LDS reads and the barrier
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            int f = tid + b * NT;
+            t1s[b] = make_double2(1, 0);
+            if ((NB % NT == 0 || f < NB) && Ns > 1) {
+                int j = f / W;
+                t1s[b] = tw[(size_t)(j & (Ns - 1)) * (n / (4 * Ns)) * tws];
+            }
+        }
 #pragma unroll
         for (int b = 0; b < B; b++) {
             int f = tid + b * NT;
@@ -79,7 +91,7 @@ __device__ __forceinline__ void fft_lds(double2 *lds, const double2 *__restrict_
                 double2 x0 = v[b][0], x1 = v[b][1], x2 = v[b][2], x3 = v[b][3];
                 if (Ns > 1) {
                     // twiddles exp(-+2 pi i k r/(4 Ns)), r = 1..3
-                    double2 t1 = tw[(size_t)k * (n / (4 * Ns)) * tws];
+                    double2 t1 = t1s[b];
                     if (INV) t1 = cconj(t1);
                     double2 t2 = cmul(t1, t1), t3 = cmul(t2, t1);
                     x1 = cmul(x1, t1);
@@ -277,7 +289,9 @@ static int run_z(cg_ctx *c, bool inverse) {
 template <int LOGN, int MODE>
 static int run_strided(cg_ctx *c, int dim /*1 = y, 0 = x*/, const KspaceParams &P) {
     constexpr int N = 1 << LOGN;
-    constexpr int NT = N >= 256 ? 256 : (N >= 64 ? 64 : 64);
+    // 512 lanes per 4-pencil workgroup from N = 512 up: the 64 KB (N = 1024) LDS tile
+    // allows only 2 workgroups per CU, so the waves must come from the workgroup size
+    constexpr int NT = N >= 512 ? 512 : (N >= 256 ? 256 : 64);
     const i64 cp = c->pad / 2;
     const int nkb = (int)((c->N / 2 + 1 + 3) / 4);
     i64 estride = dim == 1 ? cp : cp * c->N;

@@ -20,6 +20,7 @@ struct KspaceParams {
 // dimension).  Returns 0 for the nullified modes.
 __device__ __forceinline__ double kspace_factor(const KspaceParams &P, i64 N, i64 a, i64 b,
                                                 i64 kk) {
+#pragma clang fp contract(off)  // the reference's operation order, also inside cg_fft.hip
     const i64 nyq = N / 2;
     if (a == nyq || b == nyq || kk == nyq) return 0;  // nullify_modes('nyquist')
     i64 ka = a - (a >= nyq ? N : 0), kb = b - (b >= nyq ? N : 0);
