@@ -93,10 +93,16 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
              p->interp_order);
     CG_CHECK(p->nghosts >= 1 && p->nghosts <= 4, "cg_create: nghosts %d out of range", p->nghosts);
     CG_CHECK(p->boxsize > 0, "cg_create: boxsize must be positive");
-    CG_CHECK(p->nprocs == 1 && p->rank == 0 && p->subdiv[0] == 1 && p->subdiv[1] == 1 &&
-                 p->subdiv[2] == 1,
-             "cg_create: this context is single-domain; multi-GPU runs shard through "
-             "concept_amd.distributed (nprocs=%d)", p->nprocs);
+    CG_CHECK(p->nprocs >= 1 && p->rank >= 0 && p->rank < p->nprocs,
+             "cg_create: rank %d of %d", p->rank, p->nprocs);
+    CG_CHECK(p->subdiv[0] == p->nprocs && p->subdiv[1] == 1 && p->subdiv[2] == 1,
+             "cg_create: domains are x-slabs, subdiv must be (%d, 1, 1) (DESIGN.md section 6)",
+             p->nprocs);
+    CG_CHECK(p->gridsize % p->nprocs == 0 && (p->gridsize / p->nprocs) % 2 == 0,
+             "cg_create: gridsize %lld must be divisible by 2*nprocs (mesh.py:1898-1905,3779)",
+             (long long)p->gridsize);
+    CG_CHECK(p->nprocs == 1 || cgk_fft_supported(p->gridsize),
+             "cg_create: the multi-GPU FFT needs a power-of-two grid size (16..2048)");
     CG_HIP(hipSetDevice(p->device));
     if (!g_rocfft_ready) {
         CG_FFT(rocfft_setup());
@@ -106,7 +112,9 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
     c->p = *p;
     c->N = p->gridsize;
     c->pad = (c->N % 16 == 0) ? c->N + 16 : c->N + 2;
-    c->mesh_doubles = c->N * c->N * c->pad;
+    if (p->nprocs == 1) c->xmap = XMap{0, c->N, 0, 1};
+    else c->xmap = XMap{(c->N / p->nprocs) * p->rank, c->N / p->nprocs, 3, 0};
+    c->mesh_doubles = (c->xmap.nxl + 2 * c->xmap.G) * c->N * c->pad;
     auto fail = [&]() {
         cg_destroy(c);
         return 1;
@@ -117,6 +125,7 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
         return fail();
     }
     c->device_bytes += 8 * c->mesh_doubles;
+    c->mesh0 = c->mesh + (i64)c->xmap.G * c->N * c->pad;
     // geometry, reference expressions
     const double bgn[3] = {0, 0, 0};
     double cellsize_dep = p->boxsize / (double)p->gridsize;             // mesh.py:1577
@@ -146,12 +155,13 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
     // for the particle memory order and the LDS-tiled deposit / gather kernels
     {
         int t = 16;
-        while (t > 2 && (c->N % t || c->N / t < 2)) t /= 2;
-        if (c->N % t) {
-            cg_set_error("cg_create: gridsize %lld is not divisible by 2", (long long)c->N);
+        while (t > 2 && (c->N % t || c->N / t < 2 || c->xmap.nxl % t)) t /= 2;
+        if (c->N % t || c->xmap.nxl % t) {
+            cg_set_error("cg_create: gridsize %lld / %d domains is not divisible by 2",
+                         (long long)c->N, p->nprocs);
             return fail();
         }
-        c->tiles = {t, t, t, (int)(c->N / t), (int)(c->N / t), (int)(c->N / t)};
+        c->tiles = {t, t, t, (int)(c->xmap.nxl / t), (int)(c->N / t), (int)(c->N / t)};
         c->ntiles = (i64)c->tiles.ntx * c->tiles.nty * c->tiles.ntz;
         // 8 buckets per tile (which of the +x/+y/+z neighbour tiles a particle's CIC
         // cloud reaches), see cg_particles.hip
@@ -238,6 +248,7 @@ extern "C" int cg_deposit_cic(cg_ctx *c, const double *pos, int64_t n, double co
 extern "C" int cg_poisson_forward(cg_ctx *c, int deconv_order, double C, int long_range, double E,
                                   int apply_kernel) {
     CG_CHECK(c, "cg_poisson_forward: null context");
+    CG_CHECK(c->p.nprocs == 1, "cg_poisson_forward: single-domain entry point; x-slab domains use cg_dist_fft_*");
     CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_poisson_forward: deconv_order %d",
              deconv_order);
     if (c->custom_fft) {
@@ -253,6 +264,7 @@ extern "C" int cg_poisson_forward(cg_ctx *c, int deconv_order, double C, int lon
 
 extern "C" int cg_poisson_kernel(cg_ctx *c, int deconv_order, double C, int long_range, double E) {
     CG_CHECK(c, "cg_poisson_kernel: null context");
+    CG_CHECK(c->p.nprocs == 1, "cg_poisson_kernel: single-domain entry point; x-slab domains use cg_dist_fft_*");
     CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_poisson_kernel: deconv_order %d",
              deconv_order);
     return cgk_kspace(c, deconv_order, C, long_range, E);
@@ -260,6 +272,7 @@ extern "C" int cg_poisson_kernel(cg_ctx *c, int deconv_order, double C, int long
 
 extern "C" int cg_poisson_backward(cg_ctx *c) {
     CG_CHECK(c, "cg_poisson_backward: null context");
+    CG_CHECK(c->p.nprocs == 1, "cg_poisson_backward: single-domain entry point; x-slab domains use cg_dist_fft_*");
     if (c->custom_fft) return cgk_fft(c, 1, 0, 0.0, 0, 0.0);
     CG_FFT(rocfft_execution_info_set_stream(c->info_bwd, c->stream));
     void *buf[1] = {c->mesh};
@@ -269,6 +282,7 @@ extern "C" int cg_poisson_backward(cg_ctx *c) {
 
 extern "C" int cg_poisson_solve(cg_ctx *c, int deconv_order, double C, int long_range, double E) {
     CG_CHECK(c, "cg_poisson_solve: null context");
+    CG_CHECK(c->p.nprocs == 1, "cg_poisson_solve: single-domain entry point; x-slab domains use cg_dist_fft_*");
     CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_poisson_solve: deconv_order %d",
              deconv_order);
     // hand-written FFT: the k-space kernel is fused into the x pass (5 passes in all)
@@ -299,7 +313,7 @@ extern "C" int cg_drift(cg_ctx *c, double *pos, const double *mom, int64_t n,
 extern "C" int cg_tile_info(const cg_ctx *c, int64_t info[3]) {
     CG_CHECK(c && info, "cg_tile_info: null argument");
     info[0] = c->tiles.tx;
-    info[1] = c->tiles.ntx;
+    info[1] = c->tiles.nty;
     info[2] = 8 * c->ntiles + 1;
     return 0;
 }
@@ -342,19 +356,74 @@ extern "C" int cg_cic_indices(cg_ctx *c, const double *pos, int64_t n, int for_g
     return cgk_cic_indices(c, pos, n, for_gather, idx_out);
 }
 
+extern "C" int cg_local_info(const cg_ctx *c, int64_t info[6]) {
+    CG_CHECK(c && info, "cg_local_info: null argument");
+    info[0] = c->xmap.x0;
+    info[1] = c->xmap.nxl;
+    info[2] = c->xmap.G;
+    info[3] = c->N;
+    info[4] = c->pad;
+    info[5] = c->xmap.nxl * c->N * c->pad;
+    return 0;
+}
+
+extern "C" int cg_layers_read(cg_ctx *c, int64_t layer0, int64_t nlayers, double *dst) {
+    CG_CHECK(c && dst, "cg_layers_read: null argument");
+    CG_CHECK(layer0 >= -(i64)c->xmap.G && layer0 + nlayers <= c->xmap.nxl + c->xmap.G &&
+                 nlayers >= 0, "cg_layers_read: layers [%lld, %lld) outside the local buffer",
+             (long long)layer0, (long long)(layer0 + nlayers));
+    i64 per = c->N * c->pad;
+    CG_HIP(hipMemcpyAsync(dst, c->mesh0 + layer0 * per, 8 * per * nlayers,
+                          hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+extern "C" int cg_layers_write(cg_ctx *c, int64_t layer0, int64_t nlayers, const double *src,
+                               int add) {
+    CG_CHECK(c && src, "cg_layers_write: null argument");
+    CG_CHECK(layer0 >= -(i64)c->xmap.G && layer0 + nlayers <= c->xmap.nxl + c->xmap.G &&
+                 nlayers >= 0, "cg_layers_write: layers [%lld, %lld) outside the local buffer",
+             (long long)layer0, (long long)(layer0 + nlayers));
+    return cgk_layers_write(c, layer0, nlayers, src, add);
+}
+
+extern "C" int cg_dist_fft_forward(cg_ctx *c, double *send_buf) {
+    CG_CHECK(c && send_buf, "cg_dist_fft_forward: null argument");
+    CG_CHECK(c->custom_fft, "cg_dist_fft_forward: needs the hand-written FFT backend");
+    return cgk_fft_dist_forward(c, send_buf);
+}
+extern "C" int cg_dist_fft_xsolve(cg_ctx *c, double *buf, int deconv_order, double C,
+                                  int long_range, double E) {
+    CG_CHECK(c && buf, "cg_dist_fft_xsolve: null argument");
+    CG_CHECK(c->custom_fft, "cg_dist_fft_xsolve: needs the hand-written FFT backend");
+    CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_dist_fft_xsolve: deconv_order %d",
+             deconv_order);
+    return cgk_fft_dist_xsolve(c, buf, deconv_order, C, long_range, E);
+}
+extern "C" int cg_dist_fft_backward(cg_ctx *c, const double *recv_buf) {
+    CG_CHECK(c && recv_buf, "cg_dist_fft_backward: null argument");
+    CG_CHECK(c->custom_fft, "cg_dist_fft_backward: needs the hand-written FFT backend");
+    return cgk_fft_dist_backward(c, recv_buf);
+}
+extern "C" int cg_owner_rank(cg_ctx *c, const double *pos, int64_t n, int32_t *owner_out) {
+    CG_CHECK(c && (n == 0 || (pos && owner_out)), "cg_owner_rank: null argument");
+    return cgk_owner_rank(c, pos, n, owner_out);
+}
+
 extern "C" int cg_fetch(cg_ctx *c, int which, double *out, int64_t n_doubles) {
     CG_CHECK(c && out, "cg_fetch: null argument");
-    const i64 ref_doubles = c->N * c->N * (c->N + 2);  // the reference's slab shape
+    const i64 ref_doubles = c->xmap.nxl * c->N * (c->N + 2);  // the reference's slab shape
     CG_CHECK(n_doubles == ref_doubles, "cg_fetch: expected %lld doubles, got %lld",
              (long long)ref_doubles, (long long)n_doubles);
     const size_t row = 8 * (size_t)(c->N + 2);
     if (which == CG_FETCH_MESH_REAL) {
         CG_HIP(hipStreamSynchronize(c->stream));
-        CG_HIP(hipMemcpy2D(out, row, c->mesh, 8 * (size_t)c->pad, row, (size_t)(c->N * c->N),
-                           hipMemcpyDeviceToHost));
+        CG_HIP(hipMemcpy2D(out, row, c->mesh0, 8 * (size_t)c->pad, row,
+                           (size_t)(c->xmap.nxl * c->N), hipMemcpyDeviceToHost));
         return 0;
     }
     if (which == CG_FETCH_MESH_FOURIER) {
+        CG_CHECK(c->p.nprocs == 1, "cg_fetch: the Fourier slab fetch is single-domain only");
         if (!c->fetch_tmp) CG_HIP(hipMalloc(&c->fetch_tmp, 8 * ref_doubles));
         if (cgk_transpose_fourier(c, c->mesh, c->fetch_tmp)) return 1;
         CG_HIP(hipStreamSynchronize(c->stream));

@@ -202,17 +202,32 @@ __global__ __launch_bounds__(NT) void k_fft_z_backward(double *__restrict__ mesh
 }
 
 // ---------------------------------------------------------------------------
-// strided pass (y or x): n = N points with stride `estride` (complex units),
-// W = 4 adjacent kk per workgroup.  MODE 0: forward, 1: backward,
-// 2: forward * k-space factor * backward (the fused Poisson pass).
-// Workgroup -> (outer index o in [0, N), kk block): pencil base =
-// o*ostride + kk0, element m at base + m*estride.
-// For the factor the pencil index m and the outer index o are the two full
-// dimensions (the expression is symmetric in them).
+// strided pass (y or x): n = N points per pencil, W = 4 adjacent kk per
+// workgroup.  MODE 0: forward, 1: backward, 2: forward * k-space factor *
+// backward (the fused Poisson pass).
+// Workgroup -> (outer index o, kk block).  Element m of the pencil is read from
+//   src + o*src.ostride + kk0 + (m >> src.sh)*src.blk + (m & mask)*src.es
+// and written to the same expression on dst: sh = 31 gives the plain strided
+// pencil; a finite sh addresses the pencil in blocks of 2^sh points, which is
+// the layout of the all-to-all transpose buffers of the multi-GPU path (the
+// pack / unpack of the transpose is fused into this pass).
+// For the factor, the pencil index m and the outer index o + o_off are the two
+// full dimensions (the expression is symmetric in them).
 // ---------------------------------------------------------------------------
+struct PencilMap {
+    i64 ostride;  // complex elements between consecutive outer indices
+    i64 es;       // between consecutive pencil points inside a block
+    i64 blk;      // between consecutive blocks
+    int sh;       // log2(points per block); 31 = one block
+};
+__device__ __forceinline__ i64 pencil_off(const PencilMap &pm, int m) {
+    return (i64)(m >> pm.sh) * pm.blk + (i64)((unsigned)m & ((1u << pm.sh) - 1u)) * pm.es;
+}
+
 template <int LOGN, int NT, int MODE>
-__global__ __launch_bounds__(NT) void k_fft_strided(double2 *__restrict__ data, i64 estride,
-                                                    i64 ostride, int nkb,
+__global__ __launch_bounds__(NT) void k_fft_strided(const double2 *__restrict__ src,
+                                                    double2 *__restrict__ dst, PencilMap smap,
+                                                    PencilMap dmap, int nkb, i64 o_off,
                                                     const double2 *__restrict__ tw,
                                                     KspaceParams P) {
     constexpr int N = 1 << LOGN, W = 4;
@@ -223,7 +238,8 @@ __global__ __launch_bounds__(NT) void k_fft_strided(double2 *__restrict__ data, 
     const int kb = blockIdx.x - (int)o * nkb;
     const int kk0 = kb * W;
     const int nk = N / 2 + 1;  // valid kk: 0..N/2
-    double2 *base = data + o * ostride + kk0;
+    const double2 *sbase = src + o * smap.ostride + kk0;
+    double2 *dbase = dst + o * dmap.ostride + kk0;
     constexpr int TOT = N * W;
     constexpr int PER = (TOT + NT - 1) / NT;
     {
@@ -233,7 +249,7 @@ __global__ __launch_bounds__(NT) void k_fft_strided(double2 *__restrict__ data, 
             int f = tid + r * NT;
             int w = f % W, m = f / W;
             bool ok = (TOT % NT == 0 || f < TOT) && (kk0 + w < nk);
-            v[r] = ok ? base[(i64)m * estride + w] : make_double2(0, 0);
+            v[r] = ok ? sbase[pencil_off(smap, m) + w] : make_double2(0, 0);
         }
 #pragma unroll
         for (int r = 0; r < PER; r++) {
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(NT) void k_fft_strided(double2 *__restrict__ data, 
                 int w = f % W, m = f / W;
                 int kk = kk0 + w;
                 if (kk < nk) {
-                    double fac = kspace_factor(P, N, m, o, kk);
+                    double fac = kspace_factor(P, N, m, o + o_off, kk);
                     double2 x = lds[f];
                     lds[f] = make_double2(x.x * fac, x.y * fac);
                 }
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(NT) void k_fft_strided(double2 *__restrict__ data, 
     for (int r = 0; r < PER; r++) {
         int f = tid + r * NT;
         int w = f % W, m = f / W;
-        if ((TOT % NT == 0 || f < TOT) && (kk0 + w < nk)) base[(i64)m * estride + w] = lds[f];
+        if ((TOT % NT == 0 || f < TOT) && (kk0 + w < nk)) dbase[pencil_off(dmap, m) + w] = lds[f];
     }
 }
 
@@ -275,27 +291,25 @@ template <int LOGN>
 static int run_z(cg_ctx *c, bool inverse) {
     constexpr int N = 1 << LOGN;
     constexpr int NT = (N / 8) < 64 ? 64 : ((N / 8) > 256 ? 256 : (N / 8));
-    unsigned rows = (unsigned)(c->N * c->N);
+    unsigned rows = (unsigned)(c->xmap.nxl * c->N);  // owned layers only
     if (!inverse)
-        hipLaunchKernelGGL((k_fft_z_forward<LOGN, NT>), dim3(rows), dim3(NT), 0, c->stream, c->mesh,
-                           c->pad, (const double2 *)c->fft_tw);
+        hipLaunchKernelGGL((k_fft_z_forward<LOGN, NT>), dim3(rows), dim3(NT), 0, c->stream,
+                           c->mesh0, c->pad, (const double2 *)c->fft_tw);
     else
         hipLaunchKernelGGL((k_fft_z_backward<LOGN, NT>), dim3(rows), dim3(NT), 0, c->stream,
-                           c->mesh, c->pad, (const double2 *)c->fft_tw);
+                           c->mesh0, c->pad, (const double2 *)c->fft_tw);
     CG_LAUNCH_CHECK();
     return 0;
 }
 
 template <int LOGN, int MODE>
-static int run_strided(cg_ctx *c, int dim /*1 = y, 0 = x*/, const KspaceParams &P) {
+static int run_strided(cg_ctx *c, const double2 *src, double2 *dst, PencilMap smap,
+                       PencilMap dmap, i64 nouter, i64 o_off, const KspaceParams &P) {
     constexpr int N = 1 << LOGN;
     // 512 lanes per 4-pencil workgroup from N = 512 up: the 64 KB (N = 1024) LDS tile
     // allows only 2 workgroups per CU, so the waves must come from the workgroup size
     constexpr int NT = N >= 512 ? 512 : (N >= 256 ? 256 : 64);
-    const i64 cp = c->pad / 2;
     const int nkb = (int)((c->N / 2 + 1 + 3) / 4);
-    i64 estride = dim == 1 ? cp : cp * c->N;
-    i64 ostride = dim == 1 ? cp * c->N : cp;
     size_t lds = sizeof(double2) * N * 4;
     auto kern = k_fft_strided<LOGN, NT, MODE>;
     static bool attr_set = false;
@@ -304,46 +318,95 @@ static int run_strided(cg_ctx *c, int dim /*1 = y, 0 = x*/, const KspaceParams &
                                    (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(c->N * nkb)), dim3(NT), lds, c->stream,
-                       (double2 *)c->mesh, estride, ostride, nkb, (const double2 *)c->fft_tw, P);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nouter * nkb)), dim3(NT), lds, c->stream, src, dst,
+                       smap, dmap, nkb, o_off, (const double2 *)c->fft_tw, P);
     CG_LAUNCH_CHECK();
     return 0;
 }
 
+static PencilMap plain_map(i64 ostride, i64 es) { return PencilMap{ostride, es, 0, 31}; }
+
 template <int LOGN>
 static int fft3d(cg_ctx *c, int what, const KspaceParams &P) {
-    // what: 0 forward, 1 backward, 2 forward + kernel + backward (fused x pass)
+    // single domain.  what: 0 forward, 1 backward, 2 forward + kernel + backward (fused x)
+    const i64 cp = c->pad / 2, N = c->N;
+    double2 *m = (double2 *)c->mesh0;
+    PencilMap ymap = plain_map(cp * N, cp), xmap = plain_map(cp, cp * N);
     if (what == 0) {
         if (run_z<LOGN>(c, false)) return 1;
-        if (run_strided<LOGN, 0>(c, 1, P)) return 1;
-        return run_strided<LOGN, 0>(c, 0, P);
+        if (run_strided<LOGN, 0>(c, m, m, ymap, ymap, N, 0, P)) return 1;
+        return run_strided<LOGN, 0>(c, m, m, xmap, xmap, N, 0, P);
     }
     if (what == 1) {
-        if (run_strided<LOGN, 1>(c, 0, P)) return 1;
-        if (run_strided<LOGN, 1>(c, 1, P)) return 1;
+        if (run_strided<LOGN, 1>(c, m, m, xmap, xmap, N, 0, P)) return 1;
+        if (run_strided<LOGN, 1>(c, m, m, ymap, ymap, N, 0, P)) return 1;
         return run_z<LOGN>(c, true);
     }
     if (run_z<LOGN>(c, false)) return 1;
-    if (run_strided<LOGN, 0>(c, 1, P)) return 1;
-    if (run_strided<LOGN, 2>(c, 0, P)) return 1;
-    if (run_strided<LOGN, 1>(c, 1, P)) return 1;
+    if (run_strided<LOGN, 0>(c, m, m, ymap, ymap, N, 0, P)) return 1;
+    if (run_strided<LOGN, 2>(c, m, m, xmap, xmap, N, 0, P)) return 1;
+    if (run_strided<LOGN, 1>(c, m, m, ymap, ymap, N, 0, P)) return 1;
+    return run_z<LOGN>(c, true);
+}
+
+// x-slab domains (one per GPU).  The local slab complex[nxl][N][cp] is
+// transformed along z and y here; the y pass writes straight into the
+// all-to-all send buffer, blocked by destination domain:
+//   send[q][i_local][j - q*JB][kk],  JB = N/P
+// so that after the exchange every domain holds complex[i (N)][j_local (JB)][cp]
+// and the x pass is again a plain strided pencil (stride JB*cp).  The way back
+// mirrors it: the inverse y pass reads the blocked layout.
+template <int LOGN>
+static int fft_dist(cg_ctx *c, int what, double2 *buf, const KspaceParams &P) {
+    const i64 cp = c->pad / 2, N = c->N, nxl = c->xmap.nxl, JB = N / c->p.nprocs;
+    int sh = 0;
+    while ((1 << sh) < JB) sh++;
+    double2 *m = (double2 *)c->mesh0;
+    PencilMap ymap = plain_map(cp * N, cp);
+    PencilMap bmap{JB * cp, cp, nxl * JB * cp, sh};
+    if (what == 0) {  // forward z, forward y -> send buffer
+        if (run_z<LOGN>(c, false)) return 1;
+        return run_strided<LOGN, 0>(c, m, buf, ymap, bmap, nxl, 0, P);
+    }
+    if (what == 2) {  // fused x pass on complex[N][JB][cp]
+        PencilMap xmap = plain_map(cp, JB * cp);
+        return run_strided<LOGN, 2>(c, buf, buf, xmap, xmap, JB, (i64)c->p.rank * JB, P);
+    }
+    // backward y from the returned buffer, backward z
+    if (run_strided<LOGN, 1>(c, buf, m, bmap, ymap, nxl, 0, P)) return 1;
     return run_z<LOGN>(c, true);
 }
 
 bool cgk_fft_supported(i64 N) { return N >= 16 && N <= 2048 && (N & (N - 1)) == 0; }
 
+#define CG_FFT_DISPATCH(FN, ...)                                                              \
+    switch (c->N) {                                                                           \
+        case 16: return FN<4>(__VA_ARGS__);                                                   \
+        case 32: return FN<5>(__VA_ARGS__);                                                   \
+        case 64: return FN<6>(__VA_ARGS__);                                                   \
+        case 128: return FN<7>(__VA_ARGS__);                                                  \
+        case 256: return FN<8>(__VA_ARGS__);                                                  \
+        case 512: return FN<9>(__VA_ARGS__);                                                  \
+        case 1024: return FN<10>(__VA_ARGS__);                                                \
+        case 2048: return FN<11>(__VA_ARGS__);                                                \
+    }                                                                                         \
+    cg_set_error("grid size %lld not supported by the hand-written FFT", (long long)c->N);    \
+    return 1;
+
 int cgk_fft(cg_ctx *c, int what, int deconv_order, double C, int long_range, double E) {
     KspaceParams P{c->ktab_n, c->ktab_s, deconv_order, long_range, C, E};
-    switch (c->N) {
-        case 16: return fft3d<4>(c, what, P);
-        case 32: return fft3d<5>(c, what, P);
-        case 64: return fft3d<6>(c, what, P);
-        case 128: return fft3d<7>(c, what, P);
-        case 256: return fft3d<8>(c, what, P);
-        case 512: return fft3d<9>(c, what, P);
-        case 1024: return fft3d<10>(c, what, P);
-        case 2048: return fft3d<11>(c, what, P);
-    }
-    cg_set_error("cgk_fft: grid size %lld not supported by the hand-written FFT", (long long)c->N);
-    return 1;
+    CG_FFT_DISPATCH(fft3d, c, what, P)
+}
+int cgk_fft_dist_forward(cg_ctx *c, double *send_buf) {
+    KspaceParams P{c->ktab_n, c->ktab_s, 0, 0, 0.0, 0.0};
+    CG_FFT_DISPATCH(fft_dist, c, 0, (double2 *)send_buf, P)
+}
+int cgk_fft_dist_xsolve(cg_ctx *c, double *buf, int deconv_order, double C, int long_range,
+                        double E) {
+    KspaceParams P{c->ktab_n, c->ktab_s, deconv_order, long_range, C, E};
+    CG_FFT_DISPATCH(fft_dist, c, 2, (double2 *)buf, P)
+}
+int cgk_fft_dist_backward(cg_ctx *c, const double *recv_buf) {
+    KspaceParams P{c->ktab_n, c->ktab_s, 0, 0, 0.0, 0.0};
+    CG_FFT_DISPATCH(fft_dist, c, 1, (double2 *)recv_buf, P)
 }

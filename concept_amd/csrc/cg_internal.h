@@ -50,17 +50,31 @@ struct CicGeom {
     double scale;   // (1/cellsize)*(1 - machine_eps)
 };
 
-// The mesh a particle kernel addresses: periodic (wrap) in every dimension on
-// a single domain.  Cell (i,j,k) of the PERIODIC global mesh lives at
-// base[(i*nj + j)*stride_j + k]; i,j,k are obtained from the reference's
-// ghosted index by subtracting nghosts and wrapping.
-struct MeshView {
-    double *base;
-    i64 n;         // global grid size N
-    i64 stride_i;  // doubles between consecutive i
-    i64 stride_j;  // doubles between consecutive j
-    int nghosts;
+// How a global x cell index maps to a layer of the local mesh buffer.
+// Single domain: the buffer is the whole periodic mesh (layer = x mod N).
+// x-slab domains (one per GPU): the buffer holds layers [x0-G, x0+nxl+G) of
+// the global mesh — nxl owned layers between G ghost layers — and y, z stay
+// periodic.  Cell (x, j, k) lives at mesh[(layer*N + j)*pad + k].
+struct XMap {
+    i64 x0;    // first owned global layer
+    i64 nxl;   // owned layers
+    int G;     // ghost layers on each side (0 when periodic)
+    int periodic;
 };
+__host__ __device__ inline i64 cg_xlayer(const XMap &m, i64 a, i64 N) {
+    if (m.periodic) {
+        a = a < 0 ? a + N : a;
+        return a >= N ? a - N : a;
+    }
+    i64 l = a - m.x0;
+    if (l < -(i64)m.G) l += N;             // periodic image across the box seam
+    else if (l >= m.nxl + m.G) l -= N;
+    l += m.G;
+    // a cell outside the local layers can only come from a particle this domain does
+    // not own (host-side contract: exchange before use); never index out of the buffer
+    l = l < 0 ? 0 : l;
+    return l >= m.nxl + 2 * m.G ? m.nxl + 2 * m.G - 1 : l;
+}
 
 // Tile decomposition used for the particle memory order and the LDS-tiled
 // deposit / gather kernels.
@@ -73,7 +87,9 @@ struct cg_ctx {
     cg_params p;
     hipStream_t stream = nullptr;
     i64 N = 0, pad = 0;          // grid size and padded innermost length N+2
-    double *mesh = nullptr;      // double[N][N][N+2]
+    XMap xmap{};                 // local layers of the mesh buffer
+    double *mesh = nullptr;      // double[layers][N][pad], layers = nxl + 2G
+    double *mesh0 = nullptr;     // first OWNED layer (= mesh + G*N*pad)
     i64 mesh_doubles = 0;
     double *fetch_tmp = nullptr; // lazily allocated, for CG_FETCH_MESH_FOURIER
     // k-space tables: numerator n(k) and denominator sin(n(k)) by array index
@@ -108,6 +124,12 @@ int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst);
 int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
              double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out);
 bool cgk_fft_supported(i64 N);
+int cgk_fft_dist_forward(cg_ctx *c, double *send_buf);
+int cgk_fft_dist_xsolve(cg_ctx *c, double *buf, int deconv_order, double C, int long_range,
+                        double E);
+int cgk_fft_dist_backward(cg_ctx *c, const double *recv_buf);
+int cgk_layers_write(cg_ctx *c, i64 layer0, i64 nlayers, const double *src, int add);
+int cgk_owner_rank(cg_ctx *c, const double *pos, i64 n, int *owner);
 // what: 0 forward, 1 backward, 2 forward + Poisson kernel + backward (fused)
 int cgk_fft(cg_ctx *c, int what, int deconv_order, double C, int long_range, double E);
 int cgk_deposit_cic_tiled(cg_ctx *c, const double *pos, i64 n, const unsigned *tile_offset,

@@ -46,14 +46,14 @@ __device__ __forceinline__ i64 wrap(i64 a, i64 n) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_deposit_cic_direct(const double *__restrict__ pos, i64 n,
                                                             double *__restrict__ mesh, i64 N,
-                                                            i64 pad, int g, CicGeom geo,
+                                                            i64 pad, int g, XMap xm, CicGeom geo,
                                                             double contribution) {
     i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         Cic1 cx = cic1(pos[3 * p + 0], geo.off[0], geo.scale);
         Cic1 cy = cic1(pos[3 * p + 1], geo.off[1], geo.scale);
         Cic1 cz = cic1(pos[3 * p + 2], geo.off[2], geo.scale);
-        i64 i0 = wrap(cx.index - g, N), i1 = wrap(cx.index - g + 1, N);
+        i64 i0 = cg_xlayer(xm, cx.index - g, N), i1 = cg_xlayer(xm, cx.index - g + 1, N);
         i64 j0 = wrap(cy.index - g, N), j1 = wrap(cy.index - g + 1, N);
         i64 k0 = wrap(cz.index - g, N), k1 = wrap(cz.index - g + 1, N);
         // mesh.py:5142-5155: ((w_x*contribution)*w_y)*w_z
@@ -77,7 +77,7 @@ int cgk_deposit_cic(cg_ctx *c, const double *pos, i64 n, double contribution) {
     i64 blocks = (n + block - 1) / block;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(k_deposit_cic_direct, dim3((unsigned)blocks), dim3(block), 0, c->stream, pos,
-                       n, c->mesh, c->N, c->pad, c->p.nghosts, c->geom_deposit, contribution);
+                       n, c->mesh, c->N, c->pad, c->p.nghosts, c->xmap, c->geom_deposit, contribution);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -146,8 +146,8 @@ template <int ORDER>
 __global__ __launch_bounds__(256) void k_gather_kick_direct(const double *__restrict__ pos,
                                                             double *__restrict__ mom, i64 n,
                                                             const double *__restrict__ mesh, i64 N,
-                                                            i64 pad, int g, CicGeom geo, double c1,
-                                                            double c2, double factor) {
+                                                            i64 pad, int g, XMap xm, CicGeom geo,
+                                                            double c1, double c2, double factor) {
     constexpr int H = ORDER / 2;      // stencil half width
     constexpr int W = 2 + 2 * H;      // cells needed per dimension
     i64 stride = (i64)gridDim.x * blockDim.x;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_gather_kick_direct(const double *__rest
         i64 ix[W], iy[W], iz[W];
 #pragma unroll
         for (int s = 0; s < W; s++) {
-            ix[s] = wrap(cx.index - g - H + s, N) * N * pad;
+            ix[s] = cg_xlayer(xm, cx.index - g - H + s, N) * N * pad;
             iy[s] = wrap(cy.index - g - H + s, N) * pad;
             iz[s] = wrap(cz.index - g - H + s, N);
         }
@@ -211,12 +211,12 @@ int cgk_gather_kick(cg_ctx *c, const double *pos, double *mom, i64 n, int diff_o
     if (diff_order == 2) {
         double c1 = (1.0 / 2) / dx;  // mesh.py:4967
         hipLaunchKernelGGL(k_gather_kick_direct<2>, dim3((unsigned)blocks), dim3(block), 0,
-                           c->stream, pos, mom, n, c->mesh, c->N, c->pad, c->p.nghosts,
+                           c->stream, pos, mom, n, c->mesh, c->N, c->pad, c->p.nghosts, c->xmap,
                            c->geom_gather, c1, 0.0, factor);
     } else {
         double c1 = (2.0 / 3) / dx, c2 = (1.0 / 12) / dx;  // mesh.py:4973-4977
         hipLaunchKernelGGL(k_gather_kick_direct<4>, dim3((unsigned)blocks), dim3(block), 0,
-                           c->stream, pos, mom, n, c->mesh, c->N, c->pad, c->p.nghosts,
+                           c->stream, pos, mom, n, c->mesh, c->N, c->pad, c->p.nghosts, c->xmap,
                            c->geom_gather, c1, c2, factor);
     }
     CG_LAUNCH_CHECK();
@@ -234,6 +234,55 @@ int cgk_cic_indices(cg_ctx *c, const double *pos, i64 n, int for_gather, i64 *id
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_cic_indices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                        pos, n, for_gather ? c->geom_gather : c->geom_deposit, idx);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// x-slab domains: halo layers.  A layer is a contiguous [N][pad] block, so the
+// ghost exchange (communication.py:563-660) needs no packing: the host comm
+// layer sends/receives whole layers; '+=' (deposit fold) is this add kernel,
+// '=' (ghost fill) a plain copy.  layer0 is relative to the first owned layer.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_layers_add(double2 *__restrict__ dst,
+                                                    const double2 *__restrict__ src, i64 n2) {
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < n2; v += stride) {
+        double2 a = dst[v], b = src[v];
+        a.x += b.x;
+        a.y += b.y;
+        dst[v] = a;
+    }
+}
+int cgk_layers_write(cg_ctx *c, i64 layer0, i64 nlayers, const double *src, int add) {
+    i64 per = c->N * c->pad;
+    double *dst = c->mesh0 + layer0 * per;
+    if (!add) {
+        CG_HIP(hipMemcpyAsync(dst, src, 8 * per * nlayers, hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    }
+    i64 n2 = per * nlayers / 2;
+    i64 blocks = (n2 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_layers_add, dim3((unsigned)blocks), dim3(256), 0, c->stream,
+                       (double2 *)dst, (const double2 *)src, n2);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// Owner domain of each particle: the x-slab that holds its lower CIC cell
+// (counterpart of which_domain(), communication.py:756-772, for slab domains).
+__global__ void k_owner_rank(const double *__restrict__ pos, i64 n, CicGeom geo, int g, i64 N,
+                             i64 nxl, int *__restrict__ owner) {
+    i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    i64 a = wrap(cic1(pos[3 * p], geo.off[0], geo.scale).index - g, N);
+    owner[p] = (int)(a / nxl);
+}
+int cgk_owner_rank(cg_ctx *c, const double *pos, i64 n, int *owner) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_owner_rank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       pos, n, c->geom_deposit, c->p.nghosts, c->N, c->xmap.nxl, owner);
     CG_LAUNCH_CHECK();
     return 0;
 }

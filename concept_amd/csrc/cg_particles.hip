@@ -86,9 +86,12 @@ __device__ __forceinline__ i64 lower_cell(double pos, double off, double scale, 
 // the tile in dimension d, i.e. the CIC cloud reaches the next tile there
 // (bit 2: x, bit 1: y, bit 0: z).  The pull-deposit of a tile reads its own 8
 // buckets plus the matching boundary buckets of its 7 lower neighbours.
+constexpr unsigned kNoTile = 0xffffffffu;
 __device__ __forceinline__ unsigned tile_of(double x, double y, double z, const CicGeom &geo,
-                                            int g, i64 N, const TileGeom &t) {
-    unsigned ca = (unsigned)lower_cell(x, geo.off[0], geo.scale, g, N);
+                                            int g, i64 N, const TileGeom &t, i64 x0) {
+    i64 cx = lower_cell(x, geo.off[0], geo.scale, g, N) - x0;  // local layer of this domain
+    if (cx < 0 || cx >= (i64)t.ntx * t.tx) return kNoTile;      // not owned here
+    unsigned ca = (unsigned)cx;
     unsigned cb = (unsigned)lower_cell(y, geo.off[1], geo.scale, g, N);
     unsigned cc = (unsigned)lower_cell(z, geo.off[2], geo.scale, g, N);
     unsigned T = (unsigned)t.tx;
@@ -111,17 +114,15 @@ __device__ __forceinline__ void wave_runs(unsigned key, int lane, int &run_start
     run_len = next - run_start;
 }
 
-constexpr unsigned kNoTile = 0xffffffffu;
-
 __global__ __launch_bounds__(256) void k_tile_histogram(const double *__restrict__ pos, i64 n,
                                                         CicGeom geo, int g, i64 N, TileGeom t,
-                                                        unsigned *__restrict__ count) {
+                                                        i64 x0, unsigned *__restrict__ count) {
     i64 stride = (i64)gridDim.x * blockDim.x;
     int lane = threadIdx.x & 63;
     for (i64 base = (i64)blockIdx.x * blockDim.x; base < n; base += stride) {
         i64 p = base + threadIdx.x;
         unsigned key = kNoTile;
-        if (p < n) key = tile_of(pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], geo, g, N, t);
+        if (p < n) key = tile_of(pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], geo, g, N, t, x0);
         int rs, rl;
         wave_runs(key, lane, rs, rl);
         if (lane == rs && key != kNoTile) atomicAdd(&count[key], (unsigned)rl);
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_tile_histogram(const double *__restrict
 __global__ __launch_bounds__(256) void k_tile_scatter(
     const double *__restrict__ pos, const double *__restrict__ mom, const i64 *__restrict__ ids,
     double *__restrict__ pos_out, double *__restrict__ mom_out, i64 *__restrict__ ids_out, i64 n,
-    CicGeom geo, int g, i64 N, TileGeom t, const unsigned *__restrict__ offset,
+    CicGeom geo, int g, i64 N, TileGeom t, i64 x0, const unsigned *__restrict__ offset,
     unsigned *__restrict__ cursor) {
     i64 stride = (i64)gridDim.x * blockDim.x;
     int lane = threadIdx.x & 63;
@@ -143,14 +144,15 @@ __global__ __launch_bounds__(256) void k_tile_scatter(
             x = pos[3 * p];
             y = pos[3 * p + 1];
             z = pos[3 * p + 2];
-            key = tile_of(x, y, z, geo, g, N, t);
+            key = tile_of(x, y, z, geo, g, N, t, x0);
         }
         int rs, rl;
         wave_runs(key, lane, rs, rl);
         unsigned first = 0;
         if (lane == rs && key != kNoTile) first = offset[key] + atomicAdd(&cursor[key], (unsigned)rl);
         first = __shfl(first, rs);
-        if (p < n) {
+        if (p < n && key != kNoTile) {  // particles of other domains are dropped (the host
+                                        // exchanges them before sorting; table[last] = kept)
             i64 s = (i64)first + (lane - rs);
             pos_out[3 * s] = x;
             pos_out[3 * s + 1] = y;
@@ -172,7 +174,7 @@ int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *i
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (n > 0) {
         hipLaunchKernelGGL(k_tile_histogram, dim3((unsigned)blocks), dim3(256), 0, c->stream,
-                           pos_in, n, c->geom_deposit, c->p.nghosts, c->N, c->tiles,
+                           pos_in, n, c->geom_deposit, c->p.nghosts, c->N, c->tiles, c->xmap.x0,
                            c->tile_count);
         CG_LAUNCH_CHECK();
     }
@@ -191,7 +193,8 @@ int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *i
     if (n > 0) {
         hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos_in,
                            mom_in, ids_in, pos_out, mom_out, ids_out, n, c->geom_deposit,
-                           c->p.nghosts, c->N, c->tiles, tile_offset_out, c->tile_cursor);
+                           c->p.nghosts, c->N, c->tiles, c->xmap.x0, tile_offset_out,
+                           c->tile_cursor);
         CG_LAUNCH_CHECK();
     }
     return 0;

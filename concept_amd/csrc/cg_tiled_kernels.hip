@@ -65,24 +65,30 @@ __device__ __forceinline__ unsigned tile_for_block(unsigned b, unsigned ntiles) 
 template <int T, bool ACCUMULATE>
 __global__ __launch_bounds__(512) void k_deposit_cic_pull(
     const double *__restrict__ pos, const unsigned *__restrict__ table,
-    double *__restrict__ mesh, i64 N, i64 pad, int g, int nt, unsigned ntiles, CicGeom geo,
-    double contribution) {
+    double *__restrict__ mesh, i64 N, i64 pad, int g, int ntx, int nt, unsigned nblocks,
+    XMap xm, CicGeom geo, double contribution) {
+    // tiles: ntx rows along x (this domain's), nt along y and z.  An x-slab domain has
+    // one extra row ta == ntx: the ghost layer that receives the CIC clouds sticking out
+    // of the last owned layer (sent to the next domain and added there).
     constexpr int NL = T * T * T;
     __shared__ double lds[NL];
     __shared__ unsigned seg_beg[64], seg_end_prefix[65];
-    const unsigned tile = tile_for_block(blockIdx.x, ntiles);
+    const unsigned tile = tile_for_block(blockIdx.x, nblocks);
     const int tc = tile % nt, tb = (tile / nt) % nt, ta = tile / (nt * nt);
-    const i64 T0a = (i64)ta * T, T0b = (i64)tb * T, T0c = (i64)tc * T;
+    const i64 T0a = xm.x0 + (i64)ta * T, T0b = (i64)tb * T, T0c = (i64)tc * T;
     for (int idx = threadIdx.x; idx < NL; idx += 512) lds[idx] = 0;
     if (threadIdx.x < 64) {
         // segment (d, f): bucket f of the neighbour d steps back
         int d = threadIdx.x >> 3, f = threadIdx.x & 7;
         int na = ta - ((d >> 2) & 1), nb = tb - ((d >> 1) & 1), nc = tc - (d & 1);
-        na = na < 0 ? na + nt : na;
+        if (xm.periodic) na = na < 0 ? na + ntx : na;
         nb = nb < 0 ? nb + nt : nb;
         nc = nc < 0 ? nc + nt : nc;
-        unsigned e = ((unsigned)((na * nt + nb) * nt + nc)) * 8u + (unsigned)f;
-        unsigned b0 = table[e], cnt = ((f & d) == d) ? table[e + 1] - b0 : 0u;
+        // slab domain: the row below the first one is another domain's (its clouds
+        // arrive through the halo add), the ghost row itself holds no particles
+        bool have = (f & d) == d && na >= 0 && na < ntx;
+        unsigned e = have ? ((unsigned)((na * nt + nb) * nt + nc)) * 8u + (unsigned)f : 0u;
+        unsigned b0 = table[e], cnt = have ? table[e + 1] - b0 : 0u;
         // inclusive scan of cnt over the 64 lanes of this (first) wave
         unsigned incl = cnt;
 #pragma unroll
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(512) void k_deposit_cic_pull(
         // lower cell relative to this tile: -1 .. T-1 (periodic)
         i64 la = wrap(cx.index - g, N) - T0a, lb = wrap(cy.index - g, N) - T0b,
             lc = wrap(cz.index - g, N) - T0c;
-        la = la >= T ? la - N : la;
+        la = (xm.periodic && la >= T) ? la - N : la;
         lb = lb >= T ? lb - N : lb;
         lc = lc >= T ? lc - N : lc;
 #pragma unroll
@@ -129,9 +135,12 @@ __global__ __launch_bounds__(512) void k_deposit_cic_pull(
             }
     }
     __syncthreads();
+    const int a_end = (ta == ntx) ? 1 : T;  // of the ghost row only its first layer exists
     for (int idx = threadIdx.x; idx < NL; idx += 512) {
         int c = idx % T, b = (idx / T) % T, a = idx / (T * T);
-        double *dst = mesh + ((T0a + a) * N + (T0b + b)) * pad + (T0c + c);
+        if (a >= a_end) break;
+        i64 layer = xm.periodic ? (T0a + a) : ((i64)ta * T + a + xm.G);
+        double *dst = mesh + (layer * N + (T0b + b)) * pad + (T0c + c);
         if (ACCUMULATE) *dst += lds[idx];  // cells are exclusively owned: no atomics needed
         else *dst = lds[idx];
     }
@@ -140,15 +149,16 @@ __global__ __launch_bounds__(512) void k_deposit_cic_pull(
 template <int T>
 static int launch_deposit(cg_ctx *c, const double *pos, const unsigned *table,
                           double contribution, int accumulate) {
-    unsigned nt = (unsigned)c->ntiles;
+    int rows = c->tiles.ntx + (c->xmap.periodic ? 0 : 1);
+    unsigned nb = (unsigned)((i64)rows * c->tiles.nty * c->tiles.ntz);
     if (accumulate)
-        hipLaunchKernelGGL((k_deposit_cic_pull<T, true>), dim3(nt), dim3(512), 0, c->stream, pos,
-                           table, c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.ntx, nt,
-                           c->geom_deposit, contribution);
+        hipLaunchKernelGGL((k_deposit_cic_pull<T, true>), dim3(nb), dim3(512), 0, c->stream, pos,
+                           table, c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.ntx, c->tiles.nty,
+                           nb, c->xmap, c->geom_deposit, contribution);
     else
-        hipLaunchKernelGGL((k_deposit_cic_pull<T, false>), dim3(nt), dim3(512), 0, c->stream, pos,
-                           table, c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.ntx, nt,
-                           c->geom_deposit, contribution);
+        hipLaunchKernelGGL((k_deposit_cic_pull<T, false>), dim3(nb), dim3(512), 0, c->stream, pos,
+                           table, c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.ntx, c->tiles.nty,
+                           nb, c->xmap, c->geom_deposit, contribution);
     return 0;
 }
 
@@ -191,7 +201,7 @@ template <int ORDER, int T>
 __global__ __launch_bounds__(512) void k_gather_kick_tiled(
     const double *__restrict__ pos, double *__restrict__ mom,
     const unsigned *__restrict__ tile_offset, const double *__restrict__ mesh, i64 N, i64 pad,
-    int g, int nt, unsigned ntiles, CicGeom geo, double c1, double c2, double factor) {
+    int g, int nt, unsigned ntiles, XMap xm, CicGeom geo, double c1, double c2, double factor) {
     constexpr int H = ORDER / 2;
     constexpr int E = T + 1 + 2 * H;  // cells [T0-H, T0+T+H]
     constexpr int NL = E * E * E;
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(512) void k_gather_kick_tiled(
     const i64 beg = tile_offset[8 * tile], end = tile_offset[8 * tile + 8];
     if (beg == end) return;  // uniform for the workgroup
     const int tc = tile % nt, tb = (tile / nt) % nt, ta = tile / (nt * nt);
-    const i64 T0a = (i64)ta * T, T0b = (i64)tb * T, T0c = (i64)tc * T;
+    const i64 T0a = xm.x0 + (i64)ta * T, T0b = (i64)tb * T, T0c = (i64)tc * T;
     {
         // stage the potential tile + stencil halo: all loads of a lane issued before
         // the first LDS store, so they overlap instead of paying HBM latency serially
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(512) void k_gather_kick_tiled(
             int idx = threadIdx.x + r * 512;
             if (idx < NL) {
                 int c = idx % E, b = (idx / E) % E, a = idx / (E * E);
-                i64 gi = wrap(T0a - H + a, N), gj = wrap(T0b - H + b, N),
+                i64 gi = cg_xlayer(xm, T0a - H + a, N), gj = wrap(T0b - H + b, N),
                     gk = wrap(T0c - H + c, N);
                 v[r] = mesh[(gi * N + gj) * pad + gk];
             }
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(512) void k_gather_kick_tiled(
             i64 ix[W], iy[W], iz[W];
 #pragma unroll
             for (int s = 0; s < W; s++) {
-                ix[s] = wrap(ga - H + s, N) * N * pad;
+                ix[s] = cg_xlayer(xm, ga - H + s, N) * N * pad;
                 iy[s] = wrap(gb - H + s, N) * pad;
                 iz[s] = wrap(gc - H + s, N);
             }
@@ -306,8 +316,8 @@ static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsign
     }
     unsigned nt = (unsigned)c->ntiles;
     hipLaunchKernelGGL(kern, dim3(nt), dim3(512), lds, c->stream, pos, mom, tile_offset, c->mesh,
-                       c->N, c->pad, c->p.nghosts, c->tiles.ntx, nt, c->geom_gather, c1, c2,
-                       factor);
+                       c->N, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap, c->geom_gather, c1,
+                       c2, factor);
     return 0;
 }
 

@@ -1,0 +1,264 @@
+"""concept_amd.distributed — the PM path sharded over the GPUs of one node.
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).
+Decomposition: x-SLAB DOMAINS for everything.  Rank r owns the
+mesh layers x in [r*N/P, (r+1)*N/P) and the particles whose lower CIC cell
+lies there.  This replaces the reference's pair of decompositions — 3-D
+domains for particles/real-space grids, x-slabs for the FFT
+(communication.py:692-741, mesh.py:1935-1942) — so its slab<->domain remaps
+(mesh.py:2138-2411) vanish, every halo is a contiguous block of mesh layers
+exchanged with the two ring neighbours, and the only all-to-all is the FFT
+transpose.  Results do not depend on the decomposition beyond summation order
+(the reference's own bar: test/nprocs_pm/analyze.py:121, 1e-9).
+
+Exchange steps per PM kick (what replaces which MPI call site):
+  deposit ghost fold   communicate_ghosts(grid,'+=')  1 layer  -> next rank, added
+  FFT transpose        FFTW-MPI alltoall (fft.c:240)  all_to_all_single, twice
+  potential ghosts     communicate_ghosts(grid,'=')   G layers <-> both neighbours
+  particle exchange    exchange() (communication.py:135-517) after each drift
+The pack/unpack of the transpose is fused into the y pass of the FFT
+(cg_fft.hip), the halos need no packing at all.
+
+The same code runs under the "gloo" backend (tests: two ranks sharing one GPU,
+or CPU-only checks of the exchange logic) by staging messages through host
+memory; that path is for tests only.
+"""
+import torch
+import torch.distributed as dist
+
+from . import lib
+from .mesh import PotentialMesh
+
+DEAD_X_FACTOR = -4.0  # pos.x = DEAD_X_FACTOR*boxsize marks a vacated particle slot
+
+
+class Comm:
+    """Thin wrapper over torch.distributed that also works on gloo."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.stage = self.backend != 'nccl'  # gloo: stage device tensors through the host
+
+    def all_to_all(self, out, inp, out_splits=None, in_splits=None):
+        if not self.stage:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+            return
+        # gloo: pairwise exchange of the blocks through host memory
+        P = self.world
+        src = inp.cpu()
+        if in_splits is None:
+            in_splits = [src.shape[0]//P]*P
+            out_splits = [out.shape[0]//P]*P
+        ichunks = list(torch.split(src, in_splits))
+        res = torch.empty(out.shape, dtype=out.dtype)
+        ochunks = list(torch.split(res, out_splits))
+        ops = []
+        for q in range(P):
+            if q == self.rank:
+                ochunks[q].copy_(ichunks[q])
+            else:
+                if ichunks[q].numel():
+                    ops.append(dist.P2POp(dist.isend, ichunks[q].contiguous(), q,
+                                          group=self.group))
+                if ochunks[q].numel():
+                    ops.append(dist.P2POp(dist.irecv, ochunks[q], q, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        out.copy_(res)
+
+    def sendrecv(self, send, dest, recv, source):
+        """send -> dest while receiving <- source (a ring shift)."""
+        if dest == self.rank and source == self.rank:
+            recv.copy_(send)
+            return
+        if self.stage:
+            s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+        else:
+            s, r = send, recv
+        ops = [dist.P2POp(dist.isend, s, dest, group=self.group),
+               dist.P2POp(dist.irecv, r, source, group=self.group)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if self.stage:
+            recv.copy_(r)
+
+    def all_gather_ints(self, values):
+        t = torch.tensor(values, dtype=torch.int64)
+        if not self.stage:
+            t = t.cuda()
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return torch.stack(out).cpu()
+
+
+class SlabDomain:
+    """The mesh side of one rank: local mesh slab + exchange buffers."""
+
+    def __init__(self, gridsize, boxsize, nghosts=2, device=None, group=None):
+        self.comm = Comm(group)
+        self.rank, self.world = self.comm.rank, self.comm.world
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.mesh = PotentialMesh(gridsize, boxsize, nghosts=nghosts, device=self.device,
+                                  nprocs=self.world, rank=self.rank)
+        m = self.mesh
+        self.N, self.nxl, self.G = m.gridsize, m.nxl, m.ghost_layers
+        self.boxsize = float(boxsize)
+        per = m.gridsize*m.pad
+        self._layer = per
+        self.tbuf_a = torch.empty(m.transpose_doubles, dtype=torch.float64, device=self.device)
+        self.tbuf_b = torch.empty(m.transpose_doubles, dtype=torch.float64, device=self.device)
+        self.halo_s = torch.empty(self.G*per, dtype=torch.float64, device=self.device)
+        self.halo_r = torch.empty(self.G*per, dtype=torch.float64, device=self.device)
+        self.next = (self.rank + 1) % self.world
+        self.prev = (self.rank - 1) % self.world
+
+    # communicate_ghosts(grid, '+=') after the deposit (mesh.py:609)
+    def fold_deposit_ghost(self):
+        per = self._layer
+        s, r = self.halo_s[:per], self.halo_r[:per]
+        self.mesh.layers_read(self.nxl, 1, s)
+        self.comm.sendrecv(s, self.next, r, self.prev)
+        self.mesh.layers_write(0, 1, r, add=True)
+
+    # communicate_ghosts(grid, '=') of the potential (interactions.py:2303-2307)
+    def fill_potential_ghosts(self):
+        G = self.G
+        # my first G layers -> previous rank's upper ghosts [nxl, nxl+G)
+        self.mesh.layers_read(0, G, self.halo_s)
+        self.comm.sendrecv(self.halo_s, self.prev, self.halo_r, self.next)
+        self.mesh.layers_write(self.nxl, G, self.halo_r, add=False)
+        # my last G layers -> next rank's lower ghosts [-G, 0)
+        self.mesh.layers_read(self.nxl - G, G, self.halo_s)
+        self.comm.sendrecv(self.halo_s, self.next, self.halo_r, self.prev)
+        self.mesh.layers_write(-G, G, self.halo_r, add=False)
+
+    # A3..A8 with the transpose (fft.c:240-257) as all_to_all_single
+    def poisson_solve(self, deconv_order, C, long_range=False, E=0.0):
+        m = self.mesh
+        m.dist_fft_forward(self.tbuf_a)
+        self.comm.all_to_all(self.tbuf_b, self.tbuf_a)
+        m.dist_fft_xsolve(self.tbuf_b, deconv_order, C, long_range, E)
+        self.comm.all_to_all(self.tbuf_a, self.tbuf_b)
+        m.dist_fft_backward(self.tbuf_a)
+
+
+class DistributedParticles:
+    """Particles of one rank: arrays with spare capacity, n valid entries."""
+
+    def __init__(self, domain, pos, mom, ids=None, slack=1.3):
+        self.domain = domain
+        n = pos.shape[0]
+        cap = int(n*slack) + 1024
+        dev = domain.device
+        self.cap = cap
+        self.n = n
+        self.pos = torch.zeros((cap, 3), dtype=torch.float64, device=dev)
+        self.mom = torch.zeros((cap, 3), dtype=torch.float64, device=dev)
+        self.ids = torch.zeros(cap, dtype=torch.int64, device=dev)
+        self.pos[:n] = pos
+        self.mom[:n] = mom
+        if ids is not None:
+            self.ids[:n] = ids
+        self.pos2 = torch.empty_like(self.pos)
+        self.mom2 = torch.empty_like(self.mom)
+        self.ids2 = torch.empty_like(self.ids)
+        self.table = domain.mesh.new_tile_table()
+        self.sorted = False
+
+    def view(self, name):
+        return getattr(self, name)[:self.n]
+
+    def drift(self, dt_over_mass):
+        self.domain.mesh.drift(self.view('pos'), self.view('mom'), dt_over_mass)
+        self.sorted = False
+
+    def exchange(self):
+        """exchange() (communication.py:135-517): re-home particles whose lower CIC
+        cell left this rank's slab."""
+        d = self.domain
+        owner = d.mesh.owner_rank(self.view('pos'))
+        self.n, self._expected = exchange_rows(
+            d.comm, owner, self.pos, self.mom, self.ids, self.n, self.cap,
+            DEAD_X_FACTOR*d.boxsize)
+        self.sorted = False
+
+    def tile_sort(self):
+        d = self.domain
+        d.mesh.sort_particles(self.view('pos'), self.view('mom'), self.view('ids'),
+                              self.pos2[:self.n], self.mom2[:self.n], self.ids2[:self.n],
+                              self.table)
+        self.pos, self.pos2 = self.pos2, self.pos
+        self.mom, self.mom2 = self.mom2, self.mom
+        self.ids, self.ids2 = self.ids2, self.ids
+        kept = int(self.table[-1].item()) & 0xffffffff
+        expected = getattr(self, '_expected', self.n)
+        if kept != expected:
+            raise lib.ConceptGPUError(
+                f'rank {d.rank}: tile sort kept {kept} of {expected} particles — particles '
+                'outside this rank\'s slab (exchange() must run after every drift)')
+        self.n = kept
+        self._expected = kept
+        self.sorted = True
+
+
+def exchange_rows(comm, owner, pos, mom, ids, n, cap, dead_x):
+    """Move the particles with owner != comm.rank to their owners (all-to-all-v of
+    rows pos(3) mom(3) id(1)).  Vacated slots are refilled with immigrants, surplus
+    immigrants are appended after slot n, leftover holes get pos.x = dead_x (the tile
+    sort drops them).  Works on any device.  Returns (n_slots, n_alive)."""
+    P, rank = comm.world, comm.rank
+    dev = pos.device
+    move_idx = torch.nonzero(owner[:n] != rank).flatten()
+    dest = owner[move_idx].long()
+    order = torch.argsort(dest, stable=True)
+    move_idx, dest = move_idx[order], dest[order]
+    send_counts = torch.bincount(dest, minlength=P).cpu().tolist()
+    rows = torch.empty((move_idx.numel(), 7), dtype=torch.float64, device=dev)
+    rows[:, 0:3] = pos[move_idx]
+    rows[:, 3:6] = mom[move_idx]
+    rows[:, 6] = ids[move_idx].view(torch.float64)
+    counts = comm.all_gather_ints(send_counts)  # counts[src][dst]
+    recv_counts = counts[:, rank].tolist()
+    m_in, m_out = int(sum(recv_counts)), int(move_idx.numel())
+    inc = torch.empty((m_in, 7), dtype=torch.float64, device=dev)
+    comm.all_to_all(inc, rows, recv_counts, send_counts)
+    k = min(m_in, m_out)
+    if k:
+        h = move_idx[:k]
+        pos[h] = inc[:k, 0:3]
+        mom[h] = inc[:k, 3:6]
+        ids[h] = inc[:k, 6].contiguous().view(torch.int64)
+    n_slots = n
+    if m_in > k:
+        extra = m_in - k
+        if n + extra > cap:
+            raise lib.ConceptGPUError(
+                f'rank {rank}: particle capacity {cap} exceeded ({n + extra})')
+        pos[n:n + extra] = inc[k:, 0:3]
+        mom[n:n + extra] = inc[k:, 3:6]
+        ids[n:n + extra] = inc[k:, 6].contiguous().view(torch.int64)
+        n_slots = n + extra
+    elif m_out > k:
+        pos[move_idx[k:], 0] = dead_x
+    return n_slots, n - m_out + m_in
+
+
+def pm_kick(domain, particles, contribution, deconv_order, C, kick_factor, diff_order=2,
+            long_range=False, E=0.0):
+    """One long-range PM kick of a tile-sorted particle set onto itself, sharded
+    (particle_mesh(), interactions.py:1985-2335)."""
+    if not particles.sorted:
+        raise lib.ConceptGPUError('pm_kick: particles must be exchanged and tile-sorted')
+    m = domain.mesh
+    m.deposit_tiled(particles.view('pos'), particles.table, contribution, accumulate=False)
+    domain.fold_deposit_ghost()
+    domain.poisson_solve(deconv_order, C, long_range, E)
+    domain.fill_potential_ghosts()
+    m.gather_kick_tiled(particles.view('pos'), particles.view('mom'), particles.table,
+                        diff_order, kick_factor)

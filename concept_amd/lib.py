@@ -55,6 +55,13 @@ SYMBOLS = {
     'cg_drift': (_int, [_vp, _vp, _vp, _i64, _dbl]),
     'cg_sort_particles': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'cg_tile_info': (_int, [_vp, ctypes.POINTER(ctypes.c_int64*3)]),
+    'cg_local_info': (_int, [_vp, ctypes.POINTER(ctypes.c_int64*6)]),
+    'cg_layers_read': (_int, [_vp, _i64, _i64, _vp]),
+    'cg_layers_write': (_int, [_vp, _i64, _i64, _vp, _int]),
+    'cg_dist_fft_forward': (_int, [_vp, _vp]),
+    'cg_dist_fft_xsolve': (_int, [_vp, _vp, _int, _dbl, _int, _dbl]),
+    'cg_dist_fft_backward': (_int, [_vp, _vp]),
+    'cg_owner_rank': (_int, [_vp, _vp, _i64, _vp]),
     'cg_fetch': (_int, [_vp, _int, _vp, _i64]),
     'cg_cic_indices': (_int, [_vp, _vp, _i64, _int, _vp]),
 }

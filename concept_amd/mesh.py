@@ -22,7 +22,7 @@ def _ptr(t):
 
 class PotentialMesh:
     def __init__(self, gridsize, boxsize, nghosts=2, cell_centered=True, interp_order=2,
-                 device=None):
+                 device=None, nprocs=1, rank=0):
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device('cuda', device) if isinstance(device, int) else device
@@ -36,8 +36,8 @@ class PotentialMesh:
         p.cell_centered = int(cell_centered)
         p.interp_order = int(interp_order)
         p.device = self.device.index or 0
-        p.nprocs, p.rank = 1, 0
-        p.subdiv[0] = p.subdiv[1] = p.subdiv[2] = 1
+        p.nprocs, p.rank = int(nprocs), int(rank)
+        p.subdiv[0], p.subdiv[1], p.subdiv[2] = int(nprocs), 1, 1  # x-slab domains
         self._ctx = ctypes.c_void_p()
         check(_L.cg_create(ctypes.byref(p), ctypes.byref(self._ctx)))
         self.use_stream(torch.cuda.current_stream(self.device))
@@ -45,7 +45,12 @@ class PotentialMesh:
         check(_L.cg_tile_info(self._ctx, ctypes.byref(info)))
         self.tile_extent, self.tiles_per_dim, self.table_entries = (
             int(info[0]), int(info[1]), int(info[2]))
-        self.ntiles = self.tiles_per_dim**3
+        linfo = (ctypes.c_int64*6)()
+        check(_L.cg_local_info(self._ctx, ctypes.byref(linfo)))
+        (self.x0, self.nxl, self.ghost_layers, _, self.pad, self.transpose_doubles) = (
+            int(v) for v in linfo)
+        self.nprocs, self.rank = int(nprocs), int(rank)
+        self.ntiles = (self.table_entries - 1)//8
 
     def close(self):
         if self._ctx:
@@ -150,9 +155,32 @@ class PotentialMesh:
         return tile_offset
 
     # -- debug / parity -----------------------------------------------------
+    # -- x-slab domains (multi-GPU) -------------------------------------------
+    def layers_read(self, layer0, nlayers, dst):
+        check(_L.cg_layers_read(self._ctx, int(layer0), int(nlayers), _ptr(dst)))
+
+    def layers_write(self, layer0, nlayers, src, add=False):
+        check(_L.cg_layers_write(self._ctx, int(layer0), int(nlayers), _ptr(src), int(add)))
+
+    def dist_fft_forward(self, send_buf):
+        check(_L.cg_dist_fft_forward(self._ctx, _ptr(send_buf)))
+
+    def dist_fft_xsolve(self, buf, deconv_order, C, long_range=False, E=0.0):
+        check(_L.cg_dist_fft_xsolve(self._ctx, _ptr(buf), int(deconv_order), float(C),
+                                    int(long_range), float(E)))
+
+    def dist_fft_backward(self, recv_buf):
+        check(_L.cg_dist_fft_backward(self._ctx, _ptr(recv_buf)))
+
+    def owner_rank(self, pos):
+        n = self._check_particles(pos)
+        out = torch.empty(n, dtype=torch.int32, device=pos.device)
+        check(_L.cg_owner_rank(self._ctx, _ptr(pos), n, _ptr(out)))
+        return out
+
     def fetch(self, which):
         N = self.gridsize
-        out = np.empty((N, N, N + 2), dtype=np.float64)
+        out = np.empty((self.nxl, N, N + 2), dtype=np.float64)
         check(_L.cg_fetch(self._ctx, int(which), out.ctypes.data_as(ctypes.c_void_p), out.size))
         return out
 

@@ -52,8 +52,8 @@ typedef struct cg_params {
 
 /* which = selector for cg_fetch (debug / parity tests only) */
 enum {
-    CG_FETCH_MESH_REAL = 0,  /* the local real-space mesh, reference x-slab layout
-                                double[N/P][N][N+2] (mesh.py:1935-1942), padding included */
+    CG_FETCH_MESH_REAL = 0,  /* the owned layers of the real-space mesh, reference x-slab
+                                layout double[N/P][N][N+2] (mesh.py:1935-1942) */
     CG_FETCH_MESH_FOURIER = 1 /* the local Fourier slab in the reference's transposed
                                 layout double[j_local][i][N+2] re/im interleaved
                                 (fft.c:55-72, mesh.py:2716-2719) */
@@ -149,6 +149,36 @@ int cg_sort_particles(cg_ctx *ctx, const double *pos_in, const double *mom_in,
  * in that dimension (the CIC cloud then reaches the next tile).  Table entry
  * 8*t + f = index of the first particle of bucket f of tile t. */
 int cg_tile_info(const cg_ctx *ctx, int64_t info[3]);
+
+/* --- multi-GPU: x-slab domains ----------------------------------------------
+ * One context per GPU with params.nprocs = P, rank = r, subdiv = (P,1,1):
+ * domain r owns mesh layers x in [r*N/P, (r+1)*N/P) and the particles whose
+ * lower CIC cell lies there; its mesh buffer carries G ghost layers on each
+ * side; y and z stay periodic on every GPU.  This replaces the reference's
+ * 3-D domains + x-slabs (communication.py:692-741, mesh.py:1935-1942) by slabs
+ * for both, so the slab<->domain remaps (mesh.py:2138-2411) disappear and
+ * every halo is a contiguous block of layers.  The library does the local
+ * work; the exchanges themselves (RCCL through torch.distributed, or anything
+ * else) are the caller's, on the buffers named here:
+ *   ghost fold   communicate_ghosts(grid,'+=') : cg_layers_read(nxl, 1) -> next domain
+ *                                                 -> cg_layers_write(0, 1, add=1)
+ *   ghost fill   communicate_ghosts(grid,'=')  : cg_layers_read / cg_layers_write(add=0)
+ *   FFT          fft.c:240-257 (FFTW-MPI's all-to-all): cg_dist_fft_forward ->
+ *                all-to-all (equal blocks) -> cg_dist_fft_xsolve -> all-to-all back
+ *                -> cg_dist_fft_backward
+ *   exchange()   communication.py:135-517      : cg_owner_rank + caller-side moves
+ * info = {x0, nxl, G, N, pad, doubles in one transpose buffer (nxl*N*pad)} */
+int cg_local_info(const cg_ctx *ctx, int64_t info[6]);
+/* layer0 is relative to the first owned layer (-G .. nxl+G-1) */
+int cg_layers_read(cg_ctx *ctx, int64_t layer0, int64_t nlayers, double *dst /*DEV*/);
+int cg_layers_write(cg_ctx *ctx, int64_t layer0, int64_t nlayers, const double *src /*DEV*/,
+                    int add);
+int cg_dist_fft_forward(cg_ctx *ctx, double *send_buf /*DEV*/);
+int cg_dist_fft_xsolve(cg_ctx *ctx, double *buf /*DEV*/, int deconv_order, double C,
+                       int long_range, double E);
+int cg_dist_fft_backward(cg_ctx *ctx, const double *recv_buf /*DEV*/);
+int cg_owner_rank(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n,
+                  int32_t *owner_out /*DEV n*/);
 
 /* --- debug fetch (parity tests) -------------------------------------------- */
 int cg_fetch(cg_ctx *ctx, int which, double *out /*HOST*/, int64_t n_doubles);

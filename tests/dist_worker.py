@@ -1,0 +1,49 @@
+"""Worker of tests/test_gpu_distributed.py: one rank of a P-rank x-slab run.
+All ranks share cuda:0 and talk over gloo (test only; production is one GPU
+per rank over RCCL)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    out_dir, N, n_side, steps, backend = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), \
+        int(sys.argv[4]), sys.argv[5]
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) if backend == 'nccl' else 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    from concept_amd.distributed import DistributedParticles, SlabDomain, pm_kick
+    L = 64.0
+    dom = SlabDomain(N, L)
+    rng = np.random.default_rng(77)
+    n = n_side**3
+    pos = rng.uniform(0, L, (n, 3))
+    mom = rng.normal(0, 1.0, (n, 3))
+    pos_d = torch.tensor(pos, device='cuda')
+    owner = dom.mesh.owner_rank(pos_d).cpu().numpy()
+    mine = np.nonzero(owner == rank)[0]
+    parts = DistributedParticles(dom, pos_d[mine], torch.tensor(mom[mine], device='cuda'),
+                                 torch.tensor(mine, device='cuda'))
+    parts.tile_sort()
+    contribution, C, kick, dtm = 0.37, -2.5, -0.8, 0.9
+    for step in range(steps):
+        pm_kick(dom, parts, contribution, 4, C, kick, diff_order=2 + 2*(step % 2))
+        parts.drift(dtm)
+        parts.exchange()
+        parts.tile_sort()
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), ids=parts.view('ids').cpu().numpy(),
+             pos=parts.view('pos').cpu().numpy(), mom=parts.view('mom').cpu().numpy(),
+             dens=np.zeros(1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,112 @@
+"""world_size-2 (and 4) gloo tests of the multi-GPU exchange logic on CPU:
+the Comm wrapper, the particle exchange bookkeeping and the layout algebra of
+the FFT transpose (what the fused pack in cg_fft.hip writes / reads)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(fn, world, *args):
+    port = _free_port()
+    mp.spawn(_entry, args=(world, port, fn, args), nprocs=world, join=True)
+
+
+def _entry(rank, world, port, fn, args):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        fn(rank, world, *args)
+    finally:
+        dist.destroy_process_group()
+
+
+def _w_transpose(rank, world, N):
+    """send[q][i_local][j_in_block][kk] -> all-to-all -> [i_global][j_local][kk]."""
+    from concept_amd.distributed import Comm
+    comm = Comm()
+    cp = N//2 + 1
+    nxl = JB = N//world
+    rng = np.random.default_rng(0)
+    full = rng.normal(size=(N, N, cp))  # the global (i, j, kk) array, same on every rank
+    local = full[rank*nxl:(rank + 1)*nxl]  # my slab [i_local][j][kk]
+    send = np.empty((world, nxl, JB, cp))
+    for q in range(world):
+        send[q] = local[:, q*JB:(q + 1)*JB, :]
+    recv = torch.empty(world*nxl*JB*cp, dtype=torch.float64)
+    comm.all_to_all(recv, torch.from_numpy(send.reshape(-1)))
+    got = recv.numpy().reshape(N, JB, cp)  # [q*nxl + i_local][j_local][kk]
+    assert np.array_equal(got, full[:, rank*JB:(rank + 1)*JB, :])
+    # and back
+    back = torch.empty_like(recv)
+    comm.all_to_all(back, recv)
+    assert np.array_equal(back.numpy().reshape(world, nxl, JB, cp), send)
+
+
+def _w_ring(rank, world):
+    from concept_amd.distributed import Comm
+    comm = Comm()
+    s = torch.full((5,), float(rank), dtype=torch.float64)
+    r = torch.empty(5, dtype=torch.float64)
+    comm.sendrecv(s, (rank + 1) % world, r, (rank - 1) % world)
+    assert (r == float((rank - 1) % world)).all()
+    comm.sendrecv(s, (rank - 1) % world, r, (rank + 1) % world)
+    assert (r == float((rank + 1) % world)).all()
+
+
+def _w_exchange(rank, world, n_per):
+    from concept_amd.distributed import Comm, exchange_rows
+    comm = Comm()
+    L = 1.0
+    gen = torch.Generator().manual_seed(100 + rank)
+    cap = 3*n_per
+    pos = torch.zeros((cap, 3), dtype=torch.float64)
+    mom = torch.zeros((cap, 3), dtype=torch.float64)
+    ids = torch.zeros(cap, dtype=torch.int64)
+    n = n_per + 7*rank  # uneven populations
+    pos[:n] = torch.rand((n, 3), dtype=torch.float64, generator=gen)  # anywhere in the box
+    mom[:n] = pos[:n]*3 + 1
+    ids[:n] = torch.arange(n) + 10**6*rank
+    owner = torch.clamp((pos[:, 0]*world/L).long(), max=world - 1).int()
+    before = comm.all_gather_ints([n])[:, 0].sum().item()
+    n_slots, n_alive = exchange_rows(comm, owner, pos, mom, ids, n, cap, -4.0*L)
+    alive = pos[:n_slots, 0] > -1.0
+    assert int(alive.sum()) == n_alive
+    p, m, i = pos[:n_slots][alive], mom[:n_slots][alive], ids[:n_slots][alive]
+    own = torch.clamp((p[:, 0]*world/L).long(), max=world - 1)
+    assert (own == rank).all()           # everyone is home
+    assert torch.equal(m, p*3 + 1)       # rows stayed together
+    after = comm.all_gather_ints([n_alive])[:, 0].sum().item()
+    assert after == before               # nobody lost, nobody duplicated
+    all_ids = [None]*world
+    dist.all_gather_object(all_ids, i.tolist())
+    flat = sorted(x for l in all_ids for x in l)
+    assert len(flat) == len(set(flat)) == before
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_transpose_layout(world):
+    _run(_w_transpose, world, 16)
+
+
+def test_ring_sendrecv():
+    _run(_w_ring, 2)
+    _run(_w_ring, 3)
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_particle_exchange(world):
+    _run(_w_exchange, world, 500)
