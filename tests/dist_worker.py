@@ -31,7 +31,7 @@ def main():
     parts = DistributedParticles(dom, pos_d[mine], torch.tensor(mom[mine], device='cuda'),
                                  torch.tensor(mine, device='cuda'))
     parts.tile_sort()
-    contribution, C, kick, dtm = 0.37, -2.5, -0.8, 0.9
+    contribution, C, kick, dtm = 0.37, -2.5, -0.002, 0.9
     for step in range(steps):
         pm_kick(dom, parts, contribution, 4, C, kick, diff_order=2 + 2*(step % 2))
         parts.drift(dtm)

@@ -26,7 +26,7 @@ def single_domain(N, n_side, steps):
     n = n_side**3
     pos = torch.tensor(rng.uniform(0, L, (n, 3)), device='cuda')
     mom = torch.tensor(rng.normal(0, 1.0, (n, 3)), device='cuda')
-    contribution, C, kick, dtm = 0.37, -2.5, -0.8, 0.9
+    contribution, C, kick, dtm = 0.37, -2.5, -0.002, 0.9
     for step in range(steps):
         mesh.zero()
         mesh.deposit(pos, contribution)
