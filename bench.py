@@ -79,6 +79,72 @@ def cpu_baseline(sample_n=128, sample_grid=256, steps=12):
     }
 
 
+def main_distributed(args, name, n_p, N, L, dev, rank, world):
+    """Strong scaling: the same total workload on `world` x-slab domains, one per GPU
+    (concept_amd/distributed.py).  A step = drift + particle exchange + tile sort +
+    long-range kick (deposit, ghost fold, FFT with two all-to-all transposes, ghost
+    fill, gather-kick)."""
+    import torch
+    import torch.distributed as dist
+    from concept_amd.distributed import DistributedParticles, SlabDomain, pm_kick
+    dom = SlabDomain(N, L, device=dev)
+    n_local = n_p//world
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    pos = torch.rand((n_local, 3), dtype=torch.float64, device=dev, generator=gen)
+    # uniform inside this rank's slab: lower CIC cell x in [x0, x0 + nxl)  <=>
+    # x in [(x0 + 1/2) cells, (x0 + nxl + 1/2) cells), wrapped into the box
+    cell = L/N
+    pos[:, 0] = torch.remainder((dom.mesh.x0 + 0.5 + pos[:, 0]*dom.nxl*(1 - 1e-12))*cell, L)
+    pos[:, 1:] *= L
+    pos.clamp_(min=0.0, max=float(torch.nextafter(torch.tensor(L, dtype=torch.float64),
+                                                  torch.tensor(0.0, dtype=torch.float64))))
+    parts = DistributedParticles(dom, pos, torch.zeros_like(pos), None, slack=1.15)
+    del pos
+    parts.exchange()
+    parts.tile_sort()
+    mass, G, dt = 1.0, 1.0, 1e-4
+    contribution = mass*(float(N)**(-3)*(N/L)**3)
+    C = -L**2*G/3.141592653589793
+
+    def step():
+        parts.drift(dt/mass)
+        parts.exchange()
+        parts.tile_sort()
+        pm_kick(dom, parts, contribution, 4, C, mass*(-dt), diff_order=2)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    cnt = torch.tensor([parts.n], dtype=torch.int64, device=dev)
+    dist.all_reduce(cnt)
+    if rank != 0:
+        return
+    total = int(cnt.item())
+    print(json.dumps({
+        'metric': 'PM particle-updates/sec', 'value': total*args.steps/elapsed,
+        'unit': 'particle-updates/s', 'steps_per_sec': args.steps/elapsed, 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed/args.steps*1e3,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': f'{name}: {total} particles (uniform random) / {N}^3 PM mesh, '
+                               f'CIC, deconvolution order 4, FD order 2, {world} x-slab domains; '
+                               '1 PM step = drift + exchange + tile sort + long-range kick',
+                   'particles': total, 'gridsize': N, 'parallelism': f'xslab{world}'},
+        'roofline': None, 'cpu_baseline': None,
+    }))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -99,20 +165,26 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
+    # CONCEPT_BENCH_BACKEND=gloo: ranks share cuda:0 and exchange through host memory —
+    # only to exercise the multi-rank code path on a 1-GPU box, never a reported number
+    backend = os.environ.get('CONCEPT_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from concept_amd.mesh import PotentialMesh
-    if world > 1:
-        from concept_amd import distributed  # noqa: F401
-        sys.exit('bench.py: the multi-GPU domain/slab path is not built yet')
-
     name = args.workload or 'ns_256M_1024'
     n_p, N = WORKLOADS[name]
     L = float(N)  # boxsize in grid units (synthetic)
     dev = torch.device('cuda', local_rank)
+    if world > 1:
+        return main_distributed(args, name, n_p, N, L, dev, rank, world)
     mesh = PotentialMesh(N, L, nghosts=2)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     pos = torch.rand((n_p, 3), dtype=torch.float64, device=dev, generator=gen)
