@@ -29,5 +29,34 @@ def main(path, out=None):
             f.write(text + '\n')
 
 
+
+
+def pmc(path):
+    """Per-kernel mean of every collected PMC counter (rocprofv3 --pmc run)."""
+    import collections
+    dbs = glob.glob(os.path.join(path, '**', '*.db'), recursive=True)
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for db in dbs:
+        con = sqlite3.connect(db)
+        try:
+            cols = [r[1] for r in con.execute('pragma table_info(counters_collection)')]
+            rows = con.execute('select * from counters_collection').fetchall()
+        except sqlite3.Error as e:
+            print('no counters_collection view:', e)
+            continue
+        ci = {c: i for i, c in enumerate(cols)}
+        namec = 'kernel_name' if 'kernel_name' in ci else 'name'
+        for r in rows:
+            acc[r[ci[namec]]][r[ci['counter_name']]].append(r[ci['value']])
+    for k, d in sorted(acc.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values())):
+        print(k[:110])
+        for cname, vals in d.items():
+            print('    %-20s calls %4d  mean %.6g  total %.6g' % (cname, len(vals),
+                                                                 sum(vals)/len(vals), sum(vals)))
+
+
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    if sys.argv[1] == '--pmc':
+        pmc(sys.argv[2])
+    else:
+        main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
