@@ -291,6 +291,28 @@ extern "C" int cg_poisson_solve(cg_ctx *c, int deconv_order, double C, int long_
     return cg_poisson_backward(c);
 }
 
+extern "C" int cg_poisson_solve_timed(cg_ctx *c, int deconv_order, double C, int long_range,
+                                      double E, double pass_ms[5]) {
+    CG_CHECK(c && pass_ms, "cg_poisson_solve_timed: null argument");
+    CG_CHECK(c->custom_fft && c->p.nprocs == 1,
+             "cg_poisson_solve_timed: hand-written single-domain FFT only");
+    hipEvent_t ev[6];
+    for (auto &e : ev) CG_HIP(hipEventCreate(&e));
+    c->pass_events = ev;
+    int rc = cg_poisson_solve(c, deconv_order, C, long_range, E);
+    c->pass_events = nullptr;
+    if (!rc) {
+        CG_HIP(hipEventSynchronize(ev[5]));
+        for (int i = 0; i < 5; i++) {
+            float ms = 0;
+            CG_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            pass_ms[i] = ms;
+        }
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
 extern "C" int cg_gather_kick(cg_ctx *c, const double *pos, double *mom, int64_t n, int diff_order,
                               double factor) {
     CG_CHECK(c && ((pos && mom) || n == 0), "cg_gather_kick: null argument");

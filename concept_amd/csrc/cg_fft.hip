@@ -342,11 +342,21 @@ static int fft3d(cg_ctx *c, int what, const KspaceParams &P) {
         if (run_strided<LOGN, 1>(c, m, m, ymap, ymap, N, 0, P)) return 1;
         return run_z<LOGN>(c, true);
     }
+    auto mark = [&](int i) {
+        if (c->pass_events) (void)hipEventRecord(c->pass_events[i], c->stream);
+    };
+    mark(0);
     if (run_z<LOGN>(c, false)) return 1;
+    mark(1);
     if (run_strided<LOGN, 0>(c, m, m, ymap, ymap, N, 0, P)) return 1;
+    mark(2);
     if (run_strided<LOGN, 2>(c, m, m, xmap, xmap, N, 0, P)) return 1;
+    mark(3);
     if (run_strided<LOGN, 1>(c, m, m, ymap, ymap, N, 0, P)) return 1;
-    return run_z<LOGN>(c, true);
+    mark(4);
+    int rc = run_z<LOGN>(c, true);
+    mark(5);
+    return rc;
 }
 
 // x-slab domains (one per GPU).  The local slab complex[nxl][N][cp] is

@@ -102,6 +102,7 @@ struct cg_ctx {
     // hand-written FFT (cg_fft.hip): twiddles exp(-2 pi i k/N) as double2[N]
     bool custom_fft = false;
     double *fft_tw = nullptr;
+    hipEvent_t *pass_events = nullptr;  // when set: 6 events recorded around the 5 passes
     // particle sort scratch (owned, grown on demand)
     TileGeom tiles{};
     unsigned int *tile_count = nullptr;   // [ntiles + 1]

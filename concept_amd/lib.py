@@ -47,6 +47,7 @@ SYMBOLS = {
     'cg_deposit_cic': (_int, [_vp, _vp, _i64, _dbl]),
     'cg_deposit_cic_tiled': (_int, [_vp, _vp, _i64, _vp, _dbl, _int]),
     'cg_poisson_solve': (_int, [_vp, _int, _dbl, _int, _dbl]),
+    'cg_poisson_solve_timed': (_int, [_vp, _int, _dbl, _int, _dbl, ctypes.POINTER(ctypes.c_double*5)]),
     'cg_poisson_forward': (_int, [_vp, _int, _dbl, _int, _dbl, _int]),
     'cg_poisson_backward': (_int, [_vp]),
     'cg_poisson_kernel': (_int, [_vp, _int, _dbl, _int, _dbl]),

@@ -107,6 +107,13 @@ class PotentialMesh:
         check(_L.cg_poisson_solve(self._ctx, int(deconv_order), float(C), int(long_range),
                                   float(E)))
 
+    def poisson_solve_timed(self, deconv_order, C, long_range=False, E=0.0):
+        """poisson_solve + per-pass milliseconds (HIP events inside the library)."""
+        ms = (ctypes.c_double*5)()
+        check(_L.cg_poisson_solve_timed(self._ctx, int(deconv_order), float(C), int(long_range),
+                                        float(E), ctypes.byref(ms)))
+        return list(ms)
+
     def poisson_forward(self, deconv_order, C, long_range=False, E=0.0, apply_kernel=True):
         check(_L.cg_poisson_forward(self._ctx, int(deconv_order), float(C), int(long_range),
                                     float(E), int(apply_kernel)))

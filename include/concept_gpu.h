@@ -106,6 +106,11 @@ int cg_poisson_solve(cg_ctx *ctx, int deconv_order, double C, int long_range, do
 int cg_poisson_forward(cg_ctx *ctx, int deconv_order, double C, int long_range, double E,
                        int apply_kernel);
 int cg_poisson_backward(cg_ctx *ctx);
+/* cg_poisson_solve with HIP events (on the context's stream) around its five passes
+ * (z forward, y forward, x fused, y backward, z backward); synchronises.  bench.py's
+ * per-kernel roofline comes from here. */
+int cg_poisson_solve_timed(cg_ctx *ctx, int deconv_order, double C, int long_range, double E,
+                           double pass_ms[5]);
 /* Only the k-space kernel (A5/A6) on a mesh that already holds the forward transform. */
 int cg_poisson_kernel(cg_ctx *ctx, int deconv_order, double C, int long_range, double E);
 
