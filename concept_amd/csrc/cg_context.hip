@@ -214,6 +214,7 @@ extern "C" int cg_destroy(cg_ctx *c) {
     (void)hipFree(c->tile_count);
     (void)hipFree(c->tile_cursor);
     (void)hipFree(c->scan_tmp);
+    (void)hipFree(c->sr_tmp);
     delete c;
     return 0;
 }
@@ -376,6 +377,34 @@ extern "C" int cg_cic_indices(cg_ctx *c, const double *pos, int64_t n, int for_g
                               int64_t *idx_out) {
     CG_CHECK(c && pos && idx_out, "cg_cic_indices: null argument");
     return cgk_cic_indices(c, pos, n, for_gather, idx_out);
+}
+
+extern "C" int cg_shortrange_build(cg_ctx *c, const double *pos, int64_t n, int64_t nt,
+                                   double tile_extent, uint32_t *order_out,
+                                   uint32_t *offset_out) {
+    CG_CHECK(c && offset_out && (n == 0 || (pos && order_out)), "cg_shortrange_build: null argument");
+    CG_CHECK(c->p.nprocs == 1, "cg_shortrange_build: single-domain only so far");
+    CG_CHECK(nt >= 4, "The global gravity tiling needs to have at least 4 tiles across the box in "
+                      "every direction (species.py:3971); got %lld", (long long)nt);
+    CG_CHECK(nt <= 1024 && n < (1ll << 32), "cg_shortrange_build: size out of range");
+    CG_CHECK(tile_extent > 0, "cg_shortrange_build: tile_extent must be positive");
+    return cgk_shortrange_build(c, pos, n, nt, tile_extent, order_out, offset_out);
+}
+
+extern "C" int cg_shortrange_sweep(cg_ctx *c, const double *pos_r, const uint32_t *order_r,
+                                   const uint32_t *offset_r, double *dmom_r, const double *pos_s,
+                                   const uint32_t *order_s, const uint32_t *offset_s, int64_t nt,
+                                   int same_component, const double *table, int64_t tablesize,
+                                   double r2_index_scaling, double r2_max, double factor) {
+    CG_CHECK(c && pos_r && order_r && offset_r && dmom_r && pos_s && order_s && offset_s && table,
+             "cg_shortrange_sweep: null argument");
+    CG_CHECK(nt >= 4 && nt <= 1024, "cg_shortrange_sweep: nt = %lld", (long long)nt);
+    // the largest index the sweep can form is int(r2_max*scaling): must be inside the table
+    CG_CHECK((int64_t)(r2_max * r2_index_scaling) < tablesize,
+             "cg_shortrange_sweep: table of %lld entries too short for r2_max*scaling = %g",
+             (long long)tablesize, r2_max * r2_index_scaling);
+    return cgk_shortrange_sweep(c, pos_r, order_r, offset_r, dmom_r, pos_s, order_s, offset_s, nt,
+                                same_component, table, r2_index_scaling, r2_max, factor);
 }
 
 extern "C" int cg_local_info(const cg_ctx *c, int64_t info[6]) {

@@ -109,6 +109,8 @@ struct cg_ctx {
     unsigned int *tile_cursor = nullptr;  // [ntiles]
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
+    void *sr_tmp = nullptr;  // short-range cell-list counters
+    size_t sr_tmp_bytes = 0;
     i64 ntiles = 0;
     CicGeom geom_deposit{}, geom_gather{};
     i64 device_bytes = 0;
@@ -124,6 +126,13 @@ int cgk_cic_indices(cg_ctx *c, const double *pos, i64 n, int for_gather, i64 *id
 int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst);
 int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
              double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out);
+int cgk_shortrange_build(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
+                         unsigned *order, unsigned *offset);
+int cgk_shortrange_sweep(cg_ctx *c, const double *pos_r, const unsigned *order_r,
+                         const unsigned *off_r, double *dmom_r, const double *pos_s,
+                         const unsigned *order_s, const unsigned *off_s, i64 nt, int same,
+                         const double *table, double r2_index_scaling, double r2_max,
+                         double factor);
 bool cgk_fft_supported(i64 N);
 int cgk_fft_dist_forward(cg_ctx *c, double *send_buf);
 int cgk_fft_dist_xsolve(cg_ctx *c, double *buf, int deconv_order, double C, int long_range,

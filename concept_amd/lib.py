@@ -56,6 +56,9 @@ SYMBOLS = {
     'cg_drift': (_int, [_vp, _vp, _vp, _i64, _dbl]),
     'cg_sort_particles': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'cg_tile_info': (_int, [_vp, ctypes.POINTER(ctypes.c_int64*3)]),
+    'cg_shortrange_build': (_int, [_vp, _vp, _i64, _i64, _dbl, _vp, _vp]),
+    'cg_shortrange_sweep': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _i64,
+                                   _dbl, _dbl, _dbl]),
     'cg_local_info': (_int, [_vp, ctypes.POINTER(ctypes.c_int64*6)]),
     'cg_layers_read': (_int, [_vp, _i64, _i64, _vp]),
     'cg_layers_write': (_int, [_vp, _i64, _i64, _vp, _int]),

@@ -162,6 +162,26 @@ class PotentialMesh:
         return tile_offset
 
     # -- debug / parity -----------------------------------------------------
+    # -- P3M short range -----------------------------------------------------------
+    def shortrange_build(self, pos, nt, tile_extent):
+        n = self._check_particles(pos)
+        order = torch.empty(max(n, 1), dtype=torch.int32, device=pos.device)
+        offset = torch.empty(nt**3 + 1, dtype=torch.int32, device=pos.device)
+        check(_L.cg_shortrange_build(self._ctx, _ptr(pos), n, int(nt), float(tile_extent),
+                                     _ptr(order), _ptr(offset)))
+        return order, offset
+
+    def shortrange_sweep(self, pos_r, cells_r, dmom_r, pos_s, cells_s, nt, same, table,
+                         r2_index_scaling, r2_max, factor):
+        self._check_particles(pos_r, dmom_r)
+        self._check_particles(pos_s)
+        if table.dtype != torch.float64 or not table.is_cuda:
+            raise lib.ConceptGPUError('short-range table must be a float64 CUDA tensor')
+        check(_L.cg_shortrange_sweep(
+            self._ctx, _ptr(pos_r), _ptr(cells_r[0]), _ptr(cells_r[1]), _ptr(dmom_r), _ptr(pos_s),
+            _ptr(cells_s[0]), _ptr(cells_s[1]), int(nt), int(same), _ptr(table), table.numel(),
+            float(r2_index_scaling), float(r2_max), float(factor)))
+
     # -- x-slab domains (multi-GPU) -------------------------------------------
     def layers_read(self, layer0, nlayers, dst):
         check(_L.cg_layers_read(self._ctx, int(layer0), int(nlayers), _ptr(dst)))

@@ -1,7 +1,114 @@
-"""P3M short-range tile sweep (host side) — to be built on
-libconcept_gpu.so's cg_shortrange_* entry points."""
+"""concept_amd.shortrange — host side of the P3M short-range tile sweep.
+
+Counterpart of component_component(..., pairing_level='tile')
+(interactions.py:122-329) with gravity_pairwise_shortrange (gravity.py:263-354)
+for particle components whose particles all sit on rung 0 (single-rung time
+stepping; the adaptive rung machinery is SURVEY.md §8f-2, not built).
+The pair loop itself runs in libconcept_gpu.so (cg_shortrange.hip)."""
+import math
+
+import numpy as np
+import torch
+
+from . import commons
 from .lib import ConceptGPUError
+from .mesh import get_mesh
+
+_tables = {}
+
+
+def get_softened_r3inv(r2, ϵ, kernel='spline'):
+    """interactions.py:1847-1914"""
+    if kernel == 'none':
+        r3 = r2*math.sqrt(r2)
+        return 0 if r3 == 0 else 1/r3
+    if kernel == 'plummer':
+        r2_softened = r2 + ϵ**2
+        return 1/(r2_softened*math.sqrt(r2_softened))
+    if kernel != 'spline':
+        raise ConceptGPUError(f'Softening kernel "{kernel}" not understood')
+    h = 2.8*ϵ
+    r = math.sqrt(r2)
+    if r >= h:
+        return 1/(r2*r)
+    u = r/h
+    if u < 0.5:
+        return 32/h**3*(1./3. + u**2*(-6./5. + u))
+    return 32/(3*r**3)*(u**3*(2 + u*(-9./2. + u*(18./5. - u))) - 3./480.)
+
+
+def get_shortrange_table(softening, scale, range_, tablesize, kernel, device):
+    """gravity.py:373-424.  Tabulated on the host (4096 entries), cached, kept in HBM."""
+    key = (softening, scale, range_, tablesize, kernel, str(device))
+    hit = _tables.get(key)
+    if hit is not None:
+        return hit
+    maxr2 = (1 + 1/tablesize)*range_**2  # gravity.py:437
+    r_tabulation = np.sqrt(np.linspace(0, maxr2, tablesize))
+    table = np.empty(tablesize, dtype=np.float64)
+    inv_scale = 1/scale
+    for i in range(tablesize - 1):
+        r2 = float(0.5*(r_tabulation[i]**2 + r_tabulation[i + 1]**2))
+        r = math.sqrt(r2)
+        x = r*inv_scale
+        r3_inv = 1/(r2*r)
+        table[i] = (
+            - r3_inv*(1/math.sqrt(commons.π)*x*math.exp(-(0.5*x)**2) + (math.erfc(0.5*x) - 1))
+            - get_softened_r3inv(r2, softening, kernel)
+        )
+    table[tablesize - 1] = np.nan  # never accessed (gravity.py:416-421)
+    out = (torch.tensor(table, device=device), maxr2)
+    _tables[key] = out
+    return out
+
+
+def combine_softening_lengths(ϵᵢ, ϵⱼ):
+    """interactions.py:1820-1830"""
+    return 0.5*(ϵᵢ + ϵⱼ)
 
 
 def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
-    raise ConceptGPUError('the P3M short-range tile sweep is not built yet')
+    """Short-range gravity of every (receiver, supplier) component pair, accumulated
+    into the components' Δmom buffers (the caller applies them, main.py:1253-1262)."""
+    if force != 'gravity':
+        raise ConceptGPUError(f'short-range force "{force}" is not built')
+    p = receivers[0].params
+    sr = commons.resolve_shortrange(p, gridsize)
+    nt = int((p.boxsize/1)/sr['tilesize']*(1 + commons.machine_ϵ))  # species.py:3943-3950
+    if nt < 4:
+        raise ConceptGPUError(
+            'The global gravity tiling needs to have at least 4 tiles across the box in every '
+            'direction. Consider lowering shortrange_params["gravity"]["tilesize"].')
+    if sr['tilesize'] < sr['range']*(1 - 1e-12):
+        raise ConceptGPUError('shortrange_params: tilesize must be at least the range')
+    tile_extent = p.boxsize/nt  # species.py:607-609
+    mesh = get_mesh(gridsize, p.boxsize, p.nghosts, p.cell_centered, 2, receivers[0].device)
+    cells = {}
+    for c in {id(c): c for c in list(receivers) + list(suppliers)}.values():
+        if c.representation != 'particles':
+            raise ConceptGPUError(f'{c.name}: only particle components have short-range forces')
+        if c.Δmom is None:
+            c.Δmom = torch.zeros_like(c.mom)
+        cells[id(c)] = mesh.shortrange_build(c.pos, nt, tile_extent)
+    key = 'a**(-3*w_eff₀-3*w_eff₁-1)'
+    done = set()
+    for r in receivers:
+        for s in suppliers:
+            pair = frozenset((id(r), id(s)))
+            if pair in done:
+                continue
+            done.add(pair)
+            softening = combine_softening_lengths(r.softening_length, s.softening_length)
+            table, maxr2 = get_shortrange_table(softening, sr['scale'], sr['range'],
+                                                sr['tablesize'], p.softening_kernel, r.device)
+            scaling = (sr['tablesize'] - 1)/maxr2  # gravity.py:288
+            r2_max = sr['range']**2                # gravity.py:286
+            factor = p.G_Newton*r.mass*s.mass*float(ᔑdt_rungs[key, r.name, s.name][0])
+            same = r is s
+            mesh.shortrange_sweep(r.pos, cells[id(r)], r.Δmom, s.pos, cells[id(s)], nt, same,
+                                  table, scaling, r2_max, factor)
+            if not same and s in receivers:
+                # the reference kicks both partners of a pair (Δmom_s -= ..., gravity.py:341-349)
+                factor_sr = p.G_Newton*s.mass*r.mass*float(ᔑdt_rungs[key, s.name, r.name][0])
+                mesh.shortrange_sweep(s.pos, cells[id(s)], s.Δmom, r.pos, cells[id(r)], nt,
+                                      False, table, scaling, r2_max, factor_sr)

@@ -155,6 +155,30 @@ int cg_sort_particles(cg_ctx *ctx, const double *pos_in, const double *mom_in,
  * 8*t + f = index of the first particle of bucket f of tile t. */
 int cg_tile_info(const cg_ctx *ctx, int64_t info[3]);
 
+/* --- A13..A15: P3M short-range tile sweep -------------------------------------
+ * cg_shortrange_build: Tiling.sort (species.py:707-823) for the 'gravity (tiles)'
+ * tiling of nt^3 tiles (init_tiling, species.py:3943-3983: nt = int(boxsize/tilesize*
+ * (1+eps)), at least 4) as a cell list: order_out[n] = particle indices grouped by
+ * tile, offset_out[nt^3+1] = first entry of each tile.
+ * cg_shortrange_sweep: particle_particle (interactions.py:1563-1791) +
+ * gravity_pairwise_shortrange (gravity.py:263-354), all particles on rung 0:
+ *   dmom_r[i] += sum_j ((xi - xj) + periodic_offset) * factor * table[int(r2*scaling)]
+ * over all supplier particles j != i of the 27 neighbouring tiles with r2 <= r2_max.
+ * One-sided: to kick both components of a pair call it twice with the roles swapped
+ * (for one component on itself once, same_component = 1).
+ *   table            get_shortrange_table (gravity.py:373-424), DEV double[tablesize]
+ *   r2_index_scaling (tablesize - 1)/shortrange_table_maxr2      (gravity.py:288)
+ *   r2_max           shortrange_range**2                          (gravity.py:286)
+ *   factor           G_Newton*mass_r*mass_s*dt_rungs[...][0]      (gravity.py:51-64) */
+int cg_shortrange_build(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, int64_t nt,
+                        double tile_extent, uint32_t *order_out /*DEV n*/,
+                        uint32_t *offset_out /*DEV nt^3+1*/);
+int cg_shortrange_sweep(cg_ctx *ctx, const double *pos_r, const uint32_t *order_r,
+                        const uint32_t *offset_r, double *dmom_r /*DEV 3n_r, accumulated*/,
+                        const double *pos_s, const uint32_t *order_s, const uint32_t *offset_s,
+                        int64_t nt, int same_component, const double *table /*DEV*/,
+                        int64_t tablesize, double r2_index_scaling, double r2_max, double factor);
+
 /* --- multi-GPU: x-slab domains ----------------------------------------------
  * One context per GPU with params.nprocs = P, rank = r, subdiv = (P,1,1):
  * domain r owns mesh layers x in [r*N/P, (r+1)*N/P) and the particles whose
