@@ -6,6 +6,13 @@ import time."""
 import ctypes
 import os
 
+# PyTorch ships its own libamdhip64.so.7 / libhsa-runtime64 (same SONAMEs as /opt/rocm's).
+# The particle arrays this library works on are torch allocations, so both must live in
+# ONE HIP runtime: import torch first, then the dynamic loader resolves our NEEDED
+# libamdhip64.so.7 / librocfft.so.0 to the copies torch already mapped.  (Loaded the
+# other way round the process ends up with two runtimes and the second one finds no device.)
+import torch  # noqa: F401  (must precede the CDLL below)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libconcept_gpu.so')
 
