@@ -46,6 +46,8 @@ def algorithmic_bytes(n_p, n_g):
         'kspace': 16*n_g,
         'fft_backward': 48*n_g,
         'poisson': 48*n_g + 16*n_g + 48*n_g,     # A4 + A5-A7 + A8
+        'sr_cells': 2*24*n_p + 8*n_p,            # pos read twice, order written
+        'sr_sweep': 24*n_p + 48*n_p,             # not HBM-bound: FP64/LDS pair arithmetic
         'gather_kick': 24*n_p + 48*n_p + 8*n_g,  # pos, mom RMW, potential once (FD fused)
         'drift': 48*n_p + 24*n_p,
         'sort': 2*(48*n_p) + 24*n_p,             # histogram reads pos; scatter moves pos+mom
@@ -154,6 +156,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--split-poisson', action='store_true',
                     help='time FFT forward / k-space kernel / FFT backward separately (unfused)')
+    ap.add_argument('--p3m', action='store_true',
+                    help='P3M step (BASELINE configs[2]): long-range mesh with Gaussian cut-off + '
+                         'short-range tile sweep (r_s = 1.25 cells, range 4.5 r_s, spline '
+                         'softening 0.025*L/cbrt(N))')
     ap.add_argument('--no-sort', action='store_true',
                     help='direct (untiled) kernels on unsorted particles, for A/B')
     args = ap.parse_args()
@@ -179,7 +185,7 @@ def main():
             dist.init_process_group(backend)
 
     from concept_amd.mesh import PotentialMesh
-    name = args.workload or 'ns_256M_1024'
+    name = args.workload or ('c2_256c_512' if args.p3m else 'ns_256M_1024')
     n_p, N = WORKLOADS[name]
     L = float(N)  # boxsize in grid units (synthetic)
     dev = torch.device('cuda', local_rank)
@@ -203,10 +209,24 @@ def main():
     dt_over_mass = dt/mass
 
     poisson = ['fft_forward', 'kspace', 'fft_backward'] if args.split_poisson else ['poisson']
+    sr = None
+    if args.p3m:
+        from concept_amd import commons as _commons
+        from concept_amd import shortrange as _sr
+        scale = 1.25*L/N
+        rng_ = 4.5*scale
+        nt_sr = int((L/1)/rng_*(1 + _commons.machine_ϵ))
+        soft = 0.025*L/round(n_p**(1/3))
+        sr_table, maxr2 = _sr.get_shortrange_table(soft, scale, rng_, 4096, 'spline', dev)
+        dmom = torch.zeros_like(mom)
+        sr = dict(scale=scale, range=rng_, nt=nt_sr, table=sr_table, scaling=4095/maxr2,
+                  r2_max=rng_**2, factor=G*mass*mass*dt, E=-(2*3.141592653589793/L*scale)**2)
     if args.no_sort:
         PHASES = ['drift', 'zero', 'deposit'] + poisson + ['gather_kick']
     else:  # the tiled deposit assigns the mesh: no zero-fill pass
         PHASES = ['drift', 'sort', 'deposit'] + poisson + ['gather_kick']
+    if args.p3m:
+        PHASES += ['sr_cells', 'sr_sweep']
     events = []
 
     def step(record):
@@ -243,13 +263,22 @@ def main():
             mesh.poisson_backward()
             mark()
         else:  # the product path: k-space kernel fused into the x pass of the FFT
-            mesh.poisson_solve(4, C, False, 0.0)
+            mesh.poisson_solve(4, C, sr is not None, sr['E'] if sr else 0.0)
             mark()
+        order = 4 if sr else 2  # differentiation defaults: pm 2, p3m 4 (commons.py:3209-3237)
         if not args.no_sort:
-            mesh.gather_kick_tiled(pos, mom, table, 2, kick_factor)
+            mesh.gather_kick_tiled(pos, mom, table, order, kick_factor)
         else:
-            mesh.gather_kick(pos, mom, 2, kick_factor)
+            mesh.gather_kick(pos, mom, order, kick_factor)
         mark()
+        if sr:
+            dmom.zero_()
+            cells = mesh.shortrange_build(pos, sr['nt'], L/sr['nt'])
+            mark()
+            mesh.shortrange_sweep(pos, cells, dmom, pos, cells, sr['nt'], True, sr['table'],
+                                  sr['scaling'], sr['r2_max'], sr['factor'])
+            mom.add_(dmom)
+            mark()
         if record:
             events.append(ev)
 
