@@ -227,23 +227,25 @@ __device__ __forceinline__ i64 pencil_off(const PencilMap &pm, int m) {
 template <int LOGN, int NT, int MODE>
 __global__ __launch_bounds__(NT) void k_fft_strided(const double2 *__restrict__ src,
                                                     double2 *__restrict__ dst, PencilMap smap,
-                                                    PencilMap dmap, int nkb, i64 o_off,
+                                                    PencilMap dmap, int nkb, int ntiles, i64 o_off,
                                                     const double2 *__restrict__ tw,
                                                     KspaceParams P) {
+    // Persistent workgroups: each walks tiles t = blockIdx.x, += gridDim.x and keeps the
+    // NEXT tile's global loads in flight (in registers) while it transforms the current
+    // one in LDS — the 64 KB tile leaves room for only two workgroups per CU, so the
+    // overlap of HBM latency with the LDS passes has to happen inside the workgroup.
     constexpr int N = 1 << LOGN, W = 4;
     extern __shared__ double2 lds_dyn[];
     double2 *lds = lds_dyn;
     const int tid = threadIdx.x;
-    const i64 o = blockIdx.x / nkb;
-    const int kb = blockIdx.x - (int)o * nkb;
-    const int kk0 = kb * W;
     const int nk = N / 2 + 1;  // valid kk: 0..N/2
-    const double2 *sbase = src + o * smap.ostride + kk0;
-    double2 *dbase = dst + o * dmap.ostride + kk0;
     constexpr int TOT = N * W;
     constexpr int PER = (TOT + NT - 1) / NT;
-    {
-        double2 v[PER];
+    double2 v[PER];
+    auto load_tile = [&](int t) {
+        const i64 o = t / nkb;
+        const int kk0 = (t - (int)o * nkb) * W;
+        const double2 *sbase = src + o * smap.ostride + kk0;
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             int f = tid + r * NT;
@@ -251,36 +253,46 @@ __global__ __launch_bounds__(NT) void k_fft_strided(const double2 *__restrict__ 
             bool ok = (TOT % NT == 0 || f < TOT) && (kk0 + w < nk);
             v[r] = ok ? sbase[pencil_off(smap, m) + w] : make_double2(0, 0);
         }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) load_tile(t);
+    for (; t < ntiles; t += gridDim.x) {
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             int f = tid + r * NT;
             if (TOT % NT == 0 || f < TOT) lds[f] = v[r];
         }
-    }
-    __syncthreads();
-    if (MODE == 0 || MODE == 2) fft_lds<LOGN, W, NT, false>(lds, tw, 1, tid);
-    if (MODE == 2) {
+        __syncthreads();
+        if (t + (int)gridDim.x < ntiles) load_tile(t + gridDim.x);
+        const i64 o = t / nkb;
+        const int kk0 = (t - (int)o * nkb) * W;
+        if (MODE == 0 || MODE == 2) fft_lds<LOGN, W, NT, false>(lds, tw, 1, tid);
+        if (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                int f = tid + r * NT;
+                if (TOT % NT == 0 || f < TOT) {
+                    int w = f % W, m = f / W;
+                    int kk = kk0 + w;
+                    if (kk < nk) {
+                        double fac = kspace_factor(P, N, m, o + o_off, kk);
+                        double2 x = lds[f];
+                        lds[f] = make_double2(x.x * fac, x.y * fac);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (MODE == 1 || MODE == 2) fft_lds<LOGN, W, NT, true>(lds, tw, 1, tid);
+        double2 *dbase = dst + o * dmap.ostride + kk0;
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             int f = tid + r * NT;
-            if (TOT % NT == 0 || f < TOT) {
-                int w = f % W, m = f / W;
-                int kk = kk0 + w;
-                if (kk < nk) {
-                    double fac = kspace_factor(P, N, m, o + o_off, kk);
-                    double2 x = lds[f];
-                    lds[f] = make_double2(x.x * fac, x.y * fac);
-                }
-            }
+            int w = f % W, m = f / W;
+            if ((TOT % NT == 0 || f < TOT) && (kk0 + w < nk))
+                dbase[pencil_off(dmap, m) + w] = lds[f];
         }
-        __syncthreads();
-    }
-    if (MODE == 1 || MODE == 2) fft_lds<LOGN, W, NT, true>(lds, tw, 1, tid);
-#pragma unroll
-    for (int r = 0; r < PER; r++) {
-        int f = tid + r * NT;
-        int w = f % W, m = f / W;
-        if ((TOT % NT == 0 || f < TOT) && (kk0 + w < nk)) dbase[pencil_off(dmap, m) + w] = lds[f];
+        __syncthreads();  // the LDS tile is free for the next one
     }
 }
 
@@ -318,8 +330,13 @@ static int run_strided(cg_ctx *c, const double2 *src, double2 *dst, PencilMap sm
                                    (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nouter * nkb)), dim3(NT), lds, c->stream, src, dst,
-                       smap, dmap, nkb, o_off, (const double2 *)c->fft_tw, P);
+    const i64 ntiles = nouter * nkb;
+    i64 per_cu = (160 * 1024) / (i64)lds;  // workgroups one CU can hold (LDS-limited)
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2048 / NT ? 2048 / NT : per_cu);
+    i64 grid = 256 * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, c->stream, src, dst, smap, dmap,
+                       nkb, (int)ntiles, o_off, (const double2 *)c->fft_tw, P);
     CG_LAUNCH_CHECK();
     return 0;
 }
