@@ -419,3 +419,43 @@ def test_handwritten_fft_vs_numpy_and_rocfft(torch_cuda, N, monkeypatch):
     mesh2.poisson_solve(4, C, True, E)
     phi_roc = mesh2.fetch_real()[:, :, :N]
     assert np.abs(phi_fused - phi_roc).max() <= 1e-12*np.abs(phi_roc).max()
+
+
+def test_fft_2048_roundtrip(torch_cuda):
+    """The largest grid of BASELINE.json (2048^3, config 4's mesh; 69 GB on one GPU):
+    forward then backward = N^3 * identity, and the fused solve equals the split one."""
+    torch = torch_cuda
+    from concept_amd.mesh import PotentialMesh
+    N, L, n = 2048, 2048.0, 2_000_000
+    mesh = PotentialMesh(N, L)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    pos = torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=gen)*(L*(1 - 1e-12))
+    probe = torch.zeros((n, 3), dtype=torch.float64, device='cuda')
+    mesh.zero()
+    mesh.deposit(pos, 1.0)
+    mesh.poisson_forward(0, 1.0, False, 0.0, apply_kernel=False)
+    mesh.poisson_backward()
+    # read the mesh back at the particles: CIC gather of an (N^3-scaled) density is heavy to
+    # fetch whole; compare through the gather kernel instead (same on both sides)
+    mesh.gather_kick(pos, probe, 2, 1.0)
+    a = probe.clone()
+    mesh.zero()
+    mesh.deposit(pos, float(N)**3)
+    probe.zero_()
+    mesh.gather_kick(pos, probe, 2, 1.0)
+    assert float((a - probe).abs().max()) <= 1e-11*float(probe.abs().max())
+    # fused vs split Poisson solve
+    k1 = torch.zeros_like(probe)
+    k2 = torch.zeros_like(probe)
+    mesh.zero()
+    mesh.deposit(pos, 1.0)
+    mesh.poisson_solve(4, -1.0, False, 0.0)
+    mesh.gather_kick(pos, k1, 2, 1.0)
+    mesh.zero()
+    mesh.deposit(pos, 1.0)
+    mesh.poisson_forward(4, -1.0, False, 0.0, apply_kernel=True)
+    mesh.poisson_backward()
+    mesh.gather_kick(pos, k2, 2, 1.0)
+    assert float((k1 - k2).abs().max()) <= 1e-12*float(k2.abs().max())
+    assert float(k2.abs().max()) > 0
+    mesh.close()
