@@ -156,6 +156,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--split-poisson', action='store_true',
                     help='time FFT forward / k-space kernel / FFT backward separately (unfused)')
+    ap.add_argument('--dist', default='uniform', choices=['uniform', 'lattice', 'clustered'],
+                    help="particle distribution (SURVEY.md §8d): uniform random (U), displaced "
+                         "lattice (Z: rms displacement 1.5 cells), or Gaussian blobs")
     ap.add_argument('--p3m', action='store_true',
                     help='P3M step (BASELINE configs[2]): long-range mesh with Gaussian cut-off + '
                          'short-range tile sweep (r_s = 1.25 cells, range 4.5 r_s, spline '
@@ -194,8 +197,27 @@ def main():
     mesh = PotentialMesh(N, L, nghosts=2)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     pos = torch.rand((n_p, 3), dtype=torch.float64, device=dev, generator=gen)
-    pos.mul_(L).clamp_(max=float(torch.nextafter(torch.tensor(L, dtype=torch.float64),
-                                                 torch.tensor(0.0, dtype=torch.float64))))
+    if args.dist == 'uniform':
+        pos.mul_(L)
+    elif args.dist == 'lattice':
+        side = round(n_p**(1/3))
+        if side**3 != n_p:
+            sys.exit('--dist lattice needs a cubic particle count (e.g. --workload c2_256c_512)')
+        idx = torch.arange(n_p, device=dev)
+        lat = torch.stack([idx//(side*side), (idx//side) % side, idx % side], 1).double()
+        disp = torch.randn((n_p, 3), dtype=torch.float64, device=dev, generator=gen)*1.5*(L/N)
+        pos = torch.remainder((lat + 0.5)*(L/side) + disp, L)
+        del idx, lat, disp
+    else:  # clustered: 64 Gaussian blobs of sigma = L/40 holding 80 % of the particles
+        centres = torch.rand((64, 3), dtype=torch.float64, device=dev, generator=gen)*L
+        which = torch.randint(0, 64, (n_p,), device=dev, generator=gen)
+        blob = centres[which] + torch.randn((n_p, 3), dtype=torch.float64, device=dev,
+                                            generator=gen)*(L/40)
+        keep = torch.rand(n_p, dtype=torch.float64, device=dev, generator=gen) < 0.2
+        pos = torch.where(keep[:, None], pos*L, torch.remainder(blob, L))
+        del centres, which, blob, keep
+    pos.clamp_(min=0.0, max=float(torch.nextafter(torch.tensor(L, dtype=torch.float64),
+                                                  torch.tensor(0.0, dtype=torch.float64))))
     mom = torch.zeros_like(pos)
     pos2, mom2 = torch.empty_like(pos), torch.empty_like(mom)
     table = mesh.new_tile_table()
@@ -356,7 +378,7 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': f'{name}: {n_p} particles (uniform random, seed 1) / {N}^3 PM mesh, '
+        'config': {'workload': f'{name}: {n_p} particles ({args.dist}, seed 1) / {N}^3 PM mesh, '
                                'CIC, deconvolution order 4, FD order 2, 1 PM step = drift + '
                                'tile sort + long-range kick', 'particles': n_p, 'gridsize': N,
                    'parallelism': f'domains{world}'},

@@ -459,3 +459,35 @@ def test_fft_2048_roundtrip(torch_cuda):
     assert float((k1 - k2).abs().max()) <= 1e-12*float(k2.abs().max())
     assert float(k2.abs().max()) > 0
     mesh.close()
+
+
+def test_multi_component_superposition(torch_cuda, golden):
+    """particle_mesh with several suppliers/receivers (interactions.py:2029-2035,
+    mesh.py:604-608): splitting one component into two of the same particle mass must
+    give the single-component kicks; one of the two is tile-sorted (LDS path, assigns
+    the mesh), the other unsorted (direct path, accumulates)."""
+    from concept_amd import commons, interactions
+    from concept_amd.species import Component
+    g = golden('pm_n16_g32')
+    commons.load_params({
+        'boxsize': float(g['boxsize']),
+        'potential_options': {'gridsize': {'gravity': {'pm': int(g['gridsize'])}}},
+        'select_forces': {'matter': {'gravity': 'pm'}},
+    })
+    n = int(g['N'])
+    half = n//2
+    a = Component('a', 'matter', N=half, mass=float(g['mass']))
+    b = Component('b', 'matter', N=n - half, mass=float(g['mass']))
+    a.populate(g['pos_in'][:half], 'pos')
+    a.populate(g['mom_in'][:half], 'mom')
+    b.populate(g['pos_in'][half:], 'pos')
+    b.populate(g['mom_in'][half:], 'mom')
+    a.tile_sort()
+    sdt = {'1': float(g['dt_1'])}
+    for c in (a, b):
+        sdt['a**(-3*w_eff)', c.name] = float(g['dt_kick'])
+        sdt['a**(-3*w_eff-1)', c.name] = float(g['dt_dens'])
+    interactions.gravity('pm', [a, b], [a, b], sdt, 'long-range', False)
+    out = np.concatenate([a.host('mom'), b.host('mom')])
+    kick = g['mom_after_long'] - g['mom_in']
+    assert np.abs(out - g['mom_after_long']).max() <= TOL*rms(kick)
