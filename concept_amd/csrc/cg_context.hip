@@ -370,7 +370,24 @@ extern "C" int cg_sort_particles(cg_ctx *c, const double *pos_in, const double *
     CG_CHECK((ids_in == nullptr) == (ids_out == nullptr),
              "cg_sort_particles: ids_in and ids_out must both be given or both be null");
     CG_CHECK(n >= 0 && n < (1ll << 32), "cg_sort_particles: n out of range");
-    return cgk_sort(c, pos_in, mom_in, ids_in, pos_out, mom_out, ids_out, n, tile_offset_out);
+    return cgk_sort(c, pos_in, mom_in, ids_in, pos_out, mom_out, ids_out, n, tile_offset_out, 0,
+                    0.0);
+}
+
+extern "C" int cg_drift_sort(cg_ctx *c, const double *pos_in, const double *mom_in,
+                             const int64_t *ids_in, double *pos_out, double *mom_out,
+                             int64_t *ids_out, int64_t n, double dt_over_mass,
+                             uint32_t *tile_offset_out) {
+    CG_CHECK(c && pos_in && mom_in && pos_out && mom_out && tile_offset_out,
+             "cg_drift_sort: null argument");
+    CG_CHECK(pos_in != pos_out && mom_in != mom_out, "cg_drift_sort: in/out must not alias");
+    CG_CHECK((ids_in == nullptr) == (ids_out == nullptr),
+             "cg_drift_sort: ids_in and ids_out must both be given or both be null");
+    CG_CHECK(n >= 0 && n < (1ll << 32), "cg_drift_sort: n out of range");
+    CG_CHECK(c->p.nprocs == 1, "cg_drift_sort: single-domain (x-slab domains exchange "
+                               "particles between the drift and the sort)");
+    return cgk_sort(c, pos_in, mom_in, ids_in, pos_out, mom_out, ids_out, n, tile_offset_out, 1,
+                    dt_over_mass);
 }
 
 extern "C" int cg_cic_indices(cg_ctx *c, const double *pos, int64_t n, int for_gather,

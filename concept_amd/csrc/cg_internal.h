@@ -125,7 +125,8 @@ int cgk_drift(cg_ctx *c, double *pos, const double *mom, i64 n, double dt_over_m
 int cgk_cic_indices(cg_ctx *c, const double *pos, i64 n, int for_gather, i64 *idx);
 int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst);
 int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
-             double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out);
+             double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out,
+             int drift, double dt_over_mass);
 int cgk_shortrange_build(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
                          unsigned *order, unsigned *offset);
 int cgk_shortrange_sweep(cg_ctx *c, const double *pos_r, const unsigned *order_r,

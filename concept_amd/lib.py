@@ -62,6 +62,7 @@ SYMBOLS = {
     'cg_gather_kick_tiled': (_int, [_vp, _vp, _vp, _i64, _vp, _int, _dbl]),
     'cg_drift': (_int, [_vp, _vp, _vp, _i64, _dbl]),
     'cg_sort_particles': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'cg_drift_sort': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _vp]),
     'cg_tile_info': (_int, [_vp, ctypes.POINTER(ctypes.c_int64*3)]),
     'cg_shortrange_build': (_int, [_vp, _vp, _i64, _i64, _dbl, _vp, _vp]),
     'cg_shortrange_sweep': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _i64,

@@ -161,6 +161,19 @@ class PotentialMesh:
             _ptr(tile_offset)))
         return tile_offset
 
+    def drift_sort(self, pos, mom, ids, pos_out, mom_out, ids_out, dt_over_mass,
+                   tile_offset=None):
+        """Fused drift + tile sort: the outputs hold the drifted particles in tile order."""
+        n = self._check_particles(pos, mom, pos_out, mom_out)
+        if tile_offset is None:
+            tile_offset = self.new_tile_table()
+        self._check_table(tile_offset)
+        check(_L.cg_drift_sort(
+            self._ctx, _ptr(pos), _ptr(mom), _ptr(ids) if ids is not None else None,
+            _ptr(pos_out), _ptr(mom_out), _ptr(ids_out) if ids_out is not None else None, n,
+            float(dt_over_mass), _ptr(tile_offset)))
+        return tile_offset
+
     # -- debug / parity -----------------------------------------------------
     # -- P3M short range -----------------------------------------------------------
     def shortrange_build(self, pos, nt, tile_extent):

@@ -139,6 +139,24 @@ class Component:
         if self.Δmom is not None:
             self.Δmom = None  # order changed; short-range buffers are rebuilt on use
 
+    def drift_sort(self, ᔑdt, a_next=-1, a=1.0, mesh=None):
+        """drift() immediately followed by tile_sort(), fused into one pass pair
+        (cg_drift_sort): same result as the two calls."""
+        mesh = mesh or self._mesh()
+        Δt_over_mass = ᔑdt['a**(-2)']*a**(3*self.w_eff(a=a))/self.mass
+        if self._scratch is None:
+            self._scratch = (torch.empty_like(self.pos), torch.empty_like(self.mom),
+                             torch.empty_like(self.ids))
+        po, mo, io = self._scratch
+        if self.tile_table is None or self.tile_mesh is not mesh:
+            self.tile_table = mesh.new_tile_table()
+        mesh.drift_sort(self.pos, self.mom, self.ids, po, mo, io, Δt_over_mass, self.tile_table)
+        self._scratch = (self.pos, self.mom, self.ids)
+        self.pos, self.mom, self.ids = po, mo, io
+        self.tile_mesh = mesh
+        self.tiles_exact = True
+        self.Δmom = None
+
     def nullify_Δ(self, specifically=None, only_active=True):
         if specifically is None:
             raise ConceptGPUError('You must specify "specifically" when calling '

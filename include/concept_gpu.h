@@ -145,6 +145,14 @@ int cg_sort_particles(cg_ctx *ctx, const double *pos_in, const double *mom_in,
                       const int64_t *ids_in /*nullable*/, double *pos_out, double *mom_out,
                       int64_t *ids_out /*nullable*/, int64_t n,
                       uint32_t *tile_offset_out /*DEV 8*ntiles+1, see cg_tile_info*/);
+/* Fused A11 + sort (single domain): pos_out/mom_out = tile order of the DRIFTED particles,
+ * drift arithmetic identical to cg_drift (species.py:2179-2199).  The input arrays are
+ * left undrifted (they are scratch afterwards): saves writing and re-reading the drifted
+ * positions between the two steps. */
+int cg_drift_sort(cg_ctx *ctx, const double *pos_in, const double *mom_in,
+                  const int64_t *ids_in /*nullable*/, double *pos_out, double *mom_out,
+                  int64_t *ids_out /*nullable*/, int64_t n, double dt_over_mass,
+                  uint32_t *tile_offset_out /*DEV tile table*/);
 /* info[0] = tile extent T in cells (cubic), info[1] = tiles per dimension nt,
  * info[2] = number of entries of a tile table (8*nt^3 + 1).  Tile
  * t = (ta*nt + tb)*nt + tc holds the particles whose lower CIC cell
