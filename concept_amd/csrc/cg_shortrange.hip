@@ -19,6 +19,8 @@
 // chunks of 64 and broadcast to all lanes.
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+
 #include "cg_internal.h"
 
 #define CG_LAUNCH_CHECK()                                                                     \
@@ -184,14 +186,121 @@ __global__ __launch_bounds__(64) void k_sr_sweep(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Column form of the sweep.  With the default tiling a tile holds ~20 particles,
+// so one wavefront per tile leaves two thirds of the lanes idle.  Here a
+// workgroup owns a z-COLUMN of tiles (ra, rb, *): the cell list is z-fastest, so
+// the column's receivers are one contiguous run, cut into chunks of 64 lanes.
+// A chunk spans a few tiles tc_lo..tc_hi; its lanes test every particle of the
+// supplier tiles (sa, sb, tc_lo-1 .. tc_hi+1) of the 9 neighbouring columns.
+// A lane takes part only for the three supplier tiles adjacent to its own tile
+// (exactly the reference's pairs, each once), so a chunk spanning three tiles
+// keeps ~60 % of the lanes busy instead of ~34 %.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_sr_sweep_columns(
+    const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
+    const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
+    const double *__restrict__ pos_s, const unsigned *__restrict__ order_s,
+    const unsigned *__restrict__ off_s, const double *__restrict__ table, SrParams P,
+    double inv_extent) {
+    __shared__ double sx[64], sy[64], sz[64];
+    __shared__ unsigned sidx[64];
+    const int lane = threadIdx.x;
+    const int nt = P.nt;
+    const int ra = blockIdx.x / nt, rb = blockIdx.x % nt;
+    const unsigned col0 = (unsigned)((ra * nt + rb) * nt);
+    const unsigned cbeg = off_r[col0], cend = off_r[col0 + nt];
+    for (unsigned base = cbeg; base < cend; base += 64) {
+        const bool active = base + lane < cend;
+        const unsigned pi = active ? order_r[base + lane] : 0u;
+        double xi = 0, yi = 0, zi = 0;
+        int my_tc = 0;
+        if (active) {
+            xi = pos_r[3 * (i64)pi];
+            yi = pos_r[3 * (i64)pi + 1];
+            zi = pos_r[3 * (i64)pi + 2];
+            my_tc = (int)(i64)((zi - 0.0) * inv_extent);  // Tiling.sort expression
+            my_tc = my_tc >= nt ? nt - 1 : my_tc;
+        }
+        // tile range of this chunk (the list is sorted by tile: first / last active lane)
+        const int last = (int)min(63u, cend - base - 1);
+        const int tc_lo = __shfl(my_tc, 0), tc_hi = __shfl(my_tc, last);
+        double ax = 0, ay = 0, az = 0;
+        for (int d = 0; d < 9; d++) {
+            int sa = ra + d / 3 - 1, sb = rb + d % 3 - 1;
+            double ox = 0, oy = 0;
+            if (sa < 0) { sa += nt; ox = P.boxsize; } else if (sa >= nt) { sa -= nt; ox = -P.boxsize; }
+            if (sb < 0) { sb += nt; oy = P.boxsize; } else if (sb >= nt) { sb -= nt; oy = -P.boxsize; }
+            for (int sc_raw = tc_lo - 1; sc_raw <= tc_hi + 1; sc_raw++) {
+                int sc = sc_raw;
+                double oz = 0;
+                if (sc < 0) { sc += nt; oz = P.boxsize; } else if (sc >= nt) { sc -= nt; oz = -P.boxsize; }
+                const bool shifted = (ox != 0) | (oy != 0) | (oz != 0);
+                const unsigned ts = (unsigned)((sa * nt + sb) * nt + sc);
+                const unsigned sbeg = off_s[ts], send = off_s[ts + 1];
+                for (unsigned cb = sbeg; cb < send; cb += 64) {
+                    __syncthreads();
+                    if (cb + lane < send) {
+                        unsigned pj = order_s[cb + lane];
+                        sidx[lane] = pj;
+                        sx[lane] = pos_s[3 * (i64)pj];
+                        sy[lane] = pos_s[3 * (i64)pj + 1];
+                        sz[lane] = pos_s[3 * (i64)pj + 2];
+                    }
+                    __syncthreads();
+                    const int cnt = (int)min(64u, send - cb);
+                    // a supplier tile two or more tiles away from a lane's own tile is not
+                    // its neighbour: with a periodic shift its image could alias a true
+                    // neighbour, so such lanes sit the tile out
+                    int dz = sc_raw - my_tc;
+                    if (active && dz >= -1 && dz <= 1) {
+                        for (int k = 0; k < cnt; k++) {
+                            if (P.same && sidx[k] == pi) continue;
+                            double x_ji = xi - sx[k];
+                            double y_ji = yi - sy[k];
+                            double z_ji = zi - sz[k];
+                            if (shifted) {
+                                x_ji += ox;
+                                y_ji += oy;
+                                z_ji += oz;
+                            }
+                            double r2 = x_ji * x_ji + y_ji * y_ji + z_ji * z_ji;
+                            if (r2 > P.r2_max) continue;
+                            i64 idx = (i64)(r2 * P.r2_index_scaling);
+                            double total_factor = P.factor * table[idx];
+                            ax += x_ji * total_factor;
+                            ay += y_ji * total_factor;
+                            az += z_ji * total_factor;
+                        }
+                    }
+                }
+            }
+        }
+        if (active) {
+            dmom_r[3 * (i64)pi] += ax;
+            dmom_r[3 * (i64)pi + 1] += ay;
+            dmom_r[3 * (i64)pi + 2] += az;
+        }
+    }
+}
+
 int cgk_shortrange_sweep(cg_ctx *c, const double *pos_r, const unsigned *order_r,
                          const unsigned *off_r, double *dmom_r, const double *pos_s,
                          const unsigned *order_s, const unsigned *off_s, i64 nt, int same,
                          const double *table, double r2_index_scaling, double r2_max,
                          double factor) {
     SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt, same};
-    hipLaunchKernelGGL(k_sr_sweep, dim3((unsigned)(nt * nt * nt)), dim3(64), 0, c->stream, pos_r,
-                       order_r, off_r, dmom_r, pos_s, order_s, off_s, table, P);
+    const char *env = getenv("CONCEPT_GPU_SR");
+    if (env && std::string(env) == "tiles") {  // one wavefront per tile (A/B reference)
+        hipLaunchKernelGGL(k_sr_sweep, dim3((unsigned)(nt * nt * nt)), dim3(64), 0, c->stream,
+                           pos_r, order_r, off_r, dmom_r, pos_s, order_s, off_s, table, P);
+    } else {
+        const double eps = 2.220446049250313e-16;
+        double tile_extent = c->p.boxsize / (double)nt;  // species.py:607-609
+        double inv = (1 / tile_extent) * (1 - 2 * eps);
+        hipLaunchKernelGGL(k_sr_sweep_columns, dim3((unsigned)(nt * nt)), dim3(64), 0, c->stream,
+                           pos_r, order_r, off_r, dmom_r, pos_s, order_s, off_s, table, P, inv);
+    }
     CG_LAUNCH_CHECK();
     return 0;
 }
