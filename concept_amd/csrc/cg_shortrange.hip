@@ -290,8 +290,10 @@ int cgk_shortrange_sweep(cg_ctx *c, const double *pos_r, const unsigned *order_r
                          const double *table, double r2_index_scaling, double r2_max,
                          double factor) {
     SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt, same};
+    // Default: one wavefront per tile.  The column form (CONCEPT_GPU_SR=columns) keeps more
+    // lanes busy but measured slower at 256^3 / 512^3 (26.7 vs 24.7 ms): kept for A/B work.
     const char *env = getenv("CONCEPT_GPU_SR");
-    if (env && std::string(env) == "tiles") {  // one wavefront per tile (A/B reference)
+    if (!(env && std::string(env) == "columns")) {
         hipLaunchKernelGGL(k_sr_sweep, dim3((unsigned)(nt * nt * nt)), dim3(64), 0, c->stream,
                            pos_r, order_r, off_r, dmom_r, pos_s, order_s, off_s, table, P);
     } else {
