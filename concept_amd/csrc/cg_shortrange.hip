@@ -157,23 +157,27 @@ __global__ __launch_bounds__(64) void k_sr_sweep(
                 __syncthreads();
                 const int cnt = (int)min(64u, send - cb);
                 if (active) {
+                    // straight-line body (predicated, no early exits) so that the compiler
+                    // can overlap the LDS broadcasts and FP64 chains of several partners
+#pragma unroll 4
                     for (int k = 0; k < cnt; k++) {
-                        if (P.same && sidx[k] == pi) continue;  // not with itself
                         double x_ji = xi - sx[k];               // interactions.py:1787-1789
                         double y_ji = yi - sy[k];
                         double z_ji = zi - sz[k];
-                        if (shifted) {                          // gravity.py:299-302
+                        if (shifted) {                          // gravity.py:299-302 (uniform)
                             x_ji += ox;
                             y_ji += oy;
                             z_ji += oz;
                         }
                         double r2 = x_ji * x_ji + y_ji * y_ji + z_ji * z_ji;  // gravity.py:306
-                        if (r2 > P.r2_max) continue;
-                        i64 idx = (i64)(r2 * P.r2_index_scaling);            // gravity.py:316
-                        double total_factor = P.factor * table[idx];         // gravity.py:321
-                        ax += x_ji * total_factor;
-                        ay += y_ji * total_factor;
-                        az += z_ji * total_factor;
+                        bool hit = !(r2 > P.r2_max) && !(P.same && sidx[k] == pi);
+                        if (hit) {
+                            i64 idx = (i64)(r2 * P.r2_index_scaling);        // gravity.py:316
+                            double total_factor = P.factor * table[idx];     // gravity.py:321
+                            ax += x_ji * total_factor;
+                            ay += y_ji * total_factor;
+                            az += z_ji * total_factor;
+                        }
                     }
                 }
             }
