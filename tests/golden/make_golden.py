@@ -51,6 +51,12 @@ CASES = {
                                 dist='perfect_lattice', diff=4, full=False),
     'p3m_n16_g48_clustered': dict(method='p3m', n=16, gridsize=48, boxsize=48.0, seed=8,
                                   dist='clustered', diff=4, full=False),
+    # the callers (A18): init half kicks, then two base steps of drift -> kicks in the order
+    # of main.timeloop (main.py:255-361), with plain scalars
+    'steps_pm_n8_g16': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=11,
+                            dist='uniform', diff=2, steps=2),
+    'steps_p3m_n8_g32': dict(method='p3m', n=8, gridsize=32, boxsize=32.0, seed=12,
+                             dist='uniform', diff=4, steps=2),
 }
 
 
@@ -116,8 +122,81 @@ select_forces = {{'matter': {{'gravity': '{method}'}}}}
     return txt
 
 
+def child_steps(name):
+    """kick / drift sequence of main.timeloop (main.py:255-361) driven with plain
+    scalars: init = half long kick (+ half short kick for p3m); each base step =
+    drift, (short kick,) long kick.  The state after the init and after every step is
+    stored (rows sorted by x: the reference's tile_sort reorders particle memory)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, 'oracle', 'refharness'))
+    from ref_import import load_reference
+    cfg = CASES[name]
+    ref = load_reference(param_text(cfg), f'/tmp/concept_golden_work/{name}')
+    commons, interactions, species = ref.commons, ref.interactions, ref.species
+    L = commons.boxsize
+    pos = make_positions(np, cfg)
+    N = pos.shape[0]
+    rng = np.random.default_rng(1000 + cfg['seed'])
+    mass = commons.ρ_mbar*L**3/N
+    mom = rng.normal(0, 1.0, size=(N, 3))*mass*0.01
+    comp = species.Component('matter', 'matter', N=N, mass=mass)
+    for d, s_ in enumerate('xyz'):
+        comp.populate(np.ascontiguousarray(pos[:, d]), 'pos' + s_)
+        comp.populate(np.ascontiguousarray(mom[:, d]), 'mom' + s_)
+    method = cfg['method']
+    nr = commons.N_rungs
+    key2 = ('a**(-3*w_eff₀-3*w_eff₁-1)', 'matter', 'matter')
+
+    def scalars(dt):
+        return {'1': dt, 'a**(-2)': dt*1.3, ('a**(-3*w_eff)', 'matter'): dt*1.1,
+                ('a**(-3*w_eff-1)', 'matter'): dt*0.9}
+
+    def rung_scalars(dt):
+        return {key2: np.full(3*nr - 1, dt*0.8)}
+
+    def state():
+        p = np.array(comp.pos_mv3[:N])
+        m = np.array(comp.mom_mv3[:N])
+        o = np.argsort(p[:, 0], kind='stable')
+        return p[o].copy(), m[o].copy()
+
+    def kick_long(dt):
+        interactions.gravity(method, [comp], [comp], scalars(dt), 'long-range', False)
+
+    def kick_short(dt):
+        comp.nullify_Δ('mom')
+        comp.lowest_active_rung = 0
+        comp.lowest_populated_rung = 0
+        comp.highest_populated_rung = 0
+        interactions.gravity(method, [comp], [comp], rung_scalars(dt), 'short-range', False)
+        comp.apply_Δmom()
+
+    dt = 0.02
+    out = dict(boxsize=L, gridsize=cfg['gridsize'], G_Newton=commons.G_Newton, mass=mass, N=N,
+               diff_order=cfg['diff'], dt=dt, N_rungs=nr, method=method,
+               softening_length=comp.softening_length,
+               pos_in=np.array(comp.pos_mv3[:N]).copy(), mom_in=np.array(comp.mom_mv3[:N]).copy())
+    if method == 'p3m':
+        out['shortrange_scale'] = commons.shortrange_params['gravity']['scale']
+        out['shortrange_range'] = commons.shortrange_params['gravity']['range']
+    kick_long(dt/2)
+    if method == 'p3m':
+        kick_short(dt/2)
+    out['pos_init'], out['mom_init'] = state()
+    for step in range(cfg['steps']):
+        comp.drift(scalars(dt))
+        if method == 'p3m':
+            kick_short(dt)
+        kick_long(dt)
+        out[f'pos_step{step + 1}'], out[f'mom_step{step + 1}'] = state()
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, {k: getattr(v, 'shape', v) for k, v in out.items()})
+
+
 def child(name):
     import numpy as np
+    if 'steps' in CASES[name]:
+        return child_steps(name)
     sys.path.insert(0, os.path.join(REPO, 'oracle', 'refharness'))
     from ref_import import load_reference
     cfg = CASES[name]

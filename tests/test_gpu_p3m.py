@@ -118,3 +118,53 @@ def test_too_few_tiles_is_an_error():
     key = ('a**(-3*w_eff₀-3*w_eff₁-1)', 'matter', 'matter')
     with pytest.raises(ConceptGPUError):  # 16/(4.5*1.25*2) = 1.4 tiles < 4 (species.py:3971)
         interactions.gravity('p3m', [c], [c], {key: np.ones(23)}, 'short-range', False)
+
+
+@pytest.mark.parametrize('name', ['steps_pm_n8_g16', 'steps_p3m_n8_g32'])
+def test_timeloop_sequence_vs_reference(golden, name):
+    """A18: concept_amd.stepper.timeloop (init half kicks, then drift -> kicks) against
+    the reference's own sequence of Component.drift / gravity / apply_Δmom calls."""
+    import torch
+    from concept_amd import commons, stepper
+    from concept_amd.species import Component
+    g = golden(name)
+    method = str(g['method'])
+    commons.load_params({
+        'boxsize': float(g['boxsize']),
+        'potential_options': {'gridsize': {'gravity': {method: int(g['gridsize'])}},
+                              'differentiation': {'matter': {'gravity': {
+                                  method: int(g['diff_order'])}}}},
+        'select_forces': {'matter': {'gravity': method}},
+        'select_softening_length': {'matter': '0.03*boxsize/cbrt(N)'},
+    })
+    c = Component('matter', 'matter', N=int(g['N']), mass=float(g['mass']))
+    c.populate(g['pos_in'], 'pos')
+    c.populate(g['mom_in'], 'mom')
+    dt, nr = float(g['dt']), int(g['N_rungs'])
+
+    def integrals(kind):
+        d = dt/2 if kind == 'init' else dt
+        return {'1': d, 'a**(-2)': d*1.3, ('a**(-3*w_eff)', 'matter'): d*1.1,
+                ('a**(-3*w_eff-1)', 'matter'): d*0.9}
+
+    def rung_integrals(kind):
+        d = dt/2 if kind == 'init' else dt
+        return {('a**(-3*w_eff₀-3*w_eff₁-1)', 'matter', 'matter'): np.full(3*nr - 1, d*0.8)}
+
+    L = float(g['boxsize'])
+    seen = []
+
+    def on_step(step):
+        tag = 'init' if step == 0 else f'step{step}'
+        pos, mom = c.host('pos'), c.host('mom')
+        o = np.argsort(pos[:, 0], kind='stable')
+        dx = np.abs(pos[o] - g['pos_' + tag])
+        dx = np.minimum(dx, L - dx)
+        assert dx.max() <= 1e-13*L, tag
+        dm = np.abs(mom[o] - g['mom_' + tag]).max()
+        assert dm <= 1e-12*np.abs(g['mom_' + tag]).max(), tag
+        seen.append(tag)
+
+    # drift inside timeloop uses integrals('full')['a**(-2)'] like the reference's scalars(dt)
+    stepper.timeloop([c], 2, integrals, rung_integrals if method == 'p3m' else None, on_step)
+    assert seen == ['init', 'step1', 'step2']

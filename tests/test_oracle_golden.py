@@ -116,3 +116,53 @@ def test_p3m_shortrange(golden, name):
     assert np.abs(dmom - ref).max() <= 1e-13*max(np.abs(ref).max(), pair)
     # Newton's third law: the sweep conserves momentum
     assert np.abs(dmom.sum(0)).max() <= 1e-12*max(np.abs(ref).max(), pair)
+
+
+def _step_scalars(dt):
+    return dict(dt_1=dt, dt_am2=dt*1.3, dt_kick=dt*1.1, dt_dens=dt*0.9, dt_rung=dt*0.8)
+
+
+@pytest.mark.parametrize('name', ['steps_pm_n8_g16', 'steps_p3m_n8_g32'])
+def test_caller_sequence(golden, name):
+    """A18: the order of kicks and drifts of main.timeloop (main.py:255-361), replayed
+    through the oracle against the reference's own sequence (states sorted by x)."""
+    g = golden(name)
+    L, N, mass = float(g['boxsize']), int(g['gridsize']), float(g['mass'])
+    p3m = str(g['method']) == 'p3m'
+    pos, mom = g['pos_in'].copy(), g['mom_in'].copy()
+    common = dict(mass=mass, boxsize=L, gridsize=N, G_Newton=float(g['G_Newton']),
+                  diff_order=int(g['diff_order']), want_indices=False,
+                  shortrange_scale=float(g['shortrange_scale']) if p3m else None)
+
+    def kick_long(dt):
+        s = _step_scalars(dt)
+        oracle.pm_long_range(pos, mom, dt_1=s['dt_1'], dt_dens=s['dt_dens'], dt_kick=s['dt_kick'],
+                             **common)
+
+    def kick_short(dt):
+        factor = float(g['G_Newton'])*mass**2*_step_scalars(dt)['dt_rung']
+        dm, _ = oracle.shortrange_kick(
+            pos, boxsize=L, scale=float(g['shortrange_scale']), range_=float(g['shortrange_range']),
+            tilesize=float(g['shortrange_range']), tablesize=4096,
+            softening=float(g['softening_length']), factor=factor)
+        mom[...] += dm
+
+    def check(tag, exact):
+        o = np.argsort(pos[:, 0], kind='stable')
+        if exact:
+            assert np.array_equal(pos[o], g['pos_' + tag]) and np.array_equal(mom[o], g['mom_' + tag])
+        else:
+            assert np.abs(pos[o] - g['pos_' + tag]).max() <= 1e-13*L
+            assert np.abs(mom[o] - g['mom_' + tag]).max() <= 1e-12*np.abs(g['mom_' + tag]).max()
+
+    dt = float(g['dt'])
+    kick_long(dt/2)
+    if p3m:
+        kick_short(dt/2)
+    check('init', exact=not p3m)
+    for step in (1, 2):
+        oracle.drift(pos, mom, _step_scalars(dt)['dt_am2']/mass, L)
+        if p3m:
+            kick_short(dt)
+        kick_long(dt)
+        check(f'step{step}', exact=not p3m)
