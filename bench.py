@@ -349,9 +349,13 @@ def main():
         for _ in range(reps):
             for k, v in enumerate(mesh.poisson_solve_timed(4, C, False, 0.0)):
                 pass_ms[k] += v/reps
-        for nm, v in zip(('fft_z_forward', 'fft_y_forward', 'fft_x_fused_kspace',
-                          'fft_y_backward', 'fft_z_backward'), pass_ms):
-            kernels[nm] = (16*n_g, v)  # one read + one write of the mesh per pass
+        # SURVEY.md §8(d) accounting: forward 48*N_g (3 passes), k-space 16*N_g, inverse
+        # 48*N_g.  The fused x pass stands for the forward x pass + the k-space kernel +
+        # the inverse x pass (16 + 16 + 16); the five entries sum to the 112*N_g of the row.
+        for nm, v, b in zip(('fft_z_forward', 'fft_y_forward', 'fft_x_fused_kspace',
+                             'fft_y_backward', 'fft_z_backward'), pass_ms,
+                            (16, 16, 48, 16, 16)):
+            kernels[nm] = (b*n_g, v)
     dom = max(kernels, key=lambda k: kernels[k][1])
     ach = kernels[dom][0]/(kernels[dom][1]*1e-3)/1e9
     traffic = None
@@ -388,6 +392,14 @@ def main():
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach/HBM_PEAK_GBS, 4),
                      'traffic': traffic, 'algorithmic_bytes': kernels[dom][0],
                      'kernel_ms': round(kernels[dom][1], 4),
+                     'hbm_rate_GBps': (round(traffic/(kernels[dom][1]*1e-3)/1e9, 1)
+                                       if traffic else None),
+                     'note': ('algorithmic bytes follow SURVEY.md §8(d); for the fused x pass '
+                              'they are those of the three reference passes it replaces '
+                              '(x forward + k-space + x inverse = 48*N_g), its measured HBM '
+                              'traffic is one read + one write of the mesh'
+                              if dom == 'fft_x_fused_kspace' else
+                              'algorithmic bytes follow SURVEY.md §8(d) / DESIGN.md §4'),
                      'traffic_source': 'profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc '
                                        'FETCH_SIZE / WRITE_SIZE, separate passes)'},
         'kernels': {k: {'alg_GB': round(b/1e9, 3), 'ms': round(ms, 4),
