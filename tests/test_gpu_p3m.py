@@ -168,3 +168,35 @@ def test_timeloop_sequence_vs_reference(golden, name):
     # drift inside timeloop uses integrals('full')['a**(-2)'] like the reference's scalars(dt)
     stepper.timeloop([c], 2, integrals, rung_integrals if method == 'p3m' else None, on_step)
     assert seen == ['init', 'step1', 'step2']
+
+
+def test_config3_size_shortrange_properties():
+    """BASELINE configs[2] size (256^3 particles, 512^3 mesh, default short-range
+    parameters): the one-sided sweep conserves momentum (Newton's third law holds pair
+    by pair because both directions of a pair evaluate bit-identical r2 and table
+    entries), and is invariant under a permutation of the particle memory."""
+    import torch
+    from concept_amd import commons, shortrange
+    from concept_amd.mesh import PotentialMesh
+    N, L, n = 512, 512.0, 256**3
+    mesh = PotentialMesh(N, L)
+    gen = torch.Generator(device='cuda').manual_seed(8)
+    pos = torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=gen)*(L*(1 - 1e-13))
+    scale = 1.25*L/N
+    rng_ = 4.5*scale
+    nt = int(L/rng_*(1 + commons.machine_ϵ))
+    table, maxr2 = shortrange.get_shortrange_table(0.025*L/256, scale, rng_, 4096, 'spline',
+                                                   pos.device)
+    dm = torch.zeros_like(pos)
+    cells = mesh.shortrange_build(pos, nt, L/nt)
+    mesh.shortrange_sweep(pos, cells, dm, pos, cells, nt, True, table, 4095/maxr2, rng_**2, 1.0)
+    scale_f = float(dm.abs().max())
+    assert scale_f > 0
+    assert float(dm.sum(0).abs().max()) <= 1e-9*float(dm.abs().sum(0).max())
+    perm = torch.randperm(n, device='cuda', generator=gen)
+    pos2 = pos[perm].contiguous()
+    dm2 = torch.zeros_like(pos2)
+    cells2 = mesh.shortrange_build(pos2, nt, L/nt)
+    mesh.shortrange_sweep(pos2, cells2, dm2, pos2, cells2, nt, True, table, 4095/maxr2, rng_**2,
+                          1.0)
+    assert float((dm2 - dm[perm]).abs().max()) <= 1e-12*scale_f

@@ -520,3 +520,48 @@ def test_drift_sort_fused_equals_drift_then_sort(torch_cuda):
     m1[io1] = mo1
     m2[io2] = mo2
     assert torch.equal(m1, m2) and torch.equal(m1, mom)
+
+
+def test_north_star_size_properties(torch_cuda):
+    """BASELINE.json's metric configuration itself (2^28 particles / 1024^3 mesh, ~75 GB of
+    HBM): size-independent properties of the production kernels — the fused drift+sort is a
+    permutation, the LDS pull deposit equals the direct atomic deposit, total mass is
+    conserved, the tiled gather equals the direct gather bit for bit, the mesh force
+    transfers no net momentum."""
+    torch = torch_cuda
+    from concept_amd.mesh import PotentialMesh
+    N, L, n = 1024, 1024.0, 2**28
+    mesh = PotentialMesh(N, L)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    pos = torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=gen)
+    pos.mul_(L*(1 - 1e-13))
+    mom = torch.zeros_like(pos)
+    ids = torch.arange(n, device='cuda')
+    po, mo, io = torch.empty_like(pos), torch.empty_like(mom), torch.empty_like(ids)
+    table = mesh.drift_sort(pos, mom, ids, po, mo, io, 0.0)
+    assert (int(table[-1].item()) & 0xffffffff) == n
+    assert int(io.sum().item()) == n*(n - 1)//2
+    sample = torch.arange(0, n, 4099, device='cuda')
+    assert torch.equal(po[sample], pos[io[sample]])
+    del pos, ids
+    per = N*mesh.pad
+    a = torch.empty(N*per, dtype=torch.float64, device='cuda')
+    b = torch.empty(N*per, dtype=torch.float64, device='cuda')
+    mesh.deposit_tiled(po, table, 1.0, accumulate=False)
+    mesh.layers_read(0, N, a)
+    mesh.zero()
+    mesh.deposit(po, 1.0)
+    mesh.layers_read(0, N, b)
+    av = a.view(N, N, mesh.pad)[:, :, :N]
+    bv = b.view(N, N, mesh.pad)[:, :, :N]
+    assert float((av - bv).abs().max()) <= 1e-12*float(bv.abs().max())
+    assert abs(float(av.sum()) - n) <= 1e-9*n
+    del a, b, av, bv
+    mesh.poisson_solve(4, -1.0, False, 0.0)
+    k_t = torch.zeros_like(mo)
+    mesh.gather_kick_tiled(po, k_t, table, 2, 1.0)
+    mesh.gather_kick(po, mo, 2, 1.0)
+    assert torch.equal(k_t, mo)
+    tot = mo.sum(0).abs().max()
+    assert float(tot) <= 1e-9*float(mo.abs().sum(0).max())
+    mesh.close()
