@@ -20,6 +20,8 @@
 //      half-length complex transform + split/merge step
 //   y, x: complex pencils with stride pad/2 and N*pad/2; 4 adjacent kk per
 //      workgroup (64-byte segments per row)
+#include <cstdlib>
+
 #include "cg_internal.h"
 #include "cg_kspace.h"  // its factor function pins fp-contract off itself
 
@@ -227,13 +229,13 @@ __device__ __forceinline__ i64 pencil_off(const PencilMap &pm, int m) {
     return (i64)(m >> pm.sh) * pm.blk + (i64)((unsigned)m & ((1u << pm.sh) - 1u)) * pm.es;
 }
 
-template <int LOGN, int NT, int MODE>
+template <int LOGN, int NT, int MODE, int W>
 __global__ __launch_bounds__(NT) void k_fft_strided(const double2 *__restrict__ src,
                                                     double2 *__restrict__ dst, PencilMap smap,
                                                     PencilMap dmap, int nkb, i64 o_off,
                                                     const double2 *__restrict__ tw,
                                                     KspaceParams P) {
-    constexpr int N = 1 << LOGN, W = 4;
+    constexpr int N = 1 << LOGN;
     extern __shared__ double2 lds_dyn[];
     double2 *lds = lds_dyn;
     const int tid = threadIdx.x;
@@ -305,16 +307,16 @@ static int run_z(cg_ctx *c, bool inverse) {
     return 0;
 }
 
-template <int LOGN, int MODE>
-static int run_strided(cg_ctx *c, const double2 *src, double2 *dst, PencilMap smap,
-                       PencilMap dmap, i64 nouter, i64 o_off, const KspaceParams &P) {
+template <int LOGN, int MODE, int W>
+static int run_strided_w(cg_ctx *c, const double2 *src, double2 *dst, PencilMap smap,
+                         PencilMap dmap, i64 nouter, i64 o_off, const KspaceParams &P) {
     constexpr int N = 1 << LOGN;
-    // 512 lanes per 4-pencil workgroup from N = 512 up: the 64 KB (N = 1024) LDS tile
-    // allows only 2 workgroups per CU, so the waves must come from the workgroup size
-    constexpr int NT = N >= 2048 ? 1024 : (N >= 512 ? 512 : (N >= 256 ? 256 : 64));
-    const int nkb = (int)((c->N / 2 + 1 + 3) / 4);
-    size_t lds = sizeof(double2) * N * 4;
-    auto kern = k_fft_strided<LOGN, NT, MODE>;
+    // lanes: N*W/8 points per lane (two radix-4 butterflies per pass), 64..1024
+    constexpr int NTW = N * W / 8;
+    constexpr int NT = NTW < 64 ? 64 : (NTW > 1024 ? 1024 : NTW);
+    const int nkb = (int)((c->N / 2 + 1 + W - 1) / W);
+    size_t lds = sizeof(double2) * N * W;
+    auto kern = k_fft_strided<LOGN, NT, MODE, W>;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         CG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -325,6 +327,21 @@ static int run_strided(cg_ctx *c, const double2 *src, double2 *dst, PencilMap sm
                        smap, dmap, nkb, o_off, (const double2 *)c->fft_tw, P);
     CG_LAUNCH_CHECK();
     return 0;
+}
+
+// W adjacent kk per workgroup: 4 (64-byte row segments, 64 KB LDS at N = 1024, two
+// workgroups per CU) by default; CONCEPT_GPU_FFT_W=2 selects 2 (32-byte segments, four
+// workgroups per CU) for A/B measurements.
+template <int LOGN, int MODE>
+static int run_strided(cg_ctx *c, const double2 *src, double2 *dst, PencilMap smap,
+                       PencilMap dmap, i64 nouter, i64 o_off, const KspaceParams &P) {
+    static int w = 0;
+    if (!w) {
+        const char *env = getenv("CONCEPT_GPU_FFT_W");
+        w = (env && env[0] == '2') ? 2 : 4;
+    }
+    if (w == 2) return run_strided_w<LOGN, MODE, 2>(c, src, dst, smap, dmap, nouter, o_off, P);
+    return run_strided_w<LOGN, MODE, 4>(c, src, dst, smap, dmap, nouter, o_off, P);
 }
 
 static PencilMap plain_map(i64 ostride, i64 es) { return PencilMap{ostride, es, 0, 31}; }
