@@ -338,9 +338,12 @@ static int run_strided(cg_ctx *c, const double2 *src, double2 *dst, PencilMap sm
     static int w = 0;
     if (!w) {
         const char *env = getenv("CONCEPT_GPU_FFT_W");
-        w = (env && env[0] == '2') ? 2 : 4;
+        w = (env && env[0] == '2') ? 2 : ((env && env[0] == '8') ? 8 : 4);
     }
     if (w == 2) return run_strided_w<LOGN, MODE, 2>(c, src, dst, smap, dmap, nouter, o_off, P);
+    if (w == 8 && LOGN <= 10)  // 8 pencils of 2048 points would not fit the 160 KB LDS
+        return run_strided_w<(LOGN <= 10 ? LOGN : 10), MODE, 8>(c, src, dst, smap, dmap, nouter,
+                                                                o_off, P);
     return run_strided_w<LOGN, MODE, 4>(c, src, dst, smap, dmap, nouter, o_off, P);
 }
 
