@@ -329,16 +329,20 @@ static int run_strided_w(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
     return 0;
 }
 
-// W adjacent kk per workgroup: 4 (64-byte row segments, 64 KB LDS at N = 1024, two
-// workgroups per CU) by default; CONCEPT_GPU_FFT_W=2 selects 2 (32-byte segments, four
-// workgroups per CU) for A/B measurements.
+// W adjacent kk per workgroup.  Measured at 1024^3 (ms per y pass / fused x pass):
+//   W = 2 (32 B row segments, 4 workgroups per CU)  9.4 / 9.6
+//   W = 4 (64 B, 2 per CU)                          4.6 / 7.9
+//   W = 8 (128 B = one full cache line, 1 per CU)   3.95 / 7.4
+// The row-segment width, not the occupancy, decides: default 8 (N <= 1024; 8 pencils of
+// 2048 points exceed the 160 KB LDS, so 4 there).  CONCEPT_GPU_FFT_W overrides for A/B.
 template <int LOGN, int MODE>
 static int run_strided(cg_ctx *c, const double2 *src, double2 *dst, PencilMap smap,
                        PencilMap dmap, i64 nouter, i64 o_off, const KspaceParams &P) {
     static int w = 0;
     if (!w) {
         const char *env = getenv("CONCEPT_GPU_FFT_W");
-        w = (env && env[0] == '2') ? 2 : ((env && env[0] == '8') ? 8 : 4);
+        w = env ? atoi(env) : 8;
+        if (w != 2 && w != 4 && w != 8) w = 8;
     }
     if (w == 2) return run_strided_w<LOGN, MODE, 2>(c, src, dst, smap, dmap, nouter, o_off, P);
     if (w == 8 && LOGN <= 10)  // 8 pencils of 2048 points would not fit the 160 KB LDS
