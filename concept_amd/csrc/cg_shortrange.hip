@@ -117,6 +117,10 @@ __global__ __launch_bounds__(64) void k_sr_sweep(
     const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
     const double *__restrict__ pos_s, const unsigned *__restrict__ order_s,
     const unsigned *__restrict__ off_s, const double *__restrict__ table, SrParams P) {
+    // A tile holds ~20 particles with the default parameters, far fewer than the 64
+    // lanes: the wavefront is split into S = 64/R groups of R lanes (R = the power of
+    // two >= the receivers of a chunk); group s takes suppliers s, s+S, s+2S, ... of
+    // every staged chunk and the S partial sums of a receiver are folded with shuffles.
     __shared__ double sx[64], sy[64], sz[64];
     __shared__ unsigned sidx[64];
     const int lane = threadIdx.x;
@@ -126,8 +130,12 @@ __global__ __launch_bounds__(64) void k_sr_sweep(
     if (rbeg == rend) return;
     const int ra = tr / (nt * nt), rb = (tr / nt) % nt, rc = tr % nt;
     for (unsigned base = rbeg; base < rend; base += 64) {
-        const bool active = base + lane < rend;
-        const unsigned pi = active ? order_r[base + lane] : 0u;
+        const int nrec = (int)min(64u, rend - base);
+        int R = 8;
+        while (R < nrec) R <<= 1;
+        const int S = 64 / R, sub = lane / R, rl = lane % R;
+        const bool active = rl < nrec;
+        const unsigned pi = active ? order_r[base + rl] : 0u;
         double xi = 0, yi = 0, zi = 0;
         if (active) {
             xi = pos_r[3 * (i64)pi];
@@ -158,9 +166,9 @@ __global__ __launch_bounds__(64) void k_sr_sweep(
                 const int cnt = (int)min(64u, send - cb);
                 if (active) {
                     // straight-line body (predicated, no early exits) so that the compiler
-                    // can overlap the LDS broadcasts and FP64 chains of several partners
+                    // can overlap the LDS reads and FP64 chains of several partners
 #pragma unroll 4
-                    for (int k = 0; k < cnt; k++) {
+                    for (int k = sub; k < cnt; k += S) {
                         double x_ji = xi - sx[k];               // interactions.py:1787-1789
                         double y_ji = yi - sy[k];
                         double z_ji = zi - sz[k];
@@ -182,7 +190,13 @@ __global__ __launch_bounds__(64) void k_sr_sweep(
                 }
             }
         }
-        if (active) {
+        // fold the S partial sums of each receiver (lanes rl, rl + R, rl + 2R, ...)
+        for (int o = 32; o >= R; o >>= 1) {
+            ax += __shfl_down(ax, o);
+            ay += __shfl_down(ay, o);
+            az += __shfl_down(az, o);
+        }
+        if (active && sub == 0) {
             dmom_r[3 * (i64)pi] += ax;
             dmom_r[3 * (i64)pi + 1] += ay;
             dmom_r[3 * (i64)pi + 2] += az;
