@@ -379,7 +379,8 @@ def main():
     }
     ms_per_step = elapsed/args.steps*1e3
     result = {
-        'metric': 'PM particle-updates/sec', 'value': n_p*world*args.steps/elapsed,
+        'metric': ('P3M' if args.p3m else 'PM') + ' particle-updates/sec',
+        'value': n_p*world*args.steps/elapsed,
         'unit': 'particle-updates/s', 'steps_per_sec': args.steps/elapsed,
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong',

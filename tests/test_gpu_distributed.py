@@ -36,7 +36,7 @@ def single_domain(N, n_side, steps):
     return pos.cpu().numpy(), mom.cpu().numpy()
 
 
-@pytest.mark.parametrize('world,N', [(2, 32), (4, 64), (2, 64)])
+@pytest.mark.parametrize('world,N', [(2, 32), (4, 64), (2, 64), (8, 128)])
 def test_slab_domains_match_single_domain(world, N):
     n_side, steps = 20, 3
     pos_ref, mom_ref = single_domain(N, n_side, steps)
