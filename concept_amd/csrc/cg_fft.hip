@@ -213,10 +213,10 @@ __global__ __launch_bounds__(NT) void k_fft_z_backward(double *__restrict__ mesh
 // pencil; a finite sh addresses the pencil in blocks of 2^sh points, which is
 // the layout of the all-to-all transpose buffers of the multi-GPU path (the
 // pack / unpack of the transpose is fused into this pass).
-// (With 4 pencils per workgroup a persistent, prefetching variant gained nothing —
-// 4.57 vs 4.60 ms per pass — because its registers cost the second resident workgroup;
-// with 8 pencils there is one workgroup per CU anyway and the prefetch is what overlaps
-// HBM latency with the LDS passes.)
+// (Persistent variants that prefetch the next tile into registers while the current
+// one is transformed were measured twice: with 4 pencils 4.57 vs 4.60 ms per pass — the
+// registers cost the second resident workgroup what the prefetch gains; with 8 pencils
+// the 8 staged double2 per lane on top of the butterflies spill (5.8 ms).  Not used.)
 // For the factor, the pencil index m and the outer index o + o_off are the two
 // full dimensions (the expression is symmetric in them).
 // ---------------------------------------------------------------------------
@@ -233,25 +233,23 @@ __device__ __forceinline__ i64 pencil_off(const PencilMap &pm, int m) {
 template <int LOGN, int NT, int MODE, int W>
 __global__ __launch_bounds__(NT) void k_fft_strided(const double2 *__restrict__ src,
                                                     double2 *__restrict__ dst, PencilMap smap,
-                                                    PencilMap dmap, int nkb, int ntiles, i64 o_off,
+                                                    PencilMap dmap, int nkb, i64 o_off,
                                                     const double2 *__restrict__ tw,
                                                     KspaceParams P) {
-    // Persistent workgroups: each walks tiles t = blockIdx.x, += gridDim.x and keeps the
-    // NEXT tile's global loads in flight (in registers) while it transforms the current
-    // one in LDS.  With 8 pencils the 128 KB tile (N = 1024) leaves one workgroup per CU,
-    // so the overlap of HBM latency with the LDS passes has to happen inside it.
     constexpr int N = 1 << LOGN;
     extern __shared__ double2 lds_dyn[];
     double2 *lds = lds_dyn;
     const int tid = threadIdx.x;
+    const i64 o = blockIdx.x / nkb;
+    const int kb = blockIdx.x - (int)o * nkb;
+    const int kk0 = kb * W;
     const int nk = N / 2 + 1;  // valid kk: 0..N/2
+    const double2 *sbase = src + o * smap.ostride + kk0;
+    double2 *dbase = dst + o * dmap.ostride + kk0;
     constexpr int TOT = N * W;
     constexpr int PER = (TOT + NT - 1) / NT;
-    double2 v[PER];
-    auto load_tile = [&](int t) {
-        const i64 o = t / nkb;
-        const int kk0 = (t - (int)o * nkb) * W;
-        const double2 *sbase = src + o * smap.ostride + kk0;
+    {
+        double2 v[PER];
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             int f = tid + r * NT;
@@ -259,46 +257,36 @@ __global__ __launch_bounds__(NT) void k_fft_strided(const double2 *__restrict__ 
             bool ok = (TOT % NT == 0 || f < TOT) && (kk0 + w < nk);
             v[r] = ok ? sbase[pencil_off(smap, m) + w] : make_double2(0, 0);
         }
-    };
-    int t = blockIdx.x;
-    if (t < ntiles) load_tile(t);
-    for (; t < ntiles; t += gridDim.x) {
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             int f = tid + r * NT;
             if (TOT % NT == 0 || f < TOT) lds[f] = v[r];
         }
-        __syncthreads();
-        if (t + (int)gridDim.x < ntiles) load_tile(t + gridDim.x);
-        const i64 o = t / nkb;
-        const int kk0 = (t - (int)o * nkb) * W;
-        if (MODE == 0 || MODE == 2) fft_lds<LOGN, W, NT, false>(lds, tw, 1, tid);
-        if (MODE == 2) {
-#pragma unroll
-            for (int r = 0; r < PER; r++) {
-                int f = tid + r * NT;
-                if (TOT % NT == 0 || f < TOT) {
-                    int w = f % W, m = f / W;
-                    int kk = kk0 + w;
-                    if (kk < nk) {
-                        double fac = kspace_factor(P, N, m, o + o_off, kk);
-                        double2 x = lds[f];
-                        lds[f] = make_double2(x.x * fac, x.y * fac);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        if (MODE == 1 || MODE == 2) fft_lds<LOGN, W, NT, true>(lds, tw, 1, tid);
-        double2 *dbase = dst + o * dmap.ostride + kk0;
+    }
+    __syncthreads();
+    if (MODE == 0 || MODE == 2) fft_lds<LOGN, W, NT, false>(lds, tw, 1, tid);
+    if (MODE == 2) {
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             int f = tid + r * NT;
-            int w = f % W, m = f / W;
-            if ((TOT % NT == 0 || f < TOT) && (kk0 + w < nk))
-                dbase[pencil_off(dmap, m) + w] = lds[f];
+            if (TOT % NT == 0 || f < TOT) {
+                int w = f % W, m = f / W;
+                int kk = kk0 + w;
+                if (kk < nk) {
+                    double fac = kspace_factor(P, N, m, o + o_off, kk);
+                    double2 x = lds[f];
+                    lds[f] = make_double2(x.x * fac, x.y * fac);
+                }
+            }
         }
-        __syncthreads();  // the LDS tile is free for the next one
+        __syncthreads();
+    }
+    if (MODE == 1 || MODE == 2) fft_lds<LOGN, W, NT, true>(lds, tw, 1, tid);
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        int f = tid + r * NT;
+        int w = f % W, m = f / W;
+        if ((TOT % NT == 0 || f < TOT) && (kk0 + w < nk)) dbase[pencil_off(dmap, m) + w] = lds[f];
     }
 }
 
@@ -324,10 +312,9 @@ template <int LOGN, int MODE, int W>
 static int run_strided_w(cg_ctx *c, const double2 *src, double2 *dst, PencilMap smap,
                          PencilMap dmap, i64 nouter, i64 o_off, const KspaceParams &P) {
     constexpr int N = 1 << LOGN;
-    // lanes: N*W/16 (four radix-4 butterflies per lane and pass), 64..512: the prefetch
-    // registers of the persistent loop need the 256-VGPR budget of <= 2 waves per SIMD
-    constexpr int NTW = N * W / 16;
-    constexpr int NT = NTW < 64 ? 64 : (NTW > 512 ? 512 : NTW);
+    // lanes: N*W/8 points per lane (two radix-4 butterflies per pass), 64..1024
+    constexpr int NTW = N * W / 8;
+    constexpr int NT = NTW < 64 ? 64 : (NTW > 1024 ? 1024 : NTW);
     const int nkb = (int)((c->N / 2 + 1 + W - 1) / W);
     size_t lds = sizeof(double2) * N * W;
     auto kern = k_fft_strided<LOGN, NT, MODE, W>;
@@ -337,15 +324,8 @@ static int run_strided_w(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
                                    (int)lds));
         attr_set = true;
     }
-    const i64 ntiles = nouter * nkb;
-    i64 per_cu = (160 * 1024) / (i64)lds;  // workgroups one CU can hold (LDS / wave limits)
-    per_cu = per_cu < 1 ? 1 : per_cu;
-    if (per_cu > 2048 / NT) per_cu = 2048 / NT;
-    if (per_cu > 8) per_cu = 8;
-    i64 grid = 256 * per_cu;
-    if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, c->stream, src, dst, smap, dmap,
-                       nkb, (int)ntiles, o_off, (const double2 *)c->fft_tw, P);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nouter * nkb)), dim3(NT), lds, c->stream, src, dst,
+                       smap, dmap, nkb, o_off, (const double2 *)c->fft_tw, P);
     CG_LAUNCH_CHECK();
     return 0;
 }
