@@ -47,12 +47,31 @@ __device__ __forceinline__ unsigned sr_tile(const double *__restrict__ pos, i64 
     return (i * nt + j) * nt + k;
 }
 
+// runs of equal keys inside a wavefront -> one atomic per run (device-scope atomics are
+// memory-side on MI355X; particle memory is in mesh-tile order, so runs are long)
+__device__ __forceinline__ void sr_wave_runs(unsigned key, int lane, int &run_start, int &run_len) {
+    unsigned prev = __shfl_up(key, 1);
+    bool head = (lane == 0) || (key != prev);
+    unsigned long long mask = __ballot(head);
+    unsigned long long below = mask & (~0ull >> (63 - lane));
+    run_start = 63 - __clzll(below);
+    unsigned long long above = (lane == 63) ? 0ull : (mask >> (lane + 1));
+    int next = above ? (lane + 1 + (__ffsll((long long)above) - 1)) : 64;
+    run_len = next - run_start;
+}
+
 __global__ __launch_bounds__(256) void k_sr_histogram(const double *__restrict__ pos, i64 n,
                                                       double inv, unsigned nt,
                                                       unsigned *__restrict__ count) {
     i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride)
-        atomicAdd(&count[sr_tile(pos, p, inv, nt)], 1u);
+    int lane = threadIdx.x & 63;
+    for (i64 base = (i64)blockIdx.x * blockDim.x; base < n; base += stride) {
+        i64 p = base + threadIdx.x;
+        unsigned key = p < n ? sr_tile(pos, p, inv, nt) : 0xffffffffu;
+        int rs, rl;
+        sr_wave_runs(key, lane, rs, rl);
+        if (lane == rs && p < n) atomicAdd(&count[key], (unsigned)rl);
+    }
 }
 __global__ __launch_bounds__(256) void k_sr_scatter(const double *__restrict__ pos, i64 n,
                                                     double inv, unsigned nt,
@@ -60,9 +79,16 @@ __global__ __launch_bounds__(256) void k_sr_scatter(const double *__restrict__ p
                                                     unsigned *__restrict__ cursor,
                                                     unsigned *__restrict__ order) {
     i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
-        unsigned t = sr_tile(pos, p, inv, nt);
-        order[offset[t] + atomicAdd(&cursor[t], 1u)] = (unsigned)p;
+    int lane = threadIdx.x & 63;
+    for (i64 base = (i64)blockIdx.x * blockDim.x; base < n; base += stride) {
+        i64 p = base + threadIdx.x;
+        unsigned key = p < n ? sr_tile(pos, p, inv, nt) : 0xffffffffu;
+        int rs, rl;
+        sr_wave_runs(key, lane, rs, rl);
+        unsigned first = 0;
+        if (lane == rs && p < n) first = offset[key] + atomicAdd(&cursor[key], (unsigned)rl);
+        first = __shfl(first, rs);
+        if (p < n) order[first + (lane - rs)] = (unsigned)p;
     }
 }
 int cgk_shortrange_build(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
