@@ -400,7 +400,6 @@ extern "C" int cg_shortrange_build(cg_ctx *c, const double *pos, int64_t n, int6
                                    double tile_extent, uint32_t *order_out,
                                    uint32_t *offset_out) {
     CG_CHECK(c && offset_out && (n == 0 || (pos && order_out)), "cg_shortrange_build: null argument");
-    CG_CHECK(c->p.nprocs == 1, "cg_shortrange_build: single-domain only so far");
     CG_CHECK(nt >= 4, "The global gravity tiling needs to have at least 4 tiles across the box in "
                       "every direction (species.py:3971); got %lld", (long long)nt);
     CG_CHECK(nt <= 1024 && n < (1ll << 32), "cg_shortrange_build: size out of range");

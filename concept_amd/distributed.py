@@ -79,11 +79,15 @@ class Comm:
             s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
         else:
             s, r = send, recv
-        ops = [dist.P2POp(dist.isend, s, dest, group=self.group),
-               dist.P2POp(dist.irecv, r, source, group=self.group)]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        if self.stage:
+        ops = []  # empty messages are skipped on both ends (sizes are known to both)
+        if s.numel():
+            ops.append(dist.P2POp(dist.isend, s, dest, group=self.group))
+        if r.numel():
+            ops.append(dist.P2POp(dist.irecv, r, source, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if self.stage and r.numel():
             recv.copy_(r)
 
     def all_gather_ints(self, values):
@@ -247,6 +251,65 @@ def exchange_rows(comm, owner, pos, mom, ids, n, cap, dead_x):
     elif m_out > k:
         pos[move_idx[k:], 0] = dead_x
     return n_slots, n - m_out + m_in
+
+
+def shortrange_kick(domain, particles, *, scale, range_, tilesize, tablesize, softening,
+                    factor, kernel='spline'):
+    """P3M short-range kick of a particle set onto itself over x-slab domains
+    (component_component + sendrecv_component, interactions.py:122-329,
+    communication.py:847-1130).  Each rank receives the positions of the neighbour
+    ranks' particles that lie within the force range of its slab ("supplier
+    particles in the boundary tiles") and runs the one-sided tile sweep for its own
+    particles; because the sweep is one-sided no Δmom travels back (the reference
+    returns it because its pair update is symmetric).  Returns Δmom (n, 3)."""
+    from . import commons, shortrange
+    d = domain
+    comm, P, rank = d.comm, d.world, d.rank
+    L, N = d.boxsize, d.N
+    nt = int((L/1)/tilesize*(1 + commons.machine_ϵ))  # global tiling, species.py:3943-3950
+    if nt < 4:
+        raise lib.ConceptGPUError(
+            'The global gravity tiling needs to have at least 4 tiles across the box in every '
+            'direction (species.py:3971)')
+    cell = L/N
+    slab_w = d.nxl*cell
+    if range_*1.001 >= slab_w or (P == 2 and 2.002*range_ >= slab_w):
+        raise lib.ConceptGPUError('short-range force range too large for the slab width')
+    pos = particles.view('pos')
+    n = pos.shape[0]
+    # slab in position space: lower CIC cell in [x0, x0 + nxl)  <=>  x in [xlo, xhi) (wrapped)
+    xlo = (d.mesh.x0 + 0.5)*cell
+    x = pos[:, 0]
+    rel = torch.remainder(x - xlo, L)           # 0 .. slab_w for owned particles
+    margin = range_*(1 + 1e-9) + 1e-9*L
+    to_prev = pos[rel < margin]                  # near my lower face -> previous rank
+    to_next = pos[rel >= slab_w - margin]        # near my upper face -> next rank
+
+    def ship(send, dest, source):
+        cnt = torch.tensor([send.shape[0]], dtype=torch.int64, device=send.device)
+        got = torch.empty_like(cnt)
+        comm.sendrecv(cnt, dest, got, source)
+        recv = torch.empty((int(got.item()), 3), dtype=torch.float64, device=send.device)
+        comm.sendrecv(send.contiguous(), dest, recv, source)
+        return recv
+    if P == 1:
+        ghosts = [pos.new_zeros((0, 3))]
+    else:
+        from_next = ship(to_prev, d.prev, d.next)   # what my next rank has near ITS lower face
+        from_prev = ship(to_next, d.next, d.prev)
+        ghosts = [from_prev, from_next]
+    supp = torch.cat([pos] + ghosts).contiguous()
+    m = d.mesh
+    ext = L/nt
+    cells_r = m.shortrange_build(pos.contiguous(), nt, ext)
+    cells_s = m.shortrange_build(supp, nt, ext)
+    table, maxr2 = shortrange.get_shortrange_table(softening, scale, range_, tablesize, kernel,
+                                                   pos.device)
+    dmom = torch.zeros((n, 3), dtype=torch.float64, device=pos.device)
+    # `same`: supplier rows 0..n-1 ARE the receivers (same order), ghosts follow
+    m.shortrange_sweep(pos.contiguous(), cells_r, dmom, supp, cells_s, nt, True, table,
+                       (tablesize - 1)/maxr2, range_**2, factor)
+    return dmom
 
 
 def pm_kick(domain, particles, contribution, deconv_order, C, kick_factor, diff_order=2,

@@ -18,7 +18,8 @@ def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) if backend == 'nccl' else 0)
     dist.init_process_group(backend, rank=rank, world_size=world)
-    from concept_amd.distributed import DistributedParticles, SlabDomain, pm_kick
+    from concept_amd.distributed import DistributedParticles, SlabDomain, pm_kick, shortrange_kick
+    p3m = len(sys.argv) > 6 and sys.argv[6] == 'p3m'
     L = 64.0
     dom = SlabDomain(N, L)
     rng = np.random.default_rng(77)
@@ -33,7 +34,13 @@ def main():
     parts.tile_sort()
     contribution, C, kick, dtm = 0.37, -2.5, -0.002, 0.9
     for step in range(steps):
-        pm_kick(dom, parts, contribution, 4, C, kick, diff_order=2 + 2*(step % 2))
+        if p3m:
+            scale = 1.25*L/N
+            dm = shortrange_kick(dom, parts, scale=scale, range_=4.5*scale, tilesize=4.5*scale,
+                                 tablesize=4096, softening=0.05*L/n_side, factor=3e-4)
+            parts.view('mom').add_(dm)
+        pm_kick(dom, parts, contribution, 4, C, kick, diff_order=2 + 2*(step % 2),
+                long_range=p3m, E=-(2*np.pi/L*1.25*L/N)**2 if p3m else 0.0)
         parts.drift(dtm)
         parts.exchange()
         parts.tile_sort()

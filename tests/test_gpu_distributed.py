@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def single_domain(N, n_side, steps):
+def single_domain(N, n_side, steps, p3m=False):
     import torch
+    from concept_amd import commons, shortrange
     from concept_amd.mesh import PotentialMesh
     L = 64.0
     mesh = PotentialMesh(N, L)
@@ -28,18 +29,30 @@ def single_domain(N, n_side, steps):
     mom = torch.tensor(rng.normal(0, 1.0, (n, 3)), device='cuda')
     contribution, C, kick, dtm = 0.37, -2.5, -0.002, 0.9
     for step in range(steps):
+        if p3m:
+            scale = 1.25*L/N
+            rng_ = 4.5*scale
+            nt = int(L/rng_*(1 + commons.machine_ϵ))
+            table, maxr2 = shortrange.get_shortrange_table(0.05*L/n_side, scale, rng_, 4096,
+                                                           'spline', pos.device)
+            cells = mesh.shortrange_build(pos, nt, L/nt)
+            dm = torch.zeros_like(mom)
+            mesh.shortrange_sweep(pos, cells, dm, pos, cells, nt, True, table, 4095/maxr2,
+                                  rng_**2, 3e-4)
+            mom += dm
         mesh.zero()
         mesh.deposit(pos, contribution)
-        mesh.poisson_solve(4, C, False, 0.0)
+        mesh.poisson_solve(4, C, p3m, -(2*np.pi/L*1.25*L/N)**2 if p3m else 0.0)
         mesh.gather_kick(pos, mom, 2 + 2*(step % 2), kick)
         mesh.drift(pos, mom, dtm)
     return pos.cpu().numpy(), mom.cpu().numpy()
 
 
-@pytest.mark.parametrize('world,N', [(2, 32), (4, 64), (2, 64), (8, 128)])
-def test_slab_domains_match_single_domain(world, N):
+@pytest.mark.parametrize('world,N,p3m', [(2, 32, False), (4, 64, False), (2, 64, False),
+                                         (8, 128, False), (2, 64, True), (4, 128, True)])
+def test_slab_domains_match_single_domain(world, N, p3m):
     n_side, steps = 20, 3
-    pos_ref, mom_ref = single_domain(N, n_side, steps)
+    pos_ref, mom_ref = single_domain(N, n_side, steps, p3m)
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
@@ -51,7 +64,8 @@ def test_slab_domains_match_single_domain(world, N):
                        MASTER_PORT=str(port))
             procs.append(subprocess.Popen(
                 [sys.executable, os.path.join(REPO, 'tests', 'dist_worker.py'), tmp, str(N),
-                 str(n_side), str(steps), 'gloo'], env=env, stdout=subprocess.PIPE,
+                 str(n_side), str(steps), 'gloo', 'p3m' if p3m else 'pm'], env=env,
+                stdout=subprocess.PIPE,
                 stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=600)[0].decode() for p in procs]
         for r, p in enumerate(procs):
