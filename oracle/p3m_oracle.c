@@ -106,3 +106,73 @@ int orc_shortrange_sweep(const double *pos, i64 N, double *dmom, double boxsize,
     free(tile); free(start); free(order); free(cursor);
     return 0;
 }
+
+/*
+ * The sweep with adaptive rungs (particle_particle's rung logic,
+ * interactions.py:1688-1761, and gravity_pairwise_shortrange, gravity.py:318-349):
+ * particle i receives r*f*factors[rung_jumped[i]] if its rung is active
+ * (rung[i] >= lowest_active_rung); a pair of two inactive particles is skipped.
+ * factors[k] = G*m_r*m_s*ᔑdt_rungs[...][k], k < 3*N_rungs - 1 (gravity.py:51-64).
+ */
+int orc_shortrange_sweep_rungs(const double *pos, i64 N, double *dmom, double boxsize, i64 nt,
+                               double tile_extent, double eps, const double *table,
+                               double r2_index_scaling, double r2_max, const double *factors,
+                               const signed char *rung, const signed char *rung_jumped,
+                               int lowest_active_rung) {
+    i64 ntiles = nt * nt * nt;
+    i64 *tile = malloc(sizeof(i64) * (N > 0 ? N : 1));
+    i64 *start = calloc(ntiles + 1, sizeof(i64));
+    i64 *order = malloc(sizeof(i64) * (N > 0 ? N : 1));
+    i64 *cursor = calloc(ntiles, sizeof(i64));
+    if (!tile || !start || !order || !cursor) return 1;
+    orc_shortrange_tiles(pos, N, nt, tile_extent, eps, tile);
+    for (i64 p = 0; p < N; p++) {
+        if (tile[p] < 0 || tile[p] >= ntiles) return 2;
+        start[tile[p] + 1]++;
+    }
+    for (i64 t = 0; t < ntiles; t++) start[t + 1] += start[t];
+    for (i64 p = 0; p < N; p++) order[start[tile[p]] + cursor[tile[p]]++] = p;
+    for (i64 tr = 0; tr < ntiles; tr++) {
+        i64 ra = tr / (nt * nt), rb = (tr / nt) % nt, rc = tr % nt;
+        for (int da = -1; da <= 1; da++) for (int db = -1; db <= 1; db++)
+        for (int dc = -1; dc <= 1; dc++) {
+            i64 sa = ra + da, sb = rb + db, sc = rc + dc;
+            double off[3] = {0, 0, 0};
+            if (sa < 0) { sa += nt; off[0] = boxsize; } else if (sa >= nt) { sa -= nt; off[0] = -boxsize; }
+            if (sb < 0) { sb += nt; off[1] = boxsize; } else if (sb >= nt) { sb -= nt; off[1] = -boxsize; }
+            if (sc < 0) { sc += nt; off[2] = boxsize; } else if (sc >= nt) { sc -= nt; off[2] = -boxsize; }
+            i64 ts = (sa * nt + sb) * nt + sc;
+            if (ts < tr) continue;
+            for (i64 a = start[tr]; a < start[tr + 1]; a++) {
+                i64 i = order[a];
+                int act_i = rung[i] >= lowest_active_rung;
+                double xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+                for (i64 b = (ts == tr ? a + 1 : start[ts]); b < start[ts + 1]; b++) {
+                    i64 j = order[b];
+                    int act_j = rung[j] >= lowest_active_rung;
+                    if (!act_i && !act_j) continue; /* interactions.py:1693-1707 */
+                    double x_ji = xi - pos[3 * j], y_ji = yi - pos[3 * j + 1],
+                           z_ji = zi - pos[3 * j + 2];
+                    if (off[0] != 0 || off[1] != 0 || off[2] != 0) {
+                        x_ji += off[0]; y_ji += off[1]; z_ji += off[2];
+                    }
+                    double r2 = x_ji * x_ji + y_ji * y_ji + z_ji * z_ji;
+                    if (r2 > r2_max) continue;
+                    double f = table[(i64)(r2 * r2_index_scaling)];
+                    if (act_i) { /* gravity.py:320-327 */
+                        double tf = factors[rung_jumped[i]] * f;
+                        dmom[3 * i] += x_ji * tf; dmom[3 * i + 1] += y_ji * tf;
+                        dmom[3 * i + 2] += z_ji * tf;
+                    }
+                    if (act_j) { /* gravity.py:332-349 */
+                        double tf = factors[rung_jumped[j]] * f;
+                        dmom[3 * j] -= x_ji * tf; dmom[3 * j + 1] -= y_ji * tf;
+                        dmom[3 * j + 2] -= z_ji * tf;
+                    }
+                }
+            }
+        }
+    }
+    free(tile); free(start); free(order); free(cursor);
+    return 0;
+}

@@ -57,6 +57,10 @@ CASES = {
                             dist='uniform', diff=2, steps=2),
     'steps_p3m_n8_g32': dict(method='p3m', n=8, gridsize=32, boxsize=32.0, seed=12,
                              dist='uniform', diff=4, steps=2),
+    # adaptive rungs (A14/A16): the reference's own initialize_rung_populations / kick_long /
+    # kick_short / driftkick_short (main.py) with N_rungs = 4 on a clustered set
+    'rungs_p3m_n8_g32': dict(method='p3m', n=8, gridsize=32, boxsize=32.0, seed=13,
+                             dist='clustered', diff=4, rungs=4, steps=2),
 }
 
 
@@ -119,6 +123,9 @@ select_forces = {{'matter': {{'gravity': '{method}'}}}}
     if method == 'p3m':
         txt += "shortrange_params = {'gravity': {'subtiling': %r}}\n" % (cfg.get('subtiling', 2),)
         txt += "select_softening_length = {'matter': '0.03*boxsize/cbrt(N)'}\n"
+    if 'rungs' in cfg:
+        txt += f"N_rungs = {cfg['rungs']}\nenable_Hubble = False\na_begin = 1\n"
+        txt += "particle_reordering = False\n"
     return txt
 
 
@@ -193,8 +200,97 @@ def child_steps(name):
     print('wrote', name, {k: getattr(v, 'shape', v) for k, v in out.items()})
 
 
+def child_rungs(name):
+    """The reference's adaptive-rung machinery driven through its own main.py functions
+    (imported with jobid = -1 so that nothing runs at import): initialize_rung_populations
+    (main.py:1639), kick_long (:1104), kick_short (:1173), driftkick_short (:1347).  The
+    time-step integrals are replaced by t_end - t_start (a = 1, enable_Hubble = False
+    semantics) so that they are plain, bit-exact inputs."""
+    import importlib
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, 'oracle', 'refharness'))
+    from ref_import import load_reference
+    cfg = CASES[name]
+    ref = load_reference(param_text(cfg), f'/tmp/concept_golden_work/{name}')
+    commons, species = ref.commons, ref.species
+    commons.jobid = -1
+    main = importlib.import_module('main')
+    L = commons.boxsize
+    nr = commons.N_rungs
+    pos = make_positions(np, cfg)
+    N = pos.shape[0]
+    rng = np.random.default_rng(1000 + cfg['seed'])
+    mass = commons.ρ_mbar*L**3/N
+    mom = rng.normal(0, 1.0, size=(N, 3))*mass*0.002
+    comp = species.Component('matter', 'matter', N=N, mass=mass)
+    for d, s_ in enumerate('xyz'):
+        comp.populate(np.ascontiguousarray(pos[:, d]), 'pos' + s_)
+        comp.populate(np.ascontiguousarray(mom[:, d]), 'mom' + s_)
+    assert comp.use_rungs
+    calls = []
+
+    def integrals(t_start, t_end, components):
+        keys = ['1', 'a**2', 'a**(-1)', 'a**(-2)', 'ȧ/a']
+        for c in components:
+            for k in ('a**(-3*w_eff)', 'a**(-3*(1+w_eff))', 'a**(-3*w_eff-1)', 'a**(3*w_eff-2)',
+                      'a**(-3*w_eff)*Γ/H'):
+                keys.append((k, c.name))
+        for c0 in components:
+            for c1 in components:
+                keys.append(('a**(-3*w_eff₀-3*w_eff₁-1)', c0.name, c1.name))
+        if not main.ᔑdt_rungs:
+            for k in keys:
+                main.ᔑdt_rungs[k] = np.zeros(3*nr - 1)
+        calls.append((t_start, t_end))
+        return {k: (t_end - t_start) for k in keys}
+    main.get_time_step_integrals = integrals
+    uni = commons.universals
+    uni.t = 0.0
+    uni.a = 1.0
+    sync_time = float('inf')
+    dt = cfg.get('dt', 0.6)
+
+    def state():
+        p = np.array(comp.pos_mv3[:N])
+        m = np.array(comp.mom_mv3[:N])
+        r = np.array(comp.rung_indices_mv[:N]).astype(np.int8)
+        o = np.argsort(p[:, 0], kind='stable')
+        return p[o].copy(), m[o].copy(), r[o].copy()
+
+    out = dict(boxsize=L, gridsize=cfg['gridsize'], G_Newton=commons.G_Newton, mass=mass, N=N,
+               diff_order=cfg['diff'], dt=dt, N_rungs=nr, method='p3m',
+               softening_length=comp.softening_length, fac_softening=main.fac_softening,
+               dt_jump_fac=main.Δt_jump_fac, dt_reltol=main.Δt_reltol,
+               shortrange_scale=commons.shortrange_params['gravity']['scale'],
+               shortrange_range=commons.shortrange_params['gravity']['range'],
+               pos_in=np.array(comp.pos_mv3[:N]).copy(), mom_in=np.array(comp.mom_mv3[:N]).copy())
+    main.initialize_rung_populations([comp], dt)
+    out['rung_init'] = np.array(comp.rung_indices_mv[:N]).astype(np.int8)  # input order
+    out['acc_init'] = np.array(comp.Δmom_mv3[:N]).copy()  # accelerations of the fake kick
+    out['rungs_N_init'] = np.array([comp.rungs_N[i] for i in range(nr)], dtype=np.int64)
+    main.kick_long([comp], dt, sync_time, 'init')
+    main.kick_short([comp], dt)
+    out['pos_init'], out['mom_init'], out['rungs_after_init'] = state()
+    for step in range(cfg['steps']):
+        main.driftkick_short([comp], dt, sync_time)
+        uni.t += 0.5*dt
+        main.kick_long([comp], dt, sync_time, 'full')
+        uni.t += 0.5*dt
+        p_, m_, r_ = state()
+        out[f'pos_step{step + 1}'], out[f'mom_step{step + 1}'] = p_, m_
+        out[f'rungs_step{step + 1}'] = r_
+        out[f'rungs_N_step{step + 1}'] = np.array([comp.rungs_N[i] for i in range(nr)],
+                                                  dtype=np.int64)
+    out['n_integral_calls'] = len(calls)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, 'rungs_N init', out['rungs_N_init'], 'step1', out['rungs_N_step1'],
+          'step2', out['rungs_N_step2'], 'integral calls', len(calls))
+
+
 def child(name):
     import numpy as np
+    if 'rungs' in CASES[name]:
+        return child_rungs(name)
     if 'steps' in CASES[name]:
         return child_steps(name)
     sys.path.insert(0, os.path.join(REPO, 'oracle', 'refharness'))

@@ -166,3 +166,52 @@ def test_caller_sequence(golden, name):
             kick_short(dt)
         kick_long(dt)
         check(f'step{step}', exact=not p3m)
+
+
+def test_adaptive_rungs_sequence(golden):
+    """A14/A16 with adaptive rungs: the oracle's restatement of initialize_rung_populations,
+    kick_short and driftkick_short (oracle/rungs.py) against the reference's own main.py
+    functions (N_rungs = 4, two base steps with rung jumps).  Rung indices are integers:
+    bit-exact at every checkpoint; positions and momenta to rounding."""
+    from oracle import rungs
+    g = golden('rungs_p3m_n8_g32')
+    L, N, mass, nr = float(g['boxsize']), int(g['gridsize']), float(g['mass']), int(g['N_rungs'])
+    G, dt = float(g['G_Newton']), float(g['dt'])
+    scale, rng_ = float(g['shortrange_scale']), float(g['shortrange_range'])
+    table, maxr2 = oracle.shortrange_table(float(g['softening_length']), scale, rng_, 4096)
+    sr = dict(boxsize=L, nt=oracle.shortrange_tiling_shape(L, rng_), table=table, tablesize=4096,
+              maxr2=maxr2, range=rng_)
+    p = rungs.Particles(g['pos_in'], g['mom_in'], mass, float(g['softening_length']), nr)
+    dtr = rungs.new_dt_rungs(nr)
+    fs, jf, rt = float(g['fac_softening']), float(g['dt_jump_fac']), float(g['dt_reltol'])
+    t = 0.0
+    rungs.initialize_rung_populations(p, dt, t, sr, G, dtr, fs)
+    assert np.array_equal(p.rung, g['rung_init'])
+    assert np.array_equal(p.rungs_N, g['rungs_N_init'])
+    assert np.abs(p.dmom - g['acc_init']).max() <= 1e-13*np.abs(g['acc_init']).max()
+
+    def kick_long(d):
+        oracle.pm_long_range(p.pos, p.mom, mass=mass, boxsize=L, gridsize=N, G_Newton=G, dt_1=d,
+                             dt_dens=d, dt_kick=d, diff_order=int(g['diff_order']),
+                             shortrange_scale=scale, want_indices=False)
+
+    def drift(p_, dt_am2):
+        oracle.drift(p_.pos, p_.mom, dt_am2/mass, L)
+
+    def check(tag, rtag):
+        o = np.argsort(p.pos[:, 0], kind='stable')
+        assert np.array_equal(p.rung[o], g[rtag]), tag
+        assert np.abs(p.pos[o] - g['pos_' + tag]).max() <= 1e-13*L, tag
+        assert np.abs(p.mom[o] - g['mom_' + tag]).max() <= 1e-12*np.abs(g['mom_' + tag]).max()
+
+    kick_long(dt/2)
+    rungs.kick_short(p, dt, t, sr, G, dtr, fs)
+    check('init', 'rungs_after_init')
+    for step in (1, 2):
+        rungs.driftkick_short(p, dt, t, float('inf'), sr, G, dtr, fs, jf, rt, drift)
+        t += 0.5*dt
+        kick_long(dt)
+        t += 0.5*dt
+        check(f'step{step}', f'rungs_step{step}')
+        assert np.array_equal(p.rungs_N, g[f'rungs_N_step{step}'])
+    assert int(g['rungs_N_step2'][3]) != int(g['rungs_N_init'][3])  # jumps did happen
