@@ -420,7 +420,70 @@ extern "C" int cg_shortrange_sweep(cg_ctx *c, const double *pos_r, const uint32_
              "cg_shortrange_sweep: table of %lld entries too short for r2_max*scaling = %g",
              (long long)tablesize, r2_max * r2_index_scaling);
     return cgk_shortrange_sweep(c, pos_r, order_r, offset_r, dmom_r, pos_s, order_s, offset_s, nt,
-                                same_component, table, r2_index_scaling, r2_max, factor);
+                                same_component, table, r2_index_scaling, r2_max, factor, nullptr,
+                                nullptr, nullptr, 0);
+}
+
+extern "C" int cg_shortrange_sweep_rungs(cg_ctx *c, const double *pos_r, const uint32_t *order_r,
+                                         const uint32_t *offset_r, double *dmom_r,
+                                         const double *pos_s, const uint32_t *order_s,
+                                         const uint32_t *offset_s, int64_t nt, int same_component,
+                                         const double *table, int64_t tablesize,
+                                         double r2_index_scaling, double r2_max,
+                                         const double *factors, const int8_t *rung_r,
+                                         const int8_t *rung_jumped_r, int lowest_active_rung) {
+    CG_CHECK(c && pos_r && order_r && offset_r && dmom_r && pos_s && order_s && offset_s && table &&
+                 factors && rung_r && rung_jumped_r, "cg_shortrange_sweep_rungs: null argument");
+    CG_CHECK(nt >= 4 && nt <= 1024, "cg_shortrange_sweep_rungs: nt = %lld", (long long)nt);
+    CG_CHECK((int64_t)(r2_max * r2_index_scaling) < tablesize,
+             "cg_shortrange_sweep_rungs: table too short");
+    return cgk_shortrange_sweep(c, pos_r, order_r, offset_r, dmom_r, pos_s, order_s, offset_s, nt,
+                                same_component, table, r2_index_scaling, r2_max, 0.0, factors,
+                                (const signed char *)rung_r, (const signed char *)rung_jumped_r,
+                                lowest_active_rung);
+}
+
+extern "C" int cg_dmom_nullify(cg_ctx *c, double *dmom, const int8_t *rung, int64_t n,
+                               int lowest_active_rung) {
+    CG_CHECK(c && (dmom || n == 0), "cg_dmom_nullify: null argument");
+    return cgk_dmom_active(c, nullptr, dmom, (const signed char *)rung, n, lowest_active_rung, 0);
+}
+extern "C" int cg_dmom_apply(cg_ctx *c, double *mom, const double *dmom, const int8_t *rung,
+                             int64_t n, int lowest_active_rung) {
+    CG_CHECK(c && ((mom && dmom) || n == 0), "cg_dmom_apply: null argument");
+    return cgk_dmom_active(c, mom, (double *)dmom, (const signed char *)rung, n,
+                           lowest_active_rung, 1);
+}
+extern "C" int cg_dmom_to_acc(cg_ctx *c, double *dmom, const int8_t *rung,
+                              const int8_t *rung_jumped, int64_t n, int lowest_active_rung,
+                              const double *conversion_factors, int any_rung_jumps) {
+    CG_CHECK(c && conversion_factors && ((dmom && rung && rung_jumped) || n == 0),
+             "cg_dmom_to_acc: null argument");
+    return cgk_dmom_to_acc(c, dmom, (const signed char *)rung, (const signed char *)rung_jumped, n,
+                           lowest_active_rung, conversion_factors, any_rung_jumps);
+}
+extern "C" int cg_assign_rungs(cg_ctx *c, const double *acc, int8_t *rung, int8_t *rung_jumped,
+                               int64_t n, double rung_factor, int N_rungs) {
+    CG_CHECK(c && ((acc && rung && rung_jumped) || n == 0), "cg_assign_rungs: null argument");
+    CG_CHECK(N_rungs >= 1 && N_rungs <= 42, "cg_assign_rungs: N_rungs = %d", N_rungs);
+    return cgk_assign_rungs(c, acc, (signed char *)rung, (signed char *)rung_jumped, n, rung_factor,
+                            N_rungs);
+}
+extern "C" int cg_flag_rung_jumps(cg_ctx *c, const double *acc, const int8_t *rung,
+                                  int8_t *rung_jumped, int64_t n, int lowest_active_rung,
+                                  const double *integrals_1, double rung_factor_up,
+                                  double rung_factor_down, int N_rungs, int32_t *any_out) {
+    CG_CHECK(c && integrals_1 && any_out && ((acc && rung && rung_jumped) || n == 0),
+             "cg_flag_rung_jumps: null argument");
+    CG_CHECK(N_rungs >= 1 && N_rungs <= 42, "cg_flag_rung_jumps: N_rungs = %d", N_rungs);
+    return cgk_flag_rung_jumps(c, acc, (const signed char *)rung, (signed char *)rung_jumped, n,
+                               lowest_active_rung, integrals_1, rung_factor_up, rung_factor_down,
+                               N_rungs, any_out);
+}
+extern "C" int cg_apply_rung_jumps(cg_ctx *c, int8_t *rung, int8_t *rung_jumped, int64_t n,
+                                   int N_rungs) {
+    CG_CHECK(c && ((rung && rung_jumped) || n == 0), "cg_apply_rung_jumps: null argument");
+    return cgk_apply_rung_jumps(c, (signed char *)rung, (signed char *)rung_jumped, n, N_rungs);
 }
 
 extern "C" int cg_local_info(const cg_ctx *c, int64_t info[6]) {

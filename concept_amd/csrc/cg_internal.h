@@ -133,7 +133,21 @@ int cgk_shortrange_sweep(cg_ctx *c, const double *pos_r, const unsigned *order_r
                          const unsigned *off_r, double *dmom_r, const double *pos_s,
                          const unsigned *order_s, const unsigned *off_s, i64 nt, int same,
                          const double *table, double r2_index_scaling, double r2_max,
-                         double factor);
+                         double factor, const double *factors, const signed char *rung,
+                         const signed char *rung_jumped, int lowest_active);
+int cgk_dmom_active(cg_ctx *c, double *mom, double *dmom, const signed char *rung, i64 n,
+                    int lowest_active, int op);
+int cgk_dmom_to_acc(cg_ctx *c, double *dmom, const signed char *rung,
+                    const signed char *rung_jumped, i64 n, int lowest_active, const double *conv,
+                    int any_jumps);
+int cgk_assign_rungs(cg_ctx *c, const double *dmom, signed char *rung, signed char *rung_jumped,
+                     i64 n, double rung_factor, int N_rungs);
+int cgk_flag_rung_jumps(cg_ctx *c, const double *dmom, const signed char *rung,
+                        signed char *rung_jumped, i64 n, int lowest_active,
+                        const double *integrals, double rf_up, double rf_down, int N_rungs,
+                        int *any_out);
+int cgk_apply_rung_jumps(cg_ctx *c, signed char *rung, signed char *rung_jumped, i64 n,
+                         int N_rungs);
 bool cgk_fft_supported(i64 N);
 int cgk_fft_dist_forward(cg_ctx *c, double *send_buf);
 int cgk_fft_dist_xsolve(cg_ctx *c, double *buf, int deconv_order, double C, int long_range,

@@ -136,6 +136,13 @@ struct SrParams {
     double boxsize, r2_index_scaling, r2_max, factor;
     int nt;
     int same;  // receiver and supplier arrays are the same component
+    // adaptive rungs (null = every particle on rung 0 with `factor`): a receiver on an
+    // active rung (rung >= lowest_active) is kicked with factors[rung_jumped]; inactive
+    // receivers are skipped.  One-sided form of interactions.py:1688-1761 +
+    // gravity.py:318-349: each particle's kick uses its OWN rung's integral.
+    const double *factors;
+    const signed char *rung, *rung_jumped;
+    int lowest_active;
 };
 
 __global__ __launch_bounds__(64) void k_sr_sweep(
@@ -160,8 +167,13 @@ __global__ __launch_bounds__(64) void k_sr_sweep(
         int R = 8;
         while (R < nrec) R <<= 1;
         const int S = 64 / R, sub = lane / R, rl = lane % R;
-        const bool active = rl < nrec;
+        bool active = rl < nrec;
         const unsigned pi = active ? order_r[base + rl] : 0u;
+        double my_factor = P.factor;
+        if (active && P.rung) {
+            if (P.rung[pi] < P.lowest_active) active = false;
+            else my_factor = P.factors[P.rung_jumped[pi]];
+        }
         double xi = 0, yi = 0, zi = 0;
         if (active) {
             xi = pos_r[3 * (i64)pi];
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(64) void k_sr_sweep(
                         bool hit = !(r2 > P.r2_max) && !(P.same && sidx[k] == pi);
                         if (hit) {
                             i64 idx = (i64)(r2 * P.r2_index_scaling);        // gravity.py:316
-                            double total_factor = P.factor * table[idx];     // gravity.py:321
+                            double total_factor = my_factor * table[idx];    // gravity.py:321
                             ax += x_ji * total_factor;
                             ay += y_ji * total_factor;
                             az += z_ji * total_factor;
@@ -332,12 +344,14 @@ int cgk_shortrange_sweep(cg_ctx *c, const double *pos_r, const unsigned *order_r
                          const unsigned *off_r, double *dmom_r, const double *pos_s,
                          const unsigned *order_s, const unsigned *off_s, i64 nt, int same,
                          const double *table, double r2_index_scaling, double r2_max,
-                         double factor) {
-    SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt, same};
+                         double factor, const double *factors, const signed char *rung,
+                         const signed char *rung_jumped, int lowest_active) {
+    SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt, same,
+               factors,      rung,             rung_jumped, lowest_active};
     // Default: one wavefront per tile.  The column form (CONCEPT_GPU_SR=columns) keeps more
     // lanes busy but measured slower at 256^3 / 512^3 (26.7 vs 24.7 ms): kept for A/B work.
     const char *env = getenv("CONCEPT_GPU_SR");
-    if (!(env && std::string(env) == "columns")) {
+    if (rung || !(env && std::string(env) == "columns")) {
         hipLaunchKernelGGL(k_sr_sweep, dim3((unsigned)(nt * nt * nt)), dim3(64), 0, c->stream,
                            pos_r, order_r, off_r, dmom_r, pos_s, order_s, off_s, table, P);
     } else {

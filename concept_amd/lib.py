@@ -67,6 +67,14 @@ SYMBOLS = {
     'cg_shortrange_build': (_int, [_vp, _vp, _i64, _i64, _dbl, _vp, _vp]),
     'cg_shortrange_sweep': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _i64,
                                    _dbl, _dbl, _dbl]),
+    'cg_shortrange_sweep_rungs': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp,
+                                         _i64, _dbl, _dbl, _vp, _vp, _vp, _int]),
+    'cg_dmom_nullify': (_int, [_vp, _vp, _vp, _i64, _int]),
+    'cg_dmom_apply': (_int, [_vp, _vp, _vp, _vp, _i64, _int]),
+    'cg_dmom_to_acc': (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp, _int]),
+    'cg_assign_rungs': (_int, [_vp, _vp, _vp, _vp, _i64, _dbl, _int]),
+    'cg_flag_rung_jumps': (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp, _dbl, _dbl, _int, _vp]),
+    'cg_apply_rung_jumps': (_int, [_vp, _vp, _vp, _i64, _int]),
     'cg_local_info': (_int, [_vp, ctypes.POINTER(ctypes.c_int64*6)]),
     'cg_layers_read': (_int, [_vp, _i64, _i64, _vp]),
     'cg_layers_write': (_int, [_vp, _i64, _i64, _vp, _int]),

@@ -185,15 +185,73 @@ class PotentialMesh:
         return order, offset
 
     def shortrange_sweep(self, pos_r, cells_r, dmom_r, pos_s, cells_s, nt, same, table,
-                         r2_index_scaling, r2_max, factor):
-        self._check_particles(pos_r, dmom_r)
+                         r2_index_scaling, r2_max, factor, rungs=None):
+        """`rungs` = (factors[3*N_rungs-1] CUDA float64, rung int8, rung_jumped int8,
+        lowest_active_rung) selects the adaptive-rung form (then `factor` is unused)."""
+        n = self._check_particles(pos_r, dmom_r)
         self._check_particles(pos_s)
         if table.dtype != torch.float64 or not table.is_cuda:
             raise lib.ConceptGPUError('short-range table must be a float64 CUDA tensor')
-        check(_L.cg_shortrange_sweep(
+        if rungs is None:
+            check(_L.cg_shortrange_sweep(
+                self._ctx, _ptr(pos_r), _ptr(cells_r[0]), _ptr(cells_r[1]), _ptr(dmom_r),
+                _ptr(pos_s), _ptr(cells_s[0]), _ptr(cells_s[1]), int(nt), int(same), _ptr(table),
+                table.numel(), float(r2_index_scaling), float(r2_max), float(factor)))
+            return
+        factors, rung, rung_jumped, lowest = rungs
+        self._check_rungs(n, rung, rung_jumped)
+        check(_L.cg_shortrange_sweep_rungs(
             self._ctx, _ptr(pos_r), _ptr(cells_r[0]), _ptr(cells_r[1]), _ptr(dmom_r), _ptr(pos_s),
             _ptr(cells_s[0]), _ptr(cells_s[1]), int(nt), int(same), _ptr(table), table.numel(),
-            float(r2_index_scaling), float(r2_max), float(factor)))
+            float(r2_index_scaling), float(r2_max), _ptr(factors), _ptr(rung), _ptr(rung_jumped),
+            int(lowest)))
+
+    # -- A16: momentum buffers and adaptive rungs -------------------------------------
+    @staticmethod
+    def _check_rungs(n, *arrays):
+        for t in arrays:
+            if t.dtype != torch.int8 or not t.is_cuda or t.numel() != n:
+                raise lib.ConceptGPUError('rung arrays must be int8 CUDA tensors of length N')
+
+    def dmom_nullify(self, dmom, rung=None, lowest_active_rung=0):
+        n = self._check_particles(dmom)
+        check(_L.cg_dmom_nullify(self._ctx, _ptr(dmom), _ptr(rung) if rung is not None else None,
+                                 n, int(lowest_active_rung)))
+
+    def dmom_apply(self, mom, dmom, rung=None, lowest_active_rung=0):
+        n = self._check_particles(mom, dmom)
+        check(_L.cg_dmom_apply(self._ctx, _ptr(mom), _ptr(dmom),
+                               _ptr(rung) if rung is not None else None, n,
+                               int(lowest_active_rung)))
+
+    def dmom_to_acc(self, dmom, rung, rung_jumped, lowest_active_rung, conversion_factors,
+                    any_rung_jumps):
+        n = self._check_particles(dmom)
+        self._check_rungs(n, rung, rung_jumped)
+        check(_L.cg_dmom_to_acc(self._ctx, _ptr(dmom), _ptr(rung), _ptr(rung_jumped), n,
+                                int(lowest_active_rung), _ptr(conversion_factors),
+                                int(bool(any_rung_jumps))))
+
+    def assign_rungs(self, acc, rung, rung_jumped, rung_factor, N_rungs):
+        n = self._check_particles(acc)
+        self._check_rungs(n, rung, rung_jumped)
+        check(_L.cg_assign_rungs(self._ctx, _ptr(acc), _ptr(rung), _ptr(rung_jumped), n,
+                                 float(rung_factor), int(N_rungs)))
+
+    def flag_rung_jumps(self, acc, rung, rung_jumped, lowest_active_rung, integrals_1, rf_up,
+                        rf_down, N_rungs):
+        n = self._check_particles(acc)
+        self._check_rungs(n, rung, rung_jumped)
+        flag = torch.zeros(1, dtype=torch.int32, device=acc.device)
+        check(_L.cg_flag_rung_jumps(self._ctx, _ptr(acc), _ptr(rung), _ptr(rung_jumped), n,
+                                    int(lowest_active_rung), _ptr(integrals_1), float(rf_up),
+                                    float(rf_down), int(N_rungs), _ptr(flag)))
+        return bool(flag.item())
+
+    def apply_rung_jumps(self, rung, rung_jumped, N_rungs):
+        n = rung.numel()
+        self._check_rungs(n, rung, rung_jumped)
+        check(_L.cg_apply_rung_jumps(self._ctx, _ptr(rung), _ptr(rung_jumped), n, int(N_rungs)))
 
     # -- x-slab domains (multi-GPU) -------------------------------------------
     def layers_read(self, layer0, nlayers, dst):

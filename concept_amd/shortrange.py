@@ -103,12 +103,24 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
                                                 sr['tablesize'], p.softening_kernel, r.device)
             scaling = (sr['tablesize'] - 1)/maxr2  # gravity.py:288
             r2_max = sr['range']**2                # gravity.py:286
-            factor = p.G_Newton*r.mass*s.mass*float(ᔑdt_rungs[key, r.name, s.name][0])
             same = r is s
-            mesh.shortrange_sweep(r.pos, cells[id(r)], r.Δmom, s.pos, cells[id(s)], nt, same,
-                                  table, scaling, r2_max, factor)
+
+            def sweep(rec, sup, same_):
+                # compute_factors (gravity.py:51-64): G*m_r*m_s*ᔑdt_rungs[...][k] per rung k
+                integrals = np.asarray(ᔑdt_rungs[key, rec.name, sup.name], dtype=np.float64)
+                if rec.use_rungs:
+                    factors = torch.tensor(p.G_Newton*rec.mass*sup.mass*integrals,
+                                           dtype=torch.float64, device=rec.device)
+                    rungs = (factors, rec.rung_indices, rec.rung_indices_jumped,
+                             rec.lowest_active_rung)
+                    mesh.shortrange_sweep(rec.pos, cells[id(rec)], rec.Δmom, sup.pos,
+                                          cells[id(sup)], nt, same_, table, scaling, r2_max, 0.0,
+                                          rungs)
+                else:
+                    mesh.shortrange_sweep(rec.pos, cells[id(rec)], rec.Δmom, sup.pos,
+                                          cells[id(sup)], nt, same_, table, scaling, r2_max,
+                                          p.G_Newton*rec.mass*sup.mass*float(integrals[0]))
+            sweep(r, s, same)
             if not same and s in receivers:
                 # the reference kicks both partners of a pair (Δmom_s -= ..., gravity.py:341-349)
-                factor_sr = p.G_Newton*s.mass*r.mass*float(ᔑdt_rungs[key, s.name, r.name][0])
-                mesh.shortrange_sweep(s.pos, cells[id(s)], s.Δmom, r.pos, cells[id(r)], nt,
-                                      False, table, scaling, r2_max, factor_sr)
+                sweep(s, r, False)

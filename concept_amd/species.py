@@ -45,17 +45,24 @@ class Component:
         self.tile_table = None
         self.tile_mesh = None
         self.tiles_exact = False
-        # rungs: single rung 0 until adaptive rung stepping is built
-        self.use_rungs = False
-        self.lowest_active_rung = 0
-        self.lowest_populated_rung = 0
-        self.highest_populated_rung = 0
-        # forces and potential grid sizes (species.py:1100-1215)
+        # forces first: use_rungs depends on them (species.py:1444-1448)
         self.forces = {}
         for key in (self.name, species, 'particles', 'all', 'default'):
             if key in p.select_forces:
                 self.forces = dict(p.select_forces[key])
                 break
+        # short-range rungs (species.py:1443-1460): int8 rung index per particle, all on rung 0
+        self.N_rungs = p.N_rungs
+        self.use_rungs = bool(p.N_rungs > 1 and ({'ppnonperiodic', 'pp', 'p3m'}
+                                                 & set(self.forces.values())))
+        self.lowest_active_rung = 0
+        self.lowest_populated_rung = 0
+        self.highest_populated_rung = 0
+        self.rungs_N = [0]*p.N_rungs
+        self.rungs_N[0] = self.N
+        self.rung_indices = torch.zeros(self.N, dtype=torch.int8, device=self.device)
+        self.rung_indices_jumped = torch.zeros(self.N, dtype=torch.int8, device=self.device)
+        # potential grid sizes (species.py:1100-1215)
         self.potential_gridsizes = {}
         self.potential_differentiations = {}
         for force, method in self.forces.items():
@@ -121,43 +128,47 @@ class Component:
         self._mesh().drift(self.pos, self.mom, Δt_over_mass)
         self.tiles_exact = False
 
-    def tile_sort(self, mesh=None):
-        """Reorder particle memory into mesh-tile order (the reference's
-        tile_sort, species.py:2598-2810, reorders for the same reason)."""
-        mesh = mesh or self._mesh()
+    def _sorted_into(self, mesh, Δt_over_mass=None):
+        """Run the (drift +) tile sort into the scratch buffers and swap; everything that is
+        indexed by particle (ids, rung indices, Δmom) follows through the slot permutation."""
         if self._scratch is None:
             self._scratch = (torch.empty_like(self.pos), torch.empty_like(self.mom),
                              torch.empty_like(self.ids))
-        po, mo, io = self._scratch
+            self._slots = torch.arange(self.N, dtype=torch.int64, device=self.device)
+        po, mo, perm = self._scratch
         if self.tile_table is None or self.tile_mesh is not mesh:
             self.tile_table = mesh.new_tile_table()
-        mesh.sort_particles(self.pos, self.mom, self.ids, po, mo, io, self.tile_table)
-        self._scratch = (self.pos, self.mom, self.ids)
-        self.pos, self.mom, self.ids = po, mo, io
+        if Δt_over_mass is None:
+            mesh.sort_particles(self.pos, self.mom, self._slots, po, mo, perm, self.tile_table)
+        else:
+            mesh.drift_sort(self.pos, self.mom, self._slots, po, mo, perm, Δt_over_mass,
+                            self.tile_table)
+        old_ids = self.ids
+        self._scratch = (self.pos, self.mom, old_ids)
+        self.pos, self.mom = po, mo
+        self.ids = old_ids[perm]
+        if self.use_rungs:
+            self.rung_indices = self.rung_indices[perm]
+            self.rung_indices_jumped = self.rung_indices_jumped[perm]
+        if self.Δmom is not None:
+            self.Δmom = self.Δmom[perm]
         self.tile_mesh = mesh
         self.tiles_exact = True
-        if self.Δmom is not None:
-            self.Δmom = None  # order changed; short-range buffers are rebuilt on use
+
+    def tile_sort(self, mesh=None):
+        """Reorder particle memory into mesh-tile order (the reference's
+        tile_sort, species.py:2598-2810, reorders for the same reason)."""
+        self._sorted_into(mesh or self._mesh())
 
     def drift_sort(self, ᔑdt, a_next=-1, a=1.0, mesh=None):
         """drift() immediately followed by tile_sort(), fused into one pass pair
         (cg_drift_sort): same result as the two calls."""
-        mesh = mesh or self._mesh()
         Δt_over_mass = ᔑdt['a**(-2)']*a**(3*self.w_eff(a=a))/self.mass
-        if self._scratch is None:
-            self._scratch = (torch.empty_like(self.pos), torch.empty_like(self.mom),
-                             torch.empty_like(self.ids))
-        po, mo, io = self._scratch
-        if self.tile_table is None or self.tile_mesh is not mesh:
-            self.tile_table = mesh.new_tile_table()
-        mesh.drift_sort(self.pos, self.mom, self.ids, po, mo, io, Δt_over_mass, self.tile_table)
-        self._scratch = (self.pos, self.mom, self.ids)
-        self.pos, self.mom, self.ids = po, mo, io
-        self.tile_mesh = mesh
-        self.tiles_exact = True
-        self.Δmom = None
+        self._sorted_into(mesh or self._mesh(), Δt_over_mass)
 
     def nullify_Δ(self, specifically=None, only_active=True):
+        """species.py:3717-3741: Δmom = 0, for particles on active rungs only when rungs
+        are in use."""
         if specifically is None:
             raise ConceptGPUError('You must specify "specifically" when calling '
                                   'Component.nullify_Δ() for particle components.')
@@ -166,9 +177,71 @@ class Component:
                                   'not supported')
         if self.Δmom is None:
             self.Δmom = torch.zeros_like(self.mom)
+        elif only_active and self.use_rungs:
+            self._mesh().dmom_nullify(self.Δmom, self.rung_indices, self.lowest_active_rung)
         else:
             self.Δmom.zero_()
 
     def apply_Δmom(self, only_active=True):
-        if self.Δmom is not None:
-            self.mom += self.Δmom
+        """species.py:2253-2266"""
+        if self.Δmom is None:
+            return
+        if only_active and self.use_rungs:
+            self._mesh().dmom_apply(self.mom, self.Δmom, self.rung_indices,
+                                    self.lowest_active_rung)
+        else:
+            self._mesh().dmom_apply(self.mom, self.Δmom)
+
+    # -- adaptive rungs (A16) -----------------------------------------------
+    def convert_Δmom_to_acc(self, ᔑdt_rungs, any_rung_jumps=False, a=1.0):
+        """species.py:2290-2325"""
+        if not self.use_rungs:
+            return
+        import numpy as np
+        w_eff = self.w_eff(a=a)
+        conversion_factors = a**(3*w_eff)/(self.mass*(commons.machine_ϵ
+                                                      + np.asarray(ᔑdt_rungs['a**2'])))
+        conv = torch.tensor(conversion_factors, dtype=torch.float64, device=self.device)
+        self._mesh().dmom_to_acc(self.Δmom, self.rung_indices, self.rung_indices_jumped,
+                                 self.lowest_active_rung, conv, any_rung_jumps)
+
+    def get_rung_factor(self, Δt, fac_softening):
+        """species.py:2376-2400"""
+        import math
+        return 0.5*math.log2(Δt**2/(2*fac_softening*self.softening_length))
+
+    def assign_rungs(self, Δt, fac_softening):
+        """species.py:2422-2445"""
+        if not self.use_rungs:
+            self.rungs_N[0] = self.N_local
+            return
+        self._mesh().assign_rungs(self.Δmom, self.rung_indices, self.rung_indices_jumped,
+                                  self.get_rung_factor(Δt, fac_softening), self.N_rungs)
+        self.set_rungs_N()
+
+    def flag_rung_jumps(self, Δt, Δt_jump_fac, fac_softening, ᔑdt_rungs):
+        """species.py:2463-2513; returns whether any particle was flagged."""
+        if not self.use_rungs:
+            return False
+        import numpy as np
+        integrals = torch.tensor(np.asarray(ᔑdt_rungs['1']), dtype=torch.float64,
+                                 device=self.device)
+        return self._mesh().flag_rung_jumps(
+            self.Δmom, self.rung_indices, self.rung_indices_jumped, self.lowest_active_rung,
+            integrals, self.get_rung_factor(Δt*Δt_jump_fac, fac_softening),
+            self.get_rung_factor(Δt/Δt_jump_fac, fac_softening), self.N_rungs)
+
+    def apply_rung_jumps(self):
+        """species.py:2526-2549"""
+        if not self.use_rungs:
+            return
+        self._mesh().apply_rung_jumps(self.rung_indices, self.rung_indices_jumped, self.N_rungs)
+        self.set_rungs_N()
+
+    def set_rungs_N(self):
+        """species.py:2560-2587 (set_rungs_N + set_lowest_highest_populated_rung)"""
+        counts = torch.bincount(self.rung_indices.long(), minlength=self.N_rungs).cpu().tolist()
+        self.rungs_N = counts[:self.N_rungs]
+        populated = [r for r, c in enumerate(self.rungs_N) if c > 0]
+        self.lowest_populated_rung = populated[0] if populated else self.N_rungs - 1
+        self.highest_populated_rung = populated[-1] if populated else 0

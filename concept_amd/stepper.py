@@ -64,3 +64,177 @@ def timeloop(components, n_steps, integrals, rung_integrals=None, on_step=None):
         kick_long(components, integrals('full'))
         if on_step:
             on_step(step)
+
+
+# ---------------------------------------------------------------------------
+# Adaptive rungs: the reference's kick_short / driftkick_short state machine
+# ---------------------------------------------------------------------------
+import numpy as np
+
+from . import commons
+
+PAIR_KEY = 'a**(-3*w_eff₀-3*w_eff₁-1)'
+
+
+def static_integrals(components):
+    """get_time_step_integrals() (main.py:998-1073) for a static background (a = 1,
+    enable_Hubble = False): every integrand integrates to t_end - t_start."""
+    keys = ['1', 'a**2', 'a**(-1)', 'a**(-2)', 'ȧ/a']
+    for c in components:
+        for k in ('a**(-3*w_eff)', 'a**(-3*(1+w_eff))', 'a**(-3*w_eff-1)', 'a**(3*w_eff-2)',
+                  'a**(-3*w_eff)*Γ/H'):
+            keys.append((k, c.name))
+    for c0 in components:
+        for c1 in components:
+            keys.append((PAIR_KEY, c0.name, c1.name))
+
+    def integrals(t_start, t_end):
+        return {k: (t_end - t_start) for k in keys}
+    return integrals
+
+
+class RungStepper:
+    """kick_long / kick_short / driftkick_short / initialize_rung_populations of main.py
+    for particle components with a P3M short-range force and N_rungs > 1.
+    `integrals(t_start, t_end)` plays get_time_step_integrals(); `t` is universals.t."""
+
+    def __init__(self, components, integrals, t=0.0, fac_softening=None, Δt_jump_fac=0.95,
+                 Δt_reltol=1e-9):
+        self.components = list(components)
+        self.integrals = integrals
+        self.t = float(t)
+        p = self.components[0].params
+        self.N_rungs = p.N_rungs
+        # main.py:2366, 2373, 2433 (Δt_rung_factor = 1)
+        self.fac_softening = 0.025 if fac_softening is None else fac_softening
+        self.Δt_jump_fac = Δt_jump_fac
+        self.Δt_reltol = Δt_reltol
+        self.ᔑdt_rungs = {}
+
+    # -- helpers --------------------------------------------------------------
+    def _store(self, ᔑdt_rung, index):
+        for integrand, integral in ᔑdt_rung.items():
+            arr = self.ᔑdt_rungs.get(integrand)
+            if arr is None:
+                arr = self.ᔑdt_rungs[integrand] = np.zeros(3*self.N_rungs - 1)
+            arr[index] = integral
+
+    def _clip(self, t, Δt, sync_time):
+        return sync_time if t + self.Δt_reltol*Δt + 2*commons.machine_ϵ > sync_time else t
+
+    def _gravity_short(self):
+        interactions.gravity('p3m', self.components, self.components, self.ᔑdt_rungs,
+                             'short-range', False)
+
+    # -- main.kick_long (main.py:1104-1144) -----------------------------------
+    def kick_long(self, Δt, sync_time, step_type):
+        t_start = self.t
+        t_end = self._clip(t_start + (Δt/2 if step_type == 'init' else Δt), Δt, sync_time)
+        if t_start == t_end:
+            return
+        kick_long(self.components, self.integrals(t_start, t_end))
+
+    # -- main.kick_short (main.py:1173-1262) ----------------------------------
+    def kick_short(self, Δt, fake=False):
+        comps = self.components
+        for c in comps:
+            c.lowest_active_rung = c.lowest_populated_rung
+        highest_populated_rung = max(c.highest_populated_rung for c in comps)
+        t_start = self.t
+        for rung_index in range(highest_populated_rung + 1):
+            t_end = t_start + Δt/2**(rung_index + 1)
+            self._store(self.integrals(t_start, t_end), rung_index)
+        for c in comps:
+            c.nullify_Δ('mom')
+        self._gravity_short()
+        if fake:
+            for c in comps:
+                c.convert_Δmom_to_acc(self.ᔑdt_rungs)
+            for c in comps:
+                c.assign_rungs(Δt, self.fac_softening)
+        else:
+            for c in comps:
+                c.apply_Δmom()
+                c.convert_Δmom_to_acc(self.ᔑdt_rungs)
+
+    # -- main.initialize_rung_populations (main.py:1639-1659) -----------------
+    def initialize_rung_populations(self, Δt):
+        if Δt == 0:
+            raise ConceptGPUError('Cannot initialise rung populations with Δt = 0')
+        for c in self.components:
+            if c.use_rungs:
+                c.rung_indices.zero_()
+                c.set_rungs_N()
+        self.kick_short(Δt, fake=True)
+
+    # -- main.driftkick_short (main.py:1347-1603) ------------------------------
+    def driftkick_short(self, Δt, sync_time):
+        comps = self.components
+        nr = self.N_rungs
+        any_kicks = True
+        index_start = 0
+        for driftkick_index in range(2**(nr - 1)):
+            if any_kicks:
+                index_start = 2*driftkick_index
+            for rung_index in range(nr):
+                if (driftkick_index + 1) % 2**(nr - 1 - rung_index) == 0:
+                    lowest_active_rung = rung_index
+                    break
+            any_kicks = False
+            for c in comps:
+                c.lowest_active_rung = max(lowest_active_rung, c.lowest_populated_rung)
+                if c.highest_populated_rung >= c.lowest_active_rung:
+                    any_kicks = True
+            if not any_kicks:
+                continue
+            index_end = 2*driftkick_index + 2
+            t_start = self._clip(self.t + Δt*(float(index_start)/2**nr), Δt, sync_time)
+            t_end = self._clip(self.t + Δt*(float(index_end)/2**nr), Δt, sync_time)
+            if t_end > t_start:
+                ᔑdt = self.integrals(t_start, t_end)
+                for c in comps:
+                    c.drift_sort(ᔑdt)
+                    c.lowest_active_rung = max(lowest_active_rung, c.lowest_populated_rung)
+            highest_populated_rung = max(c.highest_populated_rung for c in comps)
+            for rung_index in range(lowest_active_rung, highest_populated_rung + 1):
+                i0 = (2**(nr - 1 - rung_index)
+                      + (driftkick_index//2**(nr - 1 - rung_index))*2**(nr - rung_index))
+                i1 = i0 + 2**(nr - rung_index)
+                ts = self._clip(self.t + Δt*(float(i0)/2**nr), Δt, sync_time)
+                te = self._clip(self.t + Δt*(float(i1)/2**nr), Δt, sync_time)
+                self._store(self.integrals(ts, te), rung_index)
+                # integral for jumping down a rung: only every second kick, else -1
+                if rung_index > 0 and (
+                        (driftkick_index + 1) - 2**(nr - 1 - rung_index)) % 2**(nr - rung_index) == 0:
+                    te = self._clip(self.t + Δt*(float(i0 + 2**(nr - 1 - rung_index))/2**nr), Δt,
+                                    sync_time)
+                    self._store(self.integrals(ts, te), rung_index + nr)
+                else:
+                    for arr in self.ᔑdt_rungs.values():
+                        arr[rung_index + nr] = -1
+                # integral for jumping up a rung
+                if rung_index < nr - 1:
+                    te = self._clip(self.t + Δt*(float(i0 + 3*2**(nr - 2 - rung_index))/2**nr), Δt,
+                                    sync_time)
+                    self._store(self.integrals(ts, te), rung_index + 2*nr)
+            integrals_1 = self.ᔑdt_rungs['1']
+            if sum(integrals_1[lowest_active_rung:highest_populated_rung + 1]) == 0:
+                continue
+            any_rung_jumps = [c.flag_rung_jumps(Δt, self.Δt_jump_fac, self.fac_softening,
+                                                self.ᔑdt_rungs) for c in comps]
+            for c in comps:
+                c.nullify_Δ('mom')
+            self._gravity_short()
+            for c, jumps in zip(comps, any_rung_jumps):
+                c.apply_Δmom()
+                c.convert_Δmom_to_acc(self.ᔑdt_rungs, jumps)
+            for c, jumps in zip(comps, any_rung_jumps):
+                if jumps:
+                    c.apply_rung_jumps()
+
+    # -- one base step of main.timeloop (main.py:335-361) ----------------------
+    def base_step(self, Δt, sync_time=float('inf')):
+        self.driftkick_short(Δt, sync_time)
+        self.t = self._clip(self.t + 0.5*Δt, Δt, sync_time)
+        self.kick_long(Δt, sync_time, 'full')
+        self.t = self._clip(self.t + 0.5*Δt, Δt, sync_time)

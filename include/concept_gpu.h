@@ -187,6 +187,47 @@ int cg_shortrange_sweep(cg_ctx *ctx, const double *pos_r, const uint32_t *order_
                         int64_t nt, int same_component, const double *table /*DEV*/,
                         int64_t tablesize, double r2_index_scaling, double r2_max, double factor);
 
+/* The sweep with adaptive rungs (interactions.py:1688-1761, gravity.py:318-349): a receiver
+ * on an active rung (rung_r[i] >= lowest_active_rung) is kicked with
+ * factors[rung_jumped_r[i]], factors[k] = G*m_r*m_s*dt_rungs[...][k], k < 3*N_rungs-1
+ * (DEV); receivers on inactive rungs are left alone. */
+int cg_shortrange_sweep_rungs(cg_ctx *ctx, const double *pos_r, const uint32_t *order_r,
+                              const uint32_t *offset_r, double *dmom_r, const double *pos_s,
+                              const uint32_t *order_s, const uint32_t *offset_s, int64_t nt,
+                              int same_component, const double *table /*DEV*/, int64_t tablesize,
+                              double r2_index_scaling, double r2_max,
+                              const double *factors /*DEV 3*N_rungs-1*/,
+                              const int8_t *rung_r /*DEV*/, const int8_t *rung_jumped_r /*DEV*/,
+                              int lowest_active_rung);
+
+/* --- A16: momentum buffers and adaptive rungs --------------------------------
+ * rung / rung_jumped are the reference's `signed char` arrays (species.py:2040-2064);
+ * a jumped index is rung + N_rungs (down) or rung + 2*N_rungs (up).  rung = NULL means
+ * "all particles" for the first two.
+ *   cg_dmom_nullify     Component.nullify_Δ('mom')        species.py:3717-3741
+ *   cg_dmom_apply       Component.apply_Δmom()            species.py:2253-2266
+ *   cg_dmom_to_acc      Component.convert_Δmom_to_acc()   species.py:2290-2325
+ *                       conversion_factors[k] = a**(3 w_eff)/(mass*(eps + dt_rungs['a**2'][k])), DEV
+ *   cg_assign_rungs     Component.assign_rungs()          species.py:2422-2445, rung_factor =
+ *                       get_rung_factor(dt, fac_softening) (species.py:2376-2400)
+ *   cg_flag_rung_jumps  Component.flag_rung_jumps()       species.py:2463-2513, integrals_1 =
+ *                       dt_rungs['1'] (DEV), *any_out (DEV int32) != 0 iff a jump was flagged
+ *   cg_apply_rung_jumps Component.apply_rung_jumps()      species.py:2526-2549 */
+int cg_dmom_nullify(cg_ctx *ctx, double *dmom, const int8_t *rung, int64_t n,
+                    int lowest_active_rung);
+int cg_dmom_apply(cg_ctx *ctx, double *mom, const double *dmom, const int8_t *rung, int64_t n,
+                  int lowest_active_rung);
+int cg_dmom_to_acc(cg_ctx *ctx, double *dmom, const int8_t *rung, const int8_t *rung_jumped,
+                   int64_t n, int lowest_active_rung, const double *conversion_factors,
+                   int any_rung_jumps);
+int cg_assign_rungs(cg_ctx *ctx, const double *acc, int8_t *rung, int8_t *rung_jumped, int64_t n,
+                    double rung_factor, int N_rungs);
+int cg_flag_rung_jumps(cg_ctx *ctx, const double *acc, const int8_t *rung, int8_t *rung_jumped,
+                       int64_t n, int lowest_active_rung, const double *integrals_1,
+                       double rung_factor_up, double rung_factor_down, int N_rungs,
+                       int32_t *any_out);
+int cg_apply_rung_jumps(cg_ctx *ctx, int8_t *rung, int8_t *rung_jumped, int64_t n, int N_rungs);
+
 /* --- multi-GPU: x-slab domains ----------------------------------------------
  * One context per GPU with params.nprocs = P, rank = r, subdiv = (P,1,1):
  * domain r owns mesh layers x in [r*N/P, (r+1)*N/P) and the particles whose

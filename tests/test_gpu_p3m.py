@@ -200,3 +200,55 @@ def test_config3_size_shortrange_properties():
     mesh.shortrange_sweep(pos2, cells2, dm2, pos2, cells2, nt, True, table, 4095/maxr2, rng_**2,
                           1.0)
     assert float((dm2 - dm[perm]).abs().max()) <= 1e-12*scale_f
+
+
+def test_adaptive_rungs_vs_reference(golden):
+    """A14/A16 with adaptive rungs on the GPU: RungStepper (initialize_rung_populations,
+    kick_long, kick_short, driftkick_short with rung jumps; N_rungs = 4) against the
+    reference's own main.py functions.  Rung indices bit-exact at every checkpoint."""
+    import torch
+    from concept_amd import commons, stepper
+    from concept_amd.species import Component
+    g = golden('rungs_p3m_n8_g32')
+    commons.load_params({
+        'boxsize': float(g['boxsize']),
+        'potential_options': {'gridsize': {'gravity': {'p3m': int(g['gridsize'])}},
+                              'differentiation': {'matter': {'gravity': {
+                                  'p3m': int(g['diff_order'])}}}},
+        'select_forces': {'matter': {'gravity': 'p3m'}},
+        'select_softening_length': {'matter': '0.03*boxsize/cbrt(N)'},
+        'N_rungs': int(g['N_rungs']),
+    })
+    c = Component('matter', 'matter', N=int(g['N']), mass=float(g['mass']))
+    assert c.use_rungs
+    c.populate(g['pos_in'], 'pos')
+    c.populate(g['mom_in'], 'mom')
+    L, dt = float(g['boxsize']), float(g['dt'])
+    rs = stepper.RungStepper([c], stepper.static_integrals([c]),
+                             fac_softening=float(g['fac_softening']),
+                             Δt_jump_fac=float(g['dt_jump_fac']), Δt_reltol=float(g['dt_reltol']))
+    rs.initialize_rung_populations(dt)
+    rung0 = torch.empty_like(c.rung_indices)
+    rung0[c.ids] = c.rung_indices
+    assert np.array_equal(rung0.cpu().numpy(), g['rung_init'])
+    assert c.rungs_N == list(g['rungs_N_init'])
+    acc = c.host('Δmom')
+    assert np.abs(acc - g['acc_init']).max() <= 1e-12*np.abs(g['acc_init']).max()
+
+    def check(tag, rtag):
+        pos, mom = c.host('pos'), c.host('mom')
+        rung = torch.empty_like(c.rung_indices)
+        rung[c.ids] = c.rung_indices
+        o = np.argsort(pos[:, 0], kind='stable')
+        assert np.array_equal(rung.cpu().numpy()[o], g[rtag]), tag
+        dx = np.abs(pos[o] - g['pos_' + tag])
+        assert np.minimum(dx, L - dx).max() <= 1e-13*L, tag
+        assert np.abs(mom[o] - g['mom_' + tag]).max() <= 1e-12*np.abs(g['mom_' + tag]).max(), tag
+
+    rs.kick_long(dt, float('inf'), 'init')
+    rs.kick_short(dt)
+    check('init', 'rungs_after_init')
+    for step in (1, 2):
+        rs.base_step(dt)
+        check(f'step{step}', f'rungs_step{step}')
+        assert c.rungs_N == list(g[f'rungs_N_step{step}'])
