@@ -164,6 +164,8 @@ def main():
                     help='P3M step (BASELINE configs[2]): long-range mesh with Gaussian cut-off + '
                          'short-range tile sweep (r_s = 1.25 cells, range 4.5 r_s, spline '
                          'softening 0.025*L/cbrt(N))')
+    ap.add_argument('--no-prepare', action='store_true',
+                    help='do not fuse the next drift\'s tile histogram into the gather-kick')
     ap.add_argument('--no-sort', action='store_true',
                     help='direct (untiled) kernels on unsorted particles, for A/B')
     args = ap.parse_args()
@@ -290,7 +292,11 @@ def main():
             mesh.poisson_solve(4, C, sr is not None, sr['E'] if sr else 0.0)
             mark()
         order = 4 if sr else 2  # differentiation defaults: pm 2, p3m 4 (commons.py:3209-3237)
-        if not args.no_sort:
+        if not args.no_sort and not sr and not args.no_prepare:
+            # the long kick is the last momentum update before the next drift: histogram the
+            # drifted tile keys here, the next cg_drift_sort skips its first pass
+            mesh.gather_kick_tiled_prepare(pos, mom, table, order, kick_factor, dt_over_mass)
+        elif not args.no_sort:
             mesh.gather_kick_tiled(pos, mom, table, order, kick_factor)
         else:
             mesh.gather_kick(pos, mom, order, kick_factor)

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libconcept_gpu.so')
 SOURCES = ['cg_context.hip', 'cg_mesh_kernels.hip', 'cg_tiled_kernels.hip', 'cg_fft.hip', 'cg_shortrange.hip', 'cg_rungs.hip',
            'cg_particles.hip']
-HEADERS = [os.path.join(CSRC, 'cg_internal.h'), os.path.join(CSRC, 'cg_kspace.h'), os.path.join(REPO, 'include', 'concept_gpu.h')]
+HEADERS = [os.path.join(CSRC, 'cg_internal.h'), os.path.join(CSRC, 'cg_kspace.h'), os.path.join(CSRC, 'cg_tiles.h'), os.path.join(REPO, 'include', 'concept_gpu.h')]
 
 FLAGS = [
     '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',

@@ -330,6 +330,7 @@ extern "C" int cg_drift(cg_ctx *c, double *pos, const double *mom, int64_t n,
                         double dt_over_mass) {
     CG_CHECK(c && ((pos && mom) || n == 0), "cg_drift: null argument");
     if (n == 0) return 0;
+    c->prep_valid = false;
     return cgk_drift(c, pos, mom, n, dt_over_mass);
 }
 
@@ -358,7 +359,23 @@ extern "C" int cg_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i
              "cg_gather_kick_tiled: differentiation order %d needs nghosts >= %d "
              "(commons.py:4411-4432)", diff_order, (diff_order + 1) / 2);
     if (n == 0) return 0;
-    return cgk_gather_kick_tiled(c, pos, mom, n, tile_offset, diff_order, factor);
+    return cgk_gather_kick_tiled(c, pos, mom, n, tile_offset, diff_order, factor, 0, 0.0);
+}
+
+extern "C" int cg_gather_kick_tiled_prepare(cg_ctx *c, const double *pos, double *mom, int64_t n,
+                                            const uint32_t *tile_offset, int diff_order,
+                                            double factor, double next_dt_over_mass) {
+    CG_CHECK(c && tile_offset && ((pos && mom) || n == 0),
+             "cg_gather_kick_tiled_prepare: null argument");
+    CG_CHECK(diff_order == 2 || diff_order == 4,
+             "cg_gather_kick_tiled_prepare: differentiation order %d not built", diff_order);
+    CG_CHECK((diff_order + 1) / 2 <= c->p.nghosts,
+             "cg_gather_kick_tiled_prepare: differentiation order %d needs nghosts >= %d",
+             diff_order, (diff_order + 1) / 2);
+    CG_CHECK(c->p.nprocs == 1, "cg_gather_kick_tiled_prepare: single-domain only");
+    if (n == 0) return 0;
+    return cgk_gather_kick_tiled(c, pos, mom, n, tile_offset, diff_order, factor, 1,
+                                 next_dt_over_mass);
 }
 
 extern "C" int cg_sort_particles(cg_ctx *c, const double *pos_in, const double *mom_in,
@@ -371,7 +388,7 @@ extern "C" int cg_sort_particles(cg_ctx *c, const double *pos_in, const double *
              "cg_sort_particles: ids_in and ids_out must both be given or both be null");
     CG_CHECK(n >= 0 && n < (1ll << 32), "cg_sort_particles: n out of range");
     return cgk_sort(c, pos_in, mom_in, ids_in, pos_out, mom_out, ids_out, n, tile_offset_out, 0,
-                    0.0);
+                    0.0, 0);
 }
 
 extern "C" int cg_drift_sort(cg_ctx *c, const double *pos_in, const double *mom_in,
@@ -386,8 +403,13 @@ extern "C" int cg_drift_sort(cg_ctx *c, const double *pos_in, const double *mom_
     CG_CHECK(n >= 0 && n < (1ll << 32), "cg_drift_sort: n out of range");
     CG_CHECK(c->p.nprocs == 1, "cg_drift_sort: single-domain (x-slab domains exchange "
                                "particles between the drift and the sort)");
+    // a histogram prepared by cg_gather_kick_tiled_prepare for exactly these arrays and this
+    // drift replaces the first pass (anything else touching pos/mom in between is a caller bug
+    // the pointers cannot reveal: the prepared state is consumed by the very next sort only)
+    int use_prepared = c->prep_valid && c->prep_pos == pos_in && c->prep_mom == mom_in &&
+                       c->prep_n == n && c->prep_dtm == dt_over_mass;
     return cgk_sort(c, pos_in, mom_in, ids_in, pos_out, mom_out, ids_out, n, tile_offset_out, 1,
-                    dt_over_mass);
+                    dt_over_mass, use_prepared);
 }
 
 extern "C" int cg_cic_indices(cg_ctx *c, const double *pos, int64_t n, int for_gather,

@@ -113,6 +113,11 @@ struct cg_ctx {
     size_t sr_tmp_bytes = 0;
     i64 ntiles = 0;
     CicGeom geom_deposit{}, geom_gather{};
+    // tile histogram of the NEXT drift prepared by cg_gather_kick_tiled_prepare
+    bool prep_valid = false;
+    const double *prep_pos = nullptr, *prep_mom = nullptr;
+    i64 prep_n = 0;
+    double prep_dtm = 0;
     i64 device_bytes = 0;
 };
 
@@ -126,7 +131,7 @@ int cgk_cic_indices(cg_ctx *c, const double *pos, i64 n, int for_gather, i64 *id
 int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst);
 int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
              double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out,
-             int drift, double dt_over_mass);
+             int drift, double dt_over_mass, int use_prepared);
 int cgk_shortrange_build(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
                          unsigned *order, unsigned *offset);
 int cgk_shortrange_sweep(cg_ctx *c, const double *pos_r, const unsigned *order_r,
@@ -160,4 +165,5 @@ int cgk_fft(cg_ctx *c, int what, int deconv_order, double C, int long_range, dou
 int cgk_deposit_cic_tiled(cg_ctx *c, const double *pos, i64 n, const unsigned *tile_offset,
                           double contribution, int accumulate);
 int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
-                          const unsigned *tile_offset, int diff_order, double factor);
+                          const unsigned *tile_offset, int diff_order, double factor,
+                          int prepare, double next_dtm);

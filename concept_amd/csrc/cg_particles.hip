@@ -3,6 +3,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "cg_internal.h"
+#include "cg_tiles.h"
 
 #define CG_LAUNCH_CHECK()                                                                     \
     do {                                                                                      \
@@ -21,18 +22,6 @@
 // to exactly boxsize becomes 0.  Pure streaming kernel: 2 reads + 1 write of
 // 8 B per real, 16-B vector accesses.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double ref_mod(double x, double L) {
-    if (x > 0 && x < L) return x;  // fmod(x, L) == x, same sign as L
-    double m = fmod(x, L);          // exact
-    if (m != 0) {
-        if (m < 0) m += L;          // npy_divmod: sign fix-up (L > 0)
-    } else {
-        m = 0.0;                    // copysign(0, L)
-    }
-    if (m == L) m = 0;              // commons.py:5108-5109
-    return m;
-}
-
 __global__ __launch_bounds__(256) void k_drift(double *__restrict__ pos,
                                                const double *__restrict__ mom, i64 n3,
                                                double dt_over_mass, double L) {
@@ -76,44 +65,6 @@ int cgk_drift(cg_ctx *c, double *pos, const double *mom, i64 n, double dt_over_m
 // of equal keys (the common case, the array is nearly sorted from the
 // previous step) elect the run's first lane to issue ONE atomic for the run.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ i64 lower_cell(double pos, double off, double scale, int g, i64 N) {
-    double x = (pos - off) * scale;
-    i64 a = (i64)x - g;
-    a = a < 0 ? a + N : a;
-    return a >= N ? a - N : a;
-}
-// key = 8*tile + bucket; bucket bit d is set when the lower cell is the last of
-// the tile in dimension d, i.e. the CIC cloud reaches the next tile there
-// (bit 2: x, bit 1: y, bit 0: z).  The pull-deposit of a tile reads its own 8
-// buckets plus the matching boundary buckets of its 7 lower neighbours.
-constexpr unsigned kNoTile = 0xffffffffu;
-__device__ __forceinline__ unsigned tile_of(double x, double y, double z, const CicGeom &geo,
-                                            int g, i64 N, const TileGeom &t, i64 x0) {
-    i64 cx = lower_cell(x, geo.off[0], geo.scale, g, N) - x0;  // local layer of this domain
-    if (cx < 0 || cx >= (i64)t.ntx * t.tx) return kNoTile;      // not owned here
-    unsigned ca = (unsigned)cx;
-    unsigned cb = (unsigned)lower_cell(y, geo.off[1], geo.scale, g, N);
-    unsigned cc = (unsigned)lower_cell(z, geo.off[2], geo.scale, g, N);
-    unsigned T = (unsigned)t.tx;
-    unsigned a = ca / T, b = cb / T, c = cc / T;
-    unsigned f = ((ca - a * T == T - 1) ? 4u : 0u) | ((cb - b * T == T - 1) ? 2u : 0u) |
-                 ((cc - c * T == T - 1) ? 1u : 0u);
-    return ((a * t.nty + b) * t.ntz + c) * 8u + f;
-}
-
-// For the calling wave (all 64 lanes active): runs of consecutive lanes with
-// equal key.  Returns the first lane of this lane's run and the run length.
-__device__ __forceinline__ void wave_runs(unsigned key, int lane, int &run_start, int &run_len) {
-    unsigned prev = __shfl_up(key, 1);
-    bool head = (lane == 0) || (key != prev);
-    unsigned long long mask = __ballot(head);
-    unsigned long long below = mask & (~0ull >> (63 - lane));  // heads at lanes <= lane
-    run_start = 63 - __clzll(below);
-    unsigned long long above = (lane == 63) ? 0ull : (mask >> (lane + 1));
-    int next = above ? (lane + 1 + (__ffsll((long long)above) - 1)) : 64;
-    run_len = next - run_start;
-}
-
 // Position of particle p, optionally drifted on the fly (A11, same arithmetic as
 // k_drift): the fused drift + sort reads the undrifted arrays twice instead of writing
 // the drifted positions in between.
@@ -206,13 +157,14 @@ __global__ __launch_bounds__(256) void k_tile_scatter(
 
 int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
              double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out,
-             int drift, double dt_over_mass) {
+             int drift, double dt_over_mass, int use_prepared) {
     i64 nt = 8 * c->ntiles;  // table entries (8 buckets per tile)
-    CG_HIP(hipMemsetAsync(c->tile_count, 0, 4 * (nt + 1), c->stream));
+    if (!use_prepared) CG_HIP(hipMemsetAsync(c->tile_count, 0, 4 * (nt + 1), c->stream));
     CG_HIP(hipMemsetAsync(c->tile_cursor, 0, 4 * (nt + 1), c->stream));
+    c->prep_valid = false;
     i64 blocks = (n + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    if (n > 0) {
+    if (n > 0 && !use_prepared) {
         if (drift)
             hipLaunchKernelGGL(k_tile_histogram<true>, dim3((unsigned)blocks), dim3(256), 0,
                                c->stream, pos_in, mom_in, n, dt_over_mass, c->p.boxsize,

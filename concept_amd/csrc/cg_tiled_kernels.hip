@@ -13,6 +13,7 @@
 // cg_mesh_kernels.hip); only the order in which particles are added to a
 // cell differs.  Compiled with -ffp-contract=off.
 #include "cg_internal.h"
+#include "cg_tiles.h"
 
 #define CG_LAUNCH_CHECK()                                                                     \
     do {                                                                                      \
@@ -197,11 +198,22 @@ __device__ __forceinline__ void force_cell(const P &phi, double c1, double c2, d
     }
 }
 
-template <int ORDER, int T>
+// PREP: additionally histogram where every particle will be after the NEXT drift
+// (pos + mom_new*next_dtm, the arithmetic of k_tile_histogram<true>) into `count`, so
+// that cg_drift_sort can skip its own histogram pass over pos and mom.
+struct PrepArgs {
+    double next_dtm, boxsize;
+    CicGeom geo_sort;
+    TileGeom tiles;
+    unsigned *count;
+};
+
+template <int ORDER, int T, bool PREP>
 __global__ __launch_bounds__(512) void k_gather_kick_tiled(
     const double *__restrict__ pos, double *__restrict__ mom,
     const unsigned *__restrict__ tile_offset, const double *__restrict__ mesh, i64 N, i64 pad,
-    int g, int nt, unsigned ntiles, XMap xm, CicGeom geo, double c1, double c2, double factor) {
+    int g, int nt, unsigned ntiles, XMap xm, CicGeom geo, double c1, double c2, double factor,
+    PrepArgs prep) {
     constexpr int H = ORDER / 2;
     constexpr int E = T + 1 + 2 * H;  // cells [T0-H, T0+T+H]
     constexpr int NL = E * E * E;
@@ -233,10 +245,15 @@ __global__ __launch_bounds__(512) void k_gather_kick_tiled(
         }
     }
     __syncthreads();
-    for (i64 p = beg + threadIdx.x; p < end; p += 512) {
-        Cic1 cx = cic1(pos[3 * p + 0], geo.off[0], geo.scale);
-        Cic1 cy = cic1(pos[3 * p + 1], geo.off[1], geo.scale);
-        Cic1 cz = cic1(pos[3 * p + 2], geo.off[2], geo.scale);
+    for (i64 pbase = beg; pbase < end; pbase += 512) {
+        const i64 p = pbase + threadIdx.x;
+        const bool pvalid = p < end;
+        unsigned next_key = kNoTile;
+        if (pvalid) {
+        const double px = pos[3 * p + 0], py = pos[3 * p + 1], pz = pos[3 * p + 2];
+        Cic1 cx = cic1(px, geo.off[0], geo.scale);
+        Cic1 cy = cic1(py, geo.off[1], geo.scale);
+        Cic1 cz = cic1(pz, geo.off[2], geo.scale);
         i64 ga = wrap(cx.index - g, N), gb = wrap(cy.index - g, N), gc = wrap(cz.index - g, N);
         i64 la = ga - T0a, lb = gb - T0b, lc = gc - T0c;
         double wx[2] = {cx.w0, cx.w1}, wy[2] = {cy.w0, cy.w1}, wz[2] = {cz.w0, cz.w1};
@@ -296,34 +313,60 @@ __global__ __launch_bounds__(512) void k_gather_kick_tiled(
             val[1] *= factor;
             val[2] *= factor;
         }
-        mom[3 * p + 0] += val[0];
-        mom[3 * p + 1] += val[1];
-        mom[3 * p + 2] += val[2];
+        const double m0 = mom[3 * p + 0] + val[0], m1 = mom[3 * p + 1] + val[1],
+                     m2 = mom[3 * p + 2] + val[2];
+        mom[3 * p + 0] = m0;
+        mom[3 * p + 1] = m1;
+        mom[3 * p + 2] = m2;
+        if (PREP)
+            next_key = tile_of(ref_mod(px + m0 * prep.next_dtm, prep.boxsize),
+                               ref_mod(py + m1 * prep.next_dtm, prep.boxsize),
+                               ref_mod(pz + m2 * prep.next_dtm, prep.boxsize), prep.geo_sort, g, N,
+                               prep.tiles, xm.x0);
+        }
+        if (PREP) {
+            int rs, rl;
+            wave_runs(next_key, threadIdx.x & 63, rs, rl);
+            if ((int)(threadIdx.x & 63) == rs && next_key != kNoTile)
+                atomicAdd(&prep.count[next_key], (unsigned)rl);
+        }
     }
 }
 
 template <int ORDER, int T>
 static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsigned *tile_offset,
-                         double c1, double c2, double factor) {
+                         double c1, double c2, double factor, const PrepArgs *prep) {
     constexpr int E = T + 1 + 2 * (ORDER / 2);
     size_t lds = sizeof(double) * E * E * E;
-    auto kern = k_gather_kick_tiled<ORDER, T>;
+    auto kern = k_gather_kick_tiled<ORDER, T, false>;
+    auto kern_prep = k_gather_kick_tiled<ORDER, T, true>;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         CG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
+        CG_HIP(hipFuncSetAttribute((const void *)kern_prep,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     unsigned nt = (unsigned)c->ntiles;
-    hipLaunchKernelGGL(kern, dim3(nt), dim3(512), lds, c->stream, pos, mom, tile_offset, c->mesh,
-                       c->N, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap, c->geom_gather, c1,
-                       c2, factor);
+    if (prep)
+        hipLaunchKernelGGL(kern_prep, dim3(nt), dim3(512), lds, c->stream, pos, mom, tile_offset,
+                           c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap,
+                           c->geom_gather, c1, c2, factor, *prep);
+    else
+        hipLaunchKernelGGL(kern, dim3(nt), dim3(512), lds, c->stream, pos, mom, tile_offset,
+                           c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap,
+                           c->geom_gather, c1, c2, factor, PrepArgs{});
     return 0;
 }
 
 int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
-                          const unsigned *tile_offset, int diff_order, double factor) {
-    (void)n;
+                          const unsigned *tile_offset, int diff_order, double factor,
+                          int prepare, double next_dtm) {
+    PrepArgs prep_args{next_dtm, c->p.boxsize, c->geom_deposit, c->tiles, c->tile_count};
+    const PrepArgs *prep = prepare ? &prep_args : nullptr;
+    if (prepare)
+        CG_HIP(hipMemsetAsync(c->tile_count, 0, 4 * (8 * c->ntiles + 1), c->stream));
     const int T = c->tiles.tx;
     double dx = c->p.boxsize / (double)c->N;  // interactions.py:2133
     double c1, c2 = 0;
@@ -335,8 +378,9 @@ int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
     int rc = 1;
 #define CG_GATHER_CASE(TT)                                                                       \
     case TT:                                                                                     \
-        rc = diff_order == 2 ? launch_gather<2, TT>(c, pos, mom, tile_offset, c1, c2, factor)    \
-                             : launch_gather<4, TT>(c, pos, mom, tile_offset, c1, c2, factor);   \
+        rc = diff_order == 2                                                                     \
+                 ? launch_gather<2, TT>(c, pos, mom, tile_offset, c1, c2, factor, prep)          \
+                 : launch_gather<4, TT>(c, pos, mom, tile_offset, c1, c2, factor, prep);         \
         break;
     switch (T) {
         CG_GATHER_CASE(16)
@@ -348,5 +392,10 @@ int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
 #undef CG_GATHER_CASE
     if (rc) return rc;
     CG_LAUNCH_CHECK();
+    c->prep_valid = prepare != 0;
+    c->prep_pos = pos;
+    c->prep_mom = mom;
+    c->prep_n = n;
+    c->prep_dtm = next_dtm;
     return 0;
 }

@@ -60,6 +60,7 @@ SYMBOLS = {
     'cg_poisson_kernel': (_int, [_vp, _int, _dbl, _int, _dbl]),
     'cg_gather_kick': (_int, [_vp, _vp, _vp, _i64, _int, _dbl]),
     'cg_gather_kick_tiled': (_int, [_vp, _vp, _vp, _i64, _vp, _int, _dbl]),
+    'cg_gather_kick_tiled_prepare': (_int, [_vp, _vp, _vp, _i64, _vp, _int, _dbl, _dbl]),
     'cg_drift': (_int, [_vp, _vp, _vp, _i64, _dbl]),
     'cg_sort_particles': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'cg_drift_sort': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _vp]),

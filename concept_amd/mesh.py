@@ -136,6 +136,15 @@ class PotentialMesh:
         check(_L.cg_gather_kick_tiled(self._ctx, _ptr(pos), _ptr(mom), n, _ptr(tile_offset),
                                       int(diff_order), float(factor)))
 
+    def gather_kick_tiled_prepare(self, pos, mom, tile_offset, diff_order, factor,
+                                  next_dt_over_mass):
+        """gather_kick_tiled + tile histogram of the next drift (see concept_gpu.h)."""
+        n = self._check_particles(pos, mom)
+        self._check_table(tile_offset)
+        check(_L.cg_gather_kick_tiled_prepare(self._ctx, _ptr(pos), _ptr(mom), n,
+                                              _ptr(tile_offset), int(diff_order), float(factor),
+                                              float(next_dt_over_mass)))
+
     def new_tile_table(self):
         """uint32[8*ntiles + 1] on the device (stored as int32 bits): first particle
         of each (tile, bucket), see include/concept_gpu.h cg_tile_info."""

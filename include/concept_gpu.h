@@ -130,6 +130,17 @@ int cg_gather_kick_tiled(cg_ctx *ctx, const double *pos /*DEV 3n*/, double *mom 
                          int64_t n, const uint32_t *tile_offset /*DEV tile table*/, int diff_order,
                          double factor);
 
+/* cg_gather_kick_tiled that also prepares the tile histogram of the NEXT drift
+ * (pos + mom_new*next_dt_over_mass): a following cg_drift_sort on the same arrays with the
+ * same dt_over_mass then skips its first pass.  The reference fuses kicks and drifts the
+ * same way where it can (driftkick_short, main.py:1347).  Contract: nothing else may change
+ * pos/mom between the two calls (cg_drift and cg_sort_particles invalidate the
+ * preparation; other writers are the caller's responsibility). */
+int cg_gather_kick_tiled_prepare(cg_ctx *ctx, const double *pos /*DEV 3n*/,
+                                 double *mom /*DEV 3n*/, int64_t n,
+                                 const uint32_t *tile_offset /*DEV tile table*/, int diff_order,
+                                 double factor, double next_dt_over_mass);
+
 /* --- A11: drift ------------------------------------------------------------
  * Component.drift (species.py:2179-2199): pos = mod(pos + mom*dt_over_mass, boxsize)
  * with the reference's mod (commons.py:5103-5135). */

@@ -565,3 +565,48 @@ def test_north_star_size_properties(torch_cuda):
     tot = mo.sum(0).abs().max()
     assert float(tot) <= 1e-9*float(mo.abs().sum(0).max())
     mesh.close()
+
+
+def test_prepared_histogram_equals_plain(torch_cuda):
+    """cg_gather_kick_tiled_prepare + cg_drift_sort (histogram pass skipped) gives exactly
+    the tile table and particle arrays of the unfused sequence."""
+    torch = torch_cuda
+    from concept_amd.mesh import PotentialMesh
+    L, N, n = 64.0, 64, 200_001
+    mesh = PotentialMesh(N, L)
+    rng = np.random.default_rng(21)
+    pos = torch.tensor(rng.uniform(0, L, (n, 3)), device='cuda')
+    mom = torch.tensor(rng.normal(0, 1.0, (n, 3)), device='cuda')
+    ids = torch.arange(n, device='cuda')
+    po, mo, io = torch.empty_like(pos), torch.empty_like(mom), torch.empty_like(ids)
+    table = mesh.sort_particles(pos, mom, ids, po, mo, io)
+    mesh.deposit_tiled(po, table, 1.0)
+    mesh.poisson_solve(4, -1.0, False, 0.0)
+    dtm = 0.8
+    out = {}
+    for mode in ('plain', 'prepared'):
+        p1, m1 = po.clone(), mo.clone()
+        if mode == 'plain':
+            mesh.gather_kick_tiled(p1, m1, table, 2, -0.3)
+        else:
+            mesh.gather_kick_tiled_prepare(p1, m1, table, 2, -0.3, dtm)
+        p2, m2, i2 = torch.empty_like(p1), torch.empty_like(m1), torch.empty_like(io)
+        t2 = mesh.drift_sort(p1, m1, io, p2, m2, i2, dtm)
+        back_p, back_m = torch.empty_like(p2), torch.empty_like(m2)
+        back_p[i2] = p2
+        back_m[i2] = m2
+        out[mode] = (t2.clone(), back_p, back_m)
+    assert torch.equal(out['plain'][0], out['prepared'][0])
+    assert torch.equal(out['plain'][1], out['prepared'][1])
+    assert torch.equal(out['plain'][2], out['prepared'][2])
+    # a different dt_over_mass must NOT reuse the prepared histogram
+    p1, m1 = po.clone(), mo.clone()
+    mesh.gather_kick_tiled_prepare(p1, m1, table, 2, -0.3, dtm)
+    p2, m2, i2 = torch.empty_like(p1), torch.empty_like(m1), torch.empty_like(io)
+    t3 = mesh.drift_sort(p1, m1, io, p2, m2, i2, 0.5*dtm)
+    assert (int(t3[-1].item()) & 0xffffffff) == n
+    p1b, m1b = po.clone(), mo.clone()
+    mesh.gather_kick_tiled(p1b, m1b, table, 2, -0.3)
+    t4 = mesh.drift_sort(p1b, m1b, io, torch.empty_like(p1), torch.empty_like(m1),
+                         torch.empty_like(io), 0.5*dtm)
+    assert torch.equal(t3, t4)
