@@ -266,14 +266,17 @@ __global__ __launch_bounds__(NT) void k_fft_strided(const double2 *__restrict__ 
     __syncthreads();
     if (MODE == 0 || MODE == 2) fft_lds<LOGN, W, NT, false>(lds, tw, 1, tid);
     if (MODE == 2) {
+        // NT is a multiple of W: a lane's kk (= kk0 + tid % W) and the outer index are the
+        // same for all its elements; only the pencil index m changes
+        const int wl = tid % W;
+        const int kkl = kk0 + wl;
+        if (kkl < nk) {
+            const KspaceFixed F = kspace_fix(P, N, o + o_off, kkl);
 #pragma unroll
-        for (int r = 0; r < PER; r++) {
-            int f = tid + r * NT;
-            if (TOT % NT == 0 || f < TOT) {
-                int w = f % W, m = f / W;
-                int kk = kk0 + w;
-                if (kk < nk) {
-                    double fac = kspace_factor(P, N, m, o + o_off, kk);
+            for (int r = 0; r < PER; r++) {
+                int f = tid + r * NT;
+                if (TOT % NT == 0 || f < TOT) {
+                    double fac = kspace_factor_fixed(P, F, N, f / W);
                     double2 x = lds[f];
                     lds[f] = make_double2(x.x * fac, x.y * fac);
                 }
