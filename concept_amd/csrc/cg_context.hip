@@ -136,16 +136,20 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
     // k-space tables by array index: k = idx - (idx >= N/2 ? N : 0)
     // n(k) = k*R[pi/gridsize] + machine_eps, s(k) = sin(n(k))   (mesh.py:2775-2776)
     {
-        std::vector<double> tn(c->N), ts(c->N);
+        // q = n/s: the per-dimension sinc^-1 of the deconvolution, for the fused FFT pass
+        std::vector<double> tn(c->N), ts(c->N), tq(c->N);
         double pi_over_n = kPi / (double)c->N;
         for (i64 i = 0; i < c->N; i++) {
             i64 k = i - (i >= c->N / 2 ? c->N : 0);
             tn[i] = (double)k * pi_over_n + kMachineEps;
             ts[i] = sin(tn[i]);
+            tq[i] = tn[i] / ts[i];
         }
         if (hipMalloc(&c->ktab_n, 8 * c->N) != hipSuccess ||
             hipMalloc(&c->ktab_s, 8 * c->N) != hipSuccess ||
+            hipMalloc(&c->ktab_q, 8 * c->N) != hipSuccess ||
             hipMemcpy(c->ktab_n, tn.data(), 8 * c->N, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->ktab_q, tq.data(), 8 * c->N, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(c->ktab_s, ts.data(), 8 * c->N, hipMemcpyHostToDevice) != hipSuccess) {
             cg_set_error("cg_create: k-space table upload failed");
             return fail();
@@ -211,6 +215,7 @@ extern "C" int cg_destroy(cg_ctx *c) {
     (void)hipFree(c->fetch_tmp);
     (void)hipFree(c->ktab_n);
     (void)hipFree(c->ktab_s);
+    (void)hipFree(c->ktab_q);
     (void)hipFree(c->tile_count);
     (void)hipFree(c->tile_cursor);
     (void)hipFree(c->scan_tmp);

@@ -50,99 +50,232 @@ __device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -
 // In-LDS transform of W interleaved pencils of n = 2^LOGN complex points:
 // element m of pencil w lives at lds[m*W + w].  tw[k*tws] = exp(-2 pi i k/n).
 // All NT threads of the workgroup must call it.  Natural order in and out.
+// Stockham autosort passes: a butterfly of radix R at position j (k = j mod Ns)
+// reads points j + r*n/R, multiplies by exp(-+2 pi i k r/(R Ns)) and writes
+// (j - k)*R + k + r*Ns.  The inputs sit in registers between the read and the
+// write half of a pass, so one LDS buffer suffices (two barriers per pass).
+// Schedules: R16 = false: radix 4 (+ radix-2 tail); R16 = true: radix 16 passes,
+// then radix 4 / radix 2 for the remaining bits (1024 = 16*16*4: 3 passes
+// instead of 5, i.e. 6 instead of 10 LDS round trips).
 // ---------------------------------------------------------------------------
 template <int LOGN, int W, int NT, bool INV>
+__device__ __forceinline__ void fft_pass_r4(double2 *lds, const double2 *__restrict__ tw,
+                                            int tws, int tid, int Ns) {
+    constexpr int n = 1 << LOGN;
+    constexpr int NB = (n / 4) * W;        // butterflies in the workgroup
+    constexpr int B = (NB + NT - 1) / NT;  // per thread
+    double2 v[B][4];
+    double2 t1s[B];
+    // the pass's twiddles come from global memory (L1/L2 resident table): issue
+    // those loads first so their latency hides behind the LDS reads and the barrier
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        int f = tid + b * NT;
+        t1s[b] = make_double2(1, 0);
+        if ((NB % NT == 0 || f < NB) && Ns > 1) {
+            int j = f / W;
+            t1s[b] = tw[(size_t)(j & (Ns - 1)) * (n / (4 * Ns)) * tws];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        int f = tid + b * NT;
+        if (NB % NT == 0 || f < NB) {
+            int w = f % W, j = f / W;
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[b][r] = lds[(j + r * (n / 4)) * W + w];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        int f = tid + b * NT;
+        if (NB % NT == 0 || f < NB) {
+            int w = f % W, j = f / W;
+            int k = j & (Ns - 1);
+            double2 x0 = v[b][0], x1 = v[b][1], x2 = v[b][2], x3 = v[b][3];
+            if (Ns > 1) {
+                // twiddles exp(-+2 pi i k r/(4 Ns)), r = 1..3
+                double2 t1 = t1s[b];
+                if (INV) t1 = cconj(t1);
+                double2 t2 = cmul(t1, t1), t3 = cmul(t2, t1);
+                x1 = cmul(x1, t1);
+                x2 = cmul(x2, t2);
+                x3 = cmul(x3, t3);
+            }
+            double2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), d = csub(x1, x3);
+            // (x1 - x3) * (-+ i)
+            double2 a3 = INV ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);
+            int j0 = ((j - k) << 2) + k;  // (j/Ns)*Ns*4 + k
+            lds[(j0)*W + w] = cadd(a0, a2);
+            lds[(j0 + Ns) * W + w] = cadd(a1, a3);
+            lds[(j0 + 2 * Ns) * W + w] = csub(a0, a2);
+            lds[(j0 + 3 * Ns) * W + w] = csub(a1, a3);
+        }
+    }
+    __syncthreads();
+}
+
+// radix-2 pass with Ns = n/2 (the last pass of an odd LOGN)
+template <int LOGN, int W, int NT, bool INV>
+__device__ __forceinline__ void fft_pass_r2_last(double2 *lds, const double2 *__restrict__ tw,
+                                                 int tws, int tid) {
+    constexpr int n = 1 << LOGN;
+    constexpr int NB = (n / 2) * W;
+    constexpr int B = (NB + NT - 1) / NT;
+    double2 v[B][2];
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        int f = tid + b * NT;
+        if (NB % NT == 0 || f < NB) {
+            int w = f % W, j = f / W;
+            v[b][0] = lds[j * W + w];
+            v[b][1] = lds[(j + n / 2) * W + w];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        int f = tid + b * NT;
+        if (NB % NT == 0 || f < NB) {
+            int w = f % W, j = f / W;  // k = j (Ns = n/2)
+            double2 t1 = tw[(size_t)j * tws];
+            if (INV) t1 = cconj(t1);
+            double2 x1 = cmul(v[b][1], t1);
+            lds[j * W + w] = cadd(v[b][0], x1);
+            lds[(j + n / 2) * W + w] = csub(v[b][0], x1);
+        }
+    }
+    __syncthreads();
+}
+
+// x * exp(-+2 pi i M/16) for the M the 4x4 decomposition of a 16-point butterfly needs
+template <int M, bool INV>
+__device__ __forceinline__ double2 mul_w16(double2 x) {
+    constexpr double C = 0.92387953251128674, S = 0.38268343236508977,
+                     R = 0.70710678118654752;
+    // forward factor (c, -s); inverse its conjugate
+    if (M == 0) return x;
+    if (M == 4) return INV ? make_double2(-x.y, x.x) : make_double2(x.y, -x.x);
+    if (M == 2)
+        return INV ? make_double2(R * (x.x - x.y), R * (x.x + x.y))
+                   : make_double2(R * (x.x + x.y), R * (x.y - x.x));
+    if (M == 6)
+        return INV ? make_double2(-R * (x.x + x.y), R * (x.x - x.y))
+                   : make_double2(R * (x.y - x.x), -R * (x.x + x.y));
+    double c = M == 1 ? C : (M == 3 ? S : -C);   // M = 1, 3, 9
+    double s = M == 1 ? S : (M == 3 ? C : -S);   // sin(2 pi M/16)
+    double2 t = make_double2(c, INV ? s : -s);
+    return cmul(x, t);
+}
+template <bool INV>
+__device__ __forceinline__ void bfly4(double2 &x0, double2 &x1, double2 &x2, double2 &x3) {
+    double2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), d = csub(x1, x3);
+    double2 a3 = INV ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);
+    x0 = cadd(a0, a2);
+    x1 = cadd(a1, a3);
+    x2 = csub(a0, a2);
+    x3 = csub(a1, a3);
+}
+// 16-point DFT in registers, n = a + 4m, k = b + 4c:
+//   X[b+4c] = sum_a w4^(ac) [ w16^(ab) sum_m w4^(mb) x[a+4m] ]
+// in place: after the first stage v[a+4b] holds the inner sum for (a, b); after the second
+// v[b'+4c] with b' the register row — the result index is returned by out16().
+template <bool INV>
+__device__ __forceinline__ void fft16_regs(double2 (&v)[16]) {
+#pragma unroll
+    for (int a = 0; a < 4; a++) bfly4<INV>(v[a], v[a + 4], v[a + 8], v[a + 12]);
+    // v[a + 4b] *= w16^(a b)
+    v[5] = mul_w16<1, INV>(v[5]);
+    v[6] = mul_w16<2, INV>(v[6]);
+    v[7] = mul_w16<3, INV>(v[7]);
+    v[9] = mul_w16<2, INV>(v[9]);
+    v[10] = mul_w16<4, INV>(v[10]);
+    v[11] = mul_w16<6, INV>(v[11]);
+    v[13] = mul_w16<3, INV>(v[13]);
+    v[14] = mul_w16<6, INV>(v[14]);
+    v[15] = mul_w16<9, INV>(v[15]);
+    // per b: DFT over a of v[a + 4b] -> output c lands in register c + 4b = X[b + 4c]
+#pragma unroll
+    for (int b = 0; b < 4; b++) bfly4<INV>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);
+}
+
+template <int LOGN, int W, int NT, bool INV>
+__device__ __forceinline__ void fft_pass_r16(double2 *lds, const double2 *__restrict__ tw,
+                                             int tws, int tid, int Ns) {
+    constexpr int n = 1 << LOGN;
+    constexpr int NB = (n / 16) * W;
+    constexpr int B = (NB + NT - 1) / NT;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        static_assert(B == 1, "radix-16 passes are launched with one butterfly per lane");
+        int f = tid + b * NT;
+        const bool on = (NB % NT == 0 || f < NB);
+        int w = f % W, j = f / W;
+        int k = j & (Ns - 1);
+        double2 t1 = make_double2(1, 0);
+        if (on && Ns > 1) t1 = tw[(size_t)k * (n / (16 * Ns)) * tws];
+        double2 v[16];
+        if (on) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = lds[(j + r * (n / 16)) * W + w];
+        }
+        __syncthreads();
+        if (on) {
+            if (Ns > 1) {
+                if (INV) t1 = cconj(t1);
+                // powers t^r by a balanced product tree (depth 4)
+                double2 t2 = cmul(t1, t1), t3 = cmul(t2, t1), t4 = cmul(t2, t2);
+                double2 t5 = cmul(t3, t2), t6 = cmul(t3, t3), t7 = cmul(t4, t3);
+                double2 t8 = cmul(t4, t4);
+                v[1] = cmul(v[1], t1);
+                v[2] = cmul(v[2], t2);
+                v[3] = cmul(v[3], t3);
+                v[4] = cmul(v[4], t4);
+                v[5] = cmul(v[5], t5);
+                v[6] = cmul(v[6], t6);
+                v[7] = cmul(v[7], t7);
+                v[8] = cmul(v[8], t8);
+                v[9] = cmul(v[9], cmul(t8, t1));
+                v[10] = cmul(v[10], cmul(t8, t2));
+                v[11] = cmul(v[11], cmul(t8, t3));
+                v[12] = cmul(v[12], cmul(t8, t4));
+                v[13] = cmul(v[13], cmul(t8, t5));
+                v[14] = cmul(v[14], cmul(t8, t6));
+                v[15] = cmul(v[15], cmul(t8, t7));
+            }
+            fft16_regs<INV>(v);
+            int j0 = ((j - k) << 4) + k;  // (j/Ns)*Ns*16 + k
+            // register c + 4b holds X[b + 4c]
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++)
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++)
+                    lds[(j0 + (bb + 4 * cc) * Ns) * W + w] = v[cc + 4 * bb];
+        }
+        __syncthreads();
+    }
+}
+
+template <int LOGN, int W, int NT, bool INV, bool R16 = false>
 __device__ __forceinline__ void fft_lds(double2 *lds, const double2 *__restrict__ tw, int tws,
                                         int tid) {
-    constexpr int n = 1 << LOGN;
     int Ns = 1;
+    if constexpr (R16) {
 #pragma unroll 1
-    for (int pass = 0; pass < LOGN / 2; pass++) {
-        // radix 4
-        constexpr int NB = (n / 4) * W;             // butterflies in the workgroup
-        constexpr int B = (NB + NT - 1) / NT;       // per thread
-        double2 v[B][4];
-        double2 t1s[B];
-        // the pass's twiddles come from global memory (L1/L2 resident table): issue
-        // those loads first so their latency hides behind the LDS reads and the barrier
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-            int f = tid + b * NT;
-            t1s[b] = make_double2(1, 0);
-            if ((NB % NT == 0 || f < NB) && Ns > 1) {
-                int j = f / W;
-                t1s[b] = tw[(size_t)(j & (Ns - 1)) * (n / (4 * Ns)) * tws];
-            }
+        for (int pass = 0; pass < LOGN / 4; pass++) {
+            fft_pass_r16<LOGN, W, NT, INV>(lds, tw, tws, tid, Ns);
+            Ns <<= 4;
         }
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-            int f = tid + b * NT;
-            if (NB % NT == 0 || f < NB) {
-                int w = f % W, j = f / W;
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[b][r] = lds[(j + r * (n / 4)) * W + w];
-            }
+        if ((LOGN & 3) >= 2) fft_pass_r4<LOGN, W, NT, INV>(lds, tw, tws, tid, Ns);
+    } else {
+#pragma unroll 1
+        for (int pass = 0; pass < LOGN / 2; pass++) {
+            fft_pass_r4<LOGN, W, NT, INV>(lds, tw, tws, tid, Ns);
+            Ns <<= 2;
         }
-        __syncthreads();
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-            int f = tid + b * NT;
-            if (NB % NT == 0 || f < NB) {
-                int w = f % W, j = f / W;
-                int k = j & (Ns - 1);
-                double2 x0 = v[b][0], x1 = v[b][1], x2 = v[b][2], x3 = v[b][3];
-                if (Ns > 1) {
-                    // twiddles exp(-+2 pi i k r/(4 Ns)), r = 1..3
-                    double2 t1 = t1s[b];
-                    if (INV) t1 = cconj(t1);
-                    double2 t2 = cmul(t1, t1), t3 = cmul(t2, t1);
-                    x1 = cmul(x1, t1);
-                    x2 = cmul(x2, t2);
-                    x3 = cmul(x3, t3);
-                }
-                double2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3),
-                        d = csub(x1, x3);
-                // (x1 - x3) * (-+ i)
-                double2 a3 = INV ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);
-                int j0 = ((j - k) << 2) + k;  // (j/Ns)*Ns*4 + k
-                lds[(j0)*W + w] = cadd(a0, a2);
-                lds[(j0 + Ns) * W + w] = cadd(a1, a3);
-                lds[(j0 + 2 * Ns) * W + w] = csub(a0, a2);
-                lds[(j0 + 3 * Ns) * W + w] = csub(a1, a3);
-            }
-        }
-        __syncthreads();
-        Ns <<= 2;
     }
-    if (LOGN & 1) {
-        // radix-2 tail, Ns = n/2
-        constexpr int NB = (n / 2) * W;
-        constexpr int B = (NB + NT - 1) / NT;
-        double2 v[B][2];
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-            int f = tid + b * NT;
-            if (NB % NT == 0 || f < NB) {
-                int w = f % W, j = f / W;
-                v[b][0] = lds[j * W + w];
-                v[b][1] = lds[(j + n / 2) * W + w];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-            int f = tid + b * NT;
-            if (NB % NT == 0 || f < NB) {
-                int w = f % W, j = f / W;  // k = j (Ns = n/2)
-                double2 t1 = tw[(size_t)j * tws];
-                if (INV) t1 = cconj(t1);
-                double2 x1 = cmul(v[b][1], t1);
-                lds[j * W + w] = cadd(v[b][0], x1);
-                lds[(j + n / 2) * W + w] = csub(v[b][0], x1);
-            }
-        }
-        __syncthreads();
-    }
+    if (LOGN & 1) fft_pass_r2_last<LOGN, W, NT, INV>(lds, tw, tws, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -230,7 +363,7 @@ __device__ __forceinline__ i64 pencil_off(const PencilMap &pm, int m) {
     return (i64)(m >> pm.sh) * pm.blk + (i64)((unsigned)m & ((1u << pm.sh) - 1u)) * pm.es;
 }
 
-template <int LOGN, int NT, int MODE, int W>
+template <int LOGN, int NT, int MODE, int W, bool R16>
 __global__ __launch_bounds__(NT) void k_fft_strided(const double2 *__restrict__ src,
                                                     double2 *__restrict__ dst, PencilMap smap,
                                                     PencilMap dmap, int nkb, i64 o_off,
@@ -264,7 +397,7 @@ __global__ __launch_bounds__(NT) void k_fft_strided(const double2 *__restrict__ 
         }
     }
     __syncthreads();
-    if (MODE == 0 || MODE == 2) fft_lds<LOGN, W, NT, false>(lds, tw, 1, tid);
+    if (MODE == 0 || MODE == 2) fft_lds<LOGN, W, NT, false, R16>(lds, tw, 1, tid);
     if (MODE == 2) {
         // NT is a multiple of W: a lane's kk (= kk0 + tid % W) and the outer index are the
         // same for all its elements; only the pencil index m changes
@@ -276,7 +409,7 @@ __global__ __launch_bounds__(NT) void k_fft_strided(const double2 *__restrict__ 
             for (int r = 0; r < PER; r++) {
                 int f = tid + r * NT;
                 if (TOT % NT == 0 || f < TOT) {
-                    double fac = kspace_factor_fixed(P, F, N, f / W);
+                    double fac = kspace_factor_fixed(P, F, N, f / W, P.tab_n[f / W], P.tab_s[f / W]);
                     double2 x = lds[f];
                     lds[f] = make_double2(x.x * fac, x.y * fac);
                 }
@@ -284,13 +417,284 @@ __global__ __launch_bounds__(NT) void k_fft_strided(const double2 *__restrict__ 
         }
         __syncthreads();
     }
-    if (MODE == 1 || MODE == 2) fft_lds<LOGN, W, NT, true>(lds, tw, 1, tid);
+    if (MODE == 1 || MODE == 2) fft_lds<LOGN, W, NT, true, R16>(lds, tw, 1, tid);
 #pragma unroll
     for (int r = 0; r < PER; r++) {
         int f = tid + r * NT;
         int w = f % W, m = f / W;
         if ((TOT % NT == 0 || f < TOT) && (kk0 + w < nk)) dbase[pencil_off(dmap, m) + w] = lds[f];
     }
+}
+
+// Persistent form of the same pass: one workgroup per CU walks tiles t, t + G, ... and
+// loads tile t + G into registers before transforming tile t in LDS, so the CU's memory
+// pipe stays busy during the transform (with one 128 KB tile per CU nothing else would
+// overlap them).  Needs the 256-VGPR budget of <= 512 lanes (radix-16 schedule: 126 VGPRs
+// for the transform + 64 staged) and no vmcnt-tracked access between the prefetch and
+// its use — the twiddle and k-space tables are therefore copied to LDS once per workgroup
+// (vector memory returns in order: a global twiddle load would wait for the prefetch).
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------
+// Tile transform with register input and output, for NT = n*W/16 lanes (one radix-16
+// butterfly per lane): lane (ml = tid / W, wl = tid % W) enters holding the 16 points
+// ml + r*n/16 of pencil wl — exactly the operands of its first-pass butterfly AND what it
+// loaded from global memory — and leaves holding the same 16 positions of the result —
+// exactly what the last pass's butterflies of that lane produce (q = b + r*B below).
+// So the first pass never reads LDS and the last never writes it: a 1024-point transform
+// (16*16*4) costs 2 LDS writes + 2 LDS reads of the tile instead of 4 + 4 (LDS stores run
+// at ~79 B/clk/CU against 256 B/clk for loads: they are the transform's cost), and in the
+// fused pass the k-space factor is applied in registers between the last forward pass and
+// the first inverse pass.
+// ---------------------------------------------------------------------------
+template <int LOGN, int W, int NT, bool INV, bool IN_REGS, bool OUT_REGS, int Ns>
+__device__ __forceinline__ void tile_r16(double2 (&x)[16], double2 *lds,
+                                         const double2 *__restrict__ tw, int tid) {
+    constexpr int n = 1 << LOGN;
+    static_assert((n / 16) * W == NT, "one radix-16 butterfly per lane");
+    const int w = tid % W, j = tid / W;
+    const int k = j & (Ns - 1);
+    double2 t1 = make_double2(1, 0);
+    if (!IN_REGS) {
+        t1 = tw[k * (n / (16 * Ns))];
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = lds[(j + r * (n / 16)) * W + w];
+    }
+    __syncthreads();  // LDS reads of this pass (or of the previous transform) are done
+    if (!IN_REGS) {
+        if (INV) t1 = cconj(t1);
+        double2 t2 = cmul(t1, t1), t3 = cmul(t2, t1), t4 = cmul(t2, t2);
+        double2 t5 = cmul(t3, t2), t6 = cmul(t3, t3), t7 = cmul(t4, t3);
+        double2 t8 = cmul(t4, t4);
+        x[1] = cmul(x[1], t1);
+        x[2] = cmul(x[2], t2);
+        x[3] = cmul(x[3], t3);
+        x[4] = cmul(x[4], t4);
+        x[5] = cmul(x[5], t5);
+        x[6] = cmul(x[6], t6);
+        x[7] = cmul(x[7], t7);
+        x[8] = cmul(x[8], t8);
+        x[9] = cmul(x[9], cmul(t8, t1));
+        x[10] = cmul(x[10], cmul(t8, t2));
+        x[11] = cmul(x[11], cmul(t8, t3));
+        x[12] = cmul(x[12], cmul(t8, t4));
+        x[13] = cmul(x[13], cmul(t8, t5));
+        x[14] = cmul(x[14], cmul(t8, t6));
+        x[15] = cmul(x[15], cmul(t8, t7));
+    }
+    fft16_regs<INV>(x);  // register c + 4b holds X[b + 4c]
+    if (OUT_REGS) {
+        // last pass (Ns = n/16): X[q] is point j + q*n/16 — reorder in registers
+        double2 y[16];
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) y[bb + 4 * cc] = x[cc + 4 * bb];
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = y[r];
+    } else {
+        const int j0 = ((j - k) << 4) + k;
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++)
+                lds[(j0 + (bb + 4 * cc) * Ns) * W + w] = x[cc + 4 * bb];
+        __syncthreads();
+    }
+}
+
+// radix-4 pass, 4 butterflies per lane (j = tid/W + b*n/16); OUT_REGS: last pass (Ns = n/4),
+// output r of butterfly b is point tid/W + (b + 4r)*n/16
+template <int LOGN, int W, int NT, bool INV, bool OUT_REGS, int Ns>
+__device__ __forceinline__ void tile_r4(double2 (&x)[16], double2 *lds,
+                                        const double2 *__restrict__ tw, int tid) {
+    constexpr int n = 1 << LOGN;
+    const int w = tid % W, jl = tid / W;
+    double2 t1s[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        int j = jl + b * (n / 16);
+        t1s[b] = tw[(j & (Ns - 1)) * (n / (4 * Ns))];
+#pragma unroll
+        for (int r = 0; r < 4; r++) x[4 * b + r] = lds[(j + r * (n / 4)) * W + w];
+    }
+    __syncthreads();
+    double2 y[16];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        int j = jl + b * (n / 16);
+        int k = j & (Ns - 1);
+        double2 t1 = INV ? cconj(t1s[b]) : t1s[b];
+        double2 t2 = cmul(t1, t1), t3 = cmul(t2, t1);
+        double2 x0 = x[4 * b], x1 = cmul(x[4 * b + 1], t1), x2 = cmul(x[4 * b + 2], t2),
+                x3 = cmul(x[4 * b + 3], t3);
+        bfly4<INV>(x0, x1, x2, x3);
+        if (OUT_REGS) {
+            y[b] = x0;
+            y[b + 4] = x1;
+            y[b + 8] = x2;
+            y[b + 12] = x3;
+        } else {
+            int j0 = ((j - k) << 2) + k;
+            lds[(j0)*W + w] = x0;
+            lds[(j0 + Ns) * W + w] = x1;
+            lds[(j0 + 2 * Ns) * W + w] = x2;
+            lds[(j0 + 3 * Ns) * W + w] = x3;
+        }
+    }
+    if (OUT_REGS) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = y[r];
+    } else {
+        __syncthreads();
+    }
+}
+
+// radix-2 last pass (Ns = n/2), 8 butterflies per lane, always to registers:
+// output r of butterfly b is point tid/W + (b + 8r)*n/16
+template <int LOGN, int W, int NT, bool INV>
+__device__ __forceinline__ void tile_r2_last(double2 (&x)[16], double2 *lds,
+                                             const double2 *__restrict__ tw, int tid) {
+    constexpr int n = 1 << LOGN;
+    const int w = tid % W, jl = tid / W;
+    double2 a[8], c[8], t[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        int j = jl + b * (n / 16);
+        t[b] = tw[j];
+        a[b] = lds[j * W + w];
+        c[b] = lds[(j + n / 2) * W + w];
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        double2 t1 = INV ? cconj(t[b]) : t[b];
+        double2 x1 = cmul(c[b], t1);
+        x[b] = cadd(a[b], x1);
+        x[b + 8] = csub(a[b], x1);
+    }
+}
+
+template <int LOGN, int W, int NT, bool INV>
+__device__ __forceinline__ void fft_tile(double2 (&x)[16], double2 *lds,
+                                         const double2 *__restrict__ tw, int tid) {
+    constexpr int n16 = LOGN / 4, rem = LOGN % 4;
+    constexpr int npass = n16 + (rem >= 2 ? 1 : 0) + (rem & 1);
+    static_assert(n16 >= 1 && n16 <= 2, "tile transform: 16 <= n <= 2048");
+    // the stride Ns of each pass is a compile-time constant: LDS addresses become one base
+    // register plus immediate offsets
+    tile_r16<LOGN, W, NT, INV, true, npass == 1, 1>(x, lds, tw, tid);
+    if constexpr (n16 == 2) tile_r16<LOGN, W, NT, INV, false, npass == 2, 16>(x, lds, tw, tid);
+    if constexpr (rem >= 2)
+        tile_r4<LOGN, W, NT, INV, (rem & 1) == 0, (n16 == 2 ? 256 : 16)>(x, lds, tw, tid);
+    if constexpr (rem & 1) tile_r2_last<LOGN, W, NT, INV>(x, lds, tw, tid);
+}
+
+// Persistent form of the strided pass: one workgroup per CU walks tiles t, t + G, ... and
+// loads tile t + G into registers before transforming tile t, so the CU's memory pipe
+// stays busy during the transform (with one 128 KB tile per CU nothing else would overlap
+// them).  Needs the 256-VGPR budget of <= 512 lanes (radix-16 schedule) and no
+// vmcnt-tracked access between the prefetch and its use — the twiddle and k-space tables
+// are therefore copied to LDS once per workgroup (vector memory returns in order: a global
+// twiddle load would wait for the prefetch).
+template <int LOGN, int NT, int MODE, int W>
+__global__ __launch_bounds__(NT) void k_fft_strided_p(const double2 *__restrict__ src,
+                                                      double2 *__restrict__ dst, i64 s_ostride,
+                                                      i64 s_es, i64 d_ostride, i64 d_es, int nkb,
+                                                      i64 ntiles, i64 o_off,
+                                                      const double2 *__restrict__ tw,
+                                                      KspaceParams P) {
+    // plain pencils only (element m at base + m*es): point f = tid + r*NT of the tile is
+    // pencil tid % W, element tid / W + r*(NT/W), i.e. a per-lane 32-bit offset on top of a
+    // wave-uniform base per r — no per-element 64-bit address registers
+    constexpr int N = 1 << LOGN;
+    constexpr int TOT = N * W;
+    static_assert(TOT == 16 * NT && NT % W == 0, "persistent pass: 16 points per lane");
+    constexpr int PER = 16;
+    constexpr int MSTEP = NT / W;  // = N/16
+    extern __shared__ double2 lds_dyn[];
+    double2 *lds = lds_dyn;
+    double2 *twl = lds_dyn + TOT;                  // N twiddles
+    double *tabq = (double *)(lds_dyn + TOT + N);  // MODE 2: N doubles
+    const int tid = threadIdx.x;
+    const int nk = N / 2 + 1;
+    for (int i = tid; i < N; i += NT) {
+        twl[i] = tw[i];
+        if (MODE == 2) tabq[i] = P.tab_q[i];
+    }
+    const int wl = tid % W, ml = tid / W;
+    const unsigned voff_s = (unsigned)(ml * s_es + wl), voff_d = (unsigned)(ml * d_es + wl);
+    // staged tiles are held as native vectors (plain loads/stores the optimiser keeps in
+    // registers; arrays of the double2 class are copied with memcpy and end up in scratch)
+    d2 v[PER], u[PER];
+    auto load = [&](i64 t) {
+        const i64 o = t / nkb;
+        const int kk0 = (int)(t - o * nkb) * W;
+        const double2 *sbase = src + o * s_ostride + kk0;
+        // unconditional: pencils kk >= N/2+1 of the last tile lie in the row padding
+        // (nkb*W <= pad/2), are transformed as garbage and written back there — straight-line
+        // loads and stores let the compiler count them (vmcnt)
+#pragma unroll
+        for (int r = 0; r < PER; r++)
+            v[r] = ((const d2 *)(sbase + (i64)r * MSTEP * s_es))[voff_s];
+    };
+    auto store = [&](i64 t) {
+        const i64 o = t / nkb;
+        const int kk0 = (int)(t - o * nkb) * W;
+        double2 *dbase = dst + o * d_ostride + kk0;
+#pragma unroll
+        for (int r = 0; r < PER; r++) ((d2 *)(dbase + (i64)r * MSTEP * d_es))[voff_d] = u[r];
+    };
+    // Software pipeline per tile:  x <- v (tile t) | store u (results of the previous tile)
+    // | issue loads of the next tile into v | transform x | u <- x.
+    // The stores are issued BEFORE the prefetch loads so that, at the next tile's wait for
+    // v, everything older in the (in-order) vector memory queue is stores of the tile before —
+    // the wait counts only the loads and never drains fresh stores.
+    i64 tprev = -1;
+    i64 t = blockIdx.x;
+    if (t >= ntiles) return;
+    load(t);
+    __syncthreads();  // tables
+    for (; t < ntiles; t += gridDim.x) {
+        double2 x[16];
+#pragma unroll
+        for (int r = 0; r < PER; r++) x[r] = make_double2(v[r].x, v[r].y);
+        if (tprev >= 0) store(tprev);
+        // unconditional (the last tile of a workgroup re-reads its own input): every path
+        // into the next tile carries the same loads in flight
+        load(t + gridDim.x < ntiles ? t + gridDim.x : t);
+        const i64 o = t / nkb;
+        const int kk0 = (int)(t - o * nkb) * W;
+        if (MODE == 0 || MODE == 2) fft_tile<LOGN, W, NT, false>(x, lds, twl, tid);
+        if (MODE == 2) {
+            const int kkl = kk0 + wl;
+            if (kkl < nk) {
+                const int b = (int)(o + o_off);
+                const KspaceFixedQ F = kspace_fix_q(N, b, kkl, tabq[b], tabq[kkl]);
+                // the per-element table values do not depend on the tile: keep the optimiser
+                // from hoisting 16 x (q, ka^2, ...) out of the tile loop into registers it
+                // does not have (they would be spilled to scratch); re-reading LDS is cheap
+                int ml_t = ml;
+                asm volatile("" : "+v"(ml_t));
+#pragma unroll
+                for (int r = 0; r < PER; r++) {
+                    int a = ml_t + r * MSTEP;
+                    double fac = kspace_factor_q(P, F, N, a, tabq[a]);
+                    x[r] = make_double2(x[r].x * fac, x[r].y * fac);
+                    // keep the 16 factor evaluations from being interleaved: their
+                    // temporaries on top of x and the staged v would spill
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (MODE == 1 || MODE == 2) fft_tile<LOGN, W, NT, true>(x, lds, twl, tid);
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            u[r].x = x[r].x;
+            u[r].y = x[r].y;
+        }
+        tprev = t;
+    }
+    store(tprev);
 }
 
 // ---------------------------------------------------------------------------
@@ -311,16 +715,53 @@ static int run_z(cg_ctx *c, bool inverse) {
     return 0;
 }
 
-template <int LOGN, int MODE, int W>
-static int run_strided_w(cg_ctx *c, const double2 *src, double2 *dst, PencilMap smap,
+template <int LOGN, int MODE, int W, bool R16>
+static int run_strided_r(cg_ctx *c, const double2 *src, double2 *dst, PencilMap smap,
                          PencilMap dmap, i64 nouter, i64 o_off, const KspaceParams &P) {
     constexpr int N = 1 << LOGN;
-    // lanes: N*W/8 points per lane (two radix-4 butterflies per pass), 64..1024
-    constexpr int NTW = N * W / 8;
+    // lanes: radix 4: N*W/8 (two butterflies per lane and pass); radix 16: N*W/16 (one);
+    // 64..1024
+    constexpr int NTW = N * W / (R16 ? 16 : 8);
     constexpr int NT = NTW < 64 ? 64 : (NTW > 1024 ? 1024 : NTW);
     const int nkb = (int)((c->N / 2 + 1 + W - 1) / W);
     size_t lds = sizeof(double2) * N * W;
-    auto kern = k_fft_strided<LOGN, NT, MODE, W>;
+    static int persist = -1, ncu = 0;
+    if (persist < 0) {
+        const char *env = getenv("CONCEPT_GPU_FFT_PERSIST");
+        persist = env ? atoi(env) : 1;
+        hipDeviceProp_t prop;
+        CG_HIP(hipGetDeviceProperties(&prop, c->p.device));
+        ncu = prop.multiProcessorCount;
+    }
+    const i64 ntiles = nouter * nkb;
+    // persistent form: tables in LDS on top of the tile; only where that fits the 160 KB
+    // and pays (many tiles per CU)
+    constexpr size_t lds_p = sizeof(double2) * N * W + sizeof(double2) * N +
+                             (MODE == 2 ? sizeof(double) * N : 0);
+    // per-lane offsets are 32-bit byte offsets: (NT/W) pencil points must span < 4 GB
+    constexpr bool can_persist = R16 && LOGN <= 10 && N * W == 16 * NT && NT % W == 0 &&
+                                 lds_p <= 160 * 1024;
+    if constexpr (can_persist) {
+        if (persist && ntiles >= 4 * (i64)ncu && smap.sh == 31 && dmap.sh == 31) {
+            auto kern = k_fft_strided_p<LOGN, NT, MODE, W>;
+            static bool attr_set_p = false;
+            if (!attr_set_p && lds_p > 64 * 1024) {
+                CG_HIP(hipFuncSetAttribute((const void *)kern,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+                attr_set_p = true;
+            }
+            // workgroups per CU the LDS footprint allows
+            int per_cu = (int)((160 * 1024) / lds_p);
+            if (per_cu < 1) per_cu = 1;
+            if (per_cu > 4) per_cu = 4;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(ncu * per_cu)), dim3(NT), lds_p, c->stream,
+                               src, dst, smap.ostride, smap.es, dmap.ostride, dmap.es, nkb,
+                               ntiles, o_off, (const double2 *)c->fft_tw, P);
+            CG_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    auto kern = k_fft_strided<LOGN, NT, MODE, W, R16>;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         CG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -331,6 +772,21 @@ static int run_strided_w(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
                        smap, dmap, nkb, o_off, (const double2 *)c->fft_tw, P);
     CG_LAUNCH_CHECK();
     return 0;
+}
+
+// Radix schedule of the in-LDS transform: CONCEPT_GPU_FFT_RADIX = 4 | 16 for A/B.
+template <int LOGN, int MODE, int W>
+static int run_strided_w(cg_ctx *c, const double2 *src, double2 *dst, PencilMap smap,
+                         PencilMap dmap, i64 nouter, i64 o_off, const KspaceParams &P) {
+    static int radix = 0;
+    if (!radix) {
+        const char *env = getenv("CONCEPT_GPU_FFT_RADIX");
+        radix = env ? atoi(env) : 16;
+        if (radix != 4 && radix != 16) radix = 16;
+    }
+    if (radix == 16)
+        return run_strided_r<LOGN, MODE, W, true>(c, src, dst, smap, dmap, nouter, o_off, P);
+    return run_strided_r<LOGN, MODE, W, false>(c, src, dst, smap, dmap, nouter, o_off, P);
 }
 
 // W adjacent kk per workgroup.  Measured at 1024^3 (ms per y pass / fused x pass):
@@ -435,19 +891,19 @@ bool cgk_fft_supported(i64 N) { return N >= 16 && N <= 2048 && (N & (N - 1)) == 
     return 1;
 
 int cgk_fft(cg_ctx *c, int what, int deconv_order, double C, int long_range, double E) {
-    KspaceParams P{c->ktab_n, c->ktab_s, deconv_order, long_range, C, E};
+    KspaceParams P{c->ktab_n, c->ktab_s, c->ktab_q, deconv_order, long_range, C, E};
     CG_FFT_DISPATCH(fft3d, c, what, P)
 }
 int cgk_fft_dist_forward(cg_ctx *c, double *send_buf) {
-    KspaceParams P{c->ktab_n, c->ktab_s, 0, 0, 0.0, 0.0};
+    KspaceParams P{c->ktab_n, c->ktab_s, c->ktab_q, 0, 0, 0.0, 0.0};
     CG_FFT_DISPATCH(fft_dist, c, 0, (double2 *)send_buf, P)
 }
 int cgk_fft_dist_xsolve(cg_ctx *c, double *buf, int deconv_order, double C, int long_range,
                         double E) {
-    KspaceParams P{c->ktab_n, c->ktab_s, deconv_order, long_range, C, E};
+    KspaceParams P{c->ktab_n, c->ktab_s, c->ktab_q, deconv_order, long_range, C, E};
     CG_FFT_DISPATCH(fft_dist, c, 2, (double2 *)buf, P)
 }
 int cgk_fft_dist_backward(cg_ctx *c, const double *recv_buf) {
-    KspaceParams P{c->ktab_n, c->ktab_s, 0, 0, 0.0, 0.0};
+    KspaceParams P{c->ktab_n, c->ktab_s, c->ktab_q, 0, 0, 0.0, 0.0};
     CG_FFT_DISPATCH(fft_dist, c, 1, (double2 *)recv_buf, P)
 }

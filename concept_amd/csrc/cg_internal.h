@@ -93,7 +93,7 @@ struct cg_ctx {
     i64 mesh_doubles = 0;
     double *fetch_tmp = nullptr; // lazily allocated, for CG_FETCH_MESH_FOURIER
     // k-space tables: numerator n(k) and denominator sin(n(k)) by array index
-    double *ktab_n = nullptr, *ktab_s = nullptr;
+    double *ktab_n = nullptr, *ktab_s = nullptr, *ktab_q = nullptr;
     // rocFFT
     rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr;
     rocfft_execution_info info_fwd = nullptr, info_bwd = nullptr;

@@ -9,6 +9,7 @@
 struct KspaceParams {
     const double *tab_n;  // n(k) = k*R[pi/gridsize] + machine_eps by array index
     const double *tab_s;  // sin(n(k))
+    const double *tab_q;  // n(k)/sin(n(k)) (may be null where only kspace_factor is used)
     int deconv_order;
     int long_range;
     double C;  // -boxsize**2*G_Newton/pi
@@ -45,29 +46,32 @@ __device__ __forceinline__ double kspace_factor(const KspaceParams &P, i64 N, i6
 // per-mode arithmetic is unchanged (n_a*n_b, s_a*s_b, (.*n_kk)/(.*s_kk), **order, C/k2 ...).
 struct KspaceFixed {
     double n_b, s_b, n_kk, s_kk;
-    i64 kb2_kk2;   // kb*kb (ka*ka is added per mode: kab2 = kb*kb + ka*ka as in the reference)
-    i64 kb2;
+    i64 kb2;       // kb*kb (ka*ka is added per mode: kab2 = kb*kb + ka*ka as in the reference)
     i64 kk2;
     bool dead;     // b or kk on a Nyquist plane
     bool b0kk0;    // kb == 0 and kk == 0 (origin when ka == 0 too)
 };
-__device__ __forceinline__ KspaceFixed kspace_fix(const KspaceParams &P, i64 N, i64 b, i64 kk) {
+__device__ __forceinline__ KspaceFixed kspace_fix(i64 N, i64 b, i64 kk, double n_b, double s_b,
+                                                  double n_kk, double s_kk) {
     const i64 nyq = N / 2;
     KspaceFixed F;
     F.dead = (b == nyq) || (kk == nyq);
     i64 kb = b - (b >= nyq ? N : 0);
     F.kb2 = kb * kb;
     F.kk2 = kk * kk;
-    F.kb2_kk2 = 0;
     F.b0kk0 = (kb == 0) && (kk == 0);
-    F.n_b = P.tab_n[b];
-    F.s_b = P.tab_s[b];
-    F.n_kk = P.tab_n[kk];
-    F.s_kk = P.tab_s[kk];
+    F.n_b = n_b;
+    F.s_b = s_b;
+    F.n_kk = n_kk;
+    F.s_kk = s_kk;
     return F;
 }
+__device__ __forceinline__ KspaceFixed kspace_fix(const KspaceParams &P, i64 N, i64 b, i64 kk) {
+    return kspace_fix(N, b, kk, P.tab_n[b], P.tab_s[b], P.tab_n[kk], P.tab_s[kk]);
+}
+// n_a = tab_n[a], s_a = tab_s[a] are fetched by the caller (global or LDS copy of the tables)
 __device__ __forceinline__ double kspace_factor_fixed(const KspaceParams &P, const KspaceFixed &F,
-                                                      i64 N, i64 a) {
+                                                      i64 N, i64 a, double n_a, double s_a) {
 #pragma clang fp contract(off)
     const i64 nyq = N / 2;
     if (F.dead || a == nyq) return 0;
@@ -76,13 +80,51 @@ __device__ __forceinline__ double kspace_factor_fixed(const KspaceParams &P, con
     if (F.b0kk0 && ka == 0) return 0;
     double factor = 1;
     if (P.deconv_order) {
-        double dab_n = P.tab_n[a] * F.n_b;  // mesh.py:2797
-        double dab_d = P.tab_s[a] * F.s_b;  // mesh.py:2798
+        double dab_n = n_a * F.n_b;  // mesh.py:2797
+        double dab_d = s_a * F.s_b;  // mesh.py:2798
         factor = (dab_n * F.n_kk) / (dab_d * F.s_kk);  // mesh.py:2850-2853
         double f = factor;
         for (int o = 1; o < P.deconv_order; o++) factor *= f;
     }
     i64 k2 = kab2 + F.kk2;
+    double pk = P.C / (double)k2;
+    if (P.long_range) pk = pk * exp((double)k2 * P.E);
+    return factor * pk;
+}
+
+// The factor for the persistent fused pass: same quantity, arranged for throughput — the
+// sinc ratio per dimension comes from the table q = n/s, so the mode costs one division
+// (C/k2) instead of two, and the mode numbers are 32-bit (N <= 2048: k2 < 2^24).  Differs
+// from kspace_factor by rounding only (the three ratios are rounded separately, ~3 ulp);
+// the Poisson solve is a floating-point path (FFT rounding already differs from FFTW's),
+// tested against the oracle to the tolerance stated in tests/test_gpu_pm.py.
+struct KspaceFixedQ {
+    double q_bkk;  // q_b*q_kk
+    int kb2_kk2;   // kb*kb + kk*kk
+    bool dead;     // b or kk on a Nyquist plane
+};
+__device__ __forceinline__ KspaceFixedQ kspace_fix_q(int N, int b, int kk, double q_b,
+                                                     double q_kk) {
+    const int nyq = N / 2;
+    KspaceFixedQ F;
+    F.dead = (b == nyq) || (kk == nyq);
+    int kb = b - (b >= nyq ? N : 0);
+    F.kb2_kk2 = kb * kb + kk * kk;
+    F.q_bkk = q_b * q_kk;
+    return F;
+}
+__device__ __forceinline__ double kspace_factor_q(const KspaceParams &P, const KspaceFixedQ &F,
+                                                  int N, int a, double q_a) {
+    const int nyq = N / 2;
+    int ka = a - (a >= nyq ? N : 0);
+    int k2 = F.kb2_kk2 + ka * ka;
+    if (F.dead || a == nyq || k2 == 0) return 0;  // nullify_modes('nyquist'), ('origin')
+    double factor = 1;
+    if (P.deconv_order) {
+        double f = q_a * F.q_bkk;
+        factor = f;
+        for (int o = 1; o < P.deconv_order; o++) factor *= f;
+    }
     double pk = P.C / (double)k2;
     if (P.long_range) pk = pk * exp((double)k2 * P.E);
     return factor * pk;

@@ -114,7 +114,7 @@ int cgk_kspace(cg_ctx *c, int deconv_order, double C, int long_range, double E) 
     int block = c->N / 2 + 1 >= 256 ? 256 : (c->N / 2 + 1 > 64 ? 128 : 64);
     hipLaunchKernelGGL(k_kspace, dim3((unsigned)rows), dim3(block), 0, c->stream,
                        (double2 *)c->mesh, c->N, c->pad / 2,
-                       KspaceParams{c->ktab_n, c->ktab_s, deconv_order, long_range, C, E});
+                       KspaceParams{c->ktab_n, c->ktab_s, c->ktab_q, deconv_order, long_range, C, E});
     CG_LAUNCH_CHECK();
     return 0;
 }
