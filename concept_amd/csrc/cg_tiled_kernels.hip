@@ -25,20 +25,24 @@
         }                                                                                     \
     } while (0)
 
+// 32-bit cell arithmetic: x is positive and < gridsize + 2*nghosts + 1 (positions are in
+// [0, boxsize)), so the reference's truncation to Py_ssize_t equals truncation to int —
+// one v_cvt_i32_f64 instead of the ~15-instruction double -> int64 sequence, and every
+// index below (N <= 2048 and change) stays in 32-bit registers.
 struct Cic1 {
-    i64 index;
+    int index;
     double w0, w1;
 };
 __device__ __forceinline__ Cic1 cic1(double pos, double off, double scale) {
     double x = (pos - off) * scale;
     Cic1 r;
-    r.index = (i64)x;
+    r.index = (int)x;
     double dist = x - (double)r.index;
     r.w0 = 1 - dist;
     r.w1 = dist;
     return r;
 }
-__device__ __forceinline__ i64 wrap(i64 a, i64 n) {
+__device__ __forceinline__ int wrap(int a, int n) {
     a = a < 0 ? a + n : a;
     return a >= n ? a - n : a;
 }
@@ -76,7 +80,8 @@ __global__ __launch_bounds__(512) void k_deposit_cic_pull(
     __shared__ unsigned seg_beg[64], seg_end_prefix[65];
     const unsigned tile = tile_for_block(blockIdx.x, nblocks);
     const int tc = tile % nt, tb = (tile / nt) % nt, ta = tile / (nt * nt);
-    const i64 T0a = xm.x0 + (i64)ta * T, T0b = (i64)tb * T, T0c = (i64)tc * T;
+    const int Ni = (int)N;
+    const int T0a = (int)xm.x0 + ta * T, T0b = tb * T, T0c = tc * T;
     for (int idx = threadIdx.x; idx < NL; idx += 512) lds[idx] = 0;
     if (threadIdx.x < 64) {
         // segment (d, f): bucket f of the neighbour d steps back
@@ -117,11 +122,11 @@ __global__ __launch_bounds__(512) void k_deposit_cic_pull(
         double wi[2] = {cx.w0 * contribution, cx.w1 * contribution};
         double wy[2] = {cy.w0, cy.w1}, wz[2] = {cz.w0, cz.w1};
         // lower cell relative to this tile: -1 .. T-1 (periodic)
-        i64 la = wrap(cx.index - g, N) - T0a, lb = wrap(cy.index - g, N) - T0b,
-            lc = wrap(cz.index - g, N) - T0c;
-        la = (xm.periodic && la >= T) ? la - N : la;
-        lb = lb >= T ? lb - N : lb;
-        lc = lc >= T ? lc - N : lc;
+        int la = wrap(cx.index - g, Ni) - T0a, lb = wrap(cy.index - g, Ni) - T0b,
+            lc = wrap(cz.index - g, Ni) - T0c;
+        la = (xm.periodic && la >= T) ? la - Ni : la;
+        lb = lb >= T ? lb - Ni : lb;
+        lc = lc >= T ? lc - Ni : lc;
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(512) void k_deposit_cic_pull(
                 double wij = wi[i] * wy[j];
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
-                    i64 a = la + i, b = lb + j, c = lc + k;
+                    int a = la + i, b = lb + j, c = lc + k;
                     if (a >= 0 && a < T && b >= 0 && b < T && c >= 0 && c < T)
                         atomicAdd(&lds[(a * T + b) * T + c], wij * wz[k]);
                 }
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(512) void k_deposit_cic_pull(
     for (int idx = threadIdx.x; idx < NL; idx += 512) {
         int c = idx % T, b = (idx / T) % T, a = idx / (T * T);
         if (a >= a_end) break;
-        i64 layer = xm.periodic ? (T0a + a) : ((i64)ta * T + a + xm.G);
+        i64 layer = xm.periodic ? (i64)(T0a + a) : ((i64)ta * T + a + xm.G);
         double *dst = mesh + (layer * N + (T0b + b)) * pad + (T0c + c);
         if (ACCUMULATE) *dst += lds[idx];  // cells are exclusively owned: no atomics needed
         else *dst = lds[idx];
@@ -209,39 +214,63 @@ struct PrepArgs {
 };
 
 template <int ORDER, int T, bool PREP>
-__global__ __launch_bounds__(512) void k_gather_kick_tiled(
+__global__ __launch_bounds__(512, 4) void k_gather_kick_tiled(
     const double *__restrict__ pos, double *__restrict__ mom,
     const unsigned *__restrict__ tile_offset, const double *__restrict__ mesh, i64 N, i64 pad,
     int g, int nt, unsigned ntiles, XMap xm, CicGeom geo, double c1, double c2, double factor,
     PrepArgs prep) {
     constexpr int H = ORDER / 2;
     constexpr int E = T + 1 + 2 * H;  // cells [T0-H, T0+T+H]
-    constexpr int NL = E * E * E;
     extern __shared__ double lds[];
     const unsigned tile = tile_for_block(blockIdx.x, ntiles);
     const i64 beg = tile_offset[8 * tile], end = tile_offset[8 * tile + 8];
     if (beg == end) return;  // uniform for the workgroup
     const int tc = tile % nt, tb = (tile / nt) % nt, ta = tile / (nt * nt);
-    const i64 T0a = xm.x0 + (i64)ta * T, T0b = (i64)tb * T, T0c = (i64)tc * T;
+    const int Ni = (int)N;
+    const int T0a = (int)xm.x0 + ta * T, T0b = tb * T, T0c = tc * T;
     {
-        // stage the potential tile + stencil halo: all loads of a lane issued before
-        // the first LDS store, so they overlap instead of paying HBM latency serially
-        constexpr int PER = (NL + 511) / 512;
-        double v[PER];
+        // Stage the potential tile + stencil halo.  Wave w takes the planes a = w, w+8, ...
+        // of the E^3 block: the layer index and its 64-bit row base are wave-uniform
+        // (scalar unit), a lane's (row, column) offsets inside a plane are 32-bit and the
+        // same for every plane, so a load costs one instruction (scalar base + lane
+        // offset) instead of the ~80 of per-element 64-bit index arithmetic this loop
+        // used to spend — that arithmetic, not the stencil, was two thirds of the kernel's
+        // VALU work (rocprofv3: 1060 VALU instructions per particle, VALUBusy 78 %).
+        // All loads of a lane are issued before its first LDS store.
+        constexpr int PL = E * E;                // points per plane
+        constexpr int NP = (PL + 63) / 64;       // 64-lane passes per plane
+        constexpr int NA = (E + 7) / 8;          // planes per wave
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int b0 = T0b - H, c0 = T0c - H;
+        unsigned off[NP];  // gj*pad + gk
 #pragma unroll
-        for (int r = 0; r < PER; r++) {
-            int idx = threadIdx.x + r * 512;
-            if (idx < NL) {
-                int c = idx % E, b = (idx / E) % E, a = idx / (E * E);
-                i64 gi = cg_xlayer(xm, T0a - H + a, N), gj = wrap(T0b - H + b, N),
-                    gk = wrap(T0c - H + c, N);
-                v[r] = mesh[(gi * N + gj) * pad + gk];
+        for (int q = 0; q < NP; q++) {
+            int i2 = lane + 64 * q;
+            int b = i2 / E, c = i2 - b * E;
+            int gj = b0 + b, gk = c0 + c;
+            gj += (gj < 0 ? Ni : 0) - (gj >= Ni ? Ni : 0);
+            gk += (gk < 0 ? Ni : 0) - (gk >= Ni ? Ni : 0);
+            off[q] = (unsigned)gj * (unsigned)pad + (unsigned)gk;
+        }
+        double v[NA][NP];
+#pragma unroll
+        for (int s = 0; s < NA; s++) {
+            const int a = wave + 8 * s;  // wave-uniform
+            if (a < E) {
+                const double *plane = mesh + cg_xlayer(xm, (i64)(T0a - H + a), N) * N * pad;
+#pragma unroll
+                for (int q = 0; q < NP; q++)
+                    if (PL % 64 == 0 || lane + 64 * q < PL) v[s][q] = plane[off[q]];
             }
         }
 #pragma unroll
-        for (int r = 0; r < PER; r++) {
-            int idx = threadIdx.x + r * 512;
-            if (idx < NL) lds[idx] = v[r];
+        for (int s = 0; s < NA; s++) {
+            const int a = wave + 8 * s;
+            if (a < E) {
+#pragma unroll
+                for (int q = 0; q < NP; q++)
+                    if (PL % 64 == 0 || lane + 64 * q < PL) lds[a * PL + lane + 64 * q] = v[s][q];
+            }
         }
     }
     __syncthreads();
@@ -254,8 +283,8 @@ __global__ __launch_bounds__(512) void k_gather_kick_tiled(
         Cic1 cx = cic1(px, geo.off[0], geo.scale);
         Cic1 cy = cic1(py, geo.off[1], geo.scale);
         Cic1 cz = cic1(pz, geo.off[2], geo.scale);
-        i64 ga = wrap(cx.index - g, N), gb = wrap(cy.index - g, N), gc = wrap(cz.index - g, N);
-        i64 la = ga - T0a, lb = gb - T0b, lc = gc - T0c;
+        int ga = wrap(cx.index - g, Ni), gb = wrap(cy.index - g, Ni), gc = wrap(cz.index - g, Ni);
+        int la = ga - T0a, lb = gb - T0b, lc = gc - T0c;
         double wx[2] = {cx.w0, cx.w1}, wy[2] = {cy.w0, cy.w1}, wz[2] = {cz.w0, cz.w1};
         double val[3] = {0, 0, 0};
         if (la >= 0 && la < T && lb >= 0 && lb < T && lc >= 0 && lc < T) {
@@ -285,9 +314,9 @@ __global__ __launch_bounds__(512) void k_gather_kick_tiled(
             i64 ix[W], iy[W], iz[W];
 #pragma unroll
             for (int s = 0; s < W; s++) {
-                ix[s] = cg_xlayer(xm, ga - H + s, N) * N * pad;
-                iy[s] = wrap(gb - H + s, N) * pad;
-                iz[s] = wrap(gc - H + s, N);
+                ix[s] = cg_xlayer(xm, (i64)(ga - H + s), N) * N * pad;
+                iy[s] = (i64)wrap(gb - H + s, Ni) * pad;
+                iz[s] = wrap(gc - H + s, Ni);
             }
 #pragma unroll
             for (int i = 0; i < 2; i++)

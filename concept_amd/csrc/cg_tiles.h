@@ -18,9 +18,12 @@ __device__ __forceinline__ double ref_mod(double x, double L) {
 }
 
 
-__device__ __forceinline__ i64 lower_cell(double pos, double off, double scale, int g, i64 N) {
+// 32-bit: x is positive and < gridsize + 2*nghosts + 1, so truncating to int equals the
+// reference's truncation to Py_ssize_t (one v_cvt_i32_f64 instead of the double -> int64
+// sequence)
+__device__ __forceinline__ int lower_cell(double pos, double off, double scale, int g, int N) {
     double x = (pos - off) * scale;
-    i64 a = (i64)x - g;
+    int a = (int)x - g;
     a = a < 0 ? a + N : a;
     return a >= N ? a - N : a;
 }
@@ -31,15 +34,17 @@ __device__ __forceinline__ i64 lower_cell(double pos, double off, double scale, 
 constexpr unsigned kNoTile = 0xffffffffu;
 __device__ __forceinline__ unsigned tile_of(double x, double y, double z, const CicGeom &geo,
                                             int g, i64 N, const TileGeom &t, i64 x0) {
-    i64 cx = lower_cell(x, geo.off[0], geo.scale, g, N) - x0;  // local layer of this domain
-    if (cx < 0 || cx >= (i64)t.ntx * t.tx) return kNoTile;      // not owned here
+    const int Ni = (int)N;
+    int cx = lower_cell(x, geo.off[0], geo.scale, g, Ni) - (int)x0;  // local layer of this domain
+    if (cx < 0 || cx >= t.ntx * t.tx) return kNoTile;                 // not owned here
     unsigned ca = (unsigned)cx;
-    unsigned cb = (unsigned)lower_cell(y, geo.off[1], geo.scale, g, N);
-    unsigned cc = (unsigned)lower_cell(z, geo.off[2], geo.scale, g, N);
-    unsigned T = (unsigned)t.tx;
-    unsigned a = ca / T, b = cb / T, c = cc / T;
-    unsigned f = ((ca - a * T == T - 1) ? 4u : 0u) | ((cb - b * T == T - 1) ? 2u : 0u) |
-                 ((cc - c * T == T - 1) ? 1u : 0u);
+    unsigned cb = (unsigned)lower_cell(y, geo.off[1], geo.scale, g, Ni);
+    unsigned cc = (unsigned)lower_cell(z, geo.off[2], geo.scale, g, Ni);
+    // the tile extent is a power of two (cg_create): shifts and masks, not divisions
+    const unsigned sh = (unsigned)(__ffs(t.tx) - 1), last = (unsigned)t.tx - 1u;
+    unsigned a = ca >> sh, b = cb >> sh, c = cc >> sh;
+    unsigned f = (((ca & last) == last) ? 4u : 0u) | (((cb & last) == last) ? 2u : 0u) |
+                 (((cc & last) == last) ? 1u : 0u);
     return ((a * t.nty + b) * t.ntz + c) * 8u + f;
 }
 
