@@ -367,11 +367,11 @@ def main():
     traffic = None
     try:  # HBM bytes per launch from the committed PMC run of this same command
         pmc = json.load(open(os.path.join(REPO, 'profiles', 'r01_pmc_hbm_traffic.json')))
-        key = {'fft_x_fused_kspace': 'k_fft_strided<10,512,2>',
-               'gather_kick': 'k_gather_kick_tiled<2,16>', 'drift': 'k_drift',
+        key = {'fft_x_fused_kspace': 'k_fft_strided_p<10,512,2,8>',
+               'gather_kick': 'k_gather_kick_tiled<2,16,true>', 'drift': 'k_drift',
                'deposit': 'k_deposit_cic_pull<16,false>',
-               'fft_y_forward': 'k_fft_strided<10,512,0>',
-               'fft_y_backward': 'k_fft_strided<10,512,1>',
+               'fft_y_forward': 'k_fft_strided_p<10,512,0,8>',
+               'fft_y_backward': 'k_fft_strided_p<10,512,1,8>',
                'fft_z_forward': 'k_fft_z_forward<10,128>',
                'fft_z_backward': 'k_fft_z_backward<10,128>'}.get(dom)
         if name == 'ns_256M_1024' and key:
