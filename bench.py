@@ -131,6 +131,11 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world):
     elapsed = float(t.item())
     cnt = torch.tensor([parts.n], dtype=torch.int64, device=dev)
     dist.all_reduce(cnt)
+    # RCCL prints its version banner through C stdio; push it out (and shut the communicator
+    # down) before the result so that the JSON line is the last line of stdout
+    dist.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
     if rank != 0:
         return
     total = int(cnt.item())
@@ -183,8 +188,14 @@ def main():
     if backend != 'nccl':
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # CONCEPT_BENCH_FORCE_DIST=1: run the sharded code path (RCCL init, collectives) with a
+    # single domain too — a smoke test of the N>1 path on a 1-GPU box
+    force_dist = os.environ.get('CONCEPT_BENCH_FORCE_DIST') == '1'
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
@@ -195,7 +206,7 @@ def main():
     n_p, N = WORKLOADS[name]
     L = float(N)  # boxsize in grid units (synthetic)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or force_dist:
         return main_distributed(args, name, n_p, N, L, dev, rank, world)
     mesh = PotentialMesh(N, L, nghosts=2)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)

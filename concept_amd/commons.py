@@ -148,6 +148,24 @@ def load_params(source=None, **overrides):
     if isinstance(diff, dict):
         for name, d in diff.items():
             p.potential_options['differentiation'][name] = _method_dict(d, 2, 4)
+    # component-level (upstream, downstream) grid sizes: every key of
+    # potential_options['gridsize'] other than 'global' selects components
+    # (commons.py:3095-3207; looked up with is_selected in species.py:1147-1160)
+    gs = po.get('gridsize')
+    if isinstance(gs, dict) and 'global' in gs:
+        for sel, d in gs.items():
+            if sel == 'global':
+                continue
+            entry = {}
+            if isinstance(d, dict):
+                for force, dm in d.items():
+                    if isinstance(dm, dict):
+                        entry[force] = dict(dm)
+                    else:
+                        entry[force] = {'pm': dm, 'p3m': dm}
+            else:
+                entry['gravity'] = {'pm': d, 'p3m': d}
+            p.potential_options['gridsize'][sel] = entry
     # short-range parameters (strings are evaluated per use with the grid size known)
     sr = {'scale': '1.25*boxsize/gridsize', 'range': '4.5*scale', 'tilesize': 'range',
           'subtiling': 'automatic', 'tablesize': 2**12}
@@ -176,6 +194,28 @@ def load_params(source=None, **overrides):
     p.user = user
     params = p
     return p
+
+
+def is_selected(component, d, accumulate=False, default=None):
+    """Look a component up in a selection dict (commons.py:5471-5600): keys may be
+    'default', 'all', the representation, the species, or the component's name —
+    later ones take precedence; accumulate = True merges every match (dicts are
+    merged in that order)."""
+    lowered = {(k.lower() if isinstance(k, str) else k): v for k, v in d.items()}
+    species = component.species.lower()
+    keys = ['default', 'all', component.representation.lower()]
+    keys += [s_ for s_ in species.split('+') if s_ != species] + [species, component.name.lower()]
+    found = [lowered[k] for k in keys if k in lowered]
+    if not found:
+        return default
+    if not accumulate:
+        return found[-1]
+    if all(isinstance(v, dict) for v in found):
+        merged = {}
+        for v in found:
+            merged.update(v)
+        return merged
+    return found
 
 
 def resolve_shortrange(p, gridsize):

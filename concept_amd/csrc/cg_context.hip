@@ -251,6 +251,60 @@ extern "C" int cg_deposit_cic(cg_ctx *c, const double *pos, int64_t n, double co
     return cgk_deposit_cic(c, pos, n, contribution);
 }
 
+// ---- general particle_mesh() pieces (cg_general.hip) ----
+#define CG_SINGLE(c, name) \
+    CG_CHECK((c)->p.nprocs == 1, name ": single-domain entry point (the general mesh path is not sharded)")
+
+extern "C" int cg_fluid_add(cg_ctx *c, const double *fluid, double factor, int op_add) {
+    CG_CHECK(c && fluid, "cg_fluid_add: null argument");
+    CG_SINGLE(c, "cg_fluid_add");
+    return cgk_fluid_add(c, fluid, factor, op_add ? 1 : 0);
+}
+
+extern "C" int cg_fourier_nullify_nyquist(cg_ctx *c) {
+    CG_CHECK(c, "cg_fourier_nullify_nyquist: null context");
+    CG_SINGLE(c, "cg_fourier_nullify_nyquist");
+    return cgk_nullify_nyquist(c);
+}
+
+extern "C" int cg_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
+                                  const double *shift, int diff_dim, int op_add) {
+    CG_CHECK(onto && from, "cg_fourier_operate: null context");
+    CG_SINGLE(onto, "cg_fourier_operate");
+    CG_CHECK(onto->N == from->N && onto->pad == from->pad,
+             "cg_fourier_operate: grid sizes %lld and %lld differ (different sizes go through "
+             "cg_copy_modes)", (long long)from->N, (long long)onto->N);
+    CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_fourier_operate: deconv_order %d",
+             deconv_order);
+    CG_CHECK(nlattice == 1 || nlattice == 2 || nlattice == 4,
+             "cg_fourier_operate: nlattice %d not in {1, 2, 4}", nlattice);
+    CG_CHECK(diff_dim >= -1 && diff_dim < 3,
+             "fourier_operate() called with diff_dim = %d not in {-1, 0, 1, 2}", diff_dim);
+    return cgk_fourier_operate(onto, from, deconv_order, nlattice, shift, diff_dim,
+                               op_add ? 1 : 0);
+}
+
+extern "C" int cg_mesh_copy(cg_ctx *dst, cg_ctx *src) {
+    CG_CHECK(dst && src, "cg_mesh_copy: null context");
+    CG_CHECK(dst->N == src->N && dst->mesh_doubles == src->mesh_doubles,
+             "cg_mesh_copy: the two meshes differ in shape");
+    CG_HIP(hipMemcpyAsync(dst->mesh, src->mesh, sizeof(double) * src->mesh_doubles,
+                          hipMemcpyDeviceToDevice, dst->stream));
+    return 0;
+}
+
+extern "C" int cg_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int dim,
+                             int diff_order, double minus_dt, double inv_c2) {
+    CG_CHECK(c && J && rho && P, "cg_fluid_kick: null argument");
+    CG_SINGLE(c, "cg_fluid_kick");
+    CG_CHECK(dim >= 0 && dim < 3,
+             "apply_particle_mesh_force() called with dim = %d not in {0, 1, 2}", dim);
+    CG_CHECK(diff_order == 2 || diff_order == 4,
+             "cg_fluid_kick: differentiation order %d (2 and 4 are built; nghosts = 2 "
+             "admits no higher symmetric order)", diff_order);
+    return cgk_fluid_kick(c, J, rho, P, dim, diff_order, minus_dt, inv_c2);
+}
+
 extern "C" int cg_poisson_forward(cg_ctx *c, int deconv_order, double C, int long_range, double E,
                                   int apply_kernel) {
     CG_CHECK(c, "cg_poisson_forward: null context");

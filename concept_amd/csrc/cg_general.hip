@@ -1,0 +1,214 @@
+// cg_general.hip — the pieces of the GENERAL particle_mesh() that the fused
+// fast path does not need: several suppliers and
+// receivers, particles and fluids, added together in Fourier space.
+//   k_fluid_add         add_fluid_to_grid                 mesh.py:1685-1753
+//   k_nullify_nyquist   nullify_modes('nyquist')          mesh.py:3591-3622
+//   k_fourier_operate   fourier_operate / copy_modes      mesh.py:3327-3400, 1038-1092
+//                       (equal grid sizes) over fourier_loop   mesh.py:2615-2890
+//   k_fluid_kick        diff_domaingrid + the fluid branch of
+//                       apply_particle_mesh_force         mesh.py:4874-5030,
+//                                                         interactions.py:2388-2401
+// Fluid grids are double[N][N][N] (the reference's grid_noghosts order); the
+// mesh is double[N][N][pad] / complex[N][N][pad/2], un-transposed: the first
+// index is x (the reference's ki), the second y (kj).
+// Compiled with -ffp-contract=off; every expression keeps the reference's order.
+#include "cg_internal.h"
+
+#define CG_LAUNCH_CHECK()                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) {                                                               \
+            cg_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                           \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+__global__ __launch_bounds__(256) void k_fluid_add(double *__restrict__ mesh,
+                                                   const double *__restrict__ fluid, int N,
+                                                   i64 pad, double factor, int op_add) {
+    // one thread per (i, j, k-pair): rows of the fluid grid are contiguous
+    const i64 total = (i64)N * N * N;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (i64)gridDim.x * blockDim.x) {
+        i64 row = t / N;
+        int k = (int)(t - row * N);
+        double v = fluid[t];
+        if (factor != 1) v = v * factor;  // mesh.py:1737-1751
+        double *dst = mesh + row * pad + k;
+        if (op_add) *dst += v;
+        else *dst = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nullify_nyquist(double2 *__restrict__ mesh, int N,
+                                                         i64 cp) {
+    // complex[N][N][cp]: planes a == nyq, b == nyq, kk == nyq
+    const int nyq = N / 2;
+    const i64 rows = (i64)N * N;
+    for (i64 row = (i64)blockIdx.x; row < rows; row += gridDim.x) {
+        int a = (int)(row / N), b = (int)(row - (i64)a * N);
+        double2 *r = mesh + row * cp;
+        if (a == nyq || b == nyq) {
+            for (int kk = threadIdx.x; kk <= nyq; kk += blockDim.x) r[kk] = make_double2(0, 0);
+        } else if (threadIdx.x == 0) {
+            r[nyq] = make_double2(0, 0);
+        }
+    }
+}
+
+struct FourierOp {
+    const double *tab_n, *tab_s;
+    int deconv_order, nlattice, diff_dim, shifted, op_add, zero_nyquist;
+    double A, B, Cc;  // -2*pi/N*shift[d]
+    double k_fundamental, inv_lat;
+};
+
+__global__ __launch_bounds__(256) void k_fourier_operate(const double2 *__restrict__ from,
+                                                         double2 *__restrict__ onto, int N,
+                                                         i64 cp, FourierOp P) {
+#pragma clang fp contract(off)
+    const int nyq = N / 2;
+    const i64 rows = (i64)N * N;
+    for (i64 row = (i64)blockIdx.x; row < rows; row += gridDim.x) {
+        const int a = (int)(row / N), b = (int)(row - (i64)a * N);
+        const double2 *src = from + row * cp;
+        double2 *dst = onto + row * cp;
+        const bool dead_row = (a == nyq) || (b == nyq);
+        const int ka = a - (a >= nyq ? N : 0), kb = b - (b >= nyq ? N : 0);
+        double dab_n = 0, dab_d = 0;
+        if (P.deconv_order) {
+            dab_n = P.tab_n[a] * P.tab_n[b];  // mesh.py:2797-2798
+            dab_d = P.tab_s[a] * P.tab_s[b];
+        }
+        for (int kk = threadIdx.x; kk <= nyq; kk += blockDim.x) {
+            if (dead_row || kk == nyq) {
+                if (P.zero_nyquist) dst[kk] = make_double2(0, 0);
+                continue;
+            }
+            double factor = 1;
+            if (P.deconv_order) {
+                factor = (dab_n * P.tab_n[kk]) / (dab_d * P.tab_s[kk]);  // mesh.py:2850-2853
+                double f = factor;
+                for (int o = 1; o < P.deconv_order; o++) factor *= f;   // factor **= order
+            }
+            factor *= P.inv_lat;  // mesh.py:2856
+            double re = src[kk].x, im = src[kk].y;
+            if (P.shifted) {
+                double theta = ((double)ka * P.A + (double)kb * P.B) + (double)kk * P.Cc;
+                double c = cos(theta), s = sin(theta);
+                double re2 = re * c - im * s, im2 = re * s + im * c;  // mesh.py:3376-3379
+                re = re2;
+                im = im2;
+            }
+            if (P.diff_dim >= 0) {
+                int kl = P.diff_dim == 0 ? ka : (P.diff_dim == 1 ? kb : kk);
+                factor *= P.k_fundamental * (double)kl;  // mesh.py:3391-3392
+                double t = re;
+                re = -im;
+                im = t;
+            }
+            re *= factor;
+            im *= factor;
+            if (P.op_add) dst[kk] = make_double2(dst[kk].x + re, dst[kk].y + im);
+            else dst[kk] = make_double2(re, im);
+        }
+    }
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void k_fluid_kick(double *__restrict__ J,
+                                                    const double *__restrict__ rho,
+                                                    const double *__restrict__ P,
+                                                    const double *__restrict__ mesh, int N,
+                                                    i64 pad, int dim, double c1, double c2,
+                                                    double mdt, double inv_c2) {
+#pragma clang fp contract(off)
+    const i64 total = (i64)N * N * N;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (i64)gridDim.x * blockDim.x) {
+        i64 row = t / N;
+        int k = (int)(t - row * N);
+        int i = (int)(row / N), j = (int)(row - (i64)i * N);
+        auto phi = [&](int s) {
+            int ii = i, jj = j, kk = k;
+            if (dim == 0) ii = (i + s + N) % N;
+            else if (dim == 1) jj = (j + s + N) % N;
+            else kk = (k + s + N) % N;
+            return mesh[((i64)ii * N + jj) * pad + kk];
+        };
+        double g;
+        if (ORDER == 2) g = c1 * (phi(1) - phi(-1));                          // mesh.py:4967
+        else g = c1 * (phi(1) - phi(-1)) - c2 * (phi(2) - phi(-2));           // mesh.py:4973-4977
+        // Jᵢ += ℝ[-ᔑdt]*(ϱ + ℝ[c⁻²]*𝒫)*grid   (interactions.py:2397-2400)
+        J[t] += mdt * (rho[t] + inv_c2 * P[t]) * g;
+    }
+}
+
+static unsigned blocks_for(i64 n, int per) {
+    i64 b = (n + per - 1) / per;
+    if (b > 256 * 64) b = 256 * 64;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+int cgk_fluid_add(cg_ctx *c, const double *fluid, double factor, int op_add) {
+    i64 total = c->N * c->N * c->N;
+    hipLaunchKernelGGL(k_fluid_add, dim3(blocks_for(total, 256)), dim3(256), 0, c->stream,
+                       c->mesh0, fluid, (int)c->N, c->pad, factor, op_add);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cgk_nullify_nyquist(cg_ctx *c) {
+    hipLaunchKernelGGL(k_nullify_nyquist, dim3(blocks_for(c->N * c->N, 1)), dim3(64), 0,
+                       c->stream, (double2 *)c->mesh0, (int)c->N, c->pad / 2);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cgk_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
+                        const double *shift, int diff_dim, int op_add) {
+    const double kPiLocal = 3.141592653589793;
+    FourierOp P{};
+    P.tab_n = onto->ktab_n;
+    P.tab_s = onto->ktab_s;
+    P.deconv_order = deconv_order;
+    P.nlattice = nlattice;
+    P.diff_dim = diff_dim;
+    P.op_add = op_add;
+    P.shifted = shift && (shift[0] != 0 || shift[1] != 0 || shift[2] != 0);
+    P.zero_nyquist = (from != onto) && !op_add;
+    if (P.shifted) {
+        // ℝ[-2*π/gridsize_corrections*interlace_lattice.shift[d]]  (mesh.py:2863-2878)
+        P.A = -2 * kPiLocal / (double)onto->N * shift[0];
+        P.B = -2 * kPiLocal / (double)onto->N * shift[1];
+        P.Cc = -2 * kPiLocal / (double)onto->N * shift[2];
+    }
+    P.k_fundamental = 2 * kPiLocal / onto->p.boxsize;  // mesh.py:3362
+    P.inv_lat = 1.0 / (double)nlattice;
+    hipLaunchKernelGGL(k_fourier_operate, dim3(blocks_for(onto->N * onto->N, 1)), dim3(256), 0,
+                       onto->stream, (const double2 *)from->mesh0, (double2 *)onto->mesh0,
+                       (int)onto->N, onto->pad / 2, P);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cgk_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int dim,
+                   int diff_order, double minus_dt, double inv_c2) {
+    i64 total = c->N * c->N * c->N;
+    double dx = c->p.boxsize / (double)c->N;  // interactions.py:2133
+    if (diff_order == 2) {
+        double c1 = (1.0 / 2) / dx;
+        hipLaunchKernelGGL(k_fluid_kick<2>, dim3(blocks_for(total, 256)), dim3(256), 0,
+                           c->stream, J, rho, P, c->mesh0, (int)c->N, c->pad, dim, c1, 0.0,
+                           minus_dt, inv_c2);
+    } else {
+        double c1 = (2.0 / 3) / dx, c2 = (1.0 / 12) / dx;
+        hipLaunchKernelGGL(k_fluid_kick<4>, dim3(blocks_for(total, 256)), dim3(256), 0,
+                           c->stream, J, rho, P, c->mesh0, (int)c->N, c->pad, dim, c1, c2,
+                           minus_dt, inv_c2);
+    }
+    CG_LAUNCH_CHECK();
+    return 0;
+}

@@ -161,6 +161,12 @@ int cgk_fft_dist_backward(cg_ctx *c, const double *recv_buf);
 int cgk_layers_write(cg_ctx *c, i64 layer0, i64 nlayers, const double *src, int add);
 int cgk_owner_rank(cg_ctx *c, const double *pos, i64 n, int *owner);
 // what: 0 forward, 1 backward, 2 forward + Poisson kernel + backward (fused)
+int cgk_fluid_add(cg_ctx *c, const double *fluid, double factor, int op_add);
+int cgk_nullify_nyquist(cg_ctx *c);
+int cgk_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
+                        const double *shift, int diff_dim, int op_add);
+int cgk_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int dim,
+                   int diff_order, double minus_dt, double inv_c2);
 int cgk_fft(cg_ctx *c, int what, int deconv_order, double C, int long_range, double E);
 int cgk_deposit_cic_tiled(cg_ctx *c, const double *pos, i64 n, const unsigned *tile_offset,
                           double contribution, int accumulate);

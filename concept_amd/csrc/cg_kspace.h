@@ -97,7 +97,7 @@ __device__ __forceinline__ double kspace_factor_fixed(const KspaceParams &P, con
 // (C/k2) instead of two, and the mode numbers are 32-bit (N <= 2048: k2 < 2^24).  Differs
 // from kspace_factor by rounding only (the three ratios are rounded separately, ~3 ulp);
 // the Poisson solve is a floating-point path (FFT rounding already differs from FFTW's),
-// tested against the oracle to the tolerance stated in tests/test_gpu_pm.py.
+// tested against the CPU restatement to the tolerance stated in tests/test_gpu_pm.py.
 struct KspaceFixedQ {
     double q_bkk;  // q_b*q_kk
     int kb2_kk2;   // kb*kb + kk*kk

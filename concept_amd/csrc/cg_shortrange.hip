@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64) void k_sr_sweep(
                         double r2 = x_ji * x_ji + y_ji * y_ji + z_ji * z_ji;  // gravity.py:306
                         bool hit = !(r2 > P.r2_max) && !(P.same && sidx[k] == pi);
                         if (hit) {
-                            i64 idx = (i64)(r2 * P.r2_index_scaling);        // gravity.py:316
+                            int idx = (int)(r2 * P.r2_index_scaling);         // gravity.py:316 (< 4096: int)
                             double total_factor = my_factor * table[idx];    // gravity.py:321
                             ax += x_ji * total_factor;
                             ay += y_ji * total_factor;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64) void k_sr_sweep_columns(
                             }
                             double r2 = x_ji * x_ji + y_ji * y_ji + z_ji * z_ji;
                             if (r2 > P.r2_max) continue;
-                            i64 idx = (i64)(r2 * P.r2_index_scaling);
+                            int idx = (int)(r2 * P.r2_index_scaling);
                             double total_factor = P.factor * table[idx];
                             ax += x_ji * total_factor;
                             ay += y_ji * total_factor;

@@ -124,6 +124,8 @@ class SlabDomain:
 
     # communicate_ghosts(grid, '+=') after the deposit (mesh.py:609)
     def fold_deposit_ghost(self):
+        if self.world == 1:
+            return  # one periodic domain: the deposit wraps by itself, no ghost layers
         per = self._layer
         s, r = self.halo_s[:per], self.halo_r[:per]
         self.mesh.layers_read(self.nxl, 1, s)
@@ -132,6 +134,8 @@ class SlabDomain:
 
     # communicate_ghosts(grid, '=') of the potential (interactions.py:2303-2307)
     def fill_potential_ghosts(self):
+        if self.world == 1:
+            return
         G = self.G
         # my first G layers -> previous rank's upper ghosts [nxl, nxl+G)
         self.mesh.layers_read(0, G, self.halo_s)
@@ -145,6 +149,9 @@ class SlabDomain:
     # A3..A8 with the transpose (fft.c:240-257) as all_to_all_single
     def poisson_solve(self, deconv_order, C, long_range=False, E=0.0):
         m = self.mesh
+        if self.world == 1:
+            m.poisson_solve(deconv_order, C, long_range, E)
+            return
         m.dist_fft_forward(self.tbuf_a)
         self.comm.all_to_all(self.tbuf_b, self.tbuf_a)
         m.dist_fft_xsolve(self.tbuf_b, deconv_order, C, long_range, E)

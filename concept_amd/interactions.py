@@ -62,11 +62,30 @@ def get_potential_specs(force, method, receivers, suppliers):
     )
 
 
+def _default_fast_path(receivers, suppliers, gridsize_global, force, method, interpolation_order,
+                       interlace_upstream, interlace_downstream):
+    """The default configuration: particle components only, every upstream / downstream
+    grid size equal to the global one, CIC, 'sc' lattices, finite-difference gradient."""
+    for c in list(receivers) + list(suppliers):
+        if c.representation != 'particles':
+            return False
+    if any(s.potential_gridsizes[force][method].upstream != gridsize_global for s in suppliers):
+        return False
+    if any(r.potential_gridsizes[force][method].downstream != gridsize_global
+           for r in receivers):
+        return False
+    if interpolation_order != 2 or (interlace_upstream, interlace_downstream) != ('sc', 'sc'):
+        return False
+    return all(r.potential_differentiations[force][method] in (2, 4) for r in receivers)
+
+
 def particle_mesh(receivers, suppliers, gridsize_global, quantity, force, method, potential,
                   interpolation_order, deconvolve_upstream, deconvolve_downstream,
                   interlace_upstream, interlace_downstream, ᔑdt, ᔑdt_key):
-    """interactions.py:1985-2335 for particle components whose upstream and
-    downstream grid sizes equal the global one (the default configuration)."""
+    """interactions.py:1985-2335.  The default configuration takes the fused kernels
+    (one deposit, the 5-pass Poisson solve, one gather-kick); everything else — fluid
+    components, several representations — is assembled as the reference does it
+    (particle_mesh_general)."""
     if not receivers or not suppliers:
         return
     if potential not in {'gravity', 'gravity long-range'}:
@@ -74,21 +93,12 @@ def particle_mesh(receivers, suppliers, gridsize_global, quantity, force, method
             f'particle_mesh() got potential "{potential}" ∉ {{"gravity", "gravity long-range"}}')
     if quantity != 'a²ρ':
         raise ConceptGPUError(f'particle_mesh(): quantity "{quantity}" is not on the gravity path')
-    for c in list(receivers) + list(suppliers):
-        if c.representation != 'particles':
-            raise ConceptGPUError(f'{c.name}: fluid components are not built (SURVEY.md §8f)')
-    for s in suppliers:
-        if s.potential_gridsizes[force][method].upstream != gridsize_global:
-            raise ConceptGPUError('upstream grid size ≠ global grid size is not built '
-                                  '(copy_modes, SURVEY.md §8f-1b)')
-    for r in receivers:
-        if r.potential_gridsizes[force][method].downstream != gridsize_global:
-            raise ConceptGPUError('downstream grid size ≠ global grid size is not built '
-                                  '(copy_modes, SURVEY.md §8f-1b)')
-    if interpolation_order != 2:
-        raise ConceptGPUError(f'interpolation order {interpolation_order}: only CIC (2) is built')
-    if (interlace_upstream, interlace_downstream) != ('sc', 'sc'):
-        raise ConceptGPUError('interlacing is not built (SURVEY.md §8f-3)')
+    if not _default_fast_path(receivers, suppliers, gridsize_global, force, method,
+                              interpolation_order, interlace_upstream, interlace_downstream):
+        return particle_mesh_general(
+            receivers, suppliers, gridsize_global, quantity, force, method, potential,
+            interpolation_order, deconvolve_upstream, deconvolve_downstream,
+            interlace_upstream, interlace_downstream, ᔑdt, ᔑdt_key)
     p = receivers[0].params
     boxsize = p.boxsize
     mesh = get_mesh(gridsize_global, boxsize, p.nghosts, p.cell_centered, interpolation_order,
@@ -104,11 +114,7 @@ def particle_mesh(receivers, suppliers, gridsize_global, quantity, force, method
     ordered = sorted(suppliers, key=lambda s: not (s.tiles_exact and s.tile_mesh is mesh))
     mesh_started = False
     for supplier in ordered:
-        # mesh.py:1550-1573
-        contribution = ᔑdt['a**(-3*w_eff-1)', supplier.name]/ᔑdt['1']
-        contribution *= supplier.mass
-        contribution_factor = fft_factor*(gridsize_global/boxsize)**3
-        contribution *= contribution_factor
+        contribution = _particle_contribution(supplier, ᔑdt, fft_factor, gridsize_global, boxsize)
         if supplier.tiles_exact and supplier.tile_mesh is mesh:
             mesh.deposit_tiled(supplier.pos, supplier.tile_table, contribution,
                                accumulate=mesh_started)
@@ -118,30 +124,293 @@ def particle_mesh(receivers, suppliers, gridsize_global, quantity, force, method
             mesh.deposit(supplier.pos, contribution)
         mesh_started = True
     # interactions.py:2092-2118 and :2302
-    C = -boxsize**2*p.G_Newton/π
-    if potential == 'gravity':
-        mesh.poisson_solve(deconv_order_global, C, False, 0.0)
-    else:
-        scale = commons.resolve_shortrange(p, gridsize_global)['scale']
-        E = -(2*π/boxsize*scale)**2
-        mesh.poisson_solve(deconv_order_global, C, True, E)
+    C, long_range, E = _potential_constants(p, potential, gridsize_global)
+    mesh.poisson_solve(deconv_order_global, C, long_range, E)
     # interactions.py:2311-2332 via apply_particle_mesh_force (:2359-2387)
     for receiver in receivers:
-        key = (ᔑdt_key[0], receiver.name) if isinstance(ᔑdt_key, tuple) else ᔑdt_key
-        differentiation_order = receiver.potential_differentiations[force][method]
-        if differentiation_order == 0:
-            raise ConceptGPUError('Fourier-space differentiation (order 0) is not built '
-                                  '(SURVEY.md §8f-3)')
-        factor = receiver.mass*(-ᔑdt[key])
-        if receiver.tile_table is not None and receiver.tile_mesh is mesh:
-            # tile order (possibly drifted since the sort: strays are handled)
-            mesh.gather_kick_tiled(receiver.pos, receiver.mom, receiver.tile_table,
-                                   differentiation_order, factor)
+        _kick_particles(mesh, receiver, force, method, ᔑdt, ᔑdt_key)
+
+
+def _particle_contribution(supplier, ᔑdt, fft_factor, gridsize, boxsize):
+    """mesh.py:1550-1573 for quantity 'a²ρ'"""
+    contribution = ᔑdt['a**(-3*w_eff-1)', supplier.name]/ᔑdt['1']
+    contribution *= supplier.mass
+    contribution_factor = fft_factor*(gridsize/boxsize)**3
+    contribution *= contribution_factor
+    return contribution
+
+
+def _potential_constants(p, potential, gridsize_global):
+    """interactions.py:2105 and :2110-2113"""
+    C = -p.boxsize**2*p.G_Newton/π
+    if potential == 'gravity':
+        return C, False, 0.0
+    scale = commons.resolve_shortrange(p, gridsize_global)['scale']
+    return C, True, -(2*π/p.boxsize*scale)**2
+
+
+def _kick_particles(mesh, receiver, force, method, ᔑdt, ᔑdt_key):
+    key = (ᔑdt_key[0], receiver.name) if isinstance(ᔑdt_key, tuple) else ᔑdt_key
+    differentiation_order = receiver.potential_differentiations[force][method]
+    factor = receiver.mass*(-ᔑdt[key])
+    if receiver.tile_table is not None and receiver.tile_mesh is mesh:
+        # tile order (possibly drifted since the sort: strays are handled)
+        mesh.gather_kick_tiled(receiver.pos, receiver.mom, receiver.tile_table,
+                               differentiation_order, factor)
+    else:
+        mesh.gather_kick(receiver.pos, receiver.mom, differentiation_order, factor)
+
+
+def group_components(components, gridsizes, gridsizes_order=(), split_representations=True):
+    """mesh.py:714-790: {gridsize: {representation: [components]}} (or {gridsize: [...]}),
+    grid sizes ordered as requested — an Ellipsis in `gridsizes_order` stands for every
+    grid size not listed."""
+    order = list(gridsizes_order)
+    if ... not in order:
+        order.append(...)
+    if order.count(...) != 1:
+        raise ConceptGPUError(f'group_components() got gridsizes_order = {order}')
+    present = []
+    for g in gridsizes:
+        if g not in present:
+            present.append(g)
+    i = order.index(...)
+    listed = [g for g in order if g is not ...]
+    rest = [g for g in present if g not in listed]
+    final = [g for g in order[:i] if g in present] + rest + [g for g in order[i + 1:]
+                                                           if g in present]
+    groups = collections.OrderedDict()
+    for g in final:
+        members = [c for c, gc in zip(components, gridsizes) if gc == g]
+        if split_representations:
+            groups[g] = collections.OrderedDict()
+            for c in members:
+                groups[g].setdefault(c.representation, []).append(c)
         else:
-            mesh.gather_kick(receiver.pos, receiver.mom, differentiation_order, factor)
+            groups[g] = members
+    return groups
+
+
+def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force, method,
+                          potential, interpolation_order, deconvolve_upstream,
+                          deconvolve_downstream, interlace_upstream, interlace_downstream,
+                          ᔑdt, ᔑdt_key):
+    """interactions.py:1985-2335 with interpolate_upstream (mesh.py:492-635) and
+    add_upstream_to_global_slabs (mesh.py:654-711), step for step, on one GPU: one mesh
+    context per (grid size, role) plays the reference's named slabs.  Built: particle and
+    fluid suppliers / receivers on grid sizes equal to the global
+    one, CIC, 'sc' lattices, finite-difference gradients."""
+    p = receivers[0].params
+    boxsize = p.boxsize
+    dev = receivers[0].device
+    if interpolation_order != 2:
+        raise ConceptGPUError(f'interpolation order {interpolation_order}: only CIC (2) is built '
+                              '(SURVEY.md §8f-3)')
+    if (interlace_upstream, interlace_downstream) != ('sc', 'sc'):
+        raise ConceptGPUError('interlacing is not built (SURVEY.md §8f-3)')
+    gs_up = [s.potential_gridsizes[force][method].upstream for s in suppliers]
+    gs_down = [r.potential_gridsizes[force][method].downstream for r in receivers]
+    if any(g != gridsize_global for g in gs_up + gs_down):
+        raise ConceptGPUError('upstream / downstream grid size ≠ global grid size is not built '
+                              '(copy_modes, SURVEY.md §8f-1b)')
+    for c in list(receivers) + list(suppliers):
+        if c.representation == 'fluid' and c.gridsize != gridsize_global:
+            raise ConceptGPUError(
+                f'add_fluid_to_grid() got component with global grid size {c.gridsize} and '
+                f'non-matching grid of global grid size {gridsize_global}')
+
+    def mesh_for(role):
+        return get_mesh(gridsize_global, boxsize, p.nghosts, p.cell_centered,
+                        interpolation_order, dev, role=role)
+    # interactions.py:2049-2080: which deconvolutions are promoted to the global one
+    only_particle_suppliers = all(s.representation == 'particles' for s in suppliers)
+    only_particle_receivers = all(r.representation == 'particles' for r in receivers)
+    deconv_order_global = 0
+    if deconvolve_upstream and only_particle_suppliers:
+        deconvolve_upstream = False
+        deconv_order_global += 1
+    if deconvolve_downstream and only_particle_receivers:
+        deconvolve_downstream = False
+        deconv_order_global += 1
+    deconv_order_global *= interpolation_order
+    # ---- interpolate_upstream (mesh.py:571-620): per upstream grid size, fluids then
+    # particles; each upstream slab is added onto the global one in Fourier space
+    fft_factor = float(gridsize_global)**(-3)  # mesh.py:582
+    slab_global = None
+    groups = group_components(suppliers, gs_up, [gridsize_global, ...])
+    for gridsize_upstream, group in groups.items():
+        fluid_components = group.get('fluid', [])
+        particle_components = group.get('particles', [])
+        if fluid_components:
+            up = mesh_for('global' if slab_global is None else 'upstream')
+            for i, fluid in enumerate(fluid_components):
+                # add_fluid_to_grid, quantity 'a²ρ' (mesh.py:1712-1717)
+                factor = fft_factor
+                factor *= ᔑdt['a**(-3*w_eff-1)', fluid.name]/ᔑdt['1']
+                up.fluid_add(fluid.ϱ, factor, '=' if i == 0 else '+=')
+            up.fft_forward()
+            up.nullify_nyquist()
+            if slab_global is None:
+                slab_global = up  # fourier_operate(slab, 0, None) is the identity
+            else:
+                slab_global.fourier_operate(source=up, operation='+=')
+        if particle_components:
+            up = mesh_for('global' if slab_global is None else 'upstream')
+            up.zero()
+            for supplier in particle_components:
+                up.deposit(supplier.pos, _particle_contribution(
+                    supplier, ᔑdt, fft_factor, gridsize_upstream, boxsize))
+            up.fft_forward()
+            up.nullify_nyquist()
+            deconv_order = interpolation_order*int(bool(deconvolve_upstream))
+            if slab_global is None:
+                slab_global = up.fourier_operate(deconv_order)
+            else:
+                slab_global.fourier_operate(deconv_order, source=up, operation='+=')
+    # ---- potential (interactions.py:2092-2120)
+    C, long_range, E = _potential_constants(p, potential, gridsize_global)
+    slab_global.poisson_kernel(deconv_order_global, C, long_range, E)
+    # ---- downstream (interactions.py:2124-2332)
+    groups = group_components(receivers, gs_down, [..., gridsize_global])
+    for gridsize_downstream, group in groups.items():
+        slab_downstream = slab_global
+        for representation in ('fluid', 'particles'):
+            if representation not in group:
+                continue
+            at_last_representation = representation == 'particles' or 'particles' not in group
+            deconv_order_downstream = interpolation_order*int(
+                representation == 'particles' and bool(deconvolve_downstream))
+            differentiations = [r.potential_differentiations[force][method]
+                                for r in group[representation]]
+            subgroups = group_components(group[representation], differentiations,
+                                         sorted(differentiations, reverse=True),
+                                         split_representations=False)
+            for differentiation_order, subgroup in subgroups.items():
+                if differentiation_order == 0:
+                    raise ConceptGPUError('Fourier-space differentiation (order 0) is not built '
+                                          '(SURVEY.md §8f-3)')
+                at_last_order = differentiation_order == min(differentiations)
+                if at_last_representation and at_last_order:
+                    slab = slab_downstream  # may be mutated: nobody needs it afterwards
+                else:
+                    slab = mesh_for('subgroup')
+                    slab.copy_from(slab_downstream)
+                slab.fourier_operate(deconv_order_downstream)
+                slab.poisson_backward()
+                for receiver in subgroup:
+                    if representation == 'particles':
+                        _kick_particles(slab, receiver, force, method, ᔑdt, ᔑdt_key)
+                    else:
+                        key = ((ᔑdt_key[0], receiver.name) if isinstance(ᔑdt_key, tuple)
+                               else ᔑdt_key)
+                        for dim in range(3):
+                            slab.fluid_kick(receiver.J[dim], receiver.ϱ, receiver.𝒫, dim,
+                                            differentiation_order, -ᔑdt[key],
+                                            p.light_speed**(-2))
 
 
 register('gravity', ['ppnonperiodic', 'pp', 'p3m', 'pm'], 'gravitational')
+
+
+Pairing = collections.namedtuple('Pairing', ('force', 'method', 'receivers', 'suppliers'))
+methods_implemented = ('ppnonperiodic', 'pp', 'p3m', 'pm')
+
+
+def find_interactions(components, interaction_type='any', instantaneous='both'):
+    """Which (force, method, receivers, suppliers) calls one kick consists of
+    (interactions.py:2456-2636).  Every component with the force supplies; it receives
+    through its own method.  Fluid suppliers of a non-PM interaction are split off into
+    a PM interaction of their own; interactions with equal receivers (or equal suppliers)
+    are merged; `interaction_type` 'long-range' keeps PM and P³M, 'short-range' everything
+    but PM."""
+    in_use = collections.defaultdict(set)
+    for c in components:
+        for force, method in c.forces.items():
+            in_use[force].add(method)
+    for force, methods in in_use.items():
+        info = interactions_registered.get(force)
+        if info is None:
+            raise ConceptGPUError(f'Force "{force}" is not implemented')
+        for method in methods:
+            if not method:
+                continue
+            if method not in methods_implemented:
+                raise ConceptGPUError(f'Force method "{method}" not recognised')
+            if method not in info.methods:
+                raise ConceptGPUError(
+                    f'Method "{method}" for force "{force}" is not implemented. '
+                    f'Did you mean one of {info.methods}?')
+    todo = []
+    for force, info in interactions_registered.items():
+        for method in info.methods:
+            if method not in in_use.get(force, ()):
+                continue
+            sup = [c for c in components if force in c.forces]
+            rec = [c for c in sup if c.forces[force] == method]
+            todo.append(Pairing(force, method, rec, sup))
+
+    def simplify(lst):
+        changed = True
+        while changed:
+            changed = False
+            # fluids supply through the mesh only
+            for i, it in enumerate(lst):
+                if it.method == 'pm':
+                    continue
+                fluid = next((c for c in it.suppliers if c.representation == 'fluid'), None)
+                if fluid is not None:
+                    it.suppliers.remove(fluid)
+                    lst.insert(i + 1, Pairing(it.force, 'pm', list(it.receivers), [fluid]))
+                    changed = True
+                    break
+            if changed:
+                continue
+            lst[:] = [it for it in lst if it.receivers and it.suppliers]
+            for i, a_ in enumerate(lst):
+                for j in range(i + 1, len(lst)):
+                    b_ = lst[j]
+                    if (a_.force, a_.method) != (b_.force, b_.method):
+                        continue
+                    same_r = set(a_.receivers) == set(b_.receivers)
+                    same_s = set(a_.suppliers) == set(b_.suppliers)
+                    if same_r and not same_s:
+                        for c in b_.suppliers:
+                            if c not in a_.suppliers:
+                                a_.suppliers.insert(0, c)
+                    elif same_s and not same_r:
+                        for c in b_.receivers:
+                            if c not in a_.receivers:
+                                a_.receivers.insert(0, c)
+                    else:
+                        continue
+                    lst.pop(j)
+                    changed = True
+                    break
+                if changed:
+                    break
+        return lst
+    simplify(todo)
+    if 'long' in interaction_type:
+        for it in todo:
+            if it.method not in {'pm', 'p3m'}:
+                it.receivers[:] = []
+        simplify(todo)
+    elif 'short' in interaction_type:
+        for it in todo:
+            if it.method == 'pm':
+                it.receivers[:] = []
+        simplify(todo)
+    elif 'any' not in interaction_type:
+        raise ConceptGPUError(f'find_interactions(): Unknown interaction_type "{interaction_type}"')
+    if 'True' in str(instantaneous) or 'False' in str(instantaneous):
+        want = 'True' in str(instantaneous)
+        for it in todo:
+            if interactions_registered[it.force].instantaneous != want:
+                it.receivers[:] = []
+        simplify(todo)
+    elif 'both' not in str(instantaneous):
+        raise ConceptGPUError(f'find_interactions(): Unknown instantaneous value "{instantaneous}"')
+    return todo
 
 
 def gravity(method, receivers, suppliers, ᔑdt, interaction_type, printout):

@@ -85,6 +85,11 @@ SYMBOLS = {
     'cg_owner_rank': (_int, [_vp, _vp, _i64, _vp]),
     'cg_fetch': (_int, [_vp, _int, _vp, _i64]),
     'cg_cic_indices': (_int, [_vp, _vp, _i64, _int, _vp]),
+    'cg_fluid_add': (_int, [_vp, _vp, _dbl, _int]),
+    'cg_fourier_nullify_nyquist': (_int, [_vp]),
+    'cg_fourier_operate': (_int, [_vp, _vp, _int, _int, _vp, _int, _int]),
+    'cg_mesh_copy': (_int, [_vp, _vp]),
+    'cg_fluid_kick': (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl]),
 }
 
 if not os.path.exists(LIB_PATH):

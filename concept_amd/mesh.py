@@ -125,6 +125,55 @@ class PotentialMesh:
     def poisson_backward(self):
         check(_L.cg_poisson_backward(self._ctx))
 
+    # -- general particle_mesh() pieces ------------
+    def _check_fluid(self, *grids):
+        n = self.gridsize**3
+        for g in grids:
+            if (g.dtype != torch.float64 or not g.is_contiguous() or g.device != self.device
+                    or g.numel() != n):
+                raise lib.ConceptGPUError(
+                    f'fluid grids must be contiguous float64 tensors of {self.gridsize}^3 '
+                    f'elements on {self.device}')
+
+    def fluid_add(self, fluid, factor=1.0, operation='+='):
+        """add_fluid_to_grid (mesh.py:1685-1753)"""
+        self._check_fluid(fluid)
+        check(_L.cg_fluid_add(self._ctx, _ptr(fluid), float(factor), int(operation == '+=')))
+
+    def fft_forward(self):
+        """slab_decompose + fft(slab, 'forward') (mesh.py:665-670)"""
+        check(_L.cg_poisson_forward(self._ctx, 0, 0.0, 0, 0.0, 0))
+
+    def nullify_nyquist(self):
+        """nullify_modes(slab, 'nyquist') (mesh.py:3591-3622)"""
+        check(_L.cg_fourier_nullify_nyquist(self._ctx))
+
+    def fourier_operate(self, deconv_order=0, nlattice=1, shift=(0.0, 0.0, 0.0), diff_dim=-1,
+                        source=None, operation='='):
+        """fourier_operate (mesh.py:3327-3400) when source is None, else the equal-size
+        copy_modes(source, self, ...) (mesh.py:1038-1092); their early exits included."""
+        shifted = tuple(shift) != (0, 0, 0)
+        if source is None or source is self:
+            source = self
+            if operation != '=':
+                raise lib.ConceptGPUError('fourier_operate(): in place means operation "="')
+            if deconv_order == 0 and nlattice == 1 and not shifted and diff_dim == -1:
+                return self  # mesh.py:3339-3344
+        sh = (ctypes.c_double*3)(*[float(x) for x in shift])
+        check(_L.cg_fourier_operate(self._ctx, source._ctx, int(deconv_order), int(nlattice),
+                                    sh, int(diff_dim), int(operation == '+=')))
+        return self
+
+    def copy_from(self, other):
+        check(_L.cg_mesh_copy(self._ctx, other._ctx))
+
+    def fluid_kick(self, J_dim, rho, P, dim, diff_order, minus_dt, inv_c2):
+        """diff_domaingrid + the fluid branch of apply_particle_mesh_force
+        (interactions.py:2388-2401)"""
+        self._check_fluid(J_dim, rho, P)
+        check(_L.cg_fluid_kick(self._ctx, _ptr(J_dim), _ptr(rho), _ptr(P), int(dim),
+                               int(diff_order), float(minus_dt), float(inv_c2)))
+
     def gather_kick(self, pos, mom, diff_order, factor):
         n = self._check_particles(pos, mom)
         check(_L.cg_gather_kick(self._ctx, _ptr(pos), _ptr(mom), n, int(diff_order),
@@ -304,12 +353,15 @@ class PotentialMesh:
         return idx
 
 
-def get_mesh(gridsize, boxsize, nghosts=2, cell_centered=True, interp_order=2, device=None):
-    """Persistent mesh per configuration (the reference's named buffers)."""
+def get_mesh(gridsize, boxsize, nghosts=2, cell_centered=True, interp_order=2, device=None,
+             role='global'):
+    """Persistent mesh per configuration and role — the reference's named buffers
+    ('slab_global', 'slab_updownstream', 'slab_updownstream_subgroup': mesh.py:593-617,
+    interactions.py:2159-2161, 2242-2279)."""
     if device is None:
         device = torch.cuda.current_device()
     key = (int(gridsize), float(boxsize), int(nghosts), bool(cell_centered), int(interp_order),
-           int(device) if isinstance(device, int) else device.index)
+           int(device) if isinstance(device, int) else device.index, role)
     m = _meshes.get(key)
     if m is None:
         m = _meshes[key] = PotentialMesh(gridsize, boxsize, nghosts, cell_centered, interp_order,

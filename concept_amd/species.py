@@ -18,23 +18,58 @@ PotentialGridsizes = collections.namedtuple('PotentialGridsizes', ('upstream', '
 
 
 class Component:
-    representation = 'particles'
-
-    def __init__(self, name, species, *, N, mass, boltzmann_order=-1, device=None, params=None):
-        if boltzmann_order not in (-1,):
-            raise ConceptGPUError('fluid components (boltzmann_order >= 0) are not on the '
-                                  'GPU path (SURVEY.md §8f)')
+    def __init__(self, name, species, *, N=None, gridsize=None, mass=None, boltzmann_order=-1,
+                 device=None, params=None):
+        """Component(name, species, N=..., mass=...)                      particles
+        Component(name, species, gridsize=..., boltzmann_order=1)        fluid
+        (species.py:852-1040).  A fluid component here is what the gravity path needs of
+        it: the grids ϱ, J[0..2] and 𝒫 as float64 tensors (gridsize,)*3 on the GPU (the
+        reference's grid_noghosts); its own evolution (fluid.py) stays with the caller."""
         self.params = p = params or commons.params
         if p is None:
             raise ConceptGPUError('no parameters loaded: call concept_amd.commons.load_params()')
         self.name = name.strip()
         self.species = species
-        self.N = self.N_local = int(N)
-        self.mass = float(mass)
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device())
         self.device = torch.device(device)
-        self.softening_length = commons.softening_length(p, species, self.N)
+        if (N is None) == (gridsize is None):
+            raise ConceptGPUError(
+                f'{self.name}: give N (particle component) or gridsize (fluid component)')
+        if N is not None:
+            if boltzmann_order != -1:
+                raise ConceptGPUError(f'{self.name}: particle components have '
+                                      'boltzmann_order = -1')
+            self.representation = 'particles'
+            self._init_particles(int(N), mass)
+        else:
+            if boltzmann_order < 0:
+                raise ConceptGPUError(f'{self.name}: fluid components need boltzmann_order >= 0')
+            self.representation = 'fluid'
+            self.boltzmann_order = int(boltzmann_order)
+            self._init_fluid(int(gridsize))
+        self._init_forces()
+
+    def _init_fluid(self, gridsize):
+        if gridsize < 2 or gridsize % 2:
+            raise ConceptGPUError(f'{self.name}: fluid grid size {gridsize} must be even and ≥ 2')
+        self.gridsize = gridsize
+        self.N = self.N_local = 0
+        self.mass = -1.0  # species.py: fluids carry no particle mass
+        shape = (gridsize,)*3
+        z = lambda: torch.zeros(shape, dtype=torch.float64, device=self.device)
+        self.ϱ, self.𝒫 = z(), z()
+        self.J = [z(), z(), z()]
+        self.use_rungs = False
+        self.tile_table = None
+        self.tile_mesh = None
+        self.tiles_exact = False
+
+    def _init_particles(self, N, mass):
+        p = self.params
+        self.N = self.N_local = N
+        self.mass = float(mass)
+        self.softening_length = commons.softening_length(p, self.species, self.N)
         self.pos = torch.zeros((self.N, 3), dtype=torch.float64, device=self.device)
         self.mom = torch.zeros((self.N, 3), dtype=torch.float64, device=self.device)
         self.Δmom = None  # allocated on first short-range use
@@ -45,47 +80,75 @@ class Component:
         self.tile_table = None
         self.tile_mesh = None
         self.tiles_exact = False
-        # forces first: use_rungs depends on them (species.py:1444-1448)
-        self.forces = {}
-        for key in (self.name, species, 'particles', 'all', 'default'):
-            if key in p.select_forces:
-                self.forces = dict(p.select_forces[key])
-                break
-        # short-range rungs (species.py:1443-1460): int8 rung index per particle, all on rung 0
-        self.N_rungs = p.N_rungs
-        self.use_rungs = bool(p.N_rungs > 1 and ({'ppnonperiodic', 'pp', 'p3m'}
-                                                 & set(self.forces.values())))
-        self.lowest_active_rung = 0
-        self.lowest_populated_rung = 0
-        self.highest_populated_rung = 0
-        self.rungs_N = [0]*p.N_rungs
-        self.rungs_N[0] = self.N
-        self.rung_indices = torch.zeros(self.N, dtype=torch.int8, device=self.device)
-        self.rung_indices_jumped = torch.zeros(self.N, dtype=torch.int8, device=self.device)
-        # potential grid sizes (species.py:1100-1215)
+
+    def _init_forces(self):
+        p = self.params
+        # forces first: use_rungs depends on them (species.py:1113-1117, 1444-1448)
+        self.forces = dict(commons.is_selected(self, p.select_forces, accumulate=True) or {})
+        if self.representation == 'particles':
+            # short-range rungs (species.py:1443-1460): int8 rung index per particle
+            self.N_rungs = p.N_rungs
+            self.use_rungs = bool(p.N_rungs > 1 and ({'ppnonperiodic', 'pp', 'p3m'}
+                                                     & set(self.forces.values())))
+            self.lowest_active_rung = 0
+            self.lowest_populated_rung = 0
+            self.highest_populated_rung = 0
+            self.rungs_N = [0]*p.N_rungs
+            self.rungs_N[0] = self.N
+            self.rung_indices = torch.zeros(self.N, dtype=torch.int8, device=self.device)
+            self.rung_indices_jumped = torch.zeros(self.N, dtype=torch.int8, device=self.device)
+        # potential grid sizes (species.py:1147-1203): component-level entries of
+        # potential_options['gridsize'] first; fluids default to their own grid size,
+        # particles to the global one, else cbrt(N) (2 cbrt(N) for p3m)
+        own = commons.is_selected(
+            self, {k: v for k, v in p.potential_options['gridsize'].items() if k != 'global'},
+            accumulate=True, default={}) or {}
         self.potential_gridsizes = {}
         self.potential_differentiations = {}
         for force, method in self.forces.items():
             methods = [method] + (['pm'] if method == 'p3m' else [])
             for m in methods:
-                g = p.potential_options['gridsize']['global'].get(force, {}).get(m, -1)
-                if g == -1:
-                    cb = int(round(self.N**(1/3)))
-                    g = 2*cb if m == 'p3m' else cb
-                self.potential_gridsizes.setdefault(force, {})[m] = PotentialGridsizes(g, g)
-                d = None
-                for key in (self.name, species, 'default'):
-                    dd = p.potential_options['differentiation'].get(key)
-                    if dd and m in dd.get(force, {}):
-                        d = dd[force][m]
-                        break
+                g = own.get(force, {}).get(m)
+                if g is None:
+                    if self.representation == 'fluid':
+                        g = self.gridsize
+                    else:
+                        g = p.potential_options['gridsize']['global'].get(force, {}).get(m, -1)
+                pair = list(g) if isinstance(g, (tuple, list)) else [g, g]
+                for i, v in enumerate(pair):
+                    if v == -1:
+                        if self.representation == 'fluid':
+                            v = self.gridsize
+                        else:
+                            cb = int(round(self.N**(1/3)))
+                            v = 2*cb if m == 'p3m' else cb
+                    pair[i] = int(v)
+                self.potential_gridsizes.setdefault(force, {})[m] = PotentialGridsizes(*pair)
+                dd = commons.is_selected(self, p.potential_options['differentiation'])
+                d = (dd or {}).get(force, {}).get(m)
                 self.potential_differentiations.setdefault(force, {})[m] = d
 
     # -- data in / out ------------------------------------------------------
-    def populate(self, data, var):
+    def populate(self, data, var, multi_index=None):
         """populate(array, 'posx'|'posy'|'posz'|'momx'|...) (species.py:1911-1925);
         also accepts var='pos'/'mom' with an (N, 3) array."""
         t = torch.as_tensor(np.ascontiguousarray(np.asarray(data, dtype=np.float64)))
+        if self.representation == 'fluid':
+            # populate(grid, 'ϱ') | populate(grid, 'J', dim) | populate(grid, '𝒫')
+            # (species.py:1926-1990)
+            target = {'ϱ': self.ϱ, 'rho': self.ϱ, '𝒫': self.𝒫, 'P': self.𝒫}.get(var)
+            if var == 'J':
+                if multi_index not in (0, 1, 2):
+                    raise ConceptGPUError(f'{self.name}.populate(): J needs a dimension 0, 1 or 2')
+                target = self.J[multi_index]
+            if target is None:
+                raise ConceptGPUError(f'{self.name}.populate(): unknown fluid variable "{var}"')
+            if tuple(t.shape) != (self.gridsize,)*3:
+                raise ConceptGPUError(
+                    f'{self.name}.populate(): grid of shape {tuple(t.shape)} for grid size '
+                    f'{self.gridsize}')
+            target.copy_(t)
+            return
         if var.startswith('pos'):
             self.tile_table = None
             self.tiles_exact = False
@@ -100,7 +163,15 @@ class Component:
 
     def host(self, var, original_order=True):
         """Host copy of 'pos' | 'mom' | 'Δmom', by default in the order the
-        particles were populated in (undoing tile_sort via ids)."""
+        particles were populated in (undoing tile_sort via ids); for a fluid
+        component 'ϱ' | '𝒫' | 'J' (stacked (3, g, g, g))."""
+        if self.representation == 'fluid':
+            if var == 'J':
+                return torch.stack(self.J).cpu().numpy()
+            # (identifiers are NFKC-normalised by Python: self.ϱ is the attribute 'ρ')
+            import unicodedata
+            name = unicodedata.normalize('NFKC', {'rho': 'ϱ'}.get(var, var))
+            return getattr(self, name).cpu().numpy()
         t = getattr(self, var)
         if original_order:
             out = torch.empty_like(t)

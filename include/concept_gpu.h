@@ -269,6 +269,44 @@ int cg_dist_fft_backward(cg_ctx *ctx, const double *recv_buf /*DEV*/);
 int cg_owner_rank(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n,
                   int32_t *owner_out /*DEV n*/);
 
+/* --- general particle_mesh(): several suppliers / receivers, particles and fluids
+ *     (interactions.py:1985-2402) ----------------
+ * The fused entry points above cover the default configuration (particle
+ * components only, all grid sizes equal, CIC, 'sc' lattice).  The general case
+ * is assembled by the caller from one context per (grid size, role) — the
+ * reference's 'slab_global', 'slab_updownstream', 'slab_updownstream_subgroup'
+ * buffers — with cg_poisson_forward(apply_kernel = 0) / cg_poisson_kernel /
+ * cg_poisson_backward and the operations below.
+ *
+ * cg_fluid_add: add_fluid_to_grid (mesh.py:1685-1753) / combine_fluids
+ *   (mesh.py:1657-1683): mesh (= | +=) fluid*factor for a fluid scalar grid
+ *   double[N][N][N] of the context's grid size (the caller folds the quantity's
+ *   time-step integral and fft_factor into `factor`).
+ * cg_fourier_nullify_nyquist: nullify_modes(slab, 'nyquist') (mesh.py:3591-3622).
+ * cg_fourier_operate: in place (from == onto, op_add = 0) it is fourier_operate
+ *   (mesh.py:3327-3400); otherwise the equal-size branch of copy_modes
+ *   (mesh.py:1038-1092): onto (= | +=) factor * rotated/differentiated modes of
+ *   `from`, over fourier_loop's modes (mesh.py:2615-2890: all but the Nyquist
+ *   planes; with op_add = 0 and from != onto those are zeroed, the reference's
+ *   nullified target).  deconv_order 0..8; nlattice = len(lattice) (1, 2 or 4);
+ *   shift = lattice.shift (HOST double[3], may be NULL); diff_dim -1 or 0..2.
+ *   The caller applies the reference's early exits (nothing to do; a pure
+ *   1/nlattice scaling still goes through this call).
+ * cg_mesh_copy: slab_downstream_subgroup[...] = slab_downstream
+ *   (interactions.py:2242-2245, 2276-2279).
+ * cg_fluid_kick: the fluid branch of apply_particle_mesh_force
+ *   (interactions.py:2388-2401) fused with diff_domaingrid (mesh.py:4874-5030):
+ *   J_dim[cell] += minus_dt*(rho[cell] + inv_c2*P[cell]) * d(phi)/dx_dim, symmetric
+ *   difference of order 2 or 4 on the context's real-space potential. */
+int cg_fluid_add(cg_ctx *ctx, const double *fluid /*DEV N^3*/, double factor, int op_add);
+int cg_fourier_nullify_nyquist(cg_ctx *ctx);
+int cg_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
+                       const double *shift /*HOST 3 or NULL*/, int diff_dim, int op_add);
+int cg_mesh_copy(cg_ctx *dst, cg_ctx *src);
+int cg_fluid_kick(cg_ctx *ctx, double *J_dim /*DEV N^3*/, const double *rho /*DEV N^3*/,
+                  const double *P /*DEV N^3*/, int dim, int diff_order, double minus_dt,
+                  double inv_c2);
+
 /* --- debug fetch (parity tests) -------------------------------------------- */
 int cg_fetch(cg_ctx *ctx, int which, double *out /*HOST*/, int64_t n_doubles);
 /* CIC cell indices exactly as set_weights_CIC returns them for the deposit

@@ -267,3 +267,72 @@ void orc_drift(double *pos, const double *mom, i64 n3, double dt_over_mass, doub
         pos[r] = x;
     }
 }
+
+/*
+ * fourier_operate (mesh.py:3327-3400) and the equal-size branch of copy_modes
+ * (mesh.py:1038-1092), one rank, transposed slab double[j][i][N+2]: every mode
+ * off the Nyquist planes (fourier_loop, mesh.py:2615-2890, covers j, i in
+ * [0, nyq) U (nyq, N) and kk in [0, nyq)) of `from` is
+ *   rotated by theta = (ki*A + kj*B) + kk*Cc, A = -2*pi/N*shift[0] ...  (shift != 0)
+ *   differentiated: factor *= k_fundamental*k_dim, (re, im) = (-im, re)  (diff_dim >= 0)
+ *   scaled by factor = deconvolution**order * (1/nlattice)
+ * and stored to (op_add = 0) or added to (op_add = 1) `onto`; from == onto with
+ * op_add = 0 is the in-place fourier_operate.  Both early exits of the reference
+ * (nothing to do; pure 1/nlattice scaling of every element) are the caller's.
+ */
+void orc_fourier_operate(const double *from, double *onto, i64 N, int deconv_order, int nlattice,
+                         const double *shift, int diff_dim, double k_fundamental, int op_add,
+                         double machine_eps) {
+    const double pi = 3.141592653589793;
+    double pi_over_n = pi / (double)N;
+    double inv_lat = 1.0 / (double)nlattice;
+    int shifted = shift && (shift[0] != 0 || shift[1] != 0 || shift[2] != 0);
+    double A = 0, B = 0, Cc = 0;
+    if (shifted) {
+        A = -2 * pi / (double)N * shift[0];
+        B = -2 * pi / (double)N * shift[1];
+        Cc = -2 * pi / (double)N * shift[2];
+    }
+    i64 nyq = N / 2, pad = N + 2;
+    for (i64 j = 0; j < N; j++) {
+        if (j == nyq) continue;
+        i64 kj = j - (j >= nyq ? N : 0);
+        double dj_n = (double)kj * pi_over_n + machine_eps;
+        double dj_d = sin(dj_n);
+        for (i64 i = 0; i < N; i++) {
+            if (i == nyq) continue;
+            i64 ki = i - (i >= nyq ? N : 0);
+            double di_n = (double)ki * pi_over_n + machine_eps;
+            double di_d = sin(di_n);
+            double dij_n = di_n * dj_n, dij_d = di_d * dj_d;
+            const double *src = from + (j * N + i) * pad;
+            double *dst = onto + (j * N + i) * pad;
+            for (i64 kk = 0; kk < nyq; kk++) {
+                double factor = 1;
+                if (deconv_order) {
+                    double dk_n = (double)kk * pi_over_n + machine_eps;
+                    double dk_d = sin(dk_n);
+                    factor = (dij_n * dk_n) / (dij_d * dk_d);
+                    factor = pow(factor, (double)deconv_order);
+                }
+                factor *= inv_lat;
+                double re = src[2 * kk], im = src[2 * kk + 1];
+                if (shifted) {
+                    double theta = ((double)ki * A + (double)kj * B) + (double)kk * Cc;
+                    double c = cos(theta), s = sin(theta);
+                    double re2 = re * c - im * s, im2 = re * s + im * c;
+                    re = re2; im = im2;
+                }
+                if (diff_dim >= 0) {
+                    i64 kl = diff_dim == 0 ? ki : (diff_dim == 1 ? kj : kk);
+                    factor *= k_fundamental * (double)kl;
+                    double t = re; re = -im; im = t;
+                }
+                re *= factor;
+                im *= factor;
+                if (op_add) { dst[2 * kk] += re; dst[2 * kk + 1] += im; }
+                else { dst[2 * kk] = re; dst[2 * kk + 1] = im; }
+            }
+        }
+    }
+}

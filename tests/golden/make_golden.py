@@ -61,6 +61,20 @@ CASES = {
     # kick_short / driftkick_short (main.py) with N_rungs = 4 on a clustered set
     'rungs_p3m_n8_g32': dict(method='p3m', n=8, gridsize=32, boxsize=32.0, seed=13,
                              dist='clustered', diff=4, rungs=4, steps=2),
+    # fluid coupling on the shared mesh.  One PM interaction with
+    # receivers = suppliers = [particles, fluid] (equal grid sizes): fluid ϱ added to the
+    # upstream grid, per-representation deconvolution, fluid kick J += -ᔑdt (ϱ + c⁻²𝒫) ∇φ
+    'fluid_pm_n8_g16': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=21,
+                            dist='uniform', diff=2, fluid=dict(gridsize=16)),
+    # two fluids + two particle components, differentiation order 4 for the particles
+    # the example_nonlinnu shape (param/example_nonlinnu:36-45): particles default P³M on
+    # mesh 32, fluid on grid 16, global PM grid 16 -> three long-range interactions per kick:
+    # (p3m, [particles], [particles]), (pm, [particles], [fluid]), (pm, [fluid], [particles, fluid])
+    'nonlinnu_like_n8': dict(method='pm', n=8, gridsize=16, boxsize=32.0, seed=23,
+                             dist='uniform', diff=2, fluid=dict(gridsize=16), nonlinnu=True),
+    'fluid2_pm_n6_g12': dict(method='pm', n=6, gridsize=12, boxsize=48.0, seed=22,
+                             dist='clustered', diff=4, fluid=dict(gridsize=12, count=2),
+                             particle_components=2),
 }
 
 
@@ -287,8 +301,151 @@ def child_rungs(name):
           'step2', out['rungs_N_step2'], 'integral calls', len(calls))
 
 
+def fluid_param_text(cfg):
+    g = cfg['gridsize']
+    if cfg.get('nonlinnu'):
+        return f"""
+boxsize = {cfg['boxsize']!r}*Mpc
+potential_options = {{
+    'gridsize': {{'global': {{'gravity': {{'pm': {g}, 'p3m': {2*g}}}}}}},
+}}
+H0 = 70*km/s/Mpc
+Ωcdm = 0.25
+Ωb = 0.05
+a_begin = 0.5
+enable_class_background = False
+select_forces = {{'particles': {{'gravity': 'p3m'}}, 'fluid': {{'gravity': 'pm'}}}}
+select_boltzmann_closure = {{'all': 'truncate'}}
+select_approximations = {{'all': {{'P=wρ': True}}}}
+select_softening_length = {{'particles': '0.03*boxsize/cbrt(N)'}}
+"""
+    return f"""
+boxsize = {cfg['boxsize']!r}*Mpc
+potential_options = {{
+    'gridsize': {{'global': {{'gravity': {{'pm': {g}}}}}, 'particles': {{'gravity': {{'pm': {g}}}}}}},
+    'differentiation': {{'particles': {{'gravity': {{'pm': {cfg['diff']}}}}},
+                        'fluid': {{'gravity': {{'pm': 2}}}}}},
+}}
+H0 = 70*km/s/Mpc
+Ωcdm = 0.25
+Ωb = 0.05
+a_begin = 0.5
+enable_class_background = False
+select_forces = {{'all': {{'gravity': 'pm'}}}}
+select_boltzmann_closure = {{'all': 'truncate'}}
+select_approximations = {{'all': {{'P=wρ': True}}}}
+"""
+
+
+def child_fluid(name):
+    """gravity('pm', receivers, suppliers, ...) with particle AND fluid components on equal
+    grid sizes (interactions.py:1985-2402): inputs, the momenta of every particle component
+    and the J grids of every fluid component afterwards, plus the k-space potential."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, 'oracle', 'refharness'))
+    from ref_import import load_reference
+    cfg = CASES[name]
+    ref = load_reference(fluid_param_text(cfg), f'/tmp/concept_golden_work/{name}')
+    commons, interactions, species = ref.commons, ref.interactions, ref.species
+    L = commons.boxsize
+    rng = np.random.default_rng(1000 + cfg['seed'])
+    out = dict(boxsize=L, gridsize=cfg['gridsize'], nghosts=commons.nghosts,
+               G_Newton=commons.G_Newton, light_speed=commons.light_speed, diff_order=cfg['diff'])
+    comps = []
+    npc = cfg.get('particle_components', 1)
+    pos_all = make_positions(np, cfg)
+    per = pos_all.shape[0]//npc
+    dt = 0.017
+    sdt = {'1': dt}
+    for c in range(npc):
+        pos = pos_all[c*per:(c + 1)*per]
+        N = pos.shape[0]
+        mass = commons.ρ_mbar*L**3/pos_all.shape[0]*(1.0 + 0.5*c)
+        mom = rng.normal(0, 1.0, size=(N, 3))*mass*0.01
+        nm = f'particles{c}'
+        comp = species.Component(nm, 'matter', N=N, mass=mass)
+        for d, s_ in enumerate('xyz'):
+            comp.populate(np.ascontiguousarray(pos[:, d]), 'pos' + s_)
+            comp.populate(np.ascontiguousarray(mom[:, d]), 'mom' + s_)
+        comps.append(comp)
+        sdt['a**(-3*w_eff)', nm] = dt*(1.1 + 0.1*c)
+        sdt['a**(-3*w_eff-1)', nm] = dt*(1.9 + 0.2*c)
+        out[f'p{c}_pos'] = np.array(comp.pos_mv3[:N]).copy()
+        out[f'p{c}_mom_in'] = np.array(comp.mom_mv3[:N]).copy()
+        out[f'p{c}_mass'] = mass
+        out[f'p{c}_dt_kick'] = sdt['a**(-3*w_eff)', nm]
+        out[f'p{c}_dt_dens'] = sdt['a**(-3*w_eff-1)', nm]
+    gs = cfg['fluid']['gridsize']
+    nfl = cfg['fluid'].get('count', 1)
+    for c in range(nfl):
+        nm = f'fluid{c}'
+        fl = species.Component(nm, 'matter', gridsize=gs, boltzmann_order=1)
+        rho = commons.ρ_mbar*(0.3 + 0.1*c)*(1 + 0.2*rng.normal(size=(gs, gs, gs)))
+        fl.populate(np.ascontiguousarray(rho), 'ϱ')
+        J = [0.01*commons.ρ_mbar*rng.normal(size=(gs, gs, gs)) for _ in range(3)]
+        for d in range(3):
+            fl.populate(np.ascontiguousarray(J[d]), 'J', d)
+        comps.append(fl)
+        sdt['a**(-3*w_eff)', nm] = dt*(0.7 + 0.1*c)
+        sdt['a**(-3*w_eff-1)', nm] = dt*(1.3 + 0.2*c)
+        out[f'f{c}_rho'] = np.array(fl.ϱ.grid_noghosts[:gs, :gs, :gs]).copy()
+        out[f'f{c}_P'] = np.array(fl.𝒫.grid_noghosts[:gs, :gs, :gs]).copy()
+        out[f'f{c}_J_in'] = np.stack([np.array(fl.J[d].grid_noghosts[:gs, :gs, :gs]).copy()
+                                      for d in range(3)])
+        out[f'f{c}_dt_kick'] = sdt['a**(-3*w_eff)', nm]
+        out[f'f{c}_dt_dens'] = sdt['a**(-3*w_eff-1)', nm]
+        out[f'f{c}_w_eff'] = fl.w_eff(a=commons.universals.a)
+    out['dt_1'] = dt
+    out['n_particle_components'] = npc
+    out['n_fluid_components'] = nfl
+    inter = interactions.find_interactions(comps, 'long-range')
+    out['n_interactions'] = len(inter)
+    out['interactions'] = np.array(
+        [f'{f}|{m}|' + ','.join(r.name for r in rec) + '|' + ','.join(u.name for u in sup)
+         for f, m, rec, sup in inter])
+    for comp in comps:
+        for force, dd in comp.potential_gridsizes.items():
+            for m, gsz in dd.items():
+                out[f'gridsizes_{comp.name}_{m}'] = np.array([gsz.upstream, gsz.downstream])
+        for force, dd in comp.potential_differentiations.items():
+            for m, od in dd.items():
+                out[f'differentiation_{comp.name}_{m}'] = od
+    if cfg.get('nonlinnu'):
+        out['shortrange_scale'] = commons.shortrange_params['gravity']['scale']
+        out['shortrange_range'] = commons.shortrange_params['gravity']['range']
+    # capture the k-space potential: fft(slab, 'backward') is called once per downstream
+    # subgroup; the first call's input is the (possibly deconvolved) downstream potential
+    cap = {}
+    orig_fft = interactions.fft
+
+    def fft_hook(slab, direction, *a, **k):
+        if direction == 'backward':
+            cap.setdefault('slab_k', []).append(np.array(slab).copy())
+        return orig_fft(slab, direction, *a, **k)
+    interactions.fft = fft_hook
+    for force, method, receivers, suppliers in inter:
+        getattr(interactions, force)(method, receivers, suppliers, sdt, 'long-range', False)
+    interactions.fft = orig_fft
+    for i, sk in enumerate(cap.get('slab_k', [])):
+        out[f'slab_k_before_backward_{i}'] = sk
+    ci = fi = 0
+    for comp in comps:
+        if comp.representation == 'particles':
+            out[f'p{ci}_mom_out'] = np.array(comp.mom_mv3[:comp.N]).copy()
+            ci += 1
+        else:
+            out[f'f{fi}_J_out'] = np.stack([np.array(comp.J[d].grid_noghosts[:gs, :gs, :gs]).copy()
+                                           for d in range(3)])
+            out[f'f{fi}_rho_out'] = np.array(comp.ϱ.grid_noghosts[:gs, :gs, :gs]).copy()
+            fi += 1
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, {k: getattr(v, 'shape', v) for k, v in out.items()})
+
+
 def child(name):
     import numpy as np
+    if 'fluid' in CASES[name]:
+        return child_fluid(name)
     if 'rungs' in CASES[name]:
         return child_rungs(name)
     if 'steps' in CASES[name]:

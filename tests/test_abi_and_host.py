@@ -68,3 +68,75 @@ def test_deposit_scalar_matches_oracle_expression():
     contribution *= mass
     contribution *= float(N)**(-3)*(N/L)**3
     assert contribution == oracle.deposit_contribution(mass, dt_dens, dt_1, N, L)
+
+
+class _Fake:
+    """what find_interactions() reads of a component"""
+
+    def __init__(self, name, representation, forces):
+        self.name, self.representation, self.forces = name, representation, forces
+
+    def __repr__(self):
+        return self.name
+
+
+def _describe(found):
+    return [f'{f}|{m}|' + ','.join(r.name for r in rec) + '|' + ','.join(s.name for s in sup)
+            for f, m, rec, sup in found]
+
+
+def test_find_interactions_matches_reference(golden):
+    """interactions.py:2456-2636 — against the lists the reference itself produced
+    (stored in the fluid goldens) and its documented splitting / merging rules."""
+    from concept_amd import interactions
+    g = golden('nonlinnu_like_n8')
+    part = _Fake('particles0', 'particles', {'gravity': 'p3m'})
+    fluid = _Fake('fluid0', 'fluid', {'gravity': 'pm'})
+    assert _describe(interactions.find_interactions([part, fluid], 'long-range')) == \
+        list(g['interactions'])
+    # short-range: only the P³M interaction survives, with the particle supplier
+    assert _describe(interactions.find_interactions([part, fluid], 'short-range')) == \
+        ['gravity|p3m|particles0|particles0']
+    g = golden('fluid2_pm_n6_g12')
+    comps = [_Fake(f'particles{i}', 'particles', {'gravity': 'pm'}) for i in range(2)]
+    comps += [_Fake(f'fluid{i}', 'fluid', {'gravity': 'pm'}) for i in range(2)]
+    assert _describe(interactions.find_interactions(comps, 'long-range')) == \
+        list(g['interactions'])
+    assert interactions.find_interactions(comps, 'short-range') == []
+    # two particle species on different methods supply each other
+    a = _Fake('a', 'particles', {'gravity': 'p3m'})
+    b = _Fake('b', 'particles', {'gravity': 'pm'})
+    assert _describe(interactions.find_interactions([a, b])) == \
+        ['gravity|p3m|a|a,b', 'gravity|pm|b|a,b']
+    from concept_amd.lib import ConceptGPUError
+    with pytest.raises(ConceptGPUError):
+        interactions.find_interactions([_Fake('c', 'particles', {'lapse': 'pm'})])
+    with pytest.raises(ConceptGPUError):
+        interactions.find_interactions([a], 'sideways')
+
+
+def test_group_components_ordering():
+    from concept_amd import interactions
+    cs = [_Fake('p', 'particles', {}), _Fake('f', 'fluid', {}), _Fake('q', 'particles', {})]
+    groups = interactions.group_components(cs, [32, 16, 16], [16, ...])
+    assert list(groups) == [16, 32]
+    assert [c.name for c in groups[16]['fluid']] == ['f']
+    assert [c.name for c in groups[16]['particles']] == ['q']
+    groups = interactions.group_components(cs, [32, 16, 64], [..., 32])
+    assert list(groups) == [16, 64, 32]
+    flat = interactions.group_components(cs, [4, 2, 4], [4, 2], split_representations=False)
+    assert [c.name for c in flat[4]] == ['p', 'q'] and list(flat) == [4, 2]
+
+
+def test_is_selected_precedence():
+    from concept_amd import commons
+    c = _Fake('Nu One', 'fluid', {})
+    c.species = 'neutrino'
+    d = {'default': 1, 'all': 2, 'fluid': 3, 'neutrino': 4, 'nu one': 5}
+    assert commons.is_selected(c, d) == 5
+    del d['nu one']
+    assert commons.is_selected(c, d) == 4
+    assert commons.is_selected(c, {'particles': 9}, default='none') == 'none'
+    merged = commons.is_selected(c, {'all': {'gravity': 'pm', 'x': 1}, 'fluid': {'x': 2}},
+                                 accumulate=True)
+    assert merged == {'gravity': 'pm', 'x': 2}

@@ -215,3 +215,58 @@ def test_adaptive_rungs_sequence(golden):
         check(f'step{step}', f'rungs_step{step}')
         assert np.array_equal(p.rungs_N, g[f'rungs_N_step{step}'])
     assert int(g['rungs_N_step2'][3]) != int(g['rungs_N_init'][3])  # jumps did happen
+
+
+# ---- fluid coupling (oracle/pm_general.py) --------------------
+def _fluid_components(g, particle_diff):
+    comps = []
+    for c in range(int(g['n_particle_components'])):
+        comps.append(dict(kind='particles', pos=g[f'p{c}_pos'], mom=g[f'p{c}_mom_in'].copy(),
+                          mass=float(g[f'p{c}_mass']), dt_dens=float(g[f'p{c}_dt_dens']),
+                          dt_kick=float(g[f'p{c}_dt_kick']), diff_order=particle_diff))
+    for c in range(int(g['n_fluid_components'])):
+        comps.append(dict(kind='fluid', rho=g[f'f{c}_rho'], P=g[f'f{c}_P'],
+                          J=g[f'f{c}_J_in'].copy(), dt_dens=float(g[f'f{c}_dt_dens']),
+                          dt_kick=float(g[f'f{c}_dt_kick']), diff_order=2))
+    return comps
+
+
+@pytest.mark.parametrize('name', ['fluid_pm_n8_g16', 'fluid2_pm_n6_g12'])
+def test_general_particle_mesh_bit_exact(golden, name):
+    """gravity('pm') with receivers = suppliers = particles + fluids: momenta, J grids and
+    the k-space potential handed to every backward FFT, bit for bit."""
+    from oracle import pm_general
+    g = golden(name)
+    comps = _fluid_components(g, int(g['diff_order']))
+    out = pm_general.particle_mesh(
+        comps, boxsize=float(g['boxsize']), gridsize=int(g['gridsize']),
+        G_Newton=float(g['G_Newton']), dt_1=float(g['dt_1']), light_speed=float(g['light_speed']))
+    npc = int(g['n_particle_components'])
+    for c in range(npc):
+        assert np.array_equal(comps[c]['mom'], g[f'p{c}_mom_out'])
+    for c in range(int(g['n_fluid_components'])):
+        assert np.array_equal(comps[npc + c]['J'], g[f'f{c}_J_out'])
+        assert np.abs(g[f'f{c}_J_out'] - g[f'f{c}_J_in']).max() > 0
+    for i, slab in enumerate(out['slab_before_backward']):
+        assert np.array_equal(slab, g[f'slab_k_before_backward_{i}'])
+
+
+def test_general_particle_mesh_nonlinnu_shape(golden):
+    """The three long-range interactions of an example_nonlinnu-shaped setup."""
+    from oracle import pm_general
+    g = golden('nonlinnu_like_n8')
+    assert list(g['interactions']) == ['gravity|p3m|particles0|particles0',
+                                       'gravity|pm|particles0|fluid0',
+                                       'gravity|pm|fluid0|particles0,fluid0']
+    part, fl = _fluid_components(g, 4)
+    kw = dict(boxsize=float(g['boxsize']), G_Newton=float(g['G_Newton']), dt_1=float(g['dt_1']),
+              light_speed=float(g['light_speed']))
+    gs = int(g['gridsize'])
+    scale = float(g['shortrange_scale'])*float(g['boxsize'])/(2*gs)
+    pm_general.particle_mesh([part], [part], gridsize=2*gs, shortrange_scale=scale, **kw)
+    part['diff_order'] = int(g['differentiation_particles0_pm'])
+    pm_general.particle_mesh([part], [fl], gridsize=gs, **kw)
+    pm_general.particle_mesh([fl], [part, fl], gridsize=gs, **kw)
+    assert np.array_equal(fl['J'], g['f0_J_out'])
+    kick = np.abs(g['p0_mom_out'] - g['p0_mom_in']).max()
+    assert np.abs(part['mom'] - g['p0_mom_out']).max() <= 1e-13*kick  # exp() of the cut-off
