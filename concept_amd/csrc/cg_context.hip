@@ -284,6 +284,21 @@ extern "C" int cg_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, 
                                op_add ? 1 : 0);
 }
 
+extern "C" int cg_copy_modes(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
+                             const double *shift, int op_add) {
+    CG_CHECK(onto && from, "cg_copy_modes: null context");
+    CG_SINGLE(onto, "cg_copy_modes");
+    CG_SINGLE(from, "cg_copy_modes");
+    CG_CHECK(onto->p.boxsize == from->p.boxsize, "cg_copy_modes: the two meshes span different boxes");
+    CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_copy_modes: deconv_order %d",
+             deconv_order);
+    CG_CHECK(nlattice == 1 || nlattice == 2 || nlattice == 4,
+             "cg_copy_modes: nlattice %d not in {1, 2, 4}", nlattice);
+    if (onto->N == from->N)
+        return cgk_fourier_operate(onto, from, deconv_order, nlattice, shift, -1, op_add ? 1 : 0);
+    return cgk_copy_modes(onto, from, deconv_order, nlattice, shift, op_add ? 1 : 0);
+}
+
 extern "C" int cg_mesh_copy(cg_ctx *dst, cg_ctx *src) {
     CG_CHECK(dst && src, "cg_mesh_copy: null context");
     CG_CHECK(dst->N == src->N && dst->mesh_doubles == src->mesh_doubles,

@@ -116,6 +116,55 @@ __global__ __launch_bounds__(256) void k_fourier_operate(const double2 *__restri
     }
 }
 
+// copy_modes between DIFFERENT grid sizes (mesh.py:1094-1326): one workgroup per (a, b)
+// row of the smaller grid, lanes over kk.  Deconvolution and lattice phase use the grid
+// size of `from` (fourier_loop's gridsize_corrections, mesh.py:1245-1250); the extra
+// rotation theta = (pi/N_onto - pi/N_from)*((ki + kj) + kk) re-centres the cell-centred
+// grid values (mesh.py:1302).
+struct CopyModes {
+    const double *tab_n, *tab_s;  // of the `from` context (indexed by ITS array index)
+    int deconv_order, shifted, op_add;
+    double A, B, Cc, dtheta, inv_lat;
+};
+__global__ __launch_bounds__(64) void k_copy_modes(const double2 *__restrict__ from, int N_from,
+                                                   i64 cp_from, double2 *__restrict__ onto,
+                                                   int N_onto, i64 cp_onto, CopyModes P) {
+#pragma clang fp contract(off)
+    const int N_small = N_from < N_onto ? N_from : N_onto;
+    const int nyq = N_small / 2;
+    const i64 rows = (i64)N_small * N_small;
+    for (i64 row = (i64)blockIdx.x; row < rows; row += gridDim.x) {
+        const int as = (int)(row / N_small), bs = (int)(row - (i64)as * N_small);
+        if (as == nyq || bs == nyq) continue;
+        const int ka = as - (as >= nyq ? N_small : 0), kb = bs - (bs >= nyq ? N_small : 0);
+        const int af = ka + (ka < 0 ? N_from : 0), bf = kb + (kb < 0 ? N_from : 0);
+        const int ao = ka + (ka < 0 ? N_onto : 0), bo = kb + (kb < 0 ? N_onto : 0);
+        const double2 *src = from + ((i64)af * N_from + bf) * cp_from;
+        double2 *dst = onto + ((i64)ao * N_onto + bo) * cp_onto;
+        double dab_n = 0, dab_d = 0;
+        if (P.deconv_order) {
+            dab_n = P.tab_n[af] * P.tab_n[bf];
+            dab_d = P.tab_s[af] * P.tab_s[bf];
+        }
+        for (int kk = threadIdx.x; kk < nyq; kk += blockDim.x) {
+            double factor = 1;
+            if (P.deconv_order) {
+                factor = (dab_n * P.tab_n[kk]) / (dab_d * P.tab_s[kk]);
+                double f = factor;
+                for (int o = 1; o < P.deconv_order; o++) factor *= f;
+            }
+            factor *= P.inv_lat;
+            double re = src[kk].x, im = src[kk].y;
+            double theta = P.dtheta * (double)((ka + kb) + kk);  // mesh.py:1302
+            if (P.shifted) theta += ((double)ka * P.A + (double)kb * P.B) + (double)kk * P.Cc;
+            double c = cos(theta), s = sin(theta);
+            double re2 = factor * (re * c - im * s), im2 = factor * (re * s + im * c);
+            if (P.op_add) dst[kk] = make_double2(dst[kk].x + re2, dst[kk].y + im2);
+            else dst[kk] = make_double2(re2, im2);
+        }
+    }
+}
+
 template <int ORDER>
 __global__ __launch_bounds__(256) void k_fluid_kick(double *__restrict__ J,
                                                     const double *__restrict__ rho,
@@ -190,6 +239,30 @@ int cgk_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlatti
     hipLaunchKernelGGL(k_fourier_operate, dim3(blocks_for(onto->N * onto->N, 1)), dim3(256), 0,
                        onto->stream, (const double2 *)from->mesh0, (double2 *)onto->mesh0,
                        (int)onto->N, onto->pad / 2, P);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cgk_copy_modes(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
+                   const double *shift, int op_add) {
+    const double kPiLocal = 3.141592653589793;
+    CopyModes P{};
+    P.tab_n = from->ktab_n;  // kk*pi/N_from + eps by array index of the `from` grid
+    P.tab_s = from->ktab_s;
+    P.deconv_order = deconv_order;
+    P.op_add = op_add;
+    P.shifted = shift && (shift[0] != 0 || shift[1] != 0 || shift[2] != 0);
+    if (P.shifted) {
+        P.A = -2 * kPiLocal / (double)from->N * shift[0];
+        P.B = -2 * kPiLocal / (double)from->N * shift[1];
+        P.Cc = -2 * kPiLocal / (double)from->N * shift[2];
+    }
+    P.dtheta = kPiLocal / (double)onto->N - kPiLocal / (double)from->N;
+    P.inv_lat = 1.0 / (double)nlattice;
+    i64 ns = onto->N < from->N ? onto->N : from->N;
+    hipLaunchKernelGGL(k_copy_modes, dim3(blocks_for(ns * ns, 1)), dim3(64), 0, onto->stream,
+                       (const double2 *)from->mesh0, (int)from->N, from->pad / 2,
+                       (double2 *)onto->mesh0, (int)onto->N, onto->pad / 2, P);
     CG_LAUNCH_CHECK();
     return 0;
 }

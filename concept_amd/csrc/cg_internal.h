@@ -165,6 +165,8 @@ int cgk_fluid_add(cg_ctx *c, const double *fluid, double factor, int op_add);
 int cgk_nullify_nyquist(cg_ctx *c);
 int cgk_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
                         const double *shift, int diff_dim, int op_add);
+int cgk_copy_modes(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
+                   const double *shift, int op_add);
 int cgk_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int dim,
                    int diff_order, double minus_dt, double inv_c2);
 int cgk_fft(cg_ctx *c, int what, int deconv_order, double C, int long_range, double E);

@@ -198,8 +198,9 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
     """interactions.py:1985-2335 with interpolate_upstream (mesh.py:492-635) and
     add_upstream_to_global_slabs (mesh.py:654-711), step for step, on one GPU: one mesh
     context per (grid size, role) plays the reference's named slabs.  Built: particle and
-    fluid suppliers / receivers on grid sizes equal to the global
-    one, CIC, 'sc' lattices, finite-difference gradients."""
+    fluid suppliers / receivers, upstream / downstream grid sizes
+    different from the global one (row 1b: copy_modes), CIC, 'sc' lattices,
+    finite-difference gradients."""
     p = receivers[0].params
     boxsize = p.boxsize
     dev = receivers[0].device
@@ -210,39 +211,54 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
         raise ConceptGPUError('interlacing is not built (SURVEY.md §8f-3)')
     gs_up = [s.potential_gridsizes[force][method].upstream for s in suppliers]
     gs_down = [r.potential_gridsizes[force][method].downstream for r in receivers]
-    if any(g != gridsize_global for g in gs_up + gs_down):
-        raise ConceptGPUError('upstream / downstream grid size ≠ global grid size is not built '
-                              '(copy_modes, SURVEY.md §8f-1b)')
-    for c in list(receivers) + list(suppliers):
-        if c.representation == 'fluid' and c.gridsize != gridsize_global:
+    for c, g in list(zip(suppliers, gs_up)) + list(zip(receivers, gs_down)):
+        if c.representation == 'fluid' and c.gridsize != g:
             raise ConceptGPUError(
                 f'add_fluid_to_grid() got component with global grid size {c.gridsize} and '
-                f'non-matching grid of global grid size {gridsize_global}')
+                f'non-matching grid of global grid size {g}')
 
-    def mesh_for(role):
-        return get_mesh(gridsize_global, boxsize, p.nghosts, p.cell_centered,
-                        interpolation_order, dev, role=role)
+    def mesh_for(gridsize, role):
+        return get_mesh(gridsize, boxsize, p.nghosts, p.cell_centered, interpolation_order, dev,
+                        role=role)
     # interactions.py:2049-2080: which deconvolutions are promoted to the global one
     only_particle_suppliers = all(s.representation == 'particles' for s in suppliers)
     only_particle_receivers = all(r.representation == 'particles' for r in receivers)
     deconv_order_global = 0
-    if deconvolve_upstream and only_particle_suppliers:
+    if (deconvolve_upstream and only_particle_suppliers
+            and all(g == gridsize_global for g in gs_up)):
         deconvolve_upstream = False
         deconv_order_global += 1
-    if deconvolve_downstream and only_particle_receivers:
+    if (deconvolve_downstream and only_particle_receivers
+            and all(g == gridsize_global for g in gs_down)):
         deconvolve_downstream = False
         deconv_order_global += 1
     deconv_order_global *= interpolation_order
-    # ---- interpolate_upstream (mesh.py:571-620): per upstream grid size, fluids then
-    # particles; each upstream slab is added onto the global one in Fourier space
-    fft_factor = float(gridsize_global)**(-3)  # mesh.py:582
+    # ---- interpolate_upstream (mesh.py:571-620): per upstream grid size (the global one
+    # first), fluids then particles; each upstream slab is added onto the global one in
+    # Fourier space (add_upstream_to_global_slabs, mesh.py:654-711)
     slab_global = None
+
+    def upstream_mesh(gridsize_upstream):
+        if slab_global is None and gridsize_upstream == gridsize_global:
+            return mesh_for(gridsize_global, 'global')
+        return mesh_for(gridsize_upstream, 'upstream')
+
+    def add_to_global(up, deconv_order):
+        nonlocal slab_global
+        if slab_global is None and up.gridsize == gridsize_global:
+            slab_global = up.fourier_operate(deconv_order)
+        elif slab_global is None:
+            slab_global = mesh_for(gridsize_global, 'global')
+            slab_global.copy_modes_from(up, deconv_order, operation='=')
+        else:
+            slab_global.copy_modes_from(up, deconv_order, operation='+=')
     groups = group_components(suppliers, gs_up, [gridsize_global, ...])
     for gridsize_upstream, group in groups.items():
+        fft_factor = float(gridsize_upstream)**(-3)  # mesh.py:582
         fluid_components = group.get('fluid', [])
         particle_components = group.get('particles', [])
         if fluid_components:
-            up = mesh_for('global' if slab_global is None else 'upstream')
+            up = upstream_mesh(gridsize_upstream)
             for i, fluid in enumerate(fluid_components):
                 # add_fluid_to_grid, quantity 'a²ρ' (mesh.py:1712-1717)
                 factor = fft_factor
@@ -250,30 +266,28 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
                 up.fluid_add(fluid.ϱ, factor, '=' if i == 0 else '+=')
             up.fft_forward()
             up.nullify_nyquist()
-            if slab_global is None:
-                slab_global = up  # fourier_operate(slab, 0, None) is the identity
-            else:
-                slab_global.fourier_operate(source=up, operation='+=')
+            add_to_global(up, 0)
         if particle_components:
-            up = mesh_for('global' if slab_global is None else 'upstream')
+            up = upstream_mesh(gridsize_upstream)
             up.zero()
             for supplier in particle_components:
                 up.deposit(supplier.pos, _particle_contribution(
                     supplier, ᔑdt, fft_factor, gridsize_upstream, boxsize))
             up.fft_forward()
             up.nullify_nyquist()
-            deconv_order = interpolation_order*int(bool(deconvolve_upstream))
-            if slab_global is None:
-                slab_global = up.fourier_operate(deconv_order)
-            else:
-                slab_global.fourier_operate(deconv_order, source=up, operation='+=')
+            add_to_global(up, interpolation_order*int(bool(deconvolve_upstream)))
     # ---- potential (interactions.py:2092-2120)
     C, long_range, E = _potential_constants(p, potential, gridsize_global)
     slab_global.poisson_kernel(deconv_order_global, C, long_range, E)
-    # ---- downstream (interactions.py:2124-2332)
+    # ---- downstream (interactions.py:2124-2332): per downstream grid size, the global one
+    # last (its slab may then be consumed)
     groups = group_components(receivers, gs_down, [..., gridsize_global])
     for gridsize_downstream, group in groups.items():
-        slab_downstream = slab_global
+        if gridsize_downstream == gridsize_global:
+            slab_downstream = slab_global
+        else:
+            slab_downstream = mesh_for(gridsize_downstream, 'downstream')
+            slab_downstream.copy_modes_from(slab_global, operation='=')
         for representation in ('fluid', 'particles'):
             if representation not in group:
                 continue
@@ -293,7 +307,7 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
                 if at_last_representation and at_last_order:
                     slab = slab_downstream  # may be mutated: nobody needs it afterwards
                 else:
-                    slab = mesh_for('subgroup')
+                    slab = mesh_for(gridsize_downstream, 'subgroup')
                     slab.copy_from(slab_downstream)
                 slab.fourier_operate(deconv_order_downstream)
                 slab.poisson_backward()

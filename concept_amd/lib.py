@@ -88,6 +88,7 @@ SYMBOLS = {
     'cg_fluid_add': (_int, [_vp, _vp, _dbl, _int]),
     'cg_fourier_nullify_nyquist': (_int, [_vp]),
     'cg_fourier_operate': (_int, [_vp, _vp, _int, _int, _vp, _int, _int]),
+    'cg_copy_modes': (_int, [_vp, _vp, _int, _int, _vp, _int]),
     'cg_mesh_copy': (_int, [_vp, _vp]),
     'cg_fluid_kick': (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl]),
 }

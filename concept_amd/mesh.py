@@ -164,6 +164,17 @@ class PotentialMesh:
                                     sh, int(diff_dim), int(operation == '+=')))
         return self
 
+    def copy_modes_from(self, source, deconv_order=0, nlattice=1, shift=(0.0, 0.0, 0.0),
+                        operation='='):
+        """copy_modes(source, self, ...) (mesh.py:1018-1326) for any two grid sizes.  With
+        operation '=' and different sizes this mesh is nullified first (mesh.py:686-709)."""
+        if source.gridsize != self.gridsize and operation == '=':
+            self.zero()
+        sh = (ctypes.c_double*3)(*[float(x) for x in shift])
+        check(_L.cg_copy_modes(self._ctx, source._ctx, int(deconv_order), int(nlattice), sh,
+                               int(operation == '+=')))
+        return self
+
     def copy_from(self, other):
         check(_L.cg_mesh_copy(self._ctx, other._ctx))
 

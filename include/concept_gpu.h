@@ -292,6 +292,15 @@ int cg_owner_rank(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n,
  *   shift = lattice.shift (HOST double[3], may be NULL); diff_dim -1 or 0..2.
  *   The caller applies the reference's early exits (nothing to do; a pure
  *   1/nlattice scaling still goes through this call).
+ * cg_copy_modes: copy_modes (mesh.py:1018-1326) between meshes of any two grid sizes
+ *   (SURVEY.md §8f row 1b): every mode of the smaller grid off its Nyquist planes goes
+ *   to the same wave vector of the other grid, rotated by
+ *   (pi/N_onto - pi/N_from)*(ki + kj + kk) (cell-centred grids of different spacing,
+ *   mesh.py:1302) plus the lattice phase, scaled by the deconvolution factor evaluated
+ *   with the grid size of `from`.  Modes of a larger `onto` beyond the cube, and its
+ *   Nyquist planes, are not touched: with op_add = 0 zero it first (cg_mesh_zero — the
+ *   reference's nullified get_fftw_slab, mesh.py:686-709).  Equal sizes forward to
+ *   cg_fourier_operate.
  * cg_mesh_copy: slab_downstream_subgroup[...] = slab_downstream
  *   (interactions.py:2242-2245, 2276-2279).
  * cg_fluid_kick: the fluid branch of apply_particle_mesh_force
@@ -302,6 +311,8 @@ int cg_fluid_add(cg_ctx *ctx, const double *fluid /*DEV N^3*/, double factor, in
 int cg_fourier_nullify_nyquist(cg_ctx *ctx);
 int cg_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
                        const double *shift /*HOST 3 or NULL*/, int diff_dim, int op_add);
+int cg_copy_modes(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
+                  const double *shift /*HOST 3 or NULL*/, int op_add);
 int cg_mesh_copy(cg_ctx *dst, cg_ctx *src);
 int cg_fluid_kick(cg_ctx *ctx, double *J_dim /*DEV N^3*/, const double *rho /*DEV N^3*/,
                   const double *P /*DEV N^3*/, int dim, int diff_order, double minus_dt,

@@ -336,3 +336,65 @@ void orc_fourier_operate(const double *from, double *onto, i64 N, int deconv_ord
         }
     }
 }
+
+/*
+ * copy_modes between slabs of DIFFERENT grid sizes (mesh.py:1094-1326), one rank.
+ * Every mode of the smaller grid off its Nyquist planes is read from `from` and stored
+ * to / added onto `onto` (both transposed slabs double[j][i][N+2] of their own size) as
+ *   theta_total = (pi/N_onto - pi/N_from)*((ki + kj) + kk)  [+ theta of the lattice]
+ *   (re, im) <- (factor*(re*cos - im*sin), factor*(re*sin + im*cos))
+ * with factor and the lattice phase from fourier_loop(gridsize_small,
+ * gridsize_corrections = N_from, ...) (mesh.py:1245-1250): deconvolution and shift use
+ * the grid size the data was interpolated on.
+ */
+void orc_copy_modes(const double *from, i64 N_from, double *onto, i64 N_onto, int deconv_order,
+                    int nlattice, const double *shift, int op_add, double machine_eps) {
+    const double pi = 3.141592653589793;
+    i64 N_small = N_from < N_onto ? N_from : N_onto;
+    double pi_over_n = pi / (double)N_from; /* gridsize_corrections = gridsize_from */
+    double inv_lat = 1.0 / (double)nlattice;
+    int shifted = shift && (shift[0] != 0 || shift[1] != 0 || shift[2] != 0);
+    double A = 0, B = 0, Cc = 0;
+    if (shifted) {
+        A = -2 * pi / (double)N_from * shift[0];
+        B = -2 * pi / (double)N_from * shift[1];
+        Cc = -2 * pi / (double)N_from * shift[2];
+    }
+    double dtheta = pi / (double)N_onto - pi / (double)N_from;
+    i64 nyq = N_small / 2;
+    i64 pad_f = N_from + 2, pad_o = N_onto + 2;
+    for (i64 js = 0; js < N_small; js++) {
+        if (js == nyq) continue;
+        i64 kj = js - (js >= nyq ? N_small : 0);
+        double dj_n = (double)kj * pi_over_n + machine_eps;
+        double dj_d = sin(dj_n);
+        i64 jf = kj + (kj < 0 ? N_from : 0), jo = kj + (kj < 0 ? N_onto : 0);
+        for (i64 is = 0; is < N_small; is++) {
+            if (is == nyq) continue;
+            i64 ki = is - (is >= nyq ? N_small : 0);
+            double di_n = (double)ki * pi_over_n + machine_eps;
+            double di_d = sin(di_n);
+            double dij_n = di_n * dj_n, dij_d = di_d * dj_d;
+            i64 i_f = ki + (ki < 0 ? N_from : 0), i_o = ki + (ki < 0 ? N_onto : 0);
+            const double *src = from + (jf * N_from + i_f) * pad_f;
+            double *dst = onto + (jo * N_onto + i_o) * pad_o;
+            for (i64 kk = 0; kk < nyq; kk++) {
+                double factor = 1;
+                if (deconv_order) {
+                    double dk_n = (double)kk * pi_over_n + machine_eps;
+                    double dk_d = sin(dk_n);
+                    factor = (dij_n * dk_n) / (dij_d * dk_d);
+                    factor = pow(factor, (double)deconv_order);
+                }
+                factor *= inv_lat;
+                double re = src[2 * kk], im = src[2 * kk + 1];
+                double theta_total = dtheta * (double)((ki + kj) + kk);
+                if (shifted) theta_total += ((double)ki * A + (double)kj * B) + (double)kk * Cc;
+                double c = cos(theta_total), s = sin(theta_total);
+                double re2 = factor * (re * c - im * s), im2 = factor * (re * s + im * c);
+                if (op_add) { dst[2 * kk] += re2; dst[2 * kk + 1] += im2; }
+                else { dst[2 * kk] = re2; dst[2 * kk + 1] = im2; }
+            }
+        }
+    }
+}

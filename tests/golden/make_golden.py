@@ -72,6 +72,17 @@ CASES = {
     # (p3m, [particles], [particles]), (pm, [particles], [fluid]), (pm, [fluid], [particles, fluid])
     'nonlinnu_like_n8': dict(method='pm', n=8, gridsize=16, boxsize=32.0, seed=23,
                              dist='uniform', diff=2, fluid=dict(gridsize=16), nonlinnu=True),
+    # unequal upstream / global / downstream grid sizes (copy_modes
+    # up- and down-scaling with the cell-centring phase, mesh.py:1018-1326): global 16,
+    # particles0 (up 24, down 12), particles1 (up 16, down 32), fluid on its own grid 8
+    'multigrid_n8_g16': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=24,
+                             dist='clustered', diff=2, fluid=dict(gridsize=8),
+                             particle_components=2,
+                             component_gridsizes={'particles0': (24, 12), 'particles1': (16, 32)}),
+    # particles only, one component: upstream 32 -> global 16 -> downstream 24, order 4
+    'multigrid_n8_up32_down24': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=25,
+                                     dist='uniform', diff=4, fluid=dict(gridsize=8, count=0),
+                                     component_gridsizes={'particles0': (32, 24)}),
     'fluid2_pm_n6_g12': dict(method='pm', n=6, gridsize=12, boxsize=48.0, seed=22,
                              dist='clustered', diff=4, fluid=dict(gridsize=12, count=2),
                              particle_components=2),
@@ -319,10 +330,12 @@ select_boltzmann_closure = {{'all': 'truncate'}}
 select_approximations = {{'all': {{'P=wρ': True}}}}
 select_softening_length = {{'particles': '0.03*boxsize/cbrt(N)'}}
 """
+    own = ''.join(f"'{k}': {{'gravity': {{'pm': {v!r}}}}}, "
+                  for k, v in cfg.get('component_gridsizes', {}).items())
     return f"""
 boxsize = {cfg['boxsize']!r}*Mpc
 potential_options = {{
-    'gridsize': {{'global': {{'gravity': {{'pm': {g}}}}}, 'particles': {{'gravity': {{'pm': {g}}}}}}},
+    'gridsize': {{'global': {{'gravity': {{'pm': {g}}}}}, 'particles': {{'gravity': {{'pm': {g}}}}}, {own}}},
     'differentiation': {{'particles': {{'gravity': {{'pm': {cfg['diff']}}}}},
                         'fluid': {{'gravity': {{'pm': 2}}}}}},
 }}

@@ -224,6 +224,9 @@ def _fluid_components(g, particle_diff):
         comps.append(dict(kind='particles', pos=g[f'p{c}_pos'], mom=g[f'p{c}_mom_in'].copy(),
                           mass=float(g[f'p{c}_mass']), dt_dens=float(g[f'p{c}_dt_dens']),
                           dt_kick=float(g[f'p{c}_dt_kick']), diff_order=particle_diff))
+        if f'gridsizes_particles{c}_pm' in g:
+            up, down = (int(v) for v in g[f'gridsizes_particles{c}_pm'])
+            comps[-1].update(gridsize_up=up, gridsize_down=down)
     for c in range(int(g['n_fluid_components'])):
         comps.append(dict(kind='fluid', rho=g[f'f{c}_rho'], P=g[f'f{c}_P'],
                           J=g[f'f{c}_J_in'].copy(), dt_dens=float(g[f'f{c}_dt_dens']),
@@ -231,10 +234,12 @@ def _fluid_components(g, particle_diff):
     return comps
 
 
-@pytest.mark.parametrize('name', ['fluid_pm_n8_g16', 'fluid2_pm_n6_g12'])
+@pytest.mark.parametrize('name', ['fluid_pm_n8_g16', 'fluid2_pm_n6_g12', 'multigrid_n8_g16',
+                                  'multigrid_n8_up32_down24'])
 def test_general_particle_mesh_bit_exact(golden, name):
     """gravity('pm') with receivers = suppliers = particles + fluids: momenta, J grids and
-    the k-space potential handed to every backward FFT, bit for bit."""
+    the k-space potential handed to every backward FFT, bit for bit; the multigrid cases
+    add upstream / downstream grid sizes different from the global one (copy_modes)."""
     from oracle import pm_general
     g = golden(name)
     comps = _fluid_components(g, int(g['diff_order']))
