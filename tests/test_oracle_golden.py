@@ -268,8 +268,12 @@ def test_general_particle_mesh_nonlinnu_shape(golden):
               light_speed=float(g['light_speed']))
     gs = int(g['gridsize'])
     scale = float(g['shortrange_scale'])*float(g['boxsize'])/(2*gs)
+    up, down = (int(v) for v in g['gridsizes_particles0_p3m'])
+    part.update(gridsize_up=up, gridsize_down=down)
     pm_general.particle_mesh([part], [part], gridsize=2*gs, shortrange_scale=scale, **kw)
     part['diff_order'] = int(g['differentiation_particles0_pm'])
+    up, down = (int(v) for v in g['gridsizes_particles0_pm'])
+    part.update(gridsize_up=up, gridsize_down=down)
     pm_general.particle_mesh([part], [fl], gridsize=gs, **kw)
     pm_general.particle_mesh([fl], [part, fl], gridsize=gs, **kw)
     assert np.array_equal(fl['J'], g['f0_J_out'])
