@@ -33,6 +33,18 @@ static CicGeom make_geom(double cellsize, int nghosts, int cell_centered, const 
     g.scale = (1 / cellsize) * (1 - kMachineEps);
     return g;
 }
+// the same with an interlacing lattice shift: sign = -1 for interpolate_particles
+// (mesh.py:1577-1589), +1 for interpolate_domaingrid_to_particles (mesh.py:409-420)
+static CicGeom make_geom_shift(double cellsize, int nghosts, int cell_centered,
+                               const double *shift, int sign) {
+    CicGeom g;
+    for (int d = 0; d < 3; d++) {
+        double sh = shift ? shift[d] : 0.0;
+        g.off[d] = 0.0 - (1 + kMachineEps) * (nghosts - 0.5 * cell_centered + sign * sh) * cellsize;
+    }
+    g.scale = (1 / cellsize) * (1 - kMachineEps);
+    return g;
+}
 
 static int make_plans(cg_ctx *c) {
     // In-place 3-D R2C / C2R on the padded layout FFTW uses (fft.c:34-73):
@@ -299,6 +311,43 @@ extern "C" int cg_copy_modes(cg_ctx *onto, cg_ctx *from, int deconv_order, int n
     return cgk_copy_modes(onto, from, deconv_order, nlattice, shift, op_add ? 1 : 0);
 }
 
+extern "C" int cg_deposit(cg_ctx *c, const double *pos, int64_t n, double contribution, int order,
+                          const double *shift) {
+    CG_CHECK(c && (pos || n == 0), "cg_deposit: null argument");
+    CG_SINGLE(c, "cg_deposit");
+    CG_CHECK(order >= 1 && order <= 4,
+             "interpolate_particles() called with order = %d not in {1 (NGP), 2 (CIC), 3 (TSC), 4 (PCS)}",
+             order);
+    double cellsize = c->p.boxsize / (double)c->p.gridsize;  // mesh.py:1576
+    return cgk_deposit_general(c, pos, n, contribution, order,
+                               make_geom_shift(cellsize, c->p.nghosts, c->p.cell_centered, shift, -1));
+}
+
+extern "C" int cg_gather_scalar(cg_ctx *c, const double *pos, double *mom, int64_t n, int dim,
+                                int order, const double *shift, double factor) {
+    CG_CHECK(c && ((pos && mom) || n == 0), "cg_gather_scalar: null argument");
+    CG_SINGLE(c, "cg_gather_scalar");
+    CG_CHECK(order >= 1 && order <= 4,
+             "interpolate_domaingrid_to_particles() called with order = %d not in {1, 2, 3, 4}",
+             order);
+    CG_CHECK(dim >= 0 && dim < 3,
+             "apply_particle_mesh_force() called with dim = %d not in {0, 1, 2}", dim);
+    double cellsize = c->p.boxsize / (double)c->p.gridsize;  // mesh.py:408 (one domain)
+    return cgk_gather_scalar(c, pos, mom, n, dim, order,
+                             make_geom_shift(cellsize, c->p.nghosts, c->p.cell_centered, shift, +1),
+                             factor);
+}
+
+extern "C" int cg_mesh_diff(cg_ctx *dst, cg_ctx *src, int dim, int diff_order) {
+    CG_CHECK(dst && src && dst != src, "cg_mesh_diff: two distinct contexts are needed");
+    CG_SINGLE(src, "cg_mesh_diff");
+    CG_CHECK(dst->N == src->N && dst->pad == src->pad, "cg_mesh_diff: the two meshes differ in shape");
+    CG_CHECK(dim >= 0 && dim < 3, "diff_domaingrid() called with dim = %d not in {0, 1, 2}", dim);
+    CG_CHECK(diff_order == 2 || diff_order == 4,
+             "cg_mesh_diff: differentiation order %d (2 and 4 are built)", diff_order);
+    return cgk_mesh_diff(dst, src, dim, diff_order);
+}
+
 extern "C" int cg_mesh_copy(cg_ctx *dst, cg_ctx *src) {
     CG_CHECK(dst && src, "cg_mesh_copy: null context");
     CG_CHECK(dst->N == src->N && dst->mesh_doubles == src->mesh_doubles,
@@ -314,9 +363,9 @@ extern "C" int cg_fluid_kick(cg_ctx *c, double *J, const double *rho, const doub
     CG_SINGLE(c, "cg_fluid_kick");
     CG_CHECK(dim >= 0 && dim < 3,
              "apply_particle_mesh_force() called with dim = %d not in {0, 1, 2}", dim);
-    CG_CHECK(diff_order == 2 || diff_order == 4,
-             "cg_fluid_kick: differentiation order %d (2 and 4 are built; nghosts = 2 "
-             "admits no higher symmetric order)", diff_order);
+    CG_CHECK(diff_order == 0 || diff_order == 2 || diff_order == 4,
+             "cg_fluid_kick: differentiation order %d (0 = the mesh holds the force, 2 and 4 are "
+             "built; nghosts = 2 admits no higher symmetric order)", diff_order);
     return cgk_fluid_kick(c, J, rho, P, dim, diff_order, minus_dt, inv_c2);
 }
 

@@ -187,10 +187,153 @@ __global__ __launch_bounds__(256) void k_fluid_kick(double *__restrict__ J,
             return mesh[((i64)ii * N + jj) * pad + kk];
         };
         double g;
-        if (ORDER == 2) g = c1 * (phi(1) - phi(-1));                          // mesh.py:4967
+        if (ORDER == 0) g = phi(0);  // the mesh already holds the force (Fourier-space gradient)
+        else if (ORDER == 2) g = c1 * (phi(1) - phi(-1));                     // mesh.py:4967
         else g = c1 * (phi(1) - phi(-1)) - c2 * (phi(2) - phi(-2));           // mesh.py:4973-4977
         // Jᵢ += ℝ[-ᔑdt]*(ϱ + ℝ[c⁻²]*𝒫)*grid   (interactions.py:2397-2400)
         J[t] += mdt * (rho[t] + inv_c2 * P[t]) * g;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Particle interpolation of every order: set_weights_NGP / CIC /
+// TSC / PCS (mesh.py:5305-5394) and the loops over ORDER^3 grid points
+// (mesh.py:5052-5283), with the coordinate map of interpolate_particles
+// (mesh.py:1577-1606, lattice shift subtracted) or interpolate_domaingrid_to_particles
+// (mesh.py:409-432, lattice shift added) in `geo`.  Direct form: one lane per particle,
+// device-scope FP64 atomics for the deposit (these orders are accuracy options, not the
+// benchmarked path; the tiled CIC kernels keep the default configuration).
+// ---------------------------------------------------------------------------
+template <int ORDER>
+__device__ __forceinline__ int set_weights(double x, double (&w)[4]) {
+#pragma clang fp contract(off)
+    if (ORDER == 1) {
+        int index = (int)(x + 0.5);
+        w[0] = 1;
+        return index;
+    }
+    if (ORDER == 2) {
+        int index = (int)x;
+        double dist = x - (double)index;
+        w[0] = 1 - dist;
+        w[1] = dist;
+        return index;
+    }
+    if (ORDER == 3) {
+        int index = (int)(x + 0.5);
+        double dist = x - (double)index;
+        index -= 1;
+        double dist2 = dist * dist;
+        double weight0 = 0.125 + 0.5 * (dist2 - dist);
+        double weight1 = 0.75 - dist2;
+        w[0] = weight0;
+        w[1] = weight1;
+        w[2] = 1 - weight0 - weight1;
+        return index;
+    }
+    int index = (int)x;
+    index -= 1;
+    double dist = x - (double)index;
+    double tmp = 2 - dist;
+    double tmp2 = tmp * tmp;
+    double tmp3 = tmp * tmp2;
+    double weight0 = 1. / 6. * tmp3;
+    double weight2 = 2. / 3. - tmp2 + 0.5 * tmp3;
+    double d1 = dist - 1;
+    double weight3 = 1. / 6. * (d1 * d1 * d1);
+    w[0] = weight0;
+    w[1] = 1 - weight0 - weight2 - weight3;
+    w[2] = weight2;
+    w[3] = weight3;
+    return index;
+}
+__device__ __forceinline__ int wrap32(int a, int n) {
+    a = a < 0 ? a + n : a;
+    return a >= n ? a - n : a;
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void k_deposit_general(const double *__restrict__ pos, i64 n,
+                                                         double *__restrict__ mesh, int N, i64 pad,
+                                                         int g, CicGeom geo, double contribution) {
+#pragma clang fp contract(off)
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        double wx[4], wy[4], wz[4];
+        int ii = set_weights<ORDER>((pos[3 * p + 0] - geo.off[0]) * geo.scale, wx) - g;
+        int jj = set_weights<ORDER>((pos[3 * p + 1] - geo.off[1]) * geo.scale, wy) - g;
+        int kk = set_weights<ORDER>((pos[3 * p + 2] - geo.off[2]) * geo.scale, wz) - g;
+#pragma unroll
+        for (int i = 0; i < ORDER; i++) {
+            double weight_i = wx[i];
+            weight_i *= contribution;  // apply_factor = True
+            const i64 ri = (i64)wrap32(ii + i, N) * N;
+#pragma unroll
+            for (int j = 0; j < ORDER; j++) {
+                double wij = weight_i * wy[j];
+                double *row = mesh + (ri + wrap32(jj + j, N)) * pad;
+#pragma unroll
+                for (int k = 0; k < ORDER; k++)
+                    unsafeAtomicAdd(row + wrap32(kk + k, N), ORDER == 1 ? weight_i : wij * wz[k]);
+            }
+        }
+    }
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void k_gather_scalar(const double *__restrict__ pos,
+                                                       double *__restrict__ mom, i64 n, int dim,
+                                                       const double *__restrict__ mesh, int N,
+                                                       i64 pad, int g, CicGeom geo,
+                                                       double factor) {
+#pragma clang fp contract(off)
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        double wx[4], wy[4], wz[4];
+        int ii = set_weights<ORDER>((pos[3 * p + 0] - geo.off[0]) * geo.scale, wx) - g;
+        int jj = set_weights<ORDER>((pos[3 * p + 1] - geo.off[1]) * geo.scale, wy) - g;
+        int kk = set_weights<ORDER>((pos[3 * p + 2] - geo.off[2]) * geo.scale, wz) - g;
+        double value = 0;
+#pragma unroll
+        for (int i = 0; i < ORDER; i++) {
+            const i64 ri = (i64)wrap32(ii + i, N) * N;
+#pragma unroll
+            for (int j = 0; j < ORDER; j++) {
+                double wij = wx[i] * wy[j];
+                const double *row = mesh + (ri + wrap32(jj + j, N)) * pad;
+#pragma unroll
+                for (int k = 0; k < ORDER; k++)
+                    value += row[wrap32(kk + k, N)] * (ORDER == 1 ? 1.0 : wij * wz[k]);
+            }
+        }
+        if (factor != 1) value *= factor;  // mesh.py:456-458
+        mom[3 * p + dim] += value;
+    }
+}
+
+// diff_domaingrid (mesh.py:4874-5030) of the real-space mesh of `src` into `dst`
+template <int ORDER>
+__global__ __launch_bounds__(256) void k_mesh_diff(double *__restrict__ dst,
+                                                   const double *__restrict__ src, int N, i64 pad,
+                                                   int dim, double c1, double c2) {
+#pragma clang fp contract(off)
+    const i64 total = (i64)N * N * N;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (i64)gridDim.x * blockDim.x) {
+        i64 row = t / N;
+        int k = (int)(t - row * N);
+        int i = (int)(row / N), j = (int)(row - (i64)i * N);
+        auto phi = [&](int s) {
+            int ii = i, jj = j, kk = k;
+            if (dim == 0) ii = wrap32(i + s, N);
+            else if (dim == 1) jj = wrap32(j + s, N);
+            else kk = wrap32(k + s, N);
+            return src[((i64)ii * N + jj) * pad + kk];
+        };
+        double gval;
+        if (ORDER == 2) gval = c1 * (phi(1) - phi(-1));
+        else gval = c1 * (phi(1) - phi(-1)) - c2 * (phi(2) - phi(-2));
+        dst[row * pad + k] = gval;
     }
 }
 
@@ -271,7 +414,11 @@ int cgk_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int
                    int diff_order, double minus_dt, double inv_c2) {
     i64 total = c->N * c->N * c->N;
     double dx = c->p.boxsize / (double)c->N;  // interactions.py:2133
-    if (diff_order == 2) {
+    if (diff_order == 0) {
+        hipLaunchKernelGGL(k_fluid_kick<0>, dim3(blocks_for(total, 256)), dim3(256), 0,
+                           c->stream, J, rho, P, c->mesh0, (int)c->N, c->pad, dim, 0.0, 0.0,
+                           minus_dt, inv_c2);
+    } else if (diff_order == 2) {
         double c1 = (1.0 / 2) / dx;
         hipLaunchKernelGGL(k_fluid_kick<2>, dim3(blocks_for(total, 256)), dim3(256), 0,
                            c->stream, J, rho, P, c->mesh0, (int)c->N, c->pad, dim, c1, 0.0,
@@ -281,6 +428,47 @@ int cgk_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int
         hipLaunchKernelGGL(k_fluid_kick<4>, dim3(blocks_for(total, 256)), dim3(256), 0,
                            c->stream, J, rho, P, c->mesh0, (int)c->N, c->pad, dim, c1, c2,
                            minus_dt, inv_c2);
+    }
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+#define CG_ORDER_SWITCH(order, KERNEL, ...)                                       \
+    switch (order) {                                                              \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break;                \
+        default: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;               \
+    }
+
+int cgk_deposit_general(cg_ctx *c, const double *pos, i64 n, double contribution, int order,
+                        const CicGeom &geo) {
+    if (n == 0) return 0;
+    CG_ORDER_SWITCH(order, k_deposit_general, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream,
+                    pos, n, c->mesh0, (int)c->N, c->pad, c->p.nghosts, geo, contribution)
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cgk_gather_scalar(cg_ctx *c, const double *pos, double *mom, i64 n, int dim, int order,
+                      const CicGeom &geo, double factor) {
+    if (n == 0) return 0;
+    CG_ORDER_SWITCH(order, k_gather_scalar, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream,
+                    pos, mom, n, dim, c->mesh0, (int)c->N, c->pad, c->p.nghosts, geo, factor)
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cgk_mesh_diff(cg_ctx *dst, cg_ctx *src, int dim, int diff_order) {
+    i64 total = src->N * src->N * src->N;
+    double dx = src->p.boxsize / (double)src->N;
+    if (diff_order == 2) {
+        hipLaunchKernelGGL(k_mesh_diff<2>, dim3(blocks_for(total, 256)), dim3(256), 0, dst->stream,
+                           dst->mesh0, src->mesh0, (int)src->N, src->pad, dim, (1.0 / 2) / dx, 0.0);
+    } else {
+        hipLaunchKernelGGL(k_mesh_diff<4>, dim3(blocks_for(total, 256)), dim3(256), 0, dst->stream,
+                           dst->mesh0, src->mesh0, (int)src->N, src->pad, dim, (2.0 / 3) / dx,
+                           (1.0 / 12) / dx);
     }
     CG_LAUNCH_CHECK();
     return 0;

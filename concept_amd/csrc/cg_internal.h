@@ -167,6 +167,11 @@ int cgk_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlatti
                         const double *shift, int diff_dim, int op_add);
 int cgk_copy_modes(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
                    const double *shift, int op_add);
+int cgk_deposit_general(cg_ctx *c, const double *pos, i64 n, double contribution, int order,
+                        const CicGeom &geo);
+int cgk_gather_scalar(cg_ctx *c, const double *pos, double *mom, i64 n, int dim, int order,
+                      const CicGeom &geo, double factor);
+int cgk_mesh_diff(cg_ctx *dst, cg_ctx *src, int dim, int diff_order);
 int cgk_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int dim,
                    int diff_order, double minus_dt, double inv_c2);
 int cgk_fft(cg_ctx *c, int what, int deconv_order, double C, int long_range, double E);

@@ -74,7 +74,9 @@ def _default_fast_path(receivers, suppliers, gridsize_global, force, method, int
     if any(r.potential_gridsizes[force][method].downstream != gridsize_global
            for r in receivers):
         return False
-    if interpolation_order != 2 or (interlace_upstream, interlace_downstream) != ('sc', 'sc'):
+    if interpolation_order != 2:
+        return False
+    if any(len(lattice_shifts(x)) != 1 for x in (interlace_upstream, interlace_downstream)):
         return False
     return all(r.potential_differentiations[force][method] in (2, 4) for r in receivers)
 
@@ -191,6 +193,25 @@ def group_components(components, gridsizes, gridsizes_order=(), split_representa
     return groups
 
 
+def lattice_shifts(kind, cell_centered=True):
+    """Lattice (mesh.py:77-182): the primitive simple-cubic sub-lattices of 'sc', 'bcc'
+    (body-centred) and 'fcc' (face-centred) as shifts in grid units."""
+    kind = (kind or 'sc').lower()
+    if 'simple' in kind:
+        kind = 'sc'
+    elif 'body' in kind:
+        kind = 'bcc'
+    elif 'face' in kind:
+        kind = 'fcc'
+    a = (1 - 2*cell_centered)*0.5
+    table = {'sc': [(0, 0, 0)],
+             'bcc': [(0, 0, 0), (a, a, a)],
+             'fcc': [(0, 0, 0), (0, a, a), (a, 0, a), (a, a, 0)]}
+    if kind not in table:
+        raise ConceptGPUError(f'Unrecognized lattice "{kind}" ∉ {set(table)}')
+    return table[kind]
+
+
 def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force, method,
                           potential, interpolation_order, deconvolve_upstream,
                           deconvolve_downstream, interlace_upstream, interlace_downstream,
@@ -199,16 +220,17 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
     add_upstream_to_global_slabs (mesh.py:654-711), step for step, on one GPU: one mesh
     context per (grid size, role) plays the reference's named slabs.  Built: particle and
     fluid suppliers / receivers, upstream / downstream grid sizes
-    different from the global one (row 1b: copy_modes), CIC, 'sc' lattices,
-    finite-difference gradients."""
+    different from the global one (row 1b: copy_modes), interpolation orders NGP / CIC /
+    TSC / PCS, interlacing on 'bcc' / 'fcc' lattices, finite-difference (2, 4) and
+    Fourier-space (0) gradients (row 3)."""
     p = receivers[0].params
     boxsize = p.boxsize
     dev = receivers[0].device
-    if interpolation_order != 2:
-        raise ConceptGPUError(f'interpolation order {interpolation_order}: only CIC (2) is built '
-                              '(SURVEY.md §8f-3)')
-    if (interlace_upstream, interlace_downstream) != ('sc', 'sc'):
-        raise ConceptGPUError('interlacing is not built (SURVEY.md §8f-3)')
+    if not 1 <= interpolation_order <= 4:
+        raise ConceptGPUError(
+            f'interpolate_particles() called with order = {interpolation_order} '
+            f'∉ {{1 (NGP), 2 (CIC), 3 (TSC), 4 (PCS)}}')
+    shifts_upstream = lattice_shifts(interlace_upstream, p.cell_centered)
     gs_up = [s.potential_gridsizes[force][method].upstream for s in suppliers]
     gs_down = [r.potential_gridsizes[force][method].downstream for r in receivers]
     for c, g in list(zip(suppliers, gs_up)) + list(zip(receivers, gs_down)):
@@ -218,8 +240,7 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
                 f'non-matching grid of global grid size {g}')
 
     def mesh_for(gridsize, role):
-        return get_mesh(gridsize, boxsize, p.nghosts, p.cell_centered, interpolation_order, dev,
-                        role=role)
+        return get_mesh(gridsize, boxsize, p.nghosts, p.cell_centered, 2, dev, role=role)
     # interactions.py:2049-2080: which deconvolutions are promoted to the global one
     only_particle_suppliers = all(s.representation == 'particles' for s in suppliers)
     only_particle_receivers = all(r.representation == 'particles' for r in receivers)
@@ -234,8 +255,8 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
         deconv_order_global += 1
     deconv_order_global *= interpolation_order
     # ---- interpolate_upstream (mesh.py:571-620): per upstream grid size (the global one
-    # first), fluids then particles; each upstream slab is added onto the global one in
-    # Fourier space (add_upstream_to_global_slabs, mesh.py:654-711)
+    # first), fluids then particles (once per sub-lattice); each upstream slab is added
+    # onto the global one in Fourier space (add_upstream_to_global_slabs, mesh.py:654-711)
     slab_global = None
 
     def upstream_mesh(gridsize_upstream):
@@ -243,15 +264,15 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
             return mesh_for(gridsize_global, 'global')
         return mesh_for(gridsize_upstream, 'upstream')
 
-    def add_to_global(up, deconv_order):
+    def add_to_global(up, deconv_order, nlattice=1, shift=(0, 0, 0)):
         nonlocal slab_global
         if slab_global is None and up.gridsize == gridsize_global:
-            slab_global = up.fourier_operate(deconv_order)
+            slab_global = up.fourier_operate(deconv_order, nlattice, shift)
         elif slab_global is None:
             slab_global = mesh_for(gridsize_global, 'global')
-            slab_global.copy_modes_from(up, deconv_order, operation='=')
+            slab_global.copy_modes_from(up, deconv_order, nlattice, shift, operation='=')
         else:
-            slab_global.copy_modes_from(up, deconv_order, operation='+=')
+            slab_global.copy_modes_from(up, deconv_order, nlattice, shift, operation='+=')
     groups = group_components(suppliers, gs_up, [gridsize_global, ...])
     for gridsize_upstream, group in groups.items():
         fft_factor = float(gridsize_upstream)**(-3)  # mesh.py:582
@@ -267,15 +288,20 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
             up.fft_forward()
             up.nullify_nyquist()
             add_to_global(up, 0)
-        if particle_components:
+        for shift in (shifts_upstream if particle_components else ()):
             up = upstream_mesh(gridsize_upstream)
             up.zero()
             for supplier in particle_components:
-                up.deposit(supplier.pos, _particle_contribution(
-                    supplier, ᔑdt, fft_factor, gridsize_upstream, boxsize))
+                contribution = _particle_contribution(supplier, ᔑdt, fft_factor,
+                                                      gridsize_upstream, boxsize)
+                if interpolation_order == 2 and shift == (0, 0, 0):
+                    up.deposit(supplier.pos, contribution)
+                else:
+                    up.deposit_general(supplier.pos, contribution, interpolation_order, shift)
             up.fft_forward()
             up.nullify_nyquist()
-            add_to_global(up, interpolation_order*int(bool(deconvolve_upstream)))
+            add_to_global(up, interpolation_order*int(bool(deconvolve_upstream)),
+                          len(shifts_upstream), shift)
     # ---- potential (interactions.py:2092-2120)
     C, long_range, E = _potential_constants(p, potential, gridsize_global)
     slab_global.poisson_kernel(deconv_order_global, C, long_range, E)
@@ -288,39 +314,73 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
         else:
             slab_downstream = mesh_for(gridsize_downstream, 'downstream')
             slab_downstream.copy_modes_from(slab_global, operation='=')
+
+        def apply_force(grid, dim, subgroup, representation, shift, differentiation_order):
+            """apply_particle_mesh_force (interactions.py:2359-2402); `grid` holds the
+            potential when differentiation_order is 2 or 4, else the force component"""
+            for receiver in subgroup:
+                key = (ᔑdt_key[0], receiver.name) if isinstance(ᔑdt_key, tuple) else ᔑdt_key
+                if representation == 'fluid':
+                    grid.fluid_kick(receiver.J[dim], receiver.ϱ, receiver.𝒫, dim,
+                                    differentiation_order, -ᔑdt[key], p.light_speed**(-2))
+                    continue
+                factor = receiver.mass*(-ᔑdt[key])
+                force_grid = grid
+                if differentiation_order:
+                    force_grid = mesh_for(gridsize_downstream, 'force')
+                    force_grid.diff_from(grid, dim, differentiation_order)
+                force_grid.gather_scalar(receiver.pos, receiver.mom, dim, interpolation_order,
+                                         shift, factor)
         for representation in ('fluid', 'particles'):
             if representation not in group:
                 continue
             at_last_representation = representation == 'particles' or 'particles' not in group
             deconv_order_downstream = interpolation_order*int(
                 representation == 'particles' and bool(deconvolve_downstream))
+            shifts_downstream = lattice_shifts(
+                interlace_downstream if representation == 'particles' else 'sc', p.cell_centered)
             differentiations = [r.potential_differentiations[force][method]
                                 for r in group[representation]]
+            for d in differentiations:
+                if d not in (0, 2, 4):
+                    raise ConceptGPUError(
+                        f'differentiation order {d}: 0 (Fourier space), 2 and 4 are built '
+                        f'(nghosts = {p.nghosts})')
             subgroups = group_components(group[representation], differentiations,
                                          sorted(differentiations, reverse=True),
                                          split_representations=False)
             for differentiation_order, subgroup in subgroups.items():
-                if differentiation_order == 0:
-                    raise ConceptGPUError('Fourier-space differentiation (order 0) is not built '
-                                          '(SURVEY.md §8f-3)')
                 at_last_order = differentiation_order == min(differentiations)
-                if at_last_representation and at_last_order:
-                    slab = slab_downstream  # may be mutated: nobody needs it afterwards
-                else:
-                    slab = mesh_for(gridsize_downstream, 'subgroup')
-                    slab.copy_from(slab_downstream)
-                slab.fourier_operate(deconv_order_downstream)
-                slab.poisson_backward()
-                for receiver in subgroup:
-                    if representation == 'particles':
-                        _kick_particles(slab, receiver, force, method, ᔑdt, ᔑdt_key)
-                    else:
-                        key = ((ᔑdt_key[0], receiver.name) if isinstance(ᔑdt_key, tuple)
-                               else ᔑdt_key)
+                for li, shift in enumerate(shifts_downstream):
+                    mutate_ok = (li == len(shifts_downstream) - 1 and at_last_representation
+                                 and at_last_order)
+
+                    def working_slab(may_mutate):
+                        if may_mutate:
+                            return slab_downstream  # nobody needs it afterwards
+                        slab = mesh_for(gridsize_downstream, 'subgroup')
+                        slab.copy_from(slab_downstream)
+                        return slab
+                    if differentiation_order == 0:
+                        # Fourier-space differentiation (interactions.py:2229-2268)
                         for dim in range(3):
-                            slab.fluid_kick(receiver.J[dim], receiver.ϱ, receiver.𝒫, dim,
-                                            differentiation_order, -ᔑdt[key],
-                                            p.light_speed**(-2))
+                            slab = working_slab(mutate_ok and dim == 2)
+                            slab.fourier_operate(deconv_order_downstream, len(shifts_downstream),
+                                                 shift, diff_dim=dim)
+                            slab.poisson_backward()
+                            apply_force(slab, dim, subgroup, representation, shift, 0)
+                        continue
+                    slab = working_slab(mutate_ok)
+                    slab.fourier_operate(deconv_order_downstream, len(shifts_downstream), shift)
+                    slab.poisson_backward()
+                    simple = interpolation_order == 2 and shift == (0, 0, 0)
+                    for receiver in (subgroup if representation == 'particles' and simple
+                                     else ()):
+                        _kick_particles(slab, receiver, force, method, ᔑdt, ᔑdt_key)
+                    if representation == 'fluid' or not simple:
+                        for dim in range(3):
+                            apply_force(slab, dim, subgroup, representation, shift,
+                                        differentiation_order)
 
 
 register('gravity', ['ppnonperiodic', 'pp', 'p3m', 'pm'], 'gravitational')

@@ -89,6 +89,9 @@ SYMBOLS = {
     'cg_fourier_nullify_nyquist': (_int, [_vp]),
     'cg_fourier_operate': (_int, [_vp, _vp, _int, _int, _vp, _int, _int]),
     'cg_copy_modes': (_int, [_vp, _vp, _int, _int, _vp, _int]),
+    'cg_deposit': (_int, [_vp, _vp, _i64, _dbl, _int, _vp]),
+    'cg_gather_scalar': (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _dbl]),
+    'cg_mesh_diff': (_int, [_vp, _vp, _int, _int]),
     'cg_mesh_copy': (_int, [_vp, _vp]),
     'cg_fluid_kick': (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl]),
 }

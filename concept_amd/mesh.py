@@ -175,6 +175,24 @@ class PotentialMesh:
                                int(operation == '+=')))
         return self
 
+    def deposit_general(self, pos, contribution, order=2, shift=(0.0, 0.0, 0.0)):
+        """interpolate_particles of order 1..4 with a lattice shift (mesh.py:1512-1636)"""
+        n = self._check_particles(pos)
+        sh = (ctypes.c_double*3)(*[float(x) for x in shift])
+        check(_L.cg_deposit(self._ctx, _ptr(pos), n, float(contribution), int(order), sh))
+
+    def gather_scalar(self, pos, mom, dim, order, shift, factor):
+        """interpolate_domaingrid_to_particles (mesh.py:376-459): this mesh holds one
+        force component"""
+        n = self._check_particles(pos, mom)
+        sh = (ctypes.c_double*3)(*[float(x) for x in shift])
+        check(_L.cg_gather_scalar(self._ctx, _ptr(pos), _ptr(mom), n, int(dim), int(order), sh,
+                                  float(factor)))
+
+    def diff_from(self, source, dim, diff_order):
+        """diff_domaingrid (mesh.py:4874-5030) of source's real-space mesh into this one"""
+        check(_L.cg_mesh_diff(self._ctx, source._ctx, int(dim), int(diff_order)))
+
     def copy_from(self, other):
         check(_L.cg_mesh_copy(self._ctx, other._ctx))
 

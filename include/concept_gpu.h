@@ -301,18 +301,33 @@ int cg_owner_rank(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n,
  *   Nyquist planes, are not touched: with op_add = 0 zero it first (cg_mesh_zero — the
  *   reference's nullified get_fftw_slab, mesh.py:686-709).  Equal sizes forward to
  *   cg_fourier_operate.
+ * cg_deposit: interpolate_particles (mesh.py:1512-1636) of any order 1..4 (NGP, CIC,
+ *   TSC, PCS: set_weights_*, mesh.py:5305-5394) with an interlacing lattice shift
+ *   (HOST double[3] in grid units, NULL = none; Lattice, mesh.py:77-182), ghost fold
+ *   fused (periodic).  cg_gather_scalar: interpolate_domaingrid_to_particles
+ *   (mesh.py:376-459): mom[dim] += factor * (mesh interpolated at the particle), the
+ *   mesh holding one force component (after cg_mesh_diff or a Fourier-space
+ *   differentiation).  cg_mesh_diff: diff_domaingrid (mesh.py:4874-5030), symmetric
+ *   orders 2 and 4, of `src`'s real-space mesh into `dst`'s.
  * cg_mesh_copy: slab_downstream_subgroup[...] = slab_downstream
  *   (interactions.py:2242-2245, 2276-2279).
  * cg_fluid_kick: the fluid branch of apply_particle_mesh_force
  *   (interactions.py:2388-2401) fused with diff_domaingrid (mesh.py:4874-5030):
  *   J_dim[cell] += minus_dt*(rho[cell] + inv_c2*P[cell]) * d(phi)/dx_dim, symmetric
- *   difference of order 2 or 4 on the context's real-space potential. */
+ *   difference of order 2 or 4 on the context's real-space potential (diff_order 0:
+ *   the mesh already holds the force component, Fourier-space differentiation). */
 int cg_fluid_add(cg_ctx *ctx, const double *fluid /*DEV N^3*/, double factor, int op_add);
 int cg_fourier_nullify_nyquist(cg_ctx *ctx);
 int cg_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
                        const double *shift /*HOST 3 or NULL*/, int diff_dim, int op_add);
 int cg_copy_modes(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
                   const double *shift /*HOST 3 or NULL*/, int op_add);
+int cg_deposit(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, double contribution,
+               int order, const double *shift /*HOST 3 or NULL*/);
+int cg_gather_scalar(cg_ctx *ctx, const double *pos /*DEV 3n*/, double *mom /*DEV 3n*/,
+                     int64_t n, int dim, int order, const double *shift /*HOST 3 or NULL*/,
+                     double factor);
+int cg_mesh_diff(cg_ctx *dst, cg_ctx *src, int dim, int diff_order);
 int cg_mesh_copy(cg_ctx *dst, cg_ctx *src);
 int cg_fluid_kick(cg_ctx *ctx, double *J_dim /*DEV N^3*/, const double *rho /*DEV N^3*/,
                   const double *P /*DEV N^3*/, int dim, int diff_order, double minus_dt,

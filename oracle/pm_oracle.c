@@ -398,3 +398,101 @@ void orc_copy_modes(const double *from, i64 N_from, double *onto, i64 N_onto, in
         }
     }
 }
+
+/*
+ * set_weights_{NGP,CIC,TSC,PCS} (mesh.py:5305-5394) and the particle interpolation
+ * loops of every order (mesh.py:5052-5283): `order` points per dimension starting
+ * at the returned index, visited i, j, k ascending; weight = (w_x[i]*w_y[j])*w_z[k]
+ * with w_x[i] first multiplied by the contribution when depositing.
+ * The reference's `tmp**2` is Python float pow (libm pow): pow() here.
+ */
+/* Python's dist**2 is libm pow() at run time; keep the compiler from folding pow(x, 2.0)
+ * into x*x (which can differ from glibc's pow in the last bit) */
+static volatile double exponent_two = 2.0, exponent_three = 3.0;
+static i64 set_weights_order(double x, double *w, int order) {
+    i64 index;
+    double dist;
+    if (order == 1) {
+        index = (i64)(x + 0.5);
+        w[0] = 1;
+        return index;
+    }
+    if (order == 2) return set_weights_cic(x, w);
+    if (order == 3) {
+        index = (i64)(x + 0.5);
+        dist = x - (double)index;
+        index -= 1;
+        double dist2 = pow(dist, exponent_two);
+        double weight0 = 0.125 + 0.5 * (dist2 - dist);
+        double weight1 = 0.75 - dist2;
+        w[0] = weight0;
+        w[1] = weight1;
+        w[2] = 1 - weight0 - weight1;
+        return index;
+    }
+    index = (i64)x;
+    index -= 1;
+    dist = x - (double)index;
+    double tmp = 2 - dist;
+    double tmp2 = pow(tmp, exponent_two);
+    double tmp3 = tmp * tmp2;
+    double weight0 = 1. / 6. * tmp3;
+    double weight2 = 2. / 3. - tmp2 + 0.5 * tmp3;
+    double weight3 = 1. / 6. * pow(dist - 1, exponent_three);
+    w[0] = weight0;
+    w[1] = 1 - weight0 - weight2 - weight3;
+    w[2] = weight2;
+    w[3] = weight3;
+    return index;
+}
+
+void orc_interp_deposit(const double *pos, i64 N, double *grid, i64 size_j, i64 size_k,
+                        const double *offset, double scale, double contribution, int order) {
+    double wx[4], wy[4], wz[4];
+    for (i64 p = 0; p < N; p++) {
+        double x = (pos[3 * p + 0] - offset[0]) * scale;
+        double y = (pos[3 * p + 1] - offset[1]) * scale;
+        double z = (pos[3 * p + 2] - offset[2]) * scale;
+        i64 ii = set_weights_order(x, wx, order);
+        i64 jj = set_weights_order(y, wy, order);
+        i64 kk = set_weights_order(z, wz, order);
+        for (int i = 0; i < order; i++) {
+            double weight_i = wx[i];
+            weight_i *= contribution;
+            if (order == 1) weight_i = contribution; /* NGP: weight = multiplier, mesh.py:5078 */
+            for (int j = 0; j < order; j++) {
+                double wij = weight_i * wy[j];
+                for (int k = 0; k < order; k++) {
+                    i64 index = ((ii + i) * size_j + (jj + j)) * size_k + (kk + k);
+                    grid[index] += (order == 1) ? weight_i : wij * wz[k];
+                }
+            }
+        }
+    }
+}
+
+void orc_interp_gather(const double *grid, i64 size_j, i64 size_k, const double *pos,
+                       double *mom, i64 N, int dim, const double *offset, double scale,
+                       double factor, int order) {
+    double wx[4], wy[4], wz[4];
+    for (i64 p = 0; p < N; p++) {
+        double x = (pos[3 * p + 0] - offset[0]) * scale;
+        double y = (pos[3 * p + 1] - offset[1]) * scale;
+        double z = (pos[3 * p + 2] - offset[2]) * scale;
+        i64 ii = set_weights_order(x, wx, order);
+        i64 jj = set_weights_order(y, wy, order);
+        i64 kk = set_weights_order(z, wz, order);
+        double value = 0;
+        for (int i = 0; i < order; i++)
+            for (int j = 0; j < order; j++) {
+                double wij = wx[i] * wy[j];
+                for (int k = 0; k < order; k++) {
+                    i64 index = ((ii + i) * size_j + (jj + j)) * size_k + (kk + k);
+                    double weight = (order == 1) ? 1.0 : wij * wz[k];
+                    value += grid[index] * weight;
+                }
+            }
+        if (factor != 1) value *= factor;
+        mom[3 * p + dim] += value;
+    }
+}

@@ -83,6 +83,20 @@ CASES = {
     'multigrid_n8_up32_down24': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=25,
                                      dist='uniform', diff=4, fluid=dict(gridsize=8, count=0),
                                      component_gridsizes={'particles0': (32, 24)}),
+    # interlacing, TSC / PCS / NGP, Fourier-space differentiation
+    'tsc_bcc_n8_g16': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=26, dist='uniform',
+                           diff=2, fluid=dict(gridsize=16, count=0),
+                           interpolation='TSC', interlace=('bcc', 'bcc')),
+    'pcs_fcc_fourier_n8_g16': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=27,
+                                   dist='clustered', diff=0, fluid=dict(gridsize=16, count=0),
+                                   interpolation='PCS', interlace=('fcc', 'sc')),
+    'ngp_fluid_n8_g16': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=28,
+                             dist='uniform', diff=4, fluid=dict(gridsize=16),
+                             interpolation='NGP', interlace=('sc', 'bcc')),
+    'cic_fcc_multigrid_n8': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=29,
+                                 dist='uniform', diff=0, fluid=dict(gridsize=8),
+                                 interpolation='CIC', interlace=('bcc', 'fcc'),
+                                 component_gridsizes={'particles0': (24, 12)}),
     'fluid2_pm_n6_g12': dict(method='pm', n=6, gridsize=12, boxsize=48.0, seed=22,
                              dist='clustered', diff=4, fluid=dict(gridsize=12, count=2),
                              particle_components=2),
@@ -338,6 +352,8 @@ potential_options = {{
     'gridsize': {{'global': {{'gravity': {{'pm': {g}}}}}, 'particles': {{'gravity': {{'pm': {g}}}}}, {own}}},
     'differentiation': {{'particles': {{'gravity': {{'pm': {cfg['diff']}}}}},
                         'fluid': {{'gravity': {{'pm': 2}}}}}},
+    'interpolation': {{'gravity': {{'pm': {cfg.get('interpolation', 'CIC')!r}}}}},
+    'interlace': {{'gravity': {{'pm': {cfg.get('interlace', ('sc', 'sc'))!r}}}}},
 }}
 H0 = 70*km/s/Mpc
 Ωcdm = 0.25
@@ -409,6 +425,8 @@ def child_fluid(name):
         out[f'f{c}_dt_dens'] = sdt['a**(-3*w_eff-1)', nm]
         out[f'f{c}_w_eff'] = fl.w_eff(a=commons.universals.a)
     out['dt_1'] = dt
+    out['interpolation'] = cfg.get('interpolation', 'CIC')
+    out['interlace'] = np.array(cfg.get('interlace', ('sc', 'sc')))
     out['n_particle_components'] = npc
     out['n_fluid_components'] = nfl
     inter = interactions.find_interactions(comps, 'long-range')

@@ -235,7 +235,9 @@ def _fluid_components(g, particle_diff):
 
 
 @pytest.mark.parametrize('name', ['fluid_pm_n8_g16', 'fluid2_pm_n6_g12', 'multigrid_n8_g16',
-                                  'multigrid_n8_up32_down24'])
+                                  'multigrid_n8_up32_down24', 'tsc_bcc_n8_g16',
+                                  'pcs_fcc_fourier_n8_g16', 'ngp_fluid_n8_g16',
+                                  'cic_fcc_multigrid_n8'])
 def test_general_particle_mesh_bit_exact(golden, name):
     """gravity('pm') with receivers = suppliers = particles + fluids: momenta, J grids and
     the k-space potential handed to every backward FFT, bit for bit; the multigrid cases
@@ -243,15 +245,22 @@ def test_general_particle_mesh_bit_exact(golden, name):
     from oracle import pm_general
     g = golden(name)
     comps = _fluid_components(g, int(g['diff_order']))
+    extra = {}
+    if 'interpolation' in g:  # row 3: NGP / TSC / PCS, interlacing, Fourier differentiation
+        extra = dict(interp_order={'NGP': 1, 'CIC': 2, 'TSC': 3, 'PCS': 4}[str(g['interpolation'])],
+                     interlace=tuple(str(x) for x in g['interlace']))
     out = pm_general.particle_mesh(
         comps, boxsize=float(g['boxsize']), gridsize=int(g['gridsize']),
-        G_Newton=float(g['G_Newton']), dt_1=float(g['dt_1']), light_speed=float(g['light_speed']))
+        G_Newton=float(g['G_Newton']), dt_1=float(g['dt_1']), light_speed=float(g['light_speed']),
+        **extra)
     npc = int(g['n_particle_components'])
     for c in range(npc):
         assert np.array_equal(comps[c]['mom'], g[f'p{c}_mom_out'])
     for c in range(int(g['n_fluid_components'])):
         assert np.array_equal(comps[npc + c]['J'], g[f'f{c}_J_out'])
         assert np.abs(g[f'f{c}_J_out'] - g[f'f{c}_J_in']).max() > 0
+    n_slabs = len([k for k in g.files if k.startswith('slab_k_before_backward_')])
+    assert len(out['slab_before_backward']) == n_slabs
     for i, slab in enumerate(out['slab_before_backward']):
         assert np.array_equal(slab, g[f'slab_k_before_backward_{i}'])
 
