@@ -11,7 +11,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libconcept_gpu.so')
 SOURCES = ['cg_context.hip', 'cg_mesh_kernels.hip', 'cg_tiled_kernels.hip', 'cg_fft.hip', 'cg_shortrange.hip', 'cg_rungs.hip',
-           'cg_particles.hip', 'cg_general.hip']
+           'cg_particles.hip', 'cg_general.hip', 'cg_pp.hip']
 HEADERS = [os.path.join(CSRC, 'cg_internal.h'), os.path.join(CSRC, 'cg_kspace.h'), os.path.join(CSRC, 'cg_tiles.h'), os.path.join(REPO, 'include', 'concept_gpu.h')]
 
 FLAGS = [

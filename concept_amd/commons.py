@@ -179,6 +179,7 @@ def load_params(source=None, **overrides):
     ssl.setdefault('default', '0.025*boxsize/cbrt(N)')
     p.select_softening_length = ssl
     p.softening_kernel = str(user.get('softening_kernel', 'spline')).lower()
+    p.ewald_gridsize = int(user.get('ewald_gridsize', 64))  # commons.py:3061
     p.N_rungs = int(user.get('N_rungs', 8))
     p.cell_centered = bool(user.get('cell_centered', True))
     # nghosts (commons.py:4411-4432): default 2 comes from the PCS default of the

@@ -348,6 +348,27 @@ extern "C" int cg_mesh_diff(cg_ctx *dst, cg_ctx *src, int dim, int diff_order) {
     return cgk_mesh_diff(dst, src, dim, diff_order);
 }
 
+extern "C" int cg_ewald_tabulate(cg_ctx *c, int gridsize, double *grid) {
+    CG_CHECK(c && grid, "cg_ewald_tabulate: null argument");
+    CG_CHECK(gridsize >= 2 && gridsize <= 512, "cg_ewald_tabulate: ewald_gridsize %d", gridsize);
+    return cgk_ewald_tabulate(c, gridsize, grid);
+}
+
+extern "C" int cg_pp_kick(cg_ctx *c, const double *pos_r, int64_t n_r, double *dmom_r,
+                          const double *pos_s, int64_t n_s, int same, const double *ewald_grid,
+                          int ewald_gridsize, double softening, int kernel, double factor,
+                          const double *factors, const signed char *rung,
+                          const signed char *rung_jumped, int lowest_active) {
+    CG_CHECK(c && ((pos_r && dmom_r) || n_r == 0) && (pos_s || n_s == 0),
+             "cg_pp_kick: null argument");
+    CG_CHECK(kernel >= 0 && kernel <= 2, "Softening kernel %d not understood", kernel);
+    CG_CHECK(!ewald_grid || ewald_gridsize >= 2, "cg_pp_kick: ewald_gridsize %d", ewald_gridsize);
+    CG_CHECK(!same || n_r == n_s, "cg_pp_kick: same = 1 needs identical receiver and supplier sets");
+    CG_CHECK(!rung || (factors && rung_jumped), "cg_pp_kick: rungs need factors and jumped indices");
+    return cgk_pp_kick(c, pos_r, n_r, dmom_r, pos_s, n_s, same ? 1 : 0, ewald_grid, ewald_gridsize,
+                       softening, kernel, factor, factors, rung, rung_jumped, lowest_active);
+}
+
 extern "C" int cg_mesh_copy(cg_ctx *dst, cg_ctx *src) {
     CG_CHECK(dst && src, "cg_mesh_copy: null context");
     CG_CHECK(dst->N == src->N && dst->mesh_doubles == src->mesh_doubles,

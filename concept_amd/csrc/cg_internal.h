@@ -172,6 +172,11 @@ int cgk_deposit_general(cg_ctx *c, const double *pos, i64 n, double contribution
 int cgk_gather_scalar(cg_ctx *c, const double *pos, double *mom, i64 n, int dim, int order,
                       const CicGeom &geo, double factor);
 int cgk_mesh_diff(cg_ctx *dst, cg_ctx *src, int dim, int diff_order);
+int cgk_ewald_tabulate(cg_ctx *c, int gridsize, double *grid);
+int cgk_pp_kick(cg_ctx *c, const double *pos_r, i64 n_r, double *dmom_r, const double *pos_s,
+                i64 n_s, int same, const double *ewald_grid, int ewald_gridsize,
+                double softening, int kernel, double factor, const double *factors,
+                const signed char *rung, const signed char *rung_jumped, int lowest_active);
 int cgk_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int dim,
                    int diff_order, double minus_dt, double inv_c2);
 int cgk_fft(cg_ctx *c, int what, int deconv_order, double C, int long_range, double E);

@@ -517,7 +517,9 @@ def gravity(method, receivers, suppliers, ᔑdt, interaction_type, printout):
             from .shortrange import component_component
             component_component(force, receivers, suppliers, ᔑdt, potential_specs.gridsize)
     elif method in {'pp', 'ppnonperiodic'}:
-        raise ConceptGPUError(f'gravity(): the "{method}" method is not on the GPU path '
-                              '(direct summation; SURVEY.md §8f-4)')
+        # direct summation (gravity.py:121-206 with the Ewald correction of ewald.py,
+        # gravity.py:491-560 without); SURVEY.md §8f row 4
+        from .shortrange import component_component_pp
+        component_component_pp(force, receivers, suppliers, ᔑdt, periodic=(method == 'pp'))
     else:
         raise ConceptGPUError(f'gravity() was called with the "{method}" method')

@@ -92,6 +92,9 @@ SYMBOLS = {
     'cg_deposit': (_int, [_vp, _vp, _i64, _dbl, _int, _vp]),
     'cg_gather_scalar': (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _dbl]),
     'cg_mesh_diff': (_int, [_vp, _vp, _int, _int]),
+    'cg_ewald_tabulate': (_int, [_vp, _int, _vp]),
+    'cg_pp_kick': (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _int, _dbl, _int, _dbl, _vp, _vp,
+                          _vp, _int]),
     'cg_mesh_copy': (_int, [_vp, _vp]),
     'cg_fluid_kick': (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl]),
 }

@@ -193,6 +193,35 @@ class PotentialMesh:
         """diff_domaingrid (mesh.py:4874-5030) of source's real-space mesh into this one"""
         check(_L.cg_mesh_diff(self._ctx, source._ctx, int(dim), int(diff_order)))
 
+    def ewald_tabulate(self, gridsize):
+        """ewald.tabulate() (ewald.py:226-231) -> (g, g, g, 3) tensor in HBM"""
+        grid = torch.empty((gridsize, gridsize, gridsize, 3), dtype=torch.float64,
+                           device=self.device)
+        check(_L.cg_ewald_tabulate(self._ctx, int(gridsize), _ptr(grid)))
+        return grid
+
+    def pp_kick(self, pos_r, dmom_r, pos_s, same, ewald_grid, softening, kernel, factor,
+                rungs=None):
+        """gravity_pairwise / gravity_pairwise_nonperiodic (gravity.py:121-206, 491-560);
+        rungs = (factors, rung_indices, rung_indices_jumped, lowest_active_rung) or None"""
+        n_r = self._check_particles(pos_r, dmom_r)
+        n_s = self._check_particles(pos_s)
+        kernels = {'none': 0, 'plummer': 1, 'spline': 2}
+        if kernel not in kernels:
+            raise lib.ConceptGPUError(f'Softening kernel "{kernel}" not understood')
+        gs = 0 if ewald_grid is None else int(ewald_grid.shape[0])
+        eg = None if ewald_grid is None else _ptr(ewald_grid)
+        if rungs is None:
+            f = r = rj = None
+            low = 0
+        else:
+            factors, rung, rung_jumped, low = rungs
+            self._check_rungs(n_r, rung, rung_jumped)
+            f, r, rj = _ptr(factors), _ptr(rung), _ptr(rung_jumped)
+        check(_L.cg_pp_kick(self._ctx, _ptr(pos_r), n_r, _ptr(dmom_r), _ptr(pos_s), n_s,
+                            int(bool(same)), eg, gs, float(softening), kernels[kernel],
+                            float(factor), f, r, rj, int(low)))
+
     def copy_from(self, other):
         check(_L.cg_mesh_copy(self._ctx, other._ctx))
 

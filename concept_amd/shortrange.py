@@ -124,3 +124,62 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
             if not same and s in receivers:
                 # the reference kicks both partners of a pair (Δmom_s -= ..., gravity.py:341-349)
                 sweep(s, r, False)
+
+
+_ewald_grids = {}
+
+
+def get_ewald_grid(p, device):
+    """ewald.get_ewald_grid() (ewald.py:200-224): the octant table of the Ewald correction,
+    tabulated once per (ewald_gridsize, device) on the GPU and kept in HBM (the reference
+    caches it on disk)."""
+    key = (p.ewald_gridsize, str(device))
+    grid = _ewald_grids.get(key)
+    if grid is None:
+        mesh = get_mesh(16, p.boxsize, p.nghosts, p.cell_centered, 2, device, role='pp')
+        grid = _ewald_grids[key] = mesh.ewald_tabulate(p.ewald_gridsize)
+    return grid
+
+
+def component_component_pp(force, receivers, suppliers, ᔑdt_rungs, periodic):
+    """component_component(..., pairing_level='domain') (interactions.py:122-329) with
+    gravity_pairwise (periodic, Ewald-corrected) or gravity_pairwise_nonperiodic
+    (gravity.py:121-206, 491-560): direct summation, accumulated into the components' Δmom
+    buffers (the caller applies them, main.py:1253-1262)."""
+    if force != 'gravity':
+        raise ConceptGPUError(f'direct summation of force "{force}" is not built')
+    p = receivers[0].params
+    dev = receivers[0].device
+    mesh = get_mesh(16, p.boxsize, p.nghosts, p.cell_centered, 2, dev, role='pp')
+    ewald_grid = get_ewald_grid(p, dev) if periodic else None
+    for c in {id(c): c for c in list(receivers) + list(suppliers)}.values():
+        if c.representation != 'particles':
+            raise ConceptGPUError(f'{c.name}: only particle components take part in direct '
+                                  'summation')
+        if c.Δmom is None:
+            c.Δmom = torch.zeros_like(c.mom)
+    key = 'a**(-3*w_eff₀-3*w_eff₁-1)'
+    done = set()
+    for r in receivers:
+        for s in suppliers:
+            pair = frozenset((id(r), id(s)))
+            if pair in done:
+                continue
+            done.add(pair)
+            softening = combine_softening_lengths(r.softening_length, s.softening_length)
+
+            def kick(rec, sup, same):
+                # compute_factors (gravity.py:51-64): G*m_r*m_s*ᔑdt_rungs[...][k] per rung k
+                integrals = np.asarray(ᔑdt_rungs[key, rec.name, sup.name], dtype=np.float64)
+                rungs, factor = None, p.G_Newton*rec.mass*sup.mass*float(integrals[0])
+                if rec.use_rungs:
+                    factors = torch.tensor(p.G_Newton*rec.mass*sup.mass*integrals,
+                                           dtype=torch.float64, device=rec.device)
+                    rungs = (factors, rec.rung_indices, rec.rung_indices_jumped,
+                             rec.lowest_active_rung)
+                    factor = 0.0
+                mesh.pp_kick(rec.pos, rec.Δmom, sup.pos, same, ewald_grid, softening,
+                             p.softening_kernel, factor, rungs)
+            kick(r, s, r is s)
+            if r is not s and s in receivers:
+                kick(s, r, False)  # the reference kicks both partners of a pair

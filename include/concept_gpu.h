@@ -333,6 +333,25 @@ int cg_fluid_kick(cg_ctx *ctx, double *J_dim /*DEV N^3*/, const double *rho /*DE
                   const double *P /*DEV N^3*/, int dim, int diff_order, double minus_dt,
                   double inv_c2);
 
+/* --- direct summation, 'pp' and 'ppnonperiodic'  ---------
+ * cg_ewald_tabulate: ewald.tabulate() (ewald.py:62-118, 226-231): the Ewald correction
+ *   force of a unit box on a gridsize^3 x 3 grid over one octant (DEV double[g][g][g][3]).
+ * cg_pp_kick: gravity_pairwise (gravity.py:121-206: nearest image, Ewald look-up
+ *   ewald.py:146-197, softened 1/r^3 of interactions.py:1847-1914) when ewald_grid is
+ *   given, gravity_pairwise_nonperiodic (gravity.py:491-560) when it is NULL.
+ *   dmom_r[i] += factor * sum_j force_ij over all suppliers (one-sided; the reference
+ *   visits a pair once and updates both).  same = 1: receivers and suppliers are the same
+ *   array (self pairs skipped).  kernel: 0 none, 1 plummer, 2 spline.  With rungs
+ *   (factors/rung/rung_jumped DEV, as cg_shortrange_sweep_rungs): receivers below
+ *   lowest_active are skipped, the factor is factors[rung_jumped[i]]. */
+int cg_ewald_tabulate(cg_ctx *ctx, int gridsize, double *grid /*DEV 3 g^3*/);
+int cg_pp_kick(cg_ctx *ctx, const double *pos_r /*DEV 3 n_r*/, int64_t n_r,
+               double *dmom_r /*DEV 3 n_r*/, const double *pos_s /*DEV 3 n_s*/, int64_t n_s,
+               int same, const double *ewald_grid /*DEV or NULL*/, int ewald_gridsize,
+               double softening, int kernel, double factor, const double *factors /*DEV or NULL*/,
+               const signed char *rung /*DEV or NULL*/, const signed char *rung_jumped,
+               int lowest_active);
+
 /* --- debug fetch (parity tests) -------------------------------------------- */
 int cg_fetch(cg_ctx *ctx, int which, double *out /*HOST*/, int64_t n_doubles);
 /* CIC cell indices exactly as set_weights_CIC returns them for the deposit

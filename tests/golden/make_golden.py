@@ -97,6 +97,13 @@ CASES = {
                                  dist='uniform', diff=0, fluid=dict(gridsize=8),
                                  interpolation='CIC', interlace=('bcc', 'fcc'),
                                  component_gridsizes={'particles0': (24, 12)}),
+    # direct summation with the Ewald correction (gravity 'pp':
+    # gravity_pairwise gravity.py:121-206, ewald.py) and without (ppnonperiodic); the Ewald
+    # table is tabulated by the reference's own summation() on a small grid
+    'pp_ewald_n4': dict(method='pp', n=4, gridsize=8, boxsize=20.0, seed=31, dist='uniform',
+                        diff=2, pp=True, ewald_gridsize=6),
+    'ppnonperiodic_n4': dict(method='ppnonperiodic', n=4, gridsize=8, boxsize=20.0, seed=32,
+                             dist='clustered', diff=2, pp=True, ewald_gridsize=6),
     'fluid2_pm_n6_g12': dict(method='pm', n=6, gridsize=12, boxsize=48.0, seed=22,
                              dist='clustered', diff=4, fluid=dict(gridsize=12, count=2),
                              particle_components=2),
@@ -473,8 +480,74 @@ def child_fluid(name):
     print('wrote', name, {k: getattr(v, 'shape', v) for k, v in out.items()})
 
 
+def child_pp(name):
+    """gravity('pp' | 'ppnonperiodic', [c], [c], ᔑdt_rungs, 'any', False): Δmom of every
+    particle with all particles on rung 0, the Ewald grid the reference tabulated
+    (ewald.tabulate -> summation, ewald.py:62-118) and sample look-ups ewald(x, y, z)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, 'oracle', 'refharness'))
+    from ref_import import load_reference
+    cfg = CASES[name]
+    method = cfg['method']
+    text = f"""
+boxsize = {cfg['boxsize']!r}*Mpc
+H0 = 70*km/s/Mpc
+Ωcdm = 0.25
+Ωb = 0.05
+a_begin = 0.5
+enable_class_background = False
+select_forces = {{'matter': {{'gravity': '{method}'}}}}
+select_softening_length = {{'matter': '0.03*boxsize/cbrt(N)'}}
+ewald_gridsize = {cfg['ewald_gridsize']}
+"""
+    ref = load_reference(text, f'/tmp/concept_golden_work/{name}')
+    commons, interactions, species = ref.commons, ref.interactions, ref.species
+    import importlib
+    ewald = importlib.import_module('ewald')
+    L = commons.boxsize
+    pos = make_positions(np, cfg)
+    N = pos.shape[0]
+    mass = commons.ρ_mbar*L**3/N
+    comp = species.Component('matter', 'matter', N=N, mass=mass)
+    for d, s_ in enumerate('xyz'):
+        comp.populate(np.ascontiguousarray(pos[:, d]), 'pos' + s_)
+        comp.populate(np.zeros(N), 'mom' + s_)
+    nr = commons.N_rungs
+    key2 = ('a**(-3*w_eff₀-3*w_eff₁-1)', 'matter', 'matter')
+    sdt_rungs = {key2: 0.02*2.3*(1 + 0.1*np.arange(3*nr - 1))}
+    out = dict(boxsize=L, N=N, mass=mass, G_Newton=commons.G_Newton, method=method,
+               softening_length=comp.softening_length, N_rungs=nr,
+               ewald_gridsize=commons.ewald_gridsize, dt_rungs_pair=sdt_rungs[key2].copy(),
+               pos_in=np.array(comp.pos_mv3[:N]).copy())
+    if method == 'pp':
+        # ewald.tabulate() with filename '' (h5py is absent: the grid is not cached on disk)
+        ewald.grid = ref.mesh.tabulate_vectorgrid(
+            commons.ewald_gridsize, ewald.summation, 0.5/(commons.ewald_gridsize - 1), '')
+    comp.nullify_Δ('mom')
+    comp.lowest_active_rung = 0
+    comp.lowest_populated_rung = 0
+    comp.highest_populated_rung = 0
+    interactions.gravity(method, [comp], [comp], sdt_rungs, 'any', False)
+    out['dmom'] = np.array(comp.Δmom_mv3[:N]).copy()
+    out['pos_after'] = np.array(comp.pos_mv3[:N]).copy()
+    if method == 'pp':
+        out['ewald_grid'] = np.array(ewald.grid).copy()
+        rng = np.random.default_rng(7)
+        pts = rng.uniform(-0.5*L, 0.5*L, size=(40, 3))
+        pts[0] = (0.0, 0.1*L, -0.2*L)
+        pts[1] = (0.25*L, 0.0, 0.0)
+        out['ewald_points'] = pts
+        out['ewald_values'] = np.array([[ewald.ewald(*p)[d] for d in range(3)] for p in pts])
+        out['ewald_constants'] = np.array([ewald.rs, ewald.maxdist, ewald.maxh2, ewald.h_lower,
+                                           ewald.h_upper, ewald.n_lower, ewald.n_upper], float)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, {k: getattr(v, 'shape', v) for k, v in out.items()})
+
+
 def child(name):
     import numpy as np
+    if CASES[name].get('pp'):
+        return child_pp(name)
     if 'fluid' in CASES[name]:
         return child_fluid(name)
     if 'rungs' in CASES[name]:

@@ -288,3 +288,28 @@ def test_general_particle_mesh_nonlinnu_shape(golden):
     assert np.array_equal(fl['J'], g['f0_J_out'])
     kick = np.abs(g['p0_mom_out'] - g['p0_mom_in']).max()
     assert np.abs(part['mom'] - g['p0_mom_out']).max() <= 1e-13*kick  # exp() of the cut-off
+
+
+# ---- direct summation with the Ewald correction (oracle/pp.py) ----
+def test_ewald_table_and_lookup(golden):
+    from oracle import pp
+    g = golden('pp_ewald_n4')
+    grid = pp.ewald_tabulate(int(g['ewald_gridsize']))
+    # libm here, SciPy/NumPy scalar calls in the pure-Python reference: to rounding
+    assert np.abs(grid - g['ewald_grid']).max() <= 1e-14*np.abs(g['ewald_grid']).max()
+    assert list(g['ewald_constants']) == [0.25, 3.6, 10, -3, 4, -4, 5]
+    L = float(g['boxsize'])
+    vals = np.array([pp.ewald_lookup(g['ewald_grid'], *pt, L) for pt in g['ewald_points']])
+    assert np.array_equal(vals, g['ewald_values'])   # the CIC look-up itself: bit for bit
+
+
+@pytest.mark.parametrize('name,periodic', [('pp_ewald_n4', True), ('ppnonperiodic_n4', False)])
+def test_pp_kick_bit_exact(golden, name, periodic):
+    from oracle import pp
+    g = golden(name)
+    factor = float(g['G_Newton'])*float(g['mass'])**2*float(g['dt_rungs_pair'][0])
+    dm = pp.pp_kick(g['pos_in'], boxsize=float(g['boxsize']),
+                    softening=float(g['softening_length']), factor=factor, periodic=periodic,
+                    ewald_grid=g['ewald_grid'] if periodic else None)
+    assert np.array_equal(dm, g['dmom'])
+    assert np.array_equal(g['pos_in'], g['pos_after'])
