@@ -1,0 +1,231 @@
+"""concept_amd.snapshot — initial-condition ingestion: GADGET-2 snapshots
+(SnapFormat 1 and 2), the format the reference writes and reads with its GadgetSnapshot
+class (snapshot.py:640-2640), so that the GPU stepper can start from particle data the
+reference (or GADGET / N-GenIC) produced elsewhere.  SURVEY.md §8(f) row 4.
+
+What is restated: the block structure (read_block_bgn, snapshot.py:2390-2445), the 256-byte
+HEAD block (header_fields, snapshot.py:658-689), the POS / VEL / ID blocks with 32- or
+64-bit payloads and their unit conversion (get_blocks_info, snapshot.py:1520-1553):
+    pos = POS * unit_length                       (wrapped into [0, boxsize))
+    mom = VEL * unit_velocity * mass * Time**1.5  (GADGET stores u = a dx/dt / sqrt(a))
+    mass = Massarr[type] * unit_mass
+with the default GADGET units 'kpc/h', 'km/s', '10¹⁰ m☉/h' (commons.py:2787-2804).
+Only single-file snapshots with per-type masses in the header; anything else aborts by name.
+Host-side I/O: numpy only; `to_components()` uploads to GPU Components."""
+import os
+import struct
+
+import numpy as np
+
+from . import commons
+from .lib import ConceptGPUError
+
+component_names = [f'GADGET {t}' for t in ('gas', 'halo', 'disk', 'bulge', 'stars', 'bndry')]
+num_particle_types = len(component_names)
+# name, struct format (snapshot.py:658-689); the rest of the 256 bytes is padding
+header_fields = (
+    ('Npart', '6I'), ('Massarr', '6d'), ('Time', 'd'), ('Redshift', 'd'), ('FlagSfr', 'i'),
+    ('FlagFeedback', 'i'), ('Nall', '6I'), ('FlagCooling', 'i'), ('NumFiles', 'i'),
+    ('BoxSize', 'd'), ('Omega0', 'd'), ('OmegaLambda', 'd'), ('HubbleParam', 'd'),
+    ('FlagAge', 'i'), ('FlagMetals', 'i'), ('NallHW', '6I'), ('flag_entr_ics', 'i'))
+headersize = 256
+default_units = {'length': 'kpc/h', 'velocity': 'km/s', 'mass': '10**10*m_sun/h'}
+
+
+def _unit(expr, h, p):
+    ns = dict(vars(p.units))
+    ns['h'] = h
+    return float(eval(expr, {}, ns))
+
+
+class GadgetSnapshot:
+    """load(filename) fills .header, .params and .components — dicts with name, species,
+    N, mass and float64 arrays pos (N, 3), mom (N, 3) and ids (N,) or None, in the unit
+    system of commons.params."""
+    name = 'GADGET'
+
+    def __init__(self, params=None, units=None):
+        self.p = params or commons.params
+        if self.p is None:
+            raise ConceptGPUError('no parameters loaded: call concept_amd.commons.load_params()')
+        self.unit_expr = dict(default_units)
+        self.unit_expr.update(units or {})
+        self.header, self.params, self.components = {}, {}, []
+        self.snapformat = None
+
+    # -- low level -----------------------------------------------------------
+    @staticmethod
+    def get_snapformat(f):
+        """SnapFormat 2 files open with a 8-byte record holding the block name"""
+        f.seek(0)
+        first = f.read(4)
+        if len(first) < 4:
+            return -1
+        size = struct.unpack('<I', first)[0]
+        if size == 8:
+            return 2
+        if size == headersize:
+            return 1
+        return -1
+
+    def _block(self, f, offset):
+        """-> (payload offset, payload size, name or '', offset of the next block)"""
+        f.seek(offset)
+        name = ''
+        if self.snapformat == 2:
+            rec = f.read(16)
+            if len(rec) < 16:
+                return None
+            s0, nm, nxt, s1 = struct.unpack('<I4sII', rec)
+            if s0 != 8 or s1 != 8:
+                raise ConceptGPUError(f'{self.filename}: malformed block name record at {offset}')
+            name = nm.decode('utf8').rstrip()
+            offset += 16
+            f.seek(offset)
+        head = f.read(4)
+        if len(head) < 4:
+            return None
+        size = struct.unpack('<I', head)[0]
+        payload = offset + 4
+        f.seek(payload + size)
+        tail = f.read(4)
+        if len(tail) < 4 or struct.unpack('<I', tail)[0] != size:
+            raise ConceptGPUError(f'{self.filename}: block "{name}" at {offset} is not framed by '
+                                  f'its size ({size})')
+        if self.snapformat == 2 and nxt != size + 8:
+            raise ConceptGPUError(f'{self.filename}: size of block "{name}" not consistent: '
+                                  f'{nxt} - 8 ≠ {size}')
+        return payload, size, name, payload + size + 4
+
+    def read_header(self, f):
+        blk = self._block(f, 0)
+        if blk is None:
+            raise ConceptGPUError('Expected block "HEAD" at the beginning of the file but found '
+                                  'nothing')
+        payload, size, name, nxt = blk
+        if self.snapformat == 2 and name != 'HEAD':
+            raise ConceptGPUError(f'Expected block "HEAD" at the beginning of the file but found '
+                                  f'"{name}"')
+        if size != headersize:
+            raise ConceptGPUError(f'Block "HEAD" has size {size} but expected {headersize}')
+        f.seek(payload)
+        header = {}
+        for key, fmt in header_fields:
+            t = struct.unpack('<' + fmt, f.read(struct.calcsize('<' + fmt)))
+            header[key] = t[0] if len(t) == 1 else list(t)
+        return header, nxt
+
+    # -- load ------------------------------------------------------------------
+    def load(self, filename, only_params=False):
+        if not os.path.isfile(filename):
+            raise ConceptGPUError(f'Could not locate {self.name} snapshot "{filename}"')
+        self.filename = filename
+        p = self.p
+        with open(filename, 'rb') as f:
+            self.snapformat = self.get_snapformat(f)
+            if self.snapformat not in (1, 2):
+                raise ConceptGPUError(f'Could not determine GADGET SnapFormat of "{filename}"')
+            header, offset = self.read_header(f)
+            self.header = header
+            if header['NumFiles'] > 1:
+                raise ConceptGPUError(f'{filename}: snapshots split over {header["NumFiles"]} '
+                                      'files are not read (single-file snapshots only)')
+            h = header['HubbleParam']
+            if h == 0:
+                raise ConceptGPUError(f'{filename}: HubbleParam = 0 in the header')
+            self.h = h
+            self.unit_length = _unit(self.unit_expr['length'], h, p)
+            self.unit_velocity = _unit(self.unit_expr['velocity'], h, p)
+            self.unit_mass = _unit(self.unit_expr['mass'], h, p)
+            u = p.units
+            self.params = {'H0': h*(100*u.km/(u.s*u.Mpc)), 'a': header['Time'],
+                           'boxsize': header['BoxSize']*self.unit_length,
+                           'Ωm': header['Omega0'], 'ΩΛ': header['OmegaLambda']}
+            npart = [int(n) for n in header['Npart']]
+            for j, n in enumerate(npart):
+                tot = header['Nall'][j] + 2**32*header['NallHW'][j]
+                if tot not in (n, 0):
+                    raise ConceptGPUError(
+                        f'{filename}: Nall = {tot} but Npart = {n} for "{component_names[j]}"')
+            ntot = sum(npart)
+            self.components = []
+            for j, n in enumerate(npart):
+                if n == 0:
+                    continue
+                mass = header['Massarr'][j]
+                if mass <= 0:
+                    raise ConceptGPUError(
+                        f'Mass of "{component_names[j]}" particles is {mass}×10¹⁰ h⁻¹ m☉ '
+                        '(individual particle masses, block MASS, are not read)')
+                self.components.append({'name': component_names[j], 'species': 'matter', 'N': n,
+                                        'mass': mass*self.unit_mass, 'pos': None, 'mom': None,
+                                        'ids': None})
+            if only_params:
+                return self
+            boxsize = self.params['boxsize']
+            order = ['POS', 'VEL', 'ID']  # SnapFormat 1: blocks are identified by position
+            seen = 0
+            while True:
+                blk = self._block(f, offset)
+                if blk is None:
+                    break
+                payload, size, name, offset = blk
+                if self.snapformat == 1:
+                    if seen >= len(order):
+                        break
+                    name = order[seen]
+                seen += 1
+                if name not in ('POS', 'VEL', 'ID'):
+                    continue  # Skipping block (e.g. MASS, U)
+                if ntot == 0 or size % ntot:
+                    raise ConceptGPUError(
+                        f'File {filename} contains {ntot} particles but its "{name}" block has '
+                        f'a size of {size} bytes, which does not divide the particle number.')
+                per = size//ntot
+                f.seek(payload)
+                if name in ('POS', 'VEL'):
+                    if per not in (12, 24):
+                        raise ConceptGPUError(f'No data format with a size of {per//3} bytes '
+                                              f'implemented for block "{name}"')
+                    data = np.fromfile(f, dtype='<f4' if per == 12 else '<f8', count=3*ntot)
+                    data = data.astype(np.float64).reshape(ntot, 3)
+                    start = 0
+                    for c in self.components:
+                        part = data[start:start + c['N']]
+                        start += c['N']
+                        if name == 'POS':
+                            pos = part*self.unit_length
+                            pos[pos >= boxsize] -= boxsize  # round-off safeguard
+                            c['pos'] = np.ascontiguousarray(pos)
+                        else:
+                            unit = self.unit_velocity*c['mass']*header['Time']**1.5
+                            c['mom'] = np.ascontiguousarray(part*unit)
+                else:
+                    if per not in (4, 8):
+                        raise ConceptGPUError(f'ID block with {per} bytes per particle')
+                    ids = np.fromfile(f, dtype='<u4' if per == 4 else '<u8', count=ntot)
+                    start = 0
+                    for c in self.components:
+                        c['ids'] = ids[start:start + c['N']].astype(np.int64)
+                        start += c['N']
+            for c in self.components:
+                for blockname, key in (('POS', 'pos'), ('VEL', 'mom')):
+                    if c[key] is None:
+                        raise ConceptGPUError(f'Could not find required block "{blockname}"')
+        return self
+
+    def to_components(self, device=None):
+        """GPU Components (concept_amd.species.Component) holding the loaded particles"""
+        from .species import Component
+        out = []
+        for c in self.components:
+            comp = Component(c['name'], c['species'], N=c['N'], mass=c['mass'], device=device)
+            comp.populate(c['pos'], 'pos')
+            comp.populate(c['mom'], 'mom')
+            out.append(comp)
+        return out
+
+
+def load(filename, only_params=False, params=None, units=None):
+    """snapshot.load (snapshot.py:3120-3230) for GADGET files"""
+    return GadgetSnapshot(params, units).load(filename, only_params)

@@ -104,6 +104,12 @@ CASES = {
                         diff=2, pp=True, ewald_gridsize=6),
     'ppnonperiodic_n4': dict(method='ppnonperiodic', n=4, gridsize=8, boxsize=20.0, seed=32,
                              dist='clustered', diff=2, pp=True, ewald_gridsize=6),
+    # GADGET-2 snapshots (snapshot.py:640-2640) written by the
+    # reference (the binary file is the fixture) and read back by it (expected arrays)
+    'gadget_sf2_32': dict(method='pm', n=4, gridsize=8, boxsize=64.0, seed=41, dist='uniform',
+                          diff=2, gadget=dict(snapformat=2, bits=32, types=['halo'])),
+    'gadget_sf1_64': dict(method='pm', n=4, gridsize=8, boxsize=48.0, seed=42, dist='clustered',
+                          diff=2, gadget=dict(snapformat=1, bits=64, types=['disk'])),
     'fluid2_pm_n6_g12': dict(method='pm', n=6, gridsize=12, boxsize=48.0, seed=22,
                              dist='clustered', diff=4, fluid=dict(gridsize=12, count=2),
                              particle_components=2),
@@ -480,6 +486,72 @@ def child_fluid(name):
     print('wrote', name, {k: getattr(v, 'shape', v) for k, v in out.items()})
 
 
+def child_gadget(name):
+    """snapshot.save(..., snapshot_type 'gadget') then snapshot.load() of the same file:
+    tests/golden/<name>.gadget is what the reference wrote, the .npz what it reads back
+    (positions, momenta, masses, parameters) — the reader under test must agree."""
+    import importlib
+    import shutil
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, 'oracle', 'refharness'))
+    from ref_import import load_reference
+    cfg = CASES[name]
+    gd = cfg['gadget']
+    text = f"""
+boxsize = {cfg['boxsize']!r}*Mpc
+H0 = 70*km/s/Mpc
+Ωcdm = 0.25
+Ωb = 0.05
+a_begin = 0.5
+enable_class_background = False
+select_forces = {{'all': {{'gravity': 'pm'}}}}
+snapshot_type = 'gadget'
+gadget_snapshot_params = {{'snapformat': {gd['snapformat']},
+                          'dataformat': {{'POS': {gd['bits']}, 'VEL': {gd['bits']}}}}}
+"""
+    work = f'/tmp/concept_golden_work/{name}'
+    ref = load_reference(text, work)
+    commons, species = ref.commons, ref.species
+    snapshot = importlib.import_module('snapshot')
+    L = commons.boxsize
+    rng = np.random.default_rng(1000 + cfg['seed'])
+    pos_all = make_positions(np, cfg)
+    per = pos_all.shape[0]//len(gd['types'])
+    comps = []
+    for i, typ in enumerate(gd['types']):
+        pos = pos_all[i*per:(i + 1)*per]
+        N = pos.shape[0]
+        mass = commons.ρ_mbar*L**3/pos_all.shape[0]*(1 + i)
+        mom = rng.normal(0, 1, size=(N, 3))*mass
+        comp = species.Component(f'GADGET {typ}', 'matter', N=N, mass=mass)
+        for d, s_ in enumerate('xyz'):
+            comp.populate(np.ascontiguousarray(pos[:, d]), 'pos' + s_)
+            comp.populate(np.ascontiguousarray(mom[:, d]), 'mom' + s_)
+        comps.append(comp)
+    originals = [(c.name, int(c.N), float(c.mass), np.array(c.pos_mv3[:c.N]).copy(),
+                  np.array(c.mom_mv3[:c.N]).copy()) for c in comps]
+    fn = snapshot.save(comps, f'{work}/out/snap', save_all=True)
+    shutil.copyfile(fn, os.path.join(HERE, name + '.gadget'))
+    # (the reference's GADGET *loader* does not fill the particle arrays in pure-Python
+    # mode, so the expected values are what its writer was given: the reader under test
+    # must invert the writer's unit conversions, snapshot.py:1520-1553)
+    probe = snapshot.GadgetSnapshot()
+    probe.populate(comps, {})
+    out = dict(snapformat=gd['snapformat'], bits=gd['bits'], boxsize=L,
+               a=commons.universals.a, H0=commons.H0, n_components=len(comps),
+               unit_length=probe.unit_length, unit_velocity=probe.unit_velocity,
+               unit_mass=probe.unit_mass, h=probe.h,
+               names=np.array([o[0] for o in originals]))
+    for i, (nm, n_c, mass, pos, mom) in enumerate(originals):
+        out[f'c{i}_N'] = n_c
+        out[f'c{i}_mass'] = mass
+        out[f'c{i}_pos'] = pos
+        out[f'c{i}_mom'] = mom
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, os.path.getsize(os.path.join(HERE, name + '.gadget')), 'bytes;',
+          {k: getattr(v, 'shape', v) for k, v in out.items()})
+
+
 def child_pp(name):
     """gravity('pp' | 'ppnonperiodic', [c], [c], ᔑdt_rungs, 'any', False): Δmom of every
     particle with all particles on rung 0, the Ewald grid the reference tabulated
@@ -546,6 +618,8 @@ ewald_gridsize = {cfg['ewald_gridsize']}
 
 def child(name):
     import numpy as np
+    if CASES[name].get('gadget'):
+        return child_gadget(name)
     if CASES[name].get('pp'):
         return child_pp(name)
     if 'fluid' in CASES[name]:
