@@ -151,11 +151,20 @@ def _potential_constants(p, potential, gridsize_global):
     return C, True, -(2*π/p.boxsize*scale)**2
 
 
+def _same_tiling(component, mesh):
+    """The tile order of a component depends on the grid geometry only: it is valid on
+    every mesh context of the same grid size (the roles of the general path)."""
+    t = component.tile_mesh
+    return (component.tile_table is not None and t is not None
+            and (t is mesh or (t.gridsize, t.boxsize, t.nghosts, t.device)
+                 == (mesh.gridsize, mesh.boxsize, mesh.nghosts, mesh.device)))
+
+
 def _kick_particles(mesh, receiver, force, method, ᔑdt, ᔑdt_key):
     key = (ᔑdt_key[0], receiver.name) if isinstance(ᔑdt_key, tuple) else ᔑdt_key
     differentiation_order = receiver.potential_differentiations[force][method]
     factor = receiver.mass*(-ᔑdt[key])
-    if receiver.tile_table is not None and receiver.tile_mesh is mesh:
+    if _same_tiling(receiver, mesh):
         # tile order (possibly drifted since the sort: strays are handled)
         mesh.gather_kick_tiled(receiver.pos, receiver.mom, receiver.tile_table,
                                differentiation_order, factor)
@@ -290,11 +299,24 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
             add_to_global(up, 0)
         for shift in (shifts_upstream if particle_components else ()):
             up = upstream_mesh(gridsize_upstream)
-            up.zero()
-            for supplier in particle_components:
+            simple = interpolation_order == 2 and shift == (0, 0, 0)
+            # tile-sorted suppliers first: the LDS-tiled deposit assigns the mesh (no
+            # zero-fill pass), later ones accumulate
+            ordered = sorted(particle_components,
+                             key=lambda c: not (simple and c.tiles_exact and _same_tiling(c, up)))
+            started = False
+            for supplier in ordered:
                 contribution = _particle_contribution(supplier, ᔑdt, fft_factor,
                                                       gridsize_upstream, boxsize)
-                if interpolation_order == 2 and shift == (0, 0, 0):
+                if simple and supplier.tiles_exact and _same_tiling(supplier, up):
+                    up.deposit_tiled(supplier.pos, supplier.tile_table, contribution,
+                                     accumulate=started)
+                    started = True
+                    continue
+                if not started:
+                    up.zero()
+                    started = True
+                if simple:
                     up.deposit(supplier.pos, contribution)
                 else:
                     up.deposit_general(supplier.pos, contribution, interpolation_order, shift)
