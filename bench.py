@@ -84,9 +84,9 @@ def cpu_baseline(sample_n=128, sample_grid=256, steps=12):
 
 def main_distributed(args, name, n_p, N, L, dev, rank, world):
     """Strong scaling: the same total workload on `world` x-slab domains, one per GPU
-    (concept_amd/distributed.py).  A step = drift + particle exchange + tile sort +
-    long-range kick (deposit, ghost fold, FFT with two all-to-all transposes, ghost
-    fill, gather-kick)."""
+    (concept_amd/distributed.py).  A step = drift + particle exchange + tile sort (fused:
+    DistributedParticles.drift_exchange_sort) + long-range kick (deposit, ghost fold, FFT
+    with two all-to-all transposes, ghost fill, gather-kick)."""
     import torch
     import torch.distributed as dist
     from concept_amd.distributed import DistributedParticles, SlabDomain, pm_kick
@@ -110,10 +110,11 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world):
     C = -L**2*G/3.141592653589793
 
     def step():
-        parts.drift(dt/mass)
-        parts.exchange()
-        parts.tile_sort()
-        pm_kick(dom, parts, contribution, 4, C, mass*(-dt), diff_order=2)
+        # fused: emigrants of the coming drift are shipped first, then one drift + sort pass
+        # pair; the gather-kick histograms the tiles of the next drift
+        parts.drift_exchange_sort(dt/mass)
+        pm_kick(dom, parts, contribution, 4, C, mass*(-dt), diff_order=2,
+                next_dt_over_mass=dt/mass)
 
     for _ in range(args.warmup):
         step()

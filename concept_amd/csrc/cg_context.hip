@@ -516,7 +516,6 @@ extern "C" int cg_gather_kick_tiled_prepare(cg_ctx *c, const double *pos, double
     CG_CHECK((diff_order + 1) / 2 <= c->p.nghosts,
              "cg_gather_kick_tiled_prepare: differentiation order %d needs nghosts >= %d",
              diff_order, (diff_order + 1) / 2);
-    CG_CHECK(c->p.nprocs == 1, "cg_gather_kick_tiled_prepare: single-domain only");
     if (n == 0) return 0;
     return cgk_gather_kick_tiled(c, pos, mom, n, tile_offset, diff_order, factor, 1,
                                  next_dt_over_mass);
@@ -545,8 +544,8 @@ extern "C" int cg_drift_sort(cg_ctx *c, const double *pos_in, const double *mom_
     CG_CHECK((ids_in == nullptr) == (ids_out == nullptr),
              "cg_drift_sort: ids_in and ids_out must both be given or both be null");
     CG_CHECK(n >= 0 && n < (1ll << 32), "cg_drift_sort: n out of range");
-    CG_CHECK(c->p.nprocs == 1, "cg_drift_sort: single-domain (x-slab domains exchange "
-                               "particles between the drift and the sort)");
+    // x-slab domains: particles whose drifted position leaves the slab are dropped (the host
+    // ships them beforehand: cg_owner_rank_drifted + exchange + cg_prepare_rebind)
     // a histogram prepared by cg_gather_kick_tiled_prepare for exactly these arrays and this
     // drift replaces the first pass (anything else touching pos/mom in between is a caller bug
     // the pointers cannot reveal: the prepared state is consumed by the very next sort only)
@@ -554,6 +553,20 @@ extern "C" int cg_drift_sort(cg_ctx *c, const double *pos_in, const double *mom_
                        c->prep_n == n && c->prep_dtm == dt_over_mass;
     return cgk_sort(c, pos_in, mom_in, ids_in, pos_out, mom_out, ids_out, n, tile_offset_out, 1,
                     dt_over_mass, use_prepared);
+}
+
+extern "C" int cg_owner_rank_drifted(cg_ctx *c, const double *pos, const double *mom, int64_t n,
+                                     double dt_over_mass, int32_t *owner) {
+    CG_CHECK(c && (n == 0 || (pos && mom && owner)), "cg_owner_rank_drifted: null argument");
+    return cgk_owner_rank_drifted(c, pos, mom, n, dt_over_mass, owner);
+}
+
+extern "C" int cg_prepare_rebind(cg_ctx *c, const double *pos, const double *mom, int64_t n_total,
+                                 const double *add_pos, const double *add_mom, int64_t n_add) {
+    CG_CHECK(c && pos && mom && (n_add == 0 || (add_pos && add_mom)),
+             "cg_prepare_rebind: null argument");
+    CG_CHECK(n_total >= 0 && n_add >= 0 && n_total < (1ll << 32), "cg_prepare_rebind: sizes");
+    return cgk_prepare_rebind(c, pos, mom, n_total, add_pos, add_mom, n_add);
 }
 
 extern "C" int cg_cic_indices(cg_ctx *c, const double *pos, int64_t n, int for_gather,

@@ -177,6 +177,10 @@ int cgk_pp_kick(cg_ctx *c, const double *pos_r, i64 n_r, double *dmom_r, const d
                 i64 n_s, int same, const double *ewald_grid, int ewald_gridsize,
                 double softening, int kernel, double factor, const double *factors,
                 const signed char *rung, const signed char *rung_jumped, int lowest_active);
+int cgk_owner_rank_drifted(cg_ctx *c, const double *pos, const double *mom, i64 n, double dtm,
+                           int *owner);
+int cgk_prepare_rebind(cg_ctx *c, const double *pos, const double *mom, i64 n_total,
+                       const double *add_pos, const double *add_mom, i64 n_add);
 int cgk_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int dim,
                    int diff_order, double minus_dt, double inv_c2);
 int cgk_fft(cg_ctx *c, int what, int deconv_order, double C, int long_range, double E);

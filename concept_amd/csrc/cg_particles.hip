@@ -155,6 +155,48 @@ __global__ __launch_bounds__(256) void k_tile_scatter(
     }
 }
 
+// Owner domain of each particle AFTER the drift pos + mom*dtm (the arithmetic of
+// load_pos<true>, i.e. of k_tile_scatter<true>): lets the x-slab path ship the particles that
+// are about to leave before the fused drift + sort instead of drifting in a pass of its own.
+__global__ void k_owner_rank_drifted(const double *__restrict__ pos,
+                                     const double *__restrict__ mom, i64 n, double dtm, double L,
+                                     CicGeom geo, int g, int N, int nxl, int *__restrict__ owner) {
+    i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double x, y, z;
+    load_pos<true>(pos, mom, p, dtm, L, x, y, z);
+    owner[p] = lower_cell(x, geo.off[0], geo.scale, g, N) / nxl;
+}
+int cgk_owner_rank_drifted(cg_ctx *c, const double *pos, const double *mom, i64 n, double dtm,
+                           int *owner) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_owner_rank_drifted, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       c->stream, pos, mom, n, dtm, c->p.boxsize, c->geom_deposit, c->p.nghosts,
+                       (int)c->N, (int)c->xmap.nxl, owner);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// Add the tile keys (after the drift) of `n` more particles to a prepared histogram and bind it
+// to new arrays: the x-slab path after its particle exchange (immigrants were not counted by
+// the previous gather-kick; emigrants never were, tile_of() gives them no key).
+int cgk_prepare_rebind(cg_ctx *c, const double *pos, const double *mom, i64 n_total,
+                       const double *add_pos, const double *add_mom, i64 n_add) {
+    if (!c->prep_valid) return 0;
+    if (n_add > 0) {
+        i64 blocks = (n_add + 255) / 256;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(k_tile_histogram<true>, dim3((unsigned)blocks), dim3(256), 0, c->stream,
+                           add_pos, add_mom, n_add, c->prep_dtm, c->p.boxsize, c->geom_deposit,
+                           c->p.nghosts, c->N, c->tiles, c->xmap.x0, c->tile_count);
+        CG_LAUNCH_CHECK();
+    }
+    c->prep_pos = pos;
+    c->prep_mom = mom;
+    c->prep_n = n_total;
+    return 0;
+}
+
 int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
              double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out,
              int drift, double dt_over_mass, int use_prepared) {

@@ -199,6 +199,37 @@ class DistributedParticles:
             DEAD_X_FACTOR*d.boxsize)
         self.sorted = False
 
+    def drift_exchange_sort(self, dt_over_mass):
+        """drift + exchange + tile sort in fused form: the particles whose DRIFTED position
+        leaves this rank's slab are shipped first (undrifted rows; the receiver drifts them
+        with the same arithmetic), then one fused drift + sort pass pair runs over the
+        compacted local set.  When the previous pm_kick prepared the tile histogram of this
+        drift (next_dt_over_mass), the immigrants' keys are added to it and the sort needs
+        no histogram pass.  Same result as drift(); exchange(); tile_sort()."""
+        d = self.domain
+        m = d.mesh
+        pos, mom = self.view('pos'), self.view('mom')
+        owner = m.owner_rank_drifted(pos, mom, dt_over_mass)
+        n_new, inc = exchange_rows_compact(d.comm, owner, self.pos, self.mom, self.ids, self.n,
+                                           self.cap)
+        self.n = n_new
+        pos, mom = self.view('pos'), self.view('mom')
+        if inc is not None and inc.shape[0]:
+            m.prepare_rebind(pos, mom, inc[:, 0:3].contiguous(), inc[:, 3:6].contiguous())
+        else:
+            m.prepare_rebind(pos, mom)
+        m.drift_sort(pos, mom, self.view('ids'), self.pos2[:n_new], self.mom2[:n_new],
+                     self.ids2[:n_new], dt_over_mass, self.table)
+        self.pos, self.pos2 = self.pos2, self.pos
+        self.mom, self.mom2 = self.mom2, self.mom
+        self.ids, self.ids2 = self.ids2, self.ids
+        kept = int(self.table[-1].item()) & 0xffffffff
+        if kept != n_new:
+            raise lib.ConceptGPUError(
+                f'rank {d.rank}: fused drift + sort kept {kept} of {n_new} particles')
+        self._expected = kept
+        self.sorted = True
+
     def tile_sort(self):
         d = self.domain
         d.mesh.sort_particles(self.view('pos'), self.view('mom'), self.view('ids'),
@@ -258,6 +289,51 @@ def exchange_rows(comm, owner, pos, mom, ids, n, cap, dead_x):
     elif m_out > k:
         pos[move_idx[k:], 0] = dead_x
     return n_slots, n - m_out + m_in
+
+
+def exchange_rows_compact(comm, owner, pos, mom, ids, n, cap):
+    """exchange_rows that leaves no dead rows: vacated slots are refilled with immigrants,
+    surplus immigrants are appended, leftover holes are closed with live rows from the tail.
+    Returns (n_new, immigrant rows (m_in, 7) or None); the live rows are [0, n_new)."""
+    P, rank = comm.world, comm.rank
+    dev = pos.device
+    move_idx = torch.nonzero(owner[:n] != rank).flatten()
+    dest = owner[move_idx].long()
+    order = torch.argsort(dest, stable=True)
+    move_idx, dest = move_idx[order], dest[order]
+    send_counts = torch.bincount(dest, minlength=P).cpu().tolist()
+    rows = torch.empty((move_idx.numel(), 7), dtype=torch.float64, device=dev)
+    rows[:, 0:3] = pos[move_idx]
+    rows[:, 3:6] = mom[move_idx]
+    rows[:, 6] = ids[move_idx].view(torch.float64)
+    counts = comm.all_gather_ints(send_counts)  # counts[src][dst]
+    recv_counts = counts[:, rank].tolist()
+    m_in, m_out = int(sum(recv_counts)), int(move_idx.numel())
+    inc = torch.empty((m_in, 7), dtype=torch.float64, device=dev)
+    comm.all_to_all(inc, rows, recv_counts, send_counts)
+    k = min(m_in, m_out)
+    if k:
+        h = move_idx[:k]
+        pos[h] = inc[:k, 0:3]
+        mom[h] = inc[:k, 3:6]
+        ids[h] = inc[:k, 6].contiguous().view(torch.int64)
+    n_new = n - m_out + m_in
+    if m_in > k:
+        if n_new > cap:
+            raise lib.ConceptGPUError(f'rank {rank}: particle capacity {cap} exceeded ({n_new})')
+        pos[n:n_new] = inc[k:, 0:3]
+        mom[n:n_new] = inc[k:, 3:6]
+        ids[n:n_new] = inc[k:, 6].contiguous().view(torch.int64)
+    elif m_out > k:
+        holes = move_idx[k:]
+        low = holes[holes < n_new]                       # holes to fill
+        tail = torch.ones(n - n_new, dtype=torch.bool, device=dev)
+        tail[holes[holes >= n_new] - n_new] = False      # tail rows that are holes themselves
+        src = torch.nonzero(tail).flatten() + n_new      # live rows of the tail
+        pos[low] = pos[src]
+        mom[low] = mom[src]
+        ids[low] = ids[src]
+    return n_new, (inc if m_in else None)
 
 
 def shortrange_kick(domain, particles, *, scale, range_, tilesize, tablesize, softening,
@@ -320,7 +396,7 @@ def shortrange_kick(domain, particles, *, scale, range_, tilesize, tablesize, so
 
 
 def pm_kick(domain, particles, contribution, deconv_order, C, kick_factor, diff_order=2,
-            long_range=False, E=0.0):
+            long_range=False, E=0.0, next_dt_over_mass=None):
     """One long-range PM kick of a tile-sorted particle set onto itself, sharded
     (particle_mesh(), interactions.py:1985-2335)."""
     if not particles.sorted:
@@ -330,5 +406,10 @@ def pm_kick(domain, particles, contribution, deconv_order, C, kick_factor, diff_
     domain.fold_deposit_ghost()
     domain.poisson_solve(deconv_order, C, long_range, E)
     domain.fill_potential_ghosts()
-    m.gather_kick_tiled(particles.view('pos'), particles.view('mom'), particles.table,
-                        diff_order, kick_factor)
+    if next_dt_over_mass is None:
+        m.gather_kick_tiled(particles.view('pos'), particles.view('mom'), particles.table,
+                            diff_order, kick_factor)
+    else:
+        # also histogram the tile keys after the NEXT drift (for drift_exchange_sort)
+        m.gather_kick_tiled_prepare(particles.view('pos'), particles.view('mom'),
+                                    particles.table, diff_order, kick_factor, next_dt_over_mass)

@@ -83,6 +83,8 @@ SYMBOLS = {
     'cg_dist_fft_xsolve': (_int, [_vp, _vp, _int, _dbl, _int, _dbl]),
     'cg_dist_fft_backward': (_int, [_vp, _vp]),
     'cg_owner_rank': (_int, [_vp, _vp, _i64, _vp]),
+    'cg_owner_rank_drifted': (_int, [_vp, _vp, _vp, _i64, _dbl, _vp]),
+    'cg_prepare_rebind': (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64]),
     'cg_fetch': (_int, [_vp, _int, _vp, _i64]),
     'cg_cic_indices': (_int, [_vp, _vp, _i64, _int, _vp]),
     'cg_fluid_add': (_int, [_vp, _vp, _dbl, _int]),

@@ -392,6 +392,20 @@ class PotentialMesh:
         check(_L.cg_owner_rank(self._ctx, _ptr(pos), n, _ptr(out)))
         return out
 
+    def owner_rank_drifted(self, pos, mom, dt_over_mass):
+        n = self._check_particles(pos, mom)
+        owner = torch.empty(n, dtype=torch.int32, device=pos.device)
+        check(_L.cg_owner_rank_drifted(self._ctx, _ptr(pos), _ptr(mom), n, float(dt_over_mass),
+                                       _ptr(owner)))
+        return owner
+
+    def prepare_rebind(self, pos, mom, add_pos=None, add_mom=None):
+        n = self._check_particles(pos, mom)
+        n_add = 0 if add_pos is None else self._check_particles(add_pos, add_mom)
+        check(_L.cg_prepare_rebind(self._ctx, _ptr(pos), _ptr(mom), n,
+                                   _ptr(add_pos) if n_add else None,
+                                   _ptr(add_mom) if n_add else None, n_add))
+
     def fetch(self, which):
         N = self.gridsize
         out = np.empty((self.nxl, N, N + 2), dtype=np.float64)

@@ -268,6 +268,17 @@ int cg_dist_fft_xsolve(cg_ctx *ctx, double *buf /*DEV*/, int deconv_order, doubl
 int cg_dist_fft_backward(cg_ctx *ctx, const double *recv_buf /*DEV*/);
 int cg_owner_rank(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n,
                   int32_t *owner_out /*DEV n*/);
+/* The fused step of the x-slab path: cg_owner_rank_drifted gives the owner of every particle
+ * AFTER the coming drift (same arithmetic as cg_drift_sort) so that the caller can run
+ * exchange() (communication.py:135-517) on the undrifted rows first; cg_prepare_rebind then
+ * adds the immigrants' tile keys to the histogram prepared by the previous
+ * cg_gather_kick_tiled_prepare and binds it to the compacted arrays, and cg_drift_sort
+ * drifts and sorts in one pass pair (no stand-alone drift, no histogram pass). */
+int cg_owner_rank_drifted(cg_ctx *ctx, const double *pos /*DEV 3n*/, const double *mom /*DEV 3n*/,
+                          int64_t n, double dt_over_mass, int32_t *owner_out /*DEV n*/);
+int cg_prepare_rebind(cg_ctx *ctx, const double *pos /*DEV*/, const double *mom /*DEV*/,
+                      int64_t n_total, const double *add_pos /*DEV 3 n_add*/,
+                      const double *add_mom /*DEV 3 n_add*/, int64_t n_add);
 
 /* --- general particle_mesh(): several suppliers / receivers, particles and fluids
  *     (interactions.py:1985-2402) ----------------

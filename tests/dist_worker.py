@@ -20,6 +20,7 @@ def main():
     dist.init_process_group(backend, rank=rank, world_size=world)
     from concept_amd.distributed import DistributedParticles, SlabDomain, pm_kick, shortrange_kick
     p3m = len(sys.argv) > 6 and sys.argv[6] == 'p3m'
+    fused = len(sys.argv) > 6 and sys.argv[6] == 'fused'
     L = 64.0
     dom = SlabDomain(N, L)
     rng = np.random.default_rng(77)
@@ -40,10 +41,14 @@ def main():
                                  tablesize=4096, softening=0.05*L/n_side, factor=3e-4)
             parts.view('mom').add_(dm)
         pm_kick(dom, parts, contribution, 4, C, kick, diff_order=2 + 2*(step % 2),
-                long_range=p3m, E=-(2*np.pi/L*1.25*L/N)**2 if p3m else 0.0)
-        parts.drift(dtm)
-        parts.exchange()
-        parts.tile_sort()
+                long_range=p3m, E=-(2*np.pi/L*1.25*L/N)**2 if p3m else 0.0,
+                next_dt_over_mass=dtm if fused and step % 3 != 2 else None)
+        if fused:  # (every third step without a prepared histogram: both paths of the sort)
+            parts.drift_exchange_sort(dtm)
+        else:
+            parts.drift(dtm)
+            parts.exchange()
+            parts.tile_sort()
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), ids=parts.view('ids').cpu().numpy(),
              pos=parts.view('pos').cpu().numpy(), mom=parts.view('mom').cpu().numpy(),

@@ -49,9 +49,17 @@ def single_domain(N, n_side, steps, p3m=False):
 
 
 @pytest.mark.parametrize('world,N,p3m', [(2, 32, False), (4, 64, False), (2, 64, False),
-                                         (8, 128, False), (2, 64, True), (4, 128, True)])
+                                         (8, 128, False), (2, 64, True), (4, 128, True),
+                                         (2, 32, 'fused'), (4, 64, 'fused'), (8, 128, 'fused')])
 def test_slab_domains_match_single_domain(world, N, p3m):
+    """p3m = 'fused': the PM step with the fused drift + exchange + sort
+    (DistributedParticles.drift_exchange_sort) and the tile histogram prepared by the
+    gather-kick — what bench.py runs on N > 1 GPUs."""
     n_side, steps = 20, 3
+    mode = p3m if isinstance(p3m, str) else ('p3m' if p3m else 'pm')
+    p3m = p3m is True
+    if mode == 'fused':
+        steps = 5
     pos_ref, mom_ref = single_domain(N, n_side, steps, p3m)
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -64,7 +72,7 @@ def test_slab_domains_match_single_domain(world, N, p3m):
                        MASTER_PORT=str(port))
             procs.append(subprocess.Popen(
                 [sys.executable, os.path.join(REPO, 'tests', 'dist_worker.py'), tmp, str(N),
-                 str(n_side), str(steps), 'gloo', 'p3m' if p3m else 'pm'], env=env,
+                 str(n_side), str(steps), 'gloo', mode], env=env,
                 stdout=subprocess.PIPE,
                 stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=600)[0].decode() for p in procs]
