@@ -110,3 +110,46 @@ def test_ring_sendrecv():
 @pytest.mark.parametrize('world', [2, 4])
 def test_particle_exchange(world):
     _run(_w_exchange, world, 500)
+
+
+def _w_exchange_compact(rank, world, n_per, skew):
+    """exchange_rows_compact: afterwards the live rows are exactly [0, n_new), every particle
+    is at home, rows stayed together, nothing lost or duplicated; `skew` makes one rank
+    lose far more than it gains (holes closed from the tail) and another gain more."""
+    from concept_amd.distributed import Comm, exchange_rows_compact
+    comm = Comm()
+    gen = torch.Generator().manual_seed(200 + rank)
+    cap = 4*n_per
+    pos = torch.zeros((cap, 3), dtype=torch.float64)
+    mom = torch.zeros((cap, 3), dtype=torch.float64)
+    ids = torch.zeros(cap, dtype=torch.int64)
+    n = n_per + 11*rank
+    x = torch.rand((n, 3), dtype=torch.float64, generator=gen)
+    if skew:  # almost everything of rank 0 belongs to the last rank
+        x[:, 0] = x[:, 0]**(0.15 if rank == 0 else 1.0)
+    pos[:n] = x
+    mom[:n] = pos[:n]*3 + 1
+    ids[:n] = torch.arange(n) + 10**6*rank
+    pos[n:] = float('nan')  # anything beyond n must never be picked up
+    owner = torch.clamp((pos[:n, 0]*world).long(), max=world - 1).int()
+    before = comm.all_gather_ints([n])[:, 0].sum().item()
+    n_new, inc = exchange_rows_compact(comm, owner, pos, mom, ids, n, cap)
+    p, m, i = pos[:n_new], mom[:n_new], ids[:n_new]
+    assert not torch.isnan(p).any()
+    assert (torch.clamp((p[:, 0]*world).long(), max=world - 1) == rank).all()
+    assert torch.equal(m, p*3 + 1)
+    m_in = 0 if inc is None else inc.shape[0]
+    if m_in:  # the immigrant rows are among the live rows
+        live = {tuple(r) for r in p.tolist()}
+        assert all(tuple(r) in live for r in inc[:, 0:3].tolist())
+    after = comm.all_gather_ints([n_new])[:, 0].sum().item()
+    assert after == before
+    all_ids = [None]*world
+    dist.all_gather_object(all_ids, i.tolist())
+    flat = sorted(v for l in all_ids for v in l)
+    assert len(flat) == len(set(flat)) == before
+
+
+@pytest.mark.parametrize('world,skew', [(2, False), (4, False), (3, True)])
+def test_particle_exchange_compact(world, skew):
+    _run(_w_exchange_compact, world, 400, skew)
