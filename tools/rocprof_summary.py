@@ -51,8 +51,8 @@ def pmc(path):
     for k, d in sorted(acc.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values())):
         print(k[:110])
         for cname, vals in d.items():
-            print('    %-20s calls %4d  mean %.6g  total %.6g' % (cname, len(vals),
-                                                                 sum(vals)/len(vals), sum(vals)))
+            print('    %-20s calls %4d  mean %.6g  total %.6g  min %.6g  max %.6g' % (
+                cname, len(vals), sum(vals)/len(vals), sum(vals), min(vals), max(vals)))
 
 
 if __name__ == '__main__':
