@@ -55,8 +55,8 @@ static int make_plans(cg_ctx *c) {
     // row pitch c->pad >= N + 2 doubles (a multiple of 16 doubles when N is, so that
     // rows and 16-cell tile rows start on 128-byte lines)
     const size_t P = (size_t)c->pad;
-    size_t rstr[3] = {1, P, P * N};
-    size_t cstr[3] = {1, P / 2, (P / 2) * N};
+    size_t rstr[3] = {1, P, P * (size_t)c->ny};
+    size_t cstr[3] = {1, P / 2, (P / 2) * (size_t)c->ny};
     size_t off[1] = {0};
     rocfft_plan_description d = nullptr;
     CG_FFT(rocfft_plan_description_create(&d));
@@ -126,7 +126,8 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
     c->pad = (c->N % 16 == 0) ? c->N + 16 : c->N + 2;
     if (p->nprocs == 1) c->xmap = XMap{0, c->N, 0, 1};
     else c->xmap = XMap{(c->N / p->nprocs) * p->rank, c->N / p->nprocs, 3, 0};
-    c->mesh_doubles = (c->xmap.nxl + 2 * c->xmap.G) * c->N * c->pad;
+    c->ny = (c->N % 16 == 0) ? c->N + 1 : c->N;
+    c->mesh_doubles = (c->xmap.nxl + 2 * c->xmap.G) * c->ny * c->pad;
     auto fail = [&]() {
         cg_destroy(c);
         return 1;
@@ -137,7 +138,7 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
         return fail();
     }
     c->device_bytes += 8 * c->mesh_doubles;
-    c->mesh0 = c->mesh + (i64)c->xmap.G * c->N * c->pad;
+    c->mesh0 = c->mesh + (i64)c->xmap.G * c->ny * c->pad;
     // geometry, reference expressions
     const double bgn[3] = {0, 0, 0};
     double cellsize_dep = p->boxsize / (double)p->gridsize;             // mesh.py:1577
@@ -672,16 +673,19 @@ extern "C" int cg_local_info(const cg_ctx *c, int64_t info[6]) {
     info[2] = c->xmap.G;
     info[3] = c->N;
     info[4] = c->pad;
-    info[5] = c->xmap.nxl * c->N * c->pad;
+    // transpose buffers: complex[P][nxl][N/P + 1][pad/2] (one unused row per layer, cg_fft.hip)
+    info[5] = c->xmap.nxl * (c->N + c->p.nprocs) * c->pad;
     return 0;
 }
+
+extern "C" int64_t cg_layer_doubles(const cg_ctx *c) { return c ? c->ny * c->pad : 0; }
 
 extern "C" int cg_layers_read(cg_ctx *c, int64_t layer0, int64_t nlayers, double *dst) {
     CG_CHECK(c && dst, "cg_layers_read: null argument");
     CG_CHECK(layer0 >= -(i64)c->xmap.G && layer0 + nlayers <= c->xmap.nxl + c->xmap.G &&
                  nlayers >= 0, "cg_layers_read: layers [%lld, %lld) outside the local buffer",
              (long long)layer0, (long long)(layer0 + nlayers));
-    i64 per = c->N * c->pad;
+    i64 per = c->ny * c->pad;  // whole layers, the unused row included
     CG_HIP(hipMemcpyAsync(dst, c->mesh0 + layer0 * per, 8 * per * nlayers,
                           hipMemcpyDeviceToDevice, c->stream));
     return 0;
@@ -727,8 +731,10 @@ extern "C" int cg_fetch(cg_ctx *c, int which, double *out, int64_t n_doubles) {
     const size_t row = 8 * (size_t)(c->N + 2);
     if (which == CG_FETCH_MESH_REAL) {
         CG_HIP(hipStreamSynchronize(c->stream));
-        CG_HIP(hipMemcpy2D(out, row, c->mesh0, 8 * (size_t)c->pad, row,
-                           (size_t)(c->xmap.nxl * c->N), hipMemcpyDeviceToHost));
+        for (i64 layer = 0; layer < c->xmap.nxl; layer++)  // N of the ny rows of every layer
+            CG_HIP(hipMemcpy2D(out + layer * c->N * (c->N + 2), row,
+                               c->mesh0 + layer * c->ny * c->pad, 8 * (size_t)c->pad, row,
+                               (size_t)c->N, hipMemcpyDeviceToHost));
         return 0;
     }
     if (which == CG_FETCH_MESH_FOURIER) {

@@ -283,11 +283,12 @@ __device__ __forceinline__ void fft_lds(double2 *lds, const double2 *__restrict_
 // One row per workgroup.  tw[k] = exp(-2 pi i k/N), k < N.
 // ---------------------------------------------------------------------------
 template <int LOGN /* log2 N */, int NT>
-__global__ __launch_bounds__(NT) void k_fft_z_forward(double *__restrict__ mesh, i64 pad,
-                                                      const double2 *__restrict__ tw) {
+__global__ __launch_bounds__(NT) void k_fft_z_forward(double *__restrict__ mesh, i64 ny,
+                                                      i64 pad, const double2 *__restrict__ tw) {
     constexpr int N = 1 << LOGN, H = N / 2;
     __shared__ double2 lds[H];
-    double2 *row = (double2 *)(mesh + (i64)blockIdx.x * pad);
+    // blockIdx.x = layer*N + j; a layer is ny >= N rows (cg_ctx::ny)
+    double2 *row = (double2 *)(mesh + ((i64)(blockIdx.x >> LOGN) * ny + (blockIdx.x & (N - 1))) * pad);
     const int tid = threadIdx.x;
     {
         constexpr int PER = (H + NT - 1) / NT;
@@ -317,11 +318,11 @@ __global__ __launch_bounds__(NT) void k_fft_z_forward(double *__restrict__ mesh,
 
 // z pass, backward: N/2+1 complex -> N reals (unnormalised), in place.
 template <int LOGN, int NT>
-__global__ __launch_bounds__(NT) void k_fft_z_backward(double *__restrict__ mesh, i64 pad,
-                                                       const double2 *__restrict__ tw) {
+__global__ __launch_bounds__(NT) void k_fft_z_backward(double *__restrict__ mesh, i64 ny,
+                                                       i64 pad, const double2 *__restrict__ tw) {
     constexpr int N = 1 << LOGN, H = N / 2;
     __shared__ double2 lds[H];
-    double2 *row = (double2 *)(mesh + (i64)blockIdx.x * pad);
+    double2 *row = (double2 *)(mesh + ((i64)(blockIdx.x >> LOGN) * ny + (blockIdx.x & (N - 1))) * pad);
     const int tid = threadIdx.x;
     // merge: Z[k] = (X[k] + conj X[H-k]) + i conj(w^k) (X[k] - conj X[H-k]), k = 0..H-1
     for (int k = tid; k < H; k += NT) {
@@ -707,10 +708,10 @@ static int run_z(cg_ctx *c, bool inverse) {
     unsigned rows = (unsigned)(c->xmap.nxl * c->N);  // owned layers only
     if (!inverse)
         hipLaunchKernelGGL((k_fft_z_forward<LOGN, NT>), dim3(rows), dim3(NT), 0, c->stream,
-                           c->mesh0, c->pad, (const double2 *)c->fft_tw);
+                           c->mesh0, c->ny, c->pad, (const double2 *)c->fft_tw);
     else
         hipLaunchKernelGGL((k_fft_z_backward<LOGN, NT>), dim3(rows), dim3(NT), 0, c->stream,
-                           c->mesh0, c->pad, (const double2 *)c->fft_tw);
+                           c->mesh0, c->ny, c->pad, (const double2 *)c->fft_tw);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -818,7 +819,9 @@ static int fft3d(cg_ctx *c, int what, const KspaceParams &P) {
     // single domain.  what: 0 forward, 1 backward, 2 forward + kernel + backward (fused x)
     const i64 cp = c->pad / 2, N = c->N;
     double2 *m = (double2 *)c->mesh0;
-    PencilMap ymap = plain_map(cp * N, cp), xmap = plain_map(cp, cp * N);
+    // y pencils: one per (layer, kk) with stride cp; x pencils: one per (row, kk) with the
+    // layer stride cp*ny (ny rows per layer, cg_ctx::ny)
+    PencilMap ymap = plain_map(cp * c->ny, cp), xmap = plain_map(cp, cp * c->ny);
     if (what == 0) {
         if (run_z<LOGN>(c, false)) return 1;
         if (run_strided<LOGN, 0>(c, m, m, ymap, ymap, N, 0, P)) return 1;
@@ -856,17 +859,20 @@ static int fft3d(cg_ctx *c, int what, const KspaceParams &P) {
 template <int LOGN>
 static int fft_dist(cg_ctx *c, int what, double2 *buf, const KspaceParams &P) {
     const i64 cp = c->pad / 2, N = c->N, nxl = c->xmap.nxl, JB = N / c->p.nprocs;
+    // rows per x layer in the transpose buffers: JB used + 1 unused, for the same reason as
+    // cg_ctx::ny (the x pencils' stride JB*cp*16 B would be a large power of two times 65)
+    const i64 JBp = JB + 1;
     int sh = 0;
     while ((1 << sh) < JB) sh++;
     double2 *m = (double2 *)c->mesh0;
-    PencilMap ymap = plain_map(cp * N, cp);
-    PencilMap bmap{JB * cp, cp, nxl * JB * cp, sh};
+    PencilMap ymap = plain_map(cp * c->ny, cp);
+    PencilMap bmap{JBp * cp, cp, nxl * JBp * cp, sh};
     if (what == 0) {  // forward z, forward y -> send buffer
         if (run_z<LOGN>(c, false)) return 1;
         return run_strided<LOGN, 0>(c, m, buf, ymap, bmap, nxl, 0, P);
     }
     if (what == 2) {  // fused x pass on complex[N][JB][cp]
-        PencilMap xmap = plain_map(cp, JB * cp);
+        PencilMap xmap = plain_map(cp, JBp * cp);
         return run_strided<LOGN, 2>(c, buf, buf, xmap, xmap, JB, (i64)c->p.rank * JB, P);
     }
     // backward y from the returned buffer, backward z

@@ -26,7 +26,7 @@
 
 __global__ __launch_bounds__(256) void k_fluid_add(double *__restrict__ mesh,
                                                    const double *__restrict__ fluid, int N,
-                                                   i64 pad, double factor, int op_add) {
+                                                   i64 ny, i64 pad, double factor, int op_add) {
     // one thread per (i, j, k-pair): rows of the fluid grid are contiguous
     const i64 total = (i64)N * N * N;
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -35,20 +35,21 @@ __global__ __launch_bounds__(256) void k_fluid_add(double *__restrict__ mesh,
         int k = (int)(t - row * N);
         double v = fluid[t];
         if (factor != 1) v = v * factor;  // mesh.py:1737-1751
-        double *dst = mesh + row * pad + k;
+        i64 i = row / N;
+        double *dst = mesh + (i * ny + (row - i * N)) * pad + k;
         if (op_add) *dst += v;
         else *dst = v;
     }
 }
 
 __global__ __launch_bounds__(256) void k_nullify_nyquist(double2 *__restrict__ mesh, int N,
-                                                         i64 cp) {
+                                                         i64 ny, i64 cp) {
     // complex[N][N][cp]: planes a == nyq, b == nyq, kk == nyq
     const int nyq = N / 2;
     const i64 rows = (i64)N * N;
     for (i64 row = (i64)blockIdx.x; row < rows; row += gridDim.x) {
         int a = (int)(row / N), b = (int)(row - (i64)a * N);
-        double2 *r = mesh + row * cp;
+        double2 *r = mesh + ((i64)a * ny + b) * cp;
         if (a == nyq || b == nyq) {
             for (int kk = threadIdx.x; kk <= nyq; kk += blockDim.x) r[kk] = make_double2(0, 0);
         } else if (threadIdx.x == 0) {
@@ -66,14 +67,14 @@ struct FourierOp {
 
 __global__ __launch_bounds__(256) void k_fourier_operate(const double2 *__restrict__ from,
                                                          double2 *__restrict__ onto, int N,
-                                                         i64 cp, FourierOp P) {
+                                                         i64 ny, i64 cp, FourierOp P) {
 #pragma clang fp contract(off)
     const int nyq = N / 2;
     const i64 rows = (i64)N * N;
     for (i64 row = (i64)blockIdx.x; row < rows; row += gridDim.x) {
         const int a = (int)(row / N), b = (int)(row - (i64)a * N);
-        const double2 *src = from + row * cp;
-        double2 *dst = onto + row * cp;
+        const double2 *src = from + ((i64)a * ny + b) * cp;
+        double2 *dst = onto + ((i64)a * ny + b) * cp;
         const bool dead_row = (a == nyq) || (b == nyq);
         const int ka = a - (a >= nyq ? N : 0), kb = b - (b >= nyq ? N : 0);
         double dab_n = 0, dab_d = 0;
@@ -127,8 +128,9 @@ struct CopyModes {
     double A, B, Cc, dtheta, inv_lat;
 };
 __global__ __launch_bounds__(64) void k_copy_modes(const double2 *__restrict__ from, int N_from,
-                                                   i64 cp_from, double2 *__restrict__ onto,
-                                                   int N_onto, i64 cp_onto, CopyModes P) {
+                                                   i64 ny_from, i64 cp_from,
+                                                   double2 *__restrict__ onto, int N_onto,
+                                                   i64 ny_onto, i64 cp_onto, CopyModes P) {
 #pragma clang fp contract(off)
     const int N_small = N_from < N_onto ? N_from : N_onto;
     const int nyq = N_small / 2;
@@ -139,8 +141,8 @@ __global__ __launch_bounds__(64) void k_copy_modes(const double2 *__restrict__ f
         const int ka = as - (as >= nyq ? N_small : 0), kb = bs - (bs >= nyq ? N_small : 0);
         const int af = ka + (ka < 0 ? N_from : 0), bf = kb + (kb < 0 ? N_from : 0);
         const int ao = ka + (ka < 0 ? N_onto : 0), bo = kb + (kb < 0 ? N_onto : 0);
-        const double2 *src = from + ((i64)af * N_from + bf) * cp_from;
-        double2 *dst = onto + ((i64)ao * N_onto + bo) * cp_onto;
+        const double2 *src = from + ((i64)af * ny_from + bf) * cp_from;
+        double2 *dst = onto + ((i64)ao * ny_onto + bo) * cp_onto;
         double dab_n = 0, dab_d = 0;
         if (P.deconv_order) {
             dab_n = P.tab_n[af] * P.tab_n[bf];
@@ -170,8 +172,8 @@ __global__ __launch_bounds__(256) void k_fluid_kick(double *__restrict__ J,
                                                     const double *__restrict__ rho,
                                                     const double *__restrict__ P,
                                                     const double *__restrict__ mesh, int N,
-                                                    i64 pad, int dim, double c1, double c2,
-                                                    double mdt, double inv_c2) {
+                                                    i64 ny, i64 pad, int dim, double c1,
+                                                    double c2, double mdt, double inv_c2) {
 #pragma clang fp contract(off)
     const i64 total = (i64)N * N * N;
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void k_fluid_kick(double *__restrict__ J,
             if (dim == 0) ii = (i + s + N) % N;
             else if (dim == 1) jj = (j + s + N) % N;
             else kk = (k + s + N) % N;
-            return mesh[((i64)ii * N + jj) * pad + kk];
+            return mesh[((i64)ii * ny + jj) * pad + kk];
         };
         double g;
         if (ORDER == 0) g = phi(0);  // the mesh already holds the force (Fourier-space gradient)
@@ -254,8 +256,9 @@ __device__ __forceinline__ int wrap32(int a, int n) {
 
 template <int ORDER>
 __global__ __launch_bounds__(256) void k_deposit_general(const double *__restrict__ pos, i64 n,
-                                                         double *__restrict__ mesh, int N, i64 pad,
-                                                         int g, CicGeom geo, double contribution) {
+                                                         double *__restrict__ mesh, int N, i64 ny,
+                                                         i64 pad, int g, CicGeom geo,
+                                                         double contribution) {
 #pragma clang fp contract(off)
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256) void k_deposit_general(const double *__restric
         for (int i = 0; i < ORDER; i++) {
             double weight_i = wx[i];
             weight_i *= contribution;  // apply_factor = True
-            const i64 ri = (i64)wrap32(ii + i, N) * N;
+            const i64 ri = (i64)wrap32(ii + i, N) * ny;
 #pragma unroll
             for (int j = 0; j < ORDER; j++) {
                 double wij = weight_i * wy[j];
@@ -284,7 +287,7 @@ template <int ORDER>
 __global__ __launch_bounds__(256) void k_gather_scalar(const double *__restrict__ pos,
                                                        double *__restrict__ mom, i64 n, int dim,
                                                        const double *__restrict__ mesh, int N,
-                                                       i64 pad, int g, CicGeom geo,
+                                                       i64 ny, i64 pad, int g, CicGeom geo,
                                                        double factor) {
 #pragma clang fp contract(off)
     const i64 stride = (i64)gridDim.x * blockDim.x;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void k_gather_scalar(const double *__restrict_
         double value = 0;
 #pragma unroll
         for (int i = 0; i < ORDER; i++) {
-            const i64 ri = (i64)wrap32(ii + i, N) * N;
+            const i64 ri = (i64)wrap32(ii + i, N) * ny;
 #pragma unroll
             for (int j = 0; j < ORDER; j++) {
                 double wij = wx[i] * wy[j];
@@ -314,8 +317,8 @@ __global__ __launch_bounds__(256) void k_gather_scalar(const double *__restrict_
 // diff_domaingrid (mesh.py:4874-5030) of the real-space mesh of `src` into `dst`
 template <int ORDER>
 __global__ __launch_bounds__(256) void k_mesh_diff(double *__restrict__ dst,
-                                                   const double *__restrict__ src, int N, i64 pad,
-                                                   int dim, double c1, double c2) {
+                                                   const double *__restrict__ src, int N, i64 ny,
+                                                   i64 pad, int dim, double c1, double c2) {
 #pragma clang fp contract(off)
     const i64 total = (i64)N * N * N;
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -328,12 +331,12 @@ __global__ __launch_bounds__(256) void k_mesh_diff(double *__restrict__ dst,
             if (dim == 0) ii = wrap32(i + s, N);
             else if (dim == 1) jj = wrap32(j + s, N);
             else kk = wrap32(k + s, N);
-            return src[((i64)ii * N + jj) * pad + kk];
+            return src[((i64)ii * ny + jj) * pad + kk];
         };
         double gval;
         if (ORDER == 2) gval = c1 * (phi(1) - phi(-1));
         else gval = c1 * (phi(1) - phi(-1)) - c2 * (phi(2) - phi(-2));
-        dst[row * pad + k] = gval;
+        dst[((i64)i * ny + j) * pad + k] = gval;
     }
 }
 
@@ -347,14 +350,14 @@ static unsigned blocks_for(i64 n, int per) {
 int cgk_fluid_add(cg_ctx *c, const double *fluid, double factor, int op_add) {
     i64 total = c->N * c->N * c->N;
     hipLaunchKernelGGL(k_fluid_add, dim3(blocks_for(total, 256)), dim3(256), 0, c->stream,
-                       c->mesh0, fluid, (int)c->N, c->pad, factor, op_add);
+                       c->mesh0, fluid, (int)c->N, c->ny, c->pad, factor, op_add);
     CG_LAUNCH_CHECK();
     return 0;
 }
 
 int cgk_nullify_nyquist(cg_ctx *c) {
     hipLaunchKernelGGL(k_nullify_nyquist, dim3(blocks_for(c->N * c->N, 1)), dim3(64), 0,
-                       c->stream, (double2 *)c->mesh0, (int)c->N, c->pad / 2);
+                       c->stream, (double2 *)c->mesh0, (int)c->N, c->ny, c->pad / 2);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -381,7 +384,7 @@ int cgk_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlatti
     P.inv_lat = 1.0 / (double)nlattice;
     hipLaunchKernelGGL(k_fourier_operate, dim3(blocks_for(onto->N * onto->N, 1)), dim3(256), 0,
                        onto->stream, (const double2 *)from->mesh0, (double2 *)onto->mesh0,
-                       (int)onto->N, onto->pad / 2, P);
+                       (int)onto->N, onto->ny, onto->pad / 2, P);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -404,8 +407,8 @@ int cgk_copy_modes(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
     P.inv_lat = 1.0 / (double)nlattice;
     i64 ns = onto->N < from->N ? onto->N : from->N;
     hipLaunchKernelGGL(k_copy_modes, dim3(blocks_for(ns * ns, 1)), dim3(64), 0, onto->stream,
-                       (const double2 *)from->mesh0, (int)from->N, from->pad / 2,
-                       (double2 *)onto->mesh0, (int)onto->N, onto->pad / 2, P);
+                       (const double2 *)from->mesh0, (int)from->N, from->ny, from->pad / 2,
+                       (double2 *)onto->mesh0, (int)onto->N, onto->ny, onto->pad / 2, P);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -416,17 +419,17 @@ int cgk_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int
     double dx = c->p.boxsize / (double)c->N;  // interactions.py:2133
     if (diff_order == 0) {
         hipLaunchKernelGGL(k_fluid_kick<0>, dim3(blocks_for(total, 256)), dim3(256), 0,
-                           c->stream, J, rho, P, c->mesh0, (int)c->N, c->pad, dim, 0.0, 0.0,
+                           c->stream, J, rho, P, c->mesh0, (int)c->N, c->ny, c->pad, dim, 0.0, 0.0,
                            minus_dt, inv_c2);
     } else if (diff_order == 2) {
         double c1 = (1.0 / 2) / dx;
         hipLaunchKernelGGL(k_fluid_kick<2>, dim3(blocks_for(total, 256)), dim3(256), 0,
-                           c->stream, J, rho, P, c->mesh0, (int)c->N, c->pad, dim, c1, 0.0,
+                           c->stream, J, rho, P, c->mesh0, (int)c->N, c->ny, c->pad, dim, c1, 0.0,
                            minus_dt, inv_c2);
     } else {
         double c1 = (2.0 / 3) / dx, c2 = (1.0 / 12) / dx;
         hipLaunchKernelGGL(k_fluid_kick<4>, dim3(blocks_for(total, 256)), dim3(256), 0,
-                           c->stream, J, rho, P, c->mesh0, (int)c->N, c->pad, dim, c1, c2,
+                           c->stream, J, rho, P, c->mesh0, (int)c->N, c->ny, c->pad, dim, c1, c2,
                            minus_dt, inv_c2);
     }
     CG_LAUNCH_CHECK();
@@ -445,7 +448,7 @@ int cgk_deposit_general(cg_ctx *c, const double *pos, i64 n, double contribution
                         const CicGeom &geo) {
     if (n == 0) return 0;
     CG_ORDER_SWITCH(order, k_deposit_general, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream,
-                    pos, n, c->mesh0, (int)c->N, c->pad, c->p.nghosts, geo, contribution)
+                    pos, n, c->mesh0, (int)c->N, c->ny, c->pad, c->p.nghosts, geo, contribution)
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -454,7 +457,7 @@ int cgk_gather_scalar(cg_ctx *c, const double *pos, double *mom, i64 n, int dim,
                       const CicGeom &geo, double factor) {
     if (n == 0) return 0;
     CG_ORDER_SWITCH(order, k_gather_scalar, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream,
-                    pos, mom, n, dim, c->mesh0, (int)c->N, c->pad, c->p.nghosts, geo, factor)
+                    pos, mom, n, dim, c->mesh0, (int)c->N, c->ny, c->pad, c->p.nghosts, geo, factor)
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -464,11 +467,12 @@ int cgk_mesh_diff(cg_ctx *dst, cg_ctx *src, int dim, int diff_order) {
     double dx = src->p.boxsize / (double)src->N;
     if (diff_order == 2) {
         hipLaunchKernelGGL(k_mesh_diff<2>, dim3(blocks_for(total, 256)), dim3(256), 0, dst->stream,
-                           dst->mesh0, src->mesh0, (int)src->N, src->pad, dim, (1.0 / 2) / dx, 0.0);
+                           dst->mesh0, src->mesh0, (int)src->N, src->ny, src->pad, dim, (1.0 / 2) / dx,
+                           0.0);
     } else {
         hipLaunchKernelGGL(k_mesh_diff<4>, dim3(blocks_for(total, 256)), dim3(256), 0, dst->stream,
-                           dst->mesh0, src->mesh0, (int)src->N, src->pad, dim, (2.0 / 3) / dx,
-                           (1.0 / 12) / dx);
+                           dst->mesh0, src->mesh0, (int)src->N, src->ny, src->pad, dim,
+                           (2.0 / 3) / dx, (1.0 / 12) / dx);
     }
     CG_LAUNCH_CHECK();
     return 0;

@@ -54,7 +54,8 @@ struct CicGeom {
 // Single domain: the buffer is the whole periodic mesh (layer = x mod N).
 // x-slab domains (one per GPU): the buffer holds layers [x0-G, x0+nxl+G) of
 // the global mesh — nxl owned layers between G ghost layers — and y, z stay
-// periodic.  Cell (x, j, k) lives at mesh[(layer*N + j)*pad + k].
+// periodic.  Cell (x, j, k) lives at mesh[(layer*ny + j)*pad + k]: a layer is ny >= N rows
+// of pad doubles (ny = N + 1 when N is a multiple of 16, see cg_ctx::ny).
 struct XMap {
     i64 x0;    // first owned global layer
     i64 nxl;   // owned layers
@@ -91,6 +92,12 @@ struct cg_ctx {
     double *mesh = nullptr;      // double[layers][N][pad], layers = nxl + 2G
     double *mesh0 = nullptr;     // first OWNED layer (= mesh + G*N*pad)
     i64 mesh_doubles = 0;
+    // rows per x layer.  N rows are used; with N a power of two the layer stride N*pad*8 B
+    // is 2^17 x odd at 1024^3 and the 1024 row segments an x-pass tile touches alias onto
+    // few memory channels (measured with tools/stride_probe.cpp: 3.99 ms per in-place
+    // sweep at stride 8,519,680 B, 3.52 ms at 8,528,000 B): one unused row per layer
+    // breaks the pattern.
+    i64 ny = 0;
     double *fetch_tmp = nullptr; // lazily allocated, for CG_FETCH_MESH_FOURIER
     // k-space tables: numerator n(k) and denominator sin(n(k)) by array index
     double *ktab_n = nullptr, *ktab_s = nullptr, *ktab_q = nullptr;

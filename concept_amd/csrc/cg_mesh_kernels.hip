@@ -46,8 +46,8 @@ __device__ __forceinline__ i64 wrap(i64 a, i64 n) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_deposit_cic_direct(const double *__restrict__ pos, i64 n,
                                                             double *__restrict__ mesh, i64 N,
-                                                            i64 pad, int g, XMap xm, CicGeom geo,
-                                                            double contribution) {
+                                                            i64 ny, i64 pad, int g, XMap xm,
+                                                            CicGeom geo, double contribution) {
     i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         Cic1 cx = cic1(pos[3 * p + 0], geo.off[0], geo.scale);
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256) void k_deposit_cic_direct(const double *__rest
         // mesh.py:5142-5155: ((w_x*contribution)*w_y)*w_z
         double wi0 = cx.w0 * contribution, wi1 = cx.w1 * contribution;
         double w00 = wi0 * cy.w0, w01 = wi0 * cy.w1, w10 = wi1 * cy.w0, w11 = wi1 * cy.w1;
-        double *r00 = mesh + (i0 * N + j0) * pad, *r01 = mesh + (i0 * N + j1) * pad;
-        double *r10 = mesh + (i1 * N + j0) * pad, *r11 = mesh + (i1 * N + j1) * pad;
+        double *r00 = mesh + (i0 * ny + j0) * pad, *r01 = mesh + (i0 * ny + j1) * pad;
+        double *r10 = mesh + (i1 * ny + j0) * pad, *r11 = mesh + (i1 * ny + j1) * pad;
         unsafeAtomicAdd(r00 + k0, w00 * cz.w0);
         unsafeAtomicAdd(r00 + k1, w00 * cz.w1);
         unsafeAtomicAdd(r01 + k0, w01 * cz.w0);
@@ -77,7 +77,8 @@ int cgk_deposit_cic(cg_ctx *c, const double *pos, i64 n, double contribution) {
     i64 blocks = (n + block - 1) / block;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(k_deposit_cic_direct, dim3((unsigned)blocks), dim3(block), 0, c->stream, pos,
-                       n, c->mesh, c->N, c->pad, c->p.nghosts, c->xmap, c->geom_deposit, contribution);
+                       n, c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->xmap, c->geom_deposit,
+                       contribution);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -91,12 +92,12 @@ int cgk_deposit_cic(cg_ctx *c, const double *pos, i64 n, double contribution) {
 //   nullify_modes('origin')   interactions.py:2118
 // One lane per complex mode (16 B load + 16 B store, coalesced along kk).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_kspace(double2 *__restrict__ slab, i64 N, i64 pitch,
-                                                KspaceParams P) {
+__global__ __launch_bounds__(256) void k_kspace(double2 *__restrict__ slab, i64 N, i64 ny,
+                                                i64 pitch, KspaceParams P) {
     const i64 nk = N / 2 + 1;
     i64 row = blockIdx.x;  // i*N + j
     i64 i = row / N, j = row - i * N;
-    double2 *r = slab + row * pitch;
+    double2 *r = slab + (i * ny + j) * pitch;
     for (i64 kk = threadIdx.x; kk < nk; kk += blockDim.x) {
         double factor = kspace_factor(P, N, i, j, kk);
         double2 v = make_double2(0, 0);
@@ -113,7 +114,7 @@ int cgk_kspace(cg_ctx *c, int deconv_order, double C, int long_range, double E) 
     i64 rows = c->N * c->N;
     int block = c->N / 2 + 1 >= 256 ? 256 : (c->N / 2 + 1 > 64 ? 128 : 64);
     hipLaunchKernelGGL(k_kspace, dim3((unsigned)rows), dim3(block), 0, c->stream,
-                       (double2 *)c->mesh, c->N, c->pad / 2,
+                       (double2 *)c->mesh, c->N, c->ny, c->pad / 2,
                        KspaceParams{c->ktab_n, c->ktab_s, c->ktab_q, deconv_order, long_range, C, E});
     CG_LAUNCH_CHECK();
     return 0;
@@ -121,16 +122,16 @@ int cgk_kspace(cg_ctx *c, int deconv_order, double C, int long_range, double E) 
 
 // complex[i][j][kk] -> the reference's transposed double[j][i][N+2] (debug fetch)
 __global__ void k_transpose_fourier(const double2 *__restrict__ src, double2 *__restrict__ dst,
-                                    i64 N, i64 pitch) {
+                                    i64 N, i64 ny, i64 pitch) {
     i64 nk = N / 2 + 1;
     i64 row = blockIdx.x;
     i64 i = row / N, j = row - i * N;
     for (i64 kk = threadIdx.x; kk < nk; kk += blockDim.x)
-        dst[(j * N + i) * nk + kk] = src[(i * N + j) * pitch + kk];
+        dst[(j * N + i) * nk + kk] = src[(i * ny + j) * pitch + kk];
 }
 int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst) {
     hipLaunchKernelGGL(k_transpose_fourier, dim3((unsigned)(c->N * c->N)), dim3(64), 0, c->stream,
-                       (const double2 *)src, (double2 *)dst, c->N, c->pad / 2);
+                       (const double2 *)src, (double2 *)dst, c->N, c->ny, c->pad / 2);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -146,8 +147,9 @@ template <int ORDER>
 __global__ __launch_bounds__(256) void k_gather_kick_direct(const double *__restrict__ pos,
                                                             double *__restrict__ mom, i64 n,
                                                             const double *__restrict__ mesh, i64 N,
-                                                            i64 pad, int g, XMap xm, CicGeom geo,
-                                                            double c1, double c2, double factor) {
+                                                            i64 ny, i64 pad, int g, XMap xm,
+                                                            CicGeom geo, double c1, double c2,
+                                                            double factor) {
     constexpr int H = ORDER / 2;      // stencil half width
     constexpr int W = 2 + 2 * H;      // cells needed per dimension
     i64 stride = (i64)gridDim.x * blockDim.x;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void k_gather_kick_direct(const double *__rest
         i64 ix[W], iy[W], iz[W];
 #pragma unroll
         for (int s = 0; s < W; s++) {
-            ix[s] = cg_xlayer(xm, cx.index - g - H + s, N) * N * pad;
+            ix[s] = cg_xlayer(xm, cx.index - g - H + s, N) * ny * pad;
             iy[s] = wrap(cy.index - g - H + s, N) * pad;
             iz[s] = wrap(cz.index - g - H + s, N);
         }
@@ -211,13 +213,13 @@ int cgk_gather_kick(cg_ctx *c, const double *pos, double *mom, i64 n, int diff_o
     if (diff_order == 2) {
         double c1 = (1.0 / 2) / dx;  // mesh.py:4967
         hipLaunchKernelGGL(k_gather_kick_direct<2>, dim3((unsigned)blocks), dim3(block), 0,
-                           c->stream, pos, mom, n, c->mesh, c->N, c->pad, c->p.nghosts, c->xmap,
-                           c->geom_gather, c1, 0.0, factor);
+                           c->stream, pos, mom, n, c->mesh, c->N, c->ny, c->pad, c->p.nghosts,
+                           c->xmap, c->geom_gather, c1, 0.0, factor);
     } else {
         double c1 = (2.0 / 3) / dx, c2 = (1.0 / 12) / dx;  // mesh.py:4973-4977
         hipLaunchKernelGGL(k_gather_kick_direct<4>, dim3((unsigned)blocks), dim3(block), 0,
-                           c->stream, pos, mom, n, c->mesh, c->N, c->pad, c->p.nghosts, c->xmap,
-                           c->geom_gather, c1, c2, factor);
+                           c->stream, pos, mom, n, c->mesh, c->N, c->ny, c->pad, c->p.nghosts,
+                           c->xmap, c->geom_gather, c1, c2, factor);
     }
     CG_LAUNCH_CHECK();
     return 0;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256) void k_layers_add(double2 *__restrict__ dst,
     }
 }
 int cgk_layers_write(cg_ctx *c, i64 layer0, i64 nlayers, const double *src, int add) {
-    i64 per = c->N * c->pad;
+    i64 per = c->ny * c->pad;  // whole layers, the unused row included
     double *dst = c->mesh0 + layer0 * per;
     if (!add) {
         CG_HIP(hipMemcpyAsync(dst, src, 8 * per * nlayers, hipMemcpyDeviceToDevice, c->stream));

@@ -70,7 +70,7 @@ __device__ __forceinline__ unsigned tile_for_block(unsigned b, unsigned ntiles) 
 template <int T, bool ACCUMULATE>
 __global__ __launch_bounds__(512) void k_deposit_cic_pull(
     const double *__restrict__ pos, const unsigned *__restrict__ table,
-    double *__restrict__ mesh, i64 N, i64 pad, int g, int ntx, int nt, unsigned nblocks,
+    double *__restrict__ mesh, i64 N, i64 ny, i64 pad, int g, int ntx, int nt, unsigned nblocks,
     XMap xm, CicGeom geo, double contribution) {
     // tiles: ntx rows along x (this domain's), nt along y and z.  An x-slab domain has
     // one extra row ta == ntx: the ghost layer that receives the CIC clouds sticking out
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512) void k_deposit_cic_pull(
         int c = idx % T, b = (idx / T) % T, a = idx / (T * T);
         if (a >= a_end) break;
         i64 layer = xm.periodic ? (i64)(T0a + a) : ((i64)ta * T + a + xm.G);
-        double *dst = mesh + (layer * N + (T0b + b)) * pad + (T0c + c);
+        double *dst = mesh + (layer * ny + (T0b + b)) * pad + (T0c + c);
         if (ACCUMULATE) *dst += lds[idx];  // cells are exclusively owned: no atomics needed
         else *dst = lds[idx];
     }
@@ -159,11 +159,11 @@ static int launch_deposit(cg_ctx *c, const double *pos, const unsigned *table,
     unsigned nb = (unsigned)((i64)rows * c->tiles.nty * c->tiles.ntz);
     if (accumulate)
         hipLaunchKernelGGL((k_deposit_cic_pull<T, true>), dim3(nb), dim3(512), 0, c->stream, pos,
-                           table, c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.ntx, c->tiles.nty,
+                           table, c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.ntx, c->tiles.nty,
                            nb, c->xmap, c->geom_deposit, contribution);
     else
         hipLaunchKernelGGL((k_deposit_cic_pull<T, false>), dim3(nb), dim3(512), 0, c->stream, pos,
-                           table, c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.ntx, c->tiles.nty,
+                           table, c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.ntx, c->tiles.nty,
                            nb, c->xmap, c->geom_deposit, contribution);
     return 0;
 }
@@ -216,9 +216,9 @@ struct PrepArgs {
 template <int ORDER, int T, bool PREP>
 __global__ __launch_bounds__(512, 4) void k_gather_kick_tiled(
     const double *__restrict__ pos, double *__restrict__ mom,
-    const unsigned *__restrict__ tile_offset, const double *__restrict__ mesh, i64 N, i64 pad,
-    int g, int nt, unsigned ntiles, XMap xm, CicGeom geo, double c1, double c2, double factor,
-    PrepArgs prep) {
+    const unsigned *__restrict__ tile_offset, const double *__restrict__ mesh, i64 N, i64 ny,
+    i64 pad, int g, int nt, unsigned ntiles, XMap xm, CicGeom geo, double c1, double c2,
+    double factor, PrepArgs prep) {
     constexpr int H = ORDER / 2;
     constexpr int E = T + 1 + 2 * H;  // cells [T0-H, T0+T+H]
     extern __shared__ double lds[];
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512, 4) void k_gather_kick_tiled(
         for (int s = 0; s < NA; s++) {
             const int a = wave + 8 * s;  // wave-uniform
             if (a < E) {
-                const double *plane = mesh + cg_xlayer(xm, (i64)(T0a - H + a), N) * N * pad;
+                const double *plane = mesh + cg_xlayer(xm, (i64)(T0a - H + a), N) * ny * pad;
 #pragma unroll
                 for (int q = 0; q < NP; q++)
                     if (PL % 64 == 0 || lane + 64 * q < PL) v[s][q] = plane[off[q]];
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(512, 4) void k_gather_kick_tiled(
             i64 ix[W], iy[W], iz[W];
 #pragma unroll
             for (int s = 0; s < W; s++) {
-                ix[s] = cg_xlayer(xm, (i64)(ga - H + s), N) * N * pad;
+                ix[s] = cg_xlayer(xm, (i64)(ga - H + s), N) * ny * pad;
                 iy[s] = (i64)wrap(gb - H + s, Ni) * pad;
                 iz[s] = wrap(gc - H + s, Ni);
             }
@@ -380,11 +380,11 @@ static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsign
     unsigned nt = (unsigned)c->ntiles;
     if (prep)
         hipLaunchKernelGGL(kern_prep, dim3(nt), dim3(512), lds, c->stream, pos, mom, tile_offset,
-                           c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap,
+                           c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap,
                            c->geom_gather, c1, c2, factor, *prep);
     else
         hipLaunchKernelGGL(kern, dim3(nt), dim3(512), lds, c->stream, pos, mom, tile_offset,
-                           c->mesh, c->N, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap,
+                           c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap,
                            c->geom_gather, c1, c2, factor, PrepArgs{});
     return 0;
 }

@@ -113,7 +113,7 @@ class SlabDomain:
         m = self.mesh
         self.N, self.nxl, self.G = m.gridsize, m.nxl, m.ghost_layers
         self.boxsize = float(boxsize)
-        per = m.gridsize*m.pad
+        per = m.layer_doubles
         self._layer = per
         self.tbuf_a = torch.empty(m.transpose_doubles, dtype=torch.float64, device=self.device)
         self.tbuf_b = torch.empty(m.transpose_doubles, dtype=torch.float64, device=self.device)

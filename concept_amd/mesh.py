@@ -51,6 +51,7 @@ class PotentialMesh:
             int(v) for v in linfo)
         self.nprocs, self.rank = int(nprocs), int(rank)
         self.ntiles = (self.table_entries - 1)//8
+        self.layer_doubles = int(_L.cg_layer_doubles(self._ctx))  # unit of layers_read/write
 
     def close(self):
         if self._ctx:

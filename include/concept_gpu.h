@@ -256,8 +256,12 @@ int cg_apply_rung_jumps(cg_ctx *ctx, int8_t *rung, int8_t *rung_jumped, int64_t 
  *                all-to-all (equal blocks) -> cg_dist_fft_xsolve -> all-to-all back
  *                -> cg_dist_fft_backward
  *   exchange()   communication.py:135-517      : cg_owner_rank + caller-side moves
- * info = {x0, nxl, G, N, pad, doubles in one transpose buffer (nxl*N*pad)} */
+ * info = {x0, nxl, G, N, pad, doubles in one transpose buffer: P blocks of
+ *         complex[nxl][N/P + 1][pad/2], the last row of each layer unused} */
 int cg_local_info(const cg_ctx *ctx, int64_t info[6]);
+/* doubles in one x layer of the local mesh buffer = the unit of cg_layers_read / _write (a
+ * layer holds one unused row besides its N rows of `pad` doubles) */
+int64_t cg_layer_doubles(const cg_ctx *ctx);
 /* layer0 is relative to the first owned layer (-G .. nxl+G-1) */
 int cg_layers_read(cg_ctx *ctx, int64_t layer0, int64_t nlayers, double *dst /*DEV*/);
 int cg_layers_write(cg_ctx *ctx, int64_t layer0, int64_t nlayers, const double *src /*DEV*/,

@@ -544,7 +544,8 @@ def test_north_star_size_properties(torch_cuda):
     sample = torch.arange(0, n, 4099, device='cuda')
     assert torch.equal(po[sample], pos[io[sample]])
     del pos, ids
-    per = N*mesh.pad
+    per = mesh.layer_doubles  # a layer = N rows of `pad` doubles + one unused row
+    rows = per//mesh.pad
     a = torch.empty(N*per, dtype=torch.float64, device='cuda')
     b = torch.empty(N*per, dtype=torch.float64, device='cuda')
     mesh.deposit_tiled(po, table, 1.0, accumulate=False)
@@ -552,8 +553,8 @@ def test_north_star_size_properties(torch_cuda):
     mesh.zero()
     mesh.deposit(po, 1.0)
     mesh.layers_read(0, N, b)
-    av = a.view(N, N, mesh.pad)[:, :, :N]
-    bv = b.view(N, N, mesh.pad)[:, :, :N]
+    av = a.view(N, rows, mesh.pad)[:, :N, :N]
+    bv = b.view(N, rows, mesh.pad)[:, :N, :N]
     assert float((av - bv).abs().max()) <= 1e-12*float(bv.abs().max())
     assert abs(float(av.sum()) - n) <= 1e-9*n
     del a, b, av, bv
