@@ -32,6 +32,7 @@ WORKLOADS = {
     'ns_256M_1024': (2**28, 1024),       # BASELINE.json metric config
     'c2_256c_512': (256**3, 512),        # configs[1]
     'c1_128c_256': (128**3, 256),        # configs[0]
+    'c3_1024c_2048': (1024**3, 2048),    # configs[3] (meant for 8 GPUs; fits one: ~175 GB)
     'tiny': (32**3, 64),
 }
 

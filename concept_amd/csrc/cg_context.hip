@@ -101,7 +101,7 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
     CG_CHECK(p->gridsize >= 4 && p->gridsize % 2 == 0,
              "cg_create: gridsize %lld must be even and >= 4 (mesh.py:1898-1905)",
              (long long)p->gridsize);
-    CG_CHECK(p->interp_order == 2, "cg_create: interpolation order %d not built (CIC = 2 only)",
+    CG_CHECK(p->interp_order == 2, "cg_create: the tiled kernels of a context are CIC (interp_order 2), got %d; other orders go through cg_deposit / cg_gather_scalar",
              p->interp_order);
     CG_CHECK(p->nghosts >= 1 && p->nghosts <= 4, "cg_create: nghosts %d out of range", p->nghosts);
     CG_CHECK(p->boxsize > 0, "cg_create: boxsize must be positive");

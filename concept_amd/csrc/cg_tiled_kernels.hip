@@ -1,6 +1,6 @@
 // cg_tiled_kernels.hip — LDS-tiled CIC deposit (A1/A2) and fused finite
 // difference + CIC gather + kick (A9/A10) for particles kept in mesh-tile
-// order (cg_sort_particles).  One 256-lane workgroup per T^3-cell tile.
+// order (cg_sort_particles).  One 512-lane workgroup per T^3-cell tile.
 //
 // Why tiles: on MI355X device-scope FP64 atomics execute memory-side, one
 // fabric transaction per lane (measured at 2^28 particles / 1024^3: 2^31

@@ -1,10 +1,12 @@
 """concept_amd.shortrange — host side of the P3M short-range tile sweep.
 
 Counterpart of component_component(..., pairing_level='tile')
-(interactions.py:122-329) with gravity_pairwise_shortrange (gravity.py:263-354)
-for particle components whose particles all sit on rung 0 (single-rung time
-stepping; the adaptive rung machinery is SURVEY.md §8f-2, not built).
-The pair loop itself runs in libconcept_gpu.so (cg_shortrange.hip)."""
+(interactions.py:122-329) with gravity_pairwise_shortrange (gravity.py:263-354),
+including the adaptive rungs (per-rung factors, active rungs, jumped indices:
+cg_shortrange_sweep_rungs), and of pairing_level='domain' with gravity_pairwise /
+gravity_pairwise_nonperiodic (direct summation with and without the Ewald
+correction, component_component_pp below).  The pair loops run in
+libconcept_gpu.so (cg_shortrange.hip, cg_pp.hip)."""
 import math
 
 import numpy as np
