@@ -371,9 +371,16 @@ def main():
         # SURVEY.md §8(d) accounting: forward 48*N_g (3 passes), k-space 16*N_g, inverse
         # 48*N_g.  The fused x pass stands for the forward x pass + the k-space kernel +
         # the inverse x pass (16 + 16 + 16); the five entries sum to the 112*N_g of the row.
-        for nm, v, b in zip(('fft_z_forward', 'fft_y_forward', 'fft_x_fused_kspace',
-                             'fft_y_backward', 'fft_z_backward'), pass_ms,
-                            (16, 16, 48, 16, 16)):
+        names, bytes_ = (('fft_z_forward', 'fft_y_forward', 'fft_x_fused_kspace',
+                          'fft_y_backward', 'fft_z_backward'), (16, 16, 48, 16, 16))
+        if pass_ms[1] < 0.05*pass_ms[0]:
+            # the z and y passes run interleaved over cache-sized chunks of layers (cg_fft.hip):
+            # they are timed together; the second pass of a chunk is served by the infinity
+            # cache, which is how the pair exceeds the HBM rate an isolated pass can reach
+            names, bytes_ = (('fft_zy_forward_chunked', 'fft_x_fused_kspace',
+                              'fft_yz_backward_chunked'), (32, 48, 32))
+            pass_ms = [pass_ms[0] + pass_ms[1], pass_ms[2], pass_ms[3] + pass_ms[4]]
+        for nm, v, b in zip(names, pass_ms, bytes_):
             kernels[nm] = (b*n_g, v)
     dom = max(kernels, key=lambda k: kernels[k][1])
     ach = kernels[dom][0]/(kernels[dom][1]*1e-3)/1e9
@@ -385,6 +392,7 @@ def main():
                'deposit': 'k_deposit_cic_pull<16,false>',
                'fft_y_forward': 'k_fft_strided_p<10,512,0,8>',
                'fft_y_backward': 'k_fft_strided_p<10,512,1,8>',
+               'fft_zy_forward_chunked': None, 'fft_yz_backward_chunked': None,
                'fft_z_forward': 'k_fft_z_forward<10,128>',
                'fft_z_backward': 'k_fft_z_backward<10,128>'}.get(dom)
         if name == 'ns_256M_1024' and key:
