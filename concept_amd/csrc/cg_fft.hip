@@ -822,8 +822,13 @@ static int run_strided(cg_ctx *c, const double2 *src, double2 *dst, PencilMap sm
 
 static PencilMap plain_map(i64 ostride, i64 es) { return PencilMap{ostride, es, 0, 31}; }
 
-// Layers per chunk of the interleaved z / y passes: what fits the infinity cache with some
-// room (240 MB of the 256 MB); CONCEPT_GPU_FFT_CHUNK overrides (0 = whole mesh, no chunks).
+// Layers per chunk of the interleaved z / y passes.  Measured at 1024^3 (8.5 MB per layer, ms
+// for z + y forward and inverse together): 16 layers 13.4, 24: 12.2, 27: 11.6, 28: 11.7,
+// 31: 11.3, 32: 11.9, 36: 13.2, 40: 13.6, no chunks: 14.4 — the chunk must fit the 256 MB
+// infinity cache (the cliff sits just above 32 layers = 273 MB), and among the sizes that do,
+// those whose tile count nl*ceil((N/2+1)/8) fills whole rounds of the persistent y pass (one
+// workgroup per CU) win: 31 layers = 2015 tiles = 7.9 rounds of 256 beats 32 = 8.1 rounds.
+// CONCEPT_GPU_FFT_CHUNK overrides (0 = whole mesh, no chunks).
 static i64 zy_chunk_layers(cg_ctx *c) {
     static int env_chunk = -1;
     if (env_chunk < 0) {
@@ -833,9 +838,28 @@ static i64 zy_chunk_layers(cg_ctx *c) {
     }
     if (env_chunk == 0) return c->N + 1;
     if (env_chunk > 0) return env_chunk;
-    i64 plane_bytes = c->ny * c->pad * 8;
-    i64 n = 240000000ll / plane_bytes;
-    return n < 1 ? 1 : n;
+    static int ncu = 0;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        ncu = hipGetDeviceProperties(&prop, c->p.device) == hipSuccess ? prop.multiProcessorCount
+                                                                        : 256;
+    }
+    const i64 plane_bytes = c->ny * c->pad * 8;
+    i64 cap = 266000000ll / plane_bytes;
+    if (cap < 1) cap = 1;
+    if (cap >= c->N) return c->N + 1;  // the whole mesh fits: no chunks
+    const i64 nkb = (c->N / 2 + 1 + 7) / 8;
+    i64 best = cap;
+    double best_eff = 0;
+    for (i64 nl = cap; nl >= cap - cap / 4 && nl >= 1; nl--) {
+        i64 tiles = nl * nkb, rounds = (tiles + ncu - 1) / ncu;
+        double eff = (double)tiles / (double)(rounds * ncu);
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best = nl;
+        }
+    }
+    return best;
 }
 
 template <int LOGN>
