@@ -862,6 +862,19 @@ static i64 zy_chunk_layers(cg_ctx *c) {
     return best;
 }
 
+// Split `total` layers into chunks of about `chunk` layers whose sizes differ by at most one
+// (no tiny last chunk): chunk i covers [chunk_begin(i), chunk_begin(i + 1)).
+struct ChunkPlan {
+    i64 n, base, extra;
+    ChunkPlan(i64 total, i64 chunk) {
+        n = chunk >= total ? 1 : (total + chunk / 2) / chunk;
+        if (n < 1) n = 1;
+        base = total / n;
+        extra = total % n;
+    }
+    i64 begin(i64 i) const { return i * base + (i < extra ? i : extra); }
+};
+
 template <int LOGN>
 static int fft3d(cg_ctx *c, int what, const KspaceParams &P) {
     // single domain.  what: 0 forward, 1 backward, 2 forward + kernel + backward (fused x)
@@ -873,8 +886,9 @@ static int fft3d(cg_ctx *c, int what, const KspaceParams &P) {
     if (what == 0 || what == 1) {
         const i64 chunk0 = zy_chunk_layers(c), ls0 = cp * c->ny;
         if (what == 1 && run_strided<LOGN, 1>(c, m, m, xmap, xmap, N, 0, P)) return 1;
-        for (i64 l0 = 0; l0 < N; l0 += chunk0) {  // one chunk = the whole mesh when it fits
-            i64 nl = l0 + chunk0 <= N ? chunk0 : N - l0;
+        const ChunkPlan plan0(N, chunk0);  // one chunk = the whole mesh when it fits
+        for (i64 ci = 0; ci < plan0.n; ci++) {
+            const i64 l0 = plan0.begin(ci), nl = plan0.begin(ci + 1) - l0;
             if (what == 0) {
                 if (run_z<LOGN>(c, false, l0, nl)) return 1;
                 if (run_strided<LOGN, 0>(c, m + l0 * ls0, m + l0 * ls0, ymap, ymap, nl, 0, P))
@@ -902,9 +916,10 @@ static int fft3d(cg_ctx *c, int what, const KspaceParams &P) {
         const i64 ls = cp * c->ny;  // complex elements per layer
         KspaceParams Pr = P;
         Pr.long_range |= 2;  // y forward walks a chunk from its end, where z just stopped
+        const ChunkPlan plan(N, chunk);
         mark(0);
-        for (i64 l0 = 0; l0 < N; l0 += chunk) {
-            i64 nl = l0 + chunk <= N ? chunk : N - l0;
+        for (i64 ci = 0; ci < plan.n; ci++) {
+            const i64 l0 = plan.begin(ci), nl = plan.begin(ci + 1) - l0;
             if (run_z<LOGN>(c, false, l0, nl)) return 1;
             if (run_strided<LOGN, 0>(c, m + l0 * ls, m + l0 * ls, ymap, ymap, nl, 0, Pr)) return 1;
         }
@@ -912,8 +927,8 @@ static int fft3d(cg_ctx *c, int what, const KspaceParams &P) {
         mark(2);
         if (run_strided<LOGN, 2>(c, m, m, xmap, xmap, N, 0, P)) return 1;
         mark(3);
-        for (i64 l0 = 0; l0 < N; l0 += chunk) {
-            i64 nl = l0 + chunk <= N ? chunk : N - l0;
+        for (i64 ci = 0; ci < plan.n; ci++) {
+            const i64 l0 = plan.begin(ci), nl = plan.begin(ci + 1) - l0;
             if (run_strided<LOGN, 1>(c, m + l0 * ls, m + l0 * ls, ymap, ymap, nl, 0, P)) return 1;
             if (run_z<LOGN>(c, true, l0, nl)) return 1;
         }
@@ -962,8 +977,9 @@ static int fft_dist(cg_ctx *c, int what, double2 *buf, const KspaceParams &P) {
     PencilMap bmap{JBp * cp, cp, nxl * JBp * cp, sh};
     const i64 chunk = zy_chunk_layers(c), ls = cp * c->ny, lb = JBp * cp;
     if (what == 0) {  // forward z, forward y -> send buffer, chunk by chunk (see fft3d)
-        for (i64 l0 = 0; l0 < nxl; l0 += chunk) {
-            i64 nl = l0 + chunk <= nxl ? chunk : nxl - l0;
+        const ChunkPlan plan(nxl, chunk);
+        for (i64 ci = 0; ci < plan.n; ci++) {
+            const i64 l0 = plan.begin(ci), nl = plan.begin(ci + 1) - l0;
             if (run_z<LOGN>(c, false, l0, nl)) return 1;
             if (run_strided<LOGN, 0>(c, m + l0 * ls, buf + l0 * lb, ymap, bmap, nl, 0, P)) return 1;
         }
@@ -974,8 +990,9 @@ static int fft_dist(cg_ctx *c, int what, double2 *buf, const KspaceParams &P) {
         return run_strided<LOGN, 2>(c, buf, buf, xmap, xmap, JB, (i64)c->p.rank * JB, P);
     }
     // backward y from the returned buffer, backward z
-    for (i64 l0 = 0; l0 < nxl; l0 += chunk) {
-        i64 nl = l0 + chunk <= nxl ? chunk : nxl - l0;
+    const ChunkPlan plan(nxl, chunk);
+    for (i64 ci = 0; ci < plan.n; ci++) {
+        const i64 l0 = plan.begin(ci), nl = plan.begin(ci + 1) - l0;
         if (run_strided<LOGN, 1>(c, buf + l0 * lb, m + l0 * ls, bmap, ymap, nl, 0, P)) return 1;
         if (run_z<LOGN>(c, true, l0, nl)) return 1;
     }
