@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libconcept_gpu.so')
+# CONCEPT_GPU_LIB: load another build of the same library (kernel experiments in tools/)
+LIB_PATH = os.environ.get('CONCEPT_GPU_LIB') or os.path.join(HERE, 'libconcept_gpu.so')
 
 
 class ConceptGPUError(RuntimeError):
