@@ -617,12 +617,12 @@ __global__ __launch_bounds__(NT) void k_fft_strided_p(const double2 *__restrict_
     constexpr int MSTEP = NT / W;  // = N/16
     extern __shared__ double2 lds_dyn[];
     double2 *lds = lds_dyn;
-    double2 *twl = lds_dyn + TOT;                  // N twiddles
-    double *tabq = (double *)(lds_dyn + TOT + N);  // MODE 2: N doubles
+    double2 *twl = lds_dyn + TOT;                      // N/2 twiddles (no pass indexes beyond)
+    double *tabq = (double *)(lds_dyn + TOT + N / 2);  // MODE 2: N doubles
     const int tid = threadIdx.x;
     const int nk = N / 2 + 1;
     for (int i = tid; i < N; i += NT) {
-        twl[i] = tw[i];
+        if (i < N / 2) twl[i] = tw[i];
         if (MODE == 2) tabq[i] = P.tab_q[i];
     }
     const int wl = tid % W, ml = tid / W;
@@ -745,10 +745,11 @@ static int run_strided_r(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
     const i64 ntiles = nouter * nkb;
     // persistent form: tables in LDS on top of the tile; only where that fits the 160 KB
     // and pays (many tiles per CU)
-    constexpr size_t lds_p = sizeof(double2) * N * W + sizeof(double2) * N +
+    constexpr size_t lds_p = sizeof(double2) * N * W + sizeof(double2) * (N / 2) +
                              (MODE == 2 ? sizeof(double) * N : 0);
     // per-lane offsets are 32-bit byte offsets: (NT/W) pencil points must span < 4 GB
-    constexpr bool can_persist = R16 && LOGN <= 10 && N * W == 16 * NT && NT % W == 0 &&
+    // (2048 points x 4 pencils + tables = exactly 160 KB in the fused pass)
+    constexpr bool can_persist = R16 && LOGN <= 11 && N * W == 16 * NT && NT % W == 0 &&
                                  lds_p <= 160 * 1024;
     if constexpr (can_persist) {
         if (persist && ntiles >= 4 * (i64)ncu && smap.sh == 31 && dmap.sh == 31) {
