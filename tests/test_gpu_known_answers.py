@@ -119,3 +119,50 @@ def test_k4_sine_wave_fluid_stays_uniform_in_yz(gridsize, diff_order):
     profile = Jx[:, 0, 0]
     crest = int(np.argmax(rho[:, 0, 0]))
     assert profile[(crest - gridsize//4) % gridsize] > 0 > profile[(crest + gridsize//4) % gridsize]
+
+
+@pytest.mark.parametrize('ncomponents', [1, 2, 5])
+def test_k1_lattice_stays_put_across_components(ncomponents):
+    """test/multicomponent, 'tile' subtest (gen_ic.py:21-33, param:25-42): 12^3 particles on
+    a perfect cubic lattice, dealt round-robin to 1, 2 or 5 components, P3M with the mesh
+    of that test (36): long- and short-range kicks cancel by symmetry for every particle —
+    which they only do if every pair across tiles, components and the periodic boundary is
+    counted exactly once."""
+    from concept_amd import commons, interactions
+    from concept_amd.species import Component
+    L, n_lin, dt = 36.0, 12, 0.1
+    commons.load_params({
+        'boxsize': L,
+        'potential_options': {'gridsize': {'gravity': {'p3m': 36}}},
+        'select_forces': {'matter': {'gravity': 'p3m'}},
+        'select_softening_length': {'matter': f'0.03*boxsize/{n_lin}'}})
+    ax = (0.5 + np.arange(n_lin))*L/n_lin
+    pos = np.stack(np.meshgrid(ax, ax, ax, indexing='ij'), -1).reshape(-1, 3)
+    G = float(commons.params.G_Newton)
+    mass = 10*np.pi**2/((2 + 8*np.sqrt(2))*G)*(L/n_lin)**3      # gen_ic.py:36-43 with T = 1
+    comps = []
+    for n in range(ncomponents):
+        sub = pos[n::ncomponents]
+        c = Component(f'component{n}', 'matter', N=sub.shape[0], mass=mass)
+        c.populate(sub, 'pos')
+        c.populate(np.zeros_like(sub), 'mom')
+        c.nullify_Δ('mom')
+        comps.append(c)
+    n_rungs = int(commons.params.N_rungs)
+    sdt = {'1': dt}
+    sdt_rungs = {}
+    for r in comps:
+        sdt['a**(-3*w_eff)', r.name] = dt
+        sdt['a**(-3*w_eff-1)', r.name] = dt
+        for s in comps:
+            sdt_rungs['a**(-3*w_eff₀-3*w_eff₁-1)', r.name, s.name] = np.full(3*n_rungs - 1, dt)
+    found = interactions.find_interactions(comps, 'any')
+    assert len(found) == 1 and found[0][:2] == ('gravity', 'p3m')
+    _, _, receivers, suppliers = found[0]
+    assert len(receivers) == len(suppliers) == ncomponents
+    interactions.gravity('p3m', receivers, suppliers, sdt, 'long-range', False)
+    interactions.gravity('p3m', receivers, suppliers, sdt_rungs, 'short-range', False)
+    pair = G*mass**2*dt/(L/n_lin)**2           # the kick one nearest neighbour alone would give
+    for c in comps:
+        assert np.abs(c.host('mom')).max() <= 1e-10*pair       # long range
+        assert np.abs(c.host('Δmom')).max() <= 1e-10*pair      # short range
