@@ -20,8 +20,25 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef int64_t i64;
+
+/* The `omp parallel for` pragmas below are active only in the all-cores timing build
+ * (liboracle_omp.so, -fopenmp): the parity build ignores them and runs the reference's serial
+ * loops in the reference's order.  With threads the deposit adds with `omp atomic`, i.e. in
+ * scheduling order — a CPU baseline for bench.py, not a parity instrument. */
+int orc_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 /* set_weights_CIC, mesh.py:5319-5324 */
 static inline i64 set_weights_cic(double x, double *w) {
@@ -42,8 +59,9 @@ static inline i64 set_weights_cic(double x, double *w) {
  */
 void orc_cic_deposit(const double *pos, i64 N, double *grid, i64 size_j, i64 size_k,
                      const double *offset, double scale, double contribution, i64 *idx_out) {
-    double wx[2], wy[2], wz[2];
+#pragma omp parallel for schedule(static)
     for (i64 p = 0; p < N; p++) {
+        double wx[2], wy[2], wz[2];
         double x = (pos[3 * p + 0] - offset[0]) * scale;
         double y = (pos[3 * p + 1] - offset[1]) * scale;
         double z = (pos[3 * p + 2] - offset[2]) * scale;
@@ -68,6 +86,7 @@ void orc_cic_deposit(const double *pos, i64 N, double *grid, i64 size_j, i64 siz
                 double wij = weight_i * wy[j];
                 for (int k = 0; k < 2; k++) {
                     index += 1;
+#pragma omp atomic
                     grid[index] += wij * wz[k];
                 }
             }
@@ -84,8 +103,9 @@ void orc_cic_deposit(const double *pos, i64 N, double *grid, i64 size_j, i64 siz
 void orc_cic_gather_kick(const double *grid, i64 size_j, i64 size_k, const double *pos,
                          double *mom, i64 N, int dim, const double *offset, double scale,
                          double factor, i64 *idx_out) {
-    double wx[2], wy[2], wz[2];
+#pragma omp parallel for schedule(static)
     for (i64 p = 0; p < N; p++) {
+        double wx[2], wy[2], wz[2];
         double x = (pos[3 * p + 0] - offset[0]) * scale;
         double y = (pos[3 * p + 1] - offset[1]) * scale;
         double z = (pos[3 * p + 2] - offset[2]) * scale;
@@ -154,6 +174,7 @@ void orc_communicate_ghosts(double *grid, i64 ni, i64 nj, i64 nk, i64 g, int op_
  */
 void orc_slab_decompose(const double *grid, i64 N, i64 g, double *slab) {
     i64 n = N + 2 * g, pad = N + 2;
+#pragma omp parallel for schedule(static)
     for (i64 i = 0; i < N; i++) for (i64 j = 0; j < N; j++) {
         const double *src = grid + ((i + g) * n + (j + g)) * n + g;
         double *dst = slab + (i * N + j) * pad;
@@ -164,6 +185,7 @@ void orc_slab_decompose(const double *grid, i64 N, i64 g, double *slab) {
 /* A8  domain_decompose on one rank (mesh.py:2138-2244), interior only */
 void orc_domain_decompose(const double *slab, i64 N, i64 g, double *grid) {
     i64 n = N + 2 * g, pad = N + 2;
+#pragma omp parallel for schedule(static)
     for (i64 i = 0; i < N; i++) for (i64 j = 0; j < N; j++)
         memcpy(grid + ((i + g) * n + (j + g)) * n + g, slab + (i * N + j) * pad,
                sizeof(double) * N);
@@ -175,6 +197,7 @@ void orc_domain_decompose(const double *slab, i64 N, i64 g, double *grid) {
  */
 void orc_nullify_nyquist(double *slab, i64 N) {
     i64 nyq = N / 2, pad = N + 2;
+#pragma omp parallel for schedule(static)
     for (i64 j = 0; j < N; j++) for (i64 i = 0; i < N; i++) {
         double *row = slab + (j * N + i) * pad;
         if (i == nyq || j == nyq) memset(row, 0, sizeof(double) * pad);
@@ -197,6 +220,7 @@ void orc_kspace_poisson(double *slab, i64 N, int deconv_order, double C, int lon
     const double pi = 3.141592653589793; /* float(np.pi), commons.py:1816 */
     double pi_over_n = pi / (double)N;
     i64 nyq = N / 2, pad = N + 2;
+#pragma omp parallel for schedule(static)
     for (i64 j = 0; j < N; j++) {
         if (j == nyq) continue;
         i64 kj = j - (j >= nyq ? N : 0);
@@ -239,6 +263,7 @@ void orc_diff_domaingrid(const double *grid, double *out, i64 ni, i64 nj, i64 nk
                          int order, double dx) {
     i64 step = dim == 0 ? nj * nk : (dim == 1 ? nk : 1);
     double c2 = (1.0 / 2) / dx, c4a = (2.0 / 3) / dx, c4b = (1.0 / 12) / dx;
+#pragma omp parallel for schedule(static)
     for (i64 i = g; i < ni - g; i++) for (i64 j = g; j < nj - g; j++)
         for (i64 k = g; k < nk - g; k++) {
             i64 ix = (i * nj + j) * nk + k;
@@ -261,6 +286,7 @@ static inline double np_mod(double a, double b) {
     return m;
 }
 void orc_drift(double *pos, const double *mom, i64 n3, double dt_over_mass, double boxsize) {
+#pragma omp parallel for schedule(static)
     for (i64 r = 0; r < n3; r++) {
         double x = np_mod(pos[r] + mom[r] * dt_over_mass, boxsize);
         if (x == boxsize) x = 0;
