@@ -703,7 +703,16 @@ extern "C" int cg_layers_write(cg_ctx *c, int64_t layer0, int64_t nlayers, const
 extern "C" int cg_dist_fft_forward(cg_ctx *c, double *send_buf) {
     CG_CHECK(c && send_buf, "cg_dist_fft_forward: null argument");
     CG_CHECK(c->custom_fft, "cg_dist_fft_forward: needs the hand-written FFT backend");
-    return cgk_fft_dist_forward(c, send_buf);
+    return cgk_fft_dist_forward(c, send_buf, 0, -1);
+}
+extern "C" int cg_dist_fft_forward_layers(cg_ctx *c, double *send_buf, int64_t layer0,
+                                          int64_t nlayers) {
+    CG_CHECK(c && send_buf, "cg_dist_fft_forward_layers: null argument");
+    CG_CHECK(c->custom_fft, "cg_dist_fft_forward_layers: needs the hand-written FFT backend");
+    CG_CHECK(layer0 >= 0 && nlayers >= 1 && layer0 + nlayers <= c->xmap.nxl,
+             "cg_dist_fft_forward_layers: layers [%lld, %lld) outside the %lld owned ones",
+             (long long)layer0, (long long)(layer0 + nlayers), (long long)c->xmap.nxl);
+    return cgk_fft_dist_forward(c, send_buf, layer0, nlayers);
 }
 extern "C" int cg_dist_fft_xsolve(cg_ctx *c, double *buf, int deconv_order, double C,
                                   int long_range, double E) {
@@ -716,7 +725,16 @@ extern "C" int cg_dist_fft_xsolve(cg_ctx *c, double *buf, int deconv_order, doub
 extern "C" int cg_dist_fft_backward(cg_ctx *c, const double *recv_buf) {
     CG_CHECK(c && recv_buf, "cg_dist_fft_backward: null argument");
     CG_CHECK(c->custom_fft, "cg_dist_fft_backward: needs the hand-written FFT backend");
-    return cgk_fft_dist_backward(c, recv_buf);
+    return cgk_fft_dist_backward(c, recv_buf, 0, -1);
+}
+extern "C" int cg_dist_fft_backward_layers(cg_ctx *c, const double *recv_buf, int64_t layer0,
+                                           int64_t nlayers) {
+    CG_CHECK(c && recv_buf, "cg_dist_fft_backward_layers: null argument");
+    CG_CHECK(c->custom_fft, "cg_dist_fft_backward_layers: needs the hand-written FFT backend");
+    CG_CHECK(layer0 >= 0 && nlayers >= 1 && layer0 + nlayers <= c->xmap.nxl,
+             "cg_dist_fft_backward_layers: layers [%lld, %lld) outside the %lld owned ones",
+             (long long)layer0, (long long)(layer0 + nlayers), (long long)c->xmap.nxl);
+    return cgk_fft_dist_backward(c, recv_buf, layer0, nlayers);
 }
 extern "C" int cg_owner_rank(cg_ctx *c, const double *pos, int64_t n, int32_t *owner_out) {
     CG_CHECK(c && (n == 0 || (pos && owner_out)), "cg_owner_rank: null argument");

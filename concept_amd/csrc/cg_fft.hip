@@ -966,8 +966,10 @@ static int fft3d(cg_ctx *c, int what, const KspaceParams &P) {
 // and the x pass is again a plain strided pencil (stride JB*cp).  The way back
 // mirrors it: the inverse y pass reads the blocked layout.
 template <int LOGN>
-static int fft_dist(cg_ctx *c, int what, double2 *buf, const KspaceParams &P) {
+static int fft_dist(cg_ctx *c, int what, double2 *buf, const KspaceParams &P, i64 layer0,
+                    i64 nlayers) {
     const i64 cp = c->pad / 2, N = c->N, nxl = c->xmap.nxl, JB = N / c->p.nprocs;
+    if (nlayers < 0) nlayers = nxl - layer0;  // [layer0, layer0 + nlayers) of the owned layers
     // rows per x layer in the transpose buffers: JB used + 1 unused, for the same reason as
     // cg_ctx::ny (the x pencils' stride JB*cp*16 B would be a large power of two times 65)
     const i64 JBp = JB + 1;
@@ -978,9 +980,9 @@ static int fft_dist(cg_ctx *c, int what, double2 *buf, const KspaceParams &P) {
     PencilMap bmap{JBp * cp, cp, nxl * JBp * cp, sh};
     const i64 chunk = zy_chunk_layers(c), ls = cp * c->ny, lb = JBp * cp;
     if (what == 0) {  // forward z, forward y -> send buffer, chunk by chunk (see fft3d)
-        const ChunkPlan plan(nxl, chunk);
+        const ChunkPlan plan(nlayers, chunk);
         for (i64 ci = 0; ci < plan.n; ci++) {
-            const i64 l0 = plan.begin(ci), nl = plan.begin(ci + 1) - l0;
+            const i64 l0 = layer0 + plan.begin(ci), nl = plan.begin(ci + 1) - plan.begin(ci);
             if (run_z<LOGN>(c, false, l0, nl)) return 1;
             if (run_strided<LOGN, 0>(c, m + l0 * ls, buf + l0 * lb, ymap, bmap, nl, 0, P)) return 1;
         }
@@ -991,9 +993,9 @@ static int fft_dist(cg_ctx *c, int what, double2 *buf, const KspaceParams &P) {
         return run_strided<LOGN, 2>(c, buf, buf, xmap, xmap, JB, (i64)c->p.rank * JB, P);
     }
     // backward y from the returned buffer, backward z
-    const ChunkPlan plan(nxl, chunk);
+    const ChunkPlan plan(nlayers, chunk);
     for (i64 ci = 0; ci < plan.n; ci++) {
-        const i64 l0 = plan.begin(ci), nl = plan.begin(ci + 1) - l0;
+        const i64 l0 = layer0 + plan.begin(ci), nl = plan.begin(ci + 1) - plan.begin(ci);
         if (run_strided<LOGN, 1>(c, buf + l0 * lb, m + l0 * ls, bmap, ymap, nl, 0, P)) return 1;
         if (run_z<LOGN>(c, true, l0, nl)) return 1;
     }
@@ -1020,16 +1022,16 @@ int cgk_fft(cg_ctx *c, int what, int deconv_order, double C, int long_range, dou
     KspaceParams P{c->ktab_n, c->ktab_s, c->ktab_q, deconv_order, long_range, C, E};
     CG_FFT_DISPATCH(fft3d, c, what, P)
 }
-int cgk_fft_dist_forward(cg_ctx *c, double *send_buf) {
+int cgk_fft_dist_forward(cg_ctx *c, double *send_buf, i64 layer0, i64 nlayers) {
     KspaceParams P{c->ktab_n, c->ktab_s, c->ktab_q, 0, 0, 0.0, 0.0};
-    CG_FFT_DISPATCH(fft_dist, c, 0, (double2 *)send_buf, P)
+    CG_FFT_DISPATCH(fft_dist, c, 0, (double2 *)send_buf, P, layer0, nlayers)
 }
 int cgk_fft_dist_xsolve(cg_ctx *c, double *buf, int deconv_order, double C, int long_range,
                         double E) {
     KspaceParams P{c->ktab_n, c->ktab_s, c->ktab_q, deconv_order, long_range, C, E};
-    CG_FFT_DISPATCH(fft_dist, c, 2, (double2 *)buf, P)
+    CG_FFT_DISPATCH(fft_dist, c, 2, (double2 *)buf, P, 0, -1)
 }
-int cgk_fft_dist_backward(cg_ctx *c, const double *recv_buf) {
+int cgk_fft_dist_backward(cg_ctx *c, const double *recv_buf, i64 layer0, i64 nlayers) {
     KspaceParams P{c->ktab_n, c->ktab_s, c->ktab_q, 0, 0, 0.0, 0.0};
-    CG_FFT_DISPATCH(fft_dist, c, 1, (double2 *)recv_buf, P)
+    CG_FFT_DISPATCH(fft_dist, c, 1, (double2 *)recv_buf, P, layer0, nlayers)
 }

@@ -161,10 +161,10 @@ int cgk_flag_rung_jumps(cg_ctx *c, const double *dmom, const signed char *rung,
 int cgk_apply_rung_jumps(cg_ctx *c, signed char *rung, signed char *rung_jumped, i64 n,
                          int N_rungs);
 bool cgk_fft_supported(i64 N);
-int cgk_fft_dist_forward(cg_ctx *c, double *send_buf);
+int cgk_fft_dist_forward(cg_ctx *c, double *send_buf, i64 layer0, i64 nlayers);
 int cgk_fft_dist_xsolve(cg_ctx *c, double *buf, int deconv_order, double C, int long_range,
                         double E);
-int cgk_fft_dist_backward(cg_ctx *c, const double *recv_buf);
+int cgk_fft_dist_backward(cg_ctx *c, const double *recv_buf, i64 layer0, i64 nlayers);
 int cgk_layers_write(cg_ctx *c, i64 layer0, i64 nlayers, const double *src, int add);
 int cgk_owner_rank(cg_ctx *c, const double *pos, i64 n, int *owner);
 // what: 0 forward, 1 backward, 2 forward + Poisson kernel + backward (fused)

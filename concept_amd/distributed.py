@@ -23,6 +23,8 @@ The same code runs under the "gloo" backend (tests: two ranks sharing one GPU,
 or CPU-only checks of the exchange logic) by staging messages through host
 memory; that path is for tests only.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -69,6 +71,34 @@ class Comm:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         out.copy_(res)
+
+    def all_to_all_layers(self, out, inp, nlayers_total, layer0, nlayers, async_op=False):
+        """all_to_all of the layers [layer0, layer0 + nlayers) of every peer block of two
+        transpose buffers (P blocks of `nlayers_total` layers each: the range is one contiguous
+        piece per peer, exchanged in place).  With async_op the RCCL work handle is returned:
+        the exchange runs on RCCL's stream behind what the current stream has queued so far,
+        and `wait()` makes the current stream wait for it."""
+        P = self.world
+        o = out.view(P, nlayers_total, -1)[:, layer0:layer0 + nlayers]
+        i = inp.view(P, nlayers_total, -1)[:, layer0:layer0 + nlayers]
+        if not self.stage:
+            return dist.all_to_all([o[q] for q in range(P)], [i[q] for q in range(P)],
+                                   group=self.group, async_op=async_op)
+        # gloo (tests): pairwise through host memory, synchronously
+        ops, recvs = [], {}
+        for q in range(P):
+            if q == self.rank:
+                o[q].copy_(i[q])
+                continue
+            ops.append(dist.P2POp(dist.isend, i[q].cpu().contiguous(), q, group=self.group))
+            recvs[q] = torch.empty(o[q].shape, dtype=o.dtype)
+            ops.append(dist.P2POp(dist.irecv, recvs[q], q, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for q, r in recvs.items():
+            o[q].copy_(r)
+        return None
 
     def sendrecv(self, send, dest, recv, source):
         """send -> dest while receiving <- source (a ring shift)."""
@@ -121,6 +151,15 @@ class SlabDomain:
         self.halo_r = torch.empty(self.G*per, dtype=torch.float64, device=self.device)
         self.next = (self.rank + 1) % self.world
         self.prev = (self.rank - 1) % self.world
+        # The FFT transposes are exchanged in `pieces` layer ranges so that the transform of one
+        # range overlaps the exchange of the previous one (CONCEPT_GPU_DIST_PIECES, 1 = one
+        # all_to_all_single per transpose).  A piece should stay a large message: >= 8 layers.
+        # CONCEPT_GPU_DIST_FORCE=1: a single rank also takes the transposing solve (tests)
+        self.force_dist = os.environ.get('CONCEPT_GPU_DIST_FORCE') == '1'
+        want = int(os.environ.get('CONCEPT_GPU_DIST_PIECES', '4'))
+        npieces = max(1, min(want, self.nxl//8))
+        edges = [self.nxl*k//npieces for k in range(npieces + 1)]
+        self.pieces = [(a, b - a) for a, b in zip(edges[:-1], edges[1:])]
 
     # communicate_ghosts(grid, '+=') after the deposit (mesh.py:609)
     def fold_deposit_ghost(self):
@@ -149,14 +188,33 @@ class SlabDomain:
     # A3..A8 with the transpose (fft.c:240-257) as all_to_all_single
     def poisson_solve(self, deconv_order, C, long_range=False, E=0.0):
         m = self.mesh
-        if self.world == 1:
+        if self.world == 1 and not self.force_dist:
             m.poisson_solve(deconv_order, C, long_range, E)
             return
-        m.dist_fft_forward(self.tbuf_a)
-        self.comm.all_to_all(self.tbuf_b, self.tbuf_a)
+        if len(self.pieces) == 1:
+            m.dist_fft_forward(self.tbuf_a)
+            self.comm.all_to_all(self.tbuf_b, self.tbuf_a)
+            m.dist_fft_xsolve(self.tbuf_b, deconv_order, C, long_range, E)
+            self.comm.all_to_all(self.tbuf_a, self.tbuf_b)
+            m.dist_fft_backward(self.tbuf_a)
+            return
+        # pipelined: z + y transform of layer range k+1 while range k is on the links ...
+        works = []
+        for l0, nl in self.pieces:
+            m.dist_fft_forward(self.tbuf_a, l0, nl)
+            works.append(self.comm.all_to_all_layers(self.tbuf_b, self.tbuf_a, self.nxl, l0, nl,
+                                                     async_op=True))
+        for w in works:
+            if w is not None:
+                w.wait()
         m.dist_fft_xsolve(self.tbuf_b, deconv_order, C, long_range, E)
-        self.comm.all_to_all(self.tbuf_a, self.tbuf_b)
-        m.dist_fft_backward(self.tbuf_a)
+        # ... and on the way back the inverse y + z of range k while range k+1 arrives
+        works = [self.comm.all_to_all_layers(self.tbuf_a, self.tbuf_b, self.nxl, l0, nl,
+                                             async_op=True) for l0, nl in self.pieces]
+        for (l0, nl), w in zip(self.pieces, works):
+            if w is not None:
+                w.wait()
+            m.dist_fft_backward(self.tbuf_a, l0, nl)
 
 
 class DistributedParticles:

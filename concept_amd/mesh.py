@@ -377,15 +377,23 @@ class PotentialMesh:
     def layers_write(self, layer0, nlayers, src, add=False):
         check(_L.cg_layers_write(self._ctx, int(layer0), int(nlayers), _ptr(src), int(add)))
 
-    def dist_fft_forward(self, send_buf):
-        check(_L.cg_dist_fft_forward(self._ctx, _ptr(send_buf)))
+    def dist_fft_forward(self, send_buf, layer0=None, nlayers=None):
+        if layer0 is None:
+            check(_L.cg_dist_fft_forward(self._ctx, _ptr(send_buf)))
+        else:
+            check(_L.cg_dist_fft_forward_layers(self._ctx, _ptr(send_buf), int(layer0),
+                                                int(nlayers)))
 
     def dist_fft_xsolve(self, buf, deconv_order, C, long_range=False, E=0.0):
         check(_L.cg_dist_fft_xsolve(self._ctx, _ptr(buf), int(deconv_order), float(C),
                                     int(long_range), float(E)))
 
-    def dist_fft_backward(self, recv_buf):
-        check(_L.cg_dist_fft_backward(self._ctx, _ptr(recv_buf)))
+    def dist_fft_backward(self, recv_buf, layer0=None, nlayers=None):
+        if layer0 is None:
+            check(_L.cg_dist_fft_backward(self._ctx, _ptr(recv_buf)))
+        else:
+            check(_L.cg_dist_fft_backward_layers(self._ctx, _ptr(recv_buf), int(layer0),
+                                                 int(nlayers)))
 
     def owner_rank(self, pos):
         n = self._check_particles(pos)

@@ -270,6 +270,14 @@ int cg_dist_fft_forward(cg_ctx *ctx, double *send_buf /*DEV*/);
 int cg_dist_fft_xsolve(cg_ctx *ctx, double *buf /*DEV*/, int deconv_order, double C,
                        int long_range, double E);
 int cg_dist_fft_backward(cg_ctx *ctx, const double *recv_buf /*DEV*/);
+/* The same two steps for the owned layers [layer0, layer0 + nlayers) only.  In both transpose
+ * buffers the block of domain q holds the layers of the SENDING domain outermost, so the data of
+ * a layer range is one contiguous piece per peer: the caller can exchange a range while the
+ * library transforms the next one (fft.c:240-257 does the whole transpose at once). */
+int cg_dist_fft_forward_layers(cg_ctx *ctx, double *send_buf /*DEV*/, int64_t layer0,
+                               int64_t nlayers);
+int cg_dist_fft_backward_layers(cg_ctx *ctx, const double *recv_buf /*DEV*/, int64_t layer0,
+                                int64_t nlayers);
 int cg_owner_rank(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n,
                   int32_t *owner_out /*DEV n*/);
 /* The fused step of the x-slab path: cg_owner_rank_drifted gives the owner of every particle

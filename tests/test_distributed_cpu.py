@@ -56,6 +56,33 @@ def _w_transpose(rank, world, N):
     assert np.array_equal(back.numpy().reshape(world, nxl, JB, cp), send)
 
 
+def _w_transpose_pieces(rank, world, N, npieces):
+    """The same transpose exchanged in layer ranges (Comm.all_to_all_layers): the pieces
+    together are the one all-to-all."""
+    from concept_amd.distributed import Comm
+    comm = Comm()
+    cp = N//2 + 1
+    nxl = JB = N//world
+    rng = np.random.default_rng(0)
+    full = rng.normal(size=(N, N, cp))
+    local = full[rank*nxl:(rank + 1)*nxl]
+    send = np.empty((world, nxl, JB, cp))
+    for q in range(world):
+        send[q] = local[:, q*JB:(q + 1)*JB, :]
+    send_t = torch.from_numpy(send.reshape(-1).copy())
+    recv = torch.full((world*nxl*JB*cp,), np.nan, dtype=torch.float64)
+    edges = [nxl*k//npieces for k in range(npieces + 1)]
+    for a, b in zip(edges[:-1], edges[1:]):
+        w = comm.all_to_all_layers(recv, send_t, nxl, a, b - a, async_op=True)
+        if w is not None:
+            w.wait()
+    assert np.array_equal(recv.numpy().reshape(N, JB, cp), full[:, rank*JB:(rank + 1)*JB, :])
+    back = torch.full_like(recv, np.nan)
+    for a, b in reversed(list(zip(edges[:-1], edges[1:]))):  # any order
+        comm.all_to_all_layers(back, recv, nxl, a, b - a)
+    assert np.array_equal(back.numpy().reshape(world, nxl, JB, cp), send)
+
+
 def _w_ring(rank, world):
     from concept_amd.distributed import Comm
     comm = Comm()
@@ -153,3 +180,8 @@ def _w_exchange_compact(rank, world, n_per, skew):
 @pytest.mark.parametrize('world,skew', [(2, False), (4, False), (3, True)])
 def test_particle_exchange_compact(world, skew):
     _run(_w_exchange_compact, world, 400, skew)
+
+
+@pytest.mark.parametrize('world,N,npieces', [(2, 16, 2), (4, 32, 4), (2, 16, 3)])
+def test_transpose_in_layer_pieces(world, N, npieces):
+    _run(_w_transpose_pieces, world, N, npieces)
