@@ -578,19 +578,67 @@ __device__ __forceinline__ void tile_r2_last(double2 (&x)[16], double2 *lds,
     }
 }
 
+// radix-8 last pass (Ns = n/8), 2 butterflies per lane (j = tid/W + b*n/16), always to
+// registers: output q of butterfly b is point tid/W + (b + 2q)*n/16.  Replaces a radix-4 pass
+// through LDS followed by the radix-2 pass when log2(n) mod 4 = 3 (2048 = 16*16*8: two LDS
+// exchanges of the tile instead of three).
+template <int LOGN, int W, int NT, bool INV>
+__device__ __forceinline__ void tile_r8_last(double2 (&x)[16], double2 *lds,
+                                             const double2 *__restrict__ tw, int tid) {
+    constexpr int n = 1 << LOGN;
+    const int w = tid % W, jl = tid / W;
+    const double h = 0.70710678118654752440;  // cos(pi/4)
+    double2 v[2][8], t[2];
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        int j = jl + b * (n / 16);
+        t[b] = tw[j];
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[b][r] = lds[(j + r * (n / 8)) * W + w];
+    }
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        double2 t1 = INV ? cconj(t[b]) : t[b];
+        double2 t2 = cmul(t1, t1), t3 = cmul(t2, t1), t4 = cmul(t2, t2);
+        double2 x0 = v[b][0], x1 = cmul(v[b][1], t1), x2 = cmul(v[b][2], t2),
+                x3 = cmul(v[b][3], t3), x4 = cmul(v[b][4], t4), x5 = cmul(v[b][5], cmul(t4, t1)),
+                x6 = cmul(v[b][6], cmul(t4, t2)), x7 = cmul(v[b][7], cmul(t4, t3));
+        // decimation in frequency: sums feed the even outputs, differences times w8^r the odd
+        double2 a0 = cadd(x0, x4), a1 = cadd(x1, x5), a2 = cadd(x2, x6), a3 = cadd(x3, x7);
+        double2 b0 = csub(x0, x4), d1 = csub(x1, x5), d2 = csub(x2, x6), d3 = csub(x3, x7);
+        // w8 = exp(-+ 2 pi i/8): w8 = h(1 -+ i), w8^2 = -+ i, w8^3 = h(-1 -+ i)
+        double2 b1 = INV ? make_double2(h * (d1.x - d1.y), h * (d1.x + d1.y))
+                         : make_double2(h * (d1.x + d1.y), h * (d1.y - d1.x));
+        double2 b2 = INV ? make_double2(-d2.y, d2.x) : make_double2(d2.y, -d2.x);
+        double2 b3 = INV ? make_double2(-h * (d3.x + d3.y), h * (d3.x - d3.y))
+                         : make_double2(h * (d3.y - d3.x), -h * (d3.x + d3.y));
+        bfly4<INV>(a0, a1, a2, a3);  // X[0], X[2], X[4], X[6]
+        bfly4<INV>(b0, b1, b2, b3);  // X[1], X[3], X[5], X[7]
+        x[b + 0] = a0;
+        x[b + 2] = b0;
+        x[b + 4] = a1;
+        x[b + 6] = b1;
+        x[b + 8] = a2;
+        x[b + 10] = b2;
+        x[b + 12] = a3;
+        x[b + 14] = b3;
+    }
+}
+
 template <int LOGN, int W, int NT, bool INV>
 __device__ __forceinline__ void fft_tile(double2 (&x)[16], double2 *lds,
                                          const double2 *__restrict__ tw, int tid) {
     constexpr int n16 = LOGN / 4, rem = LOGN % 4;
-    constexpr int npass = n16 + (rem >= 2 ? 1 : 0) + (rem & 1);
+    constexpr int npass = n16 + (rem ? 1 : 0);
     static_assert(n16 >= 1 && n16 <= 2, "tile transform: 16 <= n <= 2048");
     // the stride Ns of each pass is a compile-time constant: LDS addresses become one base
     // register plus immediate offsets
     tile_r16<LOGN, W, NT, INV, true, npass == 1, 1>(x, lds, tw, tid);
     if constexpr (n16 == 2) tile_r16<LOGN, W, NT, INV, false, npass == 2, 16>(x, lds, tw, tid);
-    if constexpr (rem >= 2)
-        tile_r4<LOGN, W, NT, INV, (rem & 1) == 0, (n16 == 2 ? 256 : 16)>(x, lds, tw, tid);
-    if constexpr (rem & 1) tile_r2_last<LOGN, W, NT, INV>(x, lds, tw, tid);
+    if constexpr (rem == 3) tile_r8_last<LOGN, W, NT, INV>(x, lds, tw, tid);
+    if constexpr (rem == 2)
+        tile_r4<LOGN, W, NT, INV, true, (n16 == 2 ? 256 : 16)>(x, lds, tw, tid);
+    if constexpr (rem == 1) tile_r2_last<LOGN, W, NT, INV>(x, lds, tw, tid);
 }
 
 // Persistent form of the strided pass: one workgroup per CU walks tiles t, t + G, ... and
