@@ -265,7 +265,6 @@ int cgk_layers_write(cg_ctx *c, i64 layer0, i64 nlayers, const double *src, int 
     }
     i64 n2 = per * nlayers / 2;
     i64 blocks = (n2 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_layers_add, dim3((unsigned)blocks), dim3(256), 0, c->stream,
                        (double2 *)dst, (const double2 *)src, n2);
     CG_LAUNCH_CHECK();

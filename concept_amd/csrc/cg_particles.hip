@@ -43,8 +43,7 @@ int cgk_drift(cg_ctx *c, double *pos, const double *mom, i64 n, double dt_over_m
     i64 n3 = 3 * n;
     CG_CHECK(((uintptr_t)pos % 16 == 0) && ((uintptr_t)mom % 16 == 0),
              "cg_drift: particle arrays must be 16-byte aligned");
-    i64 blocks = (n3 / 2 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    i64 blocks = (n3 / 2 + 255) / 256;  // no cap: one workgroup per 4 KiB streams fastest
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_drift, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, mom, n3,
                        dt_over_mass, c->p.boxsize);
@@ -185,7 +184,6 @@ int cgk_prepare_rebind(cg_ctx *c, const double *pos, const double *mom, i64 n_to
     if (!c->prep_valid) return 0;
     if (n_add > 0) {
         i64 blocks = (n_add + 255) / 256;
-        if (blocks > 256 * 16) blocks = 256 * 16;
         hipLaunchKernelGGL(k_tile_histogram<true>, dim3((unsigned)blocks), dim3(256), 0, c->stream,
                            add_pos, add_mom, n_add, c->prep_dtm, c->p.boxsize, c->geom_deposit,
                            c->p.nghosts, c->N, c->tiles, c->xmap.x0, c->tile_count);
@@ -204,8 +202,19 @@ int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *i
     if (!use_prepared) CG_HIP(hipMemsetAsync(c->tile_count, 0, 4 * (nt + 1), c->stream));
     CG_HIP(hipMemsetAsync(c->tile_cursor, 0, 4 * (nt + 1), c->stream));
     c->prep_valid = false;
+    // One 256-lane workgroup per 256 particles, no grid-stride loop: with the grid capped at
+    // 4096 workgroups the scatter took 5.9 ms at 2^28 particles, uncapped 5.1 ms (the same
+    // holds for a plain copy kernel, tools/copy_probe.cpp: 4.9 vs 5.6 TB/s).
+    // CONCEPT_GPU_SCATTER_BLOCKS=<cap> restores a cap for A/B.
     i64 blocks = (n + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    {
+        static i64 cap = -1;
+        if (cap < 0) {
+            const char *env = getenv("CONCEPT_GPU_SCATTER_BLOCKS");
+            cap = env ? atoll(env) : 0;
+        }
+        if (cap > 0 && blocks > cap) blocks = cap;
+    }
     if (n > 0 && !use_prepared) {
         if (drift)
             hipLaunchKernelGGL(k_tile_histogram<true>, dim3((unsigned)blocks), dim3(256), 0,

@@ -105,8 +105,7 @@ int cgk_shortrange_build(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
     }
     unsigned *count = (unsigned *)c->sr_tmp, *cursor = count + (ntiles + 1);
     CG_HIP(hipMemsetAsync(c->sr_tmp, 0, 8 * (ntiles + 1), c->stream));
-    i64 blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    i64 blocks = (n + 255) / 256;  // one workgroup per 256 particles (see cgk_sort)
     if (n > 0) {
         hipLaunchKernelGGL(k_sr_histogram, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n,
                            inv, (unsigned)nt, count);
