@@ -232,6 +232,9 @@ class DistributedParticles:
         self.ids = torch.zeros(cap, dtype=torch.int64, device=dev)
         self.pos[:n] = pos
         self.mom[:n] = mom
+        # without ids the sort moves pos and mom only (the id column of the exchanged rows is
+        # carried but meaningless)
+        self.has_ids = ids is not None
         if ids is not None:
             self.ids[:n] = ids
         self.pos2 = torch.empty_like(self.pos)
@@ -276,8 +279,9 @@ class DistributedParticles:
             m.prepare_rebind(pos, mom, inc[:, 0:3].contiguous(), inc[:, 3:6].contiguous())
         else:
             m.prepare_rebind(pos, mom)
-        m.drift_sort(pos, mom, self.view('ids'), self.pos2[:n_new], self.mom2[:n_new],
-                     self.ids2[:n_new], dt_over_mass, self.table)
+        m.drift_sort(pos, mom, self.view('ids') if self.has_ids else None, self.pos2[:n_new],
+                     self.mom2[:n_new], self.ids2[:n_new] if self.has_ids else None, dt_over_mass,
+                     self.table)
         self.pos, self.pos2 = self.pos2, self.pos
         self.mom, self.mom2 = self.mom2, self.mom
         self.ids, self.ids2 = self.ids2, self.ids
@@ -290,9 +294,10 @@ class DistributedParticles:
 
     def tile_sort(self):
         d = self.domain
-        d.mesh.sort_particles(self.view('pos'), self.view('mom'), self.view('ids'),
-                              self.pos2[:self.n], self.mom2[:self.n], self.ids2[:self.n],
-                              self.table)
+        d.mesh.sort_particles(self.view('pos'), self.view('mom'),
+                              self.view('ids') if self.has_ids else None,
+                              self.pos2[:self.n], self.mom2[:self.n],
+                              self.ids2[:self.n] if self.has_ids else None, self.table)
         self.pos, self.pos2 = self.pos2, self.pos
         self.mom, self.mom2 = self.mom2, self.mom
         self.ids, self.ids2 = self.ids2, self.ids
