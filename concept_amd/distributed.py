@@ -158,6 +158,12 @@ class SlabDomain:
         self.force_dist = os.environ.get('CONCEPT_GPU_DIST_FORCE') == '1'
         want = int(os.environ.get('CONCEPT_GPU_DIST_PIECES', '4'))
         npieces = max(1, min(want, self.nxl//8))
+        if npieces > 1:
+            # a piece should also fit the 256 MB infinity cache, like the chunks of the
+            # single-GPU schedule (cg_fft.hip zy_chunk_layers): its y pass then reads what its
+            # z pass wrote from the cache
+            cache_layers = max(1, int(266e6//(per*8)))
+            npieces = min(max(npieces, -(-self.nxl//cache_layers)), max(1, self.nxl//8))
         edges = [self.nxl*k//npieces for k in range(npieces + 1)]
         self.pieces = [(a, b - a) for a, b in zip(edges[:-1], edges[1:])]
 
