@@ -164,6 +164,19 @@ class SlabDomain:
             # z pass wrote from the cache
             cache_layers = max(1, int(266e6//(per*8)))
             npieces = min(max(npieces, -(-self.nxl//cache_layers)), max(1, self.nxl//8))
+        if npieces > 1 and not self.comm.stage:
+            # every rank probes the asynchronous list form of all_to_all once, on a few bytes;
+            # a transport that rejects it falls back to one all_to_all_single per transpose
+            try:
+                a = torch.zeros(2*self.world, dtype=torch.float64, device=self.device)
+                b = torch.empty_like(a)
+                w = self.comm.all_to_all_layers(b, a, 2, 0, 1, async_op=True)
+                if w is not None:
+                    w.wait()
+                torch.cuda.synchronize(self.device)
+            except Exception as e:  # noqa: BLE001 (any backend error means: do not pipeline)
+                print(f'[concept_amd] pipelined transposes disabled: {e}', flush=True)
+                npieces = 1
         edges = [self.nxl*k//npieces for k in range(npieces + 1)]
         self.pieces = [(a, b - a) for a, b in zip(edges[:-1], edges[1:])]
 
