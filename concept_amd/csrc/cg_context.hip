@@ -522,6 +522,16 @@ extern "C" int cg_gather_kick_tiled_prepare(cg_ctx *c, const double *pos, double
                                  next_dt_over_mass);
 }
 
+extern "C" int cg_set_emigrant_list(cg_ctx *c, int64_t *idx, uint32_t *count, int64_t cap) {
+    CG_CHECK(c, "cg_set_emigrant_list: null context");
+    CG_CHECK((idx == nullptr) == (count == nullptr) && cap >= 0,
+             "cg_set_emigrant_list: idx and count must both be given or both be null");
+    c->emig_idx = idx;
+    c->emig_count = count;
+    c->emig_cap = idx ? cap : 0;
+    return 0;
+}
+
 extern "C" int cg_sort_particles(cg_ctx *c, const double *pos_in, const double *mom_in,
                                  const int64_t *ids_in, double *pos_out, double *mom_out,
                                  int64_t *ids_out, int64_t n, uint32_t *tile_offset_out) {

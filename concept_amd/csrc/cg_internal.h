@@ -125,6 +125,10 @@ struct cg_ctx {
     const double *prep_pos = nullptr, *prep_mom = nullptr;
     i64 prep_n = 0;
     double prep_dtm = 0;
+    // caller-owned list of the particles leaving the slab with the prepared drift
+    i64 *emig_idx = nullptr;
+    unsigned *emig_count = nullptr;
+    i64 emig_cap = 0;
     i64 device_bytes = 0;
 };
 

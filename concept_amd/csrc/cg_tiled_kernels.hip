@@ -211,6 +211,12 @@ struct PrepArgs {
     CicGeom geo_sort;
     TileGeom tiles;
     unsigned *count;
+    // x-slab domains: the particles that will leave the slab with the next drift (no tile
+    // key) are listed — emig_idx[0 .. min(*emig_count, emig_cap)) — so that the exchange
+    // needs no pass of its own to find them (cg_set_emigrant_list; null = off)
+    i64 *emig_idx;
+    unsigned *emig_count;
+    i64 emig_cap;
 };
 
 template <int ORDER, int T, bool PREP>
@@ -358,6 +364,10 @@ __global__ __launch_bounds__(512, 4) void k_gather_kick_tiled(
             wave_runs(next_key, threadIdx.x & 63, rs, rl);
             if ((int)(threadIdx.x & 63) == rs && next_key != kNoTile)
                 atomicAdd(&prep.count[next_key], (unsigned)rl);
+            if (prep.emig_idx && pvalid && next_key == kNoTile) {
+                const unsigned slot = atomicAdd(prep.emig_count, 1u);
+                if ((i64)slot < prep.emig_cap) prep.emig_idx[slot] = p;
+            }
         }
     }
 }
@@ -392,7 +402,10 @@ static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsign
 int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
                           const unsigned *tile_offset, int diff_order, double factor,
                           int prepare, double next_dtm) {
-    PrepArgs prep_args{next_dtm, c->p.boxsize, c->geom_deposit, c->tiles, c->tile_count};
+    PrepArgs prep_args{next_dtm, c->p.boxsize, c->geom_deposit, c->tiles, c->tile_count,
+                       c->emig_idx, c->emig_count, c->emig_cap};
+    if (prepare && c->emig_idx)
+        CG_HIP(hipMemsetAsync(c->emig_count, 0, sizeof(unsigned), c->stream));
     const PrepArgs *prep = prepare ? &prep_args : nullptr;
     if (prepare)
         CG_HIP(hipMemsetAsync(c->tile_count, 0, 4 * (8 * c->ntiles + 1), c->stream));

@@ -261,6 +261,11 @@ class DistributedParticles:
         self.ids2 = torch.empty_like(self.ids)
         self.table = domain.mesh.new_tile_table()
         self.sorted = False
+        # rows that the drift prepared by the last pm_kick(next_dt_over_mass=...) takes out of the
+        # slab, listed by the gather-kick itself (cg_set_emigrant_list)
+        self.emig_idx = torch.empty(max(4096, cap//16), dtype=torch.int64, device=dev)
+        self.emig_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._emig_for = None  # (pos pointer, n, dt_over_mass) the list was made for
 
     def view(self, name):
         return getattr(self, name)[:self.n]
@@ -289,9 +294,17 @@ class DistributedParticles:
         d = self.domain
         m = d.mesh
         pos, mom = self.view('pos'), self.view('mom')
-        owner = m.owner_rank_drifted(pos, mom, dt_over_mass)
+        move = None
+        if self._emig_for == (self.pos.data_ptr(), self.n, float(dt_over_mass)):
+            cnt = int(self.emig_count.item())
+            if cnt <= self.emig_idx.numel():  # else the list overflowed: find them the long way
+                move_idx = self.emig_idx[:cnt]
+                move = (move_idx, m.owner_rank_drifted(pos[move_idx], mom[move_idx],
+                                                       dt_over_mass))
+        self._emig_for = None
+        owner = m.owner_rank_drifted(pos, mom, dt_over_mass) if move is None else None
         n_new, inc = exchange_rows_compact(d.comm, owner, self.pos, self.mom, self.ids, self.n,
-                                           self.cap)
+                                           self.cap, move=move)
         self.n = n_new
         pos, mom = self.view('pos'), self.view('mom')
         if inc is not None and inc.shape[0]:
@@ -373,14 +386,19 @@ def exchange_rows(comm, owner, pos, mom, ids, n, cap, dead_x):
     return n_slots, n - m_out + m_in
 
 
-def exchange_rows_compact(comm, owner, pos, mom, ids, n, cap):
+def exchange_rows_compact(comm, owner, pos, mom, ids, n, cap, move=None):
     """exchange_rows that leaves no dead rows: vacated slots are refilled with immigrants,
     surplus immigrants are appended, leftover holes are closed with live rows from the tail.
-    Returns (n_new, immigrant rows (m_in, 7) or None); the live rows are [0, n_new)."""
+    `move` = (row numbers, their owners) when the leaving rows are already known (then `owner`
+    is not needed).  Returns (n_new, immigrant rows (m_in, 7) or None); the live rows are
+    [0, n_new)."""
     P, rank = comm.world, comm.rank
     dev = pos.device
-    move_idx = torch.nonzero(owner[:n] != rank).flatten()
-    dest = owner[move_idx].long()
+    if move is None:
+        move_idx = torch.nonzero(owner[:n] != rank).flatten()
+        dest = owner[move_idx].long()
+    else:
+        move_idx, dest = move[0], move[1].long()
     order = torch.argsort(dest, stable=True)
     move_idx, dest = move_idx[order], dest[order]
     send_counts = torch.bincount(dest, minlength=P).cpu().tolist()
@@ -492,6 +510,9 @@ def pm_kick(domain, particles, contribution, deconv_order, C, kick_factor, diff_
         m.gather_kick_tiled(particles.view('pos'), particles.view('mom'), particles.table,
                             diff_order, kick_factor)
     else:
-        # also histogram the tile keys after the NEXT drift (for drift_exchange_sort)
+        # also histogram the tile keys after the NEXT drift and list the rows it takes out of the
+        # slab (for drift_exchange_sort)
+        m.set_emigrant_list(particles.emig_idx, particles.emig_count)
+        particles._emig_for = (particles.pos.data_ptr(), particles.n, float(next_dt_over_mass))
         m.gather_kick_tiled_prepare(particles.view('pos'), particles.view('mom'),
                                     particles.table, diff_order, kick_factor, next_dt_over_mass)

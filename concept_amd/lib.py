@@ -83,6 +83,7 @@ SYMBOLS = {
     'cg_dist_fft_forward': (_int, [_vp, _vp]),
     'cg_dist_fft_xsolve': (_int, [_vp, _vp, _int, _dbl, _int, _dbl]),
     'cg_dist_fft_backward': (_int, [_vp, _vp]),
+    'cg_set_emigrant_list': (_int, [_vp, _vp, _vp, _i64]),
     'cg_dist_fft_forward_layers': (_int, [_vp, _vp, _i64, _i64]),
     'cg_dist_fft_backward_layers': (_int, [_vp, _vp, _i64, _i64]),
     'cg_layer_doubles': (_i64, [_vp]),

@@ -395,6 +395,15 @@ class PotentialMesh:
             check(_L.cg_dist_fft_backward_layers(self._ctx, _ptr(recv_buf), int(layer0),
                                                  int(nlayers)))
 
+    def set_emigrant_list(self, idx, count):
+        """gather_kick_tiled_prepare also lists (int64 row numbers into `idx`, their number into
+        the one-element uint32/int32 tensor `count`) the particles its prepared drift takes out
+        of this domain's slab; None, None switches the list off."""
+        if idx is None:
+            check(_L.cg_set_emigrant_list(self._ctx, None, None, 0))
+        else:
+            check(_L.cg_set_emigrant_list(self._ctx, _ptr(idx), _ptr(count), int(idx.numel())))
+
     def owner_rank(self, pos):
         n = self._check_particles(pos)
         out = torch.empty(n, dtype=torch.int32, device=pos.device)

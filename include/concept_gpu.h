@@ -288,6 +288,13 @@ int cg_owner_rank(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n,
  * drifts and sorts in one pass pair (no stand-alone drift, no histogram pass). */
 int cg_owner_rank_drifted(cg_ctx *ctx, const double *pos /*DEV 3n*/, const double *mom /*DEV 3n*/,
                           int64_t n, double dt_over_mass, int32_t *owner_out /*DEV n*/);
+/* Optional: cg_gather_kick_tiled_prepare also lists the particles that the prepared drift takes
+ * out of this domain's slab (the candidates of exchange(), communication.py:135-517):
+ * idx[0 .. min(*count, cap)) are their row numbers, *count the number found (> cap: the list is
+ * incomplete, fall back to cg_owner_rank_drifted over all particles).  Caller-owned device
+ * buffers; idx = count = NULL switches the list off. */
+int cg_set_emigrant_list(cg_ctx *ctx, int64_t *idx /*DEV cap*/, uint32_t *count /*DEV 1*/,
+                         int64_t cap);
 int cg_prepare_rebind(cg_ctx *ctx, const double *pos /*DEV*/, const double *mom /*DEV*/,
                       int64_t n_total, const double *add_pos /*DEV 3 n_add*/,
                       const double *add_mom /*DEV 3 n_add*/, int64_t n_add);

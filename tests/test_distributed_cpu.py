@@ -139,7 +139,7 @@ def test_particle_exchange(world):
     _run(_w_exchange, world, 500)
 
 
-def _w_exchange_compact(rank, world, n_per, skew):
+def _w_exchange_compact(rank, world, n_per, skew, listed=False):
     """exchange_rows_compact: afterwards the live rows are exactly [0, n_new), every particle
     is at home, rows stayed together, nothing lost or duplicated; `skew` makes one rank
     lose far more than it gains (holes closed from the tail) and another gain more."""
@@ -160,7 +160,13 @@ def _w_exchange_compact(rank, world, n_per, skew):
     pos[n:] = float('nan')  # anything beyond n must never be picked up
     owner = torch.clamp((pos[:n, 0]*world).long(), max=world - 1).int()
     before = comm.all_gather_ints([n])[:, 0].sum().item()
-    n_new, inc = exchange_rows_compact(comm, owner, pos, mom, ids, n, cap)
+    if listed:  # the leaving rows come as a list in arbitrary order (the gather-kick's)
+        idx = torch.nonzero(owner != rank).flatten()
+        idx = idx[torch.randperm(idx.numel(), generator=gen)]
+        n_new, inc = exchange_rows_compact(comm, None, pos, mom, ids, n, cap,
+                                           move=(idx, owner[idx]))
+    else:
+        n_new, inc = exchange_rows_compact(comm, owner, pos, mom, ids, n, cap)
     p, m, i = pos[:n_new], mom[:n_new], ids[:n_new]
     assert not torch.isnan(p).any()
     assert (torch.clamp((p[:, 0]*world).long(), max=world - 1) == rank).all()
@@ -177,9 +183,11 @@ def _w_exchange_compact(rank, world, n_per, skew):
     assert len(flat) == len(set(flat)) == before
 
 
-@pytest.mark.parametrize('world,skew', [(2, False), (4, False), (3, True)])
-def test_particle_exchange_compact(world, skew):
-    _run(_w_exchange_compact, world, 400, skew)
+@pytest.mark.parametrize('world,skew,listed', [(2, False, False), (4, False, False),
+                                               (3, True, False), (3, True, True),
+                                               (4, False, True)])
+def test_particle_exchange_compact(world, skew, listed):
+    _run(_w_exchange_compact, world, 400, skew, listed)
 
 
 @pytest.mark.parametrize('world,N,npieces', [(2, 16, 2), (4, 32, 4), (2, 16, 3)])
