@@ -139,12 +139,25 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world):
     contribution = mass*(float(N)**(-3)*(N/L)**3)
     C = -L**2*G/3.141592653589793
 
-    def step():
+    stage_events = []  # per timed step: [(name, event), ...] on the compute stream
+
+    def step(record=False):
         # fused: emigrants of the coming drift are shipped first, then one drift + sort pass
         # pair; the gather-kick histograms the tiles of the next drift
+        evs = []
+
+        def mark(name):
+            if record:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append((name, e))
+        mark('start')
         parts.drift_exchange_sort(dt/mass)
+        mark('drift+exchange+sort')
         pm_kick(dom, parts, contribution, 4, C, mass*(-dt), diff_order=2,
-                next_dt_over_mass=dt/mass)
+                next_dt_over_mass=dt/mass, mark=mark)
+        if record:
+            stage_events.append(evs)
 
     for _ in range(args.warmup):
         step()
@@ -153,10 +166,15 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(record=True)
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
+    # this rank's stage times (the exchanges wait for the slowest peer inside their stage)
+    stages = {}
+    for evs in stage_events:
+        for (_, a), (name, b) in zip(evs[:-1], evs[1:]):
+            stages[name] = stages.get(name, 0.0) + a.elapsed_time(b)/len(stage_events)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -181,6 +199,7 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world):
                                '1 PM step = drift + exchange + tile sort + long-range kick',
                    'particles': total, 'gridsize': N, 'parallelism': f'xslab{world}'},
         'roofline': None, 'cpu_baseline': None,
+        'stages_ms_rank0': {k: round(v, 3) for k, v in stages.items()},
     }))
 
 

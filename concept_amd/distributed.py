@@ -496,15 +496,19 @@ def shortrange_kick(domain, particles, *, scale, range_, tilesize, tablesize, so
 
 
 def pm_kick(domain, particles, contribution, deconv_order, C, kick_factor, diff_order=2,
-            long_range=False, E=0.0, next_dt_over_mass=None):
+            long_range=False, E=0.0, next_dt_over_mass=None, mark=None):
     """One long-range PM kick of a tile-sorted particle set onto itself, sharded
-    (particle_mesh(), interactions.py:1985-2335)."""
+    (particle_mesh(), interactions.py:1985-2335).  `mark(name)` is called after each stage
+    (bench.py records an event there)."""
     if not particles.sorted:
         raise lib.ConceptGPUError('pm_kick: particles must be exchanged and tile-sorted')
+    mark = mark or (lambda name: None)
     m = domain.mesh
     m.deposit_tiled(particles.view('pos'), particles.table, contribution, accumulate=False)
     domain.fold_deposit_ghost()
+    mark('deposit+ghost_fold')
     domain.poisson_solve(deconv_order, C, long_range, E)
+    mark('poisson+transposes')
     domain.fill_potential_ghosts()
     if next_dt_over_mass is None:
         m.gather_kick_tiled(particles.view('pos'), particles.view('mom'), particles.table,
@@ -516,3 +520,4 @@ def pm_kick(domain, particles, contribution, deconv_order, C, kick_factor, diff_
         particles._emig_for = (particles.pos.data_ptr(), particles.n, float(next_dt_over_mass))
         m.gather_kick_tiled_prepare(particles.view('pos'), particles.view('mom'),
                                     particles.table, diff_order, kick_factor, next_dt_over_mass)
+    mark('ghost_fill+gather_kick')
