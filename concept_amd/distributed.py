@@ -518,6 +518,10 @@ def pm_kick(domain, particles, contribution, deconv_order, C, kick_factor, diff_
         # slab (for drift_exchange_sort)
         m.set_emigrant_list(particles.emig_idx, particles.emig_count)
         particles._emig_for = (particles.pos.data_ptr(), particles.n, float(next_dt_over_mass))
-        m.gather_kick_tiled_prepare(particles.view('pos'), particles.view('mom'),
-                                    particles.table, diff_order, kick_factor, next_dt_over_mass)
+        try:
+            m.gather_kick_tiled_prepare(particles.view('pos'), particles.view('mom'),
+                                        particles.table, diff_order, kick_factor,
+                                        next_dt_over_mass)
+        finally:
+            m.set_emigrant_list(None, None)  # the launch holds the pointers; the context must not
     mark('ghost_fill+gather_kick')
