@@ -475,6 +475,11 @@ def main():
                               '(x forward + k-space + x inverse = 48*N_g), its measured HBM '
                               'traffic is one read + one write of the mesh'
                               if dom == 'fft_x_fused_kspace' else
+                              'algorithmic bytes are the fused kernel\'s minimum (DESIGN.md §4): '
+                              'pos + mom read-modify-write + the potential once = 72*N_p + 8*N_g; '
+                              'SURVEY.md §8(d) row A10 counts three force grids (72*N_p + '
+                              '24*N_g), see unfused_accounting'
+                              if dom == 'gather_kick' else
                               'algorithmic bytes follow SURVEY.md §8(d) / DESIGN.md §4'),
                      'traffic_source': 'profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc '
                                        'FETCH_SIZE / WRITE_SIZE, separate passes)'},
@@ -488,6 +493,12 @@ def main():
                             for k, (b, ms) in groups.items()},
         'phases': phases,
     }
+    if dom == 'gather_kick':
+        # the same launch priced with SURVEY.md §8(d)'s own A10 row (three force grids read)
+        b = 72*n_p + 24*n_g
+        a = b/(kernels[dom][1]*1e-3)/1e9
+        result['roofline']['unfused_accounting'] = {
+            'algorithmic_bytes': b, 'achieved': round(a, 1), 'frac': round(a/HBM_PEAK_GBS, 4)}
     if not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline()
     print(json.dumps(result))
