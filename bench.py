@@ -178,6 +178,23 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world):
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # outside the timed region: what one whole FFT transpose costs on this transport by itself
+    # (one all_to_all_single of the transpose buffer), for reading the stage times above
+    probe = None
+    if world > 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dom.comm.all_to_all(dom.tbuf_b, dom.tbuf_a)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0.record()
+        for _ in range(3):
+            dom.comm.all_to_all(dom.tbuf_b, dom.tbuf_a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)/3
+        sent = dom.tbuf_a.numel()*8*(world - 1)/world
+        probe = {'ms': round(ms, 3), 'bytes_sent_per_rank': int(sent),
+                 'GBps_out_per_rank': round(sent/(ms*1e-3)/1e9, 1)}
     cnt = torch.tensor([parts.n], dtype=torch.int64, device=dev)
     dist.all_reduce(cnt)
     # RCCL prints its version banner through C stdio; push it out (and shut the communicator
@@ -200,6 +217,7 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world):
                    'particles': total, 'gridsize': N, 'parallelism': f'xslab{world}'},
         'roofline': None, 'cpu_baseline': None,
         'stages_ms_rank0': {k: round(v, 3) for k, v in stages.items()},
+        'transpose_probe_rank0': probe,
     }))
 
 
