@@ -144,17 +144,62 @@ struct SrParams {
     int lowest_active;
 };
 
+// The pair tests of one staged supplier chunk for this lane's receiver: branch-free (a miss adds
+// x*0) and with a wave-uniform trip count, so that the loop unrolls into straight-line code with
+// several table loads in flight.  SHIFTED (the supplier tile is a periodic image) and SELF (it is
+// the receiver's own tile of the same component: skip i == j) are wave-uniform and resolved at
+// compile time — as run-time conditions inside the loop they cost 9 selects and an LDS read per
+// pair (rocprofv3: the sweep is VALU-bound, VALUBusy 75 %).  For a hit the arithmetic and its
+// order are the reference's (gravity.py:299-349); r2 and the table index are bit-identical.
+constexpr int kSrStage = 128;  // staged suppliers per chunk
+
+template <bool SHIFTED, bool SELF>
+__device__ __forceinline__ void sr_pairs(int sub, int S, int cnt, double xi, double yi, double zi,
+                                         double ox, double oy, double oz, const double *sx,
+                                         const double *sy, const double *sz, const unsigned *sidx,
+                                         unsigned pi, double r2_max, double r2_index_scaling,
+                                         double my_factor, const double *__restrict__ table,
+                                         double &ax, double &ay, double &az) {
+#pragma unroll 4
+    for (int k0 = 0; k0 < cnt; k0 += S) {
+        const int kk = k0 + sub;
+        const int k = kk < kSrStage - 1 ? kk : kSrStage - 1;  // the staged arrays' last entry
+        double x_ji = xi - sx[k];                        // interactions.py:1787-1789
+        double y_ji = yi - sy[k];
+        double z_ji = zi - sz[k];
+        if (SHIFTED) {                                   // gravity.py:299-302
+            x_ji += ox;
+            y_ji += oy;
+            z_ji += oz;
+        }
+        const double r2 = x_ji * x_ji + y_ji * y_ji + z_ji * z_ji;  // gravity.py:306
+        bool hit = (kk < cnt) & !(r2 > r2_max);
+        if (SELF) hit &= sidx[k] != pi;
+        // (a fully branch-free form — table[hit ? idx : 0] loaded unconditionally, four loads in
+        // flight — measured slower: 15.3 vs 14.1 ms, it costs 12 more registers and the misses'
+        // loads; the compiler branches around the hit part per unrolled pair)
+        double total_factor = 0.0;
+        if (hit) {
+            const unsigned idx = (unsigned)(int)(r2 * r2_index_scaling);  // gravity.py:316
+            total_factor = my_factor * table[idx];                        // gravity.py:321
+        }
+        ax += x_ji * total_factor;
+        ay += y_ji * total_factor;
+        az += z_ji * total_factor;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_sr_sweep(
     const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
     const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
     const double *__restrict__ pos_s, const unsigned *__restrict__ order_s,
     const unsigned *__restrict__ off_s, const double *__restrict__ table, SrParams P) {
     // A tile holds ~20 particles with the default parameters, far fewer than the 64
-    // lanes: the wavefront is split into S = 64/R groups of R lanes (R = the power of
-    // two >= the receivers of a chunk); group s takes suppliers s, s+S, s+2S, ... of
-    // every staged chunk and the S partial sums of a receiver are folded with shuffles.
-    __shared__ double sx[64], sy[64], sz[64];
-    __shared__ unsigned sidx[64];
+    // lanes: the wavefront is split into S = 64/R groups of R lanes (R = the receivers of a
+    // chunk); group s takes suppliers s, s+S, s+2S, ... of every staged chunk and the S
+    // partial sums of a receiver are folded with shuffles.
+    __shared__ double sx[kSrStage], sy[kSrStage], sz[kSrStage];
+    __shared__ unsigned sidx[kSrStage];
     const int lane = threadIdx.x;
     const int nt = P.nt;
     const unsigned tr = blockIdx.x;
@@ -163,10 +208,12 @@ __global__ __launch_bounds__(64) void k_sr_sweep(
     const int ra = tr / (nt * nt), rb = (tr / nt) % nt, rc = tr % nt;
     for (unsigned base = rbeg; base < rend; base += 64) {
         const int nrec = (int)min(64u, rend - base);
-        int R = 8;
-        while (R < nrec) R <<= 1;
-        const int S = 64 / R, sub = lane / R, rl = lane % R;
-        bool active = rl < nrec;
+        // R = nrec receivers x S = 64/nrec supplier groups: 22 receivers (the mean of the default
+        // tiling) give 2 x 22 lanes, 21 give 3 x 21 (a power-of-two R left 17..32 receivers at
+        // 2 groups)
+        const int R = nrec;
+        const int S = 64 / R, sub = lane / R, rl = lane - sub * R;
+        bool active = sub < S;
         const unsigned pi = active ? order_r[base + rl] : 0u;
         double my_factor = P.factor;
         if (active && P.rung) {
@@ -180,58 +227,80 @@ __global__ __launch_bounds__(64) void k_sr_sweep(
             zi = pos_r[3 * (i64)pi + 2];
         }
         double ax = 0, ay = 0, az = 0;
-        for (int d = 0; d < 27; d++) {
-            int sa = ra + d / 9 - 1, sb = rb + (d / 3) % 3 - 1, sc = rc + d % 3 - 1;
-            // periodic offset from the tile separation (interactions.py:1615-1621)
+        // The cell list is z-fastest: the three supplier tiles (sa, sb, rc-1 .. rc+1) of a
+        // column are one contiguous run of it, staged and swept as one range (9 ranges of ~66
+        // suppliers instead of 27 of ~22: a third of the staging round trips and barriers) unless
+        // the column wraps around the box in z, where the three tiles carry different offsets.
+        const bool zwrap = rc == 0 || rc == nt - 1;
+        for (int d = 0; d < (zwrap ? 27 : 9); d++) {
+            int sa, sb, sc0, sc1;
             double ox = 0, oy = 0, oz = 0;
+            if (zwrap) {
+                sa = ra + d / 9 - 1;
+                sb = rb + (d / 3) % 3 - 1;
+                sc0 = rc + d % 3 - 1;
+                if (sc0 < 0) { sc0 += nt; oz = P.boxsize; } else if (sc0 >= nt) { sc0 -= nt; oz = -P.boxsize; }
+                sc1 = sc0;
+            } else {
+                sa = ra + d / 3 - 1;
+                sb = rb + d % 3 - 1;
+                sc0 = rc - 1;
+                sc1 = rc + 1;
+            }
+            // periodic offset from the tile separation (interactions.py:1615-1621)
             if (sa < 0) { sa += nt; ox = P.boxsize; } else if (sa >= nt) { sa -= nt; ox = -P.boxsize; }
             if (sb < 0) { sb += nt; oy = P.boxsize; } else if (sb >= nt) { sb -= nt; oy = -P.boxsize; }
-            if (sc < 0) { sc += nt; oz = P.boxsize; } else if (sc >= nt) { sc -= nt; oz = -P.boxsize; }
             const bool shifted = (ox != 0) | (oy != 0) | (oz != 0);
-            const unsigned ts = (unsigned)((sa * nt + sb) * nt + sc);
-            const unsigned sbeg = off_s[ts], send = off_s[ts + 1];
-            for (unsigned cb = sbeg; cb < send; cb += 64) {
+            const unsigned ts0 = (unsigned)((sa * nt + sb) * nt + sc0);
+            const unsigned ts1 = (unsigned)((sa * nt + sb) * nt + sc1);
+            const unsigned sbeg = off_s[ts0], send = off_s[ts1 + 1];
+            const bool self = P.same && ts0 <= tr && tr <= ts1;  // the range holds the receivers
+            for (unsigned cb = sbeg; cb < send; cb += kSrStage) {
                 __syncthreads();
-                if (cb + lane < send) {
-                    unsigned pj = order_s[cb + lane];
-                    sidx[lane] = pj;
-                    sx[lane] = pos_s[3 * (i64)pj];
-                    sy[lane] = pos_s[3 * (i64)pj + 1];
-                    sz[lane] = pos_s[3 * (i64)pj + 2];
+#pragma unroll
+                for (int h = 0; h < kSrStage / 64; h++) {
+                    const int e = lane + 64 * h;
+                    if (cb + e < send) {
+                        unsigned pj = order_s[cb + e];
+                        sidx[e] = pj;
+                        sx[e] = pos_s[3 * (i64)pj];
+                        sy[e] = pos_s[3 * (i64)pj + 1];
+                        sz[e] = pos_s[3 * (i64)pj + 2];
+                    } else {
+                        // entries past the chunk are read (and masked) by sr_pairs: keep them
+                        // finite, a masked pair contributes x*0
+                        sx[e] = sy[e] = sz[e] = 0;
+                    }
                 }
                 __syncthreads();
-                const int cnt = (int)min(64u, send - cb);
+                const int cnt = (int)min((unsigned)kSrStage, send - cb);
                 if (active) {
-                    // straight-line body (predicated, no early exits) so that the compiler
-                    // can overlap the LDS reads and FP64 chains of several partners
-#pragma unroll 4
-                    for (int k = sub; k < cnt; k += S) {
-                        double x_ji = xi - sx[k];               // interactions.py:1787-1789
-                        double y_ji = yi - sy[k];
-                        double z_ji = zi - sz[k];
-                        if (shifted) {                          // gravity.py:299-302 (uniform)
-                            x_ji += ox;
-                            y_ji += oy;
-                            z_ji += oz;
-                        }
-                        double r2 = x_ji * x_ji + y_ji * y_ji + z_ji * z_ji;  // gravity.py:306
-                        bool hit = !(r2 > P.r2_max) && !(P.same && sidx[k] == pi);
-                        if (hit) {
-                            int idx = (int)(r2 * P.r2_index_scaling);         // gravity.py:316 (< 4096: int)
-                            double total_factor = my_factor * table[idx];    // gravity.py:321
-                            ax += x_ji * total_factor;
-                            ay += y_ji * total_factor;
-                            az += z_ji * total_factor;
-                        }
+#define CG_SR_PAIRS(SH, SE)                                                                    \
+    sr_pairs<SH, SE>(sub, S, cnt, xi, yi, zi, ox, oy, oz, sx, sy, sz, sidx, pi, P.r2_max,      \
+                     P.r2_index_scaling, my_factor, table, ax, ay, az)
+                    if (shifted) {
+                        if (self) CG_SR_PAIRS(true, true);
+                        else CG_SR_PAIRS(true, false);
+                    } else {
+                        if (self) CG_SR_PAIRS(false, true);
+                        else CG_SR_PAIRS(false, false);
                     }
+#undef CG_SR_PAIRS
                 }
             }
         }
-        // fold the S partial sums of each receiver (lanes rl, rl + R, rl + 2R, ...)
-        for (int o = 32; o >= R; o >>= 1) {
-            ax += __shfl_down(ax, o);
-            ay += __shfl_down(ay, o);
-            az += __shfl_down(az, o);
+        // fold the S partial sums of each receiver (lanes rl, rl + R, rl + 2R, ...) into lane rl
+        {
+            double tx = ax, ty = ay, tz = az;
+            for (int g = 1; g < S; g++) {  // S is wave-uniform
+                const int src = (lane + g * R) & 63;
+                tx += __shfl(ax, src);
+                ty += __shfl(ay, src);
+                tz += __shfl(az, src);
+            }
+            ax = tx;
+            ay = ty;
+            az = tz;
         }
         if (active && sub == 0) {
             dmom_r[3 * (i64)pi] += ax;
