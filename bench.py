@@ -5,19 +5,30 @@
 
 One "step" = one full PM base step of the reference's time loop
 (main.py:335-358: drift -> long-range kick) on synthetic, HBM-resident
-particles: drift (A11) + tile sort, mesh zero + CIC deposit (A1/A2), rocFFT
-R2C (A4), k-space Poisson kernel (A5/A6), C2R (A8), fused finite-difference +
+particles: drift (A11) + tile sort, CIC deposit (A1/A2), forward FFT (A4),
+k-space Poisson kernel (A5/A6), inverse FFT (A8), fused finite-difference +
 CIC gather + kick (A9/A10).  Workload at N=1: BASELINE.json's metric
-configuration, 2^28 (~256M) particles on a 1024^3 mesh, FP64.
+configuration, 2^28 (~256M) particles on a 1024^3 mesh, FP64.  The particles
+carry thermal momenta (rms displacement 0.2 mesh cells per step), so the tile
+sort really reorders and, on N > 1 GPUs, particles really change domain.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant hand-written
-kernel, from HIP events on the stream the kernels run on; `cpu_baseline` is
-the C oracle (oracle/, a port of the reference's algorithm) timed on a
-bounded sample on this host's cores.
+--gpus N > 1: one process per GPU over RCCL.  Started either by an external
+launcher (torch.distributed.run: WORLD_SIZE/RANK/LOCAL_RANK in the
+environment) or, with WORLD_SIZE unset, by this script itself, which then
+re-executes under torch.distributed.run on 127.0.0.1.  With fewer visible GPUs
+than ranks the ranks share the GPUs and exchange through host memory (gloo): a
+functional run of the sharded path, flagged as such in the JSON line.
+
+Prints ONE JSON line (rank 0), the last line of stdout.  `roofline` is for the
+dominant hand-written kernel, from HIP events on the stream the kernels run
+on; `cpu_baseline` is the C oracle (oracle/, a port of the reference's
+algorithm) timed on a bounded sample on this host's cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +36,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+XGMI_LINK_GBS_DIR = 76.8     # one xGMI link, one direction (153.6 GB/s bidirectional; 7 links)
+PMC_FILE = 'profiles/r02_pmc_hbm_traffic.json'
 
 WORKLOADS = {
     # name: (particles, gridsize)
@@ -33,37 +46,63 @@ WORKLOADS = {
     'c2_256c_512': (256**3, 512),        # configs[1]
     'c1_128c_256': (128**3, 256),        # configs[0]
     'c3_1024c_2048': (1024**3, 2048),    # configs[3] (meant for 8 GPUs; fits one: ~175 GB)
+    'c4_512c_1024': (512**3, 1024),      # configs[4]'s particle part
     'tiny': (32**3, 64),
 }
 
 
-def algorithmic_bytes(n_p, n_g):
-    """SURVEY.md §8(d) per-phase algorithmic bytes (FP64), adjusted to what
-    this build's fused kernels must move at minimum (stated in DESIGN.md)."""
+def survey_bytes(n_p, n_g):
+    """algorithmic bytes of the reference's UNFUSED phases (what its table
+    credits a phase with).  Reported beside the real figures, never turned into a fraction of
+    peak for a single fused kernel."""
     return {
-        'zero': 8*n_g,
-        'deposit': 24*n_p + 8*n_g,               # read pos, write (accumulate) grid
-        'fft_forward': 48*n_g,                   # 3 passes x (read + write)
-        'kspace': 16*n_g,
-        'fft_backward': 48*n_g,
-        'poisson': 48*n_g + 16*n_g + 48*n_g,     # SURVEY.md §8(d): A4 + A5-A7 + A8
-        'sr_cells': 2*24*n_p + 8*n_p,            # pos read twice, order written
-        'sr_sweep': 24*n_p + 48*n_p,             # not HBM-bound: FP64/LDS pair arithmetic
-        'gather_kick': 24*n_p + 48*n_p + 8*n_g,  # pos, mom RMW, potential once (FD fused)
-        'drift': 48*n_p + 24*n_p,
-        'drift_sort': (48*n_p + 24*n_p) + (2*(48*n_p) + 24*n_p),  # drift row + sort row
-        'sort': 2*(48*n_p) + 24*n_p,             # histogram reads pos; scatter moves pos+mom
+        'deposit': 24*n_p + 8*n_g,
+        'poisson': 48*n_g + 16*n_g + 48*n_g,          # A4 + A5-A7 + A8
+        'fft_zy_forward_chunked': 32*n_g, 'fft_yz_backward_chunked': 32*n_g,
+        'fft_z_forward': 16*n_g, 'fft_y_forward': 16*n_g, 'fft_y_backward': 16*n_g,
+        'fft_z_backward': 16*n_g,
+        'fft_x_fused_kspace': 48*n_g,                 # x forward + k-space + x inverse
+        'gather_kick': 72*n_p + 24*n_g,               # row A10: three force grids
+        'drift': 72*n_p,
+        'drift_sort': 72*n_p + 120*n_p,               # drift row + a sort that re-reads pos
+        'sr_cells': 56*n_p, 'sr_sweep': 72*n_p,
     }
 
 
+def moved_bytes(n_p, n_g, with_ids=False):
+    """Bytes each kernel of THIS build must move between L2 and the memory fabric as designed
+     — the quantity rocprofv3's FETCH_SIZE + WRITE_SIZE measure and the one
+    every `frac` below is computed from."""
+    ids = 16*n_p if with_ids else 0
+    return {
+        'zero': 8*n_g,
+        'deposit': 24*n_p + 8*n_g,                    # read pos, write the mesh once
+        'poisson': 80*n_g,                            # five in-place passes
+        'fft_forward': 48*n_g, 'kspace': 16*n_g, 'fft_backward': 48*n_g,
+        'fft_zy_forward_chunked': 32*n_g, 'fft_yz_backward_chunked': 32*n_g,
+        'fft_z_forward': 16*n_g, 'fft_y_forward': 16*n_g, 'fft_y_backward': 16*n_g,
+        'fft_z_backward': 16*n_g,
+        'fft_x_fused_kspace': 16*n_g,                 # one read + one write of the mesh
+        'gather_kick': 72*n_p + 8*n_g,                # pos, mom RMW, the potential once
+        'drift': 72*n_p,
+        'drift_sort': 96*n_p + ids,                   # pos+mom read, pos+mom written (prepared
+                                                      # histogram: no separate counting pass)
+        'sort': 96*n_p + 24*n_p + ids,
+        'sr_cells': 2*24*n_p + 8*n_p,
+        'sr_sweep': 24*n_p + 48*n_p,                  # not HBM-bound: FP64 pair arithmetic
+    }
+
+
+# ---------------------------------------------------------------------------
+# CPU baseline (the oracle; test infrastructure used here only as the thing timed beside)
+# ---------------------------------------------------------------------------
 def cpu_baseline():
     """The oracle (a C port of the reference's algorithm) on bounded samples of the workload,
-    timed twice: with OpenMP over the particle and plane loops + scipy's threaded pocketfft
-    (the reference runs one MPI rank per core) at the best of a few thread counts, and on
-    one core with numpy's pocketfft (the reference's own pure-Python FFT).  The threaded
-    figure is the reported baseline.  Thread counts: on the 256-thread bench host 16-32
-    threads are fastest (9.6 M particle-updates/s; 128 threads: 5.3 M — the deposit's atomic
-    adds and the FFT do not scale further; tools/cpu_baseline_probe.py)."""
+    timed twice: with OpenMP over the particle and plane loops (slab-privatised deposit: no
+    atomics, like the reference's one-domain-per-core ranks) + scipy's threaded pocketfft at
+    the best of several thread counts up to all host threads, and on one core with numpy's
+    pocketfft (the reference's own pure-Python FFT).  The threaded figure is the reported
+    baseline."""
     import numpy as np
     from oracle import oracle
     oracle.build()
@@ -72,7 +111,7 @@ def cpu_baseline():
         n, L = sample_n**3, float(sample_grid)
         rng = np.random.default_rng(7)
         pos = rng.uniform(0, L, (n, 3))
-        mom = np.zeros((n, 3))
+        mom = rng.normal(0, 0.2/3**0.5*1e3, (n, 3))  # 0.2 cells rms per step, like the GPU run
         t0 = time.perf_counter()
         for _ in range(nsteps):
             oracle.drift(pos, mom, 1e-3, L, fast=fast)
@@ -87,13 +126,14 @@ def cpu_baseline():
         avail = os.cpu_count() or 1
     omp = oracle.lib('omp')
     trial = {}
-    for threads in sorted({min(avail, t) for t in (16, 32)}):
+    for threads in sorted({min(avail, t) for t in (16, 32, 64, 128, avail)}):
         omp.orc_threads(threads)
         run('omp', 128, 256, 1)  # thread pool, page faults
         trial[threads] = run('omp', 128, 256, 2)
     cores = min(trial, key=trial.get)
     omp.orc_threads(cores)
-    steps_all, steps_one = 8, 12
+    steps_all, steps_one = 8, 8
+    run('omp', 256, 512, 1)
     dt_all = run('omp', 256, 512, steps_all)
     dt_one = run(True, 128, 256, steps_one)
     flags = '-O3 -funroll-loops -ffast-math (reference src/Makefile flags)'
@@ -101,9 +141,10 @@ def cpu_baseline():
         'value': 256**3*steps_all/dt_all, 'unit': 'particle-updates/s', 'cores': cores,
         'kind': 'port', 'steps_per_sec': steps_all/dt_all,
         'sample': f'256^3 particles / 512^3 mesh (BASELINE configs[1] size), {steps_all} PM '
-                  f'steps, oracle C port built {flags} -fopenmp on {cores} of {avail} host '
-                  f'threads (fastest of {sorted(trial)}) + scipy.fft with {cores} workers, '
-                  f'{dt_all:.1f} s wall',
+                  f'steps, oracle C port built {flags} -fopenmp (slab-privatised deposit, no '
+                  f'atomics) on {cores} of {avail} host threads + scipy.fft with {cores} '
+                  f'workers, {dt_all:.1f} s wall',
+        'thread_trials_s_per_2_steps_128c_256': {str(k): round(v, 3) for k, v in trial.items()},
         'single_thread': {
             'value': 128**3*steps_one/dt_one, 'unit': 'particle-updates/s', 'cores': 1,
             'steps_per_sec': steps_one/dt_one,
@@ -112,7 +153,69 @@ def cpu_baseline():
     }
 
 
-def main_distributed(args, name, n_p, N, L, dev, rank, world):
+# ---------------------------------------------------------------------------
+# synthetic particles
+# ---------------------------------------------------------------------------
+def make_positions(torch, args, n_p, N, L, dev, gen):
+    pos = torch.rand((n_p, 3), dtype=torch.float64, device=dev, generator=gen)
+    if args.dist == 'uniform':
+        pos.mul_(L)
+    elif args.dist == 'lattice':
+        side = round(n_p**(1/3))
+        if side**3 != n_p:
+            sys.exit('--dist lattice needs a cubic particle count (e.g. --workload c2_256c_512)')
+        idx = torch.arange(n_p, device=dev)
+        lat = torch.stack([idx//(side*side), (idx//side) % side, idx % side], 1).double()
+        disp = torch.randn((n_p, 3), dtype=torch.float64, device=dev, generator=gen)*1.5*(L/N)
+        pos = torch.remainder((lat + 0.5)*(L/side) + disp, L)
+        del idx, lat, disp
+    else:  # clustered: 64 Gaussian blobs of sigma = L/40 holding 80 % of the particles
+        centres = torch.rand((64, 3), dtype=torch.float64, device=dev, generator=gen)*L
+        which = torch.randint(0, 64, (n_p,), device=dev, generator=gen)
+        blob = centres[which] + torch.randn((n_p, 3), dtype=torch.float64, device=dev,
+                                            generator=gen)*(L/40)
+        keep = torch.rand(n_p, dtype=torch.float64, device=dev, generator=gen) < 0.2
+        pos = torch.where(keep[:, None], pos*L, torch.remainder(blob, L))
+        del centres, which, blob, keep
+    top = float(torch.nextafter(torch.tensor(L, dtype=torch.float64),
+                                torch.tensor(0.0, dtype=torch.float64)))
+    pos.clamp_(min=0.0, max=top)
+    return pos
+
+
+def thermal_momenta(torch, args, shape, cell, mass, dt, dev, gen):
+    """Maxwellian momenta with a 3-D rms displacement of --thermal mesh cells per step."""
+    if args.thermal <= 0:
+        return torch.zeros(shape, dtype=torch.float64, device=dev)
+    sigma = args.thermal/3**0.5*cell*mass/dt
+    mom = torch.randn(shape, dtype=torch.float64, device=dev, generator=gen)
+    return mom.mul_(sigma)
+
+
+def pmc_traffic(dom_kernel, workload):
+    """HBM (L2 <-> fabric) bytes per launch of the dominant kernel from the committed PMC run of
+    this command (rocprofv3 --pmc needs its own process: it cannot be collected from inside the
+    bench).  None unless the file describes this workload and kernel."""
+    try:
+        pmc = json.load(open(os.path.join(REPO, PMC_FILE)))
+    except Exception:
+        return None, None
+    if pmc.get('workload_name') != workload:
+        return None, None
+    for kname, entry in pmc.get('kernels', {}).items():
+        if entry.get('bench_key') == dom_kernel:
+            return entry['total_GB']*1e9, (
+                f"{PMC_FILE}: kernel {kname}, collected at commit {pmc.get('commit', '?')} "
+                f"({pmc.get('date', '?')}) with `{pmc.get('command', '?')}`; rocprofv3 --pmc "
+                'FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections of '
+                'MI355X_MICROARCH.md')
+    return None, None
+
+
+# ---------------------------------------------------------------------------
+# N > 1: x-slab domains
+# ---------------------------------------------------------------------------
+def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
     """Strong scaling: the same total workload on `world` x-slab domains, one per GPU
     (concept_amd/distributed.py).  A step = drift + particle exchange + tile sort (fused:
     DistributedParticles.drift_exchange_sort) + long-range kick (deposit, ghost fold, FFT
@@ -131,11 +234,12 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world):
     pos[:, 1:] *= L
     pos.clamp_(min=0.0, max=float(torch.nextafter(torch.tensor(L, dtype=torch.float64),
                                                   torch.tensor(0.0, dtype=torch.float64))))
-    parts = DistributedParticles(dom, pos, torch.zeros_like(pos), None, slack=1.15)
-    del pos
+    mass, G, dt = 1.0, 1.0, 1e-4
+    mom = thermal_momenta(torch, args, pos.shape, cell, mass, dt, dev, gen)
+    parts = DistributedParticles(dom, pos, mom, None, slack=1.15)
+    del pos, mom
     parts.exchange()
     parts.tile_sort()
-    mass, G, dt = 1.0, 1.0, 1e-4
     contribution = mass*(float(N)**(-3)*(N/L)**3)
     C = -L**2*G/3.141592653589793
 
@@ -161,23 +265,26 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world):
 
     for _ in range(args.warmup):
         step()
+    parts.check()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
+    emig0 = parts.emigrants_total
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(record=True)
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
+    parts.check()
     # this rank's stage times (the exchanges wait for the slowest peer inside their stage)
     stages = {}
     for evs in stage_events:
-        for (_, a), (name, b) in zip(evs[:-1], evs[1:]):
-            stages[name] = stages.get(name, 0.0) + a.elapsed_time(b)/len(stage_events)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        for (_, a), (sname, b) in zip(evs[:-1], evs[1:]):
+            stages[sname] = stages.get(sname, 0.0) + a.elapsed_time(b)/len(stage_events)
+    red = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(red, op=dist.ReduceOp.MAX)
+    elapsed = float(red.item())
     # outside the timed region: what one whole FFT transpose costs on this transport by itself
     # (one all_to_all_single of the transpose buffer), for reading the stage times above
     probe = None
@@ -195,7 +302,7 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world):
         sent = dom.tbuf_a.numel()*8*(world - 1)/world
         probe = {'ms': round(ms, 3), 'bytes_sent_per_rank': int(sent),
                  'GBps_out_per_rank': round(sent/(ms*1e-3)/1e9, 1)}
-    cnt = torch.tensor([parts.n], dtype=torch.int64, device=dev)
+    cnt = torch.tensor([parts.n, parts.emigrants_total - emig0], dtype=torch.int64, device=dev)
     dist.all_reduce(cnt)
     # RCCL prints its version banner through C stdio; push it out (and shut the communicator
     # down) before the result so that the JSON line is the last line of stdout
@@ -204,21 +311,80 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world):
     ctypes.CDLL(None).fflush(None)
     if rank != 0:
         return
-    total = int(cnt.item())
+    total, emigrants = int(cnt[0].item()), int(cnt[1].item())
+    n_pl, n_gl = total/world, N**3/world
+    mv = moved_bytes(n_pl, n_gl)
+    # local kernels of rank 0: the gather-kick stage is one launch (+ the ghost fill messages)
+    gk_ms = stages.get('ghost_fill+gather_kick', 0.0)
+    gk_rate = mv['gather_kick']/(gk_ms*1e-3)/1e9 if gk_ms else 0.0
+    # transport: each transpose sends (P-1)/P of the local slab's transform, one peer per link
+    tr_bytes = dom.tbuf_a.numel()*8*(world - 1)/world if world > 1 else 0
+    ps_ms = stages.get('poisson+transposes', 0.0)
+    link_peak = min(world - 1, 7)*XGMI_LINK_GBS_DIR
+    transport = None
+    if world > 1:
+        transport = {
+            'bound': 'xgmi', 'unit': 'GB/s',
+            'bytes_out_per_rank_per_transpose': int(tr_bytes), 'transposes_per_step': 2,
+            'stage_ms': round(ps_ms, 3),
+            'achieved': round(2*tr_bytes/(ps_ms*1e-3)/1e9, 1) if ps_ms else None,
+            'peak': round(link_peak, 1),
+            'frac': round(2*tr_bytes/(ps_ms*1e-3)/1e9/link_peak, 4) if ps_ms else None,
+            'note': ('achieved = bytes one rank sends in the two FFT transposes / its whole '
+                     'poisson+transposes stage (z/y/x transforms run under the links); peak = '
+                     f'{min(world - 1, 7)} xGMI links x {XGMI_LINK_GBS_DIR} GB/s one way'
+                     + ('' if backend == 'nccl' else
+                        '; THIS RUN staged the messages through host memory (gloo): the '
+                        'fraction says nothing about xGMI'))}
     print(json.dumps({
         'metric': 'PM particle-updates/sec', 'value': total*args.steps/elapsed,
         'unit': 'particle-updates/s', 'steps_per_sec': args.steps/elapsed, 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed/args.steps*1e3,
+        'timed_region_s': round(elapsed, 4),
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
         'data': 'synthetic',
-        'config': {'workload': f'{name}: {total} particles (uniform random) / {N}^3 PM mesh, '
-                               f'CIC, deconvolution order 4, FD order 2, {world} x-slab domains; '
+        'config': {'workload': f'{name}: {total} particles (uniform random, thermal rms '
+                               f'displacement {args.thermal} cells/step) / {N}^3 PM mesh, CIC, '
+                               f'deconvolution order 4, FD order 2, {world} x-slab domains; '
                                '1 PM step = drift + exchange + tile sort + long-range kick',
-                   'particles': total, 'gridsize': N, 'parallelism': f'xslab{world}'},
-        'roofline': None, 'cpu_baseline': None,
+                   'particles': total, 'gridsize': N, 'parallelism': f'xslab{world}',
+                   'backend': ('rccl' if backend == 'nccl' else
+                               f'{backend} (ranks share GPUs, host-staged messages: a functional '
+                               'run of the sharded path, not a rate to quote)')},
+        'emigrants_per_step': emigrants/args.steps,
+        'emigrant_fraction_per_step': emigrants/args.steps/max(total, 1),
+        'roofline': {'bound': 'hbm', 'kernel': 'gather_kick (rank 0, incl. ghost fill messages)',
+                     'achieved': round(gk_rate, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(gk_rate/HBM_PEAK_GBS, 4), 'traffic': None,
+                     'algorithmic_bytes': int(mv['gather_kick']), 'kernel_ms': round(gk_ms, 4)},
+        'transport': transport, 'cpu_baseline': None,
         'stages_ms_rank0': {k: round(v, 3) for k, v in stages.items()},
         'transpose_probe_rank0': probe,
     }))
+
+
+# ---------------------------------------------------------------------------
+# self-spawn
+# ---------------------------------------------------------------------------
+def spawn_ranks(args):
+    """--gpus N with no launcher environment: start the N ranks under torch.distributed.run
+    (one per GPU, rendezvous on 127.0.0.1) and pass their output through; rank 0's JSON line is
+    the last line of stdout."""
+    import torch
+    ngpu = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if ngpu < args.gpus:
+        env['CONCEPT_BENCH_BACKEND'] = 'gloo'
+        print(f'[bench] {args.gpus} ranks on {ngpu} visible GPU(s): ranks share GPUs and '
+              'exchange through host memory (gloo)', file=sys.stderr, flush=True)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1', '--master-port',
+           str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -233,6 +399,9 @@ def main():
     ap.add_argument('--dist', default='uniform', choices=['uniform', 'lattice', 'clustered'],
                     help="particle distribution (SURVEY.md §8d): uniform random (U), displaced "
                          "lattice (Z: rms displacement 1.5 cells), or Gaussian blobs")
+    ap.add_argument('--thermal', type=float, default=0.2,
+                    help='rms displacement per step, in mesh cells, of the Maxwellian momenta '
+                         'the particles start with (0: particles at rest)')
     ap.add_argument('--p3m', action='store_true',
                     help='P3M step (BASELINE configs[2]): long-range mesh with Gaussian cut-off + '
                          'short-range tile sweep (r_s = 1.25 cells, range 4.5 r_s, spline '
@@ -243,6 +412,9 @@ def main():
                     help='direct (untiled) kernels on unsorted particles, for A/B')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -250,11 +422,14 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
-    # CONCEPT_BENCH_BACKEND=gloo: ranks share cuda:0 and exchange through host memory —
-    # only to exercise the multi-rank code path on a 1-GPU box, never a reported number
+    # CONCEPT_BENCH_BACKEND=gloo: ranks share the visible GPUs and exchange through host
+    # memory — exercises the multi-rank code path on a 1-GPU box, never a reported rate
     backend = os.environ.get('CONCEPT_BENCH_BACKEND', 'nccl')
+    ngpu = torch.cuda.device_count()
+    if backend == 'nccl' and world > ngpu:
+        backend = 'gloo'
     if backend != 'nccl':
-        local_rank = 0
+        local_rank = local_rank % max(ngpu, 1)
     torch.cuda.set_device(local_rank)
     # CONCEPT_BENCH_FORCE_DIST=1: run the sharded code path (RCCL init, collectives) with a
     # single domain too — a smoke test of the N>1 path on a 1-GPU box
@@ -275,38 +450,17 @@ def main():
     L = float(N)  # boxsize in grid units (synthetic)
     dev = torch.device('cuda', local_rank)
     if world > 1 or force_dist:
-        return main_distributed(args, name, n_p, N, L, dev, rank, world)
+        return main_distributed(args, name, n_p, N, L, dev, rank, world, backend)
     mesh = PotentialMesh(N, L, nghosts=2)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
-    pos = torch.rand((n_p, 3), dtype=torch.float64, device=dev, generator=gen)
-    if args.dist == 'uniform':
-        pos.mul_(L)
-    elif args.dist == 'lattice':
-        side = round(n_p**(1/3))
-        if side**3 != n_p:
-            sys.exit('--dist lattice needs a cubic particle count (e.g. --workload c2_256c_512)')
-        idx = torch.arange(n_p, device=dev)
-        lat = torch.stack([idx//(side*side), (idx//side) % side, idx % side], 1).double()
-        disp = torch.randn((n_p, 3), dtype=torch.float64, device=dev, generator=gen)*1.5*(L/N)
-        pos = torch.remainder((lat + 0.5)*(L/side) + disp, L)
-        del idx, lat, disp
-    else:  # clustered: 64 Gaussian blobs of sigma = L/40 holding 80 % of the particles
-        centres = torch.rand((64, 3), dtype=torch.float64, device=dev, generator=gen)*L
-        which = torch.randint(0, 64, (n_p,), device=dev, generator=gen)
-        blob = centres[which] + torch.randn((n_p, 3), dtype=torch.float64, device=dev,
-                                            generator=gen)*(L/40)
-        keep = torch.rand(n_p, dtype=torch.float64, device=dev, generator=gen) < 0.2
-        pos = torch.where(keep[:, None], pos*L, torch.remainder(blob, L))
-        del centres, which, blob, keep
-    pos.clamp_(min=0.0, max=float(torch.nextafter(torch.tensor(L, dtype=torch.float64),
-                                                  torch.tensor(0.0, dtype=torch.float64))))
-    mom = torch.zeros_like(pos)
-    pos2, mom2 = torch.empty_like(pos), torch.empty_like(mom)
-    table = mesh.new_tile_table()
+    pos = make_positions(torch, args, n_p, N, L, dev, gen)
     # step scalars: fixed (enable_Hubble=False semantics)
     mass = 1.0
     G = 1.0
     dt = 1e-4
+    mom = thermal_momenta(torch, args, pos.shape, L/N, mass, dt, dev, gen)
+    pos2, mom2 = torch.empty_like(pos), torch.empty_like(mom)
+    table = mesh.new_tile_table()
     contribution = (dt/dt)*mass*(float(N)**(-3)*(N/L)**3)
     C = -L**2*G/3.141592653589793
     kick_factor = mass*(-dt)
@@ -381,12 +535,12 @@ def main():
             mesh.gather_kick(pos, mom, order, kick_factor)
         mark()
         if sr:
-            dmom.zero_()
             cells = mesh.shortrange_build(pos, sr['nt'], L/sr['nt'])
             mark()
-            mesh.shortrange_sweep(pos, cells, dmom, pos, cells, sr['nt'], True, sr['table'],
+            # kick_short (main.py:1173-1262): nullify Δmom, sweep, apply — the apply is fused
+            # into the sweep's store when the target is the momentum array itself
+            mesh.shortrange_sweep(pos, cells, mom, pos, cells, sr['nt'], True, sr['table'],
                                   sr['scaling'], sr['r2_max'], sr['factor'])
-            mom.add_(dmom)
             mark()
         if record:
             events.append(ev)
@@ -394,129 +548,116 @@ def main():
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    mesh.check_errors()
 
-    if rank != 0:
-        return
     n_g = N**3
-    alg = algorithmic_bytes(n_p, n_g)
+    mv, sv = moved_bytes(n_p, n_g), survey_bytes(n_p, n_g)
     phase_ms = {ph: 0.0 for ph in PHASES}
     for ev in events:
         for k, ph in enumerate(PHASES):
             phase_ms[ph] += ev[k].elapsed_time(ev[k + 1])
     for ph in PHASES:
         phase_ms[ph] /= len(events)
-    phases = {}
-    for ph in PHASES:
-        gbs = alg[ph]/(phase_ms[ph]*1e-3)/1e9 if phase_ms[ph] > 0 else 0.0
-        phases[ph] = {'ms': round(phase_ms[ph], 4), 'alg_GB': round(alg[ph]/1e9, 3),
-                      'GBps': round(gbs, 1), 'frac_hbm': round(gbs/HBM_PEAK_GBS, 4)}
+
+    def entry(key, ms):
+        gbs = mv[key]/(ms*1e-3)/1e9 if ms > 0 else 0.0
+        e = {'ms': round(ms, 4), 'moved_GB': round(mv[key]/1e9, 3), 'GBps': round(gbs, 1),
+             'frac_hbm': round(gbs/HBM_PEAK_GBS, 4)}
+        if key in sv and sv[key] != mv[key]:
+            e['survey_8d_GB'] = round(sv[key]/1e9, 3)  # the unfused reference phases' bytes
+        return e
+    phases = {ph: entry(ph, phase_ms[ph]) for ph in PHASES}
     # single kernels: the phases that are one launch, plus the five FFT passes timed by
     # HIP events inside the library (a few extra solves after the timed region)
-    kernels = {ph: (alg[ph], phase_ms[ph]) for ph in ('deposit', 'gather_kick', 'drift')
+    kernels = {ph: phase_ms[ph] for ph in ('deposit', 'gather_kick', 'drift', 'sr_sweep')
                if ph in phase_ms}  # (drift_sort is two kernels + a scan: reported under phases)
     if not args.split_poisson:
         pass_ms = [0.0]*5
         reps = 3
+        lr, E = (True, sr['E']) if sr else (False, 0.0)
         for _ in range(reps):
-            for k, v in enumerate(mesh.poisson_solve_timed(4, C, False, 0.0)):
+            for k, v in enumerate(mesh.poisson_solve_timed(4, C, lr, E)):
                 pass_ms[k] += v/reps
-        # SURVEY.md §8(d) accounting: forward 48*N_g (3 passes), k-space 16*N_g, inverse
-        # 48*N_g.  The fused x pass stands for the forward x pass + the k-space kernel +
-        # the inverse x pass (16 + 16 + 16); the five entries sum to the 112*N_g of the row.
-        names, bytes_ = (('fft_z_forward', 'fft_y_forward', 'fft_x_fused_kspace',
-                          'fft_y_backward', 'fft_z_backward'), (16, 16, 48, 16, 16))
+        names = ('fft_z_forward', 'fft_y_forward', 'fft_x_fused_kspace', 'fft_y_backward',
+                 'fft_z_backward')
         if pass_ms[1] < 0.05*pass_ms[0]:
             # the z and y passes run interleaved over cache-sized chunks of layers (cg_fft.hip):
             # they are timed together; the second pass of a chunk is served by the infinity
-            # cache, which is how the pair exceeds the HBM rate an isolated pass can reach
-            names, bytes_ = (('fft_zy_forward_chunked', 'fft_x_fused_kspace',
-                              'fft_yz_backward_chunked'), (32, 48, 32))
+            # cache (its bytes still cross L2 <-> fabric, which is what `moved` counts)
+            names = ('fft_zy_forward_chunked', 'fft_x_fused_kspace', 'fft_yz_backward_chunked')
             pass_ms = [pass_ms[0] + pass_ms[1], pass_ms[2], pass_ms[3] + pass_ms[4]]
-        for nm, v, b in zip(names, pass_ms, bytes_):
-            kernels[nm] = (b*n_g, v)
-    dom = max(kernels, key=lambda k: kernels[k][1])
-    ach = kernels[dom][0]/(kernels[dom][1]*1e-3)/1e9
-    traffic = None
-    try:  # HBM bytes per launch from the committed PMC run of this same command
-        pmc = json.load(open(os.path.join(REPO, 'profiles', 'r01_pmc_hbm_traffic.json')))
-        key = {'fft_x_fused_kspace': 'k_fft_strided_p<10,512,2,8>',
-               'gather_kick': 'k_gather_kick_tiled<2,16,true>', 'drift': 'k_drift',
-               'deposit': 'k_deposit_cic_pull<16,false>',
-               'fft_y_forward': 'k_fft_strided_p<10,512,0,8>',
-               'fft_y_backward': 'k_fft_strided_p<10,512,1,8>',
-               'fft_zy_forward_chunked': None, 'fft_yz_backward_chunked': None,
-               'fft_z_forward': 'k_fft_z_forward<10,128>',
-               'fft_z_backward': 'k_fft_z_backward<10,128>'}.get(dom)
-        if name == 'ns_256M_1024' and key:
-            traffic = pmc['kernels'][key]['total_GB']*1e9
-    except Exception:
-        traffic = None
-    groups = {
-        'deposit+interp': (alg['deposit'] + alg['gather_kick'],
-                           phase_ms['deposit'] + phase_ms['gather_kick']),
-        'poisson_solve': (alg['poisson'], sum(phase_ms[ph] for ph in poisson)),
-    }
+        for nm, v in zip(names, pass_ms):
+            kernels[nm] = v
+    dom = max(kernels, key=lambda k: kernels[k])
     ms_per_step = elapsed/args.steps*1e3
     result = {
         'metric': ('P3M' if args.p3m else 'PM') + ' particle-updates/sec',
-        'value': n_p*world*args.steps/elapsed,
+        'value': n_p*args.steps/elapsed,
         'unit': 'particle-updates/s', 'steps_per_sec': args.steps/elapsed,
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong',
+        'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_per_step, 'timed_region_s': round(elapsed, 4),
+        'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': f'{name}: {n_p} particles ({args.dist}, seed 1) / {N}^3 PM mesh, '
-                               'CIC, deconvolution order 4, FD order 2, 1 PM step = drift + '
-                               'tile sort + long-range kick', 'particles': n_p, 'gridsize': N,
-                   'parallelism': f'domains{world}'},
-        'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1),
-                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach/HBM_PEAK_GBS, 4),
-                     'traffic': traffic, 'algorithmic_bytes': kernels[dom][0],
-                     'kernel_ms': round(kernels[dom][1], 4),
-                     'hbm_rate_GBps': (round(traffic/(kernels[dom][1]*1e-3)/1e9, 1)
-                                       if traffic else None),
-                     'note': ('algorithmic bytes follow SURVEY.md §8(d); for the fused x pass '
-                              'they are those of the three reference passes it replaces '
-                              '(x forward + k-space + x inverse = 48*N_g), its measured HBM '
-                              'traffic is one read + one write of the mesh'
-                              if dom == 'fft_x_fused_kspace' else
-                              'algorithmic bytes are the fused kernel\'s minimum (DESIGN.md §4): '
-                              'pos + mom read-modify-write + the potential once = 72*N_p + 8*N_g; '
-                              'SURVEY.md §8(d) row A10 counts three force grids (72*N_p + '
-                              '24*N_g), see unfused_accounting'
-                              if dom == 'gather_kick' else
-                              'algorithmic bytes follow SURVEY.md §8(d) / DESIGN.md §4'),
-                     'traffic_source': 'profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc '
-                                       'FETCH_SIZE / WRITE_SIZE, separate passes)'},
-        'kernels': {k: {'alg_GB': round(b/1e9, 3), 'ms': round(ms, 4),
-                        'GBps': round(b/(ms*1e-3)/1e9, 1),
-                        'frac_hbm': round(b/(ms*1e-3)/1e9/HBM_PEAK_GBS, 4)}
-                    for k, (b, ms) in kernels.items()},
-        'roofline_groups': {k: {'alg_GB': round(b/1e9, 2), 'ms': round(ms, 3),
-                                'GBps': round(b/(ms*1e-3)/1e9, 1),
-                                'frac': round(b/(ms*1e-3)/1e9/HBM_PEAK_GBS, 4)}
-                            for k, (b, ms) in groups.items()},
-        'phases': phases,
+        'config': {'workload': f'{name}: {n_p} particles ({args.dist}, seed 1, thermal rms '
+                               f'displacement {args.thermal} cells/step) / {N}^3 PM mesh, CIC, '
+                               f'deconvolution order 4, FD order {4 if sr else 2}, 1 '
+                               + ('P3M step = drift + tile sort + long-range kick + short-range '
+                                  'kick (r_s 1.25 cells, range 4.5 r_s)' if sr else
+                                  'PM step = drift + tile sort + long-range kick'),
+                   'particles': n_p, 'gridsize': N, 'parallelism': 'domains1'},
+        'emigrants_per_step': 0,
     }
-    if dom == 'gather_kick':
-        # the same launch priced with SURVEY.md §8(d)'s own A10 row (three force grids read)
-        b = 72*n_p + 24*n_g
-        a = b/(kernels[dom][1]*1e-3)/1e9
-        result['roofline']['unfused_accounting'] = {
-            'algorithmic_bytes': b, 'achieved': round(a, 1), 'frac': round(a/HBM_PEAK_GBS, 4)}
+    if dom == 'sr_sweep':
+        # FP64 VALU-bound: pair tests/s against the FP64 vector issue rate
+        npt = n_p/sr['nt']**3
+        tests = n_p*27*npt
+        ms = kernels[dom]
+        # 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2.4 GHz = one FP64 VALU op per lane-slot
+        valu_peak = 256*4*16*2.4e9
+        per_test = 14  # FP64 VALU instructions of a pair test that misses (3 sub, [3 add], 3 mul,
+        #                2 add, 1 cmp + the select/accumulate 3 fma-free mul-adds = 6): DESIGN §7
+        result['roofline'] = {
+            'bound': 'valu_fp64', 'kernel': dom, 'unit': 'pair-tests/s',
+            'achieved': round(tests/(ms*1e-3), 1), 'peak': round(valu_peak/per_test, 1),
+            'frac': round(tests/(ms*1e-3)/(valu_peak/per_test), 4), 'traffic': None,
+            'kernel_ms': round(ms, 4), 'pair_tests_per_launch': int(tests),
+            'note': ('the sweep is not HBM-bound (72 B per particle against ~600 pair tests); '
+                     f'peak = FP64 vector issue rate {valu_peak:.3g} lane-ops/s / {per_test} '
+                     'FP64 VALU instructions per pair test')}
+    else:
+        ach = mv[dom]/(kernels[dom]*1e-3)/1e9
+        traffic, traffic_source = pmc_traffic(dom, name)
+        result['roofline'] = {
+            'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': round(ach/HBM_PEAK_GBS, 4), 'traffic': traffic,
+            'algorithmic_bytes': mv[dom], 'kernel_ms': round(kernels[dom], 4),
+            'hbm_rate_GBps': (round(traffic/(kernels[dom]*1e-3)/1e9, 1) if traffic else None),
+            'survey_8d_bytes': sv.get(dom),
+            'note': ('algorithmic bytes = what this fused kernel must move (DESIGN.md §4); '
+                     'survey_8d_bytes = SURVEY.md §8(d)\'s figure for the unfused reference '
+                     'phases it replaces, given for comparison only'),
+            'traffic_source': traffic_source}
+    result['kernels'] = {k: entry(k, ms) for k, ms in kernels.items()}
+    groups = {'deposit+interp': (['deposit', 'gather_kick'],
+                                 phase_ms['deposit'] + phase_ms['gather_kick']),
+              'poisson_solve': (['poisson'] if not args.split_poisson else
+                                ['fft_forward', 'kspace', 'fft_backward'],
+                                sum(phase_ms[ph] for ph in poisson))}
+    result['roofline_groups'] = {}
+    for gname, (keys, ms) in groups.items():
+        moved = sum(mv[k] for k in keys)
+        credit = (sv['deposit'] + sv['gather_kick']) if gname == 'deposit+interp' else sv['poisson']
+        result['roofline_groups'][gname] = {
+            'ms': round(ms, 3), 'moved_GB': round(moved/1e9, 2),
+            'frac_moved': round(moved/(ms*1e-3)/1e9/HBM_PEAK_GBS, 4),
+            'survey_8d_GB': round(credit/1e9, 2),
+            'frac_survey_8d': round(credit/(ms*1e-3)/1e9/HBM_PEAK_GBS, 4)}
+    result['phases'] = phases
     if not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline()
     print(json.dumps(result))

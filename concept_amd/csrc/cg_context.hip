@@ -115,6 +115,13 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
              (long long)p->gridsize);
     CG_CHECK(p->nprocs == 1 || cgk_fft_supported(p->gridsize),
              "cg_create: the multi-GPU FFT needs a power-of-two grid size (16..2048)");
+    // the potential halo is filled from the neighbour's OWNED layers in one hop
+    // (communicate_ghosts(grid,'='), communication.py:563-660): a slab thinner than the G = 3
+    // halo layers would hand on its own ghost layers
+    CG_CHECK(p->nprocs == 1 || p->gridsize / p->nprocs >= 3,
+             "cg_create: %d domains leave slabs of %lld layers, thinner than the 3 halo layers "
+             "(use fewer domains or a larger grid)", p->nprocs,
+             (long long)(p->gridsize / p->nprocs));
     CG_HIP(hipSetDevice(p->device));
     if (!g_rocfft_ready) {
         CG_FFT(rocfft_setup());
@@ -188,6 +195,11 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
             return fail();
         }
         c->device_bytes += 8 * (8 * c->ntiles + 1);
+        if (hipMalloc(&c->err_flags, 4) != hipSuccess ||
+            hipMemset(c->err_flags, 0, 4) != hipSuccess) {
+            cg_set_error("cg_create: error word allocation failed");
+            return fail();
+        }
     }
     // FFT backend: the hand-written passes for power-of-two grids, rocFFT otherwise
     // (CONCEPT_GPU_FFT=rocfft forces the library, for A/B measurements)
@@ -231,6 +243,7 @@ extern "C" int cg_destroy(cg_ctx *c) {
     (void)hipFree(c->ktab_q);
     (void)hipFree(c->tile_count);
     (void)hipFree(c->tile_cursor);
+    (void)hipFree(c->err_flags);
     (void)hipFree(c->scan_tmp);
     (void)hipFree(c->sr_tmp);
     delete c;
@@ -250,6 +263,20 @@ extern "C" int cg_synchronize(cg_ctx *c) {
 }
 
 extern "C" int64_t cg_device_bytes(const cg_ctx *c) { return c ? c->device_bytes : 0; }
+
+extern "C" int cg_error_flags(cg_ctx *c, uint32_t *flags_out) {
+    CG_CHECK(c && flags_out, "cg_error_flags: null argument");
+    CG_HIP(hipMemcpyAsync(flags_out, c->err_flags, 4, hipMemcpyDeviceToHost, c->stream));
+    CG_HIP(hipMemsetAsync(c->err_flags, 0, 4, c->stream));
+    CG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int cg_prepare_invalidate(cg_ctx *c) {
+    CG_CHECK(c, "cg_prepare_invalidate: null context");
+    c->prep_valid = false;
+    return 0;
+}
 
 extern "C" int cg_mesh_zero(cg_ctx *c) {
     CG_CHECK(c, "cg_mesh_zero: null context");
@@ -334,6 +361,7 @@ extern "C" int cg_gather_scalar(cg_ctx *c, const double *pos, double *mom, int64
     CG_CHECK(dim >= 0 && dim < 3,
              "apply_particle_mesh_force() called with dim = %d not in {0, 1, 2}", dim);
     double cellsize = c->p.boxsize / (double)c->p.gridsize;  // mesh.py:408 (one domain)
+    c->prep_valid = false;
     return cgk_gather_scalar(c, pos, mom, n, dim, order,
                              make_geom_shift(cellsize, c->p.nghosts, c->p.cell_centered, shift, +1),
                              factor);
@@ -468,6 +496,7 @@ extern "C" int cg_gather_kick(cg_ctx *c, const double *pos, double *mom, int64_t
              "cg_gather_kick: differentiation order %d needs nghosts >= %d (commons.py:4411-4432)",
              diff_order, (diff_order + 1) / 2);
     if (n == 0) return 0;
+    c->prep_valid = false;
     return cgk_gather_kick(c, pos, mom, n, diff_order, factor);
 }
 
@@ -641,6 +670,7 @@ extern "C" int cg_dmom_nullify(cg_ctx *c, double *dmom, const int8_t *rung, int6
 extern "C" int cg_dmom_apply(cg_ctx *c, double *mom, const double *dmom, const int8_t *rung,
                              int64_t n, int lowest_active_rung) {
     CG_CHECK(c && ((mom && dmom) || n == 0), "cg_dmom_apply: null argument");
+    c->prep_valid = false;  // mom changes: a prepared drift histogram no longer describes it
     return cgk_dmom_active(c, mom, (double *)dmom, (const signed char *)rung, n,
                            lowest_active_rung, 1);
 }

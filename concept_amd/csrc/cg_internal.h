@@ -129,6 +129,8 @@ struct cg_ctx {
     i64 *emig_idx = nullptr;
     unsigned *emig_count = nullptr;
     i64 emig_cap = 0;
+    // device word of sticky error bits set by kernels (CG_ERR_*), read by cg_error_flags
+    unsigned *err_flags = nullptr;
     i64 device_bytes = 0;
 };
 

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void k_tile_scatter(
     const double *__restrict__ pos, const double *__restrict__ mom, const i64 *__restrict__ ids,
     double *__restrict__ pos_out, double *__restrict__ mom_out, i64 *__restrict__ ids_out, i64 n,
     double dtm, double L, CicGeom geo, int g, i64 N, TileGeom t, i64 x0,
-    const unsigned *__restrict__ offset, unsigned *__restrict__ cursor) {
+    const unsigned *__restrict__ offset, unsigned *__restrict__ cursor,
+    unsigned *__restrict__ err_flags) {
     i64 stride = (i64)gridDim.x * blockDim.x;
     int lane = threadIdx.x & 63;
     for (i64 base = (i64)blockIdx.x * blockDim.x; base < n; base += stride) {
@@ -143,11 +144,25 @@ __global__ __launch_bounds__(256) void k_tile_scatter(
         int rs, rl;
         wave_runs(key, lane, rs, rl);
         unsigned first = 0;
-        if (lane == rs && key != kNoTile) first = offset[key] + atomicAdd(&cursor[key], (unsigned)rl);
+        if (lane == rs && key != kNoTile) {
+            // A run that does not fit its bucket means the histogram was not made from these
+            // positions and momenta (a prepared histogram gone stale: something changed mom
+            // between cg_gather_kick_tiled_prepare and this sort).  Equal totals with unequal
+            // buckets always overflow one of them, so this check is complete; the run is
+            // dropped (never stored outside its bucket) and the context's error word is set
+            // (cg_error_flags).
+            const unsigned o0 = offset[key], room = offset[key + 1] - o0;
+            const unsigned local = atomicAdd(&cursor[key], (unsigned)rl);
+            first = o0 + local;
+            if (local + (unsigned)rl > room) {
+                atomicOr(err_flags, (unsigned)CG_ERR_STALE_HISTOGRAM);
+                first = kNoTile;
+            }
+        }
         first = __shfl(first, rs);
         // particles of other domains (kNoTile) are dropped: the host exchanges them before
         // sorting; table[last] = number kept
-        const bool valid = p < n && key != kNoTile;
+        const bool valid = p < n && key != kNoTile && first != kNoTile;
         store_run(pos_out, (i64)first, rs, rl, lane, valid, x, y, z);
         store_run(mom_out, (i64)first, rs, rl, lane, valid, mx, my, mz);
         if (valid && ids) ids_out[(i64)first + (lane - rs)] = ids[p];
@@ -244,12 +259,13 @@ int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *i
             hipLaunchKernelGGL(k_tile_scatter<true>, dim3((unsigned)blocks), dim3(256), 0,
                                c->stream, pos_in, mom_in, ids_in, pos_out, mom_out, ids_out, n,
                                dt_over_mass, c->p.boxsize, c->geom_deposit, c->p.nghosts, c->N,
-                               c->tiles, c->xmap.x0, tile_offset_out, c->tile_cursor);
+                               c->tiles, c->xmap.x0, tile_offset_out, c->tile_cursor,
+                               c->err_flags);
         else
             hipLaunchKernelGGL(k_tile_scatter<false>, dim3((unsigned)blocks), dim3(256), 0,
                                c->stream, pos_in, mom_in, ids_in, pos_out, mom_out, ids_out, n,
                                0.0, c->p.boxsize, c->geom_deposit, c->p.nghosts, c->N, c->tiles,
-                               c->xmap.x0, tile_offset_out, c->tile_cursor);
+                               c->xmap.x0, tile_offset_out, c->tile_cursor, c->err_flags);
         CG_LAUNCH_CHECK();
     }
     return 0;

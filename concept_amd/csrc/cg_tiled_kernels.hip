@@ -379,13 +379,15 @@ static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsign
     size_t lds = sizeof(double) * E * E * E;
     auto kern = k_gather_kick_tiled<ORDER, T, false>;
     auto kern_prep = k_gather_kick_tiled<ORDER, T, true>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
+    // the attribute belongs to the function ON A DEVICE: once per device of this process
+    static bool attr_set[64] = {};
+    const int dev = c->p.device & 63;
+    if (!attr_set[dev] && lds > 64 * 1024) {
         CG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
         CG_HIP(hipFuncSetAttribute((const void *)kern_prep,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     unsigned nt = (unsigned)c->ntiles;
     if (prep)

@@ -266,6 +266,17 @@ class DistributedParticles:
         self.emig_idx = torch.empty(max(4096, cap//16), dtype=torch.int64, device=dev)
         self.emig_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self._emig_for = None  # (pos pointer, n, dt_over_mass) the list was made for
+        self.emigrants_total = 0  # rows this rank has shipped so far (all exchanges)
+
+    def check(self):
+        """Raise if a kernel recorded an inconsistency since the last call (synchronises)."""
+        self.domain.mesh.check_errors()
+
+    def touch_mom(self):
+        """Call after changing `mom` by anything but pm_kick: the drift histogram and the
+        emigrant list the last kick prepared no longer describe the particles."""
+        self._emig_for = None
+        self.domain.mesh.prepare_invalidate()
 
     def view(self, name):
         return getattr(self, name)[:self.n]
@@ -305,6 +316,7 @@ class DistributedParticles:
         owner = m.owner_rank_drifted(pos, mom, dt_over_mass) if move is None else None
         n_new, inc = exchange_rows_compact(d.comm, owner, self.pos, self.mom, self.ids, self.n,
                                            self.cap, move=move)
+        self.emigrants_total += d.comm.last_sent
         self.n = n_new
         pos, mom = self.view('pos'), self.view('mom')
         if inc is not None and inc.shape[0]:
@@ -409,6 +421,7 @@ def exchange_rows_compact(comm, owner, pos, mom, ids, n, cap, move=None):
     counts = comm.all_gather_ints(send_counts)  # counts[src][dst]
     recv_counts = counts[:, rank].tolist()
     m_in, m_out = int(sum(recv_counts)), int(move_idx.numel())
+    comm.last_sent = m_out
     inc = torch.empty((m_in, 7), dtype=torch.float64, device=dev)
     comm.all_to_all(inc, rows, recv_counts, send_counts)
     k = min(m_in, m_out)

@@ -39,6 +39,7 @@ class cg_params(ctypes.Structure):
 
 CG_FETCH_MESH_REAL = 0
 CG_FETCH_MESH_FOURIER = 1
+CG_ERR_STALE_HISTOGRAM = 1
 
 _vp, _i64, _dbl, _int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int
 
@@ -51,6 +52,8 @@ SYMBOLS = {
     'cg_set_stream': (_int, [_vp, _vp]),
     'cg_synchronize': (_int, [_vp]),
     'cg_device_bytes': (_i64, [_vp]),
+    'cg_error_flags': (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
+    'cg_prepare_invalidate': (_int, [_vp]),
     'cg_mesh_zero': (_int, [_vp]),
     'cg_deposit_cic': (_int, [_vp, _vp, _i64, _dbl]),
     'cg_deposit_cic_tiled': (_int, [_vp, _vp, _i64, _vp, _dbl, _int]),

@@ -76,6 +76,24 @@ class PotentialMesh:
     def device_bytes(self):
         return int(_L.cg_device_bytes(self._ctx))
 
+    def error_flags(self):
+        """Sticky error bits set by kernels since the last call (synchronises; clears)."""
+        flags = ctypes.c_uint32(0)
+        check(_L.cg_error_flags(self._ctx, ctypes.byref(flags)))
+        return int(flags.value)
+
+    def check_errors(self):
+        flags = self.error_flags()
+        if flags & lib.CG_ERR_STALE_HISTOGRAM:
+            raise lib.ConceptGPUError(
+                'cg_drift_sort: the tile histogram prepared by the last gather-kick did not match '
+                'the particles it sorted (momenta were changed in between without '
+                'prepare_invalidate()); particles were dropped')
+
+    def prepare_invalidate(self):
+        """Momenta were changed outside this mesh: forget the prepared drift histogram."""
+        check(_L.cg_prepare_invalidate(self._ctx))
+
     @staticmethod
     def _check_particles(*tensors):
         n = None

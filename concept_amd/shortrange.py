@@ -17,6 +17,7 @@ from .lib import ConceptGPUError
 from .mesh import get_mesh
 
 _tables = {}
+PAIR_KEY = 'a**(-3*w_eff₀-3*w_eff₁-1)'
 
 
 def get_softened_r3inv(r2, ϵ, kernel='spline'):
@@ -69,6 +70,24 @@ def combine_softening_lengths(ϵᵢ, ϵⱼ):
     return 0.5*(ϵᵢ + ϵⱼ)
 
 
+def _pair_integrals(ᔑdt_rungs, rec, sup):
+    """ᔑdt_rungs['a**(-3*w_eff₀-3*w_eff₁-1)', receiver, supplier] as a 1-D array: one entry
+    per rung index (main.py:1203-1215 fills 3*N_rungs - 1 of them); a plain number — what
+    get_time_step_integrals() gives for a single step — counts as rung 0."""
+    k = (PAIR_KEY, rec.name, sup.name)
+    if k not in ᔑdt_rungs:
+        raise ConceptGPUError(
+            f'ᔑdt_rungs lacks the integral {k!r} (both orders of a component pair are needed)')
+    integrals = np.atleast_1d(np.asarray(ᔑdt_rungs[k], dtype=np.float64))
+    if integrals.ndim != 1:
+        raise ConceptGPUError(f'ᔑdt_rungs[{k!r}] must be a number or a 1-D array of rung integrals')
+    if rec.use_rungs and integrals.size < 3*rec.N_rungs - 1:
+        raise ConceptGPUError(
+            f'ᔑdt_rungs[{k!r}] holds {integrals.size} integrals, {3*rec.N_rungs - 1} '
+            f'(3*N_rungs - 1) are needed with rungs in use')
+    return integrals
+
+
 def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
     """Short-range gravity of every (receiver, supplier) component pair, accumulated
     into the components' Δmom buffers (the caller applies them, main.py:1253-1262)."""
@@ -109,7 +128,7 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
 
             def sweep(rec, sup, same_):
                 # compute_factors (gravity.py:51-64): G*m_r*m_s*ᔑdt_rungs[...][k] per rung k
-                integrals = np.asarray(ᔑdt_rungs[key, rec.name, sup.name], dtype=np.float64)
+                integrals = _pair_integrals(ᔑdt_rungs, rec, sup)
                 if rec.use_rungs:
                     factors = torch.tensor(p.G_Newton*rec.mass*sup.mass*integrals,
                                            dtype=torch.float64, device=rec.device)
@@ -172,7 +191,7 @@ def component_component_pp(force, receivers, suppliers, ᔑdt_rungs, periodic):
 
             def kick(rec, sup, same):
                 # compute_factors (gravity.py:51-64): G*m_r*m_s*ᔑdt_rungs[...][k] per rung k
-                integrals = np.asarray(ᔑdt_rungs[key, rec.name, sup.name], dtype=np.float64)
+                integrals = _pair_integrals(ᔑdt_rungs, rec, sup)
                 rungs, factor = None, p.G_Newton*rec.mass*sup.mass*float(integrals[0])
                 if rec.use_rungs:
                     factors = torch.tensor(p.G_Newton*rec.mass*sup.mass*integrals,

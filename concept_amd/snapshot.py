@@ -222,6 +222,8 @@ class GadgetSnapshot:
             comp = Component(c['name'], c['species'], N=c['N'], mass=c['mass'], device=device)
             comp.populate(c['pos'], 'pos')
             comp.populate(c['mom'], 'mom')
+            if c.get('ids') is not None:
+                comp.populate(c['ids'], 'ids')  # the file's ID block (snapshot.py:1573-1600)
             out.append(comp)
         return out
 

@@ -73,7 +73,11 @@ class Component:
         self.pos = torch.zeros((self.N, 3), dtype=torch.float64, device=self.device)
         self.mom = torch.zeros((self.N, 3), dtype=torch.float64, device=self.device)
         self.Δmom = None  # allocated on first short-range use
+        # ids: the particles' identifiers (species.py:2040-2064 `ids`; a snapshot's ID block);
+        # order: where each row stood when the arrays were populated — tile_sort permutes
+        # both with the particles, host(original_order=True) undoes it through `order`
         self.ids = torch.arange(self.N, dtype=torch.int64, device=self.device)
+        self.order = torch.arange(self.N, dtype=torch.int64, device=self.device)
         self._scratch = None
         # tile order bookkeeping: `tile_table` (first particle of each mesh tile) is
         # exact right after tile_sort() on `tile_mesh`; a drift makes it approximate
@@ -149,9 +153,14 @@ class Component:
                     f'{self.gridsize}')
             target.copy_(t)
             return
+        if var == 'ids':
+            self.ids.copy_(torch.as_tensor(np.ascontiguousarray(np.asarray(data, dtype=np.int64))))
+            return
         if var.startswith('pos'):
             self.tile_table = None
             self.tiles_exact = False
+            # new positions arrive in the caller's order: rows are "as populated" again
+            self.order = torch.arange(self.N, dtype=torch.int64, device=self.device)
         if var in ('pos', 'mom'):
             getattr(self, var).copy_(t.reshape(self.N, 3))
             return
@@ -175,7 +184,7 @@ class Component:
         t = getattr(self, var)
         if original_order:
             out = torch.empty_like(t)
-            out[self.ids] = t
+            out[self.order] = t
             t = out
         return t.cpu().numpy()
 
@@ -214,10 +223,10 @@ class Component:
         else:
             mesh.drift_sort(self.pos, self.mom, self._slots, po, mo, perm, Δt_over_mass,
                             self.tile_table)
-        old_ids = self.ids
-        self._scratch = (self.pos, self.mom, old_ids)
+        self._scratch = (self.pos, self.mom, perm)
         self.pos, self.mom = po, mo
-        self.ids = old_ids[perm]
+        self.ids = self.ids[perm]
+        self.order = self.order[perm]
         if self.use_rungs:
             self.rung_indices = self.rung_indices[perm]
             self.rung_indices_jumped = self.rung_indices_jumped[perm]

@@ -42,7 +42,9 @@ typedef struct cg_params {
     int64_t gridsize;      /* global PM grid size N (cubic, even) */
     int32_t nghosts;       /* ghost layers of a domain grid; reference default 2 */
     int32_t cell_centered; /* 1 (reference default) */
-    int32_t interp_order;  /* 2 = CIC (the only order built so far) */
+    int32_t interp_order;  /* 2 = CIC: the order of the context's fused / tiled kernels; the
+                              other orders (1 NGP, 3 TSC, 4 PCS) go through cg_deposit and
+                              cg_gather_scalar, which take the order per call */
     int32_t device;        /* HIP device ordinal */
     int32_t nprocs;        /* number of domains (= ranks = GPUs) */
     int32_t rank;          /* this domain */
@@ -71,6 +73,13 @@ int cg_set_stream(cg_ctx *ctx, void *hip_stream);
 int cg_synchronize(cg_ctx *ctx);
 /* bytes of HBM owned by the context */
 int64_t cg_device_bytes(const cg_ctx *ctx);
+/* Sticky error bits set by kernels since the last call (synchronises the stream, clears them).
+ * The reference aborts inside the loop that finds the inconsistency (commons.py:1002-1031); a
+ * kernel cannot, so it records the condition here and keeps memory safe. */
+#define CG_ERR_STALE_HISTOGRAM 1u /* cg_drift_sort: the prepared histogram did not match the
+                                     particles (mom was changed after
+                                     cg_gather_kick_tiled_prepare); particles were dropped */
+int cg_error_flags(cg_ctx *ctx, uint32_t *flags_out /*HOST*/);
 
 /* --- A1/A2: mass deposition ------------------------------------------------
  * cg_mesh_zero: get_buffer(..., nullify=True) (mesh.py:600-603).
@@ -135,11 +144,17 @@ int cg_gather_kick_tiled(cg_ctx *ctx, const double *pos /*DEV 3n*/, double *mom 
  * same dt_over_mass then skips its first pass.  The reference fuses kicks and drifts the
  * same way where it can (driftkick_short, main.py:1347).  Contract: nothing else may change
  * pos/mom between the two calls (cg_drift and cg_sort_particles invalidate the
- * preparation; other writers are the caller's responsibility). */
+ * preparation, as do this context's other momentum writers; see cg_prepare_invalidate). */
 int cg_gather_kick_tiled_prepare(cg_ctx *ctx, const double *pos /*DEV 3n*/,
                                  double *mom /*DEV 3n*/, int64_t n,
                                  const uint32_t *tile_offset /*DEV tile table*/, int diff_order,
                                  double factor, double next_dt_over_mass);
+/* Drop the prepared histogram.  Every entry point of this context that writes momenta
+ * (cg_gather_kick*, cg_gather_scalar, cg_dmom_apply, cg_drift) does so itself; a caller that
+ * changes mom by other means (another context, its own kernels) between the prepare and the
+ * sort must call this.  A stale histogram that slips through is caught by the sort
+ * (CG_ERR_STALE_HISTOGRAM). */
+int cg_prepare_invalidate(cg_ctx *ctx);
 
 /* --- A11: drift ------------------------------------------------------------
  * Component.drift (species.py:2179-2199): pos = mod(pos + mom*dt_over_mass, boxsize)

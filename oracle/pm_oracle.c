@@ -28,7 +28,8 @@ typedef int64_t i64;
 
 /* The `omp parallel for` pragmas below are active only in the all-cores timing build
  * (liboracle_omp.so, -fopenmp): the parity build ignores them and runs the reference's serial
- * loops in the reference's order.  With threads the deposit adds with `omp atomic`, i.e. in
+ * loops in the reference's order.  With threads the deposit is slab-privatised (deposit_colored;
+ * `omp atomic` only as the small-case fallback), i.e. cell sums are added in
  * scheduling order — a CPU baseline for bench.py, not a parity instrument. */
 int orc_threads(int n) {
 #ifdef _OPENMP
@@ -57,8 +58,96 @@ static inline i64 set_weights_cic(double x, double *w) {
  * grid is the ghosted domain grid double[size_i][size_j][size_k].
  * idx_out (nullable): the three set_weights_CIC indices per particle.
  */
+#ifdef _OPENMP
+#include <stdlib.h>
+/* All-cores timing build only: the deposit without atomics.  The reference runs one MPI rank per
+ * core, each depositing into its own ghosted domain grid (no write sharing at all,
+ * mesh.py:1512-1636 + communicate_ghosts '+='); the OpenMP counterpart is a slab decomposition
+ * along i with two colours: particles are binned by the slab of their lower cell (counting sort
+ * of indices), then all even slabs are deposited concurrently, then all odd ones — a slab writes
+ * the layers [s*W, (s+1)*W], so slabs of one colour never touch the same cell.  Same arithmetic
+ * per particle as the loop below; only the order of additions to a cell differs. */
+static int deposit_colored(const double *pos, i64 N, double *grid, i64 size_j, i64 size_k,
+                           const double *offset, double scale, double contribution) {
+    const int T = omp_get_max_threads();
+    if (T < 2 || N < 4096) return 0;
+    i64 imax = 0;
+#pragma omp parallel for schedule(static) reduction(max : imax)
+    for (i64 p = 0; p < N; p++) {
+        i64 ii = (i64)((pos[3 * p + 0] - offset[0]) * scale);
+        if (ii > imax) imax = ii;
+    }
+    const i64 nlayers = imax + 1;
+    i64 S = 4 * (i64)T;  /* slabs: a few per thread and colour, for balance */
+    if (S > nlayers) S = nlayers;
+    if (S < 2) return 0;
+    const i64 W = (nlayers + S - 1) / S;
+    S = (nlayers + W - 1) / W;
+    i64 *count = (i64 *)calloc((size_t)(S + 1) * (size_t)T, sizeof(i64));
+    i64 *start = (i64 *)malloc((size_t)(S + 1) * sizeof(i64));
+    int32_t *order = (int32_t *)malloc((size_t)N * sizeof(int32_t));
+    if (!count || !start || !order || N > 2147483647) {
+        free(count); free(start); free(order);
+        return 0;
+    }
+#pragma omp parallel
+    {
+        const int t = omp_get_thread_num();
+        i64 *mine = count + (size_t)t * (size_t)(S + 1);
+#pragma omp for schedule(static)
+        for (i64 p = 0; p < N; p++) mine[(i64)((pos[3 * p + 0] - offset[0]) * scale) / W]++;
+#pragma omp single
+        {
+            i64 run = 0;
+            for (i64 s = 0; s < S; s++) {
+                start[s] = run;
+                for (int u = 0; u < T; u++) {
+                    i64 c = count[(size_t)u * (size_t)(S + 1) + s];
+                    count[(size_t)u * (size_t)(S + 1) + s] = run;
+                    run += c;
+                }
+            }
+            start[S] = run;
+        }
+#pragma omp for schedule(static)
+        for (i64 p = 0; p < N; p++)
+            order[mine[(i64)((pos[3 * p + 0] - offset[0]) * scale) / W]++] = (int32_t)p;
+        for (int colour = 0; colour < 2; colour++) {
+#pragma omp for schedule(dynamic, 1)
+            for (i64 s = colour; s < S; s += 2) {
+                for (i64 q = start[s]; q < start[s + 1]; q++) {
+                    const i64 p = order[q];
+                    double wx[2], wy[2], wz[2];
+                    i64 ii = set_weights_cic((pos[3 * p + 0] - offset[0]) * scale, wx);
+                    i64 jj = set_weights_cic((pos[3 * p + 1] - offset[1]) * scale, wy);
+                    i64 kk = set_weights_cic((pos[3 * p + 2] - offset[2]) * scale, wz);
+                    i64 index_i = ((ii - 1) * size_j + (jj - 1)) * size_k + kk - 1;
+                    for (int i = 0; i < 2; i++) {
+                        double weight_i = wx[i] * contribution;
+                        index_i += size_j * size_k;
+                        i64 index_j = index_i;
+                        for (int j = 0; j < 2; j++) {
+                            index_j += size_k;
+                            double wij = weight_i * wy[j];
+                            grid[index_j + 1] += wij * wz[0];
+                            grid[index_j + 2] += wij * wz[1];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    free(count); free(start); free(order);
+    return 1;
+}
+#endif
+
 void orc_cic_deposit(const double *pos, i64 N, double *grid, i64 size_j, i64 size_k,
                      const double *offset, double scale, double contribution, i64 *idx_out) {
+#ifdef _OPENMP
+    if (!idx_out && deposit_colored(pos, N, grid, size_j, size_k, offset, scale, contribution))
+        return;
+#endif
 #pragma omp parallel for schedule(static)
     for (i64 p = 0; p < N; p++) {
         double wx[2], wy[2], wz[2];
