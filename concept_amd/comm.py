@@ -1,0 +1,157 @@
+"""concept_amd.comm — the process group of the x-slab domain decomposition.
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  The
+reference's counterpart is the module-level MPI state of commons.py:174-260
+(`comm`, `rank`, `nprocs`, `master`) that every collective in communication.py
+uses.  `init()` makes a group the ACTIVE decomposition: meshes created through
+`mesh.get_mesh()` and `species.Component`s then live on x-slab domains, and
+`interactions.gravity()` is collective over the group, as the reference's is
+over MPI ranks (interactions.py:2854-2961).
+
+The same code runs under "gloo" (tests: ranks sharing one GPU, or CPU-only
+checks of the exchange logic) by staging messages through host memory.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+_active = None
+
+
+class Comm:
+    """Thin wrapper over torch.distributed that also works on gloo."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.stage = self.backend != 'nccl'  # gloo: stage device tensors through the host
+        self.next = (self.rank + 1) % self.world
+        self.prev = (self.rank - 1) % self.world
+        self.last_sent = 0
+
+    def all_to_all(self, out, inp, out_splits=None, in_splits=None):
+        if not self.stage:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+            return
+        # gloo: pairwise exchange of the blocks through host memory
+        P = self.world
+        src = inp.cpu()
+        if in_splits is None:
+            in_splits = [src.shape[0]//P]*P
+            out_splits = [out.shape[0]//P]*P
+        ichunks = list(torch.split(src, in_splits))
+        res = torch.empty(out.shape, dtype=out.dtype)
+        ochunks = list(torch.split(res, out_splits))
+        ops = []
+        for q in range(P):
+            if q == self.rank:
+                ochunks[q].copy_(ichunks[q])
+            else:
+                if ichunks[q].numel():
+                    ops.append(dist.P2POp(dist.isend, ichunks[q].contiguous(), q,
+                                          group=self.group))
+                if ochunks[q].numel():
+                    ops.append(dist.P2POp(dist.irecv, ochunks[q], q, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        out.copy_(res)
+
+    def all_to_all_layers(self, out, inp, nlayers_total, layer0, nlayers, async_op=False):
+        """all_to_all of the layers [layer0, layer0 + nlayers) of every peer block of two
+        transpose buffers (P blocks of `nlayers_total` layers each: the range is one contiguous
+        piece per peer, exchanged in place).  With async_op the RCCL work handle is returned:
+        the exchange runs on RCCL's stream behind what the current stream has queued so far,
+        and `wait()` makes the current stream wait for it."""
+        P = self.world
+        o = out.view(P, nlayers_total, -1)[:, layer0:layer0 + nlayers]
+        i = inp.view(P, nlayers_total, -1)[:, layer0:layer0 + nlayers]
+        if not self.stage:
+            return dist.all_to_all([o[q] for q in range(P)], [i[q] for q in range(P)],
+                                   group=self.group, async_op=async_op)
+        # gloo (tests): pairwise through host memory, synchronously
+        ops, recvs = [], {}
+        for q in range(P):
+            if q == self.rank:
+                o[q].copy_(i[q])
+                continue
+            ops.append(dist.P2POp(dist.isend, i[q].cpu().contiguous(), q, group=self.group))
+            recvs[q] = torch.empty(o[q].shape, dtype=o.dtype)
+            ops.append(dist.P2POp(dist.irecv, recvs[q], q, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for q, r in recvs.items():
+            o[q].copy_(r)
+        return None
+
+    def sendrecv(self, send, dest, recv, source):
+        """send -> dest while receiving <- source (a ring shift)."""
+        if dest == self.rank and source == self.rank:
+            recv.copy_(send)
+            return
+        if self.stage:
+            s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+        else:
+            s, r = send, recv
+        ops = []  # empty messages are skipped on both ends (sizes are known to both)
+        if s.numel():
+            ops.append(dist.P2POp(dist.isend, s, dest, group=self.group))
+        if r.numel():
+            ops.append(dist.P2POp(dist.irecv, r, source, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if self.stage and r.numel():
+            recv.copy_(r)
+
+    def all_gather_ints(self, values):
+        t = torch.tensor(values, dtype=torch.int64)
+        if not self.stage:
+            t = t.cuda()
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return torch.stack(out).cpu()
+
+    def all_gather_rows(self, t):
+        """Concatenation over the ranks (in rank order) of tensors that differ in their first
+        dimension only; returned on t's device."""
+        counts = self.all_gather_ints([t.shape[0]])[:, 0].tolist()
+        m = max(counts) if counts else 0
+        pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype)
+        pad[:t.shape[0]] = t.cpu() if self.stage else t.cpu()
+        if not self.stage:
+            pad = pad.to(t.device)
+        out = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(out, pad, group=self.group)
+        return torch.cat([o[:c] for o, c in zip(out, counts)]).to(t.device)
+
+    def any(self, flag):
+        """Logical OR of a host bool over the ranks."""
+        return bool(self.all_gather_ints([int(bool(flag))]).sum().item())
+
+
+def init(group=None, force=False):
+    """Make `group` (default: the world group) the active domain decomposition.  A group of
+    one rank is ignored unless force (tests of the transposing path on one GPU)."""
+    global _active
+    c = Comm(group)
+    c.force = bool(force) or os.environ.get('CONCEPT_GPU_DIST_FORCE') == '1'
+    _active = c if (c.world > 1 or c.force) else None
+    from . import mesh
+    mesh.free_meshes()  # meshes of another decomposition must not be reused
+    return _active
+
+
+def shutdown():
+    global _active
+    _active = None
+    from . import mesh
+    mesh.free_meshes()
+
+
+def active():
+    return _active

@@ -146,6 +146,12 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
     }
     c->device_bytes += 8 * c->mesh_doubles;
     c->mesh0 = c->mesh + (i64)c->xmap.G * c->ny * c->pad;
+    if (p->nprocs == 1) {  // Fourier space shares the mesh in place, all rows
+        c->four = (double2 *)c->mesh0;
+        c->f_si = c->ny * (c->pad / 2);
+        c->f_j0 = 0;
+        c->f_nj = (int)c->N;
+    }
     // geometry, reference expressions
     const double bgn[3] = {0, 0, 0};
     double cellsize_dep = p->boxsize / (double)p->gridsize;             // mesh.py:1577
@@ -293,24 +299,30 @@ extern "C" int cg_deposit_cic(cg_ctx *c, const double *pos, int64_t n, double co
 
 // ---- general particle_mesh() pieces (cg_general.hip) ----
 #define CG_SINGLE(c, name) \
-    CG_CHECK((c)->p.nprocs == 1, name ": single-domain entry point (the general mesh path is not sharded)")
+    CG_CHECK((c)->p.nprocs == 1, name ": single-domain entry point")
+// k-space operations work on the context's Fourier view: the mesh itself on one domain, the
+// buffer bound with cg_dist_bind_fourier on x-slab domains
+#define CG_FOURIER(c, name) \
+    CG_CHECK((c)->four != nullptr, name ": no Fourier buffer bound (cg_dist_bind_fourier)")
 
 extern "C" int cg_fluid_add(cg_ctx *c, const double *fluid, double factor, int op_add) {
     CG_CHECK(c && fluid, "cg_fluid_add: null argument");
-    CG_SINGLE(c, "cg_fluid_add");
     return cgk_fluid_add(c, fluid, factor, op_add ? 1 : 0);
 }
 
 extern "C" int cg_fourier_nullify_nyquist(cg_ctx *c) {
     CG_CHECK(c, "cg_fourier_nullify_nyquist: null context");
-    CG_SINGLE(c, "cg_fourier_nullify_nyquist");
+    CG_FOURIER(c, "cg_fourier_nullify_nyquist");
     return cgk_nullify_nyquist(c);
 }
 
 extern "C" int cg_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
                                   const double *shift, int diff_dim, int op_add) {
     CG_CHECK(onto && from, "cg_fourier_operate: null context");
-    CG_SINGLE(onto, "cg_fourier_operate");
+    CG_FOURIER(onto, "cg_fourier_operate");
+    CG_FOURIER(from, "cg_fourier_operate");
+    CG_CHECK(onto->p.nprocs == from->p.nprocs && onto->p.rank == from->p.rank,
+             "cg_fourier_operate: the two meshes belong to different domain decompositions");
     CG_CHECK(onto->N == from->N && onto->pad == from->pad,
              "cg_fourier_operate: grid sizes %lld and %lld differ (different sizes go through "
              "cg_copy_modes)", (long long)from->N, (long long)onto->N);
@@ -327,8 +339,11 @@ extern "C" int cg_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, 
 extern "C" int cg_copy_modes(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
                              const double *shift, int op_add) {
     CG_CHECK(onto && from, "cg_copy_modes: null context");
-    CG_SINGLE(onto, "cg_copy_modes");
-    CG_SINGLE(from, "cg_copy_modes");
+    CG_FOURIER(onto, "cg_copy_modes");
+    CG_FOURIER(from, "cg_copy_modes");
+    CG_CHECK(onto->N == from->N || (onto->p.nprocs == 1 && from->p.nprocs == 1),
+             "cg_copy_modes: on x-slab domains rows of different grid sizes live on different "
+             "domains: exchange them with cg_copy_modes_pack / cg_copy_modes_unpack");
     CG_CHECK(onto->p.boxsize == from->p.boxsize, "cg_copy_modes: the two meshes span different boxes");
     CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_copy_modes: deconv_order %d",
              deconv_order);
@@ -339,10 +354,37 @@ extern "C" int cg_copy_modes(cg_ctx *onto, cg_ctx *from, int deconv_order, int n
     return cgk_copy_modes(onto, from, deconv_order, nlattice, shift, op_add ? 1 : 0);
 }
 
+extern "C" int cg_copy_modes_pack(cg_ctx *from, int64_t n_small, const int32_t *rows_local,
+                                  int64_t n_rows, double *out) {
+    CG_CHECK(from && (n_rows == 0 || (rows_local && out)), "cg_copy_modes_pack: null argument");
+    CG_FOURIER(from, "cg_copy_modes_pack");
+    CG_CHECK(n_small >= 2 && n_small <= from->N && n_small % 2 == 0,
+             "cg_copy_modes_pack: small grid size %lld", (long long)n_small);
+    return cgk_copy_modes_pack(from, n_small, rows_local, n_rows, out);
+}
+
+extern "C" int cg_copy_modes_unpack(cg_ctx *onto, cg_ctx *from, int64_t n_small,
+                                    const int32_t *rows_local, int64_t n_rows, const double *in,
+                                    int deconv_order, int nlattice, const double *shift,
+                                    int op_add) {
+    CG_CHECK(onto && from && (n_rows == 0 || (rows_local && in)),
+             "cg_copy_modes_unpack: null argument");
+    CG_FOURIER(onto, "cg_copy_modes_unpack");
+    CG_CHECK(onto->p.boxsize == from->p.boxsize,
+             "cg_copy_modes_unpack: the two meshes span different boxes");
+    CG_CHECK(n_small == (onto->N < from->N ? onto->N : from->N),
+             "cg_copy_modes_unpack: n_small must be the smaller of the two grid sizes");
+    CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_copy_modes_unpack: deconv_order %d",
+             deconv_order);
+    CG_CHECK(nlattice == 1 || nlattice == 2 || nlattice == 4,
+             "cg_copy_modes_unpack: nlattice %d not in {1, 2, 4}", nlattice);
+    return cgk_copy_modes_unpack(onto, from, n_small, rows_local, n_rows, in, deconv_order,
+                                 nlattice, shift, op_add ? 1 : 0);
+}
+
 extern "C" int cg_deposit(cg_ctx *c, const double *pos, int64_t n, double contribution, int order,
                           const double *shift) {
     CG_CHECK(c && (pos || n == 0), "cg_deposit: null argument");
-    CG_SINGLE(c, "cg_deposit");
     CG_CHECK(order >= 1 && order <= 4,
              "interpolate_particles() called with order = %d not in {1 (NGP), 2 (CIC), 3 (TSC), 4 (PCS)}",
              order);
@@ -354,7 +396,6 @@ extern "C" int cg_deposit(cg_ctx *c, const double *pos, int64_t n, double contri
 extern "C" int cg_gather_scalar(cg_ctx *c, const double *pos, double *mom, int64_t n, int dim,
                                 int order, const double *shift, double factor) {
     CG_CHECK(c && ((pos && mom) || n == 0), "cg_gather_scalar: null argument");
-    CG_SINGLE(c, "cg_gather_scalar");
     CG_CHECK(order >= 1 && order <= 4,
              "interpolate_domaingrid_to_particles() called with order = %d not in {1, 2, 3, 4}",
              order);
@@ -369,8 +410,8 @@ extern "C" int cg_gather_scalar(cg_ctx *c, const double *pos, double *mom, int64
 
 extern "C" int cg_mesh_diff(cg_ctx *dst, cg_ctx *src, int dim, int diff_order) {
     CG_CHECK(dst && src && dst != src, "cg_mesh_diff: two distinct contexts are needed");
-    CG_SINGLE(src, "cg_mesh_diff");
-    CG_CHECK(dst->N == src->N && dst->pad == src->pad, "cg_mesh_diff: the two meshes differ in shape");
+    CG_CHECK(dst->N == src->N && dst->pad == src->pad && dst->mesh_doubles == src->mesh_doubles,
+             "cg_mesh_diff: the two meshes differ in shape");
     CG_CHECK(dim >= 0 && dim < 3, "diff_domaingrid() called with dim = %d not in {0, 1, 2}", dim);
     CG_CHECK(diff_order == 2 || diff_order == 4,
              "cg_mesh_diff: differentiation order %d (2 and 4 are built)", diff_order);
@@ -410,7 +451,6 @@ extern "C" int cg_mesh_copy(cg_ctx *dst, cg_ctx *src) {
 extern "C" int cg_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int dim,
                              int diff_order, double minus_dt, double inv_c2) {
     CG_CHECK(c && J && rho && P, "cg_fluid_kick: null argument");
-    CG_SINGLE(c, "cg_fluid_kick");
     CG_CHECK(dim >= 0 && dim < 3,
              "apply_particle_mesh_force() called with dim = %d not in {0, 1, 2}", dim);
     CG_CHECK(diff_order == 0 || diff_order == 2 || diff_order == 4,
@@ -438,7 +478,7 @@ extern "C" int cg_poisson_forward(cg_ctx *c, int deconv_order, double C, int lon
 
 extern "C" int cg_poisson_kernel(cg_ctx *c, int deconv_order, double C, int long_range, double E) {
     CG_CHECK(c, "cg_poisson_kernel: null context");
-    CG_CHECK(c->p.nprocs == 1, "cg_poisson_kernel: single-domain entry point; x-slab domains use cg_dist_fft_*");
+    CG_FOURIER(c, "cg_poisson_kernel");
     CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_poisson_kernel: deconv_order %d",
              deconv_order);
     return cgk_kspace(c, deconv_order, C, long_range, E);
@@ -761,6 +801,36 @@ extern "C" int cg_dist_fft_xsolve(cg_ctx *c, double *buf, int deconv_order, doub
     CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_dist_fft_xsolve: deconv_order %d",
              deconv_order);
     return cgk_fft_dist_xsolve(c, buf, deconv_order, C, long_range, E);
+}
+extern "C" int cg_dist_bind_fourier(cg_ctx *c, double *buf) {
+    CG_CHECK(c, "cg_dist_bind_fourier: null context");
+    if (c->p.nprocs == 1 && buf == nullptr) {  // back to the in-place view
+        c->four = (double2 *)c->mesh0;
+        c->f_si = c->ny * (c->pad / 2);
+        c->f_j0 = 0;
+        c->f_nj = (int)c->N;
+        return 0;
+    }
+    CG_CHECK(buf, "cg_dist_bind_fourier: x-slab domains need a buffer");
+    // the transpose-buffer layout of cg_fft.hip: complex[N][JB + 1][cp]
+    const i64 JB = c->N / c->p.nprocs;
+    c->four = (double2 *)buf;
+    c->f_si = (JB + 1) * (c->pad / 2);
+    c->f_j0 = (int)(JB * c->p.rank);
+    c->f_nj = (int)JB;
+    return 0;
+}
+extern "C" int cg_dist_fft_x(cg_ctx *c, double *buf, int inverse) {
+    CG_CHECK(c && buf, "cg_dist_fft_x: null argument");
+    CG_CHECK(c->custom_fft, "cg_dist_fft_x: needs the hand-written FFT backend");
+    return cgk_fft_dist_x(c, buf, inverse ? 1 : 0);
+}
+extern "C" int cg_emigrant_dest(cg_ctx *c, const double *pos, const double *mom,
+                                const int64_t *idx, const uint32_t *count, int64_t cap,
+                                double dt_over_mass, int32_t *dest, int32_t *send_counts) {
+    CG_CHECK(c && send_counts && (cap == 0 || (pos && mom && idx && count && dest)),
+             "cg_emigrant_dest: null argument");
+    return cgk_emigrant_dest(c, pos, mom, idx, count, cap, dt_over_mass, dest, send_counts);
 }
 extern "C" int cg_dist_fft_backward(cg_ctx *c, const double *recv_buf) {
     CG_CHECK(c && recv_buf, "cg_dist_fft_backward: null argument");

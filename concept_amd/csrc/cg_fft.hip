@@ -1040,6 +1040,12 @@ static int fft_dist(cg_ctx *c, int what, double2 *buf, const KspaceParams &P, i6
         PencilMap xmap = plain_map(cp, JBp * cp);
         return run_strided<LOGN, 2>(c, buf, buf, xmap, xmap, JB, (i64)c->p.rank * JB, P);
     }
+    if (what == 3 || what == 4) {  // the x pass alone (general particle_mesh: the Fourier slab
+        PencilMap xmap = plain_map(cp, JBp * cp);  // is operated on between the two)
+        if (what == 3)
+            return run_strided<LOGN, 0>(c, buf, buf, xmap, xmap, JB, (i64)c->p.rank * JB, P);
+        return run_strided<LOGN, 1>(c, buf, buf, xmap, xmap, JB, (i64)c->p.rank * JB, P);
+    }
     // backward y from the returned buffer, backward z
     const ChunkPlan plan(nlayers, chunk);
     for (i64 ci = 0; ci < plan.n; ci++) {
@@ -1078,6 +1084,10 @@ int cgk_fft_dist_xsolve(cg_ctx *c, double *buf, int deconv_order, double C, int 
                         double E) {
     KspaceParams P{c->ktab_n, c->ktab_s, c->ktab_q, deconv_order, long_range, C, E};
     CG_FFT_DISPATCH(fft_dist, c, 2, (double2 *)buf, P, 0, -1)
+}
+int cgk_fft_dist_x(cg_ctx *c, double *buf, int inverse) {
+    KspaceParams P{c->ktab_n, c->ktab_s, c->ktab_q, 0, 0, 0.0, 0.0};
+    CG_FFT_DISPATCH(fft_dist, c, inverse ? 4 : 3, (double2 *)buf, P, 0, -1)
 }
 int cgk_fft_dist_backward(cg_ctx *c, const double *recv_buf, i64 layer0, i64 nlayers) {
     KspaceParams P{c->ktab_n, c->ktab_s, c->ktab_q, 0, 0, 0.0, 0.0};

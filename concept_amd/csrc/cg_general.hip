@@ -24,11 +24,14 @@
         }                                                                                     \
     } while (0)
 
+// Fluid grids of an x-slab domain are its own layers double[nxl][N][N]; `mesh` is then the
+// first OWNED layer of the local buffer.
 __global__ __launch_bounds__(256) void k_fluid_add(double *__restrict__ mesh,
                                                    const double *__restrict__ fluid, int N,
-                                                   i64 ny, i64 pad, double factor, int op_add) {
+                                                   int nxl, i64 ny, i64 pad, double factor,
+                                                   int op_add) {
     // one thread per (i, j, k-pair): rows of the fluid grid are contiguous
-    const i64 total = (i64)N * N * N;
+    const i64 total = (i64)nxl * N * N;
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (i64)gridDim.x * blockDim.x) {
         i64 row = t / N;
@@ -42,14 +45,14 @@ __global__ __launch_bounds__(256) void k_fluid_add(double *__restrict__ mesh,
     }
 }
 
-__global__ __launch_bounds__(256) void k_nullify_nyquist(double2 *__restrict__ mesh, int N,
-                                                         i64 ny, i64 cp) {
-    // complex[N][N][cp]: planes a == nyq, b == nyq, kk == nyq
+__global__ __launch_bounds__(256) void k_nullify_nyquist(double2 *__restrict__ four, int N,
+                                                         i64 si, i64 cp, int j0, int nj) {
+    // Fourier view (cg_ctx::four): planes a == nyq, b == nyq, kk == nyq
     const int nyq = N / 2;
-    const i64 rows = (i64)N * N;
+    const i64 rows = (i64)N * nj;
     for (i64 row = (i64)blockIdx.x; row < rows; row += gridDim.x) {
-        int a = (int)(row / N), b = (int)(row - (i64)a * N);
-        double2 *r = mesh + ((i64)a * ny + b) * cp;
+        int a = (int)(row / nj), bl = (int)(row - (i64)a * nj), b = j0 + bl;
+        double2 *r = four + (i64)a * si + (i64)bl * cp;
         if (a == nyq || b == nyq) {
             for (int kk = threadIdx.x; kk <= nyq; kk += blockDim.x) r[kk] = make_double2(0, 0);
         } else if (threadIdx.x == 0) {
@@ -67,14 +70,15 @@ struct FourierOp {
 
 __global__ __launch_bounds__(256) void k_fourier_operate(const double2 *__restrict__ from,
                                                          double2 *__restrict__ onto, int N,
-                                                         i64 ny, i64 cp, FourierOp P) {
+                                                         i64 si, i64 cp, int j0, int nj,
+                                                         FourierOp P) {
 #pragma clang fp contract(off)
     const int nyq = N / 2;
-    const i64 rows = (i64)N * N;
+    const i64 rows = (i64)N * nj;
     for (i64 row = (i64)blockIdx.x; row < rows; row += gridDim.x) {
-        const int a = (int)(row / N), b = (int)(row - (i64)a * N);
-        const double2 *src = from + ((i64)a * ny + b) * cp;
-        double2 *dst = onto + ((i64)a * ny + b) * cp;
+        const int a = (int)(row / nj), bl = (int)(row - (i64)a * nj), b = j0 + bl;
+        const double2 *src = from + (i64)a * si + (i64)bl * cp;
+        double2 *dst = onto + (i64)a * si + (i64)bl * cp;
         const bool dead_row = (a == nyq) || (b == nyq);
         const int ka = a - (a >= nyq ? N : 0), kb = b - (b >= nyq ? N : 0);
         double dab_n = 0, dab_d = 0;
@@ -127,6 +131,8 @@ struct CopyModes {
     int deconv_order, shifted, op_add;
     double A, B, Cc, dtheta, inv_lat;
 };
+static CopyModes copy_modes_params(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
+                                    const double *shift, int op_add);
 __global__ __launch_bounds__(64) void k_copy_modes(const double2 *__restrict__ from, int N_from,
                                                    i64 ny_from, i64 cp_from,
                                                    double2 *__restrict__ onto, int N_onto,
@@ -167,26 +173,88 @@ __global__ __launch_bounds__(64) void k_copy_modes(const double2 *__restrict__ f
     }
 }
 
+// copy_modes between different grid sizes over x-slab domains (get_subslabs / the sub-slab
+// exchange of mesh.py:1327-1468): a row kj of the small cube lives on different domains in
+// the two grids' decompositions, so it travels.  Pack: the small-cube part of the listed
+// local rows of `from`, out[r][as][kk] (as = array index of ki in the SMALL grid, kk < nyq).
+// Unpack: what k_copy_modes does per row, reading the packed rows.
+__global__ __launch_bounds__(64) void k_cm_pack(const double2 *__restrict__ from, int N_from,
+                                                i64 si, i64 cp, const int *__restrict__ rows,
+                                                i64 n_rows, int NS, double2 *__restrict__ out) {
+    const int nyq = NS / 2;
+    for (i64 w = blockIdx.x; w < n_rows * NS; w += gridDim.x) {
+        const i64 r = w / NS;
+        const int as = (int)(w - r * NS);
+        if (as == nyq) continue;
+        const int ka = as - (as >= nyq ? NS : 0);
+        const int af = ka + (ka < 0 ? N_from : 0);
+        const double2 *src = from + (i64)af * si + (i64)rows[r] * cp;
+        double2 *dst = out + (r * NS + as) * nyq;
+        for (int kk = threadIdx.x; kk < nyq; kk += blockDim.x) dst[kk] = src[kk];
+    }
+}
+__global__ __launch_bounds__(64) void k_cm_unpack(const double2 *__restrict__ in, int NS,
+                                                  const int *__restrict__ rows, i64 n_rows,
+                                                  double2 *__restrict__ onto, int N_onto, i64 si,
+                                                  i64 cp, int j0, int N_from, CopyModes P) {
+#pragma clang fp contract(off)
+    const int nyq = NS / 2;
+    for (i64 w = blockIdx.x; w < n_rows * NS; w += gridDim.x) {
+        const i64 r = w / NS;
+        const int as = (int)(w - r * NS);
+        if (as == nyq) continue;
+        const int bo = j0 + rows[r];
+        const int kb = bo - (bo >= N_onto / 2 ? N_onto : 0);
+        const int ka = as - (as >= nyq ? NS : 0);
+        const int af = ka + (ka < 0 ? N_from : 0), bf = kb + (kb < 0 ? N_from : 0);
+        const int ao = ka + (ka < 0 ? N_onto : 0);
+        const double2 *src = in + (r * NS + as) * nyq;
+        double2 *dst = onto + (i64)ao * si + (i64)rows[r] * cp;
+        double dab_n = 0, dab_d = 0;
+        if (P.deconv_order) {
+            dab_n = P.tab_n[af] * P.tab_n[bf];
+            dab_d = P.tab_s[af] * P.tab_s[bf];
+        }
+        for (int kk = threadIdx.x; kk < nyq; kk += blockDim.x) {
+            double factor = 1;
+            if (P.deconv_order) {
+                factor = (dab_n * P.tab_n[kk]) / (dab_d * P.tab_s[kk]);
+                double f = factor;
+                for (int o = 1; o < P.deconv_order; o++) factor *= f;
+            }
+            factor *= P.inv_lat;
+            double re = src[kk].x, im = src[kk].y;
+            double theta = P.dtheta * (double)((ka + kb) + kk);  // mesh.py:1302
+            if (P.shifted) theta += ((double)ka * P.A + (double)kb * P.B) + (double)kk * P.Cc;
+            double c = cos(theta), s = sin(theta);
+            double re2 = factor * (re * c - im * s), im2 = factor * (re * s + im * c);
+            if (P.op_add) dst[kk] = make_double2(dst[kk].x + re2, dst[kk].y + im2);
+            else dst[kk] = make_double2(re2, im2);
+        }
+    }
+}
+
 template <int ORDER>
 __global__ __launch_bounds__(256) void k_fluid_kick(double *__restrict__ J,
                                                     const double *__restrict__ rho,
                                                     const double *__restrict__ P,
                                                     const double *__restrict__ mesh, int N,
-                                                    i64 ny, i64 pad, int dim, double c1,
+                                                    XMap xm, i64 ny, i64 pad, int dim, double c1,
                                                     double c2, double mdt, double inv_c2) {
 #pragma clang fp contract(off)
-    const i64 total = (i64)N * N * N;
+    // `mesh` is the local buffer (ghost layers included); the fluid grids hold the owned layers
+    const i64 total = (i64)xm.nxl * N * N;
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (i64)gridDim.x * blockDim.x) {
         i64 row = t / N;
         int k = (int)(t - row * N);
         int i = (int)(row / N), j = (int)(row - (i64)i * N);
         auto phi = [&](int s) {
-            int ii = i, jj = j, kk = k;
-            if (dim == 0) ii = (i + s + N) % N;
-            else if (dim == 1) jj = (j + s + N) % N;
-            else kk = (k + s + N) % N;
-            return mesh[((i64)ii * ny + jj) * pad + kk];
+            i64 ii = cg_xlayer(xm, xm.x0 + i + (dim == 0 ? s : 0), N);
+            int jj = j, kk = k;
+            if (dim == 1) jj = (j + s + N) % N;
+            else if (dim == 2) kk = (k + s + N) % N;
+            return mesh[(ii * ny + jj) * pad + kk];
         };
         double g;
         if (ORDER == 0) g = phi(0);  // the mesh already holds the force (Fourier-space gradient)
@@ -257,7 +325,7 @@ __device__ __forceinline__ int wrap32(int a, int n) {
 template <int ORDER>
 __global__ __launch_bounds__(256) void k_deposit_general(const double *__restrict__ pos, i64 n,
                                                          double *__restrict__ mesh, int N, i64 ny,
-                                                         i64 pad, int g, CicGeom geo,
+                                                         i64 pad, int g, XMap xm, CicGeom geo,
                                                          double contribution) {
 #pragma clang fp contract(off)
     const i64 stride = (i64)gridDim.x * blockDim.x;
@@ -270,7 +338,7 @@ __global__ __launch_bounds__(256) void k_deposit_general(const double *__restric
         for (int i = 0; i < ORDER; i++) {
             double weight_i = wx[i];
             weight_i *= contribution;  // apply_factor = True
-            const i64 ri = (i64)wrap32(ii + i, N) * ny;
+            const i64 ri = cg_xlayer(xm, (i64)(ii + i), N) * ny;
 #pragma unroll
             for (int j = 0; j < ORDER; j++) {
                 double wij = weight_i * wy[j];
@@ -287,8 +355,8 @@ template <int ORDER>
 __global__ __launch_bounds__(256) void k_gather_scalar(const double *__restrict__ pos,
                                                        double *__restrict__ mom, i64 n, int dim,
                                                        const double *__restrict__ mesh, int N,
-                                                       i64 ny, i64 pad, int g, CicGeom geo,
-                                                       double factor) {
+                                                       i64 ny, i64 pad, int g, XMap xm,
+                                                       CicGeom geo, double factor) {
 #pragma clang fp contract(off)
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
@@ -299,7 +367,7 @@ __global__ __launch_bounds__(256) void k_gather_scalar(const double *__restrict_
         double value = 0;
 #pragma unroll
         for (int i = 0; i < ORDER; i++) {
-            const i64 ri = (i64)wrap32(ii + i, N) * ny;
+            const i64 ri = cg_xlayer(xm, (i64)(ii + i), N) * ny;
 #pragma unroll
             for (int j = 0; j < ORDER; j++) {
                 double wij = wx[i] * wy[j];
@@ -317,26 +385,28 @@ __global__ __launch_bounds__(256) void k_gather_scalar(const double *__restrict_
 // diff_domaingrid (mesh.py:4874-5030) of the real-space mesh of `src` into `dst`
 template <int ORDER>
 __global__ __launch_bounds__(256) void k_mesh_diff(double *__restrict__ dst,
-                                                   const double *__restrict__ src, int N, i64 ny,
-                                                   i64 pad, int dim, double c1, double c2) {
+                                                   const double *__restrict__ src, int N,
+                                                   XMap xm, i64 ny, i64 pad, int dim, double c1,
+                                                   double c2) {
 #pragma clang fp contract(off)
-    const i64 total = (i64)N * N * N;
+    // both are local buffers (ghost layers included); the owned layers of dst are written
+    const i64 total = (i64)xm.nxl * N * N;
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (i64)gridDim.x * blockDim.x) {
         i64 row = t / N;
         int k = (int)(t - row * N);
         int i = (int)(row / N), j = (int)(row - (i64)i * N);
         auto phi = [&](int s) {
-            int ii = i, jj = j, kk = k;
-            if (dim == 0) ii = wrap32(i + s, N);
-            else if (dim == 1) jj = wrap32(j + s, N);
-            else kk = wrap32(k + s, N);
-            return src[((i64)ii * ny + jj) * pad + kk];
+            i64 ii = cg_xlayer(xm, xm.x0 + i + (dim == 0 ? s : 0), N);
+            int jj = j, kk = k;
+            if (dim == 1) jj = wrap32(j + s, N);
+            else if (dim == 2) kk = wrap32(k + s, N);
+            return src[(ii * ny + jj) * pad + kk];
         };
         double gval;
         if (ORDER == 2) gval = c1 * (phi(1) - phi(-1));
         else gval = c1 * (phi(1) - phi(-1)) - c2 * (phi(2) - phi(-2));
-        dst[((i64)i * ny + j) * pad + k] = gval;
+        dst[(((i64)i + xm.G) * ny + j) * pad + k] = gval;
     }
 }
 
@@ -348,16 +418,16 @@ static unsigned blocks_for(i64 n, int per) {
 }
 
 int cgk_fluid_add(cg_ctx *c, const double *fluid, double factor, int op_add) {
-    i64 total = c->N * c->N * c->N;
+    i64 total = c->xmap.nxl * c->N * c->N;
     hipLaunchKernelGGL(k_fluid_add, dim3(blocks_for(total, 256)), dim3(256), 0, c->stream,
-                       c->mesh0, fluid, (int)c->N, c->ny, c->pad, factor, op_add);
+                       c->mesh0, fluid, (int)c->N, (int)c->xmap.nxl, c->ny, c->pad, factor, op_add);
     CG_LAUNCH_CHECK();
     return 0;
 }
 
 int cgk_nullify_nyquist(cg_ctx *c) {
-    hipLaunchKernelGGL(k_nullify_nyquist, dim3(blocks_for(c->N * c->N, 1)), dim3(64), 0,
-                       c->stream, (double2 *)c->mesh0, (int)c->N, c->ny, c->pad / 2);
+    hipLaunchKernelGGL(k_nullify_nyquist, dim3(blocks_for(c->N * c->f_nj, 1)), dim3(64), 0,
+                       c->stream, c->four, (int)c->N, c->f_si, c->pad / 2, c->f_j0, c->f_nj);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -382,15 +452,26 @@ int cgk_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlatti
     }
     P.k_fundamental = 2 * kPiLocal / onto->p.boxsize;  // mesh.py:3362
     P.inv_lat = 1.0 / (double)nlattice;
-    hipLaunchKernelGGL(k_fourier_operate, dim3(blocks_for(onto->N * onto->N, 1)), dim3(256), 0,
-                       onto->stream, (const double2 *)from->mesh0, (double2 *)onto->mesh0,
-                       (int)onto->N, onto->ny, onto->pad / 2, P);
+    hipLaunchKernelGGL(k_fourier_operate, dim3(blocks_for(onto->N * onto->f_nj, 1)), dim3(256), 0,
+                       onto->stream, (const double2 *)from->four, onto->four, (int)onto->N,
+                       onto->f_si, onto->pad / 2, onto->f_j0, onto->f_nj, P);
     CG_LAUNCH_CHECK();
     return 0;
 }
 
 int cgk_copy_modes(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
                    const double *shift, int op_add) {
+    CopyModes P = copy_modes_params(onto, from, deconv_order, nlattice, shift, op_add);
+    i64 ns = onto->N < from->N ? onto->N : from->N;
+    hipLaunchKernelGGL(k_copy_modes, dim3(blocks_for(ns * ns, 1)), dim3(64), 0, onto->stream,
+                       (const double2 *)from->mesh0, (int)from->N, from->ny, from->pad / 2,
+                       (double2 *)onto->mesh0, (int)onto->N, onto->ny, onto->pad / 2, P);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+static CopyModes copy_modes_params(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
+                                    const double *shift, int op_add) {
     const double kPiLocal = 3.141592653589793;
     CopyModes P{};
     P.tab_n = from->ktab_n;  // kk*pi/N_from + eps by array index of the `from` grid
@@ -405,31 +486,49 @@ int cgk_copy_modes(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,
     }
     P.dtheta = kPiLocal / (double)onto->N - kPiLocal / (double)from->N;
     P.inv_lat = 1.0 / (double)nlattice;
-    i64 ns = onto->N < from->N ? onto->N : from->N;
-    hipLaunchKernelGGL(k_copy_modes, dim3(blocks_for(ns * ns, 1)), dim3(64), 0, onto->stream,
-                       (const double2 *)from->mesh0, (int)from->N, from->ny, from->pad / 2,
-                       (double2 *)onto->mesh0, (int)onto->N, onto->ny, onto->pad / 2, P);
+    return P;
+}
+
+int cgk_copy_modes_pack(cg_ctx *from, i64 n_small, const int *rows_local, i64 n_rows,
+                        double *out) {
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(k_cm_pack, dim3(blocks_for(n_rows * n_small, 1)), dim3(64), 0, from->stream,
+                       (const double2 *)from->four, (int)from->N, from->f_si, from->pad / 2,
+                       rows_local, n_rows, (int)n_small, (double2 *)out);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cgk_copy_modes_unpack(cg_ctx *onto, cg_ctx *from, i64 n_small, const int *rows_local,
+                          i64 n_rows, const double *in, int deconv_order, int nlattice,
+                          const double *shift, int op_add) {
+    if (n_rows == 0) return 0;
+    CopyModes P = copy_modes_params(onto, from, deconv_order, nlattice, shift, op_add);
+    hipLaunchKernelGGL(k_cm_unpack, dim3(blocks_for(n_rows * n_small, 1)), dim3(64), 0,
+                       onto->stream, (const double2 *)in, (int)n_small, rows_local, n_rows,
+                       onto->four, (int)onto->N, onto->f_si, onto->pad / 2, onto->f_j0,
+                       (int)from->N, P);
     CG_LAUNCH_CHECK();
     return 0;
 }
 
 int cgk_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int dim,
                    int diff_order, double minus_dt, double inv_c2) {
-    i64 total = c->N * c->N * c->N;
+    i64 total = c->xmap.nxl * c->N * c->N;
     double dx = c->p.boxsize / (double)c->N;  // interactions.py:2133
     if (diff_order == 0) {
         hipLaunchKernelGGL(k_fluid_kick<0>, dim3(blocks_for(total, 256)), dim3(256), 0,
-                           c->stream, J, rho, P, c->mesh0, (int)c->N, c->ny, c->pad, dim, 0.0, 0.0,
+                           c->stream, J, rho, P, c->mesh, (int)c->N, c->xmap, c->ny, c->pad, dim, 0.0, 0.0,
                            minus_dt, inv_c2);
     } else if (diff_order == 2) {
         double c1 = (1.0 / 2) / dx;
         hipLaunchKernelGGL(k_fluid_kick<2>, dim3(blocks_for(total, 256)), dim3(256), 0,
-                           c->stream, J, rho, P, c->mesh0, (int)c->N, c->ny, c->pad, dim, c1, 0.0,
+                           c->stream, J, rho, P, c->mesh, (int)c->N, c->xmap, c->ny, c->pad, dim, c1, 0.0,
                            minus_dt, inv_c2);
     } else {
         double c1 = (2.0 / 3) / dx, c2 = (1.0 / 12) / dx;
         hipLaunchKernelGGL(k_fluid_kick<4>, dim3(blocks_for(total, 256)), dim3(256), 0,
-                           c->stream, J, rho, P, c->mesh0, (int)c->N, c->ny, c->pad, dim, c1, c2,
+                           c->stream, J, rho, P, c->mesh, (int)c->N, c->xmap, c->ny, c->pad, dim, c1, c2,
                            minus_dt, inv_c2);
     }
     CG_LAUNCH_CHECK();
@@ -448,7 +547,8 @@ int cgk_deposit_general(cg_ctx *c, const double *pos, i64 n, double contribution
                         const CicGeom &geo) {
     if (n == 0) return 0;
     CG_ORDER_SWITCH(order, k_deposit_general, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream,
-                    pos, n, c->mesh0, (int)c->N, c->ny, c->pad, c->p.nghosts, geo, contribution)
+                    pos, n, c->mesh, (int)c->N, c->ny, c->pad, c->p.nghosts, c->xmap, geo,
+                    contribution)
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -457,21 +557,22 @@ int cgk_gather_scalar(cg_ctx *c, const double *pos, double *mom, i64 n, int dim,
                       const CicGeom &geo, double factor) {
     if (n == 0) return 0;
     CG_ORDER_SWITCH(order, k_gather_scalar, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream,
-                    pos, mom, n, dim, c->mesh0, (int)c->N, c->ny, c->pad, c->p.nghosts, geo, factor)
+                    pos, mom, n, dim, c->mesh, (int)c->N, c->ny, c->pad, c->p.nghosts, c->xmap, geo,
+                    factor)
     CG_LAUNCH_CHECK();
     return 0;
 }
 
 int cgk_mesh_diff(cg_ctx *dst, cg_ctx *src, int dim, int diff_order) {
-    i64 total = src->N * src->N * src->N;
+    i64 total = src->xmap.nxl * src->N * src->N;
     double dx = src->p.boxsize / (double)src->N;
     if (diff_order == 2) {
         hipLaunchKernelGGL(k_mesh_diff<2>, dim3(blocks_for(total, 256)), dim3(256), 0, dst->stream,
-                           dst->mesh0, src->mesh0, (int)src->N, src->ny, src->pad, dim, (1.0 / 2) / dx,
-                           0.0);
+                           dst->mesh, src->mesh, (int)src->N, src->xmap, src->ny, src->pad, dim,
+                           (1.0 / 2) / dx, 0.0);
     } else {
         hipLaunchKernelGGL(k_mesh_diff<4>, dim3(blocks_for(total, 256)), dim3(256), 0, dst->stream,
-                           dst->mesh0, src->mesh0, (int)src->N, src->ny, src->pad, dim,
+                           dst->mesh, src->mesh, (int)src->N, src->xmap, src->ny, src->pad, dim,
                            (2.0 / 3) / dx, (1.0 / 12) / dx);
     }
     CG_LAUNCH_CHECK();

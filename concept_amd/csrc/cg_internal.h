@@ -98,6 +98,16 @@ struct cg_ctx {
     // sweep at stride 8,519,680 B, 3.52 ms at 8,528,000 B): one unused row per layer
     // breaks the pattern.
     i64 ny = 0;
+    // Fourier view: where the modes of this context live and which of them.  Mode (ki, kj, kk)
+    // with array indices (a, b, kk), b in [f_j0, f_j0 + f_nj), sits at
+    // four[a*f_si + (b - f_j0)*cp + kk], cp = pad/2.  Single domain: the mesh itself, in place
+    // (f_si = ny*cp, all N rows b).  x-slab domains: the transposed buffer of the distributed
+    // FFT, complex[N][JB + 1][cp] with the rows b of this domain's block [rank*JB, (rank+1)*JB)
+    // (fft.c:55-72: FFTW-MPI's transposed output is distributed the same way), bound by the
+    // caller with cg_dist_bind_fourier.
+    double2 *four = nullptr;
+    i64 f_si = 0;
+    int f_j0 = 0, f_nj = 0;
     double *fetch_tmp = nullptr; // lazily allocated, for CG_FETCH_MESH_FOURIER
     // k-space tables: numerator n(k) and denominator sin(n(k)) by array index
     double *ktab_n = nullptr, *ktab_s = nullptr, *ktab_q = nullptr;
@@ -171,6 +181,13 @@ int cgk_fft_dist_forward(cg_ctx *c, double *send_buf, i64 layer0, i64 nlayers);
 int cgk_fft_dist_xsolve(cg_ctx *c, double *buf, int deconv_order, double C, int long_range,
                         double E);
 int cgk_fft_dist_backward(cg_ctx *c, const double *recv_buf, i64 layer0, i64 nlayers);
+int cgk_fft_dist_x(cg_ctx *c, double *buf, int inverse);
+int cgk_copy_modes_pack(cg_ctx *from, i64 n_small, const int *rows_local, i64 n_rows, double *out);
+int cgk_copy_modes_unpack(cg_ctx *onto, cg_ctx *from, i64 n_small, const int *rows_local,
+                          i64 n_rows, const double *in, int deconv_order, int nlattice,
+                          const double *shift, int op_add);
+int cgk_emigrant_dest(cg_ctx *c, const double *pos, const double *mom, const i64 *idx,
+                      const unsigned *count, i64 cap, double dtm, int *dest, int *send_counts);
 int cgk_layers_write(cg_ctx *c, i64 layer0, i64 nlayers, const double *src, int add);
 int cgk_owner_rank(cg_ctx *c, const double *pos, i64 n, int *owner);
 // what: 0 forward, 1 backward, 2 forward + Poisson kernel + backward (fused)

@@ -92,14 +92,14 @@ int cgk_deposit_cic(cg_ctx *c, const double *pos, i64 n, double contribution) {
 //   nullify_modes('origin')   interactions.py:2118
 // One lane per complex mode (16 B load + 16 B store, coalesced along kk).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_kspace(double2 *__restrict__ slab, i64 N, i64 ny,
-                                                i64 pitch, KspaceParams P) {
+__global__ __launch_bounds__(256) void k_kspace(double2 *__restrict__ four, i64 N, i64 si,
+                                                i64 pitch, int j0, int nj, KspaceParams P) {
     const i64 nk = N / 2 + 1;
-    i64 row = blockIdx.x;  // i*N + j
-    i64 i = row / N, j = row - i * N;
-    double2 *r = slab + (i * ny + j) * pitch;
+    i64 row = blockIdx.x;  // i*nj + j_local over the Fourier view (cg_ctx::four)
+    i64 i = row / nj, jl = row - i * nj;
+    double2 *r = four + i * si + jl * pitch;
     for (i64 kk = threadIdx.x; kk < nk; kk += blockDim.x) {
-        double factor = kspace_factor(P, N, i, j, kk);
+        double factor = kspace_factor(P, N, i, j0 + jl, kk);
         double2 v = make_double2(0, 0);
         if (factor != 0) {
             v = r[kk];
@@ -111,10 +111,10 @@ __global__ __launch_bounds__(256) void k_kspace(double2 *__restrict__ slab, i64 
 }
 
 int cgk_kspace(cg_ctx *c, int deconv_order, double C, int long_range, double E) {
-    i64 rows = c->N * c->N;
+    i64 rows = c->N * c->f_nj;
     int block = c->N / 2 + 1 >= 256 ? 256 : (c->N / 2 + 1 > 64 ? 128 : 64);
-    hipLaunchKernelGGL(k_kspace, dim3((unsigned)rows), dim3(block), 0, c->stream,
-                       (double2 *)c->mesh, c->N, c->ny, c->pad / 2,
+    hipLaunchKernelGGL(k_kspace, dim3((unsigned)rows), dim3(block), 0, c->stream, c->four, c->N,
+                       c->f_si, c->pad / 2, c->f_j0, c->f_nj,
                        KspaceParams{c->ktab_n, c->ktab_s, c->ktab_q, deconv_order, long_range, C, E});
     CG_LAUNCH_CHECK();
     return 0;
@@ -280,6 +280,45 @@ __global__ void k_owner_rank(const double *__restrict__ pos, i64 n, CicGeom geo,
     i64 a = wrap(cic1(pos[3 * p], geo.off[0], geo.scale).index - g, N);
     owner[p] = (int)(a / nxl);
 }
+// Destination domain of every listed emigrant (the rows cg_gather_kick_tiled_prepare found
+// leaving the slab with the prepared drift) and the number going to each domain: what
+// exchange() (communication.py:135-517) needs before it can size its messages.  *count is read
+// on the device, so the host enqueues this right behind the gather-kick without waiting.
+__global__ void k_emigrant_dest(const double *__restrict__ pos, const double *__restrict__ mom,
+                                const i64 *__restrict__ idx, const unsigned *__restrict__ count,
+                                i64 cap, double dtm, double L, CicGeom geo, int g, i64 N, i64 nxl,
+                                int *__restrict__ dest, int *__restrict__ send_counts) {
+    i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 n = (i64)*count < cap ? (i64)*count : cap;
+    if (t >= n) return;
+    i64 p = idx[t];
+    // the arithmetic of the fused drift (load_pos<true> in cg_particles.hip): x only
+    double x = pos[3 * p] + mom[3 * p] * dtm;
+    if (!(x > 0 && x < L)) {
+        double m = fmod(x, L);
+        if (m != 0) {
+            if (m < 0) m += L;
+        } else {
+            m = 0.0;
+        }
+        if (m == L) m = 0;
+        x = m;
+    }
+    int d = (int)(wrap(cic1(x, geo.off[0], geo.scale).index - g, N) / nxl);
+    dest[t] = d;
+    atomicAdd(&send_counts[d], 1);
+}
+int cgk_emigrant_dest(cg_ctx *c, const double *pos, const double *mom, const i64 *idx,
+                      const unsigned *count, i64 cap, double dtm, int *dest, int *send_counts) {
+    CG_HIP(hipMemsetAsync(send_counts, 0, sizeof(int) * c->p.nprocs, c->stream));
+    if (cap == 0) return 0;
+    hipLaunchKernelGGL(k_emigrant_dest, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0,
+                       c->stream, pos, mom, idx, count, cap, dtm, c->p.boxsize, c->geom_deposit,
+                       c->p.nghosts, c->N, c->xmap.nxl, dest, send_counts);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
 int cgk_owner_rank(cg_ctx *c, const double *pos, i64 n, int *owner) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_owner_rank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,

@@ -1,4 +1,4 @@
-"""concept_amd.distributed — the PM path sharded over the GPUs of one node.
+"""concept_amd.distributed — particles and the PM kick on x-slab domains.
 
 One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).
 Decomposition: x-SLAB DOMAINS for everything.  Rank r owns the
@@ -16,344 +16,149 @@ Exchange steps per PM kick (what replaces which MPI call site):
   FFT transpose        FFTW-MPI alltoall (fft.c:240)  all_to_all_single, twice
   potential ghosts     communicate_ghosts(grid,'=')   G layers <-> both neighbours
   particle exchange    exchange() (communication.py:135-517) after each drift
-The pack/unpack of the transpose is fused into the y pass of the FFT
-(cg_fft.hip), the halos need no packing at all.
+The mesh side lives in concept_amd.mesh.PotentialMesh (comm=...); this module
+holds the particle side: ParticleStore (capacity arrays of any set of
+per-particle columns, tile sort, exchange()) and the bench's raw PM kick.
 
-The same code runs under the "gloo" backend (tests: two ranks sharing one GPU,
-or CPU-only checks of the exchange logic) by staging messages through host
-memory; that path is for tests only.
+The host waits for the GPU ONCE per step: the gather-kick lists the rows its
+prepared drift takes out of the slab, a small kernel counts them per
+destination, the counts are exchanged on the device and copied to pinned
+memory; the next step starts by waiting for that copy, after which every
+message size is known and the whole step is enqueued without another round
+trip.
 """
+import ctypes
 import os
 
 import torch
-import torch.distributed as dist
 
 from . import lib
+from .comm import Comm
 from .mesh import PotentialMesh
 
 DEAD_X_FACTOR = -4.0  # pos.x = DEAD_X_FACTOR*boxsize marks a vacated particle slot
 
 
-class Comm:
-    """Thin wrapper over torch.distributed that also works on gloo."""
-
-    def __init__(self, group=None):
-        self.group = group
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
-        self.backend = dist.get_backend(group)
-        self.stage = self.backend != 'nccl'  # gloo: stage device tensors through the host
-
-    def all_to_all(self, out, inp, out_splits=None, in_splits=None):
-        if not self.stage:
-            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
-            return
-        # gloo: pairwise exchange of the blocks through host memory
-        P = self.world
-        src = inp.cpu()
-        if in_splits is None:
-            in_splits = [src.shape[0]//P]*P
-            out_splits = [out.shape[0]//P]*P
-        ichunks = list(torch.split(src, in_splits))
-        res = torch.empty(out.shape, dtype=out.dtype)
-        ochunks = list(torch.split(res, out_splits))
-        ops = []
-        for q in range(P):
-            if q == self.rank:
-                ochunks[q].copy_(ichunks[q])
-            else:
-                if ichunks[q].numel():
-                    ops.append(dist.P2POp(dist.isend, ichunks[q].contiguous(), q,
-                                          group=self.group))
-                if ochunks[q].numel():
-                    ops.append(dist.P2POp(dist.irecv, ochunks[q], q, group=self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        out.copy_(res)
-
-    def all_to_all_layers(self, out, inp, nlayers_total, layer0, nlayers, async_op=False):
-        """all_to_all of the layers [layer0, layer0 + nlayers) of every peer block of two
-        transpose buffers (P blocks of `nlayers_total` layers each: the range is one contiguous
-        piece per peer, exchanged in place).  With async_op the RCCL work handle is returned:
-        the exchange runs on RCCL's stream behind what the current stream has queued so far,
-        and `wait()` makes the current stream wait for it."""
-        P = self.world
-        o = out.view(P, nlayers_total, -1)[:, layer0:layer0 + nlayers]
-        i = inp.view(P, nlayers_total, -1)[:, layer0:layer0 + nlayers]
-        if not self.stage:
-            return dist.all_to_all([o[q] for q in range(P)], [i[q] for q in range(P)],
-                                   group=self.group, async_op=async_op)
-        # gloo (tests): pairwise through host memory, synchronously
-        ops, recvs = [], {}
-        for q in range(P):
-            if q == self.rank:
-                o[q].copy_(i[q])
-                continue
-            ops.append(dist.P2POp(dist.isend, i[q].cpu().contiguous(), q, group=self.group))
-            recvs[q] = torch.empty(o[q].shape, dtype=o.dtype)
-            ops.append(dist.P2POp(dist.irecv, recvs[q], q, group=self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        for q, r in recvs.items():
-            o[q].copy_(r)
-        return None
-
-    def sendrecv(self, send, dest, recv, source):
-        """send -> dest while receiving <- source (a ring shift)."""
-        if dest == self.rank and source == self.rank:
-            recv.copy_(send)
-            return
-        if self.stage:
-            s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
-        else:
-            s, r = send, recv
-        ops = []  # empty messages are skipped on both ends (sizes are known to both)
-        if s.numel():
-            ops.append(dist.P2POp(dist.isend, s, dest, group=self.group))
-        if r.numel():
-            ops.append(dist.P2POp(dist.irecv, r, source, group=self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        if self.stage and r.numel():
-            recv.copy_(r)
-
-    def all_gather_ints(self, values):
-        t = torch.tensor(values, dtype=torch.int64)
-        if not self.stage:
-            t = t.cuda()
-        out = [torch.empty_like(t) for _ in range(self.world)]
-        dist.all_gather(out, t, group=self.group)
-        return torch.stack(out).cpu()
+def _vp(t):
+    return ctypes.c_void_p(t.data_ptr())
 
 
 class SlabDomain:
-    """The mesh side of one rank: local mesh slab + exchange buffers."""
+    """One rank's mesh slab with its exchange buffers: a PotentialMesh bound to a process
+    group (kept as the handle bench.py and the tests use)."""
 
     def __init__(self, gridsize, boxsize, nghosts=2, device=None, group=None):
         self.comm = Comm(group)
+        self.comm.force = os.environ.get('CONCEPT_GPU_DIST_FORCE') == '1'
         self.rank, self.world = self.comm.rank, self.comm.world
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device())
         self.device = torch.device(device)
         self.mesh = PotentialMesh(gridsize, boxsize, nghosts=nghosts, device=self.device,
-                                  nprocs=self.world, rank=self.rank)
+                                  comm=self.comm)
         m = self.mesh
         self.N, self.nxl, self.G = m.gridsize, m.nxl, m.ghost_layers
         self.boxsize = float(boxsize)
-        per = m.layer_doubles
-        self._layer = per
-        self.tbuf_a = torch.empty(m.transpose_doubles, dtype=torch.float64, device=self.device)
-        self.tbuf_b = torch.empty(m.transpose_doubles, dtype=torch.float64, device=self.device)
-        self.halo_s = torch.empty(self.G*per, dtype=torch.float64, device=self.device)
-        self.halo_r = torch.empty(self.G*per, dtype=torch.float64, device=self.device)
-        self.next = (self.rank + 1) % self.world
-        self.prev = (self.rank - 1) % self.world
-        # The FFT transposes are exchanged in `pieces` layer ranges so that the transform of one
-        # range overlaps the exchange of the previous one (CONCEPT_GPU_DIST_PIECES, 1 = one
-        # all_to_all_single per transpose).  A piece should stay a large message: >= 8 layers.
-        # CONCEPT_GPU_DIST_FORCE=1: a single rank also takes the transposing solve (tests)
-        self.force_dist = os.environ.get('CONCEPT_GPU_DIST_FORCE') == '1'
-        want = int(os.environ.get('CONCEPT_GPU_DIST_PIECES', '4'))
-        npieces = max(1, min(want, self.nxl//8))
-        if npieces > 1:
-            # a piece should also fit the 256 MB infinity cache, like the chunks of the
-            # single-GPU schedule (cg_fft.hip zy_chunk_layers): its y pass then reads what its
-            # z pass wrote from the cache
-            cache_layers = max(1, int(266e6//(per*8)))
-            npieces = min(max(npieces, -(-self.nxl//cache_layers)), max(1, self.nxl//8))
-        if npieces > 1 and not self.comm.stage:
-            # every rank probes the asynchronous list form of all_to_all once, on a few bytes;
-            # a transport that rejects it falls back to one all_to_all_single per transpose
-            try:
-                a = torch.zeros(2*self.world, dtype=torch.float64, device=self.device)
-                b = torch.empty_like(a)
-                w = self.comm.all_to_all_layers(b, a, 2, 0, 1, async_op=True)
-                if w is not None:
-                    w.wait()
-                torch.cuda.synchronize(self.device)
-            except Exception as e:  # noqa: BLE001 (any backend error means: do not pipeline)
-                print(f'[concept_amd] pipelined transposes disabled: {e}', flush=True)
-                npieces = 1
-        edges = [self.nxl*k//npieces for k in range(npieces + 1)]
-        self.pieces = [(a, b - a) for a, b in zip(edges[:-1], edges[1:])]
+        self.force_dist = self.comm.force
+        self.next, self.prev = self.comm.next, self.comm.prev
 
-    # communicate_ghosts(grid, '+=') after the deposit (mesh.py:609)
+    tbuf_a = property(lambda self: self.mesh.stage)
+    tbuf_b = property(lambda self: self.mesh.four)
+    pieces = property(lambda self: self.mesh.pieces)
+
     def fold_deposit_ghost(self):
-        if self.world == 1:
-            return  # one periodic domain: the deposit wraps by itself, no ghost layers
-        per = self._layer
-        s, r = self.halo_s[:per], self.halo_r[:per]
-        self.mesh.layers_read(self.nxl, 1, s)
-        self.comm.sendrecv(s, self.next, r, self.prev)
-        self.mesh.layers_write(0, 1, r, add=True)
+        self.mesh.fold_ghosts()
 
-    # communicate_ghosts(grid, '=') of the potential (interactions.py:2303-2307)
     def fill_potential_ghosts(self):
-        if self.world == 1:
-            return
-        G = self.G
-        # my first G layers -> previous rank's upper ghosts [nxl, nxl+G)
-        self.mesh.layers_read(0, G, self.halo_s)
-        self.comm.sendrecv(self.halo_s, self.prev, self.halo_r, self.next)
-        self.mesh.layers_write(self.nxl, G, self.halo_r, add=False)
-        # my last G layers -> next rank's lower ghosts [-G, 0)
-        self.mesh.layers_read(self.nxl - G, G, self.halo_s)
-        self.comm.sendrecv(self.halo_s, self.next, self.halo_r, self.prev)
-        self.mesh.layers_write(-G, G, self.halo_r, add=False)
+        self.mesh.fill_ghosts()
 
-    # A3..A8 with the transpose (fft.c:240-257) as all_to_all_single
     def poisson_solve(self, deconv_order, C, long_range=False, E=0.0):
-        m = self.mesh
-        if self.world == 1 and not self.force_dist:
-            m.poisson_solve(deconv_order, C, long_range, E)
-            return
-        if len(self.pieces) == 1:
-            m.dist_fft_forward(self.tbuf_a)
-            self.comm.all_to_all(self.tbuf_b, self.tbuf_a)
-            m.dist_fft_xsolve(self.tbuf_b, deconv_order, C, long_range, E)
-            self.comm.all_to_all(self.tbuf_a, self.tbuf_b)
-            m.dist_fft_backward(self.tbuf_a)
-            return
-        # pipelined: z + y transform of layer range k+1 while range k is on the links ...
-        works = []
-        for l0, nl in self.pieces:
-            m.dist_fft_forward(self.tbuf_a, l0, nl)
-            works.append(self.comm.all_to_all_layers(self.tbuf_b, self.tbuf_a, self.nxl, l0, nl,
-                                                     async_op=True))
-        for w in works:
-            if w is not None:
-                w.wait()
-        m.dist_fft_xsolve(self.tbuf_b, deconv_order, C, long_range, E)
-        # ... and on the way back the inverse y + z of range k while range k+1 arrives
-        works = [self.comm.all_to_all_layers(self.tbuf_a, self.tbuf_b, self.nxl, l0, nl,
-                                             async_op=True) for l0, nl in self.pieces]
-        for (l0, nl), w in zip(self.pieces, works):
-            if w is not None:
-                w.wait()
-            m.dist_fft_backward(self.tbuf_a, l0, nl)
+        self.mesh.poisson_solve(deconv_order, C, long_range, E)
 
 
-class DistributedParticles:
-    """Particles of one rank: arrays with spare capacity, n valid entries."""
+# ---------------------------------------------------------------------------
+# rows: the per-particle columns of a store packed into float64 rows for the wire
+# ---------------------------------------------------------------------------
+def _row_width(cols):
+    return sum((c.shape[1] if c.dim() == 2 else 1) for c in cols)
 
-    def __init__(self, domain, pos, mom, ids=None, slack=1.3):
-        self.domain = domain
-        n = pos.shape[0]
-        cap = int(n*slack) + 1024
-        dev = domain.device
-        self.cap = cap
-        self.n = n
-        self.pos = torch.zeros((cap, 3), dtype=torch.float64, device=dev)
-        self.mom = torch.zeros((cap, 3), dtype=torch.float64, device=dev)
-        self.ids = torch.zeros(cap, dtype=torch.int64, device=dev)
-        self.pos[:n] = pos
-        self.mom[:n] = mom
-        # without ids the sort moves pos and mom only (the id column of the exchanged rows is
-        # carried but meaningless)
-        self.has_ids = ids is not None
-        if ids is not None:
-            self.ids[:n] = ids
-        self.pos2 = torch.empty_like(self.pos)
-        self.mom2 = torch.empty_like(self.mom)
-        self.ids2 = torch.empty_like(self.ids)
-        self.table = domain.mesh.new_tile_table()
-        self.sorted = False
-        # rows that the drift prepared by the last pm_kick(next_dt_over_mass=...) takes out of the
-        # slab, listed by the gather-kick itself (cg_set_emigrant_list)
-        self.emig_idx = torch.empty(max(4096, cap//16), dtype=torch.int64, device=dev)
-        self.emig_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._emig_for = None  # (pos pointer, n, dt_over_mass) the list was made for
-        self.emigrants_total = 0  # rows this rank has shipped so far (all exchanges)
 
-    def check(self):
-        """Raise if a kernel recorded an inconsistency since the last call (synchronises)."""
-        self.domain.mesh.check_errors()
-
-    def touch_mom(self):
-        """Call after changing `mom` by anything but pm_kick: the drift histogram and the
-        emigrant list the last kick prepared no longer describe the particles."""
-        self._emig_for = None
-        self.domain.mesh.prepare_invalidate()
-
-    def view(self, name):
-        return getattr(self, name)[:self.n]
-
-    def drift(self, dt_over_mass):
-        self.domain.mesh.drift(self.view('pos'), self.view('mom'), dt_over_mass)
-        self.sorted = False
-
-    def exchange(self):
-        """exchange() (communication.py:135-517): re-home particles whose lower CIC
-        cell left this rank's slab."""
-        d = self.domain
-        owner = d.mesh.owner_rank(self.view('pos'))
-        self.n, self._expected = exchange_rows(
-            d.comm, owner, self.pos, self.mom, self.ids, self.n, self.cap,
-            DEAD_X_FACTOR*d.boxsize)
-        self.sorted = False
-
-    def drift_exchange_sort(self, dt_over_mass):
-        """drift + exchange + tile sort in fused form: the particles whose DRIFTED position
-        leaves this rank's slab are shipped first (undrifted rows; the receiver drifts them
-        with the same arithmetic), then one fused drift + sort pass pair runs over the
-        compacted local set.  When the previous pm_kick prepared the tile histogram of this
-        drift (next_dt_over_mass), the immigrants' keys are added to it and the sort needs
-        no histogram pass.  Same result as drift(); exchange(); tile_sort()."""
-        d = self.domain
-        m = d.mesh
-        pos, mom = self.view('pos'), self.view('mom')
-        move = None
-        if self._emig_for == (self.pos.data_ptr(), self.n, float(dt_over_mass)):
-            cnt = int(self.emig_count.item())
-            if cnt <= self.emig_idx.numel():  # else the list overflowed: find them the long way
-                move_idx = self.emig_idx[:cnt]
-                move = (move_idx, m.owner_rank_drifted(pos[move_idx], mom[move_idx],
-                                                       dt_over_mass))
-        self._emig_for = None
-        owner = m.owner_rank_drifted(pos, mom, dt_over_mass) if move is None else None
-        n_new, inc = exchange_rows_compact(d.comm, owner, self.pos, self.mom, self.ids, self.n,
-                                           self.cap, move=move)
-        self.emigrants_total += d.comm.last_sent
-        self.n = n_new
-        pos, mom = self.view('pos'), self.view('mom')
-        if inc is not None and inc.shape[0]:
-            m.prepare_rebind(pos, mom, inc[:, 0:3].contiguous(), inc[:, 3:6].contiguous())
+def _pack_rows(cols, idx):
+    """(len(idx), W) float64: the rows `idx` of every column side by side (int64 travels as
+    its bit pattern, the int8 rung indices as exact small doubles)."""
+    rows = torch.empty((idx.numel(), _row_width(cols)), dtype=torch.float64, device=idx.device)
+    o = 0
+    for c in cols:
+        v = c[idx]
+        if c.dim() == 2:
+            rows[:, o:o + c.shape[1]] = v
+            o += c.shape[1]
+            continue
+        if c.dtype == torch.int64:
+            rows[:, o] = v.view(torch.float64)
         else:
-            m.prepare_rebind(pos, mom)
-        m.drift_sort(pos, mom, self.view('ids') if self.has_ids else None, self.pos2[:n_new],
-                     self.mom2[:n_new], self.ids2[:n_new] if self.has_ids else None, dt_over_mass,
-                     self.table)
-        self.pos, self.pos2 = self.pos2, self.pos
-        self.mom, self.mom2 = self.mom2, self.mom
-        self.ids, self.ids2 = self.ids2, self.ids
-        kept = int(self.table[-1].item()) & 0xffffffff
-        if kept != n_new:
-            raise lib.ConceptGPUError(
-                f'rank {d.rank}: fused drift + sort kept {kept} of {n_new} particles')
-        self._expected = kept
-        self.sorted = True
+            rows[:, o] = v.to(torch.float64)
+        o += 1
+    return rows
 
-    def tile_sort(self):
-        d = self.domain
-        d.mesh.sort_particles(self.view('pos'), self.view('mom'),
-                              self.view('ids') if self.has_ids else None,
-                              self.pos2[:self.n], self.mom2[:self.n],
-                              self.ids2[:self.n] if self.has_ids else None, self.table)
-        self.pos, self.pos2 = self.pos2, self.pos
-        self.mom, self.mom2 = self.mom2, self.mom
-        self.ids, self.ids2 = self.ids2, self.ids
-        kept = int(self.table[-1].item()) & 0xffffffff
-        expected = getattr(self, '_expected', self.n)
-        if kept != expected:
-            raise lib.ConceptGPUError(
-                f'rank {d.rank}: tile sort kept {kept} of {expected} particles — particles '
-                'outside this rank\'s slab (exchange() must run after every drift)')
-        self.n = kept
-        self._expected = kept
-        self.sorted = True
+
+def _unpack_rows(cols, rows, where):
+    """cols[where] = rows (where: index tensor or slice)"""
+    o = 0
+    for c in cols:
+        if c.dim() == 2:
+            c[where] = rows[:, o:o + c.shape[1]]
+            o += c.shape[1]
+            continue
+        v = rows[:, o].contiguous()
+        c[where] = v.view(torch.int64) if c.dtype == torch.int64 else v.to(c.dtype)
+        o += 1
+
+
+def exchange_columns(comm, cols, n, cap, move_idx, dest, send_counts, recv_counts):
+    """The data movement of exchange() (communication.py:135-517) once every size is known on
+    the host: the rows `move_idx` (device int64, any order) go to the ranks `dest` (device,
+    same length); send_counts / recv_counts are host lists.  Vacated slots are refilled with
+    immigrants, surplus immigrants are appended, leftover holes are closed with live rows from
+    the tail: afterwards the live rows are exactly [0, n_new).  No host round trip.
+    Returns (n_new, immigrant rows (m_in, W) float64 or None)."""
+    rank = comm.rank
+    m_out, m_in = int(sum(send_counts)), int(sum(recv_counts))
+    if m_out != move_idx.numel() or send_counts[rank] or recv_counts[rank]:
+        raise lib.ConceptGPUError('exchange_columns: inconsistent message sizes')
+    dev = cols[0].device
+    order = torch.argsort(dest.long(), stable=True)
+    move_idx = move_idx[order]
+    rows = _pack_rows(cols, move_idx)
+    inc = torch.empty((m_in, rows.shape[1]), dtype=torch.float64, device=dev)
+    comm.all_to_all(inc, rows, list(recv_counts), list(send_counts))
+    comm.last_sent = m_out
+    n_new = n - m_out + m_in
+    if n_new > cap:
+        raise lib.ConceptGPUError(f'rank {rank}: particle capacity {cap} exceeded ({n_new})')
+    k = min(m_in, m_out)
+    if k:
+        _unpack_rows(cols, inc[:k], move_idx[:k])
+    if m_in > k:
+        _unpack_rows(cols, inc[k:], slice(n, n_new))
+    elif m_out > k:
+        # h = m_out - m_in holes remain and the tail [n_new, n) has exactly h rows: every hole
+        # below n_new takes one live row of the tail.  Fixed-size index algebra, no nonzero().
+        holes, _ = torch.sort(move_idx[k:])
+        h = holes.numel()
+        in_tail = holes >= n_new
+        flag = torch.zeros(h, dtype=torch.int32, device=dev)      # tail rows that are holes
+        flag.index_add_(0, (holes - n_new).clamp(min=0), in_tail.to(torch.int32))
+        live = flag == 0
+        live_rank = torch.cumsum(live.to(torch.int64), 0) - 1
+        by_rank = torch.zeros(h + 1, dtype=torch.int64, device=dev)
+        by_rank[torch.where(live, live_rank, torch.full_like(live_rank, h))] = \
+            torch.arange(h, device=dev) + n_new
+        # the low holes are the first of the sorted list, as many as there are live tail rows
+        src = torch.where(in_tail, holes, by_rank[:h])
+        for c in cols:
+            c[holes] = c[src]
+    return n_new, (inc if m_in else None)
 
 
 def exchange_rows(comm, owner, pos, mom, ids, n, cap, dead_x):
@@ -368,56 +173,7 @@ def exchange_rows(comm, owner, pos, mom, ids, n, cap, dead_x):
     order = torch.argsort(dest, stable=True)
     move_idx, dest = move_idx[order], dest[order]
     send_counts = torch.bincount(dest, minlength=P).cpu().tolist()
-    rows = torch.empty((move_idx.numel(), 7), dtype=torch.float64, device=dev)
-    rows[:, 0:3] = pos[move_idx]
-    rows[:, 3:6] = mom[move_idx]
-    rows[:, 6] = ids[move_idx].view(torch.float64)
-    counts = comm.all_gather_ints(send_counts)  # counts[src][dst]
-    recv_counts = counts[:, rank].tolist()
-    m_in, m_out = int(sum(recv_counts)), int(move_idx.numel())
-    inc = torch.empty((m_in, 7), dtype=torch.float64, device=dev)
-    comm.all_to_all(inc, rows, recv_counts, send_counts)
-    k = min(m_in, m_out)
-    if k:
-        h = move_idx[:k]
-        pos[h] = inc[:k, 0:3]
-        mom[h] = inc[:k, 3:6]
-        ids[h] = inc[:k, 6].contiguous().view(torch.int64)
-    n_slots = n
-    if m_in > k:
-        extra = m_in - k
-        if n + extra > cap:
-            raise lib.ConceptGPUError(
-                f'rank {rank}: particle capacity {cap} exceeded ({n + extra})')
-        pos[n:n + extra] = inc[k:, 0:3]
-        mom[n:n + extra] = inc[k:, 3:6]
-        ids[n:n + extra] = inc[k:, 6].contiguous().view(torch.int64)
-        n_slots = n + extra
-    elif m_out > k:
-        pos[move_idx[k:], 0] = dead_x
-    return n_slots, n - m_out + m_in
-
-
-def exchange_rows_compact(comm, owner, pos, mom, ids, n, cap, move=None):
-    """exchange_rows that leaves no dead rows: vacated slots are refilled with immigrants,
-    surplus immigrants are appended, leftover holes are closed with live rows from the tail.
-    `move` = (row numbers, their owners) when the leaving rows are already known (then `owner`
-    is not needed).  Returns (n_new, immigrant rows (m_in, 7) or None); the live rows are
-    [0, n_new)."""
-    P, rank = comm.world, comm.rank
-    dev = pos.device
-    if move is None:
-        move_idx = torch.nonzero(owner[:n] != rank).flatten()
-        dest = owner[move_idx].long()
-    else:
-        move_idx, dest = move[0], move[1].long()
-    order = torch.argsort(dest, stable=True)
-    move_idx, dest = move_idx[order], dest[order]
-    send_counts = torch.bincount(dest, minlength=P).cpu().tolist()
-    rows = torch.empty((move_idx.numel(), 7), dtype=torch.float64, device=dev)
-    rows[:, 0:3] = pos[move_idx]
-    rows[:, 3:6] = mom[move_idx]
-    rows[:, 6] = ids[move_idx].view(torch.float64)
+    rows = _pack_rows([pos, mom, ids], move_idx)
     counts = comm.all_gather_ints(send_counts)  # counts[src][dst]
     recv_counts = counts[:, rank].tolist()
     m_in, m_out = int(sum(recv_counts)), int(move_idx.numel())
@@ -426,27 +182,343 @@ def exchange_rows_compact(comm, owner, pos, mom, ids, n, cap, move=None):
     comm.all_to_all(inc, rows, recv_counts, send_counts)
     k = min(m_in, m_out)
     if k:
-        h = move_idx[:k]
-        pos[h] = inc[:k, 0:3]
-        mom[h] = inc[:k, 3:6]
-        ids[h] = inc[:k, 6].contiguous().view(torch.int64)
-    n_new = n - m_out + m_in
+        _unpack_rows([pos, mom, ids], inc[:k], move_idx[:k])
+    n_slots = n
     if m_in > k:
-        if n_new > cap:
-            raise lib.ConceptGPUError(f'rank {rank}: particle capacity {cap} exceeded ({n_new})')
-        pos[n:n_new] = inc[k:, 0:3]
-        mom[n:n_new] = inc[k:, 3:6]
-        ids[n:n_new] = inc[k:, 6].contiguous().view(torch.int64)
+        extra = m_in - k
+        if n + extra > cap:
+            raise lib.ConceptGPUError(
+                f'rank {rank}: particle capacity {cap} exceeded ({n + extra})')
+        _unpack_rows([pos, mom, ids], inc[k:], slice(n, n + extra))
+        n_slots = n + extra
     elif m_out > k:
-        holes = move_idx[k:]
-        low = holes[holes < n_new]                       # holes to fill
-        tail = torch.ones(n - n_new, dtype=torch.bool, device=dev)
-        tail[holes[holes >= n_new] - n_new] = False      # tail rows that are holes themselves
-        src = torch.nonzero(tail).flatten() + n_new      # live rows of the tail
-        pos[low] = pos[src]
-        mom[low] = mom[src]
-        ids[low] = ids[src]
-    return n_new, (inc if m_in else None)
+        pos[move_idx[k:], 0] = dead_x
+    return n_slots, n - m_out + m_in
+
+
+def exchange_rows_compact(comm, owner, pos, mom, ids, n, cap, move=None, extra=()):
+    """exchange_rows that leaves no dead rows (see exchange_columns).  `move` = (row numbers,
+    their owners) when the leaving rows are already known (then `owner` is not needed);
+    `extra`: further per-particle columns that travel with the rows.  This form finds the
+    message sizes with host round trips (nonzero, bincount, all_gather); the stepping path
+    gets them from the previous kick instead (ParticleStore.drift_exchange_sort).
+    Returns (n_new, immigrant rows or None); the live rows are [0, n_new)."""
+    P, rank = comm.world, comm.rank
+    if move is None:
+        move_idx = torch.nonzero(owner[:n] != rank).flatten()
+        dest = owner[move_idx].long()
+    else:
+        move_idx, dest = move[0], move[1].long()
+    send_counts = torch.bincount(dest, minlength=P).cpu().tolist()
+    counts = comm.all_gather_ints(send_counts)  # counts[src][dst]
+    recv_counts = counts[:, rank].tolist()
+    return exchange_columns(comm, [pos, mom, ids] + list(extra), n, cap, move_idx, dest,
+                            send_counts, recv_counts)
+
+
+class ParticleStore:
+    """The particle arrays of one rank: named per-particle columns with spare capacity, `n`
+    live rows; tile sort and exchange() move all columns together.  'pos' and 'mom' are
+    float64 (cap, 3) — the reference's AoS layout (species.py:2010-2064); other columns are
+    float64 (cap, 3) / (cap,), int64 (cap,) or int8 (cap,)."""
+
+    def __init__(self, domain, pos, mom, ids=None, slack=1.3, extra=None):
+        """domain: a SlabDomain or a PotentialMesh (its comm may be None: one domain)"""
+        self.domain = domain
+        self.mesh = getattr(domain, 'mesh', domain)
+        self.comm = self.mesh.comm
+        self.multi = self.comm is not None and self.comm.world > 1
+        n = pos.shape[0]
+        cap = int(n*slack) + 1024 if self.multi else n
+        dev = self.mesh.device
+        self.cap, self.n = cap, n
+        self.cols, self.spare = {}, {}
+        self.add_column('pos', pos)
+        self.add_column('mom', mom)
+        # without ids the sort moves pos and mom only
+        self.has_ids = ids is not None
+        if ids is not None:
+            self.add_column('ids', ids)
+        for name, t in (extra or {}).items():
+            self.add_column(name, t)
+        self.table = self.mesh.new_tile_table()
+        self.sorted = False
+        self._expected = n
+        self._slots = None
+        self.last_perm = None
+        # rows that the drift prepared by the last pm_kick(next_dt_over_mass=...) takes out of the
+        # slab, listed by the gather-kick itself (cg_set_emigrant_list)
+        P = self.comm.world if self.comm is not None else 1
+        self.emig_idx = torch.empty(max(4096, cap//16), dtype=torch.int64, device=dev)
+        self.emig_dest = torch.empty(self.emig_idx.numel(), dtype=torch.int32, device=dev)
+        # meta: [emigrant count | send counts (P) | recv counts (P) | rows kept by the last sort]
+        self.meta = torch.zeros(2 + 2*P, dtype=torch.int32, device=dev)
+        self.meta_host = torch.zeros(2 + 2*P, dtype=torch.int32)
+        if dev.type == 'cuda':
+            self.meta_host = self.meta_host.pin_memory()
+        self.meta_event = torch.cuda.Event() if dev.type == 'cuda' else None
+        self._emig_for = None   # (pos pointer, n, dt_over_mass) the list was made for
+        self._kept_pending = None
+        self.emigrants_total = 0  # rows this rank has shipped so far (all exchanges)
+
+    emig_count = property(lambda self: self.meta[0:1])
+
+    # -- columns ----------------------------------------------------------------
+    def add_column(self, name, values=None, dtype=None, width=None):
+        dev = self.mesh.device
+        if values is not None:
+            shape = (self.cap,) + tuple(values.shape[1:])
+            t = torch.zeros(shape, dtype=values.dtype, device=dev)
+            t[:values.shape[0]] = values
+        else:
+            shape = (self.cap,) if width is None else (self.cap, width)
+            t = torch.zeros(shape, dtype=dtype, device=dev)
+        self.cols[name] = t
+        self.spare.pop(name, None)
+
+    def drop_column(self, name):
+        self.cols.pop(name, None)
+        self.spare.pop(name, None)
+
+    def view(self, name):
+        return self.cols[name][:self.n]
+
+    def __getattr__(self, name):  # store.pos / .mom / .ids: the full-capacity buffers
+        cols = self.__dict__.get('cols')
+        if cols is not None and name in cols:
+            return cols[name]
+        raise AttributeError(name)
+
+    def _others(self):
+        return [k for k in self.cols if k not in ('pos', 'mom')]
+
+    def _columns(self):
+        return [self.cols['pos'], self.cols['mom']] + [self.cols[k] for k in self._others()]
+
+    def _spare(self, name):
+        t = self.spare.get(name)
+        c = self.cols[name]
+        if t is None or t.shape != c.shape:
+            t = self.spare[name] = torch.empty_like(c)
+        return t
+
+    def resize(self, n, cap=None):
+        """Set the number of live rows (new rows are zero), growing the buffers if needed."""
+        cap = max(cap or 0, n)
+        if cap > self.cap:
+            for name, c in list(self.cols.items()):
+                t = torch.zeros((cap,) + tuple(c.shape[1:]), dtype=c.dtype, device=c.device)
+                t[:self.n] = c[:self.n]
+                self.cols[name] = t
+            self.spare.clear()
+            self.cap = cap
+            self._slots = None
+            if self.emig_idx.numel() < max(4096, cap//16):
+                self.emig_idx = torch.empty(max(4096, cap//16), dtype=torch.int64,
+                                            device=self.mesh.device)
+                self.emig_dest = torch.empty(self.emig_idx.numel(), dtype=torch.int32,
+                                             device=self.mesh.device)
+        self.n = self._expected = n
+        self.sorted = False
+        self.touch_mom()
+
+    # -- bookkeeping ------------------------------------------------------------
+    def check(self):
+        """Raise if a kernel recorded an inconsistency since the last call (synchronises)."""
+        self._check_kept(wait=True)
+        self.mesh.check_errors()
+
+    def touch_mom(self):
+        """Call after changing `mom` by anything but pm_kick: the drift histogram and the
+        emigrant list the last kick prepared no longer describe the particles."""
+        self._emig_for = None
+        self.mesh.prepare_invalidate()
+
+    def _note_kept(self, expected):
+        """Record table[-1] (rows the sort kept) for a deferred comparison: read on the next
+        occasion the host waits for the GPU anyway."""
+        self.meta[-1:].copy_(self.table[-1:])
+        self._kept_pending = expected
+
+    def _check_kept(self, wait):
+        if self._kept_pending is None:
+            return
+        kept = int(self.meta[-1].item()) if wait else int(self.meta_host[-1].item())
+        kept &= 0xffffffff
+        expected, self._kept_pending = self._kept_pending, None
+        if kept != expected:
+            raise lib.ConceptGPUError(
+                f'rank {self.mesh.rank}: the tile sort kept {kept} of {expected} particles — '
+                'particles outside this rank\'s slab (exchange() must run after every drift)')
+
+    # -- A11 + A12 ----------------------------------------------------------------
+    def drift(self, dt_over_mass):
+        self.mesh.drift(self.view('pos'), self.view('mom'), dt_over_mass)
+        self.sorted = False
+        self._emig_for = None
+
+    def exchange(self):
+        """exchange() (communication.py:135-517): re-home particles whose lower CIC
+        cell left this rank's slab."""
+        self.sorted = False
+        if not self.multi:
+            return
+        owner = self.mesh.owner_rank(self.view('pos'))
+        n_new, _ = self._exchange_owner(owner)
+        self.n = self._expected = n_new
+
+    def _exchange_owner(self, owner):
+        """exchange with the message sizes found the long way (host round trips)"""
+        P, rank = self.comm.world, self.comm.rank
+        move_idx = torch.nonzero(owner[:self.n] != rank).flatten()
+        dest = owner[move_idx].long()
+        send_counts = torch.bincount(dest, minlength=P).cpu().tolist()
+        recv_counts = self.comm.all_gather_ints(send_counts)[:, rank].tolist()
+        n_new, inc = exchange_columns(self.comm, self._columns(), self.n, self.cap, move_idx,
+                                      dest, send_counts, recv_counts)
+        self.emigrants_total += int(sum(send_counts))
+        return n_new, inc
+
+    def prepare_exchange(self, dt_over_mass):
+        """Right after the gather-kick that listed the leavers of the coming drift: count them
+        per destination on the device, swap the counts with the peers, start their copy to
+        pinned memory.  Nothing here waits for the GPU."""
+        m = self.mesh
+        lib.check(lib.raw().cg_emigrant_dest(
+            m._ctx, _vp(self.cols['pos']), _vp(self.cols['mom']), _vp(self.emig_idx),
+            _vp(self.meta), self.emig_idx.numel(), float(dt_over_mass), _vp(self.emig_dest),
+            _vp(self.meta[1:])))
+        P = self.comm.world
+        self.comm.all_to_all(self.meta[1 + P:1 + 2*P], self.meta[1:1 + P])
+        self.meta_host.copy_(self.meta, non_blocking=True)
+        if self.meta_event is not None:
+            self.meta_event.record()
+        self._emig_for = (self.cols['pos'].data_ptr(), self.n, float(dt_over_mass))
+
+    def drift_exchange_sort(self, dt_over_mass):
+        """drift + exchange + tile sort in fused form: the particles whose DRIFTED position
+        leaves this rank's slab are shipped first (undrifted rows; the receiver drifts them
+        with the same arithmetic), then one fused drift + sort pass pair runs over the
+        compacted local set.  When the previous pm_kick prepared this drift
+        (next_dt_over_mass), the leavers and every message size are already known — one wait
+        for the pinned counts, then the whole step is enqueued — and the immigrants' keys are
+        added to the prepared histogram so that the sort needs no histogram pass.  Same result
+        as drift(); exchange(); tile_sort()."""
+        m = self.mesh
+        inc = None
+        if self.multi:
+            P = self.comm.world
+            done = False
+            if self._emig_for == (self.cols['pos'].data_ptr(), self.n, float(dt_over_mass)):
+                if self.meta_event is not None:
+                    self.meta_event.synchronize()  # the one wait of the step
+                self._check_kept(wait=False)
+                host = self.meta_host.tolist()
+                cnt = host[0] & 0xffffffff
+                if cnt <= self.emig_idx.numel():  # else the list overflowed: the long way
+                    n_new, inc = exchange_columns(
+                        self.comm, self._columns(), self.n, self.cap, self.emig_idx[:cnt],
+                        self.emig_dest[:cnt], host[1:1 + P], host[1 + P:1 + 2*P])
+                    self.emigrants_total += cnt
+                    done = True
+            self._emig_for = None
+            if not done:
+                owner = m.owner_rank_drifted(self.view('pos'), self.view('mom'), dt_over_mass)
+                n_new, inc = self._exchange_owner(owner)
+            self.n = n_new
+        pos, mom = self.view('pos'), self.view('mom')
+        if inc is not None and inc.shape[0]:
+            m.prepare_rebind(pos, mom, inc[:, 0:3].contiguous(), inc[:, 3:6].contiguous())
+        else:
+            m.prepare_rebind(pos, mom)
+        self._sort(dt_over_mass)
+        self._expected = self.n
+        self._note_kept(self.n)
+
+    def tile_sort(self):
+        self._sort(None)
+        if not self.multi:
+            return
+        kept = int(self.table[-1].item()) & 0xffffffff
+        if kept != self._expected:
+            raise lib.ConceptGPUError(
+                f'rank {self.mesh.rank}: tile sort kept {kept} of {self._expected} particles — '
+                'particles outside this rank\'s slab (exchange() must run after every drift)')
+        self.n = self._expected = kept
+
+    def _sort(self, dt_over_mass):
+        """(drift +) tile sort of pos and mom into the spare buffers; the other columns follow
+        through the permutation (a single int64 column travels inside the sort kernel)."""
+        m, n = self.mesh, self.n
+        others = self._others()
+        p2, m2 = self._spare('pos'), self._spare('mom')
+        ride = others[0] if len(others) == 1 and self.cols[others[0]].dtype == torch.int64 \
+            else None
+        if ride is not None:
+            i_in, i_out = self.cols[ride][:n], self._spare(ride)[:n]
+        elif others:
+            if self._slots is None or self._slots.numel() < self.cap:
+                self._slots = torch.arange(self.cap, dtype=torch.int64, device=m.device)
+                self._perm = torch.empty_like(self._slots)
+            i_in, i_out = self._slots[:n], self._perm[:n]
+        else:
+            i_in = i_out = None
+        if dt_over_mass is None:
+            m.sort_particles(self.view('pos'), self.view('mom'), i_in, p2[:n], m2[:n], i_out,
+                             self.table)
+        else:
+            m.drift_sort(self.view('pos'), self.view('mom'), i_in, p2[:n], m2[:n], i_out,
+                         dt_over_mass, self.table)
+        for name, new in (('pos', p2), ('mom', m2)):
+            self.spare[name], self.cols[name] = self.cols[name], new
+        if ride is not None:
+            self.spare[ride], self.cols[ride] = self.cols[ride], self.spare[ride]
+        elif others:
+            for name in others:
+                c = self.cols[name]
+                c[:n] = c[:n][i_out]
+        self.last_perm = i_out if (others and ride is None) else None
+        self.sorted = True
+
+
+DistributedParticles = ParticleStore  # the name bench.py and the tests grew up with
+
+
+def ship_boundary_positions(mesh, pos, margin):
+    """sendrecv_component (communication.py:847-1130) for x-slab domains: the positions of the
+    particles within `margin` of a slab face go to the ring neighbour beyond that face.
+    Returns (from_prev, from_next): the neighbours' particles near MY faces.  Only positions
+    travel: the sweep is one-sided, every rank kicks its own receivers with their own rung
+    factors, so neither the suppliers' rungs nor any Δmom crosses the wire."""
+    comm = mesh.comm
+    L, N = mesh.boxsize, mesh.gridsize
+    cell = L/N
+    slab_w = mesh.nxl*cell
+    xlo = (mesh.x0 + 0.5)*cell   # lower CIC cell in [x0, x0 + nxl)  <=>  x in [xlo, xlo + slab_w)
+    rel = torch.remainder(pos[:, 0] - xlo, L)
+    to_prev = pos[rel < margin]
+    to_next = pos[rel >= slab_w - margin]
+
+    def ship(send, dest, source):
+        cnt = torch.tensor([send.shape[0]], dtype=torch.int64, device=send.device)
+        got = torch.empty_like(cnt)
+        comm.sendrecv(cnt, dest, got, source)
+        recv = torch.empty((int(got.item()), 3), dtype=torch.float64, device=send.device)
+        comm.sendrecv(send.contiguous(), dest, recv, source)
+        return recv
+    from_next = ship(to_prev, comm.prev, comm.next)   # what my next rank has near ITS lower face
+    from_prev = ship(to_next, comm.next, comm.prev)
+    return from_prev, from_next
+
+
+def check_shortrange_fits(mesh, range_):
+    cell = mesh.boxsize/mesh.gridsize
+    slab_w = mesh.nxl*cell
+    P = mesh.nprocs
+    if P > 1 and (range_*1.001 >= slab_w or (P == 2 and 2.002*range_ >= slab_w)):
+        raise lib.ConceptGPUError(
+            f'short-range force range {range_:g} too large for slabs of width {slab_w:g} '
+            f'({P} domains): boundary particles would be needed from beyond the ring neighbours')
 
 
 def shortrange_kick(domain, particles, *, scale, range_, tilesize, tablesize, softening,
@@ -459,43 +531,21 @@ def shortrange_kick(domain, particles, *, scale, range_, tilesize, tablesize, so
     particles; because the sweep is one-sided no Δmom travels back (the reference
     returns it because its pair update is symmetric).  Returns Δmom (n, 3)."""
     from . import commons, shortrange
-    d = domain
-    comm, P, rank = d.comm, d.world, d.rank
-    L, N = d.boxsize, d.N
+    m = domain.mesh
+    L = m.boxsize
     nt = int((L/1)/tilesize*(1 + commons.machine_ϵ))  # global tiling, species.py:3943-3950
     if nt < 4:
         raise lib.ConceptGPUError(
             'The global gravity tiling needs to have at least 4 tiles across the box in every '
             'direction (species.py:3971)')
-    cell = L/N
-    slab_w = d.nxl*cell
-    if range_*1.001 >= slab_w or (P == 2 and 2.002*range_ >= slab_w):
-        raise lib.ConceptGPUError('short-range force range too large for the slab width')
+    check_shortrange_fits(m, range_)
     pos = particles.view('pos')
     n = pos.shape[0]
-    # slab in position space: lower CIC cell in [x0, x0 + nxl)  <=>  x in [xlo, xhi) (wrapped)
-    xlo = (d.mesh.x0 + 0.5)*cell
-    x = pos[:, 0]
-    rel = torch.remainder(x - xlo, L)           # 0 .. slab_w for owned particles
-    margin = range_*(1 + 1e-9) + 1e-9*L
-    to_prev = pos[rel < margin]                  # near my lower face -> previous rank
-    to_next = pos[rel >= slab_w - margin]        # near my upper face -> next rank
-
-    def ship(send, dest, source):
-        cnt = torch.tensor([send.shape[0]], dtype=torch.int64, device=send.device)
-        got = torch.empty_like(cnt)
-        comm.sendrecv(cnt, dest, got, source)
-        recv = torch.empty((int(got.item()), 3), dtype=torch.float64, device=send.device)
-        comm.sendrecv(send.contiguous(), dest, recv, source)
-        return recv
-    if P == 1:
-        ghosts = [pos.new_zeros((0, 3))]
+    if m.nprocs == 1:
+        ghosts = []
     else:
-        from_next = ship(to_prev, d.prev, d.next)   # what my next rank has near ITS lower face
-        from_prev = ship(to_next, d.next, d.prev)
-        ghosts = [from_prev, from_next]
+        ghosts = list(ship_boundary_positions(m, pos, range_*(1 + 1e-9) + 1e-9*L))
     supp = torch.cat([pos] + ghosts).contiguous()
-    m = d.mesh
     ext = L/nt
     cells_r = m.shortrange_build(pos.contiguous(), nt, ext)
     cells_s = m.shortrange_build(supp, nt, ext)
@@ -518,23 +568,28 @@ def pm_kick(domain, particles, contribution, deconv_order, C, kick_factor, diff_
     mark = mark or (lambda name: None)
     m = domain.mesh
     m.deposit_tiled(particles.view('pos'), particles.table, contribution, accumulate=False)
-    domain.fold_deposit_ghost()
+    m.fold_ghosts()
     mark('deposit+ghost_fold')
-    domain.poisson_solve(deconv_order, C, long_range, E)
+    m.poisson_solve(deconv_order, C, long_range, E)
     mark('poisson+transposes')
-    domain.fill_potential_ghosts()
+    m.fill_ghosts()
     if next_dt_over_mass is None:
+        particles._emig_for = None
         m.gather_kick_tiled(particles.view('pos'), particles.view('mom'), particles.table,
                             diff_order, kick_factor)
     else:
         # also histogram the tile keys after the NEXT drift and list the rows it takes out of the
         # slab (for drift_exchange_sort)
-        m.set_emigrant_list(particles.emig_idx, particles.emig_count)
-        particles._emig_for = (particles.pos.data_ptr(), particles.n, float(next_dt_over_mass))
+        multi = particles.multi
+        if multi:
+            m.set_emigrant_list(particles.emig_idx, particles.emig_count)
         try:
             m.gather_kick_tiled_prepare(particles.view('pos'), particles.view('mom'),
                                         particles.table, diff_order, kick_factor,
                                         next_dt_over_mass)
         finally:
-            m.set_emigrant_list(None, None)  # the launch holds the pointers; the context must not
+            if multi:  # the launch holds the pointers; the context must not
+                m.set_emigrant_list(None, None)
+        if multi:
+            particles.prepare_exchange(next_dt_over_mass)
     mark('ghost_fill+gather_kick')

@@ -62,6 +62,35 @@ def get_potential_specs(force, method, receivers, suppliers):
     )
 
 
+def _aligned(component, mesh):
+    """On several domains a particle component owns its particles by the x-slabs of ITS grid
+    (lower CIC cell inside the slab).  On a mesh of another grid size the slab
+    faces sit up to half a (coarser) cell elsewhere: such a component is deposited and
+    gathered with the direct kernels through the full halo on both sides, never the tiled
+    ones."""
+    if not mesh.dist or mesh.nprocs == 1 or component.representation != 'particles':
+        return True
+    return component._store.mesh.gridsize == mesh.gridsize
+
+
+def _check_halo_reach(component, mesh, cloud, stencil):
+    """The halo is G = 3 layers (cg_create): refuse what would reach beyond it.  cloud: how
+    far the interpolation reaches from the lower CIC cell (CIC: 0 below, 1 above), stencil:
+    half width of a finite difference fused into the gather."""
+    if _aligned(component, mesh):
+        return
+    import math
+    delta = (mesh.gridsize/component._store.mesh.gridsize - 1)/2
+    up = math.ceil(max(delta, 0.0)) + cloud[1] + stencil
+    down = (1 if delta < 0 else 0) + cloud[0] + stencil
+    if max(up, down) > mesh.ghost_layers:
+        raise ConceptGPUError(
+            f'{component.name}: its particles are distributed by the slabs of its '
+            f'{component._store.mesh.gridsize}^3 grid; on the {mesh.gridsize}^3 mesh they reach '
+            f'{max(up, down)} layers beyond a slab face, the halo holds {mesh.ghost_layers}. '
+            f'Use grid sizes closer to each other or fewer domains.')
+
+
 def _default_fast_path(receivers, suppliers, gridsize_global, force, method, interpolation_order,
                        interlace_upstream, interlace_downstream):
     """The default configuration: particle components only, every upstream / downstream
@@ -115,6 +144,12 @@ def particle_mesh(receivers, suppliers, gridsize_global, quantity, force, method
     fft_factor = float(gridsize_global)**(-3)  # mesh.py:582
     ordered = sorted(suppliers, key=lambda s: not (s.tiles_exact and s.tile_mesh is mesh))
     mesh_started = False
+    aligned = all(_aligned(s, mesh) for s in suppliers)
+    if not aligned:  # clouds land in the halo on both sides: it must start from zero
+        for s in suppliers:
+            _check_halo_reach(s, mesh, (0, 1), 0)
+        mesh.zero()
+        mesh_started = True
     for supplier in ordered:
         contribution = _particle_contribution(supplier, ᔑdt, fft_factor, gridsize_global, boxsize)
         if supplier.tiles_exact and supplier.tile_mesh is mesh:
@@ -125,9 +160,12 @@ def particle_mesh(receivers, suppliers, gridsize_global, quantity, force, method
                 mesh.zero()
             mesh.deposit(supplier.pos, contribution)
         mesh_started = True
+    # communicate_ghosts(grid, '+=') (mesh.py:609); one domain wraps by itself
+    mesh.fold_ghosts(general=not aligned)
     # interactions.py:2092-2118 and :2302
     C, long_range, E = _potential_constants(p, potential, gridsize_global)
     mesh.poisson_solve(deconv_order_global, C, long_range, E)
+    mesh.fill_ghosts()  # communicate_ghosts(grid, '=') (interactions.py:2303-2307)
     # interactions.py:2311-2332 via apply_particle_mesh_force (:2359-2387)
     for receiver in receivers:
         _kick_particles(mesh, receiver, force, method, ᔑdt, ᔑdt_key)
@@ -164,6 +202,7 @@ def _kick_particles(mesh, receiver, force, method, ᔑdt, ᔑdt_key):
     key = (ᔑdt_key[0], receiver.name) if isinstance(ᔑdt_key, tuple) else ᔑdt_key
     differentiation_order = receiver.potential_differentiations[force][method]
     factor = receiver.mass*(-ᔑdt[key])
+    _check_halo_reach(receiver, mesh, (0, 1), differentiation_order//2)
     if _same_tiling(receiver, mesh):
         # tile order (possibly drifted since the sort: strays are handled)
         mesh.gather_kick_tiled(receiver.pos, receiver.mom, receiver.tile_table,
@@ -305,6 +344,17 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
             ordered = sorted(particle_components,
                              key=lambda c: not (simple and c.tiles_exact and _same_tiling(c, up)))
             started = False
+            aligned = all(_aligned(c, up) for c in particle_components)
+            cloud = {1: (0, 1), 2: (0, 1), 3: (1, 2), 4: (1, 2)}[interpolation_order]
+            if shift != (0, 0, 0):
+                cloud = (cloud[0] + 1, cloud[1] + 1)
+            if up.dist and up.nprocs > 1 and max(cloud) > up.ghost_layers:
+                raise ConceptGPUError('interpolation reaches beyond the 3 halo layers')
+            if not aligned:
+                for c in particle_components:
+                    _check_halo_reach(c, up, cloud, 0)
+                up.zero()
+                started = True
             for supplier in ordered:
                 contribution = _particle_contribution(supplier, ᔑdt, fft_factor,
                                                       gridsize_upstream, boxsize)
@@ -320,6 +370,8 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
                     up.deposit(supplier.pos, contribution)
                 else:
                     up.deposit_general(supplier.pos, contribution, interpolation_order, shift)
+            # communicate_ghosts(grid, '+=') (mesh.py:609)
+            up.fold_ghosts(general=not (simple and aligned))
             up.fft_forward()
             up.nullify_nyquist()
             add_to_global(up, interpolation_order*int(bool(deconvolve_upstream)),
@@ -351,6 +403,7 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
                 if differentiation_order:
                     force_grid = mesh_for(gridsize_downstream, 'force')
                     force_grid.diff_from(grid, dim, differentiation_order)
+                    force_grid.fill_ghosts()  # mesh.py:5026-5028
                 force_grid.gather_scalar(receiver.pos, receiver.mom, dim, interpolation_order,
                                          shift, factor)
         for representation in ('fluid', 'particles'):
@@ -390,11 +443,13 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
                             slab.fourier_operate(deconv_order_downstream, len(shifts_downstream),
                                                  shift, diff_dim=dim)
                             slab.poisson_backward()
+                            slab.fill_ghosts()
                             apply_force(slab, dim, subgroup, representation, shift, 0)
                         continue
                     slab = working_slab(mutate_ok)
                     slab.fourier_operate(deconv_order_downstream, len(shifts_downstream), shift)
                     slab.poisson_backward()
+                    slab.fill_ghosts()  # communicate_ghosts(grid, '=') (interactions.py:2307)
                     simple = interpolation_order == 2 and shift == (0, 0, 0)
                     for receiver in (subgroup if representation == 'particles' and simple
                                      else ()):

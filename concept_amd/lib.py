@@ -91,6 +91,11 @@ SYMBOLS = {
     'cg_dist_fft_backward_layers': (_int, [_vp, _vp, _i64, _i64]),
     'cg_layer_doubles': (_i64, [_vp]),
     'cg_owner_rank': (_int, [_vp, _vp, _i64, _vp]),
+    'cg_dist_bind_fourier': (_int, [_vp, _vp]),
+    'cg_dist_fft_x': (_int, [_vp, _vp, _int]),
+    'cg_copy_modes_pack': (_int, [_vp, _i64, _vp, _i64, _vp]),
+    'cg_copy_modes_unpack': (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _int, _int, _vp, _int]),
+    'cg_emigrant_dest': (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _dbl, _vp, _vp]),
     'cg_owner_rank_drifted': (_int, [_vp, _vp, _vp, _i64, _dbl, _vp]),
     'cg_prepare_rebind': (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64]),
     'cg_fetch': (_int, [_vp, _int, _vp, _i64]),

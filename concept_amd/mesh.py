@@ -5,15 +5,19 @@ FFTW slabs (mesh.py:492-710 interpolate_upstream, :3769-3866 get_fftw_slab,
 communication.py:1666 get_buffer): one persistent mesh per (grid size,
 device), living in HBM, reused across calls."""
 import ctypes
+import os
 
 import numpy as np
 import torch
 
+from . import comm as _comm
 from . import lib
 from .lib import cg_params, check
 
 _L = lib.raw()
 _meshes = {}
+_stage_buffers = {}  # (device, doubles) -> transpose staging buffer shared by the meshes of a size
+_cm_plans = {}
 
 
 def _ptr(t):
@@ -22,7 +26,12 @@ def _ptr(t):
 
 class PotentialMesh:
     def __init__(self, gridsize, boxsize, nghosts=2, cell_centered=True, interp_order=2,
-                 device=None, nprocs=1, rank=0):
+                 device=None, nprocs=1, rank=0, comm=None):
+        """comm: a concept_amd.comm.Comm — the mesh then is one x-slab domain of its group
+         and poisson_solve / fft_forward / poisson_backward / copy_modes_from /
+        fold_ghosts / fill_ghosts are collective over it."""
+        if comm is not None:
+            nprocs, rank = comm.world, comm.rank
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device('cuda', device) if isinstance(device, int) else device
@@ -52,6 +61,125 @@ class PotentialMesh:
         self.nprocs, self.rank = int(nprocs), int(rank)
         self.ntiles = (self.table_entries - 1)//8
         self.layer_doubles = int(_L.cg_layer_doubles(self._ctx))  # unit of layers_read/write
+        self.comm = comm
+        self.dist = comm is not None and (comm.world > 1 or getattr(comm, 'force', False))
+        self.four = self.stage = None
+        if self.dist:
+            self._init_dist()
+
+    # -- x-slab domains: buffers of the transposing FFT and of the halos --------------
+    def _init_dist(self):
+        dev, n = self.device, self.transpose_doubles
+        # Fourier-space slab of THIS mesh (persists between forward and inverse transform) and
+        # the staging buffer of the transposes, shared by all meshes of this size
+        self.four = torch.zeros(n, dtype=torch.float64, device=dev)
+        key = (dev, n)
+        if key not in _stage_buffers:
+            _stage_buffers[key] = torch.empty(n, dtype=torch.float64, device=dev)
+        self.stage = _stage_buffers[key]
+        check(_L.cg_dist_bind_fourier(self._ctx, _ptr(self.four)))
+        per, G = self.layer_doubles, self.ghost_layers
+        if self.nprocs > 1:
+            self.halo_s = torch.empty(G*per, dtype=torch.float64, device=dev)
+            self.halo_r = torch.empty(G*per, dtype=torch.float64, device=dev)
+        # The FFT transposes are exchanged in `pieces` layer ranges so that the transform of one
+        # range overlaps the exchange of the previous one (CONCEPT_GPU_DIST_PIECES, 1 = one
+        # all_to_all_single per transpose).  A piece should stay a large message: >= 8 layers.
+        want = int(os.environ.get('CONCEPT_GPU_DIST_PIECES', '4'))
+        npieces = max(1, min(want, self.nxl//8))
+        if npieces > 1:
+            # a piece should also fit the 256 MB infinity cache, like the chunks of the
+            # single-GPU schedule (cg_fft.hip zy_chunk_layers): its y pass then reads what its
+            # z pass wrote from the cache
+            cache_layers = max(1, int(266e6//(per*8)))
+            npieces = min(max(npieces, -(-self.nxl//cache_layers)), max(1, self.nxl//8))
+        if npieces > 1 and not self.comm.stage:
+            # every rank probes the asynchronous list form of all_to_all once, on a few bytes;
+            # a transport that rejects it falls back to one all_to_all_single per transpose
+            ok = getattr(self.comm, 'async_lists_ok', None)
+            if ok is None:
+                try:
+                    a = torch.zeros(2*self.comm.world, dtype=torch.float64, device=dev)
+                    b = torch.empty_like(a)
+                    w = self.comm.all_to_all_layers(b, a, 2, 0, 1, async_op=True)
+                    if w is not None:
+                        w.wait()
+                    torch.cuda.synchronize(dev)
+                    ok = True
+                except Exception as e:  # noqa: BLE001 (any backend error: do not pipeline)
+                    print(f'[concept_amd] pipelined transposes disabled: {e}', flush=True)
+                    ok = False
+                self.comm.async_lists_ok = ok
+            if not ok:
+                npieces = 1
+        edges = [self.nxl*k//npieces for k in range(npieces + 1)]
+        self.pieces = [(a, b - a) for a, b in zip(edges[:-1], edges[1:])]
+
+    def fold_ghosts(self, general=False):
+        """communicate_ghosts(grid, '+=') after a deposit (mesh.py:609,
+        communication.py:563-660).  CIC clouds of owned particles reach one layer above the
+        slab; `general` (other orders, shifted lattices: the mesh was zeroed first) folds the
+        full halo on both sides.  One periodic domain wraps by itself."""
+        if not self.dist or self.nprocs == 1:
+            return
+        c, per, G, nxl = self.comm, self.layer_doubles, self.ghost_layers, self.nxl
+        if not general:
+            s, r = self.halo_s[:per], self.halo_r[:per]
+            self.layers_read(nxl, 1, s)
+            c.sendrecv(s, c.next, r, c.prev)
+            self.layers_write(0, 1, r, add=True)
+            return
+        self.layers_read(nxl, G, self.halo_s)
+        c.sendrecv(self.halo_s, c.next, self.halo_r, c.prev)
+        self.layers_write(0, G, self.halo_r, add=True)
+        self.layers_read(-G, G, self.halo_s)
+        c.sendrecv(self.halo_s, c.prev, self.halo_r, c.next)
+        self.layers_write(nxl - G, G, self.halo_r, add=True)
+
+    def fill_ghosts(self):
+        """communicate_ghosts(grid, '=') (interactions.py:2303-2307, mesh.py:5026-5028): the
+        G halo layers on both sides from the ring neighbours' owned layers."""
+        if not self.dist or self.nprocs == 1:
+            return
+        c, G, nxl = self.comm, self.ghost_layers, self.nxl
+        # my first G layers -> previous rank's upper ghosts [nxl, nxl+G)
+        self.layers_read(0, G, self.halo_s)
+        c.sendrecv(self.halo_s, c.prev, self.halo_r, c.next)
+        self.layers_write(nxl, G, self.halo_r, add=False)
+        # my last G layers -> next rank's lower ghosts [-G, 0)
+        self.layers_read(nxl - G, G, self.halo_s)
+        c.sendrecv(self.halo_s, c.next, self.halo_r, c.prev)
+        self.layers_write(-G, G, self.halo_r, add=False)
+
+    def _dist_forward(self):
+        """z + y transform of the local layers, transpose (fft.c:240-257), pipelined in layer
+        ranges; leaves the y-z transformed data, transposed, in self.four"""
+        c = self.comm
+        if len(self.pieces) == 1:
+            self.dist_fft_forward(self.stage)
+            c.all_to_all(self.four, self.stage)
+            return
+        works = []
+        for l0, nl in self.pieces:  # transform range k+1 while range k is on the links
+            self.dist_fft_forward(self.stage, l0, nl)
+            works.append(c.all_to_all_layers(self.four, self.stage, self.nxl, l0, nl,
+                                             async_op=True))
+        for w in works:
+            if w is not None:
+                w.wait()
+
+    def _dist_backward(self):
+        c = self.comm
+        if len(self.pieces) == 1:
+            c.all_to_all(self.stage, self.four)
+            self.dist_fft_backward(self.stage)
+            return
+        works = [c.all_to_all_layers(self.stage, self.four, self.nxl, l0, nl, async_op=True)
+                 for l0, nl in self.pieces]
+        for (l0, nl), w in zip(self.pieces, works):  # inverse y + z of range k while k+1 arrives
+            if w is not None:
+                w.wait()
+            self.dist_fft_backward(self.stage, l0, nl)
 
     def close(self):
         if self._ctx:
@@ -123,6 +251,13 @@ class PotentialMesh:
                                       float(contribution), int(accumulate)))
 
     def poisson_solve(self, deconv_order, C, long_range=False, E=0.0):
+        if self.dist:
+            # A3..A8 with the transposes as all-to-alls; the k-space factor is fused into the
+            # x pass, which runs on the transposed buffer
+            self._dist_forward()
+            self.dist_fft_xsolve(self.four, deconv_order, C, long_range, E)
+            self._dist_backward()
+            return
         check(_L.cg_poisson_solve(self._ctx, int(deconv_order), float(C), int(long_range),
                                   float(E)))
 
@@ -134,6 +269,12 @@ class PotentialMesh:
         return list(ms)
 
     def poisson_forward(self, deconv_order, C, long_range=False, E=0.0, apply_kernel=True):
+        if self.dist:
+            self._dist_forward()
+            check(_L.cg_dist_fft_x(self._ctx, _ptr(self.four), 0))
+            if apply_kernel:
+                self.poisson_kernel(deconv_order, C, long_range, E)
+            return
         check(_L.cg_poisson_forward(self._ctx, int(deconv_order), float(C), int(long_range),
                                     float(E), int(apply_kernel)))
 
@@ -142,17 +283,21 @@ class PotentialMesh:
                                    float(E)))
 
     def poisson_backward(self):
+        if self.dist:
+            check(_L.cg_dist_fft_x(self._ctx, _ptr(self.four), 1))
+            self._dist_backward()
+            return
         check(_L.cg_poisson_backward(self._ctx))
 
     # -- general particle_mesh() pieces ------------
     def _check_fluid(self, *grids):
-        n = self.gridsize**3
+        n = self.nxl*self.gridsize**2  # a domain holds its own layers of a fluid grid
         for g in grids:
             if (g.dtype != torch.float64 or not g.is_contiguous() or g.device != self.device
                     or g.numel() != n):
                 raise lib.ConceptGPUError(
-                    f'fluid grids must be contiguous float64 tensors of {self.gridsize}^3 '
-                    f'elements on {self.device}')
+                    f'fluid grids must be contiguous float64 tensors of {self.nxl} x '
+                    f'{self.gridsize}^2 elements on {self.device}')
 
     def fluid_add(self, fluid, factor=1.0, operation='+='):
         """add_fluid_to_grid (mesh.py:1685-1753)"""
@@ -161,7 +306,7 @@ class PotentialMesh:
 
     def fft_forward(self):
         """slab_decompose + fft(slab, 'forward') (mesh.py:665-670)"""
-        check(_L.cg_poisson_forward(self._ctx, 0, 0.0, 0, 0.0, 0))
+        self.poisson_forward(0, 0.0, False, 0.0, apply_kernel=False)
 
     def nullify_nyquist(self):
         """nullify_modes(slab, 'nyquist') (mesh.py:3591-3622)"""
@@ -188,10 +333,61 @@ class PotentialMesh:
         """copy_modes(source, self, ...) (mesh.py:1018-1326) for any two grid sizes.  With
         operation '=' and different sizes this mesh is nullified first (mesh.py:686-709)."""
         if source.gridsize != self.gridsize and operation == '=':
-            self.zero()
+            self.zero_fourier()
         sh = (ctypes.c_double*3)(*[float(x) for x in shift])
+        if self.dist and source.gridsize != self.gridsize:
+            return self._copy_modes_exchange(source, deconv_order, nlattice, sh, operation)
         check(_L.cg_copy_modes(self._ctx, source._ctx, int(deconv_order), int(nlattice), sh,
                                int(operation == '+=')))
+        return self
+
+    def zero_fourier(self):
+        """The nullified slab copy_modes '=' starts from (get_fftw_slab(nullify=True),
+        mesh.py:686-709)."""
+        if self.dist:
+            self.four.zero_()
+        else:
+            self.zero()
+
+    def _copy_modes_exchange(self, source, deconv_order, nlattice, sh, operation):
+        """copy_modes between different grid sizes over x-slab domains: the sub-slab exchange
+        of mesh.py:1327-1468.  Row kj of the small cube is owned by rank (kj mod N)//(N/P),
+        which differs between the two grids: the owner in `source` packs the small-cube part
+        of its rows, an all-to-all-v carries them, the owner here applies them."""
+        c, P = self.comm, self.nprocs
+        N_from, N_onto = source.gridsize, self.gridsize
+        key = (N_from, N_onto, P, c.rank, str(self.device))
+        plan = _cm_plans.get(key)
+        if plan is None:
+            NS = min(N_from, N_onto)
+            JBf, JBo = N_from//P, N_onto//P
+            send = [[] for _ in range(P)]  # my rows of `source`, by destination
+            recv = [[] for _ in range(P)]  # my rows of this mesh, by sender
+            for kb in range(-(NS//2 - 1), NS//2):  # rows off the small grid's Nyquist plane
+                bf, bo = kb % N_from, kb % N_onto
+                src, dst = bf//JBf, bo//JBo
+                if src == c.rank:
+                    send[dst].append(bf % JBf)
+                if dst == c.rank:
+                    recv[src].append(bo % JBo)
+            per_row = NS*(NS//2)*2  # doubles: complex[NS][NS/2]
+            rows_s = torch.tensor([r for q in send for r in q], dtype=torch.int32,
+                                  device=self.device)
+            rows_r = torch.tensor([r for q in recv for r in q], dtype=torch.int32,
+                                  device=self.device)
+            plan = (NS, rows_s, rows_r, [len(q)*per_row for q in send],
+                    [len(q)*per_row for q in recv], per_row)
+            _cm_plans[key] = plan
+        NS, rows_s, rows_r, send_counts, recv_counts, per_row = plan
+        out = torch.empty(max(1, rows_s.numel()*per_row), dtype=torch.float64, device=self.device)
+        inc = torch.empty(max(1, rows_r.numel()*per_row), dtype=torch.float64, device=self.device)
+        if rows_s.numel():
+            check(_L.cg_copy_modes_pack(source._ctx, NS, _ptr(rows_s), rows_s.numel(), _ptr(out)))
+        c.all_to_all(inc[:sum(recv_counts)], out[:sum(send_counts)], recv_counts, send_counts)
+        if rows_r.numel():
+            check(_L.cg_copy_modes_unpack(self._ctx, source._ctx, NS, _ptr(rows_r),
+                                          rows_r.numel(), _ptr(inc), int(deconv_order),
+                                          int(nlattice), sh, int(operation == '+=')))
         return self
 
     def deposit_general(self, pos, contribution, order=2, shift=(0.0, 0.0, 0.0)):
@@ -242,6 +438,11 @@ class PotentialMesh:
                             float(factor), f, r, rj, int(low)))
 
     def copy_from(self, other):
+        """slab_downstream_subgroup[...] = slab_downstream (interactions.py:2242-2245): the
+        Fourier-space slab — on x-slab domains that is the transposed buffer, not the mesh"""
+        if self.dist:
+            self.four.copy_(other.four)
+            return
         check(_L.cg_mesh_copy(self._ctx, other._ctx))
 
     def fluid_kick(self, J_dim, rho, P, dim, diff_order, minus_dt, inv_c2):
@@ -452,6 +653,8 @@ class PotentialMesh:
         return self.fetch(lib.CG_FETCH_MESH_REAL)
 
     def fetch_fourier(self):
+        if self.dist:
+            raise lib.ConceptGPUError('fetch_fourier(): single-domain debug fetch')
         return self.fetch(lib.CG_FETCH_MESH_FOURIER)
 
     def cic_indices(self, pos, for_gather=False):
@@ -472,8 +675,9 @@ def get_mesh(gridsize, boxsize, nghosts=2, cell_centered=True, interp_order=2, d
            int(device) if isinstance(device, int) else device.index, role)
     m = _meshes.get(key)
     if m is None:
+        # under an active domain decomposition (comm.init) every mesh is one x-slab domain
         m = _meshes[key] = PotentialMesh(gridsize, boxsize, nghosts, cell_centered, interp_order,
-                                         device)
+                                         device, comm=_comm.active())
     m.use_stream(torch.cuda.current_stream(m.device))
     return m
 
@@ -482,3 +686,5 @@ def free_meshes():
     for m in _meshes.values():
         m.close()
     _meshes.clear()
+    _stage_buffers.clear()
+    _cm_plans.clear()

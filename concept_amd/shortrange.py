@@ -104,13 +104,36 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
         raise ConceptGPUError('shortrange_params: tilesize must be at least the range')
     tile_extent = p.boxsize/nt  # species.py:607-609
     mesh = get_mesh(gridsize, p.boxsize, p.nghosts, p.cell_centered, 2, receivers[0].device)
-    cells = {}
-    for c in {id(c): c for c in list(receivers) + list(suppliers)}.values():
+    involved = list({id(c): c for c in list(receivers) + list(suppliers)}.values())
+    for c in involved:
         if c.representation != 'particles':
             raise ConceptGPUError(f'{c.name}: only particle components have short-range forces')
         if c.Δmom is None:
             c.Δmom = torch.zeros_like(c.mom)
+    # On several domains every supplier component is extended by the neighbour ranks'
+    # particles within the force range of this rank's slab (sendrecv_component,
+    # communication.py:847-1130: "supplier particles in the boundary tiles").  Positions only:
+    # the sweep is one-sided, every rank kicks its OWN receivers with their own rung factors,
+    # so neither the suppliers' rung indices nor any Δmom crosses the wire.
+    multi = mesh.dist and mesh.nprocs > 1
+    cells, supp_pos, supp_cells = {}, {}, {}
+    if multi:
+        from .distributed import check_shortrange_fits, ship_boundary_positions
+        # (components own their particles by the slabs of their own grids: the faces of two
+        # components differ by less than half a cell of the coarser one)
+        slack = max(c._store.mesh.boxsize/c._store.mesh.gridsize for c in involved)
+        for c in involved:
+            check_shortrange_fits(c._store.mesh, sr['range'] + slack)
+    for c in involved:
         cells[id(c)] = mesh.shortrange_build(c.pos, nt, tile_extent)
+        supp_pos[id(c)], supp_cells[id(c)] = c.pos, cells[id(c)]
+        if multi and any(c is s_ for s_ in suppliers):
+            ghosts = ship_boundary_positions(c._store.mesh, c.pos,
+                                             sr['range']*(1 + 1e-9) + slack + 1e-9*p.boxsize)
+            # rows 0..N_local-1 ARE the component's own particles (the sweep's `same`
+            # convention), the ghosts follow
+            supp_pos[id(c)] = torch.cat([c.pos] + list(ghosts)).contiguous()
+            supp_cells[id(c)] = mesh.shortrange_build(supp_pos[id(c)], nt, tile_extent)
     key = 'a**(-3*w_eff₀-3*w_eff₁-1)'
     done = set()
     for r in receivers:
@@ -134,12 +157,12 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
                                            dtype=torch.float64, device=rec.device)
                     rungs = (factors, rec.rung_indices, rec.rung_indices_jumped,
                              rec.lowest_active_rung)
-                    mesh.shortrange_sweep(rec.pos, cells[id(rec)], rec.Δmom, sup.pos,
-                                          cells[id(sup)], nt, same_, table, scaling, r2_max, 0.0,
-                                          rungs)
+                    mesh.shortrange_sweep(rec.pos, cells[id(rec)], rec.Δmom, supp_pos[id(sup)],
+                                          supp_cells[id(sup)], nt, same_, table, scaling, r2_max,
+                                          0.0, rungs)
                 else:
-                    mesh.shortrange_sweep(rec.pos, cells[id(rec)], rec.Δmom, sup.pos,
-                                          cells[id(sup)], nt, same_, table, scaling, r2_max,
+                    mesh.shortrange_sweep(rec.pos, cells[id(rec)], rec.Δmom, supp_pos[id(sup)],
+                                          supp_cells[id(sup)], nt, same_, table, scaling, r2_max,
                                           p.G_Newton*rec.mass*sup.mass*float(integrals[0]))
             sweep(r, s, same)
             if not same and s in receivers:

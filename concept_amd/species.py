@@ -1,15 +1,25 @@
-"""concept_amd.species — the GPU-resident particle Component.
+"""concept_amd.species — the GPU-resident Component.
 
 Mirrors the slice of the reference's Component the gravity path uses
 (species.py:852-1040 fields, :1911-1925 populate, :2010-2064 AoS double[3N]
 pos/mom/Δmom, :2179-2199 drift, :2253-2266 apply_Δmom, :3717-3741 nullify_Δ,
 :2598-2810 tile_sort), with the particle arrays living in HBM as torch CUDA
-tensors of shape (N, 3), float64 — the reference's own "xyzxyz..." layout."""
+tensors of shape (N_local, 3), float64 — the reference's own "xyzxyz..." layout.
+
+Under an active domain decomposition (concept_amd.comm.init) a Component is
+collective like the reference's: N is the global particle number, N_local this
+rank's share (species.py:955-996); the arrays hold the particles of this
+rank's x-slab with spare capacity, Component.drift() ends with exchange()
+(communication.py:135-517, the reference calls it right after every drift,
+main.py:1406) and every per-particle array (pos, mom, Δmom, ids, rung indices)
+travels with its particle.  Fluid grids are the rank's own layers
+double[gridsize/P][gridsize][gridsize]."""
 import collections
 
 import numpy as np
 import torch
 
+from . import comm as _comm
 from . import commons
 from .lib import ConceptGPUError
 from .mesh import get_mesh
@@ -17,14 +27,43 @@ from .mesh import get_mesh
 PotentialGridsizes = collections.namedtuple('PotentialGridsizes', ('upstream', 'downstream'))
 
 
+def _store_column(name):
+    """Component attribute backed by a column of its ParticleStore: the live rows"""
+    def get(self):
+        st = self.__dict__.get('_store')
+        if st is None or name not in st.cols:
+            return None
+        return st.cols[name][:st.n]
+
+    def set_(self, value):
+        st = self._store
+        if value is None:
+            st.drop_column(name)
+            return
+        if name not in st.cols:
+            st.add_column(name, dtype=value.dtype,
+                          width=(value.shape[1] if value.dim() == 2 else None))
+        st.cols[name][:st.n] = value
+    return property(get, set_)
+
+
 class Component:
+    pos = _store_column('pos')
+    mom = _store_column('mom')
+    Δmom = _store_column('Δmom')
+    ids = _store_column('ids')
+    order = _store_column('order')
+    rung_indices = _store_column('rung_indices')
+    rung_indices_jumped = _store_column('rung_indices_jumped')
+
     def __init__(self, name, species, *, N=None, gridsize=None, mass=None, boltzmann_order=-1,
                  device=None, params=None):
         """Component(name, species, N=..., mass=...)                      particles
         Component(name, species, gridsize=..., boltzmann_order=1)        fluid
         (species.py:852-1040).  A fluid component here is what the gravity path needs of
-        it: the grids ϱ, J[0..2] and 𝒫 as float64 tensors (gridsize,)*3 on the GPU (the
-        reference's grid_noghosts); its own evolution (fluid.py) stays with the caller."""
+        it: the grids ϱ, J[0..2] and 𝒫 as float64 tensors on the GPU (the reference's
+        grid_noghosts, this rank's layers); its own evolution (fluid.py) stays with the
+        caller."""
         self.params = p = params or commons.params
         if p is None:
             raise ConceptGPUError('no parameters loaded: call concept_amd.commons.load_params()')
@@ -33,6 +72,12 @@ class Component:
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device())
         self.device = torch.device(device)
+        self.comm = _comm.active()
+        self.nprocs = self.comm.world if self.comm is not None else 1
+        self.rank = self.comm.rank if self.comm is not None else 0
+        self._store = None
+        self.tile_mesh = None
+        self.tiles_exact = False
         if (N is None) == (gridsize is None):
             raise ConceptGPUError(
                 f'{self.name}: give N (particle component) or gridsize (fluid component)')
@@ -41,7 +86,9 @@ class Component:
                 raise ConceptGPUError(f'{self.name}: particle components have '
                                       'boltzmann_order = -1')
             self.representation = 'particles'
-            self._init_particles(int(N), mass)
+            self.N = int(N)
+            self.mass = float(mass)
+            self.softening_length = commons.softening_length(p, self.species, self.N)
         else:
             if boltzmann_order < 0:
                 raise ConceptGPUError(f'{self.name}: fluid components need boltzmann_order >= 0')
@@ -49,41 +96,51 @@ class Component:
             self.boltzmann_order = int(boltzmann_order)
             self._init_fluid(int(gridsize))
         self._init_forces()
+        if self.representation == 'particles':
+            # one domain: the N particles live here from the start; several: populate()
+            # (or populate_local) decides which of them are this rank's
+            self._new_store(self.N if self.nprocs == 1 else 0)
 
     def _init_fluid(self, gridsize):
         if gridsize < 2 or gridsize % 2:
             raise ConceptGPUError(f'{self.name}: fluid grid size {gridsize} must be even and ≥ 2')
+        if gridsize % (2*self.nprocs):
+            raise ConceptGPUError(f'{self.name}: fluid grid size {gridsize} must be divisible '
+                                  f'by 2*nprocs = {2*self.nprocs} (mesh.py:1898-1905)')
         self.gridsize = gridsize
-        self.N = self.N_local = 0
+        self.N = 0
         self.mass = -1.0  # species.py: fluids carry no particle mass
-        shape = (gridsize,)*3
+        self.nxl = gridsize//self.nprocs        # this rank's layers [x0, x0 + nxl)
+        self.x0 = self.nxl*self.rank
+        shape = (self.nxl, gridsize, gridsize)
         z = lambda: torch.zeros(shape, dtype=torch.float64, device=self.device)
         self.ϱ, self.𝒫 = z(), z()
         self.J = [z(), z(), z()]
         self.use_rungs = False
-        self.tile_table = None
+
+    def _new_store(self, n):
+        """n zeroed local particles.  ids: the particles' identifiers (species.py:2040-2064; a
+        snapshot's ID block); order: where each row stood when the arrays were populated —
+        tile_sort and exchange() move both with the particles, host(original_order=True)
+        undoes it through `order`."""
+        from .distributed import ParticleStore
+        dev = self.device
+        z = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        base = torch.arange(n, dtype=torch.int64, device=dev)
+        had_dmom = self._store is not None and 'Δmom' in self._store.cols
+        self._store = ParticleStore(self._mesh(), z, z, None, slack=1.4,
+                                    extra={'ids': base, 'order': base.clone()})
+        if had_dmom:
+            self._store.add_column('Δmom', dtype=torch.float64, width=3)
+        if self.use_rungs:
+            self._store.add_column('rung_indices', dtype=torch.int8)
+            self._store.add_column('rung_indices_jumped', dtype=torch.int8)
         self.tile_mesh = None
         self.tiles_exact = False
 
-    def _init_particles(self, N, mass):
-        p = self.params
-        self.N = self.N_local = N
-        self.mass = float(mass)
-        self.softening_length = commons.softening_length(p, self.species, self.N)
-        self.pos = torch.zeros((self.N, 3), dtype=torch.float64, device=self.device)
-        self.mom = torch.zeros((self.N, 3), dtype=torch.float64, device=self.device)
-        self.Δmom = None  # allocated on first short-range use
-        # ids: the particles' identifiers (species.py:2040-2064 `ids`; a snapshot's ID block);
-        # order: where each row stood when the arrays were populated — tile_sort permutes
-        # both with the particles, host(original_order=True) undoes it through `order`
-        self.ids = torch.arange(self.N, dtype=torch.int64, device=self.device)
-        self.order = torch.arange(self.N, dtype=torch.int64, device=self.device)
-        self._scratch = None
-        # tile order bookkeeping: `tile_table` (first particle of each mesh tile) is
-        # exact right after tile_sort() on `tile_mesh`; a drift makes it approximate
-        self.tile_table = None
-        self.tile_mesh = None
-        self.tiles_exact = False
+    N_local = property(lambda self: self._store.n if self._store is not None else 0)
+    tile_table = property(lambda self: self._store.table
+                          if self._store is not None and self.tile_mesh is not None else None)
 
     def _init_forces(self):
         p = self.params
@@ -99,8 +156,6 @@ class Component:
             self.highest_populated_rung = 0
             self.rungs_N = [0]*p.N_rungs
             self.rungs_N[0] = self.N
-            self.rung_indices = torch.zeros(self.N, dtype=torch.int8, device=self.device)
-            self.rung_indices_jumped = torch.zeros(self.N, dtype=torch.int8, device=self.device)
         # potential grid sizes (species.py:1147-1203): component-level entries of
         # potential_options['gridsize'] first; fluids default to their own grid size,
         # particles to the global one, else cbrt(N) (2 cbrt(N) for p3m)
@@ -135,9 +190,12 @@ class Component:
     # -- data in / out ------------------------------------------------------
     def populate(self, data, var, multi_index=None):
         """populate(array, 'posx'|'posy'|'posz'|'momx'|...) (species.py:1911-1925);
-        also accepts var='pos'/'mom' with an (N, 3) array."""
-        t = torch.as_tensor(np.ascontiguousarray(np.asarray(data, dtype=np.float64)))
+        also accepts var='pos'/'mom' with an (N, 3) array and var='ids'.  On several
+        domains every rank passes the GLOBAL array (N rows / the whole fluid grid) and
+        keeps what it owns: 'pos' decides which rows those are (the x-slab holding their
+        lower CIC cell), so it comes first; populate_local() takes per-rank data."""
         if self.representation == 'fluid':
+            t = torch.as_tensor(np.ascontiguousarray(np.asarray(data, dtype=np.float64)))
             # populate(grid, 'ϱ') | populate(grid, 'J', dim) | populate(grid, '𝒫')
             # (species.py:1926-1990)
             target = {'ϱ': self.ϱ, 'rho': self.ϱ, '𝒫': self.𝒫, 'P': self.𝒫}.get(var)
@@ -151,40 +209,107 @@ class Component:
                 raise ConceptGPUError(
                     f'{self.name}.populate(): grid of shape {tuple(t.shape)} for grid size '
                     f'{self.gridsize}')
-            target.copy_(t)
+            target.copy_(t[self.x0:self.x0 + self.nxl])
             return
         if var == 'ids':
-            self.ids.copy_(torch.as_tensor(np.ascontiguousarray(np.asarray(data, dtype=np.int64))))
-            return
+            t = torch.as_tensor(np.ascontiguousarray(np.asarray(data, dtype=np.int64)))
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(np.asarray(data, dtype=np.float64)))
+        if t.shape[0] != self.N:
+            raise ConceptGPUError(f'{self.name}.populate(): {t.shape[0]} rows for N = {self.N}')
+        if self.nprocs > 1:
+            if var in ('posx', 'posy', 'posz'):
+                # component-wise positions: ownership needs all three
+                pend = self.__dict__.setdefault('_pending_pos', {})
+                pend[var] = t
+                if len(pend) < 3:
+                    return
+                t = torch.stack([pend['posx'], pend['posy'], pend['posz']], 1)
+                self._pending_pos = {}
+                var = 'pos'
+            if var == 'pos':
+                t = t.reshape(self.N, 3).to(self.device)
+                owner = self._mesh().owner_rank(t.contiguous())
+                rows = torch.nonzero(owner == self.rank).flatten()
+                self._new_store(int(rows.numel()))
+                self.pos.copy_(t[rows])
+                self.order.copy_(rows)   # global row numbers: host() reassembles by them
+                self.ids.copy_(rows)
+                self._global_rows = rows
+                for data_, var_ in self.__dict__.pop('_pending_other', []):
+                    self.populate(data_, var_)
+                return
+            if getattr(self, '_global_rows', None) is None:
+                # the positions decide which rows are local: keep this until they are complete
+                self.__dict__.setdefault('_pending_other', []).append((t, var))
+                return
+            t = t.to(self.device)[self._global_rows]
         if var.startswith('pos'):
-            self.tile_table = None
+            self.tile_mesh = None
             self.tiles_exact = False
+            self._store.touch_mom()
             # new positions arrive in the caller's order: rows are "as populated" again
-            self.order = torch.arange(self.N, dtype=torch.int64, device=self.device)
+            if self.nprocs == 1:
+                self.order.copy_(torch.arange(self.N, dtype=torch.int64, device=self.device))
+        if var.startswith('mom'):
+            self._store.touch_mom()
         if var in ('pos', 'mom'):
-            getattr(self, var).copy_(t.reshape(self.N, 3))
+            getattr(self, var).copy_(t.reshape(-1, 3))
+            return
+        if var == 'ids':
+            self.ids.copy_(t)
             return
         prefix, suffix = var[:-1], var[-1]
         getattr(self, prefix)[:, 'xyz'.index(suffix)] = t.to(self.device)
+
+    def populate_local(self, pos, mom, ids=None):
+        """This rank's particles as device tensors (any rows; exchange() then re-homes those
+        that belong to other domains).  N_local may differ between ranks; N stays the global
+        number given to the constructor."""
+        n = pos.shape[0]
+        self._new_store(n)
+        self.pos.copy_(pos)
+        self.mom.copy_(mom)
+        if self.comm is not None:
+            counts = self.comm.all_gather_ints([n])[:, 0].tolist()
+            first = sum(counts[:self.rank])
+        else:
+            first = 0
+        base = torch.arange(first, first + n, dtype=torch.int64, device=self.device)
+        self.order.copy_(base)
+        self.ids.copy_(base if ids is None else ids)
+        self._global_rows = None
+        self.exchange()
 
     def w_eff(self, a=1.0):
         return 0.0  # matter; decaying species are out of scope
 
     def host(self, var, original_order=True):
-        """Host copy of 'pos' | 'mom' | 'Δmom', by default in the order the
-        particles were populated in (undoing tile_sort via ids); for a fluid
-        component 'ϱ' | '𝒫' | 'J' (stacked (3, g, g, g))."""
+        """Host copy of 'pos' | 'mom' | 'Δmom' | 'ids' | 'rung_indices' — of ALL N particles,
+        gathered over the domains — by default in the order the particles were populated in
+        (undoing tile_sort and exchange() through `order`); for a fluid component 'ϱ' | '𝒫' |
+        'J' (stacked (3, g, g, g)), the whole grid."""
         if self.representation == 'fluid':
             if var == 'J':
-                return torch.stack(self.J).cpu().numpy()
+                t = torch.stack(self.J)
+                if self.comm is not None and self.nprocs > 1:
+                    t = self.comm.all_gather_rows(t.transpose(0, 1).contiguous()).transpose(0, 1)
+                return t.cpu().numpy()
             # (identifiers are NFKC-normalised by Python: self.ϱ is the attribute 'ρ')
             import unicodedata
             name = unicodedata.normalize('NFKC', {'rho': 'ϱ'}.get(var, var))
-            return getattr(self, name).cpu().numpy()
+            t = getattr(self, name)
+            if self.comm is not None and self.nprocs > 1:
+                t = self.comm.all_gather_rows(t)
+            return t.cpu().numpy()
         t = getattr(self, var)
+        order = self.order
+        if self.comm is not None and self.nprocs > 1:
+            t = self.comm.all_gather_rows(t.contiguous())
+            order = self.comm.all_gather_rows(order.contiguous())
         if original_order:
             out = torch.empty_like(t)
-            out[self.order] = t
+            out[order] = t
             t = out
         return t.cpu().numpy()
 
@@ -198,53 +323,56 @@ class Component:
                 break
             break
         if g is None:
-            g = max(4, 2*int(round(self.N**(1/3))))
+            g = 2*int(round(self.N**(1/3)))
+        # only the particle bookkeeping (tile order, drift, Δmom) needs this mesh: make any
+        # size admissible (even, >= 4; on P domains a power of two with slabs >= 4 layers)
+        g = max(4, g + g % 2)
+        if self.nprocs > 1 and (g & (g - 1) or g < 4*self.nprocs or g < 16):
+            g = max(16, 4*self.nprocs, 1 << (g - 1).bit_length())
         return get_mesh(g, p.boxsize, p.nghosts, p.cell_centered, 2, self.device)
 
+    def _use_mesh(self, mesh):
+        """The store sorts and exchanges on `mesh` (tile tables are per grid size)."""
+        st = self._store
+        if st.mesh is not mesh:
+            if (st.mesh.gridsize, st.mesh.nprocs) != (mesh.gridsize, mesh.nprocs):
+                st.table = mesh.new_tile_table()
+            st.mesh = mesh
+            st._emig_for = None
+
+    def exchange(self):
+        """exchange() (communication.py:135-517)"""
+        self._store.exchange()
+        self.tiles_exact = False
+        if self.nprocs > 1:
+            self.tile_mesh = None  # rows changed hands: the tile table describes nothing now
+
     def drift(self, ᔑdt, a_next=-1, a=1.0):
-        """species.py:2179-2199.  `a` is universals.a (only enters through
+        """species.py:2179-2199, followed on several domains by exchange() as in the
+        reference's time loop (main.py:1406).  `a` is universals.a (only enters through
         a**(3*w_eff) = 1 for matter)."""
         Δt_over_mass = ᔑdt['a**(-2)']*a**(3*self.w_eff(a=a))/self.mass
-        self._mesh().drift(self.pos, self.mom, Δt_over_mass)
-        self.tiles_exact = False
-
-    def _sorted_into(self, mesh, Δt_over_mass=None):
-        """Run the (drift +) tile sort into the scratch buffers and swap; everything that is
-        indexed by particle (ids, rung indices, Δmom) follows through the slot permutation."""
-        if self._scratch is None:
-            self._scratch = (torch.empty_like(self.pos), torch.empty_like(self.mom),
-                             torch.empty_like(self.ids))
-            self._slots = torch.arange(self.N, dtype=torch.int64, device=self.device)
-        po, mo, perm = self._scratch
-        if self.tile_table is None or self.tile_mesh is not mesh:
-            self.tile_table = mesh.new_tile_table()
-        if Δt_over_mass is None:
-            mesh.sort_particles(self.pos, self.mom, self._slots, po, mo, perm, self.tile_table)
-        else:
-            mesh.drift_sort(self.pos, self.mom, self._slots, po, mo, perm, Δt_over_mass,
-                            self.tile_table)
-        self._scratch = (self.pos, self.mom, perm)
-        self.pos, self.mom = po, mo
-        self.ids = self.ids[perm]
-        self.order = self.order[perm]
-        if self.use_rungs:
-            self.rung_indices = self.rung_indices[perm]
-            self.rung_indices_jumped = self.rung_indices_jumped[perm]
-        if self.Δmom is not None:
-            self.Δmom = self.Δmom[perm]
-        self.tile_mesh = mesh
-        self.tiles_exact = True
+        self._store.drift(Δt_over_mass)
+        self.exchange()
 
     def tile_sort(self, mesh=None):
         """Reorder particle memory into mesh-tile order (the reference's
         tile_sort, species.py:2598-2810, reorders for the same reason)."""
-        self._sorted_into(mesh or self._mesh())
+        mesh = mesh or self._mesh()
+        self._use_mesh(mesh)
+        self._store.tile_sort()
+        self.tile_mesh = mesh
+        self.tiles_exact = True
 
     def drift_sort(self, ᔑdt, a_next=-1, a=1.0, mesh=None):
-        """drift() immediately followed by tile_sort(), fused into one pass pair
-        (cg_drift_sort): same result as the two calls."""
+        """drift() (with its exchange()) immediately followed by tile_sort(), fused into one
+        pass pair (cg_drift_sort): same result as the two calls."""
         Δt_over_mass = ᔑdt['a**(-2)']*a**(3*self.w_eff(a=a))/self.mass
-        self._sorted_into(mesh or self._mesh(), Δt_over_mass)
+        mesh = mesh or self._mesh()
+        self._use_mesh(mesh)
+        self._store.drift_exchange_sort(Δt_over_mass)
+        self.tile_mesh = mesh
+        self.tiles_exact = True
 
     def nullify_Δ(self, specifically=None, only_active=True):
         """species.py:3717-3741: Δmom = 0, for particles on active rungs only when rungs
@@ -256,7 +384,7 @@ class Component:
             raise ConceptGPUError(f'Component.nullify_Δ(): specifically = {specifically} '
                                   'not supported')
         if self.Δmom is None:
-            self.Δmom = torch.zeros_like(self.mom)
+            self._store.add_column('Δmom', dtype=torch.float64, width=3)
         elif only_active and self.use_rungs:
             self._mesh().dmom_nullify(self.Δmom, self.rung_indices, self.lowest_active_rung)
         else:
@@ -266,6 +394,7 @@ class Component:
         """species.py:2253-2266"""
         if self.Δmom is None:
             return
+        self._store.touch_mom()
         if only_active and self.use_rungs:
             self._mesh().dmom_apply(self.mom, self.Δmom, self.rung_indices,
                                     self.lowest_active_rung)
@@ -277,7 +406,6 @@ class Component:
         """species.py:2290-2325"""
         if not self.use_rungs:
             return
-        import numpy as np
         w_eff = self.w_eff(a=a)
         conversion_factors = a**(3*w_eff)/(self.mass*(commons.machine_ϵ
                                                       + np.asarray(ᔑdt_rungs['a**2'])))
@@ -293,23 +421,25 @@ class Component:
     def assign_rungs(self, Δt, fac_softening):
         """species.py:2422-2445"""
         if not self.use_rungs:
-            self.rungs_N[0] = self.N_local
+            self.rungs_N[0] = self.N
             return
         self._mesh().assign_rungs(self.Δmom, self.rung_indices, self.rung_indices_jumped,
                                   self.get_rung_factor(Δt, fac_softening), self.N_rungs)
         self.set_rungs_N()
 
     def flag_rung_jumps(self, Δt, Δt_jump_fac, fac_softening, ᔑdt_rungs):
-        """species.py:2463-2513; returns whether any particle was flagged."""
+        """species.py:2463-2513; returns whether any particle (of any domain) was flagged."""
         if not self.use_rungs:
             return False
-        import numpy as np
         integrals = torch.tensor(np.asarray(ᔑdt_rungs['1']), dtype=torch.float64,
                                  device=self.device)
-        return self._mesh().flag_rung_jumps(
+        flagged = self._mesh().flag_rung_jumps(
             self.Δmom, self.rung_indices, self.rung_indices_jumped, self.lowest_active_rung,
             integrals, self.get_rung_factor(Δt*Δt_jump_fac, fac_softening),
             self.get_rung_factor(Δt/Δt_jump_fac, fac_softening), self.N_rungs)
+        if self.comm is not None and self.nprocs > 1:
+            flagged = self.comm.any(flagged)  # allreduce(..., op=MPI.LOR), species.py:2511
+        return flagged
 
     def apply_rung_jumps(self):
         """species.py:2526-2549"""
@@ -319,8 +449,12 @@ class Component:
         self.set_rungs_N()
 
     def set_rungs_N(self):
-        """species.py:2560-2587 (set_rungs_N + set_lowest_highest_populated_rung)"""
-        counts = torch.bincount(self.rung_indices.long(), minlength=self.N_rungs).cpu().tolist()
+        """species.py:2560-2587 (set_rungs_N + set_lowest_highest_populated_rung): the
+        populations are global (allreduce over the domains, species.py:2571)"""
+        counts = torch.bincount(self.rung_indices.long(), minlength=self.N_rungs).cpu()
+        if self.comm is not None and self.nprocs > 1:
+            counts = self.comm.all_gather_ints(counts[:self.N_rungs].tolist()).sum(0)
+        counts = counts.tolist()
         self.rungs_N = counts[:self.N_rungs]
         populated = [r for r, c in enumerate(self.rungs_N) if c > 0]
         self.lowest_populated_rung = populated[0] if populated else self.N_rungs - 1

@@ -293,6 +293,42 @@ int cg_dist_fft_forward_layers(cg_ctx *ctx, double *send_buf /*DEV*/, int64_t la
                                int64_t nlayers);
 int cg_dist_fft_backward_layers(cg_ctx *ctx, const double *recv_buf /*DEV*/, int64_t layer0,
                                 int64_t nlayers);
+/* The general particle_mesh() on x-slab domains (SURVEY.md §8f rows 1, 1b, 3 over §8e): the
+ * Fourier-space slab must persist between the forward and the inverse transform, because
+ * fourier_operate / copy_modes / the Poisson kernel / the '+=' of several upstream slabs act
+ * on it (interactions.py:2092-2307, mesh.py:654-711).  It lives in a caller-owned buffer of
+ * cg_local_info()[5] doubles in the transposed layout complex[N][N/P + 1][pad/2] — rows kj of
+ * this domain's block, like FFTW-MPI's transposed output (fft.c:55-72).
+ *   cg_dist_bind_fourier  make `buf` the context's Fourier view: cg_fourier_nullify_nyquist,
+ *                         cg_fourier_operate, cg_poisson_kernel, cg_copy_modes (equal sizes)
+ *                         then work on it (single domain: buf = NULL restores the in-place view)
+ *   cg_dist_fft_x         the x pass alone, in place on such a buffer: forward transform =
+ *                         cg_dist_fft_forward -> all-to-all -> cg_dist_fft_x(0); inverse =
+ *                         cg_dist_fft_x(1) -> all-to-all -> cg_dist_fft_backward
+ *   cg_copy_modes_pack / _unpack   copy_modes between DIFFERENT grid sizes (mesh.py:1018-1326
+ *                         with the sub-slab exchange of get_subslabs, mesh.py:1327-1468): row kj
+ *                         of the small cube belongs to different domains in the two grids, so
+ *                         the owner in `from` packs the small-cube part of its rows
+ *                         (out[r][N_small][N_small/2] complex, rows_local = row numbers inside
+ *                         its block), the caller ships them (all-to-all-v), and the owner in
+ *                         `onto` applies factor, phase and '=' / '+=' as cg_copy_modes does
+ *                         (rows_local = the rows' numbers inside ITS block; `from` supplies
+ *                         the deconvolution tables and grid size). */
+int cg_dist_bind_fourier(cg_ctx *ctx, double *buf /*DEV or NULL*/);
+int cg_dist_fft_x(cg_ctx *ctx, double *buf /*DEV*/, int inverse);
+int cg_copy_modes_pack(cg_ctx *from, int64_t n_small, const int32_t *rows_local /*DEV*/,
+                       int64_t n_rows, double *out /*DEV*/);
+int cg_copy_modes_unpack(cg_ctx *onto, cg_ctx *from, int64_t n_small,
+                         const int32_t *rows_local /*DEV*/, int64_t n_rows,
+                         const double *in /*DEV*/, int deconv_order, int nlattice,
+                         const double *shift /*HOST 3 or NULL*/, int op_add);
+/* exchange() without a host round trip per question: destination domain of every listed
+ * emigrant (cg_set_emigrant_list) under the drift pos + mom*dt_over_mass and the number bound
+ * for each domain (send_counts[P], zeroed here).  *count is read on the device. */
+int cg_emigrant_dest(cg_ctx *ctx, const double *pos /*DEV*/, const double *mom /*DEV*/,
+                     const int64_t *idx /*DEV cap*/, const uint32_t *count /*DEV 1*/, int64_t cap,
+                     double dt_over_mass, int32_t *dest /*DEV cap*/,
+                     int32_t *send_counts /*DEV P*/);
 int cg_owner_rank(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n,
                   int32_t *owner_out /*DEV n*/);
 /* The fused step of the x-slab path: cg_owner_rank_drifted gives the owner of every particle
@@ -318,7 +354,10 @@ int cg_prepare_rebind(cg_ctx *ctx, const double *pos /*DEV*/, const double *mom 
  *     (interactions.py:1985-2402) ----------------
  * The fused entry points above cover the default configuration (particle
  * components only, all grid sizes equal, CIC, 'sc' lattice).  The general case
- * is assembled by the caller from one context per (grid size, role) — the
+ * is assembled by the caller from one context per (grid size, role) — on x-slab
+ * domains the real-space operations below act on the local layers (fluid grids are
+ * the domain's own double[N/P][N][N]; ghost layers are folded / filled by the caller
+ * with cg_layers_read / _write), the k-space ones on the bound Fourier view — the
  * reference's 'slab_global', 'slab_updownstream', 'slab_updownstream_subgroup'
  * buffers — with cg_poisson_forward(apply_kernel = 0) / cg_poisson_kernel /
  * cg_poisson_backward and the operations below.

@@ -1,0 +1,74 @@
+"""Worker of tests/test_gpu_distributed.py: one rank of a P-rank run of the Component /
+interactions.gravity() layer over x-slab domains.  The ranks share cuda:0 and talk over gloo
+(test only; production is one GPU per rank over RCCL).  Every rank runs the SAME test body
+the single-domain suite runs — gravity(), Component.drift(), stepper.timeloop, RungStepper are
+collective and unchanged — and asserts on the gathered results."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+
+
+def golden(name):
+    return np.load(os.path.join(REPO, 'tests', 'golden', name + '.npz'))
+
+
+def main():
+    case, arg = sys.argv[1], sys.argv[2]
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from concept_amd import comm
+    comm.init()
+    assert comm.active() is not None and comm.active().world == world
+    if case == 'steps':
+        import test_gpu_p3m
+        test_gpu_p3m.test_timeloop_sequence_vs_reference(golden, arg)
+    elif case == 'rungs':
+        import test_gpu_p3m
+        test_gpu_p3m.test_adaptive_rungs_vs_reference(golden)
+    elif case == 'p3m_kick':
+        import test_gpu_p3m
+        test_gpu_p3m.test_shortrange_vs_golden_and_oracle(golden, arg)
+        test_gpu_p3m.test_p3m_full_kick_any(golden)
+    elif case == 'mixed':
+        import test_gpu_fluid
+        test_gpu_fluid.test_mixed_pm_vs_golden(golden, arg)
+    elif case == 'nonlinnu':
+        import test_gpu_fluid
+        test_gpu_fluid.test_nonlinnu_shape_three_interactions(golden)
+    elif case == 'multigrid':
+        import test_gpu_fluid
+        test_gpu_fluid.test_multigrid_vs_golden(golden, arg)
+    elif case == 'orders':
+        import test_gpu_fluid
+        test_gpu_fluid.test_orders_interlacing_fourier_diff_vs_golden(golden, arg)
+    elif case == 'tiled_general':
+        import test_gpu_fluid
+        test_gpu_fluid.test_general_path_uses_tile_order(golden)
+    elif case == 'pm_api':
+        import test_gpu_pm
+        test_gpu_pm.test_gravity_api_pm(None, golden)
+    elif case == 'k1':
+        import test_gpu_known_answers
+        test_gpu_known_answers.k1_lattice(int(arg), n_lin=16, gridsize=32)
+    elif case == 'k4':
+        import test_gpu_known_answers
+        gs, order = arg.split(',')
+        test_gpu_known_answers.test_k4_sine_wave_fluid_stays_uniform_in_yz(int(gs), int(order))
+    else:
+        raise SystemExit(f'unknown case {case}')
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f'RANK{rank}-OK')
+
+
+if __name__ == '__main__':
+    main()

@@ -79,6 +79,18 @@ CASES = {
                              dist='clustered', diff=2, fluid=dict(gridsize=8),
                              particle_components=2,
                              component_gridsizes={'particles0': (24, 12), 'particles1': (16, 32)}),
+    # the same shape on power-of-two grids (the multi-GPU FFT's sizes), for the runs over
+    # 2 and 4 x-slab domains: global 16, particles0 (up 32, down 16), particles1 (up 16,
+    # down 32), fluid on its own grid 32
+    'multigrid_n8_pow2': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=34,
+                              dist='clustered', diff=2, fluid=dict(gridsize=32),
+                              particle_components=2,
+                              component_gridsizes={'particles0': (32, 16), 'particles1': (16, 32)}),
+    # ... with interlacing and Fourier-space differentiation on top
+    'cic_fcc_multigrid_pow2': dict(method='pm', n=8, gridsize=32, boxsize=64.0, seed=35,
+                                   dist='uniform', diff=0, fluid=dict(gridsize=16),
+                                   interpolation='CIC', interlace=('bcc', 'fcc'),
+                                   component_gridsizes={'particles0': (16, 32)}),
     # particles only, one component: upstream 32 -> global 16 -> downstream 24, order 4
     'multigrid_n8_up32_down24': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=25,
                                      dist='uniform', diff=4, fluid=dict(gridsize=8, count=0),

@@ -155,3 +155,46 @@ print('RCCL-PIECES-OK')
                        stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode()
     assert p.returncode == 0 and 'RCCL-PIECES-OK' in out, out[-3000:]
+
+
+def _run_ranks(world, script, args, timeout=900):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, 'tests', script)] + args,
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0 and f'RANK{r}-OK' in outs[r], f'rank {r} failed:\n{outs[r][-4000:]}'
+
+
+# The Component / gravity() layer over domains: the bodies of the
+# single-domain golden tests, unchanged, on 2 and 4 ranks.  gravity(), Component.drift(),
+# stepper.timeloop and RungStepper are collective; results are gathered by Component.host().
+COMPONENT_CASES = [
+    ('pm_api', 'pm_n16_g32'),               # gravity('pm') + drift + tile_sort + gravity again
+    ('steps', 'steps_pm_n8_g16'),           # A18: init half kick, drift -> kick, PM
+    ('steps', 'steps_p3m_n8_g32'),          # ... P3M: long + short kicks, boundary suppliers
+    ('rungs', '-'),                         # adaptive rungs incl. jumps (rungs_p3m_n8_g32)
+    ('p3m_kick', 'p3m_n8_g32'),
+    ('k1', '1'), ('k1', '2'), ('k1', '5'),  # lattice stays put: pairs across components, domains
+    ('mixed', 'fluid_pm_n8_g16'),           # particles + fluid on the shared mesh
+    ('nonlinnu', '-'),                      # configs[4]'s shape: three mesh solves, two grid sizes
+    ('multigrid', 'multigrid_n8_pow2'),     # copy_modes between grids: rows travel between ranks
+    ('orders', 'cic_fcc_multigrid_pow2'),   # ... with interlacing + Fourier differentiation
+    ('orders', 'tsc_bcc_n8_g16'), ('orders', 'pcs_fcc_fourier_n8_g16'),
+    ('orders', 'ngp_fluid_n8_g16'),
+    ('tiled_general', '-'),
+    ('k4', '16,2'), ('k4', '32,4'),
+]
+
+
+@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('case,arg', COMPONENT_CASES)
+def test_components_over_domains(world, case, arg):
+    _run_ranks(world, 'dist_component_worker.py', [case, arg])

@@ -123,6 +123,10 @@ def test_k4_sine_wave_fluid_stays_uniform_in_yz(gridsize, diff_order):
 
 @pytest.mark.parametrize('ncomponents', [1, 2, 5])
 def test_k1_lattice_stays_put_across_components(ncomponents):
+    k1_lattice(ncomponents)
+
+
+def k1_lattice(ncomponents, n_lin=12, gridsize=36):
     """test/multicomponent, 'tile' subtest (gen_ic.py:21-33, param:25-42): 12^3 particles on
     a perfect cubic lattice, dealt round-robin to 1, 2 or 5 components, P3M with the mesh
     of that test (36): long- and short-range kicks cancel by symmetry for every particle —
@@ -130,10 +134,10 @@ def test_k1_lattice_stays_put_across_components(ncomponents):
     counted exactly once."""
     from concept_amd import commons, interactions
     from concept_amd.species import Component
-    L, n_lin, dt = 36.0, 12, 0.1
+    L, dt = float(gridsize), 0.1
     commons.load_params({
         'boxsize': L,
-        'potential_options': {'gridsize': {'gravity': {'p3m': 36}}},
+        'potential_options': {'gridsize': {'gravity': {'p3m': gridsize}}},
         'select_forces': {'matter': {'gravity': 'p3m'}},
         'select_softening_length': {'matter': f'0.03*boxsize/{n_lin}'}})
     ax = (0.5 + np.arange(n_lin))*L/n_lin

@@ -237,7 +237,8 @@ def _fluid_components(g, particle_diff):
 @pytest.mark.parametrize('name', ['fluid_pm_n8_g16', 'fluid2_pm_n6_g12', 'multigrid_n8_g16',
                                   'multigrid_n8_up32_down24', 'tsc_bcc_n8_g16',
                                   'pcs_fcc_fourier_n8_g16', 'ngp_fluid_n8_g16',
-                                  'cic_fcc_multigrid_n8'])
+                                  'cic_fcc_multigrid_n8', 'multigrid_n8_pow2',
+                                  'cic_fcc_multigrid_pow2'])
 def test_general_particle_mesh_bit_exact(golden, name):
     """gravity('pm') with receivers = suppliers = particles + fluids: momenta, J grids and
     the k-space potential handed to every backward FFT, bit for bit; the multigrid cases
