@@ -406,6 +406,8 @@ def main():
                     help='P3M step (BASELINE configs[2]): long-range mesh with Gaussian cut-off + '
                          'short-range tile sweep (r_s = 1.25 cells, range 4.5 r_s, spline '
                          'softening 0.025*L/cbrt(N))')
+    ap.add_argument('--sr-tiles', action='store_true',
+                    help='P3M: the round-1 sweep (one wavefront per tile, no sub-tile pruning)')
     ap.add_argument('--no-prepare', action='store_true',
                     help='do not fuse the next drift\'s tile histogram into the gather-kick')
     ap.add_argument('--no-sort', action='store_true',
@@ -535,12 +537,18 @@ def main():
             mesh.gather_kick(pos, mom, order, kick_factor)
         mark()
         if sr:
-            cells = mesh.shortrange_build(pos, sr['nt'], L/sr['nt'])
-            mark()
-            # kick_short (main.py:1173-1262): nullify Δmom, sweep, apply — the apply is fused
-            # into the sweep's store when the target is the momentum array itself
-            mesh.shortrange_sweep(pos, cells, mom, pos, cells, sr['nt'], True, sr['table'],
-                                  sr['scaling'], sr['r2_max'], sr['factor'])
+            if args.sr_tiles:  # the one-wavefront-per-tile sweep, for A/B
+                cells = mesh.shortrange_build(pos, sr['nt'], L/sr['nt'])
+                mark()
+                mesh.shortrange_sweep(pos, cells, mom, pos, cells, sr['nt'], True, sr['table'],
+                                      sr['scaling'], sr['r2_max'], sr['factor'])
+            else:
+                cells = mesh.shortrange_cells(pos, sr['nt'], L/sr['nt'])
+                mark()
+                # kick_short (main.py:1173-1262): nullify Δmom, sweep, apply — the apply is
+                # fused into the sweep's store: the target is the momentum array itself
+                mesh.shortrange_sweep_cells(cells, mom, cells, sr['nt'], sr['table'],
+                                            sr['scaling'], sr['r2_max'], sr['factor'])
             mark()
         if record:
             events.append(ev)
@@ -614,13 +622,16 @@ def main():
     }
     if dom == 'sr_sweep':
         # FP64 VALU-bound: pair tests/s against the FP64 vector issue rate
-        npt = n_p/sr['nt']**3
-        tests = n_p*27*npt
+        if args.sr_tiles:   # every receiver against the 27 tiles around its own
+            tests = n_p*27*(n_p/sr['nt']**3)
+            per_test = 15   # FP64 VALU instructions of a pair test that misses: 3 sub, 3 mul,
+            #                 2 add, 1 cmp, 3 mul + 3 add of the (zero) accumulation
+        else:               # half-tile cells: 5 x 5 columns of 6 cells
+            tests = n_p*25*6*(n_p/(2*sr['nt'])**3)
+            per_test = 12   # 3 sub, 3 mul, 2 add, 1 cmp, 3 fma
         ms = kernels[dom]
-        # 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2.4 GHz = one FP64 VALU op per lane-slot
+        # 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2.4 GHz: one FP64 VALU op per lane slot
         valu_peak = 256*4*16*2.4e9
-        per_test = 14  # FP64 VALU instructions of a pair test that misses (3 sub, [3 add], 3 mul,
-        #                2 add, 1 cmp + the select/accumulate 3 fma-free mul-adds = 6): DESIGN §7
         result['roofline'] = {
             'bound': 'valu_fp64', 'kernel': dom, 'unit': 'pair-tests/s',
             'achieved': round(tests/(ms*1e-3), 1), 'peak': round(valu_peak/per_test, 1),

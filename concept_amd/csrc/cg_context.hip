@@ -702,6 +702,65 @@ extern "C" int cg_shortrange_sweep_rungs(cg_ctx *c, const double *pos_r, const u
                                 lowest_active_rung);
 }
 
+extern "C" int cg_shortrange_cells(cg_ctx *c, const double *pos, int64_t n, int64_t nt,
+                                   double tile_extent, uint32_t *order_out,
+                                   uint32_t *offset_out, double *pos_sorted_out) {
+    CG_CHECK(c && offset_out && (n == 0 || (pos && order_out && pos_sorted_out)),
+             "cg_shortrange_cells: null argument");
+    CG_CHECK(nt >= 4, "The global gravity tiling needs to have at least 4 tiles across the box in "
+                      "every direction (species.py:3971); got %lld", (long long)nt);
+    CG_CHECK(nt <= 512 && n < (1ll << 32), "cg_shortrange_cells: size out of range");
+    CG_CHECK(tile_extent > 0, "cg_shortrange_cells: tile_extent must be positive");
+    return cgk_shortrange_cells(c, pos, n, nt, tile_extent, order_out, offset_out,
+                                pos_sorted_out);
+}
+
+static int sweep_cells_checks(cg_ctx *c, const void *a, const void *b, const void *d,
+                              const void *e, const void *f, const void *g, const void *t,
+                              int64_t nt, int64_t tablesize, double r2_index_scaling,
+                              double r2_max) {
+    CG_CHECK(c && a && b && d && e && f && g && t, "cg_shortrange_sweep_cells: null argument");
+    CG_CHECK(nt >= 4 && nt <= 512, "cg_shortrange_sweep_cells: nt = %lld", (long long)nt);
+    // the largest index the sweep can form is int(r2_max*scaling): must be inside the table
+    CG_CHECK((int64_t)(r2_max * r2_index_scaling) < tablesize,
+             "cg_shortrange_sweep_cells: table of %lld entries too short for r2_max*scaling = %g",
+             (long long)tablesize, r2_max * r2_index_scaling);
+    // a cell is half a tile: the force range must not exceed two cells, i.e. one tile
+    CG_CHECK(r2_max <= (c->p.boxsize / (double)nt) * (c->p.boxsize / (double)nt) * (1 + 1e-12),
+             "cg_shortrange_sweep_cells: the force range exceeds the tile extent");
+    return 0;
+}
+
+extern "C" int cg_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted,
+                                         const uint32_t *order_r, const uint32_t *offset_r,
+                                         double *dmom_r, const double *pos_s_sorted,
+                                         const uint32_t *offset_s, int64_t nt,
+                                         const double *table, int64_t tablesize,
+                                         double r2_index_scaling, double r2_max, double factor) {
+    if (sweep_cells_checks(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted, offset_s,
+                           table, nt, tablesize, r2_index_scaling, r2_max))
+        return 1;
+    return cgk_shortrange_sweep_cells(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted,
+                                      offset_s, nt, table, r2_index_scaling, r2_max, factor,
+                                      nullptr, nullptr, nullptr, 0);
+}
+
+extern "C" int cg_shortrange_sweep_cells_rungs(
+    cg_ctx *c, const double *pos_r_sorted, const uint32_t *order_r, const uint32_t *offset_r,
+    double *dmom_r, const double *pos_s_sorted, const uint32_t *offset_s, int64_t nt,
+    const double *table, int64_t tablesize, double r2_index_scaling, double r2_max,
+    const double *factors, const int8_t *rung_r, const int8_t *rung_jumped_r,
+    int lowest_active_rung) {
+    if (sweep_cells_checks(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted, offset_s,
+                           table, nt, tablesize, r2_index_scaling, r2_max))
+        return 1;
+    CG_CHECK(factors && rung_r && rung_jumped_r, "cg_shortrange_sweep_cells_rungs: null argument");
+    return cgk_shortrange_sweep_cells(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted,
+                                      offset_s, nt, table, r2_index_scaling, r2_max, 0.0, factors,
+                                      (const signed char *)rung_r,
+                                      (const signed char *)rung_jumped_r, lowest_active_rung);
+}
+
 extern "C" int cg_dmom_nullify(cg_ctx *c, double *dmom, const int8_t *rung, int64_t n,
                                int lowest_active_rung) {
     CG_CHECK(c && (dmom || n == 0), "cg_dmom_nullify: null argument");

@@ -432,3 +432,443 @@ int cgk_shortrange_sweep(cg_ctx *c, const double *pos_r, const unsigned *order_r
     CG_LAUNCH_CHECK();
     return 0;
 }
+
+// ===========================================================================
+// Sweep over a cell list at HALF-tile granularity (the reference prunes below the tile level
+// with subtiles, interactions.py:1141-1278, species.py:4031-4142).
+//
+// Why: the one-wavefront-per-tile sweep above tests every receiver of a tile against all 27
+// neighbouring tiles (~600 pair tests per particle at the default parameters, ~15 % hits) with
+// 22 receivers x 2 supplier groups = 44 of 64 lanes busy, and it is bound by FP64 VALU issue
+// (17 FP64 instructions of 4 cycles per pair test; rocprofv3: VALUBusy 75 %, no memory
+// stalls).  What helps is fewer wave-iterations, i.e. fewer tests and fuller wavefronts:
+//  * cells of half a tile (extent >= range/2): a receiver cell needs supplier cells no further
+//    than 2 away;
+//  * particles are SORTED by cell (z fastest), positions copied in that order: a column of
+//    cells along z is one contiguous run, staged with plain coalesced loads (no index
+//    indirection, no dependent loads);
+//  * one 256-lane workgroup per tile stages the 6 x 6 columns x 6 cells around it ONCE, its
+//    four wavefronts take the tile's four (x, y) cell columns (2 cells along z, ~5.5
+//    receivers): wave (wx, wy) needs columns [wx, wx+4] x [wy, wy+4] over all 6 cells — per
+//    x that is one contiguous range of the staged array — 25/36 of the staged suppliers,
+//    412 tests per receiver instead of 594, with R x floor(64/R) ~ 60 of 64 lanes busy;
+//  * no self test: a particle paired with itself has x_ji = 0 exactly and contributes
+//    0 * table[0] = 0, as would two distinct particles at one position (the reference skips
+//    i == j by index, interactions.py:1722; the sums are the same);
+//  * the accumulation a += x_ji * f is a fused multiply-add (the order of partners already
+//    differs from the reference's, Δmom is compared to 1e-12); x_ji, r2 and the table index
+//    keep the reference's operation order and are bit-identical.
+// Periodic images: only tiles on the box faces see pieces with an offset; those are swept
+// piece by piece with the (uniform) offset added as the reference does, (xi - xj) + offset.
+// ===========================================================================
+#ifndef CG_SR_NB
+#define CG_SR_NB 2   // pairs per lane whose table loads are in flight together.  Measured at
+                     // 256^3 / 512^3: 2 -> 64 VGPRs, 8 wavefronts per SIMD, sweep 8.6 ms; 4 -> 80
+                     // VGPRs, 6 per SIMD, 9.4 ms; 8 -> 112 VGPRs, 4 per SIMD, 11.8 ms: the table
+                     // loads of a batch are waited for together, occupancy hides them
+#endif
+#ifndef CG_SR_WAVES
+#define CG_SR_WAVES 4  // lower bound of wavefronts per SIMD for the register allocator
+#endif
+constexpr int kSrCap = 624;   // suppliers staged per round: the default tiling stages ~594 per
+                              // tile, more take further rounds; with the slack 18.4 KB of LDS
+                              // -> 8 workgroups (32 wavefronts) per CU
+constexpr int kSrSlack = 128; // masked lanes read up to 2*S - 1 < 128 entries past a range
+constexpr int kSrPieces = 72; // 6 x 6 columns x 2 (a column that wraps around the box in z)
+
+__device__ __forceinline__ unsigned sr_cell(const double *__restrict__ pos, i64 p, double inv,
+                                            double ext, unsigned nt) {
+    // tile index exactly as Tiling.sort (species.py:775-780); the half inside the tile from
+    // the distance to the tile's lower face
+    unsigned c[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const double x = pos[3 * p + d];
+        unsigned t = (unsigned)(i64)((x - 0.0) * inv);
+        t = t >= nt ? nt - 1 : t;
+        const unsigned half = (x - (double)t * ext) >= 0.5 * ext ? 1u : 0u;
+        c[d] = 2u * t + half;
+    }
+    const unsigned nc = 2u * nt;
+    return (c[0] * nc + c[1]) * nc + c[2];
+}
+
+__global__ __launch_bounds__(256) void k_sr_cell_histogram(const double *__restrict__ pos, i64 n,
+                                                           double inv, double ext, unsigned nt,
+                                                           unsigned *__restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned key = p < n ? sr_cell(pos, p, inv, ext, nt) : 0xffffffffu;
+    int rs, rl;
+    sr_wave_runs(key, lane, rs, rl);
+    if (lane == rs && p < n) atomicAdd(&count[key], (unsigned)rl);
+}
+__global__ __launch_bounds__(256) void k_sr_cell_scatter(const double *__restrict__ pos, i64 n,
+                                                         double inv, double ext, unsigned nt,
+                                                         const unsigned *__restrict__ offset,
+                                                         unsigned *__restrict__ cursor,
+                                                         unsigned *__restrict__ order,
+                                                         double *__restrict__ pos_sorted) {
+    const int lane = threadIdx.x & 63;
+    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned key = p < n ? sr_cell(pos, p, inv, ext, nt) : 0xffffffffu;
+    int rs, rl;
+    sr_wave_runs(key, lane, rs, rl);
+    unsigned first = 0;
+    if (lane == rs && p < n) first = offset[key] + atomicAdd(&cursor[key], (unsigned)rl);
+    first = __shfl(first, rs);
+    if (p < n) {
+        const i64 q = (i64)first + (lane - rs);
+        order[q] = (unsigned)p;
+        pos_sorted[3 * q] = pos[3 * p];
+        pos_sorted[3 * q + 1] = pos[3 * p + 1];
+        pos_sorted[3 * q + 2] = pos[3 * p + 2];
+    }
+}
+
+int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
+                         unsigned *order, unsigned *offset, double *pos_sorted) {
+    const double eps = 2.220446049250313e-16;
+    double inv = (1 / tile_extent) * (1 - 2 * eps);
+    i64 ncells = 8 * nt * nt * nt;
+    if ((size_t)(8 * (ncells + 1)) > c->sr_tmp_bytes) {
+        CG_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->sr_tmp);
+        c->sr_tmp = nullptr;
+        CG_HIP(hipMalloc(&c->sr_tmp, 8 * (ncells + 1)));
+        c->sr_tmp_bytes = 8 * (ncells + 1);
+    }
+    unsigned *count = (unsigned *)c->sr_tmp, *cursor = count + (ncells + 1);
+    CG_HIP(hipMemsetAsync(c->sr_tmp, 0, 8 * (ncells + 1), c->stream));
+    i64 blocks = (n + 255) / 256;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_sr_cell_histogram, dim3((unsigned)blocks), dim3(256), 0, c->stream,
+                           pos, n, inv, tile_extent, (unsigned)nt, count);
+        CG_LAUNCH_CHECK();
+    }
+    size_t need = 0;
+    CG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, count, offset, (int)(ncells + 1),
+                                            c->stream));
+    if (need > c->scan_tmp_bytes) {
+        CG_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->scan_tmp);
+        c->scan_tmp = nullptr;
+        CG_HIP(hipMalloc(&c->scan_tmp, need));
+        c->scan_tmp_bytes = need;
+    }
+    CG_HIP(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp, need, count, offset, (int)(ncells + 1),
+                                            c->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_sr_cell_scatter, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos,
+                           n, inv, tile_extent, (unsigned)nt, offset, cursor, order, pos_sorted);
+        CG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// pair tests of this lane's receiver against the staged suppliers [a, b), lane group `sub` of S
+// taking every S-th; SHIFT: the range is a periodic image, offset (ox, oy, oz).  Accumulates
+// sum x_ji * table[...] — the receiver's factor is applied once at the end.  Four pairs per
+// trip: their table loads (hits only) are all issued before the first is used.
+template <bool SHIFT, bool MASK, int NB>
+__device__ __forceinline__ void sr_cell_batch(int k, int S, int b, double xi, double yi, double zi,
+                                              double ox, double oy, double oz, const double *sx,
+                                              const double *sy, const double *sz, double r2_max,
+                                              double r2_index_scaling,
+                                              const double *__restrict__ table, double &ax,
+                                              double &ay, double &az) {
+    // NB pairs of this lane: their table loads (hits only) are all issued before the first use
+    double xj[NB], yj[NB], zj[NB], r2[NB], t[NB];
+    bool hit[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const int kj = k + j * S;
+        xj[j] = xi - sx[kj];                             // interactions.py:1787-1789
+        yj[j] = yi - sy[kj];
+        zj[j] = zi - sz[kj];
+        if (SHIFT) {                                     // gravity.py:299-302
+            xj[j] += ox;
+            yj[j] += oy;
+            zj[j] += oz;
+        }
+        r2[j] = xj[j] * xj[j] + yj[j] * yj[j] + zj[j] * zj[j];  // gravity.py:306
+        hit[j] = r2[j] <= r2_max;                        // gravity.py:311: skip r2 > r2_max
+        if (MASK) hit[j] &= kj < b;                      // (read past the range: staged slack)
+    }
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        t[j] = 0.0;
+        if (hit[j]) t[j] = table[(unsigned)(int)(r2[j] * r2_index_scaling)];  // gravity.py:316-321
+    }
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        ax = __builtin_fma(xj[j], t[j], ax);
+        ay = __builtin_fma(yj[j], t[j], ay);
+        az = __builtin_fma(zj[j], t[j], az);
+    }
+}
+
+// pair tests of this lane's receiver against the staged suppliers [a, b), lane group `sub` of S
+// taking every S-th; SHIFT: the range is a periodic image, offset (ox, oy, oz).  Accumulates
+// sum x_ji * table[...] — the receiver's factor is applied once at the end.
+template <bool SHIFT>
+__device__ __forceinline__ void sr_cell_pairs(int a, int b, int sub, int S, double xi, double yi,
+                                              double zi, double ox, double oy, double oz,
+                                              const double *sx, const double *sy,
+                                              const double *sz, double r2_max,
+                                              double r2_index_scaling,
+                                              const double *__restrict__ table, double &ax,
+                                              double &ay, double &az) {
+    // a, b, S are wave-uniform (scalar registers): rows of S suppliers walked with scalar adds
+    // and compares only (no division); the last one or two rows may stick out of the range
+    int row = a;
+#if CG_SR_NB >= 4
+    for (; row + 4 * S <= b; row += 4 * S)
+        sr_cell_batch<SHIFT, false, 4>(row + sub, S, b, xi, yi, zi, ox, oy, oz, sx, sy, sz, r2_max,
+                                       r2_index_scaling, table, ax, ay, az);
+#endif
+    for (; row + 2 * S <= b; row += 2 * S)
+        sr_cell_batch<SHIFT, false, 2>(row + sub, S, b, xi, yi, zi, ox, oy, oz, sx, sy, sz, r2_max,
+                                       r2_index_scaling, table, ax, ay, az);
+    if (row + S < b)
+        sr_cell_batch<SHIFT, true, 2>(row + sub, S, b, xi, yi, zi, ox, oy, oz, sx, sy, sz, r2_max,
+                                      r2_index_scaling, table, ax, ay, az);
+    else if (row < b)
+        sr_cell_batch<SHIFT, true, 1>(row + sub, S, b, xi, yi, zi, ox, oy, oz, sx, sy, sz, r2_max,
+                                      r2_index_scaling, table, ax, ay, az);
+}
+
+// One receiver chunk's lanes: R receivers x S supplier groups
+struct SrChunk {
+    int R, S, sub, rl;
+    bool active;
+    unsigned pi;
+    double xi, yi, zi, factor;
+};
+__device__ __forceinline__ SrChunk sr_chunk_load(unsigned base, unsigned rend, int lane,
+                                                 const double *__restrict__ pos_r,
+                                                 const unsigned *__restrict__ order_r,
+                                                 const SrParams &P) {
+    SrChunk c;
+    // wave-uniform by construction; tell the compiler (scalar registers, scalar loops)
+    c.R = __builtin_amdgcn_readfirstlane((int)min(64u, rend - base));
+    c.S = min(64 / c.R, 32);
+    c.sub = lane / c.R;
+    c.rl = lane - c.sub * c.R;
+    c.active = c.sub < c.S;
+    const unsigned qi = base + c.rl;  // receiver's row in the sorted order
+    c.pi = 0;
+    c.factor = P.factor;
+    c.xi = c.yi = c.zi = 0;
+    if (c.active) {
+        c.pi = order_r[qi];
+        c.xi = pos_r[3 * (i64)qi];
+        c.yi = pos_r[3 * (i64)qi + 1];
+        c.zi = pos_r[3 * (i64)qi + 2];
+        if (P.rung) {
+            if (P.rung[c.pi] < P.lowest_active) c.active = false;
+            else c.factor = P.factors[P.rung_jumped[c.pi]];
+        }
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CG_SR_WAVES, 8))) void
+k_sr_sweep_cells(
+    const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
+    const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
+    const double *__restrict__ pos_s, const unsigned *__restrict__ off_s,
+    const double *__restrict__ table, SrParams P, unsigned ntiles) {
+    __shared__ double sx[kSrCap + kSrSlack], sy[kSrCap + kSrSlack], sz[kSrCap + kSrSlack];
+    __shared__ unsigned p_beg[kSrPieces], p_cnt[kSrPieces], p_off[kSrPieces + 1];
+    __shared__ signed char p_shift[kSrPieces][4];  // periodic image: -1, 0, +1 box lengths
+    __shared__ unsigned wave_any[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = P.nt, nc = 2 * nt;
+    // one workgroup per tile: a 3-D grid (no index division; tiles adjacent along z, whose
+    // supplier columns overlap most, are dispatched together)
+    const int ta = blockIdx.z, tb = blockIdx.y, tc = blockIdx.x;
+    // receivers of this wave: cell column (2 ta + wx, 2 tb + wy), cells 2 tc and 2 tc + 1
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wx = wave_u >> 1, wy = wave_u & 1;
+    const unsigned rcell = ((unsigned)(2 * ta + wx) * nc + (unsigned)(2 * tb + wy)) * nc + 2 * tc;
+    const unsigned rbeg = __builtin_amdgcn_readfirstlane(off_r[rcell]),
+                   rend = __builtin_amdgcn_readfirstlane(off_r[rcell + 2]);
+    if (lane == 0) wave_any[wave] = rend - rbeg;
+    // supplier pieces: column (cx, cy) of the 6 x 6 around the tile, cells 2 tc - 2 .. 2 tc + 3,
+    // cut in two where the column wraps around the box in z
+    if (tid < kSrPieces) {
+        const int col = tid >> 1, half = tid & 1;
+        const int cx = col / 6, cy = col - 6 * cx;
+        int gx = 2 * ta - 2 + cx, gy = 2 * tb - 2 + cy;
+        int ox = 0, oy = 0, oz = 0;
+        if (gx < 0) { gx += nc; ox = 1; } else if (gx >= nc) { gx -= nc; ox = -1; }
+        if (gy < 0) { gy += nc; oy = 1; } else if (gy >= nc) { gy -= nc; oy = -1; }
+        int z0 = 2 * tc - 2, z1 = 2 * tc + 3;  // inclusive
+        int a = 0, b = -1;                      // this piece's cells [a, b]
+        if (z0 < 0) {
+            if (half == 0) { a = z0 + nc; b = nc - 1; oz = 1; } else { a = 0; b = z1; }
+        } else if (z1 >= nc) {
+            if (half == 0) { a = z0; b = nc - 1; } else { a = 0; b = z1 - nc; oz = -1; }
+        } else if (half == 0) {
+            a = z0;
+            b = z1;
+        }
+        const unsigned base = ((unsigned)gx * nc + (unsigned)gy) * nc;
+        unsigned beg = 0, cnt = 0;
+        if (b >= a) {
+            beg = off_s[base + a];
+            cnt = off_s[base + b + 1] - beg;
+        }
+        p_beg[tid] = beg;
+        p_cnt[tid] = cnt;
+        p_shift[tid][0] = (signed char)ox;
+        p_shift[tid][1] = (signed char)oy;
+        p_shift[tid][2] = (signed char)oz;
+    }
+    // the first receiver chunk does not depend on the staging: its loads (and the Δmom it will
+    // be added to) are in flight while the suppliers are staged
+    SrChunk ch = {};
+    double d0 = 0, d1 = 0, d2 = 0;
+    if (rend > rbeg) {
+        ch = sr_chunk_load(rbeg, rend, lane, pos_r, order_r, P);
+        if (ch.active && ch.sub == 0) {
+            d0 = dmom_r[3 * (i64)ch.pi];
+            d1 = dmom_r[3 * (i64)ch.pi + 1];
+            d2 = dmom_r[3 * (i64)ch.pi + 2];
+        }
+    }
+    __syncthreads();
+    if (wave_any[0] + wave_any[1] + wave_any[2] + wave_any[3] == 0) return;  // empty tile
+    {
+        // exclusive prefix of the 72 piece sizes — by every wave for itself (identical values
+        // into p_off: a wave reads what it wrote itself, no barrier)
+        unsigned v0 = p_cnt[lane], v1 = lane < kSrPieces - 64 ? p_cnt[64 + lane] : 0u;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u0 = __shfl_up(v0, o), u1 = __shfl_up(v1, o);
+            if (lane >= o) {
+                v0 += u0;
+                v1 += u1;
+            }
+        }
+        const unsigned first64 = __shfl(v0, 63);
+        p_off[lane + 1] = v0;
+        if (lane < kSrPieces - 64) p_off[64 + lane + 1] = first64 + v1;
+        if (lane == 0) p_off[0] = 0;
+    }
+    const unsigned total = __builtin_amdgcn_readfirstlane(p_off[kSrPieces]);
+    // tiles on a box face see periodic images: they sweep piece by piece with the piece's offset
+    const bool face = ta == 0 || tb == 0 || tc == 0 || ta == nt - 1 || tb == nt - 1 || tc == nt - 1;
+    const bool simple = rend - rbeg <= 64 && total <= (unsigned)kSrCap;  // one chunk, one window
+    for (unsigned w0 = 0; w0 < total; w0 += kSrCap) {
+        const unsigned w1 = min(total, w0 + (unsigned)kSrCap);
+        if (w0) __syncthreads();  // everybody is done with the previous window
+        // staging: 16 lanes per piece, a wave takes 4 pieces at a time (pieces are short runs of
+        // ~16 suppliers; a longer one takes more turns) — no search for the piece of an entry
+        for (int p0 = wave_u * 4; p0 < kSrPieces; p0 += 16) {
+            const int p = p0 + (lane >> 4);
+            const unsigned beg = p_beg[p], o0 = p_off[p], o1 = p_off[p + 1];
+            const unsigned lo = max(o0, w0), hi = min(o1, w1);  // the part inside this window
+            for (unsigned tn = 0; __any(lo + 16u * tn < hi); tn++) {
+                const unsigned q = lo + (lane & 15) + 16u * tn;
+                if (q < hi) {
+                    const i64 g = (i64)beg + (q - o0);
+                    sx[q - w0] = pos_s[3 * g];
+                    sy[q - w0] = pos_s[3 * g + 1];
+                    sz[q - w0] = pos_s[3 * g + 2];
+                }
+            }
+        }
+        if (tid < kSrSlack) {  // the slack read by masked lanes: finite values
+            sx[w1 - w0 + tid] = 0;
+            sy[w1 - w0 + tid] = 0;
+            sz[w1 - w0 + tid] = 0;
+        }
+        __syncthreads();
+        for (unsigned base = rbeg; base < rend; base += 64) {
+            if (base != rbeg || w0) ch = sr_chunk_load(base, rend, lane, pos_r, order_r, P);
+            const int R = ch.R, S = ch.S, sub = ch.sub;
+            const bool active = ch.active;
+            if (!__any(active)) continue;
+            const double xi = ch.xi, yi = ch.yi, zi = ch.zi;
+            double ax = 0, ay = 0, az = 0;
+            if (active) {
+                for (int xg = 0; xg < 5; xg++) {
+                    const int pf = ((wx + xg) * 6 + wy) * 2;  // first piece of this x; 10 pieces
+                    if (!face) {
+                        const int a = __builtin_amdgcn_readfirstlane(
+                            (int)max(p_off[pf], w0) - (int)w0);
+                        const int b = __builtin_amdgcn_readfirstlane(
+                            (int)min(p_off[pf + 10], w1) - (int)w0);
+                        if (b > a)
+                            sr_cell_pairs<false>(a, b, sub, S, xi, yi, zi, 0, 0, 0, sx, sy, sz,
+                                                 P.r2_max, P.r2_index_scaling, table, ax, ay, az);
+                    } else {
+                        for (int p = pf; p < pf + 10; p++) {
+                            const int a = __builtin_amdgcn_readfirstlane(
+                                (int)max(p_off[p], w0) - (int)w0);
+                            const int b = __builtin_amdgcn_readfirstlane(
+                                (int)min(p_off[p + 1], w1) - (int)w0);
+                            if (b <= a) continue;
+                            const double ox = (double)p_shift[p][0] * P.boxsize,
+                                         oy = (double)p_shift[p][1] * P.boxsize,
+                                         oz = (double)p_shift[p][2] * P.boxsize;
+                            if ((ox != 0) | (oy != 0) | (oz != 0))
+                                sr_cell_pairs<true>(a, b, sub, S, xi, yi, zi, ox, oy, oz, sx, sy,
+                                                    sz, P.r2_max, P.r2_index_scaling, table, ax,
+                                                    ay, az);
+                            else
+                                sr_cell_pairs<false>(a, b, sub, S, xi, yi, zi, 0, 0, 0, sx, sy, sz,
+                                                     P.r2_max, P.r2_index_scaling, table, ax, ay,
+                                                     az);
+                        }
+                    }
+                }
+            }
+            // fold the S partial sums of each receiver (lanes rl, rl + R, ...) into lane rl: a
+            // tree over the groups, ceil(log2 S) shuffle steps (lanes that are not a node of the
+            // tree carry values nobody reads)
+            for (int d = 1; d < S; d <<= 1) {  // S is wave-uniform
+                const int src = (lane + d * R) & 63;
+                const double ux = __shfl(ax, src), uy = __shfl(ay, src), uz = __shfl(az, src);
+                if (sub + d < S) {
+                    ax += ux;
+                    ay += uy;
+                    az += uz;
+                }
+            }
+            ax *= ch.factor;  // gravity.py:321 (total_factor = factors[rung] * table[...])
+            ay *= ch.factor;
+            az *= ch.factor;
+            if (active && sub == 0) {
+                const i64 o = 3 * (i64)ch.pi;
+                if (simple) {  // the Δmom read at the top
+                    dmom_r[o] = d0 + ax;
+                    dmom_r[o + 1] = d1 + ay;
+                    dmom_r[o + 2] = d2 + az;
+                } else {
+                    dmom_r[o] += ax;
+                    dmom_r[o + 1] += ay;
+                    dmom_r[o + 2] += az;
+                }
+            }
+        }
+    }
+}
+
+int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
+                               const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
+                               const unsigned *off_s, i64 nt, const double *table,
+                               double r2_index_scaling, double r2_max, double factor,
+                               const double *factors, const signed char *rung,
+                               const signed char *rung_jumped, int lowest_active) {
+    SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt, 0,
+               factors,      rung,             rung_jumped, lowest_active};
+    const unsigned ntiles = (unsigned)(nt * nt * nt);
+    hipLaunchKernelGGL(k_sr_sweep_cells, dim3((unsigned)nt, (unsigned)nt, (unsigned)nt), dim3(256),
+                       0, c->stream, pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s,
+                       table, P, ntiles);
+    CG_LAUNCH_CHECK();
+    return 0;
+}

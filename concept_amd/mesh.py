@@ -542,6 +542,39 @@ class PotentialMesh:
             float(r2_index_scaling), float(r2_max), _ptr(factors), _ptr(rung), _ptr(rung_jumped),
             int(lowest)))
 
+    def shortrange_cells(self, pos, nt, tile_extent):
+        """Cell list at half-tile granularity with the positions copied in cell order
+        (cg_shortrange_cells): (order, offset, pos_sorted)."""
+        n = self._check_particles(pos)
+        order = torch.empty(max(n, 1), dtype=torch.int32, device=pos.device)
+        offset = torch.empty(8*nt**3 + 1, dtype=torch.int32, device=pos.device)
+        pos_sorted = torch.empty((max(n, 1), 3), dtype=torch.float64, device=pos.device)
+        check(_L.cg_shortrange_cells(self._ctx, _ptr(pos), n, int(nt), float(tile_extent),
+                                     _ptr(order), _ptr(offset), _ptr(pos_sorted)))
+        return order, offset, pos_sorted
+
+    def shortrange_sweep_cells(self, cells_r, dmom_r, cells_s, nt, table, r2_index_scaling,
+                               r2_max, factor, rungs=None):
+        """The sweep over half-tile cells; cells_* from shortrange_cells().  `rungs` as in
+        shortrange_sweep."""
+        n = self._check_particles(dmom_r)
+        if table.dtype != torch.float64 or not table.is_cuda:
+            raise lib.ConceptGPUError('short-range table must be a float64 CUDA tensor')
+        order_r, off_r, pos_r = cells_r
+        _, off_s, pos_s = cells_s
+        if rungs is None:
+            check(_L.cg_shortrange_sweep_cells(
+                self._ctx, _ptr(pos_r), _ptr(order_r), _ptr(off_r), _ptr(dmom_r), _ptr(pos_s),
+                _ptr(off_s), int(nt), _ptr(table), table.numel(), float(r2_index_scaling),
+                float(r2_max), float(factor)))
+            return
+        factors, rung, rung_jumped, lowest = rungs
+        self._check_rungs(n, rung, rung_jumped)
+        check(_L.cg_shortrange_sweep_cells_rungs(
+            self._ctx, _ptr(pos_r), _ptr(order_r), _ptr(off_r), _ptr(dmom_r), _ptr(pos_s),
+            _ptr(off_s), int(nt), _ptr(table), table.numel(), float(r2_index_scaling),
+            float(r2_max), _ptr(factors), _ptr(rung), _ptr(rung_jumped), int(lowest)))
+
     # -- A16: momentum buffers and adaptive rungs -------------------------------------
     @staticmethod
     def _check_rungs(n, *arrays):

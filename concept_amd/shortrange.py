@@ -125,7 +125,7 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
         for c in involved:
             check_shortrange_fits(c._store.mesh, sr['range'] + slack)
     for c in involved:
-        cells[id(c)] = mesh.shortrange_build(c.pos, nt, tile_extent)
+        cells[id(c)] = mesh.shortrange_cells(c.pos, nt, tile_extent)
         supp_pos[id(c)], supp_cells[id(c)] = c.pos, cells[id(c)]
         if multi and any(c is s_ for s_ in suppliers):
             ghosts = ship_boundary_positions(c._store.mesh, c.pos,
@@ -133,7 +133,7 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
             # rows 0..N_local-1 ARE the component's own particles (the sweep's `same`
             # convention), the ghosts follow
             supp_pos[id(c)] = torch.cat([c.pos] + list(ghosts)).contiguous()
-            supp_cells[id(c)] = mesh.shortrange_build(supp_pos[id(c)], nt, tile_extent)
+            supp_cells[id(c)] = mesh.shortrange_cells(supp_pos[id(c)], nt, tile_extent)
     key = 'a**(-3*w_eff₀-3*w_eff₁-1)'
     done = set()
     for r in receivers:
@@ -157,13 +157,12 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
                                            dtype=torch.float64, device=rec.device)
                     rungs = (factors, rec.rung_indices, rec.rung_indices_jumped,
                              rec.lowest_active_rung)
-                    mesh.shortrange_sweep(rec.pos, cells[id(rec)], rec.Δmom, supp_pos[id(sup)],
-                                          supp_cells[id(sup)], nt, same_, table, scaling, r2_max,
-                                          0.0, rungs)
+                    mesh.shortrange_sweep_cells(cells[id(rec)], rec.Δmom, supp_cells[id(sup)],
+                                                nt, table, scaling, r2_max, 0.0, rungs)
                 else:
-                    mesh.shortrange_sweep(rec.pos, cells[id(rec)], rec.Δmom, supp_pos[id(sup)],
-                                          supp_cells[id(sup)], nt, same_, table, scaling, r2_max,
-                                          p.G_Newton*rec.mass*sup.mass*float(integrals[0]))
+                    mesh.shortrange_sweep_cells(
+                        cells[id(rec)], rec.Δmom, supp_cells[id(sup)], nt, table, scaling,
+                        r2_max, p.G_Newton*rec.mass*sup.mass*float(integrals[0]))
             sweep(r, s, same)
             if not same and s in receivers:
                 # the reference kicks both partners of a pair (Δmom_s -= ..., gravity.py:341-349)

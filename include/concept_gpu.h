@@ -226,6 +226,40 @@ int cg_shortrange_sweep_rungs(cg_ctx *ctx, const double *pos_r, const uint32_t *
                               const int8_t *rung_r /*DEV*/, const int8_t *rung_jumped_r /*DEV*/,
                               int lowest_active_rung);
 
+/* The production form of the sweep: a cell list at HALF-tile granularity (the reference prunes
+ * below the tile level with subtiles, interactions.py:1141-1278, species.py:4031-4142).
+ * cg_shortrange_cells bins the particles into (2 nt)^3 cells — tile index exactly as
+ * Tiling.sort (species.py:775-780), then which half of the tile in each dimension — and
+ * writes, in cell order (z fastest): order_out[n] = particle indices, pos_sorted_out[3n] =
+ * their positions (the sweep stages supplier runs with plain coalesced loads), offset_out[
+ * (2 nt)^3 + 1] = first entry of each cell.
+ * cg_shortrange_sweep_cells[_rungs]: same sums as cg_shortrange_sweep[_rungs] (x_ji, r2 and the
+ * table index bit-identical; the order of partners differs), a receiver only meeting supplier
+ * cells at most two away: dmom_r[order_r[q]] += ... for every receiver row q.  The force range
+ * must not exceed the tile extent (the reference requires tilesize >= range,
+ * species.py:3943-3983).  Receivers and suppliers may be different particle sets (two
+ * components, or a component extended by the neighbour domains' boundary particles): there is
+ * no self-pair test because a particle paired with itself contributes x_ji * f = 0 * f. */
+int cg_shortrange_cells(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, int64_t nt,
+                        double tile_extent, uint32_t *order_out /*DEV n*/,
+                        uint32_t *offset_out /*DEV (2nt)^3+1*/,
+                        double *pos_sorted_out /*DEV 3n*/);
+int cg_shortrange_sweep_cells(cg_ctx *ctx, const double *pos_r_sorted /*DEV*/,
+                              const uint32_t *order_r /*DEV*/, const uint32_t *offset_r /*DEV*/,
+                              double *dmom_r /*DEV 3n_r, accumulated*/,
+                              const double *pos_s_sorted /*DEV*/, const uint32_t *offset_s /*DEV*/,
+                              int64_t nt, const double *table /*DEV*/, int64_t tablesize,
+                              double r2_index_scaling, double r2_max, double factor);
+int cg_shortrange_sweep_cells_rungs(cg_ctx *ctx, const double *pos_r_sorted,
+                                    const uint32_t *order_r, const uint32_t *offset_r,
+                                    double *dmom_r, const double *pos_s_sorted,
+                                    const uint32_t *offset_s, int64_t nt,
+                                    const double *table /*DEV*/, int64_t tablesize,
+                                    double r2_index_scaling, double r2_max,
+                                    const double *factors /*DEV 3*N_rungs-1*/,
+                                    const int8_t *rung_r /*DEV*/,
+                                    const int8_t *rung_jumped_r /*DEV*/, int lowest_active_rung);
+
 /* --- A16: momentum buffers and adaptive rungs --------------------------------
  * rung / rung_jumped are the reference's `signed char` arrays (species.py:2040-2064);
  * a jumped index is rung + N_rungs (down) or rung + 2*N_rungs (up).  rung = NULL means

@@ -233,14 +233,68 @@ def test_p3m_kick_vs_oracle(npart, N):
     nt = oracle.shortrange_tiling_shape(L, range_)
     tab, maxr2 = shortrange.get_shortrange_table(soft, scale, range_, 4096, 'spline',
                                                  torch.device('cuda'))
-    cells = mesh.shortrange_build(p1, nt, L/nt)
-    dmom = torch.zeros_like(p1)
-    mesh.shortrange_sweep(p1, cells, dmom, p1, cells, nt, True, tab, 4095/maxr2, range_**2, factor)
-    out = dmom.cpu().numpy()
     ref = dmom_o[perm]
     big = max(np.abs(ref).max(), factor/scale**2)
+    # the production sweep (half-tile cells) and the one-wavefront-per-tile form
+    cells = mesh.shortrange_cells(p1, nt, L/nt)
+    dmom = torch.zeros_like(p1)
+    mesh.shortrange_sweep_cells(cells, dmom, cells, nt, tab, 4095/maxr2, range_**2, factor)
+    out = dmom.cpu().numpy()
     assert np.abs(out - ref).max() <= 1e-12*big
     assert np.abs(out.sum(0)).max() <= 1e-10*big
+    tiles = mesh.shortrange_build(p1, nt, L/nt)
+    dmom_t = torch.zeros_like(p1)
+    mesh.shortrange_sweep(p1, tiles, dmom_t, p1, tiles, nt, True, tab, 4095/maxr2, range_**2,
+                          factor)
+    assert np.abs(dmom_t.cpu().numpy() - ref).max() <= 1e-12*big
+    # cell list: a permutation, positions copied in cell order, every particle in its cell
+    order, offset, pos_sorted = cells
+    o = order.long()
+    assert torch.equal(torch.sort(o)[0], torch.arange(n, device='cuda'))
+    assert torch.equal(pos_sorted, p1[o])
+    # every particle lies in the cell the offsets put it in (to rounding at the cell faces: the
+    # tile index itself is pinned bit-exact by test_gpu_p3m.test_table_and_tiles)
+    ext, nc = L/nt, 2*nt
+    off = offset.long()
+    assert int(off[0]) == 0 and int(off[-1]) == n and bool((off[1:] >= off[:-1]).all())
+    cell = torch.searchsorted(off, torch.arange(n, device='cuda'), right=True) - 1
+    c3 = torch.stack([cell//(nc*nc), (cell//nc) % nc, cell % nc], 1).double()
+    lo, hi = c3*(ext/2), (c3 + 1)*(ext/2)
+    tol = 1e-12*L
+    assert bool(((pos_sorted >= lo - tol) & (pos_sorted <= hi + tol)).all())
+    mesh.close()
+
+
+def test_shortrange_cells_dense_and_two_components():
+    """The half-tile sweep where its staging rounds and receiver chunks are exercised: a blob
+    with thousands of particles per tile (several staging windows, > 64 receivers per cell
+    column), a box face (periodic images), and receivers != suppliers (two components),
+    against the one-wavefront-per-tile sweep."""
+    import torch
+    from concept_amd import shortrange
+    from concept_amd.mesh import PotentialMesh
+    L, N = 64.0, 64
+    rng = np.random.default_rng(12)
+    scale = 1.25*L/N
+    range_ = 4.5*scale
+    nt = int(L/range_*(1 + 2.220446049250313e-16))
+    blob = np.mod(rng.normal(0.5, 1.6, (6000, 3)), L)     # dense, wrapped around the box corner
+    thin = rng.uniform(0, L, (9000, 3))
+    pos_a = torch.tensor(np.concatenate([blob, thin]), device='cuda')
+    pos_b = torch.tensor(np.mod(rng.normal(L - 1.0, 3.0, (3000, 3)), L), device='cuda')
+    mesh = PotentialMesh(N, L)
+    tab, maxr2 = shortrange.get_shortrange_table(0.03, scale, range_, 4096, 'spline',
+                                                 torch.device('cuda'))
+    sc, r2 = 4095/maxr2, range_**2
+    for rec, sup, same in ((pos_a, pos_a, True), (pos_a, pos_b, False), (pos_b, pos_a, False)):
+        cr, cs = mesh.shortrange_cells(rec, nt, L/nt), mesh.shortrange_cells(sup, nt, L/nt)
+        got = torch.zeros_like(rec)
+        mesh.shortrange_sweep_cells(cr, got, cs, nt, tab, sc, r2, 0.7)
+        tr, ts = mesh.shortrange_build(rec, nt, L/nt), mesh.shortrange_build(sup, nt, L/nt)
+        ref = torch.zeros_like(rec)
+        mesh.shortrange_sweep(rec, tr, ref, sup, ts, nt, same, tab, sc, r2, 0.7)
+        big = float(ref.abs().max())
+        assert big > 0 and float((got - ref).abs().max()) <= 1e-12*big, (same, big)
     mesh.close()
 
 
