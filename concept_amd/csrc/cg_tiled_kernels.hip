@@ -219,15 +219,36 @@ struct PrepArgs {
     i64 emig_cap;
 };
 
+// LDS of the staged block.  T = 16, order 2: 19^3 doubles = 54,872 B would allow two workgroups
+// per CU (160 KB); the first and the last row of the block (a = 0, b = 0 and a = E-1, b = E-1)
+// are halo EDGES, which the 6-point stencil never reads — leaving those 2 x 19 entries out
+// brings it to 54,568 B, three workgroups (24 wavefronts) per CU.
+template <int ORDER, int T>
+struct GatherLds {
+    static constexpr int H = ORDER / 2, E = T + 1 + 2 * H;
+    static constexpr int trim = (ORDER == 2 && T == 16) ? E : 0;
+    static constexpr int doubles = E * E * E - 2 * trim;
+};
+#ifndef CG_GK_WAVES
+#define CG_GK_WAVES 4  // wavefronts per SIMD the register allocation aims at.  Measured (2^28
+                       // particles / 1024^3, order 2): the plain kernel needs 78 VGPRs and runs
+                       // 3 workgroups per CU in 6.74 ms (6.9 with two); the variant that also
+                       // histograms the next drift needs 114 — squeezed into 80 (waves 6) it
+                       // spills 72 B per lane and takes 9.0 instead of 7.3 ms
+#endif
+
 template <int ORDER, int T, bool PREP>
-__global__ __launch_bounds__(512, 4) void k_gather_kick_tiled(
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
+    (ORDER == 2 ? CG_GK_WAVES : 4), 8))) void k_gather_kick_tiled(
     const double *__restrict__ pos, double *__restrict__ mom,
     const unsigned *__restrict__ tile_offset, const double *__restrict__ mesh, i64 N, i64 ny,
     i64 pad, int g, int nt, unsigned ntiles, XMap xm, CicGeom geo, double c1, double c2,
     double factor, PrepArgs prep) {
     constexpr int H = ORDER / 2;
     constexpr int E = T + 1 + 2 * H;  // cells [T0-H, T0+T+H]
-    extern __shared__ double lds[];
+    constexpr int TRIM = GatherLds<ORDER, T>::trim;
+    extern __shared__ double lds_raw[];
+    double *const lds = lds_raw - TRIM;  // entry i of the block lives at lds[i], TRIM <= i
     const unsigned tile = tile_for_block(blockIdx.x, ntiles);
     const i64 beg = tile_offset[8 * tile], end = tile_offset[8 * tile + 8];
     if (beg == end) return;  // uniform for the workgroup
@@ -274,8 +295,12 @@ __global__ __launch_bounds__(512, 4) void k_gather_kick_tiled(
             const int a = wave + 8 * s;
             if (a < E) {
 #pragma unroll
-                for (int q = 0; q < NP; q++)
-                    if (PL % 64 == 0 || lane + 64 * q < PL) lds[a * PL + lane + 64 * q] = v[s][q];
+                for (int q = 0; q < NP; q++) {
+                    const int i2 = lane + 64 * q;
+                    const bool stored = !TRIM || ((a > 0 || i2 >= TRIM) &&
+                                                  (a < E - 1 || i2 < PL - TRIM));
+                    if ((PL % 64 == 0 || i2 < PL) && stored) lds[a * PL + i2] = v[s][q];
+                }
             }
         }
     }
@@ -375,8 +400,7 @@ __global__ __launch_bounds__(512, 4) void k_gather_kick_tiled(
 template <int ORDER, int T>
 static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsigned *tile_offset,
                          double c1, double c2, double factor, const PrepArgs *prep) {
-    constexpr int E = T + 1 + 2 * (ORDER / 2);
-    size_t lds = sizeof(double) * E * E * E;
+    size_t lds = sizeof(double) * GatherLds<ORDER, T>::doubles;
     auto kern = k_gather_kick_tiled<ORDER, T, false>;
     auto kern_prep = k_gather_kick_tiled<ORDER, T, true>;
     // the attribute belongs to the function ON A DEVICE: once per device of this process
