@@ -315,11 +315,11 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
     n_pl, n_gl = total/world, N**3/world
     mv = moved_bytes(n_pl, n_gl)
     # local kernels of rank 0: the gather-kick stage is one launch (+ the ghost fill messages)
-    gk_ms = stages.get('ghost_fill+gather_kick', 0.0)
+    gk_ms = stages.get('gather_kick', 0.0)
     gk_rate = mv['gather_kick']/(gk_ms*1e-3)/1e9 if gk_ms else 0.0
     # transport: each transpose sends (P-1)/P of the local slab's transform, one peer per link
     tr_bytes = dom.tbuf_a.numel()*8*(world - 1)/world if world > 1 else 0
-    ps_ms = stages.get('poisson+transposes', 0.0)
+    ps_ms = stages.get('poisson+transposes+halos', 0.0)
     link_peak = min(world - 1, 7)*XGMI_LINK_GBS_DIR
     transport = None
     if world > 1:
@@ -353,7 +353,7 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
                                'run of the sharded path, not a rate to quote)')},
         'emigrants_per_step': emigrants/args.steps,
         'emigrant_fraction_per_step': emigrants/args.steps/max(total, 1),
-        'roofline': {'bound': 'hbm', 'kernel': 'gather_kick (rank 0, incl. ghost fill messages)',
+        'roofline': {'bound': 'hbm', 'kernel': 'gather_kick (rank 0)',
                      'achieved': round(gk_rate, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(gk_rate/HBM_PEAK_GBS, 4), 'traffic': None,
                      'algorithmic_bytes': int(mv['gather_kick']), 'kernel_ms': round(gk_ms, 4)},

@@ -108,6 +108,26 @@ class Comm:
         if self.stage and r.numel():
             recv.copy_(r)
 
+    def sendrecv_start(self, send, dest, recv, source):
+        """sendrecv posted without waiting: returns finish(), which makes the current stream
+        wait for the message (RCCL runs it on its own stream behind what the current stream
+        has queued so far, so kernels launched in between overlap it).  The buffers must stay
+        untouched until finish().  gloo (tests): completed here, finish() does nothing."""
+        if (dest == self.rank and source == self.rank) or self.stage:
+            self.sendrecv(send, dest, recv, source)
+            return lambda: None
+        ops = []
+        if send.numel():
+            ops.append(dist.P2POp(dist.isend, send, dest, group=self.group))
+        if recv.numel():
+            ops.append(dist.P2POp(dist.irecv, recv, source, group=self.group))
+        works = dist.batch_isend_irecv(ops) if ops else []
+
+        def finish():
+            for w in works:
+                w.wait()
+        return finish
+
     def all_gather_ints(self, values):
         t = torch.tensor(values, dtype=torch.int64)
         if not self.stage:

@@ -567,11 +567,10 @@ def pm_kick(domain, particles, contribution, deconv_order, C, kick_factor, diff_
     mark = mark or (lambda name: None)
     m = domain.mesh
     m.deposit_tiled(particles.view('pos'), particles.table, contribution, accumulate=False)
-    m.fold_ghosts()
-    mark('deposit+ghost_fold')
-    m.poisson_solve(deconv_order, C, long_range, E)
-    mark('poisson+transposes')
-    m.fill_ghosts()
+    fold = m.fold_ghosts_start()   # the ghost layer travels under the first transforms
+    mark('deposit')
+    m.poisson_solve(deconv_order, C, long_range, E, fold_finish=fold, fill=True)
+    mark('poisson+transposes+halos')
     if next_dt_over_mass is None:
         particles._emig_for = None
         m.gather_kick_tiled(particles.view('pos'), particles.view('mom'), particles.table,
@@ -591,4 +590,4 @@ def pm_kick(domain, particles, contribution, deconv_order, C, kick_factor, diff_
                 m.set_emigrant_list(None, None)
         if multi:
             particles.prepare_exchange(next_dt_over_mass)
-    mark('ghost_fill+gather_kick')
+    mark('gather_kick')

@@ -160,12 +160,13 @@ def particle_mesh(receivers, suppliers, gridsize_global, quantity, force, method
                 mesh.zero()
             mesh.deposit(supplier.pos, contribution)
         mesh_started = True
-    # communicate_ghosts(grid, '+=') (mesh.py:609); one domain wraps by itself
-    mesh.fold_ghosts(general=not aligned)
+    # communicate_ghosts(grid, '+=') (mesh.py:609) and, after the solve, communicate_ghosts(grid,
+    # '=') (interactions.py:2303-2307): posted here, both travel under the transforms (one
+    # domain wraps by itself and needs neither)
+    fold = mesh.fold_ghosts_start(general=not aligned)
     # interactions.py:2092-2118 and :2302
     C, long_range, E = _potential_constants(p, potential, gridsize_global)
-    mesh.poisson_solve(deconv_order_global, C, long_range, E)
-    mesh.fill_ghosts()  # communicate_ghosts(grid, '=') (interactions.py:2303-2307)
+    mesh.poisson_solve(deconv_order_global, C, long_range, E, fold_finish=fold, fill=True)
     # interactions.py:2311-2332 via apply_particle_mesh_force (:2359-2387)
     for receiver in receivers:
         _kick_particles(mesh, receiver, force, method, ᔑdt, ᔑdt_key)

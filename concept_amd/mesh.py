@@ -82,6 +82,8 @@ class PotentialMesh:
         if self.nprocs > 1:
             self.halo_s = torch.empty(G*per, dtype=torch.float64, device=dev)
             self.halo_r = torch.empty(G*per, dtype=torch.float64, device=dev)
+            self.halo_s2 = torch.empty(G*per, dtype=torch.float64, device=dev)
+            self.halo_r2 = torch.empty(G*per, dtype=torch.float64, device=dev)
         # The FFT transposes are exchanged in `pieces` layer ranges so that the transform of one
         # range overlaps the exchange of the previous one (CONCEPT_GPU_DIST_PIECES, 1 = one
         # all_to_all_single per transpose).  A piece should stay a large message: >= 8 layers.
@@ -136,6 +138,40 @@ class PotentialMesh:
         c.sendrecv(self.halo_s, c.prev, self.halo_r, c.next)
         self.layers_write(nxl - G, G, self.halo_r, add=True)
 
+    def fold_ghosts_start(self, general=False):
+        """fold_ghosts with the message in flight: returns finish() (adds what arrived).  The
+        layers it adds to — the first owned ones — must not be read before finish()."""
+        if not self.dist or self.nprocs == 1:
+            return lambda: None
+        if general:
+            self.fold_ghosts(general=True)
+            return lambda: None
+        c, per, nxl = self.comm, self.layer_doubles, self.nxl
+        s, r = self.halo_s[:per], self.halo_r[:per]
+        self.layers_read(nxl, 1, s)
+        done = c.sendrecv_start(s, c.next, r, c.prev)
+
+        def finish():
+            done()
+            self.layers_write(0, 1, r, add=True)
+        return finish
+
+    def _fill_ghosts_start(self):
+        """the two halo messages of fill_ghosts posted (the first and last G owned layers must
+        be final); returns finish(), which writes the ghost layers"""
+        c, G, nxl = self.comm, self.ghost_layers, self.nxl
+        self.layers_read(0, G, self.halo_s)
+        self.layers_read(nxl - G, G, self.halo_s2)
+        d1 = c.sendrecv_start(self.halo_s, c.prev, self.halo_r, c.next)
+        d2 = c.sendrecv_start(self.halo_s2, c.next, self.halo_r2, c.prev)
+
+        def finish():
+            d1()
+            d2()
+            self.layers_write(nxl, G, self.halo_r, add=False)
+            self.layers_write(-G, G, self.halo_r2, add=False)
+        return finish
+
     def fill_ghosts(self):
         """communicate_ghosts(grid, '=') (interactions.py:2303-2307, mesh.py:5026-5028): the
         G halo layers on both sides from the ring neighbours' owned layers."""
@@ -151,16 +187,23 @@ class PotentialMesh:
         c.sendrecv(self.halo_s, c.next, self.halo_r, c.prev)
         self.layers_write(-G, G, self.halo_r, add=False)
 
-    def _dist_forward(self):
+    def _dist_forward(self, fold_finish=None):
         """z + y transform of the local layers, transpose (fft.c:240-257), pipelined in layer
-        ranges; leaves the y-z transformed data, transposed, in self.four"""
+        ranges; leaves the y-z transformed data, transposed, in self.four.  fold_finish: the
+        pending ghost fold (fold_ghosts_start) — it lands in the first owned layer, so the
+        range holding that layer is transformed last, behind the message."""
         c = self.comm
         if len(self.pieces) == 1:
+            if fold_finish is not None:
+                fold_finish()
             self.dist_fft_forward(self.stage)
             c.all_to_all(self.four, self.stage)
             return
         works = []
-        for l0, nl in self.pieces:  # transform range k+1 while range k is on the links
+        order = self.pieces[1:] + self.pieces[:1] if fold_finish is not None else self.pieces
+        for l0, nl in order:  # transform range k+1 while range k is on the links
+            if l0 == 0 and fold_finish is not None:
+                fold_finish()
             self.dist_fft_forward(self.stage, l0, nl)
             works.append(c.all_to_all_layers(self.four, self.stage, self.nxl, l0, nl,
                                              async_op=True))
@@ -168,18 +211,29 @@ class PotentialMesh:
             if w is not None:
                 w.wait()
 
-    def _dist_backward(self):
+    def _dist_backward(self, fill=False):
+        """way back; fill: also exchange the potential's halo layers (fill_ghosts) — the two
+        boundary ranges come first, their halo messages travel under the transforms of the
+        inner ranges.  Returns the pending finish() of the halo (or None)."""
         c = self.comm
+        fill = fill and self.nprocs > 1
         if len(self.pieces) == 1:
             c.all_to_all(self.stage, self.four)
             self.dist_fft_backward(self.stage)
-            return
+            return self._fill_ghosts_start() if fill else None
+        order = list(self.pieces)
+        if fill and len(order) > 2:
+            order = [order[0], order[-1]] + order[1:-1]
         works = [c.all_to_all_layers(self.stage, self.four, self.nxl, l0, nl, async_op=True)
-                 for l0, nl in self.pieces]
-        for (l0, nl), w in zip(self.pieces, works):  # inverse y + z of range k while k+1 arrives
-            if w is not None:
+                 for l0, nl in order]
+        pending = None
+        for k, ((l0, nl), w) in enumerate(zip(order, works)):  # inverse y + z of a range while
+            if w is not None:                                  # the next ones arrive
                 w.wait()
             self.dist_fft_backward(self.stage, l0, nl)
+            if fill and k == min(1, len(order) - 1):
+                pending = self._fill_ghosts_start()
+        return pending
 
     def close(self):
         if self._ctx:
@@ -250,14 +304,21 @@ class PotentialMesh:
         check(_L.cg_deposit_cic_tiled(self._ctx, _ptr(pos), n, _ptr(tile_offset),
                                       float(contribution), int(accumulate)))
 
-    def poisson_solve(self, deconv_order, C, long_range=False, E=0.0):
+    def poisson_solve(self, deconv_order, C, long_range=False, E=0.0, fold_finish=None,
+                      fill=False):
+        """fold_finish: a pending fold_ghosts_start(); fill: end with fill_ghosts().  Both halo
+        exchanges then overlap the transforms (x-slab domains; one domain needs neither)."""
         if self.dist:
             # A3..A8 with the transposes as all-to-alls; the k-space factor is fused into the
             # x pass, which runs on the transposed buffer
-            self._dist_forward()
+            self._dist_forward(fold_finish)
             self.dist_fft_xsolve(self.four, deconv_order, C, long_range, E)
-            self._dist_backward()
+            pending = self._dist_backward(fill)
+            if pending is not None:
+                pending()
             return
+        if fold_finish is not None:
+            fold_finish()
         check(_L.cg_poisson_solve(self._ctx, int(deconv_order), float(C), int(long_range),
                                   float(E)))
 
