@@ -638,6 +638,18 @@ __device__ __forceinline__ void sr_cell_pairs(int a, int b, int sub, int S, doub
                                       r2_index_scaling, table, ax, ay, az);
 }
 
+// inclusive scan over the 64 lanes of a wave in DPP adds (no LDS round trips): row_shr 1, 2, 4,
+// 8 inside the rows of 16 lanes, then the row totals are broadcast forward (row_bcast 15, 31)
+__device__ __forceinline__ unsigned sr_wave_scan(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // One receiver chunk's lanes: R receivers x S supplier groups
 struct SrChunk {
     int R, S, sub, rl;
@@ -698,7 +710,9 @@ k_sr_sweep_cells(
     // supplier pieces: column (cx, cy) of the 6 x 6 around the tile, cells 2 tc - 2 .. 2 tc + 3,
     // cut in two where the column wraps around the box in z
     if (tid < kSrPieces) {
-        const int col = tid >> 1, half = tid & 1;
+        // piece number = half * 36 + column: a tile that does not touch a z face has all its
+        // suppliers in the first 36 pieces, in (cx, cy) order
+        const int half = tid >= 36, col = tid - 36 * half;
         const int cx = col / 6, cy = col - 6 * cx;
         int gx = 2 * ta - 2 + cx, gy = 2 * tb - 2 + cy;
         int ox = 0, oy = 0, oz = 0;
@@ -740,24 +754,21 @@ k_sr_sweep_cells(
     }
     __syncthreads();
     if (wave_any[0] + wave_any[1] + wave_any[2] + wave_any[3] == 0) return;  // empty tile
-    {
-        // exclusive prefix of the 72 piece sizes — by every wave for itself (identical values
-        // into p_off: a wave reads what it wrote itself, no barrier)
-        unsigned v0 = p_cnt[lane], v1 = lane < kSrPieces - 64 ? p_cnt[64 + lane] : 0u;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned u0 = __shfl_up(v0, o), u1 = __shfl_up(v1, o);
-            if (lane >= o) {
-                v0 += u0;
-                v1 += u1;
-            }
-        }
-        const unsigned first64 = __shfl(v0, 63);
-        p_off[lane + 1] = v0;
-        if (lane < kSrPieces - 64) p_off[64 + lane + 1] = first64 + v1;
-        if (lane == 0) p_off[0] = 0;
+    // Exclusive prefix of the 72 piece sizes — by every wave for itself (identical values into
+    // p_off: a wave reads what it wrote itself, no barrier).  Lane l keeps the bounds of pieces
+    // l (half 0) and 36 + l (half 1) in registers: range bounds below are v_readlane's.
+    const unsigned c0 = lane < 36 ? p_cnt[lane] : 0u, c1 = lane < 36 ? p_cnt[36 + lane] : 0u;
+    const unsigned i0 = sr_wave_scan(c0);                  // inclusive, half 0
+    const unsigned total0 = __builtin_amdgcn_readlane(i0, 63);
+    const unsigned i1 = sr_wave_scan(c1) + total0;         // inclusive, half 1
+    if (lane < 36) {
+        p_off[lane + 1] = i0;
+        p_off[36 + lane + 1] = i1;
     }
-    const unsigned total = __builtin_amdgcn_readfirstlane(p_off[kSrPieces]);
+    if (lane == 0) p_off[0] = 0;
+    const unsigned e0 = i0 - c0, e1 = i1 - c1;             // exclusive
+    const unsigned total = __builtin_amdgcn_readlane(i1, 63);
+    const int npieces = total == total0 ? 36 : kSrPieces;  // (half 1 is empty off the z faces)
     // tiles on a box face see periodic images: they sweep piece by piece with the piece's offset
     const bool face = ta == 0 || tb == 0 || tc == 0 || ta == nt - 1 || tb == nt - 1 || tc == nt - 1;
     const bool simple = rend - rbeg <= 64 && total <= (unsigned)kSrCap;  // one chunk, one window
@@ -766,7 +777,7 @@ k_sr_sweep_cells(
         if (w0) __syncthreads();  // everybody is done with the previous window
         // staging: 16 lanes per piece, a wave takes 4 pieces at a time (pieces are short runs of
         // ~16 suppliers; a longer one takes more turns) — no search for the piece of an entry
-        for (int p0 = wave_u * 4; p0 < kSrPieces; p0 += 16) {
+        for (int p0 = wave_u * 4; p0 < npieces; p0 += 16) {
             const int p = p0 + (lane >> 4);
             const unsigned beg = p_beg[p], o0 = p_off[p], o1 = p_off[p + 1];
             const unsigned lo = max(o0, w0), hi = min(o1, w1);  // the part inside this window
@@ -793,36 +804,37 @@ k_sr_sweep_cells(
             if (!__any(active)) continue;
             const double xi = ch.xi, yi = ch.yi, zi = ch.zi;
             double ax = 0, ay = 0, az = 0;
-            if (active) {
+            {
+                // (every lane walks the ranges, active or not: the bounds are v_readlane's of
+                // registers whose lanes 0..35 must be live, i.e. uniform control flow; an idle
+                // lane tests pairs against (0, 0, 0) and its sums are never read)
                 for (int xg = 0; xg < 5; xg++) {
-                    const int pf = ((wx + xg) * 6 + wy) * 2;  // first piece of this x; 10 pieces
-                    if (!face) {
-                        const int a = __builtin_amdgcn_readfirstlane(
-                            (int)max(p_off[pf], w0) - (int)w0);
-                        const int b = __builtin_amdgcn_readfirstlane(
-                            (int)min(p_off[pf + 10], w1) - (int)w0);
+                    const int col = (wx + xg) * 6 + wy;  // first of the 5 columns of this x
+                    if (!face) {  // no periodic image: the 5 columns are one staged range
+                        const int a = (int)max(__builtin_amdgcn_readlane(e0, col), w0) - (int)w0;
+                        const int b =
+                            (int)min(__builtin_amdgcn_readlane(i0, col + 4), w1) - (int)w0;
                         if (b > a)
                             sr_cell_pairs<false>(a, b, sub, S, xi, yi, zi, 0, 0, 0, sx, sy, sz,
                                                  P.r2_max, P.r2_index_scaling, table, ax, ay, az);
-                    } else {
-                        for (int p = pf; p < pf + 10; p++) {
-                            const int a = __builtin_amdgcn_readfirstlane(
-                                (int)max(p_off[p], w0) - (int)w0);
-                            const int b = __builtin_amdgcn_readfirstlane(
-                                (int)min(p_off[p + 1], w1) - (int)w0);
-                            if (b <= a) continue;
-                            const double ox = (double)p_shift[p][0] * P.boxsize,
-                                         oy = (double)p_shift[p][1] * P.boxsize,
-                                         oz = (double)p_shift[p][2] * P.boxsize;
-                            if ((ox != 0) | (oy != 0) | (oz != 0))
-                                sr_cell_pairs<true>(a, b, sub, S, xi, yi, zi, ox, oy, oz, sx, sy,
-                                                    sz, P.r2_max, P.r2_index_scaling, table, ax,
-                                                    ay, az);
-                            else
-                                sr_cell_pairs<false>(a, b, sub, S, xi, yi, zi, 0, 0, 0, sx, sy, sz,
-                                                     P.r2_max, P.r2_index_scaling, table, ax, ay,
-                                                     az);
-                        }
+                        continue;
+                    }
+                    for (int q = 0; q < 10; q++) {  // piece by piece with its offset
+                        const int cq = col + (q % 5), half = q / 5, p = 36 * half + cq;
+                        const int a = (int)max(__builtin_amdgcn_readlane(half ? e1 : e0, cq), w0) -
+                                      (int)w0;
+                        const int b = (int)min(__builtin_amdgcn_readlane(half ? i1 : i0, cq), w1) -
+                                      (int)w0;
+                        if (b <= a) continue;
+                        const double ox = (double)p_shift[p][0] * P.boxsize,
+                                     oy = (double)p_shift[p][1] * P.boxsize,
+                                     oz = (double)p_shift[p][2] * P.boxsize;
+                        if ((ox != 0) | (oy != 0) | (oz != 0))
+                            sr_cell_pairs<true>(a, b, sub, S, xi, yi, zi, ox, oy, oz, sx, sy, sz,
+                                                P.r2_max, P.r2_index_scaling, table, ax, ay, az);
+                        else
+                            sr_cell_pairs<false>(a, b, sub, S, xi, yi, zi, 0, 0, 0, sx, sy, sz,
+                                                 P.r2_max, P.r2_index_scaling, table, ax, ay, az);
                     }
                 }
             }
