@@ -65,6 +65,7 @@ def survey_bytes(n_p, n_g):
         'gather_kick': 72*n_p + 24*n_g,               # row A10: three force grids
         'drift': 72*n_p,
         'drift_sort': 72*n_p + 120*n_p,               # drift row + a sort that re-reads pos
+        'kick_drift_sort': 72*n_p + 24*n_g + 72*n_p + 120*n_p,  # rows A10 + A11 + the sort
         'sr_cells': 56*n_p, 'sr_sweep': 72*n_p,
     }
 
@@ -85,6 +86,8 @@ def moved_bytes(n_p, n_g, with_ids=False):
         'fft_x_fused_kspace': 16*n_g,                 # one read + one write of the mesh
         'gather_kick': 72*n_p + 8*n_g,                # pos, mom RMW, the potential once
         'drift': 72*n_p,
+        'kick_drift_sort': 96*n_p + 8*n_g + ids,      # pos+mom read, pos+mom written at their
+                                                      # new places, the potential once
         'drift_sort': 96*n_p + ids,                   # pos+mom read, pos+mom written (prepared
                                                       # histogram: no separate counting pass)
         'sort': 96*n_p + 24*n_p + ids,
@@ -408,6 +411,9 @@ def main():
                          'softening 0.025*L/cbrt(N))')
     ap.add_argument('--sr-tiles', action='store_true',
                     help='P3M: the round-1 sweep (one wavefront per tile, no sub-tile pruning)')
+    ap.add_argument('--no-fused', action='store_true',
+                    help='PM: separate gather-kick and drift + sort kernels (the round-1 step) '
+                         'instead of the fused kick + drift + scatter pass')
     ap.add_argument('--no-prepare', action='store_true',
                     help='do not fuse the next drift\'s tile histogram into the gather-kick')
     ap.add_argument('--no-sort', action='store_true',
@@ -461,6 +467,13 @@ def main():
     G = 1.0
     dt = 1e-4
     mom = thermal_momenta(torch, args, pos.shape, L/N, mass, dt, dev, gen)
+    fused = not (args.no_fused or args.no_sort or args.p3m or args.no_prepare)
+    if fused:
+        # the fused kick + drift + scatter keeps the particles in tile REGIONS WITH GAPS
+        # (capacities predicted from the present populations): arrays of that capacity
+        cap = mesh.region_capacity(n_p)
+        grow = lambda t: torch.cat([t, torch.empty((cap - n_p, 3), dtype=t.dtype, device=dev)])
+        pos, mom = grow(pos), grow(mom)
     pos2, mom2 = torch.empty_like(pos), torch.empty_like(mom)
     table = mesh.new_tile_table()
     contribution = (dt/dt)*mass*(float(N)**(-3)*(N/L)**3)
@@ -481,7 +494,18 @@ def main():
         dmom = torch.zeros_like(mom)
         sr = dict(scale=scale, range=rng_, nt=nt_sr, table=sr_table, scaling=4095/maxr2,
                   r2_max=rng_**2, factor=G*mass*mass*dt, E=-(2*3.141592653589793/L*scale)**2)
-    if args.no_sort:
+    if fused:
+        # one sort into tile order up front (untimed, like generating the particles); every
+        # timed step is deposit -> solve -> kick + drift + sort: the same cycle of one drift,
+        # one sort, one deposit, one solve and one kick per step, entered after the sort
+        PHASES = ['deposit'] + poisson + ['kick_drift_sort']
+        mesh.drift_sort(pos[:n_p], mom[:n_p], None, pos2[:n_p], mom2[:n_p], None, dt_over_mass,
+                        table)
+        pos, pos2, mom, mom2 = pos2, pos, mom2, mom
+        reg = {'start': table[:mesh.table_entries], 'count': None,
+               'spare': mesh.new_region_table()}
+        spare2 = mesh.new_region_table()
+    elif args.no_sort:
         PHASES = ['drift', 'zero', 'deposit'] + poisson + ['gather_kick']
     else:  # the tiled deposit assigns the mesh: no zero-fill pass
         PHASES = ['drift_sort', 'deposit'] + poisson + ['gather_kick']
@@ -501,6 +525,26 @@ def main():
                 ev[i].record()
                 i += 1
         mark()
+        if fused:
+            if reg['count'] is None:
+                mesh.deposit_tiled(pos[:n_p], table, contribution, accumulate=False)
+            else:
+                mesh.deposit_regions(pos, reg['start'], reg['count'], contribution)
+            mark()
+            mesh.poisson_solve(4, C, False, 0.0)
+            mark()
+            start_out, count_out = reg['spare']
+            mesh.predict_regions(reg['start'], reg['count'], start_out)
+            mesh.gather_kick_drift_scatter(pos, mom, None, reg['start'], reg['count'], pos2, mom2,
+                                           None, start_out, count_out, 2, kick_factor,
+                                           dt_over_mass)
+            mark()
+            old = (reg['start'], reg['count']) if reg['count'] is not None else spare2
+            reg.update(start=start_out, count=count_out, spare=old)
+            pos, pos2, mom, mom2 = pos2, pos, mom2, mom
+            if record:
+                events.append(ev)
+            return
         if not args.no_sort:
             # drift + tile sort fused (cg_drift_sort): the drifted particles land in tile order
             mesh.drift_sort(pos, mom, None, pos2, mom2, None, dt_over_mass, table)
@@ -561,7 +605,11 @@ def main():
         step(True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    mesh.check_errors()
+    mesh.check_errors()   # (a bucket that outgrew its region would have dropped particles)
+    if fused:
+        kept = int(reg['count'].long().sum().item())
+        if kept != n_p:
+            sys.exit(f'bench.py: {kept} of {n_p} particles after the timed steps')
 
     n_g = N**3
     mv, sv = moved_bytes(n_p, n_g), survey_bytes(n_p, n_g)
@@ -582,7 +630,8 @@ def main():
     phases = {ph: entry(ph, phase_ms[ph]) for ph in PHASES}
     # single kernels: the phases that are one launch, plus the five FFT passes timed by
     # HIP events inside the library (a few extra solves after the timed region)
-    kernels = {ph: phase_ms[ph] for ph in ('deposit', 'gather_kick', 'drift', 'sr_sweep')
+    kernels = {ph: phase_ms[ph] for ph in ('deposit', 'gather_kick', 'kick_drift_sort', 'drift',
+                                           'sr_sweep')
                if ph in phase_ms}  # (drift_sort is two kernels + a scan: reported under phases)
     if not args.split_poisson:
         pass_ms = [0.0]*5
@@ -616,7 +665,9 @@ def main():
                                f'deconvolution order 4, FD order {4 if sr else 2}, 1 '
                                + ('P3M step = drift + tile sort + long-range kick + short-range '
                                   'kick (r_s 1.25 cells, range 4.5 r_s)' if sr else
-                                  'PM step = drift + tile sort + long-range kick'),
+                                  'PM step = drift + tile sort + long-range kick'
+                                  + (' (kick, drift and sort of a step in one pass: the loop is '
+                                     'entered after the sort)' if fused else '')),
                    'particles': n_p, 'gridsize': N, 'parallelism': 'domains1'},
         'emigrants_per_step': 0,
     }
@@ -654,15 +705,15 @@ def main():
                      'phases it replaces, given for comparison only'),
             'traffic_source': traffic_source}
     result['kernels'] = {k: entry(k, ms) for k, ms in kernels.items()}
-    groups = {'deposit+interp': (['deposit', 'gather_kick'],
-                                 phase_ms['deposit'] + phase_ms['gather_kick']),
+    interp = 'kick_drift_sort' if fused else 'gather_kick'
+    groups = {'deposit+interp': (['deposit', interp], phase_ms['deposit'] + phase_ms[interp]),
               'poisson_solve': (['poisson'] if not args.split_poisson else
                                 ['fft_forward', 'kspace', 'fft_backward'],
                                 sum(phase_ms[ph] for ph in poisson))}
     result['roofline_groups'] = {}
     for gname, (keys, ms) in groups.items():
         moved = sum(mv[k] for k in keys)
-        credit = (sv['deposit'] + sv['gather_kick']) if gname == 'deposit+interp' else sv['poisson']
+        credit = (sv['deposit'] + sv[interp]) if gname == 'deposit+interp' else sv['poisson']
         result['roofline_groups'][gname] = {
             'ms': round(ms, 3), 'moved_GB': round(moved/1e9, 2),
             'frac_moved': round(moved/(ms*1e-3)/1e9/HBM_PEAK_GBS, 4),

@@ -561,7 +561,48 @@ extern "C" int cg_deposit_cic_tiled(cg_ctx *c, const double *pos, int64_t n,
                                     int accumulate) {
     CG_CHECK(c && tile_offset && (pos || n == 0), "cg_deposit_cic_tiled: null argument");
     CG_CHECK(n >= 0 && n < (1ll << 32), "cg_deposit_cic_tiled: n out of range");
-    return cgk_deposit_cic_tiled(c, pos, n, tile_offset, contribution, accumulate);
+    return cgk_deposit_cic_tiled(c, pos, n, tile_offset, nullptr, contribution, accumulate);
+}
+
+extern "C" int cg_deposit_cic_regions(cg_ctx *c, const double *pos, const uint32_t *start,
+                                      const uint32_t *count, double contribution,
+                                      int accumulate) {
+    CG_CHECK(c && pos && start && count, "cg_deposit_cic_regions: null argument");
+    return cgk_deposit_cic_tiled(c, pos, 0, start, count, contribution, accumulate);
+}
+
+extern "C" int64_t cg_region_capacity(const cg_ctx *c, int64_t n) {
+    return c ? n + n / 4 + 32 * 8 * c->ntiles : 0;
+}
+
+extern "C" int cg_predict_regions(cg_ctx *c, const uint32_t *start_in, const uint32_t *count_in,
+                                  uint32_t *start_out) {
+    CG_CHECK(c && start_in && start_out, "cg_predict_regions: null argument");
+    return cgk_predict_regions(c, start_in, count_in, start_out);
+}
+
+extern "C" int cg_gather_kick_drift_scatter(
+    cg_ctx *c, const double *pos_in, const double *mom_in, const int64_t *ids_in,
+    const uint32_t *start_in, const uint32_t *count_in, double *pos_out, double *mom_out,
+    int64_t *ids_out, const uint32_t *start_out, uint32_t *count_out, int diff_order,
+    double factor, double dt_over_mass) {
+    CG_CHECK(c && pos_in && mom_in && start_in && pos_out && mom_out && start_out && count_out,
+             "cg_gather_kick_drift_scatter: null argument");
+    CG_CHECK(pos_in != pos_out && mom_in != mom_out,
+             "cg_gather_kick_drift_scatter: in/out must not alias");
+    CG_CHECK((ids_in == nullptr) == (ids_out == nullptr),
+             "cg_gather_kick_drift_scatter: ids_in and ids_out must both be given or both be null");
+    CG_CHECK(diff_order == 2 || diff_order == 4,
+             "cg_gather_kick_drift_scatter: differentiation order %d not built", diff_order);
+    CG_CHECK((diff_order + 1) / 2 <= c->p.nghosts,
+             "cg_gather_kick_drift_scatter: differentiation order %d needs nghosts >= %d",
+             diff_order, (diff_order + 1) / 2);
+    CG_CHECK(c->p.nprocs == 1, "cg_gather_kick_drift_scatter: single-domain entry point (x-slab "
+                               "domains use cg_gather_kick_tiled_prepare + cg_drift_sort)");
+    FusedScatter fs{count_in, start_out, count_out, pos_out, mom_out, ids_in, ids_out};
+    c->prep_valid = false;
+    return cgk_gather_kick_tiled(c, pos_in, const_cast<double *>(mom_in), 0, start_in, diff_order,
+                                 factor, 0, dt_over_mass, &fs);
 }
 
 extern "C" int cg_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, int64_t n,

@@ -223,7 +223,18 @@ int cgk_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int
                    int diff_order, double minus_dt, double inv_c2);
 int cgk_fft(cg_ctx *c, int what, int deconv_order, double C, int long_range, double E);
 int cgk_deposit_cic_tiled(cg_ctx *c, const double *pos, i64 n, const unsigned *tile_offset,
-                          double contribution, int accumulate);
+                          const unsigned *count, double contribution, int accumulate);
+// output side of the fused kick + drift + scatter (cg_gather_kick_drift_scatter)
+struct FusedScatter {
+    const unsigned *count_in;  // populations of the input regions (null: dense tile order)
+    const unsigned *start_out;
+    unsigned *count_out;
+    double *pos_out, *mom_out;
+    const i64 *ids_in;
+    i64 *ids_out;
+};
 int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
                           const unsigned *tile_offset, int diff_order, double factor,
-                          int prepare, double next_dtm);
+                          int prepare, double next_dtm, const FusedScatter *fs = nullptr);
+int cgk_predict_regions(cg_ctx *c, const unsigned *start_in, const unsigned *count_in,
+                        unsigned *start_out);

@@ -270,3 +270,38 @@ int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *i
     }
     return 0;
 }
+
+// Regions with gaps for the next tile order: every (tile, bucket) gets room for its present
+// population plus a quarter plus 32 (the populations change by a few per cent per step: the
+// drift moves a particle a fraction of a cell); start_out = exclusive sum of the capacities.
+__global__ void k_region_caps(const unsigned *__restrict__ start_in,
+                              const unsigned *__restrict__ count_in, i64 nb,
+                              unsigned *__restrict__ cap) {
+    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nb) return;
+    unsigned cnt = 0;
+    if (k < nb) cnt = count_in ? count_in[k] : start_in[k + 1] - start_in[k];
+    cap[k] = k < nb ? cnt + (cnt >> 2) + 32u : 0u;
+}
+
+// cg_predict_regions: capacities -> exclusive sum
+int cgk_predict_regions(cg_ctx *c, const unsigned *start_in, const unsigned *count_in,
+                        unsigned *start_out) {
+    const i64 nb = 8 * c->ntiles;
+    hipLaunchKernelGGL(k_region_caps, dim3((unsigned)((nb + 256) / 256)), dim3(256), 0, c->stream,
+                       start_in, count_in, nb, c->tile_cursor);
+    CG_LAUNCH_CHECK();
+    size_t need = 0;
+    CG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, c->tile_cursor, start_out,
+                                            (int)(nb + 1), c->stream));
+    if (need > c->scan_tmp_bytes) {
+        CG_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->scan_tmp);
+        c->scan_tmp = nullptr;
+        CG_HIP(hipMalloc(&c->scan_tmp, need));
+        c->scan_tmp_bytes = need;
+    }
+    CG_HIP(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp, need, c->tile_cursor, start_out,
+                                            (int)(nb + 1), c->stream));
+    return 0;
+}

@@ -70,6 +70,7 @@ __device__ __forceinline__ unsigned tile_for_block(unsigned b, unsigned ntiles) 
 template <int T, bool ACCUMULATE>
 __global__ __launch_bounds__(512) void k_deposit_cic_pull(
     const double *__restrict__ pos, const unsigned *__restrict__ table,
+    const unsigned *__restrict__ count /* populations of regions with gaps, or null: dense */,
     double *__restrict__ mesh, i64 N, i64 ny, i64 pad, int g, int ntx, int nt, unsigned nblocks,
     XMap xm, CicGeom geo, double contribution) {
     // tiles: ntx rows along x (this domain's), nt along y and z.  An x-slab domain has
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(512) void k_deposit_cic_pull(
         // arrive through the halo add), the ghost row itself holds no particles
         bool have = (f & d) == d && na >= 0 && na < ntx;
         unsigned e = have ? ((unsigned)((na * nt + nb) * nt + nc)) * 8u + (unsigned)f : 0u;
-        unsigned b0 = table[e], cnt = have ? table[e + 1] - b0 : 0u;
+        unsigned b0 = table[e], cnt = have ? (count ? count[e] : table[e + 1] - b0) : 0u;
         // inclusive scan of cnt over the 64 lanes of this (first) wave
         unsigned incl = cnt;
 #pragma unroll
@@ -154,29 +155,29 @@ __global__ __launch_bounds__(512) void k_deposit_cic_pull(
 
 template <int T>
 static int launch_deposit(cg_ctx *c, const double *pos, const unsigned *table,
-                          double contribution, int accumulate) {
+                          const unsigned *count, double contribution, int accumulate) {
     int rows = c->tiles.ntx + (c->xmap.periodic ? 0 : 1);
     unsigned nb = (unsigned)((i64)rows * c->tiles.nty * c->tiles.ntz);
     if (accumulate)
         hipLaunchKernelGGL((k_deposit_cic_pull<T, true>), dim3(nb), dim3(512), 0, c->stream, pos,
-                           table, c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.ntx, c->tiles.nty,
+                           table, count, c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.ntx, c->tiles.nty,
                            nb, c->xmap, c->geom_deposit, contribution);
     else
         hipLaunchKernelGGL((k_deposit_cic_pull<T, false>), dim3(nb), dim3(512), 0, c->stream, pos,
-                           table, c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.ntx, c->tiles.nty,
+                           table, count, c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.ntx, c->tiles.nty,
                            nb, c->xmap, c->geom_deposit, contribution);
     return 0;
 }
 
 int cgk_deposit_cic_tiled(cg_ctx *c, const double *pos, i64 n, const unsigned *tile_offset,
-                          double contribution, int accumulate) {
+                          const unsigned *count, double contribution, int accumulate) {
     (void)n;
     const int T = c->tiles.tx;
     switch (T) {
-        case 16: launch_deposit<16>(c, pos, tile_offset, contribution, accumulate); break;
-        case 8: launch_deposit<8>(c, pos, tile_offset, contribution, accumulate); break;
-        case 4: launch_deposit<4>(c, pos, tile_offset, contribution, accumulate); break;
-        case 2: launch_deposit<2>(c, pos, tile_offset, contribution, accumulate); break;
+        case 16: launch_deposit<16>(c, pos, tile_offset, count, contribution, accumulate); break;
+        case 8: launch_deposit<8>(c, pos, tile_offset, count, contribution, accumulate); break;
+        case 4: launch_deposit<4>(c, pos, tile_offset, count, contribution, accumulate); break;
+        case 2: launch_deposit<2>(c, pos, tile_offset, count, contribution, accumulate); break;
         default: cg_set_error("cgk_deposit_cic_tiled: tile extent %d", T); return 1;
     }
     CG_LAUNCH_CHECK();
@@ -217,7 +218,36 @@ struct PrepArgs {
     i64 *emig_idx;
     unsigned *emig_count;
     i64 emig_cap;
+    // MODE 2 (fused kick + drift + scatter): the drifted particles with their kicked momenta go
+    // straight to their place in the next tile order.  start_out[k] = first slot of the region
+    // reserved for (tile, bucket) k (capacities predicted from the present populations,
+    // cg_predict_regions), count_out[k] = slots taken so far (zeroed before the launch; it ends
+    // as the new population).  A run that does not fit sets CG_ERR_BUCKET_OVERFLOW.
+    const unsigned *start_out;
+    unsigned *count_out;
+    double *pos_out, *mom_out;
+    const i64 *ids_in;
+    i64 *ids_out;
+    unsigned *err_flags;
+    // input populations when the input itself is in regions with gaps (null: dense tile order)
+    const unsigned *count_in;
 };
+
+// Write the 3*rl doubles of a run of rl consecutive records cooperatively (see cg_particles.hip
+// store_run): every store instruction covers a contiguous range.
+__device__ __forceinline__ void gk_store_run(double *__restrict__ out, i64 first, int rs, int rl,
+                                             int lane, bool valid, double a, double b, double c) {
+    int r = lane - rs;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int d = r + k * rl;
+        int src = rs + d / 3, comp = d - 3 * (d / 3);
+        src = src > 63 ? 63 : src;
+        double va = __shfl(a, src), vb = __shfl(b, src), vc = __shfl(c, src);
+        double v = comp == 0 ? va : (comp == 1 ? vb : vc);
+        if (valid) out[3 * first + d] = v;
+    }
+}
 
 // LDS of the staged block.  T = 16, order 2: 19^3 doubles = 54,872 B would allow two workgroups
 // per CU (160 KB); the first and the last row of the block (a = 0, b = 0 and a = E-1, b = E-1)
@@ -237,7 +267,9 @@ struct GatherLds {
                        // spills 72 B per lane and takes 9.0 instead of 7.3 ms
 #endif
 
-template <int ORDER, int T, bool PREP>
+// MODE 0: gather + kick in place.  1: also histogram the tile keys after the next drift (PREP).
+// 2: kick, drift and scatter into the next tile order in one pass (nothing written in place).
+template <int ORDER, int T, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
     (ORDER == 2 ? CG_GK_WAVES : 4), 8))) void k_gather_kick_tiled(
     const double *__restrict__ pos, double *__restrict__ mom,
@@ -249,8 +281,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
     constexpr int TRIM = GatherLds<ORDER, T>::trim;
     extern __shared__ double lds_raw[];
     double *const lds = lds_raw - TRIM;  // entry i of the block lives at lds[i], TRIM <= i
+    constexpr bool PREP = MODE == 1, FUSED = MODE == 2;
     const unsigned tile = tile_for_block(blockIdx.x, ntiles);
-    const i64 beg = tile_offset[8 * tile], end = tile_offset[8 * tile + 8];
+    // the tile's particles: dense tile order -> one range; regions with gaps (prep.count_in)
+    // -> its 8 buckets' (start, population), walked as one flat index
+    __shared__ unsigned seg_beg[8], seg_pre[9];
+    const bool gapped = FUSED && prep.count_in != nullptr;
+    i64 beg = tile_offset[8 * tile], end = tile_offset[8 * tile + 8];
+    if (gapped) {
+        if (threadIdx.x < 64) {
+            const int f = threadIdx.x & 7;
+            unsigned cnt = prep.count_in[8 * tile + f];
+            unsigned incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                unsigned v = __shfl_up(incl, o);
+                if (f >= o) incl += v;
+            }
+            if (threadIdx.x < 8) {
+                seg_beg[f] = tile_offset[8 * tile + f];
+                seg_pre[f + 1] = incl;
+                if (f == 0) seg_pre[0] = 0;
+            }
+        }
+        __syncthreads();
+        beg = 0;
+        end = seg_pre[8];
+    }
     if (beg == end) return;  // uniform for the workgroup
     const int tc = tile % nt, tb = (tile / nt) % nt, ta = tile / (nt * nt);
     const int Ni = (int)N;
@@ -306,9 +363,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
     }
     __syncthreads();
     for (i64 pbase = beg; pbase < end; pbase += 512) {
-        const i64 p = pbase + threadIdx.x;
+        i64 p = pbase + threadIdx.x;
         const bool pvalid = p < end;
+        if (gapped && pvalid) {  // flat index -> slot of its bucket's region
+            int f = 0;
+#pragma unroll
+            for (int step = 4; step > 0; step >>= 1)
+                if (seg_pre[f + step] <= (unsigned)p) f += step;
+            p = (i64)seg_beg[f] + (p - seg_pre[f]);
+        }
         unsigned next_key = kNoTile;
+        double nx = 0, ny_ = 0, nz = 0, n0 = 0, n1 = 0, n2 = 0;  // FUSED: what travels
         if (pvalid) {
         const double px = pos[3 * p + 0], py = pos[3 * p + 1], pz = pos[3 * p + 2];
         Cic1 cx = cic1(px, geo.off[0], geo.scale);
@@ -375,14 +440,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         }
         const double m0 = mom[3 * p + 0] + val[0], m1 = mom[3 * p + 1] + val[1],
                      m2 = mom[3 * p + 2] + val[2];
-        mom[3 * p + 0] = m0;
-        mom[3 * p + 1] = m1;
-        mom[3 * p + 2] = m2;
-        if (PREP)
-            next_key = tile_of(ref_mod(px + m0 * prep.next_dtm, prep.boxsize),
-                               ref_mod(py + m1 * prep.next_dtm, prep.boxsize),
-                               ref_mod(pz + m2 * prep.next_dtm, prep.boxsize), prep.geo_sort, g, N,
-                               prep.tiles, xm.x0);
+        if (!FUSED) {
+            mom[3 * p + 0] = m0;
+            mom[3 * p + 1] = m1;
+            mom[3 * p + 2] = m2;
+        }
+        if (PREP || FUSED) {
+            // Component.drift (species.py:2194-2196) of the kicked particle
+            nx = ref_mod(px + m0 * prep.next_dtm, prep.boxsize);
+            ny_ = ref_mod(py + m1 * prep.next_dtm, prep.boxsize);
+            nz = ref_mod(pz + m2 * prep.next_dtm, prep.boxsize);
+            n0 = m0;
+            n1 = m1;
+            n2 = m2;
+            next_key = tile_of(nx, ny_, nz, prep.geo_sort, g, N, prep.tiles, xm.x0);
+        }
         }
         if (PREP) {
             int rs, rl;
@@ -394,6 +466,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
                 if ((i64)slot < prep.emig_cap) prep.emig_idx[slot] = p;
             }
         }
+        if (FUSED) {
+            // the scatter of cg_particles.hip k_tile_scatter: one atomic per run of equal keys
+            // among consecutive lanes, runs stored cooperatively
+            const int lane = threadIdx.x & 63;
+            int rs, rl;
+            wave_runs(next_key, lane, rs, rl);
+            unsigned first = kNoTile;
+            if (lane == rs && next_key != kNoTile) {
+                const unsigned o0 = prep.start_out[next_key],
+                               room = prep.start_out[next_key + 1] - o0;
+                const unsigned local = atomicAdd(&prep.count_out[next_key], (unsigned)rl);
+                if (local + (unsigned)rl > room) atomicOr(prep.err_flags, 2u);  // overflow
+                else first = o0 + local;
+            }
+            first = __shfl(first, rs);
+            const bool valid = pvalid && next_key != kNoTile && first != kNoTile;
+            gk_store_run(prep.pos_out, (i64)first, rs, rl, lane, valid, nx, ny_, nz);
+            gk_store_run(prep.mom_out, (i64)first, rs, rl, lane, valid, n0, n1, n2);
+            if (valid && prep.ids_in) prep.ids_out[(i64)first + (lane - rs)] = prep.ids_in[p];
+        }
     }
 }
 
@@ -401,8 +493,9 @@ template <int ORDER, int T>
 static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsigned *tile_offset,
                          double c1, double c2, double factor, const PrepArgs *prep) {
     size_t lds = sizeof(double) * GatherLds<ORDER, T>::doubles;
-    auto kern = k_gather_kick_tiled<ORDER, T, false>;
-    auto kern_prep = k_gather_kick_tiled<ORDER, T, true>;
+    auto kern = k_gather_kick_tiled<ORDER, T, 0>;
+    auto kern_prep = k_gather_kick_tiled<ORDER, T, 1>;
+    auto kern_fused = k_gather_kick_tiled<ORDER, T, 2>;
     // the attribute belongs to the function ON A DEVICE: once per device of this process
     static bool attr_set[64] = {};
     const int dev = c->p.device & 63;
@@ -411,10 +504,16 @@ static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsign
                                    (int)lds));
         CG_HIP(hipFuncSetAttribute((const void *)kern_prep,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CG_HIP(hipFuncSetAttribute((const void *)kern_fused,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev] = true;
     }
     unsigned nt = (unsigned)c->ntiles;
-    if (prep)
+    if (prep && prep->start_out)
+        hipLaunchKernelGGL(kern_fused, dim3(nt), dim3(512), lds, c->stream, pos, mom, tile_offset,
+                           c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap,
+                           c->geom_gather, c1, c2, factor, *prep);
+    else if (prep)
         hipLaunchKernelGGL(kern_prep, dim3(nt), dim3(512), lds, c->stream, pos, mom, tile_offset,
                            c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap,
                            c->geom_gather, c1, c2, factor, *prep);
@@ -427,12 +526,24 @@ static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsign
 
 int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
                           const unsigned *tile_offset, int diff_order, double factor,
-                          int prepare, double next_dtm) {
+                          int prepare, double next_dtm, const FusedScatter *fs) {
     PrepArgs prep_args{next_dtm, c->p.boxsize, c->geom_deposit, c->tiles, c->tile_count,
                        c->emig_idx, c->emig_count, c->emig_cap};
+    if (fs) {
+        prep_args.start_out = fs->start_out;
+        prep_args.count_out = fs->count_out;
+        prep_args.pos_out = fs->pos_out;
+        prep_args.mom_out = fs->mom_out;
+        prep_args.ids_in = fs->ids_in;
+        prep_args.ids_out = fs->ids_out;
+        prep_args.err_flags = c->err_flags;
+        prep_args.count_in = fs->count_in;
+        prepare = 0;
+        CG_HIP(hipMemsetAsync(fs->count_out, 0, 4 * (8 * c->ntiles), c->stream));
+    }
     if (prepare && c->emig_idx)
         CG_HIP(hipMemsetAsync(c->emig_count, 0, sizeof(unsigned), c->stream));
-    const PrepArgs *prep = prepare ? &prep_args : nullptr;
+    const PrepArgs *prep = (prepare || fs) ? &prep_args : nullptr;
     if (prepare)
         CG_HIP(hipMemsetAsync(c->tile_count, 0, 4 * (8 * c->ntiles + 1), c->stream));
     const int T = c->tiles.tx;

@@ -40,6 +40,7 @@ class cg_params(ctypes.Structure):
 CG_FETCH_MESH_REAL = 0
 CG_FETCH_MESH_FOURIER = 1
 CG_ERR_STALE_HISTOGRAM = 1
+CG_ERR_BUCKET_OVERFLOW = 2
 
 _vp, _i64, _dbl, _int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int
 
@@ -54,6 +55,11 @@ SYMBOLS = {
     'cg_device_bytes': (_i64, [_vp]),
     'cg_error_flags': (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     'cg_prepare_invalidate': (_int, [_vp]),
+    'cg_region_capacity': (_i64, [_vp, _i64]),
+    'cg_predict_regions': (_int, [_vp, _vp, _vp, _vp]),
+    'cg_deposit_cic_regions': (_int, [_vp, _vp, _vp, _vp, _dbl, _int]),
+    'cg_gather_kick_drift_scatter': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                            _int, _dbl, _dbl]),
     'cg_mesh_zero': (_int, [_vp]),
     'cg_deposit_cic': (_int, [_vp, _vp, _i64, _dbl]),
     'cg_deposit_cic_tiled': (_int, [_vp, _vp, _i64, _vp, _dbl, _int]),

@@ -264,14 +264,6 @@ class PotentialMesh:
         check(_L.cg_error_flags(self._ctx, ctypes.byref(flags)))
         return int(flags.value)
 
-    def check_errors(self):
-        flags = self.error_flags()
-        if flags & lib.CG_ERR_STALE_HISTOGRAM:
-            raise lib.ConceptGPUError(
-                'cg_drift_sort: the tile histogram prepared by the last gather-kick did not match '
-                'the particles it sorted (momenta were changed in between without '
-                'prepare_invalidate()); particles were dropped')
-
     def prepare_invalidate(self):
         """Momenta were changed outside this mesh: forget the prepared drift histogram."""
         check(_L.cg_prepare_invalidate(self._ctx))
@@ -532,6 +524,47 @@ class PotentialMesh:
         check(_L.cg_gather_kick_tiled_prepare(self._ctx, _ptr(pos), _ptr(mom), n,
                                               _ptr(tile_offset), int(diff_order), float(factor),
                                               float(next_dt_over_mass)))
+
+    # -- regions with gaps: kick + drift + scatter in one pass ---------------------------
+    def region_capacity(self, n):
+        """rows a particle array needs to hold n particles in predicted regions"""
+        return int(_L.cg_region_capacity(self._ctx, int(n)))
+
+    def new_region_table(self):
+        """(start int32[8*ntiles+1], count int32[8*ntiles]) on the device"""
+        return (torch.zeros(8*self.ntiles + 1, dtype=torch.int32, device=self.device),
+                torch.zeros(8*self.ntiles, dtype=torch.int32, device=self.device))
+
+    def predict_regions(self, start_in, count_in, start_out):
+        check(_L.cg_predict_regions(self._ctx, _ptr(start_in),
+                                    _ptr(count_in) if count_in is not None else None,
+                                    _ptr(start_out)))
+
+    def deposit_regions(self, pos, start, count, contribution, accumulate=False):
+        check(_L.cg_deposit_cic_regions(self._ctx, _ptr(pos), _ptr(start), _ptr(count),
+                                        float(contribution), int(accumulate)))
+
+    def gather_kick_drift_scatter(self, pos_in, mom_in, ids_in, start_in, count_in, pos_out,
+                                  mom_out, ids_out, start_out, count_out, diff_order, factor,
+                                  dt_over_mass):
+        """cg_gather_kick_drift_scatter (see concept_gpu.h): nothing is written in place"""
+        check(_L.cg_gather_kick_drift_scatter(
+            self._ctx, _ptr(pos_in), _ptr(mom_in), _ptr(ids_in) if ids_in is not None else None,
+            _ptr(start_in), _ptr(count_in) if count_in is not None else None, _ptr(pos_out),
+            _ptr(mom_out), _ptr(ids_out) if ids_out is not None else None, _ptr(start_out),
+            _ptr(count_out), int(diff_order), float(factor), float(dt_over_mass)))
+
+    def check_errors(self):
+        flags = self.error_flags()
+        if flags & lib.CG_ERR_STALE_HISTOGRAM:
+            raise lib.ConceptGPUError(
+                'cg_drift_sort: the tile histogram prepared by the last gather-kick did not match '
+                'the particles it sorted (momenta were changed in between without '
+                'prepare_invalidate()); particles were dropped')
+        if flags & lib.CG_ERR_BUCKET_OVERFLOW:
+            raise lib.ConceptGPUError(
+                'cg_gather_kick_drift_scatter: a (tile, bucket) outgrew its predicted region; '
+                'particles were dropped — repeat the step on the exact path')
 
     def new_tile_table(self):
         """uint32[8*ntiles + 1] on the device (stored as int32 bits): first particle

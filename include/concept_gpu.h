@@ -149,6 +149,38 @@ int cg_gather_kick_tiled_prepare(cg_ctx *ctx, const double *pos /*DEV 3n*/,
                                  double *mom /*DEV 3n*/, int64_t n,
                                  const uint32_t *tile_offset /*DEV tile table*/, int diff_order,
                                  double factor, double next_dt_over_mass);
+/* The kick, the drift that follows it and the tile sort of the drifted particles in ONE pass
+ * (the reference fuses kicks and drifts where it can, driftkick_short, main.py:1347): a
+ * workgroup per tile gathers the force for its particles, kicks, drifts and writes position
+ * and kicked momentum straight to the particle's place in the next tile order — the momenta
+ * are not written in place and re-read, the positions are read once: 96 B per particle + the
+ * potential instead of 168 B.  The places exist before the new keys are known because the
+ * next order is laid out in REGIONS WITH GAPS: (tile, bucket) k owns the slots
+ * [start_out[k], start_out[k+1]), sized by cg_predict_regions from the present populations
+ * (population + 25 % + 32), and holds count_out[k] particles afterwards; slots beyond are
+ * never read.  A bucket that outgrows its region sets CG_ERR_BUCKET_OVERFLOW (cg_error_flags)
+ * and drops particles: the caller then repeats the step on the exact path
+ * (cg_gather_kick_tiled + cg_drift_sort) from the untouched input arrays.
+ *   cg_region_capacity   upper bound of start_out[8*ntiles] for n particles (array sizes)
+ *   cg_predict_regions   start_in / count_in: the present order (count_in NULL: dense tile
+ *                        order, populations = differences of start_in) -> start_out[8*ntiles+1]
+ *   cg_deposit_cic_regions   cg_deposit_cic_tiled for particles stored in such regions
+ *   cg_gather_kick_drift_scatter   mom_out = mom_in + kick (A9/A10), pos_out = drift(pos_in,
+ *                        mom_out) (A11), both stored in the regions start_out; count_out is
+ *                        zeroed here and ends as the new populations.  Single domain. */
+#define CG_ERR_BUCKET_OVERFLOW 2u
+int64_t cg_region_capacity(const cg_ctx *ctx, int64_t n);
+int cg_predict_regions(cg_ctx *ctx, const uint32_t *start_in /*DEV*/,
+                       const uint32_t *count_in /*DEV or NULL*/, uint32_t *start_out /*DEV*/);
+int cg_deposit_cic_regions(cg_ctx *ctx, const double *pos /*DEV*/, const uint32_t *start /*DEV*/,
+                           const uint32_t *count /*DEV*/, double contribution, int accumulate);
+int cg_gather_kick_drift_scatter(cg_ctx *ctx, const double *pos_in, const double *mom_in,
+                                 const int64_t *ids_in /*nullable*/, const uint32_t *start_in,
+                                 const uint32_t *count_in /*NULL: dense*/, double *pos_out,
+                                 double *mom_out, int64_t *ids_out /*nullable*/,
+                                 const uint32_t *start_out, uint32_t *count_out, int diff_order,
+                                 double factor, double dt_over_mass);
+
 /* Drop the prepared histogram.  Every entry point of this context that writes momenta
  * (cg_gather_kick*, cg_gather_scalar, cg_dmom_apply, cg_drift) does so itself; a caller that
  * changes mom by other means (another context, its own kernels) between the prepare and the

@@ -611,3 +611,106 @@ def test_prepared_histogram_equals_plain(torch_cuda):
     t4 = mesh.drift_sort(p1b, m1b, io, torch.empty_like(p1), torch.empty_like(m1),
                          torch.empty_like(io), 0.5*dtm)
     assert torch.equal(t3, t4)
+
+
+@pytest.mark.parametrize('order', [2, 4])
+def test_fused_kick_drift_scatter_equals_separate(torch_cuda, order):
+    """cg_gather_kick_drift_scatter (kick, drift and tile sort in one pass, particles kept in
+    regions with gaps) against cg_gather_kick_tiled + cg_drift_sort: the same particles with
+    bit-identical positions and momenta, every particle inside the region of its (tile,
+    bucket); two consecutive fused steps (the second reads regions with gaps)."""
+    torch = torch_cuda
+    from concept_amd.mesh import PotentialMesh
+    L, N, n = 64.0, 64, 300_007
+    mesh = PotentialMesh(N, L)
+    rng = np.random.default_rng(31 + order)
+    pos = torch.tensor(rng.uniform(0, L, (n, 3)), device='cuda')
+    mom = torch.tensor(rng.normal(0, 0.4, (n, 3)), device='cuda')
+    ids = torch.arange(n, device='cuda')
+    cap = mesh.region_capacity(n)
+    assert cap >= n
+    p0, m0, i0 = torch.empty_like(pos), torch.empty_like(mom), torch.empty_like(ids)
+    table = mesh.sort_particles(pos, mom, ids, p0, m0, i0)
+    dtm, kick = 0.9, -0.3
+
+    # both paths read the SAME potential in every step (the tiled deposit adds in hardware
+    # order: two deposits of the same particles differ by rounding)
+    big = lambda t: torch.cat([t, torch.full((cap - n,) + tuple(t.shape[1:]), -7,
+                                             dtype=t.dtype, device='cuda')])
+    pa, ma, ia = big(p0), big(m0), big(i0)
+    pb, mb, ib = torch.full_like(pa, -7), torch.full_like(ma, -7), torch.full_like(ia, -7)
+    start_in, count_in = table, None
+    tabs = [mesh.new_region_table(), mesh.new_region_table()]
+    pr, mr, ir, tr = p0.clone(), m0.clone(), i0.clone(), table
+    for step in range(2):
+        # potential from the fused path's layout: dense first, then regions with gaps
+        if count_in is None:
+            mesh.deposit_tiled(pa[:n], table, 1.0)
+        else:
+            mesh.deposit_regions(pa, start_in, count_in, 1.0)
+        mesh.poisson_solve(4, -1.0, False, 0.0)
+        # fused
+        start_out, count_out = tabs[step]
+        mesh.predict_regions(start_in, count_in, start_out)
+        mesh.gather_kick_drift_scatter(pa, ma, ia, start_in, count_in, pb, mb, ib, start_out,
+                                       count_out, order, kick, dtm)
+        assert mesh.error_flags() == 0
+        # reference: the separate kernels on the dense copy
+        mesh.gather_kick_tiled(pr, mr, tr, order, kick)
+        p2, m2, i2 = torch.empty_like(pr), torch.empty_like(mr), torch.empty_like(ir)
+        tr = mesh.drift_sort(pr, mr, ir, p2, m2, i2, dtm)
+        pr, mr, ir = p2, m2, i2
+        ref_p, ref_m = torch.empty_like(pr), torch.empty_like(mr)
+        ref_p[ir] = pr
+        ref_m[ir] = mr
+        st, ct = start_out.long(), count_out.long()
+        assert int(ct.sum()) == n and int(st[-1]) <= cap
+        assert bool((st[1:] - st[:-1] >= ct).all())
+        # live slots: [start[k], start[k] + count[k])
+        slot = torch.arange(cap, device='cuda')
+        k = (torch.searchsorted(st, slot, right=True) - 1).clamp(max=ct.numel() - 1)
+        live = (slot - st[k]) < ct[k]
+        assert int(live.sum()) == n
+        got_i = ib[live]
+        assert torch.equal(torch.sort(got_i)[0], torch.arange(n, device='cuda'))
+        back_p = torch.empty((n, 3), dtype=torch.float64, device='cuda')
+        back_m = torch.empty((n, 3), dtype=torch.float64, device='cuda')
+        back_p[got_i] = pb[live]
+        back_m[got_i] = mb[live]
+        assert torch.equal(back_m, ref_m) and torch.equal(back_p, ref_p)
+        # the populations are those of the exact sort
+        dense = tr.long() & 0xffffffff
+        assert torch.equal(ct, dense[1:] - dense[:-1])
+        pa, pb, ma, mb, ia, ib = pb, pa, mb, ma, ib, ia
+        start_in, count_in = start_out, count_out
+    mesh.close()
+
+
+def test_fused_scatter_overflow_is_flagged(torch_cuda):
+    """A bucket that outgrows its predicted region (here: every particle is sent into one
+    corner) sets CG_ERR_BUCKET_OVERFLOW and leaves the input arrays untouched."""
+    torch = torch_cuda
+    from concept_amd import lib
+    from concept_amd.mesh import PotentialMesh
+    L, N, n = 64.0, 64, 100_000
+    mesh = PotentialMesh(N, L)
+    rng = np.random.default_rng(5)
+    pos = torch.tensor(rng.uniform(0, L, (n, 3)), device='cuda')
+    # momenta that carry everybody to the same point under the drift below
+    target = torch.tensor([3.0, 3.0, 3.0], dtype=torch.float64, device='cuda')
+    mom = (target - pos)
+    cap = mesh.region_capacity(n)
+    p0, m0 = torch.empty_like(pos), torch.empty_like(mom)
+    table = mesh.sort_particles(pos, mom, None, p0, m0, None)
+    mesh.zero()   # zero potential: no kick
+    pa = torch.cat([p0, torch.zeros((cap - n, 3), dtype=torch.float64, device='cuda')])
+    ma = torch.cat([m0, torch.zeros((cap - n, 3), dtype=torch.float64, device='cuda')])
+    keep_p, keep_m = pa.clone(), ma.clone()
+    pb, mb = torch.empty_like(pa), torch.empty_like(ma)
+    start_out, count_out = mesh.new_region_table()
+    mesh.predict_regions(table, None, start_out)
+    mesh.gather_kick_drift_scatter(pa, ma, None, table, None, pb, mb, None, start_out, count_out,
+                                   2, 1.0, 1.0)
+    assert mesh.error_flags() & lib.CG_ERR_BUCKET_OVERFLOW
+    assert torch.equal(pa, keep_p) and torch.equal(ma, keep_m)
+    mesh.close()
