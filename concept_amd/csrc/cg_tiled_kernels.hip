@@ -309,6 +309,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         end = seg_pre[8];
     }
     if (beg == end) return;  // uniform for the workgroup
+    // FUSED: a workgroup is a chain of dependent round trips (stage the block, load a batch of
+    // particles, gather, reserve places, store) and only two fit a CU: the particle loads of a
+    // batch are issued one stage ahead — the first batch's under the staging of the block,
+    // the next one's under the arithmetic of the present one
+    i64 pre_p = 0;
+    bool pre_valid = false;
+    double pre_x = 0, pre_y = 0, pre_z = 0, pre_mx = 0, pre_my = 0, pre_mz = 0;
+    auto fetch = [&](i64 pbase) {
+        i64 p = pbase + threadIdx.x;
+        pre_valid = p < end;
+        if (gapped && pre_valid) {  // flat index -> slot of its bucket's region
+            int f = 0;
+#pragma unroll
+            for (int step = 4; step > 0; step >>= 1)
+                if (seg_pre[f + step] <= (unsigned)p) f += step;
+            p = (i64)seg_beg[f] + (p - seg_pre[f]);
+        }
+        pre_p = p;
+        if (pre_valid) {
+            pre_x = pos[3 * p + 0];
+            pre_y = pos[3 * p + 1];
+            pre_z = pos[3 * p + 2];
+            pre_mx = mom[3 * p + 0];
+            pre_my = mom[3 * p + 1];
+            pre_mz = mom[3 * p + 2];
+        }
+    };
+    if (FUSED) fetch(beg);
     const int tc = tile % nt, tb = (tile / nt) % nt, ta = tile / (nt * nt);
     const int Ni = (int)N;
     const int T0a = (int)xm.x0 + ta * T, T0b = tb * T, T0c = tc * T;
@@ -364,18 +392,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
     __syncthreads();
     for (i64 pbase = beg; pbase < end; pbase += 512) {
         i64 p = pbase + threadIdx.x;
-        const bool pvalid = p < end;
-        if (gapped && pvalid) {  // flat index -> slot of its bucket's region
-            int f = 0;
-#pragma unroll
-            for (int step = 4; step > 0; step >>= 1)
-                if (seg_pre[f + step] <= (unsigned)p) f += step;
-            p = (i64)seg_beg[f] + (p - seg_pre[f]);
+        bool pvalid = p < end;
+        double px = 0, py = 0, pz = 0, qx = 0, qy = 0, qz = 0;
+        if (FUSED) {
+            p = pre_p;
+            pvalid = pre_valid;
+            px = pre_x, py = pre_y, pz = pre_z, qx = pre_mx, qy = pre_my, qz = pre_mz;
+            if (pbase + 512 < end) fetch(pbase + 512);
+        } else if (pvalid) {
+            px = pos[3 * p + 0], py = pos[3 * p + 1], pz = pos[3 * p + 2];
         }
         unsigned next_key = kNoTile;
         double nx = 0, ny_ = 0, nz = 0, n0 = 0, n1 = 0, n2 = 0;  // FUSED: what travels
         if (pvalid) {
-        const double px = pos[3 * p + 0], py = pos[3 * p + 1], pz = pos[3 * p + 2];
         Cic1 cx = cic1(px, geo.off[0], geo.scale);
         Cic1 cy = cic1(py, geo.off[1], geo.scale);
         Cic1 cz = cic1(pz, geo.off[2], geo.scale);
@@ -438,8 +467,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
             val[1] *= factor;
             val[2] *= factor;
         }
-        const double m0 = mom[3 * p + 0] + val[0], m1 = mom[3 * p + 1] + val[1],
-                     m2 = mom[3 * p + 2] + val[2];
+        if (!FUSED) qx = mom[3 * p + 0], qy = mom[3 * p + 1], qz = mom[3 * p + 2];
+        const double m0 = qx + val[0], m1 = qy + val[1], m2 = qz + val[2];
         if (!FUSED) {
             mom[3 * p + 0] = m0;
             mom[3 * p + 1] = m1;
@@ -476,14 +505,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
             if (lane == rs && next_key != kNoTile) {
                 const unsigned o0 = prep.start_out[next_key],
                                room = prep.start_out[next_key + 1] - o0;
+#ifdef CG_GK_NOATOMIC  // timing probe only: no reservation round trip (wrong places)
+                const unsigned local = room > (unsigned)rl ? 0u : 0u * room;
+#else
                 const unsigned local = atomicAdd(&prep.count_out[next_key], (unsigned)rl);
+#endif
                 if (local + (unsigned)rl > room) atomicOr(prep.err_flags, 2u);  // overflow
                 else first = o0 + local;
             }
             first = __shfl(first, rs);
             const bool valid = pvalid && next_key != kNoTile && first != kNoTile;
+#ifndef CG_GK_NOSTORE  // timing probe only
             gk_store_run(prep.pos_out, (i64)first, rs, rl, lane, valid, nx, ny_, nz);
             gk_store_run(prep.mom_out, (i64)first, rs, rl, lane, valid, n0, n1, n2);
+#endif
             if (valid && prep.ids_in) prep.ids_out[(i64)first + (lane - rs)] = prep.ids_in[p];
         }
     }

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Time cg_gather_kick_drift_scatter by itself on the bench workload (2^28 particles / 1024^3,
+thermal momenta): the same input every call, HIP events around each.  Used with
+CONCEPT_GPU_LIB=<variant> (tools/variant.py) for A/B probes of the kernel."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from concept_amd.mesh import PotentialMesh
+n_p, N = (2**28, 1024) if len(sys.argv) < 2 else (int(sys.argv[1])**3, int(sys.argv[2]))
+L = float(N)
+dev = torch.device('cuda')
+mesh = PotentialMesh(N, L)
+gen = torch.Generator(device=dev).manual_seed(1)
+pos = torch.rand((n_p, 3), dtype=torch.float64, device=dev, generator=gen)*(L*(1 - 1e-13))
+dt = 1e-4
+mom = torch.randn((n_p, 3), dtype=torch.float64, device=dev, generator=gen)*(0.2/3**0.5/dt)
+cap = mesh.region_capacity(n_p)
+pa = torch.empty((cap, 3), dtype=torch.float64, device=dev)
+ma = torch.empty((cap, 3), dtype=torch.float64, device=dev)
+table = mesh.sort_particles(pos, mom, None, pa[:n_p], ma[:n_p], None)
+del pos, mom
+mesh.deposit_tiled(pa[:n_p], table, 1.0/N**3)
+mesh.poisson_solve(4, -L**2/3.141592653589793, False, 0.0)
+pb, mb = torch.empty_like(pa), torch.empty_like(ma)
+start_out, count_out = mesh.new_region_table()
+mesh.predict_regions(table, None, start_out)
+ms = []
+for i in range(6):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    mesh.gather_kick_drift_scatter(pa, ma, None, table, None, pb, mb, None, start_out, count_out,
+                                   2, -dt, dt)
+    e1.record()
+    torch.cuda.synchronize()
+    ms.append(e0.elapsed_time(e1))
+print('fused ms per call:', ' '.join(f'{v:.3f}' for v in ms), 'flags', mesh.error_flags(),
+      'placed', int(count_out.long().sum()))
