@@ -515,7 +515,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
             }
             first = __shfl(first, rs);
             const bool valid = pvalid && next_key != kNoTile && first != kNoTile;
-#ifndef CG_GK_NOSTORE  // timing probe only
+#if !defined(CG_GK_RUNSTORE) && !defined(CG_GK_NOSTORE)
+            // every lane stores its own record (24-byte stride; the runs of a wave are
+            // consecutive records, L2 merges the partial lines).  The cooperative run store of
+            // the stand-alone scatter (gk_store_run: contiguous stores through 36 lane
+            // permutes per particle) is slower HERE — 10.4 vs 9.9 ms — because the permutes go
+            // through the LDS crossbar, which the stencil reads already keep busy.
+            if (valid) {
+                const i64 q = 3 * ((i64)first + (lane - rs));
+                prep.pos_out[q] = nx, prep.pos_out[q + 1] = ny_, prep.pos_out[q + 2] = nz;
+                prep.mom_out[q] = n0, prep.mom_out[q + 1] = n1, prep.mom_out[q + 2] = n2;
+            }
+#elif defined(CG_GK_RUNSTORE)   // (NOSTORE: timing probe only)
             gk_store_run(prep.pos_out, (i64)first, rs, rl, lane, valid, nx, ny_, nz);
             gk_store_run(prep.mom_out, (i64)first, rs, rl, lane, valid, n0, n1, n2);
 #endif
