@@ -225,7 +225,8 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
     with two all-to-all transposes, ghost fill, gather-kick)."""
     import torch
     import torch.distributed as dist
-    from concept_amd.distributed import DistributedParticles, SlabDomain, pm_kick
+    from concept_amd.distributed import (DistributedParticles, RegionParticles, SlabDomain,
+                                         pm_kick, pm_step_regions)
     dom = SlabDomain(N, L, device=dev)
     n_local = n_p//world
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
@@ -245,12 +246,18 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
     parts.tile_sort()
     contribution = mass*(float(N)**(-3)*(N/L)**3)
     C = -L**2*G/3.141592653589793
+    fused = not args.no_fused
+    if fused:
+        # kick + drift + tile sort in one pass over particles kept in tile regions with gaps;
+        # the pass hands the leavers of the slab over, the next step ships them before its
+        # deposit (the same cycle as the unfused step, entered after the sort)
+        rp = RegionParticles(parts, slack=1.15)
+        del parts
+        parts = rp
 
     stage_events = []  # per timed step: [(name, event), ...] on the compute stream
 
     def step(record=False):
-        # fused: emigrants of the coming drift are shipped first, then one drift + sort pass
-        # pair; the gather-kick histograms the tiles of the next drift
         evs = []
 
         def mark(name):
@@ -259,10 +266,16 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
                 e.record()
                 evs.append((name, e))
         mark('start')
-        parts.drift_exchange_sort(dt/mass)
-        mark('drift+exchange+sort')
-        pm_kick(dom, parts, contribution, 4, C, mass*(-dt), diff_order=2,
-                next_dt_over_mass=dt/mass, mark=mark)
+        if fused:
+            pm_step_regions(dom, parts, contribution, 4, C, mass*(-dt), dt/mass, diff_order=2,
+                            mark=mark)
+        else:
+            # emigrants of the coming drift are shipped first, then one drift + sort pass pair;
+            # the gather-kick histograms the tiles of the next drift
+            parts.drift_exchange_sort(dt/mass)
+            mark('drift+exchange+sort')
+            pm_kick(dom, parts, contribution, 4, C, mass*(-dt), diff_order=2,
+                    next_dt_over_mass=dt/mass, mark=mark)
         if record:
             stage_events.append(evs)
 
@@ -318,8 +331,9 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
     n_pl, n_gl = total/world, N**3/world
     mv = moved_bytes(n_pl, n_gl)
     # local kernels of rank 0: the gather-kick stage is one launch (+ the ghost fill messages)
-    gk_ms = stages.get('gather_kick', 0.0)
-    gk_rate = mv['gather_kick']/(gk_ms*1e-3)/1e9 if gk_ms else 0.0
+    gk_name = 'kick_drift_sort' if fused else 'gather_kick'
+    gk_ms = stages.get(gk_name, 0.0)
+    gk_rate = mv[gk_name]/(gk_ms*1e-3)/1e9 if gk_ms else 0.0
     # transport: each transpose sends (P-1)/P of the local slab's transform, one peer per link
     tr_bytes = dom.tbuf_a.numel()*8*(world - 1)/world if world > 1 else 0
     ps_ms = stages.get('poisson+transposes+halos', 0.0)
@@ -349,17 +363,18 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
         'config': {'workload': f'{name}: {total} particles (uniform random, thermal rms '
                                f'displacement {args.thermal} cells/step) / {N}^3 PM mesh, CIC, '
                                f'deconvolution order 4, FD order 2, {world} x-slab domains; '
-                               '1 PM step = drift + exchange + tile sort + long-range kick',
+                               '1 PM step = drift + exchange + tile sort + long-range kick'
+                               + (' (kick, drift and sort in one pass)' if fused else ''),
                    'particles': total, 'gridsize': N, 'parallelism': f'xslab{world}',
                    'backend': ('rccl' if backend == 'nccl' else
                                f'{backend} (ranks share GPUs, host-staged messages: a functional '
                                'run of the sharded path, not a rate to quote)')},
         'emigrants_per_step': emigrants/args.steps,
         'emigrant_fraction_per_step': emigrants/args.steps/max(total, 1),
-        'roofline': {'bound': 'hbm', 'kernel': 'gather_kick (rank 0)',
+        'roofline': {'bound': 'hbm', 'kernel': gk_name + ' (rank 0)',
                      'achieved': round(gk_rate, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(gk_rate/HBM_PEAK_GBS, 4), 'traffic': None,
-                     'algorithmic_bytes': int(mv['gather_kick']), 'kernel_ms': round(gk_ms, 4)},
+                     'algorithmic_bytes': int(mv[gk_name]), 'kernel_ms': round(gk_ms, 4)},
         'transport': transport, 'cpu_baseline': None,
         'stages_ms_rank0': {k: round(v, 3) for k, v in stages.items()},
         'transpose_probe_rank0': probe,
@@ -587,7 +602,7 @@ def main():
                 mesh.shortrange_sweep(pos, cells, mom, pos, cells, sr['nt'], True, sr['table'],
                                       sr['scaling'], sr['r2_max'], sr['factor'])
             else:
-                cells = mesh.shortrange_cells(pos, sr['nt'], L/sr['nt'])
+                cells = sr['cells'] = mesh.shortrange_cells(pos, sr['nt'], L/sr['nt'])
                 mark()
                 # kick_short (main.py:1173-1262): nullify Δmom, sweep, apply — the apply is
                 # fused into the sweep's store: the target is the momentum array itself
@@ -677,8 +692,16 @@ def main():
             tests = n_p*27*(n_p/sr['nt']**3)
             per_test = 15   # FP64 VALU instructions of a pair test that misses: 3 sub, 3 mul,
             #                 2 add, 1 cmp, 3 mul + 3 add of the (zero) accumulation
-        else:               # half-tile cells: 5 x 5 columns of 6 cells
-            tests = n_p*25*6*(n_p/(2*sr['nt'])**3)
+        else:               # half-tile cells: 5 x 5 columns of 6 cells — counted on the actual
+            # cell list of the last step (box sums over the populations, periodic)
+            nc = 2*sr['nt']
+            off = sr['cells'][1].long()
+            pop = (off[1:] - off[:-1]).reshape(nc, nc, nc).double()
+            box = sum(torch.roll(pop, s_, 0) for s_ in range(-2, 3))
+            box = sum(torch.roll(box, s_, 1) for s_ in range(-2, 3))
+            colz = box.reshape(nc, nc, nc//2, 2).sum(3)          # per tile along z
+            win = sum(torch.roll(colz, s_, 2) for s_ in (-1, 0, 1))   # 6 cells: tiles tz-1..tz+1
+            tests = float((pop.reshape(nc, nc, nc//2, 2).sum(3)*win).sum())
             per_test = 12   # 3 sub, 3 mul, 2 add, 1 cmp, 3 fma
         ms = kernels[dom]
         # 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2.4 GHz: one FP64 VALU op per lane slot

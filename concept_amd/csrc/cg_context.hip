@@ -597,8 +597,9 @@ extern "C" int cg_gather_kick_drift_scatter(
     CG_CHECK((diff_order + 1) / 2 <= c->p.nghosts,
              "cg_gather_kick_drift_scatter: differentiation order %d needs nghosts >= %d",
              diff_order, (diff_order + 1) / 2);
-    CG_CHECK(c->p.nprocs == 1, "cg_gather_kick_drift_scatter: single-domain entry point (x-slab "
-                               "domains use cg_gather_kick_tiled_prepare + cg_drift_sort)");
+    CG_CHECK(c->p.nprocs == 1 || c->emig_rows,
+             "cg_gather_kick_drift_scatter: on x-slab domains the particles leaving the slab need "
+             "a row buffer (cg_set_emigrant_rows)");
     FusedScatter fs{count_in, start_out, count_out, pos_out, mom_out, ids_in, ids_out};
     c->prep_valid = false;
     return cgk_gather_kick_tiled(c, pos_in, const_cast<double *>(mom_in), 0, start_in, diff_order,
@@ -640,6 +641,32 @@ extern "C" int cg_set_emigrant_list(cg_ctx *c, int64_t *idx, uint32_t *count, in
     c->emig_count = count;
     c->emig_cap = idx ? cap : 0;
     return 0;
+}
+
+extern "C" int cg_set_emigrant_rows(cg_ctx *c, double *rows, uint32_t *count, int64_t cap) {
+    CG_CHECK(c, "cg_set_emigrant_rows: null context");
+    CG_CHECK((rows == nullptr) == (count == nullptr) && cap >= 0,
+             "cg_set_emigrant_rows: rows and count must both be given or both be null");
+    c->emig_rows = rows;
+    c->emig_rows_count = count;
+    c->emig_rows_cap = rows ? cap : 0;
+    return 0;
+}
+
+extern "C" int cg_emigrant_rows_dest(cg_ctx *c, const double *rows, const uint32_t *count,
+                                     int64_t cap, int32_t *dest, int32_t *send_counts) {
+    CG_CHECK(c && send_counts && (cap == 0 || (rows && count && dest)),
+             "cg_emigrant_rows_dest: null argument");
+    return cgk_emigrant_rows_dest(c, rows, count, cap, dest, send_counts);
+}
+
+extern "C" int cg_region_insert(cg_ctx *c, const double *rows, int64_t m, const uint32_t *start,
+                                uint32_t *count, double *pos_out, double *mom_out,
+                                int64_t *ids_out) {
+    CG_CHECK(c && start && count && pos_out && mom_out && (m == 0 || rows),
+             "cg_region_insert: null argument");
+    CG_CHECK(m >= 0, "cg_region_insert: negative row count");
+    return cgk_region_insert(c, rows, m, start, count, pos_out, mom_out, ids_out);
 }
 
 extern "C" int cg_sort_particles(cg_ctx *c, const double *pos_in, const double *mom_in,

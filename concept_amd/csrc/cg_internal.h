@@ -139,6 +139,11 @@ struct cg_ctx {
     i64 *emig_idx = nullptr;
     unsigned *emig_count = nullptr;
     i64 emig_cap = 0;
+    // fused kick + drift + scatter on x-slab domains: the particles the drift takes out of the
+    // slab are appended here as rows of 8 doubles (pos 3, mom 3, id bits, unused) — caller-owned
+    double *emig_rows = nullptr;
+    unsigned *emig_rows_count = nullptr;
+    i64 emig_rows_cap = 0;
     // device word of sticky error bits set by kernels (CG_ERR_*), read by cg_error_flags
     unsigned *err_flags = nullptr;
     i64 device_bytes = 0;
@@ -238,3 +243,7 @@ int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
                           int prepare, double next_dtm, const FusedScatter *fs = nullptr);
 int cgk_predict_regions(cg_ctx *c, const unsigned *start_in, const unsigned *count_in,
                         unsigned *start_out);
+int cgk_emigrant_rows_dest(cg_ctx *c, const double *rows, const unsigned *count, i64 cap,
+                           int *dest, int *send_counts);
+int cgk_region_insert(cg_ctx *c, const double *rows, i64 m, const unsigned *start,
+                      unsigned *count, double *pos_out, double *mom_out, i64 *ids_out);

@@ -305,3 +305,64 @@ int cgk_predict_regions(cg_ctx *c, const unsigned *start_in, const unsigned *cou
                                             (int)(nb + 1), c->stream));
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// x-slab domains with the fused kick + drift + scatter: the leavers sit in a row buffer,
+// already drifted.  k_rows_dest: owner domain of every row (the x-slab holding its lower CIC
+// cell) and the number bound for each domain; k_region_insert: immigrants take their places in
+// the regions of their (tile, bucket) through the same cursors the scatter used.
+// ---------------------------------------------------------------------------
+__global__ void k_rows_dest(const double *__restrict__ rows, const unsigned *__restrict__ count,
+                            i64 cap, CicGeom geo, int g, int N, int nxl, int *__restrict__ dest,
+                            int *__restrict__ send_counts) {
+    i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 n = (i64)*count < cap ? (i64)*count : cap;
+    if (t >= n) return;
+    int d = lower_cell(rows[8 * t], geo.off[0], geo.scale, g, N) / nxl;
+    dest[t] = d;
+    atomicAdd(&send_counts[d], 1);
+}
+int cgk_emigrant_rows_dest(cg_ctx *c, const double *rows, const unsigned *count, i64 cap,
+                           int *dest, int *send_counts) {
+    CG_HIP(hipMemsetAsync(send_counts, 0, sizeof(int) * c->p.nprocs, c->stream));
+    if (cap == 0) return 0;
+    hipLaunchKernelGGL(k_rows_dest, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, c->stream,
+                       rows, count, cap, c->geom_deposit, c->p.nghosts, (int)c->N,
+                       (int)c->xmap.nxl, dest, send_counts);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void k_region_insert(const double *__restrict__ rows, i64 m, CicGeom geo, int g, i64 N,
+                                TileGeom t, i64 x0, const unsigned *__restrict__ start,
+                                unsigned *__restrict__ count, double *__restrict__ pos_out,
+                                double *__restrict__ mom_out, i64 *__restrict__ ids_out,
+                                unsigned *__restrict__ err_flags) {
+    i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const double *row = rows + 8 * r;
+    unsigned key = tile_of(row[0], row[1], row[2], geo, g, N, t, x0);
+    if (key == kNoTile) {  // a row that does not belong here: the sender's owner map differs
+        atomicOr(err_flags, (unsigned)CG_ERR_BUCKET_OVERFLOW);
+        return;
+    }
+    const unsigned o0 = start[key], room = start[key + 1] - o0;
+    const unsigned local = atomicAdd(&count[key], 1u);
+    if (local >= room) {
+        atomicOr(err_flags, (unsigned)CG_ERR_BUCKET_OVERFLOW);
+        return;
+    }
+    const i64 q = (i64)o0 + local;
+    pos_out[3 * q] = row[0], pos_out[3 * q + 1] = row[1], pos_out[3 * q + 2] = row[2];
+    mom_out[3 * q] = row[3], mom_out[3 * q + 1] = row[4], mom_out[3 * q + 2] = row[5];
+    if (ids_out) ids_out[q] = __double_as_longlong(row[6]);
+}
+int cgk_region_insert(cg_ctx *c, const double *rows, i64 m, const unsigned *start,
+                      unsigned *count, double *pos_out, double *mom_out, i64 *ids_out) {
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(k_region_insert, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                       rows, m, c->geom_deposit, c->p.nghosts, c->N, c->tiles, c->xmap.x0, start,
+                       count, pos_out, mom_out, ids_out, c->err_flags);
+    CG_LAUNCH_CHECK();
+    return 0;
+}

@@ -231,6 +231,10 @@ struct PrepArgs {
     unsigned *err_flags;
     // input populations when the input itself is in regions with gaps (null: dense tile order)
     const unsigned *count_in;
+    // x-slab domains: particles leaving the slab go to this row buffer (8 doubles each)
+    double *emig_rows;
+    unsigned *emig_rows_count;
+    i64 emig_rows_cap;
 };
 
 // Write the 3*rl doubles of a run of rl consecutive records cooperatively (see cg_particles.hip
@@ -531,6 +535,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
             gk_store_run(prep.mom_out, (i64)first, rs, rl, lane, valid, n0, n1, n2);
 #endif
             if (valid && prep.ids_in) prep.ids_out[(i64)first + (lane - rs)] = prep.ids_in[p];
+            if (prep.emig_rows && pvalid && next_key == kNoTile) {
+                // leaves this domain's slab: exchange() (communication.py:135-517) takes it
+                // from here, already kicked and drifted
+                const unsigned slot = atomicAdd(prep.emig_rows_count, 1u);
+                if ((i64)slot < prep.emig_rows_cap) {
+                    double *row = prep.emig_rows + 8 * (i64)slot;
+                    row[0] = nx, row[1] = ny_, row[2] = nz, row[3] = n0, row[4] = n1, row[5] = n2;
+                    row[6] = prep.ids_in ? __longlong_as_double(prep.ids_in[p]) : 0.0;
+                    row[7] = 0.0;
+                }
+            }
         }
     }
 }
@@ -584,6 +599,10 @@ int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
         prep_args.ids_out = fs->ids_out;
         prep_args.err_flags = c->err_flags;
         prep_args.count_in = fs->count_in;
+        prep_args.emig_rows = c->emig_rows;
+        prep_args.emig_rows_count = c->emig_rows_count;
+        prep_args.emig_rows_cap = c->emig_rows_cap;
+        if (c->emig_rows) CG_HIP(hipMemsetAsync(c->emig_rows_count, 0, 4, c->stream));
         prepare = 0;
         CG_HIP(hipMemsetAsync(fs->count_out, 0, 4 * (8 * c->ntiles), c->stream));
     }

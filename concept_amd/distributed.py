@@ -591,3 +591,162 @@ def pm_kick(domain, particles, contribution, deconv_order, C, kick_factor, diff_
         if multi:
             particles.prepare_exchange(next_dt_over_mass)
     mark('gather_kick')
+
+
+class RegionParticles:
+    """The streaming form of the particle arrays for the PM step: pos / mom (/ ids) kept in
+    tile REGIONS WITH GAPS (include/concept_gpu.h, cg_gather_kick_drift_scatter), two buffer
+    sets in ping-pong.  A step is
+
+        deposit() -> mesh.poisson_solve(...) -> kick_drift_sort(...)
+
+    — the long-range kick, the drift that follows it in the time loop (main.py:335-358) and
+    the tile sort of the drifted particles in one pass.  On x-slab domains the pass also hands
+    over the particles leaving the slab; finish_exchange() (called by the next deposit()) ships
+    them and seats the arrivals, after the step's single wait for the GPU (the message sizes).
+    Built from a tile-sorted ParticleStore; dense() converts back."""
+
+    def __init__(self, store, slack=1.25):
+        if not store.sorted:
+            raise lib.ConceptGPUError('RegionParticles: the store must be tile-sorted')
+        m = self.mesh = store.mesh
+        self.comm, self.multi = store.comm, store.multi
+        dev = m.device
+        n = store.n
+        self.n_hint = n
+        cap = m.region_capacity(int(n*slack) + 1024 if self.multi else n)
+        self.cap = cap
+        self.has_ids = 'ids' in store.cols
+        mk = lambda w: torch.empty((cap, w), dtype=torch.float64, device=dev)
+        self.pos, self.mom = [mk(3), mk(3)], [mk(3), mk(3)]
+        self.ids = [torch.empty(cap, dtype=torch.int64, device=dev) for _ in range(2)] \
+            if self.has_ids else [None, None]
+        self.pos[0][:n] = store.view('pos')
+        self.mom[0][:n] = store.view('mom')
+        if self.has_ids:
+            self.ids[0][:n] = store.view('ids')
+        self.cur = 0
+        # the present order: dense (the store's tile table) until the first fused pass
+        self.start = self._dense_table = store.table[:8*m.ntiles + 1].clone()
+        self.count = None
+        self.tables = [m.new_region_table(), m.new_region_table()]
+        self.n_dense = n
+        # leavers of the fused pass: rows of 8 doubles, their destinations, the counts
+        P = self.comm.world if self.comm is not None else 1
+        rows_cap = max(4096, cap//16)
+        self.rows = torch.empty((rows_cap, 8), dtype=torch.float64, device=dev)
+        self.rows_dest = torch.empty(rows_cap, dtype=torch.int32, device=dev)
+        self.meta = torch.zeros(1 + 2*P, dtype=torch.int32, device=dev)
+        self.meta_host = torch.zeros(1 + 2*P, dtype=torch.int32)
+        if dev.type == 'cuda':
+            self.meta_host = self.meta_host.pin_memory()
+        self.meta_event = torch.cuda.Event()
+        self.pending = False
+        self.emigrants_total = 0
+
+    # -- A1 -------------------------------------------------------------------------
+    def deposit(self, contribution, accumulate=False):
+        self.finish_exchange()
+        m, c = self.mesh, self.cur
+        if self.count is None:
+            m.deposit_tiled(self.pos[c][:self.n_dense], self._dense_table, contribution,
+                            accumulate)
+        else:
+            m.deposit_regions(self.pos[c], self.start, self.count, contribution, accumulate)
+
+    # -- A9/A10 + A11 + tile sort (+ the hand-over of A12) ----------------------------
+    def kick_drift_sort(self, diff_order, kick_factor, dt_over_mass):
+        m, c, o = self.mesh, self.cur, 1 - self.cur
+        start_out, count_out = self.tables[o]
+        m.predict_regions(self.start, self.count, start_out)
+        if self.multi:
+            lib.check(lib.raw().cg_set_emigrant_rows(m._ctx, _vp(self.rows), _vp(self.meta),
+                                                     self.rows.shape[0]))
+        try:
+            m.gather_kick_drift_scatter(self.pos[c], self.mom[c], self.ids[c], self.start, self.count,
+                                        self.pos[o], self.mom[o], self.ids[o], start_out,
+                                        count_out, diff_order, kick_factor, dt_over_mass)
+        finally:
+            if self.multi:
+                lib.check(lib.raw().cg_set_emigrant_rows(m._ctx, None, None, 0))
+        self.start, self.count, self.cur = start_out, count_out, o
+        if self.multi:
+            # destinations and counts on the device, counts swapped with the peers, copy to
+            # pinned memory started: nothing here waits for the GPU
+            P = self.comm.world
+            lib.check(lib.raw().cg_emigrant_rows_dest(
+                m._ctx, _vp(self.rows), _vp(self.meta), self.rows.shape[0], _vp(self.rows_dest),
+                _vp(self.meta[1:])))
+            self.comm.all_to_all(self.meta[1 + P:1 + 2*P], self.meta[1:1 + P])
+            self.meta_host.copy_(self.meta, non_blocking=True)
+            self.meta_event.record()
+            self.pending = True
+
+    def finish_exchange(self):
+        """ship the leavers of the last kick_drift_sort and seat the arrivals (x-slab
+        domains; the one wait for the GPU of a step)"""
+        if not self.pending:
+            return
+        self.pending = False
+        m, P = self.mesh, self.comm.world
+        self.meta_event.synchronize()
+        host = self.meta_host.tolist()
+        cnt = host[0] & 0xffffffff
+        if cnt > self.rows.shape[0]:
+            raise lib.ConceptGPUError(
+                f'rank {self.comm.rank}: {cnt} particles left the slab in one step, the row '
+                f'buffer holds {self.rows.shape[0]}')
+        send_counts, recv_counts = host[1:1 + P], host[1 + P:1 + 2*P]
+        m_in = int(sum(recv_counts))
+        order = torch.argsort(self.rows_dest[:cnt].long(), stable=True)
+        rows = self.rows[:cnt][order].contiguous()
+        inc = torch.empty((m_in, 8), dtype=torch.float64, device=m.device)
+        self.comm.all_to_all(inc, rows, recv_counts, send_counts)
+        self.emigrants_total += cnt
+        if m_in:
+            c = self.cur
+            lib.check(lib.raw().cg_region_insert(
+                m._ctx, _vp(inc), m_in, _vp(self.start), _vp(self.count), _vp(self.pos[c]),
+                _vp(self.mom[c]), _vp(self.ids[c]) if self.has_ids else None))
+
+    # -- bookkeeping ------------------------------------------------------------------
+    @property
+    def n(self):
+        """live particles of this rank (synchronises)"""
+        self.finish_exchange()
+        if self.count is None:
+            return self.n_dense
+        return int(self.count.long().sum().item())
+
+    def check(self):
+        self.finish_exchange()
+        self.mesh.check_errors()
+
+    def dense(self):
+        """(pos, mom, ids or None) of the live particles as dense tensors, in tile order"""
+        self.finish_exchange()
+        c = self.cur
+        if self.count is None:
+            k = self.n_dense
+            return self.pos[c][:k], self.mom[c][:k], (self.ids[c][:k] if self.has_ids else None)
+        st, ct = self.start.long(), self.count.long()
+        slot = torch.arange(self.cap, device=self.mesh.device)
+        k = (torch.searchsorted(st, slot, right=True) - 1).clamp(max=ct.numel() - 1)
+        live = (slot - st[k]) < ct[k]
+        return self.pos[c][live], self.mom[c][live], (self.ids[c][live] if self.has_ids else None)
+
+
+def pm_step_regions(domain, rp, contribution, deconv_order, C, kick_factor, dt_over_mass,
+                    diff_order=2, long_range=False, E=0.0, mark=None):
+    """One PM step of particles kept in regions (RegionParticles), sharded: exchange of the
+    last step's leavers + deposit, the Poisson solve with its transposes and halos, then kick,
+    drift and tile sort in one pass."""
+    mark = mark or (lambda name: None)
+    m = domain.mesh
+    rp.deposit(contribution)
+    fold = m.fold_ghosts_start()
+    mark('exchange+deposit')
+    m.poisson_solve(deconv_order, C, long_range, E, fold_finish=fold, fill=True)
+    mark('poisson+transposes+halos')
+    rp.kick_drift_sort(diff_order, kick_factor, dt_over_mass)
+    mark('kick_drift_sort')

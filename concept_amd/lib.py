@@ -55,6 +55,9 @@ SYMBOLS = {
     'cg_device_bytes': (_i64, [_vp]),
     'cg_error_flags': (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     'cg_prepare_invalidate': (_int, [_vp]),
+    'cg_set_emigrant_rows': (_int, [_vp, _vp, _vp, _i64]),
+    'cg_emigrant_rows_dest': (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    'cg_region_insert': (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     'cg_region_capacity': (_i64, [_vp, _i64]),
     'cg_predict_regions': (_int, [_vp, _vp, _vp, _vp]),
     'cg_deposit_cic_regions': (_int, [_vp, _vp, _vp, _vp, _dbl, _int]),

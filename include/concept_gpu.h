@@ -181,6 +181,24 @@ int cg_gather_kick_drift_scatter(cg_ctx *ctx, const double *pos_in, const double
                                  const uint32_t *start_out, uint32_t *count_out, int diff_order,
                                  double factor, double dt_over_mass);
 
+/* The same on x-slab domains: a particle whose drift takes it out of the slab has no place in
+ * this domain's next order; the kernel appends it — kicked and drifted — to a caller-owned row
+ * buffer (8 doubles: pos 3, mom 3, id bits, unused), exchange() (communication.py:135-517)
+ * ships the rows, and the receiving domain gives each a place in its regions.  No holes to
+ * close on the sending side: a leaver was never written there.
+ *   cg_set_emigrant_rows   rows[8*cap], *count (DEV; zeroed by every fused launch); NULL = off
+ *   cg_emigrant_rows_dest  owner domain of every row + rows bound for each domain (counts
+ *                          zeroed here; *count read on the device)
+ *   cg_region_insert       m received rows -> their (tile, bucket) regions (start / count of the
+ *                          order they join); sets CG_ERR_BUCKET_OVERFLOW if one does not fit */
+int cg_set_emigrant_rows(cg_ctx *ctx, double *rows /*DEV*/, uint32_t *count /*DEV 1*/,
+                         int64_t cap);
+int cg_emigrant_rows_dest(cg_ctx *ctx, const double *rows /*DEV*/, const uint32_t *count /*DEV*/,
+                          int64_t cap, int32_t *dest /*DEV cap*/, int32_t *send_counts /*DEV P*/);
+int cg_region_insert(cg_ctx *ctx, const double *rows /*DEV 8m*/, int64_t m,
+                     const uint32_t *start /*DEV*/, uint32_t *count /*DEV*/, double *pos_out,
+                     double *mom_out, int64_t *ids_out /*nullable*/);
+
 /* Drop the prepared histogram.  Every entry point of this context that writes momenta
  * (cg_gather_kick*, cg_gather_scalar, cg_dmom_apply, cg_drift) does so itself; a caller that
  * changes mom by other means (another context, its own kernels) between the prepare and the

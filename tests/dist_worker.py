@@ -18,9 +18,11 @@ def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) if backend == 'nccl' else 0)
     dist.init_process_group(backend, rank=rank, world_size=world)
-    from concept_amd.distributed import DistributedParticles, SlabDomain, pm_kick, shortrange_kick
+    from concept_amd.distributed import (DistributedParticles, RegionParticles, SlabDomain,
+                                         pm_kick, pm_step_regions, shortrange_kick)
     p3m = len(sys.argv) > 6 and sys.argv[6] == 'p3m'
     fused = len(sys.argv) > 6 and sys.argv[6] == 'fused'
+    regions = len(sys.argv) > 6 and sys.argv[6] == 'regions'
     L = 64.0
     dom = SlabDomain(N, L)
     rng = np.random.default_rng(77)
@@ -34,6 +36,20 @@ def main():
                                  torch.tensor(mine, device='cuda'))
     parts.tile_sort()
     contribution, C, kick, dtm = 0.37, -2.5, -0.002, 0.9
+    if regions:
+        # the streaming form: kick + drift + tile sort in one pass, particles in tile regions
+        # with gaps, leavers handed over by the pass itself
+        rp = RegionParticles(parts)
+        for step in range(steps):
+            pm_step_regions(dom, rp, contribution, 4, C, kick, dtm, diff_order=2 + 2*(step % 2))
+        rp.check()
+        pos_o, mom_o, ids_o = rp.dense()
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), ids=ids_o.cpu().numpy(),
+                 pos=pos_o.cpu().numpy(), mom=mom_o.cpu().numpy(), dens=np.zeros(1))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     for step in range(steps):
         if p3m:
             scale = 1.25*L/N

@@ -50,15 +50,18 @@ def single_domain(N, n_side, steps, p3m=False):
 
 @pytest.mark.parametrize('world,N,p3m', [(2, 32, False), (4, 64, False), (2, 64, False),
                                          (8, 128, False), (2, 64, True), (4, 128, True),
-                                         (2, 32, 'fused'), (4, 64, 'fused'), (8, 128, 'fused')])
+                                         (2, 32, 'fused'), (4, 64, 'fused'), (8, 128, 'fused'),
+                                         (2, 32, 'regions'), (4, 64, 'regions'),
+                                         (8, 128, 'regions')])
 def test_slab_domains_match_single_domain(world, N, p3m):
     """p3m = 'fused': the PM step with the fused drift + exchange + sort
     (DistributedParticles.drift_exchange_sort) and the tile histogram prepared by the
-    gather-kick — what bench.py runs on N > 1 GPUs."""
+    gather-kick; 'regions': kick + drift + tile sort in one pass over particles kept in tile
+    regions with gaps (RegionParticles) — what bench.py runs on N > 1 GPUs."""
     n_side, steps = 20, 3
     mode = p3m if isinstance(p3m, str) else ('p3m' if p3m else 'pm')
     p3m = p3m is True
-    if mode == 'fused':
+    if mode in ('fused', 'regions'):
         steps = 5
     pos_ref, mom_ref = single_domain(N, n_side, steps, p3m)
     s = socket.socket()
