@@ -413,8 +413,13 @@ extern "C" int cg_mesh_diff(cg_ctx *dst, cg_ctx *src, int dim, int diff_order) {
     CG_CHECK(dst->N == src->N && dst->pad == src->pad && dst->mesh_doubles == src->mesh_doubles,
              "cg_mesh_diff: the two meshes differ in shape");
     CG_CHECK(dim >= 0 && dim < 3, "diff_domaingrid() called with dim = %d not in {0, 1, 2}", dim);
-    CG_CHECK(diff_order == 2 || diff_order == 4,
-             "cg_mesh_diff: differentiation order %d (2 and 4 are built)", diff_order);
+    CG_CHECK(diff_order == 1 || diff_order == 2 || diff_order == 4 || diff_order == 6 ||
+                 diff_order == 8,
+             "diff_domaingrid() called with order = %d not in {1, 2, 4, 6, 8}", diff_order);
+    // the stencil reaches (order + 1)/2 cells: across a slab face that is halo (3 layers)
+    CG_CHECK(src->p.nprocs == 1 || (diff_order + 1) / 2 <= src->xmap.G,
+             "cg_mesh_diff: differentiation order %d reaches %d layers beyond a slab face, the "
+             "halo holds %d", diff_order, (diff_order + 1) / 2, src->xmap.G);
     return cgk_mesh_diff(dst, src, dim, diff_order);
 }
 
@@ -453,9 +458,13 @@ extern "C" int cg_fluid_kick(cg_ctx *c, double *J, const double *rho, const doub
     CG_CHECK(c && J && rho && P, "cg_fluid_kick: null argument");
     CG_CHECK(dim >= 0 && dim < 3,
              "apply_particle_mesh_force() called with dim = %d not in {0, 1, 2}", dim);
-    CG_CHECK(diff_order == 0 || diff_order == 2 || diff_order == 4,
-             "cg_fluid_kick: differentiation order %d (0 = the mesh holds the force, 2 and 4 are "
-             "built; nghosts = 2 admits no higher symmetric order)", diff_order);
+    CG_CHECK(diff_order == 0 || diff_order == 1 || diff_order == 2 || diff_order == 4 ||
+                 diff_order == 6 || diff_order == 8,
+             "cg_fluid_kick: differentiation order %d not in {0 (the mesh holds the force), 1, 2, "
+             "4, 6, 8}", diff_order);
+    CG_CHECK(c->p.nprocs == 1 || (diff_order + 1) / 2 <= c->xmap.G,
+             "cg_fluid_kick: differentiation order %d reaches %d layers beyond a slab face, the "
+             "halo holds %d", diff_order, (diff_order + 1) / 2, c->xmap.G);
     return cgk_fluid_kick(c, J, rho, P, dim, diff_order, minus_dt, inv_c2);
 }
 

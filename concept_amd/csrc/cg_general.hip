@@ -234,13 +234,56 @@ __global__ __launch_bounds__(64) void k_cm_unpack(const double2 *__restrict__ in
     }
 }
 
+// diff_domaingrid (mesh.py:4874-5030): the value of one force cell from the potential along
+// one dimension, P(s) = the potential s cells away.  Coefficients and the order of the terms
+// are the reference's; order 1 is its one-sided 'forward' difference.
+struct FdCoef {
+    double c1, c2, c3, c4;
+};
+template <int ORDER, class P>
+__device__ __forceinline__ double fd_value(const P &phi, const FdCoef &c) {
+#pragma clang fp contract(off)
+    if (ORDER == 0) return phi(0);  // the mesh already holds the force (Fourier-space gradient)
+    if (ORDER == 1) return c.c1 * (phi(1) - phi(0));                                // mesh.py:4962
+    if (ORDER == 2) return c.c1 * (phi(1) - phi(-1));                               // mesh.py:4967
+    if (ORDER == 4) return c.c1 * (phi(1) - phi(-1)) - c.c2 * (phi(2) - phi(-2));   // mesh.py:4973
+    if (ORDER == 6)                                                                  // mesh.py:4984
+        return (c.c1 * (phi(1) - phi(-1)) - c.c2 * (phi(2) - phi(-2))) + c.c3 * (phi(3) - phi(-3));
+    return ((c.c1 * (phi(1) - phi(-1)) - c.c2 * (phi(2) - phi(-2))) +                // mesh.py:4999
+            c.c3 * (phi(3) - phi(-3))) - c.c4 * (phi(4) - phi(-4));
+}
+static bool fd_coefficients(int order, double dx, FdCoef &c) {
+    c = FdCoef{0, 0, 0, 0};
+    switch (order) {
+        case 0: return true;
+        case 1: c.c1 = 1 / dx; return true;
+        case 2: c.c1 = (1.0 / 2) / dx; return true;
+        case 4: c.c1 = (2.0 / 3) / dx; c.c2 = (1.0 / 12) / dx; return true;
+        case 6: c.c1 = (3.0 / 4) / dx; c.c2 = (3.0 / 20) / dx; c.c3 = (1.0 / 60) / dx; return true;
+        case 8:
+            c.c1 = (4.0 / 5) / dx; c.c2 = (1.0 / 5) / dx; c.c3 = (4.0 / 105) / dx;
+            c.c4 = (1.0 / 280) / dx;
+            return true;
+    }
+    return false;
+}
+#define CG_FD_SWITCH(order, KERNEL, ...)                                          \
+    switch (order) {                                                              \
+        case 0: hipLaunchKernelGGL(KERNEL<0>, __VA_ARGS__); break;                \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;                \
+        case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break;                \
+        default: hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); break;               \
+    }
+
 template <int ORDER>
 __global__ __launch_bounds__(256) void k_fluid_kick(double *__restrict__ J,
                                                     const double *__restrict__ rho,
                                                     const double *__restrict__ P,
                                                     const double *__restrict__ mesh, int N,
-                                                    XMap xm, i64 ny, i64 pad, int dim, double c1,
-                                                    double c2, double mdt, double inv_c2) {
+                                                    XMap xm, i64 ny, i64 pad, int dim, FdCoef fc,
+                                                    double mdt, double inv_c2) {
 #pragma clang fp contract(off)
     // `mesh` is the local buffer (ghost layers included); the fluid grids hold the owned layers
     const i64 total = (i64)xm.nxl * N * N;
@@ -256,10 +299,7 @@ __global__ __launch_bounds__(256) void k_fluid_kick(double *__restrict__ J,
             else if (dim == 2) kk = (k + s + N) % N;
             return mesh[(ii * ny + jj) * pad + kk];
         };
-        double g;
-        if (ORDER == 0) g = phi(0);  // the mesh already holds the force (Fourier-space gradient)
-        else if (ORDER == 2) g = c1 * (phi(1) - phi(-1));                     // mesh.py:4967
-        else g = c1 * (phi(1) - phi(-1)) - c2 * (phi(2) - phi(-2));           // mesh.py:4973-4977
+        const double g = fd_value<ORDER>(phi, fc);
         // Jᵢ += ℝ[-ᔑdt]*(ϱ + ℝ[c⁻²]*𝒫)*grid   (interactions.py:2397-2400)
         J[t] += mdt * (rho[t] + inv_c2 * P[t]) * g;
     }
@@ -386,8 +426,7 @@ __global__ __launch_bounds__(256) void k_gather_scalar(const double *__restrict_
 template <int ORDER>
 __global__ __launch_bounds__(256) void k_mesh_diff(double *__restrict__ dst,
                                                    const double *__restrict__ src, int N,
-                                                   XMap xm, i64 ny, i64 pad, int dim, double c1,
-                                                   double c2) {
+                                                   XMap xm, i64 ny, i64 pad, int dim, FdCoef fc) {
 #pragma clang fp contract(off)
     // both are local buffers (ghost layers included); the owned layers of dst are written
     const i64 total = (i64)xm.nxl * N * N;
@@ -403,9 +442,7 @@ __global__ __launch_bounds__(256) void k_mesh_diff(double *__restrict__ dst,
             else if (dim == 2) kk = wrap32(k + s, N);
             return src[(ii * ny + jj) * pad + kk];
         };
-        double gval;
-        if (ORDER == 2) gval = c1 * (phi(1) - phi(-1));
-        else gval = c1 * (phi(1) - phi(-1)) - c2 * (phi(2) - phi(-2));
+        const double gval = fd_value<ORDER>(phi, fc);
         dst[(((i64)i + xm.G) * ny + j) * pad + k] = gval;
     }
 }
@@ -516,21 +553,13 @@ int cgk_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int
                    int diff_order, double minus_dt, double inv_c2) {
     i64 total = c->xmap.nxl * c->N * c->N;
     double dx = c->p.boxsize / (double)c->N;  // interactions.py:2133
-    if (diff_order == 0) {
-        hipLaunchKernelGGL(k_fluid_kick<0>, dim3(blocks_for(total, 256)), dim3(256), 0,
-                           c->stream, J, rho, P, c->mesh, (int)c->N, c->xmap, c->ny, c->pad, dim, 0.0, 0.0,
-                           minus_dt, inv_c2);
-    } else if (diff_order == 2) {
-        double c1 = (1.0 / 2) / dx;
-        hipLaunchKernelGGL(k_fluid_kick<2>, dim3(blocks_for(total, 256)), dim3(256), 0,
-                           c->stream, J, rho, P, c->mesh, (int)c->N, c->xmap, c->ny, c->pad, dim, c1, 0.0,
-                           minus_dt, inv_c2);
-    } else {
-        double c1 = (2.0 / 3) / dx, c2 = (1.0 / 12) / dx;
-        hipLaunchKernelGGL(k_fluid_kick<4>, dim3(blocks_for(total, 256)), dim3(256), 0,
-                           c->stream, J, rho, P, c->mesh, (int)c->N, c->xmap, c->ny, c->pad, dim, c1, c2,
-                           minus_dt, inv_c2);
+    FdCoef fc;
+    if (!fd_coefficients(diff_order, dx, fc)) {
+        cg_set_error("cg_fluid_kick: differentiation order %d", diff_order);
+        return 1;
     }
+    CG_FD_SWITCH(diff_order, k_fluid_kick, dim3(blocks_for(total, 256)), dim3(256), 0, c->stream,
+                 J, rho, P, c->mesh, (int)c->N, c->xmap, c->ny, c->pad, dim, fc, minus_dt, inv_c2)
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -566,15 +595,13 @@ int cgk_gather_scalar(cg_ctx *c, const double *pos, double *mom, i64 n, int dim,
 int cgk_mesh_diff(cg_ctx *dst, cg_ctx *src, int dim, int diff_order) {
     i64 total = src->xmap.nxl * src->N * src->N;
     double dx = src->p.boxsize / (double)src->N;
-    if (diff_order == 2) {
-        hipLaunchKernelGGL(k_mesh_diff<2>, dim3(blocks_for(total, 256)), dim3(256), 0, dst->stream,
-                           dst->mesh, src->mesh, (int)src->N, src->xmap, src->ny, src->pad, dim,
-                           (1.0 / 2) / dx, 0.0);
-    } else {
-        hipLaunchKernelGGL(k_mesh_diff<4>, dim3(blocks_for(total, 256)), dim3(256), 0, dst->stream,
-                           dst->mesh, src->mesh, (int)src->N, src->xmap, src->ny, src->pad, dim,
-                           (2.0 / 3) / dx, (1.0 / 12) / dx);
+    FdCoef fc;
+    if (diff_order == 0 || !fd_coefficients(diff_order, dx, fc)) {
+        cg_set_error("cg_mesh_diff: differentiation order %d", diff_order);
+        return 1;
     }
+    CG_FD_SWITCH(diff_order, k_mesh_diff, dim3(blocks_for(total, 256)), dim3(256), 0, dst->stream,
+                 dst->mesh, src->mesh, (int)src->N, src->xmap, src->ny, src->pad, dim, fc)
     CG_LAUNCH_CHECK();
     return 0;
 }

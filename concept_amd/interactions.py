@@ -418,10 +418,13 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
             differentiations = [r.potential_differentiations[force][method]
                                 for r in group[representation]]
             for d in differentiations:
-                if d not in (0, 2, 4):
+                if d not in (0, 1, 2, 4, 6, 8):
                     raise ConceptGPUError(
-                        f'differentiation order {d}: 0 (Fourier space), 2 and 4 are built '
-                        f'(nghosts = {p.nghosts})')
+                        f'diff_domaingrid() called with order = {d} ∉ {{1, 2, 4, 6, 8}}')
+                if (d + 1)//2 > p.nghosts:
+                    raise ConceptGPUError(
+                        f'differentiation order {d} needs nghosts >= {(d + 1)//2} '
+                        f'(commons.py:4428-4430), got {p.nghosts}')
             subgroups = group_components(group[representation], differentiations,
                                          sorted(differentiations, reverse=True),
                                          split_representations=False)
@@ -451,7 +454,8 @@ def particle_mesh_general(receivers, suppliers, gridsize_global, quantity, force
                     slab.fourier_operate(deconv_order_downstream, len(shifts_downstream), shift)
                     slab.poisson_backward()
                     slab.fill_ghosts()  # communicate_ghosts(grid, '=') (interactions.py:2307)
-                    simple = interpolation_order == 2 and shift == (0, 0, 0)
+                    simple = (interpolation_order == 2 and shift == (0, 0, 0)
+                              and differentiation_order in (2, 4))  # the fused gather-kick
                     for receiver in (subgroup if representation == 'particles' and simple
                                      else ()):
                         _kick_particles(slab, receiver, force, method, ᔑdt, ᔑdt_key)

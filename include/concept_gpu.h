@@ -475,15 +475,17 @@ int cg_prepare_rebind(cg_ctx *ctx, const double *pos /*DEV*/, const double *mom 
  *   fused (periodic).  cg_gather_scalar: interpolate_domaingrid_to_particles
  *   (mesh.py:376-459): mom[dim] += factor * (mesh interpolated at the particle), the
  *   mesh holding one force component (after cg_mesh_diff or a Fourier-space
- *   differentiation).  cg_mesh_diff: diff_domaingrid (mesh.py:4874-5030), symmetric
- *   orders 2 and 4, of `src`'s real-space mesh into `dst`'s.
+ *   differentiation).  cg_mesh_diff: diff_domaingrid (mesh.py:4874-5030) of `src`'s
+ *   real-space mesh into `dst`'s: the symmetric orders 2, 4, 6, 8 and the one-sided
+ *   ('forward') order 1.
  * cg_mesh_copy: slab_downstream_subgroup[...] = slab_downstream
  *   (interactions.py:2242-2245, 2276-2279).
  * cg_fluid_kick: the fluid branch of apply_particle_mesh_force
  *   (interactions.py:2388-2401) fused with diff_domaingrid (mesh.py:4874-5030):
- *   J_dim[cell] += minus_dt*(rho[cell] + inv_c2*P[cell]) * d(phi)/dx_dim, symmetric
- *   difference of order 2 or 4 on the context's real-space potential (diff_order 0:
- *   the mesh already holds the force component, Fourier-space differentiation). */
+ *   J_dim[cell] += minus_dt*(rho[cell] + inv_c2*P[cell]) * d(phi)/dx_dim, the
+ *   difference of order 1, 2, 4, 6 or 8 on the context's real-space potential
+ *   (diff_order 0: the mesh already holds the force component, Fourier-space
+ *   differentiation). */
 int cg_fluid_add(cg_ctx *ctx, const double *fluid /*DEV N^3*/, double factor, int op_add);
 int cg_fourier_nullify_nyquist(cg_ctx *ctx);
 int cg_fourier_operate(cg_ctx *onto, cg_ctx *from, int deconv_order, int nlattice,

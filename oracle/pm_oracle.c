@@ -350,17 +350,34 @@ void orc_kspace_poisson(double *slab, i64 N, int deconv_order, double C, int lon
  */
 void orc_diff_domaingrid(const double *grid, double *out, i64 ni, i64 nj, i64 nk, i64 g, int dim,
                          int order, double dx) {
+    /* diff_domaingrid, mesh.py:4874-5030: symmetric differences of order 2, 4, 6, 8 with the
+     * coefficients written as the reference writes them, and the one-sided order 1
+     * (direction = 'forward', the default: mesh.py:4903-4910) */
     i64 step = dim == 0 ? nj * nk : (dim == 1 ? nk : 1);
-    double c2 = (1.0 / 2) / dx, c4a = (2.0 / 3) / dx, c4b = (1.0 / 12) / dx;
+    double c1 = 1 / dx, c2 = (1.0 / 2) / dx, c4a = (2.0 / 3) / dx, c4b = (1.0 / 12) / dx;
+    double c6a = (3.0 / 4) / dx, c6b = (3.0 / 20) / dx, c6c = (1.0 / 60) / dx;
+    double c8a = (4.0 / 5) / dx, c8b = (1.0 / 5) / dx, c8c = (4.0 / 105) / dx,
+           c8d = (1.0 / 280) / dx;
 #pragma omp parallel for schedule(static)
     for (i64 i = g; i < ni - g; i++) for (i64 j = g; j < nj - g; j++)
         for (i64 k = g; k < nk - g; k++) {
             i64 ix = (i * nj + j) * nk + k;
-            if (order == 2)
+            if (order == 1)
+                out[ix] = c1 * (grid[ix + step] - grid[ix]);
+            else if (order == 2)
                 out[ix] = c2 * (grid[ix + step] - grid[ix - step]);
-            else
+            else if (order == 4)
                 out[ix] = c4a * (grid[ix + step] - grid[ix - step])
                         - c4b * (grid[ix + 2 * step] - grid[ix - 2 * step]);
+            else if (order == 6)
+                out[ix] = (c6a * (grid[ix + step] - grid[ix - step])
+                           - c6b * (grid[ix + 2 * step] - grid[ix - 2 * step]))
+                        + c6c * (grid[ix + 3 * step] - grid[ix - 3 * step]);
+            else
+                out[ix] = ((c8a * (grid[ix + step] - grid[ix - step])
+                            - c8b * (grid[ix + 2 * step] - grid[ix - 2 * step]))
+                           + c8c * (grid[ix + 3 * step] - grid[ix - 3 * step]))
+                        - c8d * (grid[ix + 4 * step] - grid[ix - 4 * step]);
         }
 }
 

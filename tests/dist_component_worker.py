@@ -52,6 +52,9 @@ def main():
     elif case == 'tiled_general':
         import test_gpu_fluid
         test_gpu_fluid.test_general_path_uses_tile_order(golden)
+    elif case == 'diff_orders':
+        import test_gpu_pm
+        test_gpu_pm.test_other_differentiation_orders_vs_golden(torch, golden, arg)
     elif case == 'pm_api':
         import test_gpu_pm
         test_gpu_pm.test_gravity_api_pm(None, golden)

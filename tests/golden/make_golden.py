@@ -41,6 +41,15 @@ CASES = {
     # differentiation order 4 (the p3m default, commons.py:3209-3237)
     'pm_n8_g16_d4': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=4, dist='uniform',
                          diff=4, full=True),
+    # the other differentiation orders of diff_domaingrid (mesh.py:4874-5030): 6 and 8 (the
+    # reference raises nghosts to 3 and 4 for them, commons.py:4428-4430) and the one-sided
+    # order 1
+    'pm_n8_g16_d6': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=36, dist='uniform',
+                         diff=6, full=True),
+    'pm_n8_g16_d8': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=37, dist='clustered',
+                         diff=8, full=True),
+    'pm_n8_g16_d1': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=38, dist='uniform',
+                         diff=1, full=True),
     # clustered ("Zel'dovich-like" displaced lattice), in/out only
     'pm_n32_g64': dict(method='pm', n=32, gridsize=64, boxsize=256.0, seed=5, dist='lattice',
                        diff=2, full=False),

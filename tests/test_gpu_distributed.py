@@ -193,6 +193,7 @@ COMPONENT_CASES = [
     ('orders', 'tsc_bcc_n8_g16'), ('orders', 'pcs_fcc_fourier_n8_g16'),
     ('orders', 'ngp_fluid_n8_g16'),
     ('tiled_general', '-'),
+    ('diff_orders', 'pm_n8_g16_d6'), ('diff_orders', 'pm_n8_g16_d1'),
     ('k4', '16,2'), ('k4', '32,4'),
 ]
 

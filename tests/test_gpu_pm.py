@@ -714,3 +714,54 @@ def test_fused_scatter_overflow_is_flagged(torch_cuda):
     assert mesh.error_flags() & lib.CG_ERR_BUCKET_OVERFLOW
     assert torch.equal(pa, keep_p) and torch.equal(ma, keep_m)
     mesh.close()
+
+
+@pytest.mark.parametrize('name', ['pm_n8_g16_d1', 'pm_n8_g16_d6', 'pm_n8_g16_d8'])
+def test_other_differentiation_orders_vs_golden(torch_cuda, golden, name):
+    """diff_domaingrid's other orders (mesh.py:4874-5030): 6 and 8 — for which the reference
+    raises nghosts to 3 and 4 (commons.py:4428-4430) — and the one-sided order 1, through the
+    gravity() boundary (force grid by cg_mesh_diff, then interpolated) and mesh by mesh."""
+    from concept_amd import comm, commons, interactions
+    from concept_amd.mesh import PotentialMesh
+    from concept_amd.species import Component
+    from oracle import oracle
+    g = golden(name)
+    order, N, L = int(g['diff_order']), int(g['gridsize']), float(g['boxsize'])
+    p = commons.load_params({
+        'boxsize': L,
+        'potential_options': {'gridsize': {'gravity': {'pm': N}},
+                              'differentiation': {'matter': {'gravity': {'pm': order}}}},
+        'select_forces': {'matter': {'gravity': 'pm'}},
+    })
+    assert p.nghosts == int(g['nghosts'])
+    c = Component('matter', 'matter', N=int(g['N']), mass=float(g['mass']))
+    c.populate(g['pos_in'], 'pos')
+    c.populate(g['mom_in'], 'mom')
+    single = comm.active() is None  # (also run over domains by test_gpu_distributed.py)
+    if single:
+        assert np.array_equal(c._mesh().cic_indices(c.pos, False).cpu().numpy(),
+                              g['cic_index_deposit'])
+    sdt = {'1': float(g['dt_1']), ('a**(-3*w_eff)', 'matter'): float(g['dt_kick']),
+           ('a**(-3*w_eff-1)', 'matter'): float(g['dt_dens'])}
+    interactions.gravity('pm', [c], [c], sdt, 'long-range', False)
+    kick_ref = g['mom_after_long'] - g['mom_in']
+    assert np.abs(c.host('mom') - g['mom_after_long']).max() <= TOL*rms(kick_ref) \
+        + 4e-16*np.abs(g['mom_in']).max()
+    if not single:
+        return
+    # the force grids themselves
+    ng = int(g['nghosts'])
+    mesh = PotentialMesh(N, L, nghosts=ng)
+    force = PotentialMesh(N, L, nghosts=ng)
+    pos = torch_cuda.tensor(g['pos_in'], device='cuda')
+    contribution = oracle.deposit_contribution(float(g['mass']), float(g['dt_dens']),
+                                               float(g['dt_1']), N, L)
+    C, _ = oracle.poisson_constants(L, float(g['G_Newton']), None)
+    mesh.zero()
+    mesh.deposit(pos, contribution)
+    mesh.poisson_solve(4, C, False, 0.0)
+    for dim in range(3):
+        force.diff_from(mesh, dim, order)
+        got = force.fetch_real()[:, :, :N]
+        ref = g['grid_force'][dim][ng:-ng, ng:-ng, ng:-ng]
+        assert np.abs(got - ref).max() <= TOL*rms(ref)

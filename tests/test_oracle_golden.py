@@ -10,7 +10,8 @@ import pytest
 
 from oracle import oracle
 
-PM_CASES = ['pm_n8_g16', 'pm_n16_g32', 'pm_edge_g16', 'pm_n8_g16_d4']
+PM_CASES = ['pm_n8_g16', 'pm_n16_g32', 'pm_edge_g16', 'pm_n8_g16_d4', 'pm_n8_g16_d6',
+            'pm_n8_g16_d8', 'pm_n8_g16_d1']
 FIELDS = ['grid_deposit', 'slab_density_k', 'slab_potential_k', 'grid_potential', 'grid_force']
 
 
@@ -21,7 +22,8 @@ def run_oracle(g, **kw):
     o = oracle.pm_long_range(
         pos, mom, mass=float(g['mass']), boxsize=float(g['boxsize']), gridsize=int(g['gridsize']),
         G_Newton=float(g['G_Newton']), dt_1=float(g['dt_1']), dt_dens=float(g['dt_dens']),
-        dt_kick=float(g['dt_kick']), diff_order=int(g['diff_order']), shortrange_scale=sc, **kw)
+        dt_kick=float(g['dt_kick']), diff_order=int(g['diff_order']), shortrange_scale=sc,
+        nghosts=int(g['nghosts']), **kw)
     return o, mom
 
 
