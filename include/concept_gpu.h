@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CG_ABI_VERSION 1
+#define CG_ABI_VERSION 2  /* 2: region tables, fused kick+drift+scatter, Fourier views, error flags */
 
 typedef struct cg_ctx cg_ctx;
 

@@ -27,7 +27,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f'{n} declared in concept_gpu.h but not exported'
     from concept_amd import lib as binding
     assert sorted(binding.SYMBOLS) == names, 'ctypes binding out of sync with the header'
-    assert binding.raw().cg_abi_version() == 1
+    assert binding.raw().cg_abi_version() == 2
 
 
 def test_no_product_module_touches_the_oracle():
