@@ -598,7 +598,11 @@ __device__ __forceinline__ void sr_cell_batch(int k, int S, int b, double xi, do
 #pragma unroll
     for (int j = 0; j < NB; j++) {
         t[j] = 0.0;
+#ifdef CG_SR_PROBE_NOLOAD  // probe build (tools/variant.py): the sweep without its table gather
+        if (hit[j]) t[j] = r2[j] * r2_index_scaling;
+#else
         if (hit[j]) t[j] = table[(unsigned)(int)(r2[j] * r2_index_scaling)];  // gravity.py:316-321
+#endif
     }
 #pragma unroll
     for (int j = 0; j < NB; j++) {
@@ -774,6 +778,9 @@ k_sr_sweep_cells(
     const bool simple = rend - rbeg <= 64 && total <= (unsigned)kSrCap;  // one chunk, one window
     for (unsigned w0 = 0; w0 < total; w0 += kSrCap) {
         const unsigned w1 = min(total, w0 + (unsigned)kSrCap);
+        // (window bounds as scalar ints: the range bounds below are scalar integer min / max)
+        const int sw0 = __builtin_amdgcn_readfirstlane((int)w0),
+                  sw1 = __builtin_amdgcn_readfirstlane((int)w1);
         if (w0) __syncthreads();  // everybody is done with the previous window
         // staging: 16 lanes per piece, a wave takes 4 pieces at a time (pieces are short runs of
         // ~16 suppliers; a longer one takes more turns) — no search for the piece of an entry
@@ -811,9 +818,8 @@ k_sr_sweep_cells(
                 for (int xg = 0; xg < 5; xg++) {
                     const int col = (wx + xg) * 6 + wy;  // first of the 5 columns of this x
                     if (!face) {  // no periodic image: the 5 columns are one staged range
-                        const int a = (int)max(__builtin_amdgcn_readlane(e0, col), w0) - (int)w0;
-                        const int b =
-                            (int)min(__builtin_amdgcn_readlane(i0, col + 4), w1) - (int)w0;
+                        const int a = max(__builtin_amdgcn_readlane((int)e0, col), sw0) - sw0;
+                        const int b = min(__builtin_amdgcn_readlane((int)i0, col + 4), sw1) - sw0;
                         if (b > a)
                             sr_cell_pairs<false>(a, b, sub, S, xi, yi, zi, 0, 0, 0, sx, sy, sz,
                                                  P.r2_max, P.r2_index_scaling, table, ax, ay, az);
@@ -821,10 +827,10 @@ k_sr_sweep_cells(
                     }
                     for (int q = 0; q < 10; q++) {  // piece by piece with its offset
                         const int cq = col + (q % 5), half = q / 5, p = 36 * half + cq;
-                        const int a = (int)max(__builtin_amdgcn_readlane(half ? e1 : e0, cq), w0) -
-                                      (int)w0;
-                        const int b = (int)min(__builtin_amdgcn_readlane(half ? i1 : i0, cq), w1) -
-                                      (int)w0;
+                        const int a =
+                            max(__builtin_amdgcn_readlane((int)(half ? e1 : e0), cq), sw0) - sw0;
+                        const int b =
+                            min(__builtin_amdgcn_readlane((int)(half ? i1 : i0), cq), sw1) - sw0;
                         if (b <= a) continue;
                         const double ox = (double)p_shift[p][0] * P.boxsize,
                                      oy = (double)p_shift[p][1] * P.boxsize,
@@ -839,16 +845,15 @@ k_sr_sweep_cells(
                 }
             }
             // fold the S partial sums of each receiver (lanes rl, rl + R, ...) into lane rl: a
-            // tree over the groups, ceil(log2 S) shuffle steps (lanes that are not a node of the
-            // tree carry values nobody reads)
+            // tree over the groups, ceil(log2 S) shuffle steps.  A node whose partner group does
+            // not exist (sub + d >= S) reads lane 63 instead, which holds zeros whenever such a
+            // node exists: R*S = 64 only for powers of two, where every partner exists.
+            if (sub >= S) ax = ay = az = 0;
             for (int d = 1; d < S; d <<= 1) {  // S is wave-uniform
-                const int src = (lane + d * R) & 63;
-                const double ux = __shfl(ax, src), uy = __shfl(ay, src), uz = __shfl(az, src);
-                if (sub + d < S) {
-                    ax += ux;
-                    ay += uy;
-                    az += uz;
-                }
+                const int src = sub + d < S ? lane + d * R : 63;
+                ax += __shfl(ax, src);
+                ay += __shfl(ay, src);
+                az += __shfl(az, src);
             }
             ax *= ch.factor;  // gravity.py:321 (total_factor = factors[rung] * table[...])
             ay *= ch.factor;
