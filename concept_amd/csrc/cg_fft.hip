@@ -671,7 +671,7 @@ __global__ __launch_bounds__(NT) void k_fft_strided_p(const double2 *__restrict_
     const int nk = N / 2 + 1;
     for (int i = tid; i < N; i += NT) {
         if (i < N / 2) twl[i] = tw[i];
-        if (MODE == 2) tabq[i] = P.tab_q[i];
+        if (MODE == 2) tabq[i] = kspace_tab_sep(P, N, i, P.tab_q[i]);  // t[a], cg_kspace.h
     }
     const int wl = tid % W, ml = tid / W;
     const unsigned voff_s = (unsigned)(ml * s_es + wl), voff_d = (unsigned)(ml * d_es + wl);
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(NT) void k_fft_strided_p(const double2 *__restrict_
             const int kkl = kk0 + wl;
             if (kkl < nk) {
                 const int b = (int)(o + o_off);
-                const KspaceFixedQ F = kspace_fix_q(N, b, kkl, tabq[b], tabq[kkl]);
+                const KspaceFixedS F = kspace_fix_sep(P, N, b, kkl, tabq[b], tabq[kkl]);
                 // the per-element table values do not depend on the tile: keep the optimiser
                 // from hoisting 16 x (q, ka^2, ...) out of the tile loop into registers it
                 // does not have (they would be spilled to scratch); re-reading LDS is cheap
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(NT) void k_fft_strided_p(const double2 *__restrict_
 #pragma unroll
                 for (int r = 0; r < PER; r++) {
                     int a = ml_t + r * MSTEP;
-                    double fac = kspace_factor_q(P, F, N, a, tabq[a]);
+                    double fac = kspace_factor_sep(F, N, a, tabq[a]);
                     x[r] = make_double2(x[r].x * fac, x[r].y * fac);
                     // keep the 16 factor evaluations from being interleaved: their
                     // temporaries on top of x and the staged v would spill
@@ -750,6 +750,202 @@ __global__ __launch_bounds__(NT) void k_fft_strided_p(const double2 *__restrict_
         tprev = t;
     }
     store(tprev);
+}
+
+// ---------------------------------------------------------------------------
+// 2048-point strided passes at full line width.  Eight pencils of 2048 points (256 KB) do not
+// fit the LDS, and four (the persistent pass above with W = 4) leave every row segment at 64
+// bytes — half a line: `tools/stride_probe2048.cpp` measures 53 ms per in-place sweep of the
+// 2048^3 mesh in 64-byte segments against 28.5 ms in 128-byte ones, whatever the stride.  So
+// the transform is split once by radix 2 over even and odd rows:
+//     X[k]     = E[k] + w^k O[k]         E = FFT_1024(x[2m]),  O = FFT_1024(x[2m + 1])
+//     X[k + H] = E[k] - w^k O[k]
+// A tile is 8 pencils wide (full lines); its even rows are transformed as one 1024-point tile
+// (the 16*16*4 schedule above, 128 KB of LDS) and stay in registers while the odd rows —
+// prefetched meanwhile — go through the same LDS; lane (ml, wl) holds E and O at the same 16
+// positions k = ml + 64 r, so the last stage is register arithmetic with w^k = w^ml * w32^r.
+// The fused x pass continues with the k-space factor on all 32 values, the mirrored split
+// (decimation in frequency: A = X[k] + X[k + H], B = (X[k] - X[k + H]) conj(w)^k) and two
+// inverse 1024-point tiles whose results are the even and odd rows.  Per tile: two loads of
+// 16 values per lane (each prefetched during a transform), one store of 32, deferred to the
+// next tile like in the pass above.  Registers: 3 x 16 values + temporaries < 256.
+// ---------------------------------------------------------------------------
+template <int LOGN, int NT, int MODE>
+__global__ __launch_bounds__(NT) void k_fft_strided_h(const double2 *__restrict__ src,
+                                                      double2 *__restrict__ dst, i64 s_ostride,
+                                                      i64 s_es, i64 d_ostride, i64 d_es, int nkb,
+                                                      i64 ntiles, i64 o_off,
+                                                      const double2 *__restrict__ tw,
+                                                      KspaceParams P) {
+    constexpr int N = 1 << LOGN, H = N / 2, W = 8, LOGH = LOGN - 1;
+    constexpr int TOT = H * W;
+    static_assert(TOT == 16 * NT && NT % W == 0, "split pass: 16 points per lane and half");
+    constexpr int PER = 16;
+    constexpr int MSTEP = NT / W;  // = H/16
+    constexpr bool INV1 = MODE == 1;  // direction of the first (or only) transform
+    extern __shared__ double2 lds_dyn[];
+    double2 *lds = lds_dyn;
+    double2 *twh = lds_dyn + TOT;                      // H/2 twiddles of the H-point tiles
+    double *tabq = (double *)(lds_dyn + TOT + H / 2);  // MODE 2: N doubles, t[a] of cg_kspace.h
+    const int tid = threadIdx.x;
+    const int nk = N / 2 + 1;
+    for (int i = tid; i < N; i += NT) {
+        if (i < H / 2) twh[i] = tw[2 * i];  // w_H^i = w_N^(2i)
+        if (MODE == 2) tabq[i] = kspace_tab_sep(P, N, i, P.tab_q[i]);  // t[a], cg_kspace.h
+    }
+    // w_N^ml (ml < NT/W): w_N^(ml + 64 r) = w_N^ml * w32^r
+    double2 *wm = lds_dyn + TOT + H / 2 + (MODE == 2 ? N / 2 : 0);
+    if (tid < NT / W) wm[tid] = tw[tid];
+    // Everything a lane derives from its number (pencil wl, first point ml, the offsets of its
+    // rows, the LDS addresses inside the tile transforms) is recomputed where it is used, from
+    // a value the optimiser cannot see through: kept across the tile they would be spilled,
+    // and a scratch reload behind a prefetch waits for the prefetch (vector memory returns in
+    // order), which would serialise memory and arithmetic.
+    int tid_t = tid;
+    auto fresh_tid = [&]() {
+        asm volatile("" : "+v"(tid_t));
+        return tid_t;
+    };
+    d2 v[PER], u[2 * PER];
+    const bool reverse = (MODE != 2) && (P.long_range & 2);  // walk the tiles from the end
+    auto load = [&](i64 t, int odd) {
+        if (reverse) t = ntiles - 1 - t;
+        const i64 o = t / nkb;
+        const int kk0 = (int)(t - o * nkb) * W;
+        const double2 *sbase = src + o * s_ostride + kk0 + (odd ? s_es : 0);
+        // rows of the halves: element m = ml + 64 r of the even half is row 2m, of the odd 2m + 1
+        const int ft = fresh_tid();
+        const unsigned voff_h = (unsigned)(2 * (ft / W) * s_es + ft % W);
+#pragma unroll
+        for (int r = 0; r < PER; r++)
+            v[r] = ((const d2 *)(sbase + (i64)r * (2 * MSTEP) * s_es))[voff_h];
+    };
+    // the 32 results of a tile leave in two halves (hi = 0: u[0..15], hi = 1: u[16..31]), one
+    // at the start of each phase of the next tile, so that stores and loads alternate
+    auto store = [&](i64 t, int hi) {
+        if (reverse) t = ntiles - 1 - t;
+        const i64 o = t / nkb;
+        const int kk0 = (int)(t - o * nkb) * W;
+        // MODE 2: u[r] is row 2 (ml + 64 r), u[16 + r] the row after it;
+        // otherwise u[r] is row ml + 64 r, u[16 + r] row ml + 64 r + H
+        double2 *dbase = dst + o * d_ostride + kk0 + (hi ? (MODE == 2 ? 1 : H) * d_es : 0);
+        constexpr int RS = (MODE == 2 ? 2 : 1) * MSTEP;
+        const int ft = fresh_tid();
+        const unsigned voff_d = (unsigned)((MODE == 2 ? 2 : 1) * (ft / W) * d_es + ft % W);
+#pragma unroll
+        for (int r = 0; r < PER; r++)
+            ((d2 *)(dbase + (i64)r * RS * d_es))[voff_d] = u[(hi ? PER : 0) + r];
+    };
+    // w32^r = exp(-2 pi i r / 32), r = 0 .. 15
+    constexpr double c32[16] = {1.0,
+                                0.98078528040323044913,
+                                0.92387953251128675613,
+                                0.83146961230254523708,
+                                0.70710678118654752440,
+                                0.55557023301960222474,
+                                0.38268343236508977173,
+                                0.19509032201612826785,
+                                0.0,
+                                -0.19509032201612826785,
+                                -0.38268343236508977173,
+                                -0.55557023301960222474,
+                                -0.70710678118654752440,
+                                -0.83146961230254523708,
+                                -0.92387953251128675613,
+                                -0.98078528040323044913};
+    constexpr double s32[16] = {0.0,
+                                -0.19509032201612826785,
+                                -0.38268343236508977173,
+                                -0.55557023301960222474,
+                                -0.70710678118654752440,
+                                -0.83146961230254523708,
+                                -0.92387953251128675613,
+                                -0.98078528040323044913,
+                                -1.0,
+                                -0.98078528040323044913,
+                                -0.92387953251128675613,
+                                -0.83146961230254523708,
+                                -0.70710678118654752440,
+                                -0.55557023301960222474,
+                                -0.38268343236508977173,
+                                -0.19509032201612826785};
+    i64 tprev = -1;
+    i64 t = blockIdx.x;
+    if (t >= ntiles) return;
+    load(t, 0);
+    __syncthreads();  // tables
+    for (; t < ntiles; t += gridDim.x) {
+        double2 x[16], e[16];
+        // ---- even rows
+#pragma unroll
+        for (int r = 0; r < PER; r++) e[r] = make_double2(v[r].x, v[r].y);
+        if (tprev >= 0) store(tprev, 0);
+        load(t, 1);
+        fft_tile<LOGH, W, NT, INV1>(e, lds, twh, fresh_tid());
+        // ---- odd rows (the next tile's even rows are fetched meanwhile; in the fused pass
+        // only during the inverse transforms: the factor evaluation needs the registers)
+#pragma unroll
+        for (int r = 0; r < PER; r++) x[r] = make_double2(v[r].x, v[r].y);
+        if (tprev >= 0) store(tprev, 1);
+        const i64 tnext = t + gridDim.x < ntiles ? t + gridDim.x : t;
+        if (MODE != 2) load(tnext, 0);
+        fft_tile<LOGH, W, NT, INV1>(x, lds, twh, fresh_tid());
+        const i64 o = t / nkb;
+        const int kk0 = (int)(t - o * nkb) * W;
+        const int ftc = fresh_tid();
+        const int wl = ftc % W, ml = ftc / W;
+        const int kkl = kk0 + wl;
+        const double2 wml = wm[ml];
+        KspaceFixedS F = {};
+        if (MODE == 2) {
+            const int b = (int)(o + o_off);
+            const int kks = kkl < nk ? kkl : 0;  // (pencils in the row padding: any finite value)
+            F = kspace_fix_sep(P, N, b, kks, tabq[b], tabq[kks]);
+        }
+        const int ml_t = ml;
+        const double wmx = wml.x, wmy = wml.y;
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            // w^k, k = ml + 64 r (conjugated for the inverse transform)
+            double2 wk = cmul(make_double2(wmx, wmy), make_double2(c32[r], s32[r]));
+            if (INV1) wk = cconj(wk);
+            const double2 y = cmul(x[r], wk);
+            double2 x0 = cadd(e[r], y), x1 = csub(e[r], y);
+            if (MODE == 2) {
+                const int a = ml_t + r * MSTEP;
+                const double f0 = kspace_factor_sep(F, N, a, tabq[a]);
+                const double f1 = kspace_factor_sep(F, N, a + H, tabq[a + H]);
+                x0 = make_double2(x0.x * f0, x0.y * f0);
+                x1 = make_double2(x1.x * f1, x1.y * f1);
+                // decimation in frequency for the way back: even rows from the sums, odd rows
+                // from the differences times conj(w)^k
+                e[r] = cadd(x0, x1);
+                x[r] = cmul(csub(x0, x1), cconj(wk));
+                // (pinned here: the optimiser would sink the odd half's products below the
+                // first inverse transform and keep x0, x1 alive — in scratch — instead)
+                asm volatile("" : "+v"(x[r].x), "+v"(x[r].y), "+v"(e[r].x), "+v"(e[r].y));
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                e[r] = x0;
+                x[r] = x1;
+            }
+        }
+        if (MODE == 2) {
+            fft_tile<LOGH, W, NT, true>(e, lds, twh, fresh_tid());
+            load(tnext, 0);  // (only now: three arrays of 16 values in flight are the budget)
+            fft_tile<LOGH, W, NT, true>(x, lds, twh, fresh_tid());
+        }
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            u[r].x = e[r].x;
+            u[r].y = e[r].y;
+            u[PER + r].x = x[r].x;
+            u[PER + r].y = x[r].y;
+        }
+        tprev = t;
+    }
+    store(tprev, 0);
+    store(tprev, 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -832,6 +1028,45 @@ static int run_strided_r(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
     return 0;
 }
 
+// The split pass (k_fft_strided_h): plain pencil maps, enough tiles to keep every CU busy.
+template <int LOGN, int MODE>
+static int run_strided_h(cg_ctx *c, const double2 *src, double2 *dst, PencilMap smap,
+                         PencilMap dmap, i64 nouter, i64 o_off, const KspaceParams &P, bool *done) {
+    constexpr int N = 1 << LOGN, W = 8, NT = (N / 2) * W / 16;
+    *done = false;
+    static int enabled = -1, ncu = 0;
+    if (enabled < 0) {
+        const char *env = getenv("CONCEPT_GPU_FFT_SPLIT");
+        enabled = env ? atoi(env) : 1;
+        hipDeviceProp_t prop;
+        CG_HIP(hipGetDeviceProperties(&prop, c->p.device));
+        ncu = prop.multiProcessorCount;
+    }
+    const int nkb = (int)((c->N / 2 + 1 + W - 1) / W);
+    const i64 ntiles = nouter * nkb;
+    // per-lane offsets are 32-bit byte offsets: rows 2 ml (ml < NT/W) must span < 4 GB
+    const i64 reach = 2 * (i64)(NT / W) * (smap.es > dmap.es ? smap.es : dmap.es) * 16;
+    if (!enabled || ntiles < 2 * (i64)ncu || smap.sh != 31 || dmap.sh != 31 ||
+        reach >= ((i64)1 << 32) || (i64)nkb * W > c->pad / 2)
+        return 0;
+    constexpr size_t lds = sizeof(double2) * (N / 2) * W + sizeof(double2) * (N / 4) +
+                           (MODE == 2 ? sizeof(double) * N : 0) + sizeof(double2) * (NT / W);
+    static_assert(lds <= 160 * 1024, "split pass: LDS");
+    auto kern = k_fft_strided_h<LOGN, NT, MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        CG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)ncu), dim3(NT), lds, c->stream, src, dst, smap.ostride,
+                       smap.es, dmap.ostride, dmap.es, nkb, ntiles, o_off,
+                       (const double2 *)c->fft_tw, P);
+    CG_LAUNCH_CHECK();
+    *done = true;
+    return 0;
+}
+
 // Radix schedule of the in-LDS transform: CONCEPT_GPU_FFT_RADIX = 4 | 16 for A/B.
 template <int LOGN, int MODE, int W>
 static int run_strided_w(cg_ctx *c, const double2 *src, double2 *dst, PencilMap smap,
@@ -863,6 +1098,14 @@ static int run_strided(cg_ctx *c, const double2 *src, double2 *dst, PencilMap sm
         if (w != 2 && w != 4 && w != 8) w = 8;
     }
     if (w == 2) return run_strided_w<LOGN, MODE, 2>(c, src, dst, smap, dmap, nouter, o_off, P);
+    if constexpr (LOGN == 11) {  // 8 pencils of 2048 points: the even/odd split pass
+        if (w == 8) {
+            bool done = false;
+            if (int rc = run_strided_h<LOGN, MODE>(c, src, dst, smap, dmap, nouter, o_off, P, &done))
+                return rc;
+            if (done) return 0;
+        }
+    }
     if (w == 8 && LOGN <= 10)  // 8 pencils of 2048 points would not fit the 160 KB LDS
         return run_strided_w<(LOGN <= 10 ? LOGN : 10), MODE, 8>(c, src, dst, smap, dmap, nouter,
                                                                 o_off, P);

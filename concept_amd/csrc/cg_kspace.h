@@ -129,3 +129,46 @@ __device__ __forceinline__ double kspace_factor_q(const KspaceParams &P, const K
     if (P.long_range) pk = pk * exp((double)k2 * P.E);
     return factor * pk;
 }
+
+// Separable arrangement of the same factor for the fused x passes.  With
+// k2 = ka^2 + kb^2 + kk^2 the Gaussian of the long-range split factorises,
+// exp(k2 E) = exp(ka^2 E) exp(kb^2 E) exp(kk^2 E), and so does the deconvolution, so one table
+// per dimension index, t[a] = q_a^order * exp(ka^2 E), leaves a mode with one table value, one
+// multiplication and the division by k2 — no exp and no power loop per mode (they are most of
+// the arithmetic of a fused pass: 16 to 32 modes per lane and tile).  Differs from
+// kspace_factor_q by rounding only (a few ulp; same tolerance, tests/test_gpu_pm.py).
+__device__ __forceinline__ double kspace_tab_sep(const KspaceParams &P, int N, int a, double q_a) {
+    const int nyq = N / 2;
+    const int ka = a - (a >= nyq ? N : 0);
+    double f = 1;
+    if (P.deconv_order) {
+        f = q_a;
+        for (int o = 1; o < P.deconv_order; o++) f *= q_a;
+    }
+    if (P.long_range & 1) f *= exp((double)(ka * ka) * P.E);
+    return f;
+}
+struct KspaceFixedS {
+    double g;     // C * t_b * t_kk
+    int kb2_kk2;  // kb*kb + kk*kk
+    bool dead;    // b or kk on a Nyquist plane
+};
+__device__ __forceinline__ KspaceFixedS kspace_fix_sep(const KspaceParams &P, int N, int b, int kk,
+                                                       double t_b, double t_kk) {
+    const int nyq = N / 2;
+    KspaceFixedS F;
+    F.dead = (b == nyq) || (kk == nyq);
+    const int kb = b - (b >= nyq ? N : 0);
+    F.kb2_kk2 = kb * kb + kk * kk;
+    F.g = P.C * t_b * t_kk;
+    return F;
+}
+__device__ __forceinline__ double kspace_factor_sep(const KspaceFixedS &F, int N, int a,
+                                                    double t_a) {
+    const int nyq = N / 2;
+    const int ka = a - (a >= nyq ? N : 0);
+    const int k2 = F.kb2_kk2 + ka * ka;
+    // branch-free (a select): nullify_modes('nyquist'), ('origin')
+    const double f = t_a * F.g / (double)(k2 == 0 ? 1 : k2);
+    return (F.dead | (a == nyq) | (k2 == 0)) ? 0.0 : f;
+}
