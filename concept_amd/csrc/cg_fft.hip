@@ -883,7 +883,7 @@ __global__ __launch_bounds__(NT) void k_fft_strided_h(const double2 *__restrict_
         load(t, 1);
         fft_tile<LOGH, W, NT, INV1>(e, lds, twh, fresh_tid());
         // ---- odd rows (the next tile's even rows are fetched meanwhile; in the fused pass
-        // only during the inverse transforms: the factor evaluation needs the registers)
+        // only during the inverse transforms)
 #pragma unroll
         for (int r = 0; r < PER; r++) x[r] = make_double2(v[r].x, v[r].y);
         if (tprev >= 0) store(tprev, 1);
@@ -931,8 +931,8 @@ __global__ __launch_bounds__(NT) void k_fft_strided_h(const double2 *__restrict_
             }
         }
         if (MODE == 2) {
+            load(tnext, 0);  // (not earlier: three arrays of 16 values are the register budget)
             fft_tile<LOGH, W, NT, true>(e, lds, twh, fresh_tid());
-            load(tnext, 0);  // (only now: three arrays of 16 values in flight are the budget)
             fft_tile<LOGH, W, NT, true>(x, lds, twh, fresh_tid());
         }
 #pragma unroll
@@ -1045,7 +1045,7 @@ static int run_strided_h(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
     const int nkb = (int)((c->N / 2 + 1 + W - 1) / W);
     const i64 ntiles = nouter * nkb;
     // per-lane offsets are 32-bit byte offsets: rows 2 ml (ml < NT/W) must span < 4 GB
-    const i64 reach = 2 * (i64)(NT / W) * (smap.es > dmap.es ? smap.es : dmap.es) * 16;
+    const i64 reach = ((2 * (i64)(NT / W - 1)) * (smap.es > dmap.es ? smap.es : dmap.es) + W) * 16;
     if (!enabled || ntiles < 2 * (i64)ncu || smap.sh != 31 || dmap.sh != 31 ||
         reach >= ((i64)1 << 32) || (i64)nkb * W > c->pad / 2)
         return 0;

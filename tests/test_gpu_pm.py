@@ -461,6 +461,71 @@ def test_fft_2048_roundtrip(torch_cuda):
     mesh.close()
 
 
+def test_fft_2048_known_answer(torch_cuda):
+    """The 2048-point passes against an answer known in closed form — the kernels this size
+    instantiates (k_fft_strided_h: even/odd split over two 1024-point tiles, 8 pencils) are
+    used by no smaller grid.  The transform of a*delta_p + b*delta_q is
+    a*exp(-2 pi i k.p/N) + b*exp(-2 pi i k.q/N): every mode of sampled x layers is compared
+    (<= 1e-13: a delta's transform is a single product of twiddles), the inverse transform must
+    return the two deltas, and the fused solve must equal forward + kernel + inverse."""
+    torch = torch_cuda
+    from concept_amd.mesh import PotentialMesh
+    N, L = 2048, 2048.0
+    mesh = PotentialMesh(N, L)
+    per, pad = mesh.layer_doubles, mesh.pad
+    (a, p), (b, q) = (1.0, (3, 1029, 2047)), (-0.625, (1024, 7, 1))
+    mesh.zero()
+    layer = torch.zeros(per, dtype=torch.float64, device='cuda')
+    for amp, (px, py, pz) in ((a, p), (b, q)):
+        layer.zero_()
+        layer[py*pad + pz] = amp
+        mesh.layers_write(px, 1, layer)
+    mesh.poisson_forward(0, 1.0, False, 0.0, apply_kernel=False)
+    j = torch.arange(N, device='cuda').view(N, 1)
+    k = torch.arange(N//2 + 1, device='cuda').view(1, N//2 + 1)
+    worst = 0.0
+    for i in (0, 1, 2, 63, 64, 511, 1023, 1024, 1025, 1536, 2046, 2047):
+        mesh.layers_read(i, 1, layer)
+        got = torch.view_as_complex(layer[:N*pad].view(N, pad//2, 2))[:, :N//2 + 1]
+        ref = torch.zeros_like(got)
+        for amp, (px, py, pz) in ((a, p), (b, q)):
+            phase = ((i*px + j*py + k*pz) % N).to(torch.float64)*(-2*np.pi/N)
+            ref += amp*torch.polar(torch.ones_like(phase), phase)
+        worst = max(worst, float((got - ref).abs().max()))
+    assert worst <= 1e-13, worst
+    mesh.poisson_backward()
+    for amp, (px, py, pz) in ((a, p), (b, q)):
+        mesh.layers_read(px, 1, layer)
+        real = layer[:N*pad].view(N, pad)[:, :N]
+        assert abs(float(real[py, pz])/N**3 - amp) <= 1e-13
+        real[py, pz] = 0.0
+        assert float(real.abs().max())/N**3 <= 1e-13
+    # the fused x pass (forward, factor, inverse in one kernel) against the three separate ones
+    def prepare():
+        mesh.zero()
+        for amp, (px, py, pz) in ((a, p), (b, q)):
+            layer.zero_()
+            layer[py*pad + pz] = amp
+            mesh.layers_write(px, 1, layer)
+    other = torch.empty_like(layer)
+    for lr in (False, True):
+        prepare()
+        mesh.poisson_solve(4, -2.5, lr, -3e-5)
+        fused = {}
+        for i in (0, 3, 1024, 2047):
+            mesh.layers_read(i, 1, layer)
+            fused[i] = layer.clone()
+        prepare()
+        mesh.poisson_forward(4, -2.5, lr, -3e-5, apply_kernel=True)
+        mesh.poisson_backward()
+        for i, f in fused.items():
+            mesh.layers_read(i, 1, other)
+            s = other[:N*pad].view(N, pad)[:, :N]
+            d = (f[:N*pad].view(N, pad)[:, :N] - s).abs().max()
+            assert float(d) <= 1e-12*float(s.abs().max()), (lr, i, float(d))
+    mesh.close()
+
+
 def test_multi_component_superposition(torch_cuda, golden):
     """particle_mesh with several suppliers/receivers (interactions.py:2029-2035,
     mesh.py:604-608): splitting one component into two of the same particle mass must
