@@ -740,8 +740,9 @@ def main():
         result['roofline_groups'][gname] = {
             'ms': round(ms, 3), 'moved_GB': round(moved/1e9, 2),
             'frac_moved': round(moved/(ms*1e-3)/1e9/HBM_PEAK_GBS, 4),
-            'survey_8d_GB': round(credit/1e9, 2),
-            'frac_survey_8d': round(credit/(ms*1e-3)/1e9/HBM_PEAK_GBS, 4)}
+            # SURVEY.md §8(d)'s bytes for the unfused reference phases of the group: a credit
+            # for work removed by fusion, stated as bytes only — never turned into a fraction
+            'survey_8d_GB': round(credit/1e9, 2)}
     result['phases'] = phases
     if not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline()

@@ -237,6 +237,8 @@ struct FusedScatter {
     double *pos_out, *mom_out;
     const i64 *ids_in;
     i64 *ids_out;
+    const i64 *aux_in;
+    i64 *aux_out;
 };
 int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
                           const unsigned *tile_offset, int diff_order, double factor,
@@ -246,4 +248,5 @@ int cgk_predict_regions(cg_ctx *c, const unsigned *start_in, const unsigned *cou
 int cgk_emigrant_rows_dest(cg_ctx *c, const double *rows, const unsigned *count, i64 cap,
                            int *dest, int *send_counts);
 int cgk_region_insert(cg_ctx *c, const double *rows, i64 m, const unsigned *start,
-                      unsigned *count, double *pos_out, double *mom_out, i64 *ids_out);
+                      unsigned *count, double *pos_out, double *mom_out, i64 *ids_out,
+                      i64 *aux_out);

@@ -337,7 +337,7 @@ __global__ void k_region_insert(const double *__restrict__ rows, i64 m, CicGeom 
                                 TileGeom t, i64 x0, const unsigned *__restrict__ start,
                                 unsigned *__restrict__ count, double *__restrict__ pos_out,
                                 double *__restrict__ mom_out, i64 *__restrict__ ids_out,
-                                unsigned *__restrict__ err_flags) {
+                                i64 *__restrict__ aux_out, unsigned *__restrict__ err_flags) {
     i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m) return;
     const double *row = rows + 8 * r;
@@ -356,13 +356,15 @@ __global__ void k_region_insert(const double *__restrict__ rows, i64 m, CicGeom 
     pos_out[3 * q] = row[0], pos_out[3 * q + 1] = row[1], pos_out[3 * q + 2] = row[2];
     mom_out[3 * q] = row[3], mom_out[3 * q + 1] = row[4], mom_out[3 * q + 2] = row[5];
     if (ids_out) ids_out[q] = __double_as_longlong(row[6]);
+    if (aux_out) aux_out[q] = __double_as_longlong(row[7]);
 }
 int cgk_region_insert(cg_ctx *c, const double *rows, i64 m, const unsigned *start,
-                      unsigned *count, double *pos_out, double *mom_out, i64 *ids_out) {
+                      unsigned *count, double *pos_out, double *mom_out, i64 *ids_out,
+                      i64 *aux_out) {
     if (m == 0) return 0;
     hipLaunchKernelGGL(k_region_insert, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
                        rows, m, c->geom_deposit, c->p.nghosts, c->N, c->tiles, c->xmap.x0, start,
-                       count, pos_out, mom_out, ids_out, c->err_flags);
+                       count, pos_out, mom_out, ids_out, aux_out, c->err_flags);
     CG_LAUNCH_CHECK();
     return 0;
 }

@@ -228,6 +228,8 @@ struct PrepArgs {
     double *pos_out, *mom_out;
     const i64 *ids_in;
     i64 *ids_out;
+    const i64 *aux_in;  // a second 64-bit column travelling with the particles (or null)
+    i64 *aux_out;
     unsigned *err_flags;
     // input populations when the input itself is in regions with gaps (null: dense tile order)
     const unsigned *count_in;
@@ -535,6 +537,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
             gk_store_run(prep.mom_out, (i64)first, rs, rl, lane, valid, n0, n1, n2);
 #endif
             if (valid && prep.ids_in) prep.ids_out[(i64)first + (lane - rs)] = prep.ids_in[p];
+            if (valid && prep.aux_in) prep.aux_out[(i64)first + (lane - rs)] = prep.aux_in[p];
             if (prep.emig_rows && pvalid && next_key == kNoTile) {
                 // leaves this domain's slab: exchange() (communication.py:135-517) takes it
                 // from here, already kicked and drifted
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
                     double *row = prep.emig_rows + 8 * (i64)slot;
                     row[0] = nx, row[1] = ny_, row[2] = nz, row[3] = n0, row[4] = n1, row[5] = n2;
                     row[6] = prep.ids_in ? __longlong_as_double(prep.ids_in[p]) : 0.0;
-                    row[7] = 0.0;
+                    row[7] = prep.aux_in ? __longlong_as_double(prep.aux_in[p]) : 0.0;
                 }
             }
         }
@@ -597,6 +600,8 @@ int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
         prep_args.mom_out = fs->mom_out;
         prep_args.ids_in = fs->ids_in;
         prep_args.ids_out = fs->ids_out;
+        prep_args.aux_in = fs->aux_in;
+        prep_args.aux_out = fs->aux_out;
         prep_args.err_flags = c->err_flags;
         prep_args.count_in = fs->count_in;
         prep_args.emig_rows = c->emig_rows;

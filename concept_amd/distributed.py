@@ -616,15 +616,20 @@ class RegionParticles:
         self.n_hint = n
         cap = m.region_capacity(int(n*slack) + 1024 if self.multi else n)
         self.cap = cap
-        self.has_ids = 'ids' in store.cols
+        # two 64-bit columns may travel with the particles: `ids` and `order` (a Component's
+        # identifiers and the row numbers its host() restores the populated order with)
+        self.has_ids, self.has_aux = 'ids' in store.cols, 'order' in store.cols
         mk = lambda w: torch.empty((cap, w), dtype=torch.float64, device=dev)
+        mi = lambda have: [torch.empty(cap, dtype=torch.int64, device=dev) for _ in range(2)] \
+            if have else [None, None]
         self.pos, self.mom = [mk(3), mk(3)], [mk(3), mk(3)]
-        self.ids = [torch.empty(cap, dtype=torch.int64, device=dev) for _ in range(2)] \
-            if self.has_ids else [None, None]
+        self.ids, self.aux = mi(self.has_ids), mi(self.has_aux)
         self.pos[0][:n] = store.view('pos')
         self.mom[0][:n] = store.view('mom')
         if self.has_ids:
             self.ids[0][:n] = store.view('ids')
+        if self.has_aux:
+            self.aux[0][:n] = store.view('order')
         self.cur = 0
         # the present order: dense (the store's tile table) until the first fused pass
         self.start = self._dense_table = store.table[:8*m.ntiles + 1].clone()
@@ -665,7 +670,8 @@ class RegionParticles:
         try:
             m.gather_kick_drift_scatter(self.pos[c], self.mom[c], self.ids[c], self.start, self.count,
                                         self.pos[o], self.mom[o], self.ids[o], start_out,
-                                        count_out, diff_order, kick_factor, dt_over_mass)
+                                        count_out, diff_order, kick_factor, dt_over_mass,
+                                        aux_in=self.aux[c], aux_out=self.aux[o])
         finally:
             if self.multi:
                 lib.check(lib.raw().cg_set_emigrant_rows(m._ctx, None, None, 0))
@@ -707,7 +713,8 @@ class RegionParticles:
             c = self.cur
             lib.check(lib.raw().cg_region_insert(
                 m._ctx, _vp(inc), m_in, _vp(self.start), _vp(self.count), _vp(self.pos[c]),
-                _vp(self.mom[c]), _vp(self.ids[c]) if self.has_ids else None))
+                _vp(self.mom[c]), _vp(self.ids[c]) if self.has_ids else None,
+                _vp(self.aux[c]) if self.has_aux else None))
 
     # -- bookkeeping ------------------------------------------------------------------
     @property
@@ -722,18 +729,29 @@ class RegionParticles:
         self.finish_exchange()
         self.mesh.check_errors()
 
-    def dense(self):
-        """(pos, mom, ids or None) of the live particles as dense tensors, in tile order"""
+    def columns(self):
+        """{'pos', 'mom' (, 'ids', 'order')} of the live particles as dense tensors, in tile
+        order"""
         self.finish_exchange()
         c = self.cur
         if self.count is None:
-            k = self.n_dense
-            return self.pos[c][:k], self.mom[c][:k], (self.ids[c][:k] if self.has_ids else None)
-        st, ct = self.start.long(), self.count.long()
-        slot = torch.arange(self.cap, device=self.mesh.device)
-        k = (torch.searchsorted(st, slot, right=True) - 1).clamp(max=ct.numel() - 1)
-        live = (slot - st[k]) < ct[k]
-        return self.pos[c][live], self.mom[c][live], (self.ids[c][live] if self.has_ids else None)
+            sel = slice(0, self.n_dense)
+        else:
+            st, ct = self.start.long(), self.count.long()
+            slot = torch.arange(self.cap, device=self.mesh.device)
+            k = (torch.searchsorted(st, slot, right=True) - 1).clamp(max=ct.numel() - 1)
+            sel = (slot - st[k]) < ct[k]
+        out = {'pos': self.pos[c][sel], 'mom': self.mom[c][sel]}
+        if self.has_ids:
+            out['ids'] = self.ids[c][sel]
+        if self.has_aux:
+            out['order'] = self.aux[c][sel]
+        return out
+
+    def dense(self):
+        """(pos, mom, ids or None) of the live particles as dense tensors, in tile order"""
+        cols = self.columns()
+        return cols['pos'], cols['mom'], cols.get('ids')
 
 
 def pm_step_regions(domain, rp, contribution, deconv_order, C, kick_factor, dt_over_mass,

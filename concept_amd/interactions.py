@@ -172,6 +172,32 @@ def particle_mesh(receivers, suppliers, gridsize_global, quantity, force, method
         _kick_particles(mesh, receiver, force, method, ᔑdt, ᔑdt_key)
 
 
+def pm_streaming_plan(components):
+    """What stepper.timeloop needs to run gravity('pm') of the default configuration (the fast
+    path of particle_mesh above) together with the drift that follows it, in one pass over
+    particles kept in tile regions (cg_gather_kick_drift_scatter): the mesh, the promoted
+    deconvolution order and the potential's constants — or None where the configuration is not
+    that one (then the loop calls gravity() and drift() one after the other)."""
+    force, method = 'gravity', 'pm'
+    if any(c.representation != 'particles' or c.forces.get(force) != method or c.use_rungs
+           for c in components):
+        return None
+    specs = get_potential_specs(force, method, components, components)
+    if not _default_fast_path(components, components, specs.gridsize, force, method,
+                              specs.interpolation_order, specs.interlace.upstream,
+                              specs.interlace.downstream):
+        return None
+    p = components[0].params
+    mesh = get_mesh(specs.gridsize, p.boxsize, p.nghosts, p.cell_centered,
+                    specs.interpolation_order, components[0].device)
+    if not all(_aligned(c, mesh) for c in components):
+        return None
+    deconv = (int(bool(specs.deconvolve.upstream)) + int(bool(specs.deconvolve.downstream)))
+    C, long_range, E = _potential_constants(p, 'gravity', specs.gridsize)
+    return {'mesh': mesh, 'gridsize': specs.gridsize, 'deconv_order': deconv*specs.interpolation_order,
+            'C': C, 'long_range': long_range, 'E': E, 'force': force, 'method': method}
+
+
 def _particle_contribution(supplier, ᔑdt, fft_factor, gridsize, boxsize):
     """mesh.py:1550-1573 for quantity 'a²ρ'"""
     contribution = ᔑdt['a**(-3*w_eff-1)', supplier.name]/ᔑdt['1']

@@ -546,13 +546,15 @@ class PotentialMesh:
 
     def gather_kick_drift_scatter(self, pos_in, mom_in, ids_in, start_in, count_in, pos_out,
                                   mom_out, ids_out, start_out, count_out, diff_order, factor,
-                                  dt_over_mass):
+                                  dt_over_mass, aux_in=None, aux_out=None):
         """cg_gather_kick_drift_scatter (see concept_gpu.h): nothing is written in place"""
+        opt = lambda t: _ptr(t) if t is not None else None
         check(_L.cg_gather_kick_drift_scatter(
             self._ctx, _ptr(pos_in), _ptr(mom_in), _ptr(ids_in) if ids_in is not None else None,
             _ptr(start_in), _ptr(count_in) if count_in is not None else None, _ptr(pos_out),
             _ptr(mom_out), _ptr(ids_out) if ids_out is not None else None, _ptr(start_out),
-            _ptr(count_out), int(diff_order), float(factor), float(dt_over_mass)))
+            _ptr(count_out), int(diff_order), float(factor), float(dt_over_mass), opt(aux_in),
+            opt(aux_out)))
 
     def check_errors(self):
         flags = self.error_flags()

@@ -138,6 +138,30 @@ class Component:
         self.tile_mesh = None
         self.tiles_exact = False
 
+    def to_regions(self, mesh):
+        """The particle arrays in streaming form (distributed.RegionParticles: tile regions
+        with gaps, for the fused kick + drift + sort of stepper.timeloop); the Component's own
+        arrays are stale until from_regions()."""
+        from .distributed import RegionParticles
+        self.tile_sort(mesh)
+        return RegionParticles(self._store)
+
+    def from_regions(self, rp):
+        """Take the particles back from their streaming form (pos, mom, ids, order; Δmom and
+        rung columns start from zero as after populate())."""
+        from .distributed import ParticleStore
+        cols = rp.columns()
+        old = self._store
+        self._store = ParticleStore(old.mesh, cols['pos'], cols['mom'], None, slack=1.4,
+                                    extra={'ids': cols['ids'], 'order': cols['order']})
+        for name in ('Δmom', 'rung_indices', 'rung_indices_jumped'):
+            if name in old.cols:
+                t = old.cols[name]
+                self._store.add_column(name, dtype=t.dtype, width=(t.shape[1] if t.dim() > 1
+                                                                  else None))
+        self.tile_mesh = None
+        self.tiles_exact = False
+
     N_local = property(lambda self: self._store.n if self._store is not None else 0)
     tile_table = property(lambda self: self._store.table
                           if self._store is not None and self.tile_mesh is not None else None)

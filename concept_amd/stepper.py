@@ -52,6 +52,13 @@ def timeloop(components, n_steps, integrals, rung_integrals=None, on_step=None):
     p3m = _method(components) == 'p3m'
     if p3m and rung_integrals is None:
         raise ConceptGPUError('P3M stepping needs the per-rung integrals (ᔑdt_rungs)')
+    if on_step is None and not p3m and n_steps > 0:
+        # nobody looks at the particles between a long-range kick and the drift after it: the
+        # default PM configuration then takes both in one pass (same kicks and drifts, same
+        # order: K½ D K D ... K; drift bit-exact, kick to summation order)
+        plan = interactions.pm_streaming_plan(components)
+        if plan is not None:
+            return _timeloop_streaming(components, n_steps, integrals, plan)
     kick_long(components, integrals('init'))
     if p3m:
         kick_short(components, rung_integrals('init'))
@@ -64,6 +71,38 @@ def timeloop(components, n_steps, integrals, rung_integrals=None, on_step=None):
         kick_long(components, integrals('full'))
         if on_step:
             on_step(step)
+
+
+def _timeloop_streaming(components, n_steps, integrals, plan):
+    """timeloop() for the default PM configuration with the kick of one step and the drift of
+    the next fused.  Per pass: every component deposited from its tile regions
+    (mesh.py:1512-1636), one Poisson solve (interactions.py:2092-2118), then per component
+    cg_gather_kick_drift_scatter with the kick's ᔑdt['a**(-3*w_eff)', name] and the next
+    drift's ᔑdt['a**(-2)'] (zero after the last kick)."""
+    mesh = plan['mesh']
+    fft_factor = float(plan['gridsize'])**(-3)
+    p = components[0].params
+    rps = [c.to_regions(mesh) for c in components]
+    try:
+        for step in range(n_steps + 1):
+            ᔑdt_kick = integrals('init' if step == 0 else 'full')
+            ᔑdt_drift = integrals('full') if step < n_steps else None
+            for k, (c, rp) in enumerate(zip(components, rps)):
+                rp.deposit(interactions._particle_contribution(
+                    c, ᔑdt_kick, fft_factor, plan['gridsize'], p.boxsize), accumulate=k > 0)
+            fold = mesh.fold_ghosts_start()
+            mesh.poisson_solve(plan['deconv_order'], plan['C'], plan['long_range'], plan['E'],
+                               fold_finish=fold, fill=True)
+            for c, rp in zip(components, rps):
+                order = c.potential_differentiations[plan['force']][plan['method']]
+                Δt_over_mass = (ᔑdt_drift['a**(-2)']/c.mass) if ᔑdt_drift is not None else 0.0
+                rp.kick_drift_sort(order, c.mass*(-ᔑdt_kick['a**(-3*w_eff)', c.name]),
+                                   Δt_over_mass)
+        for rp in rps:
+            rp.check()
+    finally:
+        for c, rp in zip(components, rps):
+            c.from_regions(rp)
 
 
 # ---------------------------------------------------------------------------

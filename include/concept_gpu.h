@@ -179,11 +179,14 @@ int cg_gather_kick_drift_scatter(cg_ctx *ctx, const double *pos_in, const double
                                  const uint32_t *count_in /*NULL: dense*/, double *pos_out,
                                  double *mom_out, int64_t *ids_out /*nullable*/,
                                  const uint32_t *start_out, uint32_t *count_out, int diff_order,
-                                 double factor, double dt_over_mass);
+                                 double factor, double dt_over_mass,
+                                 const int64_t *aux_in /*nullable*/, int64_t *aux_out);
+/* (ids and aux: two 64-bit columns that travel with the particles — a Component's `ids` and
+ * the row numbers its host() uses to restore the populated order) */
 
 /* The same on x-slab domains: a particle whose drift takes it out of the slab has no place in
  * this domain's next order; the kernel appends it — kicked and drifted — to a caller-owned row
- * buffer (8 doubles: pos 3, mom 3, id bits, unused), exchange() (communication.py:135-517)
+ * buffer (8 doubles: pos 3, mom 3, id bits, aux bits), exchange() (communication.py:135-517)
  * ships the rows, and the receiving domain gives each a place in its regions.  No holes to
  * close on the sending side: a leaver was never written there.
  *   cg_set_emigrant_rows   rows[8*cap], *count (DEV; zeroed by every fused launch); NULL = off
@@ -197,7 +200,8 @@ int cg_emigrant_rows_dest(cg_ctx *ctx, const double *rows /*DEV*/, const uint32_
                           int64_t cap, int32_t *dest /*DEV cap*/, int32_t *send_counts /*DEV P*/);
 int cg_region_insert(cg_ctx *ctx, const double *rows /*DEV 8m*/, int64_t m,
                      const uint32_t *start /*DEV*/, uint32_t *count /*DEV*/, double *pos_out,
-                     double *mom_out, int64_t *ids_out /*nullable*/);
+                     double *mom_out, int64_t *ids_out /*nullable*/,
+                     int64_t *aux_out /*nullable*/);
 
 /* Drop the prepared histogram.  Every entry point of this context that writes momenta
  * (cg_gather_kick*, cg_gather_scalar, cg_dmom_apply, cg_drift) does so itself; a caller that

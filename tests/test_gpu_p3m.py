@@ -125,7 +125,7 @@ def test_timeloop_sequence_vs_reference(golden, name):
     """A18: concept_amd.stepper.timeloop (init half kicks, then drift -> kicks) against
     the reference's own sequence of Component.drift / gravity / apply_Δmom calls."""
     import torch
-    from concept_amd import commons, stepper
+    from concept_amd import commons, interactions, stepper
     from concept_amd.species import Component
     g = golden(name)
     method = str(g['method'])
@@ -168,6 +168,28 @@ def test_timeloop_sequence_vs_reference(golden, name):
     # drift inside timeloop uses integrals('full')['a**(-2)'] like the reference's scalars(dt)
     stepper.timeloop([c], 2, integrals, rung_integrals if method == 'p3m' else None, on_step)
     assert seen == ['init', 'step1', 'step2']
+    if method != 'pm':
+        return
+    # Without a callback between kick and drift the PM loop streams: the kick of a step and the
+    # drift of the next in one pass over particles kept in tile regions
+    # (cg_gather_kick_drift_scatter).  Same end state as the reference's sequence — and ids and
+    # the populated order come back with the particles.
+    c2 = Component('matter', 'matter', N=int(g['N']), mass=float(g['mass']))
+    c2.populate(g['pos_in'], 'pos')
+    c2.populate(g['mom_in'], 'mom')
+    assert interactions.pm_streaming_plan([c2]) is not None
+    stepper.timeloop([c2], 2, integrals)
+    pos, mom = c2.host('pos'), c2.host('mom')
+    o = np.argsort(pos[:, 0], kind='stable')
+    dx = np.abs(pos[o] - g['pos_step2'])
+    assert np.minimum(dx, L - dx).max() <= 1e-13*L
+    assert np.abs(mom[o] - g['mom_step2']).max() <= 1e-12*np.abs(g['mom_step2']).max()
+    # row by row against the stepwise run (host() restores the populated order through `order`)
+    dx = np.abs(pos - c.host('pos'))
+    assert np.minimum(dx, L - dx).max() <= 1e-13*L
+    assert np.abs(mom - c.host('mom')).max() <= 1e-12*np.abs(mom).max()
+    assert np.array_equal(c2.host('ids'), c.host('ids'))
+    assert c2.N_local == c.N_local
 
 
 def test_config3_size_shortrange_properties():

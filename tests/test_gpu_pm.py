@@ -830,3 +830,43 @@ def test_other_differentiation_orders_vs_golden(torch_cuda, golden, name):
         got = force.fetch_real()[:, :, :N]
         ref = g['grid_force'][dim][ng:-ng, ng:-ng, ng:-ng]
         assert np.abs(got - ref).max() <= TOL*rms(ref)
+
+
+def test_streaming_timeloop_two_components(torch_cuda):
+    """stepper.timeloop without a callback takes kick + drift + tile sort in one pass
+    (cg_gather_kick_drift_scatter) — here with two components of different mass and
+    differentiation order on the shared mesh: same end state, row by row, as the loop that calls
+    gravity() and drift() one after the other (main.py:255-361)."""
+    from concept_amd import commons, stepper
+    from concept_amd.species import Component
+    rng = np.random.default_rng(21)
+    L, gs, n = 50.0, 32, (3000, 1700)
+    commons.load_params({
+        'boxsize': L,
+        'potential_options': {'gridsize': {'gravity': {'pm': gs}},
+                              'differentiation': {'light': {'gravity': {'pm': 4}}}},
+        'select_forces': {'all': {'gravity': 'pm'}},
+    })
+    data = [(rng.uniform(0, L, (k, 3)), rng.normal(0, 2.0, (k, 3))) for k in n]
+
+    def run(stream):
+        comps = [Component('heavy', 'matter', N=n[0], mass=3.0),
+                 Component('light', 'matter', N=n[1], mass=0.7)]
+        for c, (pos, mom) in zip(comps, data):
+            c.populate(pos, 'pos')
+            c.populate(mom, 'mom')
+
+        def integrals(kind):
+            d = 0.05 if kind == 'init' else 0.1
+            out = {'1': d, 'a**(-2)': 1.2*d}
+            for c in comps:
+                out['a**(-3*w_eff)', c.name] = 1.1*d
+                out['a**(-3*w_eff-1)', c.name] = 0.9*d
+            return out
+        stepper.timeloop(comps, 3, integrals, None, None if stream else (lambda step: None))
+        return [(c.host('pos'), c.host('mom'), c.host('ids')) for c in comps]
+    for (p0, m0, i0), (p1, m1, i1), (_, mom_in) in zip(run(False), run(True), data):
+        d = np.abs(p0 - p1)
+        assert np.minimum(d, L - d).max() <= 1e-13*L
+        assert np.abs(m0 - m1).max() <= TOL*rms(m0 - mom_in) + 4e-16*np.abs(m0).max()
+        assert np.array_equal(i0, i1)
