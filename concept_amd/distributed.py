@@ -716,6 +716,16 @@ class RegionParticles:
                 _vp(self.mom[c]), _vp(self.ids[c]) if self.has_ids else None,
                 _vp(self.aux[c]) if self.has_aux else None))
 
+    def snapshot(self):
+        """The present order (which buffer set, its region tables): kick_drift_sort writes the
+        other set only, so restore(snapshot) undoes a pass whose regions overflowed."""
+        self.finish_exchange()
+        return (self.cur, self.start, self.count)
+
+    def restore(self, snap):
+        self.cur, self.start, self.count = snap
+        self.pending = False  # (the leavers of the undone pass are dropped with it)
+
     # -- bookkeeping ------------------------------------------------------------------
     @property
     def n(self):

@@ -10,7 +10,7 @@ reduced to what fixes the order of kicks and drifts:
 The time-step integrals ᔑdt[...] (main.get_time_step_integrals, integration.py:712-827)
 are inputs: the cosmological background and the Δt limiters are outside the path, the
 caller supplies plain numbers with the reference's keys."""
-from . import interactions
+from . import interactions, lib
 from .lib import ConceptGPUError
 
 
@@ -73,6 +73,9 @@ def timeloop(components, n_steps, integrals, rung_integrals=None, on_step=None):
             on_step(step)
 
 
+stream_replays = 0  # steps the streaming loop had to undo and take on the exact path
+
+
 def _timeloop_streaming(components, n_steps, integrals, plan):
     """timeloop() for the default PM configuration with the kick of one step and the drift of
     the next fused.  Per pass: every component deposited from its tile regions
@@ -93,13 +96,30 @@ def _timeloop_streaming(components, n_steps, integrals, plan):
             fold = mesh.fold_ghosts_start()
             mesh.poisson_solve(plan['deconv_order'], plan['C'], plan['long_range'], plan['E'],
                                fold_finish=fold, fill=True)
+            before = [rp.snapshot() for rp in rps]
             for c, rp in zip(components, rps):
                 order = c.potential_differentiations[plan['force']][plan['method']]
                 Δt_over_mass = (ᔑdt_drift['a**(-2)']/c.mass) if ᔑdt_drift is not None else 0.0
                 rp.kick_drift_sort(order, c.mass*(-ᔑdt_kick['a**(-3*w_eff)', c.name]),
                                    Δt_over_mass)
-        for rp in rps:
-            rp.check()
+            # The regions of the new order were sized from the present populations; a (tile,
+            # bucket) that grew beyond that in one step has dropped particles.  The pass wrote
+            # the other buffer set only: undo it and take the step on the exact path (the
+            # potential is still on the mesh), then go on streaming.
+            overflow = bool(mesh.error_flags() & lib.CG_ERR_BUCKET_OVERFLOW)
+            if mesh.comm is not None:
+                overflow = mesh.comm.any(overflow)
+            if overflow:
+                global stream_replays
+                stream_replays += 1
+                for i, c in enumerate(components):
+                    rps[i].restore(before[i])
+                    c.from_regions(rps[i])
+                    interactions._kick_particles(mesh, c, plan['force'], plan['method'],
+                                                 ᔑdt_kick, ('a**(-3*w_eff)', 'component'))
+                    if ᔑdt_drift is not None:
+                        c.drift_sort(ᔑdt_drift, mesh=mesh)
+                    rps[i] = c.to_regions(mesh)
     finally:
         for c, rp in zip(components, rps):
             c.from_regions(rp)

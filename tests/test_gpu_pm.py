@@ -870,3 +870,38 @@ def test_streaming_timeloop_two_components(torch_cuda):
         assert np.minimum(d, L - d).max() <= 1e-13*L
         assert np.abs(m0 - m1).max() <= TOL*rms(m0 - mom_in) + 4e-16*np.abs(m0).max()
         assert np.array_equal(i0, i1)
+
+
+def test_streaming_timeloop_region_overflow_is_replayed(torch_cuda):
+    """A step in which a (tile, bucket) grows beyond the region predicted for it
+    (CG_ERR_BUCKET_OVERFLOW: here a flow converging on one tile) is undone and taken on the
+    exact path by stepper.timeloop; the end state equals the non-streaming loop's."""
+    from concept_amd import commons, stepper
+    from concept_amd.species import Component
+    rng = np.random.default_rng(3)
+    L, gs, n = 32.0, 32, 20000
+    commons.load_params({'boxsize': L, 'potential_options': {'gridsize': {'gravity': {'pm': gs}}},
+                         'select_forces': {'all': {'gravity': 'pm'}}})
+    pos = rng.uniform(0, L, (n, 3))
+    d, mass = 0.1, 2.0
+    # the first full drift (a**(-2) integral 1.2 d) takes every particle 90 % of the way to (8, 8, 8)
+    mom = (8.0 - pos)*0.9*mass/(1.2*d)
+
+    def integrals(kind):
+        s = d/2 if kind == 'init' else d
+        return {'1': s, 'a**(-2)': 1.2*s if kind == 'init' else 1.2*d,
+                ('a**(-3*w_eff)', 'm'): 1e-3*s, ('a**(-3*w_eff-1)', 'm'): 0.9*s}
+
+    def run(stream):
+        c = Component('m', 'matter', N=n, mass=mass)
+        c.populate(pos, 'pos')
+        c.populate(mom, 'mom')
+        stepper.timeloop([c], 2, integrals, None, None if stream else (lambda step: None))
+        return c.host('pos'), c.host('mom'), c.host('ids')
+    replays = stepper.stream_replays
+    (p0, m0, i0), (p1, m1, i1) = run(False), run(True)
+    assert stepper.stream_replays > replays  # (the overflow really happened)
+    dd = np.abs(p0 - p1)
+    assert np.minimum(dd, L - dd).max() <= 1e-13*L
+    assert np.abs(m0 - m1).max() <= 1e-12*np.abs(m0).max()
+    assert np.array_equal(i0, i1)
