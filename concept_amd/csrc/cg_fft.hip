@@ -1038,6 +1038,7 @@ static int run_strided_h(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
     if (enabled < 0) {
         const char *env = getenv("CONCEPT_GPU_FFT_SPLIT");
         enabled = env ? atoi(env) : 1;
+        if (LOGN < 10 && enabled < 2) enabled = 0;  // (512 and below: only on request, for A/B)
         hipDeviceProp_t prop;
         CG_HIP(hipGetDeviceProperties(&prop, c->p.device));
         ncu = prop.multiProcessorCount;
@@ -1059,7 +1060,9 @@ static int run_strided_h(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
                                    (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)ncu), dim3(NT), lds, c->stream, src, dst, smap.ostride,
+    // workgroups per CU the LDS footprint allows (2048: one; 1024: two, each the other's cover)
+    const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ncu * per_cu)), dim3(NT), lds, c->stream, src, dst, smap.ostride,
                        smap.es, dmap.ostride, dmap.es, nkb, ntiles, o_off,
                        (const double2 *)c->fft_tw, P);
     CG_LAUNCH_CHECK();
@@ -1098,7 +1101,7 @@ static int run_strided(cg_ctx *c, const double2 *src, double2 *dst, PencilMap sm
         if (w != 2 && w != 4 && w != 8) w = 8;
     }
     if (w == 2) return run_strided_w<LOGN, MODE, 2>(c, src, dst, smap, dmap, nouter, o_off, P);
-    if constexpr (LOGN == 11) {  // 8 pencils of 2048 points: the even/odd split pass
+    if constexpr (LOGN >= 9 && LOGN <= 11) {  // the even/odd split pass (k_fft_strided_h)
         if (w == 8) {
             bool done = false;
             if (int rc = run_strided_h<LOGN, MODE>(c, src, dst, smap, dmap, nouter, o_off, P, &done))
