@@ -563,6 +563,11 @@ class PotentialMesh:
                 'cg_drift_sort: the tile histogram prepared by the last gather-kick did not match '
                 'the particles it sorted (momenta were changed in between without '
                 'prepare_invalidate()); particles were dropped')
+        if flags & lib.CG_ERR_NOT_IN_TILE:
+            raise lib.ConceptGPUError(
+                'cg_gather_kick_drift_scatter: a particle was not in the tile it is stored under '
+                '(positions changed since the order was made) and got no kick — repeat the step '
+                'on the exact path')
         if flags & lib.CG_ERR_BUCKET_OVERFLOW:
             raise lib.ConceptGPUError(
                 'cg_gather_kick_drift_scatter: a (tile, bucket) outgrew its predicted region; '

@@ -106,7 +106,8 @@ def _timeloop_streaming(components, n_steps, integrals, plan):
             # bucket) that grew beyond that in one step has dropped particles.  The pass wrote
             # the other buffer set only: undo it and take the step on the exact path (the
             # potential is still on the mesh), then go on streaming.
-            overflow = bool(mesh.error_flags() & lib.CG_ERR_BUCKET_OVERFLOW)
+            overflow = bool(mesh.error_flags()
+                            & (lib.CG_ERR_BUCKET_OVERFLOW | lib.CG_ERR_NOT_IN_TILE))
             if mesh.comm is not None:
                 overflow = mesh.comm.any(overflow)
             if overflow:

@@ -169,6 +169,9 @@ int cg_gather_kick_tiled_prepare(cg_ctx *ctx, const double *pos /*DEV 3n*/,
  *                        mom_out) (A11), both stored in the regions start_out; count_out is
  *                        zeroed here and ends as the new populations.  Single domain. */
 #define CG_ERR_BUCKET_OVERFLOW 2u
+#define CG_ERR_NOT_IN_TILE 4u /* cg_gather_kick_drift_scatter met a particle outside the tile it
+                                 is stored under (positions changed since the order was made):
+                                 not kicked; repeat the step on the exact path */
 int64_t cg_region_capacity(const cg_ctx *ctx, int64_t n);
 int cg_predict_regions(cg_ctx *ctx, const uint32_t *start_in /*DEV*/,
                        const uint32_t *count_in /*DEV or NULL*/, uint32_t *start_out /*DEV*/);
