@@ -131,25 +131,34 @@ assert torch.equal(out, inp)
 # the pipelined transposing solve against the local one
 from concept_amd.distributed import SlabDomain
 from concept_amd.mesh import PotentialMesh
-N, L = 64, 64.0
-rho = torch.rand((N, N, N), dtype=torch.float64, device='cuda')
-ref = PotentialMesh(N, L)
 os.environ['CONCEPT_GPU_DIST_FORCE'] = '1'
-dom = SlabDomain(N, L)
-assert len(dom.pieces) == 4
-for m in (ref, dom.mesh):
-    m.zero()
-    m.fluid_add(rho, 1.0, '=')
-ref.poisson_solve(4, -2.5)
-dom.poisson_solve(4, -2.5)
-torch.cuda.synchronize()
-pos = torch.rand((5000, 3), dtype=torch.float64, device='cuda')*L
-va = torch.zeros((5000, 3), dtype=torch.float64, device='cuda')
-vb = torch.zeros_like(va)
-ref.gather_kick(pos, va, 2, 1.0)
-dom.mesh.gather_kick(pos, vb, 2, 1.0)
-scale = va.abs().max().item()
-assert scale > 0 and (va - vb).abs().max().item() <= 1e-13*scale, (va - vb).abs().max().item()/scale
+# 64: the generic kernels; 1024: the production instantiation (even/odd split passes on the
+# transposed buffer, cache-sized pieces)
+for N in (64, 1024):
+    L = float(N)
+    gen = torch.Generator(device='cuda').manual_seed(N)
+    rho = torch.rand((N, N, N), dtype=torch.float64, device='cuda', generator=gen)
+    ref = PotentialMesh(N, L)
+    dom = SlabDomain(N, L)
+    assert len(dom.pieces) >= 4
+    for m in (ref, dom.mesh):
+        m.zero()
+        m.fluid_add(rho, 1.0, '=')
+    del rho
+    ref.poisson_solve(4, -2.5)
+    dom.poisson_solve(4, -2.5)
+    torch.cuda.synchronize()
+    pos = torch.rand((5000, 3), dtype=torch.float64, device='cuda')*L
+    va = torch.zeros((5000, 3), dtype=torch.float64, device='cuda')
+    vb = torch.zeros_like(va)
+    ref.gather_kick(pos, va, 2, 1.0)
+    dom.mesh.gather_kick(pos, vb, 2, 1.0)
+    scale = va.abs().max().item()
+    assert scale > 0 and (va - vb).abs().max().item() <= 1e-12*scale, \
+        (N, (va - vb).abs().max().item()/scale)
+    ref.close()
+    dom.mesh.close()
+    del ref, dom
 dist.destroy_process_group()
 print('RCCL-PIECES-OK')
 ''' % REPO
