@@ -998,11 +998,12 @@ static int run_strided_r(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
     if constexpr (can_persist) {
         if (persist && ntiles >= 4 * (i64)ncu && smap.sh == 31 && dmap.sh == 31) {
             auto kern = k_fft_strided_p<LOGN, NT, MODE, W>;
-            static bool attr_set_p = false;
-            if (!attr_set_p && lds_p > 64 * 1024) {
+            static bool attr_set_p[64] = {};  // per device: one process may drive several
+            const int dev_p = c->p.device & 63;
+            if (!attr_set_p[dev_p] && lds_p > 64 * 1024) {
                 CG_HIP(hipFuncSetAttribute((const void *)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
-                attr_set_p = true;
+                attr_set_p[dev_p] = true;
             }
             // workgroups per CU the LDS footprint allows
             int per_cu = (int)((160 * 1024) / lds_p);
@@ -1016,11 +1017,12 @@ static int run_strided_r(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
         }
     }
     auto kern = k_fft_strided<LOGN, NT, MODE, W, R16>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
+    static bool attr_set[64] = {};
+    const int dev = c->p.device & 63;
+    if (!attr_set[dev] && lds > 64 * 1024) {
         CG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(nouter * nkb)), dim3(NT), lds, c->stream, src, dst,
                        smap, dmap, nkb, o_off, (const double2 *)c->fft_tw, P);
@@ -1054,11 +1056,12 @@ static int run_strided_h(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
                            (MODE == 2 ? sizeof(double) * N : 0) + sizeof(double2) * (NT / W);
     static_assert(lds <= 160 * 1024, "split pass: LDS");
     auto kern = k_fft_strided_h<LOGN, NT, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    const int dev = c->p.device & 63;
+    if (!attr_set[dev]) {
         CG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     // workgroups per CU the LDS footprint allows (2048: one; 1024: two, each the other's cover)
     const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);

@@ -277,7 +277,7 @@ struct GatherLds {
 // 2: kick, drift and scatter into the next tile order in one pass (nothing written in place).
 template <int ORDER, int T, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
-    (ORDER == 2 ? CG_GK_WAVES : 4), 8))) void k_gather_kick_tiled(
+    (ORDER == 2 ? (MODE == 0 && T == 16 ? 6 : CG_GK_WAVES) : 4), 8))) void k_gather_kick_tiled(
     const double *__restrict__ pos, double *__restrict__ mom,
     const unsigned *__restrict__ tile_offset, const double *__restrict__ mesh, i64 N, i64 ny,
     i64 pad, int g, int nt, unsigned ntiles, XMap xm, CicGeom geo, double c1, double c2,
@@ -291,7 +291,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
     const unsigned tile = tile_for_block(blockIdx.x, ntiles);
     // the tile's particles: dense tile order -> one range; regions with gaps (prep.count_in)
     // -> its 8 buckets' (start, population), walked as one flat index
-    __shared__ unsigned seg_beg[8], seg_pre[9];
+    // (FUSED only: the plain kernel's LDS block is sized so that three workgroups fit a CU
+    // to the byte — nothing may be added to it)
+    __shared__ unsigned seg_beg[MODE == 2 ? 8 : 1], seg_pre[MODE == 2 ? 9 : 1];
     const bool gapped = FUSED && prep.count_in != nullptr;
     i64 beg = tile_offset[8 * tile], end = tile_offset[8 * tile + 8];
     if (gapped) {

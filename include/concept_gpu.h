@@ -167,7 +167,9 @@ int cg_gather_kick_tiled_prepare(cg_ctx *ctx, const double *pos /*DEV 3n*/,
  *   cg_deposit_cic_regions   cg_deposit_cic_tiled for particles stored in such regions
  *   cg_gather_kick_drift_scatter   mom_out = mom_in + kick (A9/A10), pos_out = drift(pos_in,
  *                        mom_out) (A11), both stored in the regions start_out; count_out is
- *                        zeroed here and ends as the new populations.  Single domain. */
+ *                        zeroed here and ends as the new populations.  A particle found
+ *                        outside the tile it is stored under is not kicked and sets
+ *                        CG_ERR_NOT_IN_TILE.  On x-slab domains see below. */
 #define CG_ERR_BUCKET_OVERFLOW 2u
 #define CG_ERR_NOT_IN_TILE 4u /* cg_gather_kick_drift_scatter met a particle outside the tile it
                                  is stored under (positions changed since the order was made):
