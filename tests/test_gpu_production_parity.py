@@ -35,7 +35,8 @@ def _mesh_view(torch, mesh):
 
 
 def test_fft_1024_vs_rocfft(monkeypatch):
-    """(i) the 1024-point instantiation (k_fft_strided_p<10,512,*,8>, radix 16*16*4, z/y passes
+    """(i) the 1024-point instantiation the bench times (k_fft_z_*<10,128>, the even/odd split
+    passes k_fft_strided_h<10,256,*> with two 512-point tiles per 8 pencils, z/y passes
     interleaved over 31-layer chunks) against rocFFT's 3-D plan, forward and fused solve."""
     import torch
     from concept_amd.mesh import PotentialMesh
@@ -95,6 +96,24 @@ def test_fft_1024_vs_rocfft(monkeypatch):
         del a, b
     own.close()
     roc.close()
+
+
+def test_fft_1024_vs_rocfft_whole_pencil_kernels():
+    """The same with CONCEPT_GPU_FFT_SPLIT=0: the whole-pencil passes
+    (k_fft_strided_p<10,512,*,8>, radix 16*16*4) that the split passes replaced as the default
+    stay a supported configuration (the switch is read once per process: a fresh one)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "from _pytest.monkeypatch import MonkeyPatch\n"
+            "import test_gpu_production_parity as t\n"
+            "t.test_fft_1024_vs_rocfft(MonkeyPatch())\n"
+            "print('WHOLE-PENCIL-OK')\n") % (here, os.path.dirname(here))
+    p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, CONCEPT_GPU_FFT_SPLIT='0'),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0 and b'WHOLE-PENCIL-OK' in p.stdout, p.stdout.decode()[-3000:]
 
 
 def _oracle_pm_step(oracle, pos, mom, *, mass, L, N, G, dt, order, shortrange_scale=None):
