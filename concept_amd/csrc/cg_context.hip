@@ -252,6 +252,11 @@ extern "C" int cg_destroy(cg_ctx *c) {
     (void)hipFree(c->err_flags);
     (void)hipFree(c->scan_tmp);
     (void)hipFree(c->sr_tmp);
+    for (int i = 0; i < 3; i++) {
+        if (c->sr_streams[i]) (void)hipStreamDestroy(c->sr_streams[i]);
+        if (c->sr_join[i]) (void)hipEventDestroy(c->sr_join[i]);
+    }
+    if (c->sr_fork) (void)hipEventDestroy(c->sr_fork);
     delete c;
     return 0;
 }

@@ -119,6 +119,11 @@ struct cg_ctx {
     // hand-written FFT (cg_fft.hip): twiddles exp(-2 pi i k/N) as double2[N]
     bool custom_fft = false;
     double *fft_tw = nullptr;
+    // side streams of the short-range sweep (its interior and face launches are independent and
+    // run side by side: a clustered box otherwise waits for the few dense tiles of each launch
+    // in turn), created at the first sweep
+    hipStream_t sr_streams[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t sr_fork = nullptr, sr_join[3] = {nullptr, nullptr, nullptr};
     hipEvent_t *pass_events = nullptr;  // when set: 6 events recorded around the 5 passes
     // particle sort scratch (owned, grown on demand)
     TileGeom tiles{};

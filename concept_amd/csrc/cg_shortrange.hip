@@ -473,6 +473,7 @@ int cgk_shortrange_sweep(cg_ctx *c, const double *pos_r, const unsigned *order_r
 constexpr int kSrCap = 624;   // suppliers staged per round: the default tiling stages ~594 per
                               // tile, more take further rounds; with the slack 18.4 KB of LDS
                               // -> 8 workgroups (32 wavefronts) per CU
+constexpr int kSrFaceStride = kSrCap + 128;  // (box-face tiles: offsets behind the positions)
 constexpr int kSrSlack = 128; // masked lanes read up to 2*S - 1 < 128 entries past a range
 constexpr int kSrPieces = 72; // 6 x 6 columns x 2 (a column that wraps around the box in z)
 
@@ -577,6 +578,7 @@ __device__ __forceinline__ void sr_cell_batch(int k, int S, int b, double xi, do
                                               double r2_index_scaling,
                                               const double *__restrict__ table, double &ax,
                                               double &ay, double &az) {
+    (void)ox, (void)oy, (void)oz;
     // NB pairs of this lane: their table loads (hits only) are all issued before the first use
     double xj[NB], yj[NB], zj[NB], r2[NB], t[NB];
     bool hit[NB];
@@ -586,10 +588,10 @@ __device__ __forceinline__ void sr_cell_batch(int k, int S, int b, double xi, do
         xj[j] = xi - sx[kj];                             // interactions.py:1787-1789
         yj[j] = yi - sy[kj];
         zj[j] = zi - sz[kj];
-        if (SHIFT) {                                     // gravity.py:299-302
-            xj[j] += ox;
-            yj[j] += oy;
-            zj[j] += oz;
+        if (SHIFT) {                                     // gravity.py:299-302: the periodic
+            xj[j] += sx[kSrFaceStride + kj];             // image's offset, staged per supplier
+            yj[j] += sy[kSrFaceStride + kj];             // behind the positions (0 for most)
+            zj[j] += sz[kSrFaceStride + kj];
         }
         r2[j] = xj[j] * xj[j] + yj[j] * yj[j] + zj[j] * zj[j];  // gravity.py:306
         hit[j] = r2[j] <= r2_max;                        // gravity.py:311: skip r2 > r2_max
@@ -689,21 +691,42 @@ __device__ __forceinline__ SrChunk sr_chunk_load(unsigned base, unsigned rend, i
     return c;
 }
 
+// FACE: the tiles on a face of the box, whose suppliers include periodic images.  Same sweep;
+// every staged supplier carries the offset of its image ((xi - xj) + offset in the reference's
+// order, gravity.py:299-302; + 0.0 for the others changes nothing), so a receiver's five
+// columns stay ONE range there too.  (Walking such tiles piece by piece — 10 short ranges per x
+// with a wave-uniform offset each — made these 6 % of the tiles 16 % of the sweep.)
+template <bool FACE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CG_SR_WAVES, 8))) void
 k_sr_sweep_cells(
     const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
     const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
     const double *__restrict__ pos_s, const unsigned *__restrict__ off_s,
-    const double *__restrict__ table, SrParams P, unsigned ntiles) {
-    __shared__ double sx[kSrCap + kSrSlack], sy[kSrCap + kSrSlack], sz[kSrCap + kSrSlack];
-    __shared__ unsigned p_beg[kSrPieces], p_cnt[kSrPieces], p_off[kSrPieces + 1];
+    const double *__restrict__ table, SrParams P, int slab) {
+    constexpr int kLen = (FACE ? 2 : 1) * (kSrCap + kSrSlack);
+    static_assert(kSrFaceStride == kSrCap + kSrSlack, "offsets follow the positions");
+    __shared__ double sx[kLen], sy[kLen], sz[kLen];
+    __shared__ unsigned p_beg[kSrPieces], p_cnt[kSrPieces], p_off[kSrPieces];
     __shared__ signed char p_shift[kSrPieces][4];  // periodic image: -1, 0, +1 box lengths
     __shared__ unsigned wave_any[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = P.nt, nc = 2 * nt;
     // one workgroup per tile: a 3-D grid (no index division; tiles adjacent along z, whose
     // supplier columns overlap most, are dispatched together)
-    const int ta = blockIdx.z, tb = blockIdx.y, tc = blockIdx.x;
+    // Launches (nt >= 4): the interior tiles as one (nt-2)^3 grid; the face tiles as three
+    // slabs — slab 0: ta on a face, 1: tb on a face (ta inside), 2: tc on a face (ta, tb inside).
+    int ta = blockIdx.z, tb = blockIdx.y, tc = blockIdx.x;
+    if (!FACE) {
+        ta++, tb++, tc++;
+    } else if (slab == 0) {
+        ta = ta ? nt - 1 : 0;
+    } else if (slab == 1) {
+        tb = tb ? nt - 1 : 0;
+        ta++;
+    } else {
+        tc = tc ? nt - 1 : 0;
+        ta++, tb++;
+    }
     // receivers of this wave: cell column (2 ta + wx, 2 tb + wy), cells 2 tc and 2 tc + 1
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wx = wave_u >> 1, wy = wave_u & 1;
@@ -758,23 +781,20 @@ k_sr_sweep_cells(
     }
     __syncthreads();
     if (wave_any[0] + wave_any[1] + wave_any[2] + wave_any[3] == 0) return;  // empty tile
-    // Exclusive prefix of the 72 piece sizes — by every wave for itself (identical values into
-    // p_off: a wave reads what it wrote itself, no barrier).  Lane l keeps the bounds of pieces
-    // l (half 0) and 36 + l (half 1) in registers: range bounds below are v_readlane's.
+    // Staged order: column by column (cx, cy), inside a column its cells in ascending relative z
+    // — where a column wraps around the box in z, its first piece (half 0) then its second.
+    // Exclusive prefix of the 36 column sizes by every wave for itself (identical values into
+    // p_off: a wave reads what it wrote itself, no barrier).  Lane l keeps the bounds of column
+    // l in registers: the range bounds below are v_readlane's.
     const unsigned c0 = lane < 36 ? p_cnt[lane] : 0u, c1 = lane < 36 ? p_cnt[36 + lane] : 0u;
-    const unsigned i0 = sr_wave_scan(c0);                  // inclusive, half 0
-    const unsigned total0 = __builtin_amdgcn_readlane(i0, 63);
-    const unsigned i1 = sr_wave_scan(c1) + total0;         // inclusive, half 1
+    const unsigned i0 = sr_wave_scan(c0 + c1);             // inclusive, whole columns
+    const unsigned e0 = i0 - (c0 + c1);                    // exclusive
     if (lane < 36) {
-        p_off[lane + 1] = i0;
-        p_off[36 + lane + 1] = i1;
+        p_off[lane] = e0;
+        p_off[36 + lane] = e0 + c0;
     }
-    if (lane == 0) p_off[0] = 0;
-    const unsigned e0 = i0 - c0, e1 = i1 - c1;             // exclusive
-    const unsigned total = __builtin_amdgcn_readlane(i1, 63);
-    const int npieces = total == total0 ? 36 : kSrPieces;  // (half 1 is empty off the z faces)
-    // tiles on a box face see periodic images: they sweep piece by piece with the piece's offset
-    const bool face = ta == 0 || tb == 0 || tc == 0 || ta == nt - 1 || tb == nt - 1 || tc == nt - 1;
+    const unsigned total = __builtin_amdgcn_readlane(i0, 63);
+    const int npieces = FACE ? kSrPieces : 36;  // (half 1 is empty off the z faces)
     const bool simple = rend - rbeg <= 64 && total <= (unsigned)kSrCap;  // one chunk, one window
     for (unsigned w0 = 0; w0 < total; w0 += kSrCap) {
         const unsigned w1 = min(total, w0 + (unsigned)kSrCap);
@@ -786,7 +806,7 @@ k_sr_sweep_cells(
         // ~16 suppliers; a longer one takes more turns) — no search for the piece of an entry
         for (int p0 = wave_u * 4; p0 < npieces; p0 += 16) {
             const int p = p0 + (lane >> 4);
-            const unsigned beg = p_beg[p], o0 = p_off[p], o1 = p_off[p + 1];
+            const unsigned beg = p_beg[p], o0 = p_off[p], o1 = o0 + p_cnt[p];
             const unsigned lo = max(o0, w0), hi = min(o1, w1);  // the part inside this window
             for (unsigned tn = 0; __any(lo + 16u * tn < hi); tn++) {
                 const unsigned q = lo + (lane & 15) + 16u * tn;
@@ -795,6 +815,11 @@ k_sr_sweep_cells(
                     sx[q - w0] = pos_s[3 * g];
                     sy[q - w0] = pos_s[3 * g + 1];
                     sz[q - w0] = pos_s[3 * g + 2];
+                    if (FACE) {
+                        sx[kSrFaceStride + q - w0] = (double)p_shift[p][0] * P.boxsize;
+                        sy[kSrFaceStride + q - w0] = (double)p_shift[p][1] * P.boxsize;
+                        sz[kSrFaceStride + q - w0] = (double)p_shift[p][2] * P.boxsize;
+                    }
                 }
             }
         }
@@ -802,6 +827,11 @@ k_sr_sweep_cells(
             sx[w1 - w0 + tid] = 0;
             sy[w1 - w0 + tid] = 0;
             sz[w1 - w0 + tid] = 0;
+            if (FACE) {
+                sx[kSrFaceStride + w1 - w0 + tid] = 0;
+                sy[kSrFaceStride + w1 - w0 + tid] = 0;
+                sz[kSrFaceStride + w1 - w0 + tid] = 0;
+            }
         }
         __syncthreads();
         for (unsigned base = rbeg; base < rend; base += 64) {
@@ -817,31 +847,12 @@ k_sr_sweep_cells(
                 // lane tests pairs against (0, 0, 0) and its sums are never read)
                 for (int xg = 0; xg < 5; xg++) {
                     const int col = (wx + xg) * 6 + wy;  // first of the 5 columns of this x
-                    if (!face) {  // no periodic image: the 5 columns are one staged range
-                        const int a = max(__builtin_amdgcn_readlane((int)e0, col), sw0) - sw0;
-                        const int b = min(__builtin_amdgcn_readlane((int)i0, col + 4), sw1) - sw0;
-                        if (b > a)
-                            sr_cell_pairs<false>(a, b, sub, S, xi, yi, zi, 0, 0, 0, sx, sy, sz,
-                                                 P.r2_max, P.r2_index_scaling, table, ax, ay, az);
-                        continue;
-                    }
-                    for (int q = 0; q < 10; q++) {  // piece by piece with its offset
-                        const int cq = col + (q % 5), half = q / 5, p = 36 * half + cq;
-                        const int a =
-                            max(__builtin_amdgcn_readlane((int)(half ? e1 : e0), cq), sw0) - sw0;
-                        const int b =
-                            min(__builtin_amdgcn_readlane((int)(half ? i1 : i0), cq), sw1) - sw0;
-                        if (b <= a) continue;
-                        const double ox = (double)p_shift[p][0] * P.boxsize,
-                                     oy = (double)p_shift[p][1] * P.boxsize,
-                                     oz = (double)p_shift[p][2] * P.boxsize;
-                        if ((ox != 0) | (oy != 0) | (oz != 0))
-                            sr_cell_pairs<true>(a, b, sub, S, xi, yi, zi, ox, oy, oz, sx, sy, sz,
-                                                P.r2_max, P.r2_index_scaling, table, ax, ay, az);
-                        else
-                            sr_cell_pairs<false>(a, b, sub, S, xi, yi, zi, 0, 0, 0, sx, sy, sz,
-                                                 P.r2_max, P.r2_index_scaling, table, ax, ay, az);
-                    }
+                    // the 5 columns of this x are one staged range
+                    const int a = max(__builtin_amdgcn_readlane((int)e0, col), sw0) - sw0;
+                    const int b = min(__builtin_amdgcn_readlane((int)i0, col + 4), sw1) - sw0;
+                    if (b > a)
+                        sr_cell_pairs<FACE>(a, b, sub, S, xi, yi, zi, 0, 0, 0, sx, sy, sz,
+                                            P.r2_max, P.r2_index_scaling, table, ax, ay, az);
                 }
             }
             // fold the S partial sums of each receiver (lanes rl, rl + R, ...) into lane rl: a
@@ -883,9 +894,30 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
     SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt, 0,
                factors,      rung,             rung_jumped, lowest_active};
     const unsigned ntiles = (unsigned)(nt * nt * nt);
-    hipLaunchKernelGGL(k_sr_sweep_cells, dim3((unsigned)nt, (unsigned)nt, (unsigned)nt), dim3(256),
-                       0, c->stream, pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s,
-                       table, P, ntiles);
+    const unsigned n = (unsigned)nt, m = (unsigned)(nt - 2);  // (nt >= 4: checked by the caller)
+    (void)ntiles;
+    // The four launches touch different receivers: the face slabs go to side streams (forked
+    // from and joined back into the context's stream) and run beside the interior grid.
+    if (!c->sr_fork) {
+        CG_HIP(hipEventCreateWithFlags(&c->sr_fork, hipEventDisableTiming));
+        for (int i = 0; i < 3; i++) {
+            CG_HIP(hipStreamCreateWithFlags(&c->sr_streams[i], hipStreamNonBlocking));
+            CG_HIP(hipEventCreateWithFlags(&c->sr_join[i], hipEventDisableTiming));
+        }
+    }
+    CG_HIP(hipEventRecord(c->sr_fork, c->stream));
+    const dim3 slabs[3] = {dim3(n, n, 2), dim3(n, 2, m), dim3(2, m, m)};
+    for (int slab = 0; slab < 3; slab++) {
+        CG_HIP(hipStreamWaitEvent(c->sr_streams[slab], c->sr_fork, 0));
+        hipLaunchKernelGGL(k_sr_sweep_cells<true>, slabs[slab], dim3(256), 0, c->sr_streams[slab],
+                           pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P,
+                           slab);
+        CG_LAUNCH_CHECK();
+        CG_HIP(hipEventRecord(c->sr_join[slab], c->sr_streams[slab]));
+    }
+    hipLaunchKernelGGL(k_sr_sweep_cells<false>, dim3(m, m, m), dim3(256), 0, c->stream,
+                       pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P, 0);
     CG_LAUNCH_CHECK();
+    for (int slab = 0; slab < 3; slab++) CG_HIP(hipStreamWaitEvent(c->stream, c->sr_join[slab], 0));
     return 0;
 }
