@@ -689,10 +689,12 @@ extern "C" int cg_region_insert(cg_ctx *c, const double *rows, int64_t m, const 
 extern "C" int cg_sort_particles(cg_ctx *c, const double *pos_in, const double *mom_in,
                                  const int64_t *ids_in, double *pos_out, double *mom_out,
                                  int64_t *ids_out, int64_t n, uint32_t *tile_offset_out) {
-    CG_CHECK(c && pos_in && mom_in && pos_out && mom_out && tile_offset_out,
+    // (an empty set — a domain without particles — may come with null arrays)
+    CG_CHECK(c && tile_offset_out && (n == 0 || (pos_in && mom_in && pos_out && mom_out)),
              "cg_sort_particles: null argument");
-    CG_CHECK(pos_in != pos_out && mom_in != mom_out, "cg_sort_particles: in/out must not alias");
-    CG_CHECK((ids_in == nullptr) == (ids_out == nullptr),
+    CG_CHECK(n == 0 || (pos_in != pos_out && mom_in != mom_out),
+             "cg_sort_particles: in/out must not alias");
+    CG_CHECK(n == 0 || (ids_in == nullptr) == (ids_out == nullptr),
              "cg_sort_particles: ids_in and ids_out must both be given or both be null");
     CG_CHECK(n >= 0 && n < (1ll << 32), "cg_sort_particles: n out of range");
     return cgk_sort(c, pos_in, mom_in, ids_in, pos_out, mom_out, ids_out, n, tile_offset_out, 0,
@@ -703,10 +705,11 @@ extern "C" int cg_drift_sort(cg_ctx *c, const double *pos_in, const double *mom_
                              const int64_t *ids_in, double *pos_out, double *mom_out,
                              int64_t *ids_out, int64_t n, double dt_over_mass,
                              uint32_t *tile_offset_out) {
-    CG_CHECK(c && pos_in && mom_in && pos_out && mom_out && tile_offset_out,
+    CG_CHECK(c && tile_offset_out && (n == 0 || (pos_in && mom_in && pos_out && mom_out)),
              "cg_drift_sort: null argument");
-    CG_CHECK(pos_in != pos_out && mom_in != mom_out, "cg_drift_sort: in/out must not alias");
-    CG_CHECK((ids_in == nullptr) == (ids_out == nullptr),
+    CG_CHECK(n == 0 || (pos_in != pos_out && mom_in != mom_out),
+             "cg_drift_sort: in/out must not alias");
+    CG_CHECK(n == 0 || (ids_in == nullptr) == (ids_out == nullptr),
              "cg_drift_sort: ids_in and ids_out must both be given or both be null");
     CG_CHECK(n >= 0 && n < (1ll << 32), "cg_drift_sort: n out of range");
     // x-slab domains: particles whose drifted position leaves the slab are dropped (the host
@@ -728,7 +731,7 @@ extern "C" int cg_owner_rank_drifted(cg_ctx *c, const double *pos, const double 
 
 extern "C" int cg_prepare_rebind(cg_ctx *c, const double *pos, const double *mom, int64_t n_total,
                                  const double *add_pos, const double *add_mom, int64_t n_add) {
-    CG_CHECK(c && pos && mom && (n_add == 0 || (add_pos && add_mom)),
+    CG_CHECK(c && (n_total == 0 || (pos && mom)) && (n_add == 0 || (add_pos && add_mom)),
              "cg_prepare_rebind: null argument");
     CG_CHECK(n_total >= 0 && n_add >= 0 && n_total < (1ll << 32), "cg_prepare_rebind: sizes");
     return cgk_prepare_rebind(c, pos, mom, n_total, add_pos, add_mom, n_add);
@@ -736,7 +739,8 @@ extern "C" int cg_prepare_rebind(cg_ctx *c, const double *pos, const double *mom
 
 extern "C" int cg_cic_indices(cg_ctx *c, const double *pos, int64_t n, int for_gather,
                               int64_t *idx_out) {
-    CG_CHECK(c && pos && idx_out, "cg_cic_indices: null argument");
+    CG_CHECK(c && (n == 0 || (pos && idx_out)), "cg_cic_indices: null argument");
+    if (n == 0) return 0;
     return cgk_cic_indices(c, pos, n, for_gather, idx_out);
 }
 
@@ -756,8 +760,8 @@ extern "C" int cg_shortrange_sweep(cg_ctx *c, const double *pos_r, const uint32_
                                    const uint32_t *order_s, const uint32_t *offset_s, int64_t nt,
                                    int same_component, const double *table, int64_t tablesize,
                                    double r2_index_scaling, double r2_max, double factor) {
-    CG_CHECK(c && pos_r && order_r && offset_r && dmom_r && pos_s && order_s && offset_s && table,
-             "cg_shortrange_sweep: null argument");
+    // (particle arrays of an empty set may be null: only what the offsets span is touched)
+    CG_CHECK(c && offset_r && offset_s && table, "cg_shortrange_sweep: null argument");
     CG_CHECK(nt >= 4 && nt <= 1024, "cg_shortrange_sweep: nt = %lld", (long long)nt);
     // the largest index the sweep can form is int(r2_max*scaling): must be inside the table
     CG_CHECK((int64_t)(r2_max * r2_index_scaling) < tablesize,
@@ -776,8 +780,8 @@ extern "C" int cg_shortrange_sweep_rungs(cg_ctx *c, const double *pos_r, const u
                                          double r2_index_scaling, double r2_max,
                                          const double *factors, const int8_t *rung_r,
                                          const int8_t *rung_jumped_r, int lowest_active_rung) {
-    CG_CHECK(c && pos_r && order_r && offset_r && dmom_r && pos_s && order_s && offset_s && table &&
-                 factors && rung_r && rung_jumped_r, "cg_shortrange_sweep_rungs: null argument");
+    CG_CHECK(c && offset_r && offset_s && table && factors,
+             "cg_shortrange_sweep_rungs: null argument");
     CG_CHECK(nt >= 4 && nt <= 1024, "cg_shortrange_sweep_rungs: nt = %lld", (long long)nt);
     CG_CHECK((int64_t)(r2_max * r2_index_scaling) < tablesize,
              "cg_shortrange_sweep_rungs: table too short");
@@ -804,7 +808,10 @@ static int sweep_cells_checks(cg_ctx *c, const void *a, const void *b, const voi
                               const void *e, const void *f, const void *g, const void *t,
                               int64_t nt, int64_t tablesize, double r2_index_scaling,
                               double r2_max) {
-    CG_CHECK(c && a && b && d && e && f && g && t, "cg_shortrange_sweep_cells: null argument");
+    // a = pos_r, b = order_r, d = offset_r, e = dmom_r, f = pos_s, g = offset_s, t = table;
+    // the particle arrays of an empty set may be null (only what the offsets span is touched)
+    (void)a, (void)b, (void)e, (void)f;
+    CG_CHECK(c && d && g && t, "cg_shortrange_sweep_cells: null argument");
     CG_CHECK(nt >= 4 && nt <= 512, "cg_shortrange_sweep_cells: nt = %lld", (long long)nt);
     // the largest index the sweep can form is int(r2_max*scaling): must be inside the table
     CG_CHECK((int64_t)(r2_max * r2_index_scaling) < tablesize,
@@ -839,7 +846,8 @@ extern "C" int cg_shortrange_sweep_cells_rungs(
     if (sweep_cells_checks(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted, offset_s,
                            table, nt, tablesize, r2_index_scaling, r2_max))
         return 1;
-    CG_CHECK(factors && rung_r && rung_jumped_r, "cg_shortrange_sweep_cells_rungs: null argument");
+    // (rung arrays of an empty receiver set may be null)
+    CG_CHECK(factors, "cg_shortrange_sweep_cells_rungs: null argument");
     return cgk_shortrange_sweep_cells(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted,
                                       offset_s, nt, table, r2_index_scaling, r2_max, 0.0, factors,
                                       (const signed char *)rung_r,

@@ -31,6 +31,10 @@ extern "C" {
 #endif
 
 #define CG_ABI_VERSION 2  /* 2: region tables, fused kick+drift+scatter, Fourier views, error flags */
+/* Empty sets: wherever an entry point takes a particle count n (or, for the short-range sweeps,
+ * cell offsets), the particle arrays may be NULL when the count is zero — an x-slab domain of a
+ * clustered or partly empty box owns no particles for a while, and the reference's loops simply
+ * run zero times there (communication.py:135-517 exchanges into and out of such domains). */
 
 typedef struct cg_ctx cg_ctx;
 

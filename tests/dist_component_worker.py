@@ -55,6 +55,10 @@ def main():
     elif case == 'diff_orders':
         import test_gpu_pm
         test_gpu_pm.test_other_differentiation_orders_vs_golden(torch, golden, arg)
+    elif case == 'void':
+        import test_gpu_pm
+        test_gpu_pm.test_void_domains_vs_oracle(torch)
+        test_gpu_pm.test_void_domains_p3m(torch)
     elif case == 'pm_api':
         import test_gpu_pm
         test_gpu_pm.test_gravity_api_pm(None, golden)

@@ -905,3 +905,87 @@ def test_streaming_timeloop_region_overflow_is_replayed(torch_cuda):
     assert np.minimum(dd, L - dd).max() <= 1e-13*L
     assert np.abs(m0 - m1).max() <= 1e-12*np.abs(m0).max()
     assert np.array_equal(i0, i1)
+
+
+def test_void_domains_vs_oracle(torch_cuda):
+    """All particles in one eighth of the box along x, streaming towards +x: on several x-slab
+    domains most ranks start EMPTY and some receive their first particles by exchange()
+    (communication.py:135-517).  stepper.timeloop — step by step and in its streaming form —
+    against the CPU oracle's K½ D K D K (decomposition-independent).  Also run on 2 and 4
+    domains by tests/test_gpu_distributed.py."""
+    from concept_amd import commons, stepper
+    from concept_amd.species import Component
+    from oracle import oracle
+    rng = np.random.default_rng(17)
+    L, gs, n, mass, d = 32.0, 32, 4000, 1.5, 0.25
+    commons.load_params({'boxsize': L, 'potential_options': {'gridsize': {'gravity': {'pm': gs}}},
+                         'select_forces': {'all': {'gravity': 'pm'}}})
+    p = commons.params
+    pos0 = rng.uniform(0, L, (n, 3))
+    pos0[:, 0] *= 1/8
+    mom0 = rng.normal(0, 0.3, (n, 3))
+    mom0[:, 0] += 2.5*mass/d  # ~2.5 cells per step towards +x
+
+    def integrals(kind):
+        s = d/2 if kind == 'init' else d
+        return {'1': s, 'a**(-2)': d, ('a**(-3*w_eff)', 'm'): s, ('a**(-3*w_eff-1)', 'm'): s}
+    # oracle: K(d/2) D K D K
+    pos, mom = pos0.copy(), mom0.copy()
+    for step in range(3):
+        s = d/2 if step == 0 else d
+        oracle.pm_long_range(pos, mom, mass=mass, boxsize=L, gridsize=gs, G_Newton=p.G_Newton,
+                             dt_1=s, dt_dens=s, dt_kick=s, diff_order=2, want_indices=False)
+        if step < 2:
+            oracle.drift(pos, mom, d/mass, L)
+    kick = rms(mom - mom0)
+    for stream in (False, True):
+        c = Component('m', 'matter', N=n, mass=mass)
+        c.populate(pos0, 'pos')
+        c.populate(mom0, 'mom')
+        stepper.timeloop([c], 2, integrals, None, None if stream else (lambda step: None))
+        dx = np.abs(c.host('pos') - pos)
+        assert np.minimum(dx, L - dx).max() <= 1e-12*L, stream
+        assert np.abs(c.host('mom') - mom).max() <= 1e-11*kick + 4e-16*np.abs(mom).max(), stream
+
+
+def test_void_domains_p3m(torch_cuda):
+    """The same void box with P3M (long-range mesh + short-range sweep, two steps): on several
+    domains — most of them empty, boundary suppliers shipped into and out of empty slabs —
+    against the single-domain run of the same calls.  (Single domain: the run against itself;
+    the multi-rank form is what tests/test_gpu_distributed.py adds.)"""
+    from concept_amd import comm, commons, stepper
+    from concept_amd.species import Component
+    rng = np.random.default_rng(23)
+    L, gs, n, mass, d = 64.0, 64, 6000, 1.5, 0.25
+    pos0 = rng.uniform(0, L, (n, 3))
+    pos0[:, 0] *= 1/8
+    mom0 = rng.normal(0, 0.3, (n, 3))
+    mom0[:, 0] += 3.0*mass/d
+
+    def integrals(kind):
+        s = d/2 if kind == 'init' else d
+        return {'1': s, 'a**(-2)': d, ('a**(-3*w_eff)', 'm'): s, ('a**(-3*w_eff-1)', 'm'): s}
+
+    def rung_integrals(kind):
+        s = d/2 if kind == 'init' else d
+        return {('a**(-3*w_eff₀-3*w_eff₁-1)', 'm', 'm'): np.full(2, s)}
+
+    def run():
+        commons.load_params({'boxsize': L, 'N_rungs': 1,
+                             'potential_options': {'gridsize': {'gravity': {'p3m': gs}}},
+                             'select_forces': {'all': {'gravity': 'p3m'}}})
+        c = Component('m', 'matter', N=n, mass=mass)
+        c.populate(pos0, 'pos')
+        c.populate(mom0, 'mom')
+        stepper.timeloop([c], 2, integrals, rung_integrals)
+        return c.host('pos'), c.host('mom')
+    active = comm.active()
+    if active is not None:
+        comm.shutdown()
+    pos_ref, mom_ref = run()
+    if active is not None:
+        comm.init()
+    pos, mom = run()
+    dx = np.abs(pos - pos_ref)
+    assert np.minimum(dx, L - dx).max() <= 1e-12*L
+    assert np.abs(mom - mom_ref).max() <= 1e-11*rms(mom_ref - mom0) + 4e-16*np.abs(mom_ref).max()
