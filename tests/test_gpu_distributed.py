@@ -203,6 +203,7 @@ COMPONENT_CASES = [
     ('orders', 'ngp_fluid_n8_g16'),
     ('tiled_general', '-'),
     ('diff_orders', 'pm_n8_g16_d6'), ('diff_orders', 'pm_n8_g16_d1'),
+    ('diff_orders', 'pm_edge_g16'),         # particles on cell / box / slab boundaries
     ('void', '-'),                          # ranks that start empty, first arrivals by exchange()
     ('k4', '16,2'), ('k4', '32,4'),
 ]

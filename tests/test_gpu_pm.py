@@ -989,3 +989,26 @@ def test_void_domains_p3m(torch_cuda):
     dx = np.abs(pos - pos_ref)
     assert np.minimum(dx, L - dx).max() <= 1e-12*L
     assert np.abs(mom - mom_ref).max() <= 1e-11*rms(mom_ref - mom0) + 4e-16*np.abs(mom_ref).max()
+
+
+def test_empty_particle_sets(torch_cuda):
+    """Zero particles through every particle entry point of the PM path (an x-slab domain of a
+    void owns none): nothing is touched, nothing fails, the mesh of an empty deposit is zero."""
+    torch = torch_cuda
+    from concept_amd.mesh import PotentialMesh
+    mesh = PotentialMesh(32, 10.0)
+    e3 = torch.empty((0, 3), dtype=torch.float64, device='cuda')
+    ids = torch.empty(0, dtype=torch.int64, device='cuda')
+    mesh.zero()
+    mesh.deposit(e3, 1.0)
+    table = mesh.sort_particles(e3, e3.clone(), ids, e3.clone(), e3.clone(), ids.clone())
+    assert int(table.long().abs().sum()) == 0
+    mesh.deposit_tiled(e3, table, 1.0, accumulate=False)
+    assert float(torch.tensor(mesh.fetch_real()).abs().max()) == 0.0
+    mesh.poisson_solve(4, -1.0, False, 0.0)
+    mesh.gather_kick(e3, e3.clone(), 2, 1.0)
+    mesh.gather_kick_tiled(e3, e3.clone(), table, 2, 1.0)
+    mesh.drift(e3, e3.clone(), 0.1)
+    mesh.drift_sort(e3, e3.clone(), None, e3.clone(), e3.clone(), None, 0.1, mesh.new_tile_table())
+    assert mesh.cic_indices(e3).shape == (0, 3)
+    mesh.check_errors()
