@@ -599,7 +599,8 @@ extern "C" int cg_gather_kick_drift_scatter(
     cg_ctx *c, const double *pos_in, const double *mom_in, const int64_t *ids_in,
     const uint32_t *start_in, const uint32_t *count_in, double *pos_out, double *mom_out,
     int64_t *ids_out, const uint32_t *start_out, uint32_t *count_out, int diff_order,
-    double factor, double dt_over_mass, const int64_t *aux_in, int64_t *aux_out) {
+    double factor, double dt_over_mass, const int64_t *aux_in, int64_t *aux_out,
+    int64_t out_capacity) {
     CG_CHECK(c && pos_in && mom_in && start_in && pos_out && mom_out && start_out && count_out,
              "cg_gather_kick_drift_scatter: null argument");
     CG_CHECK(pos_in != pos_out && mom_in != mom_out,
@@ -616,8 +617,9 @@ extern "C" int cg_gather_kick_drift_scatter(
     CG_CHECK(c->p.nprocs == 1 || c->emig_rows,
              "cg_gather_kick_drift_scatter: on x-slab domains the particles leaving the slab need "
              "a row buffer (cg_set_emigrant_rows)");
+    CG_CHECK(out_capacity > 0, "cg_gather_kick_drift_scatter: out_capacity must be positive");
     FusedScatter fs{count_in, start_out, count_out, pos_out, mom_out, ids_in, ids_out,
-                    aux_in, aux_out};
+                    aux_in, aux_out, out_capacity};
     c->prep_valid = false;
     return cgk_gather_kick_tiled(c, pos_in, const_cast<double *>(mom_in), 0, start_in, diff_order,
                                  factor, 0, dt_over_mass, &fs);
@@ -679,11 +681,12 @@ extern "C" int cg_emigrant_rows_dest(cg_ctx *c, const double *rows, const uint32
 
 extern "C" int cg_region_insert(cg_ctx *c, const double *rows, int64_t m, const uint32_t *start,
                                 uint32_t *count, double *pos_out, double *mom_out,
-                                int64_t *ids_out, int64_t *aux_out) {
+                                int64_t *ids_out, int64_t *aux_out, int64_t capacity) {
     CG_CHECK(c && start && count && pos_out && mom_out && (m == 0 || rows),
              "cg_region_insert: null argument");
     CG_CHECK(m >= 0, "cg_region_insert: negative row count");
-    return cgk_region_insert(c, rows, m, start, count, pos_out, mom_out, ids_out, aux_out);
+    return cgk_region_insert(c, rows, m, start, count, pos_out, mom_out, ids_out, aux_out,
+                             capacity);
 }
 
 extern "C" int cg_sort_particles(cg_ctx *c, const double *pos_in, const double *mom_in,

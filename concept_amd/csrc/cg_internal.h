@@ -244,6 +244,7 @@ struct FusedScatter {
     i64 *ids_out;
     const i64 *aux_in;
     i64 *aux_out;
+    i64 out_capacity;
 };
 int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
                           const unsigned *tile_offset, int diff_order, double factor,
@@ -254,4 +255,4 @@ int cgk_emigrant_rows_dest(cg_ctx *c, const double *rows, const unsigned *count,
                            int *dest, int *send_counts);
 int cgk_region_insert(cg_ctx *c, const double *rows, i64 m, const unsigned *start,
                       unsigned *count, double *pos_out, double *mom_out, i64 *ids_out,
-                      i64 *aux_out);
+                      i64 *aux_out, i64 capacity);

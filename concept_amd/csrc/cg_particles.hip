@@ -337,7 +337,8 @@ __global__ void k_region_insert(const double *__restrict__ rows, i64 m, CicGeom 
                                 TileGeom t, i64 x0, const unsigned *__restrict__ start,
                                 unsigned *__restrict__ count, double *__restrict__ pos_out,
                                 double *__restrict__ mom_out, i64 *__restrict__ ids_out,
-                                i64 *__restrict__ aux_out, unsigned *__restrict__ err_flags) {
+                                i64 *__restrict__ aux_out, i64 capacity,
+                                unsigned *__restrict__ err_flags) {
     i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m) return;
     const double *row = rows + 8 * r;
@@ -346,7 +347,8 @@ __global__ void k_region_insert(const double *__restrict__ rows, i64 m, CicGeom 
         atomicOr(err_flags, (unsigned)CG_ERR_BUCKET_OVERFLOW);
         return;
     }
-    const unsigned o0 = start[key], room = start[key + 1] - o0;
+    const unsigned o0 = start[key], o1 = start[key + 1],
+                   room = (i64)o1 <= capacity ? o1 - o0 : 0u;
     const unsigned local = atomicAdd(&count[key], 1u);
     if (local >= room) {
         atomicOr(err_flags, (unsigned)CG_ERR_BUCKET_OVERFLOW);
@@ -360,11 +362,11 @@ __global__ void k_region_insert(const double *__restrict__ rows, i64 m, CicGeom 
 }
 int cgk_region_insert(cg_ctx *c, const double *rows, i64 m, const unsigned *start,
                       unsigned *count, double *pos_out, double *mom_out, i64 *ids_out,
-                      i64 *aux_out) {
+                      i64 *aux_out, i64 capacity) {
     if (m == 0) return 0;
     hipLaunchKernelGGL(k_region_insert, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
                        rows, m, c->geom_deposit, c->p.nghosts, c->N, c->tiles, c->xmap.x0, start,
-                       count, pos_out, mom_out, ids_out, aux_out, c->err_flags);
+                       count, pos_out, mom_out, ids_out, aux_out, capacity, c->err_flags);
     CG_LAUNCH_CHECK();
     return 0;
 }

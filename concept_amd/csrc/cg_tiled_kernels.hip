@@ -230,6 +230,7 @@ struct PrepArgs {
     i64 *ids_out;
     const i64 *aux_in;  // a second 64-bit column travelling with the particles (or null)
     i64 *aux_out;
+    i64 out_capacity;   // rows of pos_out / mom_out (/ ids_out, aux_out)
     unsigned *err_flags;
     // input populations when the input itself is in regions with gaps (null: dense tile order)
     const unsigned *count_in;
@@ -518,8 +519,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
             wave_runs(next_key, lane, rs, rl);
             unsigned first = kNoTile;
             if (lane == rs && next_key != kNoTile) {
-                const unsigned o0 = prep.start_out[next_key],
-                               room = prep.start_out[next_key + 1] - o0;
+                // (a region that reaches beyond the output arrays has no room at all: the
+                // populations outgrew what the arrays were sized for)
+                const unsigned o0 = prep.start_out[next_key], o1 = prep.start_out[next_key + 1],
+                               room = (i64)o1 <= prep.out_capacity ? o1 - o0 : 0u;
 #ifdef CG_GK_NOATOMIC  // timing probe only: no reservation round trip (wrong places)
                 const unsigned local = room > (unsigned)rl ? 0u : 0u * room;
 #else
@@ -556,6 +559,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
                     row[0] = nx, row[1] = ny_, row[2] = nz, row[3] = n0, row[4] = n1, row[5] = n2;
                     row[6] = prep.ids_in ? __longlong_as_double(prep.ids_in[p]) : 0.0;
                     row[7] = prep.aux_in ? __longlong_as_double(prep.aux_in[p]) : 0.0;
+                } else {  // more leavers than the row buffer holds: the pass must be repeated
+                    atomicOr(prep.err_flags, (unsigned)CG_ERR_BUCKET_OVERFLOW);
                 }
             }
         }
@@ -611,6 +616,7 @@ int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
         prep_args.ids_out = fs->ids_out;
         prep_args.aux_in = fs->aux_in;
         prep_args.aux_out = fs->aux_out;
+        prep_args.out_capacity = fs->out_capacity;
         prep_args.err_flags = c->err_flags;
         prep_args.count_in = fs->count_in;
         prep_args.emig_rows = c->emig_rows;

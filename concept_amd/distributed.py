@@ -322,6 +322,27 @@ class ParticleStore:
         self.sorted = False
         self.touch_mom()
 
+    def _grow(self, n_needed):
+        """Room for n_needed rows: exchange() may bring in more particles than the arrays were
+        sized for (the reference resizes its arrays the same way, communication.py:431-470).
+        The live rows keep their places; buffers of the sort and the emigrant list follow."""
+        if n_needed <= self.cap:
+            return
+        cap = int(n_needed*1.3) + 1024
+        for name, c in list(self.cols.items()):
+            t = torch.empty((cap,) + tuple(c.shape[1:]), dtype=c.dtype, device=c.device)
+            t[:self.n] = c[:self.n]
+            self.cols[name] = t
+        self.spare.clear()
+        self.cap = cap
+        self._slots = None
+        if self.emig_idx.numel() < max(4096, cap//16):
+            self.emig_idx = torch.empty(max(4096, cap//16), dtype=torch.int64,
+                                        device=self.mesh.device)
+            self.emig_dest = torch.empty(self.emig_idx.numel(), dtype=torch.int32,
+                                         device=self.mesh.device)
+        self._emig_for = None  # (keyed on the old arrays)
+
     # -- bookkeeping ------------------------------------------------------------
     def check(self):
         """Raise if a kernel recorded an inconsistency since the last call (synchronises)."""
@@ -374,6 +395,7 @@ class ParticleStore:
         dest = owner[move_idx].long()
         send_counts = torch.bincount(dest, minlength=P).cpu().tolist()
         recv_counts = self.comm.all_gather_ints(send_counts)[:, rank].tolist()
+        self._grow(self.n - int(sum(send_counts)) + int(sum(recv_counts)))
         n_new, inc = exchange_columns(self.comm, self._columns(), self.n, self.cap, move_idx,
                                       dest, send_counts, recv_counts)
         self.emigrants_total += int(sum(send_counts))
@@ -416,9 +438,11 @@ class ParticleStore:
                 host = self.meta_host.tolist()
                 cnt = host[0] & 0xffffffff
                 if cnt <= self.emig_idx.numel():  # else the list overflowed: the long way
+                    idx, dst = self.emig_idx[:cnt], self.emig_dest[:cnt]
+                    self._grow(self.n - cnt + int(sum(host[1 + P:1 + 2*P])))
                     n_new, inc = exchange_columns(
-                        self.comm, self._columns(), self.n, self.cap, self.emig_idx[:cnt],
-                        self.emig_dest[:cnt], host[1:1 + P], host[1 + P:1 + 2*P])
+                        self.comm, self._columns(), self.n, self.cap, idx, dst,
+                        host[1:1 + P], host[1 + P:1 + 2*P])
                     self.emigrants_total += cnt
                     done = True
             self._emig_for = None
@@ -714,7 +738,7 @@ class RegionParticles:
             lib.check(lib.raw().cg_region_insert(
                 m._ctx, _vp(inc), m_in, _vp(self.start), _vp(self.count), _vp(self.pos[c]),
                 _vp(self.mom[c]), _vp(self.ids[c]) if self.has_ids else None,
-                _vp(self.aux[c]) if self.has_aux else None))
+                _vp(self.aux[c]) if self.has_aux else None, self.cap))
 
     def snapshot(self):
         """The present order (which buffer set, its region tables): kick_drift_sort writes the

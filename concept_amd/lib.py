@@ -58,12 +58,12 @@ SYMBOLS = {
     'cg_prepare_invalidate': (_int, [_vp]),
     'cg_set_emigrant_rows': (_int, [_vp, _vp, _vp, _i64]),
     'cg_emigrant_rows_dest': (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
-    'cg_region_insert': (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'cg_region_insert': (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     'cg_region_capacity': (_i64, [_vp, _i64]),
     'cg_predict_regions': (_int, [_vp, _vp, _vp, _vp]),
     'cg_deposit_cic_regions': (_int, [_vp, _vp, _vp, _vp, _dbl, _int]),
     'cg_gather_kick_drift_scatter': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                            _int, _dbl, _dbl, _vp, _vp]),
+                                            _int, _dbl, _dbl, _vp, _vp, _i64]),
     'cg_mesh_zero': (_int, [_vp]),
     'cg_deposit_cic': (_int, [_vp, _vp, _i64, _dbl]),
     'cg_deposit_cic_tiled': (_int, [_vp, _vp, _i64, _vp, _dbl, _int]),

@@ -554,7 +554,7 @@ class PotentialMesh:
             _ptr(start_in), _ptr(count_in) if count_in is not None else None, _ptr(pos_out),
             _ptr(mom_out), _ptr(ids_out) if ids_out is not None else None, _ptr(start_out),
             _ptr(count_out), int(diff_order), float(factor), float(dt_over_mass), opt(aux_in),
-            opt(aux_out)))
+            opt(aux_out), int(pos_out.shape[0])))
 
     def check_errors(self):
         flags = self.error_flags()

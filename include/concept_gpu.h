@@ -189,7 +189,9 @@ int cg_gather_kick_drift_scatter(cg_ctx *ctx, const double *pos_in, const double
                                  double *mom_out, int64_t *ids_out /*nullable*/,
                                  const uint32_t *start_out, uint32_t *count_out, int diff_order,
                                  double factor, double dt_over_mass,
-                                 const int64_t *aux_in /*nullable*/, int64_t *aux_out);
+                                 const int64_t *aux_in /*nullable*/, int64_t *aux_out,
+                                 int64_t out_capacity /* rows of the output arrays: a region
+                                 predicted beyond them counts as overflowed */);
 /* (ids and aux: two 64-bit columns that travel with the particles — a Component's `ids` and
  * the row numbers its host() uses to restore the populated order) */
 
@@ -198,7 +200,8 @@ int cg_gather_kick_drift_scatter(cg_ctx *ctx, const double *pos_in, const double
  * buffer (8 doubles: pos 3, mom 3, id bits, aux bits), exchange() (communication.py:135-517)
  * ships the rows, and the receiving domain gives each a place in its regions.  No holes to
  * close on the sending side: a leaver was never written there.
- *   cg_set_emigrant_rows   rows[8*cap], *count (DEV; zeroed by every fused launch); NULL = off
+ *   cg_set_emigrant_rows   rows[8*cap], *count (DEV; zeroed by every fused launch); NULL = off;
+ *                          more than cap leavers in one pass set CG_ERR_BUCKET_OVERFLOW
  *   cg_emigrant_rows_dest  owner domain of every row + rows bound for each domain (counts
  *                          zeroed here; *count read on the device)
  *   cg_region_insert       m received rows -> their (tile, bucket) regions (start / count of the
@@ -210,7 +213,7 @@ int cg_emigrant_rows_dest(cg_ctx *ctx, const double *rows /*DEV*/, const uint32_
 int cg_region_insert(cg_ctx *ctx, const double *rows /*DEV 8m*/, int64_t m,
                      const uint32_t *start /*DEV*/, uint32_t *count /*DEV*/, double *pos_out,
                      double *mom_out, int64_t *ids_out /*nullable*/,
-                     int64_t *aux_out /*nullable*/);
+                     int64_t *aux_out /*nullable*/, int64_t capacity /* rows of the arrays */);
 
 /* Drop the prepared histogram.  Every entry point of this context that writes momenta
  * (cg_gather_kick*, cg_gather_scalar, cg_dmom_apply, cg_drift) does so itself; a caller that

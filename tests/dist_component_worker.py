@@ -57,7 +57,11 @@ def main():
         test_gpu_pm.test_other_differentiation_orders_vs_golden(torch, golden, arg)
     elif case == 'void':
         import test_gpu_pm
-        test_gpu_pm.test_void_domains_vs_oracle(torch)
+        from concept_amd import stepper
+        test_gpu_pm.test_void_domains_vs_oracle(torch, False)
+        replays = stepper.stream_replays
+        test_gpu_pm.test_void_domains_vs_oracle(torch, True)
+        assert stepper.stream_replays > replays  # (the row buffer really overflowed)
         test_gpu_pm.test_void_domains_p3m(torch)
     elif case == 'pm_api':
         import test_gpu_pm

@@ -907,24 +907,27 @@ def test_streaming_timeloop_region_overflow_is_replayed(torch_cuda):
     assert np.array_equal(i0, i1)
 
 
-def test_void_domains_vs_oracle(torch_cuda):
+@pytest.mark.parametrize('bulk', [False, True])
+def test_void_domains_vs_oracle(torch_cuda, bulk):
     """All particles in one eighth of the box along x, streaming towards +x: on several x-slab
     domains most ranks start EMPTY and some receive their first particles by exchange()
     (communication.py:135-517).  stepper.timeloop — step by step and in its streaming form —
-    against the CPU oracle's K½ D K D K (decomposition-independent).  Also run on 2 and 4
-    domains by tests/test_gpu_distributed.py."""
+    against the CPU oracle's K½ D K D K (decomposition-independent).  bulk: 12000 particles
+    crossing 13 cells per step — whole slabs change hands at once, more leavers than the
+    streaming pass's row buffer holds (the step is then repeated on the exact path).  Also run
+    on 2 and 4 domains by tests/test_gpu_distributed.py."""
     from concept_amd import commons, stepper
     from concept_amd.species import Component
     from oracle import oracle
     rng = np.random.default_rng(17)
-    L, gs, n, mass, d = 32.0, 32, 4000, 1.5, 0.25
+    L, gs, n, mass, d = 32.0, 32, (12000 if bulk else 4000), 1.5, 0.25
     commons.load_params({'boxsize': L, 'potential_options': {'gridsize': {'gravity': {'pm': gs}}},
                          'select_forces': {'all': {'gravity': 'pm'}}})
     p = commons.params
     pos0 = rng.uniform(0, L, (n, 3))
     pos0[:, 0] *= 1/8
     mom0 = rng.normal(0, 0.3, (n, 3))
-    mom0[:, 0] += 2.5*mass/d  # ~2.5 cells per step towards +x
+    mom0[:, 0] += (13.0 if bulk else 2.5)*mass/d  # cells per step towards +x
 
     def integrals(kind):
         s = d/2 if kind == 'init' else d
