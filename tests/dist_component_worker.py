@@ -62,6 +62,7 @@ def main():
         replays = stepper.stream_replays
         test_gpu_pm.test_void_domains_vs_oracle(torch, True)
         assert stepper.stream_replays > replays  # (the row buffer really overflowed)
+        test_gpu_pm.test_void_domains_vs_oracle(torch, 'point')
         test_gpu_pm.test_void_domains_p3m(torch)
     elif case == 'pm_api':
         import test_gpu_pm

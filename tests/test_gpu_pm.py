@@ -907,20 +907,23 @@ def test_streaming_timeloop_region_overflow_is_replayed(torch_cuda):
     assert np.array_equal(i0, i1)
 
 
-@pytest.mark.parametrize('bulk', [False, True])
+@pytest.mark.parametrize('bulk', [False, True, 'point'])
 def test_void_domains_vs_oracle(torch_cuda, bulk):
     """All particles in one eighth of the box along x, streaming towards +x: on several x-slab
     domains most ranks start EMPTY and some receive their first particles by exchange()
     (communication.py:135-517).  stepper.timeloop — step by step and in its streaming form —
     against the CPU oracle's K½ D K D K (decomposition-independent).  bulk: 12000 particles
     crossing 13 cells per step — whole slabs change hands at once, more leavers than the
-    streaming pass's row buffer holds (the step is then repeated on the exact path).  Also run
-    on 2 and 4 domains by tests/test_gpu_distributed.py."""
+    streaming pass's row buffer holds (the step is then repeated on the exact path).  'point':
+    all 5000 particles inside ONE mesh cell, nearly at rest (one tile bucket holds everything).
+    Also run on 2 and 4 domains by tests/test_gpu_distributed.py."""
     from concept_amd import commons, stepper
     from concept_amd.species import Component
     from oracle import oracle
     rng = np.random.default_rng(17)
-    L, gs, n, mass, d = 32.0, 32, (12000 if bulk else 4000), 1.5, 0.25
+    point = bulk == 'point'
+    bulk = bulk is True
+    L, gs, n, mass, d = 32.0, 32, (12000 if bulk else 5000 if point else 4000), 1.5, 0.25
     commons.load_params({'boxsize': L, 'potential_options': {'gridsize': {'gravity': {'pm': gs}}},
                          'select_forces': {'all': {'gravity': 'pm'}}})
     p = commons.params
@@ -928,6 +931,9 @@ def test_void_domains_vs_oracle(torch_cuda, bulk):
     pos0[:, 0] *= 1/8
     mom0 = rng.normal(0, 0.3, (n, 3))
     mom0[:, 0] += (13.0 if bulk else 2.5)*mass/d  # cells per step towards +x
+    if point:
+        pos0 = 7.0 + rng.uniform(0.05, 0.95, (n, 3))*(L/gs)
+        mom0 = rng.normal(0, 1e-3, (n, 3))
 
     def integrals(kind):
         s = d/2 if kind == 'init' else d
