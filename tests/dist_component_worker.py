@@ -63,7 +63,8 @@ def main():
         test_gpu_pm.test_void_domains_vs_oracle(torch, True)
         assert stepper.stream_replays > replays  # (the row buffer really overflowed)
         test_gpu_pm.test_void_domains_vs_oracle(torch, 'point')
-        test_gpu_pm.test_void_domains_p3m(torch)
+        test_gpu_pm.test_void_domains_p3m(torch, False)
+        test_gpu_pm.test_void_domains_p3m(torch, True)
     elif case == 'pm_api':
         import test_gpu_pm
         test_gpu_pm.test_gravity_api_pm(None, golden)

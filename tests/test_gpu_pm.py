@@ -957,7 +957,8 @@ def test_void_domains_vs_oracle(torch_cuda, bulk):
         assert np.abs(c.host('mom') - mom).max() <= 1e-11*kick + 4e-16*np.abs(mom).max(), stream
 
 
-def test_void_domains_p3m(torch_cuda):
+@pytest.mark.parametrize('knot', [False, True])
+def test_void_domains_p3m(torch_cuda, knot):
     """The same void box with P3M (long-range mesh + short-range sweep, two steps): on several
     domains — most of them empty, boundary suppliers shipped into and out of empty slabs —
     against the single-domain run of the same calls.  (Single domain: the run against itself;
@@ -970,6 +971,14 @@ def test_void_domains_p3m(torch_cuda):
     pos0[:, 0] *= 1/8
     mom0 = rng.normal(0, 0.3, (n, 3))
     mom0[:, 0] += 3.0*mass/d
+    if knot:
+        # a knot of 3000 particles two cells across, centred on the face between two slabs
+        # (x = L/2 on 2 and 4 domains): thousands of pairs per tile, every pair across the face
+        # met through the shipped boundary suppliers; the rest of the box empty
+        n = 3000
+        pos0 = np.array([L/2, 20.3, 41.7]) + rng.normal(0, 0.7, (n, 3))
+        pos0 %= L
+        mom0 = rng.normal(0, 1e-2, (n, 3))
 
     def integrals(kind):
         s = d/2 if kind == 'init' else d
