@@ -33,6 +33,7 @@ def main():
     elif case == 'rungs':
         import test_gpu_p3m
         test_gpu_p3m.test_adaptive_rungs_vs_reference(golden)
+        test_gpu_p3m.test_adaptive_rungs_knot_across_domains()
     elif case == 'p3m_kick':
         import test_gpu_p3m
         test_gpu_p3m.test_shortrange_vs_golden_and_oracle(golden, arg)

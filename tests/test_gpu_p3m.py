@@ -271,3 +271,52 @@ def test_adaptive_rungs_vs_reference(golden):
         rs.base_step(dt)
         check(f'step{step}', f'rungs_step{step}')
         assert c.rungs_N == list(g[f'rungs_N_step{step}'])
+
+
+def test_adaptive_rungs_knot_across_domains():
+    """RungStepper (N_rungs = 4, rung jumps) on a box that is empty but for a knot across the
+    face between two x-slab domains and a sparse halo around it: particles on high rungs next
+    to a domain face, domains without particles, jumped rung indices travelling with the
+    shipped suppliers.  Several domains against the single-domain run of the same calls: rung
+    indices bit-exact, positions and momenta to summation order.  (On one domain: the run
+    against itself; tests/test_gpu_distributed.py adds 2 and 4 domains.)"""
+    from concept_amd import comm, commons, stepper
+    from concept_amd.species import Component
+    rng = np.random.default_rng(31)
+    L, gs, mass, dt = 64.0, 64, 300.0, 0.05  # (G m ~ 0.013: the knot's core reaches rung 2-3)
+    knot = np.array([L/2, 20.3, 41.7]) + rng.normal(0, 0.6, (1200, 3))
+    halo = np.array([L/2, 20.3, 41.7]) + rng.normal(0, 5.0, (800, 3))
+    pos0 = np.concatenate([knot, halo]) % L
+    mom0 = rng.normal(0, 0.05, pos0.shape)
+    n = pos0.shape[0]
+
+    def run():
+        commons.load_params({'boxsize': L, 'N_rungs': 4,
+                             'potential_options': {'gridsize': {'gravity': {'p3m': gs}}},
+                             'select_forces': {'all': {'gravity': 'p3m'}}})
+        c = Component('m', 'matter', N=n, mass=mass)
+        c.populate(pos0, 'pos')
+        c.populate(mom0, 'mom')
+        rs = stepper.RungStepper([c], stepper.static_integrals([c]))
+        rs.initialize_rung_populations(dt)
+        rs.kick_long(dt, float('inf'), 'init')
+        rs.kick_short(dt)
+        out = [c.host('rung_indices')]
+        for step in (1, 2):
+            rs.base_step(dt)
+            out.append(c.host('rung_indices'))
+        return c.host('pos'), c.host('mom'), out, list(c.rungs_N)
+    active = comm.active()
+    if active is not None:
+        comm.shutdown()
+    pos_ref, mom_ref, rungs_ref, pop_ref = run()
+    if active is not None:
+        comm.init()
+    pos, mom, rungs, pop = run()
+    assert len(set(rungs_ref[0].tolist())) > 1  # (more than one rung is populated)
+    for a, b in zip(rungs, rungs_ref):
+        assert np.array_equal(a, b)
+    assert pop == pop_ref
+    dx = np.abs(pos - pos_ref)
+    assert np.minimum(dx, L - dx).max() <= 1e-12*L
+    assert np.abs(mom - mom_ref).max() <= 1e-11*np.abs(mom_ref - mom0).max()
