@@ -56,6 +56,9 @@ def main():
     elif case == 'diff_orders':
         import test_gpu_pm
         test_gpu_pm.test_other_differentiation_orders_vs_golden(torch, golden, arg)
+    elif case == 'snapshot':
+        import test_gpu_pp
+        test_gpu_pp.test_gadget_snapshot_to_gpu_components(golden)
     elif case == 'void':
         import test_gpu_pm
         from concept_amd import stepper
