@@ -443,7 +443,7 @@ extern "C" int cg_pp_kick(cg_ctx *c, const double *pos_r, int64_t n_r, double *d
              "cg_pp_kick: null argument");
     CG_CHECK(kernel >= 0 && kernel <= 2, "Softening kernel %d not understood", kernel);
     CG_CHECK(!ewald_grid || ewald_gridsize >= 2, "cg_pp_kick: ewald_gridsize %d", ewald_gridsize);
-    CG_CHECK(!same || n_r == n_s, "cg_pp_kick: same = 1 needs identical receiver and supplier sets");
+    CG_CHECK(!same || n_r <= n_s, "cg_pp_kick: same = 1: the first n_r suppliers are the receivers");
     CG_CHECK(!rung || (factors && rung_jumped), "cg_pp_kick: rungs need factors and jumped indices");
     return cgk_pp_kick(c, pos_r, n_r, dmom_r, pos_s, n_s, same ? 1 : 0, ewald_grid, ewald_gridsize,
                        softening, kernel, factor, factors, rung, rung_jumped, lowest_active);

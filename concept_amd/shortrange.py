@@ -202,6 +202,18 @@ def component_component_pp(force, receivers, suppliers, ᔑdt_rungs, periodic):
         if c.Δmom is None:
             c.Δmom = torch.zeros_like(c.mom)
     key = 'a**(-3*w_eff₀-3*w_eff₁-1)'
+
+    def all_positions(sup):
+        """The supplier's particles of EVERY domain, this domain's first (the reference pairs
+        every domain with every other, interactions.py:398-590; direct summation is O(N²)
+        anyway, so the positions are simply gathered)."""
+        comm = sup.comm
+        if comm is None or comm.world == 1:
+            return sup.pos
+        counts = comm.all_gather_ints([sup.N_local])[:, 0].tolist()
+        everything = comm.all_gather_rows(sup.pos.contiguous())
+        start = int(sum(counts[:comm.rank]))
+        return torch.cat([sup.pos, everything[:start], everything[start + sup.N_local:]])
     done = set()
     for r in receivers:
         for s in suppliers:
@@ -221,7 +233,7 @@ def component_component_pp(force, receivers, suppliers, ᔑdt_rungs, periodic):
                     rungs = (factors, rec.rung_indices, rec.rung_indices_jumped,
                              rec.lowest_active_rung)
                     factor = 0.0
-                mesh.pp_kick(rec.pos, rec.Δmom, sup.pos, same, ewald_grid, softening,
+                mesh.pp_kick(rec.pos, rec.Δmom, all_positions(sup), same, ewald_grid, softening,
                              p.softening_kernel, factor, rungs)
             kick(r, s, r is s)
             if r is not s and s in receivers:

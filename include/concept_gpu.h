@@ -526,8 +526,9 @@ int cg_fluid_kick(cg_ctx *ctx, double *J_dim /*DEV N^3*/, const double *rho /*DE
  *   ewald.py:146-197, softened 1/r^3 of interactions.py:1847-1914) when ewald_grid is
  *   given, gravity_pairwise_nonperiodic (gravity.py:491-560) when it is NULL.
  *   dmom_r[i] += factor * sum_j force_ij over all suppliers (one-sided; the reference
- *   visits a pair once and updates both).  same = 1: receivers and suppliers are the same
- *   array (self pairs skipped).  kernel: 0 none, 1 plummer, 2 spline.  With rungs
+ *   visits a pair once and updates both).  same = 1: the first n_r suppliers ARE the
+ *   receivers, in the same order (pair i, i skipped); n_s > n_r: the rest of the component, on
+ *   other domains (domain_domain pairing of interactions.py:398-590 in one-sided form).  kernel: 0 none, 1 plummer, 2 spline.  With rungs
  *   (factors/rung/rung_jumped DEV, as cg_shortrange_sweep_rungs): receivers below
  *   lowest_active are skipped, the factor is factors[rung_jumped[i]]. */
 int cg_ewald_tabulate(cg_ctx *ctx, int gridsize, double *grid /*DEV 3 g^3*/);

@@ -56,6 +56,12 @@ def main():
     elif case == 'diff_orders':
         import test_gpu_pm
         test_gpu_pm.test_other_differentiation_orders_vs_golden(torch, golden, arg)
+    elif case == 'pp':
+        import test_gpu_pp
+        name, method = arg.split(',')
+        test_gpu_pp.test_pp_vs_golden_and_oracle(golden, name, method)
+        if method == 'pp':
+            test_gpu_pp.test_pp_default_ewald_grid_and_larger_set()
     elif case == 'snapshot':
         import test_gpu_pp
         test_gpu_pp.test_gadget_snapshot_to_gpu_components(golden)
