@@ -62,6 +62,13 @@ def main():
         test_gpu_pp.test_pp_vs_golden_and_oracle(golden, name, method)
         if method == 'pp':
             test_gpu_pp.test_pp_default_ewald_grid_and_larger_set()
+    elif case == 'known':
+        import test_gpu_known_answers as k
+        {'k2': k.test_k2_six_symmetric_particles_fall_to_the_centre,
+         'k3': k.test_k3_two_groups_of_four_keep_identical_x}[arg]()
+    elif case == 'mixed_random':
+        import test_gpu_fluid
+        test_gpu_fluid.test_mixed_pm_vs_oracle_random()
     elif case == 'snapshot':
         import test_gpu_pp
         test_gpu_pp.test_gadget_snapshot_to_gpu_components(golden)

@@ -205,6 +205,8 @@ COMPONENT_CASES = [
     ('diff_orders', 'pm_n8_g16_d6'), ('diff_orders', 'pm_n8_g16_d1'),
     ('diff_orders', 'pm_edge_g16'),         # particles on cell / box / slab boundaries
     ('pp', 'pp_ewald_n4,pp'), ('pp', 'ppnonperiodic_n4,ppnonperiodic'),  # direct summation
+    ('known', 'k2'), ('known', 'k3'),       # symmetric few-body configurations (pp, p3m)
+    ('mixed_random', '-'),                  # particles + fluid (non-zero 𝒫) vs the oracle
     ('snapshot', '-'),                      # GADGET file -> Components over domains
     ('void', '-'),                          # ranks that start empty, first arrivals by exchange()
     ('k4', '16,2'), ('k4', '32,4'),
