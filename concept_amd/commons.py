@@ -184,10 +184,12 @@ def load_params(source=None, **overrides):
     p.cell_centered = bool(user.get('cell_centered', True))
     # nghosts (commons.py:4411-4432): default 2 comes from the PCS default of the
     # power-spectrum options; force interpolation and differentiation orders raise it
-    nghosts = 2
+    # (powerspec_options default: PCS, interlaced -> 4//2 = 2, + 1 with cell-vertex grids)
+    nghosts = 2 + (0 if p.cell_centered else 1)
     for force, d in p.potential_options['interpolation'].items():
         for m, order in d.items():
-            nghosts = max(nghosts, order//2)
+            lattices = tuple(p.potential_options['interlace'].get(force, {}).get(m, ('sc', 'sc')))
+            nghosts = max(nghosts, order//2 + int(lattices != ('sc', 'sc') and order % 2 != 0))
     for name, d0 in p.potential_options['differentiation'].items():
         for force, d1 in d0.items():
             nghosts = max(nghosts, (max(d1.values()) + 1)//2)

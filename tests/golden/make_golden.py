@@ -50,6 +50,9 @@ CASES = {
                          diff=8, full=True),
     'pm_n8_g16_d1': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=38, dist='uniform',
                          diff=1, full=True),
+    # vertex-centred grids (the user parameter cell_centered = False, commons.py)
+    'pm_n8_g16_vertex': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=39,
+                             dist='uniform', diff=2, full=True, vertex=True),
     # clustered ("Zel'dovich-like" displaced lattice), in/out only
     'pm_n32_g64': dict(method='pm', n=32, gridsize=64, boxsize=256.0, seed=5, dist='lattice',
                        diff=2, full=False),
@@ -100,6 +103,13 @@ CASES = {
                                    dist='uniform', diff=0, fluid=dict(gridsize=16),
                                    interpolation='CIC', interlace=('bcc', 'fcc'),
                                    component_gridsizes={'particles0': (16, 32)}),
+    # the same shape on vertex-centred grids (cell_centered = False: lattice shifts of the
+    # other sign, interpolation offsets, 3 ghost layers)
+    'cic_fcc_multigrid_vertex_pow2': dict(method='pm', n=8, gridsize=32, boxsize=64.0, seed=40,
+                                          dist='uniform', diff=2, fluid=dict(gridsize=16),
+                                          interpolation='CIC', interlace=('bcc', 'fcc'),
+                                          component_gridsizes={'particles0': (16, 32)},
+                                          vertex=True),
     # particles only, one component: upstream 32 -> global 16 -> downstream 24, order 4
     'multigrid_n8_up32_down24': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=25,
                                      dist='uniform', diff=4, fluid=dict(gridsize=8, count=0),
@@ -193,6 +203,8 @@ a_begin = 0.5
 enable_class_background = False
 select_forces = {{'matter': {{'gravity': '{method}'}}}}
 """
+    if cfg.get('vertex'):
+        txt += "cell_centered = False\n"
     if method == 'p3m':
         txt += "shortrange_params = {'gravity': {'subtiling': %r}}\n" % (cfg.get('subtiling', 2),)
         txt += "select_softening_length = {'matter': '0.03*boxsize/cbrt(N)'}\n"
@@ -397,7 +409,7 @@ enable_class_background = False
 select_forces = {{'all': {{'gravity': 'pm'}}}}
 select_boltzmann_closure = {{'all': 'truncate'}}
 select_approximations = {{'all': {{'P=wρ': True}}}}
-"""
+""" + ("cell_centered = False\n" if cfg.get('vertex') else '')
 
 
 def child_fluid(name):
@@ -413,6 +425,7 @@ def child_fluid(name):
     L = commons.boxsize
     rng = np.random.default_rng(1000 + cfg['seed'])
     out = dict(boxsize=L, gridsize=cfg['gridsize'], nghosts=commons.nghosts,
+               cell_centered=int(commons.cell_centered),
                G_Newton=commons.G_Newton, light_speed=commons.light_speed, diff_order=cfg['diff'])
     comps = []
     npc = cfg.get('particle_components', 1)

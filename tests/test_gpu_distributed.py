@@ -198,12 +198,13 @@ COMPONENT_CASES = [
     ('mixed', 'fluid_pm_n8_g16'),           # particles + fluid on the shared mesh
     ('nonlinnu', '-'),                      # configs[4]'s shape: three mesh solves, two grid sizes
     ('multigrid', 'multigrid_n8_pow2'),     # copy_modes between grids: rows travel between ranks
-    ('orders', 'cic_fcc_multigrid_pow2'),   # ... with interlacing + Fourier differentiation
+    ('orders', 'cic_fcc_multigrid_pow2'),
+    ('orders', 'cic_fcc_multigrid_vertex_pow2'),  # ... on vertex-centred grids (3 ghost layers)   # ... with interlacing + Fourier differentiation
     ('orders', 'tsc_bcc_n8_g16'), ('orders', 'pcs_fcc_fourier_n8_g16'),
     ('orders', 'ngp_fluid_n8_g16'),
     ('tiled_general', '-'),
     ('diff_orders', 'pm_n8_g16_d6'), ('diff_orders', 'pm_n8_g16_d1'),
-    ('diff_orders', 'pm_edge_g16'),         # particles on cell / box / slab boundaries
+    ('diff_orders', 'pm_edge_g16'), ('diff_orders', 'pm_n8_g16_vertex'),         # particles on cell / box / slab boundaries
     ('pp', 'pp_ewald_n4,pp'), ('pp', 'ppnonperiodic_n4,ppnonperiodic'),  # direct summation
     ('known', 'k2'), ('known', 'k3'),       # symmetric few-body configurations (pp, p3m)
     ('mixed_random', '-'),                  # particles + fluid (non-zero 𝒫) vs the oracle

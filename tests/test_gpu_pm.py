@@ -781,19 +781,23 @@ def test_fused_scatter_overflow_is_flagged(torch_cuda):
     mesh.close()
 
 
-@pytest.mark.parametrize('name', ['pm_n8_g16_d1', 'pm_n8_g16_d6', 'pm_n8_g16_d8'])
+@pytest.mark.parametrize('name', ['pm_n8_g16_d1', 'pm_n8_g16_d6', 'pm_n8_g16_d8',
+                                  'pm_n8_g16_vertex'])
 def test_other_differentiation_orders_vs_golden(torch_cuda, golden, name):
     """diff_domaingrid's other orders (mesh.py:4874-5030): 6 and 8 — for which the reference
     raises nghosts to 3 and 4 (commons.py:4428-4430) — and the one-sided order 1, through the
-    gravity() boundary (force grid by cg_mesh_diff, then interpolated) and mesh by mesh."""
+    gravity() boundary (force grid by cg_mesh_diff, then interpolated) and mesh by mesh.
+    'pm_n8_g16_vertex': the user parameter cell_centered = False (vertex-centred grids; the
+    reference then keeps 3 ghost layers, commons.py:4411-4419) on the fused order-2 path."""
     from concept_amd import comm, commons, interactions
     from concept_amd.mesh import PotentialMesh
     from concept_amd.species import Component
     from oracle import oracle
     g = golden(name)
     order, N, L = int(g['diff_order']), int(g['gridsize']), float(g['boxsize'])
+    cc = bool(int(g['cell_centered']))
     p = commons.load_params({
-        'boxsize': L,
+        'boxsize': L, 'cell_centered': cc,
         'potential_options': {'gridsize': {'gravity': {'pm': N}},
                               'differentiation': {'matter': {'gravity': {'pm': order}}}},
         'select_forces': {'matter': {'gravity': 'pm'}},
@@ -816,8 +820,8 @@ def test_other_differentiation_orders_vs_golden(torch_cuda, golden, name):
         return
     # the force grids themselves
     ng = int(g['nghosts'])
-    mesh = PotentialMesh(N, L, nghosts=ng)
-    force = PotentialMesh(N, L, nghosts=ng)
+    mesh = PotentialMesh(N, L, nghosts=ng, cell_centered=cc)
+    force = PotentialMesh(N, L, nghosts=ng, cell_centered=cc)
     pos = torch_cuda.tensor(g['pos_in'], device='cuda')
     contribution = oracle.deposit_contribution(float(g['mass']), float(g['dt_dens']),
                                                float(g['dt_1']), N, L)

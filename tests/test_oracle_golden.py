@@ -11,7 +11,7 @@ import pytest
 from oracle import oracle
 
 PM_CASES = ['pm_n8_g16', 'pm_n16_g32', 'pm_edge_g16', 'pm_n8_g16_d4', 'pm_n8_g16_d6',
-            'pm_n8_g16_d8', 'pm_n8_g16_d1']
+            'pm_n8_g16_d8', 'pm_n8_g16_d1', 'pm_n8_g16_vertex']
 FIELDS = ['grid_deposit', 'slab_density_k', 'slab_potential_k', 'grid_potential', 'grid_force']
 
 
@@ -23,7 +23,7 @@ def run_oracle(g, **kw):
         pos, mom, mass=float(g['mass']), boxsize=float(g['boxsize']), gridsize=int(g['gridsize']),
         G_Newton=float(g['G_Newton']), dt_1=float(g['dt_1']), dt_dens=float(g['dt_dens']),
         dt_kick=float(g['dt_kick']), diff_order=int(g['diff_order']), shortrange_scale=sc,
-        nghosts=int(g['nghosts']), **kw)
+        nghosts=int(g['nghosts']), cell_centered=bool(int(g['cell_centered'])), **kw)
     return o, mom
 
 
@@ -240,7 +240,7 @@ def _fluid_components(g, particle_diff):
                                   'multigrid_n8_up32_down24', 'tsc_bcc_n8_g16',
                                   'pcs_fcc_fourier_n8_g16', 'ngp_fluid_n8_g16',
                                   'cic_fcc_multigrid_n8', 'multigrid_n8_pow2',
-                                  'cic_fcc_multigrid_pow2'])
+                                  'cic_fcc_multigrid_pow2', 'cic_fcc_multigrid_vertex_pow2'])
 def test_general_particle_mesh_bit_exact(golden, name):
     """gravity('pm') with receivers = suppliers = particles + fluids: momenta, J grids and
     the k-space potential handed to every backward FFT, bit for bit; the multigrid cases
@@ -252,6 +252,8 @@ def test_general_particle_mesh_bit_exact(golden, name):
     if 'interpolation' in g:  # row 3: NGP / TSC / PCS, interlacing, Fourier differentiation
         extra = dict(interp_order={'NGP': 1, 'CIC': 2, 'TSC': 3, 'PCS': 4}[str(g['interpolation'])],
                      interlace=tuple(str(x) for x in g['interlace']))
+    if 'cell_centered' in g:
+        extra.update(cell_centered=bool(int(g['cell_centered'])), nghosts=int(g['nghosts']))
     out = pm_general.particle_mesh(
         comps, boxsize=float(g['boxsize']), gridsize=int(g['gridsize']),
         G_Newton=float(g['G_Newton']), dt_1=float(g['dt_1']), light_speed=float(g['light_speed']),
