@@ -50,6 +50,18 @@ CASES = {
                          diff=8, full=True),
     'pm_n8_g16_d1': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=38, dist='uniform',
                          diff=1, full=True),
+    # other user parameters of the path: only the upstream deconvolution; Plummer softening
+    # with a non-default short-range scale / range / table size
+    'pm_n8_g16_deconv_up': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=41,
+                                dist='uniform', diff=2, full=True,
+                                extra="potential_options['deconvolve'] = "
+                                      "{'gravity': {'pm': (True, False)}}\n"),
+    'p3m_n8_g32_plummer': dict(method='p3m', n=8, gridsize=32, boxsize=32.0, seed=42,
+                               dist='uniform', diff=4, full=True,
+                               extra="softening_kernel = 'plummer'\n"
+                                     "shortrange_params = {'gravity': {'scale': "
+                                     "'1.1*boxsize/gridsize', 'range': '4.2*scale', "
+                                     "'tablesize': 2048, 'subtiling': 2}}\n"),
     # vertex-centred grids (the user parameter cell_centered = False, commons.py)
     'pm_n8_g16_vertex': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=39,
                              dist='uniform', diff=2, full=True, vertex=True),
@@ -211,6 +223,7 @@ select_forces = {{'matter': {{'gravity': '{method}'}}}}
     if 'rungs' in cfg:
         txt += f"N_rungs = {cfg['rungs']}\nenable_Hubble = False\na_begin = 1\n"
         txt += "particle_reordering = False\n"
+    txt += cfg.get('extra', '')
     return txt
 
 
@@ -681,6 +694,9 @@ def child(name):
     out = dict(
         boxsize=L, gridsize=cfg['gridsize'], nghosts=commons.nghosts, G_Newton=commons.G_Newton,
         mass=mass, N=N, diff_order=cfg['diff'], cell_centered=int(commons.cell_centered),
+        softening_kernel=str(commons.softening_kernel),
+        deconvolve=np.array(commons.potential_options['deconvolve']['gravity'][cfg['method']],
+                            dtype=np.int64),
         softening_length=comp.softening_length,
         pos_in=np.array(comp.pos_mv3[:N]).copy(), mom_in=np.array(comp.mom_mv3[:N]).copy(),
     )

@@ -204,7 +204,8 @@ COMPONENT_CASES = [
     ('orders', 'ngp_fluid_n8_g16'),
     ('tiled_general', '-'),
     ('diff_orders', 'pm_n8_g16_d6'), ('diff_orders', 'pm_n8_g16_d1'),
-    ('diff_orders', 'pm_edge_g16'), ('diff_orders', 'pm_n8_g16_vertex'),         # particles on cell / box / slab boundaries
+    ('diff_orders', 'pm_edge_g16'), ('diff_orders', 'pm_n8_g16_vertex'),
+    ('diff_orders', 'pm_n8_g16_deconv_up'), ('p3m_kick', 'p3m_n8_g32_plummer'),         # particles on cell / box / slab boundaries
     ('pp', 'pp_ewald_n4,pp'), ('pp', 'ppnonperiodic_n4,ppnonperiodic'),  # direct summation
     ('known', 'k2'), ('known', 'k3'),       # symmetric few-body configurations (pp, p3m)
     ('mixed_random', '-'),                  # particles + fluid (non-zero 𝒫) vs the oracle

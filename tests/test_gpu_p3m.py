@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-CASES = ['p3m_n8_g32', 'p3m_n12_g36_lattice', 'p3m_n16_g48_clustered']
+CASES = ['p3m_n8_g32', 'p3m_n12_g36_lattice', 'p3m_n16_g48_clustered', 'p3m_n8_g32_plummer']
 
 
 def setup(g):
@@ -20,6 +20,12 @@ def setup(g):
                               'differentiation': {'matter': {'gravity': {'p3m': 4}}}},
         'select_forces': {'matter': {'gravity': 'p3m'}},
         'select_softening_length': {'matter': '0.03*boxsize/cbrt(N)'},
+        # (non-default short-range parameters and softening kernel where the golden has them)
+        'softening_kernel': str(g['softening_kernel']) if 'softening_kernel' in g else 'spline',
+        'shortrange_params': {'gravity': {'scale': float(g['shortrange_scale']),
+                                          'range': float(g['shortrange_range']),
+                                          'tilesize': float(g['shortrange_tilesize']),
+                                          'tablesize': int(g['shortrange_tablesize'])}},
     })
     c = Component('matter', 'matter', N=int(g['N']), mass=float(g['mass']))
     assert abs(c.softening_length - float(g['softening_length'])) < 1e-15
@@ -51,7 +57,7 @@ def test_shortrange_vs_golden_and_oracle(golden, name):
         g['pos_after_short'], boxsize=float(g['boxsize']), scale=float(g['shortrange_scale']),
         range_=float(g['shortrange_range']), tilesize=float(g['shortrange_tilesize']),
         tablesize=int(g['shortrange_tablesize']), softening=float(g['softening_length']),
-        factor=factor)
+        factor=factor, kernel=str(g['softening_kernel']) if 'softening_kernel' in g else 'spline')
     assert np.abs(out - dm).max() <= 1e-12*scale
     # momentum conservation of the one-sided sweep
     assert np.abs(out.sum(0)).max() <= 1e-11*scale
@@ -67,7 +73,8 @@ def test_table_and_tiles(golden, name):
     g = golden(name)
     table, maxr2 = shortrange.get_shortrange_table(
         float(g['softening_length']), float(g['shortrange_scale']), float(g['shortrange_range']),
-        int(g['shortrange_tablesize']), 'spline', torch.device('cuda'))
+        int(g['shortrange_tablesize']),
+        str(g['softening_kernel']) if 'softening_kernel' in g else 'spline', torch.device('cuda'))
     ref = g['shortrange_table']
     t = table.cpu().numpy()
     assert maxr2 == float(g['shortrange_table_maxr2'])

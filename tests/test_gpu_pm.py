@@ -782,7 +782,7 @@ def test_fused_scatter_overflow_is_flagged(torch_cuda):
 
 
 @pytest.mark.parametrize('name', ['pm_n8_g16_d1', 'pm_n8_g16_d6', 'pm_n8_g16_d8',
-                                  'pm_n8_g16_vertex'])
+                                  'pm_n8_g16_vertex', 'pm_n8_g16_deconv_up'])
 def test_other_differentiation_orders_vs_golden(torch_cuda, golden, name):
     """diff_domaingrid's other orders (mesh.py:4874-5030): 6 and 8 — for which the reference
     raises nghosts to 3 and 4 (commons.py:4428-4430) — and the one-sided order 1, through the
@@ -796,9 +796,11 @@ def test_other_differentiation_orders_vs_golden(torch_cuda, golden, name):
     g = golden(name)
     order, N, L = int(g['diff_order']), int(g['gridsize']), float(g['boxsize'])
     cc = bool(int(g['cell_centered']))
+    deconv = tuple(bool(v) for v in g['deconvolve']) if 'deconvolve' in g else (True, True)
     p = commons.load_params({
         'boxsize': L, 'cell_centered': cc,
         'potential_options': {'gridsize': {'gravity': {'pm': N}},
+                              'deconvolve': {'gravity': {'pm': deconv}},
                               'differentiation': {'matter': {'gravity': {'pm': order}}}},
         'select_forces': {'matter': {'gravity': 'pm'}},
     })
@@ -828,7 +830,7 @@ def test_other_differentiation_orders_vs_golden(torch_cuda, golden, name):
     C, _ = oracle.poisson_constants(L, float(g['G_Newton']), None)
     mesh.zero()
     mesh.deposit(pos, contribution)
-    mesh.poisson_solve(4, C, False, 0.0)
+    mesh.poisson_solve(2*sum(deconv), C, False, 0.0)  # (interactions.py:2069-2080)
     for dim in range(3):
         force.diff_from(mesh, dim, order)
         got = force.fetch_real()[:, :, :N]

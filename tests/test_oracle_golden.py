@@ -11,7 +11,7 @@ import pytest
 from oracle import oracle
 
 PM_CASES = ['pm_n8_g16', 'pm_n16_g32', 'pm_edge_g16', 'pm_n8_g16_d4', 'pm_n8_g16_d6',
-            'pm_n8_g16_d8', 'pm_n8_g16_d1', 'pm_n8_g16_vertex']
+            'pm_n8_g16_d8', 'pm_n8_g16_d1', 'pm_n8_g16_vertex', 'pm_n8_g16_deconv_up']
 FIELDS = ['grid_deposit', 'slab_density_k', 'slab_potential_k', 'grid_potential', 'grid_force']
 
 
@@ -23,7 +23,9 @@ def run_oracle(g, **kw):
         pos, mom, mass=float(g['mass']), boxsize=float(g['boxsize']), gridsize=int(g['gridsize']),
         G_Newton=float(g['G_Newton']), dt_1=float(g['dt_1']), dt_dens=float(g['dt_dens']),
         dt_kick=float(g['dt_kick']), diff_order=int(g['diff_order']), shortrange_scale=sc,
-        nghosts=int(g['nghosts']), cell_centered=bool(int(g['cell_centered'])), **kw)
+        nghosts=int(g['nghosts']), cell_centered=bool(int(g['cell_centered'])),
+        deconvolve=tuple(bool(v) for v in g['deconvolve']) if 'deconvolve' in g else (True, True),
+        **kw)
     return o, mom
 
 
@@ -97,7 +99,8 @@ def test_fast_build_agrees_to_rounding(golden):
     assert np.abs(mom - g['mom_after_long']).max() <= 1e-10*np.abs(kick).max()
 
 
-@pytest.mark.parametrize('name', ['p3m_n8_g32', 'p3m_n12_g36_lattice', 'p3m_n16_g48_clustered'])
+@pytest.mark.parametrize('name', ['p3m_n8_g32', 'p3m_n12_g36_lattice', 'p3m_n16_g48_clustered',
+                                  'p3m_n8_g32_plummer'])
 def test_p3m_shortrange(golden, name):
     """Short-range tile sweep: the force table bit-exact, Δmom to summation rounding
     (the oracle visits the pairs in a different order than the reference)."""
@@ -107,7 +110,7 @@ def test_p3m_shortrange(golden, name):
         g['pos_after_short'], boxsize=float(g['boxsize']), scale=float(g['shortrange_scale']),
         range_=float(g['shortrange_range']), tilesize=float(g['shortrange_tilesize']),
         tablesize=int(g['shortrange_tablesize']), softening=float(g['softening_length']),
-        factor=factor)
+        factor=factor, kernel=str(g['softening_kernel']) if 'softening_kernel' in g else 'spline')
     assert np.array_equal(table[:-1], g['shortrange_table'][:-1])
     assert oracle.shortrange_tiling_shape(float(g['boxsize']), float(g['shortrange_tilesize'])) \
         == int(g['tiling_shape'][0])
