@@ -130,6 +130,12 @@ CASES = {
     'tsc_bcc_n8_g16': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=26, dist='uniform',
                            diff=2, fluid=dict(gridsize=16, count=0),
                            interpolation='TSC', interlace=('bcc', 'bcc')),
+    # ... with only the downstream deconvolution (general path: the two are applied apart)
+    'tsc_bcc_deconv_down_n8_g16': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=43,
+                                       dist='uniform', diff=2, fluid=dict(gridsize=16),
+                                       interpolation='TSC', interlace=('bcc', 'bcc'),
+                                       extra="potential_options['deconvolve'] = "
+                                             "{'gravity': {'pm': (False, True)}}\n"),
     'pcs_fcc_fourier_n8_g16': dict(method='pm', n=8, gridsize=16, boxsize=64.0, seed=27,
                                    dist='clustered', diff=0, fluid=dict(gridsize=16, count=0),
                                    interpolation='PCS', interlace=('fcc', 'sc')),
@@ -422,7 +428,7 @@ enable_class_background = False
 select_forces = {{'all': {{'gravity': 'pm'}}}}
 select_boltzmann_closure = {{'all': 'truncate'}}
 select_approximations = {{'all': {{'P=wρ': True}}}}
-""" + ("cell_centered = False\n" if cfg.get('vertex') else '')
+""" + ("cell_centered = False\n" if cfg.get('vertex') else '') + cfg.get('extra', '')
 
 
 def child_fluid(name):
@@ -439,6 +445,8 @@ def child_fluid(name):
     rng = np.random.default_rng(1000 + cfg['seed'])
     out = dict(boxsize=L, gridsize=cfg['gridsize'], nghosts=commons.nghosts,
                cell_centered=int(commons.cell_centered),
+               deconvolve=np.array(commons.potential_options['deconvolve']['gravity']['pm'],
+                                   dtype=np.int64),
                G_Newton=commons.G_Newton, light_speed=commons.light_speed, diff_order=cfg['diff'])
     comps = []
     npc = cfg.get('particle_components', 1)

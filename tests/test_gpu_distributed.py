@@ -200,7 +200,7 @@ COMPONENT_CASES = [
     ('multigrid', 'multigrid_n8_pow2'),     # copy_modes between grids: rows travel between ranks
     ('orders', 'cic_fcc_multigrid_pow2'),
     ('orders', 'cic_fcc_multigrid_vertex_pow2'),  # ... on vertex-centred grids (3 ghost layers)   # ... with interlacing + Fourier differentiation
-    ('orders', 'tsc_bcc_n8_g16'), ('orders', 'pcs_fcc_fourier_n8_g16'),
+    ('orders', 'tsc_bcc_n8_g16'), ('orders', 'tsc_bcc_deconv_down_n8_g16'), ('orders', 'pcs_fcc_fourier_n8_g16'),
     ('orders', 'ngp_fluid_n8_g16'),
     ('tiled_general', '-'),
     ('diff_orders', 'pm_n8_g16_d6'), ('diff_orders', 'pm_n8_g16_d1'),

@@ -243,7 +243,8 @@ def _fluid_components(g, particle_diff):
                                   'multigrid_n8_up32_down24', 'tsc_bcc_n8_g16',
                                   'pcs_fcc_fourier_n8_g16', 'ngp_fluid_n8_g16',
                                   'cic_fcc_multigrid_n8', 'multigrid_n8_pow2',
-                                  'cic_fcc_multigrid_pow2', 'cic_fcc_multigrid_vertex_pow2'])
+                                  'cic_fcc_multigrid_pow2', 'cic_fcc_multigrid_vertex_pow2',
+                                  'tsc_bcc_deconv_down_n8_g16'])
 def test_general_particle_mesh_bit_exact(golden, name):
     """gravity('pm') with receivers = suppliers = particles + fluids: momenta, J grids and
     the k-space potential handed to every backward FFT, bit for bit; the multigrid cases
@@ -257,6 +258,8 @@ def test_general_particle_mesh_bit_exact(golden, name):
                      interlace=tuple(str(x) for x in g['interlace']))
     if 'cell_centered' in g:
         extra.update(cell_centered=bool(int(g['cell_centered'])), nghosts=int(g['nghosts']))
+    if 'deconvolve' in g:
+        extra.update(deconvolve=tuple(bool(v) for v in g['deconvolve']))
     out = pm_general.particle_mesh(
         comps, boxsize=float(g['boxsize']), gridsize=int(g['gridsize']),
         G_Newton=float(g['G_Newton']), dt_1=float(g['dt_1']), light_speed=float(g['light_speed']),
