@@ -171,7 +171,45 @@ def load_params(source=None, **overrides):
           'subtiling': 'automatic', 'tablesize': 2**12}
     sr.update((user.get('shortrange_params') or {}).get('gravity', {}))
     p.shortrange_params = {'gravity': sr}
-    p.select_forces = user.get('select_forces', {'particles': {'gravity': 'p3m'}})
+    # select_forces (commons.py:3664-3700): {selector: {force: method}}, or {selector: 'force'}
+    # for the force's default method; absent, it follows the methods the global grid sizes
+    # were given for — only 'pm': everything by PM; 'p3m' (with or without 'pm'): particles by
+    # P3M, fluids by PM
+    default_force_method = {'gravity': 'p3m'}
+    methods_implemented = ('ppnonperiodic', 'pp', 'p3m', 'pm')
+    sf = {}
+    for key, val in dict(user.get('select_forces') or {}).items():
+        key = str(key).strip().lower() if key != 'default' else key
+        if isinstance(val, dict):
+            sf[key] = {str(f).strip().lower(): str(m).strip().lower() for f, m in val.items()}
+        elif isinstance(val, str):
+            force = val.strip().lower()
+            if force not in default_force_method:
+                raise ValueError(f'select_forces: force "{val}" has no default method')
+            sf[key] = {force: default_force_method[force]}
+        else:
+            raise ValueError(f'select_forces[{key!r}] = {val!r} not understood')
+        for force, method in sf[key].items():
+            if method not in methods_implemented:
+                raise ValueError(f'select_forces: method "{method}" for force "{force}" not '
+                                 f'implemented (methods: {methods_implemented})')
+    if not sf:
+        for force, dm in p.potential_options['gridsize']['global'].items():
+            methods = {m for m, g in dm.items() if g != -1}
+            if not methods:
+                continue
+            sf.setdefault('particles', {})
+            sf.setdefault('fluid', {})
+            if methods == {'pm'}:
+                sf['particles'].setdefault(force, 'pm')
+                sf['fluid'].setdefault(force, 'pm')
+            elif methods in ({'p3m'}, {'pm', 'p3m'}):
+                sf['particles'].setdefault(force, 'p3m')
+                sf['fluid'].setdefault(force, 'pm')
+            else:
+                raise ValueError(f'Force methods "{methods}" from potential_options'
+                                 f'["gridsize"]["global"]["{force}"] not understood')
+    p.select_forces = sf
     ssl = user.get('select_softening_length') or {}
     if not isinstance(ssl, dict):
         ssl = {'all': ssl}

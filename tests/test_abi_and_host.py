@@ -140,3 +140,25 @@ def test_is_selected_precedence():
     merged = commons.is_selected(c, {'all': {'gravity': 'pm', 'x': 1}, 'fluid': {'x': 2}},
                                  accumulate=True)
     assert merged == {'gravity': 'pm', 'x': 2}
+
+
+def test_select_forces_forms_and_defaults():
+    """select_forces as the reference reads it (commons.py:3664-3700): a dict per selector, a
+    bare force name (its default method), or nothing at all — then the methods follow the
+    global potential grid sizes."""
+    import pytest
+    from concept_amd import commons
+    p = commons.load_params({'potential_options': {'gridsize': {'global': {'gravity': {'pm': 64}}}}})
+    assert p.select_forces == {'particles': {'gravity': 'pm'}, 'fluid': {'gravity': 'pm'}}
+    p = commons.load_params({'potential_options': {'gridsize': {'global': {'gravity': {
+        'pm': 64, 'p3m': 128}}}}})
+    assert p.select_forces == {'particles': {'gravity': 'p3m'}, 'fluid': {'gravity': 'pm'}}
+    p = commons.load_params({'select_forces': {'Matter': 'gravity'}})
+    assert p.select_forces == {'matter': {'gravity': 'p3m'}}
+    p = commons.load_params({'select_forces': {'all': {'Gravity': 'PM'}}})
+    assert p.select_forces == {'all': {'gravity': 'pm'}}
+    with pytest.raises(ValueError):
+        commons.load_params({'select_forces': {'all': {'gravity': 'tree'}}})
+    # vertex-centred grids keep one more ghost layer (commons.py:4411-4419)
+    assert commons.load_params({'cell_centered': False}).nghosts == 3
+    assert commons.load_params({}).nghosts == 2
