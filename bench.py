@@ -546,7 +546,14 @@ def main():
             else:
                 mesh.deposit_regions(pos, reg['start'], reg['count'], contribution)
             mark()
-            mesh.poisson_solve(4, C, False, 0.0)
+            if args.split_poisson:
+                mesh.poisson_forward(4, C, False, 0.0, apply_kernel=False)
+                mark()
+                mesh.poisson_kernel(4, C, False, 0.0)
+                mark()
+                mesh.poisson_backward()
+            else:
+                mesh.poisson_solve(4, C, False, 0.0)
             mark()
             start_out, count_out = reg['spare']
             mesh.predict_regions(reg['start'], reg['count'], start_out)
