@@ -320,11 +320,14 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
                  'GBps_out_per_rank': round(sent/(ms*1e-3)/1e9, 1)}
     cnt = torch.tensor([parts.n, parts.emigrants_total - emig0], dtype=torch.int64, device=dev)
     dist.all_reduce(cnt)
-    # RCCL prints its version banner through C stdio; push it out (and shut the communicator
-    # down) before the result so that the JSON line is the last line of stdout
+    # shut the communicator down and push out what C stdio still holds (it went to stderr, see
+    # main()), then give stdout back: the JSON line is the only line on it
     dist.destroy_process_group()
     import ctypes
+    sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
+    if _saved_stdout is not None:
+        os.dup2(_saved_stdout, 1)
     if rank != 0:
         return
     total, emigrants = int(cnt[0].item()), int(cnt[1].item())
@@ -384,6 +387,9 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
 # ---------------------------------------------------------------------------
 # self-spawn
 # ---------------------------------------------------------------------------
+_saved_stdout = None
+
+
 def spawn_ranks(args):
     """--gpus N with no launcher environment: start the N ranks under torch.distributed.run
     (one per GPU, rendezvous on 127.0.0.1) and pass their output through; rank 0's JSON line is
@@ -458,6 +464,12 @@ def main():
     # single domain too — a smoke test of the N>1 path on a 1-GPU box
     force_dist = os.environ.get('CONCEPT_BENCH_FORCE_DIST') == '1'
     if world > 1 or force_dist:
+        # RCCL writes a version banner to stdout through C stdio: while the ranks run, file
+        # descriptor 1 points at stderr; rank 0 gets it back for its one JSON line
+        sys.stdout.flush()
+        global _saved_stdout
+        _saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('RANK', '0')
