@@ -770,11 +770,11 @@ __global__ __launch_bounds__(NT) void k_fft_strided_p(const double2 *__restrict_
 // 16 values per lane (each prefetched during a transform), one store of 32, deferred to the
 // next tile like in the pass above.  Registers: 3 x 16 values + temporaries < 256.
 // ---------------------------------------------------------------------------
-template <int LOGN, int NT, int MODE>
+template <int LOGN, int NT, int MODE, bool BLOCKED>
 __global__ __launch_bounds__(NT) void k_fft_strided_h(const double2 *__restrict__ src,
-                                                      double2 *__restrict__ dst, i64 s_ostride,
-                                                      i64 s_es, i64 d_ostride, i64 d_es, int nkb,
-                                                      i64 ntiles, i64 o_off,
+                                                      double2 *__restrict__ dst, PencilMap smap,
+                                                      PencilMap dmap, int nkb, i64 ntiles,
+                                                      i64 o_off,
                                                       const double2 *__restrict__ tw,
                                                       KspaceParams P) {
     constexpr int N = 1 << LOGN, H = N / 2, W = 8, LOGH = LOGN - 1;
@@ -783,6 +783,19 @@ __global__ __launch_bounds__(NT) void k_fft_strided_h(const double2 *__restrict_
     constexpr int PER = 16;
     constexpr int MSTEP = NT / W;  // = H/16
     constexpr bool INV1 = MODE == 1;  // direction of the first (or only) transform
+    // Pencil maps: plain (point m at m*es) or blocked by destination domain (the all-to-all
+    // buffers of the x-slab decomposition, fft_dist): a lane's points are m = l + c with the
+    // lane part l < 2*MSTEP and the wave-uniform c a multiple of 2*MSTEP (MSTEP for the
+    // natural-order stores); blocks hold a multiple of 2*MSTEP points (checked by the
+    // launcher), so block number and offset inside the block of c are scalar and the lane
+    // part never leaves the block.
+    const i64 s_es = smap.es, d_es = dmap.es;
+    // (blocked maps: the 64 block offsets of a tile are scalar arithmetic redone at every use —
+    // hoisted out of the tile loop they would be 128 scalar registers, spilled)
+    auto opaque = [](int c) {
+        asm volatile("" : "+s"(c));
+        return c;
+    };
     extern __shared__ double2 lds_dyn[];
     double2 *lds = lds_dyn;
     double2 *twh = lds_dyn + TOT;                      // H/2 twiddles of the H-point tiles
@@ -812,13 +825,14 @@ __global__ __launch_bounds__(NT) void k_fft_strided_h(const double2 *__restrict_
         if (reverse) t = ntiles - 1 - t;
         const i64 o = t / nkb;
         const int kk0 = (int)(t - o * nkb) * W;
-        const double2 *sbase = src + o * s_ostride + kk0 + (odd ? s_es : 0);
+        const double2 *sbase = src + o * smap.ostride + kk0;
         // rows of the halves: element m = ml + 64 r of the even half is row 2m, of the odd 2m + 1
         const int ft = fresh_tid();
         const unsigned voff_h = (unsigned)(2 * (ft / W) * s_es + ft % W);
 #pragma unroll
         for (int r = 0; r < PER; r++)
-            v[r] = ((const d2 *)(sbase + (i64)r * (2 * MSTEP) * s_es))[voff_h];
+            v[r] = ((const d2 *)(sbase + (BLOCKED ? pencil_off(smap, opaque(r * (2 * MSTEP)) + odd)
+                                                  : ((i64)r * (2 * MSTEP) + odd) * s_es)))[voff_h];
     };
     // the 32 results of a tile leave in two halves (hi = 0: u[0..15], hi = 1: u[16..31]), one
     // at the start of each phase of the next tile, so that stores and loads alternate
@@ -828,13 +842,15 @@ __global__ __launch_bounds__(NT) void k_fft_strided_h(const double2 *__restrict_
         const int kk0 = (int)(t - o * nkb) * W;
         // MODE 2: u[r] is row 2 (ml + 64 r), u[16 + r] the row after it;
         // otherwise u[r] is row ml + 64 r, u[16 + r] row ml + 64 r + H
-        double2 *dbase = dst + o * d_ostride + kk0 + (hi ? (MODE == 2 ? 1 : H) * d_es : 0);
+        double2 *dbase = dst + o * dmap.ostride + kk0;
         constexpr int RS = (MODE == 2 ? 2 : 1) * MSTEP;
+        const int c0 = hi ? (MODE == 2 ? 1 : H) : 0;
         const int ft = fresh_tid();
         const unsigned voff_d = (unsigned)((MODE == 2 ? 2 : 1) * (ft / W) * d_es + ft % W);
 #pragma unroll
         for (int r = 0; r < PER; r++)
-            ((d2 *)(dbase + (i64)r * RS * d_es))[voff_d] = u[(hi ? PER : 0) + r];
+            ((d2 *)(dbase + (BLOCKED ? pencil_off(dmap, opaque(r * RS) + c0)
+                                     : ((i64)r * RS + c0) * d_es)))[voff_d] = u[(hi ? PER : 0) + r];
     };
     // w32^r = exp(-2 pi i r / 32), r = 0 .. 15
     constexpr double c32[16] = {1.0,
@@ -1049,25 +1065,27 @@ static int run_strided_h(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
     const i64 ntiles = nouter * nkb;
     // per-lane offsets are 32-bit byte offsets: rows 2 ml (ml < NT/W) must span < 4 GB
     const i64 reach = ((2 * (i64)(NT / W - 1)) * (smap.es > dmap.es ? smap.es : dmap.es) + W) * 16;
-    if (!enabled || ntiles < 2 * (i64)ncu || smap.sh != 31 || dmap.sh != 31 ||
+    // blocked maps (fft_dist): whole multiples of the 2*(NT/W) rows a lane spans per block
+    auto blocks_ok = [](const PencilMap &m) { return m.sh == 31 || (1 << m.sh) >= 2 * (NT / W); };
+    if (!enabled || ntiles < 2 * (i64)ncu || !blocks_ok(smap) || !blocks_ok(dmap) ||
         reach >= ((i64)1 << 32) || (i64)nkb * W > c->pad / 2)
         return 0;
     constexpr size_t lds = sizeof(double2) * (N / 2) * W + sizeof(double2) * (N / 4) +
                            (MODE == 2 ? sizeof(double) * N : 0) + sizeof(double2) * (NT / W);
     static_assert(lds <= 160 * 1024, "split pass: LDS");
-    auto kern = k_fft_strided_h<LOGN, NT, MODE>;
-    static bool attr_set[64] = {};
+    const bool blocked = smap.sh != 31 || dmap.sh != 31;
+    auto kern = blocked ? k_fft_strided_h<LOGN, NT, MODE, true> : k_fft_strided_h<LOGN, NT, MODE, false>;
+    static bool attr_set[64][2] = {};
     const int dev = c->p.device & 63;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev][blocked]) {
         CG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
-        attr_set[dev] = true;
+        attr_set[dev][blocked] = true;
     }
     // workgroups per CU the LDS footprint allows (2048: one; 1024: two, each the other's cover)
     const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ncu * per_cu)), dim3(NT), lds, c->stream, src, dst, smap.ostride,
-                       smap.es, dmap.ostride, dmap.es, nkb, ntiles, o_off,
-                       (const double2 *)c->fft_tw, P);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ncu * per_cu)), dim3(NT), lds, c->stream, src, dst,
+                       smap, dmap, nkb, ntiles, o_off, (const double2 *)c->fft_tw, P);
     CG_LAUNCH_CHECK();
     *done = true;
     return 0;

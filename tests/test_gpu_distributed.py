@@ -52,7 +52,11 @@ def single_domain(N, n_side, steps, p3m=False):
                                          (8, 128, False), (2, 64, True), (4, 128, True),
                                          (2, 32, 'fused'), (4, 64, 'fused'), (8, 128, 'fused'),
                                          (2, 32, 'regions'), (4, 64, 'regions'),
-                                         (8, 128, 'regions')])
+                                         (8, 128, 'regions'),
+                                         # the production instantiation of the FFT passes (even /
+                                         # odd split pass writing / reading the all-to-all
+                                         # buffers blocked by destination domain), one step
+                                         (2, 1024, False), (4, 1024, False)])
 def test_slab_domains_match_single_domain(world, N, p3m):
     """p3m = 'fused': the PM step with the fused drift + exchange + sort
     (DistributedParticles.drift_exchange_sort) and the tile histogram prepared by the
@@ -63,6 +67,8 @@ def test_slab_domains_match_single_domain(world, N, p3m):
     p3m = p3m is True
     if mode in ('fused', 'regions'):
         steps = 5
+    if N >= 1024:
+        steps = 1
     pos_ref, mom_ref = single_domain(N, n_side, steps, p3m)
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
