@@ -92,51 +92,17 @@ __device__ __forceinline__ double kspace_factor_fixed(const KspaceParams &P, con
     return factor * pk;
 }
 
-// The factor for the persistent fused pass: same quantity, arranged for throughput — the
-// sinc ratio per dimension comes from the table q = n/s, so the mode costs one division
-// (C/k2) instead of two, and the mode numbers are 32-bit (N <= 2048: k2 < 2^24).  Differs
-// from kspace_factor by rounding only (the three ratios are rounded separately, ~3 ulp);
-// the Poisson solve is a floating-point path (FFT rounding already differs from FFTW's),
-// tested against the CPU restatement to the tolerance stated in tests/test_gpu_pm.py.
-struct KspaceFixedQ {
-    double q_bkk;  // q_b*q_kk
-    int kb2_kk2;   // kb*kb + kk*kk
-    bool dead;     // b or kk on a Nyquist plane
-};
-__device__ __forceinline__ KspaceFixedQ kspace_fix_q(int N, int b, int kk, double q_b,
-                                                     double q_kk) {
-    const int nyq = N / 2;
-    KspaceFixedQ F;
-    F.dead = (b == nyq) || (kk == nyq);
-    int kb = b - (b >= nyq ? N : 0);
-    F.kb2_kk2 = kb * kb + kk * kk;
-    F.q_bkk = q_b * q_kk;
-    return F;
-}
-__device__ __forceinline__ double kspace_factor_q(const KspaceParams &P, const KspaceFixedQ &F,
-                                                  int N, int a, double q_a) {
-    const int nyq = N / 2;
-    int ka = a - (a >= nyq ? N : 0);
-    int k2 = F.kb2_kk2 + ka * ka;
-    if (F.dead || a == nyq || k2 == 0) return 0;  // nullify_modes('nyquist'), ('origin')
-    double factor = 1;
-    if (P.deconv_order) {
-        double f = q_a * F.q_bkk;
-        factor = f;
-        for (int o = 1; o < P.deconv_order; o++) factor *= f;
-    }
-    double pk = P.C / (double)k2;
-    if (P.long_range) pk = pk * exp((double)k2 * P.E);
-    return factor * pk;
-}
-
 // Separable arrangement of the same factor for the fused x passes.  With
 // k2 = ka^2 + kb^2 + kk^2 the Gaussian of the long-range split factorises,
 // exp(k2 E) = exp(ka^2 E) exp(kb^2 E) exp(kk^2 E), and so does the deconvolution, so one table
 // per dimension index, t[a] = q_a^order * exp(ka^2 E), leaves a mode with one table value, one
 // multiplication and the division by k2 — no exp and no power loop per mode (they are most of
-// the arithmetic of a fused pass: 16 to 32 modes per lane and tile).  Differs from
-// kspace_factor_q by rounding only (a few ulp; same tolerance, tests/test_gpu_pm.py).
+// the arithmetic of a fused pass: 16 to 32 modes per lane and tile).  The sinc ratio of a
+// dimension comes from the table q = n/sin(n); the mode numbers are 32-bit (N <= 2048:
+// k2 < 2^24).  Differs from kspace_factor by rounding only (the three ratios and the three
+// Gaussians are rounded separately, a few ulp); the Poisson solve is a floating-point path
+// (FFT rounding already differs from FFTW's), tested against the CPU restatement to the
+// tolerance stated in tests/test_gpu_pm.py.
 __device__ __forceinline__ double kspace_tab_sep(const KspaceParams &P, int N, int a, double q_a) {
     const int nyq = N / 2;
     const int ka = a - (a >= nyq ? N : 0);

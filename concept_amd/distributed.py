@@ -36,7 +36,6 @@ from . import lib
 from .comm import Comm
 from .mesh import PotentialMesh
 
-DEAD_X_FACTOR = -4.0  # pos.x = DEAD_X_FACTOR*boxsize marks a vacated particle slot
 
 
 def _vp(t):
@@ -161,43 +160,8 @@ def exchange_columns(comm, cols, n, cap, move_idx, dest, send_counts, recv_count
     return n_new, (inc if m_in else None)
 
 
-def exchange_rows(comm, owner, pos, mom, ids, n, cap, dead_x):
-    """Move the particles with owner != comm.rank to their owners (all-to-all-v of
-    rows pos(3) mom(3) id(1)).  Vacated slots are refilled with immigrants, surplus
-    immigrants are appended after slot n, leftover holes get pos.x = dead_x (the tile
-    sort drops them).  Works on any device.  Returns (n_slots, n_alive)."""
-    P, rank = comm.world, comm.rank
-    dev = pos.device
-    move_idx = torch.nonzero(owner[:n] != rank).flatten()
-    dest = owner[move_idx].long()
-    order = torch.argsort(dest, stable=True)
-    move_idx, dest = move_idx[order], dest[order]
-    send_counts = torch.bincount(dest, minlength=P).cpu().tolist()
-    rows = _pack_rows([pos, mom, ids], move_idx)
-    counts = comm.all_gather_ints(send_counts)  # counts[src][dst]
-    recv_counts = counts[:, rank].tolist()
-    m_in, m_out = int(sum(recv_counts)), int(move_idx.numel())
-    comm.last_sent = m_out
-    inc = torch.empty((m_in, 7), dtype=torch.float64, device=dev)
-    comm.all_to_all(inc, rows, recv_counts, send_counts)
-    k = min(m_in, m_out)
-    if k:
-        _unpack_rows([pos, mom, ids], inc[:k], move_idx[:k])
-    n_slots = n
-    if m_in > k:
-        extra = m_in - k
-        if n + extra > cap:
-            raise lib.ConceptGPUError(
-                f'rank {rank}: particle capacity {cap} exceeded ({n + extra})')
-        _unpack_rows([pos, mom, ids], inc[k:], slice(n, n + extra))
-        n_slots = n + extra
-    elif m_out > k:
-        pos[move_idx[k:], 0] = dead_x
-    return n_slots, n - m_out + m_in
-
-
 def exchange_rows_compact(comm, owner, pos, mom, ids, n, cap, move=None, extra=()):
-    """exchange_rows that leaves no dead rows (see exchange_columns).  `move` = (row numbers,
+    """exchange() by explicit owners (see exchange_columns).  `move` = (row numbers,
     their owners) when the leaving rows are already known (then `owner` is not needed);
     `extra`: further per-particle columns that travel with the rows.  This form finds the
     message sizes with host round trips (nonzero, bincount, all_gather); the stepping path

@@ -94,36 +94,6 @@ def _w_ring(rank, world):
     assert (r == float((rank + 1) % world)).all()
 
 
-def _w_exchange(rank, world, n_per):
-    from concept_amd.distributed import Comm, exchange_rows
-    comm = Comm()
-    L = 1.0
-    gen = torch.Generator().manual_seed(100 + rank)
-    cap = 3*n_per
-    pos = torch.zeros((cap, 3), dtype=torch.float64)
-    mom = torch.zeros((cap, 3), dtype=torch.float64)
-    ids = torch.zeros(cap, dtype=torch.int64)
-    n = n_per + 7*rank  # uneven populations
-    pos[:n] = torch.rand((n, 3), dtype=torch.float64, generator=gen)  # anywhere in the box
-    mom[:n] = pos[:n]*3 + 1
-    ids[:n] = torch.arange(n) + 10**6*rank
-    owner = torch.clamp((pos[:, 0]*world/L).long(), max=world - 1).int()
-    before = comm.all_gather_ints([n])[:, 0].sum().item()
-    n_slots, n_alive = exchange_rows(comm, owner, pos, mom, ids, n, cap, -4.0*L)
-    alive = pos[:n_slots, 0] > -1.0
-    assert int(alive.sum()) == n_alive
-    p, m, i = pos[:n_slots][alive], mom[:n_slots][alive], ids[:n_slots][alive]
-    own = torch.clamp((p[:, 0]*world/L).long(), max=world - 1)
-    assert (own == rank).all()           # everyone is home
-    assert torch.equal(m, p*3 + 1)       # rows stayed together
-    after = comm.all_gather_ints([n_alive])[:, 0].sum().item()
-    assert after == before               # nobody lost, nobody duplicated
-    all_ids = [None]*world
-    dist.all_gather_object(all_ids, i.tolist())
-    flat = sorted(x for l in all_ids for x in l)
-    assert len(flat) == len(set(flat)) == before
-
-
 @pytest.mark.parametrize('world', [2, 4])
 def test_transpose_layout(world):
     _run(_w_transpose, world, 16)
@@ -133,10 +103,6 @@ def test_ring_sendrecv():
     _run(_w_ring, 2)
     _run(_w_ring, 3)
 
-
-@pytest.mark.parametrize('world', [2, 4])
-def test_particle_exchange(world):
-    _run(_w_exchange, world, 500)
 
 
 def _w_exchange_compact(rank, world, n_per, skew, listed=False):
