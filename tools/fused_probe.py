@@ -35,3 +35,17 @@ for i in range(6):
     ms.append(e0.elapsed_time(e1))
 print('fused ms per call:', ' '.join(f'{v:.3f}' for v in ms), 'flags', mesh.error_flags(),
       'placed', int(count_out.long().sum()))
+# the steady state: the input itself in regions with gaps (the output of the pass above)
+start2, count2 = mesh.new_region_table()
+mesh.predict_regions(start_out, count_out, start2)
+ms = []
+for i in range(6):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    mesh.gather_kick_drift_scatter(pb, mb, None, start_out, count_out, pa, ma, None, start2, count2,
+                                   2, -dt, dt)
+    e1.record()
+    torch.cuda.synchronize()
+    ms.append(e0.elapsed_time(e1))
+print('from regions with gaps:', ' '.join(f'{v:.3f}' for v in ms), 'flags', mesh.error_flags(),
+      'placed', int(count2.long().sum()))
