@@ -69,6 +69,10 @@ def main():
     elif case == 'mixed_random':
         import test_gpu_fluid
         test_gpu_fluid.test_mixed_pm_vs_oracle_random()
+    elif case == 'random_configs':
+        import test_gpu_fluid
+        for seed in range(int(arg)):
+            test_gpu_fluid.test_random_configurations_vs_oracle(seed)
     elif case == 'snapshot':
         import test_gpu_pp
         test_gpu_pp.test_gadget_snapshot_to_gpu_components(golden)

@@ -214,7 +214,8 @@ COMPONENT_CASES = [
     ('diff_orders', 'pm_n8_g16_deconv_up'), ('p3m_kick', 'p3m_n8_g32_plummer'),         # particles on cell / box / slab boundaries
     ('pp', 'pp_ewald_n4,pp'), ('pp', 'ppnonperiodic_n4,ppnonperiodic'),  # direct summation
     ('known', 'k2'), ('known', 'k3'),       # symmetric few-body configurations (pp, p3m)
-    ('mixed_random', '-'),                  # particles + fluid (non-zero 𝒫) vs the oracle
+    ('mixed_random', '-'),
+    ('random_configs', '16'),               # the option space of gravity('pm'), drawn at random                  # particles + fluid (non-zero 𝒫) vs the oracle
     ('snapshot', '-'),                      # GADGET file -> Components over domains
     ('void', '-'),                          # ranks that start empty, first arrivals by exchange()
     ('k4', '16,2'), ('k4', '32,4'),
