@@ -71,8 +71,15 @@ def main():
         test_gpu_fluid.test_mixed_pm_vs_oracle_random()
     elif case == 'random_configs':
         import test_gpu_fluid
+        import test_gpu_p3m
         for seed in range(int(arg)):
             test_gpu_fluid.test_random_configurations_vs_oracle(seed)
+        for seed in range(int(arg)):
+            try:
+                test_gpu_p3m.test_random_shortrange_vs_oracle(seed)
+            except Exception as e:  # a slab thinner than the force range is refused, not wrong
+                if 'too large for slabs of width' not in str(e):
+                    raise
     elif case == 'snapshot':
         import test_gpu_pp
         test_gpu_pp.test_gadget_snapshot_to_gpu_components(golden)

@@ -327,3 +327,51 @@ def test_adaptive_rungs_knot_across_domains():
     dx = np.abs(pos - pos_ref)
     assert np.minimum(dx, L - dx).max() <= 1e-12*L
     assert np.abs(mom - mom_ref).max() <= 1e-11*np.abs(mom_ref - mom0).max()
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_random_shortrange_vs_oracle(seed):
+    """Differential test of the short-range part of gravity('p3m') over its parameters (force
+    split scale, range, tile size, table size, softening kernel and length, particle number and
+    clustering) against the CPU oracle.  Also run over 2 and 4 domains."""
+    from concept_amd import commons, interactions
+    from concept_amd.species import Component
+    from oracle import oracle
+    rng = np.random.default_rng(2000 + seed)
+    L = float(rng.choice([32.0, 50.0]))
+    gs = int(rng.choice([32, 64]))
+    scale = float(rng.uniform(1.0, 1.5))*L/gs
+    range_ = float(rng.uniform(3.5, 5.0))*scale
+    tilesize = range_*float(rng.choice([1.0, 1.2]))
+    tablesize = int(rng.choice([1024, 4096]))
+    kernel = str(rng.choice(['spline', 'plummer', 'none']))
+    N = int(rng.integers(500, 4000))
+    pos = rng.uniform(0, L, (N, 3))
+    if rng.integers(0, 2):  # half of the particles in a blob
+        k = N//2
+        pos[:k] = (rng.uniform(0, L, 3) + rng.normal(0, 0.04*L, (k, 3))) % L
+    commons.load_params({
+        'boxsize': L, 'N_rungs': 1, 'softening_kernel': kernel,
+        'potential_options': {'gridsize': {'gravity': {'p3m': gs}}},
+        'select_forces': {'all': {'gravity': 'p3m'}},
+        'select_softening_length': {'all': f'{float(rng.uniform(0.01, 0.05))}*boxsize/cbrt(N)'},
+        'shortrange_params': {'gravity': {'scale': scale, 'range': range_, 'tilesize': tilesize,
+                                          'tablesize': tablesize}},
+    })
+    p = commons.params
+    mass = float(rng.uniform(0.5, 3.0))
+    c = Component('m', 'matter', N=N, mass=mass)
+    c.populate(pos, 'pos')
+    c.populate(np.zeros((N, 3)), 'mom')
+    integral = 0.37
+    c.nullify_Δ('mom')
+    interactions.gravity('p3m', [c], [c],
+                         {('a**(-3*w_eff₀-3*w_eff₁-1)', 'm', 'm'): np.full(2, integral)},
+                         'short-range', False)
+    factor = p.G_Newton*mass**2*integral
+    dm, _ = oracle.shortrange_kick(pos, boxsize=L, scale=scale, range_=range_, tilesize=tilesize,
+                                   tablesize=tablesize, softening=c.softening_length,
+                                   factor=factor, kernel=kernel)
+    got = c.host('Δmom')
+    ref_scale = max(np.abs(dm).max(), factor/scale**2)
+    assert np.abs(got - dm).max() <= 1e-11*ref_scale, (seed, kernel, scale, range_, tablesize, N)
