@@ -102,10 +102,16 @@ def _timeloop_streaming(components, n_steps, integrals, plan):
                 Δt_over_mass = (ᔑdt_drift['a**(-2)']/c.mass) if ᔑdt_drift is not None else 0.0
                 rp.kick_drift_sort(order, c.mass*(-ᔑdt_kick['a**(-3*w_eff)', c.name]),
                                    Δt_over_mass)
+            # On several domains: ship the leavers and seat the arrivals now (into the new
+            # buffer set), so that everything that can go wrong with this pass is known before
+            # the next one starts.
+            for rp in rps:
+                rp.finish_exchange()
             # The regions of the new order were sized from the present populations; a (tile,
-            # bucket) that grew beyond that in one step has dropped particles.  The pass wrote
-            # the other buffer set only: undo it and take the step on the exact path (the
-            # potential is still on the mesh), then go on streaming.
+            # bucket) that grew beyond that in one step — by the drift or by arrivals from other
+            # domains — or more leavers than the row buffer holds have dropped particles.  The
+            # pass and the exchange wrote the other buffer set only: undo them and take the step
+            # on the exact path (the potential is still on the mesh), then go on streaming.
             overflow = bool(mesh.error_flags()
                             & (lib.CG_ERR_BUCKET_OVERFLOW | lib.CG_ERR_NOT_IN_TILE))
             if mesh.comm is not None:

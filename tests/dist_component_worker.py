@@ -74,6 +74,9 @@ def main():
         import test_gpu_p3m
         for seed in range(int(arg)):
             test_gpu_fluid.test_random_configurations_vs_oracle(seed)
+        import test_gpu_pm
+        for seed in range(8):
+            test_gpu_pm.test_random_streaming_timeloops(torch, seed)
         for seed in range(int(arg)):
             try:
                 test_gpu_p3m.test_random_shortrange_vs_oracle(seed)

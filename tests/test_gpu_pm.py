@@ -1036,3 +1036,61 @@ def test_empty_particle_sets(torch_cuda):
     mesh.drift_sort(e3, e3.clone(), None, e3.clone(), e3.clone(), None, 0.1, mesh.new_tile_table())
     assert mesh.cic_indices(e3).shape == (0, 3)
     mesh.check_errors()
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_streaming_timeloops(torch_cuda, seed):
+    """stepper.timeloop in streaming form against the loop that calls gravity() and drift() one
+    after the other, over random draws: one to three components of different mass and
+    differentiation order, velocities from a fraction of a cell to several tiles per step
+    (region overflows are replayed), two to four steps.  Also run over 2 and 4 domains."""
+    from concept_amd import commons, stepper
+    from concept_amd.species import Component
+    rng = np.random.default_rng(3000 + seed)
+    L = float(rng.choice([32.0, 64.0]))
+    gs = int(rng.choice([32, 64]))
+    ncomp = int(rng.integers(1, 4))
+    names = ['a', 'b', 'c'][:ncomp]
+    orders = {nm: int(rng.choice([2, 4])) for nm in names}
+    commons.load_params({
+        'boxsize': L,
+        'potential_options': {'gridsize': {'gravity': {'pm': gs}},
+                              'differentiation': {nm: {'gravity': {'pm': o}}
+                                                  for nm, o in orders.items()}},
+        'select_forces': {'all': {'gravity': 'pm'}}})
+    d = float(rng.uniform(0.05, 0.3))
+    nsteps = int(rng.integers(2, 5))
+    data = []
+    for nm in names:
+        n = int(rng.integers(300, 5000))
+        mass = float(rng.uniform(0.5, 3.0))
+        pos = rng.uniform(0, L, (n, 3))
+        if rng.integers(0, 2):
+            pos[:n//2] = (rng.uniform(0, L, 3) + rng.normal(0, 0.05*L, (n//2, 3))) % L
+        speed = float(rng.choice([0.3, 3.0, 25.0]))*(L/gs)  # cells per step
+        mom = rng.normal(0, speed*mass/(1.2*d), (n, 3))
+        data.append((nm, n, mass, pos, mom))
+
+    def integrals(kind):
+        s = d/2 if kind == 'init' else d
+        out = {'1': s, 'a**(-2)': 1.2*d}
+        for nm in names:
+            out['a**(-3*w_eff)', nm] = 1.1*s
+            out['a**(-3*w_eff-1)', nm] = 0.9*s
+        return out
+
+    def run(stream):
+        comps = []
+        for nm, n, mass, pos, mom in data:
+            c = Component(nm, 'matter', N=n, mass=mass)
+            c.populate(pos, 'pos')
+            c.populate(mom, 'mom')
+            comps.append(c)
+        stepper.timeloop(comps, nsteps, integrals, None, None if stream else (lambda step: None))
+        return [(c.host('pos'), c.host('mom'), c.host('ids')) for c in comps]
+    for (p0, m0, i0), (p1, m1, i1), (nm, n, mass, pos, mom) in zip(run(False), run(True), data):
+        dd = np.abs(p0 - p1)
+        assert np.minimum(dd, L - dd).max() <= 1e-12*L, (seed, nm)
+        kick = np.abs(m0 - mom).max()
+        assert np.abs(m0 - m1).max() <= 1e-11*kick + 4e-16*np.abs(m0).max(), (seed, nm)
+        assert np.array_equal(i0, i1)
