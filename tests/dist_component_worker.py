@@ -77,6 +77,8 @@ def main():
         import test_gpu_pm
         for seed in range(8):
             test_gpu_pm.test_random_streaming_timeloops(torch, seed)
+        for seed in range(8):
+            test_gpu_p3m.test_random_p3m_timeloops_across_domains(seed)
         for seed in range(int(arg)):
             try:
                 test_gpu_p3m.test_random_shortrange_vs_oracle(seed)

@@ -375,3 +375,57 @@ def test_random_shortrange_vs_oracle(seed):
     got = c.host('Δmom')
     ref_scale = max(np.abs(dm).max(), factor/scale**2)
     assert np.abs(got - dm).max() <= 1e-11*ref_scale, (seed, kernel, scale, range_, tablesize, N)
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_random_p3m_timeloops_across_domains(seed):
+    """P3M time loops (long-range + short-range kicks, drift, exchange, tile sort) over random
+    draws of box, mesh, particle number, clustering and speed: several domains against the
+    single-domain run of the same calls.  (On one domain: the run against itself;
+    tests/test_gpu_distributed.py runs it on 2 and 4.)"""
+    from concept_amd import comm, commons, stepper
+    from concept_amd.species import Component
+    rng = np.random.default_rng(4000 + seed)
+    L = float(rng.choice([48.0, 64.0]))
+    gs = int(rng.choice([32, 64]))  # (several domains: power-of-two meshes)
+    n = int(rng.integers(1000, 6000))
+    mass, d = float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.05, 0.3))
+    nsteps = int(rng.integers(1, 4))
+    pos0 = rng.uniform(0, L, (n, 3))
+    kind = int(rng.integers(0, 3))
+    if kind == 1:    # half in a blob
+        pos0[:n//2] = (rng.uniform(0, L, 3) + rng.normal(0, 0.05*L, (n//2, 3))) % L
+    elif kind == 2:  # everything in a slab along x (most domains start empty)
+        pos0[:, 0] = (rng.uniform(0, L) + rng.uniform(0, L/6, n)) % L
+    speed = float(rng.choice([0.2, 1.5, 4.0]))*(L/gs)
+    mom0 = rng.normal(0, speed*mass/d, (n, 3))
+
+    def integrals(kind):
+        s = d/2 if kind == 'init' else d
+        return {'1': s, 'a**(-2)': d, ('a**(-3*w_eff)', 'm'): s, ('a**(-3*w_eff-1)', 'm'): s}
+
+    def rung_integrals(kind):
+        s = d/2 if kind == 'init' else d
+        return {('a**(-3*w_eff₀-3*w_eff₁-1)', 'm', 'm'): np.full(2, s)}
+
+    def run():
+        commons.load_params({'boxsize': L, 'N_rungs': 1,
+                             'potential_options': {'gridsize': {'gravity': {'p3m': gs}}},
+                             'select_forces': {'all': {'gravity': 'p3m'}}})
+        c = Component('m', 'matter', N=n, mass=mass)
+        c.populate(pos0, 'pos')
+        c.populate(mom0, 'mom')
+        stepper.timeloop([c], nsteps, integrals, rung_integrals)
+        return c.host('pos'), c.host('mom'), c.host('ids')
+    active = comm.active()
+    if active is not None:
+        comm.shutdown()
+    pos_ref, mom_ref, ids_ref = run()
+    if active is not None:
+        comm.init()
+    pos, mom, ids = run()
+    assert np.array_equal(ids, ids_ref)
+    dx = np.abs(pos - pos_ref)
+    assert np.minimum(dx, L - dx).max() <= 1e-12*L, seed
+    kick = np.abs(mom_ref - mom0).max()
+    assert np.abs(mom - mom_ref).max() <= 1e-11*kick + 4e-16*np.abs(mom_ref).max(), seed
