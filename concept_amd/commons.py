@@ -104,22 +104,41 @@ def load_params(source=None, **overrides):
             with open(source, encoding='utf-8') as f:
                 text = f.read()
         ns = dict(units)
-        ns.update(π=π, pi=π, τ=τ, ထ=ထ, inf=ထ, sqrt=math.sqrt, cbrt=np.cbrt, h=1.0,
-                  param=types.SimpleNamespace(dir='.', path='.'))
-        lines = text.split('\n')
+        ns.update(π=π, pi=π, τ=τ, ထ=ထ, inf=ထ, sqrt=math.sqrt, cbrt=np.cbrt, h=1.0)
         # the reference executes the file repeatedly until all names resolve
-        # (commons.py:2001-2040); two whole-file passes with per-statement
-        # tolerance cover the names this path reads.
+        # (commons.py:2001-2040); here: the whole file, else statement by statement (whole
+        # statements — dict literals span many lines — skipping those that use names outside
+        # this path: output paths, CLASS, ...), twice, so that later definitions reach earlier
+        # uses.  `path` and `param` (directories and the parameter file's own name in the
+        # reference) resolve to placeholders.
+        class _Placeholder(str):
+            def __getattr__(self, name):
+                return _Placeholder(name)
+        ns.setdefault('path', _Placeholder('path'))
+        if not isinstance(source, str) or '\n' in source or '=' in source:
+            ns['param'] = _Placeholder('param')
+        else:
+            ns['param'] = _Placeholder(source)
+        import ast
+        try:
+            statements = [ast.get_source_segment(text, node) for node in ast.parse(text).body]
+        except SyntaxError:
+            statements = text.split('\n')
         for _ in range(2):
             try:
                 exec(text, ns)
-                break
             except Exception:
-                for ln in lines:
+                for st in statements:
                     try:
-                        exec(ln, ns)
+                        exec(st, ns)
                     except Exception:
                         pass
+            # h follows H0 (commons.py:1790-1792); a file that uses it (boxsize = 200*Mpc/h)
+            # before defining H0 gets it right on the second pass
+            h_new = ns['H0']/(100*ns['km']/(ns['s']*ns['Mpc'])) if 'H0' in ns else 1.0
+            if h_new == ns['h']:
+                break
+            ns['h'] = h_new
         user.update({k: v for k, v in ns.items() if not k.startswith('__')})
     user.update(overrides)
     p = Params()
@@ -148,6 +167,17 @@ def load_params(source=None, **overrides):
     if isinstance(diff, dict):
         for name, d in diff.items():
             p.potential_options['differentiation'][name] = _method_dict(d, 2, 4)
+    # 'fourier' = differentiation in Fourier space, encoded as order 0 (commons.py:3220-3233)
+    for name, d0 in p.potential_options['differentiation'].items():
+        for force, d1 in d0.items():
+            for m, v in d1.items():
+                if isinstance(v, str):
+                    if v.lower() != 'fourier':
+                        raise ValueError(
+                            f'Invalid potential_options["differentiation"] value {v}')
+                    d1[m] = 0
+                else:
+                    d1[m] = int(round(v))
     # component-level (upstream, downstream) grid sizes: every key of
     # potential_options['gridsize'] other than 'global' selects components
     # (commons.py:3095-3207; looked up with is_selected in species.py:1147-1160)

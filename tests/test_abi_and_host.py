@@ -162,3 +162,43 @@ def test_select_forces_forms_and_defaults():
     # vertex-centred grids keep one more ghost layer (commons.py:4411-4419)
     assert commons.load_params({'cell_centered': False}).nghosts == 3
     assert commons.load_params({}).nghosts == 2
+
+
+def test_parameter_file_with_foreign_names_and_late_definitions():
+    """A parameter file in the style of the reference's param/example_*: names of other
+    subsystems (`path`, `param`, CLASS settings), multi-line dict literals, `h` used before H0
+    is defined, Fourier-space differentiation by name.  What the gravity path reads must come
+    out; the rest is ignored."""
+    from concept_amd import commons
+    text = '''
+_n = 48
+initial_conditions = {'species': 'matter', 'N': _n**3}
+output_dirs = {'powerspec': f'{path.output_dir}/{param}'}
+output_times = {'powerspec': logspace(log10(a_begin), log10(1), 3)}
+boxsize = 300*Mpc/h
+potential_options = {
+    'gridsize': {
+        'global': {
+            'gravity': {
+                'pm' : _n//2,
+                'p3m': 2*_n,
+            },
+        },
+    },
+    'differentiation': {
+        'all': {'gravity': {'pm': 'Fourier', 'p3m': 4}},
+    },
+}
+H0 = 75*km/(s*Mpc)
+a_begin = 0.02
+class_params = {'N_ncdm': 1, 'm_ncdm': 0.1}
+shortrange_params = {'gravity': {'scale': '1.1*boxsize/gridsize', 'range': '4.8*scale'}}
+'''
+    p = commons.load_params(text)
+    assert abs(p.boxsize - 400.0) < 1e-9                      # h = 0.75 from the later H0
+    assert p.potential_options['gridsize']['global']['gravity'] == {'pm': 24, 'p3m': 96}
+    assert p.potential_options['differentiation']['all']['gravity'] == {'pm': 0, 'p3m': 4}
+    assert p.select_forces == {'particles': {'gravity': 'p3m'}, 'fluid': {'gravity': 'pm'}}
+    sr = commons.resolve_shortrange(p, 96)
+    assert abs(sr['scale'] - 1.1*400.0/96) < 1e-12 and abs(sr['range'] - 4.8*sr['scale']) < 1e-12
+    assert p.nghosts == 2
