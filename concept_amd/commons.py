@@ -90,6 +90,14 @@ def _method_dict(user, default_pm, default_p3m):
     return out
 
 
+_PATH_PARAMETERS = ('G_Newton', 'N_rungs', 'boxsize', 'cell_centered', 'ewald_gridsize', 'nghosts',
+                    'potential_options', 'select_forces', 'select_softening_length',
+                    'shortrange_params', 'softening_kernel', 'H0', 'Ωb', 'Ωcdm', 'a_begin',
+                    'enable_Hubble', 'Δt_base_background_factor', 'Δt_base_nonlinear_factor',
+                    'Δt_increase_max_factor', 'Δt_rung_factor', 'Δa_max_early', 'Δa_max_late',
+                    'static_timestepping')
+
+
 def load_params(source=None, **overrides):
     """`source`: path to a parameter file, parameter text, a dict, or None.
     Returns a Params object and makes it the active one (`commons.params`)."""
@@ -124,21 +132,34 @@ def load_params(source=None, **overrides):
             statements = [ast.get_source_segment(text, node) for node in ast.parse(text).body]
         except SyntaxError:
             statements = text.split('\n')
-        for _ in range(2):
+        # passes until nothing changes any more: a statement that failed may succeed once a
+        # later one has defined the name it uses (forward references), and h follows H0
+        # (commons.py:1790-1792): a file that uses it (boxsize = 200*Mpc/h) before defining H0
+        # gets it right on the next pass
+        failed_prev = None
+        for _ in range(16):
+            failed = set()
             try:
                 exec(text, ns)
             except Exception:
-                for st in statements:
+                for i, st in enumerate(statements):
                     try:
                         exec(st, ns)
                     except Exception:
-                        pass
-            # h follows H0 (commons.py:1790-1792); a file that uses it (boxsize = 200*Mpc/h)
-            # before defining H0 gets it right on the second pass
+                        failed.add(i)
             h_new = ns['H0']/(100*ns['km']/(ns['s']*ns['Mpc'])) if 'H0' in ns else 1.0
-            if h_new == ns['h']:
-                break
+            h_same = (h_new == ns['h'])
             ns['h'] = h_new
+            if h_same and (not failed or failed == failed_prev):
+                break
+            failed_prev = failed
+        # a statement of this path's own parameters that never ran must not pass silently
+        for i in sorted(failed):
+            target = statements[i].split('=')[0].strip()
+            if target in _PATH_PARAMETERS:
+                import warnings
+                warnings.warn(f'parameter file: the statement assigning {target!r} could not '
+                              f'be executed; its default is used')
         user.update({k: v for k, v in ns.items() if not k.startswith('__')})
     user.update(overrides)
     p = Params()

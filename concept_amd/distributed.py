@@ -482,7 +482,10 @@ def ship_boundary_positions(mesh, pos, margin):
     L, N = mesh.boxsize, mesh.gridsize
     cell = L/N
     slab_w = mesh.nxl*cell
-    xlo = (mesh.x0 + 0.5)*cell   # lower CIC cell in [x0, x0 + nxl)  <=>  x in [xlo, xlo + slab_w)
+    # lower CIC cell in [x0, x0 + nxl)  <=>  x in [xlo, xlo + slab_w); the CIC index map is
+    # floor(x/cell - 0.5) on cell-centred grids and floor(x/cell) on vertex-centred ones
+    # (the ownership rule of cg_owner_rank / geom_deposit)
+    xlo = (mesh.x0 + 0.5*mesh.cell_centered)*cell
     rel = torch.remainder(pos[:, 0] - xlo, L)
     to_prev = pos[rel < margin]
     to_next = pos[rel >= slab_w - margin]

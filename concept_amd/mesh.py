@@ -38,6 +38,7 @@ class PotentialMesh:
         self.gridsize = int(gridsize)
         self.boxsize = float(boxsize)
         self.nghosts = int(nghosts)
+        self.cell_centered = int(bool(cell_centered))
         p = cg_params()
         p.boxsize = self.boxsize
         p.gridsize = self.gridsize

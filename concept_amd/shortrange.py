@@ -127,7 +127,9 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
     for c in involved:
         cells[id(c)] = mesh.shortrange_cells(c.pos, nt, tile_extent)
         supp_pos[id(c)], supp_cells[id(c)] = c.pos, cells[id(c)]
-        if multi and any(c is s_ for s_ in suppliers):
+        # every involved component can act as supplier: s of sweep(r, s), and r of the
+        # reciprocal sweep(s, r) when s is also a receiver
+        if multi:
             ghosts = ship_boundary_positions(c._store.mesh, c.pos,
                                              sr['range']*(1 + 1e-9) + slack + 1e-9*p.boxsize)
             # rows 0..N_local-1 ARE the component's own particles (the sweep's `same`

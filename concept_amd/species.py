@@ -146,10 +146,14 @@ class Component:
         self.tile_sort(mesh)
         return RegionParticles(self._store)
 
-    def from_regions(self, rp):
+    def from_regions(self, rp, collective=True):
         """Take the particles back from their streaming form (pos, mom, ids, order; Δmom and
-        rung columns start from zero as after populate())."""
+        rung columns start from zero as after populate()).  collective=False (unwinding from an
+        exception on one rank): the exchange still pending from the last pass — a collective —
+        is abandoned, its leavers with it."""
         from .distributed import ParticleStore
+        if not collective:
+            rp.pending = False
         cols = rp.columns()
         old = self._store
         self._store = ParticleStore(old.mesh, cols['pos'], cols['mom'], None, slack=1.4,
@@ -259,22 +263,22 @@ class Component:
                 self.pos.copy_(t[rows])
                 self.order.copy_(rows)   # global row numbers: host() reassembles by them
                 self.ids.copy_(rows)
-                self._global_rows = rows
+                self._rows_known = True
                 for data_, var_ in self.__dict__.pop('_pending_other', []):
                     self.populate(data_, var_)
                 return
-            if getattr(self, '_global_rows', None) is None:
+            if not getattr(self, '_rows_known', False):
                 # the positions decide which rows are local: keep this until they are complete
                 self.__dict__.setdefault('_pending_other', []).append((t, var))
                 return
-            t = t.to(self.device)[self._global_rows]
+        # the caller's row i is the local row whose `order` entry is i: `order` travels with
+        # the particles through tile_sort, exchange() and the streaming loop, so data populated
+        # after any of them still lands on the right particles (fresh arrays: the identity)
+        t = t.to(self.device)[self.order]
         if var.startswith('pos'):
             self.tile_mesh = None
             self.tiles_exact = False
             self._store.touch_mom()
-            # new positions arrive in the caller's order: rows are "as populated" again
-            if self.nprocs == 1:
-                self.order.copy_(torch.arange(self.N, dtype=torch.int64, device=self.device))
         if var.startswith('mom'):
             self._store.touch_mom()
         if var in ('pos', 'mom'):
@@ -302,7 +306,7 @@ class Component:
         base = torch.arange(first, first + n, dtype=torch.int64, device=self.device)
         self.order.copy_(base)
         self.ids.copy_(base if ids is None else ids)
-        self._global_rows = None
+        self._rows_known = True
         self.exchange()
 
     def w_eff(self, a=1.0):

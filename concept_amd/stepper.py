@@ -112,8 +112,14 @@ def _timeloop_streaming(components, n_steps, integrals, plan):
             # domains — or more leavers than the row buffer holds have dropped particles.  The
             # pass and the exchange wrote the other buffer set only: undo them and take the step
             # on the exact path (the potential is still on the mesh), then go on streaming.
-            overflow = bool(mesh.error_flags()
-                            & (lib.CG_ERR_BUCKET_OVERFLOW | lib.CG_ERR_NOT_IN_TILE))
+            flags = mesh.error_flags()   # reads AND clears the sticky bits
+            other = flags & ~(lib.CG_ERR_BUCKET_OVERFLOW | lib.CG_ERR_NOT_IN_TILE)
+            if other:
+                # e.g. CG_ERR_STALE_HISTOGRAM of a drift_sort on the replay path: that sort has
+                # dropped particles, nothing to recover from here
+                raise ConceptGPUError(f'streaming time loop: device error flags {other:#x} '
+                                      f'in step {step}')
+            overflow = bool(flags & (lib.CG_ERR_BUCKET_OVERFLOW | lib.CG_ERR_NOT_IN_TILE))
             if mesh.comm is not None:
                 overflow = mesh.comm.any(overflow)
             if overflow:
@@ -127,9 +133,17 @@ def _timeloop_streaming(components, n_steps, integrals, plan):
                     if ᔑdt_drift is not None:
                         c.drift_sort(ᔑdt_drift, mesh=mesh)
                     rps[i] = c.to_regions(mesh)
-    finally:
+    except BaseException:
+        # unwinding: hand the particles back without the collective part of from_regions (the
+        # other domains may not be unwinding), then let the exception travel
         for c, rp in zip(components, rps):
-            c.from_regions(rp)
+            try:
+                c.from_regions(rp, collective=False)
+            except Exception:
+                pass
+        raise
+    for c, rp in zip(components, rps):
+        c.from_regions(rp)
 
 
 # ---------------------------------------------------------------------------

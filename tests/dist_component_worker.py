@@ -85,6 +85,10 @@ def main():
             except Exception as e:  # a slab thinner than the force range is refused, not wrong
                 if 'too large for slabs of width' not in str(e):
                     raise
+    elif case == 'advice':
+        import test_gpu_p3m
+        test_gpu_p3m.test_shortrange_two_components_receivers_not_suppliers(arg == 'cell')
+        test_gpu_p3m.test_populate_after_sort_lands_on_the_right_particles()
     elif case == 'snapshot':
         import test_gpu_pp
         test_gpu_pp.test_gadget_snapshot_to_gpu_components(golden)

@@ -219,6 +219,9 @@ COMPONENT_CASES = [
     ('snapshot', '-'),                      # GADGET file -> Components over domains
     ('void', '-'),                          # ranks that start empty, first arrivals by exchange()
     ('k4', '16,2'), ('k4', '32,4'),
+    # receivers not among the suppliers; slab faces of vertex-centred grids; populate() after
+    # the rows have moved
+    ('advice', 'cell'), ('advice', 'vertex'),
 ]
 
 

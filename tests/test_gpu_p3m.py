@@ -199,36 +199,61 @@ def test_timeloop_sequence_vs_reference(golden, name):
     assert c2.N_local == c.N_local
 
 
-def test_config3_size_shortrange_properties():
+def _config3_positions(torch, dist, n, L, gen):
+    pos = torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=gen)
+    if dist == 'clustered':  # bench.py --dist clustered: 80 % in 64 Gaussian blobs, σ = L/40
+        centres = torch.rand((64, 3), dtype=torch.float64, device='cuda', generator=gen)*L
+        which = torch.randint(0, 64, (n,), device='cuda', generator=gen)
+        blob = centres[which] + torch.randn((n, 3), dtype=torch.float64, device='cuda',
+                                            generator=gen)*(L/40)
+        keep = torch.rand(n, dtype=torch.float64, device='cuda', generator=gen) < 0.2
+        pos = torch.where(keep[:, None], pos*L, torch.remainder(blob, L))
+        return pos.clamp_(0.0, L*(1 - 1e-13)).contiguous()
+    return pos*(L*(1 - 1e-13))
+
+
+@pytest.mark.parametrize('dist', ['uniform', 'clustered'])
+def test_config3_size_shortrange_properties(dist):
     """BASELINE configs[2] size (256^3 particles, 512^3 mesh, default short-range
-    parameters): the one-sided sweep conserves momentum (Newton's third law holds pair
-    by pair because both directions of a pair evaluate bit-identical r2 and table
-    entries), and is invariant under a permutation of the particle memory."""
+    parameters) through the sweep bench.py --p3m and shortrange.component_component run
+    (cg_shortrange_cells + cg_shortrange_sweep_cells: half-tile cells), for the uniform and
+    the clustered box of the bench: the one-sided sweep conserves momentum (Newton's third
+    law holds pair by pair because both directions of a pair evaluate bit-identical r2 and
+    table entries), is invariant under a permutation of the particle memory, and equals the
+    round-1 sweep (one wavefront per tile, cg_shortrange_build + cg_shortrange_sweep: A/B of
+    two independent pair enumerations) to summation order."""
     import torch
     from concept_amd import commons, shortrange
     from concept_amd.mesh import PotentialMesh
     N, L, n = 512, 512.0, 256**3
     mesh = PotentialMesh(N, L)
     gen = torch.Generator(device='cuda').manual_seed(8)
-    pos = torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=gen)*(L*(1 - 1e-13))
+    pos = _config3_positions(torch, dist, n, L, gen)
     scale = 1.25*L/N
     rng_ = 4.5*scale
     nt = int(L/rng_*(1 + commons.machine_ϵ))
     table, maxr2 = shortrange.get_shortrange_table(0.025*L/256, scale, rng_, 4096, 'spline',
                                                    pos.device)
     dm = torch.zeros_like(pos)
-    cells = mesh.shortrange_build(pos, nt, L/nt)
-    mesh.shortrange_sweep(pos, cells, dm, pos, cells, nt, True, table, 4095/maxr2, rng_**2, 1.0)
+    cells = mesh.shortrange_cells(pos, nt, L/nt)
+    mesh.shortrange_sweep_cells(cells, dm, cells, nt, table, 4095/maxr2, rng_**2, 1.0)
     scale_f = float(dm.abs().max())
     assert scale_f > 0
     assert float(dm.sum(0).abs().max()) <= 1e-9*float(dm.abs().sum(0).max())
+    # A/B: the round-1 sweep
+    dm1 = torch.zeros_like(pos)
+    cells1 = mesh.shortrange_build(pos, nt, L/nt)
+    mesh.shortrange_sweep(pos, cells1, dm1, pos, cells1, nt, True, table, 4095/maxr2, rng_**2,
+                          1.0)
+    assert float((dm1 - dm).abs().max()) <= 1e-11*scale_f
+    del dm1, cells1
     perm = torch.randperm(n, device='cuda', generator=gen)
     pos2 = pos[perm].contiguous()
     dm2 = torch.zeros_like(pos2)
-    cells2 = mesh.shortrange_build(pos2, nt, L/nt)
-    mesh.shortrange_sweep(pos2, cells2, dm2, pos2, cells2, nt, True, table, 4095/maxr2, rng_**2,
-                          1.0)
+    cells2 = mesh.shortrange_cells(pos2, nt, L/nt)
+    mesh.shortrange_sweep_cells(cells2, dm2, cells2, nt, table, 4095/maxr2, rng_**2, 1.0)
     assert float((dm2 - dm[perm]).abs().max()) <= 1e-12*scale_f
+    mesh.close()
 
 
 def test_adaptive_rungs_vs_reference(golden):
@@ -429,3 +454,97 @@ def test_random_p3m_timeloops_across_domains(seed):
     assert np.minimum(dx, L - dx).max() <= 1e-12*L, seed
     kick = np.abs(mom_ref - mom0).max()
     assert np.abs(mom - mom_ref).max() <= 1e-11*kick + 4e-16*np.abs(mom_ref).max(), seed
+
+
+@pytest.mark.parametrize('cell_centered', [True, False])
+def test_shortrange_two_components_receivers_not_suppliers(cell_centered):
+    """gravity('p3m', [A, B], [B], 'short-range'): A is kicked by B, and B — a receiver too —
+    by itself and, reciprocally, by A, which is NOT among the suppliers (gravity.py:341-349
+    kicks both partners of a pair).  On several domains A's boundary particles therefore have
+    to travel as well, and the slab faces follow the grid's centring (vertex-
+    centred: [x0*cell, (x0 + nxl)*cell)).  Checked against the oracle on the union
+    (equal masses and softening: the kicks are linear in the supplier set) and, on several
+    domains, against the single-domain run."""
+    from concept_amd import comm, commons, interactions
+    from concept_amd.species import Component
+    from oracle import oracle
+    rng = np.random.default_rng(77)
+    L, gs, nA, nB = 64.0, 64, 3000, 2500
+    # particles crowd the slab faces of a 4-domain run (x = 0, 16, 32, 48 cells, and half a cell
+    # above: the faces of the cell-centred grid)
+    def cloud(n):
+        pos = rng.uniform(0, L, (n, 3))
+        k = n//2
+        pos[:k, 0] = (rng.choice([0.0, 16.0, 32.0, 48.0], k) + rng.uniform(-0.2, 0.8, k)) % L
+        return pos
+    posA, posB = cloud(nA), cloud(nB)
+    integral, mass = 0.41, 1.7
+
+    def run():
+        commons.load_params({
+            'boxsize': L, 'N_rungs': 1, 'cell_centered': cell_centered,
+            'potential_options': {'gridsize': {'gravity': {'p3m': gs}}},
+            'select_forces': {'all': {'gravity': 'p3m'}},
+            'select_softening_length': {'all': 0.02}})
+        A = Component('A', 'matter', N=nA, mass=mass)
+        B = Component('B', 'matter', N=nB, mass=mass)
+        for c, pos in ((A, posA), (B, posB)):
+            c.populate(pos, 'pos')
+            c.populate(np.zeros_like(pos), 'mom')
+            c.nullify_Δ('mom')
+        key = 'a**(-3*w_eff₀-3*w_eff₁-1)'
+        sdt = {(key, x, y): np.full(2, integral) for x in 'AB' for y in 'AB'}
+        interactions.gravity('p3m', [A, B], [B], sdt, 'short-range', False)
+        return A.host('Δmom'), B.host('Δmom'), commons.params
+    dA, dB, p = run()
+    sr = commons.resolve_shortrange(p, gs)
+    factor = p.G_Newton*mass**2*integral
+    kw = dict(boxsize=L, scale=sr['scale'], range_=sr['range'], tilesize=sr['tilesize'],
+              tablesize=sr['tablesize'], softening=0.02, factor=factor, kernel='spline')
+    both, _ = oracle.shortrange_kick(np.concatenate([posA, posB]), **kw)
+    onlyA, _ = oracle.shortrange_kick(posA, **kw)
+    scale = max(np.abs(both).max(), factor/sr['scale']**2)
+    assert np.abs(dA - (both[:nA] - onlyA)).max() <= 1e-11*scale   # A by B
+    assert np.abs(dB - both[nA:]).max() <= 1e-11*scale             # B by A and B
+    active = comm.active()
+    if active is not None and active.world > 1:
+        comm.shutdown()
+        try:
+            sA, sB, _ = run()
+        finally:
+            comm.init()
+        assert np.abs(dA - sA).max() <= 1e-12*scale
+        assert np.abs(dB - sB).max() <= 1e-12*scale
+
+
+def test_populate_after_sort_lands_on_the_right_particles():
+    """populate() of further columns after the particles have been reordered (tile_sort, a
+    drift with its exchange, the streaming loop): data is given in the caller's row order and
+    must reach the particles that stood in those rows (species.py populate)."""
+    from concept_amd import commons
+    from concept_amd.species import Component
+    rng = np.random.default_rng(5)
+    L, n = 32.0, 4000
+    commons.load_params({'boxsize': L, 'potential_options': {'gridsize': {'gravity': {'pm': 32}}},
+                         'select_forces': {'all': {'gravity': 'pm'}}})
+    c = Component('m', 'matter', N=n, mass=1.0)
+    pos, mom = rng.uniform(0, L, (n, 3)), rng.normal(0, 1, (n, 3))
+    c.populate(pos, 'pos')
+    c.populate(mom, 'mom')
+    c.drift({'a**(-2)': 0.7})
+    c.tile_sort()
+    mom2 = rng.normal(0, 1, (n, 3))
+    c.populate(mom2[:, 1], 'momy')
+    c.populate(np.arange(n)[::-1].copy(), 'ids')
+    want = mom.copy()
+    want[:, 1] = mom2[:, 1]
+    assert np.array_equal(c.host('mom'), want)
+    assert np.array_equal(c.host('ids'), np.arange(n)[::-1])
+    assert np.array_equal(c.host('pos'), (pos + mom*0.7) % L)
+    # new positions for the same rows: the other columns stay with their rows
+    pos2 = rng.uniform(0, L, (n, 3))
+    c.populate(pos2[:, 0], 'posx')
+    if c.nprocs == 1:
+        got = c.host('pos')
+        assert np.array_equal(got[:, 0], pos2[:, 0])
+        assert np.array_equal(c.host('mom'), want)
