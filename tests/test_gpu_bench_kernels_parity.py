@@ -196,11 +196,12 @@ def test_fused_pass_north_star_size_properties(torch_cuda):
     start, count = table[:mesh.table_entries], None
     tabs = [mesh.new_region_table(), mesh.new_region_table()]
     C = -L**2/np.pi
+    contribution = mass*float(N)**(-3)*(N/L)**3   # bench.py's (G = 1)
     for step in range(2):
         if count is None:
-            mesh.deposit_tiled(pos[:n], table, 1.0, accumulate=False)
+            mesh.deposit_tiled(pos[:n], table, contribution, accumulate=False)
         else:
-            mesh.deposit_regions(pos, start, count, 1.0)
+            mesh.deposit_regions(pos, start, count, contribution)
         # mass conservation of the deposit from (gapped) regions
         per = mesh.layer_doubles
         rows = per//mesh.pad
@@ -210,7 +211,7 @@ def test_fused_pass_north_star_size_properties(torch_cuda):
             mesh.layers_read(l0, 64, buf)
             tot += float(buf.view(64, rows, mesh.pad)[:, :N, :N].sum())
         del buf
-        assert abs(tot - n) <= 1e-9*n
+        assert abs(tot - n*contribution) <= 1e-9*n*contribution
         mesh.poisson_solve(4, C, False, 0.0)
         start_out, count_out = tabs[step]
         mesh.predict_regions(start, count, start_out)
@@ -252,7 +253,7 @@ def test_fused_pass_north_star_size_properties(torch_cuda):
     # a third pass from the gapped regions with the momenta at zero and no drift: what it
     # stores are the kicks themselves — the mesh force transfers no net momentum — and the
     # positions come through unchanged, in the same regions
-    mesh.deposit_regions(pos, start, count, 1.0)
+    mesh.deposit_regions(pos, start, count, contribution)
     mesh.poisson_solve(4, C, False, 0.0)
     mom.zero_()
     start_out, count_out = mesh.new_region_table()
