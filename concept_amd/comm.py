@@ -136,6 +136,16 @@ class Comm:
         dist.all_gather(out, t, group=self.group)
         return torch.stack(out).cpu()
 
+    def all_gather_floats(self, values):
+        """float64 [world, len(values)] of host numbers, in rank order (every rank gets the
+        same array: a sum over it is the same on every rank, bit for bit)"""
+        t = torch.tensor(values, dtype=torch.float64)
+        if not self.stage:
+            t = t.cuda()
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return torch.stack(out).cpu()
+
     def all_gather_rows(self, t):
         """Concatenation over the ranks (in rank order) of tensors that differ in their first
         dimension only; returned on t's device."""

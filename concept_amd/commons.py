@@ -95,7 +95,7 @@ _PATH_PARAMETERS = ('G_Newton', 'N_rungs', 'boxsize', 'cell_centered', 'ewald_gr
                     'shortrange_params', 'softening_kernel', 'H0', 'Ωb', 'Ωcdm', 'a_begin',
                     'enable_Hubble', 'Δt_base_background_factor', 'Δt_base_nonlinear_factor',
                     'Δt_increase_max_factor', 'Δt_rung_factor', 'Δa_max_early', 'Δa_max_late',
-                    'static_timestepping')
+                    'static_timestepping', 'output_times', 't_begin')
 
 
 def load_params(source=None, **overrides):
@@ -283,6 +283,57 @@ def load_params(source=None, **overrides):
         for force, d1 in d0.items():
             nghosts = max(nghosts, (max(d1.values()) + 1)//2)
     p.nghosts = int(user.get('nghosts', nghosts))
+    # cosmology and time stepping (commons.py:3630-3638, 3875-3890, 4313-4319, 4435-4479)
+    u = p.units
+    p.H0 = float(user.get('H0', 67*u.km/(u.s*u.Mpc)))
+    p.Ωb = float(user.get('Ωb', 0.049))
+    p.Ωcdm = float(user.get('Ωcdm', 0.27))
+    p.Ωm = p.Ωb + p.Ωcdm
+    p.a_begin = float(user.get('a_begin', 1))
+    p.t_begin = float(user.get('t_begin', 0))
+    p.enable_Hubble = bool(user.get('enable_Hubble', True))
+    p.ρ_crit = 3*p.H0**2/(8*π*p.G_Newton)
+    p.ρ_mbar = p.Ωm*p.ρ_crit
+    p.Δt_base_background_factor = float(user.get('Δt_base_background_factor', 1))
+    p.Δt_base_nonlinear_factor = float(user.get('Δt_base_nonlinear_factor', 1))
+    p.Δt_increase_max_factor = float(user.get('Δt_increase_max_factor', ထ))
+    p.Δt_rung_factor = float(user.get('Δt_rung_factor', 1))
+    p.Δa_max_early = float(user.get('Δa_max_early', 0.00153))
+    p.Δa_max_late = float(user.get('Δa_max_late', 0.022))
+    p.static_timestepping = user.get('static_timestepping') or None
+    if p.Δt_increase_max_factor <= 1:
+        raise ValueError('You must have Δt_increase_max_factor > 1')
+    if p.Δa_max_early < 0:
+        raise ValueError('You must have Δa_max_early ≥ 0')
+    if p.Δa_max_late <= 0:
+        raise ValueError('You must have Δa_max_late > 0')
+    if p.static_timestepping is not None and not p.enable_Hubble:
+        raise ValueError('You may not specify static_timestepping with the Hubble expansion '
+                         'disabled')
+    # output_times (commons.py: {'a': {kind: (...)}, 't': {kind: (...)}}): the dump times of the
+    # time loop.  Accepted: {kind: times} (scale factors when the Hubble expansion is enabled,
+    # cosmic times otherwise), {'a': ..., 't': ...} with {kind: times} or plain times inside.
+    def _times(v):
+        if v is None:
+            return ()
+        if isinstance(v, dict):
+            out = []
+            for w in v.values():
+                out += list(_times(w))
+            return tuple(out)
+        if isinstance(v, (int, float)):
+            return (float(v),)
+        return tuple(float(x) for x in v)
+    ot = user.get('output_times') or {}
+    default_param = 'a' if p.enable_Hubble else 't'
+    p.output_times = {'a': (), 't': ()}
+    if isinstance(ot, dict) and set(ot) & {'a', 't'}:
+        for tp in ('a', 't'):
+            p.output_times[tp] = _times(ot.get(tp))
+        rest = {k: v for k, v in ot.items() if k not in ('a', 't')}
+        p.output_times[default_param] += _times(rest)
+    else:
+        p.output_times[default_param] = _times(ot)
     p.user = user
     params = p
     return p

@@ -562,6 +562,13 @@ extern "C" int cg_drift(cg_ctx *c, double *pos, const double *mom, int64_t n,
     return cgk_drift(c, pos, mom, n, dt_over_mass);
 }
 
+extern "C" int cg_measure_momentum(cg_ctx *c, const double *mom, int64_t n, double *out,
+                                   double *scratch) {
+    CG_CHECK(c && out && scratch && (mom || n == 0), "cg_measure_momentum: null argument");
+    CG_CHECK(n >= 0, "cg_measure_momentum: n out of range");
+    return cgk_measure_mom(c, mom, n, out, scratch);
+}
+
 extern "C" int cg_tile_info(const cg_ctx *c, int64_t info[3]) {
     CG_CHECK(c && info, "cg_tile_info: null argument");
     info[0] = c->tiles.tx;

@@ -52,6 +52,73 @@ int cgk_drift(cg_ctx *c, double *pos, const double *mom, i64 n, double dt_over_m
 }
 
 // ---------------------------------------------------------------------------
+// measure(component, 'v_rms' | 'v_max') of a particle component (analysis.py:3902-3910,
+// 3965-3972): sum of mom[r]^2 over all 3N reals and the largest |mom_i|^2 of a particle — the
+// inputs of the time loop's PM / P3M step-size limiters (main.py:842-912).  Two stages so that
+// the sum has a fixed order (bit-reproducible): kMeasureBlocks workgroups each reduce a
+// contiguous share to one partial, one workgroup adds the partials in index order.
+// ---------------------------------------------------------------------------
+constexpr int kMeasureBlocks = 1024;
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off));
+    return v;
+}
+__global__ __launch_bounds__(256) void k_measure_mom(const double *__restrict__ mom, i64 n,
+                                                     double *__restrict__ partial) {
+    __shared__ double s_sum[4], s_max[4];
+    const i64 per = (n + gridDim.x - 1) / gridDim.x;
+    const i64 p0 = (i64)blockIdx.x * per, p1 = p0 + per < n ? p0 + per : n;
+    double sum = 0, mx = 0;
+    for (i64 p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        double x = mom[3 * p], y = mom[3 * p + 1], z = mom[3 * p + 2];
+        double m2 = x * x + y * y + z * z;
+        sum += m2;
+        mx = fmax(mx, m2);
+    }
+    sum = wave_sum(sum);
+    mx = wave_max(mx);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_sum[w] = sum;
+        s_max[w] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        partial[2 * blockIdx.x + 1] = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+    }
+}
+__global__ __launch_bounds__(64) void k_measure_final(const double *__restrict__ partial, int nb,
+                                                      double *__restrict__ out) {
+    // lane l adds partials l, l + 64, ... in order; then the fixed shuffle tree
+    double sum = 0, mx = 0;
+    for (int b = threadIdx.x; b < nb; b += 64) {
+        sum += partial[2 * b];
+        mx = fmax(mx, partial[2 * b + 1]);
+    }
+    sum = wave_sum(sum);
+    mx = wave_max(mx);
+    if (threadIdx.x == 0) {
+        out[0] = sum;
+        out[1] = mx;
+    }
+}
+
+int cgk_measure_mom(cg_ctx *c, const double *mom, i64 n, double *out, double *scratch) {
+    int nb = (int)((n + 255) / 256 < kMeasureBlocks ? (n + 255) / 256 : kMeasureBlocks);
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_measure_mom, dim3(nb), dim3(256), 0, c->stream, mom, n, scratch);
+    CG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_measure_final, dim3(1), dim3(64), 0, c->stream, scratch, nb, out);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // Tile sort.  Key = the mesh tile that holds the particle's lower CIC cell
 // (the reference's own index map, so the tile of a particle is consistent
 // with the cells the deposit / gather kernels touch).  Counting sort:

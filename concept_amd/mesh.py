@@ -588,6 +588,19 @@ class PotentialMesh:
         n = self._check_particles(pos, mom)
         check(_L.cg_drift(self._ctx, _ptr(pos), _ptr(mom), n, float(dt_over_mass)))
 
+    def measure_momentum(self, mom):
+        """(Σ mom², max |mom_i|²) of the local particles (cg_measure_momentum): the inputs of
+        measure(component, 'v_rms' | 'v_max'), analysis.py:3902-3972.  Synchronises."""
+        n = mom.shape[0]
+        if n == 0:
+            return 0.0, 0.0
+        if getattr(self, '_measure_buf', None) is None:
+            self._measure_buf = torch.empty(2048 + 2, dtype=torch.float64, device=self.device)
+        buf = self._measure_buf
+        check(_L.cg_measure_momentum(self._ctx, _ptr(mom), n, _ptr(buf[2048:]), _ptr(buf)))
+        s, m = buf[2048:].tolist()
+        return s, m
+
     def sort_particles(self, pos, mom, ids, pos_out, mom_out, ids_out, tile_offset=None):
         n = self._check_particles(pos, mom, pos_out, mom_out)
         if tile_offset is None:

@@ -309,6 +309,19 @@ class Component:
         self._rows_known = True
         self.exchange()
 
+    @property
+    def ϱ_bar(self):
+        """species.py:1790-1836 without CLASS: Ω ρ_crit for the plain matter species, else
+        N mass / boxsize³ (particles)."""
+        p = self.params
+        class_species = {'matter': 'b+cdm', 'baryon': 'b', 'baryons': 'b',
+                         'cold dark matter': 'cdm', 'dark matter': 'cdm'}.get(self.species)
+        if class_species is not None:
+            return sum({'b': p.Ωb, 'cdm': p.Ωcdm}[s_] for s_ in class_species.split('+'))*p.ρ_crit
+        if self.representation == 'particles':
+            return self.N*self.mass/p.boxsize**3
+        raise ConceptGPUError(f'Cannot determine ϱ_bar for {self.name}')
+
     def w_eff(self, a=1.0):
         return 0.0  # matter; decaying species are out of scope
 

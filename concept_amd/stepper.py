@@ -202,9 +202,20 @@ class RungStepper:
     def _clip(self, t, Δt, sync_time):
         return sync_time if t + self.Δt_reltol*Δt + 2*commons.machine_ϵ > sync_time else t
 
+    def _shortrange_interactions(self):
+        """find_interactions(particle_components, 'short-range') (main.py:1216-1225,
+        1395-1403)"""
+        return interactions.find_interactions(self.components, 'short-range')
+
     def _gravity_short(self):
-        interactions.gravity('p3m', self.components, self.components, self.ᔑdt_rungs,
-                             'short-range', False)
+        """every short-range interaction once (main.py:1249-1262, 1559-1576); returns the
+        receivers"""
+        receivers_all = []
+        for force, method, receivers, suppliers in self._shortrange_interactions():
+            getattr(interactions, force)(method, receivers, suppliers, self.ᔑdt_rungs,
+                                         'short-range', False)
+            receivers_all += [r for r in receivers if r not in receivers_all]
+        return receivers_all
 
     # -- main.kick_long (main.py:1104-1144) -----------------------------------
     def kick_long(self, Δt, sync_time, step_type):
@@ -212,11 +223,16 @@ class RungStepper:
         t_end = self._clip(t_start + (Δt/2 if step_type == 'init' else Δt), Δt, sync_time)
         if t_start == t_end:
             return
-        kick_long(self.components, self.integrals(t_start, t_end))
+        ᔑdt = self.integrals(t_start, t_end)
+        for force, method, receivers, suppliers in interactions.find_interactions(
+                self.components, 'long-range'):
+            getattr(interactions, force)(method, receivers, suppliers, ᔑdt, 'long-range', False)
 
     # -- main.kick_short (main.py:1173-1262) ----------------------------------
     def kick_short(self, Δt, fake=False):
         comps = self.components
+        if not self._shortrange_interactions():
+            return
         for c in comps:
             c.lowest_active_rung = c.lowest_populated_rung
         highest_populated_rung = max(c.highest_populated_rung for c in comps)
@@ -226,14 +242,14 @@ class RungStepper:
             self._store(self.integrals(t_start, t_end), rung_index)
         for c in comps:
             c.nullify_Δ('mom')
-        self._gravity_short()
+        receivers_all = self._gravity_short()
         if fake:
-            for c in comps:
+            for c in receivers_all:
                 c.convert_Δmom_to_acc(self.ᔑdt_rungs)
             for c in comps:
                 c.assign_rungs(Δt, self.fac_softening)
         else:
-            for c in comps:
+            for c in receivers_all:
                 c.apply_Δmom()
                 c.convert_Δmom_to_acc(self.ᔑdt_rungs)
 
@@ -251,6 +267,17 @@ class RungStepper:
     def driftkick_short(self, Δt, sync_time):
         comps = self.components
         nr = self.N_rungs
+        if not self._shortrange_interactions():
+            # no short-range interactions at all: the particles drift in one go
+            # (main.py:1395-1413)
+            t_start = self.t
+            t_end = self._clip(t_start + Δt, Δt, sync_time)
+            if t_start == t_end:
+                return
+            ᔑdt = self.integrals(t_start, t_end)
+            for c in comps:
+                c.drift_sort(ᔑdt)
+            return
         any_kicks = True
         index_start = 0
         for driftkick_index in range(2**(nr - 1)):
@@ -304,10 +331,11 @@ class RungStepper:
                                                 self.ᔑdt_rungs) for c in comps]
             for c in comps:
                 c.nullify_Δ('mom')
-            self._gravity_short()
+            receivers_all = self._gravity_short()
             for c, jumps in zip(comps, any_rung_jumps):
-                c.apply_Δmom()
-                c.convert_Δmom_to_acc(self.ᔑdt_rungs, jumps)
+                if c in receivers_all:
+                    c.apply_Δmom()
+                    c.convert_Δmom_to_acc(self.ᔑdt_rungs, jumps)
             for c, jumps in zip(comps, any_rung_jumps):
                 if jumps:
                     c.apply_rung_jumps()
@@ -318,3 +346,352 @@ class RungStepper:
         self.t = self._clip(self.t + 0.5*Δt, Δt, sync_time)
         self.kick_long(Δt, sync_time, 'full')
         self.t = self._clip(self.t + 0.5*Δt, Δt, sync_time)
+
+
+# ---------------------------------------------------------------------------
+# main.timeloop() with the cosmic clock: base time step control, synchronisations, dumps
+# ---------------------------------------------------------------------------
+import collections
+import math
+
+from .integration import Cosmology
+
+DumpTime = collections.namedtuple('DumpTime', ('time_param', 't', 'a'))
+ထ = math.inf
+
+
+def measure(component, quantity, a):
+    """analysis.measure(component, 'v_rms' | 'v_max') for particle components
+    (analysis.py:3902-3910, 3965-3972); collective over the domains."""
+    if component.representation != 'particles':
+        raise ConceptGPUError('measure(): particle components only (the fluid solvers are '
+                              'outside this path)')
+    mom2_sum, mom2_max = component._store.mesh.measure_momentum(component.mom)
+    if component.comm is not None and component.nprocs > 1:
+        both = component.comm.all_gather_floats([mom2_sum, mom2_max])
+        mom2_sum, mom2_max = float(both[:, 0].sum()), float(both[:, 1].max())
+    w_eff = component.w_eff(a=a)
+    if quantity == 'v_rms':
+        return math.sqrt(mom2_sum/component.N)/(a**(2 - 3*w_eff)*component.mass)
+    if quantity == 'v_max':
+        return math.sqrt(mom2_max)/(a**(2 - 3*w_eff)*component.mass)
+    raise ConceptGPUError(f'measure(): quantity "{quantity}" not implemented')
+
+
+class Timeloop(RungStepper):
+    """main.timeloop() (main.py:102-471) for particle components: from the initial time to the
+    last dump time with the reference's base-step control — get_base_timestep_size
+    (main.py:697-916: dynamical time, Δa limits, Hubble time, PM and P³M limiters),
+    update_base_timestep_size (main.py:922-982), synchronisation of kicks and drifts at dumps and
+    at changes of Δt, the init / full step types — on top of kick_long / kick_short /
+    driftkick_short (RungStepper) with the time-step integrals of integration.Cosmology.
+
+    on_dump(loop, dump_time) is the reference's dump() (snapshot output is outside the path)."""
+    # main.py:2336-2378
+    Δt_initial_fac = 0.95
+    Δt_reduce_fac = 0.94
+    Δt_increase_fac = 0.96
+    Δt_increase_min_factor = 1.01
+    Δt_ratio_warn = 0.7
+    Δt_ratio_abort = 0.01
+    Δt_period = 1*8
+
+    def __init__(self, components, cosmology=None, on_dump=None, on_step=None):
+        p = components[0].params
+        self.cosmo = cosmology or Cosmology(p)
+        self.cosmo.init_time()
+        for c in components:
+            if c.representation != 'particles':
+                raise ConceptGPUError(
+                    f'Timeloop: {c.name} is a fluid component; fluids take part in gravity() '
+                    'but their own evolution (fluid.py) is outside this path')
+        super().__init__(components, self._integrals, t=self.cosmo.t,
+                         fac_softening=0.025*p.Δt_rung_factor)
+        self.params = p
+        self.on_dump, self.on_step = on_dump, on_step
+        # main.py:2386-2426
+        bg, nl = p.Δt_base_background_factor, p.Δt_base_nonlinear_factor
+        self.fac_dynamical = 0.056*bg
+        self.fac_hubble = 0.031*bg
+        self.fac_pm = 0.13*nl
+        self.fac_p3m = 0.14*nl
+        self.initial_fac_times = set()
+        self.keys = None
+        self.static_timestepping_func = None
+        if callable(p.static_timestepping):
+            def func(a):   # main.py:646-660
+                t = self.cosmo.t if a == self.cosmo.a else self.cosmo.cosmic_time(a)
+                a_next = a + p.static_timestepping(a)
+                return self.cosmo.cosmic_time(a_next) - t if a_next <= 1 else ထ
+            self.static_timestepping_func = func
+        elif p.static_timestepping is not None:
+            raise ConceptGPUError('static_timestepping: only a callable Δa(a) is supported here '
+                                  '(recording to / replaying from a file is outside the path)')
+        self.time_step = 0
+        self.Δt = 0.0
+        self.history = []   # (time_step, t, a, Δt) at the beginning of every time step
+
+    # universals.t / universals.a live in the Cosmology object
+    t = property(lambda self: self.cosmo.t, lambda self, v: setattr(self.cosmo, 't', float(v)))
+
+    def _integrals(self, t_start, t_end):
+        return self.cosmo.get_time_step_integrals(t_start, t_end, self.components, self.keys)
+
+    # -- main.prepare_for_output (main.py:2188-2310), the dump times -----------------------
+    def dump_times(self):
+        p, cosmo = self.params, self.cosmo
+        for tp, at_begin in (('a', cosmo.a), ('t', cosmo.t)):
+            if p.output_times[tp] and min(p.output_times[tp]) < at_begin:
+                raise ConceptGPUError(
+                    f'Cannot produce output at {tp} = {min(p.output_times[tp])}, as the '
+                    f'simulation starts at {tp} = {at_begin}.')
+        dumps = [DumpTime('t', t=t, a=None) for t in sorted(set(p.output_times['t']))]
+        dumps += [DumpTime('a', a=a, t=None) for a in sorted(set(p.output_times['a']))]
+        if cosmo.enable_Hubble:
+            for i, d in enumerate(dumps):
+                if d.time_param == 't':
+                    dumps[i] = DumpTime('t', t=d.t, a=cosmo.scale_factor(d.t))
+                else:
+                    dumps[i] = DumpTime('a', a=d.a, t=cosmo.cosmic_time(d.a))
+        elif any(d.t is None for d in dumps):
+            raise ConceptGPUError('output_times given as scale factors with the Hubble '
+                                  'expansion disabled')
+        dumps.sort(key=lambda d: d.t)
+        unique = dumps[:1]
+        for d in dumps[1:]:
+            if not np.isclose(d.t, unique[-1].t, rtol=1e-6, atol=0):
+                unique.append(d)
+        return unique
+
+    # -- main.get_base_timestep_size (main.py:697-916) -------------------------------------
+    def get_base_timestep_size(self):
+        cosmo, p = self.cosmo, self.params
+        t, a = cosmo.t, cosmo.a
+        if self.static_timestepping_func is not None:
+            return self.static_timestepping_func(a), 'static time-stepping'
+        H = cosmo.hubble(a)
+        Δt_max, bottleneck = ထ, ''
+        measurements = {}
+        # the dynamical time scale
+        ρ_bar = 0
+        for c in self.components:
+            ρ_bar += a**(-3*(1 + c.w_eff(a=a)))*c.ϱ_bar
+        Δt_dynamical = self.fac_dynamical/(math.sqrt(p.G_Newton*ρ_bar) + commons.machine_ϵ)
+        if Δt_dynamical < Δt_max:
+            Δt_max, bottleneck = Δt_dynamical, 'the dynamical time scale'
+        if cosmo.enable_Hubble:
+            # maximum allowed Δa at late times
+            a_next = a + p.Δa_max_late
+            if a_next < 1:
+                Δt_Δa_late = p.Δt_base_background_factor*(cosmo.cosmic_time(a_next) - t)
+                if Δt_Δa_late < Δt_max:
+                    Δt_max, bottleneck = Δt_Δa_late, 'the maximum allowed Δa (late)'
+            # the Hubble time, overruled by a constant Δa at early times
+            Δt_hubble, bottleneck_hubble = self.fac_hubble/H, 'the Hubble time'
+            if p.Δa_max_early > 0:
+                a_next = a + p.Δa_max_early
+                if a_next < 1:
+                    Δt_Δa_early = p.Δt_base_background_factor*(cosmo.cosmic_time(a_next) - t)
+                    if Δt_Δa_early > Δt_hubble:
+                        Δt_hubble = Δt_Δa_early
+                        bottleneck_hubble = 'the maximum allowed Δa (early)'
+            if Δt_hubble < Δt_max:
+                Δt_max, bottleneck = Δt_hubble, bottleneck_hubble
+        # (1/|ẇ| and the decay rate: matter, w = 0 and Γ = 0, never the bottleneck; the Courant
+        # condition belongs to fluids)
+
+        def v_rms_of(c):
+            if c not in measurements:
+                measurements[c] = measure(c, 'v_rms', a)
+            v_rms = measurements[c]
+            # in the odd case of a completely static component, just above 0
+            return commons.machine_ϵ if v_rms < commons.machine_ϵ else v_rms
+        # PM limiter
+        for c in self.components:
+            resolution, extreme_force = 0, None
+            for force, method in c.forces.items():
+                if method != 'pm':
+                    continue
+                for method_, gridsize in c.potential_gridsizes[force].items():
+                    if method_ != 'pm':
+                        continue
+                    gridsize = int(np.max(gridsize))
+                    if gridsize > resolution:
+                        resolution, extreme_force = gridsize, force
+            if resolution == 0:
+                continue
+            Δt_pm = self.fac_pm*(p.boxsize/resolution)/v_rms_of(c)
+            if Δt_pm < Δt_max:
+                Δt_max = Δt_pm
+                bottleneck = f'the PM method of the {extreme_force} force for {c.name}'
+        # P³M limiter
+        for c in self.components:
+            scale = ထ
+            for force, method in c.forces.items():
+                if method != 'p3m':
+                    continue
+                # shortrange_params are resolved with the global P³M grid size
+                # (commons.py:3254-3300)
+                gs = p.potential_options['gridsize']['global'].get(force, {}).get('p3m', -1)
+                if gs == -1:
+                    gs = int(np.max(c.potential_gridsizes[force]['p3m']))
+                s_ = commons.resolve_shortrange(p, gs)['scale']
+                if s_ < scale:
+                    scale = s_
+            if scale == ထ:
+                continue
+            Δt_p3m = self.fac_p3m*scale/v_rms_of(c)
+            if Δt_p3m < Δt_max:
+                Δt_max = Δt_p3m
+                bottleneck = f'the P³M method of the gravity force for {c.name}'
+        if t in self.initial_fac_times:
+            Δt_max *= self.Δt_initial_fac
+        return Δt_max, bottleneck
+
+    # -- main.update_base_timestep_size (main.py:922-982) ----------------------------------
+    def update_base_timestep_size(self, Δt, Δt_min, Δt_max, bottleneck, time_step=-1,
+                                  time_step_last_sync=-1, *, allow_increase=True,
+                                  tolerate_danger=False):
+        p, cosmo = self.params, self.cosmo
+        if Δt > Δt_max:
+            Δt_new = self.Δt_reduce_fac*Δt_max
+            Δt_ratio = Δt_new/Δt
+            if Δt_ratio < self.Δt_ratio_abort and not tolerate_danger:
+                raise ConceptGPUError(
+                    f'Due to {bottleneck}, the time step size needs to be rescaled by a factor '
+                    f'{Δt_ratio:.1g}. This extreme change is unacceptable.')
+            if Δt_new < Δt_min:
+                raise ConceptGPUError('Time evolution effectively halted with a time step size '
+                                      f'of {Δt_new}')
+            return Δt_new, bottleneck
+        if not allow_increase:
+            return Δt, bottleneck
+        Δt_new = self.Δt_increase_fac*Δt_max
+        if Δt_new < Δt:
+            Δt_new = Δt
+        period_frac = (time_step + 1 - time_step_last_sync)*(1/self.Δt_period)
+        if period_frac > 1:
+            period_frac = 1
+        elif period_frac < 0:
+            period_frac = 0
+        Δt_tmp = (1 + period_frac*(p.Δt_increase_max_factor - 1))*Δt
+        if Δt_new > Δt_tmp:
+            Δt_new = Δt_tmp
+        if cosmo.enable_Hubble and cosmo.t + Δt_new > cosmo.cosmic_time(1):
+            return Δt, 'a ≈ 1'
+        return Δt_new, ''
+
+    def _advance(self, Δt, sync_time):
+        # universals.t += 0.5*Δt, snapped onto the sync time (main.py:343-346, 353-356)
+        cosmo = self.cosmo
+        cosmo.t += 0.5*Δt
+        if cosmo.t + self.Δt_reltol*Δt + 2*commons.machine_ϵ > sync_time:
+            cosmo.t = sync_time
+        cosmo.a = cosmo.scale_factor(cosmo.t)
+
+    def _dump(self, dump_time):
+        if self.on_dump is not None:
+            self.on_dump(self, dump_time)
+
+    # -- main.timeloop (main.py:102-471) ---------------------------------------------------
+    def run(self):
+        cosmo, components = self.cosmo, self.components
+        dump_times = self.dump_times()
+        if not dump_times:
+            return
+        if dump_times[0].t == cosmo.t or dump_times[0].a == cosmo.a:
+            self._dump(dump_times[0])
+            dump_times.pop(0)
+            if not dump_times:
+                return
+        self.initial_fac_times.add(cosmo.t)
+        Δt_max, bottleneck = self.get_base_timestep_size()
+        Δt_begin = Δt_max
+        if Δt_begin > dump_times[0].t - cosmo.t:
+            Δt_begin = dump_times[0].t - cosmo.t
+        Δt = Δt_begin
+        Δt_min = 1e-4*Δt_begin
+        self.keys = cosmo.integrand_keys(components)
+        self.initialize_rung_populations(Δt)
+        time_step = time_step_last_sync = 0
+        time_step_previous = time_step - 1
+        bottleneck = ''
+        time_step_type = 'init'
+        sync_time = ထ
+        recompute_Δt_max = True
+        Δt_backup = -1
+        for dump_index, dump_time in enumerate(dump_times):
+            while True:
+                if time_step > time_step_previous:
+                    time_step_previous = time_step
+                    if time_step_type == 'init':
+                        for c in components:
+                            c.assign_rungs(Δt, self.fac_softening)
+                    self.time_step, self.Δt = time_step, Δt
+                    Δt_print = Δt
+                    if cosmo.t + Δt*(1 + self.Δt_reltol) + 2*commons.machine_ϵ > sync_time:
+                        Δt_print = sync_time - cosmo.t
+                    self.history.append((time_step, cosmo.t, cosmo.a, Δt_print))
+                    if self.on_step is not None:
+                        self.on_step(self)
+                if time_step_type == 'init':
+                    time_step_type = 'full'
+                    self.kick_long(Δt, sync_time, 'init')
+                    self.kick_short(Δt)
+                    if dump_time.t - cosmo.t <= 1.5*Δt:
+                        sync_time = dump_time.t
+                        continue
+                    Δt_max, bottleneck = self.get_base_timestep_size()
+                    if Δt > Δt_max:
+                        sync_time = cosmo.t + 0.5*Δt
+                        recompute_Δt_max = False
+                        continue
+                elif time_step_type == 'full':
+                    self.driftkick_short(Δt, sync_time)
+                    self._advance(Δt, sync_time)
+                    self.kick_long(Δt, sync_time, 'full')
+                    self._advance(Δt, sync_time)
+                    if cosmo.t == sync_time:
+                        time_step_type = 'init'
+                        sync_time = ထ
+                        if Δt_backup != -1:
+                            if Δt < Δt_backup:
+                                Δt = Δt_backup
+                            Δt_backup = -1
+                        if recompute_Δt_max:
+                            Δt_max, bottleneck = self.get_base_timestep_size()
+                        recompute_Δt_max = True
+                        Δt, bottleneck = self.update_base_timestep_size(
+                            Δt, Δt_min, Δt_max, bottleneck, time_step, time_step_last_sync,
+                            tolerate_danger=(bottleneck == 'static time-stepping'))
+                        time_step += 1
+                        time_step_last_sync = time_step
+                        if cosmo.t == dump_time.t:
+                            self._dump(dump_time)
+                            if dump_index != len(dump_times) - 1:
+                                Δt_max = dump_times[dump_index + 1].t - cosmo.t
+                                if Δt > Δt_max:
+                                    Δt_backup = Δt
+                                    Δt = Δt_max
+                            break
+                        Δt_max = dump_time.t - cosmo.t
+                        if Δt > Δt_max:
+                            Δt_backup = Δt
+                            Δt = Δt_max
+                        continue
+                    time_step += 1
+                    if dump_time.t - cosmo.t <= 1.5*Δt:
+                        sync_time = dump_time.t
+                        continue
+                    Δt_max, bottleneck = self.get_base_timestep_size()
+                    if Δt > Δt_max:
+                        sync_time = cosmo.t + Δt
+                        recompute_Δt_max = False
+                        continue
+                    if (Δt_max > self.Δt_increase_min_factor*Δt
+                            and (time_step + 1 - time_step_last_sync) >= self.Δt_period):
+                        sync_time = cosmo.t + Δt
+                        recompute_Δt_max = False
+                        continue
+        self.time_step, self.Δt = time_step, Δt
+        self.history.append((time_step, cosmo.t, cosmo.a, Δt))

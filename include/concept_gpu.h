@@ -228,6 +228,16 @@ int cg_prepare_invalidate(cg_ctx *ctx);
 int cg_drift(cg_ctx *ctx, double *pos /*DEV 3n*/, const double *mom /*DEV 3n*/, int64_t n,
              double dt_over_mass);
 
+/* --- A18: what the time loop's step-size limiters measure ------------------
+ * measure(component, 'v_rms') and measure(component, 'v_max') of a particle component
+ * (analysis.py:3965-3972, 3902-3910; used by get_base_timestep_size, main.py:842-912):
+ *   out[0] = sum over the 3n reals of mom^2,   out[1] = max over particles of |mom_i|^2
+ * (the caller divides by N, a^2 and the mass; over domains it sums / maximises the ranks'
+ * values, the reference's allreduce).  Fixed summation order: bit-reproducible.
+ * scratch: DEV double[2048]. */
+int cg_measure_momentum(cg_ctx *ctx, const double *mom /*DEV 3n*/, int64_t n,
+                        double *out /*DEV 2*/, double *scratch /*DEV 2048*/);
+
 /* --- particle memory order -------------------------------------------------
  * The reference reorders particle memory for locality (Component.tile_sort,
  * species.py:2598-2810).  cg_sort_particles bins particles by mesh tile and

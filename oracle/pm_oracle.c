@@ -271,6 +271,23 @@ void orc_slab_decompose(const double *grid, i64 N, i64 g, double *slab) {
         dst[N] = 0; dst[N + 1] = 0;
     }
 }
+/* The layout steps around the FFT for the threaded timing path (oracle.fft_forward /
+ * fft_backward with workers): the (i, j) transposition of FFTW-MPI's transposed output
+ * (fft.c:240-257) on rows of `row` doubles, and the copy of the real result into the padded
+ * slab.  Same data movement as the numpy expressions of the parity path, over all threads. */
+void orc_transpose_ij(const double *in, double *out, i64 N, i64 row) {
+#pragma omp parallel for schedule(static)
+    for (i64 j = 0; j < N; j++) for (i64 i = 0; i < N; i++)
+        memcpy(out + (j * N + i) * row, in + (i * N + j) * row, sizeof(double) * row);
+}
+void orc_copy_pad(const double *in, double *out, i64 N) {
+    i64 pad = N + 2;
+#pragma omp parallel for schedule(static)
+    for (i64 r = 0; r < N * N; r++) {
+        memcpy(out + r * pad, in + r * N, sizeof(double) * N);
+        out[r * pad + N] = 0; out[r * pad + N + 1] = 0;
+    }
+}
 /* A8  domain_decompose on one rank (mesh.py:2138-2244), interior only */
 void orc_domain_decompose(const double *slab, i64 N, i64 g, double *grid) {
     i64 n = N + 2 * g, pad = N + 2;

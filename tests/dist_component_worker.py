@@ -89,6 +89,12 @@ def main():
         import test_gpu_p3m
         test_gpu_p3m.test_shortrange_two_components_receivers_not_suppliers(arg == 'cell')
         test_gpu_p3m.test_populate_after_sort_lands_on_the_right_particles()
+    elif case == 'traj':
+        import test_gpu_trajectory as tt
+        tt.test_timeloop_run_vs_reference(golden, arg)
+        if 'traj_pm' in arg:
+            for streaming in (True, False):
+                tt.test_stepper_timeloop_replays_reference_integrals(golden, arg, streaming)
     elif case == 'snapshot':
         import test_gpu_pp
         test_gpu_pp.test_gadget_snapshot_to_gpu_components(golden)

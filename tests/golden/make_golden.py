@@ -162,6 +162,31 @@ CASES = {
     'fluid2_pm_n6_g12': dict(method='pm', n=6, gridsize=12, boxsize=48.0, seed=22,
                              dist='clustered', diff=4, fluid=dict(gridsize=12, count=2),
                              particle_components=2),
+    # A18, trajectory level: the reference's own main.timeloop() (main.py:102-471) from a_begin
+    # to a = 1 on the shapes of test/pure_python_pm/param (8^3 particles, PM mesh 8, box 8 Mpc,
+    # a: 0.02 -> 1, dumps at 0.1, 0.5, 1) and test/pure_python_p3m/param (P3M mesh 24, box
+    # 4 Mpc, range 3.1 scale, a: 0.1 -> 1, dumps at 0.3, 0.5, 1, adaptive rungs) with the matter
+    # + Λ background (enable_class_background = False).  Records every call of
+    # get_time_step_integrals (t_start, t_end, all integrals), every base step's (t, a, Δt) and
+    # the particles at every dump.
+    'traj_pm_n8_g8': dict(method='pm', n=8, gridsize=8, boxsize=8.0, seed=51, traj=dict(
+        a_begin=0.02, outputs=(0.1, 0.5, 1))),
+    'traj_p3m_n8_g24': dict(method='p3m', n=8, gridsize=24, boxsize=4.0, seed=52, traj=dict(
+        a_begin=0.1, outputs=(0.3, 0.5, 1),
+        extra="shortrange_params = {'gravity': {'scale': '1.25*boxsize/gridsize', "
+              "'range': '3.1*scale', 'subtiling': 2}}\n")),
+    # on a power-of-two mesh (the multi-GPU FFT's sizes) for the runs over 2 and 4 domains
+    'traj_p3m_n8_g32': dict(method='p3m', n=8, gridsize=32, boxsize=4.0, seed=53, traj=dict(
+        a_begin=0.1, outputs=(0.3, 1),
+        extra="shortrange_params = {'gravity': {'scale': '1.25*boxsize/gridsize', "
+              "'range': '3.1*scale', 'subtiling': 2}}\n")),
+    'traj_pm_n8_g16': dict(method='pm', n=8, gridsize=16, boxsize=8.0, seed=54, traj=dict(
+        a_begin=0.05, outputs=(0.2, 1))),
+    # the same P3M run without adaptive rungs (N_rungs = 1)
+    'traj_p3m_n8_g24_r1': dict(method='p3m', n=8, gridsize=24, boxsize=4.0, seed=52, traj=dict(
+        a_begin=0.1, outputs=(0.3, 0.5, 1),
+        extra="shortrange_params = {'gravity': {'scale': '1.25*boxsize/gridsize', "
+              "'range': '3.1*scale', 'subtiling': 2}}\nN_rungs = 1\n")),
 }
 
 
@@ -671,8 +696,160 @@ ewald_gridsize = {cfg['ewald_gridsize']}
     print('wrote', name, {k: getattr(v, 'shape', v) for k, v in out.items()})
 
 
+def traj_param_text(cfg):
+    tr = cfg['traj']
+    method = cfg['method']
+    return f"""
+output_dirs = {{'snapshot': f'{{param.dir}}/output'}}
+output_bases = {{'snapshot': 'snapshot'}}
+output_times = {{'snapshot': {tuple(tr['outputs'])!r}}}
+boxsize = {cfg['boxsize']!r}*Mpc
+potential_options = {{'gridsize': {{'gravity': {{'{method}': {cfg['gridsize']}}}}}}}
+H0 = 70*km/s/Mpc
+Ωcdm = 0.25
+Ωb = 0.05
+a_begin = {tr['a_begin']!r}
+enable_class_background = False
+select_forces = {{'matter': {{'gravity': '{method}'}}}}
+particle_reordering = False
+print_load_imbalance = False
+""" + tr.get('extra', '')
+
+
+def child_traj(name):
+    """The reference's main.timeloop() itself (imported with jobid = -1 so that nothing runs at
+    import), fed in-memory initial conditions through main.get_initial_conditions, its dumps
+    captured through main.dump, every get_time_step_integrals call recorded."""
+    import importlib
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, 'oracle', 'refharness'))
+    from ref_import import load_reference
+    cfg = CASES[name]
+    text = traj_param_text(cfg)
+    work = f'/tmp/concept_golden_work/{name}'
+    ref = load_reference(text, work)
+    commons, species, integration = ref.commons, ref.species, ref.integration
+    commons.jobid = -1
+    main = importlib.import_module('main')
+    L = commons.boxsize
+    n = cfg['n']
+    N = n**3
+    rng = np.random.default_rng(1000 + cfg['seed'])
+    # a displaced lattice moving in the growing mode: mom = m a^2 H f ψ with f = 1
+    lat = (np.stack(np.meshgrid(*[np.arange(n)]*3, indexing='ij'), -1).reshape(-1, 3) + 0.5)*(L/n)
+    psi = rng.normal(0, 0.08*L/n, (N, 3))
+    pos = np.ascontiguousarray((lat + psi) % L)
+    pos[pos >= L] = 0.0
+    mass = commons.ρ_mbar*L**3/N
+    integration.init_time()
+    uni = commons.universals
+    mom = np.ascontiguousarray(psi*mass*uni.a**2*integration.hubble(uni.a))
+    comp = species.Component('matter', 'matter', N=N, mass=mass)
+    for d, s_ in enumerate('xyz'):
+        comp.populate(np.ascontiguousarray(pos[:, d]), 'pos' + s_)
+        comp.populate(np.ascontiguousarray(mom[:, d]), 'mom' + s_)
+    ids = np.arange(N)
+    out = dict(param_text=text, boxsize=L, gridsize=cfg['gridsize'], N=N, mass=mass,
+               method=cfg['method'], G_Newton=commons.G_Newton, H0=commons.H0, Ωm=commons.Ωm,
+               N_rungs=commons.N_rungs, softening_length=comp.softening_length,
+               a_begin=uni.a, t_begin=uni.t, pos_in=pos.copy(), mom_in=mom.copy(),
+               bg_a=np.array(integration.temporal_splines.a_t.x)[::25].copy(),
+               bg_t=np.array(integration.temporal_splines.a_t.y)[::25].copy())
+    main.get_initial_conditions = lambda *a, **k: [comp]
+    main.check_autosave = lambda: (0, 0.0, 0.0, {})
+    main.autosave_subdir = work + '/no_autosave'
+    dumps = []
+
+    def dump(components, output_filenames, dump_time, Δt=0):
+        c = components[0]
+        # particle memory may have been reordered (tile_sort): rows are identified by the
+        # lattice site nearest to where each particle started — instead, keep the order
+        # fixed with particle_reordering = False and check it
+        dumps.append((uni.a, uni.t, np.array(c.pos_mv3[:N]).copy(), np.array(c.mom_mv3[:N]).copy()))
+        return False
+    main.dump = dump
+    calls = []
+    orig_integrals = main.get_time_step_integrals
+
+    def integrals(t_start, t_end, components):
+        res = orig_integrals(t_start, t_end, components)
+        if t_start != t_end:
+            calls.append((float(t_start), float(t_end), {k: float(v) for k, v in res.items()}))
+            contexts.append(context[0])
+        return res
+    main.get_time_step_integrals = integrals
+    # who asked: 'L0' / 'L1' kick_long init / full, 'S' kick_short, 'D' driftkick_short (rung
+    # kicks), 'Dd' the drift inside driftkick_short
+    contexts, context = [], ['']
+
+    def tagged(tag, func):
+        def wrapper(*a, **k):
+            context[0] = tag(*a, **k) if callable(tag) else tag
+            try:
+                return func(*a, **k)
+            finally:
+                context[0] = ''
+        return wrapper
+    main.kick_short = tagged('S', main.kick_short)
+    main.driftkick_short = tagged('D', main.driftkick_short)
+    orig_drift = species.Component.drift
+
+    def drift(self, *a, **k):
+        contexts[-1] = 'Dd'   # the call just made was for this drift
+        return orig_drift(self, *a, **k)
+    species.Component.drift = drift
+    steps = []
+    orig_heading = main.print_timestep_heading
+
+    def heading(time_step, Δt, bottleneck, components, end=False):
+        steps.append((int(time_step), float(uni.t), float(uni.a), float(Δt), str(bottleneck),
+                      int(end)))
+        return orig_heading(time_step, Δt, bottleneck, components, end)
+    main.print_timestep_heading = heading
+    kicks = []
+    orig_kick_long = main.kick_long
+
+    def kick_long(components, Δt, sync_time, step_type):
+        kicks.append((float(uni.t), float(Δt), float(sync_time), step_type == 'full'))
+        context[0] = 'L1' if step_type == 'full' else 'L0'
+        try:
+            return orig_kick_long(components, Δt, sync_time, step_type)
+        finally:
+            context[0] = ''
+    main.kick_long = kick_long
+    main.timeloop()
+    keys = list(calls[0][2])
+    out['integral_keys'] = np.array(['|'.join(k) if isinstance(k, tuple) else k for k in keys])
+    out['integral_t'] = np.array([(c[0], c[1]) for c in calls])
+    out['integral_values'] = np.array([[c[2][k] for k in keys] for c in calls])
+    out['integral_context'] = np.array(contexts)
+    out['step_number'] = np.array([s_[0] for s_ in steps])
+    out['step_t'] = np.array([s_[1] for s_ in steps])
+    out['step_a'] = np.array([s_[2] for s_ in steps])
+    out['step_dt'] = np.array([s_[3] for s_ in steps])
+    out['step_bottleneck'] = np.array([s_[4] for s_ in steps])
+    out['kick_t'] = np.array([k[0] for k in kicks])
+    out['kick_dt'] = np.array([k[1] for k in kicks])
+    out['kick_sync'] = np.array([k[2] for k in kicks])
+    out['kick_full'] = np.array([k[3] for k in kicks])
+    out['dump_a'] = np.array([d[0] for d in dumps])
+    out['dump_t'] = np.array([d[1] for d in dumps])
+    out['dump_pos'] = np.array([d[2] for d in dumps])
+    out['dump_mom'] = np.array([d[3] for d in dumps])
+    if cfg['method'] == 'p3m':
+        out['shortrange_scale'] = commons.shortrange_params['gravity']['scale']
+        out['shortrange_range'] = commons.shortrange_params['gravity']['range']
+        out['shortrange_tilesize'] = commons.shortrange_params['gravity']['tilesize']
+        out['shortrange_tablesize'] = commons.shortrange_params['gravity']['tablesize']
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, 'steps', len(steps), 'integral calls', len(calls), 'dumps at a =',
+          out['dump_a'])
+
+
 def child(name):
     import numpy as np
+    if 'traj' in CASES[name]:
+        return child_traj(name)
     if CASES[name].get('gadget'):
         return child_gadget(name)
     if CASES[name].get('pp'):

@@ -222,6 +222,9 @@ COMPONENT_CASES = [
     # receivers not among the suppliers; slab faces of vertex-centred grids; populate() after
     # the rows have moved
     ('advice', 'cell'), ('advice', 'vertex'),
+    # whole runs of the time loop (a_begin -> 1, ~140 base steps) against the reference's
+    # (power-of-two meshes: the transposing FFT's sizes)
+    ('traj', 'traj_pm_n8_g16'), ('traj', 'traj_p3m_n8_g32'),
 ]
 
 

@@ -1,0 +1,131 @@
+"""Trajectory-level parity: whole runs of the time loop
+against the reference's own main.timeloop() on the shapes of test/pure_python_pm/param and
+test/pure_python_p3m/param (tests/golden/traj_*.npz: ~140 base steps from a_begin to a = 1,
+matter + Λ background).
+
+  * Timeloop.run(): the build computes everything itself — background, time-step integrals,
+    base-step control (limiters, synchronisations at dumps and at changes of Δt), rungs.  Bars:
+    every step's (t, a, Δt) within 1e-10 relative of the reference's; particle positions at every
+    dump within the reference's own bar of test/pure_python_pm/analyze.py:125 (mean |Δx| / boxsize
+    <= 1e-10) — asserted on the MAXIMUM over the particles.
+  * stepper.timeloop (the streaming loop — kick + drift + tile sort in one pass — and the
+    stepwise loop) replaying the reference's recorded integrals segment by segment.
+All of it also on 2 and 4 x-slab domains (tests/test_gpu_distributed.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+KEY2 = 'a**(-3*w_eff₀-3*w_eff₁-1)'
+
+
+def _component(g):
+    from concept_amd import commons
+    from concept_amd.species import Component
+    p = commons.load_params(str(g['param_text']))
+    c = Component('matter', 'matter', N=int(g['N']), mass=float(g['mass']))
+    c.populate(g['pos_in'], 'pos')
+    c.populate(g['mom_in'], 'mom')
+    return p, c
+
+
+def _pos_err(pos, ref, L):
+    d = np.abs(pos - ref)
+    return np.minimum(d, L - d).max()/L
+
+
+@pytest.mark.parametrize('name', ['traj_pm_n8_g8', 'traj_p3m_n8_g24_r1', 'traj_p3m_n8_g24',
+                                  'traj_pm_n8_g16', 'traj_p3m_n8_g32'])
+def test_timeloop_run_vs_reference(golden, name):
+    from concept_amd import stepper
+    g = golden(name)
+    p, c = _component(g)
+    L = p.boxsize
+    assert p.N_rungs == int(g['N_rungs'])
+    dumps = []
+
+    def on_dump(loop, dump_time):
+        dumps.append((loop.cosmo.a, loop.cosmo.t, c.host('pos'), c.host('mom')))
+    loop = stepper.Timeloop([c], on_dump=on_dump)
+    loop.run()
+    # the step sequence: number, cosmic time, scale factor and size of every base step
+    hist = np.array(loop.history)
+    assert hist.shape[0] == g['step_number'].shape[0], (hist.shape, g['step_number'].shape)
+    assert np.array_equal(hist[:, 0], g['step_number'])
+    for col, key in ((1, 'step_t'), (2, 'step_a'), (3, 'step_dt')):
+        assert np.abs(hist[:, col]/g[key] - 1).max() <= 1e-10, key
+    # the dumps
+    assert len(dumps) == len(g['dump_a'])
+    kick = np.abs(g['dump_mom'][-1] - g['mom_in']).max()
+    for i, (a, t, pos, mom) in enumerate(dumps):
+        assert a == g['dump_a'][i] and abs(t/g['dump_t'][i] - 1) <= 1e-12
+        assert _pos_err(pos, g['dump_pos'][i], L) <= 1e-10, (i, a)
+        assert np.abs(mom - g['dump_mom'][i]).max() <= 1e-9*kick, (i, a)
+    assert dumps[-1][0] == 1.0
+    # the particles have really moved: several cells between the first and the last dump
+    moved = np.abs(g['dump_pos'][-1] - g['pos_in'])
+    assert np.minimum(moved, L - moved).max() > L/int(g['gridsize'])
+
+
+@pytest.mark.parametrize('name', ['traj_pm_n8_g8', 'traj_p3m_n8_g24_r1', 'traj_pm_n8_g16'])
+@pytest.mark.parametrize('streaming', [True, False])
+def test_stepper_timeloop_replays_reference_integrals(golden, name, streaming):
+    """stepper.timeloop with the integrals the reference recorded, call by call: a segment
+    between two synchronisations is K½ D K D ... K; (with on_step = None the PM loop takes the
+    streaming form, cg_gather_kick_drift_scatter; with a callback the separate passes)."""
+    from concept_amd import stepper
+    g = golden(name)
+    p, c = _component(g)
+    L = p.boxsize
+    p3m = str(g['method']) == 'p3m'
+    if p3m and streaming:
+        pytest.skip('the streaming form is the PM loop')
+    keys = [tuple(k.split('|')) if '|' in k else str(k) for k in g['integral_keys']]
+    calls = [dict(zip(keys, v)) for v in g['integral_values']]
+    cursor = [0]
+
+    def pop(kind):
+        cursor[0] += 1
+        return calls[cursor[0] - 1]
+
+    def pop_rungs(kind):
+        d = pop(kind)
+        return {(KEY2, 'matter', 'matter'): np.full(2, d[KEY2, 'matter', 'matter'])}
+    # Segments between synchronisations, from who asked for each integral ('L0' / 'L1'
+    # kick_long init / full, 'S' the init short kick, 'Dd' the drift and 'D' the rung kick of
+    # driftkick_short): L0 [S] (Dd [D] L1)*n, then possibly a lone Dd — the last step before a
+    # synchronisation time less than half a step away is a drift only, the kicks are there
+    # already (main.py:1131-1135: t_start == t_end).
+    ctx = [str(x) for x in g['integral_context']]
+    group = ['Dd', 'D', 'L1'] if p3m else ['Dd', 'L1']
+    head = ['L0', 'S'] if p3m else ['L0']
+    segments = []
+    i = 0
+    while i < len(ctx):
+        assert ctx[i:i + len(head)] == head, (i, ctx[i:i + 4])
+        i += len(head)
+        n = 0
+        while ctx[i:i + len(group)] == group:
+            n += 1
+            i += len(group)
+        tail = ctx[i:i + 1] == ['Dd']
+        i += int(tail)
+        segments.append((n, tail))
+    replays = stepper.stream_replays
+    dump_pos = list(g['dump_pos'])
+    # the dumps happen at synchronisations, i.e. at ends of segments: the particle positions
+    # at the end of a segment either equal the next dump's or belong to no dump
+    n_dump = 0
+    for n_steps, tail in segments:
+        stepper.timeloop([c], n_steps, pop, pop_rungs if p3m else None,
+                         on_step=None if streaming else (lambda step: None))
+        if tail:
+            stepper.drift([c], pop('full'))
+        if n_dump < len(dump_pos) and _pos_err(c.host('pos'), dump_pos[n_dump], L) <= 1e-10:
+            n_dump += 1
+    assert cursor[0] == len(calls)
+    assert n_dump == len(dump_pos)
+    assert _pos_err(c.host('pos'), g['dump_pos'][-1], L) <= 1e-10
+    kick = np.abs(g['dump_mom'][-1] - g['mom_in']).max()
+    assert np.abs(c.host('mom') - g['dump_mom'][-1]).max() <= 1e-9*kick
+    if streaming:
+        assert stepper.stream_replays == replays   # (no region overflowed on the way)
