@@ -29,6 +29,8 @@
 // [0, boxsize)), so the reference's truncation to Py_ssize_t equals truncation to int —
 // one v_cvt_i32_f64 instead of the ~15-instruction double -> int64 sequence, and every
 // index below (N <= 2048 and change) stays in 32-bit registers.
+// two doubles at 8-byte alignment (the xy of an xyz record)
+typedef double d2u8 __attribute__((ext_vector_type(2), aligned(8)));
 struct Cic1 {
     int index;
     double w0, w1;
@@ -256,47 +258,93 @@ __device__ __forceinline__ void gk_store_run(double *__restrict__ out, i64 first
     }
 }
 
-// LDS of the staged block.  T = 16, order 2: 19^3 doubles = 54,872 B would allow two workgroups
-// per CU (160 KB); the first and the last row of the block (a = 0, b = 0 and a = E-1, b = E-1)
-// are halo EDGES, which the 6-point stencil never reads — leaving those 2 x 19 entries out
-// brings it to 54,568 B, three workgroups (24 wavefronts) per CU.
+// LDS of the staged block.  A workgroup's allocation is rounded up to 1280 B and three workgroups
+// per CU need <= 53,760 B each (measured with a probe allocation: 53,760 B runs three, 54,016 B
+// two).  T = 16, order 2: the full 19^3 block is 54,872 B.  The 6-point stencil never reads an
+// entry with two or three coordinates on the block's boundary, so the two boundary PLANES
+// a = 0 and a = E - 1 are kept compact — only their 17 x 17 interior, row stride 17, behind
+// the 17 ordinary planes a = 1 .. 17 — 6137 + 2 * 289 = 6715 doubles = 53,720 B.  Only the
+// x-difference of a particle in the first (last) layer of cells of the tile reaches a compact
+// plane: one select per (i, j) on the plane offset.  Other tile sizes and order 4 keep the
+// plain block (they fit two workgroups either way).
 template <int ORDER, int T>
 struct GatherLds {
-    static constexpr int H = ORDER / 2, E = T + 1 + 2 * H;
-    static constexpr int trim = (ORDER == 2 && T == 16) ? E : 0;
-    static constexpr int doubles = E * E * E - 2 * trim;
+    static constexpr int H = ORDER / 2, E = T + 1 + 2 * H, PL = E * E;
+    static constexpr bool compact = (ORDER == 2 && T == 16);
+    static constexpr int main_planes = compact ? E - 2 : E;       // planes kept as E x E
+    static constexpr int IN = E - 2;                                // interior of a compact plane
+    static constexpr int P_LO = main_planes * PL;                   // compact plane a = 0
+    static constexpr int P_HI = P_LO + IN * IN;                     // compact plane a = E - 1
+    static constexpr int doubles = compact ? P_HI + IN * IN : E * E * E;
+    // index of block entry (a, b, c) for a in the main planes (compact: a = 1 .. E - 2)
+    __device__ static constexpr int main(int a, int b, int c) {
+        return ((a - (compact ? 1 : 0)) * E + b) * E + c;
+    }
 };
-#ifndef CG_GK_WAVES
-#define CG_GK_WAVES 4  // wavefronts per SIMD the register allocation aims at.  Measured (2^28
-                       // particles / 1024^3, order 2): the plain kernel needs 78 VGPRs and runs
-                       // 3 workgroups per CU in 6.74 ms (6.9 with two); the variant that also
-                       // histograms the next drift needs 114 — squeezed into 80 (waves 6) it
-                       // spills 72 B per lane and takes 9.0 instead of 7.3 ms
+// Wavefronts per SIMD the register allocation aims at (T = 16, order 2; 512-lane workgroups: 6
+// waves per SIMD = three workgroups per CU, which the compact LDS block above admits).  Measured
+// at 2^28 particles / 1024^3: the fused pass (MODE 2) 9.9 -> 8.8 ms with three instead of two;
+// it fits 80 registers without a spill once the x loop of its stencil is not unrolled and the
+// particle indices are 32-bit.  A build that spills loses more than the third workgroup gives
+// (MODE 2 with 4 spilled registers: 10.0 ms; the histogramming variant, MODE 1, squeezed into 80
+// spills 72 B per lane: 9.0 instead of 7.3 ms) — so MODE 1 stays at 4.
+#ifndef CG_GK_WAVES_FUSED
+#define CG_GK_WAVES_FUSED 6
 #endif
+#ifndef CG_GK_WAVES_PLAIN
+#define CG_GK_WAVES_PLAIN 6
+#endif
+template <int ORDER, int T, int MODE>
+constexpr int gk_waves() {
+    if (ORDER != 2 || T != 16) return 4;
+    return MODE == 2 ? CG_GK_WAVES_FUSED : (MODE == 0 ? CG_GK_WAVES_PLAIN : 4);
+}
 
 // MODE 0: gather + kick in place.  1: also histogram the tile keys after the next drift (PREP).
 // 2: kick, drift and scatter into the next tile order in one pass (nothing written in place).
 template <int ORDER, int T, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
-    (ORDER == 2 ? (MODE == 0 && T == 16 ? 6 : CG_GK_WAVES) : 4), 8))) void k_gather_kick_tiled(
+    gk_waves<ORDER, T, MODE>(), 8))) void k_gather_kick_tiled(
     const double *__restrict__ pos, double *__restrict__ mom,
     const unsigned *__restrict__ tile_offset, const double *__restrict__ mesh, i64 N, i64 ny,
     i64 pad, int g, int nt, unsigned ntiles, XMap xm, CicGeom geo, double c1, double c2,
     double factor, PrepArgs prep) {
     constexpr int H = ORDER / 2;
     constexpr int E = T + 1 + 2 * H;  // cells [T0-H, T0+T+H]
-    constexpr int TRIM = GatherLds<ORDER, T>::trim;
-    extern __shared__ double lds_raw[];
-    double *const lds = lds_raw - TRIM;  // entry i of the block lives at lds[i], TRIM <= i
+    using BL = GatherLds<ORDER, T>;
+    constexpr bool COMPACT = BL::compact;
+    extern __shared__ double lds[];
     constexpr bool PREP = MODE == 1, FUSED = MODE == 2;
+#ifdef CG_GK_STAGGER  // timing probe: the second workgroup of every CU starts half a period late
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)CG_GK_STAGGER)
+            __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     const unsigned tile = tile_for_block(blockIdx.x, ntiles);
     // the tile's particles: dense tile order -> one range; regions with gaps (prep.count_in)
     // -> its 8 buckets' (start, population), walked as one flat index
     // (FUSED only: the plain kernel's LDS block is sized so that three workgroups fit a CU
     // to the byte — nothing may be added to it)
-    __shared__ unsigned seg_beg[MODE == 2 ? 8 : 1], seg_pre[MODE == 2 ? 9 : 1];
+    // They live in entries of the staged block that no stencil reads and the staging leaves
+    // alone: compact layout — the corners (a, 0, 0) of the planes a = 1 .. 9, two words each;
+    // plain layout — rows b = E - 1 (8 words) and b = 0 (9 words) of plane a = 0 (a particle's
+    // stencil reaches plane 0 only at rows H .. E-1-H; E >= 5 doubles per row).
+    constexpr int SEG_AT = (E - 1) * E;   // plain layout: block index of row (0, E - 1)
+    static_assert(E * 8 >= 9 * 4, "segment tables do not fit");
+    auto seg_beg = [&](int f) -> unsigned & {
+        return COMPACT ? ((unsigned *)(lds + BL::main(1 + (f >> 1), 0, 0)))[f & 1]
+                       : ((unsigned *)(lds + SEG_AT))[f];
+    };
+    auto seg_pre = [&](int f) -> unsigned & {
+        return COMPACT ? ((unsigned *)(lds + BL::main(5 + (f >> 1), 0, 0)))[f & 1]
+                       : ((unsigned *)lds)[f];
+    };
     const bool gapped = FUSED && prep.count_in != nullptr;
-    i64 beg = tile_offset[8 * tile], end = tile_offset[8 * tile + 8];
+    // (particle indices fit 32 bits: the tile tables are uint32)
+    typedef unsigned pidx;
+    pidx beg = tile_offset[8 * tile], end = tile_offset[8 * tile + 8];
     if (gapped) {
         if (threadIdx.x < 64) {
             const int f = threadIdx.x & 7;
@@ -308,44 +356,55 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
                 if (f >= o) incl += v;
             }
             if (threadIdx.x < 8) {
-                seg_beg[f] = tile_offset[8 * tile + f];
-                seg_pre[f + 1] = incl;
-                if (f == 0) seg_pre[0] = 0;
+                seg_beg(f) = tile_offset[8 * tile + f];
+                seg_pre(f + 1) = incl;
+                if (f == 0) seg_pre(0) = 0;
             }
         }
         __syncthreads();
         beg = 0;
-        end = seg_pre[8];
+        end = seg_pre(8);
     }
     if (beg == end) return;  // uniform for the workgroup
     // FUSED: a workgroup is a chain of dependent round trips (stage the block, load a batch of
     // particles, gather, reserve places, store) and only two fit a CU: the particle loads of a
     // batch are issued one stage ahead — the first batch's under the staging of the block,
     // the next one's under the arithmetic of the present one
-    i64 pre_p = 0;
+    pidx pre_p = 0;
     bool pre_valid = false;
     double pre_x = 0, pre_y = 0, pre_z = 0, pre_mx = 0, pre_my = 0, pre_mz = 0;
-    auto fetch = [&](i64 pbase) {
-        i64 p = pbase + threadIdx.x;
+    auto fetch = [&](pidx pbase) {
+        pidx p = pbase + threadIdx.x;
         pre_valid = p < end;
         if (gapped && pre_valid) {  // flat index -> slot of its bucket's region
             int f = 0;
 #pragma unroll
             for (int step = 4; step > 0; step >>= 1)
-                if (seg_pre[f + step] <= (unsigned)p) f += step;
-            p = (i64)seg_beg[f] + (p - seg_pre[f]);
+                if (seg_pre(f + step) <= (unsigned)p) f += step;
+            p = seg_beg(f) + (p - seg_pre(f));
         }
         pre_p = p;
         if (pre_valid) {
-            pre_x = pos[3 * p + 0];
-            pre_y = pos[3 * p + 1];
-            pre_z = pos[3 * p + 2];
-            pre_mx = mom[3 * p + 0];
-            pre_my = mom[3 * p + 1];
-            pre_mz = mom[3 * p + 2];
+#ifdef CG_GK_NARROW
+            pre_x = pos[3 * (i64)p + 0];
+            pre_y = pos[3 * (i64)p + 1];
+            pre_z = pos[3 * (i64)p + 2];
+            pre_mx = mom[3 * (i64)p + 0];
+            pre_my = mom[3 * (i64)p + 1];
+            pre_mz = mom[3 * (i64)p + 2];
+#else
+            // a record is 24 B at an 8-byte boundary: one 16-byte and one 8-byte access (global
+            // memory takes vector accesses at their element's alignment) — 4 requests per
+            // particle instead of 6
+            const d2u8 a = *(const d2u8 *)(pos + 3 * (i64)p), b = *(const d2u8 *)(mom + 3 * (i64)p);
+            pre_x = a.x, pre_y = a.y, pre_z = pos[3 * (i64)p + 2];
+            pre_mx = b.x, pre_my = b.y, pre_mz = mom[3 * (i64)p + 2];
+#endif
         }
     };
+#ifdef CG_GK_PREFETCH
     if (FUSED) fetch(beg);
+#endif
     const int tc = tile % nt, tb = (tile / nt) % nt, ta = tile / (nt * nt);
     const int Ni = (int)N;
     const int T0a = (int)xm.x0 + ta * T, T0b = tb * T, T0c = tc * T;
@@ -381,7 +440,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
                 const double *plane = mesh + cg_xlayer(xm, (i64)(T0a - H + a), N) * ny * pad;
 #pragma unroll
                 for (int q = 0; q < NP; q++)
+#ifdef CG_GK_NOSTAGE  // timing probe only: the block is not read
+                    if (PL % 64 == 0 || lane + 64 * q < PL) v[s][q] = (double)off[q];
+#else
                     if (PL % 64 == 0 || lane + 64 * q < PL) v[s][q] = plane[off[q]];
+#endif
             }
         }
 #pragma unroll
@@ -391,25 +454,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                 for (int q = 0; q < NP; q++) {
                     const int i2 = lane + 64 * q;
-                    const bool stored = !TRIM || ((a > 0 || i2 >= TRIM) &&
-                                                  (a < E - 1 || i2 < PL - TRIM));
-                    if ((PL % 64 == 0 || i2 < PL) && stored) lds[a * PL + i2] = v[s][q];
+                    // where entry (a, i2 = b*E + c) of the block lives (-1: nowhere)
+                    int at;
+                    if (COMPACT) {
+                        const int b = i2 / E, c = i2 - b * E;
+                        const bool inner = b >= 1 && b <= E - 2 && c >= 1 && c <= E - 2;
+                        if (a == 0) at = inner ? BL::P_LO + (b - 1) * BL::IN + (c - 1) : -1;
+                        else if (a == E - 1) at = inner ? BL::P_HI + (b - 1) * BL::IN + (c - 1) : -1;
+                        else at = (FUSED && i2 == 0 && a <= 9) ? -1 : BL::main(a, 0, 0) + i2;
+                    } else {
+                        at = (FUSED && a == 0 && (i2 >= SEG_AT || i2 < E)) ? -1 : a * PL + i2;
+                    }
+                    const bool stored = at >= 0;
+                    if ((PL % 64 == 0 || i2 < PL) && stored) lds[at] = v[s][q];
                 }
             }
         }
     }
     __syncthreads();
-    for (i64 pbase = beg; pbase < end; pbase += 512) {
-        i64 p = pbase + threadIdx.x;
+    for (pidx pbase = beg; pbase < end; pbase += 512) {
+        pidx p = pbase + threadIdx.x;
         bool pvalid = p < end;
         double px = 0, py = 0, pz = 0, qx = 0, qy = 0, qz = 0;
         if (FUSED) {
+#ifndef CG_GK_PREFETCH
+            fetch(pbase);
+#endif
             p = pre_p;
             pvalid = pre_valid;
             px = pre_x, py = pre_y, pz = pre_z, qx = pre_mx, qy = pre_my, qz = pre_mz;
+#ifdef CG_GK_PREFETCH
             if (pbase + 512 < end) fetch(pbase + 512);
+#endif
         } else if (pvalid) {
-            px = pos[3 * p + 0], py = pos[3 * p + 1], pz = pos[3 * p + 2];
+            px = pos[3 * (i64)p + 0], py = pos[3 * (i64)p + 1], pz = pos[3 * (i64)p + 2];
         }
         unsigned next_key = kNoTile;
         double nx = 0, ny_ = 0, nz = 0, n0 = 0, n1 = 0, n2 = 0;  // FUSED: what travels
@@ -422,16 +500,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         double wx[2] = {cx.w0, cx.w1}, wy[2] = {cy.w0, cy.w1}, wz[2] = {cz.w0, cz.w1};
         double val[3] = {0, 0, 0};
         if (la >= 0 && la < T && lb >= 0 && lb < T && lc >= 0 && lc < T) {
-            const double *base = lds + ((la + H) * E + (lb + H)) * E + (lc + H);
-#pragma unroll
+            const double *base = lds + BL::main(la + H, lb + H, lc + H);
+            // compact layout: offsets from the central cell (la+1+i, lb+1+j, lc+1+k) to its
+            // x-neighbours when those lie in a compact boundary plane (row stride IN instead of
+            // E: the offset depends on j through -2j)
+            // (x_hi - x_lo is a constant: one register for both)
+            const int x_lo = BL::P_LO + lb * BL::IN + lc - BL::main(1, lb + 1, lc + 1);
+            constexpr int X_HI_LO = BL::P_HI - BL::P_LO - (BL::main(E - 2, 0, 0) - BL::main(1, 0, 0));
+            // FUSED: the x loop stays a loop (the 24 stencil reads of one x at a time): 80
+            // registers without a spill, i.e. three workgroups per CU
+#pragma unroll PREP ? 2 : 1
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     double wij = wx[i] * wy[j];
+                    const int xm = (COMPACT && la + i == 0) ? x_lo - 2 * j : -E * E;
+                    const int xp = (COMPACT && la + i == T) ? x_lo + X_HI_LO - 2 * j : E * E;
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         const double *cell = base + (i * E + j) * E + k;
                         auto phi = [&](int da, int db, int dc) {
+                            if (COMPACT && da != 0) return cell[da < 0 ? xm : xp];
                             return cell[(da * E + db) * E + dc];
                         };
                         double fx, fy, fz;
@@ -483,12 +572,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
             val[1] *= factor;
             val[2] *= factor;
         }
-        if (!FUSED) qx = mom[3 * p + 0], qy = mom[3 * p + 1], qz = mom[3 * p + 2];
+        if (!FUSED) qx = mom[3 * (i64)p + 0], qy = mom[3 * (i64)p + 1], qz = mom[3 * (i64)p + 2];
         const double m0 = qx + val[0], m1 = qy + val[1], m2 = qz + val[2];
         if (!FUSED) {
-            mom[3 * p + 0] = m0;
-            mom[3 * p + 1] = m1;
-            mom[3 * p + 2] = m2;
+            mom[3 * (i64)p + 0] = m0;
+            mom[3 * (i64)p + 1] = m1;
+            mom[3 * (i64)p + 2] = m2;
         }
         if (PREP || FUSED) {
             // Component.drift (species.py:2194-2196) of the kicked particle
@@ -540,9 +629,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
             // permutes per particle) is slower HERE — 10.4 vs 9.9 ms — because the permutes go
             // through the LDS crossbar, which the stencil reads already keep busy.
             if (valid) {
+#ifdef CG_GK_STOREINPLACE  // timing probe only: dense stores at the input slot
+                const i64 q = 3 * (i64)p;
+#else
                 const i64 q = 3 * ((i64)first + (lane - rs));
+#endif
+#ifdef CG_GK_NARROW
                 prep.pos_out[q] = nx, prep.pos_out[q + 1] = ny_, prep.pos_out[q + 2] = nz;
                 prep.mom_out[q] = n0, prep.mom_out[q + 1] = n1, prep.mom_out[q + 2] = n2;
+#else
+                d2u8 a, b;
+                a.x = nx, a.y = ny_, b.x = n0, b.y = n1;
+                *(d2u8 *)(prep.pos_out + q) = a;
+                prep.pos_out[q + 2] = nz;
+                *(d2u8 *)(prep.mom_out + q) = b;
+                prep.mom_out[q + 2] = n2;
+#endif
             }
 #elif defined(CG_GK_RUNSTORE)   // (NOSTORE: timing probe only)
             gk_store_run(prep.pos_out, (i64)first, rs, rl, lane, valid, nx, ny_, nz);
@@ -571,6 +673,9 @@ template <int ORDER, int T>
 static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsigned *tile_offset,
                          double c1, double c2, double factor, const PrepArgs *prep) {
     size_t lds = sizeof(double) * GatherLds<ORDER, T>::doubles;
+#ifdef CG_GK_LDS_PROBE  // timing probe only: a smaller LDS allocation (accesses beyond it are dropped)
+    if (const char *e = getenv("CONCEPT_GPU_GK_LDS_PROBE")) lds = (size_t)atol(e);
+#endif
     auto kern = k_gather_kick_tiled<ORDER, T, 0>;
     auto kern_prep = k_gather_kick_tiled<ORDER, T, 1>;
     auto kern_fused = k_gather_kick_tiled<ORDER, T, 2>;
