@@ -31,6 +31,10 @@ class Comm:
         self.next = (self.rank + 1) % self.world
         self.prev = (self.rank - 1) % self.world
         self.last_sent = 0
+        # CONCEPT_GPU_COMM_SELF=1: messages of a rank to itself go through the transport as
+        # well (a one-rank RCCL group then exercises every send / receive call of the sharded
+        # path on the one GPU there is: tests)
+        self.self_transport = os.environ.get('CONCEPT_GPU_COMM_SELF') == '1'
 
     def all_to_all(self, out, inp, out_splits=None, in_splits=None):
         if not self.stage:
@@ -90,7 +94,7 @@ class Comm:
 
     def sendrecv(self, send, dest, recv, source):
         """send -> dest while receiving <- source (a ring shift)."""
-        if dest == self.rank and source == self.rank:
+        if dest == self.rank and source == self.rank and not self.self_transport:
             recv.copy_(send)
             return
         if self.stage:
@@ -113,7 +117,7 @@ class Comm:
         wait for the message (RCCL runs it on its own stream behind what the current stream
         has queued so far, so kernels launched in between overlap it).  The buffers must stay
         untouched until finish().  gloo (tests): completed here, finish() does nothing."""
-        if (dest == self.rank and source == self.rank) or self.stage:
+        if (dest == self.rank and source == self.rank and not self.self_transport) or self.stage:
             self.sendrecv(send, dest, recv, source)
             return lambda: None
         ops = []

@@ -11,7 +11,13 @@ HEAD block (header_fields, snapshot.py:658-689), the POS / VEL / ID blocks with 
     mass = Massarr[type] * unit_mass
 with the default GADGET units 'kpc/h', 'km/s', '10¹⁰ m☉/h' (commons.py:2787-2804).
 Only single-file snapshots with per-type masses in the header; anything else aborts by name.
-Host-side I/O: numpy only; `to_components()` uploads to GPU Components."""
+Host-side I/O: numpy only; `to_components()` uploads to GPU Components.
+
+Over several domains (comm.init) every rank reads ITS SHARE of every component — the rows
+[start_local, start_local + N_local) of communication.partition() (communication.py:39-56), the
+byte ranges of the POS / VEL / ID blocks that hold them, as the reference's loader does
+(snapshot.py:2066-2330) — and `to_components()` hands them to Component.populate_local(), whose
+exchange() re-homes them to the slabs that own them: no rank ever holds the whole file."""
 import os
 import struct
 
@@ -32,6 +38,18 @@ headersize = 256
 default_units = {'length': 'kpc/h', 'velocity': 'km/s', 'mass': '10**10*m_sun/h'}
 
 
+def partition(size, rank, nprocs):
+    """communication.partition (communication.py:39-56): (start_local, size_local) of a fair
+    split of `size` rows; the higher ranks take the extra rows."""
+    size_local = size//nprocs
+    start_local = rank*size_local
+    rank_transition = nprocs + size_local*nprocs - size
+    if rank >= rank_transition:
+        size_local += 1
+        start_local += rank - rank_transition
+    return start_local, size_local
+
+
 def _unit(expr, h, p):
     ns = dict(vars(p.units))
     ns['h'] = h
@@ -44,7 +62,14 @@ class GadgetSnapshot:
     system of commons.params."""
     name = 'GADGET'
 
-    def __init__(self, params=None, units=None):
+    def __init__(self, params=None, units=None, rank=None, nprocs=None):
+        """rank / nprocs: read only this rank's share of every component (default: the active
+        domain decomposition's, concept_amd.comm; one domain: everything)"""
+        if rank is None:
+            from . import comm
+            active = comm.active()
+            rank, nprocs = (active.rank, active.world) if active is not None else (0, 1)
+        self.rank, self.nprocs = int(rank), int(nprocs)
         self.p = params or commons.params
         if self.p is None:
             raise ConceptGPUError('no parameters loaded: call concept_amd.commons.load_params()')
@@ -157,9 +182,11 @@ class GadgetSnapshot:
                     raise ConceptGPUError(
                         f'Mass of "{component_names[j]}" particles is {mass}×10¹⁰ h⁻¹ m☉ '
                         '(individual particle masses, block MASS, are not read)')
+                start_local, n_local = partition(n, self.rank, self.nprocs)
                 self.components.append({'name': component_names[j], 'species': 'matter', 'N': n,
                                         'mass': mass*self.unit_mass, 'pos': None, 'mom': None,
-                                        'ids': None})
+                                        'ids': None, 'start_local': start_local,
+                                        'N_local': n_local})
             if only_params:
                 return self
             boxsize = self.params['boxsize']
@@ -182,16 +209,20 @@ class GadgetSnapshot:
                         f'File {filename} contains {ntot} particles but its "{name}" block has '
                         f'a size of {size} bytes, which does not divide the particle number.')
                 per = size//ntot
-                f.seek(payload)
+
+                def rows(c, first, dtype, width):
+                    """rows [start_local, start_local + N_local) of component c, whose rows
+                    begin at row `first` of the block"""
+                    f.seek(payload + (first + c['start_local'])*per)
+                    return np.fromfile(f, dtype=dtype, count=width*c['N_local'])
                 if name in ('POS', 'VEL'):
                     if per not in (12, 24):
                         raise ConceptGPUError(f'No data format with a size of {per//3} bytes '
                                               f'implemented for block "{name}"')
-                    data = np.fromfile(f, dtype='<f4' if per == 12 else '<f8', count=3*ntot)
-                    data = data.astype(np.float64).reshape(ntot, 3)
                     start = 0
                     for c in self.components:
-                        part = data[start:start + c['N']]
+                        part = rows(c, start, '<f4' if per == 12 else '<f8', 3)
+                        part = part.astype(np.float64).reshape(c['N_local'], 3)
                         start += c['N']
                         if name == 'POS':
                             pos = part*self.unit_length
@@ -203,10 +234,9 @@ class GadgetSnapshot:
                 else:
                     if per not in (4, 8):
                         raise ConceptGPUError(f'ID block with {per} bytes per particle')
-                    ids = np.fromfile(f, dtype='<u4' if per == 4 else '<u8', count=ntot)
                     start = 0
                     for c in self.components:
-                        c['ids'] = ids[start:start + c['N']].astype(np.int64)
+                        c['ids'] = rows(c, start, '<u4' if per == 4 else '<u8', 1).astype(np.int64)
                         start += c['N']
             for c in self.components:
                 for blockname, key in (('POS', 'pos'), ('VEL', 'mom')):
@@ -218,16 +248,34 @@ class GadgetSnapshot:
         """GPU Components (concept_amd.species.Component) holding the loaded particles"""
         from .species import Component
         out = []
+        import torch
         for c in self.components:
             comp = Component(c['name'], c['species'], N=c['N'], mass=c['mass'], device=device)
-            comp.populate(c['pos'], 'pos')
-            comp.populate(c['mom'], 'mom')
-            if c.get('ids') is not None:
-                comp.populate(c['ids'], 'ids')  # the file's ID block (snapshot.py:1573-1600)
+            if comp.nprocs != self.nprocs:
+                raise ConceptGPUError(
+                    f'snapshot read as the share of rank {self.rank} of {self.nprocs}, but the '
+                    f'active decomposition has {comp.nprocs} domains')
+            if self.nprocs == 1:
+                comp.populate(c['pos'], 'pos')
+                comp.populate(c['mom'], 'mom')
+                if c.get('ids') is not None:
+                    comp.populate(c['ids'], 'ids')  # the file's ID block (snapshot.py:1573-1600)
+            else:
+                # this rank's rows of the file; exchange() (inside populate_local) re-homes
+                # them.  Without an ID block the reference numbers the particles by their row in
+                # the file (snapshot.py:2313-2322)
+                dev = comp.device
+                ids = c['ids'] if c.get('ids') is not None else \
+                    np.arange(c['start_local'], c['start_local'] + c['N_local'], dtype=np.int64)
+                comp.populate_local(torch.as_tensor(c['pos'], device=dev),
+                                    torch.as_tensor(c['mom'], device=dev),
+                                    torch.as_tensor(ids, device=dev),
+                                    first_row=c['start_local'])
             out.append(comp)
         return out
 
 
-def load(filename, only_params=False, params=None, units=None):
-    """snapshot.load (snapshot.py:3120-3230) for GADGET files"""
-    return GadgetSnapshot(params, units).load(filename, only_params)
+def load(filename, only_params=False, params=None, units=None, rank=None, nprocs=None):
+    """snapshot.load (snapshot.py:3120-3230) for GADGET files; over several domains every rank
+    reads its own share (see the module docstring)"""
+    return GadgetSnapshot(params, units, rank, nprocs).load(filename, only_params)

@@ -290,15 +290,19 @@ class Component:
         prefix, suffix = var[:-1], var[-1]
         getattr(self, prefix)[:, 'xyz'.index(suffix)] = t.to(self.device)
 
-    def populate_local(self, pos, mom, ids=None):
+    def populate_local(self, pos, mom, ids=None, first_row=None):
         """This rank's particles as device tensors (any rows; exchange() then re-homes those
         that belong to other domains).  N_local may differ between ranks; N stays the global
-        number given to the constructor."""
+        number given to the constructor.  first_row: the global row number of the first of
+        these rows (a rank-wise read of a file: its start_local); default: the ranks' rows
+        follow each other in rank order.  host() returns the particles in global row order."""
         n = pos.shape[0]
         self._new_store(n)
         self.pos.copy_(pos)
         self.mom.copy_(mom)
-        if self.comm is not None:
+        if first_row is not None:
+            first = int(first_row)
+        elif self.comm is not None:
             counts = self.comm.all_gather_ints([n])[:, 0].tolist()
             first = sum(counts[:self.rank])
         else:

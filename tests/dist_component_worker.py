@@ -95,6 +95,10 @@ def main():
         if 'traj_pm' in arg:
             for streaming in (True, False):
                 tt.test_stepper_timeloop_replays_reference_integrals(golden, arg, streaming)
+    elif case == 'config4':
+        import test_gpu_fluid
+        n_side, gs = (int(v) for v in arg.split(','))
+        test_gpu_fluid.test_config4_shape_across_domains(n_side, gs)
     elif case == 'snapshot':
         import test_gpu_pp
         test_gpu_pp.test_gadget_snapshot_to_gpu_components(golden)

@@ -28,7 +28,8 @@ def main():
     rng = np.random.default_rng(77)
     n = n_side**3
     pos = rng.uniform(0, L, (n, 3))
-    mom = rng.normal(0, 1.0, (n, 3))
+    cells_per_step = float(sys.argv[7]) if len(sys.argv) > 7 else 0.0
+    mom = rng.normal(0, cells_per_step*(L/N)/0.9 if cells_per_step else 1.0, (n, 3))
     pos_d = torch.tensor(pos, device='cuda')
     owner = dom.mesh.owner_rank(pos_d).cpu().numpy()
     mine = np.nonzero(owner == rank)[0]
@@ -36,6 +37,8 @@ def main():
                                  torch.tensor(mine, device='cuda'))
     parts.tile_sort()
     contribution, C, kick, dtm = 0.37, -2.5, -0.002, 0.9
+    if cells_per_step:
+        contribution *= 1.4e-3   # (kicks about half the size of the thermal momenta)
     if regions:
         # the streaming form: kick + drift + tile sort in one pass, particles in tile regions
         # with gaps, leavers handed over by the pass itself

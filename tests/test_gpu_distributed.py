@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def single_domain(N, n_side, steps, p3m=False):
+def single_domain(N, n_side, steps, p3m=False, cells_per_step=0.0):
     import torch
     from concept_amd import commons, shortrange
     from concept_amd.mesh import PotentialMesh
@@ -26,8 +26,12 @@ def single_domain(N, n_side, steps, p3m=False):
     rng = np.random.default_rng(77)
     n = n_side**3
     pos = torch.tensor(rng.uniform(0, L, (n, 3)), device='cuda')
-    mom = torch.tensor(rng.normal(0, 1.0, (n, 3)), device='cuda')
     contribution, C, kick, dtm = 0.37, -2.5, -0.002, 0.9
+    # (cells_per_step: rms displacement per step and dimension in mesh cells; 0: unit momenta)
+    sigma = cells_per_step*(L/N)/dtm if cells_per_step else 1.0
+    if cells_per_step:
+        contribution *= 1.4e-3   # (kicks about half the size of the thermal momenta)
+    mom = torch.tensor(rng.normal(0, sigma, (n, 3)), device='cuda')
     for step in range(steps):
         if p3m:
             scale = 1.25*L/N
@@ -57,19 +61,23 @@ def single_domain(N, n_side, steps, p3m=False):
                                          # odd split pass writing / reading the all-to-all
                                          # buffers blocked by destination domain), one step
                                          (2, 1024, False), (4, 1024, False)])
-def test_slab_domains_match_single_domain(world, N, p3m):
+def test_slab_domains_match_single_domain(world, N, p3m, n_side=20, steps=None):
     """p3m = 'fused': the PM step with the fused drift + exchange + sort
     (DistributedParticles.drift_exchange_sort) and the tile histogram prepared by the
     gather-kick; 'regions': kick + drift + tile sort in one pass over particles kept in tile
     regions with gaps (RegionParticles) — what bench.py runs on N > 1 GPUs."""
-    n_side, steps = 20, 3
+    steps_given = steps
+    steps = 3
     mode = p3m if isinstance(p3m, str) else ('p3m' if p3m else 'pm')
     p3m = p3m is True
     if mode in ('fused', 'regions'):
         steps = 5
     if N >= 1024:
         steps = 1
-    pos_ref, mom_ref = single_domain(N, n_side, steps, p3m)
+    if steps_given is not None:
+        steps = steps_given
+    cells_per_step = 0.4 if n_side > 20 else 0.0
+    pos_ref, mom_ref = single_domain(N, n_side, steps, p3m, cells_per_step)
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
@@ -81,10 +89,10 @@ def test_slab_domains_match_single_domain(world, N, p3m):
                        MASTER_PORT=str(port))
             procs.append(subprocess.Popen(
                 [sys.executable, os.path.join(REPO, 'tests', 'dist_worker.py'), tmp, str(N),
-                 str(n_side), str(steps), 'gloo', mode], env=env,
+                 str(n_side), str(steps), 'gloo', mode, str(cells_per_step)], env=env,
                 stdout=subprocess.PIPE,
                 stderr=subprocess.STDOUT))
-        outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+        outs = [p.communicate(timeout=1500)[0].decode() for p in procs]
         for r, p in enumerate(procs):
             assert p.returncode == 0, f'rank {r} failed:\n{outs[r][-3000:]}'
         ids, pos, mom = [], [], []
@@ -232,3 +240,63 @@ COMPONENT_CASES = [
 @pytest.mark.parametrize('case,arg', COMPONENT_CASES)
 def test_components_over_domains(world, case, arg):
     _run_ranks(world, 'dist_component_worker.py', [case, arg])
+
+
+def test_config3_shape_eight_slabs():
+    """BASELINE configs[3]'s decomposition at an eighth of its linear size: 8 x-slab domains of
+    64 layers of a 512^3 mesh, 256^3 particles, the streaming step (kick + drift + tile sort in
+    one pass over particles in tile regions, leavers shipped by the pass: what bench.py runs
+    on N > 1 GPUs), two steps, against one domain.  (The ranks share this GPU over gloo.)"""
+    test_slab_domains_match_single_domain(8, 512, 'regions', n_side=256, steps=2)
+
+
+def test_config4_shape_eight_slabs():
+    """BASELINE configs[4]'s shape — particles by P³M on a 128^3 mesh, a fluid on a 64^3 grid,
+    global PM grid 64: three mesh solves per long-range kick, the short-range kick with
+    boundary suppliers, drift and exchange — on 8 domains against one (tests/test_gpu_fluid.py:
+    test_config4_shape_across_domains)."""
+    _run_ranks(8, 'dist_component_worker.py', ['config4', '48,64'], timeout=1500)
+
+
+def test_rccl_one_rank_component_layer():
+    """The production transport under the Component layer on the one GPU there is: a 1-rank
+    RCCL group made the active decomposition (comm.init(force=True)), messages of the rank to
+    itself sent through RCCL as well (CONCEPT_GPU_COMM_SELF=1).  Exercised calls: the particle
+    exchange (all-to-all-v of rows with device-side destinations), the ghost-layer send /
+    receive of the slab mesh, the transposes of the distributed solve, the P³M boundary-supplier
+    shipping (sendrecv_component), the all-gathers of host(); results against the reference-
+    generated goldens, as on gloo."""
+    code = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path[:0] = [%r, %r]
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+from concept_amd import comm
+c = comm.init(force=True)
+assert c is not None and not c.stage and c.self_transport and c.world == 1
+def golden(name):
+    return np.load(os.path.join(%r, 'tests', 'golden', name + '.npz'))
+import test_gpu_p3m, test_gpu_pm, test_gpu_trajectory
+test_gpu_pm.test_gravity_api_pm(None, golden)                       # PM kick, drift, exchange, sort
+test_gpu_p3m.test_timeloop_sequence_vs_reference(golden, 'steps_p3m_n8_g32')  # + boundary suppliers
+test_gpu_p3m.test_shortrange_two_components_receivers_not_suppliers(True)
+test_gpu_trajectory.test_timeloop_run_vs_reference(golden, 'traj_pm_n8_g16')  # streaming + exchange
+for seed in range(2):
+    test_gpu_pm.test_random_streaming_timeloops(torch, seed)
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print('RCCL-COMPONENTS-OK')
+''' % (REPO, os.path.join(REPO, 'tests'), REPO)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               CONCEPT_GPU_COMM_SELF='1')
+    p = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and 'RCCL-COMPONENTS-OK' in out, out[-4000:]

@@ -57,3 +57,27 @@ def test_gadget_reader_only_params_and_errors(golden, tmp_path):
     bad2.write_bytes(b'\x00'*64)
     with pytest.raises(ConceptGPUError):
         snapshot.load(str(bad2))
+
+
+@pytest.mark.parametrize('name', ['gadget_sf2_32', 'gadget_sf1_64'])
+@pytest.mark.parametrize('nprocs', [2, 3, 8])
+def test_rank_wise_read_is_a_partition_of_the_file(golden, name, nprocs):
+    """Every rank reads its own byte ranges (communication.partition, communication.py:39-56:
+    the higher ranks take the extra rows); the shares, in rank order, are the whole file."""
+    from concept_amd import commons, snapshot
+    g = golden(name)
+    commons.load_params({'boxsize': float(g['boxsize'])})
+    path = os.path.join(HERE, 'golden', name + '.gadget')
+    whole = snapshot.load(path, rank=0, nprocs=1)
+    shares = [snapshot.load(path, rank=r, nprocs=nprocs) for r in range(nprocs)]
+    for i, c in enumerate(whole.components):
+        starts = [s.components[i]['start_local'] for s in shares]
+        counts = [s.components[i]['N_local'] for s in shares]
+        assert starts[0] == 0 and sum(counts) == c['N']
+        assert all(starts[r + 1] == starts[r] + counts[r] for r in range(nprocs - 1))
+        assert max(counts) - min(counts) <= 1 and counts == sorted(counts)
+        for key in ('pos', 'mom', 'ids'):
+            if c[key] is None:
+                continue
+            assert np.array_equal(np.concatenate([s.components[i][key] for s in shares]), c[key])
+    assert snapshot.partition(10, 0, 4) == (0, 2) and snapshot.partition(10, 3, 4) == (7, 3)
