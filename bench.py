@@ -430,6 +430,34 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
                      + ('' if backend == 'nccl' else
                         '; THIS RUN staged the messages through host memory (gloo): the '
                         'fraction says nothing about xGMI'))}
+    # The link model of DESIGN.md §6 beside the measured stages, so that a scaling run can be
+    # read stage by stage: local kernels at 1/P of their single-GPU times (measured on one
+    # MI355X at this workload, profiles/r03_bench_ns_full_default.json), each transpose at
+    # N^3*8/P^2 B per peer over that peer's own xGMI link, the z / y transforms hidden under
+    # the links when those are slower (the transposes are pipelined with them), the x pass not.
+    link_model = None
+    if world > 1:
+        scale = (N/1024.0)**3/world
+        single = {'deposit': 3.1, 'fft_zy_pairs': 11.6, 'fft_x_fused': 4.0,
+                  'kick_drift_sort': 9.0}   # ms, one GPU, 2^28 particles / 1024^3
+        local = {k: v*scale*((total/2.0**28)/(N/1024.0)**3 if k in ('deposit', 'kick_drift_sort')
+                             else 1.0) for k, v in single.items()}
+        per_peer = dom.tbuf_a.numel()*8/world
+        t_transpose = per_peer/(XGMI_LINK_GBS_DIR*1e9)*1e3
+        poisson_pred = max(2*t_transpose, local['fft_zy_pairs']) + local['fft_x_fused']
+        pred = local['deposit'] + poisson_pred + local['kick_drift_sort']
+        link_model = {
+            'single_gpu_kernel_ms': single,
+            'local_kernel_ms_at_this_P': {k: round(v, 3) for k, v in local.items()},
+            'bytes_per_peer_per_transpose': int(per_peer),
+            'transpose_ms_at_link_rate': round(t_transpose, 3),
+            'predicted_poisson_stage_ms': round(poisson_pred, 3),
+            'predicted_step_ms': round(pred, 3),
+            'measured_step_ms': round(elapsed/args.steps*1e3, 3),
+            'measured_poisson_stage_ms': round(ps_ms, 3),
+            'note': ('prediction = deposit/P + max(2 transposes at one xGMI link per peer '
+                     f'({XGMI_LINK_GBS_DIR} GB/s one way), z/y transforms/P) + x pass/P + fused '
+                     'particle pass/P; exchange of leavers and halo layers not priced (MBs)')}
     print(json.dumps({
         'metric': 'PM particle-updates/sec', 'value': total*args.steps/elapsed,
         'unit': 'particle-updates/s', 'steps_per_sec': args.steps/elapsed, 'n_gpus': world,
@@ -452,7 +480,7 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
                      'achieved': round(gk_rate, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(gk_rate/HBM_PEAK_GBS, 4), 'traffic': None,
                      'algorithmic_bytes': int(mv[gk_name]), 'kernel_ms': round(gk_ms, 4)},
-        'transport': transport, 'cpu_baseline': None,
+        'transport': transport, 'link_model': link_model, 'cpu_baseline': None,
         'stages_ms_rank0': {k: round(v, 3) for k, v in stages.items()},
         'transpose_probe_rank0': probe,
     }))

@@ -93,6 +93,177 @@ static int make_plans(cg_ctx *c) {
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------
+// x-slab domains on the rocFFT backend: grids that are not a power of two (the reference
+// accepts any size divisible by the decomposition, communication.py:692-741,
+// mesh.py:1898-1905; its own tests use 24 and 36).  Same stages and the same transpose-buffer
+// layout as the hand-written path (cg_fft.hip fft_dist): 2-D real transforms of the owned
+// layers, rows packed by destination domain, all-to-all (the caller's), 1-D transforms along x
+// on complex[N][JB + 1][cp], and back.  The pack / unpack is a pass of its own here (the
+// hand-written y pass writes the blocked layout directly).
+// ---------------------------------------------------------------------------
+#include <map>
+struct DistPlans {
+    std::map<i64, std::pair<rocfft_plan, rocfft_plan>> layers2d;  // by number of layers
+    rocfft_plan x_fwd = nullptr, x_bwd = nullptr;
+    rocfft_execution_info info = nullptr;
+    void *work = nullptr;
+    size_t work_bytes = 0;
+};
+
+static int dist_work(cg_ctx *c, rocfft_plan plan) {
+    DistPlans *d = c->dist_plans;
+    size_t w = 0;
+    CG_FFT(rocfft_plan_get_work_buffer_size(plan, &w));
+    if (w > d->work_bytes) {
+        CG_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(d->work);
+        d->work = nullptr;
+        CG_HIP(hipMalloc(&d->work, w));
+        d->work_bytes = w;
+    }
+    if (!d->info) CG_FFT(rocfft_execution_info_create(&d->info));
+    if (d->work_bytes)
+        CG_FFT(rocfft_execution_info_set_work_buffer(d->info, d->work, d->work_bytes));
+    CG_FFT(rocfft_execution_info_set_stream(d->info, c->stream));
+    return 0;
+}
+
+static int dist_plans_2d(cg_ctx *c, i64 nlayers, rocfft_plan *fwd, rocfft_plan *bwd) {
+    if (!c->dist_plans) c->dist_plans = new DistPlans();
+    auto &m = c->dist_plans->layers2d;
+    auto it = m.find(nlayers);
+    if (it == m.end()) {
+        const size_t N = (size_t)c->N, P = (size_t)c->pad;
+        size_t lengths[2] = {N, N};  // fastest first: z, y
+        size_t rstr[2] = {1, P}, cstr[2] = {1, P / 2}, off[1] = {0};
+        rocfft_plan pf = nullptr, pb = nullptr;
+        rocfft_plan_description d = nullptr;
+        CG_FFT(rocfft_plan_description_create(&d));
+        CG_FFT(rocfft_plan_description_set_data_layout(
+            d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, off, off, 2, rstr,
+            P * (size_t)c->ny, 2, cstr, (P / 2) * (size_t)c->ny));
+        CG_FFT(rocfft_plan_create(&pf, rocfft_placement_inplace, rocfft_transform_type_real_forward,
+                                  rocfft_precision_double, 2, lengths, (size_t)nlayers, d));
+        CG_FFT(rocfft_plan_description_destroy(d));
+        CG_FFT(rocfft_plan_description_create(&d));
+        CG_FFT(rocfft_plan_description_set_data_layout(
+            d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, off, off, 2, cstr,
+            (P / 2) * (size_t)c->ny, 2, rstr, P * (size_t)c->ny));
+        CG_FFT(rocfft_plan_create(&pb, rocfft_placement_inplace, rocfft_transform_type_real_inverse,
+                                  rocfft_precision_double, 2, lengths, (size_t)nlayers, d));
+        CG_FFT(rocfft_plan_description_destroy(d));
+        it = m.emplace(nlayers, std::make_pair(pf, pb)).first;
+    }
+    *fwd = it->second.first;
+    *bwd = it->second.second;
+    return 0;
+}
+
+static int dist_plans_x(cg_ctx *c) {
+    if (!c->dist_plans) c->dist_plans = new DistPlans();
+    DistPlans *dp = c->dist_plans;
+    if (dp->x_fwd) return 0;
+    const size_t N = (size_t)c->N, cp = (size_t)c->pad / 2, JB = N / (size_t)c->p.nprocs;
+    size_t lengths[1] = {N}, str[1] = {(JB + 1) * cp}, off[1] = {0};
+    for (int inv = 0; inv < 2; inv++) {
+        rocfft_plan_description d = nullptr;
+        CG_FFT(rocfft_plan_description_create(&d));
+        // one transform per (row of the own block, kk): consecutive complex numbers
+        CG_FFT(rocfft_plan_description_set_data_layout(
+            d, rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, off,
+            off, 1, str, 1, 1, str, 1));
+        CG_FFT(rocfft_plan_create(inv ? &dp->x_bwd : &dp->x_fwd, rocfft_placement_inplace,
+                                  inv ? rocfft_transform_type_complex_inverse
+                                      : rocfft_transform_type_complex_forward,
+                                  rocfft_precision_double, 1, lengths, JB * cp, d));
+        CG_FFT(rocfft_plan_description_destroy(d));
+    }
+    return 0;
+}
+
+// rows j of the layers [layer0, layer0 + nlayers) between the slab's Fourier layout
+// complex[layer][ny][cp] and the transpose buffer blocked by destination domain
+// buf[q = j / JB][layer][j - q JB][cp] (JB + 1 rows per layer)
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_dist_rows(double2 *__restrict__ slab,
+                                                   double2 *__restrict__ buf, i64 N, i64 ny,
+                                                   i64 cp, i64 nxl, i64 JB, i64 layer0) {
+    const i64 row = blockIdx.x;  // (layer - layer0) * N + j
+    const i64 l = layer0 + row / N, j = row % N, q = j / JB;
+    double2 *a = slab + (l * ny + j) * cp;
+    double2 *b = buf + ((q * nxl + l) * (JB + 1) + (j - q * JB)) * cp;
+    for (i64 kk = threadIdx.x; kk < N / 2 + 1; kk += blockDim.x) {
+        if (PACK) b[kk] = a[kk];
+        else a[kk] = b[kk];
+    }
+}
+
+static int dist_generic(cg_ctx *c, int what, double2 *buf, int deconv_order, double C,
+                        int long_range, double E, i64 layer0, i64 nlayers) {
+    const i64 cp = c->pad / 2, N = c->N, nxl = c->xmap.nxl, JB = N / c->p.nprocs;
+    if (nlayers < 0) nlayers = nxl - layer0;
+    double2 *m = (double2 *)c->mesh0;
+    if (what == 0 || what == 1) {
+        rocfft_plan pf, pb;
+        if (dist_plans_2d(c, nlayers, &pf, &pb)) return 1;
+        void *io[1] = {(void *)(m + layer0 * c->ny * cp)};
+        if (what == 0) {
+            if (dist_work(c, pf)) return 1;
+            CG_FFT(rocfft_execute(pf, io, nullptr, c->dist_plans->info));
+            hipLaunchKernelGGL((k_dist_rows<true>), dim3((unsigned)(nlayers * N)), dim3(256), 0,
+                               c->stream, m, buf, N, c->ny, cp, nxl, JB, layer0);
+        } else {
+            hipLaunchKernelGGL((k_dist_rows<false>), dim3((unsigned)(nlayers * N)), dim3(256), 0,
+                               c->stream, m, buf, N, c->ny, cp, nxl, JB, layer0);
+            if (dist_work(c, pb)) return 1;
+            CG_FFT(rocfft_execute(pb, io, nullptr, c->dist_plans->info));
+        }
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
+    if (dist_plans_x(c)) return 1;
+    void *io[1] = {(void *)buf};
+    if (what == 2 || what == 3) {
+        if (dist_work(c, c->dist_plans->x_fwd)) return 1;
+        CG_FFT(rocfft_execute(c->dist_plans->x_fwd, io, nullptr, c->dist_plans->info));
+    }
+    if (what == 2) {
+        // the Poisson / deconvolution kernel on the rows of this domain (the Fourier view of
+        // cg_dist_bind_fourier, for the duration of the call on `buf`)
+        double2 *four = c->four;
+        const i64 f_si = c->f_si;
+        const int f_j0 = c->f_j0, f_nj = c->f_nj;
+        c->four = buf;
+        c->f_si = (JB + 1) * cp;
+        c->f_j0 = (int)(JB * c->p.rank);
+        c->f_nj = (int)JB;
+        int rc = cgk_kspace(c, deconv_order, C, long_range, E);
+        c->four = four, c->f_si = f_si, c->f_j0 = f_j0, c->f_nj = f_nj;
+        if (rc) return rc;
+    }
+    if (what == 2 || what == 4) {
+        if (dist_work(c, c->dist_plans->x_bwd)) return 1;
+        CG_FFT(rocfft_execute(c->dist_plans->x_bwd, io, nullptr, c->dist_plans->info));
+    }
+    return 0;
+}
+
+static void dist_plans_destroy(cg_ctx *c) {
+    DistPlans *d = c->dist_plans;
+    if (!d) return;
+    for (auto &kv : d->layers2d) {
+        rocfft_plan_destroy(kv.second.first);
+        rocfft_plan_destroy(kv.second.second);
+    }
+    if (d->x_fwd) rocfft_plan_destroy(d->x_fwd);
+    if (d->x_bwd) rocfft_plan_destroy(d->x_bwd);
+    if (d->info) rocfft_execution_info_destroy(d->info);
+    (void)hipFree(d->work);
+    delete d;
+    c->dist_plans = nullptr;
+}
+
 static bool g_rocfft_ready = false;
 
 extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
@@ -113,8 +284,8 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
     CG_CHECK(p->gridsize % p->nprocs == 0 && (p->gridsize / p->nprocs) % 2 == 0,
              "cg_create: gridsize %lld must be divisible by 2*nprocs (mesh.py:1898-1905,3779)",
              (long long)p->gridsize);
-    CG_CHECK(p->nprocs == 1 || cgk_fft_supported(p->gridsize),
-             "cg_create: the multi-GPU FFT needs a power-of-two grid size (16..2048)");
+    // (x-slab domains: power-of-two grids 16..2048 take the hand-written passes, any other
+    // admissible size rocFFT per slab + a pack pass — dist_generic above)
     // the potential halo is filled from the neighbour's OWNED layers in one hop
     // (communicate_ghosts(grid,'='), communication.py:563-660): a slab thinner than the G = 3
     // halo layers would hand on its own ghost layers
@@ -227,7 +398,7 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
             cg_set_error("cg_create: FFT twiddle upload failed");
             return fail();
         }
-    } else if (make_plans(c)) {
+    } else if (p->nprocs == 1 && make_plans(c)) {  // (x-slab domains: plans made on first use)
         return fail();
     }
     *out = c;
@@ -236,6 +407,7 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
 
 extern "C" int cg_destroy(cg_ctx *c) {
     if (!c) return 0;
+    dist_plans_destroy(c);
     if (c->plan_fwd) rocfft_plan_destroy(c->plan_fwd);
     if (c->plan_bwd) rocfft_plan_destroy(c->plan_bwd);
     if (c->info_fwd) rocfft_execution_info_destroy(c->info_fwd);
@@ -944,24 +1116,26 @@ extern "C" int cg_layers_write(cg_ctx *c, int64_t layer0, int64_t nlayers, const
 
 extern "C" int cg_dist_fft_forward(cg_ctx *c, double *send_buf) {
     CG_CHECK(c && send_buf, "cg_dist_fft_forward: null argument");
-    CG_CHECK(c->custom_fft, "cg_dist_fft_forward: needs the hand-written FFT backend");
+    if (!c->custom_fft) return dist_generic(c, 0, (double2 *)send_buf, 0, 0.0, 0, 0.0, 0, -1);
     return cgk_fft_dist_forward(c, send_buf, 0, -1);
 }
 extern "C" int cg_dist_fft_forward_layers(cg_ctx *c, double *send_buf, int64_t layer0,
                                           int64_t nlayers) {
     CG_CHECK(c && send_buf, "cg_dist_fft_forward_layers: null argument");
-    CG_CHECK(c->custom_fft, "cg_dist_fft_forward_layers: needs the hand-written FFT backend");
     CG_CHECK(layer0 >= 0 && nlayers >= 1 && layer0 + nlayers <= c->xmap.nxl,
              "cg_dist_fft_forward_layers: layers [%lld, %lld) outside the %lld owned ones",
              (long long)layer0, (long long)(layer0 + nlayers), (long long)c->xmap.nxl);
+    if (!c->custom_fft)
+        return dist_generic(c, 0, (double2 *)send_buf, 0, 0.0, 0, 0.0, layer0, nlayers);
     return cgk_fft_dist_forward(c, send_buf, layer0, nlayers);
 }
 extern "C" int cg_dist_fft_xsolve(cg_ctx *c, double *buf, int deconv_order, double C,
                                   int long_range, double E) {
     CG_CHECK(c && buf, "cg_dist_fft_xsolve: null argument");
-    CG_CHECK(c->custom_fft, "cg_dist_fft_xsolve: needs the hand-written FFT backend");
     CG_CHECK(deconv_order >= 0 && deconv_order <= 8, "cg_dist_fft_xsolve: deconv_order %d",
              deconv_order);
+    if (!c->custom_fft)
+        return dist_generic(c, 2, (double2 *)buf, deconv_order, C, long_range, E, 0, -1);
     return cgk_fft_dist_xsolve(c, buf, deconv_order, C, long_range, E);
 }
 extern "C" int cg_dist_bind_fourier(cg_ctx *c, double *buf) {
@@ -984,7 +1158,8 @@ extern "C" int cg_dist_bind_fourier(cg_ctx *c, double *buf) {
 }
 extern "C" int cg_dist_fft_x(cg_ctx *c, double *buf, int inverse) {
     CG_CHECK(c && buf, "cg_dist_fft_x: null argument");
-    CG_CHECK(c->custom_fft, "cg_dist_fft_x: needs the hand-written FFT backend");
+    if (!c->custom_fft)
+        return dist_generic(c, inverse ? 4 : 3, (double2 *)buf, 0, 0.0, 0, 0.0, 0, -1);
     return cgk_fft_dist_x(c, buf, inverse ? 1 : 0);
 }
 extern "C" int cg_emigrant_dest(cg_ctx *c, const double *pos, const double *mom,
@@ -996,16 +1171,19 @@ extern "C" int cg_emigrant_dest(cg_ctx *c, const double *pos, const double *mom,
 }
 extern "C" int cg_dist_fft_backward(cg_ctx *c, const double *recv_buf) {
     CG_CHECK(c && recv_buf, "cg_dist_fft_backward: null argument");
-    CG_CHECK(c->custom_fft, "cg_dist_fft_backward: needs the hand-written FFT backend");
+    if (!c->custom_fft)
+        return dist_generic(c, 1, (double2 *)const_cast<double *>(recv_buf), 0, 0.0, 0, 0.0, 0, -1);
     return cgk_fft_dist_backward(c, recv_buf, 0, -1);
 }
 extern "C" int cg_dist_fft_backward_layers(cg_ctx *c, const double *recv_buf, int64_t layer0,
                                            int64_t nlayers) {
     CG_CHECK(c && recv_buf, "cg_dist_fft_backward_layers: null argument");
-    CG_CHECK(c->custom_fft, "cg_dist_fft_backward_layers: needs the hand-written FFT backend");
     CG_CHECK(layer0 >= 0 && nlayers >= 1 && layer0 + nlayers <= c->xmap.nxl,
              "cg_dist_fft_backward_layers: layers [%lld, %lld) outside the %lld owned ones",
              (long long)layer0, (long long)(layer0 + nlayers), (long long)c->xmap.nxl);
+    if (!c->custom_fft)
+        return dist_generic(c, 1, (double2 *)const_cast<double *>(recv_buf), 0, 0.0, 0, 0.0,
+                            layer0, nlayers);
     return cgk_fft_dist_backward(c, recv_buf, layer0, nlayers);
 }
 extern "C" int cg_owner_rank(cg_ctx *c, const double *pos, int64_t n, int32_t *owner_out) {

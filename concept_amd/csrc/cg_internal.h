@@ -113,6 +113,7 @@ struct cg_ctx {
     double *ktab_n = nullptr, *ktab_s = nullptr, *ktab_q = nullptr;
     // rocFFT
     rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr;
+    struct DistPlans *dist_plans = nullptr;  // x-slab domains on the rocFFT backend (cg_context.hip)
     rocfft_execution_info info_fwd = nullptr, info_bwd = nullptr;
     void *fft_work = nullptr;
     size_t fft_work_bytes = 0;

@@ -370,10 +370,12 @@ class Component:
         if g is None:
             g = 2*int(round(self.N**(1/3)))
         # only the particle bookkeeping (tile order, drift, Δmom) needs this mesh: make any
-        # size admissible (even, >= 4; on P domains a power of two with slabs >= 4 layers)
+        # size admissible (even, >= 4; on P domains divisible by 2 P with slabs >= 4 layers:
+        # cg_create, mesh.py:1898-1905)
         g = max(4, g + g % 2)
-        if self.nprocs > 1 and (g & (g - 1) or g < 4*self.nprocs or g < 16):
-            g = max(16, 4*self.nprocs, 1 << (g - 1).bit_length())
+        if self.nprocs > 1:
+            step = 2*self.nprocs
+            g = max(4*self.nprocs, -(-g//step)*step)
         return get_mesh(g, p.boxsize, p.nghosts, p.cell_centered, 2, self.device)
 
     def _use_mesh(self, mesh):

@@ -300,3 +300,33 @@ print('RCCL-COMPONENTS-OK')
                        stderr=subprocess.STDOUT, timeout=900)
     out = p.stdout.decode()
     assert p.returncode == 0 and 'RCCL-COMPONENTS-OK' in out, out[-4000:]
+
+
+# Grids that are not a power of two on several domains (rocFFT per slab + a pack pass instead of
+# the hand-written transposing passes; the reference takes any size divisible by the
+# decomposition, communication.py:692-741, and its own tests use 24 and 36): the same bodies,
+# against the same reference-generated goldens.  A slab must hold an even number (>= 4) of
+# layers, which decides the admissible domain counts per case.
+NON_POW2_CASES = [
+    (2, 'p3m_kick', 'p3m_n12_g36_lattice'),      # 36: slabs of 18 layers
+    (2, 'p3m_kick', 'p3m_n16_g48_clustered'), (4, 'p3m_kick', 'p3m_n16_g48_clustered'),
+    (2, 'multigrid', 'multigrid_n8_g16'),        # 24 -> 16 -> 12, fluid on 8
+    (2, 'multigrid', 'multigrid_n8_up32_down24'),
+    (2, 'orders', 'cic_fcc_multigrid_n8'),
+    (2, 'mixed', 'fluid2_pm_n6_g12'),
+    (2, 'traj', 'traj_p3m_n8_g24'), (4, 'traj', 'traj_p3m_n8_g24'),   # whole runs, rungs
+    (2, 'traj', 'traj_p3m_n8_g24_r1'),
+]
+
+
+@pytest.mark.parametrize('world,case,arg', NON_POW2_CASES)
+def test_non_power_of_two_over_domains(world, case, arg):
+    _run_ranks(world, 'dist_component_worker.py', [case, arg])
+
+
+@pytest.mark.parametrize('world,N,mode', [(2, 48, False), (4, 96, 'regions'), (2, 72, 'fused'),
+                                          (3, 36, False), (6, 96, 'regions')])
+def test_slab_domains_match_single_domain_non_power_of_two(world, N, mode):
+    """the low-level step (deposit, transposing solve, gather, drift, exchange, sort) on grids
+    of 48, 72, 96 and 36 cells, also on 3 and 6 domains"""
+    test_slab_domains_match_single_domain(world, N, mode)
