@@ -38,7 +38,7 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 XGMI_LINK_GBS_DIR = 76.8     # one xGMI link, one direction (153.6 GB/s bidirectional; 7 links)
-PMC_FILE = 'profiles/r02_pmc_hbm_traffic.json'
+PMC_FILE = 'profiles/r03_pmc_hbm_traffic.json'
 
 WORKLOADS = {
     # name: (particles, gridsize)
@@ -272,21 +272,32 @@ def thermal_momenta(torch, args, shape, cell, mass, dt, dev, gen):
 def pmc_traffic(dom_kernel, workload):
     """HBM (L2 <-> fabric) bytes per launch of the dominant kernel from the committed PMC run of
     this command (rocprofv3 --pmc needs its own process: it cannot be collected from inside the
-    bench).  None unless the file describes this workload and kernel."""
+    bench).  (None, why) unless the file describes this workload, this kernel AND the sources
+    the loaded library was built from (tools/pmc_traffic.py stamps their hash; the build writes
+    it beside the .so): a counter run of other kernels is not quoted."""
     try:
         pmc = json.load(open(os.path.join(REPO, PMC_FILE)))
     except Exception:
-        return None, None
+        return None, f'{PMC_FILE} not found'
     if pmc.get('workload_name') != workload:
-        return None, None
+        return None, f'{PMC_FILE} describes workload {pmc.get("workload_name")}, not {workload}'
+    try:
+        from concept_amd import build as cg_build
+        built = open(cg_build.LIB + '.srchash').read().strip()
+    except Exception:
+        built = None
+    if built is None or pmc.get('csrc_hash') != built:
+        return None, (f'{PMC_FILE} was collected on a library built from sources '
+                      f'{pmc.get("csrc_hash")}, the one loaded now is built from {built}: not '
+                      'quoted (re-collect with tools/record_profiles.sh)')
     for kname, entry in pmc.get('kernels', {}).items():
         if entry.get('bench_key') == dom_kernel:
             return entry['total_GB']*1e9, (
                 f"{PMC_FILE}: kernel {kname}, collected at commit {pmc.get('commit', '?')} "
-                f"({pmc.get('date', '?')}) with `{pmc.get('command', '?')}`; rocprofv3 --pmc "
-                'FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections of '
-                'MI355X_MICROARCH.md')
-    return None, None
+                f"({pmc.get('date', '?')}, sources {built}) with `{pmc.get('command', '?')}`; "
+                'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections '
+                'of MI355X_MICROARCH.md')
+    return None, f'{PMC_FILE} has no entry for {dom_kernel}'
 
 
 # ---------------------------------------------------------------------------

@@ -25,6 +25,23 @@ FLAGS = [
 ]
 
 
+def source_hash():
+    """sha256 over the sources libconcept_gpu.so is built from (csrc/*.hip, *.h, the C ABI header
+    and the compiler flags): written beside the library at build time (libconcept_gpu.so.srchash)
+    and stamped into profiles/*_pmc_hbm_traffic.json by tools/pmc_traffic.py, so that bench.py
+    can tell whether a committed counter run describes the kernels it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                   if f.endswith(('.hip', '.h'))) + [HEADERS[-1]]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    h.update(' '.join(FLAGS[:7]).encode())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -55,6 +72,11 @@ def build(force=False, verbose=True):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(LIB + '.srchash', 'w') as f:
+            f.write(source_hash() + '\n')
+    if not os.path.exists(LIB + '.srchash'):
+        with open(LIB + '.srchash', 'w') as f:
+            f.write(source_hash() + '\n')
     return LIB
 
 

@@ -19,8 +19,11 @@ import os
 import sqlite3
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 BENCH_KEYS = {  # bench.py kernel names -> demangled prefixes of the device kernels
     'kick_drift_sort': ['k_gather_kick_tiled<2, 16, 2>'],
+    'fft_zy_forward_chunked': [], 'fft_yz_backward_chunked': [],
     'gather_kick': ['k_gather_kick_tiled<2, 16, 1>', 'k_gather_kick_tiled<2, 16, 0>'],
     'deposit': ['k_deposit_cic_pull<16, false>'],
     'fft_x_fused_kspace': ['k_fft_strided_h<10, 256, 2>', 'k_fft_strided_p<10, 512, 2, 8>'],
@@ -57,7 +60,11 @@ def main():
             if any(short.startswith(p) for p in prefixes):
                 e['bench_key'] = key
         kernels[short] = e
+    from concept_amd import build as cg_build
     json.dump({'workload_name': workload, 'commit': commit,
+               # what the library that ran was built from (bench.py quotes these figures only
+               # for a library with the same hash)
+               'csrc_hash': open(cg_build.LIB + '.srchash').read().strip(),
                'date': datetime.date.today().isoformat(), 'command': command,
                'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate '
                          'passes); KiB of L2 <-> fabric requests, reads doubled (gfx950), per '

@@ -1,0 +1,39 @@
+#!/bin/bash
+# Records the round's measurements on the GPU box into gpurun_out/profiles_new/ (copied into
+# profiles/ afterwards):  tools/record_profiles.sh r03 <commit>
+# One-liners a driver can reproduce are listed in profiles/README.md.
+set -u
+TAG=${1:-r03}; COMMIT=${2:-unknown}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/profiles_new; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+# 1. per-kernel statistics of the default command
+rocprofv3 --kernel-trace --stats -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
+python $R/tools/rocprof_summary.py $OUT/stats $OUT/${TAG}_rocprof_kernel_stats_ns.txt > /dev/null
+# 2. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_f -- $CMD > $OUT/pmc_f.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_w -- $CMD > $OUT/pmc_w.log 2>&1
+python $R/tools/rocprof_summary.py --pmc $OUT/pmc_f > $OUT/${TAG}_pmc_FETCH_SIZE_per_kernel.txt
+python $R/tools/rocprof_summary.py --pmc $OUT/pmc_w > $OUT/${TAG}_pmc_WRITE_SIZE_per_kernel.txt
+python $R/tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w $OUT/${TAG}_pmc_hbm_traffic.json ns_256M_1024 $COMMIT "python bench.py --steps 4 --warmup 2 --no-cpu-baseline" > $OUT/pmc_traffic.log 2>&1
+cp $OUT/${TAG}_pmc_hbm_traffic.json $R/profiles/${TAG}_pmc_hbm_traffic.json   # (so that the lines below quote it)
+# 3. P3M: statistics and SQ counters of the sweep
+P3M="python $R/bench.py --workload c2_256c_512 --p3m --steps 5 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/stats_p3m -- $P3M > $OUT/stats_p3m.log 2>&1
+python $R/tools/rocprof_summary.py $OUT/stats_p3m $OUT/${TAG}_rocprof_kernel_stats_p3m.txt > /dev/null
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/pmc_sr -- $P3M > $OUT/pmc_sr.log 2>&1
+python $R/tools/rocprof_summary.py --pmc $OUT/pmc_sr > $OUT/${TAG}_pmc_sr_sweep.txt
+# 4. the bench lines
+cd $R
+python bench.py --workload c2_256c_512 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_c2_256c_512.json
+python bench.py --workload c2_256c_512 --p3m --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_p3m_c3_256c_512.json
+python bench.py --workload c2_256c_512 --p3m --dist clustered --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_p3m_clustered.json
+python bench.py --dist clustered --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_ns_clustered.json
+python bench.py --no-fused --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_ns_unfused.json
+python bench.py --workload c3_1024c_2048 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_c3_1024c_2048.json
+CONCEPT_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_ns_forced_dist_1rank_rccl.json
+python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_ns_full_default.json
+./tools/mall_probe > $OUT/${TAG}_mall_probe.txt 2>&1
+rm -rf $OUT/stats $OUT/pmc_f $OUT/pmc_w $OUT/stats_p3m $OUT/pmc_sr
+ls -la $OUT
