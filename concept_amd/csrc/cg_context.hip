@@ -741,6 +741,12 @@ extern "C" int cg_measure_momentum(cg_ctx *c, const double *mom, int64_t n, doub
     return cgk_measure_mom(c, mom, n, out, scratch);
 }
 
+extern "C" int cg_measure_momentum_regions(cg_ctx *c, const double *mom, const uint32_t *start,
+                                           const uint32_t *count, double *out, double *scratch) {
+    CG_CHECK(c && mom && start && out && scratch, "cg_measure_momentum_regions: null argument");
+    return cgk_measure_mom_regions(c, mom, start, count, out, scratch);
+}
+
 extern "C" int cg_tile_info(const cg_ctx *c, int64_t info[3]) {
     CG_CHECK(c && info, "cg_tile_info: null argument");
     info[0] = c->tiles.tx;

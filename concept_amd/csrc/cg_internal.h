@@ -162,6 +162,8 @@ int cgk_gather_kick(cg_ctx *c, const double *pos, double *mom, i64 n, int diff_o
                     double factor);
 int cgk_drift(cg_ctx *c, double *pos, const double *mom, i64 n, double dt_over_mass);
 int cgk_measure_mom(cg_ctx *c, const double *mom, i64 n, double *out, double *scratch);
+int cgk_measure_mom_regions(cg_ctx *c, const double *mom, const unsigned *start,
+                            const unsigned *count, double *out, double *scratch);
 int cgk_cic_indices(cg_ctx *c, const double *pos, i64 n, int for_gather, i64 *idx);
 int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst);
 int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,

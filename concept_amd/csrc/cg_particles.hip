@@ -108,6 +108,53 @@ __global__ __launch_bounds__(64) void k_measure_final(const double *__restrict__
     }
 }
 
+// The same for particles kept in tile regions with gaps (the streaming form of the time loop):
+// workgroup b walks the regions [first, first + per) region by region, live rows only.
+__global__ __launch_bounds__(256) void k_measure_mom_regions(const double *__restrict__ mom,
+                                                             const unsigned *__restrict__ start,
+                                                             const unsigned *__restrict__ count,
+                                                             i64 nregions,
+                                                             double *__restrict__ partial) {
+    __shared__ double s_sum[4], s_max[4];
+    const i64 per = (nregions + gridDim.x - 1) / gridDim.x;
+    const i64 r0 = (i64)blockIdx.x * per, r1 = r0 + per < nregions ? r0 + per : nregions;
+    double sum = 0, mx = 0;
+    for (i64 r = r0; r < r1; r++) {
+        const i64 p0 = start[r], n = count ? count[r] : start[r + 1] - start[r];
+        for (i64 k = threadIdx.x; k < n; k += blockDim.x) {
+            const i64 p = p0 + k;
+            double x = mom[3 * p], y = mom[3 * p + 1], z = mom[3 * p + 2];
+            double m2 = x * x + y * y + z * z;
+            sum += m2;
+            mx = fmax(mx, m2);
+        }
+    }
+    sum = wave_sum(sum);
+    mx = wave_max(mx);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_sum[w] = sum;
+        s_max[w] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        partial[2 * blockIdx.x + 1] = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+    }
+}
+
+int cgk_measure_mom_regions(cg_ctx *c, const double *mom, const unsigned *start,
+                            const unsigned *count, double *out, double *scratch) {
+    const i64 nregions = 8 * c->ntiles;
+    int nb = (int)(nregions < kMeasureBlocks ? nregions : kMeasureBlocks);
+    hipLaunchKernelGGL(k_measure_mom_regions, dim3(nb), dim3(256), 0, c->stream, mom, start, count,
+                       nregions, scratch);
+    CG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_measure_final, dim3(1), dim3(64), 0, c->stream, scratch, nb, out);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
 int cgk_measure_mom(cg_ctx *c, const double *mom, i64 n, double *out, double *scratch) {
     int nb = (int)((n + 255) / 256 < kMeasureBlocks ? (n + 255) / 256 : kMeasureBlocks);
     if (nb < 1) nb = 1;

@@ -679,6 +679,13 @@ class RegionParticles:
             self.meta_event.record()
             self.pending = True
 
+    def measure_momentum(self):
+        """(Σ mom², max |mom_i|²) of this rank's live particles (analysis.measure's inputs)"""
+        self.finish_exchange()
+        if self.count is None:
+            return self.mesh.measure_momentum(self.mom[self.cur][:self.n_dense])
+        return self.mesh.measure_momentum_regions(self.mom[self.cur], self.start, self.count)
+
     def finish_exchange(self):
         """ship the leavers of the last kick_drift_sort and seat the arrivals (x-slab
         domains; the one wait for the GPU of a step)"""

@@ -77,6 +77,7 @@ SYMBOLS = {
     'cg_gather_kick_tiled_prepare': (_int, [_vp, _vp, _vp, _i64, _vp, _int, _dbl, _dbl]),
     'cg_drift': (_int, [_vp, _vp, _vp, _i64, _dbl]),
     'cg_measure_momentum': (_int, [_vp, _vp, _i64, _vp, _vp]),
+    'cg_measure_momentum_regions': (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     'cg_sort_particles': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'cg_drift_sort': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _vp]),
     'cg_tile_info': (_int, [_vp, ctypes.POINTER(ctypes.c_int64*3)]),

@@ -601,6 +601,17 @@ class PotentialMesh:
         s, m = buf[2048:].tolist()
         return s, m
 
+    def measure_momentum_regions(self, mom, start, count):
+        """measure_momentum() for particles kept in tile regions with gaps"""
+        if getattr(self, '_measure_buf', None) is None:
+            self._measure_buf = torch.empty(2048 + 2, dtype=torch.float64, device=self.device)
+        buf = self._measure_buf
+        check(_L.cg_measure_momentum_regions(
+            self._ctx, _ptr(mom), _ptr(start), _ptr(count) if count is not None else None,
+            _ptr(buf[2048:]), _ptr(buf)))
+        s, m = buf[2048:].tolist()
+        return s, m
+
     def sort_particles(self, pos, mom, ids, pos_out, mom_out, ids_out, tile_offset=None):
         n = self._check_particles(pos, mom, pos_out, mom_out)
         if tile_offset is None:

@@ -76,63 +76,72 @@ def timeloop(components, n_steps, integrals, rung_integrals=None, on_step=None):
 stream_replays = 0  # steps the streaming loop had to undo and take on the exact path
 
 
-def _timeloop_streaming(components, n_steps, integrals, plan):
-    """timeloop() for the default PM configuration with the kick of one step and the drift of
-    the next fused.  Per pass: every component deposited from its tile regions
-    (mesh.py:1512-1636), one Poisson solve (interactions.py:2092-2118), then per component
-    cg_gather_kick_drift_scatter with the kick's ᔑdt['a**(-3*w_eff)', name] and the next
-    drift's ᔑdt['a**(-2)'] (zero after the last kick)."""
+def _streaming_pass(plan, components, rps, ᔑdt_kick, ᔑdt_drift, label=''):
+    """One pass of the streaming form over particles kept in tile regions: every
+    component deposited from its regions (mesh.py:1512-1636), one Poisson solve
+    (interactions.py:2092-2118), then per component cg_gather_kick_drift_scatter with the kick's
+    ᔑdt['a**(-3*w_eff)', name] and the following drift's ᔑdt['a**(-2)'].  ᔑdt_drift None: a kick
+    only (the particles keep their places); ᔑdt_kick None: a drift only (kick factor 0: the
+    momenta pass through unchanged, bit for bit).  `rps` is updated in place."""
     mesh = plan['mesh']
     fft_factor = float(plan['gridsize'])**(-3)
     p = components[0].params
+    if ᔑdt_kick is not None:
+        for k, (c, rp) in enumerate(zip(components, rps)):
+            rp.deposit(interactions._particle_contribution(
+                c, ᔑdt_kick, fft_factor, plan['gridsize'], p.boxsize), accumulate=k > 0)
+        fold = mesh.fold_ghosts_start()
+        mesh.poisson_solve(plan['deconv_order'], plan['C'], plan['long_range'], plan['E'],
+                           fold_finish=fold, fill=True)
+    before = [rp.snapshot() for rp in rps]
+    for c, rp in zip(components, rps):
+        order = c.potential_differentiations[plan['force']][plan['method']]
+        Δt_over_mass = (ᔑdt_drift['a**(-2)']/c.mass) if ᔑdt_drift is not None else 0.0
+        factor = c.mass*(-ᔑdt_kick['a**(-3*w_eff)', c.name]) if ᔑdt_kick is not None else 0.0
+        rp.kick_drift_sort(order, factor, Δt_over_mass)
+    # On several domains: ship the leavers and seat the arrivals now (into the new buffer
+    # set), so that everything that can go wrong with this pass is known before the next one
+    # starts.
+    for rp in rps:
+        rp.finish_exchange()
+    # The regions of the new order were sized from the present populations; a (tile, bucket)
+    # that grew beyond that in one step — by the drift or by arrivals from other domains — or
+    # more leavers than the row buffer holds have dropped particles.  The pass and the exchange
+    # wrote the other buffer set only: undo them and take the step on the exact path (the
+    # potential is still on the mesh), then go on streaming.
+    flags = mesh.error_flags()   # reads AND clears the sticky bits
+    other = flags & ~(lib.CG_ERR_BUCKET_OVERFLOW | lib.CG_ERR_NOT_IN_TILE)
+    if other:
+        # e.g. CG_ERR_STALE_HISTOGRAM of a drift_sort on the replay path: that sort has
+        # dropped particles, nothing to recover from here
+        raise ConceptGPUError(f'streaming time loop: device error flags {other:#x} {label}')
+    overflow = bool(flags & (lib.CG_ERR_BUCKET_OVERFLOW | lib.CG_ERR_NOT_IN_TILE))
+    if mesh.comm is not None:
+        overflow = mesh.comm.any(overflow)
+    if overflow:
+        global stream_replays
+        stream_replays += 1
+        for i, c in enumerate(components):
+            rps[i].restore(before[i])
+            c.from_regions(rps[i])
+            if ᔑdt_kick is not None:
+                interactions._kick_particles(mesh, c, plan['force'], plan['method'],
+                                             ᔑdt_kick, ('a**(-3*w_eff)', 'component'))
+            if ᔑdt_drift is not None:
+                c.drift_sort(ᔑdt_drift, mesh=mesh)
+            rps[i] = c.to_regions(mesh)
+
+
+def _timeloop_streaming(components, n_steps, integrals, plan):
+    """timeloop() for the default PM configuration with the kick of one step and the drift of
+    the next fused: K½ D K D ... K as n_steps + 1 passes of _streaming_pass."""
+    mesh = plan['mesh']
     rps = [c.to_regions(mesh) for c in components]
     try:
         for step in range(n_steps + 1):
             ᔑdt_kick = integrals('init' if step == 0 else 'full')
             ᔑdt_drift = integrals('full') if step < n_steps else None
-            for k, (c, rp) in enumerate(zip(components, rps)):
-                rp.deposit(interactions._particle_contribution(
-                    c, ᔑdt_kick, fft_factor, plan['gridsize'], p.boxsize), accumulate=k > 0)
-            fold = mesh.fold_ghosts_start()
-            mesh.poisson_solve(plan['deconv_order'], plan['C'], plan['long_range'], plan['E'],
-                               fold_finish=fold, fill=True)
-            before = [rp.snapshot() for rp in rps]
-            for c, rp in zip(components, rps):
-                order = c.potential_differentiations[plan['force']][plan['method']]
-                Δt_over_mass = (ᔑdt_drift['a**(-2)']/c.mass) if ᔑdt_drift is not None else 0.0
-                rp.kick_drift_sort(order, c.mass*(-ᔑdt_kick['a**(-3*w_eff)', c.name]),
-                                   Δt_over_mass)
-            # On several domains: ship the leavers and seat the arrivals now (into the new
-            # buffer set), so that everything that can go wrong with this pass is known before
-            # the next one starts.
-            for rp in rps:
-                rp.finish_exchange()
-            # The regions of the new order were sized from the present populations; a (tile,
-            # bucket) that grew beyond that in one step — by the drift or by arrivals from other
-            # domains — or more leavers than the row buffer holds have dropped particles.  The
-            # pass and the exchange wrote the other buffer set only: undo them and take the step
-            # on the exact path (the potential is still on the mesh), then go on streaming.
-            flags = mesh.error_flags()   # reads AND clears the sticky bits
-            other = flags & ~(lib.CG_ERR_BUCKET_OVERFLOW | lib.CG_ERR_NOT_IN_TILE)
-            if other:
-                # e.g. CG_ERR_STALE_HISTOGRAM of a drift_sort on the replay path: that sort has
-                # dropped particles, nothing to recover from here
-                raise ConceptGPUError(f'streaming time loop: device error flags {other:#x} '
-                                      f'in step {step}')
-            overflow = bool(flags & (lib.CG_ERR_BUCKET_OVERFLOW | lib.CG_ERR_NOT_IN_TILE))
-            if mesh.comm is not None:
-                overflow = mesh.comm.any(overflow)
-            if overflow:
-                global stream_replays
-                stream_replays += 1
-                for i, c in enumerate(components):
-                    rps[i].restore(before[i])
-                    c.from_regions(rps[i])
-                    interactions._kick_particles(mesh, c, plan['force'], plan['method'],
-                                                 ᔑdt_kick, ('a**(-3*w_eff)', 'component'))
-                    if ᔑdt_drift is not None:
-                        c.drift_sort(ᔑdt_drift, mesh=mesh)
-                    rps[i] = c.to_regions(mesh)
+            _streaming_pass(plan, components, rps, ᔑdt_kick, ᔑdt_drift, f'in step {step}')
     except BaseException:
         # unwinding: hand the particles back without the collective part of from_regions (the
         # other domains may not be unwinding), then let the exception travel
@@ -360,13 +369,17 @@ DumpTime = collections.namedtuple('DumpTime', ('time_param', 't', 'a'))
 ထ = math.inf
 
 
-def measure(component, quantity, a):
+def measure(component, quantity, a, regions=None):
     """analysis.measure(component, 'v_rms' | 'v_max') for particle components
-    (analysis.py:3902-3910, 3965-3972); collective over the domains."""
+    (analysis.py:3902-3910, 3965-3972); collective over the domains.  regions: the component's
+    particles in streaming form (distributed.RegionParticles)."""
     if component.representation != 'particles':
         raise ConceptGPUError('measure(): particle components only (the fluid solvers are '
                               'outside this path)')
-    mom2_sum, mom2_max = component._store.mesh.measure_momentum(component.mom)
+    if regions is not None:
+        mom2_sum, mom2_max = regions.measure_momentum()
+    else:
+        mom2_sum, mom2_max = component._store.mesh.measure_momentum(component.mom)
     if component.comm is not None and component.nprocs > 1:
         both = component.comm.all_gather_floats([mom2_sum, mom2_max])
         mom2_sum, mom2_max = float(both[:, 0].sum()), float(both[:, 1].max())
@@ -386,7 +399,19 @@ class Timeloop(RungStepper):
     at changes of Δt, the init / full step types — on top of kick_long / kick_short /
     driftkick_short (RungStepper) with the time-step integrals of integration.Cosmology.
 
-    on_dump(loop, dump_time) is the reference's dump() (snapshot output is outside the path)."""
+    on_dump(loop, dump_time) is the reference's dump() (snapshot output is outside the path).
+
+    Streaming (streaming = None: whenever the configuration allows; False: never).  The default
+    PM configuration (interactions.pm_streaming_plan) with no short-range force takes every long
+    kick together with the drift that follows it as ONE pass over the particles (DESIGN.md
+    §4a).  The drift's interval is known when the kick is asked for: inside a segment K½ D K D
+    ... K it depends on t, Δt and the dump times only — what get_base_timestep_size measures
+    after kick n decides the LENGTH OF KICK n + 1 and whether a synchronisation follows, never
+    drift n + 1 — and the last kick of a segment is followed by no drift.  The one exception is
+    the drift after an init kick, which a reduction of Δt found right after that kick cuts to
+    half a step (main.py:316-321): there the pass is speculative — the drift the loop then asks
+    for is compared with the one taken, and a pass whose guess was wrong is undone (it wrote
+    the other buffer set only) and retaken as a kick and a drift of their own."""
     # main.py:2336-2378
     Δt_initial_fac = 0.95
     Δt_reduce_fac = 0.94
@@ -396,7 +421,7 @@ class Timeloop(RungStepper):
     Δt_ratio_abort = 0.01
     Δt_period = 1*8
 
-    def __init__(self, components, cosmology=None, on_dump=None, on_step=None):
+    def __init__(self, components, cosmology=None, on_dump=None, on_step=None, streaming=None):
         p = components[0].params
         self.cosmo = cosmology or Cosmology(p)
         self.cosmo.init_time()
@@ -430,12 +455,85 @@ class Timeloop(RungStepper):
         self.time_step = 0
         self.Δt = 0.0
         self.history = []   # (time_step, t, a, Δt) at the beginning of every time step
+        self.streaming = streaming
+        self._plan = self._rps = self._spec = self._next_drift = None
+        self.stream_passes = self.stream_wrong_guesses = 0
 
     # universals.t / universals.a live in the Cosmology object
     t = property(lambda self: self.cosmo.t, lambda self, v: setattr(self.cosmo, 't', float(v)))
 
     def _integrals(self, t_start, t_end):
         return self.cosmo.get_time_step_integrals(t_start, t_end, self.components, self.keys)
+
+    # -- the streaming form of the loop ----------------------------------------------------
+    def _stream_begin(self):
+        if self.streaming is False or self._shortrange_interactions():
+            return
+        plan = interactions.pm_streaming_plan(self.components)
+        if plan is None:
+            if self.streaming:
+                raise ConceptGPUError('Timeloop(streaming=True): not the default PM '
+                                      'configuration (interactions.pm_streaming_plan)')
+            return
+        self._plan = plan
+        self._rps = [c.to_regions(plan['mesh']) for c in self.components]
+
+    def _stream_end(self, collective=True):
+        if self._rps is not None:
+            for c, rp in zip(self.components, self._rps):
+                c.from_regions(rp, collective=collective)
+        self._plan = self._rps = self._spec = None
+
+    def _predict_drift(self, step_type, Δt, sync_time, dump_time):
+        """the drift that follows the long kick about to be asked for, as (t_start, t_end), or
+        None if none follows (the kick ends at a synchronisation time)"""
+        t = self.cosmo.t
+        if step_type == 'full':
+            # main.py:353-356: the clock after the kick
+            t = t + 0.5*Δt
+            if t + self.Δt_reltol*Δt + 2*commons.machine_ϵ > sync_time:
+                return None
+        # main.py:311-314, 436-440 (v_rms plays no part in these)
+        if dump_time.t - t <= 1.5*Δt:
+            sync_time = dump_time.t
+        t_end = self._clip(t + Δt, Δt, sync_time)
+        return (t, t_end) if t_end != t else None
+
+    def kick_long(self, Δt, sync_time, step_type):
+        if self._rps is None:
+            return super().kick_long(Δt, sync_time, step_type)
+        t_start = self.t
+        t_end = self._clip(t_start + (Δt/2 if step_type == 'init' else Δt), Δt, sync_time)
+        if t_start == t_end:
+            return
+        ᔑdt = self.integrals(t_start, t_end)
+        drift = self._next_drift
+        before = [rp.snapshot() for rp in self._rps]
+        _streaming_pass(self._plan, self.components, self._rps, ᔑdt,
+                        self.integrals(*drift) if drift is not None else None,
+                        f'at t = {t_start}')
+        self.stream_passes += 1
+        self._spec = {'kick': ᔑdt, 'drift': drift, 'before': before}
+
+    def driftkick_short(self, Δt, sync_time):
+        if self._rps is None:
+            return super().driftkick_short(Δt, sync_time)
+        t_start = self.t
+        t_end = self._clip(t_start + Δt, Δt, sync_time)
+        spec, self._spec = self._spec, None
+        if spec is not None and spec['drift'] is not None:
+            if t_start == t_end or spec['drift'] != (t_start, t_end):
+                # the guess was wrong: undo the pass, take the kick alone
+                self.stream_wrong_guesses += 1
+                for rp, snap in zip(self._rps, spec['before']):
+                    rp.restore(snap)
+                _streaming_pass(self._plan, self.components, self._rps, spec['kick'], None)
+            else:
+                return   # this drift was taken with the kick before it
+        if t_start == t_end:
+            return
+        _streaming_pass(self._plan, self.components, self._rps, None,
+                        self.integrals(t_start, t_end))
 
     # -- main.prepare_for_output (main.py:2188-2310), the dump times -----------------------
     def dump_times(self):
@@ -502,7 +600,8 @@ class Timeloop(RungStepper):
 
         def v_rms_of(c):
             if c not in measurements:
-                measurements[c] = measure(c, 'v_rms', a)
+                rp = self._rps[self.components.index(c)] if self._rps is not None else None
+                measurements[c] = measure(c, 'v_rms', a, rp)
             v_rms = measurements[c]
             # in the odd case of a completely static component, just above 0
             return commons.machine_ϵ if v_rms < commons.machine_ϵ else v_rms
@@ -591,10 +690,29 @@ class Timeloop(RungStepper):
 
     def _dump(self, dump_time):
         if self.on_dump is not None:
+            streaming = self._rps is not None
+            if streaming:   # the callback looks at the Components' own arrays
+                for c, rp in zip(self.components, self._rps):
+                    c.from_regions(rp)
             self.on_dump(self, dump_time)
+            if streaming:
+                self._rps = [c.to_regions(self._plan['mesh']) for c in self.components]
 
     # -- main.timeloop (main.py:102-471) ---------------------------------------------------
     def run(self):
+        try:
+            self._run()
+        except BaseException:
+            # unwinding: hand the particles back without the collective part (the other
+            # domains may not be unwinding), then let the exception travel
+            try:
+                self._stream_end(collective=False)
+            except Exception:
+                pass
+            raise
+        self._stream_end()
+
+    def _run(self):
         cosmo, components = self.cosmo, self.components
         dump_times = self.dump_times()
         if not dump_times:
@@ -604,6 +722,7 @@ class Timeloop(RungStepper):
             dump_times.pop(0)
             if not dump_times:
                 return
+        self._stream_begin()
         self.initial_fac_times.add(cosmo.t)
         Δt_max, bottleneck = self.get_base_timestep_size()
         Δt_begin = Δt_max
@@ -636,6 +755,7 @@ class Timeloop(RungStepper):
                         self.on_step(self)
                 if time_step_type == 'init':
                     time_step_type = 'full'
+                    self._next_drift = self._predict_drift('init', Δt, sync_time, dump_time)
                     self.kick_long(Δt, sync_time, 'init')
                     self.kick_short(Δt)
                     if dump_time.t - cosmo.t <= 1.5*Δt:
@@ -649,6 +769,7 @@ class Timeloop(RungStepper):
                 elif time_step_type == 'full':
                     self.driftkick_short(Δt, sync_time)
                     self._advance(Δt, sync_time)
+                    self._next_drift = self._predict_drift('full', Δt, sync_time, dump_time)
                     self.kick_long(Δt, sync_time, 'full')
                     self._advance(Δt, sync_time)
                     if cosmo.t == sync_time:

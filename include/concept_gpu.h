@@ -237,6 +237,11 @@ int cg_drift(cg_ctx *ctx, double *pos /*DEV 3n*/, const double *mom /*DEV 3n*/, 
  * scratch: DEV double[2048]. */
 int cg_measure_momentum(cg_ctx *ctx, const double *mom /*DEV 3n*/, int64_t n,
                         double *out /*DEV 2*/, double *scratch /*DEV 2048*/);
+/* the same over particles kept in tile regions with gaps (start / count as for
+ * cg_deposit_cic_regions; count = NULL: dense tile order) */
+int cg_measure_momentum_regions(cg_ctx *ctx, const double *mom /*DEV rows*/,
+                                const uint32_t *start, const uint32_t *count,
+                                double *out /*DEV 2*/, double *scratch /*DEV 2048*/);
 
 /* --- particle memory order -------------------------------------------------
  * The reference reorders particle memory for locality (Component.tile_sort,

@@ -35,7 +35,7 @@ def _pos_err(pos, ref, L):
 
 @pytest.mark.parametrize('name', ['traj_pm_n8_g8', 'traj_p3m_n8_g24_r1', 'traj_p3m_n8_g24',
                                   'traj_pm_n8_g16', 'traj_p3m_n8_g32'])
-def test_timeloop_run_vs_reference(golden, name):
+def test_timeloop_run_vs_reference(golden, name, streaming=None):
     from concept_amd import stepper
     g = golden(name)
     p, c = _component(g)
@@ -45,8 +45,16 @@ def test_timeloop_run_vs_reference(golden, name):
 
     def on_dump(loop, dump_time):
         dumps.append((loop.cosmo.a, loop.cosmo.t, c.host('pos'), c.host('mom')))
-    loop = stepper.Timeloop([c], on_dump=on_dump)
+    loop = stepper.Timeloop([c], on_dump=on_dump, streaming=streaming)
     loop.run()
+    if str(g['method']) == 'pm' and streaming is not False:
+        # the PM runs took the streaming form: one pass per long kick (+ one per drift that
+        # could not ride with a kick), every guess about the drift after an init kick right
+        n_kicks = int((g['kick_t'] >= 0).sum())
+        assert n_kicks - 25 <= loop.stream_passes <= n_kicks + 25, (loop.stream_passes, n_kicks)
+        assert loop.stream_wrong_guesses == 0
+    else:
+        assert loop.stream_passes == 0
     # the step sequence: number, cosmic time, scale factor and size of every base step
     hist = np.array(loop.history)
     assert hist.shape[0] == g['step_number'].shape[0], (hist.shape, g['step_number'].shape)
@@ -64,6 +72,12 @@ def test_timeloop_run_vs_reference(golden, name):
     # the particles have really moved: several cells between the first and the last dump
     moved = np.abs(g['dump_pos'][-1] - g['pos_in'])
     assert np.minimum(moved, L - moved).max() > L/int(g['gridsize'])
+
+
+@pytest.mark.parametrize('name', ['traj_pm_n8_g8', 'traj_pm_n8_g16'])
+def test_timeloop_run_stepwise_vs_reference(golden, name):
+    """the same runs with the separate kick and drift + sort passes (streaming = False)"""
+    test_timeloop_run_vs_reference(golden, name, streaming=False)
 
 
 @pytest.mark.parametrize('name', ['traj_pm_n8_g8', 'traj_p3m_n8_g24_r1', 'traj_pm_n8_g16'])
@@ -129,3 +143,37 @@ def test_stepper_timeloop_replays_reference_integrals(golden, name, streaming):
     assert np.abs(c.host('mom') - g['dump_mom'][-1]).max() <= 1e-9*kick
     if streaming:
         assert stepper.stream_replays == replays   # (no region overflowed on the way)
+
+
+def test_timeloop_wrong_guess_is_undone(golden):
+    """The one speculative pass of the streaming loop: the drift after an init kick.  A
+    limiter that drops between the choice of Δt at a synchronisation and the look at it after
+    the init kick that follows (here: every limiter lowered by the on_step callback of the very
+    first step, which runs between the two) synchronises half a step later (main.py:316-321),
+    i.e. the drift taken with that kick was too long: the pass is undone and retaken.  The run
+    must equal the stepwise one in its step sequence and, to rounding, in the particles."""
+    from concept_amd import stepper
+    g = golden('traj_pm_n8_g16')
+    results = []
+    for streaming in (None, False):
+        p, c = _component(g)
+
+        def on_step(loop):
+            if loop.time_step == 0 and not getattr(loop, 'lowered', False):
+                loop.lowered = True
+                loop.fac_dynamical *= 0.3
+                loop.fac_hubble *= 0.3
+                loop.fac_pm *= 0.3
+                loop.params.Δa_max_early *= 0.3
+                loop.params.Δa_max_late *= 0.3
+        loop = stepper.Timeloop([c], on_step=on_step, streaming=streaming)
+        loop.run()
+        results.append((np.array(loop.history), c.host('pos'), c.host('mom'),
+                        loop.stream_wrong_guesses, loop.stream_passes))
+    (h0, p0, m0, wrong, passes), (h1, p1, m1, _, none) = results
+    assert passes > 0 and none == 0
+    assert wrong >= 1, 'the scenario was meant to make a guess fail'
+    assert h0.shape == h1.shape and np.abs(h0/np.where(h1 == 0, 1, h1) - 1)[:, 1:].max() <= 1e-12
+    L = float(g['boxsize'])
+    assert _pos_err(p0, p1, L) <= 1e-11
+    assert np.abs(m0 - m1).max() <= 1e-10*np.abs(m1).max()
