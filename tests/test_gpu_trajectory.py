@@ -177,3 +177,54 @@ def test_timeloop_wrong_guess_is_undone(golden):
     L = float(g['boxsize'])
     assert _pos_err(p0, p1, L) <= 1e-11
     assert np.abs(m0 - m1).max() <= 1e-10*np.abs(m1).max()
+
+
+def test_timeloop_streaming_at_north_star_size():
+    """The time loop itself at the metric's size (2^28 particles / 1024^3 mesh, ΛCDM clock):
+    a few base steps from a = 0.1 through stepper.Timeloop — background, integrals, limiters,
+    v_rms measured on the regions, every long kick riding with its drift.  Properties: the
+    streaming form was taken (one pass per kick), no guess failed, no region overflowed, every
+    particle is still there, the clock arrived; prints the wall time per base step."""
+    import time
+    import torch
+    from concept_amd import commons, stepper
+    from concept_amd.species import Component
+    n, N = 2**28, 1024
+    p = commons.load_params({
+        'boxsize': 1024.0, 'H0': 0.07, 'Ωb': 0.05, 'Ωcdm': 0.25, 'a_begin': 0.1,
+        'output_times': {'a': (0.13,)},
+        'potential_options': {'gridsize': {'gravity': {'pm': N}}},
+        'select_forces': {'all': {'gravity': 'pm'}}})
+    mass = p.ρ_mbar*p.boxsize**3/n
+    c = Component('matter', 'matter', N=n, mass=mass)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=gen, out=c.pos)
+    c.pos.mul_(p.boxsize*(1 - 1e-13))
+    # peculiar velocities of ~100 km/s: u = a ẋ -> mom = a m u
+    u = 100*p.units.km/p.units.s
+    torch.randn((n, 3), dtype=torch.float64, device='cuda', generator=gen, out=c.mom)
+    c.mom.mul_(0.1*mass*u/3**0.5)
+    ids_sum = n*(n - 1)//2
+    steps = []
+    def on_step(lp):
+        torch.cuda.synchronize()
+        steps.append(time.perf_counter())
+    loop = stepper.Timeloop([c], on_step=on_step)
+    replays = stepper.stream_replays
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop.run()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    nsteps = loop.time_step
+    assert nsteps >= 3 and loop.cosmo.a == pytest.approx(0.13, rel=1e-12)
+    assert loop.stream_passes >= nsteps and loop.stream_wrong_guesses == 0
+    assert stepper.stream_replays == replays
+    assert c.N_local == n and int(c.ids.sum().item()) == ids_sum
+    assert bool(((c.pos >= 0) & (c.pos < p.boxsize)).all())
+    d = np.diff(np.array(steps))*1e3
+    print('\nwall time between the beginnings of consecutive base steps (ms):',
+          ' '.join(f'{v:.1f}' for v in d))
+    print(f'Timeloop at 2^28 / 1024^3: {nsteps} base steps, {loop.stream_passes} passes in '
+          f'{wall:.2f} s = {wall/max(loop.stream_passes, 1)*1e3:.1f} ms per pass (deposit + solve '
+          f'+ fused kick/drift/sort + v_rms + host)')
