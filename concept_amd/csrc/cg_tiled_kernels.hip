@@ -423,6 +423,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int b0 = T0b - H, c0 = T0c - H;
         unsigned off[NP];  // gj*pad + gk
+        int cmp[COMPACT ? NP : 1];  // compact planes: (b-1)*IN + (c-1) of the interior, else -1
 #pragma unroll
         for (int q = 0; q < NP; q++) {
             int i2 = lane + 64 * q;
@@ -431,42 +432,49 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
             gj += (gj < 0 ? Ni : 0) - (gj >= Ni ? Ni : 0);
             gk += (gk < 0 ? Ni : 0) - (gk >= Ni ? Ni : 0);
             off[q] = (unsigned)gj * (unsigned)pad + (unsigned)gk;
+            if (COMPACT)
+                cmp[q] = (b >= 1 && b <= E - 2 && c >= 1 && c <= E - 2)
+                             ? (b - 1) * BL::IN + (c - 1) : -1;
         }
         double v[NA][NP];
 #pragma unroll
         for (int s = 0; s < NA; s++) {
-            const int a = wave + 8 * s;  // wave-uniform
+            const int a = __builtin_amdgcn_readfirstlane(wave) + 8 * s;  // wave-uniform
             if (a < E) {
                 const double *plane = mesh + cg_xlayer(xm, (i64)(T0a - H + a), N) * ny * pad;
+                const bool edge = COMPACT && (a == 0 || a == E - 1);  // (uniform)
 #pragma unroll
-                for (int q = 0; q < NP; q++)
+                for (int q = 0; q < NP; q++) {
+                    const bool want = (PL % 64 == 0 || lane + 64 * q < PL) &&
+                                      (!edge || cmp[COMPACT ? q : 0] >= 0);
 #ifdef CG_GK_NOSTAGE  // timing probe only: the block is not read
-                    if (PL % 64 == 0 || lane + 64 * q < PL) v[s][q] = (double)off[q];
+                    if (want) v[s][q] = (double)off[q];
 #else
-                    if (PL % 64 == 0 || lane + 64 * q < PL) v[s][q] = plane[off[q]];
+                    if (want) v[s][q] = plane[off[q]];
 #endif
+                }
             }
         }
 #pragma unroll
         for (int s = 0; s < NA; s++) {
-            const int a = wave + 8 * s;
-            if (a < E) {
+            const int a = __builtin_amdgcn_readfirstlane(wave) + 8 * s;
+            if (a >= E) continue;
+            if (COMPACT && (a == 0 || a == E - 1)) {
+                // a compact boundary plane: its interior only (the branch is wave-uniform)
+                const int base = a == 0 ? BL::P_LO : BL::P_HI;
+#pragma unroll
+                for (int q = 0; q < NP; q++)
+                    if ((PL % 64 == 0 || lane + 64 * q < PL) && cmp[COMPACT ? q : 0] >= 0)
+                        lds[base + cmp[COMPACT ? q : 0]] = v[s][q];
+            } else {
+                const int base = COMPACT ? BL::main(a, 0, 0) : a * PL;
 #pragma unroll
                 for (int q = 0; q < NP; q++) {
                     const int i2 = lane + 64 * q;
-                    // where entry (a, i2 = b*E + c) of the block lives (-1: nowhere)
-                    int at;
-                    if (COMPACT) {
-                        const int b = i2 / E, c = i2 - b * E;
-                        const bool inner = b >= 1 && b <= E - 2 && c >= 1 && c <= E - 2;
-                        if (a == 0) at = inner ? BL::P_LO + (b - 1) * BL::IN + (c - 1) : -1;
-                        else if (a == E - 1) at = inner ? BL::P_HI + (b - 1) * BL::IN + (c - 1) : -1;
-                        else at = (FUSED && i2 == 0 && a <= 9) ? -1 : BL::main(a, 0, 0) + i2;
-                    } else {
-                        at = (FUSED && a == 0 && (i2 >= SEG_AT || i2 < E)) ? -1 : a * PL + i2;
-                    }
-                    const bool stored = at >= 0;
-                    if ((PL % 64 == 0 || i2 < PL) && stored) lds[at] = v[s][q];
+                    // the entries that hold the segment tables (FUSED) are left alone
+                    const bool seg = FUSED && (COMPACT ? (i2 == 0 && a <= 9)
+                                                       : (a == 0 && (i2 >= SEG_AT || i2 < E)));
+                    if ((PL % 64 == 0 || i2 < PL) && !seg) lds[base + i2] = v[s][q];
                 }
             }
         }
