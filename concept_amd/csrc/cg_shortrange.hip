@@ -812,9 +812,15 @@ k_sr_sweep_cells(
                 const unsigned q = lo + (lane & 15) + 16u * tn;
                 if (q < hi) {
                     const i64 g = (i64)beg + (q - o0);
+#ifdef CG_SR_NT_STAGE  // streamed once per tile: keep them out of the way of the table
+                    sx[q - w0] = __builtin_nontemporal_load(pos_s + 3 * g);
+                    sy[q - w0] = __builtin_nontemporal_load(pos_s + 3 * g + 1);
+                    sz[q - w0] = __builtin_nontemporal_load(pos_s + 3 * g + 2);
+#else
                     sx[q - w0] = pos_s[3 * g];
                     sy[q - w0] = pos_s[3 * g + 1];
                     sz[q - w0] = pos_s[3 * g + 2];
+#endif
                     if (FACE) {
                         sx[kSrFaceStride + q - w0] = (double)p_shift[p][0] * P.boxsize;
                         sy[kSrFaceStride + q - w0] = (double)p_shift[p][1] * P.boxsize;

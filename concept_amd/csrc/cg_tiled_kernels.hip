@@ -377,11 +377,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         pidx p = pbase + threadIdx.x;
         pre_valid = p < end;
         if (gapped && pre_valid) {  // flat index -> slot of its bucket's region
-            int f = 0;
+            // bucket 0 (the tile's interior, (15/16)^3 of its particles) first: a wave that
+            // lies in it entirely — most do — skips the search (uniform branch)
+            if (p < seg_pre(1)) {
+                p = seg_beg(0) + p;
+            } else {
+                int f = 0;
 #pragma unroll
-            for (int step = 4; step > 0; step >>= 1)
-                if (seg_pre(f + step) <= (unsigned)p) f += step;
-            p = seg_beg(f) + (p - seg_pre(f));
+                for (int step = 4; step > 0; step >>= 1)
+                    if (seg_pre(f + step) <= (unsigned)p) f += step;
+                p = seg_beg(f) + (p - seg_pre(f));
+            }
         }
         pre_p = p;
         if (pre_valid) {
