@@ -50,4 +50,7 @@ def test_bench_cpu_baseline_and_sharded_paths():
     assert d['n_gpus'] == 1 and 'stages_ms_rank0' in d
     d = run('--no-cpu-baseline', '--gpus', '2')
     assert d['n_gpus'] == 2 and d['transport']['bound'] == 'xgmi'
+    lm = d['link_model']   # the prediction beside the measured stages
+    assert lm['predicted_step_ms'] > 0 and lm['transpose_ms_at_link_rate'] > 0
+    assert lm['measured_step_ms'] == pytest.approx(d['ms_per_step'], rel=1e-3)
     assert d['config']['particles'] == 32**3
