@@ -142,6 +142,7 @@ struct SrParams {
     const double *factors;
     const signed char *rung, *rung_jumped;
     int lowest_active;
+    float r2_pre;  // single-precision pre-test: a pair with |x_ji|^2 (float) above this is a miss
 };
 
 // The pair tests of one staged supplier chunk for this lane's receiver: branch-free (a miss adds
@@ -644,6 +645,104 @@ __device__ __forceinline__ void sr_cell_pairs(int a, int b, int sub, int S, doub
                                       r2_index_scaling, table, ax, ay, az);
 }
 
+// ---------------------------------------------------------------------------
+// Single-precision pre-test (round 3).  73 % of the pair tests are misses, and in the loop
+// above a miss costs what a hit costs: in a 64-lane wavefront some lane hits in nearly every
+// trip, so the whole hit path (table index, look-up, three FMAs) issues every time — 27 lane
+// instructions per pair test against 12 for the bare test.  Here a lane first runs ALL its
+// pairs of a receiver chunk through a packed single-precision distance test on float copies of
+// the staged positions (relative to the tile's corner; two adjacent suppliers per
+// v_pk_*_f32 instruction: 4.5 instructions per pair), shifting one "miss" bit per pair into a
+// mask, and then evaluates only the pairs the pre-test could not rule out — in double precision,
+// exactly as before (same x_ji, r2, range test, table index: bit-identical contributions; the
+// pre-test's threshold sits above r2_max by more than float rounding can move a distance, so it
+// never drops a hit).  The second loop runs as long as the slowest lane has candidates.
+// MEASURED (256^3 / 512^3, round 3): 8.98 ms against 7.63 ms for the loop above (clustered box
+// 101 against 75 ms), so it is NOT the default (CONCEPT_GPU_SR_PRE32=1 selects it).  Why it
+// does not pay: a lane has only ~45 pairs per receiver chunk (the wave splits a receiver's ~490
+// suppliers over S ~ 11 lane groups), of which ~10 are candidates with a spread of +-3 between
+// the lanes; the candidate loop runs for the slowest lane, four at a time, so fewer than half of
+// its slots do work — that waste plus the pre-test itself (6 instructions per pair with its
+// loop) comes to the ~27 instructions per pair of the plain loop, and the float copies cost LDS
+// (28 KB: 5 workgroups per CU instead of 8).  It would take sharing a receiver's candidates
+// between its S lanes to win; the queue that does that was tried in round 1 and lost more to
+// its LDS traffic.
+// Suppliers [A, B) of the staged window are ONE range here: the five x rows of the receiver's
+// neighbourhood with all six y columns each (the sixth is beyond the range and falls to the
+// pre-test), lane group `sub` of S takes suppliers A + 2 sub + {0, 1} + 2 S row.
+// ---------------------------------------------------------------------------
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <bool FACE>
+__device__ __forceinline__ void sr_cell_pairs_pre32(int A, int B, int sub, int S, double xi,
+                                                    double yi, double zi, float xf, float yf,
+                                                    float zf, float r2_pre, const double *sx,
+                                                    const double *sy, const double *sz,
+                                                    const float *fx, const float *fy,
+                                                    const float *fz, double r2_max,
+                                                    double r2_index_scaling,
+                                                    const double *__restrict__ table, double &ax,
+                                                    double &ay, double &az) {
+    const int stride = 2 * S;                       // suppliers per row of the lane groups
+    const int nrows = (B - A + stride - 1) / stride;  // wave-uniform
+    const f2v xr = {xf, xf}, yr = {yf, yf}, zr = {zf, zf}, lim = {r2_pre, r2_pre};
+    for (int r0 = 0; r0 < nrows; r0 += 16) {        // 16 rows = 32 pairs per lane and mask
+        const int n = min(16, nrows - r0);
+        unsigned miss = 0;                          // pair p of this batch ends at bit 2n-1-p
+        int k = A + r0 * stride + 2 * sub;
+#pragma unroll 4
+        for (int r = 0; r < n; r++, k += stride) {
+            const f2v dx = xr - f2v{fx[k], fx[k + 1]};
+            const f2v dy = yr - f2v{fy[k], fy[k + 1]};
+            const f2v dz = zr - f2v{fz[k], fz[k + 1]};
+            f2v d2 = dx * dx;
+            d2 = __builtin_elementwise_fma(dy, dy, d2);
+            d2 = __builtin_elementwise_fma(dz, dz, d2);
+            const f2v rest = lim - d2;              // negative (sign bit): a miss
+            miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(rest.x), 31);
+            miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(rest.y), 31);
+        }
+        unsigned cand = ~miss & (n == 16 ? 0xffffffffu : ((1u << (2 * n)) - 1u));
+        const int kbase = A + r0 * stride + 2 * sub;
+        // The candidates, kNBD per lane and trip: exact distances, range test and table index
+        // of all of them first, their look-ups in flight together (a candidate the exact test
+        // rejects — one in ~10^4 — reads entry 0 and counts for nothing; so does an empty slot).
+        constexpr int kNBD = 4;
+        while (__any(cand != 0)) {
+            double xj[kNBD], yj[kNBD], zj[kNBD], t[kNBD];
+            unsigned idx[kNBD];
+            bool hit[kNBD];
+#pragma unroll
+            for (int q = 0; q < kNBD; q++) {
+                const bool have = cand != 0;
+                const int bit = have ? __ffs((int)cand) - 1 : 2 * n - 1;
+                cand &= cand - 1;                   // (0 stays 0)
+                const int pr = 2 * n - 1 - bit;     // pair number in this batch
+                const int kj = kbase + (pr >> 1) * stride + (pr & 1);
+                xj[q] = xi - sx[kj];                // interactions.py:1787-1789
+                yj[q] = yi - sy[kj];
+                zj[q] = zi - sz[kj];
+                if (FACE) {                         // gravity.py:299-302
+                    xj[q] += sx[kSrFaceStride + kj];
+                    yj[q] += sy[kSrFaceStride + kj];
+                    zj[q] += sz[kSrFaceStride + kj];
+                }
+                const double r2 = xj[q] * xj[q] + yj[q] * yj[q] + zj[q] * zj[q];  // gravity.py:306
+                hit[q] = have && r2 <= r2_max && kj < B;                        // gravity.py:311
+                idx[q] = hit[q] ? (unsigned)(int)(r2 * r2_index_scaling) : 0u;  // gravity.py:316
+            }
+#pragma unroll
+            for (int q = 0; q < kNBD; q++) t[q] = table[idx[q]];
+#pragma unroll
+            for (int q = 0; q < kNBD; q++) {
+                const double tq = hit[q] ? t[q] : 0.0;
+                ax = __builtin_fma(xj[q], tq, ax);
+                ay = __builtin_fma(yj[q], tq, ay);
+                az = __builtin_fma(zj[q], tq, az);
+            }
+        }
+    }
+}
+
 // inclusive scan over the 64 lanes of a wave in DPP adds (no LDS round trips): row_shr 1, 2, 4,
 // 8 inside the rows of 16 lanes, then the row totals are broadcast forward (row_bcast 15, 31)
 __device__ __forceinline__ unsigned sr_wave_scan(unsigned v) {
@@ -696,7 +795,7 @@ __device__ __forceinline__ SrChunk sr_chunk_load(unsigned base, unsigned rend, i
 // order, gravity.py:299-302; + 0.0 for the others changes nothing), so a receiver's five
 // columns stay ONE range there too.  (Walking such tiles piece by piece — 10 short ranges per x
 // with a wave-uniform offset each — made these 6 % of the tiles 16 % of the sweep.)
-template <bool FACE>
+template <bool FACE, bool PRE32>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CG_SR_WAVES, 8))) void
 k_sr_sweep_cells(
     const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
@@ -706,6 +805,10 @@ k_sr_sweep_cells(
     constexpr int kLen = (FACE ? 2 : 1) * (kSrCap + kSrSlack);
     static_assert(kSrFaceStride == kSrCap + kSrSlack, "offsets follow the positions");
     __shared__ double sx[kLen], sy[kLen], sz[kLen];
+    // PRE32: float copies of the staged positions (image offset included), relative to the
+    // tile's lower corner, for the single-precision pre-test
+    __shared__ float fx[PRE32 ? kSrCap + kSrSlack : 1], fy[PRE32 ? kSrCap + kSrSlack : 1],
+        fz[PRE32 ? kSrCap + kSrSlack : 1];
     __shared__ unsigned p_beg[kSrPieces], p_cnt[kSrPieces], p_off[kSrPieces];
     __shared__ signed char p_shift[kSrPieces][4];  // periodic image: -1, 0, +1 box lengths
     __shared__ unsigned wave_any[4];
@@ -727,6 +830,8 @@ k_sr_sweep_cells(
         tc = tc ? nt - 1 : 0;
         ta++, tb++;
     }
+    const double ext = P.boxsize / (double)nt;  // tile extent
+    const double ox0 = ta * ext, oy0 = tb * ext, oz0 = tc * ext;  // the tile's lower corner
     // receivers of this wave: cell column (2 ta + wx, 2 tb + wy), cells 2 tc and 2 tc + 1
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wx = wave_u >> 1, wy = wave_u & 1;
@@ -821,10 +926,20 @@ k_sr_sweep_cells(
                     sy[q - w0] = pos_s[3 * g + 1];
                     sz[q - w0] = pos_s[3 * g + 2];
 #endif
+                    double shx = 0, shy = 0, shz = 0;
                     if (FACE) {
-                        sx[kSrFaceStride + q - w0] = (double)p_shift[p][0] * P.boxsize;
-                        sy[kSrFaceStride + q - w0] = (double)p_shift[p][1] * P.boxsize;
-                        sz[kSrFaceStride + q - w0] = (double)p_shift[p][2] * P.boxsize;
+                        shx = (double)p_shift[p][0] * P.boxsize;
+                        shy = (double)p_shift[p][1] * P.boxsize;
+                        shz = (double)p_shift[p][2] * P.boxsize;
+                        sx[kSrFaceStride + q - w0] = shx;
+                        sy[kSrFaceStride + q - w0] = shy;
+                        sz[kSrFaceStride + q - w0] = shz;
+                    }
+                    if (PRE32) {
+                        // x_ji = (xi - xj) + offset: the supplier's image sits at xj - offset
+                        fx[q - w0] = (float)((sx[q - w0] - shx) - ox0);
+                        fy[q - w0] = (float)((sy[q - w0] - shy) - oy0);
+                        fz[q - w0] = (float)((sz[q - w0] - shz) - oz0);
                     }
                 }
             }
@@ -833,6 +948,7 @@ k_sr_sweep_cells(
             sx[w1 - w0 + tid] = 0;
             sy[w1 - w0 + tid] = 0;
             sz[w1 - w0 + tid] = 0;
+            if (PRE32) fx[w1 - w0 + tid] = fy[w1 - w0 + tid] = fz[w1 - w0 + tid] = 1e30f;
             if (FACE) {
                 sx[kSrFaceStride + w1 - w0 + tid] = 0;
                 sy[kSrFaceStride + w1 - w0 + tid] = 0;
@@ -847,7 +963,16 @@ k_sr_sweep_cells(
             if (!__any(active)) continue;
             const double xi = ch.xi, yi = ch.yi, zi = ch.zi;
             double ax = 0, ay = 0, az = 0;
-            {
+            if (PRE32) {
+                // one range: x rows wx .. wx + 4 of the 6 x 6 columns, all six y columns
+                const int a = max(__builtin_amdgcn_readlane((int)e0, wx * 6), sw0) - sw0;
+                const int b = min(__builtin_amdgcn_readlane((int)i0, wx * 6 + 29), sw1) - sw0;
+                if (b > a)
+                    sr_cell_pairs_pre32<FACE>(a, b, sub, S, xi, yi, zi, (float)(xi - ox0),
+                                              (float)(yi - oy0), (float)(zi - oz0), P.r2_pre, sx,
+                                              sy, sz, fx, fy, fz, P.r2_max, P.r2_index_scaling,
+                                              table, ax, ay, az);
+            } else {
                 // (every lane walks the ranges, active or not: the bounds are v_readlane's of
                 // registers whose lanes 0..35 must be live, i.e. uniform control flow; an idle
                 // lane tests pairs against (0, 0, 0) and its sums are never read)
@@ -898,7 +1023,22 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                                const double *factors, const signed char *rung,
                                const signed char *rung_jumped, int lowest_active) {
     SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt, 0,
-               factors,      rung,             rung_jumped, lowest_active};
+               factors,      rung,             rung_jumped, lowest_active, 0.0f};
+    // The single-precision pre-test's threshold: coordinates relative to the tile's corner are
+    // below 3.5 tile extents E in size, a float carries them to 2^-24 relative, a difference of
+    // two to 2 * 3.5 E * 2^-24, and |x|^2 near r^2_max moves by at most
+    // 2 r * sqrt(3) * 7 E * 2^-24 + 4 * 2^-24 r^2 (its own roundings); 8 x that on top.
+    static int pre32 = -1;
+    if (pre32 < 0) {
+        const char *env = getenv("CONCEPT_GPU_SR_PRE32");
+        pre32 = env ? atoi(env) : 0;   // measured slower than the plain sweep (see above): off
+    }
+    {
+        const double E = c->p.boxsize / (double)nt, r = sqrt(r2_max), u = 5.9604644775390625e-08;
+        const double slack = 8 * (2 * r * 1.7320508 * 7 * E * u + 4 * u * r2_max);
+        P.r2_pre = (float)(r2_max + slack);
+        while ((double)P.r2_pre < r2_max + slack) P.r2_pre = nextafterf(P.r2_pre, 3.4e38f);
+    }
     const unsigned ntiles = (unsigned)(nt * nt * nt);
     const unsigned n = (unsigned)nt, m = (unsigned)(nt - 2);  // (nt >= 4: checked by the caller)
     (void)ntiles;
@@ -915,14 +1055,24 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
     const dim3 slabs[3] = {dim3(n, n, 2), dim3(n, 2, m), dim3(2, m, m)};
     for (int slab = 0; slab < 3; slab++) {
         CG_HIP(hipStreamWaitEvent(c->sr_streams[slab], c->sr_fork, 0));
-        hipLaunchKernelGGL(k_sr_sweep_cells<true>, slabs[slab], dim3(256), 0, c->sr_streams[slab],
-                           pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P,
-                           slab);
+        if (pre32)
+            hipLaunchKernelGGL((k_sr_sweep_cells<true, true>), slabs[slab], dim3(256), 0,
+                               c->sr_streams[slab], pos_r_sorted, order_r, off_r, dmom_r,
+                               pos_s_sorted, off_s, table, P, slab);
+        else
+            hipLaunchKernelGGL((k_sr_sweep_cells<true, false>), slabs[slab], dim3(256), 0,
+                               c->sr_streams[slab], pos_r_sorted, order_r, off_r, dmom_r,
+                               pos_s_sorted, off_s, table, P, slab);
         CG_LAUNCH_CHECK();
         CG_HIP(hipEventRecord(c->sr_join[slab], c->sr_streams[slab]));
     }
-    hipLaunchKernelGGL(k_sr_sweep_cells<false>, dim3(m, m, m), dim3(256), 0, c->stream,
-                       pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P, 0);
+    if (pre32)
+        hipLaunchKernelGGL((k_sr_sweep_cells<false, true>), dim3(m, m, m), dim3(256), 0, c->stream,
+                           pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P, 0);
+    else
+        hipLaunchKernelGGL((k_sr_sweep_cells<false, false>), dim3(m, m, m), dim3(256), 0,
+                           c->stream, pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s,
+                           table, P, 0);
     CG_LAUNCH_CHECK();
     for (int slab = 0; slab < 3; slab++) CG_HIP(hipStreamWaitEvent(c->stream, c->sr_join[slab], 0));
     return 0;
