@@ -589,10 +589,15 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
+        # a collective that a peer never joins fails after 5 minutes instead of hanging the box
+        import datetime
+        os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '1')
+        limit = datetime.timedelta(minutes=5)
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank),
+                                    timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     from concept_amd.mesh import PotentialMesh
     name = args.workload or ('c2_256c_512' if args.p3m else 'ns_256M_1024')

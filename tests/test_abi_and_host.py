@@ -202,3 +202,46 @@ shortrange_params = {'gravity': {'scale': '1.1*boxsize/gridsize', 'range': '4.8*
     sr = commons.resolve_shortrange(p, 96)
     assert abs(sr['scale'] - 1.1*400.0/96) < 1e-12 and abs(sr['range'] - 4.8*sr['scale']) < 1e-12
     assert p.nghosts == 2
+
+
+def test_cosmology_and_timestep_parameters():
+    """The parameters of the time loop and its clock keep the reference's names and defaults
+    (commons.py:3630-3638, 3875-3890, 4313-4319, 4435-4479)."""
+    from concept_amd import commons
+    p = commons.load_params({})
+    u = p.units
+    assert p.H0 == 67*u.km/(u.s*u.Mpc) and p.Ωb == 0.049 and p.Ωcdm == 0.27
+    assert p.a_begin == 1 and p.t_begin == 0 and p.enable_Hubble is True
+    assert p.Δa_max_early == 0.00153 and p.Δa_max_late == 0.022
+    assert p.Δt_base_background_factor == p.Δt_base_nonlinear_factor == p.Δt_rung_factor == 1
+    assert p.Δt_increase_max_factor == float('inf') and p.static_timestepping is None
+    assert p.ρ_crit == 3*p.H0**2/(8*commons.π*p.G_Newton) and p.ρ_mbar == p.Ωm*p.ρ_crit
+    assert p.output_times == {'a': (), 't': ()}
+    # output_times: {kind: times} are scale factors with the Hubble expansion, cosmic times
+    # without; {'a': ..., 't': ...} with {kind: times} or plain times inside
+    p = commons.load_params("output_times = {'snapshot': (0.1, 0.5, 1), 'powerspec': 1}\n")
+    assert sorted(p.output_times['a']) == [0.1, 0.5, 1.0, 1.0] and p.output_times['t'] == ()
+    p = commons.load_params({'enable_Hubble': False, 'output_times': {'snapshot': (2, 3)}})
+    assert p.output_times == {'a': (), 't': (2.0, 3.0)}
+    p = commons.load_params({'output_times': {'a': {'snapshot': 0.5}, 't': (13.0,)}})
+    assert p.output_times == {'a': (0.5,), 't': (13.0,)}
+    for bad in ({'Δt_increase_max_factor': 1.0}, {'Δa_max_late': 0},
+                {'enable_Hubble': False, 'static_timestepping': (lambda a: 0.01)}):
+        with pytest.raises(ValueError):
+            commons.load_params(bad)
+
+
+def test_parameter_file_forward_references_and_skipped_path_parameters():
+    """statements are re-executed until nothing new resolves (later definitions
+    reach earlier uses, with and without H0); a statement assigning one of THIS path's
+    parameters that never runs is warned about instead of silently defaulting."""
+    import warnings
+    from concept_amd import commons
+    p = commons.load_params("boxsize = _L*Mpc\n_L = 100\nfoo = CLASS_thing\n")
+    assert p.boxsize == 100.0
+    p = commons.load_params("boxsize = _L*Mpc/h\n_L = 100\nH0 = 50*km/(s*Mpc)\nbar = _undefined\n")
+    assert p.boxsize == 200.0
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        p = commons.load_params("boxsize = 3*_never_defined\nN_rungs = 4\n")
+    assert p.N_rungs == 4 and any('boxsize' in str(x.message) for x in w)
