@@ -220,7 +220,13 @@ static int dist_generic(cg_ctx *c, int what, double2 *buf, int deconv_order, dou
             if (dist_work(c, pb)) return 1;
             CG_FFT(rocfft_execute(pb, io, nullptr, c->dist_plans->info));
         }
-        return hipGetLastError() == hipSuccess ? 0 : 1;
+        hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) {
+            cg_set_error("cg_dist_fft (rocFFT backend): pack / unpack launch failed: %s",
+                         hipGetErrorString(e_));
+            return 1;
+        }
+        return 0;
     }
     if (dist_plans_x(c)) return 1;
     void *io[1] = {(void *)buf};

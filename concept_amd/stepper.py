@@ -93,6 +93,12 @@ def _streaming_pass(plan, components, rps, ᔑdt_kick, ᔑdt_drift, label=''):
         fold = mesh.fold_ghosts_start()
         mesh.poisson_solve(plan['deconv_order'], plan['C'], plan['long_range'], plan['E'],
                            fold_finish=fold, fill=True)
+        plan['solved'] = True
+    elif not plan.get('solved'):
+        # a drift before any kick: the gather multiplies what the mesh holds by 0 — make sure
+        # that is a number
+        mesh.zero()
+        plan['solved'] = True
     before = [rp.snapshot() for rp in rps]
     for c, rp in zip(components, rps):
         order = c.potential_differentiations[plan['force']][plan['method']]
