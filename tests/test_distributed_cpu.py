@@ -159,3 +159,31 @@ def test_particle_exchange_compact(world, skew, listed):
 @pytest.mark.parametrize('world,N,npieces', [(2, 16, 2), (4, 32, 4), (2, 16, 3)])
 def test_transpose_in_layer_pieces(world, N, npieces):
     _run(_w_transpose_pieces, world, N, npieces)
+
+
+def _w_floats_and_snapshot_shares(rank, world):
+    """Comm.all_gather_floats: the same array on every rank, in rank order (what the v_rms of
+    the time loop sums over); and the rank-wise snapshot reader: every rank its own rows of a
+    reference-written GADGET file, together the whole file (communication.partition)."""
+    from concept_amd import commons, snapshot
+    from concept_amd.distributed import Comm
+    comm = Comm()
+    got = comm.all_gather_floats([rank + 0.25, 10.0*rank])
+    want = np.array([[r + 0.25, 10.0*r] for r in range(world)])
+    assert np.array_equal(got.numpy(), want)
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, 'golden', 'gadget_sf2_32.npz'))
+    commons.load_params({'boxsize': float(g['boxsize'])})
+    path = os.path.join(here, 'golden', 'gadget_sf2_32.gadget')
+    mine = snapshot.load(path, rank=rank, nprocs=world)
+    whole = snapshot.load(path, rank=0, nprocs=1)
+    for c, w in zip(mine.components, whole.components):
+        counts = comm.all_gather_ints([c['N_local'], c['start_local']])
+        assert int(counts[:, 0].sum()) == w['N']
+        assert np.array_equal(c['pos'], w['pos'][c['start_local']:c['start_local'] + c['N_local']])
+        assert np.array_equal(c['mom'], w['mom'][c['start_local']:c['start_local'] + c['N_local']])
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_gather_floats_and_rank_wise_snapshot(world):
+    _run(_w_floats_and_snapshot_shares, world)
