@@ -17,6 +17,10 @@ Reference entry points exercised (file:line in /root/reference/src):
   mesh.diff_domaingrid            mesh.py:4874
   species.Component.drift         species.py:2179
   gravity.gravity_pairwise_shortrange gravity.py:263 (P3M cases)
+  main.timeloop                   main.py:102       (traj_* cases: whole runs a_begin -> 1 with
+                                                     the matter + Λ clock, every
+                                                     get_time_step_integrals call recorded)
+  integration.init_time / scalefactor_integral  integration.py:864, 712 (through the above)
 Intermediates are captured by rebinding module globals of the imported
 pure-Python modules (commons.py:1268-1274 binds cimported names as plain
 globals), never by editing reference files.

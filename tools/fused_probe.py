@@ -25,7 +25,7 @@ pb, mb = torch.empty_like(pa), torch.empty_like(ma)
 start_out, count_out = mesh.new_region_table()
 mesh.predict_regions(table, None, start_out)
 ms = []
-for i in range(6):
+for i in range(int(os.environ.get("PROBE_ITERS", "6"))):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     mesh.gather_kick_drift_scatter(pa, ma, None, table, None, pb, mb, None, start_out, count_out,
@@ -39,7 +39,7 @@ print('fused ms per call:', ' '.join(f'{v:.3f}' for v in ms), 'flags', mesh.erro
 start2, count2 = mesh.new_region_table()
 mesh.predict_regions(start_out, count_out, start2)
 ms = []
-for i in range(6):
+for i in range(int(os.environ.get("PROBE_ITERS", "6"))):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     mesh.gather_kick_drift_scatter(pb, mb, None, start_out, count_out, pa, ma, None, start2, count2,
