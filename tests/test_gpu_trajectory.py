@@ -228,3 +228,64 @@ def test_timeloop_streaming_at_north_star_size():
     print(f'Timeloop at 2^28 / 1024^3: {nsteps} base steps, {loop.stream_passes} passes in '
           f'{wall:.2f} s = {wall/max(loop.stream_passes, 1)*1e3:.1f} ms per pass (deposit + solve '
           f'+ fused kick/drift/sort + v_rms + host)')
+
+
+def test_streaming_loop_through_structure_formation():
+    """A whole run with real clustering — 64^3 particles on a 128^3 PM mesh from a displaced
+    lattice at a = 0.05 to a = 1, ~120 base steps in which the tiles' populations change by
+    factors — through the streaming form of the time loop and through the separate passes:
+    same step sequence, every particle kept (identifiers a permutation), positions equal to
+    what rounding allows after that many steps.  The streaming loop sizes its tile regions from
+    the previous step's populations; where a region overflows it undoes and replays the pass
+    (stepper.stream_replays is printed)."""
+    from concept_amd import commons, stepper
+    from concept_amd.species import Component
+    n_side, gs, L = 64, 128, 64.0
+    n = n_side**3
+    rng = np.random.default_rng(2024)
+    lat = (np.stack(np.meshgrid(*[np.arange(n_side)]*3, indexing='ij'), -1).reshape(-1, 3)
+           + 0.5)*(L/n_side)
+    # a smooth displacement field (a few long waves) + small-scale noise, growing mode
+    k = 2*np.pi/L
+    psi = np.zeros((n, 3))
+    for d in range(3):
+        for m in range(1, 4):
+            ph = rng.uniform(0, 2*np.pi, 3)
+            psi[:, d] += 0.35/m*np.sin(m*k*lat[:, (d + 1) % 3] + ph[0]) \
+                * np.cos(m*k*lat[:, (d + 2) % 3] + ph[1])
+    psi += rng.normal(0, 0.02, (n, 3))
+    results = []
+    for streaming in (None, False):
+        p = commons.load_params({
+            'boxsize': L, 'H0': 0.07, 'Ωb': 0.05, 'Ωcdm': 0.25, 'a_begin': 0.05,
+            'output_times': {'a': (1.0,)},
+            'potential_options': {'gridsize': {'gravity': {'pm': gs}}},
+            'select_forces': {'all': {'gravity': 'pm'}}})
+        mass = p.ρ_mbar*L**3/n
+        c = Component('matter', 'matter', N=n, mass=mass)
+        loop = stepper.Timeloop([c], streaming=streaming)
+        a0 = loop.cosmo.a
+        pos = (lat + psi*a0/0.05) % L
+        c.populate(pos, 'pos')
+        c.populate(psi*mass*a0**2*loop.cosmo.hubble(a0), 'mom')
+        replays = stepper.stream_replays
+        loop.run()
+        ids = c.host('ids', original_order=False)
+        assert np.array_equal(np.sort(ids), np.arange(n))
+        results.append((np.array(loop.history), c.host('pos'), loop.stream_passes,
+                        stepper.stream_replays - replays))
+    (h0, p0, passes, replays), (h1, p1, none, _) = results
+    assert passes > 100 and none == 0
+    assert h0.shape == h1.shape and h0.shape[0] > 100
+    assert np.abs(h0[:, 1:]/h1[:, 1:] - 1).max() <= 1e-9
+    d = np.abs(p0 - p1)
+    d = np.minimum(d, L - d)
+    # the two runs differ by rounding only (summation orders of v_rms and of the deposit); the
+    # clustered end state amplifies that: mean over the particles, generous bar
+    assert d.mean() <= 1e-7*L, d.mean()
+    # it did cluster: the particles have left the lattice by several cells
+    moved = np.abs(p1 - lat % L)
+    assert np.minimum(moved, L - moved).max() > 4*L/gs
+    print(f'\nstructure formation run: {h0.shape[0]} steps, {passes} streaming passes, '
+          f'{replays} replayed, mean |dx| between the two forms {d.mean()/L:.2e} L, max '
+          f'{d.max()/L:.2e} L')
