@@ -454,6 +454,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         constexpr int NA = (E + 7) / 8;          // planes per wave
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int b0 = T0b - H, c0 = T0c - H;
+        const bool seam = b0 < 0 || c0 < 0 || b0 + E > Ni || c0 + E > Ni;
         unsigned off[NP];  // gj*pad + gk
         int cmp[COMPACT ? NP : 1];  // compact planes: (b-1)*IN + (c-1) of the interior, else -1
 #pragma unroll
@@ -461,8 +462,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
             int i2 = lane + 64 * q;
             int b = i2 / E, c = i2 - b * E;
             int gj = b0 + b, gk = c0 + c;
-            gj += (gj < 0 ? Ni : 0) - (gj >= Ni ? Ni : 0);
-            gk += (gk < 0 ? Ni : 0) - (gk >= Ni ? Ni : 0);
+            if (seam) {  // (tile-uniform) the block reaches across the periodic seam in y or z
+                gj += (gj < 0 ? Ni : 0) - (gj >= Ni ? Ni : 0);
+                gk += (gk < 0 ? Ni : 0) - (gk >= Ni ? Ni : 0);
+            }
             off[q] = (unsigned)gj * (unsigned)pad + (unsigned)gk;
             if (COMPACT)
                 cmp[q] = (b >= 1 && b <= E - 2 && c >= 1 && c <= E - 2)
@@ -535,7 +538,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         Cic1 cx = cic1(px, geo.off[0], geo.scale);
         Cic1 cy = cic1(py, geo.off[1], geo.scale);
         Cic1 cz = cic1(pz, geo.off[2], geo.scale);
-        int ga = wrap(cx.index - g, Ni), gb = wrap(cy.index - g, Ni), gc = wrap(cz.index - g, Ni);
+        // (a position in [0, boxsize) has its lower cell in [-1, N - 1]: only the lower wrap)
+        int ga = cx.index - g, gb = cy.index - g, gc = cz.index - g;
+        ga += ga < 0 ? Ni : 0;
+        gb += gb < 0 ? Ni : 0;
+        gc += gc < 0 ? Ni : 0;
         int la = ga - T0a, lb = gb - T0b, lc = gc - T0c;
         double wx[2] = {cx.w0, cx.w1}, wy[2] = {cy.w0, cy.w1}, wz[2] = {cz.w0, cz.w1};
         double val[3] = {0, 0, 0};
