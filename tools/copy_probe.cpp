@@ -1,5 +1,6 @@
-// HBM copy-rate probe: how fast can a hand-written kernel copy 8 GB on this part, and does the
-// form of the kernel matter?  (torch's elementwise copy: 4.8 TB/s read+write.)
+// Out-of-place against in-place: does a pass that reads buffer A and writes buffer B run faster
+// than one that overwrites A?  (The FFT passes of cg_fft.hip are in place.)  Also the strided
+// access of the y / x passes: rows of 16 B * 8 = 128 B gathered with a stride of one plane row.
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/copy_probe tools/copy_probe.cpp
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -7,64 +8,116 @@
 typedef double d2 __attribute__((ext_vector_type(2)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template <int U, bool NT>
-__global__ __launch_bounds__(256) void k_copy(const d2 *__restrict__ src, d2 *__restrict__ dst, size_t n) {
-    // grid-stride over blocks of 256*U elements
-    for (size_t base = (size_t)blockIdx.x * 256 * U; base < n; base += (size_t)gridDim.x * 256 * U) {
+template <int U, int NT>
+__global__ __launch_bounds__(256) void k_pass(const d2 *src, d2 *dst) {
+    size_t base = (size_t)blockIdx.x * 256 * U;
+    d2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        v[u] = NT & 1 ? __builtin_nontemporal_load(&src[base + u * 256 + threadIdx.x]) : src[base + u * 256 + threadIdx.x];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        v[u].x += 1.0;
+        if (NT & 2) __builtin_nontemporal_store(v[u], &dst[base + u * 256 + threadIdx.x]);
+        else dst[base + u * 256 + threadIdx.x] = v[u];
+    }
+}
+// persistent form: a fixed grid, each workgroup walks chunks
+template <int U>
+__global__ __launch_bounds__(256) void k_pass_persist(const d2 *src, d2 *dst, size_t nchunks) {
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        size_t base = c * 256 * U;
         d2 v[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            size_t i = base + u * 256 + threadIdx.x;
-            v[u] = NT ? __builtin_nontemporal_load(src + i) : src[i];
-        }
+        for (int u = 0; u < U; u++) v[u] = src[base + u * 256 + threadIdx.x];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            size_t i = base + u * 256 + threadIdx.x;
-            if (NT) __builtin_nontemporal_store(v[u], dst + i); else dst[i] = v[u];
-        }
+        for (int u = 0; u < U; u++) { v[u].x += 1.0; dst[base + u * 256 + threadIdx.x] = v[u]; }
     }
 }
-template <int U>
-__global__ __launch_bounds__(256) void k_read(const d2 *__restrict__ src, double *out, size_t n) {
-    double acc = 0;
-    for (size_t base = (size_t)blockIdx.x * 256 * U; base < n; base += (size_t)gridDim.x * 256 * U) {
-#pragma unroll
-        for (int u = 0; u < U; u++) { d2 v = src[base + u * 256 + threadIdx.x]; acc += v.x + v.y; }
-    }
-    if (acc == 1.2345) out[0] = acc;
-}
-template <int U>
-__global__ __launch_bounds__(256) void k_rmw(d2 *__restrict__ buf, size_t n) {
-    for (size_t base = (size_t)blockIdx.x * 256 * U; base < n; base += (size_t)gridDim.x * 256 * U) {
-        d2 v[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) v[u] = buf[base + u * 256 + threadIdx.x];
-#pragma unroll
-        for (int u = 0; u < U; u++) { v[u].x += 1.0; buf[base + u * 256 + threadIdx.x] = v[u]; }
-    }
-}
-template <class F> float timeit(F f, int reps = 5) {
-    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    f(); CK(hipDeviceSynchronize());
-    CK(hipEventRecord(a)); for (int i = 0; i < reps; i++) f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
-    float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / reps;
+template <int U, int NT>
+static double run(const d2 *s, d2 *d, size_t bytes, hipEvent_t e0, hipEvent_t e1) {
+    unsigned g = (unsigned)(bytes / 16 / (256 * U));
+    for (int i = 0; i < 2; i++) hipLaunchKernelGGL((k_pass<U, NT>), dim3(g), dim3(256), 0, 0, s, d);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 6; i++) hipLaunchKernelGGL((k_pass<U, NT>), dim3(g), dim3(256), 0, 0, s, d);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return 2.0 * bytes * 6 / ms / 1e9;
 }
 int main() {
-    const size_t bytes = (size_t)8 << 30, n = bytes / 16;
-    d2 *a, *b; double *o; CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&o, 8));
-    CK(hipMemset(a, 0, bytes)); CK(hipMemset(b, 0, bytes));
-    int grids[] = {256 * 2, 256 * 4, 256 * 8, 256 * 16, 256 * 64, 0};
-    for (int gi = 0; gi < 6; gi++) {
-        size_t g = grids[gi] ? grids[gi] : n / (256 * 4);
-        float t1 = timeit([&] { hipLaunchKernelGGL((k_copy<4, false>), dim3(g), dim3(256), 0, 0, a, b, n); });
-        float t2 = timeit([&] { hipLaunchKernelGGL((k_copy<8, false>), dim3(g), dim3(256), 0, 0, a, b, n); });
-        float t3 = timeit([&] { hipLaunchKernelGGL((k_copy<4, true>), dim3(g), dim3(256), 0, 0, a, b, n); });
-        float t4 = timeit([&] { hipLaunchKernelGGL((k_read<8>), dim3(g), dim3(256), 0, 0, a, o, n); });
-        float t5 = timeit([&] { hipLaunchKernelGGL((k_rmw<4>), dim3(g), dim3(256), 0, 0, a, n); });
-        printf("grid %8zu: copy U4 %.2f TB/s  U8 %.2f  NT %.2f | read %.2f TB/s | rmw %.2f TB/s\n", g,
-               2 * bytes / t1 / 1e9, 2 * bytes / t2 / 1e9, 2 * bytes / t3 / 1e9, bytes / t4 / 1e9, 2 * bytes / t5 / 1e9);
+    const size_t total = (size_t)8704 << 20;
+    d2 *a, *b; CK(hipMalloc(&a, total)); CK(hipMalloc(&b, total)); CK(hipMemset(a, 0, total)); CK(hipMemset(b, 0, total));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    printf("U=4  in-place      plain %.2f  nt-load %.2f  nt-store %.2f  nt-both %.2f TB/s\n",
+           run<4, 0>(a, a, total, e0, e1), run<4, 1>(a, a, total, e0, e1), run<4, 2>(a, a, total, e0, e1), run<4, 3>(a, a, total, e0, e1));
+    printf("U=4  out-of-place  plain %.2f  nt-load %.2f  nt-store %.2f  nt-both %.2f TB/s\n",
+           run<4, 0>(a, b, total, e0, e1), run<4, 1>(a, b, total, e0, e1), run<4, 2>(a, b, total, e0, e1), run<4, 3>(a, b, total, e0, e1));
+    printf("U=8  in-place      plain %.2f  nt-both %.2f   out-of-place plain %.2f  nt-both %.2f TB/s\n",
+           run<8, 0>(a, a, total, e0, e1), run<8, 3>(a, a, total, e0, e1), run<8, 0>(a, b, total, e0, e1), run<8, 3>(a, b, total, e0, e1));
+    printf("U=16 in-place      plain %.2f  nt-both %.2f   out-of-place plain %.2f  nt-both %.2f TB/s\n",
+           run<16, 0>(a, a, total, e0, e1), run<16, 3>(a, a, total, e0, e1), run<16, 0>(a, b, total, e0, e1), run<16, 3>(a, b, total, e0, e1));
+    printf("U=1  in-place      plain %.2f  out-of-place plain %.2f  nt-both %.2f TB/s\n",
+           run<1, 0>(a, a, total, e0, e1), run<1, 0>(a, b, total, e0, e1), run<1, 3>(a, b, total, e0, e1));
+    for (unsigned g : {256u * 4, 256u * 8, 256u * 16, 256u * 32}) {
+        size_t nch = total / 16 / (256 * 4);
+        for (int pass = 0; pass < 2; pass++) {
+            d2 *dst = pass ? b : a;
+            hipLaunchKernelGGL((k_pass_persist<4>), dim3(g), dim3(256), 0, 0, a, dst, nch);
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 6; i++) hipLaunchKernelGGL((k_pass_persist<4>), dim3(g), dim3(256), 0, 0, a, dst, nch);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("persistent grid %5u %s: %.2f TB/s\n", g, pass ? "out-of-place" : "in-place", 2.0 * total * 6 / ms / 1e9);
+        }
     }
-    float tm = timeit([&] { CK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0)); });
-    printf("hipMemcpy D2D: %.2f TB/s (read+write)\n", 2 * bytes / tm / 1e9);
+    // chunked two-pass schedules (the z / y FFT passes): (a) both in place on the chunk, (b) pass 1
+    // writes a chunk-sized scratch that stays cache-resident, pass 2 reads it and writes the chunk
+    {
+        d2 *scr = b;
+        for (size_t mb : {64, 96, 128, 192, 256}) {
+            size_t chunk = mb << 20, nchunks = total / chunk, n = chunk / 16;
+            unsigned g = (unsigned)(n / (256 * 4));
+            float ms;
+            CK(hipEventRecord(e0));
+            for (int rep = 0; rep < 3; rep++)
+                for (size_t c = 0; c < nchunks; c++) {
+                    d2 *pc = a + c * n;
+                    hipLaunchKernelGGL((k_pass<4, 0>), dim3(g), dim3(256), 0, 0, pc, pc);
+                    hipLaunchKernelGGL((k_pass<4, 0>), dim3(g), dim3(256), 0, 0, pc, pc);
+                }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            float t_in = ms / 3;
+            CK(hipEventRecord(e0));
+            for (int rep = 0; rep < 3; rep++)
+                for (size_t c = 0; c < nchunks; c++) {
+                    d2 *pc = a + c * n;
+                    hipLaunchKernelGGL((k_pass<4, 0>), dim3(g), dim3(256), 0, 0, pc, scr);
+                    hipLaunchKernelGGL((k_pass<4, 0>), dim3(g), dim3(256), 0, 0, scr, pc);
+                }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            float t_scr = ms / 3;
+            CK(hipEventRecord(e0));
+            for (int rep = 0; rep < 3; rep++)
+                for (size_t c = 0; c < nchunks; c++) {
+                    d2 *pc = a + c * n;
+                    hipLaunchKernelGGL((k_pass<4, 1>), dim3(g), dim3(256), 0, 0, pc, scr);
+                    hipLaunchKernelGGL((k_pass<4, 2>), dim3(g), dim3(256), 0, 0, scr, pc);
+                }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            float t_scr_nt = ms / 3;
+            unsigned g1 = (unsigned)(n / 256);
+            CK(hipEventRecord(e0));
+            for (int rep = 0; rep < 3; rep++)
+                for (size_t c = 0; c < nchunks; c++) {
+                    d2 *pc = a + c * n;
+                    hipLaunchKernelGGL((k_pass<1, 0>), dim3(g1), dim3(256), 0, 0, pc, scr);
+                    hipLaunchKernelGGL((k_pass<1, 0>), dim3(g1), dim3(256), 0, 0, scr, pc);
+                }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            float t_scr_u1 = ms / 3;
+            printf("two passes per chunk of %3zu MB: in place %.2f ms   via scratch %.2f   via scratch nt %.2f   via scratch U=1 %.2f ms per sweep\n",
+                   mb, t_in, t_scr, t_scr_nt, t_scr_u1);
+        }
+    }
     return 0;
 }
