@@ -66,15 +66,36 @@ __device__ __forceinline__ unsigned tile_for_block(unsigned b, unsigned ntiles) 
 #ifndef CG_TILE_GROUP
 #define CG_TILE_GROUP 4
 #endif
+// CG_TILE_INTERLEAVE=1 (A/B, off): the groups dealt out to the XCDs in a 2-D pattern,
+// XCD = (gb + 3 ga) mod 8, instead of a contiguous eighth of the box (a slab of a-layers) per
+// XCD, so that a clump of a clustered box is shared by several XCDs.  Measured on the clustered
+// bench box (64 clumps, 80 % of the particles): 11.32 against 11.25 ms, uniform 8.56 against
+// 8.52 — no gain: the clustered pass is not slower because XCDs are unevenly loaded but because
+// its 260,000 nearly empty tiles still stage their block while the heavy ones run at the
+// uniform rate per particle (tools/fused_probe.py PROBE_CLUSTERED / PROBE_SUBBOX, CG_GK_TIMING).
+#ifndef CG_TILE_INTERLEAVE
+#define CG_TILE_INTERLEAVE 0
+#endif
 __device__ __forceinline__ unsigned tile_for_block_grouped(unsigned b, unsigned ntiles,
                                                            unsigned nb, unsigned nc) {
     constexpr unsigned G = CG_TILE_GROUP;
     const unsigned per = ntiles / 8u;          // tiles per XCD
-    if (G < 2u || ntiles % 8u || per % (G * nb * nc) || nb % G) return tile_for_block(b, ntiles);
+    const unsigned nbg = nb / G, na = ntiles / (nb * nc);
+    const bool interleave = CG_TILE_INTERLEAVE && G >= 2u && nb % G == 0 && nbg % 8u == 0 &&
+                            na % G == 0 && na * nb * nc == ntiles;
+    if (!interleave && (G < 2u || ntiles % 8u || per % (G * nb * nc) || nb % G))
+        return tile_for_block(b, ntiles);
     const unsigned x = b % 8u, i = b / 8u;     // XCD, position in its walk
     const unsigned q = i % (G * G), col = i / (G * G);   // member of the group, group number
     const unsigned c = col % nc, g = col / nc; // column position, group in the (a/G, b/G) plane
-    const unsigned gb = g % (nb / G), ga = g / (nb / G);
+    if (interleave) {
+        // the XCD's g-th group: row ga of groups, the j-th of the row's groups that are its own
+        const unsigned ga = g / (nbg / 8u), j = g % (nbg / 8u);
+        const unsigned gb = ((x + 8u - (3u * ga) % 8u) % 8u) + 8u * j;
+        const unsigned ta = G * ga + q / G, tb = G * gb + q % G;
+        return (ta * nb + tb) * nc + c;
+    }
+    const unsigned gb = g % nbg, ga = g / nbg;
     const unsigned ta = G * ga + q / G, tb = G * gb + q % G;
     return x * per + (ta * nb + tb) * nc + c;
 }
@@ -326,6 +347,21 @@ constexpr int gk_waves() {
     return MODE == 2 ? CG_GK_WAVES_FUSED : (MODE == 0 ? CG_GK_WAVES_PLAIN : 4);
 }
 
+#ifdef CG_GK_TIMING  // probe build: where a workgroup's time goes (wave 0 of every workgroup)
+__device__ unsigned long long cg_gk_timing[16];
+extern "C" int cg_debug_gk_timing(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(cg_gk_timing), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(cg_gk_timing), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#define GK_T(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    const unsigned long long now_ = __builtin_readcyclecounter(); gk_t[i] += now_ - gk_last; gk_last = now_; } while (0)
+#else
+#define GK_T(i) do { } while (0)
+#endif
 // MODE 0: gather + kick in place.  1: also histogram the tile keys after the next drift (PREP).
 // 2: kick, drift and scatter into the next tile order in one pass (nothing written in place).
 template <int ORDER, int T, int MODE>
@@ -347,6 +383,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         while (__builtin_readcyclecounter() - t0 < (unsigned long long)CG_GK_STAGGER)
             __builtin_amdgcn_s_sleep(32);
     }
+#endif
+#ifdef CG_GK_TIMING
+    unsigned long long gk_t[8] = {}, gk_last = __builtin_readcyclecounter();
 #endif
     const unsigned tile = tile_for_block_grouped(blockIdx.x, ntiles, (unsigned)nt, (unsigned)nt);
     // the tile's particles: dense tile order -> one range; regions with gaps (prep.count_in)
@@ -522,6 +561,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         }
     }
     __syncthreads();
+    GK_T(0);  // staging
     for (pidx pbase = beg; pbase < end; pbase += 512) {
         pidx p = pbase + threadIdx.x;
         bool pvalid = p < end;
@@ -533,6 +573,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
             p = pre_p;
             pvalid = pre_valid;
             px = pre_x, py = pre_y, pz = pre_z, qx = pre_mx, qy = pre_my, qz = pre_mz;
+            GK_T(1);  // particle loads
 #ifdef CG_GK_PREFETCH
             if (pbase + 512 < end) fetch(pbase + 512);
 #endif
@@ -657,6 +698,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         if (FUSED) {
             // the scatter of cg_particles.hip k_tile_scatter: one atomic per run of equal keys
             // among consecutive lanes, runs stored cooperatively
+            GK_T(2);  // gather, kick, drift, key
             const int lane = threadIdx.x & 63;
             int rs, rl;
             wave_runs(next_key, lane, rs, rl);
@@ -675,6 +717,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
                 else first = o0 + local;
             }
             first = __shfl(first, rs);
+            GK_T(3);  // reservation round trip
             const bool valid = pvalid && next_key != kNoTile && first != kNoTile;
 #if !defined(CG_GK_RUNSTORE) && !defined(CG_GK_NOSTORE)
             // every lane stores its own record (24-byte stride; the runs of a wave are
@@ -719,8 +762,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
                     atomicOr(prep.err_flags, (unsigned)CG_ERR_BUCKET_OVERFLOW);
                 }
             }
+            GK_T(4);  // stores
         }
     }
+#ifdef CG_GK_TIMING
+    if (FUSED && threadIdx.x == 0) {
+        for (int i = 0; i < 5; i++) atomicAdd(&cg_gk_timing[i], gk_t[i]);
+        atomicAdd(&cg_gk_timing[8], 1ull);
+    }
+#endif
 }
 
 template <int ORDER, int T>

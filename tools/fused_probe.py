@@ -12,6 +12,15 @@ dev = torch.device('cuda')
 mesh = PotentialMesh(N, L)
 gen = torch.Generator(device=dev).manual_seed(1)
 pos = torch.rand((n_p, 3), dtype=torch.float64, device=dev, generator=gen)*(L*(1 - 1e-13))
+if os.environ.get('PROBE_SUBBOX'):   # all particles in the sub-box [0, L/k)^3: k^-3 of the tiles, heavy
+    pos /= float(os.environ['PROBE_SUBBOX'])
+if os.environ.get('PROBE_CLUSTERED'):  # bench.py's clustered box
+    centres = torch.rand((64, 3), dtype=torch.float64, device=dev, generator=gen)*L
+    which = torch.randint(0, 64, (n_p,), device=dev, generator=gen)
+    blob = centres[which] + torch.randn((n_p, 3), dtype=torch.float64, device=dev, generator=gen)*(L/40)
+    keep = torch.rand(n_p, dtype=torch.float64, device=dev, generator=gen) < 0.2
+    pos = torch.where(keep[:, None], pos, torch.remainder(blob, L)).clamp_(0.0, L*(1 - 1e-13))
+    del centres, which, blob, keep
 dt = 1e-4
 mom = torch.randn((n_p, 3), dtype=torch.float64, device=dev, generator=gen)*(0.2/3**0.5/dt)
 cap = mesh.region_capacity(n_p)
@@ -49,3 +58,15 @@ for i in range(int(os.environ.get("PROBE_ITERS", "6"))):
     ms.append(e0.elapsed_time(e1))
 print('from regions with gaps:', ' '.join(f'{v:.3f}' for v in ms), 'flags', mesh.error_flags(),
       'placed', int(count2.long().sum()))
+
+# probe build with -DCG_GK_TIMING: where wave 0 of every workgroup spent its cycles
+import ctypes
+try:
+    h = ctypes.CDLL(os.environ.get('CONCEPT_GPU_LIB', ''))
+    buf = (ctypes.c_ulonglong*16)()
+    if h.cg_debug_gk_timing(buf, 1) == 0:
+        tot = sum(buf[i] for i in range(5))
+        names = ['staging', 'particle loads', 'gather/kick/drift/key', 'reservation', 'stores']
+        print('workgroups', buf[8], ' cycles per workgroup:', ' '.join(f'{n} {buf[i]/max(buf[8],1):.0f} ({100*buf[i]/max(tot,1):.0f}%)' for i, n in enumerate(names)))
+except (OSError, AttributeError):
+    pass
