@@ -17,7 +17,15 @@ Over several domains (comm.init) every rank reads ITS SHARE of every component â
 [start_local, start_local + N_local) of communication.partition() (communication.py:39-56), the
 byte ranges of the POS / VEL / ID blocks that hold them, as the reference's loader does
 (snapshot.py:2066-2330) â€” and `to_components()` hands them to Component.populate_local(), whose
-exchange() re-homes them to the slabs that own them: no rank ever holds the whole file."""
+exchange() re-homes them to the slabs that own them: no rank ever holds the whole file.
+
+`save()` writes the same format (the writer of snapshot.py:880-1420 for one file): HEAD block as
+`populate()` builds it (snapshot.py:2462-2560), then POS / VEL / ID with the reference's
+conversion â€” value*(1/unit) (the reciprocal is formed first, snapshot.py:1375-1392), positions
+that reach the box size in file units after the conversion wrapped by one box, the result cast
+to the block's width; components without identifiers get running numbers that continue over the
+components (snapshot.py:1343-1349, 1406-1412).  Files written here are byte-identical to those
+the reference writes from the same arrays (tests/test_snapshot.py, both fixtures)."""
 import os
 import struct
 
@@ -54,6 +62,31 @@ def _unit(expr, h, p):
     ns = dict(vars(p.units))
     ns['h'] = h
     return float(eval(expr, {}, ns))
+
+
+def correct_float(val_raw):
+    """commons.correct_float (commons.py:5356-5388), which the reference's writer applies to
+    every double of the header (snapshot.py:1731-1733): the float with the shortest decimal
+    form within Â±10 Îµ of the value, when that form is shorter by more than two characters
+    (33599.99999999999 â†’ 33600.0)."""
+    val_raw = float(val_raw)
+    val_g = float(f'{val_raw:g}')
+    if val_g == val_raw:
+        return val_g
+    val_str = str(abs(val_raw))
+    if 'e' in val_str:
+        val_str = val_str[:val_str.index('e')]
+    if len(val_str.replace('.', '')) < 15:
+        return val_raw
+    eps = float(np.finfo(np.float64).eps)
+    val_new = val_raw*(1 - 10*eps)
+    upper = val_raw*(1 + 10*eps)
+    val_correct = val_new
+    while val_new <= upper:
+        if len(str(val_new)) < len(str(val_correct)):
+            val_correct = val_new
+        val_new = float(np.nextafter(val_new, np.inf))
+    return val_correct if len(str(val_correct)) < len(str(val_raw)) - 2 else val_raw
 
 
 class GadgetSnapshot:
@@ -244,6 +277,145 @@ class GadgetSnapshot:
                         raise ConceptGPUError(f'Could not find required block "{blockname}"')
         return self
 
+    # -- save ------------------------------------------------------------------
+    def save(self, components, filename, a=None, params=None, snapformat=2, dataformat=None,
+             header=None):
+        """One-file GADGET snapshot of particle components.  components: Components (or the
+        dicts load() makes) whose names are GADGET type names ('GADGET halo', ...); a single
+        matter / cold dark matter component of another name is written as the halo type
+        (snapshot.py:2470-2505).  a: scale factor (header Time); params: overrides for H0,
+        boxsize, Î©m, Î©Î› (snapshot.py:2517-2527); dataformat: bits of 'POS', 'VEL' (32 | 64) and
+        'ID' (32 | 64 | 'automatic'); header: fields to overwrite (gadget_snapshot_params
+        ['header']).  On several domains the particles are gathered (Component.host) and rank 0
+        writes.  Returns the file name."""
+        p = self.p
+        params = dict(params or {})
+        fmt = {'POS': 32, 'VEL': 32, 'ID': 'automatic'}
+        fmt.update(dataformat or {})
+        if snapformat not in (1, 2):
+            raise ConceptGPUError(f'gadget_snapshot_params["snapformat"] = {snapformat} but must '
+                                  'be 1 or 2')
+        if not components:
+            raise ConceptGPUError(f'Cannot save a {self.name} snapshot with no components')
+
+        def get(c, key, default=None):
+            return c.get(key, default) if isinstance(c, dict) else getattr(c, key, default)
+        halo_like = [c for c in components if get(c, 'representation', 'particles') == 'particles'
+                     and get(c, 'species') in ('matter', 'cold dark matter')]
+        slots = [None]*num_particle_types
+        for c in components:
+            if get(c, 'representation', 'particles') != 'particles':
+                continue  # only particle components are supported (snapshot.py:2478-2484)
+            name = get(c, 'name')
+            if name in component_names:
+                slots[component_names.index(name)] = c
+            elif len(halo_like) == 1 and c is halo_like[0]:
+                slots[1] = c  # Mapping the component to "GADGET halo"
+        comps = [c for c in slots if c is not None]
+        if not comps:
+            raise ConceptGPUError(f'No components left to store in the {self.name} snapshot')
+        u = p.units
+        H0 = params.get('H0', p.H0)
+        a = params.get('a', a if a is not None else getattr(p, 'a_begin', 1.0))
+        boxsize = params.get('boxsize', p.boxsize)
+        Î©m = params.get('Î©m', p.Î©m)
+        Î©Î› = params.get('Î©Î›', 1 - Î©m)
+        h = H0/(100*u.km/(u.s*u.Mpc))
+        self.h = h
+        self.unit_length = _unit(self.unit_expr['length'], h, p)
+        self.unit_velocity = _unit(self.unit_expr['velocity'], h, p)
+        self.unit_mass = _unit(self.unit_expr['mass'], h, p)
+        num = [0 if c is None else int(get(c, 'N')) for c in slots]
+        hw = [n//2**32 for n in num]
+        lw = [n - 2**32*w for n, w in zip(num, hw)]
+        hd = {'Npart': list(num), 'Massarr': [0.0]*6, 'Time': a, 'Redshift': 1/a - 1, 'FlagSfr': 0,
+              'FlagFeedback': 0, 'Nall': lw, 'FlagCooling': 0, 'NumFiles': 1,
+              'BoxSize': boxsize/self.unit_length, 'Omega0': Î©m, 'OmegaLambda': Î©Î›,
+              'HubbleParam': h, 'FlagAge': 0, 'FlagMetals': 0, 'NallHW': hw, 'flag_entr_ics': 0}
+        for j, c in enumerate(slots):
+            if c is not None:
+                hd['Massarr'][j] = get(c, 'mass')/self.unit_mass
+        if any(n >= 2**32 for n in num):
+            raise ConceptGPUError('more than 2Â³Â² particles of one type: a snapshot of several '
+                                  'files, which is not written here')
+        for key, val in (header or {}).items():
+            simple = key.lower().replace(' ', '').replace('-', '').replace('_', '')
+            for k in hd:
+                if k.lower().replace('_', '') == simple:
+                    hd[k] = [type(x)(v) for v, x in zip(val, hd[k])] if isinstance(hd[k], list) \
+                        else type(hd[k])(val)
+                    break
+        self.header = hd
+        self.snapformat = snapformat
+        ntot = sum(num)
+        idbits = fmt['ID']
+        if idbits == 'automatic':
+            idbits = 64 if ntot > 2**32 else 32
+        for k, b in (('POS', fmt['POS']), ('VEL', fmt['VEL']), ('ID', idbits)):
+            if b not in (32, 64):
+                raise ConceptGPUError(f'Could not understand gadget_snapshot_params["dataformat"]'
+                                      f'[{k}] = {b}')
+
+        def arrays(c):
+            if isinstance(c, dict):
+                return c['pos'], c['mom'], c.get('ids')
+            ids = c.host('ids') if getattr(c, 'use_ids', False) else None
+            return c.host('pos'), c.host('mom'), ids
+        from . import comm
+        active = comm.active()
+        writer = active is None or active.rank == 0
+
+        def block_bgn(f, size, name):
+            if snapformat == 2:
+                f.write(struct.pack('<I4sII', 8, name.ljust(4).encode('ascii'), 4 + size + 4, 8))
+            f.write(struct.pack('<I', size))
+        data = [arrays(c) for c in comps]   # (collective on several domains)
+        if not writer:
+            return filename
+        os.makedirs(os.path.dirname(os.path.abspath(filename)) or '.', exist_ok=True)
+        with open(filename, 'wb') as f:
+            block_bgn(f, headersize, 'HEAD')
+            size = 0
+            for key, fm in header_fields:
+                v = hd[key] if isinstance(hd[key], list) else [hd[key]]
+                if fm.endswith('d'):
+                    v = [correct_float(x) for x in v]
+                b = struct.pack('<' + fm, *v)
+                f.write(b)
+                size += len(b)
+            f.write(b'\0'*(headersize - size))
+            f.write(struct.pack('<I', headersize))
+            for name, bits in (('POS', fmt['POS']), ('VEL', fmt['VEL'])):
+                size = ntot*3*(bits//8)
+                block_bgn(f, size, name)
+                for c, (pos, mom, ids) in zip(comps, data):
+                    if name == 'POS':
+                        unit = self.unit_length
+                        val = np.asarray(pos, dtype=np.float64).reshape(-1)*(1/unit)
+                        # safeguard against round-off: compared at the block's precision
+                        # (snapshot.py:1117-1118, 1378-1391)
+                        box = np.float32(boxsize/unit) if bits == 32 else np.float64(boxsize/unit)
+                        out = val.astype(np.float32 if bits == 32 else np.float64)
+                        hi = val >= np.float64(box)
+                        out[hi] = (val[hi] - np.float64(box)).astype(out.dtype)
+                    else:
+                        unit = self.unit_velocity*get(c, 'mass')*a**1.5
+                        val = np.asarray(mom, dtype=np.float64).reshape(-1)*(1/unit)
+                        out = val.astype(np.float32 if bits == 32 else np.float64)
+                    out.astype('<f4' if bits == 32 else '<f8').tofile(f)
+                f.write(struct.pack('<I', size))
+            size = ntot*(idbits//8)
+            block_bgn(f, size, 'ID')
+            id_base = 0
+            for c, (pos, mom, ids) in zip(comps, data):
+                n = int(get(c, 'N'))
+                if ids is None:  # running numbers, continued over the components
+                    ids = np.arange(id_base, id_base + n, dtype=np.uint64)
+                    id_base += n
+                np.asarray(ids).astype('<u4' if idbits == 32 else '<u8').tofile(f)
+            f.write(struct.pack('<I', size))
+        return filename
+
     def to_components(self, device=None):
         """GPU Components (concept_amd.species.Component) holding the loaded particles"""
         from .species import Component
@@ -279,3 +451,10 @@ def load(filename, only_params=False, params=None, units=None, rank=None, nprocs
     """snapshot.load (snapshot.py:3120-3230) for GADGET files; over several domains every rank
     reads its own share (see the module docstring)"""
     return GadgetSnapshot(params, units, rank, nprocs).load(filename, only_params)
+
+
+def save(components, filename, a=None, params=None, snapformat=2, dataformat=None, header=None,
+         units=None):
+    """snapshot.save (snapshot.py:3060-3118) for snapshot_type = 'gadget': one file"""
+    return GadgetSnapshot(None, units).save(components, filename, a, params, snapformat,
+                                            dataformat, header)

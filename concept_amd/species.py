@@ -78,6 +78,7 @@ class Component:
         self._store = None
         self.tile_mesh = None
         self.tiles_exact = False
+        self.use_ids = False  # identifiers are the running row numbers until some are populated
         if (N is None) == (gridsize is None):
             raise ConceptGPUError(
                 f'{self.name}: give N (particle component) or gridsize (fluid component)')
@@ -286,6 +287,7 @@ class Component:
             return
         if var == 'ids':
             self.ids.copy_(t)
+            self.use_ids = True   # (species.py:1253: identifiers given, not running numbers)
             return
         prefix, suffix = var[:-1], var[-1]
         getattr(self, prefix)[:, 'xyz'.index(suffix)] = t.to(self.device)
@@ -310,6 +312,7 @@ class Component:
         base = torch.arange(first, first + n, dtype=torch.int64, device=self.device)
         self.order.copy_(base)
         self.ids.copy_(base if ids is None else ids)
+        self.use_ids = ids is not None
         self._rows_known = True
         self.exchange()
 

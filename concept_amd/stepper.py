@@ -704,6 +704,38 @@ class Timeloop(RungStepper):
             if streaming:
                 self._rps = [c.to_regions(self._plan['mesh']) for c in self.components]
 
+    def snapshot_dumper(self, output_dir, output_base='snapshot', **save_options):
+        """An on_dump callback that writes a GADGET snapshot per dump time (main.dump,
+        main.py:1660-1760, for snapshots of snapshot_type = 'gadget'; concept_amd.snapshot.save)
+        named like the reference's — <output_dir>/<output_base>_<a|t>=<value> with just enough
+        digits that neighbouring dumps and the initial time differ (prepare_for_output,
+        main.py:2242-2278).  Usage: loop.on_dump = loop.snapshot_dumper('output/run')."""
+        from . import snapshot
+        p = self.params
+        fmts = {}
+        for kind, begin in (('a', self.cosmo.a), ('t', self.cosmo.t)):
+            times = sorted(set((begin,) + tuple(p.output_times[kind])))
+            if len(times) < 2 and not p.output_times[kind]:
+                continue
+            ndigits = 0
+            while True:
+                fmt = f'{{:.{ndigits}f}}'
+                if (len(set(fmt.format(ot) for ot in times)) == len(times)
+                        and (fmt.format(times[0]) != fmt.format(0) or not times[0])):
+                    break
+                ndigits += 1
+            fmts[kind] = ndigits
+        ndigits = max(fmts.values()) if fmts else 2
+        sep = '_' if output_base else ''
+        self.snapshots_written = []
+
+        def on_dump(loop, dump_time):
+            value = dump_time.a if dump_time.time_param == 'a' else dump_time.t
+            name = f'{output_dir}/{output_base}{sep}{dump_time.time_param}={value:.{ndigits}f}'
+            fn = snapshot.save(loop.components, name, a=loop.cosmo.a, **save_options)
+            loop.snapshots_written.append(fn)
+        return on_dump
+
     # -- main.timeloop (main.py:102-471) ---------------------------------------------------
     def run(self):
         try:

@@ -163,6 +163,11 @@ CASES = {
                           diff=2, gadget=dict(snapformat=2, bits=32, types=['halo'])),
     'gadget_sf1_64': dict(method='pm', n=4, gridsize=8, boxsize=48.0, seed=42, dist='clustered',
                           diff=2, gadget=dict(snapformat=1, bits=64, types=['disk'])),
+    # two components (running identifiers continue over them), POS in double and VEL in single
+    # precision, 64-bit identifiers: for the writer (snapshot.save)
+    'gadget_sf2_multi': dict(method='pm', n=4, gridsize=8, boxsize=40.0, seed=43, dist='uniform',
+                             diff=2, gadget=dict(snapformat=2, bits=64, vel_bits=32, id_bits=64,
+                                                 types=['halo', 'stars'])),
     'fluid2_pm_n6_g12': dict(method='pm', n=6, gridsize=12, boxsize=48.0, seed=22,
                              dist='clustered', diff=4, fluid=dict(gridsize=12, count=2),
                              particle_components=2),
@@ -591,7 +596,8 @@ enable_class_background = False
 select_forces = {{'all': {{'gravity': 'pm'}}}}
 snapshot_type = 'gadget'
 gadget_snapshot_params = {{'snapformat': {gd['snapformat']},
-                          'dataformat': {{'POS': {gd['bits']}, 'VEL': {gd['bits']}}}}}
+                          'dataformat': {{'POS': {gd['bits']}, 'VEL': {gd.get('vel_bits', gd['bits'])},
+                                         'ID': {gd.get('id_bits', 'automatic')!r}}}}}
 """
     work = f'/tmp/concept_golden_work/{name}'
     ref = load_reference(text, work)
@@ -621,7 +627,8 @@ gadget_snapshot_params = {{'snapformat': {gd['snapformat']},
     # must invert the writer's unit conversions, snapshot.py:1520-1553)
     probe = snapshot.GadgetSnapshot()
     probe.populate(comps, {})
-    out = dict(snapformat=gd['snapformat'], bits=gd['bits'], boxsize=L,
+    out = dict(snapformat=gd['snapformat'], bits=gd['bits'], vel_bits=gd.get('vel_bits', gd['bits']),
+               id_bits=gd.get('id_bits', 0), boxsize=L,
                a=commons.universals.a, H0=commons.H0, n_components=len(comps),
                unit_length=probe.unit_length, unit_velocity=probe.unit_velocity,
                unit_mass=probe.unit_mass, h=probe.h,

@@ -289,3 +289,38 @@ def test_streaming_loop_through_structure_formation():
     print(f'\nstructure formation run: {h0.shape[0]} steps, {passes} streaming passes, '
           f'{replays} replayed, mean |dx| between the two forms {d.mean()/L:.2e} L, max '
           f'{d.max()/L:.2e} L')
+
+
+def test_timeloop_writes_gadget_snapshots_at_the_dumps(golden, tmp_path):
+    """The reference's run writes a snapshot at every dump time (main.dump): here
+    Timeloop.snapshot_dumper → concept_amd.snapshot.save.  The files (double precision
+    payloads) read back hold the reference's dump positions to its own bar and the momenta of
+    the run; their names carry the dump's scale factor with the digits the reference's
+    prepare_for_output would use."""
+    import os
+    from concept_amd import snapshot, stepper
+    g = golden('traj_pm_n8_g8')
+    p, c = _component(g)
+    L = p.boxsize
+    loop = stepper.Timeloop([c])
+    loop.on_dump = loop.snapshot_dumper(str(tmp_path), dataformat={'POS': 64, 'VEL': 64})
+    loop.run()
+    files = loop.snapshots_written
+    assert len(files) == len(g['dump_a'])
+    # (a_begin = 0.02: two digits are needed for the initial time not to read 0.0)
+    assert [os.path.basename(f) for f in files] == [f'snapshot_a={a:.2f}' for a in g['dump_a']]
+    kick = np.abs(g['dump_mom'][-1] - g['mom_in']).max()
+    for i, fn in enumerate(files):
+        snap = snapshot.load(fn)
+        # (the header's Time went through commons.correct_float, as in the reference's writer)
+        assert snap.params['a'] == pytest.approx(g['dump_a'][i], rel=1e-14)
+        assert snap.params['boxsize'] == pytest.approx(L, rel=1e-14)
+        (comp,) = snap.components
+        assert comp['name'] == 'GADGET halo' and comp['N'] == int(g['N'])
+        assert comp['mass'] == pytest.approx(float(g['mass']), rel=1e-13)
+        assert _pos_err(comp['pos'], g['dump_pos'][i], L) <= 1e-10
+        assert np.abs(comp['mom'] - g['dump_mom'][i]).max() <= 1e-9*kick
+    # and a run can start from one of them (snapshot.to_components)
+    (restart,) = snapshot.load(files[0]).to_components()
+    assert restart.N == int(g['N'])
+    assert _pos_err(restart.host('pos'), g['dump_pos'][0], L) <= 1e-10
