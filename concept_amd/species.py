@@ -145,7 +145,8 @@ class Component:
         arrays are stale until from_regions()."""
         from .distributed import RegionParticles
         self.tile_sort(mesh)
-        return RegionParticles(self._store)
+        # identifiers that are the running row numbers equal `order`: one column travels
+        return RegionParticles(self._store, drop_order=not self.use_ids)
 
     def from_regions(self, rp, collective=True):
         """Take the particles back from their streaming form (pos, mom, ids, order; Δmom and
@@ -158,7 +159,9 @@ class Component:
         cols = rp.columns()
         old = self._store
         self._store = ParticleStore(old.mesh, cols['pos'], cols['mom'], None, slack=1.4,
-                                    extra={'ids': cols['ids'], 'order': cols['order']})
+                                    extra={'ids': cols['ids'],
+                                           'order': cols['order'] if 'order' in cols
+                                           else cols['ids'].clone()})
         for name in ('Δmom', 'rung_indices', 'rung_indices_jumped'):
             if name in old.cols:
                 t = old.cols[name]
