@@ -1092,6 +1092,13 @@ extern "C" int cg_apply_rung_jumps(cg_ctx *c, int8_t *rung, int8_t *rung_jumped,
     return cgk_apply_rung_jumps(c, (signed char *)rung, (signed char *)rung_jumped, n, N_rungs);
 }
 
+extern "C" int cg_rung_populations(cg_ctx *c, const int8_t *rung, int64_t n, int N_rungs,
+                                   int64_t *counts) {
+    CG_CHECK(c && counts && (rung || n == 0), "cg_rung_populations: null argument");
+    CG_CHECK(N_rungs >= 1 && N_rungs <= 64, "cg_rung_populations: N_rungs out of range");
+    return cgk_rung_populations(c, (const signed char *)rung, n, N_rungs, (long long *)counts);
+}
+
 extern "C" int cg_local_info(const cg_ctx *c, int64_t info[6]) {
     CG_CHECK(c && info, "cg_local_info: null argument");
     info[0] = c->xmap.x0;

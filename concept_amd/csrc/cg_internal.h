@@ -198,6 +198,7 @@ int cgk_flag_rung_jumps(cg_ctx *c, const double *dmom, const signed char *rung,
                         int *any_out);
 int cgk_apply_rung_jumps(cg_ctx *c, signed char *rung, signed char *rung_jumped, i64 n,
                          int N_rungs);
+int cgk_rung_populations(cg_ctx *c, const signed char *rung, i64 n, int N_rungs, long long *counts);
 bool cgk_fft_supported(i64 N);
 int cgk_fft_dist_forward(cg_ctx *c, double *send_buf, i64 layer0, i64 nlayers);
 int cgk_fft_dist_xsolve(cg_ctx *c, double *buf, int deconv_order, double C, int long_range,

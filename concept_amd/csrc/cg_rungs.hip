@@ -112,6 +112,42 @@ __global__ void k_apply_rung_jumps(i8 *__restrict__ rung, i8 *__restrict__ rung_
     rung_jumped[p] = (i8)r;
 }
 
+// set_rungs_N, species.py:2560-2587: how many particles sit on each rung.  Every thread takes 16
+// consecutive particles; per wave one ballot per rung and member, the counts gathered in LDS, one
+// atomic per rung and workgroup.
+__global__ __launch_bounds__(256) void k_rung_populations(const i8 *__restrict__ rung, i64 n,
+                                                          int N_rungs,
+                                                          unsigned long long *__restrict__ counts) {
+    __shared__ unsigned s_cnt[64];
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const i64 first = ((i64)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    unsigned mine[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) mine[k] = first + k < n ? (unsigned)(unsigned char)rung[first + k] : 255u;
+    for (int r = 0; r < N_rungs && r < 64; r++) {
+        unsigned c = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) c += (unsigned)__popcll(__ballot(mine[k] == (unsigned)r));
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt[r], c);
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)N_rungs && threadIdx.x < 64 && s_cnt[threadIdx.x])
+        atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+int cgk_rung_populations(cg_ctx *c, const i8 *rung, i64 n, int N_rungs, long long *counts) {
+    if (hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)N_rungs, c->stream) != hipSuccess) {
+        cg_set_error("cg_rung_populations: hipMemsetAsync failed");
+        return 1;
+    }
+    if (n == 0) return 0;
+    const i64 per = 256 * 16;
+    hipLaunchKernelGGL(k_rung_populations, dim3((unsigned)((n + per - 1) / per)), dim3(256), 0,
+                       c->stream, rung, n, N_rungs, (unsigned long long *)counts);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
 int cgk_dmom_active(cg_ctx *c, double *mom, double *dmom, const i8 *rung, i64 n, int lowest_active,
                     int op) {
     if (n == 0) return 0;

@@ -838,7 +838,17 @@ k_sr_sweep_cells(
     const unsigned rcell = ((unsigned)(2 * ta + wx) * nc + (unsigned)(2 * tb + wy)) * nc + 2 * tc;
     const unsigned rbeg = __builtin_amdgcn_readfirstlane(off_r[rcell]),
                    rend = __builtin_amdgcn_readfirstlane(off_r[rcell + 2]);
-    if (lane == 0) wave_any[wave] = rend - rbeg;
+    // receivers of this wave that take part: all of them, or — with rungs — those on an active
+    // rung.  A tile none of whose receivers is active returns before it stages anything: in a
+    // base step most sub-steps kick the highest rungs only (main.py:1347-1624 visits the tiles'
+    // active rungs only, species.py:439-847 tiles_rungs_N), a few per cent of the particles
+    unsigned mine = rend - rbeg;
+    if (P.rung && P.lowest_active > 0) {
+        unsigned act = 0;
+        for (unsigned q = rbeg + lane; q < rend; q += 64) act += P.rung[order_r[q]] >= P.lowest_active;
+        mine = (unsigned)__popcll(__ballot(act != 0));
+    }
+    if (lane == 0) wave_any[wave] = mine;
     // supplier pieces: column (cx, cy) of the 6 x 6 around the tile, cells 2 tc - 2 .. 2 tc + 3,
     // cut in two where the column wraps around the box in z
     if (tid < kSrPieces) {

@@ -462,9 +462,12 @@ class ParticleStore:
         if ride is not None:
             self.spare[ride], self.cols[ride] = self.cols[ride], self.spare[ride]
         elif others:
+            # gathered straight into the spare buffer, then the buffers trade places (no copy
+            # back: with the five columns of a rung run that was 0.3 ms per sort at 256^3)
             for name in others:
-                c = self.cols[name]
-                c[:n] = c[:n][i_out]
+                c, t = self.cols[name], self._spare(name)
+                torch.index_select(c[:n], 0, i_out, out=t[:n])
+                self.spare[name], self.cols[name] = c, t
         self.last_perm = i_out if (others and ride is None) else None
         self.sorted = True
 

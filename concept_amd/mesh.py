@@ -748,6 +748,13 @@ class PotentialMesh:
         self._check_rungs(n, rung, rung_jumped)
         check(_L.cg_apply_rung_jumps(self._ctx, _ptr(rung), _ptr(rung_jumped), n, int(N_rungs)))
 
+    def rung_populations(self, rung, N_rungs):
+        """int64 tensor [N_rungs]: the particles on each rung (set_rungs_N, species.py:2560-2587)"""
+        counts = torch.empty(int(N_rungs), dtype=torch.int64, device=self.device)
+        check(_L.cg_rung_populations(self._ctx, _ptr(rung), rung.numel(), int(N_rungs),
+                                     _ptr(counts)))
+        return counts
+
     # -- x-slab domains (multi-GPU) -------------------------------------------
     def layers_read(self, layer0, nlayers, dst):
         check(_L.cg_layers_read(self._ctx, int(layer0), int(nlayers), _ptr(dst)))

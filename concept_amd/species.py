@@ -504,7 +504,7 @@ class Component:
     def set_rungs_N(self):
         """species.py:2560-2587 (set_rungs_N + set_lowest_highest_populated_rung): the
         populations are global (allreduce over the domains, species.py:2571)"""
-        counts = torch.bincount(self.rung_indices.long(), minlength=self.N_rungs).cpu()
+        counts = self._mesh().rung_populations(self.rung_indices, self.N_rungs).cpu()
         if self.comm is not None and self.nprocs > 1:
             counts = self.comm.all_gather_ints(counts[:self.N_rungs].tolist()).sum(0)
         counts = counts.tolist()

@@ -353,7 +353,9 @@ int cg_shortrange_sweep_cells_rungs(cg_ctx *ctx, const double *pos_r_sorted,
  *                       get_rung_factor(dt, fac_softening) (species.py:2376-2400)
  *   cg_flag_rung_jumps  Component.flag_rung_jumps()       species.py:2463-2513, integrals_1 =
  *                       dt_rungs['1'] (DEV), *any_out (DEV int32) != 0 iff a jump was flagged
- *   cg_apply_rung_jumps Component.apply_rung_jumps()      species.py:2526-2549 */
+ *   cg_apply_rung_jumps Component.apply_rung_jumps()      species.py:2526-2549
+ *   cg_rung_populations Component.set_rungs_N()           species.py:2560-2587, counts[N_rungs]
+ *                       (DEV int64): the particles on each rung of this rank */
 int cg_dmom_nullify(cg_ctx *ctx, double *dmom, const int8_t *rung, int64_t n,
                     int lowest_active_rung);
 int cg_dmom_apply(cg_ctx *ctx, double *mom, const double *dmom, const int8_t *rung, int64_t n,
@@ -368,6 +370,7 @@ int cg_flag_rung_jumps(cg_ctx *ctx, const double *acc, const int8_t *rung, int8_
                        double rung_factor_up, double rung_factor_down, int N_rungs,
                        int32_t *any_out);
 int cg_apply_rung_jumps(cg_ctx *ctx, int8_t *rung, int8_t *rung_jumped, int64_t n, int N_rungs);
+int cg_rung_populations(cg_ctx *ctx, const int8_t *rung, int64_t n, int N_rungs, int64_t *counts);
 
 /* --- multi-GPU: x-slab domains ----------------------------------------------
  * One context per GPU with params.nprocs = P, rank = r, subdiv = (P,1,1):

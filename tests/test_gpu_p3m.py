@@ -569,3 +569,18 @@ def test_shortrange_pre32_variant_vs_oracle():
     p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, CONCEPT_GPU_SR_PRE32='1'),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert p.returncode == 0 and b'PRE32-OK' in p.stdout, p.stdout.decode()[-3000:]
+
+
+@pytest.mark.parametrize('n,N_rungs', [(0, 8), (5, 8), (4096, 1), (1000003, 8), (300007, 10)])
+def test_rung_populations(n, N_rungs):
+    """cg_rung_populations (Component.set_rungs_N, species.py:2560-2587) against numpy.bincount;
+    empty and ragged lengths, one rung only, more rungs than the default"""
+    import torch
+    from concept_amd.mesh import PotentialMesh
+    mesh = PotentialMesh(16, 16.0)
+    rng = np.random.default_rng(n + N_rungs)
+    # (most particles on the low rungs, as in a run)
+    r = np.minimum(rng.geometric(0.5, n) - 1, N_rungs - 1).astype(np.int8)
+    got = mesh.rung_populations(torch.as_tensor(r, device='cuda'), N_rungs).cpu().numpy()
+    assert got.dtype == np.int64 and got.shape == (N_rungs,)
+    assert np.array_equal(got, np.bincount(r.astype(np.int64), minlength=N_rungs))
