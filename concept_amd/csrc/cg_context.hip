@@ -428,6 +428,7 @@ extern "C" int cg_destroy(cg_ctx *c) {
     (void)hipFree(c->tile_count);
     (void)hipFree(c->tile_cursor);
     (void)hipFree(c->err_flags);
+    (void)hipFree(c->sr_tile_active);
     (void)hipFree(c->scan_tmp);
     (void)hipFree(c->sr_tmp);
     for (int i = 0; i < 3; i++) {

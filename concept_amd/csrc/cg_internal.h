@@ -125,6 +125,8 @@ struct cg_ctx {
     // in turn), created at the first sweep
     hipStream_t sr_streams[3] = {nullptr, nullptr, nullptr};
     hipEvent_t sr_fork = nullptr, sr_join[3] = {nullptr, nullptr, nullptr};
+    unsigned char *sr_tile_active = nullptr;  // cells sweep with rungs: one byte per tile
+    size_t sr_tile_active_cap = 0;
     hipEvent_t *pass_events = nullptr;  // when set: 6 events recorded around the 5 passes
     // particle sort scratch (owned, grown on demand)
     TileGeom tiles{};

@@ -143,6 +143,9 @@ struct SrParams {
     const signed char *rung, *rung_jumped;
     int lowest_active;
     float r2_pre;  // single-precision pre-test: a pair with |x_ji|^2 (float) above this is a miss
+    // cells sweep with rungs: one byte per tile, non-zero where a receiver of the tile sits on an
+    // active rung (k_sr_tile_activity; null = every tile takes part)
+    const unsigned char *tile_active;
 };
 
 // The pair tests of one staged supplier chunk for this lane's receiver: branch-free (a miss adds
@@ -790,6 +793,26 @@ __device__ __forceinline__ SrChunk sr_chunk_load(unsigned base, unsigned rend, i
     return c;
 }
 
+// One thread per tile: does any of its receivers (the 2 x 2 columns of 2 cells each) sit on an
+// active rung?
+__global__ __launch_bounds__(256) void k_sr_tile_activity(const unsigned *__restrict__ order_r,
+                                                          const unsigned *__restrict__ off_r,
+                                                          const signed char *__restrict__ rung,
+                                                          int lowest_active, int nt,
+                                                          unsigned char *__restrict__ tile_active) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned ntiles = (unsigned)nt * nt * nt;
+    if (t >= ntiles) return;
+    const unsigned tc = t % nt, tb = (t / nt) % nt, ta = t / ((unsigned)nt * nt), nc = 2u * nt;
+    bool any = false;
+    for (unsigned w = 0; w < 4 && !any; w++) {
+        const unsigned cell = ((2 * ta + (w >> 1)) * nc + (2 * tb + (w & 1))) * nc + 2 * tc;
+        for (unsigned q = off_r[cell], e = off_r[cell + 2]; q < e && !any; q++)
+            any = rung[order_r[q]] >= lowest_active;
+    }
+    tile_active[t] = any ? 1 : 0;
+}
+
 // FACE: the tiles on a face of the box, whose suppliers include periodic images.  Same sweep;
 // every staged supplier carries the offset of its image ((xi - xj) + offset in the reference's
 // order, gravity.py:299-302; + 0.0 for the others changes nothing), so a receiver's five
@@ -830,6 +853,10 @@ k_sr_sweep_cells(
         tc = tc ? nt - 1 : 0;
         ta++, tb++;
     }
+    // With rungs, most sub-steps of a base step kick the highest rungs only (main.py:1347-1624
+    // visits the tiles' active rungs only, species.py tiles_rungs_N): a tile none of whose
+    // receivers is active is gone after one byte
+    if (P.tile_active && !P.tile_active[((unsigned)ta * nt + (unsigned)tb) * nt + (unsigned)tc]) return;
     const double ext = P.boxsize / (double)nt;  // tile extent
     const double ox0 = ta * ext, oy0 = tb * ext, oz0 = tc * ext;  // the tile's lower corner
     // receivers of this wave: cell column (2 ta + wx, 2 tb + wy), cells 2 tc and 2 tc + 1
@@ -838,17 +865,7 @@ k_sr_sweep_cells(
     const unsigned rcell = ((unsigned)(2 * ta + wx) * nc + (unsigned)(2 * tb + wy)) * nc + 2 * tc;
     const unsigned rbeg = __builtin_amdgcn_readfirstlane(off_r[rcell]),
                    rend = __builtin_amdgcn_readfirstlane(off_r[rcell + 2]);
-    // receivers of this wave that take part: all of them, or — with rungs — those on an active
-    // rung.  A tile none of whose receivers is active returns before it stages anything: in a
-    // base step most sub-steps kick the highest rungs only (main.py:1347-1624 visits the tiles'
-    // active rungs only, species.py:439-847 tiles_rungs_N), a few per cent of the particles
-    unsigned mine = rend - rbeg;
-    if (P.rung && P.lowest_active > 0) {
-        unsigned act = 0;
-        for (unsigned q = rbeg + lane; q < rend; q += 64) act += P.rung[order_r[q]] >= P.lowest_active;
-        mine = (unsigned)__popcll(__ballot(act != 0));
-    }
-    if (lane == 0) wave_any[wave] = mine;
+    if (lane == 0) wave_any[wave] = rend - rbeg;
     // supplier pieces: column (cx, cy) of the 6 x 6 around the tile, cells 2 tc - 2 .. 2 tc + 3,
     // cut in two where the column wraps around the box in z
     if (tid < kSrPieces) {
@@ -1033,7 +1050,23 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                                const double *factors, const signed char *rung,
                                const signed char *rung_jumped, int lowest_active) {
     SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt, 0,
-               factors,      rung,             rung_jumped, lowest_active, 0.0f};
+               factors,      rung,             rung_jumped, lowest_active, 0.0f, nullptr};
+    if (rung && lowest_active > 0) {
+        // which tiles have a receiver on an active rung (the others leave at once)
+        const size_t ntl = (size_t)nt * nt * nt;
+        if (c->sr_tile_active_cap < ntl) {
+            (void)hipFree(c->sr_tile_active);
+            c->sr_tile_active = nullptr;
+            c->sr_tile_active_cap = 0;
+            CG_HIP(hipMalloc((void **)&c->sr_tile_active, ntl));
+            c->sr_tile_active_cap = ntl;
+        }
+        hipLaunchKernelGGL(k_sr_tile_activity, dim3((unsigned)((ntl + 255) / 256)), dim3(256), 0,
+                           c->stream, order_r, off_r, rung, lowest_active, (int)nt,
+                           c->sr_tile_active);
+        CG_LAUNCH_CHECK();
+        P.tile_active = c->sr_tile_active;
+    }
     // The single-precision pre-test's threshold: coordinates relative to the tile's corner are
     // below 3.5 tile extents E in size, a float carries them to 2^-24 relative, a difference of
     // two to 2 * 3.5 E * 2^-24, and |x|^2 near r^2_max moves by at most

@@ -239,6 +239,11 @@ class RungStepper:
         if t_start == t_end:
             return
         ᔑdt = self.integrals(t_start, t_end)
+        for c in self.components:
+            # the sub-steps of driftkick_short drift without sorting (one domain): the mesh
+            # kernels want tile order — once per base step, not once per sub-step
+            if c.representation == 'particles' and not c.tiles_exact and c._store is not None:
+                c.tile_sort()
         for force, method, receivers, suppliers in interactions.find_interactions(
                 self.components, 'long-range'):
             getattr(interactions, force)(method, receivers, suppliers, ᔑdt, 'long-range', False)
@@ -315,7 +320,13 @@ class RungStepper:
             if t_end > t_start:
                 ᔑdt = self.integrals(t_start, t_end)
                 for c in comps:
-                    c.drift_sort(ᔑdt)
+                    # (one domain: nothing to exchange, and the short-range cell list does not
+                    # need the mesh-tile order — kick_long sorts once before the mesh kernels;
+                    # several domains: the fused drift + exchange + sort)
+                    if c.nprocs == 1:
+                        c.drift(ᔑdt)
+                    else:
+                        c.drift_sort(ᔑdt)
                     c.lowest_active_rung = max(lowest_active_rung, c.lowest_populated_rung)
             highest_populated_rung = max(c.highest_populated_rung for c in comps)
             for rung_index in range(lowest_active_rung, highest_populated_rung + 1):
