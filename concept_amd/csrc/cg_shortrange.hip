@@ -765,30 +765,73 @@ struct SrChunk {
     unsigned pi;
     double xi, yi, zi, factor;
 };
+// (RUNGS: the instantiation for particles on adaptive rungs — the plain sweep carries none of it:
+// with the packing below in one kernel the single-rung sweep measured 7.84 against 7.62 ms)
+template <bool RUNGS>
 __device__ __forceinline__ SrChunk sr_chunk_load(unsigned base, unsigned rend, int lane,
                                                  const double *__restrict__ pos_r,
                                                  const unsigned *__restrict__ order_r,
                                                  const SrParams &P) {
     SrChunk c;
+    c.pi = 0;
+    c.factor = P.factor;
+    c.xi = c.yi = c.zi = 0;
+    const unsigned cand = min(64u, rend - base);  // this chunk's rows of the sorted order
+    unsigned qi = base;
+    if (RUNGS && P.lowest_active > 0) {
+        // With rungs only the receivers on an active rung take part (gravity.py:318-349 through
+        // the tiles' active rungs): they are packed to the front — lane l of the active ones
+        // hands its row to lane rank(l) — so that R counts them alone and every one of them
+        // gets 64 / R lanes (a sub-step for the upper rungs kicks a third of a tile's
+        // particles or fewer)
+        unsigned pi = 0;
+        bool act = false;
+        if ((unsigned)lane < cand) {
+            pi = order_r[base + lane];
+            act = P.rung[pi] >= P.lowest_active;
+        }
+        const unsigned long long mask = __ballot(act);
+        const int R = __builtin_amdgcn_readfirstlane(__popcll(mask));
+        if (R == 0) {
+            c.R = 1, c.S = 1, c.sub = lane, c.rl = 0, c.active = false;
+            return c;
+        }
+        const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        // (an inactive lane parks its row at lane 63, which no active lane targets unless all
+        // 64 are active — and then nobody is inactive)
+        const int target = act ? rank : 63;
+        const int q_packed = __builtin_amdgcn_ds_permute(4 * target, (int)(base + lane));
+        const int p_packed = __builtin_amdgcn_ds_permute(4 * target, (int)pi);
+        c.R = R;
+        c.S = min(64 / R, 32);
+        c.sub = lane / R;
+        c.rl = lane - c.sub * R;
+        c.active = c.sub < c.S;
+        qi = (unsigned)__shfl(q_packed, c.rl);
+        c.pi = (unsigned)__shfl(p_packed, c.rl);
+        if (c.active) {
+            c.xi = pos_r[3 * (i64)qi];
+            c.yi = pos_r[3 * (i64)qi + 1];
+            c.zi = pos_r[3 * (i64)qi + 2];
+            c.factor = P.factors[P.rung_jumped[c.pi]];
+        } else {
+            c.pi = 0;
+        }
+        return c;
+    }
     // wave-uniform by construction; tell the compiler (scalar registers, scalar loops)
-    c.R = __builtin_amdgcn_readfirstlane((int)min(64u, rend - base));
+    c.R = __builtin_amdgcn_readfirstlane((int)cand);
     c.S = min(64 / c.R, 32);
     c.sub = lane / c.R;
     c.rl = lane - c.sub * c.R;
     c.active = c.sub < c.S;
-    const unsigned qi = base + c.rl;  // receiver's row in the sorted order
-    c.pi = 0;
-    c.factor = P.factor;
-    c.xi = c.yi = c.zi = 0;
+    qi = base + c.rl;  // receiver's row in the sorted order
     if (c.active) {
         c.pi = order_r[qi];
         c.xi = pos_r[3 * (i64)qi];
         c.yi = pos_r[3 * (i64)qi + 1];
         c.zi = pos_r[3 * (i64)qi + 2];
-        if (P.rung) {
-            if (P.rung[c.pi] < P.lowest_active) c.active = false;
-            else c.factor = P.factors[P.rung_jumped[c.pi]];
-        }
+        if (RUNGS) c.factor = P.factors[P.rung_jumped[c.pi]];  // (every rung is active)
     }
     return c;
 }
@@ -818,7 +861,7 @@ __global__ __launch_bounds__(256) void k_sr_tile_activity(const unsigned *__rest
 // order, gravity.py:299-302; + 0.0 for the others changes nothing), so a receiver's five
 // columns stay ONE range there too.  (Walking such tiles piece by piece — 10 short ranges per x
 // with a wave-uniform offset each — made these 6 % of the tiles 16 % of the sweep.)
-template <bool FACE, bool PRE32>
+template <bool FACE, bool PRE32, bool RUNGS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CG_SR_WAVES, 8))) void
 k_sr_sweep_cells(
     const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
@@ -856,7 +899,7 @@ k_sr_sweep_cells(
     // With rungs, most sub-steps of a base step kick the highest rungs only (main.py:1347-1624
     // visits the tiles' active rungs only, species.py tiles_rungs_N): a tile none of whose
     // receivers is active is gone after one byte
-    if (P.tile_active && !P.tile_active[((unsigned)ta * nt + (unsigned)tb) * nt + (unsigned)tc]) return;
+    if (RUNGS && P.tile_active && !P.tile_active[((unsigned)ta * nt + (unsigned)tb) * nt + (unsigned)tc]) return;
     const double ext = P.boxsize / (double)nt;  // tile extent
     const double ox0 = ta * ext, oy0 = tb * ext, oz0 = tc * ext;  // the tile's lower corner
     // receivers of this wave: cell column (2 ta + wx, 2 tb + wy), cells 2 tc and 2 tc + 1
@@ -904,7 +947,7 @@ k_sr_sweep_cells(
     SrChunk ch = {};
     double d0 = 0, d1 = 0, d2 = 0;
     if (rend > rbeg) {
-        ch = sr_chunk_load(rbeg, rend, lane, pos_r, order_r, P);
+        ch = sr_chunk_load<RUNGS>(rbeg, rend, lane, pos_r, order_r, P);
         if (ch.active && ch.sub == 0) {
             d0 = dmom_r[3 * (i64)ch.pi];
             d1 = dmom_r[3 * (i64)ch.pi + 1];
@@ -984,7 +1027,7 @@ k_sr_sweep_cells(
         }
         __syncthreads();
         for (unsigned base = rbeg; base < rend; base += 64) {
-            if (base != rbeg || w0) ch = sr_chunk_load(base, rend, lane, pos_r, order_r, P);
+            if (base != rbeg || w0) ch = sr_chunk_load<RUNGS>(base, rend, lane, pos_r, order_r, P);
             const int R = ch.R, S = ch.S, sub = ch.sub;
             const bool active = ch.active;
             if (!__any(active)) continue;
@@ -1096,26 +1139,20 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
     }
     CG_HIP(hipEventRecord(c->sr_fork, c->stream));
     const dim3 slabs[3] = {dim3(n, n, 2), dim3(n, 2, m), dim3(2, m, m)};
+    const bool rungs = rung != nullptr;
+    auto face = pre32 ? (rungs ? k_sr_sweep_cells<true, true, true> : k_sr_sweep_cells<true, true, false>)
+                      : (rungs ? k_sr_sweep_cells<true, false, true> : k_sr_sweep_cells<true, false, false>);
+    auto inner = pre32 ? (rungs ? k_sr_sweep_cells<false, true, true> : k_sr_sweep_cells<false, true, false>)
+                       : (rungs ? k_sr_sweep_cells<false, false, true> : k_sr_sweep_cells<false, false, false>);
     for (int slab = 0; slab < 3; slab++) {
         CG_HIP(hipStreamWaitEvent(c->sr_streams[slab], c->sr_fork, 0));
-        if (pre32)
-            hipLaunchKernelGGL((k_sr_sweep_cells<true, true>), slabs[slab], dim3(256), 0,
-                               c->sr_streams[slab], pos_r_sorted, order_r, off_r, dmom_r,
-                               pos_s_sorted, off_s, table, P, slab);
-        else
-            hipLaunchKernelGGL((k_sr_sweep_cells<true, false>), slabs[slab], dim3(256), 0,
-                               c->sr_streams[slab], pos_r_sorted, order_r, off_r, dmom_r,
-                               pos_s_sorted, off_s, table, P, slab);
+        hipLaunchKernelGGL(face, slabs[slab], dim3(256), 0, c->sr_streams[slab], pos_r_sorted,
+                           order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P, slab);
         CG_LAUNCH_CHECK();
         CG_HIP(hipEventRecord(c->sr_join[slab], c->sr_streams[slab]));
     }
-    if (pre32)
-        hipLaunchKernelGGL((k_sr_sweep_cells<false, true>), dim3(m, m, m), dim3(256), 0, c->stream,
-                           pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P, 0);
-    else
-        hipLaunchKernelGGL((k_sr_sweep_cells<false, false>), dim3(m, m, m), dim3(256), 0,
-                           c->stream, pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s,
-                           table, P, 0);
+    hipLaunchKernelGGL(inner, dim3(m, m, m), dim3(256), 0, c->stream, pos_r_sorted, order_r, off_r,
+                       dmom_r, pos_s_sorted, off_s, table, P, 0);
     CG_LAUNCH_CHECK();
     for (int slab = 0; slab < 3; slab++) CG_HIP(hipStreamWaitEvent(c->stream, c->sr_join[slab], 0));
     return 0;
