@@ -429,6 +429,7 @@ extern "C" int cg_destroy(cg_ctx *c) {
     (void)hipFree(c->tile_cursor);
     (void)hipFree(c->err_flags);
     (void)hipFree(c->sr_tile_active);
+    (void)hipFree(c->sr_sparse_partial);
     (void)hipFree(c->scan_tmp);
     (void)hipFree(c->sr_tmp);
     for (int i = 0; i < 3; i++) {
@@ -1091,6 +1092,24 @@ extern "C" int cg_apply_rung_jumps(cg_ctx *c, int8_t *rung, int8_t *rung_jumped,
                                    int N_rungs) {
     CG_CHECK(c && ((rung && rung_jumped) || n == 0), "cg_apply_rung_jumps: null argument");
     return cgk_apply_rung_jumps(c, (signed char *)rung, (signed char *)rung_jumped, n, N_rungs);
+}
+
+extern "C" int cg_shortrange_sparse(cg_ctx *c, const double *pos_r, const int64_t *active, int k,
+                                   double *dmom_r, const double *pos_s, int64_t n_s,
+                                   const double *table, int64_t tablesize,
+                                   double r2_index_scaling, double r2_max, double factor,
+                                   const double *factors, const int8_t *rung_jumped) {
+    CG_CHECK(c && pos_r && active && dmom_r && table && (pos_s || n_s == 0),
+             "cg_shortrange_sparse: null argument");
+    CG_CHECK(tablesize >= 2 && (double)(tablesize - 1) >= r2_max * r2_index_scaling,
+             "cg_shortrange_sparse: table too short for r2_max * r2_index_scaling");
+    CG_CHECK((factors == nullptr) == (rung_jumped == nullptr),
+             "cg_shortrange_sparse: factors and rung_jumped go together");
+    CG_CHECK(16 * r2_max <= c->p.boxsize * c->p.boxsize,
+             "cg_shortrange_sparse: the range must stay below a quarter of the box");
+    return cgk_shortrange_sparse(c, pos_r, (const i64 *)active, k, dmom_r, pos_s, n_s, table,
+                                 r2_index_scaling, r2_max, factor, factors,
+                                 (const signed char *)rung_jumped);
 }
 
 extern "C" int cg_rung_populations(cg_ctx *c, const int8_t *rung, int64_t n, int N_rungs,

@@ -126,6 +126,7 @@ struct cg_ctx {
     hipStream_t sr_streams[3] = {nullptr, nullptr, nullptr};
     hipEvent_t sr_fork = nullptr, sr_join[3] = {nullptr, nullptr, nullptr};
     unsigned char *sr_tile_active = nullptr;  // cells sweep with rungs: one byte per tile
+    double *sr_sparse_partial = nullptr;      // cg_shortrange_sparse: per-workgroup partial sums
     size_t sr_tile_active_cap = 0;
     hipEvent_t *pass_events = nullptr;  // when set: 6 events recorded around the 5 passes
     // particle sort scratch (owned, grown on demand)
@@ -181,6 +182,10 @@ int cgk_shortrange_sweep(cg_ctx *c, const double *pos_r, const unsigned *order_r
                          const signed char *rung_jumped, int lowest_active);
 int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
                          unsigned *order, unsigned *offset, double *pos_sorted);
+int cgk_shortrange_sparse(cg_ctx *c, const double *pos_r, const i64 *active, int K, double *dmom_r,
+                          const double *pos_s, i64 n_s, const double *table,
+                          double r2_index_scaling, double r2_max, double factor,
+                          const double *factors, const signed char *rung_jumped);
 int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
                                const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
                                const unsigned *off_s, i64 nt, const double *table,

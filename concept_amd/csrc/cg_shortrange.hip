@@ -1086,6 +1086,108 @@ k_sr_sweep_cells(
     }
 }
 
+// ===========================================================================
+// A handful of active receivers (the top rungs of a base step's sub-steps: sixteen of the 32
+// sub-steps of a run with six rungs kick the few particles of the highest one): no cell list at
+// all.  Every workgroup takes a slice of the suppliers, tests each against the K <= 8 receivers
+// (nearest periodic image: (xi - xj) + offset with offset = -L, 0 or +L, the same operations as
+// the tile offsets of interactions.py:1615-1621 give for a range below a quarter of the box) with
+// the sweep's pair arithmetic, and reduces its sums in a fixed tree; a second kernel adds the
+// slices' partials in order and applies the receiver's rung factor.  Bit-reproducible; equal to
+// the cells sweep up to the order of the additions.
+// ===========================================================================
+constexpr int kSrSparseMax = 8, kSrSparseBlocks = 1024;
+__global__ __launch_bounds__(256) void k_sr_sparse(const double *__restrict__ pos_r,
+                                                   const i64 *__restrict__ active, int K,
+                                                   const double *__restrict__ pos_s, i64 n_s,
+                                                   const double *__restrict__ table,
+                                                   SrParams P, double *__restrict__ partial) {
+    __shared__ double rx[kSrSparseMax], ry[kSrSparseMax], rz[kSrSparseMax];
+    __shared__ double red[4][3 * kSrSparseMax];
+    if (threadIdx.x < (unsigned)K) {
+        const i64 i = active[threadIdx.x];
+        rx[threadIdx.x] = pos_r[3 * i];
+        ry[threadIdx.x] = pos_r[3 * i + 1];
+        rz[threadIdx.x] = pos_r[3 * i + 2];
+    }
+    __syncthreads();
+    const i64 per = (n_s + gridDim.x - 1) / gridDim.x;
+    const i64 lo = (i64)blockIdx.x * per, hi = lo + per < n_s ? lo + per : n_s;
+    const double L = P.boxsize, half = 0.5 * L;
+    double acc[kSrSparseMax][3] = {};
+    for (i64 j = lo + threadIdx.x; j < hi; j += 256) {
+        const double sx = pos_s[3 * j], sy = pos_s[3 * j + 1], sz = pos_s[3 * j + 2];
+#pragma unroll
+        for (int r = 0; r < kSrSparseMax; r++) {
+            if (r >= K) break;
+            double x = rx[r] - sx, y = ry[r] - sy, z = rz[r] - sz;   // interactions.py:1787-1789
+            x = x + (x > half ? -L : (x < -half ? L : 0.0));       // + the image's offset
+            y = y + (y > half ? -L : (y < -half ? L : 0.0));
+            z = z + (z > half ? -L : (z < -half ? L : 0.0));
+            const double r2 = x * x + y * y + z * z;               // gravity.py:306
+            if (r2 <= P.r2_max) {                                   // gravity.py:311
+                const double t = table[(unsigned)(int)(r2 * P.r2_index_scaling)];
+                acc[r][0] = __builtin_fma(x, t, acc[r][0]);
+                acc[r][1] = __builtin_fma(y, t, acc[r][1]);
+                acc[r][2] = __builtin_fma(z, t, acc[r][2]);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < kSrSparseMax; r++) {
+        if (r >= K) break;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            double v = acc[r][d];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0) red[wave][3 * r + d] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)(3 * K)) {
+        const int e = threadIdx.x;
+        partial[(i64)e * gridDim.x + blockIdx.x] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    }
+}
+__global__ __launch_bounds__(64) void k_sr_sparse_final(const double *__restrict__ partial, int nb,
+                                                        const i64 *__restrict__ active, int K,
+                                                        SrParams P, double *__restrict__ dmom_r) {
+    // one wave: lane e < 3K adds the nb partials of its entry in index order
+    const int e = threadIdx.x;
+    if (e >= 3 * K) return;
+    double sum = 0;
+    for (int b = 0; b < nb; b++) sum += partial[(i64)e * nb + b];
+    const i64 i = active[e / 3];
+    const double factor = P.rung ? P.factors[P.rung_jumped[i]] : P.factor;
+    dmom_r[3 * i + e % 3] += sum * factor;   // gravity.py:321-349 (factors[rung] * x * f)
+}
+int cgk_shortrange_sparse(cg_ctx *c, const double *pos_r, const i64 *active, int K, double *dmom_r,
+                          const double *pos_s, i64 n_s, const double *table,
+                          double r2_index_scaling, double r2_max, double factor,
+                          const double *factors, const signed char *rung_jumped) {
+    if (K < 1 || K > kSrSparseMax) {
+        cg_set_error("cg_shortrange_sparse: %d active receivers (1..%d)", K, kSrSparseMax);
+        return 1;
+    }
+    if (n_s == 0) return 0;
+    SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, 0, 0,
+               factors,      rung_jumped /* non-null = rungs in use */, rung_jumped, 0, 0.0f, nullptr};
+    if (!factors) P.rung = nullptr;
+    if (!c->sr_sparse_partial)
+        CG_HIP(hipMalloc((void **)&c->sr_sparse_partial,
+                         sizeof(double) * 3 * kSrSparseMax * kSrSparseBlocks));
+    i64 nbl = (n_s + 255) / 256;
+    const int nb = (int)(nbl < kSrSparseBlocks ? nbl : kSrSparseBlocks);
+    hipLaunchKernelGGL(k_sr_sparse, dim3(nb), dim3(256), 0, c->stream, pos_r, active, K, pos_s, n_s,
+                       table, P, c->sr_sparse_partial);
+    CG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sr_sparse_final, dim3(1), dim3(64), 0, c->stream, c->sr_sparse_partial, nb,
+                       active, K, P, dmom_r);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
 int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
                                const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
                                const unsigned *off_s, i64 nt, const double *table,

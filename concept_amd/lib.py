@@ -98,6 +98,8 @@ SYMBOLS = {
     'cg_flag_rung_jumps': (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp, _dbl, _dbl, _int, _vp]),
     'cg_apply_rung_jumps': (_int, [_vp, _vp, _vp, _i64, _int]),
     'cg_rung_populations': (_int, [_vp, _vp, _i64, _int, _vp]),
+    'cg_shortrange_sparse': (_int, [_vp, _vp, _vp, _int, _vp, _vp, _i64, _vp, _i64, _dbl, _dbl, _dbl,
+                             _vp, _vp]),
     'cg_local_info': (_int, [_vp, ctypes.POINTER(ctypes.c_int64*6)]),
     'cg_layers_read': (_int, [_vp, _i64, _i64, _vp]),
     'cg_layers_write': (_int, [_vp, _i64, _i64, _vp, _int]),

@@ -701,6 +701,25 @@ class PotentialMesh:
             _ptr(off_s), int(nt), _ptr(table), table.numel(), float(r2_index_scaling),
             float(r2_max), _ptr(factors), _ptr(rung), _ptr(rung_jumped), int(lowest)))
 
+    SHORTRANGE_SPARSE_MAX = 8
+
+    def shortrange_sparse(self, pos_r, active, dmom_r, pos_s, table, r2_index_scaling, r2_max,
+                          factor, rungs=None):
+        """The short-range sums of the receivers in rows `active` (int64 CUDA tensor, at most
+        SHORTRANGE_SPARSE_MAX of them) against all suppliers, without a cell list
+        (cg_shortrange_sparse).  rungs: (factors, rung_jumped) or None with `factor`."""
+        self._check_particles(pos_r, dmom_r)
+        self._check_particles(pos_s)
+        k = active.numel()
+        if active.dtype != torch.int64 or not active.is_cuda:
+            raise lib.ConceptGPUError('active rows must be an int64 CUDA tensor')
+        factors, rung_jumped = rungs if rungs is not None else (None, None)
+        check(_L.cg_shortrange_sparse(
+            self._ctx, _ptr(pos_r), _ptr(active), int(k), _ptr(dmom_r), _ptr(pos_s),
+            pos_s.shape[0], _ptr(table), table.numel(), float(r2_index_scaling), float(r2_max),
+            float(factor), _ptr(factors) if factors is not None else None,
+            _ptr(rung_jumped) if rung_jumped is not None else None))
+
     # -- A16: momentum buffers and adaptive rungs -------------------------------------
     @staticmethod
     def _check_rungs(n, *arrays):

@@ -88,6 +88,9 @@ def _pair_integrals(ᔑdt_rungs, rec, sup):
     return integrals
 
 
+sparse_sweeps = 0   # sweeps taken without a cell list (a handful of active receivers)
+
+
 def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
     """Short-range gravity of every (receiver, supplier) component pair, accumulated
     into the components' Δmom buffers (the caller applies them, main.py:1253-1262)."""
@@ -124,18 +127,40 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
         slack = max(c._store.mesh.boxsize/c._store.mesh.gridsize for c in involved)
         for c in involved:
             check_shortrange_fits(c._store.mesh, sr['range'] + slack)
+    def get_cells(c):
+        """the component's cell list (built when a sweep first asks for it: a sub-step that
+        kicks a handful of particles needs none, see sweep() below)"""
+        if id(c) not in cells:
+            cells[id(c)] = mesh.shortrange_cells(c.pos, nt, tile_extent)
+            supp_cells.setdefault(id(c), cells[id(c)])
+        return cells[id(c)]
     for c in involved:
-        cells[id(c)] = mesh.shortrange_cells(c.pos, nt, tile_extent)
-        supp_pos[id(c)], supp_cells[id(c)] = c.pos, cells[id(c)]
+        supp_pos[id(c)] = c.pos
         # every involved component can act as supplier: s of sweep(r, s), and r of the
         # reciprocal sweep(s, r) when s is also a receiver
         if multi:
+            get_cells(c)
             ghosts = ship_boundary_positions(c._store.mesh, c.pos,
                                              sr['range']*(1 + 1e-9) + slack + 1e-9*p.boxsize)
             # rows 0..N_local-1 ARE the component's own particles (the sweep's `same`
             # convention), the ghosts follow
             supp_pos[id(c)] = torch.cat([c.pos] + list(ghosts)).contiguous()
             supp_cells[id(c)] = mesh.shortrange_cells(supp_pos[id(c)], nt, tile_extent)
+
+    def active_rows(rec):
+        """rows of the receiver's particles on active rungs when they are few (one domain:
+        rungs_N counts them without looking), else None"""
+        if multi or not rec.use_rungs or rec.lowest_active_rung <= 0:
+            return None
+        n_active = sum(rec.rungs_N[rec.lowest_active_rung:])
+        if n_active > mesh.SHORTRANGE_SPARSE_MAX:
+            return None
+        key_ = (id(rec), rec.lowest_active_rung)
+        if key_ not in sparse_rows:
+            sparse_rows[key_] = torch.nonzero(
+                rec.rung_indices >= rec.lowest_active_rung).flatten()
+        return sparse_rows[key_]
+    sparse_rows = {}
     key = 'a**(-3*w_eff₀-3*w_eff₁-1)'
     done = set()
     for r in receivers:
@@ -157,13 +182,28 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
                 if rec.use_rungs:
                     factors = torch.tensor(p.G_Newton*rec.mass*sup.mass*integrals,
                                            dtype=torch.float64, device=rec.device)
+                    rows = active_rows(rec)
+                    if rows is not None:
+                        # the sub-steps for the highest rungs (main.py:1347-1624): a handful
+                        # of receivers against all suppliers, no cell list
+                        global sparse_sweeps
+                        sparse_sweeps += 1
+                        if rows.numel():
+                            mesh.shortrange_sparse(rec.pos, rows, rec.Δmom, supp_pos[id(sup)],
+                                                   table, scaling, r2_max, 0.0,
+                                                   (factors, rec.rung_indices_jumped))
+                        return
                     rungs = (factors, rec.rung_indices, rec.rung_indices_jumped,
                              rec.lowest_active_rung)
-                    mesh.shortrange_sweep_cells(cells[id(rec)], rec.Δmom, supp_cells[id(sup)],
-                                                nt, table, scaling, r2_max, 0.0, rungs)
+                    rc = get_cells(rec)
+                    get_cells(sup)
+                    mesh.shortrange_sweep_cells(rc, rec.Δmom, supp_cells[id(sup)], nt, table,
+                                                scaling, r2_max, 0.0, rungs)
                 else:
+                    rc = get_cells(rec)
+                    get_cells(sup)
                     mesh.shortrange_sweep_cells(
-                        cells[id(rec)], rec.Δmom, supp_cells[id(sup)], nt, table, scaling,
+                        rc, rec.Δmom, supp_cells[id(sup)], nt, table, scaling,
                         r2_max, p.G_Newton*rec.mass*sup.mass*float(integrals[0]))
             sweep(r, s, same)
             if not same and s in receivers:

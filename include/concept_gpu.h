@@ -341,6 +341,18 @@ int cg_shortrange_sweep_cells_rungs(cg_ctx *ctx, const double *pos_r_sorted,
                                     const int8_t *rung_r /*DEV*/,
                                     const int8_t *rung_jumped_r /*DEV*/, int lowest_active_rung);
 
+/* The same sums for k <= 8 receivers (rows active[0..k) of pos_r / dmom_r) against ALL n_s
+ * suppliers, without a cell list: the sub-steps of driftkick_short (main.py:1347-1624) that kick
+ * only the few particles of the highest rungs.  Nearest periodic image; the range must stay
+ * below a quarter of the box (it does: >= 4 tiles of at least the range, species.py:3971).
+ * factors / rung_jumped as in cg_shortrange_sweep_cells_rungs, or both null with `factor`. */
+int cg_shortrange_sparse(cg_ctx *ctx, const double *pos_r /*DEV*/, const int64_t *active /*DEV k*/,
+                         int k, double *dmom_r /*DEV, accumulated*/, const double *pos_s /*DEV*/,
+                         int64_t n_s, const double *table /*DEV*/, int64_t tablesize,
+                         double r2_index_scaling, double r2_max, double factor,
+                         const double *factors /*DEV or null*/,
+                         const int8_t *rung_jumped_r /*DEV or null*/);
+
 /* --- A16: momentum buffers and adaptive rungs --------------------------------
  * rung / rung_jumped are the reference's `signed char` arrays (species.py:2040-2064);
  * a jumped index is rung + N_rungs (down) or rung + 2*N_rungs (up).  rung = NULL means

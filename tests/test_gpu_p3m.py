@@ -584,3 +584,70 @@ def test_rung_populations(n, N_rungs):
     got = mesh.rung_populations(torch.as_tensor(r, device='cuda'), N_rungs).cpu().numpy()
     assert got.dtype == np.int64 and got.shape == (N_rungs,)
     assert np.array_equal(got, np.bincount(r.astype(np.int64), minlength=N_rungs))
+
+
+@pytest.mark.parametrize('k', [1, 3, 8])
+def test_sparse_shortrange_equals_the_cells_sweep(k):
+    """cg_shortrange_sparse (a handful of receivers on the top rungs against all suppliers, no
+    cell list, nearest periodic image) against the cells sweep restricted to the same active
+    rungs: the same sums up to the order of the additions; receivers chosen in dense spots and
+    next to the box faces and corners (periodic images in one, two and three dimensions), a
+    receiver and a supplier component that differ, momentum buffers accumulated not
+    overwritten."""
+    import torch
+    from concept_amd import commons, shortrange
+    from concept_amd.mesh import PotentialMesh
+    N, L = 64, 64.0
+    mesh = PotentialMesh(N, L)
+    rng = np.random.default_rng(70 + k)
+    n_r, n_s = 20000, 30011
+    pos_r = rng.uniform(0, L, (n_r, 3))
+    pos_s = rng.uniform(0, L, (n_s, 3))
+    # the active receivers: box corner, an edge, a face, a clump of suppliers, the rest anywhere
+    special = np.array([[1e-9, L - 1e-9, 0.3], [L - 0.2, 0.1, 31.0], [12.0, 40.0, L - 1e-7],
+                        [20.0, 20.0, 20.0]])
+    pos_s[:2000] = 20.0 + rng.normal(0, 0.4, (2000, 3))
+    active = rng.choice(n_r, k, replace=False)
+    pos_r[active[:min(k, 4)]] = special[:min(k, 4)]
+    pos_r_t = torch.as_tensor(pos_r, device='cuda')
+    pos_s_t = torch.as_tensor(np.mod(pos_s, L), device='cuda')
+    scale = 1.25*L/N
+    rng_ = 4.5*scale
+    nt = int(L/rng_*(1 + commons.machine_ϵ))
+    table, maxr2 = shortrange.get_shortrange_table(0.03*L/27, scale, rng_, 4096, 'spline',
+                                                   pos_r_t.device)
+    N_rungs = 8
+    rung = np.zeros(n_r, dtype=np.int8)
+    rung[active] = rng.integers(5, 8, k)
+    jumped = rung.copy()
+    jumped[active[0]] = rung[active[0]] + N_rungs      # flagged to jump up: another factor
+    factors = torch.as_tensor(rng.uniform(0.5, 2.0, 3*N_rungs - 1), device='cuda')
+    rung_t, jumped_t = torch.as_tensor(rung, device='cuda'), torch.as_tensor(jumped, device='cuda')
+    base = torch.as_tensor(rng.normal(0, 1e-3, (n_r, 3)), device='cuda')
+    # the cells sweep, rungs >= 5 active
+    ref = base.clone()
+    cr = mesh.shortrange_cells(pos_r_t, nt, L/nt)
+    cs = mesh.shortrange_cells(pos_s_t, nt, L/nt)
+    mesh.shortrange_sweep_cells(cr, ref, cs, nt, table, 4095/maxr2, rng_**2, 0.0,
+                                (factors, rung_t, jumped_t, 5))
+    got = base.clone()
+    rows = torch.nonzero(rung_t >= 5).flatten()
+    assert rows.numel() == k
+    mesh.shortrange_sparse(pos_r_t, rows, got, pos_s_t, table, 4095/maxr2, rng_**2, 0.0,
+                           (factors, jumped_t))
+    kick = (ref - base).abs().max()
+    assert float(kick) > 0
+    assert float((got - ref).abs().max()) <= 1e-12*float(kick)
+    others = torch.ones(n_r, dtype=torch.bool, device='cuda')
+    others[rows] = False
+    assert bool((got[others] == base[others]).all())   # nobody else was touched
+    # without rungs: one factor for all
+    ref2, got2 = torch.zeros_like(base), torch.zeros_like(base)
+    mesh.shortrange_sweep_cells(cr, ref2, cs, nt, table, 4095/maxr2, rng_**2, 1.7)
+    mesh.shortrange_sparse(pos_r_t, rows, got2, pos_s_t, table, 4095/maxr2, rng_**2, 1.7)
+    assert float((got2[rows] - ref2[rows]).abs().max()) <= 1e-12*float(ref2[rows].abs().max())
+    from concept_amd.lib import ConceptGPUError
+    with pytest.raises(ConceptGPUError, match='active receivers'):
+        mesh.shortrange_sparse(pos_r_t, torch.arange(9, device='cuda'), got2, pos_s_t, table,
+                               4095/maxr2, rng_**2, 1.0)
+    mesh.close()

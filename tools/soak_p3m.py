@@ -38,6 +38,8 @@ wall = time.perf_counter() - t0
 d = np.diff(np.array(stamps))
 print(f'a 0.02 -> {loop.cosmo.a}: {loop.time_step} base steps in {wall:.1f} s; s per step: first 5 '
       + ' '.join(f'{v:.2f}' for v in d[:5]) + ' | last 5 ' + ' '.join(f'{v:.2f}' for v in d[-5:]))
+from concept_amd import shortrange  # noqa: E402
+print('sweeps without a cell list:', shortrange.sparse_sweeps)
 pops = torch.bincount(c.rung_indices.long(), minlength=8).tolist()
 print('rung populations at the end:', pops)
 assert c.N_local == n
