@@ -245,3 +245,13 @@ def test_parameter_file_forward_references_and_skipped_path_parameters():
         warnings.simplefilter('always')
         p = commons.load_params("boxsize = 3*_never_defined\nN_rungs = 4\n")
     assert p.N_rungs == 4 and any('boxsize' in str(x.message) for x in w)
+
+
+def test_library_is_built_from_the_sources_in_the_tree():
+    """libconcept_gpu.so.srchash (written by concept_amd.build) names the sources the library was
+    built from: a library older than an edit of csrc/ would run — and be profiled — as something
+    the tree no longer describes (bench.py quotes the committed counter run only for a matching
+    hash).  __graft_entry__.build() rebuilds a stale library; this catches one that was not."""
+    from concept_amd import build
+    built = open(build.LIB + '.srchash').read().strip()
+    assert built == build.source_hash(), 'run `python -m concept_amd.build`'

@@ -7,6 +7,7 @@ TAG=${1:-r03}; COMMIT=${2:-unknown}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_new; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+(cd $R && python -m concept_amd.build > /dev/null 2>&1)  # (a library older than csrc/ would be profiled under the wrong hash)
 CMD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
 # 1. per-kernel statistics of the default command
 rocprofv3 --kernel-trace --stats -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
