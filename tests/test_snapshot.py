@@ -148,3 +148,15 @@ def test_gadget_writer_round_trip_and_options(golden, tmp_path):
                       str(tmp_path/'c'))
     with pytest.raises(ConceptGPUError, match='snapformat'):
         snapshot.save([comp], str(tmp_path/'d'), snapformat=3)
+
+
+def test_correct_float():
+    """commons.correct_float (commons.py:5356-5388) as the writer applies it to the header's
+    doubles: the example of its docstring, values that must stay as they are, containers"""
+    from concept_amd.snapshot import correct_float
+    assert correct_float(1.234499999999998) == 1.2345
+    assert correct_float(33599.99999999999) == 33600.0
+    assert correct_float(0.1 + 0.2) == 0.3
+    for v in (0.0, 1.0, 0.7, 1e-300, 0.6666666666666666, 3.141592653589793, 2.0**0.5, -1.5):
+        assert correct_float(v) == v, v
+    assert correct_float(np.float64(0.30000000000000004)) == 0.3
