@@ -10,7 +10,9 @@ HEAD block (header_fields, snapshot.py:658-689), the POS / VEL / ID blocks with 
     mom = VEL * unit_velocity * mass * Time**1.5  (GADGET stores u = a dx/dt / sqrt(a))
     mass = Massarr[type] * unit_mass
 with the default GADGET units 'kpc/h', 'km/s', '10¹⁰ m☉/h' (commons.py:2787-2804).
-Only single-file snapshots with per-type masses in the header; anything else aborts by name.
+Snapshots of one file or split over several (<base>.0, <base>.1, ...: named by their directory,
+their first file or a pattern, snapshot.py:1821-1925); per-type masses in the header (a MASS
+block with individual masses aborts by name).
 Host-side I/O: numpy only; `to_components()` uploads to GPU Components.
 
 Over several domains (comm.init) every rank reads ITS SHARE of every component — the rows
@@ -174,107 +176,173 @@ class GadgetSnapshot:
         return header, nxt
 
     # -- load ------------------------------------------------------------------
-    def load(self, filename, only_params=False):
-        if not os.path.isfile(filename):
+    def _files(self, filename):
+        """The files of the snapshot `filename` names (snapshot.py:1821-1858): the file itself;
+        or, for a directory, a name ending in '.0' or in '*', the sequence <base>.0, <base>.1,
+        ... as far as it exists."""
+        def is_gadget(fn):
+            try:
+                with open(fn, 'rb') as f:
+                    return self.get_snapformat(f) in (1, 2)
+            except OSError:
+                return False
+        if os.path.isfile(filename) and not filename.endswith(('*', '.0')):
+            return [filename]
+        if os.path.isdir(filename):
+            import glob
+            firsts = [fn for fn in sorted(glob.glob(f'{filename}/*.0')) if is_gadget(fn)]
+            if len(firsts) != 1:
+                msg = ', '.join(f'"{fn}"' for fn in firsts)
+                raise ConceptGPUError(f'Found several candidates for the first {self.name} '
+                                      f'snapshot file: {msg}' if firsts else
+                                      f'Could not locate {self.name} snapshot "{filename}"')
+            filename = firsts[0]
+        base = filename[:-2] if filename.endswith('.0') else filename
+        base = base.rstrip('.*')
+        files = []
+        while os.path.isfile(f'{base}.{len(files)}') and is_gadget(f'{base}.{len(files)}'):
+            files.append(f'{base}.{len(files)}')
+        if not files:
             raise ConceptGPUError(f'Could not locate {self.name} snapshot "{filename}"')
-        self.filename = filename
-        p = self.p
-        with open(filename, 'rb') as f:
-            self.snapformat = self.get_snapformat(f)
-            if self.snapformat not in (1, 2):
-                raise ConceptGPUError(f'Could not determine GADGET SnapFormat of "{filename}"')
-            header, offset = self.read_header(f)
-            self.header = header
-            if header['NumFiles'] > 1:
-                raise ConceptGPUError(f'{filename}: snapshots split over {header["NumFiles"]} '
-                                      'files are not read (single-file snapshots only)')
-            h = header['HubbleParam']
-            if h == 0:
-                raise ConceptGPUError(f'{filename}: HubbleParam = 0 in the header')
-            self.h = h
-            self.unit_length = _unit(self.unit_expr['length'], h, p)
-            self.unit_velocity = _unit(self.unit_expr['velocity'], h, p)
-            self.unit_mass = _unit(self.unit_expr['mass'], h, p)
-            u = p.units
-            self.params = {'H0': h*(100*u.km/(u.s*u.Mpc)), 'a': header['Time'],
-                           'boxsize': header['BoxSize']*self.unit_length,
-                           'Ωm': header['Omega0'], 'ΩΛ': header['OmegaLambda']}
-            npart = [int(n) for n in header['Npart']]
-            for j, n in enumerate(npart):
-                tot = header['Nall'][j] + 2**32*header['NallHW'][j]
-                if tot not in (n, 0):
-                    raise ConceptGPUError(
-                        f'{filename}: Nall = {tot} but Npart = {n} for "{component_names[j]}"')
-            ntot = sum(npart)
-            self.components = []
-            for j, n in enumerate(npart):
-                if n == 0:
-                    continue
-                mass = header['Massarr'][j]
-                if mass <= 0:
-                    raise ConceptGPUError(
-                        f'Mass of "{component_names[j]}" particles is {mass}×10¹⁰ h⁻¹ m☉ '
-                        '(individual particle masses, block MASS, are not read)')
-                start_local, n_local = partition(n, self.rank, self.nprocs)
-                self.components.append({'name': component_names[j], 'species': 'matter', 'N': n,
-                                        'mass': mass*self.unit_mass, 'pos': None, 'mom': None,
-                                        'ids': None, 'start_local': start_local,
-                                        'N_local': n_local})
-            if only_params:
-                return self
-            boxsize = self.params['boxsize']
-            order = ['POS', 'VEL', 'ID']  # SnapFormat 1: blocks are identified by position
-            seen = 0
-            while True:
-                blk = self._block(f, offset)
-                if blk is None:
-                    break
-                payload, size, name, offset = blk
-                if self.snapformat == 1:
-                    if seen >= len(order):
-                        break
-                    name = order[seen]
-                seen += 1
-                if name not in ('POS', 'VEL', 'ID'):
-                    continue  # Skipping block (e.g. MASS, U)
-                if ntot == 0 or size % ntot:
-                    raise ConceptGPUError(
-                        f'File {filename} contains {ntot} particles but its "{name}" block has '
-                        f'a size of {size} bytes, which does not divide the particle number.')
-                per = size//ntot
+        return files
 
-                def rows(c, first, dtype, width):
-                    """rows [start_local, start_local + N_local) of component c, whose rows
-                    begin at row `first` of the block"""
-                    f.seek(payload + (first + c['start_local'])*per)
-                    return np.fromfile(f, dtype=dtype, count=width*c['N_local'])
-                if name in ('POS', 'VEL'):
-                    if per not in (12, 24):
-                        raise ConceptGPUError(f'No data format with a size of {per//3} bytes '
-                                              f'implemented for block "{name}"')
-                    start = 0
-                    for c in self.components:
-                        part = rows(c, start, '<f4' if per == 12 else '<f8', 3)
-                        part = part.astype(np.float64).reshape(c['N_local'], 3)
-                        start += c['N']
-                        if name == 'POS':
-                            pos = part*self.unit_length
-                            pos[pos >= boxsize] -= boxsize  # round-off safeguard
-                            c['pos'] = np.ascontiguousarray(pos)
-                        else:
-                            unit = self.unit_velocity*c['mass']*header['Time']**1.5
-                            c['mom'] = np.ascontiguousarray(part*unit)
+    def load(self, filename, only_params=False):
+        files = self._files(filename)
+        self.filename = filename = files[0]
+        p = self.p
+        # the header of every file (snapshot.py:1880-1925): the first one counts, the others
+        # contribute their Npart
+        npart_files, offsets = [], []
+        for i, fn in enumerate(files):
+            with open(fn, 'rb') as f:
+                if i == 0:
+                    self.snapformat = self.get_snapformat(f)
+                    if self.snapformat not in (1, 2):
+                        raise ConceptGPUError(
+                            f'Could not determine GADGET SnapFormat of "{filename}"')
+                header_i, offset_i = self.read_header(f)
+            if i == 0:
+                header = self.header = header_i
+                num_files = max(int(header['NumFiles']), 1)
+                if num_files > len(files):
+                    msg = (f'Could only locate {len(files)} of the supposed {num_files} files '
+                           'making up the snapshot.')
+                    if not filename.endswith('.0'):
+                        msg += f' Is "{filename}" not the first file of the snapshot?'
+                    raise ConceptGPUError(msg)
+                files = files[:num_files]   # (more files than the header counts: ignored)
+            elif i >= len(files):
+                break
+            npart_files.append([int(n) for n in header_i['Npart']])
+            offsets.append(offset_i)
+        npart_files = npart_files[:len(files)]
+        h = header['HubbleParam']
+        if h == 0:
+            raise ConceptGPUError(f'{filename}: HubbleParam = 0 in the header')
+        self.h = h
+        self.unit_length = _unit(self.unit_expr['length'], h, p)
+        self.unit_velocity = _unit(self.unit_expr['velocity'], h, p)
+        self.unit_mass = _unit(self.unit_expr['mass'], h, p)
+        u = p.units
+        self.params = {'H0': h*(100*u.km/(u.s*u.Mpc)), 'a': header['Time'],
+                       'boxsize': header['BoxSize']*self.unit_length,
+                       'Ωm': header['Omega0'], 'ΩΛ': header['OmegaLambda']}
+        npart = [sum(nf[j] for nf in npart_files) for j in range(num_particle_types)]
+        # Nall + 2³² NallHW must agree with the files' Npart — in the standard convention or in
+        # N-GenIC's, which keeps the high word of type 1 in Nall[2] (snapshot.py:1931-1952)
+        nall, nhw = list(header['Nall']), list(header['NallHW'])
+        alt_nall, alt_nhw = list(nall), list(nhw)
+        alt_nhw[1], alt_nall[2] = alt_nall[2], 0
+        if not any(all(a_ + 2**32*w_ in (n, 0) for a_, w_, n in zip(A, W, npart))
+                   for A, W in ((nall, nhw), (alt_nall, alt_nhw))):
+            raise ConceptGPUError(
+                f'{filename}: inconsistent particle counts in the header: Nall = {nall}, '
+                f'NallHW = {nhw}, while Npart summed over the files is {npart}')
+        self.components = []
+        for j, n in enumerate(npart):
+            if n == 0:
+                continue
+            mass = header['Massarr'][j]
+            if mass <= 0:
+                raise ConceptGPUError(
+                    f'Mass of "{component_names[j]}" particles is {mass}×10¹⁰ h⁻¹ m☉ '
+                    '(individual particle masses, block MASS, are not read)')
+            start_local, n_local = partition(n, self.rank, self.nprocs)
+            self.components.append({'name': component_names[j], 'species': 'matter', 'N': n,
+                                    'mass': mass*self.unit_mass, 'pos': None, 'mom': None,
+                                    'ids': None, 'start_local': start_local,
+                                    'N_local': n_local, 'type': j})
+        if only_params:
+            return self
+        boxsize = self.params['boxsize']
+        raw = {}   # (component index, block) -> this rank's rows, in file order
+        done = [0]*num_particle_types   # rows of each type in the files before this one
+        for fn, npf, offset in zip(files, npart_files, offsets):
+            ntot = sum(npf)
+            with open(fn, 'rb') as f:
+                order = ['POS', 'VEL', 'ID']  # SnapFormat 1: blocks are identified by position
+                seen = 0
+                while ntot:
+                    blk = self._block(f, offset)
+                    if blk is None:
+                        break
+                    payload, size, name, offset = blk
+                    if self.snapformat == 1:
+                        if seen >= len(order):
+                            break
+                        name = order[seen]
+                    seen += 1
+                    if name not in ('POS', 'VEL', 'ID'):
+                        continue  # Skipping block (e.g. MASS, U)
+                    if size % ntot:
+                        raise ConceptGPUError(
+                            f'File {fn} contains {ntot} particles but its "{name}" block has '
+                            f'a size of {size} bytes, which does not divide the particle number.')
+                    per = size//ntot
+                    if name == 'ID':
+                        if per not in (4, 8):
+                            raise ConceptGPUError(f'ID block with {per} bytes per particle')
+                        dtype, width = ('<u4' if per == 4 else '<u8'), 1
+                    else:
+                        if per not in (12, 24):
+                            raise ConceptGPUError(f'No data format with a size of {per//3} bytes '
+                                                  f'implemented for block "{name}"')
+                        dtype, width = ('<f4' if per == 12 else '<f8'), 3
+                    for ci, c in enumerate(self.components):
+                        j = c['type']
+                        # this file holds rows [g0, g1) of the component; mine are [lo, hi)
+                        g0, g1 = done[j], done[j] + npf[j]
+                        lo, hi = max(g0, c['start_local']), min(g1, c['start_local'] + c['N_local'])
+                        if hi <= lo:
+                            continue
+                        first = sum(npf[:j]) + (lo - g0)   # row of the block
+                        f.seek(payload + first*per)
+                        part = np.fromfile(f, dtype=dtype, count=width*(hi - lo))
+                        raw.setdefault((ci, name), []).append(part)
+            for j in range(num_particle_types):
+                done[j] += npf[j]
+        for ci, c in enumerate(self.components):
+            for name, key in (('POS', 'pos'), ('VEL', 'mom'), ('ID', 'ids')):
+                parts = raw.get((ci, name))
+                if parts is None:
+                    if c['N_local'] == 0 and name != 'ID':
+                        c[key] = np.zeros((0, 3))
+                        continue
+                    if name == 'ID':
+                        continue
+                    raise ConceptGPUError(f'Could not find required block "{name}"')
+                data = np.concatenate(parts) if len(parts) > 1 else parts[0]
+                if name == 'ID':
+                    c['ids'] = data.astype(np.int64)
+                    continue
+                part = data.astype(np.float64).reshape(c['N_local'], 3)
+                if name == 'POS':
+                    pos = part*self.unit_length
+                    pos[pos >= boxsize] -= boxsize  # round-off safeguard
+                    c['pos'] = np.ascontiguousarray(pos)
                 else:
-                    if per not in (4, 8):
-                        raise ConceptGPUError(f'ID block with {per} bytes per particle')
-                    start = 0
-                    for c in self.components:
-                        c['ids'] = rows(c, start, '<u4' if per == 4 else '<u8', 1).astype(np.int64)
-                        start += c['N']
-            for c in self.components:
-                for blockname, key in (('POS', 'pos'), ('VEL', 'mom')):
-                    if c[key] is None:
-                        raise ConceptGPUError(f'Could not find required block "{blockname}"')
+                    unit = self.unit_velocity*c['mass']*header['Time']**1.5
+                    c['mom'] = np.ascontiguousarray(part*unit)
         return self
 
     # -- save ------------------------------------------------------------------

@@ -165,6 +165,11 @@ CASES = {
                           diff=2, gadget=dict(snapformat=1, bits=64, types=['disk'])),
     # two components (running identifiers continue over them), POS in double and VEL in single
     # precision, 64-bit identifiers: for the writer (snapshot.save)
+    # a snapshot split over several files (gadget_snapshot_params['particles per file']): two
+    # components, 100 + 100 particles, at most 70 per file -> three files; for the reader
+    'gadget_files3': dict(method='pm', n=5, gridsize=8, boxsize=56.0, seed=44, dist='uniform',
+                          diff=2, gadget=dict(snapformat=2, bits=64, id_bits=32, per_file=70,
+                                              types=['halo', 'bndry'], n_each=100)),
     'gadget_sf2_multi': dict(method='pm', n=4, gridsize=8, boxsize=40.0, seed=43, dist='uniform',
                              diff=2, gadget=dict(snapformat=2, bits=64, vel_bits=32, id_bits=64,
                                                  types=['halo', 'stars'])),
@@ -597,7 +602,8 @@ select_forces = {{'all': {{'gravity': 'pm'}}}}
 snapshot_type = 'gadget'
 gadget_snapshot_params = {{'snapformat': {gd['snapformat']},
                           'dataformat': {{'POS': {gd['bits']}, 'VEL': {gd.get('vel_bits', gd['bits'])},
-                                         'ID': {gd.get('id_bits', 'automatic')!r}}}}}
+                                         'ID': {gd.get('id_bits', 'automatic')!r}}},
+                          'particles per file': {gd.get('per_file', 'automatic')!r}}}
 """
     work = f'/tmp/concept_golden_work/{name}'
     ref = load_reference(text, work)
@@ -606,6 +612,8 @@ gadget_snapshot_params = {{'snapformat': {gd['snapformat']},
     L = commons.boxsize
     rng = np.random.default_rng(1000 + cfg['seed'])
     pos_all = make_positions(np, cfg)
+    if gd.get('n_each'):
+        pos_all = np.random.default_rng(cfg['seed']).uniform(0, L, (gd['n_each']*len(gd['types']), 3))
     per = pos_all.shape[0]//len(gd['types'])
     comps = []
     for i, typ in enumerate(gd['types']):
@@ -621,7 +629,12 @@ gadget_snapshot_params = {{'snapformat': {gd['snapformat']},
     originals = [(c.name, int(c.N), float(c.mass), np.array(c.pos_mv3[:c.N]).copy(),
                   np.array(c.mom_mv3[:c.N]).copy()) for c in comps]
     fn = snapshot.save(comps, f'{work}/out/snap', save_all=True)
-    shutil.copyfile(fn, os.path.join(HERE, name + '.gadget'))
+    if os.path.isdir(fn):   # several files: the directory as it is
+        dst = os.path.join(HERE, name + '.gadget')
+        shutil.rmtree(dst, ignore_errors=True)
+        shutil.copytree(fn, dst)
+    else:
+        shutil.copyfile(fn, os.path.join(HERE, name + '.gadget'))
     # (the reference's GADGET *loader* does not fill the particle arrays in pure-Python
     # mode, so the expected values are what its writer was given: the reader under test
     # must invert the writer's unit conversions, snapshot.py:1520-1553)
@@ -639,7 +652,9 @@ gadget_snapshot_params = {{'snapformat': {gd['snapformat']},
         out[f'c{i}_pos'] = pos
         out[f'c{i}_mom'] = mom
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
-    print('wrote', name, os.path.getsize(os.path.join(HERE, name + '.gadget')), 'bytes;',
+    print('wrote', name, (sorted(os.listdir(os.path.join(HERE, name + '.gadget')))
+                         if os.path.isdir(os.path.join(HERE, name + '.gadget'))
+                         else os.path.getsize(os.path.join(HERE, name + '.gadget'))), 'bytes;',
           {k: getattr(v, 'shape', v) for k, v in out.items()})
 
 
