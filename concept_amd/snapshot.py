@@ -424,6 +424,12 @@ class GadgetSnapshot:
                 raise ConceptGPUError(f'Could not understand gadget_snapshot_params["dataformat"]'
                                       f'[{k}] = {b}')
 
+        for k, b in (('POS', 3*fmt['POS']//8), ('VEL', 3*fmt['VEL']//8), ('ID', idbits//8)):
+            if ntot*b >= 2**32:
+                raise ConceptGPUError(
+                    f'block "{k}" of {ntot} particles takes {ntot*b} bytes, more than the 32-bit '
+                    'block size of the format holds: such a snapshot is split over several files '
+                    "(gadget_snapshot_params['particles per file']), which is not written here")
         def arrays(c):
             if isinstance(c, dict):
                 return c['pos'], c['mom'], c.get('ids')
