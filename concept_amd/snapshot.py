@@ -21,7 +21,7 @@ byte ranges of the POS / VEL / ID blocks that hold them, as the reference's load
 (snapshot.py:2066-2330) — and `to_components()` hands them to Component.populate_local(), whose
 exchange() re-homes them to the slabs that own them: no rank ever holds the whole file.
 
-`save()` writes the same format (the writer of snapshot.py:880-1420 for one file): HEAD block as
+`save()` writes the same format (the writer of snapshot.py:880-1512, one file or several): HEAD block as
 `populate()` builds it (snapshot.py:2462-2560), then POS / VEL / ID with the reference's
 conversion — value*(1/unit) (the reciprocal is formed first, snapshot.py:1375-1392), positions
 that reach the box size in file units after the conversion wrapped by one box, the result cast
@@ -89,6 +89,57 @@ def correct_float(val_raw):
             val_correct = val_new
         val_new = float(np.nextafter(val_new, np.inf))
     return val_correct if len(str(val_correct)) < len(str(val_raw)) - 2 else val_raw
+
+
+def divvy(num_particles, file_max):
+    """GadgetSnapshot.divvy (snapshot.py:1424-1512): how many particles of each component go to
+    each file of a snapshot whose files hold at most `file_max` particles — the number of files
+    from filling them to the brim, then the particles spread evenly over that many files, the
+    fuller files (and those with more particles of the lower types) first."""
+    num_particles = [int(n) for n in num_particles]
+    tot = sum(num_particles)
+
+    def fill(file_max):
+        num_files = tot//file_max + 1
+        common = [max(n//num_files, 1) for n in num_particles]
+        remaining = list(num_particles)
+        files = []
+        while sum(remaining) > 0:
+            row = []
+            for j, c in enumerate(common):
+                c = min(c, remaining[j])
+                row.append(c)
+                remaining[j] -= c
+            files.append(row)
+        i_left, i_right = 0, len(files) - 1
+        while i_left != i_right:
+            left = files[i_left]
+            n_left = sum(left)
+            if n_left == file_max:
+                i_left += 1
+                continue
+            right = files[i_right]
+            for j, move in enumerate(list(right)):
+                if move + n_left > file_max:
+                    move = file_max - n_left
+                right[j] -= move
+                left[j] += move
+                n_left += move
+            if sum(right) == 0:
+                i_right -= 1
+        for i in range(len(files) - 1, 0, -1):
+            if sum(files[i]) > 0:
+                break
+            files.pop()
+        return files
+    num_files = len(fill(file_max))
+    even = tot//num_files
+    even += (even*num_files < tot)
+    files = fill(even)
+    files.sort(key=lambda row: (sum(row), row), reverse=True)
+    if len(files) != num_files or sum(map(sum, files)) != tot or max(map(sum, files)) > file_max:
+        raise ConceptGPUError('Something went wrong divvying up the particles')
+    return files
 
 
 class GadgetSnapshot:
@@ -347,7 +398,7 @@ class GadgetSnapshot:
 
     # -- save ------------------------------------------------------------------
     def save(self, components, filename, a=None, params=None, snapformat=2, dataformat=None,
-             header=None):
+             header=None, particles_per_file='automatic'):
         """One-file GADGET snapshot of particle components.  components: Components (or the
         dicts load() makes) whose names are GADGET type names ('GADGET halo', ...); a single
         matter / cold dark matter component of another name is written as the halo type
@@ -355,7 +406,10 @@ class GadgetSnapshot:
         boxsize, Ωm, ΩΛ (snapshot.py:2517-2527); dataformat: bits of 'POS', 'VEL' (32 | 64) and
         'ID' (32 | 64 | 'automatic'); header: fields to overwrite (gadget_snapshot_params
         ['header']).  On several domains the particles are gathered (Component.host) and rank 0
-        writes.  Returns the file name."""
+        writes.  particles_per_file: gadget_snapshot_params['particles per file'] — 'automatic':
+        as many as the format's 32-bit block size holds (snapshot.py:706-732); a snapshot that
+        needs several files becomes the directory `filename` with snapshot.0, snapshot.1, ...
+        (snapshot.py:1310-1323).  Returns the file (or directory) name."""
         p = self.p
         params = dict(params or {})
         fmt = {'POS': 32, 'VEL': 32, 'ID': 'automatic'}
@@ -403,9 +457,6 @@ class GadgetSnapshot:
         for j, c in enumerate(slots):
             if c is not None:
                 hd['Massarr'][j] = get(c, 'mass')/self.unit_mass
-        if any(n >= 2**32 for n in num):
-            raise ConceptGPUError('more than 2³² particles of one type: a snapshot of several '
-                                  'files, which is not written here')
         for key, val in (header or {}).items():
             simple = key.lower().replace(' ', '').replace('-', '').replace('_', '')
             for k in hd:
@@ -424,12 +475,6 @@ class GadgetSnapshot:
                 raise ConceptGPUError(f'Could not understand gadget_snapshot_params["dataformat"]'
                                       f'[{k}] = {b}')
 
-        for k, b in (('POS', 3*fmt['POS']//8), ('VEL', 3*fmt['VEL']//8), ('ID', idbits//8)):
-            if ntot*b >= 2**32:
-                raise ConceptGPUError(
-                    f'block "{k}" of {ntot} particles takes {ntot*b} bytes, more than the 32-bit '
-                    'block size of the format holds: such a snapshot is split over several files '
-                    "(gadget_snapshot_params['particles per file']), which is not written here")
         def arrays(c):
             if isinstance(c, dict):
                 return c['pos'], c['mom'], c.get('ids')
@@ -444,50 +489,84 @@ class GadgetSnapshot:
                 f.write(struct.pack('<I4sII', 8, name.ljust(4).encode('ascii'), 4 + size + 4, 8))
             f.write(struct.pack('<I', size))
         data = [arrays(c) for c in comps]   # (collective on several domains)
+        # how many particles a file may hold: what a signed 32-bit block size leaves for the
+        # wider of POS and VEL (snapshot.py:706-732), or the caller's number
+        file_max = ((2**31 - 1) - 2*4)//(3*(max(fmt['POS'], fmt['VEL'])//8))
+        if particles_per_file != 'automatic' and int(particles_per_file) > 0:
+            file_max = int(particles_per_file)
+        Ns = [int(get(c, 'N')) for c in comps]
+        per_file = divvy(Ns, file_max)
+        num_files = len(per_file)
+        hd['NumFiles'] = num_files
+        if 'numfiles' in {k.lower().replace(' ', '').replace('-', '').replace('_', '')
+                          for k in (header or {})}:
+            hd['NumFiles'] = int(next(v for k, v in header.items() if k.lower().replace(
+                ' ', '').replace('-', '').replace('_', '') == 'numfiles'))
         if not writer:
             return filename
-        os.makedirs(os.path.dirname(os.path.abspath(filename)) or '.', exist_ok=True)
-        with open(filename, 'wb') as f:
-            block_bgn(f, headersize, 'HEAD')
-            size = 0
-            for key, fm in header_fields:
-                v = hd[key] if isinstance(hd[key], list) else [hd[key]]
-                if fm.endswith('d'):
-                    v = [correct_float(x) for x in v]
-                b = struct.pack('<' + fm, *v)
-                f.write(b)
-                size += len(b)
-            f.write(b'\0'*(headersize - size))
-            f.write(struct.pack('<I', headersize))
-            for name, bits in (('POS', fmt['POS']), ('VEL', fmt['VEL'])):
-                size = ntot*3*(bits//8)
-                block_bgn(f, size, name)
-                for c, (pos, mom, ids) in zip(comps, data):
-                    if name == 'POS':
-                        unit = self.unit_length
-                        val = np.asarray(pos, dtype=np.float64).reshape(-1)*(1/unit)
-                        # safeguard against round-off: compared at the block's precision
-                        # (snapshot.py:1117-1118, 1378-1391)
-                        box = np.float32(boxsize/unit) if bits == 32 else np.float64(boxsize/unit)
-                        out = val.astype(np.float32 if bits == 32 else np.float64)
-                        hi = val >= np.float64(box)
-                        out[hi] = (val[hi] - np.float64(box)).astype(out.dtype)
+        types = [slots.index(c) for c in comps]
+        id_bases = [sum(Ns[:i]) for i in range(len(comps))]
+        if num_files > 1:
+            if os.path.isfile(filename):
+                os.remove(filename)
+            os.makedirs(filename, exist_ok=True)
+        else:
+            os.makedirs(os.path.dirname(os.path.abspath(filename)) or '.', exist_ok=True)
+        done = [0]*len(comps)   # rows of each component already written to earlier files
+        for file_index, counts in enumerate(per_file):
+            fn = f'{filename}/snapshot.{file_index}' if num_files > 1 else filename
+            nfile = sum(counts)
+            npart = [0]*num_particle_types
+            for t, n in zip(types, counts):
+                npart[t] = n
+            with open(fn, 'wb') as f:
+                block_bgn(f, headersize, 'HEAD')
+                size = 0
+                for key, fm in header_fields:
+                    v = npart if key == 'Npart' else hd[key]
+                    v = v if isinstance(v, list) else [v]
+                    if fm.endswith('d'):
+                        v = [correct_float(x) for x in v]
+                    b = struct.pack('<' + fm, *v)
+                    f.write(b)
+                    size += len(b)
+                f.write(b'\0'*(headersize - size))
+                f.write(struct.pack('<I', headersize))
+                for name, bits in (('POS', fmt['POS']), ('VEL', fmt['VEL'])):
+                    size = nfile*3*(bits//8)
+                    block_bgn(f, size, name)
+                    for i, (c, (pos, mom, ids)) in enumerate(zip(comps, data)):
+                        rows = slice(done[i], done[i] + counts[i])
+                        if name == 'POS':
+                            unit = self.unit_length
+                            val = np.asarray(pos, dtype=np.float64).reshape(-1, 3)[rows]
+                            val = val.reshape(-1)*(1/unit)
+                            # safeguard against round-off: compared at the block's precision
+                            # (snapshot.py:1117-1118, 1378-1391)
+                            box = np.float32(boxsize/unit) if bits == 32 \
+                                else np.float64(boxsize/unit)
+                            out = val.astype(np.float32 if bits == 32 else np.float64)
+                            hi = val >= np.float64(box)
+                            out[hi] = (val[hi] - np.float64(box)).astype(out.dtype)
+                        else:
+                            unit = self.unit_velocity*get(c, 'mass')*a**1.5
+                            val = np.asarray(mom, dtype=np.float64).reshape(-1, 3)[rows]
+                            val = val.reshape(-1)*(1/unit)
+                            out = val.astype(np.float32 if bits == 32 else np.float64)
+                        out.astype('<f4' if bits == 32 else '<f8').tofile(f)
+                    f.write(struct.pack('<I', size))
+                size = nfile*(idbits//8)
+                block_bgn(f, size, 'ID')
+                for i, (c, (pos, mom, ids)) in enumerate(zip(comps, data)):
+                    if ids is None:  # running numbers, continued over the components
+                        part = np.arange(id_bases[i] + done[i], id_bases[i] + done[i] + counts[i],
+                                         dtype=np.uint64)
                     else:
-                        unit = self.unit_velocity*get(c, 'mass')*a**1.5
-                        val = np.asarray(mom, dtype=np.float64).reshape(-1)*(1/unit)
-                        out = val.astype(np.float32 if bits == 32 else np.float64)
-                    out.astype('<f4' if bits == 32 else '<f8').tofile(f)
+                        part = np.asarray(ids)[done[i]:done[i] + counts[i]]
+                    part.astype('<u4' if idbits == 32 else '<u8').tofile(f)
                 f.write(struct.pack('<I', size))
-            size = ntot*(idbits//8)
-            block_bgn(f, size, 'ID')
-            id_base = 0
-            for c, (pos, mom, ids) in zip(comps, data):
-                n = int(get(c, 'N'))
-                if ids is None:  # running numbers, continued over the components
-                    ids = np.arange(id_base, id_base + n, dtype=np.uint64)
-                    id_base += n
-                np.asarray(ids).astype('<u4' if idbits == 32 else '<u8').tofile(f)
-            f.write(struct.pack('<I', size))
+            for i, n in enumerate(counts):
+                done[i] += n
         return filename
 
     def to_components(self, device=None):
@@ -528,7 +607,7 @@ def load(filename, only_params=False, params=None, units=None, rank=None, nprocs
 
 
 def save(components, filename, a=None, params=None, snapformat=2, dataformat=None, header=None,
-         units=None):
-    """snapshot.save (snapshot.py:3060-3118) for snapshot_type = 'gadget': one file"""
+         units=None, particles_per_file='automatic'):
+    """snapshot.save (snapshot.py:3060-3118) for snapshot_type = 'gadget'"""
     return GadgetSnapshot(None, units).save(components, filename, a, params, snapformat,
-                                            dataformat, header)
+                                            dataformat, header, particles_per_file)

@@ -208,3 +208,40 @@ def test_snapshot_split_over_several_files(golden, how, tmp_path):
     shutil.copy(os.path.join(d, 'snapshot.1'), lone)
     with pytest.raises(ConceptGPUError, match='not the first file'):
         snapshot.load(str(lone))
+
+
+def test_writer_splits_a_snapshot_over_files_like_the_reference(golden, tmp_path):
+    """gadget_snapshot_params['particles per file'] = 70 for 100 + 100 particles: the three
+    files the reference wrote (divvy, snapshot.py:1424-1512: 34 + 33, 33 + 34, 33 + 33), byte
+    for byte — per-file Npart, NumFiles, running identifiers that continue through files and
+    components.  And divvy() by itself on other counts."""
+    from concept_amd import commons, snapshot
+    g = golden('gadget_files3')
+    commons.load_params({'boxsize': float(g['boxsize']), 'H0': float(g['H0']), 'Ωb': 0.05,
+                         'Ωcdm': 0.25, 'a_begin': 0.5})
+    out = snapshot.save(_writer_inputs(g), str(tmp_path/'snap'), a=float(g['a']), snapformat=2,
+                        dataformat={'POS': 64, 'VEL': 64, 'ID': 32}, particles_per_file=70)
+    ref = os.path.join(HERE, 'golden', 'gadget_files3.gadget')
+    assert sorted(os.listdir(out)) == sorted(os.listdir(ref)) == [f'snapshot.{k}' for k in range(3)]
+    for k in range(3):
+        ours = open(os.path.join(out, f'snapshot.{k}'), 'rb').read()
+        assert ours == open(os.path.join(ref, f'snapshot.{k}'), 'rb').read(), k
+    # what was written is read back whole
+    back = snapshot.load(out)
+    for i, c in enumerate(back.components):
+        assert np.array_equal(c['pos'], snapshot.load(ref).components[i]['pos'])
+    # divvy: every particle in exactly one file, no file above the limit, as few files as
+    # filling them to the brim needs, the fuller files first
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        Ns = [int(n) for n in rng.integers(1, 400, rng.integers(1, 4))]
+        file_max = int(rng.integers(4, 500))   # (below the number of components the
+        # reference's own sanity check aborts: one particle of each type per file)
+        files = snapshot.divvy(Ns, file_max)
+        assert [sum(col) for col in zip(*files)] == Ns
+        assert max(sum(row) for row in files) <= file_max and min(sum(row) for row in files) > 0
+        assert len(files) == -(-sum(Ns)//file_max) or len(files) == sum(Ns)//file_max + 1
+        sums = [sum(row) for row in files]
+        assert sums == sorted(sums, reverse=True)
+    assert snapshot.divvy([100, 100], 70) == [[34, 33], [33, 34], [33, 33]]
+    assert snapshot.divvy([64], 10**9) == [[64]]
