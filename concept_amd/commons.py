@@ -95,7 +95,8 @@ _PATH_PARAMETERS = ('G_Newton', 'N_rungs', 'boxsize', 'cell_centered', 'ewald_gr
                     'shortrange_params', 'softening_kernel', 'H0', 'Ωb', 'Ωcdm', 'a_begin',
                     'enable_Hubble', 'Δt_base_background_factor', 'Δt_base_nonlinear_factor',
                     'Δt_increase_max_factor', 'Δt_rung_factor', 'Δa_max_early', 'Δa_max_late',
-                    'static_timestepping', 'output_times', 't_begin')
+                    'static_timestepping', 'output_times', 't_begin', 'output_dirs', 'output_bases',
+                    'snapshot_type', 'gadget_snapshot_params', 'initial_conditions')
 
 
 def load_params(source=None, **overrides):
@@ -334,6 +335,46 @@ def load_params(source=None, **overrides):
         p.output_times[default_param] += _times(rest)
     else:
         p.output_times[default_param] = _times(ot)
+    # which of those dump times are snapshot times, per time parameter (the other output kinds —
+    # power spectra, renders — are dumps of the time loop too, but nothing is written for them)
+    def _kind_times(v, kind):
+        if isinstance(v, dict):
+            return _times(v.get(kind))
+        return ()
+    p.snapshot_times = {'a': (), 't': ()}
+    if isinstance(ot, dict) and set(ot) & {'a', 't'}:
+        for tp in ('a', 't'):
+            p.snapshot_times[tp] = _kind_times(ot.get(tp), 'snapshot')
+        p.snapshot_times[default_param] += _kind_times(ot, 'snapshot')
+    else:
+        p.snapshot_times[default_param] = _kind_times(ot, 'snapshot')
+    # input / output (commons.py:2547-2572, 2787-2830): where snapshots go, what they are
+    # called and which format they have
+    od = user.get('output_dirs', {})
+    if isinstance(od, str):
+        od = {'snapshot': od}
+    p.output_dirs = {k: str(v) for k, v in dict(od).items() if v}
+    p.output_bases = {'snapshot': 'snapshot'}
+    p.output_bases.update({k: str(v) for k, v in dict(user.get('output_bases', {})).items()})
+    p.snapshot_type = str(user.get('snapshot_type', 'concept')).lower()
+    p.initial_conditions = user.get('initial_conditions', '')
+    gsp = {'snapformat': 2, 'dataformat': {'POS': 32, 'VEL': 32, 'ID': 'automatic'},
+           'particles per file': 'automatic', 'header': {},
+           'units': {'length': 'kpc/h', 'velocity': 'km/s', 'mass': '10**10*m_sun/h'}}
+    for key, val in dict(user.get('gadget_snapshot_params', {})).items():
+        simple = str(key).lower().replace(' ', '').replace('_', '').replace('-', '')
+        for known in gsp:
+            if simple == known.replace(' ', ''):
+                if isinstance(gsp[known], dict) and isinstance(val, dict):
+                    gsp[known] = dict(gsp[known], **val)
+                else:
+                    gsp[known] = val
+                break
+    gsp['snapformat'] = int(gsp['snapformat'])
+    if gsp['snapformat'] not in (1, 2):
+        raise ValueError(f'gadget_snapshot_params["snapformat"] = {gsp["snapformat"]} but must '
+                         'be 1 or 2')
+    p.gadget_snapshot_params = gsp
     p.user = user
     params = p
     return p

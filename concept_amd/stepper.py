@@ -475,6 +475,22 @@ class Timeloop(RungStepper):
         self.streaming = streaming
         self._plan = self._rps = self._spec = self._next_drift = None
         self.stream_passes = self.stream_wrong_guesses = 0
+        if on_dump is None and p.output_dirs.get('snapshot') and (
+                p.snapshot_times['a'] or p.snapshot_times['t']):
+            # the parameter file asks for snapshots (output_dirs, output_times['snapshot'],
+            # snapshot_type, gadget_snapshot_params: main.dump, main.py:1660-1760)
+            if p.snapshot_type != 'gadget':
+                import warnings
+                warnings.warn(f"snapshot_type = '{p.snapshot_type}': only 'gadget' snapshots are "
+                              'written here (the reference\'s own format is HDF5, which needs h5py); '
+                              'no snapshots will be dumped')
+            else:
+                gsp = p.gadget_snapshot_params
+                self.on_dump = self.snapshot_dumper(
+                    p.output_dirs['snapshot'], p.output_bases.get('snapshot', 'snapshot'),
+                    only_snapshot_times=True, snapformat=gsp['snapformat'],
+                    dataformat=gsp['dataformat'], header=gsp['header'],
+                    particles_per_file=gsp['particles per file'], units=gsp['units'])
 
     # universals.t / universals.a live in the Cosmology object
     t = property(lambda self: self.cosmo.t, lambda self, v: setattr(self.cosmo, 't', float(v)))
@@ -715,12 +731,15 @@ class Timeloop(RungStepper):
             if streaming:
                 self._rps = [c.to_regions(self._plan['mesh']) for c in self.components]
 
-    def snapshot_dumper(self, output_dir, output_base='snapshot', **save_options):
+    def snapshot_dumper(self, output_dir, output_base='snapshot', only_snapshot_times=False,
+                        **save_options):
         """An on_dump callback that writes a GADGET snapshot per dump time (main.dump,
         main.py:1660-1760, for snapshots of snapshot_type = 'gadget'; concept_amd.snapshot.save)
         named like the reference's — <output_dir>/<output_base>_<a|t>=<value> with just enough
         digits that neighbouring dumps and the initial time differ (prepare_for_output,
-        main.py:2242-2278).  Usage: loop.on_dump = loop.snapshot_dumper('output/run')."""
+        main.py:2242-2278).  Usage: loop.on_dump = loop.snapshot_dumper('output/run').
+        only_snapshot_times: write at the times output_times lists for 'snapshot' only (the
+        other output kinds' times are dumps of the loop too)."""
         from . import snapshot
         p = self.params
         fmts = {}
@@ -742,6 +761,10 @@ class Timeloop(RungStepper):
 
         def on_dump(loop, dump_time):
             value = dump_time.a if dump_time.time_param == 'a' else dump_time.t
+            if only_snapshot_times and not any(
+                    abs(value - v) <= 1e-12*max(abs(v), 1e-300)
+                    for v in p.snapshot_times[dump_time.time_param]):
+                return
             name = f'{output_dir}/{output_base}{sep}{dump_time.time_param}={value:.{ndigits}f}'
             fn = snapshot.save(loop.components, name, a=loop.cosmo.a, **save_options)
             loop.snapshots_written.append(fn)
@@ -865,3 +888,20 @@ class Timeloop(RungStepper):
                         continue
         self.time_step, self.Δt = time_step, Δt
         self.history.append((time_step, cosmo.t, cosmo.a, Δt))
+
+
+def get_initial_conditions(params=None, device=None):
+    """main.get_initial_conditions (main.py:2080-2186) for the case of a snapshot on disk: the
+    components of the file `initial_conditions` names (GADGET-2, one file or several; over several
+    domains every rank reads its own rows).  Component specifications to be REALISED (dicts in
+    `initial_conditions`) need the reference's IC generator and CLASS: outside this path."""
+    from . import snapshot
+    p = params or commons.params
+    ic = p.initial_conditions
+    if not ic:
+        return []
+    if not isinstance(ic, str):
+        raise ConceptGPUError('initial_conditions: only the path of a snapshot is supported here '
+                              '(realising components needs the reference\'s IC generator)')
+    gsp = p.gadget_snapshot_params
+    return snapshot.load(ic, params=p, units=gsp['units']).to_components(device=device)

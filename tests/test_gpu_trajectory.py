@@ -384,3 +384,47 @@ def test_p3m_timeloop_with_rungs_at_config3_size():
     d = np.diff(np.array(steps))
     print(f'\nP³M time loop at 256^3 / 512^3, 8 rungs: {loop.time_step} base steps in {wall:.2f} s; '
           f'between steps (s): ' + ' '.join(f'{v:.2f}' for v in d) + f'; rungs seen {sorted(rungs_seen)}; net momentum / exchanged = {drift/exchanged:.2e}')
+
+
+def test_run_driven_by_a_parameter_file(golden, tmp_path):
+    """The reference's way of running (param file: initial_conditions, output_dirs, output_times
+    by kind, snapshot_type, gadget_snapshot_params): the initial snapshot is written from the
+    trajectory golden's particles, a parameter file names it and asks for GADGET snapshots at two
+    of the golden's dump times (and a power spectrum — a dump that writes nothing — at a third);
+    get_initial_conditions() + Timeloop().run() then produce the reference run's particles in
+    files of the requested format under the requested names."""
+    import os
+    from concept_amd import commons, snapshot, stepper
+    g = golden('traj_pm_n8_g8')
+    p0, c0 = _component(g)
+    L = p0.boxsize
+    ic = str(tmp_path/'ic')
+    snapshot.save([{'name': 'GADGET halo', 'species': 'matter', 'N': int(g['N']),
+                    'mass': float(g['mass']), 'pos': g['pos_in'], 'mom': g['mom_in'], 'ids': None}],
+                  ic, a=p0.a_begin, dataformat={'POS': 64, 'VEL': 64})
+    a_dumps = [float(a) for a in g['dump_a']]
+    out = str(tmp_path/'out')
+    text = str(g['param_text']) + f"""
+initial_conditions = {ic!r}
+output_dirs = {{'snapshot': {out!r}}}
+output_bases = {{'snapshot': 'snap'}}
+output_times = {{'snapshot': ({a_dumps[0]!r}, {a_dumps[-1]!r}), 'powerspec': {a_dumps[1]!r}}}
+snapshot_type = 'gadget'
+gadget_snapshot_params = {{'snapformat': 1, 'dataformat': {{'POS': 64, 'VEL': 64}}}}
+"""
+    p = commons.load_params(text)
+    assert p.snapshot_times['a'] == (a_dumps[0], a_dumps[-1]) and len(p.output_times['a']) == 3
+    comps = stepper.get_initial_conditions()
+    assert [c.name for c in comps] == ['GADGET halo'] and comps[0].N == int(g['N'])
+    loop = stepper.Timeloop(comps)
+    loop.run()
+    files = sorted(os.listdir(out))
+    assert files == [f'snap_a={a_dumps[0]:.2f}', f'snap_a={a_dumps[-1]:.2f}'], files
+    kick = np.abs(g['dump_mom'][-1] - g['mom_in']).max()
+    for fn, i in zip(files, (0, len(a_dumps) - 1)):
+        snap = snapshot.load(os.path.join(out, fn))
+        assert snap.snapformat == 1
+        (comp,) = snap.components
+        # (the initial momenta went through a file: u = mom/(m a^1.5) and back, an ulp or two)
+        assert _pos_err(comp['pos'], g['dump_pos'][i], L) <= 1e-10
+        assert np.abs(comp['mom'] - g['dump_mom'][i]).max() <= 1e-9*kick
