@@ -255,3 +255,34 @@ def test_library_is_built_from_the_sources_in_the_tree():
     from concept_amd import build
     built = open(build.LIB + '.srchash').read().strip()
     assert built == build.source_hash(), 'run `python -m concept_amd.build`'
+
+
+def test_output_parameters():
+    """load_params: the input / output names of a parameter file (commons.py:2547-2572,
+    2787-2830) — output_dirs as a dict or one directory, output_bases, snapshot_type,
+    gadget_snapshot_params with the reference's loose key matching, output_times by kind (all of
+    them are dumps of the time loop, the 'snapshot' ones write files), initial_conditions"""
+    from concept_amd import commons
+    p = commons.load_params("""
+boxsize = 100*Mpc
+output_dirs = {'snapshot': '/tmp/out', 'powerspec': '/tmp/ps'}
+output_times = {'a': {'snapshot': (0.5, 1), 'powerspec': 0.7}, 't': {'snapshot': 13*Gyr}}
+snapshot_type = 'GADGET'
+gadget_snapshot_params = {'SnapFormat': 1, 'dataformat': {'POS': 64}, 'Particles per file': 1000}
+initial_conditions = '/tmp/ic'
+""")
+    assert p.output_times == {'a': (0.5, 1.0, 0.7), 't': (13.0,)}
+    assert p.snapshot_times == {'a': (0.5, 1.0), 't': (13.0,)}
+    assert p.output_dirs['snapshot'] == '/tmp/out' and p.output_bases['snapshot'] == 'snapshot'
+    assert p.snapshot_type == 'gadget' and p.initial_conditions == '/tmp/ic'
+    gsp = p.gadget_snapshot_params
+    assert gsp['snapformat'] == 1 and gsp['particles per file'] == 1000
+    assert gsp['dataformat'] == {'POS': 64, 'VEL': 32, 'ID': 'automatic'}
+    p = commons.load_params({'output_dirs': '/tmp/all', 'output_times': {'snapshot': 1.0},
+                             'output_bases': {'snapshot': 'snap'}})
+    assert p.output_dirs == {'snapshot': '/tmp/all'} and p.output_bases['snapshot'] == 'snap'
+    assert p.snapshot_times['a'] == (1.0,) and p.snapshot_type == 'concept'
+    with pytest.raises(ValueError, match='snapformat'):
+        commons.load_params({'gadget_snapshot_params': {'snapformat': 3}})
+    p = commons.load_params({})
+    assert p.output_dirs == {} and p.snapshot_times == {'a': (), 't': ()}
