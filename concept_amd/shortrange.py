@@ -159,7 +159,10 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
         if key_ not in sparse_rows:
             sparse_rows[key_] = torch.nonzero(
                 rec.rung_indices >= rec.lowest_active_rung).flatten()
-        return sparse_rows[key_]
+        rows_ = sparse_rows[key_]
+        # (the populations are bookkeeping of the time loop: should they lag behind the rung
+        # array, the cells sweep takes over)
+        return rows_ if rows_.numel() <= mesh.SHORTRANGE_SPARSE_MAX else None
     sparse_rows = {}
     key = 'a**(-3*w_eff₀-3*w_eff₁-1)'
     done = set()
