@@ -1050,6 +1050,43 @@ extern "C" int cg_shortrange_sweep_cells_rungs(
                                       (const signed char *)rung_jumped_r, lowest_active_rung);
 }
 
+extern "C" int cg_shortrange_tiles(cg_ctx *c, const double *pos, int64_t n, int64_t nt,
+                                   double tile_extent, const int8_t *rung,
+                                   int lowest_active_rung, uint32_t *order_out,
+                                   uint32_t *offset_out, double *pos_sorted_out) {
+    CG_CHECK(c && offset_out && (n == 0 || (pos && order_out && pos_sorted_out)),
+             "cg_shortrange_tiles: null argument");
+    CG_CHECK(nt >= 4, "The global gravity tiling needs to have at least 4 tiles across the box in "
+                      "every direction (species.py:3971); got %lld", (long long)nt);
+    CG_CHECK(nt <= 1024 && n < (1ll << 32), "cg_shortrange_tiles: size out of range");
+    CG_CHECK(tile_extent > 0, "cg_shortrange_tiles: tile_extent must be positive");
+    return cgk_shortrange_tiles(c, pos, n, nt, tile_extent, (const signed char *)rung,
+                                lowest_active_rung, order_out, offset_out, pos_sorted_out);
+}
+
+extern "C" int cg_shortrange_sweep_tiles(cg_ctx *c, const double *pos_r_sorted,
+                                         const uint32_t *order_r, const uint32_t *offset_r,
+                                         double *dmom_r, const double *pos_s_sorted,
+                                         const uint32_t *offset_s, int64_t nt,
+                                         const double *table, int64_t tablesize,
+                                         double r2_index_scaling, double r2_max, double factor,
+                                         const double *factors, const int8_t *rung_jumped_r) {
+    CG_CHECK(c && offset_r && offset_s && table, "cg_shortrange_sweep_tiles: null argument");
+    CG_CHECK(nt >= 4 && nt <= 1024, "cg_shortrange_sweep_tiles: nt = %lld", (long long)nt);
+    CG_CHECK((factors == nullptr) == (rung_jumped_r == nullptr),
+             "cg_shortrange_sweep_tiles: factors and rung_jumped come together");
+    // the largest index the sweep can form is int(r2_max*scaling): must be inside the table
+    CG_CHECK((int64_t)(r2_max * r2_index_scaling) < tablesize,
+             "cg_shortrange_sweep_tiles: table of %lld entries too short for r2_max*scaling = %g",
+             (long long)tablesize, r2_max * r2_index_scaling);
+    // a receiver meets the tiles around its own only: the force range must not exceed one tile
+    CG_CHECK(r2_max <= (c->p.boxsize / (double)nt) * (c->p.boxsize / (double)nt) * (1 + 1e-12),
+             "cg_shortrange_sweep_tiles: the force range exceeds the tile extent");
+    return cgk_shortrange_sweep_tiles(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted,
+                                      offset_s, nt, table, r2_index_scaling, r2_max, factor,
+                                      factors, (const signed char *)rung_jumped_r);
+}
+
 extern "C" int cg_dmom_nullify(cg_ctx *c, double *dmom, const int8_t *rung, int64_t n,
                                int lowest_active_rung) {
     CG_CHECK(c && (dmom || n == 0), "cg_dmom_nullify: null argument");

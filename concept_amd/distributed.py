@@ -541,13 +541,15 @@ def shortrange_kick(domain, particles, *, scale, range_, tilesize, tablesize, so
         ghosts = list(ship_boundary_positions(m, pos, range_*(1 + 1e-9) + 1e-9*L))
     supp = torch.cat([pos] + ghosts).contiguous()
     ext = L/nt
-    cells_r = m.shortrange_cells(pos.contiguous(), nt, ext)
-    cells_s = m.shortrange_cells(supp, nt, ext) if ghosts else cells_r
+    mfma = shortrange.SWEEP == 'mfma'
+    build = m.shortrange_tiles if mfma else m.shortrange_cells
+    cells_r = build(pos.contiguous(), nt, ext)
+    cells_s = build(supp, nt, ext) if ghosts else cells_r
     table, maxr2 = shortrange.get_shortrange_table(softening, scale, range_, tablesize, kernel,
                                                    pos.device)
     dmom = torch.zeros((n, 3), dtype=torch.float64, device=pos.device)
-    m.shortrange_sweep_cells(cells_r, dmom, cells_s, nt, table, (tablesize - 1)/maxr2,
-                             range_**2, factor)
+    (m.shortrange_sweep_tiles if mfma else m.shortrange_sweep_cells)(
+        cells_r, dmom, cells_s, nt, table, (tablesize - 1)/maxr2, range_**2, factor)
     return dmom
 
 

@@ -701,6 +701,42 @@ class PotentialMesh:
             _ptr(off_s), int(nt), _ptr(table), table.numel(), float(r2_index_scaling),
             float(r2_max), _ptr(factors), _ptr(rung), _ptr(rung_jumped), int(lowest)))
 
+    def shortrange_tiles(self, pos, nt, tile_extent, active=None):
+        """The particles listed by tile (z fastest) with their positions copied in that order
+        (cg_shortrange_tiles): (order, offset, pos_sorted).  active = (rung int8,
+        lowest_active_rung) lists the particles on active rungs only (a sub-step's receivers);
+        the tensors keep room for all n, offset[-1] says how many are listed."""
+        n = self._check_particles(pos)
+        order = torch.empty(max(n, 1), dtype=torch.int32, device=pos.device)
+        offset = torch.empty(nt**3 + 1, dtype=torch.int32, device=pos.device)
+        pos_sorted = torch.empty((max(n, 1), 3), dtype=torch.float64, device=pos.device)
+        rung, lowest = (None, 0) if active is None else active
+        if rung is not None:
+            self._check_rungs(n, rung)
+        check(_L.cg_shortrange_tiles(self._ctx, _ptr(pos), n, int(nt), float(tile_extent),
+                                     _ptr(rung) if rung is not None else None, int(lowest),
+                                     _ptr(order), _ptr(offset), _ptr(pos_sorted)))
+        return order, offset, pos_sorted
+
+    def shortrange_sweep_tiles(self, tiles_r, dmom_r, tiles_s, nt, table, r2_index_scaling,
+                               r2_max, factor, rungs=None):
+        """The sweep with the matrix-core pre-filter over the lists of shortrange_tiles().
+        rungs = (factors, rung_jumped int8): dmom += factors[rung_jumped] * sum per receiver
+        (the receiver list then holds the active receivers only), else `factor`."""
+        n = self._check_particles(dmom_r)
+        if table.dtype != torch.float64 or not table.is_cuda:
+            raise lib.ConceptGPUError('short-range table must be a float64 CUDA tensor')
+        order_r, off_r, pos_r = tiles_r
+        _, off_s, pos_s = tiles_s
+        factors, rung_jumped = (None, None) if rungs is None else rungs
+        if rung_jumped is not None:
+            self._check_rungs(n, rung_jumped)
+        check(_L.cg_shortrange_sweep_tiles(
+            self._ctx, _ptr(pos_r), _ptr(order_r), _ptr(off_r), _ptr(dmom_r), _ptr(pos_s),
+            _ptr(off_s), int(nt), _ptr(table), table.numel(), float(r2_index_scaling),
+            float(r2_max), float(factor), _ptr(factors) if factors is not None else None,
+            _ptr(rung_jumped) if rung_jumped is not None else None))
+
     SHORTRANGE_SPARSE_MAX = 8
 
     def shortrange_sparse(self, pos_r, active, dmom_r, pos_s, table, r2_index_scaling, r2_max,

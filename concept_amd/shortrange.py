@@ -8,6 +8,7 @@ gravity_pairwise_nonperiodic (direct summation with and without the Ewald
 correction, component_component_pp below).  The pair loops run in
 libconcept_gpu.so (cg_shortrange.hip, cg_pp.hip)."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -89,6 +90,10 @@ def _pair_integrals(ᔑdt_rungs, rec, sup):
 
 
 sparse_sweeps = 0   # sweeps taken without a cell list (a handful of active receivers)
+# which tile sweep runs: 'mfma' = lists by tile + matrix-core range pre-filter
+# (cg_shortrange_sweep_tiles), 'cells' = the half-tile cell list of rounds 2-3
+# (cg_shortrange_sweep_cells): same sums, kept for A/B runs and as a cross-check
+SWEEP = os.environ.get('CONCEPT_GPU_SR_SWEEP', 'mfma')
 
 
 def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
@@ -127,13 +132,25 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
         slack = max(c._store.mesh.boxsize/c._store.mesh.gridsize for c in involved)
         for c in involved:
             check_shortrange_fits(c._store.mesh, sr['range'] + slack)
+    if SWEEP not in ('mfma', 'cells'):
+        raise ConceptGPUError(f'CONCEPT_GPU_SR_SWEEP={SWEEP!r}: "mfma" or "cells"')
+    build = mesh.shortrange_tiles if SWEEP == 'mfma' else mesh.shortrange_cells
     def get_cells(c):
         """the component's cell list (built when a sweep first asks for it: a sub-step that
         kicks a handful of particles needs none, see sweep() below)"""
         if id(c) not in cells:
-            cells[id(c)] = mesh.shortrange_cells(c.pos, nt, tile_extent)
+            cells[id(c)] = build(c.pos, nt, tile_extent)
             supp_cells.setdefault(id(c), cells[id(c)])
         return cells[id(c)]
+    active_lists = {}
+    def get_active(c):
+        """the component's particles on active rungs, by tile: the receivers of a sub-step
+        (main.py:1347-1624 visits the tiles' active rungs only)"""
+        key_ = (id(c), c.lowest_active_rung)
+        if key_ not in active_lists:
+            active_lists[key_] = mesh.shortrange_tiles(
+                c.pos, nt, tile_extent, active=(c.rung_indices, c.lowest_active_rung))
+        return active_lists[key_]
     for c in involved:
         supp_pos[id(c)] = c.pos
         # every involved component can act as supplier: s of sweep(r, s), and r of the
@@ -145,7 +162,7 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
             # rows 0..N_local-1 ARE the component's own particles (the sweep's `same`
             # convention), the ghosts follow
             supp_pos[id(c)] = torch.cat([c.pos] + list(ghosts)).contiguous()
-            supp_cells[id(c)] = mesh.shortrange_cells(supp_pos[id(c)], nt, tile_extent)
+            supp_cells[id(c)] = build(supp_pos[id(c)], nt, tile_extent)
 
     def active_rows(rec):
         """rows of the receiver's particles on active rungs when they are few (one domain:
@@ -196,18 +213,25 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
                                                    table, scaling, r2_max, 0.0,
                                                    (factors, rec.rung_indices_jumped))
                         return
+                    get_cells(sup)
+                    if SWEEP == 'mfma':
+                        rc = get_active(rec) if rec.lowest_active_rung > 0 else get_cells(rec)
+                        mesh.shortrange_sweep_tiles(rc, rec.Δmom, supp_cells[id(sup)], nt, table,
+                                                    scaling, r2_max, 0.0,
+                                                    (factors, rec.rung_indices_jumped))
+                        return
                     rungs = (factors, rec.rung_indices, rec.rung_indices_jumped,
                              rec.lowest_active_rung)
                     rc = get_cells(rec)
-                    get_cells(sup)
                     mesh.shortrange_sweep_cells(rc, rec.Δmom, supp_cells[id(sup)], nt, table,
                                                 scaling, r2_max, 0.0, rungs)
                 else:
                     rc = get_cells(rec)
                     get_cells(sup)
-                    mesh.shortrange_sweep_cells(
-                        rc, rec.Δmom, supp_cells[id(sup)], nt, table, scaling,
-                        r2_max, p.G_Newton*rec.mass*sup.mass*float(integrals[0]))
+                    sweep_ = (mesh.shortrange_sweep_tiles if SWEEP == 'mfma'
+                              else mesh.shortrange_sweep_cells)
+                    sweep_(rc, rec.Δmom, supp_cells[id(sup)], nt, table, scaling,
+                           r2_max, p.G_Newton*rec.mass*sup.mass*float(integrals[0]))
             sweep(r, s, same)
             if not same and s in receivers:
                 # the reference kicks both partners of a pair (Δmom_s -= ..., gravity.py:341-349)

@@ -341,6 +341,31 @@ int cg_shortrange_sweep_cells_rungs(cg_ctx *ctx, const double *pos_r_sorted,
                                     const int8_t *rung_r /*DEV*/,
                                     const int8_t *rung_jumped_r /*DEV*/, int lowest_active_rung);
 
+/* The sweep with a matrix-core range pre-filter (round 4; csrc/cg_shortrange_mfma.hip): the
+ * counterpart of the reference's automatic subtile refinement (species.py:4031-4142,
+ * interactions.py:145-329, :1141-1278) — the pairs out of range are discarded by single-precision
+ * 16 x 16 distance products on the matrix cores instead of by ever finer subtiles, and the units
+ * of work are counts of particles (16 receivers per wavefront wherever the tile borders fall),
+ * so a dense tile and a void cost what their pairs cost.  Every pair that passes is evaluated
+ * in FP64 exactly as in cg_shortrange_sweep_cells (x_ji, r2, the table index bit-identical).
+ * cg_shortrange_tiles lists the particles by tile (Tiling.sort, species.py:775-780), z fastest:
+ * order_out[m], pos_sorted_out[3m], offset_out[nt^3 + 1]; with `rung` only the m particles on
+ * rungs >= lowest_active_rung are listed (the receivers of a sub-step), otherwise m = n.
+ * cg_shortrange_sweep_tiles: dmom_r[order_r[q]] += factor * sum over the suppliers in range, or
+ * factors[rung_jumped_r[order_r[q]]] * sum when factors is given (gravity.py:318-349). */
+int cg_shortrange_tiles(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, int64_t nt,
+                        double tile_extent, const int8_t *rung /*DEV n or null*/,
+                        int lowest_active_rung, uint32_t *order_out /*DEV n*/,
+                        uint32_t *offset_out /*DEV nt^3+1*/, double *pos_sorted_out /*DEV 3n*/);
+int cg_shortrange_sweep_tiles(cg_ctx *ctx, const double *pos_r_sorted /*DEV*/,
+                              const uint32_t *order_r /*DEV*/, const uint32_t *offset_r /*DEV*/,
+                              double *dmom_r /*DEV, accumulated*/,
+                              const double *pos_s_sorted /*DEV*/, const uint32_t *offset_s /*DEV*/,
+                              int64_t nt, const double *table /*DEV*/, int64_t tablesize,
+                              double r2_index_scaling, double r2_max, double factor,
+                              const double *factors /*DEV 3*N_rungs-1 or null*/,
+                              const int8_t *rung_jumped_r /*DEV or null*/);
+
 /* The same sums for k <= 8 receivers (rows active[0..k) of pos_r / dmom_r) against ALL n_s
  * suppliers, without a cell list: the sub-steps of driftkick_short (main.py:1347-1624) that kick
  * only the few particles of the highest rungs.  Nearest periodic image; the range must stay
