@@ -1083,8 +1083,8 @@ extern "C" int cg_shortrange_sweep_tiles(cg_ctx *c, const double *pos_r_sorted,
     CG_CHECK(r2_max <= (c->p.boxsize / (double)nt) * (c->p.boxsize / (double)nt) * (1 + 1e-12),
              "cg_shortrange_sweep_tiles: the force range exceeds the tile extent");
     return cgk_shortrange_sweep_tiles(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted,
-                                      offset_s, nt, table, r2_index_scaling, r2_max, factor,
-                                      factors, (const signed char *)rung_jumped_r);
+                                      offset_s, nt, table, tablesize, r2_index_scaling, r2_max,
+                                      factor, factors, (const signed char *)rung_jumped_r);
 }
 
 extern "C" int cg_dmom_nullify(cg_ctx *c, double *dmom, const int8_t *rung, int64_t n,

@@ -135,11 +135,18 @@ __global__ __launch_bounds__(256) void k_srm_scatter(const double *__restrict__ 
     }
 }
 
+#ifdef SRM_PROBE_COUNT  // probe build: how many trips, candidates, hits, matrix products
+__device__ unsigned long long srm_dbg[8];
+#define SRM_COUNT(i, v) atomicAdd(&srm_dbg[i], (unsigned long long)(v))
+#else
+#define SRM_COUNT(i, v) ((void)0)
+#endif
+
 struct SrmParams {
     double boxsize, ext, inv_ext, inv_tile, r2_index_scaling, r2_max, factor;
     const double *factors;          // adaptive rungs: factors[rung_jumped[i]] per receiver
     const signed char *rung_jumped;
-    int nt;
+    int nt, tablesize;
 };
 
 // inclusive scan over the 64 lanes of a wave in DPP adds
@@ -153,6 +160,10 @@ __device__ __forceinline__ unsigned srm_wave_scan(unsigned v) {
     return v;
 }
 
+#ifndef SRM_LDS_TABLE
+#define SRM_LDS_TABLE 1
+#endif
+constexpr int kTableLds = 4096;   // entries of the short-range table kept in LDS
 struct SrmShared {
     double sx[kRows], sy[kRows], sz[kRows];   // staged supplier positions (FP64, as stored)
     f32x4 fa[kRows];                          // (-2u_x, -2u_y, -2u_z, |u|^2): the A operand
@@ -160,6 +171,9 @@ struct SrmShared {
     unsigned pbeg[128], ppre[130];            // piece table: first source row, prefix of the counts
     unsigned char pimg[128];
     double ltab[4];                           // image code -> offset: -L, 0, +L
+#if SRM_LDS_TABLE
+    double table[kTableLds];                  // the short-range table (gravity.py:373-424)
+#endif
 };
 
 // The lanes' candidates: each lane walks its own masks — bit t of a word (from the top) is row
@@ -170,7 +184,7 @@ __device__ __forceinline__ void srm_candidates(unsigned m0, unsigned m1, unsigne
                                                int rowb, int bend, double xi, double yi, double zi,
                                                const SrmShared &S, double r2_max,
                                                double r2_index_scaling,
-                                               const double *__restrict__ table, double &ax,
+                                               const double *table, double &ax,
                                                double &ay, double &az) {
     for (;;) {
         if (m0 == 0) {  // this lane's word is used up: the next one moves down
@@ -182,6 +196,10 @@ __device__ __forceinline__ void srm_candidates(unsigned m0, unsigned m1, unsigne
         }
         if (!__any((m0 | m1 | m2) != 0)) break;
         const bool have = m0 != 0;
+#ifdef SRM_PROBE_COUNT
+        if ((threadIdx.x & 63) == 0) SRM_COUNT(0, 1);
+        SRM_COUNT(1, have ? 1 : 0);
+#endif
         const int t = have ? __clz((int)m0) : 0;
         m0 = have ? (m0 ^ (0x80000000u >> t)) : 0u;
         const int row = rowb + ((t & ~3) << 2) + (t & 3);
@@ -198,6 +216,10 @@ __device__ __forceinline__ void srm_candidates(unsigned m0, unsigned m1, unsigne
         }
         const double r2 = x_ji * x_ji + y_ji * y_ji + z_ji * z_ji;  // gravity.py:306
         const bool hit = ok && r2 <= r2_max;                          // gravity.py:311
+#ifdef SRM_PROBE_COUNT
+        SRM_COUNT(2, hit ? 1 : 0);
+        SRM_COUNT(4, ok ? 1 : 0);
+#endif
         double tv = 0.0;
         if (hit) tv = table[(unsigned)(int)(r2 * r2_index_scaling)];  // gravity.py:316-321
         ax = __builtin_fma(x_ji, tv, ax);
@@ -222,6 +244,12 @@ __global__ __launch_bounds__(64 * kWaves) void k_sr_sweep_mfma(
                    qc1 = __builtin_amdgcn_readfirstlane(off_r[col + nt]);
     if (qc0 == qc1) return;
     if (tid < 4) S.ltab[tid] = tid == 0 ? -P.boxsize : (tid == 2 ? P.boxsize : 0.0);
+#if SRM_LDS_TABLE
+    for (int e = tid; e < P.tablesize; e += 64 * kWaves) S.table[e] = table[e];
+    const double *tbl = S.table;
+#else
+    const double *tbl = table;
+#endif
     const bool xyface = ta == 0 || ta == nt - 1 || tb == 0 || tb == nt - 1;
     const double ox = (ta + 0.5) * P.ext, oy = (tb + 0.5) * P.ext;
     const float rc2u = (float)(P.r2_max * P.inv_ext * P.inv_ext);
@@ -356,7 +384,12 @@ __global__ __launch_bounds__(64 * kWaves) void k_sr_sweep_mfma(
                 __syncthreads();
                 const int a = max(RA, (int)r0) - (int)r0, b = min(RB, (int)r1) - (int)r0;
                 const float *fa1 = (const float *)S.fa;
-                for (int ba = a; ba < b; ba += kBatch) {
+#ifdef SRM_PROBE_NOMFMA
+                const int b_ = a;  // probe build: staging only
+#else
+                const int b_ = b;
+#endif
+                for (int ba = a; ba < b_; ba += kBatch) {
                     const int nrows = min(kBatch, b - ba);
                     const int ngrp = (nrows + 63) >> 6;  // groups of 4 blocks of 16 rows
                     unsigned m[4] = {0u, 0u, 0u, 0u};
@@ -365,6 +398,9 @@ __global__ __launch_bounds__(64 * kWaves) void k_sr_sweep_mfma(
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
                             if (2 * w + h < ngrp) {  // wave-uniform
+#ifdef SRM_PROBE_COUNT
+                                if (lane == 0) SRM_COUNT(3, 4);
+#endif
                                 const int rowg = ba + 64 * (2 * w + h);
                                 float av[4];
 #pragma unroll
@@ -384,12 +420,16 @@ __global__ __launch_bounds__(64 * kWaves) void k_sr_sweep_mfma(
                             }
                         }
                     }
+#ifdef SRM_PROBE_NOCAND  // probe build: the matrix products and masks, no pair evaluated
+                    ax += (double)(m[0] ^ m[1] ^ m[2] ^ m[3]) * 1e-300;
+                    continue;
+#endif
                     if (wface)
                         srm_candidates<true>(m[0], m[1], m[2], m[3], ba + 4 * g, b, xi, yi, zi, S,
-                                             P.r2_max, P.r2_index_scaling, table, ax, ay, az);
+                                             P.r2_max, P.r2_index_scaling, tbl, ax, ay, az);
                     else
                         srm_candidates<false>(m[0], m[1], m[2], m[3], ba + 4 * g, b, xi, yi, zi, S,
-                                              P.r2_max, P.r2_index_scaling, table, ax, ay, az);
+                                              P.r2_max, P.r2_index_scaling, tbl, ax, ay, az);
                 }
                 r0 = r1;
             }
@@ -413,6 +453,18 @@ __global__ __launch_bounds__(64 * kWaves) void k_sr_sweep_mfma(
 }
 
 }  // namespace
+
+#ifdef SRM_PROBE_COUNT
+extern "C" int cg_srm_debug_counters(unsigned long long *out, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(srm_dbg), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {};
+        hipMemcpyToSymbol(HIP_SYMBOL(srm_dbg), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
 
 int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
                          const signed char *rung, int lowest_active, unsigned *order,
@@ -461,12 +513,16 @@ int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
 int cgk_shortrange_sweep_tiles(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
                                const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
                                const unsigned *off_s, i64 nt, const double *table,
-                               double r2_index_scaling, double r2_max, double factor,
-                               const double *factors, const signed char *rung_jumped) {
+                               int64_t tablesize, double r2_index_scaling, double r2_max,
+                               double factor, const double *factors,
+                               const signed char *rung_jumped) {
     const double eps = 2.220446049250313e-16;
     const double ext = c->p.boxsize / (double)nt;  // species.py:607-609
     SrmParams P{c->p.boxsize, ext, 1.0 / ext, (1 / ext) * (1 - 2 * eps), r2_index_scaling, r2_max,
-                factor, factors, rung_jumped, (int)nt};
+                factor, factors, rung_jumped, (int)nt, (int)tablesize};
+#if SRM_LDS_TABLE
+    CG_CHECK(tablesize <= kTableLds, "cg_shortrange_sweep_tiles: tables of up to %d entries", kTableLds);
+#endif
     hipLaunchKernelGGL(k_sr_sweep_mfma, dim3(kSplit, (unsigned)nt, (unsigned)nt),
                        dim3(64 * kWaves), 0, c->stream, pos_r_sorted, order_r, off_r, dmom_r,
                        pos_s_sorted, off_s, table, P);
