@@ -1053,7 +1053,8 @@ extern "C" int cg_shortrange_sweep_cells_rungs(
 extern "C" int cg_shortrange_tiles(cg_ctx *c, const double *pos, int64_t n, int64_t nt,
                                    double tile_extent, const int8_t *rung,
                                    int lowest_active_rung, uint32_t *order_out,
-                                   uint32_t *offset_out, double *pos_sorted_out) {
+                                   uint32_t *offset_out, double *pos_sorted_out,
+                                   float *operand_out) {
     CG_CHECK(c && offset_out && (n == 0 || (pos && order_out && pos_sorted_out)),
              "cg_shortrange_tiles: null argument");
     CG_CHECK(nt >= 4, "The global gravity tiling needs to have at least 4 tiles across the box in "
@@ -1061,17 +1062,21 @@ extern "C" int cg_shortrange_tiles(cg_ctx *c, const double *pos, int64_t n, int6
     CG_CHECK(nt <= 1024 && n < (1ll << 32), "cg_shortrange_tiles: size out of range");
     CG_CHECK(tile_extent > 0, "cg_shortrange_tiles: tile_extent must be positive");
     return cgk_shortrange_tiles(c, pos, n, nt, tile_extent, (const signed char *)rung,
-                                lowest_active_rung, order_out, offset_out, pos_sorted_out);
+                                lowest_active_rung, order_out, offset_out, pos_sorted_out,
+                                operand_out);
 }
 
 extern "C" int cg_shortrange_sweep_tiles(cg_ctx *c, const double *pos_r_sorted,
                                          const uint32_t *order_r, const uint32_t *offset_r,
                                          double *dmom_r, const double *pos_s_sorted,
-                                         const uint32_t *offset_s, int64_t nt,
-                                         const double *table, int64_t tablesize,
-                                         double r2_index_scaling, double r2_max, double factor,
-                                         const double *factors, const int8_t *rung_jumped_r) {
+                                         const uint32_t *offset_s, const float *operand_s,
+                                         int64_t n_s, int64_t nt, const double *table,
+                                         int64_t tablesize, double r2_index_scaling,
+                                         double r2_max, double factor, const double *factors,
+                                         const int8_t *rung_jumped_r) {
     CG_CHECK(c && offset_r && offset_s && table, "cg_shortrange_sweep_tiles: null argument");
+    CG_CHECK(n_s == 0 || (pos_s_sorted && operand_s),
+             "cg_shortrange_sweep_tiles: the supplier list lacks its positions or operand rows");
     CG_CHECK(nt >= 4 && nt <= 1024, "cg_shortrange_sweep_tiles: nt = %lld", (long long)nt);
     CG_CHECK((factors == nullptr) == (rung_jumped_r == nullptr),
              "cg_shortrange_sweep_tiles: factors and rung_jumped come together");
@@ -1083,8 +1088,9 @@ extern "C" int cg_shortrange_sweep_tiles(cg_ctx *c, const double *pos_r_sorted,
     CG_CHECK(r2_max <= (c->p.boxsize / (double)nt) * (c->p.boxsize / (double)nt) * (1 + 1e-12),
              "cg_shortrange_sweep_tiles: the force range exceeds the tile extent");
     return cgk_shortrange_sweep_tiles(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted,
-                                      offset_s, nt, table, tablesize, r2_index_scaling, r2_max,
-                                      factor, factors, (const signed char *)rung_jumped_r);
+                                      offset_s, operand_s, n_s, nt, table, tablesize,
+                                      r2_index_scaling, r2_max, factor, factors,
+                                      (const signed char *)rung_jumped_r);
 }
 
 extern "C" int cg_dmom_nullify(cg_ctx *c, double *dmom, const int8_t *rung, int64_t n,

@@ -194,12 +194,12 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                                const signed char *rung_jumped, int lowest_active);
 int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
                          const signed char *rung, int lowest_active, unsigned *order,
-                         unsigned *offset, double *pos_sorted);
+                         unsigned *offset, double *pos_sorted, float *aop);
 int cgk_shortrange_sweep_tiles(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
                                const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
-                               const unsigned *off_s, i64 nt, const double *table,
-                               int64_t tablesize, double r2_index_scaling, double r2_max,
-                               double factor, const double *factors,
+                               const unsigned *off_s, const float *aop_s, i64 n_s, i64 nt,
+                               const double *table, int64_t tablesize, double r2_index_scaling,
+                               double r2_max, double factor, const double *factors,
                                const signed char *rung_jumped);
 int cgk_dmom_active(cg_ctx *c, double *mom, double *dmom, const signed char *rung, i64 n,
                     int lowest_active, int op);

@@ -13,30 +13,37 @@
 // subtiles.  On CDNA4 the cheaper answer is to make the misses (almost) free: the squared
 // distance of every (receiver, supplier) pair of a 16 x 16 block is one single-precision
 // matrix product on the matrix cores,
-//       D[i][j] = [-2x_j, -2y_j, -2z_j, |u_j|^2] . [x_i, y_i, z_i, 1]  +  (|u_i|^2 - r2_pre)
-//               = |u_i - u_j|^2 - r2_pre                       (v_mfma_f32_16x16x4_f32)
-// with coordinates u relative to a local origin in units of the tile extent, so that the sign
-// bit of D says "possibly in range" — 256 pair tests per instruction on a pipe of its own,
-// beside the vector ALU.  r2_pre sits above r2_max by more than single-precision rounding can
-// move a distance (bound below), so the filter never drops a pair; the pairs it lets through
-// are then evaluated in FP64 exactly as before — (xi - xj) + offset, x*x + y*y + z*z, the range
-// test, int(r2*scaling): every contribution is bit-identical to the cells sweep's, only the
-// order of the additions differs.  No MFMA result ever reaches the momenta.
+//       D[i][j] = [-2x_j, -2y_j, -2z_j, |v_j|^2] . [x_i, y_i, z_i, 1]  +  (|u_i|^2 - r2_pre)
+//               = |u_i - v_j|^2 - r2_pre                       (v_mfma_f32_16x16x4_f32)
+// so that the sign bit of D says "possibly in range" — 256 pair tests per instruction on a
+// pipe of its own, beside the vector ALU.  r2_pre sits above r2_max by more than
+// single-precision rounding can move a distance (bound below), so the filter never drops a
+// pair; the pairs it lets through (measured: hits + 0.1 %) are then evaluated in FP64 exactly
+// as before — (xi - xj) + offset, x*x + y*y + z*z, the range test, int(r2*scaling): every
+// contribution is bit-identical to the cells sweep's, only the order of the additions differs.
+// No MFMA result ever reaches the momenta.
+//
+// Coordinates of the products.  A supplier's row of the A operand, (-2v, |v|^2), is written
+// once, when the list is built: v = position / tile extent - (tile x, tile y, first tile of
+// its block of kZB tiles in z) — a local coordinate that does not depend on who asks.  The
+// receiver side u is the receiver's position relative to that same corner, unwrapped across
+// the box faces: a periodic image costs a different corner, not a different operand.
 //
 // Layout of the work (density-adaptive by construction: the units are COUNTS, not volumes):
-//  * particles sorted by tile, z fastest (cg_shortrange_tiles), positions copied in that order;
+//  * particles listed by tile, z fastest (cg_shortrange_tiles), positions copied in that order;
 //  * a wavefront takes 16 consecutive receivers of a tile column — wherever the tile borders
 //    fall: a dense tile is many such rows, a void is one row over many tiles — four lanes per
 //    receiver, each lane four supplier rows of every 16-row block;
-//  * a workgroup (8 wavefronts, 128 consecutive receivers) stages the suppliers of the 3 x 3
-//    neighbouring columns slab by slab in z (a slab = the 9 tiles of one z), in windows of
-//    kW rows: a wavefront's suppliers — slabs tz0-1 .. tz1+1 of its receivers' tiles — are
-//    one contiguous range of the staged sequence;
-//  * per 512 rows: the matrix products, four sign bits per product shifted into four mask
-//    registers per lane; then the lanes walk their masks independently (count leading
-//    zeros -> supplier row), one FP64 pair per trip.
-// Periodic images: a supplier row of an image tile carries a 6-bit code of its offset
-// (-L, 0, +L per dimension), added as the reference does, (xi - xj) + offset.
+//  * a workgroup (8 wavefronts, 128 consecutive receivers) copies the suppliers its receivers
+//    can reach — the 3 x 3 neighbouring columns over the tiles TZ0-1 .. TZ1+1, nine
+//    contiguous runs of the list — into LDS once (FP64 positions only: they are what the
+//    candidates read at random), then its wavefronts work on their own: no barrier until the
+//    next 128 receivers;
+//  * a wavefront walks the nine runs over its own tiles tz0-1 .. tz1+1: operand rows straight
+//    from the list (coalesced 256-byte reads, L2), one product per 16 rows, four sign bits per
+//    product shifted into mask words; then the lanes walk their masks independently (count
+//    leading zeros -> block -> row), one FP64 pair per trip, software-pipelined over three
+//    trips (positions, table entry, accumulation).
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
@@ -57,26 +64,30 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kW = 640;               // supplier rows staged per window
-constexpr int kSlack = 64;            // rows past a window a started group of 4 blocks may read
-constexpr int kRows = kW + kSlack;
-constexpr int kSlabs = 14;            // z slabs per piece table
-constexpr int kWaves = 8;             // wavefronts per workgroup, 16 receivers each
+#ifndef SRM_LDS_TABLE
+#define SRM_LDS_TABLE 0               // 1: the short-range table in LDS (32 KB per workgroup)
+#endif
+#ifndef SRM_WAVES
+#define SRM_WAVES 8
+#endif
+#ifndef SRM_CAP
+#define SRM_CAP (SRM_LDS_TABLE ? 1792 : 1920)
+#endif
+constexpr int kZB = 16;               // tiles per z block of the operand coordinates
+constexpr int kCap = SRM_CAP;         // supplier rows a workgroup holds in LDS (< 2048)
+constexpr int kSlabs = 32;            // z slabs (tiles along z) per piece table
+constexpr int kPieces = 64;           // pieces: 9 columns x runs of slabs
+constexpr int kWaves = SRM_WAVES;     // wavefronts per workgroup, 16 receivers each
 constexpr int kChunk = 16 * kWaves;   // receivers per workgroup and chunk
-constexpr int kBatch = 512;           // rows per mask batch: 4 words x 8 blocks x 16 rows
+constexpr int kWords = 6;             // mask words per batch: 6 x 8 blocks x 16 rows
 constexpr int kSplit = 4;             // workgroups per tile column (chunks dealt round robin)
+[[maybe_unused]] constexpr int kTableLds = 4096;  // entries of the short-range table kept in LDS
+static_assert(kCap < 2048 && kWords * 8 <= 64 && 9 * 7 <= kPieces, "packing of the block table");
 
 // Tiling.sort (species.py:775-780) with tiling location 0
 __device__ __forceinline__ unsigned srm_tile1(double x, double inv, unsigned nt) {
     unsigned t = (unsigned)(i64)((x - 0.0) * inv);
     return t >= nt ? nt - 1 : t;
-}
-__device__ __forceinline__ unsigned srm_tile(const double *__restrict__ pos, i64 p, double inv,
-                                             unsigned nt) {
-    const unsigned i = srm_tile1(pos[3 * p + 0], inv, nt);
-    const unsigned j = srm_tile1(pos[3 * p + 1], inv, nt);
-    const unsigned k = srm_tile1(pos[3 * p + 2], inv, nt);
-    return (i * nt + j) * nt + k;
 }
 
 // runs of equal keys inside a wavefront -> one atomic per run
@@ -94,8 +105,28 @@ __device__ __forceinline__ void srm_wave_runs(unsigned key, int lane, int &run_s
 
 constexpr unsigned kNoKey = 0xffffffffu;
 
+struct SrmKey {
+    unsigned key, gx, gy, gz;
+    double x, y, z;
+};
 // (rung != null: only the particles on rungs >= lowest_active are listed — the receivers of a
 // sub-step, gravity.py:318-349 through the tiles' active rungs)
+__device__ __forceinline__ SrmKey srm_key(const double *__restrict__ pos, i64 p, i64 n, double inv,
+                                          unsigned nt, const signed char *__restrict__ rung,
+                                          int lowest_active) {
+    SrmKey k;
+    k.key = kNoKey;
+    k.gx = k.gy = k.gz = 0;
+    k.x = k.y = k.z = 0;
+    if (p < n && !(rung && rung[p] < lowest_active)) {
+        k.x = pos[3 * p], k.y = pos[3 * p + 1], k.z = pos[3 * p + 2];
+        k.gx = srm_tile1(k.x, inv, nt);
+        k.gy = srm_tile1(k.y, inv, nt);
+        k.gz = srm_tile1(k.z, inv, nt);
+        k.key = (k.gx * nt + k.gy) * nt + k.gz;
+    }
+    return k;
+}
 __global__ __launch_bounds__(256) void k_srm_histogram(const double *__restrict__ pos, i64 n,
                                                        double inv, unsigned nt,
                                                        const signed char *__restrict__ rung,
@@ -103,35 +134,44 @@ __global__ __launch_bounds__(256) void k_srm_histogram(const double *__restrict_
                                                        unsigned *__restrict__ count) {
     const int lane = threadIdx.x & 63;
     const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned key = kNoKey;
-    if (p < n && !(rung && rung[p] < lowest_active)) key = srm_tile(pos, p, inv, nt);
+    const SrmKey k = srm_key(pos, p, n, inv, nt, rung, lowest_active);
     int rs, rl;
-    srm_wave_runs(key, lane, rs, rl);
-    if (lane == rs && key != kNoKey) atomicAdd(&count[key], (unsigned)rl);
+    srm_wave_runs(k.key, lane, rs, rl);
+    if (lane == rs && k.key != kNoKey) atomicAdd(&count[k.key], (unsigned)rl);
 }
 __global__ __launch_bounds__(256) void k_srm_scatter(const double *__restrict__ pos, i64 n,
-                                                     double inv, unsigned nt,
+                                                     double inv, double inv_ext, unsigned nt,
                                                      const signed char *__restrict__ rung,
                                                      int lowest_active,
                                                      const unsigned *__restrict__ offset,
                                                      unsigned *__restrict__ cursor,
                                                      unsigned *__restrict__ order,
-                                                     double *__restrict__ pos_sorted) {
+                                                     double *__restrict__ pos_sorted,
+                                                     f32x4 *__restrict__ aop) {
     const int lane = threadIdx.x & 63;
     const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned key = kNoKey;
-    if (p < n && !(rung && rung[p] < lowest_active)) key = srm_tile(pos, p, inv, nt);
+    const SrmKey k = srm_key(pos, p, n, inv, nt, rung, lowest_active);
     int rs, rl;
-    srm_wave_runs(key, lane, rs, rl);
+    srm_wave_runs(k.key, lane, rs, rl);
     unsigned first = 0;
-    if (lane == rs && key != kNoKey) first = offset[key] + atomicAdd(&cursor[key], (unsigned)rl);
+    if (lane == rs && k.key != kNoKey)
+        first = offset[k.key] + atomicAdd(&cursor[k.key], (unsigned)rl);
     first = __shfl(first, rs);
-    if (key != kNoKey) {
+    if (k.key != kNoKey) {
         const i64 q = (i64)first + (lane - rs);
         order[q] = (unsigned)p;
-        pos_sorted[3 * q] = pos[3 * p];
-        pos_sorted[3 * q + 1] = pos[3 * p + 1];
-        pos_sorted[3 * q + 2] = pos[3 * p + 2];
+        pos_sorted[3 * q] = k.x;
+        pos_sorted[3 * q + 1] = k.y;
+        pos_sorted[3 * q + 2] = k.z;
+        if (aop) {
+            // the A operand of the range products: coordinates relative to the corner of the
+            // particle's own tile (z: of its block of kZB tiles), unit = tile extent
+            const float vx = (float)(k.x * inv_ext - (double)k.gx),
+                        vy = (float)(k.y * inv_ext - (double)k.gy),
+                        vz = (float)(k.z * inv_ext - (double)(k.gz - k.gz % kZB));
+            const f32x4 a4 = {-2.0f * vx, -2.0f * vy, -2.0f * vz, vx * vx + vy * vy + vz * vz};
+            aop[q] = a4;
+        }
     }
 }
 
@@ -146,6 +186,7 @@ struct SrmParams {
     double boxsize, ext, inv_ext, inv_tile, r2_index_scaling, r2_max, factor;
     const double *factors;          // adaptive rungs: factors[rung_jumped[i]] per receiver
     const signed char *rung_jumped;
+    i64 n_s;                        // rows of the supplier list
     int nt, tablesize;
 };
 
@@ -160,79 +201,147 @@ __device__ __forceinline__ unsigned srm_wave_scan(unsigned v) {
     return v;
 }
 
-#ifndef SRM_LDS_TABLE
-#define SRM_LDS_TABLE 1
-#endif
-constexpr int kTableLds = 4096;   // entries of the short-range table kept in LDS
 struct SrmShared {
-    double sx[kRows], sy[kRows], sz[kRows];   // staged supplier positions (FP64, as stored)
-    f32x4 fa[kRows];                          // (-2u_x, -2u_y, -2u_z, |u|^2): the A operand
-    unsigned char simg[kRows];                // image code of the row: (ix, iy, iz) 2 bits each
-    unsigned pbeg[128], ppre[130];            // piece table: first source row, prefix of the counts
-    unsigned char pimg[128];
-    double ltab[4];                           // image code -> offset: -L, 0, +L
+    double sx[kCap], sy[kCap], sz[kCap];    // the suppliers' positions (FP64, as stored)
+    unsigned char simg[kCap];               // image code of the row: (ix, iy, iz) 2 bits each
+    unsigned tstart[9][kSlabs], tend[9][kSlabs];  // list rows of tile (column c, slab s)
+    // pieces: column c9 over the slabs [ps0, ps1) — a run of the list without a box face or a
+    // z-block border inside — in the order (c9, slab)
+    unsigned pbeg[kPieces], ppre[kPieces + 1];
+    short ps0[kPieces], ps1[kPieces], pgx[kPieces], pgy[kPieces], pzb[kPieces];
+    unsigned char pimg[kPieces];
+    int nseg;                               // pieces per column
+    double ltab[4];                         // image code -> offset: -L, 0, +L
 #if SRM_LDS_TABLE
-    double table[kTableLds];                  // the short-range table (gravity.py:373-424)
+    double table[kTableLds];                // the short-range table (gravity.py:373-424)
 #endif
 };
 
-// The lanes' candidates: each lane walks its own masks — bit t of a word (from the top) is row
-// 16 (t / 4) + 4 g + (t % 4) of the word's 128 rows — one exact FP64 pair per trip, in the
-// reference's operation order (interactions.py:1787-1789, gravity.py:299-321).
+// The lanes' candidates.  Each lane walks its own masks, one exact FP64 pair per trip in the
+// reference's operation order (interactions.py:1787-1789, gravity.py:299-321), as a software
+// pipeline of four stages over four trips, so that no trip waits for what it asked for itself:
+//   S1  next set bit of the masks -> block; ask lane `block` for the block's entry (bpermute)
+//   S2  entry -> LDS row; ask for the supplier's position
+//   S3  x_ji, r2, range test, table index; ask for the table entry
+//   S4  the three multiply-adds
+// The loop body is two trips with the two register sets swapped, so that nothing loaded is
+// ever copied (a copy would wait for it).
+struct SrmMasks {
+    unsigned m[kWords];
+    int wc;  // first block of word m[0]
+};
+struct SrmBit {   // S1 -> S2
+    bool have;
+    unsigned r;   // row of the block: 4 g + t % 4
+    unsigned e;   // the block's entry: first LDS row | rows inside the wave's range << 11
+};
+struct SrmPos {   // S2 -> S3
+    bool ok;
+    double sx, sy, sz;
+    unsigned img;
+};
+struct SrmEv {    // S3 -> S4
+    double x, y, z, t;
+    bool hit;
+};
+__device__ __forceinline__ bool srm_left(const SrmMasks &M) {
+    unsigned any = 0;
+#pragma unroll
+    for (int w = 0; w < kWords; w++) any |= M.m[w];
+    return any != 0;
+}
 template <bool FACE>
-__device__ __forceinline__ void srm_candidates(unsigned m0, unsigned m1, unsigned m2, unsigned m3,
-                                               int rowb, int bend, double xi, double yi, double zi,
-                                               const SrmShared &S, double r2_max,
-                                               double r2_index_scaling,
-                                               const double *table, double &ax,
-                                               double &ay, double &az) {
-    for (;;) {
-        if (m0 == 0) {  // this lane's word is used up: the next one moves down
-            m0 = m1;
-            m1 = m2;
-            m2 = m3;
-            m3 = 0;
-            rowb += 128;
-        }
-        if (!__any((m0 | m1 | m2) != 0)) break;
-        const bool have = m0 != 0;
-#ifdef SRM_PROBE_COUNT
-        if ((threadIdx.x & 63) == 0) SRM_COUNT(0, 1);
-        SRM_COUNT(1, have ? 1 : 0);
-#endif
-        const int t = have ? __clz((int)m0) : 0;
-        m0 = have ? (m0 ^ (0x80000000u >> t)) : 0u;
-        const int row = rowb + ((t & ~3) << 2) + (t & 3);
-        const bool ok = have && row < bend;   // (a started block may reach past the range)
-        const int rr = ok ? row : 0;
-        double x_ji = xi - S.sx[rr];          // interactions.py:1787-1789
-        double y_ji = yi - S.sy[rr];
-        double z_ji = zi - S.sz[rr];
-        if (FACE) {                           // gravity.py:299-302
-            const unsigned c = S.simg[rr];
-            x_ji += S.ltab[c & 3];
-            y_ji += S.ltab[(c >> 2) & 3];
-            z_ji += S.ltab[(c >> 4) & 3];
+__device__ __forceinline__ void srm_trip(SrmMasks &M, unsigned btab, int g, double xi, double yi,
+                                         double zi, const SrmShared &S, double boxsize,
+                                         double r2_max, double r2_index_scaling,
+                                         const double *table, const SrmBit &bin, SrmBit &bout,
+                                         const SrmPos &pin, SrmPos &pout, const SrmEv &ein,
+                                         SrmEv &eout, double &ax, double &ay, double &az) {
+    // S4 (a miss has read entry 0 of the table: it counts for nothing)
+    {
+        const double t = ein.hit ? ein.t : 0.0;
+        ax = __builtin_fma(ein.x, t, ax);
+        ay = __builtin_fma(ein.y, t, ay);
+        az = __builtin_fma(ein.z, t, az);
+    }
+    // S3
+    {
+        double x_ji = xi - pin.sx;            // interactions.py:1787-1789
+        double y_ji = yi - pin.sy;
+        double z_ji = zi - pin.sz;
+        if (FACE) {                           // gravity.py:299-302: + the image's offset,
+            // -L, 0 or +L from the row's code (a product with -1, 0 or 1 is exact)
+            x_ji += (double)((int)(pin.img & 3) - 1) * boxsize;
+            y_ji += (double)((int)((pin.img >> 2) & 3) - 1) * boxsize;
+            z_ji += (double)((int)((pin.img >> 4) & 3) - 1) * boxsize;
         }
         const double r2 = x_ji * x_ji + y_ji * y_ji + z_ji * z_ji;  // gravity.py:306
-        const bool hit = ok && r2 <= r2_max;                          // gravity.py:311
+        const bool hit = pin.ok && r2 <= r2_max;                      // gravity.py:311
 #ifdef SRM_PROBE_COUNT
+        SRM_COUNT(1, pin.ok ? 1 : 0);
         SRM_COUNT(2, hit ? 1 : 0);
-        SRM_COUNT(4, ok ? 1 : 0);
+        if ((threadIdx.x & 63) == 0) SRM_COUNT(0, 1);
 #endif
-        double tv = 0.0;
-        if (hit) tv = table[(unsigned)(int)(r2 * r2_index_scaling)];  // gravity.py:316-321
-        ax = __builtin_fma(x_ji, tv, ax);
-        ay = __builtin_fma(y_ji, tv, ay);
-        az = __builtin_fma(z_ji, tv, az);
+        const unsigned idx = hit ? (unsigned)(int)(r2 * r2_index_scaling) : 0u;  // gravity.py:316
+        eout.x = x_ji, eout.y = y_ji, eout.z = z_ji;
+        eout.t = table[idx];                                                     // gravity.py:321
+        eout.hit = hit;
+    }
+    // S2
+    {
+        pout.ok = bin.have && bin.r < (bin.e >> 11);
+        const unsigned row = pout.ok ? (bin.e & 0x7ffu) + bin.r : 0u;
+        pout.sx = S.sx[row];
+        pout.sy = S.sy[row];
+        pout.sz = S.sz[row];
+        pout.img = FACE ? S.simg[row] : 0x15u;
+    }
+    // S1
+    {
+        if (M.m[0] == 0) {  // this lane's word is used up: the next ones move down
+#pragma unroll
+            for (int w = 0; w + 1 < kWords; w++) M.m[w] = M.m[w + 1];
+            M.m[kWords - 1] = 0;
+            M.wc += 8;
+        }
+        bout.have = M.m[0] != 0;
+        const int t = bout.have ? __clz((int)M.m[0]) : 0;
+        M.m[0] = bout.have ? (M.m[0] ^ (0x80000000u >> t)) : 0u;
+        // bit t of a word (from the top) = block t / 4 of the word, row 4 g + t % 4 of it
+        const int blk = (M.wc + (t >> 2)) & 63;
+        bout.e = (unsigned)__builtin_amdgcn_ds_bpermute(4 * blk, (int)btab);
+        bout.r = 4u * (unsigned)g + (unsigned)(t & 3);
+    }
+}
+template <bool FACE>
+__device__ __forceinline__ void srm_candidates(SrmMasks M, unsigned btab, int g, double xi,
+                                               double yi, double zi, const SrmShared &S,
+                                               double boxsize, double r2_max,
+                                               double r2_index_scaling, const double *table,
+                                               double &ax, double &ay, double &az) {
+    SrmBit b0 = {false, 0, 0}, b1 = {false, 0, 0};
+    SrmPos p0 = {false, 0, 0, 0, 0x15u}, p1 = {false, 0, 0, 0, 0x15u};
+    SrmEv e0 = {0, 0, 0, 0, false}, e1 = {0, 0, 0, 0, false};
+    int idle = 0;  // trips since the masks ran dry: three more empty what is under way
+    for (;;) {
+        if (!__any(srm_left(M)) && ++idle > 3) break;
+        srm_trip<FACE>(M, btab, g, xi, yi, zi, S, boxsize, r2_max, r2_index_scaling, table, b0, b1,
+                       p0, p1, e0, e1, ax, ay, az);
+        if (!__any(srm_left(M)) && ++idle > 3) break;
+        srm_trip<FACE>(M, btab, g, xi, yi, zi, S, boxsize, r2_max, r2_index_scaling, table, b1, b0,
+                       p1, p0, e1, e0, ax, ay, az);
     }
 }
 
-__global__ __launch_bounds__(64 * kWaves) void k_sr_sweep_mfma(
+#ifndef SRM_WAVES_PER_EU
+#define SRM_WAVES_PER_EU 6
+#endif
+__global__ __launch_bounds__(64 * kWaves)
+__attribute__((amdgpu_waves_per_eu(SRM_WAVES_PER_EU, 8))) void k_sr_sweep_mfma(
     const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
     const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
     const double *__restrict__ pos_s, const unsigned *__restrict__ off_s,
-    const double *__restrict__ table, SrmParams P) {
+    const f32x4 *__restrict__ aop_s, const double *__restrict__ table, SrmParams P) {
     __shared__ SrmShared S;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -242,7 +351,7 @@ __global__ __launch_bounds__(64 * kWaves) void k_sr_sweep_mfma(
     const unsigned col = (unsigned)(ta * nt + tb) * (unsigned)nt;
     const unsigned qc0 = __builtin_amdgcn_readfirstlane(off_r[col]),
                    qc1 = __builtin_amdgcn_readfirstlane(off_r[col + nt]);
-    if (qc0 == qc1) return;
+    if (qc0 + (unsigned)kChunk * blockIdx.x >= qc1) return;
     if (tid < 4) S.ltab[tid] = tid == 0 ? -P.boxsize : (tid == 2 ? P.boxsize : 0.0);
 #if SRM_LDS_TABLE
     for (int e = tid; e < P.tablesize; e += 64 * kWaves) S.table[e] = table[e];
@@ -251,8 +360,15 @@ __global__ __launch_bounds__(64 * kWaves) void k_sr_sweep_mfma(
     const double *tbl = table;
 #endif
     const bool xyface = ta == 0 || ta == nt - 1 || tb == 0 || tb == nt - 1;
-    const double ox = (ta + 0.5) * P.ext, oy = (tb + 0.5) * P.ext;
-    const float rc2u = (float)(P.r2_max * P.inv_ext * P.inv_ext);
+    const float *aop1 = (const float *)aop_s;
+    // The filter's threshold.  |u - v| <= kZB + 2 along z and 3 across; error of D against the
+    // exact |u - v|^2: the coordinates' rounding moves a distance d ~ 1 by 2 sqrt(3) 2^-24
+    // |u|max, i.e. d^2 by ~7 eps |u|max; the two norms carry 3 eps n2max each and the four fused
+    // multiply-adds of the product 2 eps n2max each: below eps (14 n2max + 7 |u|max).  Twice
+    // that on top of r2_max.
+    const float umax = (float)(kZB + 2), n2max = umax * umax + 8.0f;
+    const float r2pre = (float)(P.r2_max * P.inv_ext * P.inv_ext) +
+                        2.0f * 5.9604645e-08f * (14.0f * n2max + 7.0f * (umax + kSlabs + kZB));
 
     for (unsigned qa = qc0 + (unsigned)kChunk * blockIdx.x; qa < qc1;
          qa += (unsigned)kChunk * gridDim.x) {
@@ -277,161 +393,200 @@ __global__ __launch_bounds__(64 * kWaves) void k_sr_sweep_mfma(
             tz1 = __builtin_amdgcn_readlane(tzl, nv - 1);
         }
         const bool wface = xyface || tz0 - 1 < 0 || tz1 + 1 >= nt;
+        // the receiver in units of the tile extent (FP64: the corners are subtracted exactly)
+        // and in single precision relative to the column's corner at the group's first slab: a
+        // piece's corner is a whole number of tiles from there (one rounding more, below the
+        // margin of r2_pre)
+        const float fx = (float)(xi * P.inv_ext - (double)ta), fy = (float)(yi * P.inv_ext - (double)tb);
         double ax = 0, ay = 0, az = 0;
 
         for (int zg = TZ0 - 1; zg <= TZ1 + 1; zg += kSlabs) {
             const int ns = min(kSlabs, TZ1 + 2 - zg);  // slabs zg .. zg + ns - 1
-            __syncthreads();  // everybody is done with the previous table and window
-            if (wave == 0) {
-                // piece p = slab * 9 + column: tile (ta + p/3 % 3 - 1, tb + p % 3 - 1, zg + slab)
-                unsigned beg[2], cnt[2], img[2];
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const int p = 2 * lane + e;
-                    beg[e] = cnt[e] = 0;
-                    img[e] = 0x15;
-                    if (p < 9 * ns) {
-                        const int s = p / 9, c9 = p - 9 * s;
-                        int gx = ta + c9 / 3 - 1, gy = tb + c9 % 3 - 1, gz = zg + s;
-                        unsigned ix = 1, iy = 1, iz = 1;
-                        // periodic offset from the tile separation (interactions.py:1615-1621)
-                        if (gx < 0) { gx += nt; ix = 2; } else if (gx >= nt) { gx -= nt; ix = 0; }
-                        if (gy < 0) { gy += nt; iy = 2; } else if (gy >= nt) { gy -= nt; iy = 0; }
-                        if (gz < 0) { gz += nt; iz = 2; } else if (gz >= nt) { gz -= nt; iz = 0; }
-                        const unsigned t = ((unsigned)gx * nt + (unsigned)gy) * nt + (unsigned)gz;
-                        beg[e] = off_s[t];
-                        cnt[e] = off_s[t + 1] - beg[e];
-                        img[e] = ix | (iy << 2) | (iz << 4);
-                    }
-                }
-                const unsigned incl = srm_wave_scan(cnt[0] + cnt[1]);
-                const unsigned excl = incl - (cnt[0] + cnt[1]);
-                S.pbeg[2 * lane] = beg[0];
-                S.pbeg[2 * lane + 1] = beg[1];
-                S.pimg[2 * lane] = (unsigned char)img[0];
-                S.pimg[2 * lane + 1] = (unsigned char)img[1];
-                S.ppre[2 * lane] = excl;
-                S.ppre[2 * lane + 1] = excl + cnt[0];
-                if (lane == 63) S.ppre[128] = incl;
+            const float fz = (float)(zi * P.inv_ext - (double)zg);
+            __syncthreads();  // everybody is done with the previous tables and rows
+            // list rows of every tile (column c9, slab s) of this group
+            for (int e = tid; e < 9 * ns; e += 64 * kWaves) {
+                const int c9 = e / ns, s = e - c9 * ns;
+                int gx = ta + c9 / 3 - 1, gy = tb + c9 % 3 - 1, gz = zg + s;
+                gx = gx < 0 ? gx + nt : (gx >= nt ? gx - nt : gx);
+                gy = gy < 0 ? gy + nt : (gy >= nt ? gy - nt : gy);
+                gz = gz < 0 ? gz + nt : (gz >= nt ? gz - nt : gz);
+                const unsigned t = ((unsigned)gx * nt + (unsigned)gy) * nt + (unsigned)gz;
+                S.tstart[c9][s] = off_s[t];
+                S.tend[c9][s] = off_s[t + 1];
             }
             __syncthreads();
-            const unsigned total = S.ppre[9 * ns];
-            // single-precision coordinates: origin at the centre of the column and of the slabs,
-            // unit = tile extent.  |u| <= 1.5 across, uzmax along z.  Error of D against the
-            // exact |u_i - u_j|^2: the coordinates' rounding moves a distance d ~ 1 by
-            // 2 sqrt(3) 2^-24 |u|max, i.e. d^2 by ~7 eps |u|max; the two norms carry 3 eps n2max
-            // each and the four fused multiply-adds of the product 2 eps n2max each: below
-            // eps (14 n2max + 7 |u|max).  Twice that on top of r2_max.
-            const double oz = (zg + 0.5 * ns) * P.ext;
-            const float uzmax = 0.5f * (float)ns + 1.5f;
-            const float n2max = 8.0f + uzmax * uzmax;
-            const float r2pre = rc2u + 2.0f * 5.9604645e-08f * (14.0f * n2max + 7.0f * uzmax);
-            const float ux = (float)((xi - ox) * P.inv_ext), uy = (float)((yi - oy) * P.inv_ext),
-                        uz = (float)((zi - oz) * P.inv_ext);
-            const float cval = valid ? (ux * ux + uy * uy + uz * uz) - r2pre : 1e30f;
-            const f32x4 cvec = {cval, cval, cval, cval};
-            const float bq = g == 0 ? ux : (g == 1 ? uy : (g == 2 ? uz : 1.0f));
-            // this wave's suppliers: slabs tz0 - 1 .. tz1 + 1, rows [RA, RB) of the sequence
-            int RA = 0, RB = 0;
-            if (wvalid) {
-                const int sa = max(tz0 - 1, zg), sb = min(tz1 + 1, zg + ns - 1);
-                if (sa <= sb) {
-                    RA = (int)S.ppre[9 * (sa - zg)];
-                    RB = (int)S.ppre[9 * (sb - zg + 1)];
+            if (wave == 0) {
+                // a piece starts at slab 0 of the group, below and above the box (a periodic
+                // image: another offset) and at the first tile of every z block (another
+                // corner of the operand coordinates)
+                unsigned flags = 0;
+                for (int s = 0; s < ns; s++) {
+                    const int z = zg + s, gz = z < 0 ? z + nt : (z >= nt ? z - nt : z);
+                    if (s == 0 || z == 0 || z == nt || gz % kZB == 0) flags |= 1u << s;
                 }
+                const int nseg = __popc(flags);
+                unsigned beg = 0, cnt = 0;
+                if (lane < 9 * nseg) {
+                    const int c9 = lane / nseg, k = lane - c9 * nseg;
+                    unsigned f = flags;
+                    for (int i = 0; i < k; i++) f &= f - 1;
+                    const int s0 = __ffs((int)f) - 1;
+                    f &= f - 1;
+                    const int s1 = f ? __ffs((int)f) - 1 : ns;
+                    const int gx = ta + c9 / 3 - 1, gy = tb + c9 % 3 - 1, z0 = zg + s0;
+                    // periodic offset from the tile separation (interactions.py:1615-1621)
+                    const unsigned ix = gx < 0 ? 2 : (gx >= nt ? 0 : 1),
+                                   iy = gy < 0 ? 2 : (gy >= nt ? 0 : 1),
+                                   iz = z0 < 0 ? 2 : (z0 >= nt ? 0 : 1);
+                    const int gz0 = z0 < 0 ? z0 + nt : (z0 >= nt ? z0 - nt : z0);
+                    beg = S.tstart[c9][s0];               // (the tiles of a piece follow each
+                    cnt = S.tend[c9][s1 - 1] - beg;       // other in the list)
+                    S.ps0[lane] = (short)s0;
+                    S.ps1[lane] = (short)s1;
+                    S.pgx[lane] = (short)gx;
+                    S.pgy[lane] = (short)gy;
+                    S.pzb[lane] = (short)(z0 - gz0 % kZB);  // unwrapped first tile of the z block
+                    S.pimg[lane] = (unsigned char)(ix | (iy << 2) | (iz << 4));
+                }
+                const unsigned incl = srm_wave_scan(cnt);
+                S.pbeg[lane] = beg;
+                S.ppre[lane] = incl - cnt;
+                if (lane == 63) S.ppre[64] = incl;
+                if (lane == 0) S.nseg = nseg;
             }
-            for (unsigned r0 = 0; r0 < total;) {
-                unsigned r1 = min(total, r0 + (unsigned)kW);
-                if (r1 < total) {  // cut at a slab boundary when one falls into the window
-                    unsigned best = 0;
-                    for (int s = 1; s < ns; s++) {
-                        const unsigned e = S.ppre[9 * s];
-                        if (e > r0 && e <= r0 + (unsigned)kW) best = e;
-                    }
-                    if (best) r1 = best;
-                }
+            __syncthreads();
+            const int nseg = S.nseg, np = 9 * nseg;
+            const unsigned total = S.ppre[np];
+
+            for (unsigned r0 = 0; r0 < total; r0 += kCap) {
+                const unsigned r1 = min(total, r0 + (unsigned)kCap);
                 if (r0) __syncthreads();  // the previous window has been consumed
-                const unsigned nw = r1 - r0;
-                for (unsigned w = tid; w < nw + kSlack; w += 64 * kWaves) {
-                    if (w < nw) {
-                        const unsigned row = r0 + w;
-                        int p = 0;  // the piece of this row: ppre[p] <= row < ppre[p + 1]
+                // copy rows [r0, r1) of the sequence: the column first, then the piece in it
+                for (unsigned w = tid; w < r1 - r0; w += 64 * kWaves) {
+                    const unsigned row = r0 + w;
+                    int c9 = 0;
 #pragma unroll
-                        for (int step = 64; step; step >>= 1)
-                            if (S.ppre[p + step] <= row) p += step;
-                        const i64 src = (i64)S.pbeg[p] + (row - S.ppre[p]);
-                        const unsigned c = S.pimg[p];
-                        const double xs = pos_s[3 * src], ys = pos_s[3 * src + 1],
-                                     zs = pos_s[3 * src + 2];
-                        S.sx[w] = xs;
-                        S.sy[w] = ys;
-                        S.sz[w] = zs;
-                        S.simg[w] = (unsigned char)c;
-                        // x_ji = (xi - xj) + offset: the image sits at xj - offset
-                        const float vx = (float)(((xs - S.ltab[c & 3]) - ox) * P.inv_ext),
-                                    vy = (float)(((ys - S.ltab[(c >> 2) & 3]) - oy) * P.inv_ext),
-                                    vz = (float)(((zs - S.ltab[(c >> 4) & 3]) - oz) * P.inv_ext);
-                        const f32x4 a4 = {-2.0f * vx, -2.0f * vy, -2.0f * vz,
-                                          vx * vx + vy * vy + vz * vz};
-                        S.fa[w] = a4;
-                    } else {  // slack: rows that never pass the filter
-                        S.sx[w] = S.sy[w] = S.sz[w] = 0.0;
-                        S.simg[w] = 0x15;
-                        const f32x4 a4 = {0.0f, 0.0f, 0.0f, 1e30f};
-                        S.fa[w] = a4;
-                    }
+                    for (int c = 1; c < 9; c++) c9 += S.ppre[c * nseg] <= row ? 1 : 0;
+                    int p = c9 * nseg;
+                    for (int k = 1; k < nseg; k++) p += S.ppre[c9 * nseg + k] <= row ? 1 : 0;
+                    const i64 src = (i64)S.pbeg[p] + (row - S.ppre[p]);
+                    S.sx[w] = pos_s[3 * src];
+                    S.sy[w] = pos_s[3 * src + 1];
+                    S.sz[w] = pos_s[3 * src + 2];
+                    S.simg[w] = S.pimg[p];
                 }
                 __syncthreads();
-                const int a = max(RA, (int)r0) - (int)r0, b = min(RB, (int)r1) - (int)r0;
-                const float *fa1 = (const float *)S.fa;
 #ifdef SRM_PROBE_NOMFMA
-                const int b_ = a;  // probe build: staging only
-#else
-                const int b_ = b;
+                continue;  // probe build: the copies only
 #endif
-                for (int ba = a; ba < b_; ba += kBatch) {
-                    const int nrows = min(kBatch, b - ba);
-                    const int ngrp = (nrows + 63) >> 6;  // groups of 4 blocks of 16 rows
-                    unsigned m[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                    for (int w = 0; w < 4; w++) {
-#pragma unroll
-                        for (int h = 0; h < 2; h++) {
-                            if (2 * w + h < ngrp) {  // wave-uniform
-#ifdef SRM_PROBE_COUNT
-                                if (lane == 0) SRM_COUNT(3, 4);
-#endif
-                                const int rowg = ba + 64 * (2 * w + h);
-                                float av[4];
-#pragma unroll
-                                for (int k = 0; k < 4; k++) av[k] = fa1[(rowg + 16 * k + j) * 4 + g];
-                                f32x4 d[4];
-#pragma unroll
-                                for (int k = 0; k < 4; k++)
-                                    d[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bq, cvec, 0, 0, 0);
-#pragma unroll
-                                for (int k = 0; k < 4; k++) {
-#pragma unroll
-                                    for (int r = 0; r < 4; r++)
-                                        m[w] = __builtin_amdgcn_alignbit(m[w], __float_as_uint(d[k][r]), 31);
-                                }
-                            } else {
-                                m[w] <<= 16;
-                            }
+                if (!wvalid) continue;
+                // ---- this wave: products over its own rows of every piece, then the pairs ----
+                // (A) lane p: the wave's rows of piece p — slabs tz0 - 1 .. tz1 + 1 — as LDS rows
+                // [pa, pb_) of this window, their first list row and how many 16-row blocks
+                int pa = 0, pb_ = 0, pnblk = 0;
+                unsigned pg0 = 0;
+                float pdx = 0, pdy = 0, pdz = 0;  // the piece's corner relative to (ta, tb, zg)
+                if (lane < np) {
+                    const int c9 = lane / nseg;
+                    const int lo = max((int)S.ps0[lane], tz0 - 1 - zg),
+                              hi = min((int)S.ps1[lane] - 1, tz1 + 1 - zg);
+                    if (lo <= hi) {
+                        const unsigned pb = S.pbeg[lane], pp = S.ppre[lane];
+                        const i64 fa = (i64)pp + (S.tstart[c9][lo] - pb),
+                                  fb = (i64)pp + (S.tend[c9][hi] - pb);
+                        const int a = (int)(max(fa, (i64)r0) - (i64)r0),
+                                  b = (int)(min(fb, (i64)r1) - (i64)r0);
+                        if (b > a) {
+                            pa = a, pb_ = b, pnblk = (b - a + 15) >> 4;
+                            pg0 = pb + (unsigned)((i64)a + (i64)r0 - (i64)pp);
                         }
                     }
-#ifdef SRM_PROBE_NOCAND  // probe build: the matrix products and masks, no pair evaluated
-                    ax += (double)(m[0] ^ m[1] ^ m[2] ^ m[3]) * 1e-300;
-                    continue;
-#endif
-                    if (wface)
-                        srm_candidates<true>(m[0], m[1], m[2], m[3], ba + 4 * g, b, xi, yi, zi, S,
-                                             P.r2_max, P.r2_index_scaling, tbl, ax, ay, az);
-                    else
-                        srm_candidates<false>(m[0], m[1], m[2], m[3], ba + 4 * g, b, xi, yi, zi, S,
-                                              P.r2_max, P.r2_index_scaling, tbl, ax, ay, az);
+                    pdx = (float)((int)S.pgx[lane] - ta);
+                    pdy = (float)((int)S.pgy[lane] - tb);
+                    pdz = (float)((int)S.pzb[lane] - zg);
                 }
-                r0 = r1;
+                const unsigned pincl = srm_wave_scan((unsigned)pnblk);
+                const int pstart = (int)pincl - pnblk;
+                const int NB = __builtin_amdgcn_readlane((int)pincl, 63);  // the wave's blocks
+                for (int B0 = 0; B0 < NB; B0 += 8 * kWords) {
+                    const int nb = min(8 * kWords, NB - B0);  // blocks of this batch (uniform)
+                    // (B) lane b: block B0 + b of the wave's list of blocks -> its piece (first
+                    // lane whose inclusive count exceeds it), LDS rows, list rows
+                    const int fblk = B0 + lane;
+                    int pid = 0;
+#pragma unroll
+                    for (int step = 32; step; step >>= 1) {
+                        const int v = __builtin_amdgcn_ds_bpermute(4 * (pid + step - 1), (int)pincl);
+                        pid += v <= fblk ? step : 0;
+                    }
+                    pid = min(pid, 63);
+                    const int qa_ = __builtin_amdgcn_ds_bpermute(4 * pid, pa),
+                              qb_ = __builtin_amdgcn_ds_bpermute(4 * pid, pb_),
+                              qs_ = __builtin_amdgcn_ds_bpermute(4 * pid, pstart);
+                    const unsigned qg_ = (unsigned)__builtin_amdgcn_ds_bpermute(4 * pid, (int)pg0);
+                    unsigned btab = 0, grow = 0;
+                    if (lane < nb) {
+                        const int first = qa_ + 16 * (fblk - qs_);
+                        btab = (unsigned)first | ((unsigned)min(16, qb_ - first) << 11);
+                        grow = qg_ + 16u * (unsigned)(fblk - qs_);
+                    }
+                    // (C) the products, eight blocks (one mask word) at a time: operand rows
+                    // straight from the list — 16 rows x 16 bytes, one coalesced read
+                    SrmMasks M;
+                    M.wc = 0;
+                    int curpid = -1;
+                    float bq = 0;
+                    f32x4 cvec = {0, 0, 0, 0};
+#pragma unroll
+                    for (int w = 0; w < kWords; w++) {
+                        M.m[w] = 0;
+                        if (8 * w < nb) {  // wave-uniform
+                            float av[8];
+#pragma unroll
+                            for (int i = 0; i < 8; i++) {
+                                // (blocks past the batch: row 0 of the list, their bits are
+                                // never looked at)
+                                const unsigned srow =
+                                    (unsigned)__builtin_amdgcn_readlane((int)grow, 8 * w + i);
+                                av[i] = aop1[4 * ((i64)srow + j) + g];
+                            }
+                            unsigned cur = 0;
+#pragma unroll
+                            for (int i = 0; i < 8; i++) {
+                                const int bp = __builtin_amdgcn_readlane(pid, 8 * w + i);
+                                if (bp != curpid) {  // another piece: the receivers relative
+                                    curpid = bp;     // to its corner
+                                    const float ux = fx - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pdx), bp)),
+                                                uy = fy - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pdy), bp)),
+                                                uz = fz - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pdz), bp));
+                                    const float cval =
+                                        valid ? (ux * ux + uy * uy + uz * uz) - r2pre : 1e30f;
+                                    cvec = f32x4{cval, cval, cval, cval};
+                                    bq = g == 0 ? ux : (g == 1 ? uy : (g == 2 ? uz : 1.0f));
+                                }
+                                const f32x4 d =
+                                    __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bq, cvec, 0, 0, 0);
+                                SRM_COUNT(3, lane == 0 ? 1 : 0);
+#pragma unroll
+                                for (int r = 0; r < 4; r++)
+                                    cur = __builtin_amdgcn_alignbit(cur, __float_as_uint(d[r]), 31);
+                            }
+                            M.m[w] = cur;
+                        }
+                    }
+                    // (D) the pairs
+#ifdef SRM_PROBE_NOCAND
+                    ax += (double)(M.m[0] ^ M.m[1] ^ M.m[2] ^ M.m[3] ^ btab) * 1e-300;
+#else
+                    if (wface)
+                        srm_candidates<true>(M, btab, g, xi, yi, zi, S, P.boxsize, P.r2_max,
+                                             P.r2_index_scaling, tbl, ax, ay, az);
+                    else
+                        srm_candidates<false>(M, btab, g, xi, yi, zi, S, P.boxsize, P.r2_max,
+                                              P.r2_index_scaling, tbl, ax, ay, az);
+#endif
+                }
             }
         }
         // the four lanes of a receiver: one sum, in a fixed order
@@ -468,7 +623,7 @@ extern "C" int cg_srm_debug_counters(unsigned long long *out, int reset) {
 
 int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
                          const signed char *rung, int lowest_active, unsigned *order,
-                         unsigned *offset, double *pos_sorted) {
+                         unsigned *offset, double *pos_sorted, float *aop) {
     const double eps = 2.220446049250313e-16;
     const double inv = (1 / tile_extent) * (1 - 2 * eps);
     const i64 ntiles = nt * nt * nt;
@@ -503,8 +658,8 @@ int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
                                             c->stream));
     if (n > 0) {
         hipLaunchKernelGGL(k_srm_scatter, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n,
-                           inv, (unsigned)nt, rung, lowest_active, offset, cursor, order,
-                           pos_sorted);
+                           inv, 1 / tile_extent, (unsigned)nt, rung, lowest_active, offset, cursor,
+                           order, pos_sorted, (f32x4 *)aop);
         CG_LAUNCH_CHECK();
     }
     return 0;
@@ -512,20 +667,22 @@ int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
 
 int cgk_shortrange_sweep_tiles(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
                                const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
-                               const unsigned *off_s, i64 nt, const double *table,
-                               int64_t tablesize, double r2_index_scaling, double r2_max,
-                               double factor, const double *factors,
+                               const unsigned *off_s, const float *aop_s, i64 n_s, i64 nt,
+                               const double *table, int64_t tablesize, double r2_index_scaling,
+                               double r2_max, double factor, const double *factors,
                                const signed char *rung_jumped) {
     const double eps = 2.220446049250313e-16;
     const double ext = c->p.boxsize / (double)nt;  // species.py:607-609
     SrmParams P{c->p.boxsize, ext, 1.0 / ext, (1 / ext) * (1 - 2 * eps), r2_index_scaling, r2_max,
-                factor, factors, rung_jumped, (int)nt, (int)tablesize};
+                factor, factors, rung_jumped, n_s, (int)nt, (int)tablesize};
 #if SRM_LDS_TABLE
-    CG_CHECK(tablesize <= kTableLds, "cg_shortrange_sweep_tiles: tables of up to %d entries", kTableLds);
+    CG_CHECK(tablesize <= kTableLds, "cg_shortrange_sweep_tiles: tables of up to %d entries",
+             kTableLds);
 #endif
+    if (n_s <= 0) return 0;
     hipLaunchKernelGGL(k_sr_sweep_mfma, dim3(kSplit, (unsigned)nt, (unsigned)nt),
                        dim3(64 * kWaves), 0, c->stream, pos_r_sorted, order_r, off_r, dmom_r,
-                       pos_s_sorted, off_s, table, P);
+                       pos_s_sorted, off_s, (const f32x4 *)aop_s, table, P);
     CG_LAUNCH_CHECK();
     return 0;
 }

@@ -91,9 +91,9 @@ SYMBOLS = {
                                          _dbl, _dbl]),
     'cg_shortrange_sweep_cells_rungs': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64,
                                                _dbl, _dbl, _vp, _vp, _vp, _int]),
-    'cg_shortrange_tiles': (_int, [_vp, _vp, _i64, _i64, _dbl, _vp, _int, _vp, _vp, _vp]),
-    'cg_shortrange_sweep_tiles': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _dbl,
-                                         _dbl, _dbl, _vp, _vp]),
+    'cg_shortrange_tiles': (_int, [_vp, _vp, _i64, _i64, _dbl, _vp, _int, _vp, _vp, _vp, _vp]),
+    'cg_shortrange_sweep_tiles': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64,
+                                         _dbl, _dbl, _dbl, _vp, _vp]),
     'cg_dmom_nullify': (_int, [_vp, _vp, _vp, _i64, _int]),
     'cg_dmom_apply': (_int, [_vp, _vp, _vp, _vp, _i64, _int]),
     'cg_dmom_to_acc': (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp, _int]),

@@ -703,20 +703,26 @@ class PotentialMesh:
 
     def shortrange_tiles(self, pos, nt, tile_extent, active=None):
         """The particles listed by tile (z fastest) with their positions copied in that order
-        (cg_shortrange_tiles): (order, offset, pos_sorted).  active = (rung int8,
-        lowest_active_rung) lists the particles on active rungs only (a sub-step's receivers);
-        the tensors keep room for all n, offset[-1] says how many are listed."""
+        (cg_shortrange_tiles): (order, offset, pos_sorted, operand).  active = (rung int8,
+        lowest_active_rung) lists the particles on active rungs only (a sub-step's receivers:
+        no operand rows); the tensors keep room for all n, offset[-1] says how many are
+        listed."""
         n = self._check_particles(pos)
         order = torch.empty(max(n, 1), dtype=torch.int32, device=pos.device)
         offset = torch.empty(nt**3 + 1, dtype=torch.int32, device=pos.device)
         pos_sorted = torch.empty((max(n, 1), 3), dtype=torch.float64, device=pos.device)
         rung, lowest = (None, 0) if active is None else active
+        operand = None
         if rung is not None:
             self._check_rungs(n, rung)
+        else:
+            # (16 rows of padding: the last 16-row block of the list is read whole)
+            operand = torch.empty((n + 16, 4), dtype=torch.float32, device=pos.device)
         check(_L.cg_shortrange_tiles(self._ctx, _ptr(pos), n, int(nt), float(tile_extent),
                                      _ptr(rung) if rung is not None else None, int(lowest),
-                                     _ptr(order), _ptr(offset), _ptr(pos_sorted)))
-        return order, offset, pos_sorted
+                                     _ptr(order), _ptr(offset), _ptr(pos_sorted),
+                                     _ptr(operand) if operand is not None else None))
+        return order, offset, pos_sorted, operand
 
     def shortrange_sweep_tiles(self, tiles_r, dmom_r, tiles_s, nt, table, r2_index_scaling,
                                r2_max, factor, rungs=None):
@@ -726,15 +732,18 @@ class PotentialMesh:
         n = self._check_particles(dmom_r)
         if table.dtype != torch.float64 or not table.is_cuda:
             raise lib.ConceptGPUError('short-range table must be a float64 CUDA tensor')
-        order_r, off_r, pos_r = tiles_r
-        _, off_s, pos_s = tiles_s
+        order_r, off_r, pos_r = tiles_r[:3]
+        _, off_s, pos_s, op_s = tiles_s
+        if op_s is None:
+            raise lib.ConceptGPUError('the supplier list was built for receivers only')
         factors, rung_jumped = (None, None) if rungs is None else rungs
         if rung_jumped is not None:
             self._check_rungs(n, rung_jumped)
         check(_L.cg_shortrange_sweep_tiles(
             self._ctx, _ptr(pos_r), _ptr(order_r), _ptr(off_r), _ptr(dmom_r), _ptr(pos_s),
-            _ptr(off_s), int(nt), _ptr(table), table.numel(), float(r2_index_scaling),
-            float(r2_max), float(factor), _ptr(factors) if factors is not None else None,
+            _ptr(off_s), _ptr(op_s), pos_s.shape[0], int(nt), _ptr(table), table.numel(),
+            float(r2_index_scaling), float(r2_max), float(factor),
+            _ptr(factors) if factors is not None else None,
             _ptr(rung_jumped) if rung_jumped is not None else None))
 
     SHORTRANGE_SPARSE_MAX = 8

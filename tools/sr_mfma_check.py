@@ -78,6 +78,9 @@ if __name__ == '__main__':
                            (64, 32**3, 'uniform'), (64, 32**3, 'clustered'), (128, 4000, 'void'),
                            (128, 64**3, 'uniform'), (128, 64**3, 'clustered')):
             ok &= run(N, n, dist)
+    if 'dense' in what:  # every tile dense: 128^3 particles on a 64^3 mesh (~1600 per tile)
+        ok &= run(64, 128**3, 'uniform', reps=2)
+        ok &= run(128, 128**3, 'uniform', reps=3)   # ~200 per tile
     if 'big' in what:
         for dist in ('uniform', 'clustered'):
             ok &= run(512, 256**3, dist, reps=3 if 'time' in what else 0)
