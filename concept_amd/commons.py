@@ -137,13 +137,25 @@ def load_params(source=None, **overrides):
         # later one has defined the name it uses (forward references), and h follows H0
         # (commons.py:1790-1792): a file that uses it (boxsize = 200*Mpc/h) before defining H0
         # gets it right on the next pass
-        failed_prev = None
+        # (the reference re-executes every line until the set of lines that ran stops growing,
+        # commons.py:2001-2040; here a pass after the first re-runs only what failed before —
+        # a statement with side effects runs once — unless h changed, which every line that
+        # uses it must see)
+        failed, todo = set(), None   # todo None: everything
         for _ in range(16):
+            failed_prev = failed
             failed = set()
-            try:
-                exec(text, ns)
-            except Exception:
+            whole = False
+            if todo is None:
+                try:
+                    exec(text, ns)
+                    whole = True
+                except Exception:
+                    pass
+            if not whole:
                 for i, st in enumerate(statements):
+                    if todo is not None and i not in todo:
+                        continue
                     try:
                         exec(st, ns)
                     except Exception:
@@ -153,7 +165,7 @@ def load_params(source=None, **overrides):
             ns['h'] = h_new
             if h_same and (not failed or failed == failed_prev):
                 break
-            failed_prev = failed
+            todo = None if not h_same else set(failed)
         # a statement of this path's own parameters that never ran must not pass silently
         for i in sorted(failed):
             target = statements[i].split('=')[0].strip()

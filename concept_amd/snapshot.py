@@ -398,7 +398,7 @@ class GadgetSnapshot:
 
     # -- save ------------------------------------------------------------------
     def save(self, components, filename, a=None, params=None, snapformat=2, dataformat=None,
-             header=None, particles_per_file='automatic'):
+             header=None, particles_per_file='automatic', output_base='snapshot'):
         """One-file GADGET snapshot of particle components.  components: Components (or the
         dicts load() makes) whose names are GADGET type names ('GADGET halo', ...); a single
         matter / cold dark matter component of another name is written as the halo type
@@ -510,11 +510,18 @@ class GadgetSnapshot:
             if os.path.isfile(filename):
                 os.remove(filename)
             os.makedirs(filename, exist_ok=True)
+            # files of an earlier dump into this directory (snapshot.py:1003-1010)
+            import glob as _glob
+            import re as _re
+            prefix = f'{filename}/{output_base}.'
+            for old in _glob.glob(prefix + '*'):
+                if _re.fullmatch(r'\d+', old[len(prefix):]):
+                    os.remove(old)
         else:
             os.makedirs(os.path.dirname(os.path.abspath(filename)) or '.', exist_ok=True)
         done = [0]*len(comps)   # rows of each component already written to earlier files
         for file_index, counts in enumerate(per_file):
-            fn = f'{filename}/snapshot.{file_index}' if num_files > 1 else filename
+            fn = f'{filename}/{output_base}.{file_index}' if num_files > 1 else filename
             nfile = sum(counts)
             npart = [0]*num_particle_types
             for t, n in zip(types, counts):
@@ -543,11 +550,13 @@ class GadgetSnapshot:
                             val = val.reshape(-1)*(1/unit)
                             # safeguard against round-off: compared at the block's precision
                             # (snapshot.py:1117-1118, 1378-1391)
-                            box = np.float32(boxsize/unit) if bits == 32 \
-                                else np.float64(boxsize/unit)
-                            out = val.astype(np.float32 if bits == 32 else np.float64)
-                            hi = val >= np.float64(box)
-                            out[hi] = (val[hi] - np.float64(box)).astype(out.dtype)
+                            # (the value is cast FIRST: one that rounds up to the box size
+                            # in single precision is wrapped to 0 there, as the reference's)
+                            dt_ = np.float32 if bits == 32 else np.float64
+                            box = dt_(boxsize/unit)
+                            out = val.astype(dt_)
+                            hi = out >= box
+                            out[hi] -= box
                         else:
                             unit = self.unit_velocity*get(c, 'mass')*a**1.5
                             val = np.asarray(mom, dtype=np.float64).reshape(-1, 3)[rows]
@@ -563,6 +572,12 @@ class GadgetSnapshot:
                                          dtype=np.uint64)
                     else:
                         part = np.asarray(ids)[done[i]:done[i] + counts[i]]
+                    if len(part) and int(part.max()) >= 2**idbits:
+                        # (snapshot.py:1063-1080 warns as well: the identifiers do not fit)
+                        import warnings
+                        warnings.warn(f'{get(c, "name")}: identifiers up to {int(part.max())} are '
+                                      f'written as {idbits}-bit integers and wrap around; set '
+                                      'gadget_snapshot_params["dataformat"]["ID"] = 64')
                     part.astype('<u4' if idbits == 32 else '<u8').tofile(f)
                 f.write(struct.pack('<I', size))
             for i, n in enumerate(counts):
@@ -607,7 +622,7 @@ def load(filename, only_params=False, params=None, units=None, rank=None, nprocs
 
 
 def save(components, filename, a=None, params=None, snapformat=2, dataformat=None, header=None,
-         units=None, particles_per_file='automatic'):
+         units=None, particles_per_file='automatic', output_base='snapshot'):
     """snapshot.save (snapshot.py:3060-3118) for snapshot_type = 'gadget'"""
     return GadgetSnapshot(None, units).save(components, filename, a, params, snapformat,
-                                            dataformat, header, particles_per_file)
+                                            dataformat, header, particles_per_file, output_base)

@@ -76,13 +76,19 @@ def timeloop(components, n_steps, integrals, rung_integrals=None, on_step=None):
 stream_replays = 0  # steps the streaming loop had to undo and take on the exact path
 
 
-def _streaming_pass(plan, components, rps, ᔑdt_kick, ᔑdt_drift, label=''):
+force_replays = 0   # test hook: that many of the next streaming passes are replayed
+
+
+def _streaming_pass(plan, components, rps, ᔑdt_kick, ᔑdt_drift, label='', drift_on_replay=True):
     """One pass of the streaming form over particles kept in tile regions: every
     component deposited from its regions (mesh.py:1512-1636), one Poisson solve
     (interactions.py:2092-2118), then per component cg_gather_kick_drift_scatter with the kick's
     ᔑdt['a**(-3*w_eff)', name] and the following drift's ᔑdt['a**(-2)'].  ᔑdt_drift None: a kick
     only (the particles keep their places); ᔑdt_kick None: a drift only (kick factor 0: the
-    momenta pass through unchanged, bit for bit).  `rps` is updated in place."""
+    momenta pass through unchanged, bit for bit).  `rps` is updated in place.  Returns True if the
+    pass overflowed and was taken again on the exact path — the entries of `rps` are then NEW
+    objects (snapshots of the old ones no longer apply); with drift_on_replay=False the replay
+    takes the kick only and leaves the drift to the caller (a pass whose drift is a guess)."""
     mesh = plan['mesh']
     fft_factor = float(plan['gridsize'])**(-3)
     p = components[0].params
@@ -122,6 +128,10 @@ def _streaming_pass(plan, components, rps, ᔑdt_kick, ᔑdt_drift, label=''):
         # dropped particles, nothing to recover from here
         raise ConceptGPUError(f'streaming time loop: device error flags {other:#x} {label}')
     overflow = bool(flags & (lib.CG_ERR_BUCKET_OVERFLOW | lib.CG_ERR_NOT_IN_TILE))
+    global force_replays
+    if force_replays > 0:   # (tests: treat this pass as overflowed)
+        force_replays -= 1
+        overflow = True
     if mesh.comm is not None:
         overflow = mesh.comm.any(overflow)
     if overflow:
@@ -133,9 +143,10 @@ def _streaming_pass(plan, components, rps, ᔑdt_kick, ᔑdt_drift, label=''):
             if ᔑdt_kick is not None:
                 interactions._kick_particles(mesh, c, plan['force'], plan['method'],
                                              ᔑdt_kick, ('a**(-3*w_eff)', 'component'))
-            if ᔑdt_drift is not None:
+            if ᔑdt_drift is not None and drift_on_replay:
                 c.drift_sort(ᔑdt_drift, mesh=mesh)
             rps[i] = c.to_regions(mesh)
+    return overflow
 
 
 def _timeloop_streaming(components, n_steps, integrals, plan):
@@ -542,11 +553,18 @@ class Timeloop(RungStepper):
         ᔑdt = self.integrals(t_start, t_end)
         drift = self._next_drift
         before = [rp.snapshot() for rp in self._rps]
-        _streaming_pass(self._plan, self.components, self._rps, ᔑdt,
-                        self.integrals(*drift) if drift is not None else None,
-                        f'at t = {t_start}')
+        replayed = _streaming_pass(self._plan, self.components, self._rps, ᔑdt,
+                                   self.integrals(*drift) if drift is not None else None,
+                                   f'at t = {t_start}', drift_on_replay=False)
         self.stream_passes += 1
-        self._spec = {'kick': ᔑdt, 'drift': drift, 'before': before}
+        if replayed:
+            # the pass overflowed: the kick has been taken on the exact path, the drift not at
+            # all, and the region objects are new ones — `before` describes buffers that no
+            # longer exist.  No guess is outstanding: the loop's next driftkick_short() takes
+            # its drift as a pass of its own.
+            self._spec = None
+        else:
+            self._spec = {'kick': ᔑdt, 'drift': drift, 'before': before}
 
     def driftkick_short(self, Δt, sync_time):
         if self._rps is None:
@@ -766,7 +784,8 @@ class Timeloop(RungStepper):
                     for v in p.snapshot_times[dump_time.time_param]):
                 return
             name = f'{output_dir}/{output_base}{sep}{dump_time.time_param}={value:.{ndigits}f}'
-            fn = snapshot.save(loop.components, name, a=loop.cosmo.a, **save_options)
+            fn = snapshot.save(loop.components, name, a=loop.cosmo.a,
+                               **{'output_base': output_base or 'snapshot', **save_options})
             loop.snapshots_written.append(fn)
         return on_dump
 

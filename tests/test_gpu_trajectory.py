@@ -179,6 +179,44 @@ def test_timeloop_wrong_guess_is_undone(golden):
     assert np.abs(m0 - m1).max() <= 1e-10*np.abs(m1).max()
 
 
+def test_timeloop_overflow_of_the_speculative_pass(golden):
+    """The speculative pass (kick + guessed drift after an init kick) overflows AND its guess
+    turns out wrong: the replay on the exact path replaces the region objects, so the guess
+    must not be undone from snapshots of the old ones (particles were corrupted and
+    the kick applied twice).  The replay takes the kick only; the drift the loop then asks for
+    is a pass of its own.  Must equal the stepwise run."""
+    from concept_amd import stepper
+    g = golden('traj_pm_n8_g16')
+    results = []
+    for streaming in (None, False):
+        p, c = _component(g)
+
+        def on_step(loop):
+            if loop.time_step == 0 and not getattr(loop, 'lowered', False):
+                loop.lowered = True
+                loop.fac_dynamical *= 0.3
+                loop.fac_hubble *= 0.3
+                loop.fac_pm *= 0.3
+                loop.params.Δa_max_early *= 0.3
+                loop.params.Δa_max_late *= 0.3
+                # the next pass is the init kick after the synchronisation this causes
+                if loop._rps is not None:
+                    stepper.force_replays = 1
+        loop = stepper.Timeloop([c], on_step=on_step, streaming=streaming)
+        replays = stepper.stream_replays
+        loop.run()
+        results.append((np.array(loop.history), c.host('pos'), c.host('mom'), c.host('ids'),
+                        stepper.stream_replays - replays))
+    assert stepper.force_replays == 0
+    (h0, p0, m0, i0, r0), (h1, p1, m1, i1, _) = results
+    assert r0 >= 1
+    assert h0.shape == h1.shape and np.abs(h0/np.where(h1 == 0, 1, h1) - 1)[:, 1:].max() <= 1e-12
+    L = float(g['boxsize'])
+    o0, o1 = np.argsort(i0), np.argsort(i1)
+    assert _pos_err(p0[o0], p1[o1], L) <= 1e-11
+    assert np.abs(m0[o0] - m1[o1]).max() <= 1e-10*np.abs(m1).max()
+
+
 def test_timeloop_streaming_at_north_star_size():
     """The time loop itself at the metric's size (2^28 particles / 1024^3 mesh, ΛCDM clock):
     a few base steps from a = 0.1 through stepper.Timeloop — background, integrals, limiters,

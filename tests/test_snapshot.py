@@ -141,6 +141,16 @@ def test_gadget_writer_round_trip_and_options(golden, tmp_path):
     d = np.abs(c['pos'] - pos)
     assert np.minimum(d, 32.0 - d).max() <= 2e-7*32.0
     assert np.abs(c['mom'] - mom).max() <= 1e-14*np.abs(mom).max()
+    # a coordinate within half a single-precision ulp below the box size becomes the box size
+    # when cast: the reference compares and subtracts AFTER the cast (snapshot.py:1375-1383),
+    # the file holds 0, never the box size
+    pos2 = pos.copy()
+    pos2[1] = [32.0*(1 - 2e-8), 32.0*(1 - 1e-8), 5.0]
+    fn2 = snapshot.save([dict(comp, pos=pos2)], str(tmp_path/'a2'), a=0.25,
+                        dataformat={'POS': 32, 'VEL': 32})
+    c2 = snapshot.load(fn2).components[0]
+    assert c2['pos'][1, 0] == 0.0 and c2['pos'][1, 1] == 0.0
+    assert (c2['pos'] >= 0).all() and (c2['pos'] < 32.0).all()
     with pytest.raises(ConceptGPUError, match='no components'):
         snapshot.save([], str(tmp_path/'b'))
     with pytest.raises(ConceptGPUError, match='No components left'):
