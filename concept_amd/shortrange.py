@@ -90,10 +90,10 @@ def _pair_integrals(ᔑdt_rungs, rec, sup):
 
 
 sparse_sweeps = 0   # sweeps taken without a cell list (a handful of active receivers)
-# which tile sweep runs: 'mfma' = lists by tile + matrix-core range pre-filter
-# (cg_shortrange_sweep_tiles), 'cells' = the half-tile cell list of rounds 2-3
-# (cg_shortrange_sweep_cells): same sums, kept for A/B runs and as a cross-check
-SWEEP = os.environ.get('CONCEPT_GPU_SR_SWEEP', 'mfma')
+# which tile sweep runs: 'cells' = the half-tile cell list (cg_shortrange_sweep_cells), the
+# faster of the two on MI355X; 'mfma' = lists by tile + matrix-core range pre-filter
+# (cg_shortrange_sweep_tiles, round 4: same sums; DESIGN.md §16 has the measurements)
+SWEEP = os.environ.get('CONCEPT_GPU_SR_SWEEP', 'cells')
 
 
 def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):

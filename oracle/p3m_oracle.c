@@ -176,3 +176,64 @@ int orc_shortrange_sweep_rungs(const double *pos, i64 N, double *dmom, double bo
     free(tile); free(start); free(order); free(cursor);
     return 0;
 }
+
+/*
+ * The same sums for a SAMPLE of receivers, one-sided: receiver i = sample[s] meets every
+ * particle of the 27 tiles around its own (particle_particle's tile neighbourhood,
+ * interactions.py:1563-1791, periodic offset :1615-1621) with the pair arithmetic of
+ * gravity_pairwise_shortrange (gravity.py:299-321) — O(M x 27 tile populations), so that a
+ * check at full size (256^3 particles: 1.7e7 x 600 pairs for everything) takes seconds.
+ * tile[N] from orc_shortrange_tiles; dmom_out[3 M].  Self pairs contribute x_ji * f = 0 * f.
+ */
+int orc_shortrange_sample(const double *pos, i64 N, const i64 *tile, const i64 *sample, i64 M,
+                          double *dmom_out, double boxsize, i64 nt, const double *table,
+                          double r2_index_scaling, double r2_max, double factor) {
+    i64 ntiles = nt * nt * nt;
+    i64 *start = calloc(ntiles + 1, sizeof(i64));
+    i64 *order = malloc(sizeof(i64) * (N > 0 ? N : 1));
+    i64 *cursor = calloc(ntiles, sizeof(i64));
+    if (!start || !order || !cursor) return 1;
+    for (i64 p = 0; p < N; p++) {
+        if (tile[p] < 0 || tile[p] >= ntiles) return 2;
+        start[tile[p] + 1]++;
+    }
+    for (i64 t = 0; t < ntiles; t++) start[t + 1] += start[t];
+    for (i64 p = 0; p < N; p++) order[start[tile[p]] + cursor[tile[p]]++] = p;
+    for (i64 s = 0; s < M; s++) {
+        i64 i = sample[s], tr = tile[i];
+        i64 ra = tr / (nt * nt), rb = (tr / nt) % nt, rc = tr % nt;
+        double xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+        double ax = 0, ay = 0, az = 0;
+        for (int da = -1; da <= 1; da++) for (int db = -1; db <= 1; db++)
+        for (int dc = -1; dc <= 1; dc++) {
+            i64 sa = ra + da, sb = rb + db, sc = rc + dc;
+            double off[3] = {0, 0, 0};
+            if (sa < 0) { sa += nt; off[0] = boxsize; } else if (sa >= nt) { sa -= nt; off[0] = -boxsize; }
+            if (sb < 0) { sb += nt; off[1] = boxsize; } else if (sb >= nt) { sb -= nt; off[1] = -boxsize; }
+            if (sc < 0) { sc += nt; off[2] = boxsize; } else if (sc >= nt) { sc -= nt; off[2] = -boxsize; }
+            i64 ts = (sa * nt + sb) * nt + sc;
+            for (i64 b = start[ts]; b < start[ts + 1]; b++) {
+                i64 j = order[b];
+                double x_ji = xi - pos[3 * j];         /* interactions.py:1787-1789 */
+                double y_ji = yi - pos[3 * j + 1];
+                double z_ji = zi - pos[3 * j + 2];
+                if (off[0] != 0 || off[1] != 0 || off[2] != 0) { /* gravity.py:299-302 */
+                    x_ji += off[0];
+                    y_ji += off[1];
+                    z_ji += off[2];
+                }
+                double r2 = x_ji * x_ji + y_ji * y_ji + z_ji * z_ji; /* gravity.py:306 */
+                if (r2 > r2_max) continue;
+                double total_factor = factor * table[(i64)(r2 * r2_index_scaling)];
+                ax += x_ji * total_factor;
+                ay += y_ji * total_factor;
+                az += z_ji * total_factor;
+            }
+        }
+        dmom_out[3 * s] = ax;
+        dmom_out[3 * s + 1] = ay;
+        dmom_out[3 * s + 2] = az;
+    }
+    free(start); free(order); free(cursor);
+    return 0;
+}

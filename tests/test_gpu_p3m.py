@@ -32,10 +32,14 @@ def setup(g):
     return torch, c
 
 
+@pytest.mark.parametrize('sweep', ['cells', 'mfma'])
 @pytest.mark.parametrize('name', CASES)
-def test_shortrange_vs_golden_and_oracle(golden, name):
-    from concept_amd import interactions
+def test_shortrange_vs_golden_and_oracle(golden, name, sweep, monkeypatch):
+    """(both tile sweeps: the half-tile cells and the lists by tile with the matrix-core
+    pre-filter, shortrange.SWEEP)"""
+    from concept_amd import interactions, shortrange
     from oracle import oracle
+    monkeypatch.setattr(shortrange, 'SWEEP', sweep)
     g = golden(name)
     torch, c = setup(g)
     c.populate(g['pos_after_short'], 'pos')
@@ -256,13 +260,73 @@ def test_config3_size_shortrange_properties(dist):
     mesh.close()
 
 
-def test_adaptive_rungs_vs_reference(golden):
+@pytest.mark.parametrize('sweep', ['cells', 'tiles'])
+@pytest.mark.parametrize('dist', ['uniform', 'clustered'])
+def test_config3_size_shortrange_vs_oracle_sample(dist, sweep):
+    """BASELINE configs[2]'s own size (256^3 particles, 512^3 mesh, default short-range
+    parameters, test/concept_vs_gadget_p3m/param:10-46) against the ORACLE, uniform and
+    clustered (where tile populations reach the staging limits): the receivers of every 97th
+    tile plus those of the 32 most populated tiles (at most 64 of each), summed by the oracle
+    over the 27 tiles around their own (orc_shortrange_sample: O(sample x 600) pairs).  Both
+    sweeps: the half-tile cells (the default) and the lists by tile with the matrix-core
+    pre-filter.  Tile index of EVERY particle bit-exact; Δmom <= 1e-12 of the rms kick."""
+    import torch
+    from concept_amd import commons, shortrange
+    from concept_amd.mesh import PotentialMesh
+    from oracle import oracle
+    N, L, n = 512, 512.0, 256**3
+    mesh = PotentialMesh(N, L)
+    gen = torch.Generator(device='cuda').manual_seed(8)
+    pos = _config3_positions(torch, dist, n, L, gen)
+    scale = 1.25*L/N
+    rng_ = 4.5*scale
+    nt = int(L/rng_*(1 + commons.machine_ϵ))
+    soft = 0.025*L/256
+    table, maxr2 = shortrange.get_shortrange_table(soft, scale, rng_, 4096, 'spline', pos.device)
+    dm = torch.zeros_like(pos)
+    if sweep == 'cells':
+        lst = mesh.shortrange_cells(pos, nt, L/nt)
+        mesh.shortrange_sweep_cells(lst, dm, lst, nt, table, 4095/maxr2, rng_**2, 1.0)
+    else:
+        lst = mesh.shortrange_tiles(pos, nt, L/nt)
+        mesh.shortrange_sweep_tiles(lst, dm, lst, nt, table, 4095/maxr2, rng_**2, 1.0)
+    pos_h = pos.cpu().numpy()
+    dm_h = dm.cpu().numpy()
+    # the sample: by the oracle's own tile indices
+    eps = np.finfo(float).eps
+    idx = ((pos_h - 0.0)*((1/(L/nt))*(1 - 2*eps))).astype(np.int64)
+    tile = (idx[:, 0]*nt + idx[:, 1])*nt + idx[:, 2]
+    counts = np.bincount(tile, minlength=nt**3)
+    order = np.argsort(tile, kind='stable')
+    start = np.concatenate([[0], np.cumsum(counts)])
+    chosen = set(range(0, nt**3, 97)) | set(np.argsort(counts)[-32:].tolist())
+    sample = np.concatenate([order[start[t]:start[t] + min(counts[t], 64)] for t in sorted(chosen)])
+    ref, tile_o = oracle.shortrange_sample(pos_h, sample, boxsize=L, scale=scale, range_=rng_,
+                                           tilesize=rng_, tablesize=4096, softening=soft,
+                                           factor=1.0)
+    assert np.array_equal(tile_o, tile)
+    if sweep == 'tiles':   # the list by tile IS the oracle's tiling, particle by particle
+        off = lst[1].cpu().numpy().astype(np.int64)
+        assert np.array_equal(off, start)
+        o = lst[0].cpu().numpy().astype(np.int64)[:n]
+        assert np.array_equal(tile[o], np.repeat(np.arange(nt**3), counts))
+    rms = np.sqrt((dm_h**2).mean())
+    assert rms > 0 and len(sample) > 50000
+    assert counts.max() >= (1000 if dist == 'clustered' else 40)
+    err = np.abs(dm_h[sample] - ref).max()
+    assert err <= 1e-12*rms, (err/rms, dist, sweep)
+    mesh.close()
+
+
+@pytest.mark.parametrize('sweep', ['cells', 'mfma'])
+def test_adaptive_rungs_vs_reference(golden, sweep, monkeypatch):
     """A14/A16 with adaptive rungs on the GPU: RungStepper (initialize_rung_populations,
     kick_long, kick_short, driftkick_short with rung jumps; N_rungs = 4) against the
     reference's own main.py functions.  Rung indices bit-exact at every checkpoint."""
     import torch
-    from concept_amd import commons, stepper
+    from concept_amd import commons, shortrange, stepper
     from concept_amd.species import Component
+    monkeypatch.setattr(shortrange, 'SWEEP', sweep)
     g = golden('rungs_p3m_n8_g32')
     commons.load_params({
         'boxsize': float(g['boxsize']),

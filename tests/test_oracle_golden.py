@@ -123,6 +123,26 @@ def test_p3m_shortrange(golden, name):
     assert np.abs(dmom.sum(0)).max() <= 1e-12*max(np.abs(ref).max(), pair)
 
 
+@pytest.mark.parametrize('name', ['p3m_n8_g32', 'p3m_n12_g36_lattice', 'p3m_n16_g48_clustered',
+                                  'p3m_n8_g32_plummer'])
+def test_p3m_shortrange_sample_is_pinned(golden, name):
+    """orc_shortrange_sample (the one-sided sums the full-size GPU tests are checked against)
+    pinned like the sweep itself: every particle as a sampled receiver against the
+    reference-generated Δmom."""
+    g = golden(name)
+    factor = float(g['G_Newton'])*float(g['mass'])**2*float(g['dt_rungs_pair'][0])
+    pos = g['pos_after_short']
+    dmom, tile = oracle.shortrange_sample(
+        pos, np.arange(len(pos)), boxsize=float(g['boxsize']),
+        scale=float(g['shortrange_scale']), range_=float(g['shortrange_range']),
+        tilesize=float(g['shortrange_tilesize']), tablesize=int(g['shortrange_tablesize']),
+        softening=float(g['softening_length']), factor=factor,
+        kernel=str(g['softening_kernel']) if 'softening_kernel' in g else 'spline')
+    ref = g['dmom_short']
+    pair = factor/float(g['shortrange_scale'])**2
+    assert np.abs(dmom - ref).max() <= 1e-13*max(np.abs(ref).max(), pair)
+
+
 def _step_scalars(dt):
     return dict(dt_1=dt, dt_am2=dt*1.3, dt_kick=dt*1.1, dt_dens=dt*0.9, dt_rung=dt*0.8)
 
