@@ -134,25 +134,58 @@ def cpu_baseline_child(workload):
     oracle.build()
     n_p, N = WORKLOADS[workload]
 
+    import ctypes
+    omp_lib = oracle.lib('omp')
+    _dp = ctypes.POINTER(ctypes.c_double)
+    omp_lib.orc_fill_tiled.argtypes = [_dp, ctypes.c_int64, _dp, ctypes.c_int64, ctypes.c_double,
+                                       ctypes.c_double]
+    omp_lib.orc_fill_tiled.restype = None
+
     def particles(n, L):
+        """positions uniform in the box, momenta 0.2 cells rms per step like the GPU run.  Both
+        arrays are WRITTEN BY THE OPENMP THREADS (static schedule, as every particle loop of
+        the port): first touch spreads their pages over the NUMA domains — generated by one
+        numpy thread they would all sit on one, and no thread count beyond that domain's
+        cores would help.  The values are a block of 2^22 random rows repeated with a shift
+        (positions) / as they are (momenta): they do not matter to the timing."""
         rng = np.random.default_rng(7)
-        pos = rng.random((n, 3))
-        pos *= L
-        # 0.2 cells rms per step, like the GPU run (a block of normals, repeated: the values
-        # do not matter to the timing, generating 8e8 of them would)
-        block = rng.normal(0, 0.2/3**0.5*1e3, (min(n, 1 << 22), 3))
-        mom = np.tile(block, (-(-n//block.shape[0]), 1))[:n].copy()
+        nb = min(n, 1 << 22)
+        bpos = np.ascontiguousarray(rng.random((nb, 3))*L)
+        bmom = np.ascontiguousarray(rng.normal(0, 0.2/3**0.5*1e3, (nb, 3)))
+        pos = np.empty((n, 3), dtype=np.float64)
+        mom = np.empty((n, 3), dtype=np.float64)
+        ptr = lambda a: a.ctypes.data_as(_dp)
+        omp_lib.orc_fill_tiled(ptr(pos), 3*n, ptr(bpos), 3*nb, 0.6180339887498949*L, L)
+        omp_lib.orc_fill_tiled(ptr(mom), 3*n, ptr(bmom), 3*nb, 0.0, 0.0)
         return pos, mom
 
-    def run(fast, pos, mom, grid, nsteps):
+    def run(fast, pos, mom, grid, nsteps, timings=None):
         L = float(grid)
         t0 = time.perf_counter()
         for _ in range(nsteps):
+            t1 = time.perf_counter()
             oracle.drift(pos, mom, 1e-3, L, fast=fast)
+            if timings is not None:
+                timings['drift'] = timings.get('drift', 0.0) + time.perf_counter() - t1
             oracle.pm_long_range(pos, mom, mass=1.0, boxsize=L, gridsize=grid,
                                  G_Newton=1.0, dt_1=1e-3, dt_dens=1e-3, dt_kick=1e-3,
-                                 diff_order=2, fast=fast, want_indices=False)
+                                 diff_order=2, fast=fast, want_indices=False, timings=timings)
         return time.perf_counter() - t0
+
+    def phase_table(timings, nsteps, n, grid):
+        """the CPU path's phases beside the GPU's — wall time per step and the
+        rate at which each moves SURVEY.md §8(d)'s algorithmic bytes"""
+        sv = survey_bytes(n, grid**3)
+        credit = {'deposit': sv['deposit'], 'fft_forward': 48*grid**3, 'kspace': 16*grid**3,
+                  'fft_backward': 48*grid**3, 'gather_kick': sv['gather_kick'],
+                  'drift': sv['drift']}
+        out = {}
+        for k, v in timings.items():
+            e = {'s_per_step': round(v/nsteps, 4)}
+            if k in credit:
+                e['GBps_of_survey_8d_bytes'] = round(credit[k]/(v/nsteps)/1e9, 2)
+            out[k] = e
+        return out
 
     try:
         avail = len(os.sched_getaffinity(0))
@@ -166,7 +199,7 @@ def cpu_baseline_child(workload):
                     mem_gb = int(line.split()[1])/2**20
     except OSError:
         pass
-    omp = oracle.lib('omp')
+    omp = omp_lib
     flags = '-O3 -funroll-loops -ffast-math (reference src/Makefile flags)'
     binding = f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}"
     # 1. candidates ranked at 256^3 / 512^3 (2 steps each after one warm-up step)
@@ -178,8 +211,11 @@ def cpu_baseline_child(workload):
         trial[threads] = run('omp', pos2, mom2, 512, 2)/2
     ranked = sorted(trial, key=trial.get)
     c2_threads = ranked[0]
+    omp.orc_threads(c2_threads)
+    tm2 = {}
+    run('omp', pos2, mom2, 512, 2, tm2)
     c2 = {'value': 256**3/trial[c2_threads], 'unit': 'particle-updates/s', 'cores': c2_threads,
-          'steps_per_sec': 1/trial[c2_threads],
+          'steps_per_sec': 1/trial[c2_threads], 'phases': phase_table(tm2, 2, 256**3, 512),
           'sample': '256^3 particles / 512^3 mesh (BASELINE configs[1] size), 2 PM steps'}
     del pos2, mom2
     # 2. one core, numpy's pocketfft (the reference's own pure-Python FFT)
@@ -208,13 +244,15 @@ def cpu_baseline_child(workload):
     # 3. the workload itself: one PM step per candidate thread count
     pos, mom = particles(n_p, float(N))
     cand = []
-    for t in ranked[:2] + [avail]:
+    for t in [ranked[0], min(avail, 128), avail]:
         if t not in cand:
             cand.append(t)
-    at_size = {}
+    at_size, at_size_phases = {}, {}
     for threads in cand:
         omp.orc_threads(threads)
-        at_size[threads] = run('omp', pos, mom, N, 1)
+        tm = {}
+        at_size[threads] = run('omp', pos, mom, N, 1, tm)
+        at_size_phases[threads] = phase_table(tm, 1, n_p, N)
     cores = min(at_size, key=at_size.get)
     dt = at_size[cores]
     out = {'value': n_p/dt, 'unit': 'particle-updates/s', 'cores': cores, 'kind': 'port',
@@ -225,7 +263,12 @@ def cpu_baseline_child(workload):
                      f'built {flags} -fopenmp (slab-privatised deposit, no atomics) on {cores} '
                      f'of {avail} host threads ({binding}) + scipy.fft with {cores} workers, '
                      f'{dt:.1f} s wall per step',
-           'thread_trials_s_per_step_at_size': {str(k): round(v, 2) for k, v in at_size.items()}}
+           'thread_trials_s_per_step_at_size': {str(k): round(v, 2) for k, v in at_size.items()},
+           'phases': at_size_phases[cores],
+           'phases_note': ('wall time per step of each phase of the port at the reported thread '
+                           'count; GBps = SURVEY.md §8(d) bytes of the phase / its time (zero, '
+                           'slab_decompose and domain_decompose are layout passes the GPU build '
+                           'does not have)')}
     out.update(extras)
     print(json.dumps(out))
 
@@ -238,9 +281,11 @@ def make_positions(torch, args, n_p, N, L, dev, gen):
     if args.dist == 'uniform':
         pos.mul_(L)
     elif args.dist == 'lattice':
+        # a cubic lattice; a count that is not a cube fills the first n_p sites of the next
+        # larger one (its last layers stay partly empty)
         side = round(n_p**(1/3))
-        if side**3 != n_p:
-            sys.exit('--dist lattice needs a cubic particle count (e.g. --workload c2_256c_512)')
+        if side**3 < n_p:
+            side += 1
         idx = torch.arange(n_p, device=dev)
         lat = torch.stack([idx//(side*side), (idx//side) % side, idx % side], 1).double()
         disp = torch.randn((n_p, 3), dtype=torch.float64, device=dev, generator=gen)*1.5*(L/N)
@@ -533,6 +578,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra-configs', action='store_true',
+                    help='default run only: skip the other configurations timed after the '
+                         'north-star region (the `configs` block of the JSON line)')
     ap.add_argument('--split-poisson', action='store_true',
                     help='time FFT forward / k-space kernel / FFT backward separately (unfused)')
     ap.add_argument('--dist', default='uniform', choices=['uniform', 'lattice', 'clustered'],
@@ -599,13 +647,53 @@ def main():
         else:
             dist.init_process_group(backend, timeout=limit)
 
-    from concept_amd.mesh import PotentialMesh
     name = args.workload or ('c2_256c_512' if args.p3m else 'ns_256M_1024')
     n_p, N = WORKLOADS[name]
     L = float(N)  # boxsize in grid units (synthetic)
     dev = torch.device('cuda', local_rank)
     if world > 1 or force_dist:
         return main_distributed(args, name, n_p, N, L, dev, rank, world, backend)
+    result = run_single(args, torch, dev, rank)
+    torch.cuda.empty_cache()
+    if args.workload is None and not args.no_extra_configs and not args.p3m \
+            and args.dist == 'uniform' and not (args.no_fused or args.no_sort or args.no_prepare
+                                                or args.split_poisson):
+        # The other configurations under the same clock: after the timed
+        # north-star region, 20 steps each of BASELINE configs[1] as a PM and as a P3M step and
+        # of the north-star size on the clustered and the displaced-lattice
+        # distributions.  The headline fields above are untouched.
+        import copy
+        result['configs'] = {}
+        for cname, over in (('c2_256c_512_pm', dict(workload='c2_256c_512')),
+                            ('c2_256c_512_p3m', dict(workload='c2_256c_512', p3m=True)),
+                            ('ns_256M_1024_clustered', dict(dist='clustered')),
+                            ('ns_256M_1024_lattice', dict(dist='lattice'))):
+            a2 = copy.copy(args)
+            a2.steps, a2.warmup = 20, 3
+            for k, v in over.items():
+                setattr(a2, k, v)
+            r2 = run_single(a2, torch, dev, rank)
+            torch.cuda.empty_cache()
+            result['configs'][cname] = {
+                'ms_per_step': round(r2['ms_per_step'], 4), 'steps': a2.steps,
+                'particle_updates_per_s': r2['value'],
+                'dominant_kernel': r2['roofline']['kernel'],
+                'dominant_kernel_ms': r2['roofline']['kernel_ms'],
+                'bound': r2['roofline']['bound'], 'frac': r2['roofline']['frac'],
+                'phases_ms': {k: v['ms'] for k, v in r2['phases'].items()},
+                'workload': r2['config']['workload']}
+    if not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(name)
+    print(json.dumps(result))
+
+
+def run_single(args, torch, dev, rank=0):
+    """The timed steps of one configuration on one GPU: the result dict of the JSON line
+    (without cpu_baseline)."""
+    from concept_amd.mesh import PotentialMesh
+    name = args.workload or ('c2_256c_512' if args.p3m else 'ns_256M_1024')
+    n_p, N = WORKLOADS[name]
+    L = float(N)  # boxsize in grid units (synthetic; SURVEY.md §8d)
     mesh = PotentialMesh(N, L, nghosts=2)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     pos = make_positions(torch, args, n_p, N, L, dev, gen)
@@ -883,11 +971,9 @@ def main():
             # for work removed by fusion, stated as bytes only — never turned into a fraction
             'survey_8d_GB': round(credit/1e9, 2)}
     result['phases'] = phases
-    if not args.no_cpu_baseline:
-        del pos, mom, pos2, mom2, mesh
-        torch.cuda.empty_cache()
-        result['cpu_baseline'] = cpu_baseline(name)
-    print(json.dumps(result))
+    del pos, mom, pos2, mom2
+    mesh.close()
+    return result
 
 
 if __name__ == '__main__':

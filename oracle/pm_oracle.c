@@ -408,6 +408,27 @@ static inline double np_mod(double a, double b) {
     else m = copysign(0.0, b);
     return m;
 }
+/* First touch for the timing baseline (bench.py): dst[i] = fmod(block[i % nb] + (i / nb) * shift,
+ * period) written by the threads that will later stream it (static schedule, as every particle
+ * loop here), so that the pages of a large array spread over the NUMA domains instead of
+ * landing where a single generating thread ran.  Not part of any parity path. */
+void orc_fill_tiled(double *dst, i64 n, const double *block, i64 nb, double shift, double period) {
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; i++) {
+        double v = block[i % nb] + (double)(i / nb) * shift;
+        if (period > 0) {
+            v = fmod(v, period);
+            if (v < 0) v += period;
+            if (v >= period) v = 0;
+        }
+        dst[i] = v;
+    }
+}
+void orc_zero(double *dst, i64 n) {
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; i++) dst[i] = 0.0;
+}
+
 void orc_drift(double *pos, const double *mom, i64 n3, double dt_over_mass, double boxsize) {
 #pragma omp parallel for schedule(static)
     for (i64 r = 0; r < n3; r++) {
