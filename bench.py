@@ -51,6 +51,14 @@ WORKLOADS = {
 }
 
 
+# --weak: the work PER GPU stays the same as the ranks grow — 2^25 particles and ~1.3e8 mesh
+# cells each (a cubic mesh cannot be scaled by exactly 2 and 4: 640^3 and 800^3 are within 5 %
+# of twice and four times 512^3; they are not powers of two, so their slab transforms take the
+# rocFFT backend, DESIGN.md §6 — stated in the line as fft_backend).  P = 8 is the metric's
+# own size.
+WEAK = {1: (2**25, 512), 2: (2**26, 640), 4: (2**27, 800), 8: (2**28, 1024)}
+
+
 def survey_bytes(n_p, n_g):
     """algorithmic bytes of the reference's UNFUSED phases (what its table
     credits a phase with).  Reported beside the real figures, never turned into a fraction of
@@ -428,6 +436,37 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
     for evs in stage_events:
         for (_, a), (sname, b) in zip(evs[:-1], evs[1:]):
             stages[sname] = stages.get(sname, 0.0) + a.elapsed_time(b)/len(stage_events)
+    dry = None
+    if args.dry_links and world > 1:
+        # The schedule with sleeping links against its two parts, all three measured the same
+        # way (every rank at once, behind a barrier): the solve with the sleeps under its
+        # transforms, the sleeps alone (what was requested), the transforms alone (the same
+        # solve at an infinite rate).
+        def solves(rate):
+            dom.comm.dry_rate = rate
+            dom.comm.dry_ms = 0.0
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                dom.mesh.poisson_solve(4, C, False, 0.0, fill=True)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1)/3, dom.comm.dry_ms/3
+        solves(args.dry_links*1e9)
+        with_ms, links_ms = solves(args.dry_links*1e9)
+        compute_ms, _ = solves(1e30)
+        hidden = compute_ms + links_ms - with_ms
+        dry = {'rate_GBps_per_link': args.dry_links, 'links_ms_per_solve': round(links_ms, 3),
+               'transforms_alone_ms': round(compute_ms, 3), 'solve_ms': round(with_ms, 3),
+               'hidden_ms': round(hidden, 3),
+               'overlap_fraction': round(hidden/max(min(compute_ms, links_ms), 1e-9), 3),
+               'note': ('every FFT transpose replaced by a device sleep of (bytes to one peer) / '
+                        'rate on a side stream; overlap = (transforms alone + sleeps - solve) / '
+                        'min(transforms alone, sleeps).  Ranks sharing one GPU slow each '
+                        'other\'s transforms down: the fraction describes the schedule, the '
+                        'milliseconds do not describe a node')}
     red = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(red, op=dist.ReduceOp.MAX)
     elapsed = float(red.item())
@@ -519,8 +558,8 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
         'unit': 'particle-updates/s', 'steps_per_sec': args.steps/elapsed, 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed/args.steps*1e3,
         'timed_region_s': round(elapsed, 4),
-        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
-        'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': f'{name}: {total} particles (uniform random, thermal rms '
                                f'displacement {args.thermal} cells/step) / {N}^3 PM mesh, CIC, '
                                f'deconvolution order 4, FD order 2, {world} x-slab domains; '
@@ -537,6 +576,10 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
                      'frac': round(gk_rate/HBM_PEAK_GBS, 4), 'traffic': None,
                      'algorithmic_bytes': int(mv[gk_name]), 'kernel_ms': round(gk_ms, 4)},
         'transport': transport, 'link_model': link_model, 'cpu_baseline': None,
+        'dry_links': dry, 'per_gpu': {'particle_updates_per_s': total*args.steps/elapsed/world,
+                                      'particles': total//world, 'mesh_cells': N**3//world,
+                                      'fft_backend': 'hand-written passes' if N & (N - 1) == 0
+                                      else 'rocFFT per slab (grid size not a power of two)'},
         'stages_ms_rank0': {k: round(v, 3) for k, v in stages.items()},
         'transpose_probe_rank0': probe,
     }))
@@ -583,6 +626,16 @@ def main():
                          'north-star region (the `configs` block of the JSON line)')
     ap.add_argument('--split-poisson', action='store_true',
                     help='time FFT forward / k-space kernel / FFT backward separately (unfused)')
+    ap.add_argument('--weak', action='store_true',
+                    help='weak scaling: 2^25 particles and ~1.3e8 mesh cells PER GPU '
+                         '(512^3 / 640^3 / 800^3 / 1024^3 meshes on 1 / 2 / 4 / 8 GPUs) instead '
+                         'of the fixed 2^28 / 1024^3 total')
+    ap.add_argument('--dry-links', type=float, nargs='?', const=XGMI_LINK_GBS_DIR, default=0.0,
+                    metavar='GB/s',
+                    help='N > 1: replace every FFT transpose by a device sleep of (bytes to one '
+                         'peer) / rate (default: one xGMI link, one way) — the pipelining '
+                         'schedule and its overlap measured without a second GPU; results are '
+                         'not meaningful')
     ap.add_argument('--dist', default='uniform', choices=['uniform', 'lattice', 'clustered'],
                     help="particle distribution (SURVEY.md §8d): uniform random (U), displaced "
                          "lattice (Z: rms displacement 1.5 cells), or Gaussian blobs")
@@ -604,6 +657,8 @@ def main():
                     help='direct (untiled) kernels on unsorted particles, for A/B')
     args = ap.parse_args()
 
+    if args.dry_links:
+        os.environ['CONCEPT_GPU_DRY_LINKS'] = str(args.dry_links)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))
 
@@ -648,6 +703,11 @@ def main():
             dist.init_process_group(backend, timeout=limit)
 
     name = args.workload or ('c2_256c_512' if args.p3m else 'ns_256M_1024')
+    if args.weak:
+        if world not in WEAK:
+            sys.exit(f'bench.py --weak: 1, 2, 4 or 8 GPUs (got {world})')
+        name = f'weak_{world}x2^25'
+        WORKLOADS[name] = WEAK[world]
     n_p, N = WORKLOADS[name]
     L = float(N)  # boxsize in grid units (synthetic)
     dev = torch.device('cuda', local_rank)
@@ -655,7 +715,7 @@ def main():
         return main_distributed(args, name, n_p, N, L, dev, rank, world, backend)
     result = run_single(args, torch, dev, rank)
     torch.cuda.empty_cache()
-    if args.workload is None and not args.no_extra_configs and not args.p3m \
+    if args.workload is None and not args.no_extra_configs and not args.p3m and not args.weak \
             and args.dist == 'uniform' and not (args.no_fused or args.no_sort or args.no_prepare
                                                 or args.split_poisson):
         # The other configurations under the same clock: after the timed
@@ -692,6 +752,9 @@ def run_single(args, torch, dev, rank=0):
     (without cpu_baseline)."""
     from concept_amd.mesh import PotentialMesh
     name = args.workload or ('c2_256c_512' if args.p3m else 'ns_256M_1024')
+    if args.weak:
+        name = 'weak_1x2^25'
+        WORKLOADS[name] = WEAK[1]
     n_p, N = WORKLOADS[name]
     L = float(N)  # boxsize in grid units (synthetic; SURVEY.md §8d)
     mesh = PotentialMesh(N, L, nghosts=2)
@@ -900,7 +963,7 @@ def run_single(args, torch, dev, rank=0):
         'unit': 'particle-updates/s', 'steps_per_sec': args.steps/elapsed,
         'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'timed_region_s': round(elapsed, 4),
-        'higher_is_better': True, 'scaling': 'strong',
+        'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': f'{name}: {n_p} particles ({args.dist}, seed 1, thermal rms '
                                f'displacement {args.thermal} cells/step) / {N}^3 PM mesh, CIC, '

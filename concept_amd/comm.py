@@ -35,8 +35,49 @@ class Comm:
         # well (a one-rank RCCL group then exercises every send / receive call of the sharded
         # path on the one GPU there is: tests)
         self.self_transport = os.environ.get('CONCEPT_GPU_COMM_SELF') == '1'
+        # CONCEPT_GPU_DRY_LINKS=<GB/s>: the FFT transposes move no data — each is replaced by a
+        # device sleep of (bytes one rank sends to ONE peer) / rate on a side stream, the way
+        # RCCL would occupy one xGMI link per peer (bench.py --dry-links: the pipelining
+        # schedule of the transposing solve is exercised, and its overlap with the transforms
+        # measured, where there is no second GPU).  The results are garbage: a timing mode.
+        self.dry_rate = float(os.environ.get('CONCEPT_GPU_DRY_LINKS', '0') or 0)*1e9
+        self.dry_ms = 0.0          # sleep time requested so far
+        self._dry_stream = None
+        self._dry_cycles_per_ms = None
+
+    def _dry(self, bytes_per_peer):
+        """a sleep of bytes_per_peer / dry_rate on the side stream, behind what the current
+        stream has queued; returns a work-like object whose wait() joins it"""
+        if self._dry_stream is None:
+            self._dry_stream = torch.cuda.Stream()
+            # calibrate torch.cuda._sleep (cycles of the device's timer)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(1000)
+            torch.cuda.synchronize()
+            e0.record()
+            torch.cuda._sleep(20_000_000)
+            e1.record()
+            torch.cuda.synchronize()
+            self._dry_cycles_per_ms = 20_000_000/max(e0.elapsed_time(e1), 1e-3)
+        ms = bytes_per_peer/self.dry_rate*1e3
+        self.dry_ms += ms
+        side = self._dry_stream
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(int(ms*self._dry_cycles_per_ms))
+            ev = torch.cuda.Event()
+            ev.record(side)
+
+        class _Work:
+            def wait(self_inner):
+                torch.cuda.current_stream().wait_event(ev)
+        return _Work()
 
     def all_to_all(self, out, inp, out_splits=None, in_splits=None):
+        if self.dry_rate and out_splits is None and inp.numel()*inp.element_size() >= 1 << 20:
+            # (a transpose buffer: the small all-to-alls of counts and particle rows are real)
+            self._dry(inp.numel()*inp.element_size()/self.world).wait()
+            return
         if not self.stage:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
             return
@@ -73,6 +114,12 @@ class Comm:
         P = self.world
         o = out.view(P, nlayers_total, -1)[:, layer0:layer0 + nlayers]
         i = inp.view(P, nlayers_total, -1)[:, layer0:layer0 + nlayers]
+        if self.dry_rate:
+            w = self._dry(i[0].numel()*i.element_size())
+            if async_op:
+                return w
+            w.wait()
+            return None
         if not self.stage:
             return dist.all_to_all([o[q] for q in range(P)], [i[q] for q in range(P)],
                                    group=self.group, async_op=async_op)
