@@ -294,73 +294,54 @@ class Cosmology:
         self.t, self.a = t_begin, a_begin
 
     # -- integration.py:712-827 ------------------------------------------------------------
+    # The integrands of the time loop as a table: name -> (number of components it names,
+    # function of the background, the scale factor and the components' w_eff(a)).  Stable
+    # matter has Γ = 0.
+    INTEGRANDS = {
+        '1': (0, lambda bg, a: 1.0),
+        '': (0, lambda bg, a: 1.0),
+        'a**2': (0, lambda bg, a: a**2),
+        'a**(-1)': (0, lambda bg, a: 1/a),
+        'a**(-2)': (0, lambda bg, a: 1/a**2),
+        'ȧ/a': (0, lambda bg, a: bg.hubble(a)),
+        'a**(-3*w_eff)': (1, lambda bg, a, w: a**(-3*w)),
+        'a**(-3*(1+w_eff))': (1, lambda bg, a, w: a**(-3*(1 + w))),
+        'a**(-3*w_eff-1)': (1, lambda bg, a, w: a**(-3*w - 1)),
+        'a**(3*w_eff-2)': (1, lambda bg, a, w: a**(3*w - 2)),
+        'a**(-3*w_eff)*Γ/H': (1, lambda bg, a, w: 0.0),
+        'a**(-3*w_eff₀-3*w_eff₁-1)': (2, lambda bg, a, w0, w1: a**(-3*w0 - 3*w1 - 1)),
+    }
+
     def scalefactor_integral(self, key, t_start, t_end, all_components):
         """ᔑ_t_start^t_end integrand(a(t)) dt; key = 'integrand' or ('integrand', name[, name]).
         The integrand is tabulated on the points of the a(t) table and integrated as a
-        natural cubic spline in t (not logged), cached per key as in the reference."""
+        natural cubic spline in t (not logged), one spline per key kept for the run."""
         if t_start == t_end:
             return 0
-        if isinstance(key, str):
-            integrand, components = key, []
-        else:
-            integrand, *names = key
-            components = []
-            for name in names:
-                for c in all_components:
-                    if c.name == name:
-                        components.append(c)
-                        break
         spline = self.spline_t_integrands.get(key)
         if spline is not None:
             return spline.integrate(t_start, t_end)
+        integrand, names = (key, ()) if isinstance(key, str) else (key[0], tuple(key[1:]))
+        entry = self.INTEGRANDS.get(integrand)
+        if entry is None or entry[0] != len(names):
+            known = sorted(k for k, (n, _) in self.INTEGRANDS.items() if n == len(names) and k)
+            raise ConceptGPUError(
+                f'scalefactor_integral: no integrand {integrand!r} over {len(names)} '
+                f'component(s); the time loop knows {known}')
+        by_name = {c.name: c for c in all_components}
+        missing = [nm for nm in names if nm not in by_name]
+        if missing:
+            raise ConceptGPUError(f'scalefactor_integral: {key!r} names the component(s) '
+                                  f'{missing}, which are not in the run')
+        comps = [by_name[nm] for nm in names]
+        func = entry[1]
         if self.enable_Hubble:
             a_tab, t_tab = self.a_t.x, self.a_t.y
         else:
             t_tab = np.linspace(t_start, t_end, Spline.size_min)
             a_tab = np.asarray([self.scale_factor(t) for t in t_tab], dtype=np.float64)
-        size = t_tab.shape[0]
-        tab = np.empty(size, dtype=np.float64)
-        for i in range(size):
-            a, t = float(a_tab[i]), float(t_tab[i])
-            if isinstance(key, str):
-                if integrand in ('1', ''):
-                    tab[i] = 1
-                elif integrand == 'a**2':
-                    tab[i] = a**2
-                elif integrand == 'a**(-1)':
-                    tab[i] = 1/a
-                elif integrand == 'a**(-2)':
-                    tab[i] = 1/a**2
-                elif integrand == 'ȧ/a':
-                    tab[i] = self.hubble(a)
-                else:
-                    raise ConceptGPUError(f'The scale factor integral with "{integrand}" as '
-                                          'the integrand is not implemented')
-            elif len(key) == 2:
-                w_eff = components[0].w_eff(a=a)
-                if integrand == 'a**(-3*w_eff)':
-                    tab[i] = a**(-3*w_eff)
-                elif integrand == 'a**(-3*(1+w_eff))':
-                    tab[i] = a**(-3*(1 + w_eff))
-                elif integrand == 'a**(-3*w_eff-1)':
-                    tab[i] = a**(-3*w_eff - 1)
-                elif integrand == 'a**(3*w_eff-2)':
-                    tab[i] = a**(3*w_eff - 2)
-                elif integrand == 'a**(-3*w_eff)*Γ/H':
-                    tab[i] = 0.0   # Γ = 0: stable matter
-                else:
-                    raise ConceptGPUError(f'The scale factor integral with "{integrand}" as '
-                                          'the integrand is not implemented')
-            elif len(key) == 3:
-                w0, w1 = components[0].w_eff(a=a), components[1].w_eff(a=a)
-                if integrand == 'a**(-3*w_eff₀-3*w_eff₁-1)':
-                    tab[i] = a**(-3*w0 - 3*w1 - 1)
-                else:
-                    raise ConceptGPUError(f'The scale factor integral with "{integrand}" as '
-                                          'the integrand is not implemented')
-            else:
-                raise ConceptGPUError(f'scalefactor_integral(): Invalid length ({len(key)}) of '
-                                      f'key {key}')
+        tab = np.fromiter((func(self, a, *(c.w_eff(a=a) for c in comps))
+                           for a in map(float, a_tab)), dtype=np.float64, count=len(a_tab))
         spline = Spline(t_tab, tab, integrand)
         if self.enable_Hubble:
             self.spline_t_integrands[key] = spline

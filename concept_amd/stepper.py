@@ -613,90 +613,93 @@ class Timeloop(RungStepper):
         return unique
 
     # -- main.get_base_timestep_size (main.py:697-916) -------------------------------------
+    # The base step is the smallest of what a list of limiters allows; a limiter is a method
+    # that yields (Δt, what it stands for) candidates.  The first of equal candidates names the
+    # bottleneck.  (1/|ẇ| and the decay rate: matter has w = 0 and Γ = 0, never the bottleneck;
+    # the Courant condition belongs to fluids.)
+    LIMITERS = ('_limit_dynamical', '_limit_background', '_limit_pm', '_limit_p3m')
+
     def get_base_timestep_size(self):
-        cosmo, p = self.cosmo, self.params
-        t, a = cosmo.t, cosmo.a
+        cosmo = self.cosmo
         if self.static_timestepping_func is not None:
-            return self.static_timestepping_func(a), 'static time-stepping'
-        H = cosmo.hubble(a)
+            return self.static_timestepping_func(cosmo.a), 'static time-stepping'
+        state = {'t': cosmo.t, 'a': cosmo.a, 'v_rms': {}}
         Δt_max, bottleneck = ထ, ''
-        measurements = {}
-        # the dynamical time scale
-        ρ_bar = 0
+        for name in self.LIMITERS:
+            for Δt, what in getattr(self, name)(state):
+                if Δt < Δt_max:
+                    Δt_max, bottleneck = Δt, what
+        if state['t'] in self.initial_fac_times:
+            Δt_max *= self.Δt_initial_fac
+        return Δt_max, bottleneck
+
+    def _limit_dynamical(self, state):
+        """the dynamical time scale of the mean density (main.py:724-737)"""
+        a, ρ_bar = state['a'], 0
         for c in self.components:
             ρ_bar += a**(-3*(1 + c.w_eff(a=a)))*c.ϱ_bar
-        Δt_dynamical = self.fac_dynamical/(math.sqrt(p.G_Newton*ρ_bar) + commons.machine_ϵ)
-        if Δt_dynamical < Δt_max:
-            Δt_max, bottleneck = Δt_dynamical, 'the dynamical time scale'
-        if cosmo.enable_Hubble:
-            # maximum allowed Δa at late times
-            a_next = a + p.Δa_max_late
-            if a_next < 1:
-                Δt_Δa_late = p.Δt_base_background_factor*(cosmo.cosmic_time(a_next) - t)
-                if Δt_Δa_late < Δt_max:
-                    Δt_max, bottleneck = Δt_Δa_late, 'the maximum allowed Δa (late)'
-            # the Hubble time, overruled by a constant Δa at early times
-            Δt_hubble, bottleneck_hubble = self.fac_hubble/H, 'the Hubble time'
-            if p.Δa_max_early > 0:
-                a_next = a + p.Δa_max_early
-                if a_next < 1:
-                    Δt_Δa_early = p.Δt_base_background_factor*(cosmo.cosmic_time(a_next) - t)
-                    if Δt_Δa_early > Δt_hubble:
-                        Δt_hubble = Δt_Δa_early
-                        bottleneck_hubble = 'the maximum allowed Δa (early)'
-            if Δt_hubble < Δt_max:
-                Δt_max, bottleneck = Δt_hubble, bottleneck_hubble
-        # (1/|ẇ| and the decay rate: matter, w = 0 and Γ = 0, never the bottleneck; the Courant
-        # condition belongs to fluids)
+        yield (self.fac_dynamical/(math.sqrt(self.params.G_Newton*ρ_bar) + commons.machine_ϵ),
+               'the dynamical time scale')
 
-        def v_rms_of(c):
-            if c not in measurements:
-                rp = self._rps[self.components.index(c)] if self._rps is not None else None
-                measurements[c] = measure(c, 'v_rms', a, rp)
-            v_rms = measurements[c]
-            # in the odd case of a completely static component, just above 0
-            return commons.machine_ϵ if v_rms < commons.machine_ϵ else v_rms
-        # PM limiter
+    def _limit_background(self, state):
+        """the largest allowed Δa at late times; the Hubble time, overruled by a constant Δa
+        at early times (main.py:739-771)"""
+        cosmo, p = self.cosmo, self.params
+        if not cosmo.enable_Hubble:
+            return
+        t, a = state['t'], state['a']
+        a_next = a + p.Δa_max_late
+        if a_next < 1:
+            yield (p.Δt_base_background_factor*(cosmo.cosmic_time(a_next) - t),
+                   'the maximum allowed Δa (late)')
+        Δt_hubble, what = self.fac_hubble/cosmo.hubble(a), 'the Hubble time'
+        if p.Δa_max_early > 0:
+            a_next = a + p.Δa_max_early
+            if a_next < 1:
+                Δt_early = p.Δt_base_background_factor*(cosmo.cosmic_time(a_next) - t)
+                if Δt_early > Δt_hubble:
+                    Δt_hubble, what = Δt_early, 'the maximum allowed Δa (early)'
+        yield Δt_hubble, what
+
+    def _v_rms(self, c, state):
+        """rms velocity of a component, measured once per call of get_base_timestep_size
+        (on the regions when the loop streams); a static component counts as just above 0"""
+        if c not in state['v_rms']:
+            rp = self._rps[self.components.index(c)] if self._rps is not None else None
+            state['v_rms'][c] = measure(c, 'v_rms', state['a'], rp)
+        v_rms = state['v_rms'][c]
+        return commons.machine_ϵ if v_rms < commons.machine_ϵ else v_rms
+
+    def _limit_pm(self, state):
+        """a particle may cross a fraction of a cell of its finest PM mesh (main.py:838-872)"""
+        p = self.params
         for c in self.components:
-            resolution, extreme_force = 0, None
+            finest = (0, None)   # (of equal grid sizes the first force names the bottleneck)
             for force, method in c.forces.items():
-                if method != 'pm':
-                    continue
                 for method_, gridsize in c.potential_gridsizes[force].items():
-                    if method_ != 'pm':
-                        continue
-                    gridsize = int(np.max(gridsize))
-                    if gridsize > resolution:
-                        resolution, extreme_force = gridsize, force
-            if resolution == 0:
+                    if method == method_ == 'pm' and int(np.max(gridsize)) > finest[0]:
+                        finest = (int(np.max(gridsize)), force)
+            if finest[0] == 0:
                 continue
-            Δt_pm = self.fac_pm*(p.boxsize/resolution)/v_rms_of(c)
-            if Δt_pm < Δt_max:
-                Δt_max = Δt_pm
-                bottleneck = f'the PM method of the {extreme_force} force for {c.name}'
-        # P³M limiter
+            yield (self.fac_pm*(p.boxsize/finest[0])/self._v_rms(c, state),
+                   f'the PM method of the {finest[1]} force for {c.name}')
+
+    def _limit_p3m(self, state):
+        """... or of the short-range scale of its P³M force (main.py:873-906); the short-range
+        parameters are resolved with the global P³M grid size (commons.py:3254-3300)"""
+        p = self.params
         for c in self.components:
-            scale = ထ
+            scales = []
             for force, method in c.forces.items():
                 if method != 'p3m':
                     continue
-                # shortrange_params are resolved with the global P³M grid size
-                # (commons.py:3254-3300)
                 gs = p.potential_options['gridsize']['global'].get(force, {}).get('p3m', -1)
                 if gs == -1:
                     gs = int(np.max(c.potential_gridsizes[force]['p3m']))
-                s_ = commons.resolve_shortrange(p, gs)['scale']
-                if s_ < scale:
-                    scale = s_
-            if scale == ထ:
-                continue
-            Δt_p3m = self.fac_p3m*scale/v_rms_of(c)
-            if Δt_p3m < Δt_max:
-                Δt_max = Δt_p3m
-                bottleneck = f'the P³M method of the gravity force for {c.name}'
-        if t in self.initial_fac_times:
-            Δt_max *= self.Δt_initial_fac
-        return Δt_max, bottleneck
+                scales.append(commons.resolve_shortrange(p, gs)['scale'])
+            if scales:
+                yield (self.fac_p3m*min(scales)/self._v_rms(c, state),
+                       f'the P³M method of the gravity force for {c.name}')
 
     # -- main.update_base_timestep_size (main.py:922-982) ----------------------------------
     def update_base_timestep_size(self, Δt, Δt_min, Δt_max, bottleneck, time_step=-1,

@@ -107,8 +107,16 @@ def test_slab_domains_match_single_domain(world, N, p3m, n_side=20, steps=None):
     mom_d = np.empty_like(mom_ref)
     pos_d[ids] = np.concatenate(pos)
     mom_d[ids] = np.concatenate(mom)
-    scale = np.sqrt(((mom_ref)**2).mean())
-    assert np.abs(mom_d - mom_ref).max() <= 1e-12*scale
+    # the bar is on the KICKS (the momenta themselves are of order one where the kicks are
+    # 1e-3 of that: 1e-12 of their rms said little), plus the rounding of adding a kick to a
+    # momentum, once per kick
+    rng = np.random.default_rng(77)
+    rng.uniform(0, 64.0, (n_side**3, 3))
+    mom0 = rng.normal(0, cells_per_step*(64.0/N)/0.9 if cells_per_step else 1.0, (n_side**3, 3))
+    kick_rms = np.sqrt(((mom_ref - mom0)**2).mean())
+    assert kick_rms > 0
+    assert np.abs(mom_d - mom_ref).max() <= 1e-12*kick_rms \
+        + 2.3e-16*(2*steps)*np.abs(mom_ref).max()
     dx = np.abs(pos_d - pos_ref)
     dx = np.minimum(dx, 64.0 - dx)
     assert dx.max() <= 1e-13*64.0
