@@ -330,6 +330,13 @@ class Component:
             return sum({'b': p.Ωb, 'cdm': p.Ωcdm}[s_] for s_ in class_species.split('+'))*p.ρ_crit
         if self.representation == 'particles':
             return self.N*self.mass/p.boxsize**3
+        if getattr(self, 'ρ', None) is not None:
+            # a fluid of another species: the mean of its (conserved) density grid; on several
+            # domains every slab has the same number of cells
+            mean = float(self.ρ.mean().item())
+            if self.comm is not None and self.nprocs > 1:
+                mean = float(self.comm.all_gather_floats([mean]).mean())
+            return mean
         raise ConceptGPUError(f'Cannot determine ϱ_bar for {self.name}')
 
     def w_eff(self, a=1.0):

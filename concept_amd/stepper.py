@@ -207,6 +207,9 @@ class RungStepper:
     def __init__(self, components, integrals, t=0.0, fac_softening=None, Δt_jump_fac=0.95,
                  Δt_reltol=1e-9):
         self.components = list(components)
+        # the short-range machinery (rungs, sub-steps, drifts) is the particles' alone
+        # (main.py's particle_components); fluids take part in kick_long()
+        self.particles = [c for c in self.components if c.representation == 'particles']
         self.integrals = integrals
         self.t = float(t)
         p = self.components[0].params
@@ -231,7 +234,7 @@ class RungStepper:
     def _shortrange_interactions(self):
         """find_interactions(particle_components, 'short-range') (main.py:1216-1225,
         1395-1403)"""
-        return interactions.find_interactions(self.components, 'short-range')
+        return interactions.find_interactions(self.particles, 'short-range')
 
     def _gravity_short(self):
         """every short-range interaction once (main.py:1249-1262, 1559-1576); returns the
@@ -261,7 +264,7 @@ class RungStepper:
 
     # -- main.kick_short (main.py:1173-1262) ----------------------------------
     def kick_short(self, Δt, fake=False):
-        comps = self.components
+        comps = self.particles
         if not self._shortrange_interactions():
             return
         for c in comps:
@@ -288,7 +291,7 @@ class RungStepper:
     def initialize_rung_populations(self, Δt):
         if Δt == 0:
             raise ConceptGPUError('Cannot initialise rung populations with Δt = 0')
-        for c in self.components:
+        for c in self.particles:
             if c.use_rungs:
                 c.rung_indices.zero_()
                 c.set_rungs_N()
@@ -296,7 +299,7 @@ class RungStepper:
 
     # -- main.driftkick_short (main.py:1347-1603) ------------------------------
     def driftkick_short(self, Δt, sync_time):
-        comps = self.components
+        comps = self.particles
         nr = self.N_rungs
         if not self._shortrange_interactions():
             # no short-range interactions at all: the particles drift in one go
@@ -449,15 +452,28 @@ class Timeloop(RungStepper):
     Δt_ratio_abort = 0.01
     Δt_period = 1*8
 
-    def __init__(self, components, cosmology=None, on_dump=None, on_step=None, streaming=None):
+    def __init__(self, components, cosmology=None, on_dump=None, on_step=None, streaming=None,
+                 fluid_drift=None, fluid_limiter=None):
+        """fluid_drift(component, ᔑdt, a_end): the hook for fluid components.  Their solvers
+        (fluid.py: MacCormack / Kurganov-Tadmor on ϱ, J) are outside this path, but the loop
+        around them is not: with the hook given, fluid components ride along — they take
+        part in every kick_long() through gravity() (deposit of ϱ, fluid kick of J,
+        interactions.py:1985-2335) and the hook is called where main.py calls
+        Component.drift() for them (drift_fluids, main.py:1279-1299: once per full base step,
+        over the whole step, before the particles' sub-steps) with the step's integrals and the
+        scale factor at its end; it advances component.ϱ / component.J in place.
+        fluid_limiter(component, a) -> Δt: the fluid's own limit on the base step (the
+        reference's Courant condition, main.py:773-836), optional."""
         p = components[0].params
         self.cosmo = cosmology or Cosmology(p)
         self.cosmo.init_time()
+        self.fluid_drift, self.fluid_limiter = fluid_drift, fluid_limiter
         for c in components:
-            if c.representation != 'particles':
+            if c.representation != 'particles' and fluid_drift is None:
                 raise ConceptGPUError(
                     f'Timeloop: {c.name} is a fluid component; fluids take part in gravity() '
-                    'but their own evolution (fluid.py) is outside this path')
+                    'but their own evolution (fluid.py) is outside this path: pass '
+                    'fluid_drift=callback(component, ᔑdt, a_end) to advance ϱ and J')
         super().__init__(components, self._integrals, t=self.cosmo.t,
                          fac_softening=0.025*p.Δt_rung_factor)
         self.params = p
@@ -617,7 +633,8 @@ class Timeloop(RungStepper):
     # that yields (Δt, what it stands for) candidates.  The first of equal candidates names the
     # bottleneck.  (1/|ẇ| and the decay rate: matter has w = 0 and Γ = 0, never the bottleneck;
     # the Courant condition belongs to fluids.)
-    LIMITERS = ('_limit_dynamical', '_limit_background', '_limit_pm', '_limit_p3m')
+    LIMITERS = ('_limit_dynamical', '_limit_background', '_limit_fluids', '_limit_pm',
+                '_limit_p3m')
 
     def get_base_timestep_size(self):
         cosmo = self.cosmo
@@ -670,10 +687,18 @@ class Timeloop(RungStepper):
         v_rms = state['v_rms'][c]
         return commons.machine_ϵ if v_rms < commons.machine_ϵ else v_rms
 
+    def _limit_fluids(self, state):
+        """what the caller's fluid solver allows (its Courant condition, main.py:773-836)"""
+        if self.fluid_limiter is None:
+            return
+        for c in self.components:
+            if c.representation == 'fluid':
+                yield self.fluid_limiter(c, state['a']), f'the fluid solver of {c.name}'
+
     def _limit_pm(self, state):
         """a particle may cross a fraction of a cell of its finest PM mesh (main.py:838-872)"""
         p = self.params
-        for c in self.components:
+        for c in self.particles:
             finest = (0, None)   # (of equal grid sizes the first force names the bottleneck)
             for force, method in c.forces.items():
                 for method_, gridsize in c.potential_gridsizes[force].items():
@@ -688,7 +713,7 @@ class Timeloop(RungStepper):
         """... or of the short-range scale of its P³M force (main.py:873-906); the short-range
         parameters are resolved with the global P³M grid size (commons.py:3254-3300)"""
         p = self.params
-        for c in self.components:
+        for c in self.particles:
             scales = []
             for force, method in c.forces.items():
                 if method != 'p3m':
@@ -733,6 +758,20 @@ class Timeloop(RungStepper):
         if cosmo.enable_Hubble and cosmo.t + Δt_new > cosmo.cosmic_time(1):
             return Δt, 'a ≈ 1'
         return Δt_new, ''
+
+    def drift_fluids(self, Δt, sync_time):
+        """main.drift_fluids (main.py:1279-1299): always over a full base step"""
+        fluids = [c for c in self.components if c.representation == 'fluid']
+        if not fluids:
+            return
+        t_start = self.cosmo.t
+        t_end = self._clip(t_start + Δt, Δt, sync_time)
+        if t_start == t_end:
+            return
+        ᔑdt = self.integrals(t_start, t_end)
+        a_end = self.cosmo.scale_factor(t_end)
+        for c in fluids:
+            self.fluid_drift(c, ᔑdt, a_end)
 
     def _advance(self, Δt, sync_time):
         # universals.t += 0.5*Δt, snapped onto the sync time (main.py:343-346, 353-356)
@@ -838,7 +877,7 @@ class Timeloop(RungStepper):
                 if time_step > time_step_previous:
                     time_step_previous = time_step
                     if time_step_type == 'init':
-                        for c in components:
+                        for c in self.particles:
                             c.assign_rungs(Δt, self.fac_softening)
                     self.time_step, self.Δt = time_step, Δt
                     Δt_print = Δt
@@ -861,6 +900,7 @@ class Timeloop(RungStepper):
                         recompute_Δt_max = False
                         continue
                 elif time_step_type == 'full':
+                    self.drift_fluids(Δt, sync_time)
                     self.driftkick_short(Δt, sync_time)
                     self._advance(Δt, sync_time)
                     self._next_drift = self._predict_drift('full', Δt, sync_time, dump_time)
