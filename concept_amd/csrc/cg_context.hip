@@ -432,6 +432,7 @@ extern "C" int cg_destroy(cg_ctx *c) {
     (void)hipFree(c->sr_sparse_partial);
     (void)hipFree(c->scan_tmp);
     (void)hipFree(c->sr_tmp);
+    (void)hipFree(c->sr_sub_tmp);
     for (int i = 0; i < 3; i++) {
         if (c->sr_streams[i]) (void)hipStreamDestroy(c->sr_streams[i]);
         if (c->sr_join[i]) (void)hipEventDestroy(c->sr_join[i]);

@@ -137,6 +137,9 @@ struct cg_ctx {
     size_t scan_tmp_bytes = 0;
     void *sr_tmp = nullptr;  // short-range cell-list counters
     size_t sr_tmp_bytes = 0;
+    // lists by tile: rows of the densely populated tiles re-ordered by sub-cell (scratch)
+    void *sr_sub_tmp = nullptr;
+    size_t sr_sub_bytes = 0;
     i64 ntiles = 0;
     CicGeom geom_deposit{}, geom_gather{};
     // tile histogram of the NEXT drift prepared by cg_gather_kick_tiled_prepare

@@ -71,7 +71,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SRM_WAVES 8
 #endif
 #ifndef SRM_CAP
-#define SRM_CAP (SRM_LDS_TABLE ? 1792 : 1920)
+#define SRM_CAP (SRM_LDS_TABLE ? 1792 : 2016)
 #endif
 constexpr int kZB = 16;               // tiles per z block of the operand coordinates
 constexpr int kCap = SRM_CAP;         // supplier rows a workgroup holds in LDS (< 2048)
@@ -175,6 +175,147 @@ __global__ __launch_bounds__(256) void k_srm_scatter(const double *__restrict__ 
     }
 }
 
+// inclusive scan over the 64 lanes of a wave in DPP adds
+__device__ __forceinline__ unsigned srm_wave_scan(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Density-adaptive order inside the tiles (the counterpart of the reference's automatic
+// subtile refinement, species.py:4031-4142: subtiles fine enough to hold a handful of
+// particles each).  A tile with many particles has its rows of the list re-ordered by
+// sub-cell — 4^3 sub-cells, 8^3 from kSubFine particles on, along a Morton curve — so that
+// 16 consecutive rows (a wavefront's receivers; a block of suppliers) are neighbours in space
+// wherever the particles are many: the receivers of a wavefront then see the same suppliers
+// (their lanes finish together), and a supplier block has a bounding box worth testing.
+// Sparse tiles (fewer than kSubMin rows) stay as the tile sort left them.
+// ---------------------------------------------------------------------------
+constexpr int kSubMin = 48;      // rows from which a tile is re-ordered
+constexpr int kSubFine = 1536;   // rows from which 8^3 sub-cells are used instead of 4^3
+
+__global__ __launch_bounds__(256) void k_srm_dense_tiles(const unsigned *__restrict__ offset,
+                                                         unsigned ntiles,
+                                                         unsigned *__restrict__ ndense,
+                                                         unsigned *__restrict__ dense) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    if (offset[t + 1] - offset[t] >= (unsigned)kSubMin) dense[atomicAdd(ndense, 1u)] = t;
+}
+
+__device__ __forceinline__ unsigned srm_spread3(unsigned v) {  // 3 bits -> every third bit
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4);
+}
+__device__ __forceinline__ unsigned srm_subkey(double x, double y, double z, double inv_ext,
+                                               unsigned gx, unsigned gy, unsigned gz, int nsub) {
+    const int a = min(nsub - 1, max(0, (int)((x * inv_ext - (double)gx) * nsub))),
+              b = min(nsub - 1, max(0, (int)((y * inv_ext - (double)gy) * nsub))),
+              c = min(nsub - 1, max(0, (int)((z * inv_ext - (double)gz) * nsub)));
+    return (srm_spread3((unsigned)a) << 2) | (srm_spread3((unsigned)b) << 1) |
+           srm_spread3((unsigned)c);
+}
+
+struct SrmRow {  // what travels with a row of the list
+    double x, y, z;
+    f32x4 a;
+    unsigned order;
+    unsigned pad;
+};
+
+__global__ __launch_bounds__(256) void k_srm_subsort(const unsigned *__restrict__ offset,
+                                                     const unsigned *__restrict__ ndense,
+                                                     const unsigned *__restrict__ dense,
+                                                     double inv_ext, unsigned nt,
+                                                     unsigned *__restrict__ order,
+                                                     double *__restrict__ pos_sorted,
+                                                     f32x4 *__restrict__ aop,
+                                                     SrmRow *__restrict__ scratch) {
+    __shared__ unsigned hist[512], base[512];
+    if (blockIdx.x >= *ndense) return;
+    const unsigned t = dense[blockIdx.x];
+    const unsigned b = offset[t], e = offset[t + 1];
+    const unsigned gz = t % nt, gy = (t / nt) % nt, gx = t / (nt * nt);
+    const int nsub = (e - b) >= (unsigned)kSubFine ? 8 : 4;
+    for (int i = threadIdx.x; i < 512; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (unsigned q = b + threadIdx.x; q < e; q += 256)
+        atomicAdd(&hist[srm_subkey(pos_sorted[3 * (i64)q], pos_sorted[3 * (i64)q + 1],
+                                   pos_sorted[3 * (i64)q + 2], inv_ext, gx, gy, gz, nsub)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive scan of the 512 counts: 8 per lane of one wave
+        unsigned v[8], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            v[i] = hist[8 * threadIdx.x + i];
+            sum += v[i];
+        }
+        unsigned run = srm_wave_scan(sum) - sum;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            base[8 * threadIdx.x + i] = run;
+            run += v[i];
+        }
+    }
+    __syncthreads();
+    for (unsigned q = b + threadIdx.x; q < e; q += 256) {
+        SrmRow r;
+        r.x = pos_sorted[3 * (i64)q], r.y = pos_sorted[3 * (i64)q + 1],
+        r.z = pos_sorted[3 * (i64)q + 2];
+        r.order = order[q];
+        r.pad = 0;
+        if (aop) r.a = aop[q];
+        const unsigned at = atomicAdd(&base[srm_subkey(r.x, r.y, r.z, inv_ext, gx, gy, gz, nsub)],
+                                      1u);
+        scratch[(i64)b + at] = r;
+    }
+    __syncthreads();  // (the workgroup's own writes to global memory, read back by itself)
+    __threadfence_block();
+    for (unsigned q = b + threadIdx.x; q < e; q += 256) {
+        const SrmRow r = scratch[q];
+        pos_sorted[3 * (i64)q] = r.x;
+        pos_sorted[3 * (i64)q + 1] = r.y;
+        pos_sorted[3 * (i64)q + 2] = r.z;
+        order[q] = r.order;
+        if (aop) aop[q] = r.a;
+    }
+}
+
+// Bounding box of every block of 16 consecutive rows of the list (global blocks: rows 16 b ..
+// 16 b + 15), in units of the tile extent, kept behind the operand rows: the sweep does not
+// form the products of a block none of whose rows can be in range of any of a wavefront's
+// receivers — the minimum-distance test of the reference's subtile pairs
+// (interactions.py:1236-1251) at the granularity the sub-cell order above makes worthwhile.
+__global__ __launch_bounds__(256) void k_srm_bbox(const double *__restrict__ pos_sorted,
+                                                  const unsigned *__restrict__ offset,
+                                                  unsigned ntiles, double inv_ext,
+                                                  f32x4 *__restrict__ bb) {
+    const i64 n = offset[ntiles];
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 gb = q >> 4;
+    if (16 * gb >= n) return;
+    const i64 qq = q < n ? q : 16 * gb;  // (past the end: the block's first row again)
+    float lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) lo[d] = hi[d] = (float)(pos_sorted[3 * qq + d] * inv_ext);
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], m));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], m));
+        }
+    }
+    if ((threadIdx.x & 15) == 0) {
+        bb[2 * gb] = f32x4{lo[0], lo[1], lo[2], 0.0f};
+        bb[2 * gb + 1] = f32x4{hi[0], hi[1], hi[2], 0.0f};
+    }
+}
+
 #ifdef SRM_PROBE_COUNT  // probe build: how many trips, candidates, hits, matrix products
 __device__ unsigned long long srm_dbg[8];
 #define SRM_COUNT(i, v) atomicAdd(&srm_dbg[i], (unsigned long long)(v))
@@ -189,17 +330,6 @@ struct SrmParams {
     i64 n_s;                        // rows of the supplier list
     int nt, tablesize;
 };
-
-// inclusive scan over the 64 lanes of a wave in DPP adds
-__device__ __forceinline__ unsigned srm_wave_scan(unsigned v) {
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-    return v;
-}
 
 struct SrmShared {
     double sx[kCap], sy[kCap], sz[kCap];    // the suppliers' positions (FP64, as stored)
@@ -233,7 +363,7 @@ struct SrmMasks {
 struct SrmBit {   // S1 -> S2
     bool have;
     unsigned r;   // row of the block: 4 g + t % 4
-    unsigned e;   // the block's entry: first LDS row | rows inside the wave's range << 11
+    unsigned e;   // the block's entry: LDS row of its row 0 + 16 | first row << 12 | rows << 17
 };
 struct SrmPos {   // S2 -> S3
     bool ok;
@@ -289,8 +419,8 @@ __device__ __forceinline__ void srm_trip(SrmMasks &M, unsigned btab, int g, doub
     }
     // S2
     {
-        pout.ok = bin.have && bin.r < (bin.e >> 11);
-        const unsigned row = pout.ok ? (bin.e & 0x7ffu) + bin.r : 0u;
+        pout.ok = bin.have && bin.r - ((bin.e >> 12) & 31u) < (bin.e >> 17);
+        const unsigned row = pout.ok ? (bin.e & 0xfffu) + bin.r - 16u : 0u;
         pout.sx = S.sx[row];
         pout.sy = S.sy[row];
         pout.sz = S.sz[row];
@@ -322,19 +452,28 @@ __device__ __forceinline__ void srm_candidates(SrmMasks M, unsigned btab, int g,
     SrmBit b0 = {false, 0, 0}, b1 = {false, 0, 0};
     SrmPos p0 = {false, 0, 0, 0, 0x15u}, p1 = {false, 0, 0, 0, 0x15u};
     SrmEv e0 = {0, 0, 0, 0, false}, e1 = {0, 0, 0, 0, false};
-    int idle = 0;  // trips since the masks ran dry: three more empty what is under way
-    for (;;) {
-        if (!__any(srm_left(M)) && ++idle > 3) break;
+    // How many trips the slowest lane needs: one per set bit, plus one for every empty word
+    // with a set bit somewhere behind it (a trip that only moves the words down) — the
+    // maximum over the wave, once, instead of a look at every lane's masks in every trip.
+    int need = 0, behind = 0;
+#pragma unroll
+    for (int w = kWords - 1; w >= 0; w--) {
+        need += __popc(M.m[w]) + (M.m[w] == 0 ? behind : 0);
+        behind |= M.m[w] != 0 ? 1 : 0;
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) need = max(need, __shfl_xor(need, d));
+    const int trips = __builtin_amdgcn_readfirstlane(need) + 3;  // + what is under way at the end
+    for (int trip = 0; trip < trips; trip += 2) {
         srm_trip<FACE>(M, btab, g, xi, yi, zi, S, boxsize, r2_max, r2_index_scaling, table, b0, b1,
                        p0, p1, e0, e1, ax, ay, az);
-        if (!__any(srm_left(M)) && ++idle > 3) break;
         srm_trip<FACE>(M, btab, g, xi, yi, zi, S, boxsize, r2_max, r2_index_scaling, table, b1, b0,
                        p1, p0, e1, e0, ax, ay, az);
     }
 }
 
 #ifndef SRM_WAVES_PER_EU
-#define SRM_WAVES_PER_EU 6
+#define SRM_WAVES_PER_EU 4
 #endif
 __global__ __launch_bounds__(64 * kWaves)
 __attribute__((amdgpu_waves_per_eu(SRM_WAVES_PER_EU, 8))) void k_sr_sweep_mfma(
@@ -346,6 +485,7 @@ __attribute__((amdgpu_waves_per_eu(SRM_WAVES_PER_EU, 8))) void k_sr_sweep_mfma(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
+    const int lane_off = 4 * j + g;  // this lane's element of a 16-row block of operand rows
     const int nt = P.nt;
     const int ta = blockIdx.z, tb = blockIdx.y;
     const unsigned col = (unsigned)(ta * nt + tb) * (unsigned)nt;
@@ -361,6 +501,9 @@ __attribute__((amdgpu_waves_per_eu(SRM_WAVES_PER_EU, 8))) void k_sr_sweep_mfma(
 #endif
     const bool xyface = ta == 0 || ta == nt - 1 || tb == 0 || tb == nt - 1;
     const float *aop1 = (const float *)aop_s;
+    const f32x4 *bbs = aop_s + (P.n_s + 16);   // the blocks' bounding boxes, behind the operand rows
+    // (single-precision coordinates of up to nt tiles: 2^-24 nt each, twice, on a distance ~ 1)
+    const float r2cull = (float)(P.r2_max * P.inv_ext * P.inv_ext) * 1.0001f + 4.0e-6f * (float)P.nt;
     // The filter's threshold.  |u - v| <= kZB + 2 along z and 3 across; error of D against the
     // exact |u - v|^2: the coordinates' rounding moves a distance d ~ 1 by 2 sqrt(3) 2^-24
     // |u|max, i.e. d^2 by ~7 eps |u|max; the two norms carry 3 eps n2max each and the four fused
@@ -393,6 +536,22 @@ __attribute__((amdgpu_waves_per_eu(SRM_WAVES_PER_EU, 8))) void k_sr_sweep_mfma(
             tz1 = __builtin_amdgcn_readlane(tzl, nv - 1);
         }
         const bool wface = xyface || tz0 - 1 < 0 || tz1 + 1 >= nt;
+        // the box of this wave's receivers, in tiles (wave-uniform)
+        float rlo[3], rhi[3];
+        {
+            const double pr[3] = {xi, yi, zi};
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const float v = (float)(pr[d] * P.inv_ext);
+                rlo[d] = valid ? v : 3.0e38f;
+                rhi[d] = valid ? v : -3.0e38f;
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    rlo[d] = fminf(rlo[d], __shfl_xor(rlo[d], m));
+                    rhi[d] = fmaxf(rhi[d], __shfl_xor(rhi[d], m));
+                }
+            }
+        }
         // the receiver in units of the tile extent (FP64: the corners are subtracted exactly)
         // and in single precision relative to the column's corner at the group's first slab: a
         // piece's corner is a whole number of tiles from there (one rounding more, below the
@@ -483,10 +642,14 @@ __attribute__((amdgpu_waves_per_eu(SRM_WAVES_PER_EU, 8))) void k_sr_sweep_mfma(
                 if (!wvalid) continue;
                 // ---- this wave: products over its own rows of every piece, then the pairs ----
                 // (A) lane p: the wave's rows of piece p — slabs tz0 - 1 .. tz1 + 1 — as LDS rows
-                // [pa, pb_) of this window, their first list row and how many 16-row blocks
+                // [pa, pb_) of this window, the list row of the first (pg0) and the blocks of
+                // 16 list rows they lie in: GLOBAL blocks (rows 16 b .. 16 b + 15 of the list,
+                // the ones that have a bounding box), of which the first and the last may reach
+                // past the range
                 int pa = 0, pb_ = 0, pnblk = 0;
                 unsigned pg0 = 0;
                 float pdx = 0, pdy = 0, pdz = 0;  // the piece's corner relative to (ta, tb, zg)
+                float psx = 0, psy = 0, psz = 0;  // the periodic image, in tiles: -nt, 0, +nt
                 if (lane < np) {
                     const int c9 = lane / nseg;
                     const int lo = max((int)S.ps0[lane], tz0 - 1 - zg),
@@ -498,22 +661,29 @@ __attribute__((amdgpu_waves_per_eu(SRM_WAVES_PER_EU, 8))) void k_sr_sweep_mfma(
                         const int a = (int)(max(fa, (i64)r0) - (i64)r0),
                                   b = (int)(min(fb, (i64)r1) - (i64)r0);
                         if (b > a) {
-                            pa = a, pb_ = b, pnblk = (b - a + 15) >> 4;
+                            pa = a, pb_ = b;
                             pg0 = pb + (unsigned)((i64)a + (i64)r0 - (i64)pp);
+                            pnblk = (int)(((pg0 + (unsigned)(b - a) + 15u) >> 4) - (pg0 >> 4));
                         }
                     }
                     pdx = (float)((int)S.pgx[lane] - ta);
                     pdy = (float)((int)S.pgy[lane] - tb);
                     pdz = (float)((int)S.pzb[lane] - zg);
+                    const unsigned im = S.pimg[lane];
+                    psx = (float)(((int)(im & 3) - 1) * nt);
+                    psy = (float)(((int)((im >> 2) & 3) - 1) * nt);
+                    psz = (float)(((int)((im >> 4) & 3) - 1) * nt);
                 }
                 const unsigned pincl = srm_wave_scan((unsigned)pnblk);
                 const int pstart = (int)pincl - pnblk;
                 const int NB = __builtin_amdgcn_readlane((int)pincl, 63);  // the wave's blocks
                 for (int B0 = 0; B0 < NB; B0 += 8 * kWords) {
-                    const int nb = min(8 * kWords, NB - B0);  // blocks of this batch (uniform)
                     // (B) lane b: block B0 + b of the wave's list of blocks -> its piece (first
-                    // lane whose inclusive count exceeds it), LDS rows, list rows
+                    // lane whose inclusive count exceeds it), LDS rows, list rows; then the
+                    // blocks whose bounding box no receiver of the wave can reach are dropped
+                    // and the others move up
                     const int fblk = B0 + lane;
+                    const bool isblk = lane < 8 * kWords && fblk < NB;
                     int pid = 0;
 #pragma unroll
                     for (int step = 32; step; step >>= 1) {
@@ -525,11 +695,44 @@ __attribute__((amdgpu_waves_per_eu(SRM_WAVES_PER_EU, 8))) void k_sr_sweep_mfma(
                               qb_ = __builtin_amdgcn_ds_bpermute(4 * pid, pb_),
                               qs_ = __builtin_amdgcn_ds_bpermute(4 * pid, pstart);
                     const unsigned qg_ = (unsigned)__builtin_amdgcn_ds_bpermute(4 * pid, (int)pg0);
+                    // (every lane takes part in a bpermute: a lane that is switched off reads as 0)
+                    const float sx_ = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * pid, __builtin_bit_cast(int, psx))),
+                                sy_ = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * pid, __builtin_bit_cast(int, psy))),
+                                sz_ = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * pid, __builtin_bit_cast(int, psz)));
                     unsigned btab = 0, grow = 0;
-                    if (lane < nb) {
-                        const int first = qa_ + 16 * (fblk - qs_);
-                        btab = (unsigned)first | ((unsigned)min(16, qb_ - first) << 11);
-                        grow = qg_ + 16u * (unsigned)(fblk - qs_);
+                    bool keep = false;
+                    if (isblk) {
+                        const int k = fblk - qs_, off = (int)(qg_ & 15u);
+                        const int base = qa_ - off + 16 * k;        // LDS row of the block's row 0
+                        const int first = k == 0 ? off : 0,
+                                  last = min(16, qb_ - base);       // its rows inside the range
+                        // entry: LDS row of row 0 (+ 16: it may lie before the window) |
+                        // first row << 12 | number of rows << 17
+                        btab = (unsigned)(base + 16) | ((unsigned)first << 12) |
+                               ((unsigned)(last - first) << 17);
+                        grow = (qg_ & ~15u) + 16u * (unsigned)k;
+                        // minimum distance of the receivers' box to the block's (both in
+                        // tiles; the receivers seen from the supplier's periodic image)
+                        const f32x4 blo = bbs[2 * (i64)(grow >> 4)], bhi = bbs[2 * (i64)(grow >> 4) + 1];
+                        const float gx_ = fmaxf(fmaxf(blo[0] - (rhi[0] + sx_), (rlo[0] + sx_) - bhi[0]), 0.0f),
+                                    gy_ = fmaxf(fmaxf(blo[1] - (rhi[1] + sy_), (rlo[1] + sy_) - bhi[1]), 0.0f),
+                                    gz_ = fmaxf(fmaxf(blo[2] - (rhi[2] + sz_), (rlo[2] + sz_) - bhi[2]), 0.0f);
+                        keep = gx_ * gx_ + gy_ * gy_ + gz_ * gz_ <= r2cull;
+#ifdef SRM_NOCULL
+                        keep = true;
+#endif
+                    }
+                    const unsigned long long kmask = __ballot(keep);
+                    const int nb = __popcll(kmask);   // blocks of this batch (uniform)
+                    SRM_COUNT(5, lane == 0 ? __popcll(__ballot(isblk)) - nb : 0);
+                    if (nb == 0) continue;
+                    {
+                        const int rank = __popcll(kmask & ((1ull << lane) - 1ull));
+                        const int to = 4 * (keep ? rank : 63);
+                        btab = (unsigned)__builtin_amdgcn_ds_permute(to, (int)btab);
+                        grow = (unsigned)__builtin_amdgcn_ds_permute(to, (int)grow);
+                        pid = __builtin_amdgcn_ds_permute(to, pid);
+                        if (lane >= nb) btab = 0, grow = 0;
                     }
                     // (C) the products, eight blocks (one mask word) at a time: operand rows
                     // straight from the list — 16 rows x 16 bytes, one coalesced read
@@ -549,7 +752,8 @@ __attribute__((amdgpu_waves_per_eu(SRM_WAVES_PER_EU, 8))) void k_sr_sweep_mfma(
                                 // never looked at)
                                 const unsigned srow =
                                     (unsigned)__builtin_amdgcn_readlane((int)grow, 8 * w + i);
-                                av[i] = aop1[4 * ((i64)srow + j) + g];
+                                // (a scalar base + one lane offset: no vector address arithmetic)
+                                av[i] = (aop1 + 4 * (i64)srow)[lane_off];
                             }
                             unsigned cur = 0;
 #pragma unroll
@@ -661,6 +865,41 @@ int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
                            inv, 1 / tile_extent, (unsigned)nt, rung, lowest_active, offset, cursor,
                            order, pos_sorted, (f32x4 *)aop);
         CG_LAUNCH_CHECK();
+        // the densely populated tiles: rows re-ordered by sub-cell
+        static int subsort = -1;
+        if (subsort < 0) {
+            const char *env = getenv("CONCEPT_GPU_SR_SUBSORT");
+            subsort = env ? atoi(env) : 1;
+        }
+        if (subsort) {
+            const i64 maxdense = n / kSubMin + 1;
+            const size_t head = (size_t)((4 * (maxdense + 4) + 255) / 256 * 256);
+            const size_t need2 = head + sizeof(SrmRow) * (size_t)n;
+            if (need2 > c->sr_sub_bytes) {
+                CG_HIP(hipStreamSynchronize(c->stream));
+                (void)hipFree(c->sr_sub_tmp);
+                c->sr_sub_tmp = nullptr;
+                c->sr_sub_bytes = 0;
+                CG_HIP(hipMalloc(&c->sr_sub_tmp, need2));
+                c->sr_sub_bytes = need2;
+            }
+            unsigned *ndense = (unsigned *)c->sr_sub_tmp, *dense = ndense + 4;
+            SrmRow *scratch = (SrmRow *)((char *)c->sr_sub_tmp + head);
+            CG_HIP(hipMemsetAsync(ndense, 0, 16, c->stream));
+            hipLaunchKernelGGL(k_srm_dense_tiles, dim3((unsigned)((ntiles + 255) / 256)), dim3(256),
+                               0, c->stream, offset, (unsigned)ntiles, ndense, dense);
+            CG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_srm_subsort, dim3((unsigned)maxdense), dim3(256), 0, c->stream,
+                               offset, ndense, dense, 1 / tile_extent, (unsigned)nt, order,
+                               pos_sorted, (f32x4 *)aop, scratch);
+            CG_LAUNCH_CHECK();
+        }
+        if (aop) {
+            hipLaunchKernelGGL(k_srm_bbox, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                               c->stream, pos_sorted, offset, (unsigned)ntiles, 1 / tile_extent,
+                               (f32x4 *)aop + (n + 16));
+            CG_LAUNCH_CHECK();
+        }
     }
     return 0;
 }

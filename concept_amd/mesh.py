@@ -716,8 +716,10 @@ class PotentialMesh:
         if rung is not None:
             self._check_rungs(n, rung)
         else:
-            # (16 rows of padding: the last 16-row block of the list is read whole)
-            operand = torch.empty((n + 16, 4), dtype=torch.float32, device=pos.device)
+            # operand rows (16 rows of padding: the last 16-row block of the list is read
+            # whole), then the bounding boxes of the 16-row blocks (2 x 4 floats each)
+            operand = torch.empty(4*(n + 16) + 8*(n//16 + 2), dtype=torch.float32,
+                                  device=pos.device)
         check(_L.cg_shortrange_tiles(self._ctx, _ptr(pos), n, int(nt), float(tile_extent),
                                      _ptr(rung) if rung is not None else None, int(lowest),
                                      _ptr(order), _ptr(offset), _ptr(pos_sorted),

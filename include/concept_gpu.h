@@ -350,9 +350,13 @@ int cg_shortrange_sweep_cells_rungs(cg_ctx *ctx, const double *pos_r_sorted,
  * in FP64 exactly as in cg_shortrange_sweep_cells (x_ji, r2, the table index bit-identical).
  * cg_shortrange_tiles lists the particles by tile (Tiling.sort, species.py:775-780), z fastest:
  * order_out[m], pos_sorted_out[3m], offset_out[nt^3 + 1] and, for a list that will supply,
- * operand_out[4(n + 16)] (single precision: (-2v, |v|^2) of the particle's coordinates v inside
- * its tile, the A operand of the products, 4m floats written; the sweep reads whole 16-row blocks,
- * hence the 16 rows of room behind; null for a list of receivers only); with `rung` only the
+ * operand_out[4(n + 16) + 8(n/16 + 2)] (single precision: first (-2v, |v|^2) of the particle's
+ * coordinates v inside its tile, the A operand of the products — 4m floats written, the sweep
+ * reads whole 16-row blocks, hence 16 rows of room — then, from float 4(n + 16) on, the
+ * bounding boxes (min xyz 0, max xyz 0, in tiles) of the blocks of 16 consecutive rows; null
+ * for a list of receivers only).  Tiles of kSubMin = 48 or more particles have their rows
+ * ordered by sub-cell (4^3, from 1536 particles 8^3, Morton order), so that blocks and the
+ * receivers of a wavefront are compact where the particles are many.  With `rung` only the
  * m particles on rungs >= lowest_active_rung are listed (the receivers of a sub-step),
  * otherwise m = n.
  * cg_shortrange_sweep_tiles: dmom_r[order_r[q]] += factor * sum over the suppliers in range, or
@@ -362,12 +366,12 @@ int cg_shortrange_tiles(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, in
                         double tile_extent, const int8_t *rung /*DEV n or null*/,
                         int lowest_active_rung, uint32_t *order_out /*DEV n*/,
                         uint32_t *offset_out /*DEV nt^3+1*/, double *pos_sorted_out /*DEV 3n*/,
-                        float *operand_out /*DEV 4(n+16) or null*/);
+                        float *operand_out /*DEV 4(n+16)+8(n/16+2) or null*/);
 int cg_shortrange_sweep_tiles(cg_ctx *ctx, const double *pos_r_sorted /*DEV*/,
                               const uint32_t *order_r /*DEV*/, const uint32_t *offset_r /*DEV*/,
                               double *dmom_r /*DEV, accumulated*/,
                               const double *pos_s_sorted /*DEV*/, const uint32_t *offset_s /*DEV*/,
-                              const float *operand_s /*DEV 4(n_s+16)*/, int64_t n_s, int64_t nt,
+                              const float *operand_s /*DEV, as written by cg_shortrange_tiles*/, int64_t n_s, int64_t nt,
                               const double *table /*DEV*/, int64_t tablesize,
                               double r2_index_scaling, double r2_max, double factor,
                               const double *factors /*DEV 3*N_rungs-1 or null*/,

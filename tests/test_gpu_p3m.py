@@ -34,12 +34,14 @@ def setup(g):
 
 @pytest.mark.parametrize('sweep', ['cells', 'mfma'])
 @pytest.mark.parametrize('name', CASES)
-def test_shortrange_vs_golden_and_oracle(golden, name, sweep, monkeypatch):
+def test_shortrange_vs_golden_and_oracle(golden, name, sweep=None, monkeypatch=None):
     """(both tile sweeps: the half-tile cells and the lists by tile with the matrix-core
-    pre-filter, shortrange.SWEEP)"""
+    pre-filter, shortrange.SWEEP; called without a sweep — tests/dist_component_worker.py, on
+    several domains — the configured one runs)"""
     from concept_amd import interactions, shortrange
     from oracle import oracle
-    monkeypatch.setattr(shortrange, 'SWEEP', sweep)
+    if sweep is not None:
+        monkeypatch.setattr(shortrange, 'SWEEP', sweep)
     g = golden(name)
     torch, c = setup(g)
     c.populate(g['pos_after_short'], 'pos')
@@ -319,14 +321,15 @@ def test_config3_size_shortrange_vs_oracle_sample(dist, sweep):
 
 
 @pytest.mark.parametrize('sweep', ['cells', 'mfma'])
-def test_adaptive_rungs_vs_reference(golden, sweep, monkeypatch):
+def test_adaptive_rungs_vs_reference(golden, sweep=None, monkeypatch=None):
     """A14/A16 with adaptive rungs on the GPU: RungStepper (initialize_rung_populations,
     kick_long, kick_short, driftkick_short with rung jumps; N_rungs = 4) against the
     reference's own main.py functions.  Rung indices bit-exact at every checkpoint."""
     import torch
     from concept_amd import commons, shortrange, stepper
     from concept_amd.species import Component
-    monkeypatch.setattr(shortrange, 'SWEEP', sweep)
+    if sweep is not None:
+        monkeypatch.setattr(shortrange, 'SWEEP', sweep)
     g = golden('rungs_p3m_n8_g32')
     commons.load_params({
         'boxsize': float(g['boxsize']),
