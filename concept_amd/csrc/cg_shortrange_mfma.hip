@@ -374,7 +374,7 @@ struct SrmEv {    // S3 -> S4
     double x, y, z, t;
     bool hit;
 };
-__device__ __forceinline__ bool srm_left(const SrmMasks &M) {
+[[maybe_unused]] __device__ __forceinline__ bool srm_left(const SrmMasks &M) {
     unsigned any = 0;
 #pragma unroll
     for (int w = 0; w < kWords; w++) any |= M.m[w];
