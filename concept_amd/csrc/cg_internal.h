@@ -195,6 +195,8 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                                double r2_index_scaling, double r2_max, double factor,
                                const double *factors, const signed char *rung,
                                const signed char *rung_jumped, int lowest_active);
+int cgk_shortrange_subsort(cg_ctx *c, const unsigned *offset, i64 n, i64 nper, double extent,
+                           unsigned *order, double *pos_sorted, float *aop);
 int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
                          const signed char *rung, int lowest_active, unsigned *order,
                          unsigned *offset, double *pos_sorted, float *aop);

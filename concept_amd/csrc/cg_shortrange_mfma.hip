@@ -825,6 +825,42 @@ extern "C" int cg_srm_debug_counters(unsigned long long *out, int reset) {
 }
 #endif
 
+// Rows of the densely populated cells of a list (cells of `extent`, nper per dimension, z
+// fastest: the tiles of cg_shortrange_tiles, the half-tiles of cg_shortrange_cells) re-ordered
+// by sub-cell; aop (operand rows that travel with the positions) may be null.
+int cgk_shortrange_subsort(cg_ctx *c, const unsigned *offset, i64 n, i64 nper, double extent,
+                           unsigned *order, double *pos_sorted, float *aop) {
+    static int subsort = -1;
+    if (subsort < 0) {
+        const char *env = getenv("CONCEPT_GPU_SR_SUBSORT");
+        subsort = env ? atoi(env) : 1;
+    }
+    if (!subsort || n <= 0) return 0;
+    const i64 ncells = nper * nper * nper;
+    const i64 maxdense = n / kSubMin + 1;
+    const size_t head = (size_t)((4 * (maxdense + 4) + 255) / 256 * 256);
+    const size_t need2 = head + sizeof(SrmRow) * (size_t)n;
+    if (need2 > c->sr_sub_bytes) {
+        CG_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->sr_sub_tmp);
+        c->sr_sub_tmp = nullptr;
+        c->sr_sub_bytes = 0;
+        CG_HIP(hipMalloc(&c->sr_sub_tmp, need2));
+        c->sr_sub_bytes = need2;
+    }
+    unsigned *ndense = (unsigned *)c->sr_sub_tmp, *dense = ndense + 4;
+    SrmRow *scratch = (SrmRow *)((char *)c->sr_sub_tmp + head);
+    CG_HIP(hipMemsetAsync(ndense, 0, 16, c->stream));
+    hipLaunchKernelGGL(k_srm_dense_tiles, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0,
+                       c->stream, offset, (unsigned)ncells, ndense, dense);
+    CG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_srm_subsort, dim3((unsigned)maxdense), dim3(256), 0, c->stream, offset,
+                       ndense, dense, 1 / extent, (unsigned)nper, order, pos_sorted, (f32x4 *)aop,
+                       scratch);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
 int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
                          const signed char *rung, int lowest_active, unsigned *order,
                          unsigned *offset, double *pos_sorted, float *aop) {
@@ -866,34 +902,7 @@ int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
                            order, pos_sorted, (f32x4 *)aop);
         CG_LAUNCH_CHECK();
         // the densely populated tiles: rows re-ordered by sub-cell
-        static int subsort = -1;
-        if (subsort < 0) {
-            const char *env = getenv("CONCEPT_GPU_SR_SUBSORT");
-            subsort = env ? atoi(env) : 1;
-        }
-        if (subsort) {
-            const i64 maxdense = n / kSubMin + 1;
-            const size_t head = (size_t)((4 * (maxdense + 4) + 255) / 256 * 256);
-            const size_t need2 = head + sizeof(SrmRow) * (size_t)n;
-            if (need2 > c->sr_sub_bytes) {
-                CG_HIP(hipStreamSynchronize(c->stream));
-                (void)hipFree(c->sr_sub_tmp);
-                c->sr_sub_tmp = nullptr;
-                c->sr_sub_bytes = 0;
-                CG_HIP(hipMalloc(&c->sr_sub_tmp, need2));
-                c->sr_sub_bytes = need2;
-            }
-            unsigned *ndense = (unsigned *)c->sr_sub_tmp, *dense = ndense + 4;
-            SrmRow *scratch = (SrmRow *)((char *)c->sr_sub_tmp + head);
-            CG_HIP(hipMemsetAsync(ndense, 0, 16, c->stream));
-            hipLaunchKernelGGL(k_srm_dense_tiles, dim3((unsigned)((ntiles + 255) / 256)), dim3(256),
-                               0, c->stream, offset, (unsigned)ntiles, ndense, dense);
-            CG_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_srm_subsort, dim3((unsigned)maxdense), dim3(256), 0, c->stream,
-                               offset, ndense, dense, 1 / tile_extent, (unsigned)nt, order,
-                               pos_sorted, (f32x4 *)aop, scratch);
-            CG_LAUNCH_CHECK();
-        }
+        if (cgk_shortrange_subsort(c, offset, n, nt, tile_extent, order, pos_sorted, aop)) return 1;
         if (aop) {
             hipLaunchKernelGGL(k_srm_bbox, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                                c->stream, pos_sorted, offset, (unsigned)ntiles, 1 / tile_extent,

@@ -32,11 +32,11 @@ def main():
         test_gpu_p3m.test_timeloop_sequence_vs_reference(golden, arg)
     elif case == 'rungs':
         import test_gpu_p3m
-        test_gpu_p3m.test_adaptive_rungs_vs_reference(golden)
+        test_gpu_p3m.test_adaptive_rungs_vs_reference(golden, None, None)
         test_gpu_p3m.test_adaptive_rungs_knot_across_domains()
     elif case == 'p3m_kick':
         import test_gpu_p3m
-        test_gpu_p3m.test_shortrange_vs_golden_and_oracle(golden, arg)
+        test_gpu_p3m.test_shortrange_vs_golden_and_oracle(golden, arg, None, None)
         test_gpu_p3m.test_p3m_full_kick_any(golden)
     elif case == 'mixed':
         import test_gpu_fluid

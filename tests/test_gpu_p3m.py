@@ -34,10 +34,10 @@ def setup(g):
 
 @pytest.mark.parametrize('sweep', ['cells', 'mfma'])
 @pytest.mark.parametrize('name', CASES)
-def test_shortrange_vs_golden_and_oracle(golden, name, sweep=None, monkeypatch=None):
+def test_shortrange_vs_golden_and_oracle(golden, name, sweep, monkeypatch):
     """(both tile sweeps: the half-tile cells and the lists by tile with the matrix-core
-    pre-filter, shortrange.SWEEP; called without a sweep — tests/dist_component_worker.py, on
-    several domains — the configured one runs)"""
+    pre-filter, shortrange.SWEEP; sweep None — tests/dist_component_worker.py, on several
+    domains — runs the configured one)"""
     from concept_amd import interactions, shortrange
     from oracle import oracle
     if sweep is not None:
@@ -321,7 +321,7 @@ def test_config3_size_shortrange_vs_oracle_sample(dist, sweep):
 
 
 @pytest.mark.parametrize('sweep', ['cells', 'mfma'])
-def test_adaptive_rungs_vs_reference(golden, sweep=None, monkeypatch=None):
+def test_adaptive_rungs_vs_reference(golden, sweep, monkeypatch):
     """A14/A16 with adaptive rungs on the GPU: RungStepper (initialize_rung_populations,
     kick_long, kick_short, driftkick_short with rung jumps; N_rungs = 4) against the
     reference's own main.py functions.  Rung indices bit-exact at every checkpoint."""
