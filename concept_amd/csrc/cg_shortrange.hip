@@ -498,15 +498,53 @@ __device__ __forceinline__ unsigned sr_cell(const double *__restrict__ pos, i64 
     return (c[0] * nc + c[1]) * nc + c[2];
 }
 
+// The cell list is a counting sort by cell: a histogram, a scan, a scatter.  Device-scope
+// atomics execute memory-side on MI355X (2^31 of them take 77 ms): one per particle, twice, was
+// most of the list's time.  Particle memory is in mesh-tile order (16^3 mesh cells), so the 1024
+// consecutive particles a workgroup takes fall into a few hundred short-range cells at most:
+// they are counted in an LDS hash table first (key -> slot by open addressing, the slot's counter
+// hands every particle its rank among the workgroup's particles of that cell), and the
+// workgroup then issues ONE device atomic per cell it met.  Particles in any other order still
+// sort correctly (up to 1024 distinct cells fit the table: one per particle).
+constexpr int kSrHashSlots = 2048, kSrPerThread = 4;
+struct SrHash {
+    unsigned key[kSrHashSlots], cnt[kSrHashSlots];
+};
+__device__ __forceinline__ void sr_hash_clear(SrHash &H) {
+    for (int i = threadIdx.x; i < kSrHashSlots; i += 256) {
+        H.key[i] = 0xffffffffu;
+        H.cnt[i] = 0;
+    }
+}
+// returns the slot of `key`; rank = how many of the workgroup's particles took it before
+__device__ __forceinline__ unsigned sr_hash_insert(SrHash &H, unsigned key, unsigned &rank) {
+    unsigned slot = (key * 2654435761u) >> (32 - 11);
+    for (;;) {
+        const unsigned old = atomicCAS(&H.key[slot], 0xffffffffu, key);
+        if (old == 0xffffffffu || old == key) break;
+        slot = (slot + 1) & (kSrHashSlots - 1);
+    }
+    rank = atomicAdd(&H.cnt[slot], 1u);
+    return slot;
+}
 __global__ __launch_bounds__(256) void k_sr_cell_histogram(const double *__restrict__ pos, i64 n,
                                                            double inv, double ext, unsigned nt,
                                                            unsigned *__restrict__ count) {
-    const int lane = threadIdx.x & 63;
-    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned key = p < n ? sr_cell(pos, p, inv, ext, nt) : 0xffffffffu;
-    int rs, rl;
-    sr_wave_runs(key, lane, rs, rl);
-    if (lane == rs && p < n) atomicAdd(&count[key], (unsigned)rl);
+    __shared__ SrHash H;
+    sr_hash_clear(H);
+    __syncthreads();
+    const i64 base = (i64)blockIdx.x * (256 * kSrPerThread);
+#pragma unroll
+    for (int u = 0; u < kSrPerThread; u++) {
+        const i64 p = base + threadIdx.x + 256 * u;
+        if (p < n) {
+            unsigned rank;
+            sr_hash_insert(H, sr_cell(pos, p, inv, ext, nt), rank);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSrHashSlots; i += 256)
+        if (H.cnt[i]) atomicAdd(&count[H.key[i]], H.cnt[i]);
 }
 __global__ __launch_bounds__(256) void k_sr_cell_scatter(const double *__restrict__ pos, i64 n,
                                                          double inv, double ext, unsigned nt,
@@ -514,20 +552,36 @@ __global__ __launch_bounds__(256) void k_sr_cell_scatter(const double *__restric
                                                          unsigned *__restrict__ cursor,
                                                          unsigned *__restrict__ order,
                                                          double *__restrict__ pos_sorted) {
-    const int lane = threadIdx.x & 63;
-    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned key = p < n ? sr_cell(pos, p, inv, ext, nt) : 0xffffffffu;
-    int rs, rl;
-    sr_wave_runs(key, lane, rs, rl);
-    unsigned first = 0;
-    if (lane == rs && p < n) first = offset[key] + atomicAdd(&cursor[key], (unsigned)rl);
-    first = __shfl(first, rs);
-    if (p < n) {
-        const i64 q = (i64)first + (lane - rs);
-        order[q] = (unsigned)p;
-        pos_sorted[3 * q] = pos[3 * p];
-        pos_sorted[3 * q + 1] = pos[3 * p + 1];
-        pos_sorted[3 * q + 2] = pos[3 * p + 2];
+    __shared__ SrHash H;
+    sr_hash_clear(H);
+    __syncthreads();
+    const i64 base = (i64)blockIdx.x * (256 * kSrPerThread);
+    unsigned slot[kSrPerThread], rank[kSrPerThread];
+    double x[kSrPerThread], y[kSrPerThread], z[kSrPerThread];
+#pragma unroll
+    for (int u = 0; u < kSrPerThread; u++) {
+        const i64 p = base + threadIdx.x + 256 * u;
+        slot[u] = 0, rank[u] = 0;
+        if (p < n) {
+            x[u] = pos[3 * p], y[u] = pos[3 * p + 1], z[u] = pos[3 * p + 2];
+            slot[u] = sr_hash_insert(H, sr_cell(pos, p, inv, ext, nt), rank[u]);
+        }
+    }
+    __syncthreads();
+    // a slot's first row in the list: the cell's offset + what earlier workgroups reserved
+    for (int i = threadIdx.x; i < kSrHashSlots; i += 256)
+        if (H.cnt[i]) H.cnt[i] = offset[H.key[i]] + atomicAdd(&cursor[H.key[i]], H.cnt[i]);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kSrPerThread; u++) {
+        const i64 p = base + threadIdx.x + 256 * u;
+        if (p < n) {
+            const i64 q = (i64)H.cnt[slot[u]] + rank[u];
+            order[q] = (unsigned)p;
+            pos_sorted[3 * q] = x[u];
+            pos_sorted[3 * q + 1] = y[u];
+            pos_sorted[3 * q + 2] = z[u];
+        }
     }
 }
 
@@ -545,7 +599,7 @@ int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
     }
     unsigned *count = (unsigned *)c->sr_tmp, *cursor = count + (ncells + 1);
     CG_HIP(hipMemsetAsync(c->sr_tmp, 0, 8 * (ncells + 1), c->stream));
-    i64 blocks = (n + 255) / 256;
+    i64 blocks = (n + 256 * kSrPerThread - 1) / (256 * kSrPerThread);
     if (n > 0) {
         hipLaunchKernelGGL(k_sr_cell_histogram, dim3((unsigned)blocks), dim3(256), 0, c->stream,
                            pos, n, inv, tile_extent, (unsigned)nt, count);
@@ -606,6 +660,13 @@ __device__ __forceinline__ void sr_cell_batch(int k, int S, int b, double xi, do
         t[j] = 0.0;
 #ifdef CG_SR_PROBE_NOLOAD  // probe build (tools/variant.py): the sweep without its table gather
         if (hit[j]) t[j] = r2[j] * r2_index_scaling;
+#elif defined(CG_SR_BRANCHFREE)
+        // (probe) no exec-mask region: a miss looks entry 0 up and is multiplied away
+        {
+            const unsigned idx = hit[j] ? (unsigned)(int)(r2[j] * r2_index_scaling) : 0u;
+            const double tv = table[idx];
+            t[j] = hit[j] ? tv : 0.0;
+        }
 #else
         if (hit[j]) t[j] = table[(unsigned)(int)(r2[j] * r2_index_scaling)];  // gravity.py:316-321
 #endif

@@ -629,9 +629,9 @@ def test_shortrange_pre32_variant_vs_oracle():
             "import numpy as np, os\n"
             "import test_gpu_p3m as t\n"
             "golden = lambda name: np.load(os.path.join(%r, 'golden', name + '.npz'))\n"
-            "for name in t.CASES: t.test_shortrange_vs_golden_and_oracle(golden, name)\n"
+            "for name in t.CASES: t.test_shortrange_vs_golden_and_oracle(golden, name, None, None)\n"
             "for seed in range(6): t.test_random_shortrange_vs_oracle(seed)\n"
-            "t.test_adaptive_rungs_vs_reference(golden)\n"
+            "t.test_adaptive_rungs_vs_reference(golden, None, None)\n"
             "print('PRE32-OK')\n") % (here, os.path.dirname(here), here)
     p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, CONCEPT_GPU_SR_PRE32='1'),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
