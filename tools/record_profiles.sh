@@ -1,9 +1,9 @@
 #!/bin/bash
 # Records the round's measurements on the GPU box into gpurun_out/profiles_new/ (copied into
-# profiles/ afterwards):  tools/record_profiles.sh r03 <commit>
+# profiles/ afterwards):  tools/record_profiles.sh r04 <commit>
 # One-liners a driver can reproduce are listed in profiles/README.md.
 set -u
-TAG=${1:-r03}; COMMIT=${2:-unknown}
+TAG=${1:-r04}; COMMIT=${2:-unknown}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_new; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -35,6 +35,16 @@ python bench.py --no-fused --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}
 python bench.py --workload c3_1024c_2048 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_c3_1024c_2048.json
 CONCEPT_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_ns_forced_dist_1rank_rccl.json
 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_ns_full_default.json
+python bench.py --workload ns_256M_1024 --p3m --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_p3m_ns_256M_1024.json
+python bench.py --weak --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_weak_1gpu.json
+python bench.py --workload c2_256c_512 --gpus 8 --dry-links --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_c2_8ranks_gloo_dry_links.json
+# 5. the tile sweep with the matrix-core pre-filter beside the cells sweep (round 4)
+python tools/sr_mfma_check.py big time > $OUT/${TAG}_sr_tiles_vs_cells.txt 2>&1
+(cd /tmp && SR_DIST=uniform $R/tools/pmc_sr.sh > $OUT/${TAG}_pmc_sr_tiles.txt 2>&1)
+python tools/variant.py tools/_variants/srm_count.so cg_shortrange_mfma.hip -DSRM_PROBE_COUNT > /dev/null 2>&1
+python tools/variant.py tools/_variants/srm_nocand.so cg_shortrange_mfma.hip -DSRM_PROBE_NOCAND > /dev/null 2>&1
+python tools/variant.py tools/_variants/srm_nomfma.so cg_shortrange_mfma.hip -DSRM_PROBE_NOMFMA > /dev/null 2>&1
+for v in "" tools/_variants/srm_nocand.so tools/_variants/srm_nomfma.so tools/_variants/srm_count.so; do CONCEPT_GPU_LIB=$v python tools/sr_mfma_time.py; done 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_sr_tiles_phases_and_counts.txt
 ./tools/mall_probe > $OUT/${TAG}_mall_probe.txt 2>&1
 rm -rf $OUT/stats $OUT/pmc_f $OUT/pmc_w $OUT/stats_p3m $OUT/pmc_sr
 ls -la $OUT
