@@ -718,3 +718,20 @@ def test_sparse_shortrange_equals_the_cells_sweep(k):
         mesh.shortrange_sparse(pos_r_t, torch.arange(9, device='cuda'), got2, pos_s_t, table,
                                4095/maxr2, rng_**2, 1.0)
     mesh.close()
+
+
+def test_tile_sweep_on_the_randomised_and_multi_component_cases(monkeypatch):
+    """The second tile sweep (lists by tile, sub-cell order, block boxes, matrix-core range
+    pre-filter; shortrange.SWEEP = 'mfma') through the cases the default one is fuzzed with:
+    the random parameter draws (tile size above the range, small tables, the three softening
+    kernels, blobs), two components with receivers that are not suppliers, the knot with
+    adaptive rungs, whole random P³M time loops with rungs."""
+    from concept_amd import shortrange
+    monkeypatch.setattr(shortrange, 'SWEEP', 'mfma')
+    for seed in range(16):
+        test_random_shortrange_vs_oracle(seed)
+    for cell_centered in (True, False):
+        test_shortrange_two_components_receivers_not_suppliers(cell_centered)
+    test_adaptive_rungs_knot_across_domains()
+    for seed in range(2):
+        test_random_p3m_timeloops_across_domains(seed)

@@ -39,5 +39,5 @@ for dist in (sys.argv[1:] or ['uniform', 'clustered']):
         _lib.raw().cg_srm_debug_counters(out, 1)
         k = reps + 1
         print(f'   per sweep: wave trips {out[0]/k:.4g}, lane candidates {out[1]/k:.4g} (in range of '
-              f'the wave {out[4]/k:.4g}), hits {out[2]/k:.4g}, products {out[3]/k:.4g}, blocks culled {out[5]/k:.4g} '
+              f'the wave {out[4]/k:.4g}), hits {out[2]/k:.4g}, products {out[3]/k:.4g} '
               f'-> lanes busy per trip {out[1]/max(out[0], 1)/64:.2f}', flush=True)
