@@ -433,6 +433,14 @@ extern "C" int cg_destroy(cg_ctx *c) {
     (void)hipFree(c->scan_tmp);
     (void)hipFree(c->sr_tmp);
     (void)hipFree(c->sr_sub_tmp);
+    (void)hipFree(c->srd_small);
+    (void)hipFree(c->srd_buf);
+    if (c->srd_host) (void)hipHostFree(c->srd_host);
+    if (c->srd_stream) {
+        (void)hipStreamDestroy(c->srd_stream);
+        (void)hipEventDestroy(c->srd_fork);
+        (void)hipEventDestroy(c->srd_join);
+    }
     for (int i = 0; i < 3; i++) {
         if (c->sr_streams[i]) (void)hipStreamDestroy(c->sr_streams[i]);
         if (c->sr_join[i]) (void)hipEventDestroy(c->sr_join[i]);

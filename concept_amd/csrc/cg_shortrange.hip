@@ -960,7 +960,7 @@ k_sr_sweep_cells(
     // With rungs, most sub-steps of a base step kick the highest rungs only (main.py:1347-1624
     // visits the tiles' active rungs only, species.py tiles_rungs_N): a tile none of whose
     // receivers is active is gone after one byte
-    if (RUNGS && P.tile_active && !P.tile_active[((unsigned)ta * nt + (unsigned)tb) * nt + (unsigned)tc]) return;
+    if (P.tile_active && !P.tile_active[((unsigned)ta * nt + (unsigned)tb) * nt + (unsigned)tc]) return;
     const double ext = P.boxsize / (double)nt;  // tile extent
     const double ox0 = ta * ext, oy0 = tb * ext, oz0 = tc * ext;  // the tile's lower corner
     // receivers of this wave: cell column (2 ta + wx, 2 tb + wy), cells 2 tc and 2 tc + 1
@@ -1273,6 +1273,17 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
         CG_LAUNCH_CHECK();
         P.tile_active = c->sr_tile_active;
     }
+    // The densely populated tiles go to the sweep with sub-cell order and box culling
+    // (cg_shortrange_dense.hip); `take` then keeps this sweep off them.  (Not with a subset of
+    // active rungs: those sub-steps kick few receivers per tile.)
+    const unsigned char *take = nullptr;
+    if (!(rung && lowest_active > 0)) {
+        if (cgk_shortrange_dense(c, pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, nt,
+                                 table, r2_index_scaling, r2_max, factor, factors, rung_jumped,
+                                 &take))
+            return 1;
+        if (take) P.tile_active = take;
+    }
     // The single-precision pre-test's threshold: coordinates relative to the tile's corner are
     // below 3.5 tile extents E in size, a float carries them to 2^-24 relative, a difference of
     // two to 2 * 3.5 E * 2^-24, and |x|^2 near r^2_max moves by at most
@@ -1318,5 +1329,6 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                        dmom_r, pos_s_sorted, off_s, table, P, 0);
     CG_LAUNCH_CHECK();
     for (int slab = 0; slab < 3; slab++) CG_HIP(hipStreamWaitEvent(c->stream, c->sr_join[slab], 0));
+    if (take && cgk_shortrange_dense_join(c)) return 1;
     return 0;
 }

@@ -1,0 +1,476 @@
+// cg_shortrange_dense.hip — the densely populated tiles of the P3M short-range sweep (round 4).
+//
+//   particle_particle           interactions.py:1563-1791  tile neighbours, periodic offset
+//   gravity_pairwise_shortrange gravity.py:263-354         r2 cut, r2-indexed table, Δmom
+//   subtile refinement          species.py:4031-4142 (init_subtiling: subtiles of a handful of
+//                               particles), interactions.py:145-329 (refinement chosen from the
+//                               population), interactions.py:1236-1251 (subtile pairs further apart
+//                               than the range are never visited)
+//
+// The cells sweep (cg_shortrange.hip) searches 5 x 5 x 6 half-tile cells around every receiver
+// whatever the density: 4.2-4.4 pair tests per pair in range.  Where a tile holds a hundred
+// particles or more, the reference refines its subtiles until each holds ~10 and skips the
+// subtile pairs that are out of reach.  The counterpart here:
+//  * the tile list of cg_shortrange_tiles (cg_shortrange_mfma.hip) orders the rows of such a tile
+//    along a Hilbert curve through 8^3 sub-cells, so that ANY run of consecutive rows is a
+//    compact blob whose size follows the density (a run of k rows at density rho fills a volume
+//    ~ k / rho) — subtiles by count instead of by edge length;
+//  * a wavefront takes 16 consecutive receivers (four lanes each) and the suppliers come as
+//    "quads" of 4 consecutive rows: a quad whose bounding box is further than the range from
+//    the bounding box of the 16 receivers is skipped (one lane per quad, 64 quads per look);
+//  * the quads that are left are evaluated exactly as the cells sweep evaluates a row of
+//    suppliers — 16 receivers x 4 suppliers per trip, (xi - xj) + offset, r2, the range test,
+//    table[int(r2*scaling)], three multiply-adds in FP64 — every contribution bit-identical to the
+//    cells sweep's, only the order of the additions differs.  All 64 lanes work in every trip:
+//    no per-lane candidate lists.
+// Measured on a Gaussian blob of the bench's clustered box (tools: DESIGN.md §16b): 2.1-2.6 pair
+// tests per pair in range in tiles of 256 particles and more, 3.2 at 128-256, 4.1 at 64-128
+// (the cells sweep: 4.1-4.7), worse below — so cg_shortrange_sweep_cells hands the tiles above a
+// population threshold to this kernel and keeps the others.
+#include <cstdlib>
+
+#include "cg_internal.h"
+
+#define CG_LAUNCH_CHECK()                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) {                                                               \
+            cg_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                           \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+namespace {
+
+#ifndef SRD_CAP
+#define SRD_CAP 960
+#endif
+#ifndef SRD_WAVES_PER_EU
+#define SRD_WAVES_PER_EU 5
+#endif
+constexpr int kdWaves = 4;             // wavefronts per workgroup, 16 receivers each
+constexpr int kdChunk = 16 * kdWaves;  // receivers per work item
+constexpr int kdCap = SRD_CAP;         // supplier rows per LDS window (a multiple of 64)
+constexpr int kdQuads = kdCap / 4;
+constexpr int kdPieces = 18;           // 9 tile columns x 2 (a column that wraps around in z)
+static_assert(kdCap % 64 == 0, "whole looks of 64 quads... rows");
+
+struct SrdParams {
+    double boxsize, ext, inv_ext, r2_index_scaling, r2_max, factor;
+    const double *factors;          // adaptive rungs: factors[rung_jumped[i]] per receiver
+    const signed char *rung_jumped;
+    int nt;
+};
+
+struct SrdShared {
+    // the suppliers' positions as stored (+ 4 rows far away: the stand-in of an absent quad)
+    double sx[kdCap + 4], sy[kdCap + 4], sz[kdCap + 4];
+    unsigned char simg[kdCap + 4];     // image code of the row: (ix, iy, iz) 2 bits each, 1 = none
+    // bounding box of every quad: tile units relative to the receivers' tile, image applied
+    float qlo[3][kdQuads], qhi[3][kdQuads];
+    unsigned pbeg[kdPieces], ppre[kdPieces + 1];
+    unsigned char pimg[kdPieces];
+};
+
+// inclusive scan over the 64 lanes of a wave in DPP adds
+__device__ __forceinline__ unsigned srd_wave_scan(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// Population of every tile from the half-tile cell list (8 cells = 4 z-pairs): how many
+// receivers sit in tiles of min_pop and more, and in how many tiles
+__global__ __launch_bounds__(256) void k_srd_precheck(const unsigned *__restrict__ off_cells,
+                                                      unsigned nt, unsigned min_pop,
+                                                      unsigned *__restrict__ out) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned pop = 0;
+    if (t < nt * nt * nt) {
+        const unsigned tc = t % nt, tb = (t / nt) % nt, ta = t / (nt * nt), nc = 2 * nt;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const unsigned cell = ((2 * ta + a) * nc + (2 * tb + b)) * nc + 2 * tc;
+                pop += off_cells[cell + 2] - off_cells[cell];
+            }
+    }
+    const bool dense = pop >= min_pop;
+    const unsigned long long m = __ballot(dense);
+    unsigned sum = dense ? pop : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) sum += __shfl_xor(sum, d);
+    if ((threadIdx.x & 63) == 0 && m) {
+        atomicAdd(&out[0], sum);
+        atomicAdd(&out[1], (unsigned)__popcll(m));
+    }
+}
+
+// The plan: one byte per tile for the cells sweep (1 = yours), one work item (tile << 32 |
+// chunk) per 64 receivers of the other tiles
+__global__ __launch_bounds__(256) void k_srd_plan(const unsigned *__restrict__ off_tiles,
+                                                  unsigned ntiles, unsigned min_pop,
+                                                  unsigned char *__restrict__ take,
+                                                  unsigned long long *__restrict__ items,
+                                                  unsigned *__restrict__ nitems) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    const unsigned pop = off_tiles[t + 1] - off_tiles[t];
+    const bool dense = pop >= min_pop;
+    take[t] = dense ? 0 : 1;
+    if (dense) {
+        const unsigned nch = (pop + kdChunk - 1) / kdChunk;
+        const unsigned base = atomicAdd(nitems, nch);
+        for (unsigned c = 0; c < nch; c++) items[base + c] = ((unsigned long long)t << 32) | c;
+    }
+}
+
+// NB quads of 4 supplier rows against the wave's 16 receivers: lane (j, g) pairs receiver j
+// with row g of every quad.  Same arithmetic, in the same order, as sr_cell_batch
+// (cg_shortrange.hip): the table loads of the hits are all issued before the first is used.
+template <bool FACE, int NB>
+__device__ __forceinline__ void srd_quads(const SrdShared &S, const int (&q)[NB], int g, double xi,
+                                          double yi, double zi, double boxsize, double r2_max,
+                                          double r2_index_scaling,
+                                          const double *__restrict__ table, double &ax, double &ay,
+                                          double &az) {
+    double xj[NB], yj[NB], zj[NB], r2[NB], t[NB];
+    bool hit[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const int row = 4 * q[k] + g;
+        xj[k] = xi - S.sx[row];                          // interactions.py:1787-1789
+        yj[k] = yi - S.sy[row];
+        zj[k] = zi - S.sz[row];
+        if (FACE) {                                      // gravity.py:299-302: + the image's
+            const unsigned im = S.simg[row];             // offset -L, 0 or +L (exact products)
+            xj[k] += (double)((int)(im & 3) - 1) * boxsize;
+            yj[k] += (double)((int)((im >> 2) & 3) - 1) * boxsize;
+            zj[k] += (double)((int)((im >> 4) & 3) - 1) * boxsize;
+        }
+        r2[k] = xj[k] * xj[k] + yj[k] * yj[k] + zj[k] * zj[k];  // gravity.py:306
+        hit[k] = r2[k] <= r2_max;                        // gravity.py:311
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        t[k] = 0.0;
+        if (hit[k]) t[k] = table[(unsigned)(int)(r2[k] * r2_index_scaling)];  // gravity.py:316-321
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        ax = __builtin_fma(xj[k], t[k], ax);
+        ay = __builtin_fma(yj[k], t[k], ay);
+        az = __builtin_fma(zj[k], t[k], az);
+    }
+}
+
+// the quads of one look (bits of `m`: quad 64 look + bit), four at a time
+template <bool FACE>
+__device__ __forceinline__ void srd_look(const SrdShared &S, unsigned long long m, int q0, int g,
+                                         double xi, double yi, double zi, double boxsize,
+                                         double r2_max, double r2_index_scaling,
+                                         const double *__restrict__ table, double &ax, double &ay,
+                                         double &az) {
+    while (m) {
+        int q[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            q[k] = m ? q0 + (int)__builtin_ctzll(m) : kdQuads;  // (none left: the far quad)
+            m &= m - 1;                                         // (0 stays 0)
+        }
+        if (q[2] != kdQuads) {
+            srd_quads<FACE, 4>(S, q, g, xi, yi, zi, boxsize, r2_max, r2_index_scaling, table, ax, ay,
+                               az);
+        } else {
+            const int q2[2] = {q[0], q[1]};
+            srd_quads<FACE, 2>(S, q2, g, xi, yi, zi, boxsize, r2_max, r2_index_scaling, table, ax,
+                               ay, az);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * kdWaves)
+__attribute__((amdgpu_waves_per_eu(SRD_WAVES_PER_EU, 8))) void k_sr_sweep_dense(
+    const double *__restrict__ pos_r, const unsigned *__restrict__ order_rt,
+    const unsigned *__restrict__ order_rc, const unsigned *__restrict__ off_r,
+    double *__restrict__ dmom_r, const double *__restrict__ pos_s,
+    const unsigned *__restrict__ off_s, const unsigned long long *__restrict__ items,
+    const unsigned *__restrict__ nitems, const double *__restrict__ table, SrdParams P) {
+    __shared__ SrdShared S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int nt = P.nt;
+    const unsigned count = *nitems;
+    for (unsigned it = blockIdx.x; it < count; it += gridDim.x) {
+    if (it != blockIdx.x) __syncthreads();  // the previous item's tables and rows are done with
+    const unsigned long long item = items[it];
+    const unsigned t = (unsigned)(item >> 32), chunk = (unsigned)item;
+    const int tc = (int)(t % (unsigned)nt), tb = (int)((t / (unsigned)nt) % (unsigned)nt),
+              ta = (int)(t / (unsigned)(nt * nt));
+    const unsigned q0 = off_r[t] + (unsigned)kdChunk * chunk, q1 = min(q0 + (unsigned)kdChunk, off_r[t + 1]);
+    const bool face = ta == 0 || ta == nt - 1 || tb == 0 || tb == nt - 1 || tc == 0 || tc == nt - 1;
+    // the pieces: column (ta + dx, tb + dy), tiles tc - 1 .. tc + 1 — one run of the list (z is
+    // fastest), two where the column wraps around the box in z
+    if (tid < kdPieces) {
+        const int c9 = tid >> 1, half = tid & 1;
+        int gx = ta + c9 / 3 - 1, gy = tb + c9 % 3 - 1;
+        // periodic offset from the tile separation (interactions.py:1615-1621): code 2 = +L
+        unsigned ix = 1, iy = 1, iz = 1;
+        if (gx < 0) { gx += nt; ix = 2; } else if (gx >= nt) { gx -= nt; ix = 0; }
+        if (gy < 0) { gy += nt; iy = 2; } else if (gy >= nt) { gy -= nt; iy = 0; }
+        int za = 0, zb = -1;  // tiles [za, zb] of the column
+        if (tc == 0) {
+            if (half == 0) { za = zb = nt - 1; iz = 2; } else { za = 0; zb = 1; }
+        } else if (tc == nt - 1) {
+            if (half == 0) { za = nt - 2; zb = nt - 1; } else { za = zb = 0; iz = 0; }
+        } else if (half == 0) {
+            za = tc - 1;
+            zb = tc + 1;
+        }
+        const unsigned col = ((unsigned)gx * (unsigned)nt + (unsigned)gy) * (unsigned)nt;
+        unsigned beg = 0, cnt = 0;
+        if (zb >= za) {
+            beg = off_s[col + (unsigned)za];
+            cnt = off_s[col + (unsigned)zb + 1] - beg;
+        }
+        S.pbeg[tid] = beg;
+        S.ppre[tid] = cnt;  // (counts for now)
+        S.pimg[tid] = (unsigned char)(ix | (iy << 2) | (iz << 4));
+    }
+    if (tid < 4) {  // the far quad
+        S.sx[kdCap + tid] = S.sy[kdCap + tid] = S.sz[kdCap + tid] = 1e300;
+        S.simg[kdCap + tid] = 0x15;
+    }
+    // this wave's 16 receivers, four lanes each
+    const unsigned qw = q0 + 16u * (unsigned)wave;
+    const bool wvalid = qw < q1;
+    const bool valid = qw + (unsigned)j < q1;
+    const unsigned ql = valid ? qw + (unsigned)j : q0;  // (a finite stand-in)
+    const double xi = pos_r[3 * (i64)ql], yi = pos_r[3 * (i64)ql + 1], zi = pos_r[3 * (i64)ql + 2];
+    const double cx = (double)ta * P.ext, cy = (double)tb * P.ext, cz = (double)tc * P.ext;
+    // the box of the wave's receivers, in tiles relative to the tile's corner (wave-uniform)
+    float rlo[3], rhi[3];
+    {
+        const double pr[3] = {(xi - cx) * P.inv_ext, (yi - cy) * P.inv_ext, (zi - cz) * P.inv_ext};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float v = (float)pr[d];
+            rlo[d] = valid ? v : 3.0e38f;
+            rhi[d] = valid ? v : -3.0e38f;
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                rlo[d] = fminf(rlo[d], __shfl_xor(rlo[d], m));
+                rhi[d] = fmaxf(rhi[d], __shfl_xor(rhi[d], m));
+            }
+        }
+    }
+    // (single-precision coordinates of size <= 2 tiles: 2^-23 each, on a distance ~ 1)
+    const float r2cull = (float)(P.r2_max * P.inv_ext * P.inv_ext) * 1.0001f + 1.0e-5f;
+    __syncthreads();
+    if (wave == 0) {  // counts -> exclusive prefix
+        const unsigned cnt = lane < kdPieces ? S.ppre[lane] : 0u;
+        const unsigned incl = srd_wave_scan(cnt);
+        if (lane < kdPieces) S.ppre[lane] = incl - cnt;
+        if (lane == kdPieces) S.ppre[kdPieces] = incl;
+    }
+    __syncthreads();
+    const unsigned total = S.ppre[kdPieces];
+    double ax = 0, ay = 0, az = 0;
+    for (unsigned r0 = 0; r0 < total; r0 += kdCap) {
+        const int nrows = (int)(min(total, r0 + (unsigned)kdCap) - r0);
+        const int nq = (nrows + 3) >> 2;
+        if (r0) __syncthreads();  // the previous window has been consumed
+        for (int w = tid; w < 4 * nq; w += 64 * kdWaves) {
+            if (w < nrows) {
+                const unsigned row = r0 + (unsigned)w;
+                int p = 0;  // the last piece that starts at or before the row
+#pragma unroll
+                for (int step = 16; step; step >>= 1)
+                    if (p + step < kdPieces && S.ppre[p + step] <= row) p += step;
+                const i64 src = (i64)S.pbeg[p] + (row - S.ppre[p]);
+                S.sx[w] = pos_s[3 * src];
+                S.sy[w] = pos_s[3 * src + 1];
+                S.sz[w] = pos_s[3 * src + 2];
+                S.simg[w] = S.pimg[p];
+            } else {  // the rest of the last quad: out of everybody's range
+                S.sx[w] = S.sy[w] = S.sz[w] = 1e300;
+                S.simg[w] = 0x15;
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < nq; q += 64 * kdWaves) {
+            float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int w = 4 * q + i;
+                if (w < nrows) {
+                    const unsigned im = S.simg[w];
+                    // x_ji = (xi - xj) + offset: the supplier's image sits at xj - offset
+                    const double v[3] = {
+                        ((S.sx[w] - (double)((int)(im & 3) - 1) * P.boxsize) - cx) * P.inv_ext,
+                        ((S.sy[w] - (double)((int)((im >> 2) & 3) - 1) * P.boxsize) - cy) * P.inv_ext,
+                        ((S.sz[w] - (double)((int)((im >> 4) & 3) - 1) * P.boxsize) - cz) * P.inv_ext};
+#pragma unroll
+                    for (int d = 0; d < 3; d++) {
+                        lo[d] = fminf(lo[d], (float)v[d]);
+                        hi[d] = fmaxf(hi[d], (float)v[d]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                S.qlo[d][q] = lo[d];
+                S.qhi[d][q] = hi[d];
+            }
+        }
+        __syncthreads();
+        if (wvalid)
+        for (int look = 0; 64 * look < nq; look++) {
+            const int q = 64 * look + lane;
+            bool keep = false;
+            if (q < nq) {
+                // minimum distance of the receivers' box to the quad's (interactions.py:1236-1251)
+                float d2 = 0;
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const float gap = fmaxf(fmaxf(S.qlo[d][q] - rhi[d], rlo[d] - S.qhi[d][q]), 0.0f);
+                    d2 = __builtin_fmaf(gap, gap, d2);
+                }
+                keep = d2 <= r2cull;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (face)
+                srd_look<true>(S, m, 64 * look, g, xi, yi, zi, P.boxsize, P.r2_max,
+                               P.r2_index_scaling, table, ax, ay, az);
+            else
+                srd_look<false>(S, m, 64 * look, g, xi, yi, zi, P.boxsize, P.r2_max,
+                                P.r2_index_scaling, table, ax, ay, az);
+        }
+    }
+    // the four lanes of a receiver: one sum, in a fixed order
+    ax += __shfl_xor(ax, 16);
+    ay += __shfl_xor(ay, 16);
+    az += __shfl_xor(az, 16);
+    ax += __shfl_xor(ax, 32);
+    ay += __shfl_xor(ay, 32);
+    az += __shfl_xor(az, 32);
+    if (valid && g == 0) {
+        i64 pi = (i64)order_rt[ql];
+        if (order_rc) pi = (i64)order_rc[pi];
+        // gravity.py:321 (total_factor = factors[rung] * table[...])
+        const double f = P.factors ? P.factors[P.rung_jumped[pi]] : P.factor;
+        dmom_r[3 * pi] += ax * f;
+        dmom_r[3 * pi + 1] += ay * f;
+        dmom_r[3 * pi + 2] += az * f;
+    }
+    }
+}
+
+// grows a device buffer of the context (the stream is drained first: the old one may be in use)
+int srd_reserve(cg_ctx *c, void **buf, size_t *have, size_t need) {
+    if (need <= *have) return 0;
+    CG_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    CG_HIP(hipMalloc(buf, need));
+    *have = need;
+    return 0;
+}
+
+}  // namespace
+
+// CONCEPT_GPU_SR_DENSE=0 switches the dense tiles' sweep off; CONCEPT_GPU_SR_DENSE_MIN is the
+// population from which a tile is "dense" (read at every call: a test may change them)
+int cgk_shortrange_dense_min() {
+    const char *on = getenv("CONCEPT_GPU_SR_DENSE"), *mp = getenv("CONCEPT_GPU_SR_DENSE_MIN");
+    if (on && atoi(on) == 0) return -1;
+    const int min_pop = mp ? atoi(mp) : 96;
+    return min_pop < 1 ? 1 : min_pop;
+}
+
+// Looks at the receivers' half-tile cell list: are there tiles of min_pop receivers and more?
+// If so: tile lists (Hilbert order inside the dense tiles) of the receivers and the suppliers,
+// the byte per tile that keeps the cells sweep off the dense tiles (*take_out) and the launch
+// of the dense tiles' sweep on a stream of its own (joined back into the context's stream by
+// cgk_shortrange_dense_join).  *take_out stays null where the cells sweep does it all.
+int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
+                         const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
+                         const unsigned *off_s, i64 nt, const double *table,
+                         double r2_index_scaling, double r2_max, double factor,
+                         const double *factors, const signed char *rung_jumped,
+                         const unsigned char **take_out) {
+    *take_out = nullptr;
+    const int min_pop = cgk_shortrange_dense_min();
+    if (min_pop < 0 || nt < 4) return 0;
+    const i64 ntiles = nt * nt * nt, ncells = 8 * ntiles;
+    if (!c->srd_host) CG_HIP(hipHostMalloc((void **)&c->srd_host, 64));
+    if (srd_reserve(c, (void **)&c->srd_small, &c->srd_small_bytes, 64)) return 1;
+    unsigned *dev = (unsigned *)c->srd_small;  // [0] receivers in dense tiles, [1] dense tiles, [2] items
+    CG_HIP(hipMemsetAsync(dev, 0, 16, c->stream));
+    hipLaunchKernelGGL(k_srd_precheck, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0,
+                       c->stream, off_r, (unsigned)nt, (unsigned)min_pop, dev);
+    CG_LAUNCH_CHECK();
+    CG_HIP(hipMemcpyAsync(c->srd_host, dev, 8, hipMemcpyDeviceToHost, c->stream));
+    CG_HIP(hipMemcpyAsync(c->srd_host + 2, off_r + ncells, 4, hipMemcpyDeviceToHost, c->stream));
+    CG_HIP(hipMemcpyAsync(c->srd_host + 3, off_s + ncells, 4, hipMemcpyDeviceToHost, c->stream));
+    CG_HIP(hipStreamSynchronize(c->stream));
+    const i64 ndense = c->srd_host[0], tdense = c->srd_host[1], n_r = c->srd_host[2],
+              n_s = c->srd_host[3];
+    if (ndense == 0) return 0;
+    const bool same = pos_r_sorted == pos_s_sorted && off_r == off_s;
+    // buffers: take | items | offsets r, s | order r, s | positions r, s
+    const size_t a_take = 0, a_items = (size_t)((ntiles + 255) / 256 * 256),
+                 a_offr = a_items + 8 * (size_t)(ndense / kdChunk + tdense + 1),
+                 a_offs = a_offr + (size_t)((4 * (ntiles + 1) + 255) / 256 * 256),
+                 a_ordr = a_offs + (same ? 0 : (size_t)((4 * (ntiles + 1) + 255) / 256 * 256)),
+                 a_ords = a_ordr + (size_t)((4 * n_r + 255) / 256 * 256),
+                 a_posr = a_ords + (same ? 0 : (size_t)((4 * n_s + 255) / 256 * 256)),
+                 a_poss = a_posr + 24 * (size_t)n_r,
+                 a_end = a_poss + (same ? 0 : 24 * (size_t)n_s);
+    if (srd_reserve(c, &c->srd_buf, &c->srd_buf_bytes, a_end)) return 1;
+    char *B = (char *)c->srd_buf;
+    unsigned char *take = (unsigned char *)(B + a_take);
+    unsigned long long *items = (unsigned long long *)(B + a_items);
+    unsigned *offr = (unsigned *)(B + a_offr), *offs = same ? offr : (unsigned *)(B + a_offs);
+    unsigned *ordr = (unsigned *)(B + a_ordr), *ords = same ? ordr : (unsigned *)(B + a_ords);
+    double *posr = (double *)(B + a_posr), *poss = same ? posr : (double *)(B + a_poss);
+    const double ext = c->p.boxsize / (double)nt;  // species.py:607-609
+    if (cgk_shortrange_tiles(c, pos_r_sorted, n_r, nt, ext, nullptr, 0, ordr, offr, posr, nullptr))
+        return 1;
+    if (!same &&
+        cgk_shortrange_tiles(c, pos_s_sorted, n_s, nt, ext, nullptr, 0, ords, offs, poss, nullptr))
+        return 1;
+    hipLaunchKernelGGL(k_srd_plan, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream,
+                       offr, (unsigned)ntiles, (unsigned)min_pop, take, items, dev + 2);
+    CG_LAUNCH_CHECK();
+    if (!c->srd_stream) {
+        CG_HIP(hipStreamCreateWithFlags(&c->srd_stream, hipStreamNonBlocking));
+        CG_HIP(hipEventCreateWithFlags(&c->srd_fork, hipEventDisableTiming));
+        CG_HIP(hipEventCreateWithFlags(&c->srd_join, hipEventDisableTiming));
+    }
+    CG_HIP(hipEventRecord(c->srd_fork, c->stream));
+    CG_HIP(hipStreamWaitEvent(c->srd_stream, c->srd_fork, 0));
+    SrdParams P{c->p.boxsize, ext, 1.0 / ext, r2_index_scaling, r2_max, factor, factors,
+                rung_jumped, (int)nt};
+    // (as many workgroups as there can be items; the ones past the count leave at once)
+    const unsigned grid = (unsigned)(ndense / kdChunk + tdense);
+    hipLaunchKernelGGL(k_sr_sweep_dense, dim3(grid), dim3(64 * kdWaves), 0, c->srd_stream, posr,
+                       ordr, order_r, offr, dmom_r, poss, offs, items, dev + 2, table, P);
+    CG_LAUNCH_CHECK();
+    CG_HIP(hipEventRecord(c->srd_join, c->srd_stream));
+    *take_out = take;
+    return 0;
+}
+
+int cgk_shortrange_dense_join(cg_ctx *c) {
+    CG_HIP(hipStreamWaitEvent(c->stream, c->srd_join, 0));
+    return 0;
+}

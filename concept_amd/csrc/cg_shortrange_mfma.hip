@@ -190,14 +190,13 @@ __device__ __forceinline__ unsigned srm_wave_scan(unsigned v) {
 // Density-adaptive order inside the tiles (the counterpart of the reference's automatic
 // subtile refinement, species.py:4031-4142: subtiles fine enough to hold a handful of
 // particles each).  A tile with many particles has its rows of the list re-ordered by
-// sub-cell — 4^3 sub-cells, 8^3 from kSubFine particles on, along a Morton curve — so that
+// sub-cell — 8^3 sub-cells along a Hilbert curve — so that
 // 16 consecutive rows (a wavefront's receivers; a block of suppliers) are neighbours in space
 // wherever the particles are many: the receivers of a wavefront then see the same suppliers
 // (their lanes finish together), and a supplier block has a bounding box worth testing.
 // Sparse tiles (fewer than kSubMin rows) stay as the tile sort left them.
 // ---------------------------------------------------------------------------
 constexpr int kSubMin = 48;      // rows from which a tile is re-ordered
-constexpr int kSubFine = 1536;   // rows from which 8^3 sub-cells are used instead of 4^3
 
 __global__ __launch_bounds__(256) void k_srm_dense_tiles(const unsigned *__restrict__ offset,
                                                          unsigned ntiles,
@@ -208,16 +207,19 @@ __global__ __launch_bounds__(256) void k_srm_dense_tiles(const unsigned *__restr
     if (offset[t + 1] - offset[t] >= (unsigned)kSubMin) dense[atomicAdd(ndense, 1u)] = t;
 }
 
-__device__ __forceinline__ unsigned srm_spread3(unsigned v) {  // 3 bits -> every third bit
-    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4);
-}
+// sub-cell (a, b, c) of an 8 x 8 x 8 division of the tile -> its place on a Hilbert curve
+// through the 512 sub-cells (consecutive places are face neighbours: a run of rows is a compact
+// blob wherever it starts, which a Morton curve's jumps do not give).  Filled once by the host
+// (srm_hilbert_table).
+__device__ unsigned short srm_hilbert[512];
+constexpr int kSubCells = 8;
+
 __device__ __forceinline__ unsigned srm_subkey(double x, double y, double z, double inv_ext,
-                                               unsigned gx, unsigned gy, unsigned gz, int nsub) {
-    const int a = min(nsub - 1, max(0, (int)((x * inv_ext - (double)gx) * nsub))),
-              b = min(nsub - 1, max(0, (int)((y * inv_ext - (double)gy) * nsub))),
-              c = min(nsub - 1, max(0, (int)((z * inv_ext - (double)gz) * nsub)));
-    return (srm_spread3((unsigned)a) << 2) | (srm_spread3((unsigned)b) << 1) |
-           srm_spread3((unsigned)c);
+                                               unsigned gx, unsigned gy, unsigned gz) {
+    const int a = min(kSubCells - 1, max(0, (int)((x * inv_ext - (double)gx) * kSubCells))),
+              b = min(kSubCells - 1, max(0, (int)((y * inv_ext - (double)gy) * kSubCells))),
+              c = min(kSubCells - 1, max(0, (int)((z * inv_ext - (double)gz) * kSubCells)));
+    return srm_hilbert[(a * kSubCells + b) * kSubCells + c];
 }
 
 struct SrmRow {  // what travels with a row of the list
@@ -240,12 +242,11 @@ __global__ __launch_bounds__(256) void k_srm_subsort(const unsigned *__restrict_
     const unsigned t = dense[blockIdx.x];
     const unsigned b = offset[t], e = offset[t + 1];
     const unsigned gz = t % nt, gy = (t / nt) % nt, gx = t / (nt * nt);
-    const int nsub = (e - b) >= (unsigned)kSubFine ? 8 : 4;
     for (int i = threadIdx.x; i < 512; i += 256) hist[i] = 0;
     __syncthreads();
     for (unsigned q = b + threadIdx.x; q < e; q += 256)
         atomicAdd(&hist[srm_subkey(pos_sorted[3 * (i64)q], pos_sorted[3 * (i64)q + 1],
-                                   pos_sorted[3 * (i64)q + 2], inv_ext, gx, gy, gz, nsub)], 1u);
+                                   pos_sorted[3 * (i64)q + 2], inv_ext, gx, gy, gz)], 1u);
     __syncthreads();
     if (threadIdx.x < 64) {  // exclusive scan of the 512 counts: 8 per lane of one wave
         unsigned v[8], sum = 0;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void k_srm_subsort(const unsigned *__restrict_
         r.order = order[q];
         r.pad = 0;
         if (aop) r.a = aop[q];
-        const unsigned at = atomicAdd(&base[srm_subkey(r.x, r.y, r.z, inv_ext, gx, gy, gz, nsub)],
+        const unsigned at = atomicAdd(&base[srm_subkey(r.x, r.y, r.z, inv_ext, gx, gy, gz)],
                                       1u);
         scratch[(i64)b + at] = r;
     }
@@ -828,8 +829,47 @@ extern "C" int cg_srm_debug_counters(unsigned long long *out, int reset) {
 // Rows of the densely populated cells of a list (cells of `extent`, nper per dimension, z
 // fastest: the tiles of cg_shortrange_tiles, the half-tiles of cg_shortrange_cells) re-ordered
 // by sub-cell; aop (operand rows that travel with the positions) may be null.
+// Hilbert index of every cell of the 8^3 grid (Skilling's transpose form: Gray decode of the
+// axes, then the bits interleaved)
+static void srm_hilbert_table(unsigned short *out) {
+    const int bits = 3, M = 1 << (bits - 1);
+    for (int x = 0; x < 8; x++)
+        for (int y = 0; y < 8; y++)
+            for (int z = 0; z < 8; z++) {
+                int X[3] = {x, y, z};
+                for (int Q = M; Q > 1; Q >>= 1) {
+                    const int P = Q - 1;
+                    for (int i = 0; i < 3; i++) {
+                        if (X[i] & Q) {
+                            X[0] ^= P;
+                        } else {
+                            const int t = (X[0] ^ X[i]) & P;
+                            X[0] ^= t;
+                            X[i] ^= t;
+                        }
+                    }
+                }
+                for (int i = 1; i < 3; i++) X[i] ^= X[i - 1];
+                int t = 0;
+                for (int Q = M; Q > 1; Q >>= 1)
+                    if (X[2] & Q) t ^= Q - 1;
+                for (int i = 0; i < 3; i++) X[i] ^= t;
+                int h = 0;
+                for (int b = bits - 1; b >= 0; b--)
+                    for (int i = 0; i < 3; i++) h = (h << 1) | ((X[i] >> b) & 1);
+                out[(x * 8 + y) * 8 + z] = (unsigned short)h;
+            }
+}
+
 int cgk_shortrange_subsort(cg_ctx *c, const unsigned *offset, i64 n, i64 nper, double extent,
                            unsigned *order, double *pos_sorted, float *aop) {
+    static bool table_done = false;
+    if (!table_done) {
+        unsigned short h[512];
+        srm_hilbert_table(h);
+        CG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(srm_hilbert), h, sizeof(h)));
+        table_done = true;
+    }
     static int subsort = -1;
     if (subsort < 0) {
         const char *env = getenv("CONCEPT_GPU_SR_SUBSORT");
