@@ -43,13 +43,23 @@
 
 namespace {
 
+// Measured (256^3 / 512^3 clustered, tools/sr_dense_time.py): windows of 960 rows, four quads per
+// trip at 92 registers (5 waves per SIMD) 53.2 ms; 448 rows and two quads per trip at 64 registers
+// (8 waves per SIMD) 48.0 ms; 256 rows 48.4, 320 rows 50.1, 8 wavefronts per workgroup 47.9-49.4,
+// two 57.9.  The pair loop is 18 vector instructions per trip of 64 pair tests.
 #ifndef SRD_CAP
-#define SRD_CAP 960
+#define SRD_CAP 448
 #endif
 #ifndef SRD_WAVES_PER_EU
-#define SRD_WAVES_PER_EU 5
+#define SRD_WAVES_PER_EU 8
 #endif
-constexpr int kdWaves = 4;             // wavefronts per workgroup, 16 receivers each
+#ifndef SRD_NB
+#define SRD_NB 2                       // quads per trip of a wavefront (their table loads in flight together)
+#endif
+#ifndef SRD_WAVES
+#define SRD_WAVES 4
+#endif
+constexpr int kdWaves = SRD_WAVES;     // wavefronts per workgroup, 16 receivers each
 constexpr int kdChunk = 16 * kdWaves;  // receivers per work item
 constexpr int kdCap = SRD_CAP;         // supplier rows per LDS window (a multiple of 64)
 constexpr int kdQuads = kdCap / 4;
@@ -178,20 +188,22 @@ __device__ __forceinline__ void srd_look(const SrdShared &S, unsigned long long 
                                          const double *__restrict__ table, double &ax, double &ay,
                                          double &az) {
     while (m) {
-        int q[4];
+        int q[SRD_NB];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < SRD_NB; k++) {
             q[k] = m ? q0 + (int)__builtin_ctzll(m) : kdQuads;  // (none left: the far quad)
             m &= m - 1;                                         // (0 stays 0)
         }
-        if (q[2] != kdQuads) {
-            srd_quads<FACE, 4>(S, q, g, xi, yi, zi, boxsize, r2_max, r2_index_scaling, table, ax, ay,
-                               az);
-        } else {
+#if SRD_NB == 4
+        if (q[2] == kdQuads) {
             const int q2[2] = {q[0], q[1]};
             srd_quads<FACE, 2>(S, q2, g, xi, yi, zi, boxsize, r2_max, r2_index_scaling, table, ax,
                                ay, az);
+            continue;
         }
+#endif
+        srd_quads<FACE, SRD_NB>(S, q, g, xi, yi, zi, boxsize, r2_max, r2_index_scaling, table, ax, ay,
+                                az);
     }
 }
 
@@ -344,8 +356,15 @@ __attribute__((amdgpu_waves_per_eu(SRD_WAVES_PER_EU, 8))) void k_sr_sweep_dense(
                     d2 = __builtin_fmaf(gap, gap, d2);
                 }
                 keep = d2 <= r2cull;
+#ifdef SRD_PROBE_NOCULL   // probe build: every quad of the 27 tiles
+                keep = true;
+#endif
             }
             const unsigned long long m = __ballot(keep);
+#ifdef SRD_PROBE_NOPAIRS  // probe build: staging, boxes and culling only
+            ax += (double)__popcll(m) * 1e-300;
+            continue;
+#endif
             if (face)
                 srd_look<true>(S, m, 64 * look, g, xi, yi, zi, P.boxsize, P.r2_max,
                                P.r2_index_scaling, table, ax, ay, az);
