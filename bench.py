@@ -991,8 +991,16 @@ def run_single(args, torch, dev, rank=0):
             box = sum(torch.roll(box, s_, 1) for s_ in range(-2, 3))
             colz = box.reshape(nc, nc, nc//2, 2).sum(3)          # per tile along z
             win = sum(torch.roll(colz, s_, 2) for s_ in (-1, 0, 1))   # 6 cells: tiles tz-1..tz+1
-            tests = float((pop.reshape(nc, nc, nc//2, 2).sum(3)*win).sum())
+            tpop = pop.reshape(nc, nc, nc//2, 2).sum(3)
+            tests = float((tpop*win).sum())
             per_test = 12   # 3 sub, 3 mul, 2 add, 1 cmp, 3 fma
+            # tiles of the dense tiles' sweep (cg_shortrange_dense.hip): their receivers test
+            # fewer pairs than the cells geometry counted here, which stays the unit of work
+            tiles = tpop.reshape(nc//2, 2, nc//2, 2, nc//2).sum((1, 3))
+            dense_min = (-1 if os.environ.get('CONCEPT_GPU_SR_DENSE', '1') == '0'
+                         else int(os.environ.get('CONCEPT_GPU_SR_DENSE_MIN', '64')))
+            dense_tiles = int((tiles >= dense_min).sum()) if dense_min > 0 else 0
+            dense_receivers = int(tiles[tiles >= dense_min].sum()) if dense_min > 0 else 0
         ms = kernels[dom]
         # 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2.4 GHz: one FP64 VALU op per lane slot
         valu_peak = 256*4*16*2.4e9
@@ -1001,9 +1009,15 @@ def run_single(args, torch, dev, rank=0):
             'achieved': round(tests/(ms*1e-3), 1), 'peak': round(valu_peak/per_test, 1),
             'frac': round(tests/(ms*1e-3)/(valu_peak/per_test), 4), 'traffic': None,
             'kernel_ms': round(ms, 4), 'pair_tests_per_launch': int(tests),
+            'dense_tiles': None if args.sr_tiles else dense_tiles,
+            'receivers_in_dense_tiles': None if args.sr_tiles else dense_receivers,
             'note': ('the sweep is not HBM-bound (72 B per particle against ~600 pair tests); '
                      f'peak = FP64 vector issue rate {valu_peak:.3g} lane-ops/s / {per_test} '
-                     'FP64 VALU instructions per pair test')}
+                     'FP64 VALU instructions per pair test; pair tests = those of the half-tile '
+                     'cells geometry (5 x 5 x 6 cells per receiver) — the receivers in dense '
+                     'tiles go through a sweep that tests about half as many, so that with '
+                     'dense tiles "achieved" is work done per second in the cells sweep\'s '
+                     'units, not tests executed')}
     else:
         ach = mv[dom]/(kernels[dom]*1e-3)/1e9
         traffic, traffic_source = pmc_traffic(dom, name)

@@ -411,7 +411,7 @@ int srd_reserve(cg_ctx *c, void **buf, size_t *have, size_t need) {
 int cgk_shortrange_dense_min() {
     const char *on = getenv("CONCEPT_GPU_SR_DENSE"), *mp = getenv("CONCEPT_GPU_SR_DENSE_MIN");
     if (on && atoi(on) == 0) return -1;
-    const int min_pop = mp ? atoi(mp) : 96;
+    const int min_pop = mp ? atoi(mp) : 64;
     return min_pop < 1 ? 1 : min_pop;
 }
 

@@ -32,14 +32,23 @@ def setup(g):
     return torch, c
 
 
-@pytest.mark.parametrize('sweep', ['cells', 'mfma'])
+def dense_everywhere(monkeypatch):
+    """The cells sweep hands every tile of 3 particles and more to the dense tiles' sweep
+    (cg_shortrange_dense.hip; the default threshold is 64)"""
+    monkeypatch.setenv('CONCEPT_GPU_SR_DENSE_MIN', '3')
+    return 'cells'
+
+
+@pytest.mark.parametrize('sweep', ['cells', 'dense', 'mfma'])
 @pytest.mark.parametrize('name', CASES)
 def test_shortrange_vs_golden_and_oracle(golden, name, sweep, monkeypatch):
-    """(both tile sweeps: the half-tile cells and the lists by tile with the matrix-core
-    pre-filter, shortrange.SWEEP; sweep None — tests/dist_component_worker.py, on several
-    domains — runs the configured one)"""
+    """(the tile sweeps: the half-tile cells, the same with the dense tiles' sweep taking every
+    populated tile, and the lists by tile with the matrix-core pre-filter, shortrange.SWEEP;
+    sweep None — tests/dist_component_worker.py, on several domains — runs the configured one)"""
     from concept_amd import interactions, shortrange
     from oracle import oracle
+    if sweep == 'dense':
+        sweep = dense_everywhere(monkeypatch)
     if sweep is not None:
         monkeypatch.setattr(shortrange, 'SWEEP', sweep)
     g = golden(name)
@@ -320,7 +329,7 @@ def test_config3_size_shortrange_vs_oracle_sample(dist, sweep):
     mesh.close()
 
 
-@pytest.mark.parametrize('sweep', ['cells', 'mfma'])
+@pytest.mark.parametrize('sweep', ['cells', 'dense', 'mfma'])
 def test_adaptive_rungs_vs_reference(golden, sweep, monkeypatch):
     """A14/A16 with adaptive rungs on the GPU: RungStepper (initialize_rung_populations,
     kick_long, kick_short, driftkick_short with rung jumps; N_rungs = 4) against the
@@ -328,6 +337,8 @@ def test_adaptive_rungs_vs_reference(golden, sweep, monkeypatch):
     import torch
     from concept_amd import commons, shortrange, stepper
     from concept_amd.species import Component
+    if sweep == 'dense':
+        sweep = dense_everywhere(monkeypatch)
     if sweep is not None:
         monkeypatch.setattr(shortrange, 'SWEEP', sweep)
     g = golden('rungs_p3m_n8_g32')
@@ -717,6 +728,45 @@ def test_sparse_shortrange_equals_the_cells_sweep(k):
     with pytest.raises(ConceptGPUError, match='active receivers'):
         mesh.shortrange_sparse(pos_r_t, torch.arange(9, device='cuda'), got2, pos_s_t, table,
                                4095/maxr2, rng_**2, 1.0)
+    mesh.close()
+
+
+def test_dense_sweep_on_the_randomised_and_multi_component_cases(monkeypatch):
+    """The dense tiles' sweep (Hilbert sub-cell order, supplier quads culled by their boxes;
+    here from 3 particles per tile on instead of 64) through the cases the cells sweep is fuzzed
+    with — the random parameter draws, receivers that are not suppliers, the knot with adaptive
+    rungs across domains, whole random P³M time loops with rungs — and, with the default
+    threshold, a box of 1576 particles per tile against the cells sweep by itself."""
+    import torch
+    from concept_amd import commons, shortrange
+    from concept_amd.mesh import PotentialMesh
+    dense_everywhere(monkeypatch)
+    for seed in range(16):
+        test_random_shortrange_vs_oracle(seed)
+    for cell_centered in (True, False):
+        test_shortrange_two_components_receivers_not_suppliers(cell_centered)
+    test_adaptive_rungs_knot_across_domains()
+    for seed in range(2):
+        test_random_p3m_timeloops_across_domains(seed)
+    monkeypatch.delenv('CONCEPT_GPU_SR_DENSE_MIN')
+    N, n = 64, 100**3
+    mesh = PotentialMesh(N, float(N))
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    pos = torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=gen)*(N*(1 - 1e-13))
+    scale = 1.25
+    rng_ = 4.5*scale
+    nt = int(N/rng_*(1 + commons.machine_ϵ))
+    table, maxr2 = shortrange.get_shortrange_table(0.01, scale, rng_, 4096, 'spline', pos.device)
+    cells = mesh.shortrange_cells(pos, nt, N/nt)
+    out = []
+    for dense in ('0', '1'):
+        monkeypatch.setenv('CONCEPT_GPU_SR_DENSE', dense)
+        dm = torch.zeros_like(pos)
+        mesh.shortrange_sweep_cells(cells, dm, cells, nt, table, 4095/maxr2, rng_**2, 1.0)
+        out.append(dm)
+    rms = float(out[0].pow(2).mean().sqrt())
+    assert float((out[1] - out[0]).abs().max()) <= 1e-12*rms
+    assert float(out[1].sum(0).abs().max()) <= 1e-9*rms*n**0.5   # Newton's third law
     mesh.close()
 
 
