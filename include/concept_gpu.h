@@ -320,7 +320,18 @@ int cg_shortrange_sweep_rungs(cg_ctx *ctx, const double *pos_r, const uint32_t *
  * must not exceed the tile extent (the reference requires tilesize >= range,
  * species.py:3943-3983).  Receivers and suppliers may be different particle sets (two
  * components, or a component extended by the neighbour domains' boundary particles): there is
- * no self-pair test because a particle paired with itself contributes x_ji * f = 0 * f. */
+ * no self-pair test because a particle paired with itself contributes x_ji * f = 0 * f.
+ * Density-adaptive (round 4; csrc/cg_shortrange_dense.hip — the counterpart of the reference's
+ * automatic subtile refinement, species.py:4031-4142, interactions.py:145-329, :1236-1251): the
+ * receivers of tiles holding 64 particles or more are taken off the cells and swept from a list by
+ * tile whose rows follow a Hilbert curve through 8^3 sub-cells — 16 consecutive receivers per
+ * wavefront against supplier rows in groups of four, a group whose bounding box is out of the
+ * 16 receivers' reach is skipped (2.1-2.6 pair tests per pair in range instead of 4.2-4.4) —
+ * with the same pair arithmetic; nothing changes for the caller (the lists are built inside the
+ * call, only when such tiles exist: one 16-byte read-back per call decides).  With rungs this
+ * happens where every rung is active (lowest_active_rung = 0).  Environment:
+ * CONCEPT_GPU_SR_DENSE=0 switches it off, CONCEPT_GPU_SR_DENSE_MIN=<particles per tile> moves
+ * the threshold. */
 int cg_shortrange_cells(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, int64_t nt,
                         double tile_extent, uint32_t *order_out /*DEV n*/,
                         uint32_t *offset_out /*DEV (2nt)^3+1*/,
@@ -355,7 +366,7 @@ int cg_shortrange_sweep_cells_rungs(cg_ctx *ctx, const double *pos_r_sorted,
  * reads whole 16-row blocks, hence 16 rows of room — then, from float 4(n + 16) on, the
  * bounding boxes (min xyz 0, max xyz 0, in tiles) of the blocks of 16 consecutive rows; null
  * for a list of receivers only).  Tiles of kSubMin = 48 or more particles have their rows
- * ordered by sub-cell (4^3, from 1536 particles 8^3, Morton order), so that blocks and the
+ * ordered by sub-cell (8^3 sub-cells along a Hilbert curve), so that blocks and the
  * receivers of a wavefront are compact where the particles are many.  With `rung` only the
  * m particles on rungs >= lowest_active_rung are listed (the receivers of a sub-step),
  * otherwise m = n.
