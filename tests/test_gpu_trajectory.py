@@ -529,3 +529,47 @@ def test_timeloop_with_a_fluid_component(golden):
     assert _pos_err(pos_f, comps0[0].host('pos'), L) <= 1e-9
     kick = np.abs(comps0[0].host('mom') - g['mom_in']).max()
     assert np.abs(mom_f - comps0[0].host('mom')).max() <= 1e-8*kick
+
+
+def test_p3m_timeloop_with_dense_tiles_equals_the_cells_sweep(monkeypatch):
+    """A clustered box (80 % of 64^3 particles in 8 Gaussian blobs: tiles of several hundred
+    particles) through the P³M time loop with 8 rungs, twice: with the dense tiles' sweep
+    (cg_shortrange_dense.hip, the default from 64 particles per tile on) and with the half-tile
+    cells everywhere (CONCEPT_GPU_SR_DENSE=0).  The two differ in the order of the additions
+    only: same steps, same rungs, positions equal to 1e-9 of the box after the run."""
+    import torch
+    from concept_amd import commons, stepper
+    from concept_amd.species import Component
+    n, N, L = 64**3, 128, 128.0
+
+    def run(dense):
+        monkeypatch.setenv('CONCEPT_GPU_SR_DENSE', dense)
+        p = commons.load_params({
+            'boxsize': L, 'H0': 0.07, 'Ωb': 0.05, 'Ωcdm': 0.25, 'a_begin': 0.1,
+            'output_times': {'a': (0.105,)},
+            'potential_options': {'gridsize': {'gravity': {'p3m': N}}},
+            'select_forces': {'all': {'gravity': 'p3m'}}})
+        mass = p.ρ_mbar*L**3/n
+        c = Component('matter', 'matter', N=n, mass=mass)
+        gen = torch.Generator(device='cuda').manual_seed(21)
+        pos = torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=gen)*L
+        centres = torch.rand((8, 3), dtype=torch.float64, device='cuda', generator=gen)*L
+        which = torch.randint(0, 8, (n,), device='cuda', generator=gen)
+        blob = centres[which] + torch.randn((n, 3), dtype=torch.float64, device='cuda',
+                                            generator=gen)*(L/40)
+        keep = torch.rand(n, dtype=torch.float64, device='cuda', generator=gen) < 0.2
+        c.pos.copy_(torch.where(keep[:, None], pos, torch.remainder(blob, L)).clamp_(0, L*(1 - 1e-13)))
+        c.mom.zero_()
+        loop = stepper.Timeloop([c])
+        loop.run()
+        order = torch.argsort(c.ids)
+        return loop.time_step, c.pos[order].clone(), c.rung_indices[order].clone()
+
+    steps0, pos0, rungs0 = run('0')
+    steps1, pos1, rungs1 = run('1')
+    assert steps0 == steps1 and steps0 >= 2
+    d = (pos1 - pos0).abs()
+    d = torch.minimum(d, L - d)
+    assert float(d.max()) <= 1e-9*L, float(d.max())
+    assert float((rungs0 != rungs1).double().mean()) <= 1e-4   # (a particle on a rung's border)
+    assert int(rungs0.max()) >= 2

@@ -45,6 +45,13 @@ python tools/variant.py tools/_variants/srm_count.so cg_shortrange_mfma.hip -DSR
 python tools/variant.py tools/_variants/srm_nocand.so cg_shortrange_mfma.hip -DSRM_PROBE_NOCAND > /dev/null 2>&1
 python tools/variant.py tools/_variants/srm_nomfma.so cg_shortrange_mfma.hip -DSRM_PROBE_NOMFMA > /dev/null 2>&1
 for v in "" tools/_variants/srm_nocand.so tools/_variants/srm_nomfma.so tools/_variants/srm_count.so; do CONCEPT_GPU_LIB=$v python tools/sr_mfma_time.py; done 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_sr_tiles_phases_and_counts.txt
+# 6. the dense tiles' sweep (round 4): against the cells sweep by itself, its counters, its phases
+python tools/sr_dense_check.py scan big time 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_sr_dense_vs_cells.txt
+(SR_DIST=clustered $R/tools/pmc_srd.sh 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_pmc_sr_dense.txt)
+python tools/variant.py tools/_variants/srd_nopairs.so cg_shortrange_dense.hip -DSRD_PROBE_NOPAIRS > /dev/null 2>&1
+python tools/variant.py tools/_variants/srd_nocull.so cg_shortrange_dense.hip -DSRD_PROBE_NOCULL > /dev/null 2>&1
+for v in "" tools/_variants/srd_nopairs.so tools/_variants/srd_nocull.so; do CONCEPT_GPU_LIB=$v python tools/sr_dense_time.py clustered; done 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_sr_dense_phases.txt
+CONCEPT_GPU_SR_DENSE=0 python tools/sr_dense_time.py clustered 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_sr_dense_phases.txt
 ./tools/mall_probe > $OUT/${TAG}_mall_probe.txt 2>&1
 rm -rf $OUT/stats $OUT/pmc_f $OUT/pmc_w $OUT/stats_p3m $OUT/pmc_sr
 ls -la $OUT
