@@ -726,6 +726,8 @@ def main():
         result['configs'] = {}
         for cname, over in (('c2_256c_512_pm', dict(workload='c2_256c_512')),
                             ('c2_256c_512_p3m', dict(workload='c2_256c_512', p3m=True)),
+                            ('c2_256c_512_p3m_clustered', dict(workload='c2_256c_512', p3m=True,
+                                                               dist='clustered')),
                             ('ns_256M_1024_clustered', dict(dist='clustered')),
                             ('ns_256M_1024_lattice', dict(dist='lattice'))):
             a2 = copy.copy(args)
@@ -742,6 +744,9 @@ def main():
                 'bound': r2['roofline']['bound'], 'frac': r2['roofline']['frac'],
                 'phases_ms': {k: v['ms'] for k, v in r2['phases'].items()},
                 'workload': r2['config']['workload']}
+            if r2['roofline'].get('receivers_in_dense_tiles') is not None:
+                result['configs'][cname]['receivers_in_dense_tiles'] = \
+                    r2['roofline']['receivers_in_dense_tiles']
     if not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(name)
     print(json.dumps(result))
