@@ -28,6 +28,7 @@
 // (the cells sweep: 4.1-4.7), worse below — so cg_shortrange_sweep_cells hands the tiles above a
 // population threshold to this kernel and keeps the others.
 #include <cstdlib>
+#include <cstring>
 
 #include "cg_internal.h"
 
@@ -116,9 +117,15 @@ __global__ __launch_bounds__(256) void k_srd_precheck(const unsigned *__restrict
     unsigned sum = dense ? pop : 0u;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) sum += __shfl_xor(sum, d);
+    // (sum of pop^2 over the dense tiles: what the cells sweep would spend there is 18.75 pair
+    // tests per receiver and particle of the neighbourhood, ~ 18.75 pop^2 per tile)
+    unsigned long long sq = dense ? (unsigned long long)pop * pop : 0ull;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) sq += __shfl_xor(sq, d);
     if ((threadIdx.x & 63) == 0 && m) {
         atomicAdd(&out[0], sum);
         atomicAdd(&out[1], (unsigned)__popcll(m));
+        atomicAdd((unsigned long long *)(out + 4), sq);
     }
 }
 
@@ -433,18 +440,30 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
     if (!c->srd_host) CG_HIP(hipHostMalloc((void **)&c->srd_host, 64));
     if (srd_reserve(c, (void **)&c->srd_small, &c->srd_small_bytes, 64)) return 1;
     unsigned *dev = (unsigned *)c->srd_small;  // [0] receivers in dense tiles, [1] dense tiles, [2] items
-    CG_HIP(hipMemsetAsync(dev, 0, 16, c->stream));
+    CG_HIP(hipMemsetAsync(dev, 0, 24, c->stream));
     hipLaunchKernelGGL(k_srd_precheck, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0,
                        c->stream, off_r, (unsigned)nt, (unsigned)min_pop, dev);
     CG_LAUNCH_CHECK();
     CG_HIP(hipMemcpyAsync(c->srd_host, dev, 8, hipMemcpyDeviceToHost, c->stream));
     CG_HIP(hipMemcpyAsync(c->srd_host + 2, off_r + ncells, 4, hipMemcpyDeviceToHost, c->stream));
     CG_HIP(hipMemcpyAsync(c->srd_host + 3, off_s + ncells, 4, hipMemcpyDeviceToHost, c->stream));
+    CG_HIP(hipMemcpyAsync(c->srd_host + 4, dev + 4, 8, hipMemcpyDeviceToHost, c->stream));
     CG_HIP(hipStreamSynchronize(c->stream));
     const i64 ndense = c->srd_host[0], tdense = c->srd_host[1], n_r = c->srd_host[2],
               n_s = c->srd_host[3];
     if (ndense == 0) return 0;
     const bool same = pos_r_sorted == pos_s_sorted && off_r == off_s;
+    if (!getenv("CONCEPT_GPU_SR_DENSE_MIN")) {
+        // Is it worth the lists?  What the dense tiles cost the cells sweep (~18.75 pop^2 pair
+        // tests per tile at its 0.9e12 tests/s; this sweep needs about half) against a list build
+        // (measured 0.07 ns per particle; 0.1 here).  A uniform box of 2^28 particles at 44 per tile
+        // has 0.3 % of its tiles above the threshold and 17 ms of lists to pay: not worth it.
+        unsigned long long sq;
+        memcpy(&sq, c->srd_host + 4, 8);
+        const double saved = 0.45 * 18.75 * (double)sq / 0.9e12;
+        const double cost = 5e-5 + 1e-10 * (double)(n_r + (same ? 0 : n_s));
+        if (saved < 2 * cost) return 0;
+    }
     // buffers: take | items | offsets r, s | order r, s | positions r, s
     const size_t a_take = 0, a_items = (size_t)((ntiles + 255) / 256 * 256),
                  a_offr = a_items + 8 * (size_t)(ndense / kdChunk + tdense + 1),

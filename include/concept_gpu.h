@@ -328,7 +328,8 @@ int cg_shortrange_sweep_rungs(cg_ctx *ctx, const double *pos_r, const uint32_t *
  * wavefront against supplier rows in groups of four, a group whose bounding box is out of the
  * 16 receivers' reach is skipped (2.1-2.6 pair tests per pair in range instead of 4.2-4.4) —
  * with the same pair arithmetic; nothing changes for the caller (the lists are built inside the
- * call, only when such tiles exist: one 16-byte read-back per call decides).  With rungs this
+ * call, only when such tiles exist and hold enough of the pair work to pay for the lists: one
+ * 24-byte read-back per call decides).  With rungs this
  * happens where every rung is active (lowest_active_rung = 0).  Environment:
  * CONCEPT_GPU_SR_DENSE=0 switches it off, CONCEPT_GPU_SR_DENSE_MIN=<particles per tile> moves
  * the threshold. */
