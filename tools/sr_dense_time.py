@@ -12,7 +12,8 @@ from concept_amd import commons, shortrange  # noqa: E402
 from concept_amd.mesh import PotentialMesh  # noqa: E402
 from tools.sr_mfma_check import positions  # noqa: E402
 
-N, L, n = 512, 512.0, 256**3
+N = int(os.environ.get('SR_N', '512'))
+L, n = float(N), int(os.environ.get('SR_NP', str(256**3)))
 mesh = PotentialMesh(N, L)
 for dist in (sys.argv[1:] or ['clustered']):
     gen = torch.Generator(device='cuda').manual_seed(3)
@@ -20,7 +21,7 @@ for dist in (sys.argv[1:] or ['clustered']):
     scale = 1.25*L/N
     rng_ = 4.5*scale
     nt = int(L/rng_*(1 + commons.machine_ϵ))
-    table, maxr2 = shortrange.get_shortrange_table(0.025*L/256, scale, rng_, 4096, 'spline',
+    table, maxr2 = shortrange.get_shortrange_table(0.025*L/round(n**(1/3)), scale, rng_, 4096, 'spline',
                                                    pos.device)
     dm = torch.zeros_like(pos)
     lst = mesh.shortrange_cells(pos, nt, L/nt)
