@@ -62,10 +62,10 @@ namespace {
 #endif
 constexpr int kdWaves = SRD_WAVES;     // wavefronts per workgroup, 16 receivers each
 constexpr int kdChunk = 16 * kdWaves;  // receivers per work item
-constexpr int kdCap = SRD_CAP;         // supplier rows per LDS window (a multiple of 64)
+constexpr int kdCap = SRD_CAP;         // supplier rows per LDS window (whole quads)
 constexpr int kdQuads = kdCap / 4;
 constexpr int kdPieces = 18;           // 9 tile columns x 2 (a column that wraps around in z)
-static_assert(kdCap % 64 == 0, "whole looks of 64 quads... rows");
+static_assert(kdCap % 4 == 0, "whole quads");
 
 struct SrdParams {
     double boxsize, ext, inv_ext, r2_index_scaling, r2_max, factor;

@@ -329,7 +329,7 @@ int cg_shortrange_sweep_rungs(cg_ctx *ctx, const double *pos_r, const uint32_t *
  * 16 receivers' reach is skipped (2.1-2.6 pair tests per pair in range instead of 4.2-4.4) —
  * with the same pair arithmetic; nothing changes for the caller (the lists are built inside the
  * call, only when such tiles exist and hold enough of the pair work to pay for the lists: one
- * 24-byte read-back per call decides).  With rungs this
+ * 24-byte read-back per call decides — the call waits for the context's stream once).  With rungs this
  * happens where every rung is active (lowest_active_rung = 0).  Environment:
  * CONCEPT_GPU_SR_DENSE=0 switches it off, CONCEPT_GPU_SR_DENSE_MIN=<particles per tile> moves
  * the threshold. */
