@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_new; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 (cd $R && python -m concept_amd.build > /dev/null 2>&1)  # (a library older than csrc/ would be profiled under the wrong hash)
-CMD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs"
 # 1. per-kernel statistics of the default command
 rocprofv3 --kernel-trace --stats -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 python $R/tools/rocprof_summary.py $OUT/stats $OUT/${TAG}_rocprof_kernel_stats_ns.txt > /dev/null
@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_f -- $CMD > $OUT/pmc_f.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_w -- $CMD > $OUT/pmc_w.log 2>&1
 python $R/tools/rocprof_summary.py --pmc $OUT/pmc_f > $OUT/${TAG}_pmc_FETCH_SIZE_per_kernel.txt
 python $R/tools/rocprof_summary.py --pmc $OUT/pmc_w > $OUT/${TAG}_pmc_WRITE_SIZE_per_kernel.txt
-python $R/tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w $OUT/${TAG}_pmc_hbm_traffic.json ns_256M_1024 $COMMIT "python bench.py --steps 4 --warmup 2 --no-cpu-baseline" > $OUT/pmc_traffic.log 2>&1
+python $R/tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w $OUT/${TAG}_pmc_hbm_traffic.json ns_256M_1024 $COMMIT "python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs" > $OUT/pmc_traffic.log 2>&1
 cp $OUT/${TAG}_pmc_hbm_traffic.json $R/profiles/${TAG}_pmc_hbm_traffic.json   # (so that the lines below quote it)
 # 3. P3M: statistics and SQ counters of the sweep
 P3M="python $R/bench.py --workload c2_256c_512 --p3m --steps 5 --warmup 2 --no-cpu-baseline"
