@@ -249,10 +249,22 @@ def cpu_baseline_child(workload):
                          f'host threads ({binding}) + scipy.fft with as many workers')
         print(json.dumps(out))
         return
-    # 3. the workload itself: one PM step per candidate thread count
+    # 3. the workload itself: one PM step per candidate thread count — bounded: what a step at
+    # size will take is known from the sample (the port is memory-bound: time ~ particles + cells)
+    est = trial[c2_threads]*(n_p/256**3)
+    if est > 60:
+        # (a host that offers this process a handful of threads: a full step would take minutes)
+        out = dict(c2, kind='port', **extras)
+        out['sample'] = (f'{c2["sample"]} = 1/{n_p//256**3} of the workload {workload} (same code, same work '
+                         f'per particle and cell): a full step at size would take ~{est:.0f} s on the '
+                         f'{avail} host thread(s) this process may use, beyond the bound of the '
+                         f'baseline leg; oracle C port built {flags} -fopenmp on {c2_threads} of '
+                         f'{avail} host threads ({binding}) + scipy.fft with as many workers')
+        print(json.dumps(out))
+        return
     pos, mom = particles(n_p, float(N))
     cand = []
-    for t in [ranked[0], min(avail, 128), avail]:
+    for t in ([ranked[0]] if est > 40 else [ranked[0], min(avail, 128), avail]):
         if t not in cand:
             cand.append(t)
     at_size, at_size_phases = {}, {}
