@@ -435,6 +435,7 @@ extern "C" int cg_destroy(cg_ctx *c) {
     (void)hipFree(c->sr_sub_tmp);
     (void)hipFree(c->srd_small);
     (void)hipFree(c->srd_buf);
+    (void)hipFree(c->srd_rung);
     if (c->srd_host) (void)hipHostFree(c->srd_host);
     if (c->srd_stream) {
         (void)hipStreamDestroy(c->srd_stream);

@@ -140,8 +140,8 @@ struct cg_ctx {
     // lists by tile: rows of the densely populated tiles re-ordered by sub-cell (scratch)
     // the dense tiles' sweep (cg_shortrange_dense.hip): counters, pinned read-back, lists, stream
     unsigned *srd_host = nullptr;
-    void *srd_small = nullptr, *srd_buf = nullptr;
-    size_t srd_small_bytes = 0, srd_buf_bytes = 0;
+    void *srd_small = nullptr, *srd_buf = nullptr, *srd_rung = nullptr;
+    size_t srd_small_bytes = 0, srd_buf_bytes = 0, srd_rung_bytes = 0;
     hipStream_t srd_stream = nullptr;
     hipEvent_t srd_fork = nullptr, srd_join = nullptr;
     void *sr_sub_tmp = nullptr;
@@ -205,8 +205,12 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
                          const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
                          const unsigned *off_s, i64 nt, const double *table,
                          double r2_index_scaling, double r2_max, double factor,
-                         const double *factors, const signed char *rung_jumped,
-                         const unsigned char **take_out);
+                         const double *factors, const signed char *rung,
+                         const signed char *rung_jumped, int lowest_active,
+                         const unsigned char *active_in, const unsigned char **take_out);
+int cgk_shortrange_tiles_phase(cg_ctx *c, int phase, const double *pos, i64 n, i64 nt,
+                               double tile_extent, const signed char *rung, int lowest_active,
+                               unsigned *order, unsigned *offset, double *pos_sorted, float *aop);
 int cgk_shortrange_dense_join(cg_ctx *c);
 int cgk_shortrange_subsort(cg_ctx *c, const unsigned *offset, i64 n, i64 nper, double extent,
                            unsigned *order, double *pos_sorted, float *aop);

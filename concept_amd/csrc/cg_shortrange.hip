@@ -1274,16 +1274,15 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
         P.tile_active = c->sr_tile_active;
     }
     // The densely populated tiles go to the sweep with sub-cell order and box culling
-    // (cg_shortrange_dense.hip); `take` then keeps this sweep off them.  (Not with a subset of
-    // active rungs: those sub-steps kick few receivers per tile.)
+    // (cg_shortrange_dense.hip); `take` then keeps this sweep off them.  With a subset of active
+    // rungs: the tiles that hold many ACTIVE receivers (the upper rungs live where the
+    // particles are dense, and are kicked 2^rung times per base step).
     const unsigned char *take = nullptr;
-    if (!(rung && lowest_active > 0)) {
-        if (cgk_shortrange_dense(c, pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, nt,
-                                 table, r2_index_scaling, r2_max, factor, factors, rung_jumped,
-                                 &take))
-            return 1;
-        if (take) P.tile_active = take;
-    }
+    if (cgk_shortrange_dense(c, pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, nt,
+                             table, r2_index_scaling, r2_max, factor, factors, rung, rung_jumped,
+                             rung ? lowest_active : 0, P.tile_active, &take))
+        return 1;
+    if (take) P.tile_active = take;
     // The single-precision pre-test's threshold: coordinates relative to the tile's corner are
     // below 3.5 tile extents E in size, a float carries them to 2^-24 relative, a difference of
     // two to 2 * 3.5 E * 2^-24, and |x|^2 near r^2_max moves by at most

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void k_srd_precheck(const unsigned *__restrict
 // chunk) per 64 receivers of the other tiles
 __global__ __launch_bounds__(256) void k_srd_plan(const unsigned *__restrict__ off_tiles,
                                                   unsigned ntiles, unsigned min_pop,
+                                                  const unsigned char *__restrict__ active_in,
                                                   unsigned char *__restrict__ take,
                                                   unsigned long long *__restrict__ items,
                                                   unsigned *__restrict__ nitems) {
@@ -140,11 +141,57 @@ __global__ __launch_bounds__(256) void k_srd_plan(const unsigned *__restrict__ o
     if (t >= ntiles) return;
     const unsigned pop = off_tiles[t + 1] - off_tiles[t];
     const bool dense = pop >= min_pop;
-    take[t] = dense ? 0 : 1;
+    // (active_in: the tiles with a receiver on an active rung, k_sr_tile_activity)
+    take[t] = dense ? 0 : (active_in ? active_in[t] : 1);
     if (dense) {
         const unsigned nch = (pop + kdChunk - 1) / kdChunk;
         const unsigned base = atomicAdd(nitems, nch);
         for (unsigned c = 0; c < nch; c++) items[base + c] = ((unsigned long long)t << 32) | c;
+    }
+}
+
+// A sub-step that kicks the rungs >= lowest_active only: the rung of every row of the cell list
+__global__ __launch_bounds__(256) void k_srd_gather_rung(const unsigned *__restrict__ order,
+                                                         const signed char *__restrict__ rung,
+                                                         unsigned n, signed char *__restrict__ out) {
+    const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) out[q] = rung[order[q]];
+}
+// ... and what its dense tiles (min_pop ACTIVE receivers and more; off_active: the tile offsets of
+// the list of active receivers) would cost the cells sweep: active receivers x particles of the
+// tile, summed — out[0] active receivers in such tiles, out[1] such tiles, out[2..3] the sum
+__global__ __launch_bounds__(256) void k_srd_gate(const unsigned *__restrict__ off_active,
+                                                  const unsigned *__restrict__ off_cells,
+                                                  unsigned nt, unsigned min_pop,
+                                                  unsigned *__restrict__ out) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned act = 0, pop = 0;
+    if (t < nt * nt * nt) {
+        act = off_active[t + 1] - off_active[t];
+        if (act >= min_pop) {
+            const unsigned tc = t % nt, tb = (t / nt) % nt, ta = t / (nt * nt), nc = 2 * nt;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const unsigned cell = ((2 * ta + a) * nc + (2 * tb + b)) * nc + 2 * tc;
+                    pop += off_cells[cell + 2] - off_cells[cell];
+                }
+        }
+    }
+    const bool dense = act >= min_pop;
+    const unsigned long long m = __ballot(dense);
+    unsigned sum = dense ? act : 0u;
+    unsigned long long sq = dense ? (unsigned long long)act * pop : 0ull;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        sum += __shfl_xor(sum, d);
+        sq += __shfl_xor(sq, d);
+    }
+    if ((threadIdx.x & 63) == 0 && m) {
+        atomicAdd(&out[0], sum);
+        atomicAdd(&out[1], (unsigned)__popcll(m));
+        atomicAdd((unsigned long long *)(out + 2), sq);
     }
 }
 
@@ -427,20 +474,28 @@ int cgk_shortrange_dense_min() {
 // the byte per tile that keeps the cells sweep off the dense tiles (*take_out) and the launch
 // of the dense tiles' sweep on a stream of its own (joined back into the context's stream by
 // cgk_shortrange_dense_join).  *take_out stays null where the cells sweep does it all.
+// rung, lowest_active > 0: a sub-step for the upper rungs — the receivers are the particles on
+// rungs >= lowest_active (gravity.py:318-349), "dense" counts those, active_in is the cells
+// sweep's byte per tile (tiles with an active receiver).
 int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
                          const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
                          const unsigned *off_s, i64 nt, const double *table,
                          double r2_index_scaling, double r2_max, double factor,
-                         const double *factors, const signed char *rung_jumped,
-                         const unsigned char **take_out) {
+                         const double *factors, const signed char *rung,
+                         const signed char *rung_jumped, int lowest_active,
+                         const unsigned char *active_in, const unsigned char **take_out) {
     *take_out = nullptr;
     const int min_pop = cgk_shortrange_dense_min();
     if (min_pop < 0 || nt < 4) return 0;
+    const bool partial = rung && lowest_active > 0;
+    const bool by_threshold = getenv("CONCEPT_GPU_SR_DENSE_MIN") != nullptr;
     const i64 ntiles = nt * nt * nt, ncells = 8 * ntiles;
     if (!c->srd_host) CG_HIP(hipHostMalloc((void **)&c->srd_host, 64));
     if (srd_reserve(c, (void **)&c->srd_small, &c->srd_small_bytes, 64)) return 1;
-    unsigned *dev = (unsigned *)c->srd_small;  // [0] receivers in dense tiles, [1] dense tiles, [2] items
-    CG_HIP(hipMemsetAsync(dev, 0, 24, c->stream));
+    // [0] receivers in dense tiles, [1] dense tiles, [2] items, [4..5] sum of pop^2,
+    // [6] active receivers in tiles dense with them, [7] such tiles, [8..9] sum of active x pop
+    unsigned *dev = (unsigned *)c->srd_small;
+    CG_HIP(hipMemsetAsync(dev, 0, 40, c->stream));
     hipLaunchKernelGGL(k_srd_precheck, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0,
                        c->stream, off_r, (unsigned)nt, (unsigned)min_pop, dev);
     CG_LAUNCH_CHECK();
@@ -452,18 +507,17 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
     const i64 ndense = c->srd_host[0], tdense = c->srd_host[1], n_r = c->srd_host[2],
               n_s = c->srd_host[3];
     if (ndense == 0) return 0;
-    const bool same = pos_r_sorted == pos_s_sorted && off_r == off_s;
-    if (!getenv("CONCEPT_GPU_SR_DENSE_MIN")) {
-        // Is it worth the lists?  What the dense tiles cost the cells sweep (~18.75 pop^2 pair
-        // tests per tile at its 0.9e12 tests/s; this sweep needs about half) against a list build
-        // (measured 0.07 ns per particle; 0.1 here).  A uniform box of 2^28 particles at 44 per tile
-        // has 0.3 % of its tiles above the threshold and 17 ms of lists to pay: not worth it.
-        unsigned long long sq;
-        memcpy(&sq, c->srd_host + 4, 8);
-        const double saved = 0.45 * 18.75 * (double)sq / 0.9e12;
-        const double cost = 5e-5 + 1e-10 * (double)(n_r + (same ? 0 : n_s));
-        if (saved < 2 * cost) return 0;
-    }
+    // (the list of a sub-step's receivers is a subset: the suppliers get a list of their own)
+    const bool same = !partial && pos_r_sorted == pos_s_sorted && off_r == off_s;
+    // Is it worth the lists?  What the dense tiles cost the cells sweep (~18.75 pair tests per
+    // receiver and particle of the tile at its 0.9e12 tests/s; this sweep needs about half)
+    // against a list build (measured 0.07 ns per particle; 0.1 here).  A uniform box of 2^28
+    // particles at 44 per tile has 0.3 % of its tiles above the threshold and 17 ms of lists to
+    // pay: not worth it.  (With CONCEPT_GPU_SR_DENSE_MIN set the threshold alone decides.)
+    const double cost = 5e-5 + 1e-10 * (double)(n_r + (same ? 0 : n_s));
+    unsigned long long sq;
+    memcpy(&sq, c->srd_host + 4, 8);
+    if (!by_threshold && 0.45 * 18.75 * (double)sq / 0.9e12 < 2 * cost) return 0;
     // buffers: take | items | offsets r, s | order r, s | positions r, s
     const size_t a_take = 0, a_items = (size_t)((ntiles + 255) / 256 * 256),
                  a_offr = a_items + 8 * (size_t)(ndense / kdChunk + tdense + 1),
@@ -481,13 +535,38 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
     unsigned *ordr = (unsigned *)(B + a_ordr), *ords = same ? ordr : (unsigned *)(B + a_ords);
     double *posr = (double *)(B + a_posr), *poss = same ? posr : (double *)(B + a_poss);
     const double ext = c->p.boxsize / (double)nt;  // species.py:607-609
-    if (cgk_shortrange_tiles(c, pos_r_sorted, n_r, nt, ext, nullptr, 0, ordr, offr, posr, nullptr))
+    if (partial) {
+        // the active receivers' offsets first (a histogram: 0.07 ms at 256^3): do the tiles that
+        // are dense WITH THEM hold enough of this sub-step's pair work?
+        if (srd_reserve(c, &c->srd_rung, &c->srd_rung_bytes, (size_t)n_r)) return 1;
+        signed char *rung_sorted = (signed char *)c->srd_rung;
+        hipLaunchKernelGGL(k_srd_gather_rung, dim3((unsigned)((n_r + 255) / 256)), dim3(256), 0,
+                           c->stream, order_r, rung, (unsigned)n_r, rung_sorted);
+        CG_LAUNCH_CHECK();
+        if (cgk_shortrange_tiles_phase(c, 1, pos_r_sorted, n_r, nt, ext, rung_sorted, lowest_active,
+                                       ordr, offr, posr, nullptr))
+            return 1;
+        hipLaunchKernelGGL(k_srd_gate, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0,
+                           c->stream, offr, off_r, (unsigned)nt, (unsigned)min_pop, dev + 6);
+        CG_LAUNCH_CHECK();
+        CG_HIP(hipMemcpyAsync(c->srd_host + 6, dev + 6, 16, hipMemcpyDeviceToHost, c->stream));
+        CG_HIP(hipStreamSynchronize(c->stream));
+        memcpy(&sq, c->srd_host + 8, 8);
+        if (c->srd_host[6] == 0) return 0;
+        if (!by_threshold && 0.45 * 18.75 * (double)sq / 0.9e12 < 2 * cost) return 0;
+        if (cgk_shortrange_tiles_phase(c, 2, pos_r_sorted, n_r, nt, ext, rung_sorted, lowest_active,
+                                       ordr, offr, posr, nullptr))
+            return 1;
+    } else if (cgk_shortrange_tiles(c, pos_r_sorted, n_r, nt, ext, nullptr, 0, ordr, offr, posr,
+                                    nullptr)) {
         return 1;
+    }
     if (!same &&
         cgk_shortrange_tiles(c, pos_s_sorted, n_s, nt, ext, nullptr, 0, ords, offs, poss, nullptr))
         return 1;
     hipLaunchKernelGGL(k_srd_plan, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream,
-                       offr, (unsigned)ntiles, (unsigned)min_pop, take, items, dev + 2);
+                       offr, (unsigned)ntiles, (unsigned)min_pop, partial ? active_in : nullptr,
+                       take, items, dev + 2);
     CG_LAUNCH_CHECK();
     if (!c->srd_stream) {
         CG_HIP(hipStreamCreateWithFlags(&c->srd_stream, hipStreamNonBlocking));
@@ -498,7 +577,8 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
     CG_HIP(hipStreamWaitEvent(c->srd_stream, c->srd_fork, 0));
     SrdParams P{c->p.boxsize, ext, 1.0 / ext, r2_index_scaling, r2_max, factor, factors,
                 rung_jumped, (int)nt};
-    // (as many workgroups as there can be items; the ones past the count leave at once)
+    // (as many workgroups as there can be items — counted on all the particles, an upper bound
+    // for a subset; the ones past the count leave at once)
     const unsigned grid = (unsigned)(ndense / kdChunk + tdense);
     hipLaunchKernelGGL(k_sr_sweep_dense, dim3(grid), dim3(64 * kdWaves), 0, c->srd_stream, posr,
                        ordr, order_r, offr, dmom_r, poss, offs, items, dev + 2, table, P);

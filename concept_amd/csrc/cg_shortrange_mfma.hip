@@ -901,47 +901,53 @@ int cgk_shortrange_subsort(cg_ctx *c, const unsigned *offset, i64 n, i64 nper, d
     return 0;
 }
 
-int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
-                         const signed char *rung, int lowest_active, unsigned *order,
-                         unsigned *offset, double *pos_sorted, float *aop) {
+// phase 0: the whole list; 1: the tiles' offsets only (histogram + scan — what a caller needs to
+// decide whether it wants the list); 2: the rest, after a call with phase 1 on the same arguments
+int cgk_shortrange_tiles_phase(cg_ctx *c, int phase, const double *pos, i64 n, i64 nt,
+                               double tile_extent, const signed char *rung, int lowest_active,
+                               unsigned *order, unsigned *offset, double *pos_sorted, float *aop) {
     const double eps = 2.220446049250313e-16;
     const double inv = (1 / tile_extent) * (1 - 2 * eps);
     const i64 ntiles = nt * nt * nt;
-    if ((size_t)(8 * (ntiles + 1)) > c->sr_tmp_bytes) {
-        CG_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->sr_tmp);
-        c->sr_tmp = nullptr;
-        c->sr_tmp_bytes = 0;
-        CG_HIP(hipMalloc(&c->sr_tmp, 8 * (ntiles + 1)));
-        c->sr_tmp_bytes = 8 * (ntiles + 1);
-    }
-    unsigned *count = (unsigned *)c->sr_tmp, *cursor = count + (ntiles + 1);
-    CG_HIP(hipMemsetAsync(c->sr_tmp, 0, 8 * (ntiles + 1), c->stream));
     const i64 blocks = (n + 255) / 256;
-    if (n > 0) {
-        hipLaunchKernelGGL(k_srm_histogram, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n,
-                           inv, (unsigned)nt, rung, lowest_active, count);
-        CG_LAUNCH_CHECK();
+    if (phase != 2) {
+        if ((size_t)(8 * (ntiles + 1)) > c->sr_tmp_bytes) {
+            CG_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->sr_tmp);
+            c->sr_tmp = nullptr;
+            c->sr_tmp_bytes = 0;
+            CG_HIP(hipMalloc(&c->sr_tmp, 8 * (ntiles + 1)));
+            c->sr_tmp_bytes = 8 * (ntiles + 1);
+        }
+        unsigned *count = (unsigned *)c->sr_tmp;
+        CG_HIP(hipMemsetAsync(c->sr_tmp, 0, 8 * (ntiles + 1), c->stream));
+        if (n > 0) {
+            hipLaunchKernelGGL(k_srm_histogram, dim3((unsigned)blocks), dim3(256), 0, c->stream,
+                               pos, n, inv, (unsigned)nt, rung, lowest_active, count);
+            CG_LAUNCH_CHECK();
+        }
+        size_t need = 0;
+        CG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, count, offset, (int)(ntiles + 1),
+                                                c->stream));
+        if (need > c->scan_tmp_bytes) {
+            CG_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->scan_tmp);
+            c->scan_tmp = nullptr;
+            c->scan_tmp_bytes = 0;
+            CG_HIP(hipMalloc(&c->scan_tmp, need));
+            c->scan_tmp_bytes = need;
+        }
+        CG_HIP(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp, need, count, offset,
+                                                (int)(ntiles + 1), c->stream));
     }
-    size_t need = 0;
-    CG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, count, offset, (int)(ntiles + 1),
-                                            c->stream));
-    if (need > c->scan_tmp_bytes) {
-        CG_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->scan_tmp);
-        c->scan_tmp = nullptr;
-        c->scan_tmp_bytes = 0;
-        CG_HIP(hipMalloc(&c->scan_tmp, need));
-        c->scan_tmp_bytes = need;
-    }
-    CG_HIP(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp, need, count, offset, (int)(ntiles + 1),
-                                            c->stream));
-    if (n > 0) {
+    if (phase != 1 && n > 0) {
+        unsigned *cursor = (unsigned *)c->sr_tmp + (ntiles + 1);
         hipLaunchKernelGGL(k_srm_scatter, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n,
                            inv, 1 / tile_extent, (unsigned)nt, rung, lowest_active, offset, cursor,
                            order, pos_sorted, (f32x4 *)aop);
         CG_LAUNCH_CHECK();
-        // the densely populated tiles: rows re-ordered by sub-cell
+        // the densely populated tiles: rows re-ordered by sub-cell (a filtered list has fewer
+        // rows than n: the scratch is sized for n all the same)
         if (cgk_shortrange_subsort(c, offset, n, nt, tile_extent, order, pos_sorted, aop)) return 1;
         if (aop) {
             hipLaunchKernelGGL(k_srm_bbox, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -951,6 +957,13 @@ int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
         }
     }
     return 0;
+}
+
+int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
+                         const signed char *rung, int lowest_active, unsigned *order,
+                         unsigned *offset, double *pos_sorted, float *aop) {
+    return cgk_shortrange_tiles_phase(c, 0, pos, n, nt, tile_extent, rung, lowest_active, order,
+                                      offset, pos_sorted, aop);
 }
 
 int cgk_shortrange_sweep_tiles(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,

@@ -329,8 +329,10 @@ int cg_shortrange_sweep_rungs(cg_ctx *ctx, const double *pos_r, const uint32_t *
  * 16 receivers' reach is skipped (2.1-2.6 pair tests per pair in range instead of 4.2-4.4) —
  * with the same pair arithmetic; nothing changes for the caller (the lists are built inside the
  * call, only when such tiles exist and hold enough of the pair work to pay for the lists: one
- * 24-byte read-back per call decides — the call waits for the context's stream once).  With rungs this
- * happens where every rung is active (lowest_active_rung = 0).  Environment:
+ * 24-byte read-back per call decides — the call waits for the context's stream once).  With
+ * rungs: where every rung is active, as above; in a sub-step for the rungs >= lowest_active_rung
+ * the tiles that hold 64 and more ACTIVE receivers (a second look, at the histogram of the active
+ * receivers' tiles: the upper rungs live where the particles are dense).  Environment:
  * CONCEPT_GPU_SR_DENSE=0 switches it off, CONCEPT_GPU_SR_DENSE_MIN=<particles per tile> moves
  * the threshold. */
 int cg_shortrange_cells(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, int64_t nt,

@@ -13,10 +13,11 @@ from concept_amd import commons, stepper  # noqa: E402
 from concept_amd.species import Component  # noqa: E402
 
 a1 = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
+a0 = float(os.environ.get('SOAK_A0', '0.02'))   # SOAK_DIST=clustered: the bench's clustered box
 n_side, N = 256, 512
 n = n_side**3
 p = commons.load_params({
-    'boxsize': 512.0, 'H0': 0.07, 'Ωb': 0.05, 'Ωcdm': 0.25, 'a_begin': 0.02,
+    'boxsize': 512.0, 'H0': 0.07, 'Ωb': 0.05, 'Ωcdm': 0.25, 'a_begin': a0,
     'output_times': {'a': (a1,)},
     'potential_options': {'gridsize': {'gravity': {'p3m': N}}},
     'select_forces': {'all': {'gravity': 'p3m'}}})
@@ -25,6 +26,9 @@ c = Component('matter', 'matter', N=n, mass=mass)
 gen = torch.Generator(device='cuda').manual_seed(13)
 torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=gen, out=c.pos)
 c.pos.mul_(p.boxsize*(1 - 1e-13))
+if os.environ.get('SOAK_DIST') == 'clustered':
+    from tools.sr_mfma_check import positions
+    c.pos.copy_(positions('clustered', n, p.boxsize, gen))
 c.mom.zero_()
 stamps = []
 def on_step(lp):
@@ -36,7 +40,7 @@ loop.run()
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 d = np.diff(np.array(stamps))
-print(f'a 0.02 -> {loop.cosmo.a}: {loop.time_step} base steps in {wall:.1f} s; s per step: first 5 '
+print(f'a {a0} -> {loop.cosmo.a}: {loop.time_step} base steps in {wall:.1f} s; s per step: first 5 '
       + ' '.join(f'{v:.2f}' for v in d[:5]) + ' | last 5 ' + ' '.join(f'{v:.2f}' for v in d[-5:]))
 from concept_amd import shortrange  # noqa: E402
 print('sweeps without a cell list:', shortrange.sparse_sweeps)
