@@ -785,3 +785,59 @@ def test_tile_sweep_on_the_randomised_and_multi_component_cases(monkeypatch):
     test_adaptive_rungs_knot_across_domains()
     for seed in range(2):
         test_random_p3m_timeloops_across_domains(seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('lowest', [0, 1, 3])
+def test_dense_sweep_with_active_rungs_equals_the_cells_sweep(lowest, monkeypatch):
+    """cg_shortrange_sweep_cells_rungs on a clustered box (blobs of several hundred particles per
+    tile; rungs assigned so that the upper ones sit in the blobs, some flagged to jump; receivers
+    and suppliers two different components): the sub-step for the rungs >= lowest with the
+    dense tiles' sweep — tiles dense with ACTIVE receivers, by the default threshold and cost
+    model — against the half-tile cells everywhere (CONCEPT_GPU_SR_DENSE=0).  Same sums; the
+    inactive receivers untouched."""
+    import torch
+    from concept_amd import commons, shortrange
+    from concept_amd.mesh import PotentialMesh
+    N, L = 96, 96.0
+    mesh = PotentialMesh(N, L)
+    rng = np.random.default_rng(5)
+    n_r, n_s = 160000, 150000
+
+    def box(n):
+        pos = rng.uniform(0, L, (n, 3))
+        centres = np.array([[20.0, 20.0, 20.0], [0.5, 48.0, 95.5], [70.0, 1.0, 40.0]])
+        k = int(0.7*n)
+        pos[:k] = centres[rng.integers(0, 3, k)] + rng.normal(0, 2.5, (k, 3))
+        return np.mod(pos, L), k
+    pos_r, k_r = box(n_r)
+    pos_s, _ = box(n_s)
+    N_rungs = 8
+    rung = rng.integers(0, 2, n_r).astype(np.int8)
+    rung[:k_r] = rng.integers(0, 5, k_r)              # the blobs: rungs 0-4
+    jumped = rung.copy()
+    flag = rng.choice(n_r, 500, replace=False)
+    jumped[flag] = rung[flag] + N_rungs                # flagged to jump up: another factor
+    pos_r_t, pos_s_t = torch.as_tensor(pos_r, device='cuda'), torch.as_tensor(pos_s, device='cuda')
+    rung_t, jumped_t = torch.as_tensor(rung, device='cuda'), torch.as_tensor(jumped, device='cuda')
+    factors = torch.as_tensor(rng.uniform(0.5, 2.0, 3*N_rungs - 1), device='cuda')
+    scale = 1.25*L/N
+    rng_ = 4.5*scale
+    nt = int(L/rng_*(1 + commons.machine_ϵ))
+    table, maxr2 = shortrange.get_shortrange_table(0.02, scale, rng_, 4096, 'spline', 'cuda')
+    cr = mesh.shortrange_cells(pos_r_t, nt, L/nt)
+    cs = mesh.shortrange_cells(pos_s_t, nt, L/nt)
+    base = torch.as_tensor(rng.normal(0, 1e-3, (n_r, 3)), device='cuda')
+    out = []
+    for dense in ('0', '1'):
+        monkeypatch.setenv('CONCEPT_GPU_SR_DENSE', dense)
+        dm = base.clone()
+        mesh.shortrange_sweep_cells(cr, dm, cs, nt, table, 4095/maxr2, rng_**2, 0.0,
+                                    (factors, rung_t, jumped_t, lowest))
+        out.append(dm)
+    kick = float((out[0] - base).abs().max())
+    assert kick > 0
+    assert float((out[1] - out[0]).abs().max()) <= 1e-12*kick
+    idle = rung_t < lowest
+    assert bool((out[1][idle] == base[idle]).all())
+    mesh.close()
