@@ -431,6 +431,8 @@ extern "C" int cg_destroy(cg_ctx *c) {
     (void)hipFree(c->sr_tile_active);
     (void)hipFree(c->sr_sparse_partial);
     (void)hipFree(c->scan_tmp);
+    (void)hipFree(c->tile_order_buf);
+    if (c->tile_order_seen) (void)hipHostFree(c->tile_order_seen);
     (void)hipFree(c->sr_tmp);
     (void)hipFree(c->sr_sub_tmp);
     (void)hipFree(c->srd_small);
@@ -796,6 +798,20 @@ extern "C" int cg_predict_regions(cg_ctx *c, const uint32_t *start_in, const uin
                                   uint32_t *start_out) {
     CG_CHECK(c && start_in && start_out, "cg_predict_regions: null argument");
     return cgk_predict_regions(c, start_in, count_in, start_out);
+}
+
+extern "C" int cg_tile_order_read(cg_ctx *c, uint32_t *heavy_out, int64_t capacity,
+                                  int64_t *n_heavy) {
+    CG_CHECK(c && n_heavy && (heavy_out || capacity == 0), "cg_tile_order_read: null argument");
+    *n_heavy = -1;
+    if (!c->tile_order_on) return 0;
+    CG_HIP(hipStreamSynchronize(c->stream));
+    unsigned n = 0;
+    CG_HIP(hipMemcpy(&n, c->tile_order + c->tile_order_cap + 1, sizeof n, hipMemcpyDeviceToHost));
+    *n_heavy = n;
+    const size_t m = (int64_t)n < capacity ? (size_t)n : (size_t)capacity;
+    if (m) CG_HIP(hipMemcpy(heavy_out, c->tile_order, sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 extern "C" int cg_gather_kick_drift_scatter(

@@ -134,6 +134,16 @@ struct cg_ctx {
     unsigned int *tile_count = nullptr;   // [ntiles + 1]
     unsigned int *tile_cursor = nullptr;  // [ntiles]
     void *scan_tmp = nullptr;
+    // tile kernels: heavy tiles first when the tiles' populations are far from equal
+    // (cgk_tile_order; off = the plain walk)
+    unsigned int *tile_order = nullptr;  // the list [tile_order_cap], counters and bytes behind
+    unsigned int *tile_order_buf = nullptr;
+    unsigned tile_order_cap = 0;
+    unsigned *tile_order_seen = nullptr;  // pinned: length of the list of the last build done
+    bool tile_order_on = false;          // list and bytes of one build are there
+    int tile_order_mode = -1;            // CONCEPT_GPU_TILE_ORDER: 0 off, 1 on (default)
+    unsigned tile_order_floor = 1536;    // CONCEPT_GPU_TILE_ORDER_MIN
+    const void *tile_order_src[2] = {nullptr, nullptr};  // (start, count) it was made from
     size_t scan_tmp_bytes = 0;
     void *sr_tmp = nullptr;  // short-range cell-list counters
     size_t sr_tmp_bytes = 0;
@@ -292,6 +302,8 @@ struct FusedScatter {
 int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
                           const unsigned *tile_offset, int diff_order, double factor,
                           int prepare, double next_dtm, const FusedScatter *fs = nullptr);
+// workgroup -> tile for the kernels that give a tile to a workgroup (cg_tiled_kernels.hip)
+int cgk_tile_order(cg_ctx *c, const unsigned *start, const unsigned *count);
 int cgk_predict_regions(cg_ctx *c, const unsigned *start_in, const unsigned *count_in,
                         unsigned *start_out);
 int cgk_emigrant_rows_dest(cg_ctx *c, const double *rows, const unsigned *count, i64 cap,

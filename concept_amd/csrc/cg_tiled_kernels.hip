@@ -101,6 +101,185 @@ __device__ __forceinline__ unsigned tile_for_block_grouped(unsigned b, unsigned 
 }
 
 // ---------------------------------------------------------------------------
+// heavy tiles first: the launch order when the tiles' populations are far from equal
+//
+// The kernels of this file give a tile to a workgroup, and a workgroup walks its tile's
+// particles in batches of 512: its time follows the population.  With the plain walk every XCD
+// owns an eighth of the box (a slab of a-layers), so on a clustered box (bench.py --dist
+// clustered: 64 Gaussian clumps with 80 % of 2^28 particles, up to 79,000 in a tile against a
+// mean of 1024) the XCDs' loads differ by the clumps each slab happens to hold, and a tile of
+// 150 batches that starts late is a tail of its own.  Measured, fused pass, with workgroup ->
+// tile tables made on the host (round 4): plain walk 10.8 ms; the heavy tiles of each XCD first,
+// by falling population: 9.3; the heavy tiles of the whole box by falling population dealt out
+// to the XCDs in turn (block b runs on XCD b % 8), then all others in the walk's order: 8.4 ms
+// — the uniform box's time.  ALL tiles by falling population: 11.0 (the sparse tiles lose the
+// L2 locality of their halos); heavy and sparse tiles merged at equal fractions of their work:
+// 10.0.  Heavy = more than max(1536, 1.5 x mean) particles (thresholds of 1024 .. 3072: 8.39 ..
+// 8.45 ms).
+//
+// A table read by EVERY workgroup costs the uniform box what it gains the clustered one (a
+// dependent load in front of a workgroup's first loads, 341 rounds of workgroups: fused pass
+// 8.45 -> 8.78 ms with a table that holds the plain walk).  So only the heavy tiles go
+// through a list: the grid is `cap` blocks longer; block b < cap takes heavy[b] (or ends at
+// once when the list is shorter), block cap + b' takes the tile of the plain walk at b' and
+// ends when that tile's place on the list is in front of `cap` — a load that travels with the
+// workgroup's first loads instead of in front of them.  How many blocks go in front is the
+// launch's choice (a tile beyond them is simply left to the walk): the list's length of the
+// last build the host has seen (written to pinned memory, read without waiting), a quarter
+// more; none at all, and no loads either, when that was zero — the uniform box launches what
+// it always did.
+//
+// cgk_tile_order makes the list and every tile's place on it on the device from the populations the kernel is about
+// to read.  The order among tiles of about the same population is free, so the heavy tiles
+// are counted into 61 classes of population (units of a third of the threshold) and take
+// their places through one cursor per class: three launches of a few microseconds.  List and
+// places of one build describe every tile exactly once whatever the populations are by the
+// time they are used, so the gather-kick takes over what the deposit of the same tables made.
+// ---------------------------------------------------------------------------
+constexpr int ORD_B = 256;       // lanes per workgroup of the order kernels
+constexpr int ORD_CLASSES = 64;  // counters: [0] particles, [1] tiles on the list, [2..65] tiles
+                                 // per class, [66..129] cursor per class
+__global__ void k_order_pops(const unsigned *__restrict__ start, const unsigned *__restrict__ count,
+                             unsigned ntiles, unsigned *__restrict__ pops,
+                             unsigned *__restrict__ counters) {
+    const unsigned tile = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned pop = 0;
+    if (tile < ntiles) {
+        if (count) {
+#pragma unroll
+            for (int f = 0; f < 8; f++) pop += count[8 * (size_t)tile + f];
+        } else {
+            pop = start[8 * (size_t)tile + 8] - start[8 * (size_t)tile];
+        }
+        pops[tile] = pop;
+    }
+    // (sum over the wave, one atomic per wave)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pop += __shfl_down(pop, o);
+    if ((threadIdx.x & 63) == 0 && pop) atomicAdd(&counters[0], pop);
+}
+// class of population into pops[] (0: not heavy), heavy tiles per class
+__global__ __launch_bounds__(ORD_B) void k_order_classes(unsigned *__restrict__ pops,
+                                                         unsigned ntiles, unsigned floor_,
+                                                         unsigned *__restrict__ counters) {
+    __shared__ unsigned hist[ORD_CLASSES];
+    if (threadIdx.x < ORD_CLASSES) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned t = blockIdx.x * ORD_B + threadIdx.x;
+    const unsigned mean15 = (unsigned)(((unsigned long long)counters[0] * 3ull) / (2ull * ntiles));
+    const unsigned thr = mean15 > floor_ ? mean15 : floor_, unit = thr / 3u ? thr / 3u : 1u;
+    if (t < ntiles) {
+        const unsigned pop = pops[t];
+        unsigned cls = 0;
+        if (pop > thr) {
+            cls = pop / unit;  // >= 3
+            cls = cls < (unsigned)ORD_CLASSES ? cls : (unsigned)ORD_CLASSES - 1u;
+            atomicAdd(&hist[cls], 1u);
+        }
+        pops[t] = cls;
+    }
+    __syncthreads();
+    if (threadIdx.x < ORD_CLASSES && hist[threadIdx.x])
+        atomicAdd(&counters[2 + threadIdx.x], hist[threadIdx.x]);
+}
+// the list by falling class, as far as it reaches; a tile's place on it (none: all ones)
+__global__ __launch_bounds__(ORD_B) void k_order_place(const unsigned *__restrict__ cls_of,
+                                                       unsigned ntiles, unsigned cap,
+                                                       unsigned *__restrict__ counters,
+                                                       unsigned *__restrict__ heavy,
+                                                       unsigned *__restrict__ rank,
+                                                       unsigned *__restrict__ host_n) {
+    __shared__ unsigned base[ORD_CLASSES];
+    if (threadIdx.x < ORD_CLASSES) {
+        // first place of a class: the tiles of the classes above it
+        const unsigned mine = counters[2 + threadIdx.x];
+        unsigned incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_down(incl, o);
+            if ((int)threadIdx.x + o < ORD_CLASSES) incl += u;
+        }
+        base[threadIdx.x] = incl - mine;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *host_n = counters[1] = incl < cap ? incl : cap;
+    }
+    __syncthreads();
+    const unsigned t = blockIdx.x * ORD_B + threadIdx.x;
+    if (t >= ntiles) return;
+    const unsigned cls = cls_of[t];
+    unsigned k = ~0u;
+    if (cls) {
+        k = base[cls] + atomicAdd(&counters[2 + ORD_CLASSES + cls], 1u);
+        if (k < cap) heavy[k] = t;
+        else k = ~0u;  // (a list that is full leaves the tile to the walk)
+    }
+    rank[t] = k;
+}
+
+int cgk_tile_order(cg_ctx *c, const unsigned *start, const unsigned *count) {
+    if (c->tile_order_mode < 0) {
+        const char *env = getenv("CONCEPT_GPU_TILE_ORDER");
+        c->tile_order_mode = env ? atoi(env) : 1;  // 2: also on boxes of a few tiles (tests)
+        env = getenv("CONCEPT_GPU_TILE_ORDER_MIN");  // particles from which a tile can be heavy
+        c->tile_order_floor = env ? (unsigned)atoi(env) : 1536u;
+    }
+    const unsigned ntiles = (unsigned)c->ntiles;
+    if (!c->tile_order_mode || ntiles < (c->tile_order_mode == 2 ? 8u : 4096u)) {
+        c->tile_order_on = false;
+        return 0;
+    }
+    if (c->tile_order_on && c->tile_order_src[0] == start && c->tile_order_src[1] == count)
+        return 0;  // made from these tables by the step's previous kernel
+    const unsigned nblk = (ntiles + ORD_B - 1) / ORD_B;
+    const size_t ncounters = 2 + 2 * ORD_CLASSES;
+    // the list's length: an eighth of the tiles, a multiple of 8 (the walk behind it keeps its
+    // blocks on the XCDs it had)
+    const unsigned cap = ((ntiles / 8u) + 7u) & ~7u;
+    if (!c->tile_order_buf) {
+        CG_HIP(hipMalloc(&c->tile_order_buf,
+                         sizeof(unsigned) * (2 * (size_t)ntiles + cap + ncounters)));
+        c->tile_order = c->tile_order_buf + ntiles;
+        c->tile_order_cap = cap;
+        CG_HIP(hipHostMalloc((void **)&c->tile_order_seen, sizeof(unsigned), hipHostMallocMapped));
+        *c->tile_order_seen = ~0u;  // no build seen yet
+    }
+    unsigned *pops = c->tile_order_buf, *heavy = c->tile_order, *counters = heavy + cap;
+    unsigned *rank = counters + ncounters, *seen_dev = nullptr;
+    CG_HIP(hipHostGetDevicePointer((void **)&seen_dev, c->tile_order_seen, 0));
+    CG_HIP(hipMemsetAsync(counters, 0, sizeof(unsigned) * ncounters, c->stream));
+    hipLaunchKernelGGL(k_order_pops, dim3(nblk), dim3(ORD_B), 0, c->stream, start, count, ntiles,
+                       pops, counters);
+    hipLaunchKernelGGL(k_order_classes, dim3(nblk), dim3(ORD_B), 0, c->stream, pops, ntiles,
+                       c->tile_order_floor, counters);
+    hipLaunchKernelGGL(k_order_place, dim3(nblk), dim3(ORD_B), 0, c->stream, pops, ntiles, cap,
+                       counters, heavy, rank, seen_dev);
+    CG_LAUNCH_CHECK();
+    c->tile_order_on = true;
+    c->tile_order_src[0] = start;
+    c->tile_order_src[1] = count;
+    return 0;
+}
+// what a tile kernel is launched with (list == null: the plain walk, no extra blocks)
+struct TileOrder {
+    const unsigned *list;        // heavy tiles, *n of them
+    const unsigned *n;
+    const unsigned *rank;        // per tile: its place on the list (all ones: not on it)
+    unsigned cap;                // blocks in front of the walk (a multiple of 8)
+};
+static TileOrder tile_order_args(const cg_ctx *c) {
+    TileOrder o{};
+    if (!c->tile_order_on) return o;
+    const unsigned seen = *(volatile unsigned *)c->tile_order_seen;
+    if (seen == 0) return o;  // no heavy tiles the last time we looked: the plain launch
+    unsigned front = c->tile_order_cap;
+    if (seen != ~0u && seen + seen / 4u + 64u < front) front = (seen + seen / 4u + 64u + 7u) & ~7u;
+    o.list = c->tile_order;
+    o.n = c->tile_order + c->tile_order_cap + 1;
+    o.rank = c->tile_order + c->tile_order_cap + 2 + 2 * ORD_CLASSES;
+    o.cap = front;
+    return o;
+}
+
+// ---------------------------------------------------------------------------
 // tiled deposit, owner-computes ("pull") form
 //
 // Workgroup of tile t accumulates in LDS every contribution to the T^3 cells
@@ -117,18 +296,30 @@ __global__ __launch_bounds__(512) void k_deposit_cic_pull(
     const double *__restrict__ pos, const unsigned *__restrict__ table,
     const unsigned *__restrict__ count /* populations of regions with gaps, or null: dense */,
     double *__restrict__ mesh, i64 N, i64 ny, i64 pad, int g, int ntx, int nt, unsigned nblocks,
-    XMap xm, CicGeom geo, double contribution) {
+    XMap xm, CicGeom geo, double contribution, TileOrder ord, unsigned nordered) {
     // tiles: ntx rows along x (this domain's), nt along y and z.  An x-slab domain has
     // one extra row ta == ntx: the ghost layer that receives the CIC clouds sticking out
     // of the last owned layer (sent to the next domain and added there).
     constexpr int NL = T * T * T;
     __shared__ double lds[NL];
     __shared__ unsigned seg_beg[64], seg_end_prefix[65];
+    // (ord: heavy tiles first, see cgk_tile_order; it knows the first `nordered` tiles — those
+    // that hold particles; a slab domain's ghost row behind them is walked as ever)
+    unsigned tile;
+    if (ord.list && blockIdx.x < ord.cap) {
+        if (blockIdx.x >= (unsigned)__builtin_amdgcn_readfirstlane((int)*ord.n)) return;
+        tile = (unsigned)__builtin_amdgcn_readfirstlane((int)ord.list[blockIdx.x]);
+    } else {
+        const unsigned b = blockIdx.x - (ord.list ? ord.cap : 0u);
 #ifdef CG_TILE_GROUP_DEPOSIT
-    const unsigned tile = tile_for_block_grouped(blockIdx.x, nblocks, (unsigned)nt, (unsigned)nt);
+        tile = tile_for_block_grouped(b, nblocks, (unsigned)nt, (unsigned)nt);
 #else
-    const unsigned tile = tile_for_block(blockIdx.x, nblocks);
+        tile = tile_for_block(b, nblocks);
 #endif
+        if (ord.list && tile < nordered &&
+            (unsigned)__builtin_amdgcn_readfirstlane((int)ord.rank[tile]) < ord.cap)
+            return;
+    }
     const int tc = tile % nt, tb = (tile / nt) % nt, ta = tile / (nt * nt);
     const int Ni = (int)N;
     const int T0a = (int)xm.x0 + ta * T, T0b = tb * T, T0c = tc * T;
@@ -207,14 +398,20 @@ static int launch_deposit(cg_ctx *c, const double *pos, const unsigned *table,
                           const unsigned *count, double contribution, int accumulate) {
     int rows = c->tiles.ntx + (c->xmap.periodic ? 0 : 1);
     unsigned nb = (unsigned)((i64)rows * c->tiles.nty * c->tiles.ntz);
+    // the populations are new with every deposit of a step: the order is made here and the
+    // gather of the same tables takes it over
+    c->tile_order_on = false;
+    if (cgk_tile_order(c, table, count)) return 1;
+    const TileOrder order = tile_order_args(c);
+    const unsigned nordered = (unsigned)c->ntiles;
     if (accumulate)
-        hipLaunchKernelGGL((k_deposit_cic_pull<T, true>), dim3(nb), dim3(512), 0, c->stream, pos,
+        hipLaunchKernelGGL((k_deposit_cic_pull<T, true>), dim3(nb + order.cap), dim3(512), 0, c->stream, pos,
                            table, count, c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.ntx, c->tiles.nty,
-                           nb, c->xmap, c->geom_deposit, contribution);
+                           nb, c->xmap, c->geom_deposit, contribution, order, nordered);
     else
-        hipLaunchKernelGGL((k_deposit_cic_pull<T, false>), dim3(nb), dim3(512), 0, c->stream, pos,
+        hipLaunchKernelGGL((k_deposit_cic_pull<T, false>), dim3(nb + order.cap), dim3(512), 0, c->stream, pos,
                            table, count, c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.ntx, c->tiles.nty,
-                           nb, c->xmap, c->geom_deposit, contribution);
+                           nb, c->xmap, c->geom_deposit, contribution, order, nordered);
     return 0;
 }
 
@@ -223,10 +420,10 @@ int cgk_deposit_cic_tiled(cg_ctx *c, const double *pos, i64 n, const unsigned *t
     (void)n;
     const int T = c->tiles.tx;
     switch (T) {
-        case 16: launch_deposit<16>(c, pos, tile_offset, count, contribution, accumulate); break;
-        case 8: launch_deposit<8>(c, pos, tile_offset, count, contribution, accumulate); break;
-        case 4: launch_deposit<4>(c, pos, tile_offset, count, contribution, accumulate); break;
-        case 2: launch_deposit<2>(c, pos, tile_offset, count, contribution, accumulate); break;
+        case 16: if (launch_deposit<16>(c, pos, tile_offset, count, contribution, accumulate)) return 1; break;
+        case 8: if (launch_deposit<8>(c, pos, tile_offset, count, contribution, accumulate)) return 1; break;
+        case 4: if (launch_deposit<4>(c, pos, tile_offset, count, contribution, accumulate)) return 1; break;
+        case 2: if (launch_deposit<2>(c, pos, tile_offset, count, contribution, accumulate)) return 1; break;
         default: cg_set_error("cgk_deposit_cic_tiled: tile extent %d", T); return 1;
     }
     CG_LAUNCH_CHECK();
@@ -287,6 +484,8 @@ struct PrepArgs {
     double *emig_rows;
     unsigned *emig_rows_count;
     i64 emig_rows_cap;
+    // heavy tiles first (cgk_tile_order; list null: the plain walk)
+    TileOrder order;
 };
 
 // Write the 3*rl doubles of a run of rl consecutive records cooperatively (see cg_particles.hip
@@ -387,7 +586,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
 #ifdef CG_GK_TIMING
     unsigned long long gk_t[8] = {}, gk_last = __builtin_readcyclecounter();
 #endif
-    const unsigned tile = tile_for_block_grouped(blockIdx.x, ntiles, (unsigned)nt, (unsigned)nt);
+    unsigned tile;
+    unsigned place = ~0u;  // of the walk's tile on the list of heavy tiles
+    if (prep.order.list && blockIdx.x < prep.order.cap) {
+        if (blockIdx.x >= (unsigned)__builtin_amdgcn_readfirstlane((int)*prep.order.n)) return;
+        tile = (unsigned)__builtin_amdgcn_readfirstlane((int)prep.order.list[blockIdx.x]);
+    } else {
+        tile = tile_for_block_grouped(blockIdx.x - (prep.order.list ? prep.order.cap : 0u),
+                                      ntiles, (unsigned)nt, (unsigned)nt);
+        // (no wait here: the byte arrives with the tile's offsets)
+        if (prep.order.list) place = prep.order.rank[tile];
+    }
     // the tile's particles: dense tile order -> one range; regions with gaps (prep.count_in)
     // -> its 8 buckets' (start, population), walked as one flat index
     // (FUSED only: the plain kernel's LDS block is sized so that three workgroups fit a CU
@@ -436,7 +645,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         beg = 0;
         end = total;
     }
-    if (beg == end) return;  // uniform for the workgroup
+    // (uniform; a tile with a place among the blocks in front was theirs)
+    if (beg == end || (unsigned)__builtin_amdgcn_readfirstlane((int)place) < prep.order.cap) return;
     // FUSED: a workgroup is a chain of dependent round trips (stage the block, load a batch of
     // particles, gather, reserve places, store) and only two fit a CU: the particle loads of a
     // batch are issued one stage ahead — the first batch's under the staging of the block,
@@ -796,18 +1006,21 @@ static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsign
         attr_set[dev] = true;
     }
     unsigned nt = (unsigned)c->ntiles;
+    PrepArgs plain{};
+    plain.order = prep ? prep->order : tile_order_args(c);
+    const unsigned nblocks = nt + plain.order.cap;
     if (prep && prep->start_out)
-        hipLaunchKernelGGL(kern_fused, dim3(nt), dim3(512), lds, c->stream, pos, mom, tile_offset,
+        hipLaunchKernelGGL(kern_fused, dim3(nblocks), dim3(512), lds, c->stream, pos, mom, tile_offset,
                            c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap,
                            c->geom_gather, c1, c2, factor, *prep);
     else if (prep)
-        hipLaunchKernelGGL(kern_prep, dim3(nt), dim3(512), lds, c->stream, pos, mom, tile_offset,
+        hipLaunchKernelGGL(kern_prep, dim3(nblocks), dim3(512), lds, c->stream, pos, mom, tile_offset,
                            c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap,
                            c->geom_gather, c1, c2, factor, *prep);
     else
-        hipLaunchKernelGGL(kern, dim3(nt), dim3(512), lds, c->stream, pos, mom, tile_offset,
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds, c->stream, pos, mom, tile_offset,
                            c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap,
-                           c->geom_gather, c1, c2, factor, PrepArgs{});
+                           c->geom_gather, c1, c2, factor, plain);
     return 0;
 }
 
@@ -837,6 +1050,8 @@ int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
     }
     if (prepare && c->emig_idx)
         CG_HIP(hipMemsetAsync(c->emig_count, 0, sizeof(unsigned), c->stream));
+    if (cgk_tile_order(c, tile_offset, fs ? fs->count_in : nullptr)) return 1;
+    prep_args.order = tile_order_args(c);
     const PrepArgs *prep = (prepare || fs) ? &prep_args : nullptr;
     if (prepare)
         CG_HIP(hipMemsetAsync(c->tile_count, 0, 4 * (8 * c->ntiles + 1), c->stream));

@@ -61,6 +61,7 @@ SYMBOLS = {
     'cg_region_insert': (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     'cg_region_capacity': (_i64, [_vp, _i64]),
     'cg_predict_regions': (_int, [_vp, _vp, _vp, _vp]),
+    'cg_tile_order_read': (_int, [_vp, _vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     'cg_deposit_cic_regions': (_int, [_vp, _vp, _vp, _vp, _dbl, _int]),
     'cg_gather_kick_drift_scatter': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                             _int, _dbl, _dbl, _vp, _vp, _i64]),

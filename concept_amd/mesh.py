@@ -541,6 +541,15 @@ class PotentialMesh:
                                     _ptr(count_in) if count_in is not None else None,
                                     _ptr(start_out)))
 
+    def tile_order(self):
+        """cg_tile_order_read: the heavy tiles the tile kernels run first (numpy uint32, in
+        launch order), or None when they walk the tiles in the plain order"""
+        out = np.empty(self.ntiles, dtype=np.uint32)
+        nh = ctypes.c_int64(-1)
+        check(_L.cg_tile_order_read(self._ctx, out.ctypes.data_as(ctypes.c_void_p), out.size,
+                                    ctypes.byref(nh)))
+        return out[:nh.value].copy() if nh.value >= 0 else None
+
     def deposit_regions(self, pos, start, count, contribution, accumulate=False):
         check(_L.cg_deposit_cic_regions(self._ctx, _ptr(pos), _ptr(start), _ptr(count),
                                         float(contribution), int(accumulate)))

@@ -192,6 +192,19 @@ int cg_gather_kick_drift_scatter(cg_ctx *ctx, const double *pos_in, const double
                                  const int64_t *aux_in /*nullable*/, int64_t *aux_out,
                                  int64_t out_capacity /* rows of the output arrays: a region
                                  predicted beyond them counts as overflowed */);
+/* Launch order of the tile kernels (deposit, gather-kick, the fused pass).  A workgroup's time
+ * follows its tile's population; on a clustered box the plain walk (an eighth of the box per
+ * XCD) leaves the XCDs unequal loads and lets a tile of a hundred batches start late.
+ * cg_deposit_cic_tiled / _regions therefore list the heavy tiles (more than max(1536, 1.5 x
+ * mean) particles; at most an eighth of the tiles) of the populations they are given by falling
+ * population (in 61 classes); the tile kernels run those first, dealt out to the XCDs in turn,
+ * and the walk behind them skips them; the gather-kick of the same tables takes the list over.
+ * Results do not depend on it.  CONCEPT_GPU_TILE_ORDER=0 keeps the plain walk.
+ * cg_tile_order_read copies the present list to the host (at most `capacity` tiles) and
+ * reports its length; *n_heavy = -1 when no list is in use (switched off, or fewer than 4096
+ * tiles). */
+int cg_tile_order_read(cg_ctx *ctx, uint32_t *heavy_out /*HOST*/, int64_t capacity,
+                       int64_t *n_heavy /*HOST*/);
 /* (ids and aux: two 64-bit columns that travel with the particles — a Component's `ids` and
  * the row numbers its host() uses to restore the populated order) */
 

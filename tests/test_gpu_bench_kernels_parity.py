@@ -48,8 +48,22 @@ def _keys(torch, mesh, pos, N, g=2):
     return tile*8 + last[:, 0]*4 + last[:, 1]*2 + last[:, 2]*1
 
 
-@pytest.mark.parametrize('npart,N', [(128, 256), (256, 512)])
-def test_bench_sequence_two_steps_vs_oracle(npart, N):
+def _clustered(rng, n, L, nclumps=8, frac=0.8, sigma=1/10):
+    """bench.py --dist clustered in small: Gaussian clumps over a uniform background (as wide
+    in cells as the bench's: regions sized for the present populations + 25 % hold the next)"""
+    pos = rng.uniform(0, L, (n, 3))
+    centres = rng.uniform(0, L, (nclumps, 3))
+    in_clump = rng.uniform(size=n) < frac
+    blob = centres[rng.integers(0, nclumps, n)] + rng.normal(0, sigma*L, (n, 3))
+    pos[in_clump] = np.mod(blob[in_clump], L)
+    return np.minimum(pos, np.nextafter(L, 0))
+
+
+@pytest.mark.parametrize('npart,N,dist', [(128, 256, 'uniform'), (256, 512, 'uniform'),
+                                          (128, 256, 'clustered')])
+def test_bench_sequence_two_steps_vs_oracle(npart, N, dist):
+    """(the clustered box: 4096 tiles of 512 particles on average, several thousand in the
+    clumps' tiles — the tile kernels run in the order of cgk_tile_order, heavy tiles first)"""
     import torch
     from concept_amd.mesh import PotentialMesh
     from oracle import oracle
@@ -57,7 +71,7 @@ def test_bench_sequence_two_steps_vs_oracle(npart, N):
     mass, G, dt, order = 1.7, 0.9, 0.03, 2
     dtm, kick_factor = dt/mass, mass*(-dt)
     rng = np.random.default_rng(1000 + npart)
-    pos0 = rng.uniform(0, L, (n, 3))
+    pos0 = rng.uniform(0, L, (n, 3)) if dist == 'uniform' else _clustered(rng, n, L)
     # ~0.3 cells per drift: particles change bucket and tile, and wrap around the box
     mom0 = rng.normal(0, 0.3*(L/N)*mass/dt/3**0.5, (n, 3))
     mesh = PotentialMesh(N, L, nghosts=2)
@@ -134,6 +148,22 @@ def test_bench_sequence_two_steps_vs_oracle(npart, N):
         mesh.gather_kick_drift_scatter(pos, mom, ids, start, count, pos2, mom2, ids2, start_out,
                                        count_out, order, kick_factor, dtm)
         assert mesh.error_flags() == 0
+        heavy = mesh.tile_order()
+        if dist == 'clustered':
+            # the pass ran the heavy tiles of these populations first, by falling (class of)
+            # population: units of a third of the threshold, 63 at most
+            if count is None:
+                tab = start.cpu().numpy().astype(np.int64)
+                pops = tab[8::8] - tab[:-8:8]
+            else:
+                pops = count.cpu().numpy().astype(np.int64).reshape(-1, 8).sum(1)
+            thr = max(1536, 3*n//(2*mesh.ntiles))
+            want = np.flatnonzero(pops > thr)
+            assert 8 < want.size <= mesh.ntiles//8
+            assert np.array_equal(np.sort(heavy), want)
+            assert (np.diff(np.minimum(pops[heavy]//(thr//3), 63)) <= 0).all()
+        else:
+            assert heavy is not None and heavy.size == 0
         pos_prev = np.empty((n, 3))
         pos_prev[idin] = pin.cpu().numpy()
         del pin

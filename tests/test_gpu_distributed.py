@@ -123,6 +123,17 @@ def test_slab_domains_match_single_domain(world, N, p3m, n_side=20, steps=None):
     assert dx.max() <= 1e-13*64.0
 
 
+@pytest.mark.parametrize('world,N,mode', [(2, 64, 'regions'), (4, 128, 'regions'), (2, 64, False)])
+def test_slab_domains_with_the_tile_order(world, N, mode, monkeypatch):
+    """The same with the tile kernels walking their tiles in cgk_tile_order's order on boxes this
+    small too (CONCEPT_GPU_TILE_ORDER=2) and every tile above 1.5 times the mean population
+    counted as heavy: the slab deposit's ghost row behind the ordered tiles, the gather-kick and
+    the fused pass of every domain."""
+    monkeypatch.setenv('CONCEPT_GPU_TILE_ORDER', '2')
+    monkeypatch.setenv('CONCEPT_GPU_TILE_ORDER_MIN', '1')
+    test_slab_domains_match_single_domain(world, N, mode)
+
+
 def test_rccl_async_layer_exchange_and_pipelined_solve():
     """The production transport on the one GPU there is: a 1-rank RCCL group.  Checks that the
     asynchronous piecewise all_to_all (lists of views, work handles) is accepted by RCCL and
