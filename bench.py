@@ -296,7 +296,7 @@ def cpu_baseline_child(workload):
 # ---------------------------------------------------------------------------
 # synthetic particles
 # ---------------------------------------------------------------------------
-def make_positions(torch, args, n_p, N, L, dev, gen):
+def make_positions(torch, args, n_p, N, L, dev, gen, mesh=None):
     pos = torch.rand((n_p, 3), dtype=torch.float64, device=dev, generator=gen)
     if args.dist == 'uniform':
         pos.mul_(L)
@@ -311,6 +311,30 @@ def make_positions(torch, args, n_p, N, L, dev, gen):
         disp = torch.randn((n_p, 3), dtype=torch.float64, device=dev, generator=gen)*1.5*(L/N)
         pos = torch.remainder((lat + 0.5)*(L/side) + disp, L)
         del idx, lat, disp
+    elif args.dist == 'zeldovich':
+        # a cubic lattice displaced by a Gaussian random field with a k^-2
+        # spectrum, 3-D rms displacement 1.5 mesh cells — made with the build's own deposit, FFT
+        # and gather: the shot noise of n_p random points is white, its potential (one Poisson
+        # solve) has a k^-4 spectrum and the potential's gradient at the lattice sites, k^-2
+        if mesh is None:
+            raise SystemExit('--dist zeldovich: single-GPU runs only')
+        side = round(n_p**(1/3))
+        if side**3 < n_p:
+            side += 1
+        pos.mul_(L).clamp_(max=float(torch.nextafter(torch.tensor(L, dtype=torch.float64),
+                                                     torch.tensor(0.0, dtype=torch.float64))))
+        mesh.zero()
+        mesh.deposit(pos, 1.0)
+        mesh.poisson_solve(4, 1.0, False, 0.0)
+        idx = torch.arange(n_p, device=dev)
+        pos = torch.stack([idx//(side*side), (idx//side) % side, idx % side], 1).double()
+        pos.add_(0.5).mul_(L/side)
+        del idx
+        disp = torch.zeros_like(pos)
+        mesh.gather_kick(pos, disp, 2, 1.0)
+        disp.mul_(1.5*(L/N)/float(disp.square().sum(1).mean().sqrt()))
+        pos = torch.remainder(pos.add_(disp), L)
+        del disp
     else:  # clustered: 64 Gaussian blobs of sigma = L/40 holding 80 % of the particles
         centres = torch.rand((64, 3), dtype=torch.float64, device=dev, generator=gen)*L
         which = torch.randint(0, 64, (n_p,), device=dev, generator=gen)
@@ -379,7 +403,7 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
                                          pm_kick, pm_step_regions)
     dom = SlabDomain(N, L, device=dev)
     n_local = n_p//world
-    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    gen = torch.Generator(device=dev).manual_seed(args.seed + rank)
     pos = torch.rand((n_local, 3), dtype=torch.float64, device=dev, generator=gen)
     # uniform inside this rank's slab: lower CIC cell x in [x0, x0 + nxl)  <=>
     # x in [(x0 + 1/2) cells, (x0 + nxl + 1/2) cells), wrapped into the box
@@ -648,7 +672,9 @@ def main():
                          'peer) / rate (default: one xGMI link, one way) — the pipelining '
                          'schedule and its overlap measured without a second GPU; results are '
                          'not meaningful')
-    ap.add_argument('--dist', default='uniform', choices=['uniform', 'lattice', 'clustered'],
+    ap.add_argument('--seed', type=int, default=1,
+                    help='seed of the synthetic particles (SURVEY.md §8d: 1, 2, 3)')
+    ap.add_argument('--dist', default='uniform', choices=['uniform', 'lattice', 'clustered', 'zeldovich'],
                     help="particle distribution (SURVEY.md §8d): uniform random (U), displaced "
                          "lattice (Z: rms displacement 1.5 cells), or Gaussian blobs")
     ap.add_argument('--thermal', type=float, default=0.2,
@@ -732,8 +758,9 @@ def main():
                                                 or args.split_poisson):
         # The other configurations under the same clock: after the timed
         # north-star region, 20 steps each of BASELINE configs[1] as a PM and as a P3M step and
-        # of the north-star size on the clustered and the displaced-lattice
-        # distributions.  The headline fields above are untouched.
+        # of the north-star size on the clustered, the displaced-lattice and the Zel'dovich-like
+        #  distributions and with the seeds 2 and 3.  The headline fields
+        # above are untouched.
         import copy
         result['configs'] = {}
         for cname, over in (('c2_256c_512_pm', dict(workload='c2_256c_512')),
@@ -741,7 +768,10 @@ def main():
                             ('c2_256c_512_p3m_clustered', dict(workload='c2_256c_512', p3m=True,
                                                                dist='clustered')),
                             ('ns_256M_1024_clustered', dict(dist='clustered')),
-                            ('ns_256M_1024_lattice', dict(dist='lattice'))):
+                            ('ns_256M_1024_lattice', dict(dist='lattice')),
+                            ('ns_256M_1024_zeldovich', dict(dist='zeldovich')),
+                            ('ns_256M_1024_seed2', dict(seed=2)),
+                            ('ns_256M_1024_seed3', dict(seed=3))):
             a2 = copy.copy(args)
             a2.steps, a2.warmup = 20, 3
             for k, v in over.items():
@@ -775,8 +805,8 @@ def run_single(args, torch, dev, rank=0):
     n_p, N = WORKLOADS[name]
     L = float(N)  # boxsize in grid units (synthetic)
     mesh = PotentialMesh(N, L, nghosts=2)
-    gen = torch.Generator(device=dev).manual_seed(1 + rank)
-    pos = make_positions(torch, args, n_p, N, L, dev, gen)
+    gen = torch.Generator(device=dev).manual_seed(args.seed + rank)
+    pos = make_positions(torch, args, n_p, N, L, dev, gen, mesh)
     # step scalars: fixed (enable_Hubble=False semantics)
     mass = 1.0
     G = 1.0
@@ -982,7 +1012,7 @@ def run_single(args, torch, dev, rank=0):
         'ms_per_step': ms_per_step, 'timed_region_s': round(elapsed, 4),
         'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': f'{name}: {n_p} particles ({args.dist}, seed 1, thermal rms '
+        'config': {'workload': f'{name}: {n_p} particles ({args.dist}, seed {args.seed}, thermal rms '
                                f'displacement {args.thermal} cells/step) / {N}^3 PM mesh, CIC, '
                                f'deconvolution order 4, FD order {4 if sr else 2}, 1 '
                                + ('P3M step = drift + tile sort + long-range kick + short-range '

@@ -922,6 +922,14 @@ __global__ __launch_bounds__(256) void k_sr_tile_activity(const unsigned *__rest
 // order, gravity.py:299-302; + 0.0 for the others changes nothing), so a receiver's five
 // columns stay ONE range there too.  (Walking such tiles piece by piece — 10 short ranges per x
 // with a wave-uniform offset each — made these 6 % of the tiles 16 % of the sweep.)
+// CG_SR_XCDWALK=1 (A/B, off): the interior as a 1-D grid in which every XCD walks its own
+// contiguous eighth of the tiles, so that the supplier columns a tile stages were staged into
+// the same L2 just before.  Measured at 256^3 / 512^3 (tools/sr_dense_time.py, twice each):
+// 8.17 against 8.08 ms uniform, 46.6 against 46.5 ms clustered — the staging of the sparse
+// tiles does not wait for the L2 it misses; the 3-D grid stays.
+#ifndef CG_SR_XCDWALK
+#define CG_SR_XCDWALK 0
+#endif
 template <bool FACE, bool PRE32, bool RUNGS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CG_SR_WAVES, 8))) void
 k_sr_sweep_cells(
@@ -947,6 +955,15 @@ k_sr_sweep_cells(
     // slabs — slab 0: ta on a face, 1: tb on a face (ta inside), 2: tc on a face (ta, tb inside).
     int ta = blockIdx.z, tb = blockIdx.y, tc = blockIdx.x;
     if (!FACE) {
+#if CG_SR_XCDWALK
+        // the interior as a 1-D grid: block b runs on XCD b % 8, and every XCD walks its own
+        // contiguous eighth of the tiles (z fastest), so that the supplier columns a tile
+        // stages were staged into the same L2 by the tiles just before it (`slab`: nt - 2)
+        const unsigned m = (unsigned)slab, total = m * m * m, per = (total + 7u) / 8u;
+        const unsigned lin = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
+        if (lin >= total || blockIdx.x / 8u >= per) return;
+        tc = (int)(lin % m), tb = (int)((lin / m) % m), ta = (int)(lin / (m * m));
+#endif
         ta++, tb++, tc++;
     } else if (slab == 0) {
         ta = ta ? nt - 1 : 0;
@@ -1324,8 +1341,13 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
         CG_LAUNCH_CHECK();
         CG_HIP(hipEventRecord(c->sr_join[slab], c->sr_streams[slab]));
     }
+#if CG_SR_XCDWALK
+    hipLaunchKernelGGL(inner, dim3(8u * ((m * m * m + 7u) / 8u)), dim3(256), 0, c->stream,
+                       pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P, (int)m);
+#else
     hipLaunchKernelGGL(inner, dim3(m, m, m), dim3(256), 0, c->stream, pos_r_sorted, order_r, off_r,
                        dmom_r, pos_s_sorted, off_s, table, P, 0);
+#endif
     CG_LAUNCH_CHECK();
     for (int slab = 0; slab < 3; slab++) CG_HIP(hipStreamWaitEvent(c->stream, c->sr_join[slab], 0));
     if (take && cgk_shortrange_dense_join(c)) return 1;

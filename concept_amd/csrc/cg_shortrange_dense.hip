@@ -261,6 +261,9 @@ __device__ __forceinline__ void srd_look(const SrdShared &S, unsigned long long 
     }
 }
 
+#ifndef SRD_XCD_GRANULE
+#define SRD_XCD_GRANULE 16
+#endif
 __global__ __launch_bounds__(64 * kdWaves)
 __attribute__((amdgpu_waves_per_eu(SRD_WAVES_PER_EU, 8))) void k_sr_sweep_dense(
     const double *__restrict__ pos_r, const unsigned *__restrict__ order_rt,
@@ -274,8 +277,20 @@ __attribute__((amdgpu_waves_per_eu(SRD_WAVES_PER_EU, 8))) void k_sr_sweep_dense(
     const int j = lane & 15, g = lane >> 4;
     const int nt = P.nt;
     const unsigned count = *nitems;
+#if SRD_XCD_GRANULE
+    // Block b runs on XCD b % 8.  The items of a tile follow each other on the list and stage the
+    // same 27 tiles: granules of SRD_XCD_GRANULE consecutive items go to one XCD (one L2), the
+    // granules to the XCDs in turn.
+    constexpr unsigned G = SRD_XCD_GRANULE;
+    const unsigned vmax = (count + 8u * G - 1u) / (8u * G) * (8u * G);
+    for (unsigned v = blockIdx.x; v < vmax; v += gridDim.x) {
+    if (v != blockIdx.x) __syncthreads();  // the previous item's tables and rows are done with
+    const unsigned it = ((v / 8u / G) * 8u + v % 8u) * G + (v / 8u) % G;
+    if (it >= count) continue;
+#else
     for (unsigned it = blockIdx.x; it < count; it += gridDim.x) {
     if (it != blockIdx.x) __syncthreads();  // the previous item's tables and rows are done with
+#endif
     const unsigned long long item = items[it];
     const unsigned t = (unsigned)(item >> 32), chunk = (unsigned)item;
     const int tc = (int)(t % (unsigned)nt), tb = (int)((t / (unsigned)nt) % (unsigned)nt),
@@ -579,7 +594,7 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
                 rung_jumped, (int)nt};
     // (as many workgroups as there can be items — counted on all the particles, an upper bound
     // for a subset; the ones past the count leave at once)
-    const unsigned grid = (unsigned)(ndense / kdChunk + tdense);
+    const unsigned grid = (unsigned)(ndense / kdChunk + tdense) + 8u * SRD_XCD_GRANULE;
     hipLaunchKernelGGL(k_sr_sweep_dense, dim3(grid), dim3(64 * kdWaves), 0, c->srd_stream, posr,
                        ordr, order_r, offr, dmom_r, poss, offs, items, dev + 2, table, P);
     CG_LAUNCH_CHECK();

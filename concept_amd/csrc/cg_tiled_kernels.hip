@@ -70,9 +70,9 @@ __device__ __forceinline__ unsigned tile_for_block(unsigned b, unsigned ntiles) 
 // XCD = (gb + 3 ga) mod 8, instead of a contiguous eighth of the box (a slab of a-layers) per
 // XCD, so that a clump of a clustered box is shared by several XCDs.  Measured on the clustered
 // bench box (64 clumps, 80 % of the particles): 11.32 against 11.25 ms, uniform 8.56 against
-// 8.52 — no gain: the clustered pass is not slower because XCDs are unevenly loaded but because
-// its 260,000 nearly empty tiles still stage their block while the heavy ones run at the
-// uniform rate per particle (tools/fused_probe.py PROBE_CLUSTERED / PROBE_SUBBOX, CG_GK_TIMING).
+// 8.52 — no gain, from which rounds 2-3 concluded that the XCDs' loads were not the matter.
+// They were (together with heavy tiles that start late): see cgk_tile_order below, which
+// orders the launch by population instead of by place.
 #ifndef CG_TILE_INTERLEAVE
 #define CG_TILE_INTERLEAVE 0
 #endif
