@@ -3,7 +3,7 @@
 # profiles/ afterwards):  tools/record_profiles.sh r04 <commit>
 # One-liners a driver can reproduce are listed in profiles/README.md.
 set -u
-TAG=${1:-r04}; COMMIT=${2:-unknown}
+TAG=${1:-r04}; COMMIT=${2:-unknown}; MODE=${3:-full}   # quick: kernel statistics, HBM traffic and the default line only
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_new; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -20,6 +20,10 @@ python $R/tools/rocprof_summary.py --pmc $OUT/pmc_w > $OUT/${TAG}_pmc_WRITE_SIZE
 python $R/tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w $OUT/${TAG}_pmc_hbm_traffic.json ns_256M_1024 $COMMIT "python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs" > $OUT/pmc_traffic.log 2>&1
 cp $OUT/${TAG}_pmc_hbm_traffic.json $R/profiles/${TAG}_pmc_hbm_traffic.json   # (so that the lines below quote it)
 # 3. P3M: statistics and SQ counters of the sweep
+if [ "$MODE" = quick ]; then
+  (cd $R && python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_ns_full_default.json)
+  rm -rf $OUT/stats $OUT/pmc_f $OUT/pmc_w; ls -la $OUT; exit 0
+fi
 P3M="python $R/bench.py --workload c2_256c_512 --p3m --steps 5 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT/stats_p3m -- $P3M > $OUT/stats_p3m.log 2>&1
 python $R/tools/rocprof_summary.py $OUT/stats_p3m $OUT/${TAG}_rocprof_kernel_stats_p3m.txt > /dev/null
@@ -53,5 +57,7 @@ python tools/variant.py tools/_variants/srd_nocull.so cg_shortrange_dense.hip -D
 for v in "" tools/_variants/srd_nopairs.so tools/_variants/srd_nocull.so; do CONCEPT_GPU_LIB=$v python tools/sr_dense_time.py clustered; done 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_sr_dense_phases.txt
 CONCEPT_GPU_SR_DENSE=0 python tools/sr_dense_time.py clustered 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_sr_dense_phases.txt
 ./tools/mall_probe > $OUT/${TAG}_mall_probe.txt 2>&1
+# heavy tiles first (cgk_tile_order) against the plain walk, one process
+python tools/fused_order_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_tile_order_ab.txt
 rm -rf $OUT/stats $OUT/pmc_f $OUT/pmc_w $OUT/stats_p3m $OUT/pmc_sr
 ls -la $OUT
