@@ -140,12 +140,16 @@ constexpr int ORD_B = 256;       // lanes per workgroup of the order kernels
 constexpr int ORD_CLASSES = 64;  // counters: [0] particles, [1] tiles on the list, [2..65] tiles
                                  // per class, [66..129] cursor per class
 __global__ void k_order_pops(const unsigned *__restrict__ start, const unsigned *__restrict__ count,
-                             unsigned ntiles, unsigned *__restrict__ pops,
+                             unsigned ntiles, bool vec, unsigned *__restrict__ pops,
                              unsigned *__restrict__ counters) {
     const unsigned tile = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned pop = 0;
     if (tile < ntiles) {
-        if (count) {
+        if (count && vec) {  // (a table at a 16-byte boundary: two loads instead of eight)
+            const uint4 lo = *(const uint4 *)(count + 8 * (size_t)tile),
+                        hi = *(const uint4 *)(count + 8 * (size_t)tile + 4);
+            pop = ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+        } else if (count) {
 #pragma unroll
             for (int f = 0; f < 8; f++) pop += count[8 * (size_t)tile + f];
         } else {
@@ -247,7 +251,7 @@ int cgk_tile_order(cg_ctx *c, const unsigned *start, const unsigned *count) {
     CG_HIP(hipHostGetDevicePointer((void **)&seen_dev, c->tile_order_seen, 0));
     CG_HIP(hipMemsetAsync(counters, 0, sizeof(unsigned) * ncounters, c->stream));
     hipLaunchKernelGGL(k_order_pops, dim3(nblk), dim3(ORD_B), 0, c->stream, start, count, ntiles,
-                       pops, counters);
+                       ((uintptr_t)count & 15u) == 0, pops, counters);
     hipLaunchKernelGGL(k_order_classes, dim3(nblk), dim3(ORD_B), 0, c->stream, pops, ntiles,
                        c->tile_order_floor, counters);
     hipLaunchKernelGGL(k_order_place, dim3(nblk), dim3(ORD_B), 0, c->stream, pops, ntiles, cap,
@@ -690,6 +694,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         }
     };
 #ifdef CG_GK_PREFETCH
+    // (off.  Round 4 also tried the first batch's POSITIONS alone under the staging — from regions
+    // with gaps the lanes of bucket 0, whose start and population are scalar loads, so that no
+    // table has to be waited for: 4 spilled registers at the 80 that three workgroups per CU
+    // allow, 9.4 against 8.4 ms)
     if (gapped) __syncthreads();  // (the fetch reads the segment table)
     if (FUSED) fetch(beg);
 #endif
