@@ -139,7 +139,7 @@ __device__ __forceinline__ unsigned tile_for_block_grouped(unsigned b, unsigned 
 constexpr int ORD_B = 256;       // lanes per workgroup of the order kernels
 constexpr int ORD_CLASSES = 64;  // counters: [0] particles, [1] tiles on the list, [2..65] tiles
                                  // per class, [66..129] cursor per class
-__global__ void k_order_pops(const unsigned *__restrict__ start, const unsigned *__restrict__ count,
+__global__ __launch_bounds__(1024) void k_order_pops(const unsigned *__restrict__ start, const unsigned *__restrict__ count,
                              unsigned ntiles, bool vec, unsigned *__restrict__ pops,
                              unsigned *__restrict__ counters) {
     const unsigned tile = blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,10 +157,18 @@ __global__ void k_order_pops(const unsigned *__restrict__ start, const unsigned 
         }
         pops[tile] = pop;
     }
-    // (sum over the wave, one atomic per wave)
+    // (sum over the workgroup, one device atomic each: they execute memory-side one after the
+    // other — one per wave, 4096 of them on one word, was 45 of this kernel's 49 us)
+    __shared__ unsigned wsum[16];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) pop += __shfl_down(pop, o);
-    if ((threadIdx.x & 63) == 0 && pop) atomicAdd(&counters[0], pop);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = pop;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned sum = 0;
+        for (unsigned i = 0; i < blockDim.x / 64; i++) sum += wsum[i];
+        if (sum) atomicAdd(&counters[0], sum);
+    }
 }
 // class of population into pops[] (0: not heavy), heavy tiles per class
 __global__ __launch_bounds__(ORD_B) void k_order_classes(unsigned *__restrict__ pops,
@@ -207,12 +215,23 @@ __global__ __launch_bounds__(ORD_B) void k_order_place(const unsigned *__restric
         if (blockIdx.x == 0 && threadIdx.x == 0) *host_n = counters[1] = incl < cap ? incl : cap;
     }
     __syncthreads();
+    // places inside a class: counted per workgroup in LDS, one device atomic per workgroup and
+    // class it holds (device atomics run memory-side, one after the other)
+    __shared__ unsigned mine[ORD_CLASSES], first[ORD_CLASSES];
+    if (threadIdx.x < ORD_CLASSES) mine[threadIdx.x] = 0;
+    __syncthreads();
     const unsigned t = blockIdx.x * ORD_B + threadIdx.x;
+    const unsigned cls = t < ntiles ? cls_of[t] : 0u;
+    unsigned local = 0;
+    if (cls) local = atomicAdd(&mine[cls], 1u);
+    __syncthreads();
+    if (threadIdx.x < ORD_CLASSES && mine[threadIdx.x])
+        first[threadIdx.x] = atomicAdd(&counters[2 + ORD_CLASSES + threadIdx.x], mine[threadIdx.x]);
+    __syncthreads();
     if (t >= ntiles) return;
-    const unsigned cls = cls_of[t];
     unsigned k = ~0u;
     if (cls) {
-        k = base[cls] + atomicAdd(&counters[2 + ORD_CLASSES + cls], 1u);
+        k = base[cls] + first[cls] + local;
         if (k < cap) heavy[k] = t;
         else k = ~0u;  // (a list that is full leaves the tile to the walk)
     }
@@ -250,7 +269,7 @@ int cgk_tile_order(cg_ctx *c, const unsigned *start, const unsigned *count) {
     unsigned *rank = counters + ncounters, *seen_dev = nullptr;
     CG_HIP(hipHostGetDevicePointer((void **)&seen_dev, c->tile_order_seen, 0));
     CG_HIP(hipMemsetAsync(counters, 0, sizeof(unsigned) * ncounters, c->stream));
-    hipLaunchKernelGGL(k_order_pops, dim3(nblk), dim3(ORD_B), 0, c->stream, start, count, ntiles,
+    hipLaunchKernelGGL(k_order_pops, dim3((ntiles + 1023u) / 1024u), dim3(1024), 0, c->stream, start, count, ntiles,
                        ((uintptr_t)count & 15u) == 0, pops, counters);
     hipLaunchKernelGGL(k_order_classes, dim3(nblk), dim3(ORD_B), 0, c->stream, pops, ntiles,
                        c->tile_order_floor, counters);
