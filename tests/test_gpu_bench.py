@@ -34,7 +34,8 @@ def run(*flags, env=None):
 
 @pytest.mark.parametrize('flags', [
     (), ('--no-fused',), ('--no-sort',), ('--no-prepare',), ('--split-poisson',),
-    ('--dist', 'lattice'), ('--dist', 'clustered'), ('--thermal', '0'), ('--p3m',),
+    ('--dist', 'lattice'), ('--dist', 'clustered'), ('--dist', 'zeldovich', '--seed', '2'),
+    ('--thermal', '0'), ('--p3m',),
     ('--p3m', '--sr-tiles'), ('--p3m', '--dist', 'clustered')])
 def test_bench_flags(flags):
     d = run('--no-cpu-baseline', *flags)

@@ -228,7 +228,107 @@ __global__ __launch_bounds__(LANES) void k_handover(d2 *mesh, unsigned nx, d2 *s
     }
 }
 
+// ---------------------------------------------------------------------------
+// Second question (argv[1] = "column"): a hand-over between NEIGHBOURING kernels.  The deposit
+// writes the mesh tile by tile (16^3 doubles: 256 segments of 128 bytes), the forward z pass reads
+// and rewrites it row by row (1024 doubles).  A column of 64 tiles along z is 256 such rows = 2 MB:
+// if the 32 workgroups of an XCD write a column's tiles and transform its rows right away, the rows
+// are read from the L2 they were just written to and overwritten there — one write-back per line
+// instead of write, read, write.
+//   D  tile stores over the whole mesh (a workgroup per tile, the tiles of an XCD's eighth in order)
+//   A  rows in place (k_rows above, on the same 8.6 GB)
+//   F  fused: XCD g owns the columns (ta in [8g, 8g+8), tb); member w stores tiles tc = 2w, 2w+1,
+//      barrier, then reads (sc1), negates and stores rows 8w .. 8w+7 of the column
+// ---------------------------------------------------------------------------
+constexpr int MT = 16, MN = 1024, MNT = MN / MT;   // tile edge, mesh edge (doubles), tiles per edge
+__device__ __forceinline__ double rpattern(unsigned a, unsigned b, unsigned c) {
+    return (double)(a * 1024u + b) + (double)c / 2048.0;
+}
+__device__ __forceinline__ void store_tile(double *mesh, unsigned ta, unsigned tb, unsigned tc, unsigned t, unsigned nthreads) {
+    // 16 x 16 segments of 16 doubles = 2048 d2; thread -> d2 number i: segment i / 8, pair i % 8
+    for (unsigned i = t; i < 2048u; i += nthreads) {
+        const unsigned seg = i / 8u, pair = i % 8u, a = MT * ta + seg / MT, b = MT * tb + seg % MT,
+                       c = MT * tc + 2u * pair;
+        d2 v;
+        v.x = rpattern(a, b, c);
+        v.y = rpattern(a, b, c + 1u);
+        *(d2 *)(mesh + ((size_t)a * MN + b) * MN + c) = v;
+    }
+}
+__global__ __launch_bounds__(512) void k_tiles(double *mesh) {
+    const unsigned ntiles = MNT * MNT * MNT, b = blockIdx.x, tile = (b % 8u) * (ntiles / 8u) + b / 8u;
+    store_tile(mesh, tile / (MNT * MNT), (tile / MNT) % MNT, tile % MNT, threadIdx.x, 512u);
+}
+__global__ void k_check_neg(const double *mesh, unsigned long long *bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned c = i % MN, b = (i / MN) % MN, a = (unsigned)(i / ((size_t)MN * MN));
+    if (mesh[i] != -rpattern(a, b, c)) atomicAdd(bad, 1ull);
+}
+__global__ __launch_bounds__(LANES) void k_column(double *mesh, unsigned *flags, unsigned *abort_flag) {
+    extern __shared__ char force_one_per_cu[];
+    const unsigned g = blockIdx.x % GROUPS, w = blockIdx.x / GROUPS;
+    unsigned epoch = 0;
+    for (unsigned col = 0; col < 8u * MNT; col++) {
+        const unsigned ta = 8u * g + col / MNT, tb = col % MNT;
+        store_tile(mesh, ta, tb, 2u * w, threadIdx.x, LANES);
+        store_tile(mesh, ta, tb, 2u * w + 1u, threadIdx.x, LANES);
+        epoch++;
+        if (!group_barrier_flags(flags + 16 * WG_PER_GROUP * g, w, epoch, abort_flag)) return;
+        // rows 8w .. 8w+7 of the column's 256 (row r: a = 16 ta + r / 16, b = 16 tb + r % 16)
+        d2 u[4];
+        const d2 *rows[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned i = threadIdx.x + LANES * j, r = 8u * w + i / 512u, a = MT * ta + r / MT,
+                           b = MT * tb + r % MT;
+            rows[j] = (const d2 *)(mesh + ((size_t)a * MN + b) * MN) + i % 512u;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(u[j]) : "v"(rows[j]) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; j++) *(d2 *)rows[j] = -u[j];
+    }
+}
+int main_column() {
+    double *mesh; unsigned *flags, *abort_flag; unsigned long long *bad;
+    const size_t n = (size_t)MN * MN * MN;
+    CK(hipMalloc(&mesh, n * 8)); CK(hipMalloc(&flags, 16 * WG_PER_GROUP * GROUPS * 4)); CK(hipMalloc(&abort_flag, 4));
+    CK(hipMalloc(&bad, 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int lds = 96 * 1024;
+    CK(hipFuncSetAttribute((const void *)k_column, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    { const int one = 1; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_no_inv), &one, 4)); }
+    float ms_d, ms_a, ms;
+    const double gb = n * 8 / 1e9;
+    for (int rep = 0; rep < 3; rep++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_tiles, dim3(MNT * MNT * MNT), dim3(512), 0, 0, mesh);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_d, e0, e1));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_rows, dim3(MN * (NY / 32)), dim3(LANES), 0, 0, (d2 *)mesh);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_a, e0, e1));
+        printf("D tile stores %.3f ms (%.2f TB/s written)   A rows in place %.3f ms   D + A %.3f ms\n", ms_d,
+               gb / ms_d, ms_a, ms_d + ms_a);
+    }
+    for (int rep = 0; rep < 4; rep++) {
+        CK(hipMemset(flags, 0, 16 * WG_PER_GROUP * GROUPS * 4)); CK(hipMemset(abort_flag, 0, 4));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_column, dim3(GROUPS * WG_PER_GROUP), dim3(LANES), lds, 0, mesh, flags, abort_flag);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned ab; CK(hipMemcpy(&ab, abort_flag, 4, hipMemcpyDeviceToHost));
+        printf("F column of tiles written and its rows rewritten by the same XCD: %.3f ms%s\n", ms,
+               ab ? "  ABORTED (a barrier timed out)" : "");
+        if (ab) break;
+    }
+    CK(hipMemset(bad, 0, 8));
+    hipLaunchKernelGGL(k_check_neg, dim3((unsigned)(n / 256)), dim3(256), 0, 0, mesh, bad);
+    unsigned long long nbad; CK(hipMemcpy(&nbad, bad, 8, hipMemcpyDeviceToHost));
+    printf("values that are not the negated pattern: %llu of %zu\n", nbad, n);
+    return nbad != 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && argv[1][0] == 'c') return main_column();
     const unsigned nx = argc > 1 ? (unsigned)atoi(argv[1]) : 1024;
     const int rounds = argc > 2 ? atoi(argv[2]) : 4;
     const int l2mode = argc > 3 ? atoi(argv[3]) : 1;   // 0: L1 invalidate after the barrier, plain accesses
