@@ -16,7 +16,12 @@
 //      it to the layer in the y pass's pattern.  HBM sees the layer once each way; the window
 //      traffic should stay in L2.
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/xcd_handover_probe tools/xcd_handover_probe.cpp
-// run:   tools/xcd_handover_probe [layers=1024] [rounds=4]
+// run:   tools/xcd_handover_probe [layers=1024] [rounds=4] [mode: 1 = window read with sc1 loads,
+//        2 = the CU's L1 invalidated by one wave (buffer_inv sc0) + plain loads, 0 = buffer_inv sc1]
+//        tools/xcd_handover_probe column [mode]     (the second question, further down)
+// Measured (MI355X, round 4; profiles/r04_xcd_handover_probe.txt, tools/pmc_handover.sh): A + B 7.0 ms,
+// C 5.5-6.0 ms with every value in place, but two passes' WRITE_SIZE in every variant and two
+// passes' FETCH_SIZE unless the window is <= 1 MB per XCD: the window does not stay in the L2.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +34,7 @@ constexpr size_t LAYER = (size_t)NY * NZ;       // complex values per layer (8 M
 constexpr int GROUPS = 8, WG_PER_GROUP = 32, LANES = 1024, PER = 16;
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 __device__ int g_l2mode = 0;   // C: window loads that bypass the L1 (sc1) instead of an invalidate, layer traffic non-temporal
+__device__ int g_inv_sc0 = 0;   // the invalidate after a barrier at workgroup scope (the CU's L1 only) instead of agent scope
 __device__ int g_no_inv = 0, g_no_sleep = 0;   // parts of the barrier switched off (timing only)
 
 __device__ __forceinline__ d2 pattern(unsigned x, unsigned y, unsigned kz) {
@@ -92,7 +98,10 @@ __device__ __forceinline__ bool group_barrier(unsigned *counter, unsigned target
     }
     // what the others wrote is read from the L2: the CU's L1 is invalidated ONCE, by the first
     // wave, before the others go on (every wave doing it: 30 us per barrier instead of ~2)
-    if (threadIdx.x < 64 && !g_no_inv) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x < 64 && !g_no_inv) {
+        if (g_inv_sc0) asm volatile("buffer_inv sc0\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     return ok != 0;
 }
@@ -118,7 +127,10 @@ __device__ __forceinline__ bool group_barrier_flags(unsigned *flags, unsigned w,
             if (!good) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok2 = good;
         }
-        if (!g_no_inv) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        if (!g_no_inv) {
+            if (g_inv_sc0) asm volatile("buffer_inv sc0\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     __syncthreads();
     return ok2 != 0;
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(LANES) void k_handover(d2 *mesh, unsigned nx, d2 *s
                 const unsigned kb = h / 2, half = h % 2;
                 const d2 *src = buf + (kb * NY + 512 * half) * 8;
                 d2 u[4];
-                if (g_l2mode) {
+                if (g_l2mode == 1) {
                     // past the L1, from the L2 the other members' stores went to
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
@@ -238,16 +250,25 @@ __global__ __launch_bounds__(LANES) void k_handover(d2 *mesh, unsigned nx, d2 *s
 //   D  tile stores over the whole mesh (a workgroup per tile, the tiles of an XCD's eighth in order)
 //   A  rows in place (k_rows above, on the same 8.6 GB)
 //   F  fused: XCD g owns the columns (ta in [8g, 8g+8), tb); member w stores tiles tc = 2w, 2w+1,
-//      barrier, then reads (sc1), negates and stores rows 8w .. 8w+7 of the column
+//      barrier, then reads, negates and stores rows 8w .. 8w+7 of the column
+// Measured: D + A 4.7 ms; F 4.6 / 5.0 / 5.5 ms with columns of 2 MB / 1 MB / 512 KB (-DCOL_A=16, 8, 4).
+// WRITE_SIZE of F: 1.74 / 1.01 / 1.00 passes (the tiles' write-back is saved when the column
+// fits), FETCH_SIZE: one full pass in all three — a row that is read is fetched from the fabric
+// although its line was stored into the same L2 just before.  (Mode 1 — sc1 loads without any
+// invalidate — once returned 24 % stale rows here: use mode 2.)
 // ---------------------------------------------------------------------------
+#ifndef COL_A
+#define COL_A 16   // x extent of a tile (-DCOL_A=8, 4: columns of 1 MB, 512 KB instead of 2 MB)
+#endif
 constexpr int MT = 16, MN = 1024, MNT = MN / MT;   // tile edge, mesh edge (doubles), tiles per edge
+constexpr int MTA = COL_A, MNTA = MN / MTA;
 __device__ __forceinline__ double rpattern(unsigned a, unsigned b, unsigned c) {
     return (double)(a * 1024u + b) + (double)c / 2048.0;
 }
 __device__ __forceinline__ void store_tile(double *mesh, unsigned ta, unsigned tb, unsigned tc, unsigned t, unsigned nthreads) {
     // 16 x 16 segments of 16 doubles = 2048 d2; thread -> d2 number i: segment i / 8, pair i % 8
-    for (unsigned i = t; i < 2048u; i += nthreads) {
-        const unsigned seg = i / 8u, pair = i % 8u, a = MT * ta + seg / MT, b = MT * tb + seg % MT,
+    for (unsigned i = t; i < 128u * MTA; i += nthreads) {
+        const unsigned seg = i / 8u, pair = i % 8u, a = MTA * ta + seg / MT, b = MT * tb + seg % MT,
                        c = MT * tc + 2u * pair;
         d2 v;
         v.x = rpattern(a, b, c);
@@ -256,7 +277,7 @@ __device__ __forceinline__ void store_tile(double *mesh, unsigned ta, unsigned t
     }
 }
 __global__ __launch_bounds__(512) void k_tiles(double *mesh) {
-    const unsigned ntiles = MNT * MNT * MNT, b = blockIdx.x, tile = (b % 8u) * (ntiles / 8u) + b / 8u;
+    const unsigned ntiles = MNTA * MNT * MNT, b = blockIdx.x, tile = (b % 8u) * (ntiles / 8u) + b / 8u;
     store_tile(mesh, tile / (MNT * MNT), (tile / MNT) % MNT, tile % MNT, threadIdx.x, 512u);
 }
 __global__ void k_check_neg(const double *mesh, unsigned long long *bad) {
@@ -264,32 +285,34 @@ __global__ void k_check_neg(const double *mesh, unsigned long long *bad) {
     unsigned c = i % MN, b = (i / MN) % MN, a = (unsigned)(i / ((size_t)MN * MN));
     if (mesh[i] != -rpattern(a, b, c)) atomicAdd(bad, 1ull);
 }
-__global__ __launch_bounds__(LANES) void k_column(double *mesh, unsigned *flags, unsigned *abort_flag) {
+__global__ __launch_bounds__(LANES) void k_column(double *mesh, unsigned *flags, unsigned *abort_flag, int mode) {
     extern __shared__ char force_one_per_cu[];
     const unsigned g = blockIdx.x % GROUPS, w = blockIdx.x / GROUPS;
     unsigned epoch = 0;
-    for (unsigned col = 0; col < 8u * MNT; col++) {
-        const unsigned ta = 8u * g + col / MNT, tb = col % MNT;
+    for (unsigned col = 0; col < (MNTA / 8u) * MNT; col++) {
+        const unsigned ta = (MNTA / 8u) * g + col / MNT, tb = col % MNT;
         store_tile(mesh, ta, tb, 2u * w, threadIdx.x, LANES);
         store_tile(mesh, ta, tb, 2u * w + 1u, threadIdx.x, LANES);
         epoch++;
         if (!group_barrier_flags(flags + 16 * WG_PER_GROUP * g, w, epoch, abort_flag)) return;
         // rows 8w .. 8w+7 of the column's 256 (row r: a = 16 ta + r / 16, b = 16 tb + r % 16)
-        d2 u[4];
-        const d2 *rows[4];
+        constexpr int NJ = MTA / 4;   // rows per member: MTA * 16 / 32, of 512 d2 each
+        d2 u[NJ];
+        const d2 *rows[NJ];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const unsigned i = threadIdx.x + LANES * j, r = 8u * w + i / 512u, a = MT * ta + r / MT,
+        for (int j = 0; j < NJ; j++) {
+            const unsigned i = threadIdx.x + LANES * j, r = (MTA / 2u) * w + i / 512u, a = MTA * ta + r / MT,
                            b = MT * tb + r % MT;
             rows[j] = (const d2 *)(mesh + ((size_t)a * MN + b) * MN) + i % 512u;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(u[j]) : "v"(rows[j]) : "memory");
+            if (mode == 1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(u[j]) : "v"(rows[j]) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(u[j]) : "v"(rows[j]) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < 4; j++) *(d2 *)rows[j] = -u[j];
+        for (int j = 0; j < NJ; j++) *(d2 *)rows[j] = -u[j];
     }
 }
-int main_column() {
+int main_column(int mode) {
     double *mesh; unsigned *flags, *abort_flag; unsigned long long *bad;
     const size_t n = (size_t)MN * MN * MN;
     CK(hipMalloc(&mesh, n * 8)); CK(hipMalloc(&flags, 16 * WG_PER_GROUP * GROUPS * 4)); CK(hipMalloc(&abort_flag, 4));
@@ -297,12 +320,14 @@ int main_column() {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int lds = 96 * 1024;
     CK(hipFuncSetAttribute((const void *)k_column, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    { const int one = 1; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_no_inv), &one, 4)); }
+    { const int noinv = mode == 1, sc0 = mode == 2;
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_no_inv), &noinv, 4)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_inv_sc0), &sc0, 4)); }
+    printf("F: %s\n", mode == 1 ? "rows read with sc1 loads, no invalidate" : mode == 2 ? "the CU's L1 invalidated by one wave (buffer_inv sc0), plain loads" : "L1 invalidated at agent scope (buffer_inv sc1), plain loads");
     float ms_d, ms_a, ms;
     const double gb = n * 8 / 1e9;
     for (int rep = 0; rep < 3; rep++) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_tiles, dim3(MNT * MNT * MNT), dim3(512), 0, 0, mesh);
+        hipLaunchKernelGGL(k_tiles, dim3(MNTA * MNT * MNT), dim3(512), 0, 0, mesh);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_d, e0, e1));
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(k_rows, dim3(MN * (NY / 32)), dim3(LANES), 0, 0, (d2 *)mesh);
@@ -313,10 +338,10 @@ int main_column() {
     for (int rep = 0; rep < 4; rep++) {
         CK(hipMemset(flags, 0, 16 * WG_PER_GROUP * GROUPS * 4)); CK(hipMemset(abort_flag, 0, 4));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_column, dim3(GROUPS * WG_PER_GROUP), dim3(LANES), lds, 0, mesh, flags, abort_flag);
+        hipLaunchKernelGGL(k_column, dim3(GROUPS * WG_PER_GROUP), dim3(LANES), lds, 0, mesh, flags, abort_flag, mode);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         unsigned ab; CK(hipMemcpy(&ab, abort_flag, 4, hipMemcpyDeviceToHost));
-        printf("F column of tiles written and its rows rewritten by the same XCD: %.3f ms%s\n", ms,
+        printf("F column of tiles (%d KB) written and its rows rewritten by the same XCD: %.3f ms%s\n", MTA * 128, ms,
                ab ? "  ABORTED (a barrier timed out)" : "");
         if (ab) break;
     }
@@ -328,7 +353,7 @@ int main_column() {
 }
 
 int main(int argc, char **argv) {
-    if (argc > 1 && argv[1][0] == 'c') return main_column();
+    if (argc > 1 && argv[1][0] == 'c') return main_column(argc > 2 ? atoi(argv[2]) : 2);
     const unsigned nx = argc > 1 ? (unsigned)atoi(argv[1]) : 1024;
     const int rounds = argc > 2 ? atoi(argv[2]) : 4;
     const int l2mode = argc > 3 ? atoi(argv[3]) : 1;   // 0: L1 invalidate after the barrier, plain accesses
@@ -380,9 +405,12 @@ int main(int argc, char **argv) {
     { const int z = 0; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_no_inv), &z, 4)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_no_sleep), &z, 4)); }
     CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipFuncSetAttribute((const void *)kern_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    { const int one = l2mode; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_l2mode), &one, 4)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_no_inv), &one, 4)); }
-    printf("C: %s\n", l2mode ? "window loads past the L1 (sc1), no invalidate, layer loads and stores non-temporal"
-                             : "L1 invalidated after every barrier (buffer_inv sc1), plain accesses");
+    { const int m = l2mode, noinv = l2mode == 1, sc0 = l2mode == 2;
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_l2mode), &m, 4)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_no_inv), &noinv, 4));
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_inv_sc0), &sc0, 4)); }
+    printf("C: %s\n", l2mode == 1 ? "window loads past the L1 (sc1), no invalidate, layer loads and stores non-temporal"
+                       : l2mode == 2 ? "the CU's L1 invalidated after every barrier by one wave (buffer_inv sc0), plain window loads, layer loads and stores non-temporal"
+                                     : "L1 invalidated after every barrier (buffer_inv sc1), plain accesses");
     for (int rep = 0; rep < 8; rep++) {
         const bool fl = rep >= 2 && rep != 4 && rep != 5;
         const int pipe = rep >= 4;
