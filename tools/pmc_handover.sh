@@ -11,10 +11,3 @@ for rounds in 8 4 2; do
     python $R/tools/rocprof_summary.py --pmc /tmp/ho_$c | grep -A2 "k_rows\|k_cols\|k_handover" | grep -v "^--"
   done
 done
-# the column question (deposit's tiles -> forward z rows, see the probe's header)
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/hc_$c
-  rocprofv3 --kernel-trace --pmc $c -d /tmp/hc_$c -- $R/tools/xcd_handover_probe column $MODE > /tmp/hc_$c.log 2>&1
-  echo "== column, $c (mean per launch, raw counter)"
-  python $R/tools/rocprof_summary.py --pmc /tmp/hc_$c | grep -A2 "k_rows\|k_tiles\|k_column" | grep -v "^--"
-done

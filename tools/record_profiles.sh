@@ -58,7 +58,12 @@ for v in "" tools/_variants/srd_nopairs.so tools/_variants/srd_nocull.so; do CON
 CONCEPT_GPU_SR_DENSE=0 python tools/sr_dense_time.py clustered 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_sr_dense_phases.txt
 ./tools/mall_probe > $OUT/${TAG}_mall_probe.txt 2>&1
 # a layer handed from the z pass to the y pass inside an XCD (data movement only): times and HBM-side counters
-(for r in 8 4 2; do ./tools/xcd_handover_probe 1024 $r 1; done; ./tools/xcd_handover_probe 1024 4 0; bash tools/pmc_handover.sh 1) 2>&1 | grep -v amdgpu.ids | cut -c1-160 > $OUT/${TAG}_xcd_handover_probe.txt
+(for r in 8 4 2; do ./tools/xcd_handover_probe 1024 $r 2; done; ./tools/xcd_handover_probe 1024 4 1; ./tools/xcd_handover_probe 1024 4 0; bash tools/pmc_handover.sh 2
+ for a in 16 8 4; do
+   hipcc --offload-arch=gfx950 -O3 -DCOL_A=$a -o tools/_variants/xcd_col$a tools/xcd_handover_probe.cpp
+   echo "--- column question, COL_A=$a"; ./tools/_variants/xcd_col$a column 2
+   for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && rm -rf /tmp/hc && rocprofv3 --kernel-trace --pmc $c -d /tmp/hc -- $R/tools/_variants/xcd_col$a column 2 > /tmp/hc.log 2>&1; python $R/tools/rocprof_summary.py --pmc /tmp/hc | grep -A1 "k_column\|k_tiles\|k_rows" | grep -v "^--"); done
+ done) 2>&1 | grep -v amdgpu.ids | cut -c1-160 > $OUT/${TAG}_xcd_handover_probe.txt
 # heavy tiles first (cgk_tile_order) against the plain walk, one process
 python tools/fused_order_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_tile_order_ab.txt
 rm -rf $OUT/stats $OUT/pmc_f $OUT/pmc_w $OUT/stats_p3m $OUT/pmc_sr
