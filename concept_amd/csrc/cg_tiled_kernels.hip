@@ -262,12 +262,22 @@ int cgk_tile_order(cg_ctx *c, const unsigned *start, const unsigned *count) {
                          sizeof(unsigned) * (2 * (size_t)ntiles + cap + ncounters)));
         c->tile_order = c->tile_order_buf + ntiles;
         c->tile_order_cap = cap;
-        CG_HIP(hipHostMalloc((void **)&c->tile_order_seen, sizeof(unsigned), hipHostMallocMapped));
-        *c->tile_order_seen = ~0u;  // no build seen yet
+        // (pinned memory is a convenience: without it every launch takes the full number of
+        // blocks in front)
+        if (hipHostMalloc((void **)&c->tile_order_seen, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            c->tile_order_seen = nullptr;
+        } else {
+            *c->tile_order_seen = ~0u;  // no build seen yet
+        }
     }
     unsigned *pops = c->tile_order_buf, *heavy = c->tile_order, *counters = heavy + cap;
     unsigned *rank = counters + ncounters, *seen_dev = nullptr;
-    CG_HIP(hipHostGetDevicePointer((void **)&seen_dev, c->tile_order_seen, 0));
+    if (!c->tile_order_seen ||
+        hipHostGetDevicePointer((void **)&seen_dev, c->tile_order_seen, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        seen_dev = counters + 1;  // (the kernel's own word: nothing for the host to see)
+    }
     CG_HIP(hipMemsetAsync(counters, 0, sizeof(unsigned) * ncounters, c->stream));
     hipLaunchKernelGGL(k_order_pops, dim3((ntiles + 1023u) / 1024u), dim3(1024), 0, c->stream, start, count, ntiles,
                        ((uintptr_t)count & 15u) == 0, pops, counters);
@@ -291,7 +301,7 @@ struct TileOrder {
 static TileOrder tile_order_args(const cg_ctx *c) {
     TileOrder o{};
     if (!c->tile_order_on) return o;
-    const unsigned seen = *(volatile unsigned *)c->tile_order_seen;
+    const unsigned seen = c->tile_order_seen ? *(volatile unsigned *)c->tile_order_seen : ~0u;
     if (seen == 0) return o;  // no heavy tiles the last time we looked: the plain launch
     unsigned front = c->tile_order_cap;
     if (seen != ~0u && seen + seen / 4u + 64u < front) front = (seen + seen / 4u + 64u + 7u) & ~7u;
