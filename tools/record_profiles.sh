@@ -56,6 +56,10 @@ python tools/variant.py tools/_variants/srd_nopairs.so cg_shortrange_dense.hip -
 python tools/variant.py tools/_variants/srd_nocull.so cg_shortrange_dense.hip -DSRD_PROBE_NOCULL > /dev/null 2>&1
 for v in "" tools/_variants/srd_nopairs.so tools/_variants/srd_nocull.so; do CONCEPT_GPU_LIB=$v python tools/sr_dense_time.py clustered; done 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_sr_dense_phases.txt
 CONCEPT_GPU_SR_DENSE=0 python tools/sr_dense_time.py clustered 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_sr_dense_phases.txt
+# (the stand-alone probes are built here when the tree does not hold them: a fresh clone)
+mkdir -p tools/_variants
+[ -x tools/mall_probe ] || hipcc --offload-arch=gfx950 -O3 -o tools/mall_probe tools/mall_probe.cpp
+[ -x tools/xcd_handover_probe ] || hipcc --offload-arch=gfx950 -O3 -o tools/xcd_handover_probe tools/xcd_handover_probe.cpp
 ./tools/mall_probe > $OUT/${TAG}_mall_probe.txt 2>&1
 # a layer handed from the z pass to the y pass inside an XCD (data movement only): times and HBM-side counters
 (for r in 8 4 2; do ./tools/xcd_handover_probe 1024 $r 2; done; ./tools/xcd_handover_probe 1024 4 1; ./tools/xcd_handover_probe 1024 4 0; bash tools/pmc_handover.sh 2
