@@ -49,9 +49,16 @@ for dist in (sys.argv[1:] or ['uniform', 'clustered']):
     mesh.close()
     del pos, mom
     pb, mb = torch.empty_like(pa), torch.empty_like(ma)
-    for rep in range(2):
-        for mode in ('0', '1'):
-            os.environ['CONCEPT_GPU_TILE_ORDER'] = mode
+    # PROBE_MINS=1536,3072,...: the order on with these thresholds (CONCEPT_GPU_TILE_ORDER_MIN) instead
+    # of off against on
+    mins = [m for m in os.environ.get('PROBE_MINS', '').split(',') if m]
+    for rep in range(3 if mins else 2):
+        for mode in (mins or ('0', '1')):
+            if mins:
+                os.environ['CONCEPT_GPU_TILE_ORDER'] = '1'
+                os.environ['CONCEPT_GPU_TILE_ORDER_MIN'] = mode
+            else:
+                os.environ['CONCEPT_GPU_TILE_ORDER'] = mode
             mesh = PotentialMesh(N, L)
             # (each deposit makes the order anew: its cost is inside these times)
             dep = timed(lambda: mesh.deposit_tiled(pa[:n_p], table, 1.0/N**3))
@@ -62,7 +69,7 @@ for dist in (sys.argv[1:] or ['uniform', 'clustered']):
                 pa, ma, None, table, None, pb, mb, None, start_out, count_out, 2, -dt, dt))
             nh = mesh.tile_order()
             nh = -1 if nh is None else len(nh)
-            print(f'{dist:9s} order {mode} heavy tiles {nh:6d}  deposit',
+            print(f'{dist:9s} {"min" if mins else "order"} {mode} heavy tiles {nh:6d}  deposit',
                   ' '.join(f'{v:.3f}' for v in dep[1:]), ' fused', ' '.join(f'{v:.3f}' for v in fu[1:]),
                   ' flags', mesh.error_flags(), flush=True)
             mesh.close()
