@@ -390,6 +390,108 @@ def pmc_traffic(dom_kernel, workload):
 
 
 # ---------------------------------------------------------------------------
+# particles as a function of (seed, global identifier) only — the same box on 1, 2, 4, 8 ranks —
+# and the check an N-rank run carries with it
+# ---------------------------------------------------------------------------
+ID_CHUNK = 1 << 20
+VERIFY_SAMPLES = 512
+VERIFY_DIR = os.path.join(REPO, '.bench_verify')
+VERIFY_COMMITTED = 'profiles/r05_bench_verify_{key}.json'
+
+
+def global_particles(torch, args, n_p, L, cell, mass, dt, dev, rank=0, world=1):
+    """(pos, mom, ids) of the particles whose identifiers lie in the chunks rank, rank + world,
+    ... of ID_CHUNK identifiers: uniform positions, Maxwellian momenta (--thermal), each chunk
+    from a generator seeded by (seed, chunk).  Who generates a particle does not matter: the
+    owner gets it through exchange()."""
+    sigma = args.thermal/3**0.5*cell*mass/dt if args.thermal > 0 else 0.0
+    top = float(torch.nextafter(torch.tensor(L, dtype=torch.float64),
+                                torch.tensor(0.0, dtype=torch.float64)))
+    nchunks = (n_p + ID_CHUNK - 1)//ID_CHUNK
+    mine = list(range(rank, nchunks, world))
+    m_total = sum(min(ID_CHUNK, n_p - c*ID_CHUNK) for c in mine)
+    pos = torch.empty((m_total, 3), dtype=torch.float64, device=dev)
+    mom = torch.zeros((m_total, 3), dtype=torch.float64, device=dev)
+    ids = torch.empty(m_total, dtype=torch.int64, device=dev)
+    at = 0
+    for c in mine:
+        m = min(ID_CHUNK, n_p - c*ID_CHUNK)
+        gen = torch.Generator(device=dev).manual_seed(1000003*args.seed + c)
+        # (always a whole chunk: how a generator's stream maps onto the elements may depend on
+        # the tensor's size)
+        x = torch.rand((ID_CHUNK, 3), dtype=torch.float64, device=dev, generator=gen)
+        pos[at:at + m] = x[:m].mul_(L).clamp_(min=0.0, max=top)
+        if sigma:
+            v = torch.randn((ID_CHUNK, 3), dtype=torch.float64, device=dev, generator=gen)
+            mom[at:at + m] = v[:m].mul_(sigma)
+        ids[at:at + m] = torch.arange(c*ID_CHUNK, c*ID_CHUNK + m, device=dev)
+        at += m
+    return pos, mom, ids
+
+
+def verify_key(args, name, steps_total):
+    return f'{name}_seed{args.seed}_thermal{args.thermal:g}_steps{steps_total}'
+
+
+def verify_replay(torch, args, domain, name, n_p, N, L, dev, rank, world, steps_total):
+    """The sharded step sequence on the (seed, identifier)-defined box, with the identifiers
+    travelling: tile sort, then steps_total x (deposit, solve, kick + drift + sort) — the
+    sequence of the timed region (warm-up included) — and what it leaves behind: particle
+    count, sum of mom^2, and the positions and momenta of the VERIFY_SAMPLES particles whose
+    identifiers are multiples of n_p / VERIFY_SAMPLES.  Untimed."""
+    from concept_amd.distributed import ParticleStore, RegionParticles, pm_step_regions
+    mass, G, dt = 1.0, 1.0, 1e-4
+    pos, mom, ids = global_particles(torch, args, n_p, L, L/N, mass, dt, dev, rank, world)
+    parts = ParticleStore(domain, pos, mom, ids, slack=1.15)
+    del pos, mom, ids
+    parts.exchange()
+    parts.tile_sort()
+    rp = RegionParticles(parts, slack=1.15)
+    del parts
+    contribution = mass*(float(N)**(-3)*(N/L)**3)
+    C = -L**2*G/3.141592653589793
+    for _ in range(steps_total):
+        pm_step_regions(domain, rp, contribution, 4, C, mass*(-dt), dt/mass, diff_order=2)
+    rp.check()
+    cols = rp.columns()
+    stride = max(n_p//VERIFY_SAMPLES, 1)
+    sel = (cols['ids'] % stride == 0) & (cols['ids'] < stride*VERIFY_SAMPLES)
+    out = {'n_local': int(cols['ids'].numel()),
+           'sum_mom2': float(cols['mom'].square().sum()),
+           'ids': cols['ids'][sel].cpu().numpy(), 'pos': cols['pos'][sel].cpu().numpy(),
+           'mom': cols['mom'][sel].cpu().numpy()}
+    del cols, rp
+    torch.cuda.empty_cache()
+    return out
+
+
+def verify_save(key, ids, pos, mom, n, sum_mom2, extra):
+    """the 1-rank values, where the N-rank runs of this box look for them"""
+    os.makedirs(VERIFY_DIR, exist_ok=True)
+    path = os.path.join(VERIFY_DIR, key + '.json')
+    with open(path, 'w') as f:
+        json.dump(dict(extra, key=key, particles=int(n), sum_mom2=float(sum_mom2).hex(),
+                       ids=[int(i) for i in ids],
+                       pos=[[float(v).hex() for v in row] for row in pos],
+                       mom=[[float(v).hex() for v in row] for row in mom]), f)
+    return path
+
+
+def verify_load(key):
+    import numpy as np
+    for path in (os.path.join(VERIFY_DIR, key + '.json'),
+                 os.path.join(REPO, VERIFY_COMMITTED.format(key=key))):
+        if os.path.exists(path):
+            d = json.load(open(path))
+            unhex = lambda rows: np.array([[float.fromhex(v) for v in row] for row in rows])
+            return {'path': os.path.relpath(path, REPO), 'particles': d['particles'],
+                    'sum_mom2': float.fromhex(d['sum_mom2']), 'ids': np.array(d['ids']),
+                    'pos': unhex(d['pos']), 'mom': unhex(d['mom']),
+                    'made_by': d.get('made_by')}
+    return None
+
+
+# ---------------------------------------------------------------------------
 # N > 1: x-slab domains
 # ---------------------------------------------------------------------------
 def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
@@ -402,18 +504,11 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
     from concept_amd.distributed import (DistributedParticles, RegionParticles, SlabDomain,
                                          pm_kick, pm_step_regions)
     dom = SlabDomain(N, L, device=dev)
-    n_local = n_p//world
-    gen = torch.Generator(device=dev).manual_seed(args.seed + rank)
-    pos = torch.rand((n_local, 3), dtype=torch.float64, device=dev, generator=gen)
-    # uniform inside this rank's slab: lower CIC cell x in [x0, x0 + nxl)  <=>
-    # x in [(x0 + 1/2) cells, (x0 + nxl + 1/2) cells), wrapped into the box
+    # the box is a function of (seed, global identifier): the same particles on any number of
+    # ranks (each rank makes every world-th chunk of identifiers, exchange() takes them home)
     cell = L/N
-    pos[:, 0] = torch.remainder((dom.mesh.x0 + 0.5 + pos[:, 0]*dom.nxl*(1 - 1e-12))*cell, L)
-    pos[:, 1:] *= L
-    pos.clamp_(min=0.0, max=float(torch.nextafter(torch.tensor(L, dtype=torch.float64),
-                                                  torch.tensor(0.0, dtype=torch.float64))))
     mass, G, dt = 1.0, 1.0, 1e-4
-    mom = thermal_momenta(torch, args, pos.shape, cell, mass, dt, dev, gen)
+    pos, mom, _ = global_particles(torch, args, n_p, L, cell, mass, dt, dev, rank, world)
     parts = DistributedParticles(dom, pos, mom, None, slack=1.15)
     del pos, mom
     parts.exchange()
@@ -506,6 +601,15 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
     red = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(red, op=dist.ReduceOp.MAX)
     elapsed = float(red.item())
+    # what the timed run left behind, rank by rank: particles (load balance of the slabs) and
+    # the sum of mom^2
+    m2 = parts.measure_momentum() if fused else dom.mesh.measure_momentum(parts.view('mom'))
+    mine = torch.tensor([float(parts.n), float(m2[0]), float(rank),
+                         float(torch.cuda.current_device())], dtype=torch.float64, device=dev)
+    seen = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(seen, mine)
+    seen = torch.stack(seen).cpu().numpy()
+    emig_total = parts.emigrants_total
     # outside the timed region: what one whole FFT transpose costs on this transport by itself
     # (one all_to_all_single of the transpose buffer), for reading the stage times above
     probe = None
@@ -523,8 +627,68 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
         sent = dom.tbuf_a.numel()*8*(world - 1)/world
         probe = {'ms': round(ms, 3), 'bytes_sent_per_rank': int(sent),
                  'GBps_out_per_rank': round(sent/(ms*1e-3)/1e9, 1)}
-    cnt = torch.tensor([parts.n, parts.emigrants_total - emig0], dtype=torch.int64, device=dev)
+    cnt = torch.tensor([parts.n, emig_total - emig0], dtype=torch.int64, device=dev)
     dist.all_reduce(cnt)
+    # The check this line carries: the same step sequence once more, untimed,
+    # with the identifiers travelling, and its id-keyed sample against the 1-rank values
+    verify = None
+    if not args.no_verify and not args.weak and fused:
+        import numpy as np
+        del parts
+        torch.cuda.empty_cache()
+        steps_total = args.warmup + args.steps
+        rep = verify_replay(torch, args, dom, name, n_p, N, L, dev, rank, world, steps_total)
+        tot = torch.tensor([float(rep['n_local']), rep['sum_mom2']], dtype=torch.float64,
+                           device=dev)
+        dist.all_reduce(tot)
+        k = torch.tensor([len(rep['ids'])], dtype=torch.int64, device=dev)
+        ks = [torch.empty_like(k) for _ in range(world)]
+        dist.all_gather(ks, k)
+        kmax = int(max(int(v) for v in ks))
+        row = torch.zeros((kmax, 7), dtype=torch.float64, device=dev)
+        if len(rep['ids']):
+            row[:len(rep['ids']), 0] = torch.as_tensor(rep['ids'].astype(np.float64), device=dev)
+            row[:len(rep['ids']), 1:4] = torch.as_tensor(rep['pos'], device=dev)
+            row[:len(rep['ids']), 4:7] = torch.as_tensor(rep['mom'], device=dev)
+        rows = [torch.empty_like(row) for _ in range(world)]
+        dist.all_gather(rows, row)
+        if rank == 0:
+            got = np.concatenate([r.cpu().numpy()[:int(c)] for r, c in zip(rows, ks)])
+            got = got[np.argsort(got[:, 0])]
+            key = verify_key(args, name, steps_total)
+            timed_m2 = float(seen[:, 1].sum())
+            verify = {
+                'key': key, 'particles': int(tot[0].item()), 'particles_expected': n_p,
+                'sum_mom2_replay': float(tot[1].item()), 'sum_mom2_timed_run': timed_m2,
+                'timed_vs_replay_rel': abs(timed_m2 - float(tot[1].item()))/float(tot[1].item()),
+                'sample': int(got.shape[0]),
+                'what': ('the timed step sequence (tile sort, then warmup + steps x deposit / '
+                         'solve / kick + drift + sort) run once more, untimed, on the same '
+                         '(seed, identifier)-defined box with the identifiers travelling; the '
+                         f'{VERIFY_SAMPLES} particles with identifiers k * n/{VERIFY_SAMPLES} '
+                         'compared with the values a 1-rank run of this command left')}
+            ref = verify_load(key)
+            if ref is None:
+                verify.update(reference=None, ok=None,
+                              note='no 1-rank values for this key: run the same command with '
+                                   '--gpus 1 first (it writes .bench_verify/<key>.json)')
+            else:
+                same = got.shape[0] == ref['ids'].shape[0] and \
+                    np.array_equal(got[:, 0].astype(np.int64), ref['ids'])
+                if same:
+                    dx = np.abs(got[:, 1:4] - ref['pos'])
+                    dx = np.minimum(dx, L - dx)
+                    rms = np.sqrt((ref['mom']**2).mean()) or 1.0
+                    dm = np.abs(got[:, 4:7] - ref['mom'])
+                    verify.update(max_pos_err_over_boxsize=float(dx.max()/L),
+                                  max_mom_err_over_rms=float(dm.max()/rms))
+                verify.update(
+                    reference=ref['path'], reference_made_by=ref['made_by'],
+                    sum_mom2_reference=ref['sum_mom2'],
+                    sum_mom2_rel_err=abs(float(tot[1].item()) - ref['sum_mom2'])/ref['sum_mom2'],
+                    ok=bool(same and int(tot[0].item()) == ref['particles'] == n_p
+                            and dx.max() <= 1e-12*L and dm.max() <= 1e-12*rms
+                            and verify['timed_vs_replay_rel'] <= 1e-12))
     # shut the communicator down and push out what C stdio still holds (it went to stderr, see
     # main()), then give stdout back: the JSON line is the only line on it
     dist.destroy_process_group()
@@ -607,6 +771,11 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
                                'run of the sharded path, not a rate to quote)')},
         'emigrants_per_step': emigrants/args.steps,
         'emigrant_fraction_per_step': emigrants/args.steps/max(total, 1),
+        'ranks_seen': {'world': world, 'backend': backend,
+                       'rank_device': [[int(r[2]), int(r[3])] for r in seen]},
+        'particles_per_rank': {'counts': [int(r[0]) for r in seen],
+                               'max_over_mean': round(float(seen[:, 0].max()/seen[:, 0].mean()), 4)},
+        'verify': verify,
         'roofline': {'bound': 'hbm', 'kernel': gk_name + ' (rank 0)',
                      'achieved': round(gk_rate, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(gk_rate/HBM_PEAK_GBS, 4), 'traffic': None,
@@ -672,6 +841,8 @@ def main():
                          'peer) / rate (default: one xGMI link, one way) — the pipelining '
                          'schedule and its overlap measured without a second GPU; results are '
                          'not meaningful')
+    ap.add_argument('--no-verify', action='store_true',
+                    help='skip the untimed replay with identifiers (the `verify` block)')
     ap.add_argument('--seed', type=int, default=1,
                     help='seed of the synthetic particles (SURVEY.md §8d: 1, 2, 3)')
     ap.add_argument('--dist', default='uniform', choices=['uniform', 'lattice', 'clustered', 'zeldovich'],
@@ -684,8 +855,6 @@ def main():
                     help='P3M step (BASELINE configs[2]): long-range mesh with Gaussian cut-off + '
                          'short-range tile sweep (r_s = 1.25 cells, range 4.5 r_s, spline '
                          'softening 0.025*L/cbrt(N))')
-    ap.add_argument('--sr-tiles', action='store_true',
-                    help='P3M: the round-1 sweep (one wavefront per tile, no sub-tile pruning)')
     ap.add_argument('--no-fused', action='store_true',
                     help='PM: separate gather-kick and drift + sort kernels (the round-1 step) '
                          'instead of the fused kick + drift + scatter pass')
@@ -789,9 +958,78 @@ def main():
             if r2['roofline'].get('receivers_in_dense_tiles') is not None:
                 result['configs'][cname]['receivers_in_dense_tiles'] = \
                     r2['roofline']['receivers_in_dense_tiles']
+        # the same workload through the drop-in API
+        result['timeloop'] = timeloop_leg(torch, dev, result['ms_per_step'])
+        result['timeloop_ms_per_step'] = result['timeloop']['ms_per_base_step']
     if not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(name)
     print(json.dumps(result))
+
+
+def timeloop_leg(torch, dev, raw_ms, n=2**28, N=1024, base_steps=24):
+    """The metric's workload through the API the boundary promises instead of through the raw
+    kernel sequence: concept_amd.stepper.Timeloop = main.timeloop() (main.py:102-471) on a
+    Component of 2^28 particles with a 1024^3 PM mesh and the matter + Λ clock from a = 0.1 —
+    background, time-step integrals, limiters (v_rms after every kick), the streaming form of
+    the loop (every long kick riding with the drift after it: deposit, solve, one fused pass
+    per base step).  Wall time between the beginnings of consecutive base steps, host included;
+    a synchronisation step (every 8th, and at reductions of Δt) takes two passes."""
+    import statistics
+    from concept_amd import commons, stepper
+    from concept_amd.species import Component
+    p = commons.load_params({
+        'boxsize': float(N), 'H0': 0.07, 'Ωb': 0.05, 'Ωcdm': 0.25, 'a_begin': 0.1,
+        'output_times': {'a': (0.5,)},
+        'potential_options': {'gridsize': {'gravity': {'pm': N}}},
+        'select_forces': {'all': {'gravity': 'pm'}}})
+    mass = p.ρ_mbar*p.boxsize**3/n
+    c = Component('matter', 'matter', N=n, mass=mass)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    torch.rand((n, 3), dtype=torch.float64, device=dev, generator=gen, out=c.pos)
+    c.pos.mul_(p.boxsize*(1 - 1e-13))
+    u = 100*p.units.km/p.units.s   # peculiar velocities of ~100 km/s: mom = a m u
+    torch.randn((n, 3), dtype=torch.float64, device=dev, generator=gen, out=c.mom)
+    c.mom.mul_(0.1*mass*u/3**0.5)
+
+    class Enough(Exception):
+        pass
+    stamps, passes = [], []
+
+    def on_step(lp):
+        torch.cuda.synchronize()
+        stamps.append(time.perf_counter())
+        passes.append(lp.stream_passes)
+        if len(stamps) > base_steps:
+            raise Enough
+    loop = stepper.Timeloop([c], on_step=on_step)
+    replays = stepper.stream_replays
+    try:
+        loop.run()
+    except Enough:
+        pass
+    torch.cuda.synchronize()
+    dts = [(b - a)*1e3 for a, b in zip(stamps[:-1], stamps[1:])]
+    dps = [b - a for a, b in zip(passes[:-1], passes[1:])]
+    plain = [t for t, k in zip(dts, dps) if k == 1]   # base steps of one pass
+    ms = statistics.median(plain) if plain else float('nan')
+    out = {'ms_per_base_step': round(ms, 3), 'base_steps_timed': len(dts),
+           'one_pass_steps': len(plain),
+           'ms_per_synchronisation_step': (round(statistics.median(
+               [t for t, k in zip(dts, dps) if k > 1]), 3) if len(plain) < len(dts) else None),
+           'mean_ms_over_all_steps': round(sum(dts)/max(len(dts), 1), 3),
+           'ratio_to_raw_step': round(ms/raw_ms, 4), 'raw_ms_per_step': round(raw_ms, 3),
+           'stream_passes': loop.stream_passes, 'wrong_guesses': loop.stream_wrong_guesses,
+           'replays': stepper.stream_replays - replays, 'particles_kept': int(c.N_local) == n,
+           'a_reached': loop.cosmo.a,
+           'what': ('stepper.Timeloop (= main.timeloop(), main.py:102-471) on a Component of 2^28 '
+                    'particles / 1024^3 PM mesh, matter + Λ clock from a = 0.1, streaming form; '
+                    'median wall time between the beginnings of consecutive one-pass base steps '
+                    '(deposit + solve + fused kick/drift/sort with the identifier column and the '
+                    'sum of mom^2 for v_rms + host), torch.cuda.synchronize() in the step '
+                    'callback')}
+    del c, loop
+    torch.cuda.empty_cache()
+    return out
 
 
 def run_single(args, torch, dev, rank=0):
@@ -805,13 +1043,17 @@ def run_single(args, torch, dev, rank=0):
     n_p, N = WORKLOADS[name]
     L = float(N)  # boxsize in grid units (synthetic)
     mesh = PotentialMesh(N, L, nghosts=2)
-    gen = torch.Generator(device=dev).manual_seed(args.seed + rank)
-    pos = make_positions(torch, args, n_p, N, L, dev, gen, mesh)
     # step scalars: fixed (enable_Hubble=False semantics)
     mass = 1.0
     G = 1.0
     dt = 1e-4
-    mom = thermal_momenta(torch, args, pos.shape, L/N, mass, dt, dev, gen)
+    if args.dist == 'uniform':
+        # a function of (seed, identifier): the box an N-rank run of this command steps too
+        pos, mom, _ = global_particles(torch, args, n_p, L, L/N, mass, dt, dev)
+    else:
+        gen = torch.Generator(device=dev).manual_seed(args.seed + rank)
+        pos = make_positions(torch, args, n_p, N, L, dev, gen, mesh)
+        mom = thermal_momenta(torch, args, pos.shape, L/N, mass, dt, dev, gen)
     fused = not (args.no_fused or args.no_sort or args.p3m or args.no_prepare)
     if fused:
         # the fused kick + drift + scatter keeps the particles in tile REGIONS WITH GAPS
@@ -844,8 +1086,7 @@ def run_single(args, torch, dev, rank=0):
         # timed step is deposit -> solve -> kick + drift + sort: the same cycle of one drift,
         # one sort, one deposit, one solve and one kick per step, entered after the sort
         PHASES = ['deposit'] + poisson + ['kick_drift_sort']
-        mesh.drift_sort(pos[:n_p], mom[:n_p], None, pos2[:n_p], mom2[:n_p], None, dt_over_mass,
-                        table)
+        mesh.sort_particles(pos[:n_p], mom[:n_p], None, pos2[:n_p], mom2[:n_p], None, table)
         pos, pos2, mom, mom2 = pos2, pos, mom2, mom
         reg = {'start': table[:mesh.table_entries], 'count': None,
                'spare': mesh.new_region_table()}
@@ -933,18 +1174,12 @@ def run_single(args, torch, dev, rank=0):
             mesh.gather_kick(pos, mom, order, kick_factor)
         mark()
         if sr:
-            if args.sr_tiles:  # the one-wavefront-per-tile sweep, for A/B
-                cells = mesh.shortrange_build(pos, sr['nt'], L/sr['nt'])
-                mark()
-                mesh.shortrange_sweep(pos, cells, mom, pos, cells, sr['nt'], True, sr['table'],
-                                      sr['scaling'], sr['r2_max'], sr['factor'])
-            else:
-                cells = sr['cells'] = mesh.shortrange_cells(pos, sr['nt'], L/sr['nt'])
-                mark()
-                # kick_short (main.py:1173-1262): nullify Δmom, sweep, apply — the apply is
-                # fused into the sweep's store: the target is the momentum array itself
-                mesh.shortrange_sweep_cells(cells, mom, cells, sr['nt'], sr['table'],
-                                            sr['scaling'], sr['r2_max'], sr['factor'])
+            cells = sr['cells'] = mesh.shortrange_cells(pos, sr['nt'], L/sr['nt'])
+            mark()
+            # kick_short (main.py:1173-1262): nullify Δmom, sweep, apply — the apply is
+            # fused into the sweep's store: the target is the momentum array itself
+            mesh.shortrange_sweep_cells(cells, mom, cells, sr['nt'], sr['table'],
+                                        sr['scaling'], sr['r2_max'], sr['factor'])
             mark()
         if record:
             events.append(ev)
@@ -958,10 +1193,12 @@ def run_single(args, torch, dev, rank=0):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     mesh.check_errors()   # (a bucket that outgrew its region would have dropped particles)
+    timed_m2 = None
     if fused:
         kept = int(reg['count'].long().sum().item())
         if kept != n_p:
             sys.exit(f'bench.py: {kept} of {n_p} particles after the timed steps')
+        timed_m2 = mesh.measure_momentum_regions(mom, reg['start'], reg['count'])[0]
 
     n_g = N**3
     mv, sv = moved_bytes(n_p, n_g), survey_bytes(n_p, n_g)
@@ -1024,30 +1261,29 @@ def run_single(args, torch, dev, rank=0):
         'emigrants_per_step': 0,
     }
     if dom == 'sr_sweep':
-        # FP64 VALU-bound: pair tests/s against the FP64 vector issue rate
-        if args.sr_tiles:   # every receiver against the 27 tiles around its own
-            tests = n_p*27*(n_p/sr['nt']**3)
-            per_test = 15   # FP64 VALU instructions of a pair test that misses: 3 sub, 3 mul,
-            #                 2 add, 1 cmp, 3 mul + 3 add of the (zero) accumulation
-        else:               # half-tile cells: 5 x 5 columns of 6 cells — counted on the actual
-            # cell list of the last step (box sums over the populations, periodic)
-            nc = 2*sr['nt']
-            off = sr['cells'][1].long()
-            pop = (off[1:] - off[:-1]).reshape(nc, nc, nc).double()
-            box = sum(torch.roll(pop, s_, 0) for s_ in range(-2, 3))
-            box = sum(torch.roll(box, s_, 1) for s_ in range(-2, 3))
-            colz = box.reshape(nc, nc, nc//2, 2).sum(3)          # per tile along z
-            win = sum(torch.roll(colz, s_, 2) for s_ in (-1, 0, 1))   # 6 cells: tiles tz-1..tz+1
-            tpop = pop.reshape(nc, nc, nc//2, 2).sum(3)
-            tests = float((tpop*win).sum())
-            per_test = 12   # 3 sub, 3 mul, 2 add, 1 cmp, 3 fma
-            # tiles of the dense tiles' sweep (cg_shortrange_dense.hip): their receivers test
-            # fewer pairs than the cells geometry counted here, which stays the unit of work
-            tiles = tpop.reshape(nc//2, 2, nc//2, 2, nc//2).sum((1, 3))
-            dense_min = (-1 if os.environ.get('CONCEPT_GPU_SR_DENSE', '1') == '0'
-                         else int(os.environ.get('CONCEPT_GPU_SR_DENSE_MIN', '64')))
-            dense_tiles = int((tiles >= dense_min).sum()) if dense_min > 0 else 0
-            dense_receivers = int(tiles[tiles >= dense_min].sum()) if dense_min > 0 else 0
+        # FP64 VALU-bound: EXECUTED pair tests/s against the FP64 vector issue rate.  The tests
+        # are counted by the sweeps themselves (cg_shortrange_stats: counting instantiations of
+        # the two kernels, one extra sweep over the last step's cell list after the timed
+        # region, on a scratch copy of the momenta): a lane that holds a receiver against a
+        # supplier of its range is one test, a test with r2 <= r2_max one hit.
+        scratch = mom.clone()
+        mesh.shortrange_stats(True)
+        mesh.shortrange_sweep_cells(sr['cells'], scratch, sr['cells'], sr['nt'], sr['table'],
+                                    sr['scaling'], sr['r2_max'], sr['factor'])
+        st = mesh.shortrange_stats(False)
+        del scratch
+        tests = st['cells'][0] + st['dense'][0]
+        hits = st['cells'][1] + st['dense'][1]
+        trips = st['cells'][2] + st['dense'][2]
+        per_test = 12   # 3 sub, 3 mul, 2 add, 1 cmp, 3 fma
+        # the receivers the dense tiles' sweep took: populations of the tiles from the cell list
+        nc = 2*sr['nt']
+        off = sr['cells'][1].long()
+        pop = (off[1:] - off[:-1]).reshape(nc//2, 2, nc//2, 2, nc//2, 2).sum((1, 3, 5))
+        dense_min = int(os.environ.get('CONCEPT_GPU_SR_DENSE_MIN', '64'))
+        took = st['dense'][0] > 0 and dense_min > 0
+        dense_tiles = int((pop >= dense_min).sum()) if took else 0
+        dense_receivers = int(pop[pop >= dense_min].sum()) if took else 0
         ms = kernels[dom]
         # 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2.4 GHz: one FP64 VALU op per lane slot
         valu_peak = 256*4*16*2.4e9
@@ -1056,15 +1292,19 @@ def run_single(args, torch, dev, rank=0):
             'achieved': round(tests/(ms*1e-3), 1), 'peak': round(valu_peak/per_test, 1),
             'frac': round(tests/(ms*1e-3)/(valu_peak/per_test), 4), 'traffic': None,
             'kernel_ms': round(ms, 4), 'pair_tests_per_launch': int(tests),
-            'dense_tiles': None if args.sr_tiles else dense_tiles,
-            'receivers_in_dense_tiles': None if args.sr_tiles else dense_receivers,
-            'note': ('the sweep is not HBM-bound (72 B per particle against ~600 pair tests); '
-                     f'peak = FP64 vector issue rate {valu_peak:.3g} lane-ops/s / {per_test} '
-                     'FP64 VALU instructions per pair test; pair tests = those of the half-tile '
-                     'cells geometry (5 x 5 x 6 cells per receiver) — the receivers in dense '
-                     'tiles go through a sweep that tests about half as many, so that with '
-                     'dense tiles "achieved" is work done per second in the cells sweep\'s '
-                     'units, not tests executed')}
+            'pairs_in_range_per_launch': int(hits),
+            'tests_per_hit': round(tests/max(hits, 1), 3),
+            'lane_slots_per_launch': int(64*trips),
+            'lane_use': round(tests/max(64*trips, 1), 4),
+            'by_kernel': {k: {'pair_tests': v[0], 'in_range': v[1], 'wave_trips': v[2]}
+                          for k, v in st.items()},
+            'dense_tiles': dense_tiles, 'receivers_in_dense_tiles': dense_receivers,
+            'note': ('the sweep is not HBM-bound (72 B per particle against hundreds of pair '
+                     f'tests); peak = FP64 vector issue rate {valu_peak:.3g} lane-ops/s / '
+                     f'{per_test} FP64 VALU instructions per pair test; pair tests = EXECUTED '
+                     'tests counted on the device (half-tile cells sweep + dense tiles\' sweep), '
+                     'tests_per_hit = executed tests per pair inside the force range, lane_use = '
+                     'tests per lane slot of the pair loops')}
     else:
         ach = mv[dom]/(kernels[dom]*1e-3)/1e9
         traffic, traffic_source = pmc_traffic(dom, name)
@@ -1096,6 +1336,35 @@ def run_single(args, torch, dev, rank=0):
             'survey_8d_GB': round(credit/1e9, 2)}
     result['phases'] = phases
     del pos, mom, pos2, mom2
+    if fused and args.dist == 'uniform' and not args.no_verify and not args.weak:
+        # the values an N-rank run of this command is checked against (its `verify` block):
+        # the same step sequence once more, untimed, with the identifiers travelling
+        import types
+        torch.cuda.empty_cache()
+        steps_total = args.warmup + args.steps
+        rep = verify_replay(torch, args, types.SimpleNamespace(mesh=mesh), name, n_p, N, L, dev,
+                            0, 1, steps_total)
+        import numpy as np
+        order = np.argsort(rep['ids'])
+        key = verify_key(args, name, steps_total)
+        path = verify_save(key, rep['ids'][order], rep['pos'][order], rep['mom'][order],
+                           rep['n_local'], rep['sum_mom2'],
+                           {'made_by': f'bench.py --gpus 1 --steps {args.steps} --warmup '
+                                       f'{args.warmup} --seed {args.seed}'
+                                       + (f' --workload {args.workload}' if args.workload else '')})
+        result['verify'] = {
+            'key': key, 'role': 'reference (1 rank)', 'written_to': os.path.relpath(path, REPO),
+            'particles': rep['n_local'], 'particles_expected': n_p,
+            'sum_mom2_replay': rep['sum_mom2'], 'sum_mom2_timed_run': timed_m2,
+            'timed_vs_replay_rel': abs(timed_m2 - rep['sum_mom2'])/rep['sum_mom2'],
+            'sample': int(len(order)),
+            'ok': bool(rep['n_local'] == n_p
+                       and abs(timed_m2 - rep['sum_mom2']) <= 1e-12*rep['sum_mom2']),
+            'what': ('the timed step sequence run once more, untimed, through the sharded code '
+                     'path (ParticleStore / RegionParticles / pm_step_regions on one domain) with '
+                     f'the identifiers travelling; the {VERIFY_SAMPLES} particles with '
+                     f'identifiers k * n/{VERIFY_SAMPLES} are what `--gpus N` runs of this '
+                     'command compare their own with')}
     mesh.close()
     return result
 

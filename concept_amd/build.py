@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libconcept_gpu.so')
-SOURCES = ['cg_context.hip', 'cg_mesh_kernels.hip', 'cg_tiled_kernels.hip', 'cg_fft.hip', 'cg_shortrange.hip', 'cg_shortrange_mfma.hip', 'cg_shortrange_dense.hip', 'cg_rungs.hip',
+SOURCES = ['cg_context.hip', 'cg_mesh_kernels.hip', 'cg_tiled_kernels.hip', 'cg_fft.hip', 'cg_shortrange.hip', 'cg_shortrange_dense.hip', 'cg_rungs.hip',
            'cg_particles.hip', 'cg_general.hip', 'cg_pp.hip']
 HEADERS = [os.path.join(CSRC, 'cg_internal.h'), os.path.join(CSRC, 'cg_kspace.h'), os.path.join(CSRC, 'cg_tiles.h'), os.path.join(REPO, 'include', 'concept_gpu.h')]
 

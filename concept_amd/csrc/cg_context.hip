@@ -429,6 +429,8 @@ extern "C" int cg_destroy(cg_ctx *c) {
     (void)hipFree(c->tile_cursor);
     (void)hipFree(c->err_flags);
     (void)hipFree(c->sr_tile_active);
+    (void)hipFree(c->mom2_partial);
+    (void)hipFree(c->sr_stats);
     (void)hipFree(c->sr_sparse_partial);
     (void)hipFree(c->scan_tmp);
     (void)hipFree(c->tile_order_buf);
@@ -438,6 +440,8 @@ extern "C" int cg_destroy(cg_ctx *c) {
     (void)hipFree(c->srd_small);
     (void)hipFree(c->srd_buf);
     (void)hipFree(c->srd_rung);
+    for (auto &look : c->srd_look)
+        if (look.ev) (void)hipEventDestroy(look.ev);
     if (c->srd_host) (void)hipHostFree(c->srd_host);
     if (c->srd_stream) {
         (void)hipStreamDestroy(c->srd_stream);
@@ -891,6 +895,12 @@ extern "C" int cg_set_emigrant_rows(cg_ctx *c, double *rows, uint32_t *count, in
     return 0;
 }
 
+extern "C" int cg_set_momentum_sum(cg_ctx *c, double *sum_out) {
+    CG_CHECK(c, "cg_set_momentum_sum: null context");
+    c->mom2_sum_out = sum_out;
+    return 0;
+}
+
 extern "C" int cg_emigrant_rows_dest(cg_ctx *c, const double *rows, const uint32_t *count,
                                      int64_t cap, int32_t *dest, int32_t *send_counts) {
     CG_CHECK(c && send_counts && (cap == 0 || (rows && count && dest)),
@@ -966,53 +976,6 @@ extern "C" int cg_cic_indices(cg_ctx *c, const double *pos, int64_t n, int for_g
     return cgk_cic_indices(c, pos, n, for_gather, idx_out);
 }
 
-extern "C" int cg_shortrange_build(cg_ctx *c, const double *pos, int64_t n, int64_t nt,
-                                   double tile_extent, uint32_t *order_out,
-                                   uint32_t *offset_out) {
-    CG_CHECK(c && offset_out && (n == 0 || (pos && order_out)), "cg_shortrange_build: null argument");
-    CG_CHECK(nt >= 4, "The global gravity tiling needs to have at least 4 tiles across the box in "
-                      "every direction (species.py:3971); got %lld", (long long)nt);
-    CG_CHECK(nt <= 1024 && n < (1ll << 32), "cg_shortrange_build: size out of range");
-    CG_CHECK(tile_extent > 0, "cg_shortrange_build: tile_extent must be positive");
-    return cgk_shortrange_build(c, pos, n, nt, tile_extent, order_out, offset_out);
-}
-
-extern "C" int cg_shortrange_sweep(cg_ctx *c, const double *pos_r, const uint32_t *order_r,
-                                   const uint32_t *offset_r, double *dmom_r, const double *pos_s,
-                                   const uint32_t *order_s, const uint32_t *offset_s, int64_t nt,
-                                   int same_component, const double *table, int64_t tablesize,
-                                   double r2_index_scaling, double r2_max, double factor) {
-    // (particle arrays of an empty set may be null: only what the offsets span is touched)
-    CG_CHECK(c && offset_r && offset_s && table, "cg_shortrange_sweep: null argument");
-    CG_CHECK(nt >= 4 && nt <= 1024, "cg_shortrange_sweep: nt = %lld", (long long)nt);
-    // the largest index the sweep can form is int(r2_max*scaling): must be inside the table
-    CG_CHECK((int64_t)(r2_max * r2_index_scaling) < tablesize,
-             "cg_shortrange_sweep: table of %lld entries too short for r2_max*scaling = %g",
-             (long long)tablesize, r2_max * r2_index_scaling);
-    return cgk_shortrange_sweep(c, pos_r, order_r, offset_r, dmom_r, pos_s, order_s, offset_s, nt,
-                                same_component, table, r2_index_scaling, r2_max, factor, nullptr,
-                                nullptr, nullptr, 0);
-}
-
-extern "C" int cg_shortrange_sweep_rungs(cg_ctx *c, const double *pos_r, const uint32_t *order_r,
-                                         const uint32_t *offset_r, double *dmom_r,
-                                         const double *pos_s, const uint32_t *order_s,
-                                         const uint32_t *offset_s, int64_t nt, int same_component,
-                                         const double *table, int64_t tablesize,
-                                         double r2_index_scaling, double r2_max,
-                                         const double *factors, const int8_t *rung_r,
-                                         const int8_t *rung_jumped_r, int lowest_active_rung) {
-    CG_CHECK(c && offset_r && offset_s && table && factors,
-             "cg_shortrange_sweep_rungs: null argument");
-    CG_CHECK(nt >= 4 && nt <= 1024, "cg_shortrange_sweep_rungs: nt = %lld", (long long)nt);
-    CG_CHECK((int64_t)(r2_max * r2_index_scaling) < tablesize,
-             "cg_shortrange_sweep_rungs: table too short");
-    return cgk_shortrange_sweep(c, pos_r, order_r, offset_r, dmom_r, pos_s, order_s, offset_s, nt,
-                                same_component, table, r2_index_scaling, r2_max, 0.0, factors,
-                                (const signed char *)rung_r, (const signed char *)rung_jumped_r,
-                                lowest_active_rung);
-}
-
 extern "C" int cg_shortrange_cells(cg_ctx *c, const double *pos, int64_t n, int64_t nt,
                                    double tile_extent, uint32_t *order_out,
                                    uint32_t *offset_out, double *pos_sorted_out) {
@@ -1021,7 +984,11 @@ extern "C" int cg_shortrange_cells(cg_ctx *c, const double *pos, int64_t n, int6
     CG_CHECK(nt >= 4, "The global gravity tiling needs to have at least 4 tiles across the box in "
                       "every direction (species.py:3971); got %lld", (long long)nt);
     CG_CHECK(nt <= 512 && n < (1ll << 32), "cg_shortrange_cells: size out of range");
-    CG_CHECK(tile_extent > 0, "cg_shortrange_cells: tile_extent must be positive");
+    // the sweeps take the tile extent from the box (species.py:607-609): a list made with another
+    // one would put a particle on a tile border into one tile here and into its neighbour there
+    CG_CHECK(tile_extent == c->p.boxsize / (double)nt,
+             "cg_shortrange_cells: tile_extent must be boxsize/nt (%.17g), got %.17g",
+             c->p.boxsize / (double)nt, tile_extent);
     return cgk_shortrange_cells(c, pos, n, nt, tile_extent, order_out, offset_out,
                                 pos_sorted_out);
 }
@@ -1076,47 +1043,38 @@ extern "C" int cg_shortrange_sweep_cells_rungs(
                                       (const signed char *)rung_jumped_r, lowest_active_rung);
 }
 
+extern "C" int cg_shortrange_stats(cg_ctx *c, int enable, uint64_t *out) {
+    CG_CHECK(c, "cg_shortrange_stats: null context");
+    if (enable) {
+        if (!c->sr_stats) CG_HIP(hipMalloc((void **)&c->sr_stats, 8 * sizeof(uint64_t)));
+        CG_HIP(hipMemsetAsync(c->sr_stats, 0, 8 * sizeof(uint64_t), c->stream));
+        return 0;
+    }
+    if (!c->sr_stats) {
+        if (out) memset(out, 0, 8 * sizeof(uint64_t));
+        return 0;
+    }
+    CG_HIP(hipStreamSynchronize(c->stream));
+    if (out) CG_HIP(hipMemcpy(out, c->sr_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    (void)hipFree(c->sr_stats);
+    c->sr_stats = nullptr;
+    return 0;
+}
+
 extern "C" int cg_shortrange_tiles(cg_ctx *c, const double *pos, int64_t n, int64_t nt,
                                    double tile_extent, const int8_t *rung,
                                    int lowest_active_rung, uint32_t *order_out,
-                                   uint32_t *offset_out, double *pos_sorted_out,
-                                   float *operand_out) {
-    CG_CHECK(c && offset_out && (n == 0 || (pos && order_out && pos_sorted_out)),
+                                   uint32_t *offset_out, double *pos_sorted_out) {
+    CG_CHECK(c && offset_out && (n == 0 || (pos && order_out)),
              "cg_shortrange_tiles: null argument");
     CG_CHECK(nt >= 4, "The global gravity tiling needs to have at least 4 tiles across the box in "
                       "every direction (species.py:3971); got %lld", (long long)nt);
     CG_CHECK(nt <= 1024 && n < (1ll << 32), "cg_shortrange_tiles: size out of range");
-    CG_CHECK(tile_extent > 0, "cg_shortrange_tiles: tile_extent must be positive");
+    CG_CHECK(tile_extent == c->p.boxsize / (double)nt,
+             "cg_shortrange_tiles: tile_extent must be boxsize/nt (%.17g), got %.17g",
+             c->p.boxsize / (double)nt, tile_extent);
     return cgk_shortrange_tiles(c, pos, n, nt, tile_extent, (const signed char *)rung,
-                                lowest_active_rung, order_out, offset_out, pos_sorted_out,
-                                operand_out);
-}
-
-extern "C" int cg_shortrange_sweep_tiles(cg_ctx *c, const double *pos_r_sorted,
-                                         const uint32_t *order_r, const uint32_t *offset_r,
-                                         double *dmom_r, const double *pos_s_sorted,
-                                         const uint32_t *offset_s, const float *operand_s,
-                                         int64_t n_s, int64_t nt, const double *table,
-                                         int64_t tablesize, double r2_index_scaling,
-                                         double r2_max, double factor, const double *factors,
-                                         const int8_t *rung_jumped_r) {
-    CG_CHECK(c && offset_r && offset_s && table, "cg_shortrange_sweep_tiles: null argument");
-    CG_CHECK(n_s == 0 || (pos_s_sorted && operand_s),
-             "cg_shortrange_sweep_tiles: the supplier list lacks its positions or operand rows");
-    CG_CHECK(nt >= 4 && nt <= 1024, "cg_shortrange_sweep_tiles: nt = %lld", (long long)nt);
-    CG_CHECK((factors == nullptr) == (rung_jumped_r == nullptr),
-             "cg_shortrange_sweep_tiles: factors and rung_jumped come together");
-    // the largest index the sweep can form is int(r2_max*scaling): must be inside the table
-    CG_CHECK((int64_t)(r2_max * r2_index_scaling) < tablesize,
-             "cg_shortrange_sweep_tiles: table of %lld entries too short for r2_max*scaling = %g",
-             (long long)tablesize, r2_max * r2_index_scaling);
-    // a receiver meets the tiles around its own only: the force range must not exceed one tile
-    CG_CHECK(r2_max <= (c->p.boxsize / (double)nt) * (c->p.boxsize / (double)nt) * (1 + 1e-12),
-             "cg_shortrange_sweep_tiles: the force range exceeds the tile extent");
-    return cgk_shortrange_sweep_tiles(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted,
-                                      offset_s, operand_s, n_s, nt, table, tablesize,
-                                      r2_index_scaling, r2_max, factor, factors,
-                                      (const signed char *)rung_jumped_r);
+                                lowest_active_rung, order_out, offset_out, pos_sorted_out);
 }
 
 extern "C" int cg_dmom_nullify(cg_ctx *c, double *dmom, const int8_t *rung, int64_t n,

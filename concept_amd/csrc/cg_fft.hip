@@ -994,10 +994,8 @@ static int run_strided_r(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
     constexpr int NT = NTW < 64 ? 64 : (NTW > 1024 ? 1024 : NTW);
     const int nkb = (int)((c->N / 2 + 1 + W - 1) / W);
     size_t lds = sizeof(double2) * N * W;
-    static int persist = -1, ncu = 0;
-    if (persist < 0) {
-        const char *env = getenv("CONCEPT_GPU_FFT_PERSIST");
-        persist = env ? atoi(env) : 1;
+    static int ncu = 0;
+    if (!ncu) {
         hipDeviceProp_t prop;
         CG_HIP(hipGetDeviceProperties(&prop, c->p.device));
         ncu = prop.multiProcessorCount;
@@ -1012,7 +1010,7 @@ static int run_strided_r(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
     constexpr bool can_persist = R16 && LOGN <= 11 && N * W == 16 * NT && NT % W == 0 &&
                                  lds_p <= 160 * 1024;
     if constexpr (can_persist) {
-        if (persist && ntiles >= 4 * (i64)ncu && smap.sh == 31 && dmap.sh == 31) {
+        if (ntiles >= 4 * (i64)ncu && smap.sh == 31 && dmap.sh == 31) {
             auto kern = k_fft_strided_p<LOGN, NT, MODE, W>;
             static bool attr_set_p[64] = {};  // per device: one process may drive several
             const int dev_p = c->p.device & 63;
@@ -1054,9 +1052,12 @@ static int run_strided_h(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
     *done = false;
     static int enabled = -1, ncu = 0;
     if (enabled < 0) {
+        // CONCEPT_GPU_FFT_SPLIT=0: the whole-pencil passes everywhere (what small meshes and the
+        // blocked maps of narrow slabs take anyway: the tests run them at size this way);
+        // 2: the split pass at 512 points too (it does not pay there: 0.48 against 0.46 ms)
         const char *env = getenv("CONCEPT_GPU_FFT_SPLIT");
         enabled = env ? atoi(env) : 1;
-        if (LOGN < 10 && enabled < 2) enabled = 0;  // (512 and below: only on request, for A/B)
+        if (LOGN < 10 && enabled < 2) enabled = 0;
         hipDeviceProp_t prop;
         CG_HIP(hipGetDeviceProperties(&prop, c->p.device));
         ncu = prop.multiProcessorCount;
@@ -1091,19 +1092,11 @@ static int run_strided_h(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
     return 0;
 }
 
-// Radix schedule of the in-LDS transform: CONCEPT_GPU_FFT_RADIX = 4 | 16 for A/B.
+// (radix-16 schedule of the in-LDS transform: the radix-4 one of round 1 lost)
 template <int LOGN, int MODE, int W>
 static int run_strided_w(cg_ctx *c, const double2 *src, double2 *dst, PencilMap smap,
                          PencilMap dmap, i64 nouter, i64 o_off, const KspaceParams &P) {
-    static int radix = 0;
-    if (!radix) {
-        const char *env = getenv("CONCEPT_GPU_FFT_RADIX");
-        radix = env ? atoi(env) : 16;
-        if (radix != 4 && radix != 16) radix = 16;
-    }
-    if (radix == 16)
-        return run_strided_r<LOGN, MODE, W, true>(c, src, dst, smap, dmap, nouter, o_off, P);
-    return run_strided_r<LOGN, MODE, W, false>(c, src, dst, smap, dmap, nouter, o_off, P);
+    return run_strided_r<LOGN, MODE, W, true>(c, src, dst, smap, dmap, nouter, o_off, P);
 }
 
 // W adjacent kk per workgroup.  Measured at 1024^3 (ms per y pass / fused x pass):
@@ -1111,26 +1104,17 @@ static int run_strided_w(cg_ctx *c, const double2 *src, double2 *dst, PencilMap 
 //   W = 4 (64 B, 2 per CU)                          4.6 / 7.9
 //   W = 8 (128 B = one full cache line, 1 per CU)   3.95 / 7.4
 // The row-segment width, not the occupancy, decides: default 8 (N <= 1024; 8 pencils of
-// 2048 points exceed the 160 KB LDS, so 4 there).  CONCEPT_GPU_FFT_W overrides for A/B.
+// 2048 points exceed the 160 KB LDS, so 4 there).
 template <int LOGN, int MODE>
 static int run_strided(cg_ctx *c, const double2 *src, double2 *dst, PencilMap smap,
                        PencilMap dmap, i64 nouter, i64 o_off, const KspaceParams &P) {
-    static int w = 0;
-    if (!w) {
-        const char *env = getenv("CONCEPT_GPU_FFT_W");
-        w = env ? atoi(env) : 8;
-        if (w != 2 && w != 4 && w != 8) w = 8;
-    }
-    if (w == 2) return run_strided_w<LOGN, MODE, 2>(c, src, dst, smap, dmap, nouter, o_off, P);
     if constexpr (LOGN >= 9 && LOGN <= 11) {  // the even/odd split pass (k_fft_strided_h)
-        if (w == 8) {
-            bool done = false;
-            if (int rc = run_strided_h<LOGN, MODE>(c, src, dst, smap, dmap, nouter, o_off, P, &done))
-                return rc;
-            if (done) return 0;
-        }
+        bool done = false;
+        if (int rc = run_strided_h<LOGN, MODE>(c, src, dst, smap, dmap, nouter, o_off, P, &done))
+            return rc;
+        if (done) return 0;
     }
-    if (w == 8 && LOGN <= 10)  // 8 pencils of 2048 points would not fit the 160 KB LDS
+    if (LOGN <= 10)  // 8 pencils of 2048 points would not fit the 160 KB LDS
         return run_strided_w<(LOGN <= 10 ? LOGN : 10), MODE, 8>(c, src, dst, smap, dmap, nouter,
                                                                 o_off, P);
     return run_strided_w<LOGN, MODE, 4>(c, src, dst, smap, dmap, nouter, o_off, P);
@@ -1144,16 +1128,7 @@ static PencilMap plain_map(i64 ostride, i64 es) { return PencilMap{ostride, es, 
 // infinity cache (the cliff sits just above 32 layers = 273 MB), and among the sizes that do,
 // those whose tile count nl*ceil((N/2+1)/8) fills whole rounds of the persistent y pass (one
 // workgroup per CU) win: 31 layers = 2015 tiles = 7.9 rounds of 256 beats 32 = 8.1 rounds.
-// CONCEPT_GPU_FFT_CHUNK overrides (0 = whole mesh, no chunks).
 static i64 zy_chunk_layers(cg_ctx *c) {
-    static int env_chunk = -1;
-    if (env_chunk < 0) {
-        const char *env = getenv("CONCEPT_GPU_FFT_CHUNK");
-        env_chunk = env ? atoi(env) : -2;
-        if (env_chunk == -1) env_chunk = -2;
-    }
-    if (env_chunk == 0) return c->N + 1;
-    if (env_chunk > 0) return env_chunk;
     static int ncu = 0;
     if (!ncu) {
         hipDeviceProp_t prop;

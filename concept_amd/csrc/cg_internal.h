@@ -125,6 +125,7 @@ struct cg_ctx {
     // in turn), created at the first sweep
     hipStream_t sr_streams[3] = {nullptr, nullptr, nullptr};
     hipEvent_t sr_fork = nullptr, sr_join[3] = {nullptr, nullptr, nullptr};
+    unsigned long long *sr_stats = nullptr;   // cg_shortrange_stats: device counters while on
     unsigned char *sr_tile_active = nullptr;  // cells sweep with rungs: one byte per tile
     double *sr_sparse_partial = nullptr;      // cg_shortrange_sparse: per-workgroup partial sums
     size_t sr_tile_active_cap = 0;
@@ -147,14 +148,22 @@ struct cg_ctx {
     size_t scan_tmp_bytes = 0;
     void *sr_tmp = nullptr;  // short-range cell-list counters
     size_t sr_tmp_bytes = 0;
-    // lists by tile: rows of the densely populated tiles re-ordered by sub-cell (scratch)
-    // the dense tiles' sweep (cg_shortrange_dense.hip): counters, pinned read-back, lists, stream
+    // the dense tiles' sweep (cg_shortrange_dense.hip): counters, pinned read-back, lists, stream;
+    // srd_look: what is known about the cell lists built last (keyed by their offsets' address)
+    struct SrdLook {
+        const unsigned *off = nullptr;
+        i64 nt = 0;
+        int min_pop = 0;
+        hipEvent_t ev = nullptr;
+    } srd_look[4];
+    int srd_look_next = 0, srd_idle = 0;
+    bool srd_hilbert_done = false;
     unsigned *srd_host = nullptr;
     void *srd_small = nullptr, *srd_buf = nullptr, *srd_rung = nullptr;
     size_t srd_small_bytes = 0, srd_buf_bytes = 0, srd_rung_bytes = 0;
     hipStream_t srd_stream = nullptr;
     hipEvent_t srd_fork = nullptr, srd_join = nullptr;
-    void *sr_sub_tmp = nullptr;
+    void *sr_sub_tmp = nullptr;  // rows of the dense tiles while they are re-ordered by sub-cell
     size_t sr_sub_bytes = 0;
     i64 ntiles = 0;
     CicGeom geom_deposit{}, geom_gather{};
@@ -169,6 +178,9 @@ struct cg_ctx {
     i64 emig_cap = 0;
     // fused kick + drift + scatter on x-slab domains: the particles the drift takes out of the
     // slab are appended here as rows of 8 doubles (pos 3, mom 3, id bits, unused) — caller-owned
+    // cg_set_momentum_sum: where the fused pass leaves the sum of |mom|^2 (null: not summed)
+    double *mom2_sum_out = nullptr, *mom2_partial = nullptr;
+    size_t mom2_partial_bytes = 0;
     double *emig_rows = nullptr;
     unsigned *emig_rows_count = nullptr;
     i64 emig_rows_cap = 0;
@@ -191,14 +203,6 @@ int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst);
 int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
              double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out,
              int drift, double dt_over_mass, int use_prepared);
-int cgk_shortrange_build(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
-                         unsigned *order, unsigned *offset);
-int cgk_shortrange_sweep(cg_ctx *c, const double *pos_r, const unsigned *order_r,
-                         const unsigned *off_r, double *dmom_r, const double *pos_s,
-                         const unsigned *order_s, const unsigned *off_s, i64 nt, int same,
-                         const double *table, double r2_index_scaling, double r2_max,
-                         double factor, const double *factors, const signed char *rung,
-                         const signed char *rung_jumped, int lowest_active);
 int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
                          unsigned *order, unsigned *offset, double *pos_sorted);
 int cgk_shortrange_sparse(cg_ctx *c, const double *pos_r, const i64 *active, int K, double *dmom_r,
@@ -220,19 +224,13 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
                          const unsigned char *active_in, const unsigned char **take_out);
 int cgk_shortrange_tiles_phase(cg_ctx *c, int phase, const double *pos, i64 n, i64 nt,
                                double tile_extent, const signed char *rung, int lowest_active,
-                               unsigned *order, unsigned *offset, double *pos_sorted, float *aop);
+                               unsigned *order, unsigned *offset, double *pos_sorted,
+                               i64 sub_min, i64 sub_rows);
 int cgk_shortrange_dense_join(cg_ctx *c);
-int cgk_shortrange_subsort(cg_ctx *c, const unsigned *offset, i64 n, i64 nper, double extent,
-                           unsigned *order, double *pos_sorted, float *aop);
+int cgk_shortrange_dense_look(cg_ctx *c, const unsigned *off_cells, i64 nt);
 int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
                          const signed char *rung, int lowest_active, unsigned *order,
-                         unsigned *offset, double *pos_sorted, float *aop);
-int cgk_shortrange_sweep_tiles(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
-                               const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
-                               const unsigned *off_s, const float *aop_s, i64 n_s, i64 nt,
-                               const double *table, int64_t tablesize, double r2_index_scaling,
-                               double r2_max, double factor, const double *factors,
-                               const signed char *rung_jumped);
+                         unsigned *offset, double *pos_sorted);
 int cgk_dmom_active(cg_ctx *c, double *mom, double *dmom, const signed char *rung, i64 n,
                     int lowest_active, int op);
 int cgk_dmom_to_acc(cg_ctx *c, double *dmom, const signed char *rung,

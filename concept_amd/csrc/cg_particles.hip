@@ -334,16 +334,7 @@ int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *i
     // One 256-lane workgroup per 256 particles, no grid-stride loop: with the grid capped at
     // 4096 workgroups the scatter took 5.9 ms at 2^28 particles, uncapped 5.1 ms (the same
     // holds for a plain copy kernel, tools/copy_probe.cpp: 4.9 vs 5.6 TB/s).
-    // CONCEPT_GPU_SCATTER_BLOCKS=<cap> restores a cap for A/B.
-    i64 blocks = (n + 255) / 256;
-    {
-        static i64 cap = -1;
-        if (cap < 0) {
-            const char *env = getenv("CONCEPT_GPU_SCATTER_BLOCKS");
-            cap = env ? atoll(env) : 0;
-        }
-        if (cap > 0 && blocks > cap) blocks = cap;
-    }
+    const i64 blocks = (n + 255) / 256;
     if (n > 0 && !use_prepared) {
         if (drift)
             hipLaunchKernelGGL(k_tile_histogram<true>, dim3((unsigned)blocks), dim3(256), 0,

@@ -1,4 +1,4 @@
-// cg_shortrange.hip — P3M short-range tile sweep (A13-A15) on gfx950.
+// cg_shortrange.hip — P3M short-range sweep over half-tile cells (A13-A15) on gfx950.
 //
 //   Tiling.sort                 species.py:707-823      particle -> tile
 //   particle_particle           interactions.py:1563-1791  tile neighbours, periodic offset,
@@ -8,15 +8,14 @@
 // Form: one-sided.  The reference visits every unordered pair once and updates
 // both partners (Δmom_r += r*f, Δmom_s -= r*f); here every receiver particle
 // sums over all its partners itself — twice the arithmetic, but no atomics, no
-// write conflicts (the order of partners inside a tile follows the cell-list
+// write conflicts (the order of partners inside a cell follows the cell-list
 // scatter, so sums are reproducible to rounding, not bit for bit).  The pair
 // vector, r2 and the table index are evaluated with the reference's expression
 // and operation order ((xi - xj) + offset; x*x + y*y + z*z; int(r2*scaling)):
 // exact negation symmetry makes the two directions of a pair bit-consistent.
-//
-// Layout: a cell list over the short-range tiling (uint32 order[] + offset[]);
-// one wavefront per receiver tile; supplier tiles are staged through LDS in
-// chunks of 64 and broadcast to all lanes.
+// (The tiles of 64 particles and more go to cg_shortrange_dense.hip; earlier forms of the
+// sweep — one wavefront per tile, a single-precision pre-test, a matrix-core range filter —
+// were measured slower and are gone: profiles/README.md keeps their numbers.)
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
@@ -33,108 +32,9 @@
         }                                                                                     \
     } while (0)
 
-// Tiling.sort (species.py:775-780) with tiling location 0:
-//   i = int((x - loc*(1 + 2 eps))*((1/tile_extent)*(1 - 2 eps)))
-__device__ __forceinline__ unsigned sr_tile(const double *__restrict__ pos, i64 p, double inv,
-                                            unsigned nt) {
-    unsigned i = (unsigned)(i64)((pos[3 * p + 0] - 0.0) * inv);
-    unsigned j = (unsigned)(i64)((pos[3 * p + 1] - 0.0) * inv);
-    unsigned k = (unsigned)(i64)((pos[3 * p + 2] - 0.0) * inv);
-    // a position exactly at boxsize cannot occur (drift wraps into [0, L)); clamp anyway
-    i = i >= nt ? nt - 1 : i;
-    j = j >= nt ? nt - 1 : j;
-    k = k >= nt ? nt - 1 : k;
-    return (i * nt + j) * nt + k;
-}
-
-// runs of equal keys inside a wavefront -> one atomic per run (device-scope atomics are
-// memory-side on MI355X; particle memory is in mesh-tile order, so runs are long)
-__device__ __forceinline__ void sr_wave_runs(unsigned key, int lane, int &run_start, int &run_len) {
-    unsigned prev = __shfl_up(key, 1);
-    bool head = (lane == 0) || (key != prev);
-    unsigned long long mask = __ballot(head);
-    unsigned long long below = mask & (~0ull >> (63 - lane));
-    run_start = 63 - __clzll(below);
-    unsigned long long above = (lane == 63) ? 0ull : (mask >> (lane + 1));
-    int next = above ? (lane + 1 + (__ffsll((long long)above) - 1)) : 64;
-    run_len = next - run_start;
-}
-
-__global__ __launch_bounds__(256) void k_sr_histogram(const double *__restrict__ pos, i64 n,
-                                                      double inv, unsigned nt,
-                                                      unsigned *__restrict__ count) {
-    i64 stride = (i64)gridDim.x * blockDim.x;
-    int lane = threadIdx.x & 63;
-    for (i64 base = (i64)blockIdx.x * blockDim.x; base < n; base += stride) {
-        i64 p = base + threadIdx.x;
-        unsigned key = p < n ? sr_tile(pos, p, inv, nt) : 0xffffffffu;
-        int rs, rl;
-        sr_wave_runs(key, lane, rs, rl);
-        if (lane == rs && p < n) atomicAdd(&count[key], (unsigned)rl);
-    }
-}
-__global__ __launch_bounds__(256) void k_sr_scatter(const double *__restrict__ pos, i64 n,
-                                                    double inv, unsigned nt,
-                                                    const unsigned *__restrict__ offset,
-                                                    unsigned *__restrict__ cursor,
-                                                    unsigned *__restrict__ order) {
-    i64 stride = (i64)gridDim.x * blockDim.x;
-    int lane = threadIdx.x & 63;
-    for (i64 base = (i64)blockIdx.x * blockDim.x; base < n; base += stride) {
-        i64 p = base + threadIdx.x;
-        unsigned key = p < n ? sr_tile(pos, p, inv, nt) : 0xffffffffu;
-        int rs, rl;
-        sr_wave_runs(key, lane, rs, rl);
-        unsigned first = 0;
-        if (lane == rs && p < n) first = offset[key] + atomicAdd(&cursor[key], (unsigned)rl);
-        first = __shfl(first, rs);
-        if (p < n) order[first + (lane - rs)] = (unsigned)p;
-    }
-}
-int cgk_shortrange_build(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
-                         unsigned *order, unsigned *offset) {
-    const double eps = 2.220446049250313e-16;
-    double inv = (1 / tile_extent) * (1 - 2 * eps);
-    i64 ntiles = nt * nt * nt;
-    if ((size_t)(8 * (ntiles + 1)) > c->sr_tmp_bytes) {
-        CG_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->sr_tmp);
-        c->sr_tmp = nullptr;
-        CG_HIP(hipMalloc(&c->sr_tmp, 8 * (ntiles + 1)));
-        c->sr_tmp_bytes = 8 * (ntiles + 1);
-    }
-    unsigned *count = (unsigned *)c->sr_tmp, *cursor = count + (ntiles + 1);
-    CG_HIP(hipMemsetAsync(c->sr_tmp, 0, 8 * (ntiles + 1), c->stream));
-    i64 blocks = (n + 255) / 256;  // one workgroup per 256 particles (see cgk_sort)
-    if (n > 0) {
-        hipLaunchKernelGGL(k_sr_histogram, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n,
-                           inv, (unsigned)nt, count);
-        CG_LAUNCH_CHECK();
-    }
-    size_t need = 0;
-    CG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, count, offset, (int)(ntiles + 1),
-                                            c->stream));
-    if (need > c->scan_tmp_bytes) {
-        CG_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->scan_tmp);
-        c->scan_tmp = nullptr;
-        CG_HIP(hipMalloc(&c->scan_tmp, need));
-        c->scan_tmp_bytes = need;
-    }
-    CG_HIP(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp, need, count, offset, (int)(ntiles + 1),
-                                            c->stream));
-    if (n > 0) {
-        hipLaunchKernelGGL(k_sr_scatter, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n,
-                           inv, (unsigned)nt, offset, cursor, order);
-        CG_LAUNCH_CHECK();
-    }
-    return 0;
-}
-
 struct SrParams {
     double boxsize, r2_index_scaling, r2_max, factor;
     int nt;
-    int same;  // receiver and supplier arrays are the same component
     // adaptive rungs (null = every particle on rung 0 with `factor`): a receiver on an
     // active rung (rung >= lowest_active) is kicked with factors[rung_jumped]; inactive
     // receivers are skipped.  One-sided form of interactions.py:1688-1761 +
@@ -142,310 +42,27 @@ struct SrParams {
     const double *factors;
     const signed char *rung, *rung_jumped;
     int lowest_active;
-    float r2_pre;  // single-precision pre-test: a pair with |x_ji|^2 (float) above this is a miss
-    // cells sweep with rungs: one byte per tile, non-zero where a receiver of the tile sits on an
-    // active rung (k_sr_tile_activity; null = every tile takes part)
+    // one byte per tile, non-zero where the cells sweep has receivers to kick: a tile with a
+    // receiver on an active rung (k_sr_tile_activity) that the dense tiles' sweep has not
+    // taken (null = every tile takes part)
     const unsigned char *tile_active;
+    // cg_shortrange_stats: [0] pair tests executed (lanes that hold a receiver and a supplier of
+    // the range), [1] of them in range, [2] wavefront trips (64 lane slots each) — counted by the
+    // STATS instantiations only, which run while the statistics are switched on
+    unsigned long long *stats;
 };
-
-// The pair tests of one staged supplier chunk for this lane's receiver: branch-free (a miss adds
-// x*0) and with a wave-uniform trip count, so that the loop unrolls into straight-line code with
-// several table loads in flight.  SHIFTED (the supplier tile is a periodic image) and SELF (it is
-// the receiver's own tile of the same component: skip i == j) are wave-uniform and resolved at
-// compile time — as run-time conditions inside the loop they cost 9 selects and an LDS read per
-// pair (rocprofv3: the sweep is VALU-bound, VALUBusy 75 %).  For a hit the arithmetic and its
-// order are the reference's (gravity.py:299-349); r2 and the table index are bit-identical.
-constexpr int kSrStage = 128;  // staged suppliers per chunk
-
-template <bool SHIFTED, bool SELF>
-__device__ __forceinline__ void sr_pairs(int sub, int S, int cnt, double xi, double yi, double zi,
-                                         double ox, double oy, double oz, const double *sx,
-                                         const double *sy, const double *sz, const unsigned *sidx,
-                                         unsigned pi, double r2_max, double r2_index_scaling,
-                                         double my_factor, const double *__restrict__ table,
-                                         double &ax, double &ay, double &az) {
-#pragma unroll 4
-    for (int k0 = 0; k0 < cnt; k0 += S) {
-        const int kk = k0 + sub;
-        const int k = kk < kSrStage - 1 ? kk : kSrStage - 1;  // the staged arrays' last entry
-        double x_ji = xi - sx[k];                        // interactions.py:1787-1789
-        double y_ji = yi - sy[k];
-        double z_ji = zi - sz[k];
-        if (SHIFTED) {                                   // gravity.py:299-302
-            x_ji += ox;
-            y_ji += oy;
-            z_ji += oz;
-        }
-        const double r2 = x_ji * x_ji + y_ji * y_ji + z_ji * z_ji;  // gravity.py:306
-        bool hit = (kk < cnt) & !(r2 > r2_max);
-        if (SELF) hit &= sidx[k] != pi;
-        // (a fully branch-free form — table[hit ? idx : 0] loaded unconditionally, four loads in
-        // flight — measured slower: 15.3 vs 14.1 ms, it costs 12 more registers and the misses'
-        // loads; the compiler branches around the hit part per unrolled pair)
-        double total_factor = 0.0;
-        if (hit) {
-            const unsigned idx = (unsigned)(int)(r2 * r2_index_scaling);  // gravity.py:316
-            total_factor = my_factor * table[idx];                        // gravity.py:321
-        }
-        ax += x_ji * total_factor;
-        ay += y_ji * total_factor;
-        az += z_ji * total_factor;
-    }
-}
-
-__global__ __launch_bounds__(64) void k_sr_sweep(
-    const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
-    const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
-    const double *__restrict__ pos_s, const unsigned *__restrict__ order_s,
-    const unsigned *__restrict__ off_s, const double *__restrict__ table, SrParams P) {
-    // A tile holds ~20 particles with the default parameters, far fewer than the 64
-    // lanes: the wavefront is split into S = 64/R groups of R lanes (R = the receivers of a
-    // chunk); group s takes suppliers s, s+S, s+2S, ... of every staged chunk and the S
-    // partial sums of a receiver are folded with shuffles.
-    __shared__ double sx[kSrStage], sy[kSrStage], sz[kSrStage];
-    __shared__ unsigned sidx[kSrStage];
-    const int lane = threadIdx.x;
-    const int nt = P.nt;
-    const unsigned tr = blockIdx.x;
-    const unsigned rbeg = off_r[tr], rend = off_r[tr + 1];
-    if (rbeg == rend) return;
-    const int ra = tr / (nt * nt), rb = (tr / nt) % nt, rc = tr % nt;
-    for (unsigned base = rbeg; base < rend; base += 64) {
-        const int nrec = (int)min(64u, rend - base);
-        // R = nrec receivers x S = 64/nrec supplier groups: 22 receivers (the mean of the default
-        // tiling) give 2 x 22 lanes, 21 give 3 x 21 (a power-of-two R left 17..32 receivers at
-        // 2 groups)
-        const int R = nrec;
-        const int S = 64 / R, sub = lane / R, rl = lane - sub * R;
-        bool active = sub < S;
-        const unsigned pi = active ? order_r[base + rl] : 0u;
-        double my_factor = P.factor;
-        if (active && P.rung) {
-            if (P.rung[pi] < P.lowest_active) active = false;
-            else my_factor = P.factors[P.rung_jumped[pi]];
-        }
-        double xi = 0, yi = 0, zi = 0;
-        if (active) {
-            xi = pos_r[3 * (i64)pi];
-            yi = pos_r[3 * (i64)pi + 1];
-            zi = pos_r[3 * (i64)pi + 2];
-        }
-        double ax = 0, ay = 0, az = 0;
-        // The cell list is z-fastest: the three supplier tiles (sa, sb, rc-1 .. rc+1) of a
-        // column are one contiguous run of it, staged and swept as one range (9 ranges of ~66
-        // suppliers instead of 27 of ~22: a third of the staging round trips and barriers) unless
-        // the column wraps around the box in z, where the three tiles carry different offsets.
-        const bool zwrap = rc == 0 || rc == nt - 1;
-        for (int d = 0; d < (zwrap ? 27 : 9); d++) {
-            int sa, sb, sc0, sc1;
-            double ox = 0, oy = 0, oz = 0;
-            if (zwrap) {
-                sa = ra + d / 9 - 1;
-                sb = rb + (d / 3) % 3 - 1;
-                sc0 = rc + d % 3 - 1;
-                if (sc0 < 0) { sc0 += nt; oz = P.boxsize; } else if (sc0 >= nt) { sc0 -= nt; oz = -P.boxsize; }
-                sc1 = sc0;
-            } else {
-                sa = ra + d / 3 - 1;
-                sb = rb + d % 3 - 1;
-                sc0 = rc - 1;
-                sc1 = rc + 1;
-            }
-            // periodic offset from the tile separation (interactions.py:1615-1621)
-            if (sa < 0) { sa += nt; ox = P.boxsize; } else if (sa >= nt) { sa -= nt; ox = -P.boxsize; }
-            if (sb < 0) { sb += nt; oy = P.boxsize; } else if (sb >= nt) { sb -= nt; oy = -P.boxsize; }
-            const bool shifted = (ox != 0) | (oy != 0) | (oz != 0);
-            const unsigned ts0 = (unsigned)((sa * nt + sb) * nt + sc0);
-            const unsigned ts1 = (unsigned)((sa * nt + sb) * nt + sc1);
-            const unsigned sbeg = off_s[ts0], send = off_s[ts1 + 1];
-            const bool self = P.same && ts0 <= tr && tr <= ts1;  // the range holds the receivers
-            for (unsigned cb = sbeg; cb < send; cb += kSrStage) {
-                __syncthreads();
-#pragma unroll
-                for (int h = 0; h < kSrStage / 64; h++) {
-                    const int e = lane + 64 * h;
-                    if (cb + e < send) {
-                        unsigned pj = order_s[cb + e];
-                        sidx[e] = pj;
-                        sx[e] = pos_s[3 * (i64)pj];
-                        sy[e] = pos_s[3 * (i64)pj + 1];
-                        sz[e] = pos_s[3 * (i64)pj + 2];
-                    } else {
-                        // entries past the chunk are read (and masked) by sr_pairs: keep them
-                        // finite, a masked pair contributes x*0
-                        sx[e] = sy[e] = sz[e] = 0;
-                    }
-                }
-                __syncthreads();
-                const int cnt = (int)min((unsigned)kSrStage, send - cb);
-                if (active) {
-#define CG_SR_PAIRS(SH, SE)                                                                    \
-    sr_pairs<SH, SE>(sub, S, cnt, xi, yi, zi, ox, oy, oz, sx, sy, sz, sidx, pi, P.r2_max,      \
-                     P.r2_index_scaling, my_factor, table, ax, ay, az)
-                    if (shifted) {
-                        if (self) CG_SR_PAIRS(true, true);
-                        else CG_SR_PAIRS(true, false);
-                    } else {
-                        if (self) CG_SR_PAIRS(false, true);
-                        else CG_SR_PAIRS(false, false);
-                    }
-#undef CG_SR_PAIRS
-                }
-            }
-        }
-        // fold the S partial sums of each receiver (lanes rl, rl + R, rl + 2R, ...) into lane rl
-        {
-            double tx = ax, ty = ay, tz = az;
-            for (int g = 1; g < S; g++) {  // S is wave-uniform
-                const int src = (lane + g * R) & 63;
-                tx += __shfl(ax, src);
-                ty += __shfl(ay, src);
-                tz += __shfl(az, src);
-            }
-            ax = tx;
-            ay = ty;
-            az = tz;
-        }
-        if (active && sub == 0) {
-            dmom_r[3 * (i64)pi] += ax;
-            dmom_r[3 * (i64)pi + 1] += ay;
-            dmom_r[3 * (i64)pi + 2] += az;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Column form of the sweep.  With the default tiling a tile holds ~20 particles,
-// so one wavefront per tile leaves two thirds of the lanes idle.  Here a
-// workgroup owns a z-COLUMN of tiles (ra, rb, *): the cell list is z-fastest, so
-// the column's receivers are one contiguous run, cut into chunks of 64 lanes.
-// A chunk spans a few tiles tc_lo..tc_hi; its lanes test every particle of the
-// supplier tiles (sa, sb, tc_lo-1 .. tc_hi+1) of the 9 neighbouring columns.
-// A lane takes part only for the three supplier tiles adjacent to its own tile
-// (exactly the reference's pairs, each once), so a chunk spanning three tiles
-// keeps ~60 % of the lanes busy instead of ~34 %.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_sr_sweep_columns(
-    const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
-    const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
-    const double *__restrict__ pos_s, const unsigned *__restrict__ order_s,
-    const unsigned *__restrict__ off_s, const double *__restrict__ table, SrParams P,
-    double inv_extent) {
-    __shared__ double sx[64], sy[64], sz[64];
-    __shared__ unsigned sidx[64];
-    const int lane = threadIdx.x;
-    const int nt = P.nt;
-    const int ra = blockIdx.x / nt, rb = blockIdx.x % nt;
-    const unsigned col0 = (unsigned)((ra * nt + rb) * nt);
-    const unsigned cbeg = off_r[col0], cend = off_r[col0 + nt];
-    for (unsigned base = cbeg; base < cend; base += 64) {
-        const bool active = base + lane < cend;
-        const unsigned pi = active ? order_r[base + lane] : 0u;
-        double xi = 0, yi = 0, zi = 0;
-        int my_tc = 0;
-        if (active) {
-            xi = pos_r[3 * (i64)pi];
-            yi = pos_r[3 * (i64)pi + 1];
-            zi = pos_r[3 * (i64)pi + 2];
-            my_tc = (int)(i64)((zi - 0.0) * inv_extent);  // Tiling.sort expression
-            my_tc = my_tc >= nt ? nt - 1 : my_tc;
-        }
-        // tile range of this chunk (the list is sorted by tile: first / last active lane)
-        const int last = (int)min(63u, cend - base - 1);
-        const int tc_lo = __shfl(my_tc, 0), tc_hi = __shfl(my_tc, last);
-        double ax = 0, ay = 0, az = 0;
-        for (int d = 0; d < 9; d++) {
-            int sa = ra + d / 3 - 1, sb = rb + d % 3 - 1;
-            double ox = 0, oy = 0;
-            if (sa < 0) { sa += nt; ox = P.boxsize; } else if (sa >= nt) { sa -= nt; ox = -P.boxsize; }
-            if (sb < 0) { sb += nt; oy = P.boxsize; } else if (sb >= nt) { sb -= nt; oy = -P.boxsize; }
-            for (int sc_raw = tc_lo - 1; sc_raw <= tc_hi + 1; sc_raw++) {
-                int sc = sc_raw;
-                double oz = 0;
-                if (sc < 0) { sc += nt; oz = P.boxsize; } else if (sc >= nt) { sc -= nt; oz = -P.boxsize; }
-                const bool shifted = (ox != 0) | (oy != 0) | (oz != 0);
-                const unsigned ts = (unsigned)((sa * nt + sb) * nt + sc);
-                const unsigned sbeg = off_s[ts], send = off_s[ts + 1];
-                for (unsigned cb = sbeg; cb < send; cb += 64) {
-                    __syncthreads();
-                    if (cb + lane < send) {
-                        unsigned pj = order_s[cb + lane];
-                        sidx[lane] = pj;
-                        sx[lane] = pos_s[3 * (i64)pj];
-                        sy[lane] = pos_s[3 * (i64)pj + 1];
-                        sz[lane] = pos_s[3 * (i64)pj + 2];
-                    }
-                    __syncthreads();
-                    const int cnt = (int)min(64u, send - cb);
-                    // a supplier tile two or more tiles away from a lane's own tile is not
-                    // its neighbour: with a periodic shift its image could alias a true
-                    // neighbour, so such lanes sit the tile out
-                    int dz = sc_raw - my_tc;
-                    if (active && dz >= -1 && dz <= 1) {
-                        for (int k = 0; k < cnt; k++) {
-                            if (P.same && sidx[k] == pi) continue;
-                            double x_ji = xi - sx[k];
-                            double y_ji = yi - sy[k];
-                            double z_ji = zi - sz[k];
-                            if (shifted) {
-                                x_ji += ox;
-                                y_ji += oy;
-                                z_ji += oz;
-                            }
-                            double r2 = x_ji * x_ji + y_ji * y_ji + z_ji * z_ji;
-                            if (r2 > P.r2_max) continue;
-                            int idx = (int)(r2 * P.r2_index_scaling);
-                            double total_factor = P.factor * table[idx];
-                            ax += x_ji * total_factor;
-                            ay += y_ji * total_factor;
-                            az += z_ji * total_factor;
-                        }
-                    }
-                }
-            }
-        }
-        if (active) {
-            dmom_r[3 * (i64)pi] += ax;
-            dmom_r[3 * (i64)pi + 1] += ay;
-            dmom_r[3 * (i64)pi + 2] += az;
-        }
-    }
-}
-
-int cgk_shortrange_sweep(cg_ctx *c, const double *pos_r, const unsigned *order_r,
-                         const unsigned *off_r, double *dmom_r, const double *pos_s,
-                         const unsigned *order_s, const unsigned *off_s, i64 nt, int same,
-                         const double *table, double r2_index_scaling, double r2_max,
-                         double factor, const double *factors, const signed char *rung,
-                         const signed char *rung_jumped, int lowest_active) {
-    SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt, same,
-               factors,      rung,             rung_jumped, lowest_active};
-    // Default: one wavefront per tile.  The column form (CONCEPT_GPU_SR=columns) keeps more
-    // lanes busy but measured slower at 256^3 / 512^3 (26.7 vs 24.7 ms): kept for A/B work.
-    const char *env = getenv("CONCEPT_GPU_SR");
-    if (rung || !(env && std::string(env) == "columns")) {
-        hipLaunchKernelGGL(k_sr_sweep, dim3((unsigned)(nt * nt * nt)), dim3(64), 0, c->stream,
-                           pos_r, order_r, off_r, dmom_r, pos_s, order_s, off_s, table, P);
-    } else {
-        const double eps = 2.220446049250313e-16;
-        double tile_extent = c->p.boxsize / (double)nt;  // species.py:607-609
-        double inv = (1 / tile_extent) * (1 - 2 * eps);
-        hipLaunchKernelGGL(k_sr_sweep_columns, dim3((unsigned)(nt * nt)), dim3(64), 0, c->stream,
-                           pos_r, order_r, off_r, dmom_r, pos_s, order_s, off_s, table, P, inv);
-    }
-    CG_LAUNCH_CHECK();
-    return 0;
-}
+struct SrCount {
+    unsigned tests = 0, hits = 0, trips = 0;
+};
 
 // ===========================================================================
 // Sweep over a cell list at HALF-tile granularity (the reference prunes below the tile level
 // with subtiles, interactions.py:1141-1278, species.py:4031-4142).
 //
-// Why: the one-wavefront-per-tile sweep above tests every receiver of a tile against all 27
-// neighbouring tiles (~600 pair tests per particle at the default parameters, ~15 % hits) with
-// 22 receivers x 2 supplier groups = 44 of 64 lanes busy, and it is bound by FP64 VALU issue
-// (17 FP64 instructions of 4 cycles per pair test; rocprofv3: VALUBusy 75 %, no memory
-// stalls).  What helps is fewer wave-iterations, i.e. fewer tests and fuller wavefronts:
+// Why: a sweep with one wavefront per tile tests every receiver against all 27 neighbouring
+// tiles (~600 pair tests per particle at the default parameters, ~15 % hits) with 22 receivers
+// x 2 supplier groups = 44 of 64 lanes busy, and it is bound by FP64 VALU issue.  What helps
+// is fewer wave-iterations, i.e. fewer tests and fuller wavefronts:
 //  * cells of half a tile (extent >= range/2): a receiver cell needs supplier cells no further
 //    than 2 away;
 //  * particles are SORTED by cell (z fastest), positions copied in that order: a column of
@@ -465,12 +82,6 @@ int cgk_shortrange_sweep(cg_ctx *c, const double *pos_r, const unsigned *order_r
 // Periodic images: only tiles on the box faces see pieces with an offset; those are swept
 // piece by piece with the (uniform) offset added as the reference does, (xi - xj) + offset.
 // ===========================================================================
-#ifndef CG_SR_NB
-#define CG_SR_NB 2   // pairs per lane whose table loads are in flight together.  Measured at
-                     // 256^3 / 512^3: 2 -> 64 VGPRs, 8 wavefronts per SIMD, sweep 8.6 ms; 4 -> 80
-                     // VGPRs, 6 per SIMD, 9.4 ms; 8 -> 112 VGPRs, 4 per SIMD, 11.8 ms: the table
-                     // loads of a batch are waited for together, occupancy hides them
-#endif
 #ifndef CG_SR_WAVES
 #define CG_SR_WAVES 4  // lower bound of wavefronts per SIMD for the register allocator
 #endif
@@ -622,21 +233,22 @@ int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
                            n, inv, tile_extent, (unsigned)nt, offset, cursor, order, pos_sorted);
         CG_LAUNCH_CHECK();
     }
-    return 0;
+    // what the dense tiles' sweep wants to know about this list, while it is being made
+    return cgk_shortrange_dense_look(c, offset, nt);
 }
 
 // pair tests of this lane's receiver against the staged suppliers [a, b), lane group `sub` of S
 // taking every S-th; SHIFT: the range is a periodic image, offset (ox, oy, oz).  Accumulates
-// sum x_ji * table[...] — the receiver's factor is applied once at the end.  Four pairs per
-// trip: their table loads (hits only) are all issued before the first is used.
-template <bool SHIFT, bool MASK, int NB>
+// sum x_ji * table[...] — the receiver's factor is applied once at the end.  NB pairs per trip:
+// their table loads (hits only) are all issued before the first is used (two: 64 VGPRs, 8
+// wavefronts per SIMD, 8.6 ms at 256^3 / 512^3; four: 80 VGPRs, 9.4 ms; eight: 11.8 ms).
+template <bool SHIFT, bool MASK, int NB, bool STATS>
 __device__ __forceinline__ void sr_cell_batch(int k, int S, int b, double xi, double yi, double zi,
-                                              double ox, double oy, double oz, const double *sx,
-                                              const double *sy, const double *sz, double r2_max,
+                                              const double *sx, const double *sy,
+                                              const double *sz, double r2_max,
                                               double r2_index_scaling,
                                               const double *__restrict__ table, double &ax,
-                                              double &ay, double &az) {
-    (void)ox, (void)oy, (void)oz;
+                                              double &ay, double &az, bool counted, SrCount &cnt) {
     // NB pairs of this lane: their table loads (hits only) are all issued before the first use
     double xj[NB], yj[NB], zj[NB], r2[NB], t[NB];
     bool hit[NB];
@@ -654,22 +266,17 @@ __device__ __forceinline__ void sr_cell_batch(int k, int S, int b, double xi, do
         r2[j] = xj[j] * xj[j] + yj[j] * yj[j] + zj[j] * zj[j];  // gravity.py:306
         hit[j] = r2[j] <= r2_max;                        // gravity.py:311: skip r2 > r2_max
         if (MASK) hit[j] &= kj < b;                      // (read past the range: staged slack)
+        if (STATS) {
+            const bool valid = counted && (!MASK || kj < b);
+            cnt.tests += (unsigned)__popcll(__ballot(valid));
+            cnt.hits += (unsigned)__popcll(__ballot(valid && hit[j]));
+            cnt.trips++;
+        }
     }
 #pragma unroll
     for (int j = 0; j < NB; j++) {
         t[j] = 0.0;
-#ifdef CG_SR_PROBE_NOLOAD  // probe build (tools/variant.py): the sweep without its table gather
-        if (hit[j]) t[j] = r2[j] * r2_index_scaling;
-#elif defined(CG_SR_BRANCHFREE)
-        // (probe) no exec-mask region: a miss looks entry 0 up and is multiplied away
-        {
-            const unsigned idx = hit[j] ? (unsigned)(int)(r2[j] * r2_index_scaling) : 0u;
-            const double tv = table[idx];
-            t[j] = hit[j] ? tv : 0.0;
-        }
-#else
         if (hit[j]) t[j] = table[(unsigned)(int)(r2[j] * r2_index_scaling)];  // gravity.py:316-321
-#endif
     }
 #pragma unroll
     for (int j = 0; j < NB; j++) {
@@ -679,132 +286,26 @@ __device__ __forceinline__ void sr_cell_batch(int k, int S, int b, double xi, do
     }
 }
 
-// pair tests of this lane's receiver against the staged suppliers [a, b), lane group `sub` of S
-// taking every S-th; SHIFT: the range is a periodic image, offset (ox, oy, oz).  Accumulates
-// sum x_ji * table[...] — the receiver's factor is applied once at the end.
-template <bool SHIFT>
+// the range [a, b) of the staged window: rows of S suppliers, two rows per trip
+template <bool SHIFT, bool STATS>
 __device__ __forceinline__ void sr_cell_pairs(int a, int b, int sub, int S, double xi, double yi,
-                                              double zi, double ox, double oy, double oz,
-                                              const double *sx, const double *sy,
+                                              double zi, const double *sx, const double *sy,
                                               const double *sz, double r2_max,
                                               double r2_index_scaling,
                                               const double *__restrict__ table, double &ax,
-                                              double &ay, double &az) {
+                                              double &ay, double &az, bool counted, SrCount &cnt) {
     // a, b, S are wave-uniform (scalar registers): rows of S suppliers walked with scalar adds
     // and compares only (no division); the last one or two rows may stick out of the range
     int row = a;
-#if CG_SR_NB >= 4
-    for (; row + 4 * S <= b; row += 4 * S)
-        sr_cell_batch<SHIFT, false, 4>(row + sub, S, b, xi, yi, zi, ox, oy, oz, sx, sy, sz, r2_max,
-                                       r2_index_scaling, table, ax, ay, az);
-#endif
     for (; row + 2 * S <= b; row += 2 * S)
-        sr_cell_batch<SHIFT, false, 2>(row + sub, S, b, xi, yi, zi, ox, oy, oz, sx, sy, sz, r2_max,
-                                       r2_index_scaling, table, ax, ay, az);
+        sr_cell_batch<SHIFT, false, 2, STATS>(row + sub, S, b, xi, yi, zi, sx, sy, sz, r2_max,
+                                              r2_index_scaling, table, ax, ay, az, counted, cnt);
     if (row + S < b)
-        sr_cell_batch<SHIFT, true, 2>(row + sub, S, b, xi, yi, zi, ox, oy, oz, sx, sy, sz, r2_max,
-                                      r2_index_scaling, table, ax, ay, az);
+        sr_cell_batch<SHIFT, true, 2, STATS>(row + sub, S, b, xi, yi, zi, sx, sy, sz, r2_max,
+                                             r2_index_scaling, table, ax, ay, az, counted, cnt);
     else if (row < b)
-        sr_cell_batch<SHIFT, true, 1>(row + sub, S, b, xi, yi, zi, ox, oy, oz, sx, sy, sz, r2_max,
-                                      r2_index_scaling, table, ax, ay, az);
-}
-
-// ---------------------------------------------------------------------------
-// Single-precision pre-test (round 3).  73 % of the pair tests are misses, and in the loop
-// above a miss costs what a hit costs: in a 64-lane wavefront some lane hits in nearly every
-// trip, so the whole hit path (table index, look-up, three FMAs) issues every time — 27 lane
-// instructions per pair test against 12 for the bare test.  Here a lane first runs ALL its
-// pairs of a receiver chunk through a packed single-precision distance test on float copies of
-// the staged positions (relative to the tile's corner; two adjacent suppliers per
-// v_pk_*_f32 instruction: 4.5 instructions per pair), shifting one "miss" bit per pair into a
-// mask, and then evaluates only the pairs the pre-test could not rule out — in double precision,
-// exactly as before (same x_ji, r2, range test, table index: bit-identical contributions; the
-// pre-test's threshold sits above r2_max by more than float rounding can move a distance, so it
-// never drops a hit).  The second loop runs as long as the slowest lane has candidates.
-// MEASURED (256^3 / 512^3, round 3): 8.98 ms against 7.63 ms for the loop above (clustered box
-// 101 against 75 ms), so it is NOT the default (CONCEPT_GPU_SR_PRE32=1 selects it).  Why it
-// does not pay: a lane has only ~45 pairs per receiver chunk (the wave splits a receiver's ~490
-// suppliers over S ~ 11 lane groups), of which ~10 are candidates with a spread of +-3 between
-// the lanes; the candidate loop runs for the slowest lane, four at a time, so fewer than half of
-// its slots do work — that waste plus the pre-test itself (6 instructions per pair with its
-// loop) comes to the ~27 instructions per pair of the plain loop, and the float copies cost LDS
-// (28 KB: 5 workgroups per CU instead of 8).  It would take sharing a receiver's candidates
-// between its S lanes to win; the queue that does that was tried in round 1 and lost more to
-// its LDS traffic.
-// Suppliers [A, B) of the staged window are ONE range here: the five x rows of the receiver's
-// neighbourhood with all six y columns each (the sixth is beyond the range and falls to the
-// pre-test), lane group `sub` of S takes suppliers A + 2 sub + {0, 1} + 2 S row.
-// ---------------------------------------------------------------------------
-typedef float f2v __attribute__((ext_vector_type(2)));
-template <bool FACE>
-__device__ __forceinline__ void sr_cell_pairs_pre32(int A, int B, int sub, int S, double xi,
-                                                    double yi, double zi, float xf, float yf,
-                                                    float zf, float r2_pre, const double *sx,
-                                                    const double *sy, const double *sz,
-                                                    const float *fx, const float *fy,
-                                                    const float *fz, double r2_max,
-                                                    double r2_index_scaling,
-                                                    const double *__restrict__ table, double &ax,
-                                                    double &ay, double &az) {
-    const int stride = 2 * S;                       // suppliers per row of the lane groups
-    const int nrows = (B - A + stride - 1) / stride;  // wave-uniform
-    const f2v xr = {xf, xf}, yr = {yf, yf}, zr = {zf, zf}, lim = {r2_pre, r2_pre};
-    for (int r0 = 0; r0 < nrows; r0 += 16) {        // 16 rows = 32 pairs per lane and mask
-        const int n = min(16, nrows - r0);
-        unsigned miss = 0;                          // pair p of this batch ends at bit 2n-1-p
-        int k = A + r0 * stride + 2 * sub;
-#pragma unroll 4
-        for (int r = 0; r < n; r++, k += stride) {
-            const f2v dx = xr - f2v{fx[k], fx[k + 1]};
-            const f2v dy = yr - f2v{fy[k], fy[k + 1]};
-            const f2v dz = zr - f2v{fz[k], fz[k + 1]};
-            f2v d2 = dx * dx;
-            d2 = __builtin_elementwise_fma(dy, dy, d2);
-            d2 = __builtin_elementwise_fma(dz, dz, d2);
-            const f2v rest = lim - d2;              // negative (sign bit): a miss
-            miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(rest.x), 31);
-            miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(rest.y), 31);
-        }
-        unsigned cand = ~miss & (n == 16 ? 0xffffffffu : ((1u << (2 * n)) - 1u));
-        const int kbase = A + r0 * stride + 2 * sub;
-        // The candidates, kNBD per lane and trip: exact distances, range test and table index
-        // of all of them first, their look-ups in flight together (a candidate the exact test
-        // rejects — one in ~10^4 — reads entry 0 and counts for nothing; so does an empty slot).
-        constexpr int kNBD = 4;
-        while (__any(cand != 0)) {
-            double xj[kNBD], yj[kNBD], zj[kNBD], t[kNBD];
-            unsigned idx[kNBD];
-            bool hit[kNBD];
-#pragma unroll
-            for (int q = 0; q < kNBD; q++) {
-                const bool have = cand != 0;
-                const int bit = have ? __ffs((int)cand) - 1 : 2 * n - 1;
-                cand &= cand - 1;                   // (0 stays 0)
-                const int pr = 2 * n - 1 - bit;     // pair number in this batch
-                const int kj = kbase + (pr >> 1) * stride + (pr & 1);
-                xj[q] = xi - sx[kj];                // interactions.py:1787-1789
-                yj[q] = yi - sy[kj];
-                zj[q] = zi - sz[kj];
-                if (FACE) {                         // gravity.py:299-302
-                    xj[q] += sx[kSrFaceStride + kj];
-                    yj[q] += sy[kSrFaceStride + kj];
-                    zj[q] += sz[kSrFaceStride + kj];
-                }
-                const double r2 = xj[q] * xj[q] + yj[q] * yj[q] + zj[q] * zj[q];  // gravity.py:306
-                hit[q] = have && r2 <= r2_max && kj < B;                        // gravity.py:311
-                idx[q] = hit[q] ? (unsigned)(int)(r2 * r2_index_scaling) : 0u;  // gravity.py:316
-            }
-#pragma unroll
-            for (int q = 0; q < kNBD; q++) t[q] = table[idx[q]];
-#pragma unroll
-            for (int q = 0; q < kNBD; q++) {
-                const double tq = hit[q] ? t[q] : 0.0;
-                ax = __builtin_fma(xj[q], tq, ax);
-                ay = __builtin_fma(yj[q], tq, ay);
-                az = __builtin_fma(zj[q], tq, az);
-            }
-        }
-    }
+        sr_cell_batch<SHIFT, true, 1, STATS>(row + sub, S, b, xi, yi, zi, sx, sy, sz, r2_max,
+                                             r2_index_scaling, table, ax, ay, az, counted, cnt);
 }
 
 // inclusive scan over the 64 lanes of a wave in DPP adds (no LDS round trips): row_shr 1, 2, 4,
@@ -922,15 +423,9 @@ __global__ __launch_bounds__(256) void k_sr_tile_activity(const unsigned *__rest
 // order, gravity.py:299-302; + 0.0 for the others changes nothing), so a receiver's five
 // columns stay ONE range there too.  (Walking such tiles piece by piece — 10 short ranges per x
 // with a wave-uniform offset each — made these 6 % of the tiles 16 % of the sweep.)
-// CG_SR_XCDWALK=1 (A/B, off): the interior as a 1-D grid in which every XCD walks its own
-// contiguous eighth of the tiles, so that the supplier columns a tile stages were staged into
-// the same L2 just before.  Measured at 256^3 / 512^3 (tools/sr_dense_time.py, twice each):
-// 8.17 against 8.08 ms uniform, 46.6 against 46.5 ms clustered — the staging of the sparse
-// tiles does not wait for the L2 it misses; the 3-D grid stays.
-#ifndef CG_SR_XCDWALK
-#define CG_SR_XCDWALK 0
-#endif
-template <bool FACE, bool PRE32, bool RUNGS>
+// (An XCD-contiguous walk of the interior tiles — so that a tile's supplier columns were staged
+// into the same L2 just before — measured 8.17 against 8.08 ms: the 3-D grid stays.)
+template <bool FACE, bool RUNGS, bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CG_SR_WAVES, 8))) void
 k_sr_sweep_cells(
     const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
@@ -940,10 +435,6 @@ k_sr_sweep_cells(
     constexpr int kLen = (FACE ? 2 : 1) * (kSrCap + kSrSlack);
     static_assert(kSrFaceStride == kSrCap + kSrSlack, "offsets follow the positions");
     __shared__ double sx[kLen], sy[kLen], sz[kLen];
-    // PRE32: float copies of the staged positions (image offset included), relative to the
-    // tile's lower corner, for the single-precision pre-test
-    __shared__ float fx[PRE32 ? kSrCap + kSrSlack : 1], fy[PRE32 ? kSrCap + kSrSlack : 1],
-        fz[PRE32 ? kSrCap + kSrSlack : 1];
     __shared__ unsigned p_beg[kSrPieces], p_cnt[kSrPieces], p_off[kSrPieces];
     __shared__ signed char p_shift[kSrPieces][4];  // periodic image: -1, 0, +1 box lengths
     __shared__ unsigned wave_any[4];
@@ -955,15 +446,6 @@ k_sr_sweep_cells(
     // slabs — slab 0: ta on a face, 1: tb on a face (ta inside), 2: tc on a face (ta, tb inside).
     int ta = blockIdx.z, tb = blockIdx.y, tc = blockIdx.x;
     if (!FACE) {
-#if CG_SR_XCDWALK
-        // the interior as a 1-D grid: block b runs on XCD b % 8, and every XCD walks its own
-        // contiguous eighth of the tiles (z fastest), so that the supplier columns a tile
-        // stages were staged into the same L2 by the tiles just before it (`slab`: nt - 2)
-        const unsigned m = (unsigned)slab, total = m * m * m, per = (total + 7u) / 8u;
-        const unsigned lin = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
-        if (lin >= total || blockIdx.x / 8u >= per) return;
-        tc = (int)(lin % m), tb = (int)((lin / m) % m), ta = (int)(lin / (m * m));
-#endif
         ta++, tb++, tc++;
     } else if (slab == 0) {
         ta = ta ? nt - 1 : 0;
@@ -978,8 +460,6 @@ k_sr_sweep_cells(
     // visits the tiles' active rungs only, species.py tiles_rungs_N): a tile none of whose
     // receivers is active is gone after one byte
     if (P.tile_active && !P.tile_active[((unsigned)ta * nt + (unsigned)tb) * nt + (unsigned)tc]) return;
-    const double ext = P.boxsize / (double)nt;  // tile extent
-    const double ox0 = ta * ext, oy0 = tb * ext, oz0 = tc * ext;  // the tile's lower corner
     // receivers of this wave: cell column (2 ta + wx, 2 tb + wy), cells 2 tc and 2 tc + 1
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wx = wave_u >> 1, wy = wave_u & 1;
@@ -1049,6 +529,7 @@ k_sr_sweep_cells(
     const unsigned total = __builtin_amdgcn_readlane(i0, 63);
     const int npieces = FACE ? kSrPieces : 36;  // (half 1 is empty off the z faces)
     const bool simple = rend - rbeg <= 64 && total <= (unsigned)kSrCap;  // one chunk, one window
+    SrCount cnt;
     for (unsigned w0 = 0; w0 < total; w0 += kSrCap) {
         const unsigned w1 = min(total, w0 + (unsigned)kSrCap);
         // (window bounds as scalar ints: the range bounds below are scalar integer min / max)
@@ -1065,29 +546,13 @@ k_sr_sweep_cells(
                 const unsigned q = lo + (lane & 15) + 16u * tn;
                 if (q < hi) {
                     const i64 g = (i64)beg + (q - o0);
-#ifdef CG_SR_NT_STAGE  // streamed once per tile: keep them out of the way of the table
-                    sx[q - w0] = __builtin_nontemporal_load(pos_s + 3 * g);
-                    sy[q - w0] = __builtin_nontemporal_load(pos_s + 3 * g + 1);
-                    sz[q - w0] = __builtin_nontemporal_load(pos_s + 3 * g + 2);
-#else
                     sx[q - w0] = pos_s[3 * g];
                     sy[q - w0] = pos_s[3 * g + 1];
                     sz[q - w0] = pos_s[3 * g + 2];
-#endif
-                    double shx = 0, shy = 0, shz = 0;
                     if (FACE) {
-                        shx = (double)p_shift[p][0] * P.boxsize;
-                        shy = (double)p_shift[p][1] * P.boxsize;
-                        shz = (double)p_shift[p][2] * P.boxsize;
-                        sx[kSrFaceStride + q - w0] = shx;
-                        sy[kSrFaceStride + q - w0] = shy;
-                        sz[kSrFaceStride + q - w0] = shz;
-                    }
-                    if (PRE32) {
-                        // x_ji = (xi - xj) + offset: the supplier's image sits at xj - offset
-                        fx[q - w0] = (float)((sx[q - w0] - shx) - ox0);
-                        fy[q - w0] = (float)((sy[q - w0] - shy) - oy0);
-                        fz[q - w0] = (float)((sz[q - w0] - shz) - oz0);
+                        sx[kSrFaceStride + q - w0] = (double)p_shift[p][0] * P.boxsize;
+                        sy[kSrFaceStride + q - w0] = (double)p_shift[p][1] * P.boxsize;
+                        sz[kSrFaceStride + q - w0] = (double)p_shift[p][2] * P.boxsize;
                     }
                 }
             }
@@ -1096,7 +561,6 @@ k_sr_sweep_cells(
             sx[w1 - w0 + tid] = 0;
             sy[w1 - w0 + tid] = 0;
             sz[w1 - w0 + tid] = 0;
-            if (PRE32) fx[w1 - w0 + tid] = fy[w1 - w0 + tid] = fz[w1 - w0 + tid] = 1e30f;
             if (FACE) {
                 sx[kSrFaceStride + w1 - w0 + tid] = 0;
                 sy[kSrFaceStride + w1 - w0 + tid] = 0;
@@ -1111,28 +575,17 @@ k_sr_sweep_cells(
             if (!__any(active)) continue;
             const double xi = ch.xi, yi = ch.yi, zi = ch.zi;
             double ax = 0, ay = 0, az = 0;
-            if (PRE32) {
-                // one range: x rows wx .. wx + 4 of the 6 x 6 columns, all six y columns
-                const int a = max(__builtin_amdgcn_readlane((int)e0, wx * 6), sw0) - sw0;
-                const int b = min(__builtin_amdgcn_readlane((int)i0, wx * 6 + 29), sw1) - sw0;
+            // (every lane walks the ranges, active or not: the bounds are v_readlane's of
+            // registers whose lanes 0..35 must be live, i.e. uniform control flow; an idle
+            // lane tests pairs against (0, 0, 0) and its sums are never read)
+            for (int xg = 0; xg < 5; xg++) {
+                const int col = (wx + xg) * 6 + wy;  // first of the 5 columns of this x
+                // the 5 columns of this x are one staged range
+                const int a = max(__builtin_amdgcn_readlane((int)e0, col), sw0) - sw0;
+                const int b = min(__builtin_amdgcn_readlane((int)i0, col + 4), sw1) - sw0;
                 if (b > a)
-                    sr_cell_pairs_pre32<FACE>(a, b, sub, S, xi, yi, zi, (float)(xi - ox0),
-                                              (float)(yi - oy0), (float)(zi - oz0), P.r2_pre, sx,
-                                              sy, sz, fx, fy, fz, P.r2_max, P.r2_index_scaling,
-                                              table, ax, ay, az);
-            } else {
-                // (every lane walks the ranges, active or not: the bounds are v_readlane's of
-                // registers whose lanes 0..35 must be live, i.e. uniform control flow; an idle
-                // lane tests pairs against (0, 0, 0) and its sums are never read)
-                for (int xg = 0; xg < 5; xg++) {
-                    const int col = (wx + xg) * 6 + wy;  // first of the 5 columns of this x
-                    // the 5 columns of this x are one staged range
-                    const int a = max(__builtin_amdgcn_readlane((int)e0, col), sw0) - sw0;
-                    const int b = min(__builtin_amdgcn_readlane((int)i0, col + 4), sw1) - sw0;
-                    if (b > a)
-                        sr_cell_pairs<FACE>(a, b, sub, S, xi, yi, zi, 0, 0, 0, sx, sy, sz,
-                                            P.r2_max, P.r2_index_scaling, table, ax, ay, az);
-                }
+                    sr_cell_pairs<FACE, STATS>(a, b, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
+                                               P.r2_index_scaling, table, ax, ay, az, active, cnt);
             }
             // fold the S partial sums of each receiver (lanes rl, rl + R, ...) into lane rl: a
             // tree over the groups, ceil(log2 S) shuffle steps.  A node whose partner group does
@@ -1161,6 +614,11 @@ k_sr_sweep_cells(
                 }
             }
         }
+    }
+    if (STATS && lane == 0) {
+        atomicAdd(&P.stats[0], (unsigned long long)cnt.tests);
+        atomicAdd(&P.stats[1], (unsigned long long)cnt.hits);
+        atomicAdd(&P.stats[2], (unsigned long long)cnt.trips);
     }
 }
 
@@ -1249,8 +707,9 @@ int cgk_shortrange_sparse(cg_ctx *c, const double *pos_r, const i64 *active, int
         return 1;
     }
     if (n_s == 0) return 0;
-    SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, 0, 0,
-               factors,      rung_jumped /* non-null = rungs in use */, rung_jumped, 0, 0.0f, nullptr};
+    SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, 0,
+               factors,      rung_jumped /* non-null = rungs in use */, rung_jumped, 0, nullptr,
+               nullptr};
     if (!factors) P.rung = nullptr;
     if (!c->sr_sparse_partial)
         CG_HIP(hipMalloc((void **)&c->sr_sparse_partial,
@@ -1272,8 +731,8 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                                double r2_index_scaling, double r2_max, double factor,
                                const double *factors, const signed char *rung,
                                const signed char *rung_jumped, int lowest_active) {
-    SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt, 0,
-               factors,      rung,             rung_jumped, lowest_active, 0.0f, nullptr};
+    SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt,
+               factors,      rung,             rung_jumped, lowest_active, nullptr, nullptr};
     if (rung && lowest_active > 0) {
         // which tiles have a receiver on an active rung (the others leave at once)
         const size_t ntl = (size_t)nt * nt * nt;
@@ -1300,24 +759,7 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                              rung ? lowest_active : 0, P.tile_active, &take))
         return 1;
     if (take) P.tile_active = take;
-    // The single-precision pre-test's threshold: coordinates relative to the tile's corner are
-    // below 3.5 tile extents E in size, a float carries them to 2^-24 relative, a difference of
-    // two to 2 * 3.5 E * 2^-24, and |x|^2 near r^2_max moves by at most
-    // 2 r * sqrt(3) * 7 E * 2^-24 + 4 * 2^-24 r^2 (its own roundings); 8 x that on top.
-    static int pre32 = -1;
-    if (pre32 < 0) {
-        const char *env = getenv("CONCEPT_GPU_SR_PRE32");
-        pre32 = env ? atoi(env) : 0;   // measured slower than the plain sweep (see above): off
-    }
-    {
-        const double E = c->p.boxsize / (double)nt, r = sqrt(r2_max), u = 5.9604644775390625e-08;
-        const double slack = 8 * (2 * r * 1.7320508 * 7 * E * u + 4 * u * r2_max);
-        P.r2_pre = (float)(r2_max + slack);
-        while ((double)P.r2_pre < r2_max + slack) P.r2_pre = nextafterf(P.r2_pre, 3.4e38f);
-    }
-    const unsigned ntiles = (unsigned)(nt * nt * nt);
     const unsigned n = (unsigned)nt, m = (unsigned)(nt - 2);  // (nt >= 4: checked by the caller)
-    (void)ntiles;
     // The four launches touch different receivers: the face slabs go to side streams (forked
     // from and joined back into the context's stream) and run beside the interior grid.
     if (!c->sr_fork) {
@@ -1330,10 +772,11 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
     CG_HIP(hipEventRecord(c->sr_fork, c->stream));
     const dim3 slabs[3] = {dim3(n, n, 2), dim3(n, 2, m), dim3(2, m, m)};
     const bool rungs = rung != nullptr;
-    auto face = pre32 ? (rungs ? k_sr_sweep_cells<true, true, true> : k_sr_sweep_cells<true, true, false>)
-                      : (rungs ? k_sr_sweep_cells<true, false, true> : k_sr_sweep_cells<true, false, false>);
-    auto inner = pre32 ? (rungs ? k_sr_sweep_cells<false, true, true> : k_sr_sweep_cells<false, true, false>)
-                       : (rungs ? k_sr_sweep_cells<false, false, true> : k_sr_sweep_cells<false, false, false>);
+    P.stats = c->sr_stats;
+    auto face = rungs ? (P.stats ? k_sr_sweep_cells<true, true, true> : k_sr_sweep_cells<true, true, false>)
+                      : (P.stats ? k_sr_sweep_cells<true, false, true> : k_sr_sweep_cells<true, false, false>);
+    auto inner = rungs ? (P.stats ? k_sr_sweep_cells<false, true, true> : k_sr_sweep_cells<false, true, false>)
+                       : (P.stats ? k_sr_sweep_cells<false, false, true> : k_sr_sweep_cells<false, false, false>);
     for (int slab = 0; slab < 3; slab++) {
         CG_HIP(hipStreamWaitEvent(c->sr_streams[slab], c->sr_fork, 0));
         hipLaunchKernelGGL(face, slabs[slab], dim3(256), 0, c->sr_streams[slab], pos_r_sorted,
@@ -1341,13 +784,8 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
         CG_LAUNCH_CHECK();
         CG_HIP(hipEventRecord(c->sr_join[slab], c->sr_streams[slab]));
     }
-#if CG_SR_XCDWALK
-    hipLaunchKernelGGL(inner, dim3(8u * ((m * m * m + 7u) / 8u)), dim3(256), 0, c->stream,
-                       pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P, (int)m);
-#else
     hipLaunchKernelGGL(inner, dim3(m, m, m), dim3(256), 0, c->stream, pos_r_sorted, order_r, off_r,
                        dmom_r, pos_s_sorted, off_s, table, P, 0);
-#endif
     CG_LAUNCH_CHECK();
     for (int slab = 0; slab < 3; slab++) CG_HIP(hipStreamWaitEvent(c->stream, c->sr_join[slab], 0));
     if (take && cgk_shortrange_dense_join(c)) return 1;

@@ -11,8 +11,8 @@
 // whatever the density: 4.2-4.4 pair tests per pair in range.  Where a tile holds a hundred
 // particles or more, the reference refines its subtiles until each holds ~10 and skips the
 // subtile pairs that are out of reach.  The counterpart here:
-//  * the tile list of cg_shortrange_tiles (cg_shortrange_mfma.hip) orders the rows of such a tile
-//    along a Hilbert curve through 8^3 sub-cells, so that ANY run of consecutive rows is a
+//  * a list by tile (below: cg_shortrange_tiles) whose rows, in such a tile, follow a Hilbert
+//    curve through 8^3 sub-cells, so that ANY run of consecutive rows is a
 //    compact blob whose size follows the density (a run of k rows at density rho fills a volume
 //    ~ k / rho) — subtiles by count instead of by edge length;
 //  * a wavefront takes 16 consecutive receivers (four lanes each) and the suppliers come as
@@ -27,6 +27,8 @@
 // tests per pair in range in tiles of 256 particles and more, 3.2 at 128-256, 4.1 at 64-128
 // (the cells sweep: 4.1-4.7), worse below — so cg_shortrange_sweep_cells hands the tiles above a
 // population threshold to this kernel and keeps the others.
+#include <hipcub/hipcub.hpp>
+
 #include <cstdlib>
 #include <cstring>
 
@@ -48,21 +50,10 @@ namespace {
 // trip at 92 registers (5 waves per SIMD) 53.2 ms; 448 rows and two quads per trip at 64 registers
 // (8 waves per SIMD) 48.0 ms; 256 rows 48.4, 320 rows 50.1, 8 wavefronts per workgroup 47.9-49.4,
 // two 57.9.  The pair loop is 18 vector instructions per trip of 64 pair tests.
-#ifndef SRD_CAP
-#define SRD_CAP 448
-#endif
-#ifndef SRD_WAVES_PER_EU
-#define SRD_WAVES_PER_EU 8
-#endif
-#ifndef SRD_NB
-#define SRD_NB 2                       // quads per trip of a wavefront (their table loads in flight together)
-#endif
-#ifndef SRD_WAVES
-#define SRD_WAVES 4
-#endif
-constexpr int kdWaves = SRD_WAVES;     // wavefronts per workgroup, 16 receivers each
+constexpr int kdNB = 2;                // quads per trip of a wavefront (their table loads in flight together)
+constexpr int kdWaves = 4;             // wavefronts per workgroup, 16 receivers each
 constexpr int kdChunk = 16 * kdWaves;  // receivers per work item
-constexpr int kdCap = SRD_CAP;         // supplier rows per LDS window (whole quads)
+constexpr int kdCap = 448;             // supplier rows per LDS window (whole quads)
 constexpr int kdQuads = kdCap / 4;
 constexpr int kdPieces = 18;           // 9 tile columns x 2 (a column that wraps around in z)
 static_assert(kdCap % 4 == 0, "whole quads");
@@ -72,6 +63,7 @@ struct SrdParams {
     const double *factors;          // adaptive rungs: factors[rung_jumped[i]] per receiver
     const signed char *rung_jumped;
     int nt;
+    unsigned long long *stats;      // cg_shortrange_stats: [3] tests, [4] in range, [5] trips
 };
 
 struct SrdShared {
@@ -93,6 +85,224 @@ __device__ __forceinline__ unsigned srd_wave_scan(unsigned v) {
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
     return v;
+}
+
+// ---------------------------------------------------------------------------
+// Lists by tile (Tiling.sort, species.py:775-780; z fastest): a counting sort — histogram,
+// scan, scatter — with the positions copied in list order.
+// ---------------------------------------------------------------------------
+// Tiling.sort (species.py:775-780) with tiling location 0
+__device__ __forceinline__ unsigned srd_tile1(double x, double inv, unsigned nt) {
+    unsigned t = (unsigned)(i64)((x - 0.0) * inv);
+    return t >= nt ? nt - 1 : t;
+}
+
+// runs of equal keys inside a wavefront -> one atomic per run (device-scope atomics execute
+// memory-side on MI355X; particle memory is in mesh-tile order, so runs are long)
+__device__ __forceinline__ void srd_wave_runs(unsigned key, int lane, int &run_start,
+                                              int &run_len) {
+    unsigned prev = __shfl_up(key, 1);
+    bool head = (lane == 0) || (key != prev);
+    unsigned long long mask = __ballot(head);
+    unsigned long long below = mask & (~0ull >> (63 - lane));
+    run_start = 63 - __clzll(below);
+    unsigned long long above = (lane == 63) ? 0ull : (mask >> (lane + 1));
+    int next = above ? (lane + 1 + (__ffsll((long long)above) - 1)) : 64;
+    run_len = next - run_start;
+}
+
+constexpr unsigned kdNoKey = 0xffffffffu;
+
+struct SrdKey {
+    unsigned key;
+    double x, y, z;
+};
+// (rung != null: only the particles on rungs >= lowest_active are listed — the receivers of a
+// sub-step, gravity.py:318-349 through the tiles' active rungs)
+__device__ __forceinline__ SrdKey srd_key(const double *__restrict__ pos, i64 p, i64 n, double inv,
+                                          unsigned nt, const signed char *__restrict__ rung,
+                                          int lowest_active) {
+    SrdKey k;
+    k.key = kdNoKey;
+    k.x = k.y = k.z = 0;
+    if (p < n && !(rung && rung[p] < lowest_active)) {
+        k.x = pos[3 * p], k.y = pos[3 * p + 1], k.z = pos[3 * p + 2];
+        k.key = (srd_tile1(k.x, inv, nt) * nt + srd_tile1(k.y, inv, nt)) * nt +
+                srd_tile1(k.z, inv, nt);
+    }
+    return k;
+}
+__global__ __launch_bounds__(256) void k_srd_histogram(const double *__restrict__ pos, i64 n,
+                                                       double inv, unsigned nt,
+                                                       const signed char *__restrict__ rung,
+                                                       int lowest_active,
+                                                       unsigned *__restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const SrdKey k = srd_key(pos, p, n, inv, nt, rung, lowest_active);
+    int rs, rl;
+    srd_wave_runs(k.key, lane, rs, rl);
+    if (lane == rs && k.key != kdNoKey) atomicAdd(&count[k.key], (unsigned)rl);
+}
+__global__ __launch_bounds__(256) void k_srd_scatter(const double *__restrict__ pos, i64 n,
+                                                     double inv, unsigned nt,
+                                                     const signed char *__restrict__ rung,
+                                                     int lowest_active,
+                                                     const unsigned *__restrict__ offset,
+                                                     unsigned *__restrict__ cursor,
+                                                     unsigned *__restrict__ order,
+                                                     double *__restrict__ pos_sorted) {
+    const int lane = threadIdx.x & 63;
+    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const SrdKey k = srd_key(pos, p, n, inv, nt, rung, lowest_active);
+    int rs, rl;
+    srd_wave_runs(k.key, lane, rs, rl);
+    unsigned first = 0;
+    if (lane == rs && k.key != kdNoKey)
+        first = offset[k.key] + atomicAdd(&cursor[k.key], (unsigned)rl);
+    first = __shfl(first, rs);
+    if (k.key != kdNoKey) {
+        const i64 q = (i64)first + (lane - rs);
+        order[q] = (unsigned)p;
+        if (pos_sorted) {
+            pos_sorted[3 * q] = k.x;
+            pos_sorted[3 * q + 1] = k.y;
+            pos_sorted[3 * q + 2] = k.z;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Density-adaptive order inside the tiles (the counterpart of the reference's automatic
+// subtile refinement, species.py:4031-4142: subtiles fine enough to hold a handful of
+// particles each).  A tile with many particles has its rows of the list re-ordered by
+// sub-cell — 8^3 sub-cells along a Hilbert curve (consecutive places are face neighbours: a run
+// of rows is a compact blob wherever it starts, which a Morton curve's jumps do not give) — so
+// that 16 consecutive rows (a wavefront's receivers) and 4 consecutive rows (a quad of
+// suppliers) are neighbours in space wherever the particles are many.  Tiles below `min_rows`
+// stay as the tile sort left them.
+// ---------------------------------------------------------------------------
+__device__ unsigned short srd_hilbert[512];   // filled per context by srd_hilbert_upload
+constexpr int kdSubCells = 8;
+
+__device__ __forceinline__ unsigned srd_subkey(double x, double y, double z, double inv_ext,
+                                               unsigned gx, unsigned gy, unsigned gz) {
+    const int a = min(kdSubCells - 1, max(0, (int)((x * inv_ext - (double)gx) * kdSubCells))),
+              b = min(kdSubCells - 1, max(0, (int)((y * inv_ext - (double)gy) * kdSubCells))),
+              c = min(kdSubCells - 1, max(0, (int)((z * inv_ext - (double)gz) * kdSubCells)));
+    return srd_hilbert[(a * kdSubCells + b) * kdSubCells + c];
+}
+
+struct SrdRow {  // what travels with a row of the list
+    double x, y, z;
+    unsigned order, pad;
+};
+
+// the tiles to re-order, each with a segment of the scratch (as many rows as it holds)
+__global__ __launch_bounds__(256) void k_srd_sub_tiles(const unsigned *__restrict__ offset,
+                                                       unsigned ntiles, unsigned min_rows,
+                                                       unsigned cap_tiles, unsigned cap_rows,
+                                                       unsigned *__restrict__ counters,
+                                                       unsigned *__restrict__ tiles,
+                                                       unsigned *__restrict__ seg) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    const unsigned cnt = offset[t + 1] - offset[t];
+    if (cnt < min_rows) return;
+    // (a caller's bound that turns out too small leaves a tile in the order of the tile sort:
+    // the sweep's results do not depend on the order, only its culling does)
+    const unsigned at = atomicAdd(&counters[1], cnt);
+    if (at + cnt > cap_rows) return;
+    const unsigned i = atomicAdd(&counters[0], 1u);
+    if (i >= cap_tiles) return;
+    tiles[i] = t;
+    seg[i] = at;
+}
+
+__global__ __launch_bounds__(256) void k_srd_subsort(const unsigned *__restrict__ offset,
+                                                     const unsigned *__restrict__ counters,
+                                                     const unsigned *__restrict__ tiles,
+                                                     const unsigned *__restrict__ seg,
+                                                     unsigned cap_tiles, double inv_ext,
+                                                     unsigned nt, unsigned *__restrict__ order,
+                                                     double *__restrict__ pos_sorted,
+                                                     SrdRow *__restrict__ scratch) {
+    __shared__ unsigned hist[512], base[512];
+    if (blockIdx.x >= min(counters[0], cap_tiles)) return;
+    const unsigned t = tiles[blockIdx.x];
+    const unsigned b = offset[t], e = offset[t + 1];
+    SrdRow *const mine = scratch + seg[blockIdx.x];
+    const unsigned gz = t % nt, gy = (t / nt) % nt, gx = t / (nt * nt);
+    for (int i = threadIdx.x; i < 512; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (unsigned q = b + threadIdx.x; q < e; q += 256)
+        atomicAdd(&hist[srd_subkey(pos_sorted[3 * (i64)q], pos_sorted[3 * (i64)q + 1],
+                                   pos_sorted[3 * (i64)q + 2], inv_ext, gx, gy, gz)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive scan of the 512 counts: 8 per lane of one wave
+        unsigned v[8], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            v[i] = hist[8 * threadIdx.x + i];
+            sum += v[i];
+        }
+        unsigned run = srd_wave_scan(sum) - sum;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            base[8 * threadIdx.x + i] = run;
+            run += v[i];
+        }
+    }
+    __syncthreads();
+    for (unsigned q = b + threadIdx.x; q < e; q += 256) {
+        SrdRow r;
+        r.x = pos_sorted[3 * (i64)q], r.y = pos_sorted[3 * (i64)q + 1],
+        r.z = pos_sorted[3 * (i64)q + 2];
+        r.order = order[q];
+        r.pad = 0;
+        mine[atomicAdd(&base[srd_subkey(r.x, r.y, r.z, inv_ext, gx, gy, gz)], 1u)] = r;
+    }
+    __syncthreads();  // (the workgroup's own writes to global memory, read back by itself)
+    __threadfence_block();
+    for (unsigned q = b + threadIdx.x; q < e; q += 256) {
+        const SrdRow r = mine[q - b];
+        pos_sorted[3 * (i64)q] = r.x;
+        pos_sorted[3 * (i64)q + 1] = r.y;
+        pos_sorted[3 * (i64)q + 2] = r.z;
+        order[q] = r.order;
+    }
+}
+
+// Hilbert index of every cell of the 8^3 grid (Skilling's transpose form: Gray decode of the
+// axes, then the bits interleaved)
+void srd_hilbert_table(unsigned short *out) {
+    const int bits = 3, M = 1 << (bits - 1);
+    for (int x = 0; x < 8; x++)
+        for (int y = 0; y < 8; y++)
+            for (int z = 0; z < 8; z++) {
+                int X[3] = {x, y, z};
+                for (int Q = M; Q > 1; Q >>= 1) {
+                    const int P = Q - 1;
+                    for (int i = 0; i < 3; i++) {
+                        if (X[i] & Q) {
+                            X[0] ^= P;
+                        } else {
+                            const int t = (X[0] ^ X[i]) & P;
+                            X[0] ^= t;
+                            X[i] ^= t;
+                        }
+                    }
+                }
+                for (int i = 1; i < 3; i++) X[i] ^= X[i - 1];
+                int t = 0;
+                for (int Q = M; Q > 1; Q >>= 1)
+                    if (X[2] & Q) t ^= Q - 1;
+                for (int i = 0; i < 3; i++) X[i] ^= t;
+                int h = 0;
+                for (int b = bits - 1; b >= 0; b--)
+                    for (int i = 0; i < 3; i++) h = (h << 1) | ((X[i] >> b) & 1);
+                out[(x * 8 + y) * 8 + z] = (unsigned short)h;
+            }
 }
 
 // Population of every tile from the half-tile cell list (8 cells = 4 z-pairs): how many
@@ -198,12 +408,12 @@ __global__ __launch_bounds__(256) void k_srd_gate(const unsigned *__restrict__ o
 // NB quads of 4 supplier rows against the wave's 16 receivers: lane (j, g) pairs receiver j
 // with row g of every quad.  Same arithmetic, in the same order, as sr_cell_batch
 // (cg_shortrange.hip): the table loads of the hits are all issued before the first is used.
-template <bool FACE, int NB>
+template <bool FACE, int NB, bool STATS>
 __device__ __forceinline__ void srd_quads(const SrdShared &S, const int (&q)[NB], int g, double xi,
                                           double yi, double zi, double boxsize, double r2_max,
                                           double r2_index_scaling,
                                           const double *__restrict__ table, double &ax, double &ay,
-                                          double &az) {
+                                          double &az, bool counted, unsigned *cnt) {
     double xj[NB], yj[NB], zj[NB], r2[NB], t[NB];
     bool hit[NB];
 #pragma unroll
@@ -220,6 +430,13 @@ __device__ __forceinline__ void srd_quads(const SrdShared &S, const int (&q)[NB]
         }
         r2[k] = xj[k] * xj[k] + yj[k] * yj[k] + zj[k] * zj[k];  // gravity.py:306
         hit[k] = r2[k] <= r2_max;                        // gravity.py:311
+        if (STATS) {
+            // a row of padding (the rest of a last quad, the far quad) sits at 1e300
+            const bool valid = counted && S.sx[4 * q[k] + g] < 1e299;
+            cnt[0] += (unsigned)__popcll(__ballot(valid));
+            cnt[1] += (unsigned)__popcll(__ballot(valid && hit[k]));
+            cnt[2]++;
+        }
     }
 #pragma unroll
     for (int k = 0; k < NB; k++) {
@@ -235,37 +452,28 @@ __device__ __forceinline__ void srd_quads(const SrdShared &S, const int (&q)[NB]
 }
 
 // the quads of one look (bits of `m`: quad 64 look + bit), four at a time
-template <bool FACE>
+template <bool FACE, bool STATS>
 __device__ __forceinline__ void srd_look(const SrdShared &S, unsigned long long m, int q0, int g,
                                          double xi, double yi, double zi, double boxsize,
                                          double r2_max, double r2_index_scaling,
                                          const double *__restrict__ table, double &ax, double &ay,
-                                         double &az) {
+                                         double &az, bool counted, unsigned *cnt) {
     while (m) {
-        int q[SRD_NB];
+        int q[kdNB];
 #pragma unroll
-        for (int k = 0; k < SRD_NB; k++) {
+        for (int k = 0; k < kdNB; k++) {
             q[k] = m ? q0 + (int)__builtin_ctzll(m) : kdQuads;  // (none left: the far quad)
             m &= m - 1;                                         // (0 stays 0)
         }
-#if SRD_NB == 4
-        if (q[2] == kdQuads) {
-            const int q2[2] = {q[0], q[1]};
-            srd_quads<FACE, 2>(S, q2, g, xi, yi, zi, boxsize, r2_max, r2_index_scaling, table, ax,
-                               ay, az);
-            continue;
-        }
-#endif
-        srd_quads<FACE, SRD_NB>(S, q, g, xi, yi, zi, boxsize, r2_max, r2_index_scaling, table, ax, ay,
-                                az);
+        srd_quads<FACE, kdNB, STATS>(S, q, g, xi, yi, zi, boxsize, r2_max, r2_index_scaling, table, ax, ay,
+                              az, counted, cnt);
     }
 }
 
-#ifndef SRD_XCD_GRANULE
-#define SRD_XCD_GRANULE 16
-#endif
+constexpr unsigned kdGranule = 16;   // consecutive work items per XCD (below)
+template <bool STATS>
 __global__ __launch_bounds__(64 * kdWaves)
-__attribute__((amdgpu_waves_per_eu(SRD_WAVES_PER_EU, 8))) void k_sr_sweep_dense(
+__attribute__((amdgpu_waves_per_eu(8, 8))) void k_sr_sweep_dense(
     const double *__restrict__ pos_r, const unsigned *__restrict__ order_rt,
     const unsigned *__restrict__ order_rc, const unsigned *__restrict__ off_r,
     double *__restrict__ dmom_r, const double *__restrict__ pos_s,
@@ -277,20 +485,15 @@ __attribute__((amdgpu_waves_per_eu(SRD_WAVES_PER_EU, 8))) void k_sr_sweep_dense(
     const int j = lane & 15, g = lane >> 4;
     const int nt = P.nt;
     const unsigned count = *nitems;
-#if SRD_XCD_GRANULE
     // Block b runs on XCD b % 8.  The items of a tile follow each other on the list and stage the
-    // same 27 tiles: granules of SRD_XCD_GRANULE consecutive items go to one XCD (one L2), the
-    // granules to the XCDs in turn.
-    constexpr unsigned G = SRD_XCD_GRANULE;
+    // same 27 tiles: granules of kdGranule consecutive items go to one XCD (one L2), the
+    // granules to the XCDs in turn (profiles/r04_sr_xcd_walk_ab.txt: 46.5 against 47.8 ms).
+    constexpr unsigned G = kdGranule;
     const unsigned vmax = (count + 8u * G - 1u) / (8u * G) * (8u * G);
     for (unsigned v = blockIdx.x; v < vmax; v += gridDim.x) {
     if (v != blockIdx.x) __syncthreads();  // the previous item's tables and rows are done with
     const unsigned it = ((v / 8u / G) * 8u + v % 8u) * G + (v / 8u) % G;
     if (it >= count) continue;
-#else
-    for (unsigned it = blockIdx.x; it < count; it += gridDim.x) {
-    if (it != blockIdx.x) __syncthreads();  // the previous item's tables and rows are done with
-#endif
     const unsigned long long item = items[it];
     const unsigned t = (unsigned)(item >> 32), chunk = (unsigned)item;
     const int tc = (int)(t % (unsigned)nt), tb = (int)((t / (unsigned)nt) % (unsigned)nt),
@@ -364,6 +567,7 @@ __attribute__((amdgpu_waves_per_eu(SRD_WAVES_PER_EU, 8))) void k_sr_sweep_dense(
     __syncthreads();
     const unsigned total = S.ppre[kdPieces];
     double ax = 0, ay = 0, az = 0;
+    unsigned cnt[3] = {0, 0, 0};
     for (unsigned r0 = 0; r0 < total; r0 += kdCap) {
         const int nrows = (int)(min(total, r0 + (unsigned)kdCap) - r0);
         const int nq = (nrows + 3) >> 2;
@@ -425,21 +629,14 @@ __attribute__((amdgpu_waves_per_eu(SRD_WAVES_PER_EU, 8))) void k_sr_sweep_dense(
                     d2 = __builtin_fmaf(gap, gap, d2);
                 }
                 keep = d2 <= r2cull;
-#ifdef SRD_PROBE_NOCULL   // probe build: every quad of the 27 tiles
-                keep = true;
-#endif
             }
             const unsigned long long m = __ballot(keep);
-#ifdef SRD_PROBE_NOPAIRS  // probe build: staging, boxes and culling only
-            ax += (double)__popcll(m) * 1e-300;
-            continue;
-#endif
             if (face)
-                srd_look<true>(S, m, 64 * look, g, xi, yi, zi, P.boxsize, P.r2_max,
-                               P.r2_index_scaling, table, ax, ay, az);
+                srd_look<true, STATS>(S, m, 64 * look, g, xi, yi, zi, P.boxsize, P.r2_max,
+                               P.r2_index_scaling, table, ax, ay, az, valid, cnt);
             else
-                srd_look<false>(S, m, 64 * look, g, xi, yi, zi, P.boxsize, P.r2_max,
-                                P.r2_index_scaling, table, ax, ay, az);
+                srd_look<false, STATS>(S, m, 64 * look, g, xi, yi, zi, P.boxsize, P.r2_max,
+                                P.r2_index_scaling, table, ax, ay, az, valid, cnt);
         }
     }
     // the four lanes of a receiver: one sum, in a fixed order
@@ -458,6 +655,11 @@ __attribute__((amdgpu_waves_per_eu(SRD_WAVES_PER_EU, 8))) void k_sr_sweep_dense(
         dmom_r[3 * pi + 1] += ay * f;
         dmom_r[3 * pi + 2] += az * f;
     }
+    if (STATS && lane == 0) {
+        atomicAdd(&P.stats[3], (unsigned long long)cnt[0]);
+        atomicAdd(&P.stats[4], (unsigned long long)cnt[1]);
+        atomicAdd(&P.stats[5], (unsigned long long)cnt[2]);
+    }
     }
 }
 
@@ -475,23 +677,137 @@ int srd_reserve(cg_ctx *c, void **buf, size_t *have, size_t need) {
 
 }  // namespace
 
-// CONCEPT_GPU_SR_DENSE=0 switches the dense tiles' sweep off; CONCEPT_GPU_SR_DENSE_MIN is the
-// population from which a tile is "dense" (read at every call: a test may change them)
+// CONCEPT_GPU_SR_DENSE_MIN: the population from which a tile is "dense" (64; 0 switches the
+// dense tiles' sweep off; read at every call: a test may change it)
 int cgk_shortrange_dense_min() {
-    const char *on = getenv("CONCEPT_GPU_SR_DENSE"), *mp = getenv("CONCEPT_GPU_SR_DENSE_MIN");
-    if (on && atoi(on) == 0) return -1;
+    const char *mp = getenv("CONCEPT_GPU_SR_DENSE_MIN");
     const int min_pop = mp ? atoi(mp) : 64;
-    return min_pop < 1 ? 1 : min_pop;
+    return min_pop < 1 ? -1 : min_pop;
 }
 
-// Looks at the receivers' half-tile cell list: are there tiles of min_pop receivers and more?
-// If so: tile lists (Hilbert order inside the dense tiles) of the receivers and the suppliers,
-// the byte per tile that keeps the cells sweep off the dense tiles (*take_out) and the launch
-// of the dense tiles' sweep on a stream of its own (joined back into the context's stream by
-// cgk_shortrange_dense_join).  *take_out stays null where the cells sweep does it all.
+// phase 0: the whole list; 1: the tiles' offsets only (histogram + scan — what a caller needs to
+// decide whether it wants the list); 2: the rest, after a call with phase 1 on the same arguments.
+// sub_min > 0: the tiles of sub_min rows and more are re-ordered by sub-cell (their rows are
+// sub_rows at most — the caller's count; a bound that is too small leaves tiles unordered).
+int cgk_shortrange_tiles_phase(cg_ctx *c, int phase, const double *pos, i64 n, i64 nt,
+                               double tile_extent, const signed char *rung, int lowest_active,
+                               unsigned *order, unsigned *offset, double *pos_sorted,
+                               i64 sub_min, i64 sub_rows) {
+    const double eps = 2.220446049250313e-16;
+    const double inv = (1 / tile_extent) * (1 - 2 * eps);
+    const i64 ntiles = nt * nt * nt;
+    const i64 blocks = (n + 255) / 256;
+    if (phase != 2) {
+        if (srd_reserve(c, &c->sr_tmp, &c->sr_tmp_bytes, (size_t)(8 * (ntiles + 1)))) return 1;
+        unsigned *count = (unsigned *)c->sr_tmp;
+        CG_HIP(hipMemsetAsync(c->sr_tmp, 0, 8 * (ntiles + 1), c->stream));
+        if (n > 0) {
+            hipLaunchKernelGGL(k_srd_histogram, dim3((unsigned)blocks), dim3(256), 0, c->stream,
+                               pos, n, inv, (unsigned)nt, rung, lowest_active, count);
+            CG_LAUNCH_CHECK();
+        }
+        size_t need = 0;
+        CG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, count, offset, (int)(ntiles + 1),
+                                                c->stream));
+        if (srd_reserve(c, &c->scan_tmp, &c->scan_tmp_bytes, need)) return 1;
+        CG_HIP(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp, need, count, offset,
+                                                (int)(ntiles + 1), c->stream));
+    }
+    if (phase != 1 && n > 0) {
+        unsigned *cursor = (unsigned *)c->sr_tmp + (ntiles + 1);
+        hipLaunchKernelGGL(k_srd_scatter, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n,
+                           inv, (unsigned)nt, rung, lowest_active, offset, cursor, order,
+                           pos_sorted);
+        CG_LAUNCH_CHECK();
+        if (sub_min > 0 && sub_rows > 0 && pos_sorted) {
+            if (!c->srd_hilbert_done) {  // (per context: the table lives on the context's device)
+                unsigned short h[512];
+                srd_hilbert_table(h);
+                CG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(srd_hilbert), h, sizeof(h)));
+                c->srd_hilbert_done = true;
+            }
+            const i64 cap_tiles = sub_rows / sub_min + 1;
+            const size_t head = (size_t)((8 * (cap_tiles + 2) + 255) / 256 * 256);
+            if (srd_reserve(c, &c->sr_sub_tmp, &c->sr_sub_bytes,
+                            head + sizeof(SrdRow) * (size_t)sub_rows))
+                return 1;
+            unsigned *counters = (unsigned *)c->sr_sub_tmp, *tiles = counters + 2,
+                     *seg = tiles + cap_tiles;
+            SrdRow *scratch = (SrdRow *)((char *)c->sr_sub_tmp + head);
+            CG_HIP(hipMemsetAsync(counters, 0, 8, c->stream));
+            hipLaunchKernelGGL(k_srd_sub_tiles, dim3((unsigned)((ntiles + 255) / 256)), dim3(256),
+                               0, c->stream, offset, (unsigned)ntiles, (unsigned)sub_min,
+                               (unsigned)cap_tiles, (unsigned)sub_rows, counters, tiles, seg);
+            CG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_srd_subsort, dim3((unsigned)cap_tiles), dim3(256), 0, c->stream,
+                               offset, counters, tiles, seg, (unsigned)cap_tiles,
+                               1 / tile_extent, (unsigned)nt, order, pos_sorted, scratch);
+            CG_LAUNCH_CHECK();
+        }
+    }
+    return 0;
+}
+
+// cg_shortrange_tiles: the plain list by tile (no sub-cell order)
+int cgk_shortrange_tiles(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
+                         const signed char *rung, int lowest_active, unsigned *order,
+                         unsigned *offset, double *pos_sorted) {
+    return cgk_shortrange_tiles_phase(c, 0, pos, n, nt, tile_extent, rung, lowest_active, order,
+                                      offset, pos_sorted, 0, 0);
+}
+
+// The look at a half-tile cell list, taken when the list is built (cg_shortrange_cells): how
+// many of its particles sit in tiles of min_pop and more, in how many tiles, the sum of their
+// squared populations, and the length of the list — copied to pinned memory behind an event, so
+// that the sweeps over this list (one per sub-step with adaptive rungs) find the answer without
+// a kernel, a copy or a wait of their own.  Slots are keyed by the offsets' address.
+namespace {
+constexpr int kdLooks = 4;
+int srd_look_slot(cg_ctx *c, const unsigned *off, i64 nt, int min_pop) {
+    for (int i = 0; i < kdLooks; i++)
+        if (c->srd_look[i].off == off && c->srd_look[i].nt == nt &&
+            c->srd_look[i].min_pop == min_pop)
+            return i;
+    return -1;
+}
+}  // namespace
+int cgk_shortrange_dense_look(cg_ctx *c, const unsigned *off_cells, i64 nt) {
+    for (int i = 0; i < kdLooks; i++)   // whatever was known about this address is stale now
+        if (c->srd_look[i].off == off_cells) c->srd_look[i].off = nullptr;
+    const int min_pop = cgk_shortrange_dense_min();
+    if (min_pop < 0 || nt < 4) return 0;
+    const i64 ntiles = nt * nt * nt, ncells = 8 * ntiles;
+    if (!c->srd_host) CG_HIP(hipHostMalloc((void **)&c->srd_host, 256));
+    if (srd_reserve(c, (void **)&c->srd_small, &c->srd_small_bytes, 256)) return 1;
+    const int slot = c->srd_look_next;
+    c->srd_look_next = (slot + 1) % kdLooks;
+    cg_ctx::SrdLook &L = c->srd_look[slot];
+    if (!L.ev) CG_HIP(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
+    // device words 16 + 8 slot: [0] particles in dense tiles, [1] dense tiles, [4..5] sum pop^2
+    unsigned *dev = (unsigned *)c->srd_small + 16 + 8 * slot, *host = c->srd_host + 16 + 8 * slot;
+    CG_HIP(hipMemsetAsync(dev, 0, 32, c->stream));
+    hipLaunchKernelGGL(k_srd_precheck, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0,
+                       c->stream, off_cells, (unsigned)nt, (unsigned)min_pop, dev);
+    CG_LAUNCH_CHECK();
+    CG_HIP(hipMemcpyAsync(host, dev, 32, hipMemcpyDeviceToHost, c->stream));
+    CG_HIP(hipMemcpyAsync(host + 2, off_cells + ncells, 4, hipMemcpyDeviceToHost, c->stream));
+    CG_HIP(hipEventRecord(L.ev, c->stream));
+    L.off = off_cells;
+    L.nt = nt;
+    L.min_pop = min_pop;
+    return 0;
+}
+
+// Are there tiles of min_pop receivers and more (the look taken when the receivers' cell list
+// was built)?  If so: tile lists (Hilbert order inside the dense tiles) of the receivers and the
+// suppliers, the byte per tile that keeps the cells sweep off the dense tiles (*take_out) and the
+// launch of the dense tiles' sweep on a stream of its own (joined back into the context's stream
+// by cgk_shortrange_dense_join).  *take_out stays null where the cells sweep does it all.
 // rung, lowest_active > 0: a sub-step for the upper rungs — the receivers are the particles on
 // rungs >= lowest_active (gravity.py:318-349), "dense" counts those, active_in is the cells
 // sweep's byte per tile (tiles with an active receiver).
+// Host waits: for the look's event (over when the cell list is; nothing on a list looked at
+// before), and — only on a sub-step over a box that has dense tiles — once for the gate's counts.
 int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
                          const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
                          const unsigned *off_s, i64 nt, const double *table,
@@ -504,26 +820,40 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
     if (min_pop < 0 || nt < 4) return 0;
     const bool partial = rung && lowest_active > 0;
     const bool by_threshold = getenv("CONCEPT_GPU_SR_DENSE_MIN") != nullptr;
-    const i64 ntiles = nt * nt * nt, ncells = 8 * ntiles;
-    if (!c->srd_host) CG_HIP(hipHostMalloc((void **)&c->srd_host, 64));
-    if (srd_reserve(c, (void **)&c->srd_small, &c->srd_small_bytes, 64)) return 1;
-    // [0] receivers in dense tiles, [1] dense tiles, [2] items, [4..5] sum of pop^2,
-    // [6] active receivers in tiles dense with them, [7] such tiles, [8..9] sum of active x pop
-    unsigned *dev = (unsigned *)c->srd_small;
-    CG_HIP(hipMemsetAsync(dev, 0, 40, c->stream));
-    hipLaunchKernelGGL(k_srd_precheck, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0,
-                       c->stream, off_r, (unsigned)nt, (unsigned)min_pop, dev);
-    CG_LAUNCH_CHECK();
-    CG_HIP(hipMemcpyAsync(c->srd_host, dev, 8, hipMemcpyDeviceToHost, c->stream));
-    CG_HIP(hipMemcpyAsync(c->srd_host + 2, off_r + ncells, 4, hipMemcpyDeviceToHost, c->stream));
-    CG_HIP(hipMemcpyAsync(c->srd_host + 3, off_s + ncells, 4, hipMemcpyDeviceToHost, c->stream));
-    CG_HIP(hipMemcpyAsync(c->srd_host + 4, dev + 4, 8, hipMemcpyDeviceToHost, c->stream));
-    CG_HIP(hipStreamSynchronize(c->stream));
-    const i64 ndense = c->srd_host[0], tdense = c->srd_host[1], n_r = c->srd_host[2],
-              n_s = c->srd_host[3];
-    if (ndense == 0) return 0;
+    const i64 ntiles = nt * nt * nt;
+    int lr = srd_look_slot(c, off_r, nt, min_pop);
+    if (lr < 0) {  // (a list that did not come from cg_shortrange_cells of this context)
+        if (cgk_shortrange_dense_look(c, off_r, nt)) return 1;
+        lr = srd_look_slot(c, off_r, nt, min_pop);
+    }
+    CG_HIP(hipEventSynchronize(c->srd_look[lr].ev));
+    const unsigned *hr = c->srd_host + 16 + 8 * lr;
+    const i64 ndense = hr[0], tdense = hr[1], n_r = hr[2];
+    // buffers nobody has used for a while go back (a run whose clumps dissolve, a test)
+    if (ndense == 0) {
+        if (++c->srd_idle >= 16 && c->srd_buf_bytes + c->sr_sub_bytes > ((size_t)256 << 20)) {
+            CG_HIP(hipStreamSynchronize(c->stream));
+            if (c->srd_stream) CG_HIP(hipStreamSynchronize(c->srd_stream));
+            (void)hipFree(c->srd_buf);
+            (void)hipFree(c->sr_sub_tmp);
+            c->srd_buf = c->sr_sub_tmp = nullptr;
+            c->srd_buf_bytes = c->sr_sub_bytes = 0;
+        }
+        return 0;
+    }
     // (the list of a sub-step's receivers is a subset: the suppliers get a list of their own)
     const bool same = !partial && pos_r_sorted == pos_s_sorted && off_r == off_s;
+    i64 n_s = n_r, sdense = ndense;
+    if (off_s != off_r) {
+        int ls = srd_look_slot(c, off_s, nt, min_pop);
+        if (ls < 0) {
+            if (cgk_shortrange_dense_look(c, off_s, nt)) return 1;
+            ls = srd_look_slot(c, off_s, nt, min_pop);
+        }
+        CG_HIP(hipEventSynchronize(c->srd_look[ls].ev));
+        n_s = c->srd_host[16 + 8 * ls + 2];
+        sdense = c->srd_host[16 + 8 * ls];
+    }
     // Is it worth the lists?  What the dense tiles cost the cells sweep (~18.75 pair tests per
     // receiver and particle of the tile at its 0.9e12 tests/s; this sweep needs about half)
     // against a list build (measured 0.07 ns per particle; 0.1 here).  A uniform box of 2^28
@@ -531,8 +861,13 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
     // pay: not worth it.  (With CONCEPT_GPU_SR_DENSE_MIN set the threshold alone decides.)
     const double cost = 5e-5 + 1e-10 * (double)(n_r + (same ? 0 : n_s));
     unsigned long long sq;
-    memcpy(&sq, c->srd_host + 4, 8);
+    memcpy(&sq, hr + 4, 8);
     if (!by_threshold && 0.45 * 18.75 * (double)sq / 0.9e12 < 2 * cost) return 0;
+    c->srd_idle = 0;
+    // [2] items, [6] active receivers in tiles dense with them, [7] such tiles, [8..9] sum of
+    // active x pop
+    unsigned *dev = (unsigned *)c->srd_small;
+    CG_HIP(hipMemsetAsync(dev, 0, 40, c->stream));
     // buffers: take | items | offsets r, s | order r, s | positions r, s
     const size_t a_take = 0, a_items = (size_t)((ntiles + 255) / 256 * 256),
                  a_offr = a_items + 8 * (size_t)(ndense / kdChunk + tdense + 1),
@@ -559,7 +894,7 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
                            c->stream, order_r, rung, (unsigned)n_r, rung_sorted);
         CG_LAUNCH_CHECK();
         if (cgk_shortrange_tiles_phase(c, 1, pos_r_sorted, n_r, nt, ext, rung_sorted, lowest_active,
-                                       ordr, offr, posr, nullptr))
+                                       ordr, offr, posr, 0, 0))
             return 1;
         hipLaunchKernelGGL(k_srd_gate, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0,
                            c->stream, offr, off_r, (unsigned)nt, (unsigned)min_pop, dev + 6);
@@ -570,14 +905,14 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
         if (c->srd_host[6] == 0) return 0;
         if (!by_threshold && 0.45 * 18.75 * (double)sq / 0.9e12 < 2 * cost) return 0;
         if (cgk_shortrange_tiles_phase(c, 2, pos_r_sorted, n_r, nt, ext, rung_sorted, lowest_active,
-                                       ordr, offr, posr, nullptr))
+                                       ordr, offr, posr, min_pop, (i64)c->srd_host[6]))
             return 1;
-    } else if (cgk_shortrange_tiles(c, pos_r_sorted, n_r, nt, ext, nullptr, 0, ordr, offr, posr,
-                                    nullptr)) {
+    } else if (cgk_shortrange_tiles_phase(c, 0, pos_r_sorted, n_r, nt, ext, nullptr, 0, ordr, offr,
+                                          posr, min_pop, ndense)) {
         return 1;
     }
-    if (!same &&
-        cgk_shortrange_tiles(c, pos_s_sorted, n_s, nt, ext, nullptr, 0, ords, offs, poss, nullptr))
+    if (!same && cgk_shortrange_tiles_phase(c, 0, pos_s_sorted, n_s, nt, ext, nullptr, 0, ords,
+                                            offs, poss, min_pop, sdense))
         return 1;
     hipLaunchKernelGGL(k_srd_plan, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream,
                        offr, (unsigned)ntiles, (unsigned)min_pop, partial ? active_in : nullptr,
@@ -591,11 +926,12 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
     CG_HIP(hipEventRecord(c->srd_fork, c->stream));
     CG_HIP(hipStreamWaitEvent(c->srd_stream, c->srd_fork, 0));
     SrdParams P{c->p.boxsize, ext, 1.0 / ext, r2_index_scaling, r2_max, factor, factors,
-                rung_jumped, (int)nt};
+                rung_jumped, (int)nt, c->sr_stats};
     // (as many workgroups as there can be items — counted on all the particles, an upper bound
     // for a subset; the ones past the count leave at once)
-    const unsigned grid = (unsigned)(ndense / kdChunk + tdense) + 8u * SRD_XCD_GRANULE;
-    hipLaunchKernelGGL(k_sr_sweep_dense, dim3(grid), dim3(64 * kdWaves), 0, c->srd_stream, posr,
+    const unsigned grid = (unsigned)(ndense / kdChunk + tdense) + 8u * kdGranule;
+    hipLaunchKernelGGL(c->sr_stats ? k_sr_sweep_dense<true> : k_sr_sweep_dense<false>, dim3(grid),
+                       dim3(64 * kdWaves), 0, c->srd_stream, posr,
                        ordr, order_r, offr, dmom_r, poss, offs, items, dev + 2, table, P);
     CG_LAUNCH_CHECK();
     CG_HIP(hipEventRecord(c->srd_join, c->srd_stream));

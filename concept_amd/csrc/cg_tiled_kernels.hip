@@ -62,39 +62,18 @@ __device__ __forceinline__ unsigned tile_for_block(unsigned b, unsigned ntiles) 
 // only.  nb, nc: tiles per dimension (b, c); needs a whole number of groups per XCD, else the
 // plain order.  Measured (2^28 particles / 1024^3, fused pass inside bench.py, i.e. from regions
 // with gaps): G = 1 (plain) 8.89 ms, 2: 8.83, 4: 8.74, 8: 8.85.  (The pull deposit does not
-// gain from it: CG_TILE_GROUP_DEPOSIT.)
-#ifndef CG_TILE_GROUP
-#define CG_TILE_GROUP 4
-#endif
-// CG_TILE_INTERLEAVE=1 (A/B, off): the groups dealt out to the XCDs in a 2-D pattern,
-// XCD = (gb + 3 ga) mod 8, instead of a contiguous eighth of the box (a slab of a-layers) per
-// XCD, so that a clump of a clustered box is shared by several XCDs.  Measured on the clustered
-// bench box (64 clumps, 80 % of the particles): 11.32 against 11.25 ms, uniform 8.56 against
-// 8.52 — no gain, from which rounds 2-3 concluded that the XCDs' loads were not the matter.
-// They were (together with heavy tiles that start late): see cgk_tile_order below, which
-// orders the launch by population instead of by place.
-#ifndef CG_TILE_INTERLEAVE
-#define CG_TILE_INTERLEAVE 0
-#endif
+// gain from it.  Dealing the groups out to the XCDs in a 2-D pattern instead of a contiguous
+// eighth of the box per XCD: no gain either — what a clustered box needed was the launch
+// ORDER, cgk_tile_order below.)
 __device__ __forceinline__ unsigned tile_for_block_grouped(unsigned b, unsigned ntiles,
                                                            unsigned nb, unsigned nc) {
-    constexpr unsigned G = CG_TILE_GROUP;
+    constexpr unsigned G = 4;
     const unsigned per = ntiles / 8u;          // tiles per XCD
-    const unsigned nbg = nb / G, na = ntiles / (nb * nc);
-    const bool interleave = CG_TILE_INTERLEAVE && G >= 2u && nb % G == 0 && nbg % 8u == 0 &&
-                            na % G == 0 && na * nb * nc == ntiles;
-    if (!interleave && (G < 2u || ntiles % 8u || per % (G * nb * nc) || nb % G))
-        return tile_for_block(b, ntiles);
+    const unsigned nbg = nb / G;
+    if (ntiles % 8u || per % (G * nb * nc) || nb % G) return tile_for_block(b, ntiles);
     const unsigned x = b % 8u, i = b / 8u;     // XCD, position in its walk
     const unsigned q = i % (G * G), col = i / (G * G);   // member of the group, group number
     const unsigned c = col % nc, g = col / nc; // column position, group in the (a/G, b/G) plane
-    if (interleave) {
-        // the XCD's g-th group: row ga of groups, the j-th of the row's groups that are its own
-        const unsigned ga = g / (nbg / 8u), j = g % (nbg / 8u);
-        const unsigned gb = ((x + 8u - (3u * ga) % 8u) % 8u) + 8u * j;
-        const unsigned ta = G * ga + q / G, tb = G * gb + q % G;
-        return (ta * nb + tb) * nc + c;
-    }
     const unsigned gb = g % nbg, ga = g / nbg;
     const unsigned ta = G * ga + q / G, tb = G * gb + q % G;
     return x * per + (ta * nb + tb) * nc + c;
@@ -240,10 +219,12 @@ __global__ __launch_bounds__(ORD_B) void k_order_place(const unsigned *__restric
 
 int cgk_tile_order(cg_ctx *c, const unsigned *start, const unsigned *count) {
     if (c->tile_order_mode < 0) {
-        const char *env = getenv("CONCEPT_GPU_TILE_ORDER");
-        c->tile_order_mode = env ? atoi(env) : 1;  // 2: also on boxes of a few tiles (tests)
-        env = getenv("CONCEPT_GPU_TILE_ORDER_MIN");  // particles from which a tile can be heavy
-        c->tile_order_floor = env ? (unsigned)atoi(env) : 1536u;
+        // CONCEPT_GPU_TILE_ORDER_MIN: particles from which a tile can be heavy (1536); 0: the
+        // plain walk; negative: |value|, also on boxes of a few tiles (the tests)
+        const char *env = getenv("CONCEPT_GPU_TILE_ORDER_MIN");
+        const int v = env ? atoi(env) : 1536;
+        c->tile_order_mode = v == 0 ? 0 : (v < 0 ? 2 : 1);
+        c->tile_order_floor = (unsigned)(v < 0 ? -v : v);
     }
     const unsigned ntiles = (unsigned)c->ntiles;
     if (!c->tile_order_mode || ntiles < (c->tile_order_mode == 2 ? 8u : 4096u)) {
@@ -344,11 +325,7 @@ __global__ __launch_bounds__(512) void k_deposit_cic_pull(
         tile = (unsigned)__builtin_amdgcn_readfirstlane((int)ord.list[blockIdx.x]);
     } else {
         const unsigned b = blockIdx.x - (ord.list ? ord.cap : 0u);
-#ifdef CG_TILE_GROUP_DEPOSIT
-        tile = tile_for_block_grouped(b, nblocks, (unsigned)nt, (unsigned)nt);
-#else
         tile = tile_for_block(b, nblocks);
-#endif
         if (ord.list && tile < nordered &&
             (unsigned)__builtin_amdgcn_readfirstlane((int)ord.rank[tile]) < ord.cap)
             return;
@@ -519,22 +496,28 @@ struct PrepArgs {
     i64 emig_rows_cap;
     // heavy tiles first (cgk_tile_order; list null: the plain walk)
     TileOrder order;
+    // MODE 2: the sum of |mom|^2 over the KICKED momenta, one partial per wavefront
+    // (mom2_out[8 * block + wave]; zeroed before the launch; cg_set_momentum_sum; null = off)
+    double *mom2_out;
 };
 
-// Write the 3*rl doubles of a run of rl consecutive records cooperatively (see cg_particles.hip
-// store_run): every store instruction covers a contiguous range.
-__device__ __forceinline__ void gk_store_run(double *__restrict__ out, i64 first, int rs, int rl,
-                                             int lane, bool valid, double a, double b, double c) {
-    int r = lane - rs;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        int d = r + k * rl;
-        int src = rs + d / 3, comp = d - 3 * (d / 3);
-        src = src > 63 ? 63 : src;
-        double va = __shfl(a, src), vb = __shfl(b, src), vc = __shfl(c, src);
-        double v = comp == 0 ? va : (comp == 1 ? vb : vc);
-        if (valid) out[3 * first + d] = v;
-    }
+// sum over the 64 lanes of a wave, in DPP moves (the lanes' order is fixed: reproducible);
+// returned in lane 63
+__device__ __forceinline__ double gk_wave_sum(double v) {
+#define GK_DPP_ADD(ctrl, rows)                                                                    \
+    do {                                                                                          \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rows, 0xf, false); \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rows, 0xf, false); \
+        v += __hiloint2double(hi_, lo_);                                                          \
+    } while (0)
+    GK_DPP_ADD(0x111, 0xf);  // row_shr 1, 2, 4, 8: inclusive scan inside the rows of 16 lanes
+    GK_DPP_ADD(0x112, 0xf);
+    GK_DPP_ADD(0x114, 0xf);
+    GK_DPP_ADD(0x118, 0xf);
+    GK_DPP_ADD(0x142, 0xa);  // row_bcast 15, 31: the row totals forward
+    GK_DPP_ADD(0x143, 0xc);
+#undef GK_DPP_ADD
+    return v;
 }
 
 // LDS of the staged block.  A workgroup's allocation is rounded up to 1280 B and three workgroups
@@ -567,33 +550,12 @@ struct GatherLds {
 // particle indices are 32-bit.  A build that spills loses more than the third workgroup gives
 // (MODE 2 with 4 spilled registers: 10.0 ms; the histogramming variant, MODE 1, squeezed into 80
 // spills 72 B per lane: 9.0 instead of 7.3 ms) — so MODE 1 stays at 4.
-#ifndef CG_GK_WAVES_FUSED
-#define CG_GK_WAVES_FUSED 6
-#endif
-#ifndef CG_GK_WAVES_PLAIN
-#define CG_GK_WAVES_PLAIN 6
-#endif
 template <int ORDER, int T, int MODE>
 constexpr int gk_waves() {
     if (ORDER != 2 || T != 16) return 4;
-    return MODE == 2 ? CG_GK_WAVES_FUSED : (MODE == 0 ? CG_GK_WAVES_PLAIN : 4);
+    return MODE == 1 ? 4 : 6;
 }
 
-#ifdef CG_GK_TIMING  // probe build: where a workgroup's time goes (wave 0 of every workgroup)
-__device__ unsigned long long cg_gk_timing[16];
-extern "C" int cg_debug_gk_timing(unsigned long long *out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(cg_gk_timing), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-    if (reset) {
-        unsigned long long z[16] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(cg_gk_timing), z, sizeof z) != hipSuccess) return 1;
-    }
-    return 0;
-}
-#define GK_T(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
-    const unsigned long long now_ = __builtin_readcyclecounter(); gk_t[i] += now_ - gk_last; gk_last = now_; } while (0)
-#else
-#define GK_T(i) do { } while (0)
-#endif
 // MODE 0: gather + kick in place.  1: also histogram the tile keys after the next drift (PREP).
 // 2: kick, drift and scatter into the next tile order in one pass (nothing written in place).
 template <int ORDER, int T, int MODE>
@@ -609,16 +571,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
     constexpr bool COMPACT = BL::compact;
     extern __shared__ double lds[];
     constexpr bool PREP = MODE == 1, FUSED = MODE == 2;
-#ifdef CG_GK_STAGGER  // timing probe: the second workgroup of every CU starts half a period late
-    if (blockIdx.x >= 256 && blockIdx.x < 512) {
-        const unsigned long long t0 = __builtin_readcyclecounter();
-        while (__builtin_readcyclecounter() - t0 < (unsigned long long)CG_GK_STAGGER)
-            __builtin_amdgcn_s_sleep(32);
-    }
-#endif
-#ifdef CG_GK_TIMING
-    unsigned long long gk_t[8] = {}, gk_last = __builtin_readcyclecounter();
-#endif
     unsigned tile;
     unsigned place = ~0u;  // of the walk's tile on the list of heavy tiles
     if (prep.order.list && blockIdx.x < prep.order.cap) {
@@ -705,31 +657,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         }
         pre_p = p;
         if (pre_valid) {
-#ifdef CG_GK_NARROW
-            pre_x = pos[3 * (i64)p + 0];
-            pre_y = pos[3 * (i64)p + 1];
-            pre_z = pos[3 * (i64)p + 2];
-            pre_mx = mom[3 * (i64)p + 0];
-            pre_my = mom[3 * (i64)p + 1];
-            pre_mz = mom[3 * (i64)p + 2];
-#else
             // a record is 24 B at an 8-byte boundary: one 16-byte and one 8-byte access (global
             // memory takes vector accesses at their element's alignment) — 4 requests per
             // particle instead of 6
             const d2u8 a = *(const d2u8 *)(pos + 3 * (i64)p), b = *(const d2u8 *)(mom + 3 * (i64)p);
             pre_x = a.x, pre_y = a.y, pre_z = pos[3 * (i64)p + 2];
             pre_mx = b.x, pre_my = b.y, pre_mz = mom[3 * (i64)p + 2];
-#endif
         }
     };
-#ifdef CG_GK_PREFETCH
-    // (off.  Round 4 also tried the first batch's POSITIONS alone under the staging — from regions
-    // with gaps the lanes of bucket 0, whose start and population are scalar loads, so that no
-    // table has to be waited for: 4 spilled registers at the 80 that three workgroups per CU
-    // allow, 9.4 against 8.4 ms)
-    if (gapped) __syncthreads();  // (the fetch reads the segment table)
-    if (FUSED) fetch(beg);
-#endif
+    // (Issuing a batch's particle loads one stage ahead — the first batch's under the staging of
+    // the block, the next one's under the arithmetic of the present one — costs 4 spilled
+    // registers at the 80 that three workgroups per CU allow: 9.4 against 8.4 ms.)
     const int tc = tile % nt, tb = (tile / nt) % nt, ta = tile / (nt * nt);
     const int Ni = (int)N;
     const int T0a = (int)xm.x0 + ta * T, T0b = tb * T, T0c = tc * T;
@@ -775,11 +713,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
                 for (int q = 0; q < NP; q++) {
                     const bool want = (PL % 64 == 0 || lane + 64 * q < PL) &&
                                       (!edge || cmp[COMPACT ? q : 0] >= 0);
-#ifdef CG_GK_NOSTAGE  // timing probe only: the block is not read
-                    if (want) v[s][q] = (double)off[q];
-#else
                     if (want) v[s][q] = plane[off[q]];
-#endif
                 }
             }
         }
@@ -808,22 +742,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         }
     }
     __syncthreads();
-    GK_T(0);  // staging
+    int m2_lo = 0, m2_hi = 0;  // (FUSED, prep.mom2_out: this wave's sum of |mom|^2, wave-uniform)
     for (pidx pbase = beg; pbase < end; pbase += 512) {
         pidx p = pbase + threadIdx.x;
         bool pvalid = p < end;
         double px = 0, py = 0, pz = 0, qx = 0, qy = 0, qz = 0;
         if (FUSED) {
-#ifndef CG_GK_PREFETCH
             fetch(pbase);
-#endif
             p = pre_p;
             pvalid = pre_valid;
             px = pre_x, py = pre_y, pz = pre_z, qx = pre_mx, qy = pre_my, qz = pre_mz;
-            GK_T(1);  // particle loads
-#ifdef CG_GK_PREFETCH
-            if (pbase + 512 < end) fetch(pbase + 512);
-#endif
         } else if (pvalid) {
             px = pos[3 * (i64)p + 0], py = pos[3 * (i64)p + 1], pz = pos[3 * (i64)p + 2];
         }
@@ -945,7 +873,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         if (FUSED) {
             // the scatter of cg_particles.hip k_tile_scatter: one atomic per run of equal keys
             // among consecutive lanes, runs stored cooperatively
-            GK_T(2);  // gather, kick, drift, key
             const int lane = threadIdx.x & 63;
             int rs, rl;
             wave_runs(next_key, lane, rs, rl);
@@ -955,45 +882,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
                 // populations outgrew what the arrays were sized for)
                 const unsigned o0 = prep.start_out[next_key], o1 = prep.start_out[next_key + 1],
                                room = (i64)o1 <= prep.out_capacity ? o1 - o0 : 0u;
-#ifdef CG_GK_NOATOMIC  // timing probe only: no reservation round trip (wrong places)
-                const unsigned local = room > (unsigned)rl ? 0u : 0u * room;
-#else
                 const unsigned local = atomicAdd(&prep.count_out[next_key], (unsigned)rl);
-#endif
                 if (local + (unsigned)rl > room) atomicOr(prep.err_flags, 2u);  // overflow
                 else first = o0 + local;
             }
             first = __shfl(first, rs);
-            GK_T(3);  // reservation round trip
             const bool valid = pvalid && next_key != kNoTile && first != kNoTile;
-#if !defined(CG_GK_RUNSTORE) && !defined(CG_GK_NOSTORE)
             // every lane stores its own record (24-byte stride; the runs of a wave are
             // consecutive records, L2 merges the partial lines).  The cooperative run store of
-            // the stand-alone scatter (gk_store_run: contiguous stores through 36 lane
+            // the stand-alone scatter (store_run there: contiguous stores through 36 lane
             // permutes per particle) is slower HERE — 10.4 vs 9.9 ms — because the permutes go
             // through the LDS crossbar, which the stencil reads already keep busy.
             if (valid) {
-#ifdef CG_GK_STOREINPLACE  // timing probe only: dense stores at the input slot
-                const i64 q = 3 * (i64)p;
-#else
                 const i64 q = 3 * ((i64)first + (lane - rs));
-#endif
-#ifdef CG_GK_NARROW
-                prep.pos_out[q] = nx, prep.pos_out[q + 1] = ny_, prep.pos_out[q + 2] = nz;
-                prep.mom_out[q] = n0, prep.mom_out[q + 1] = n1, prep.mom_out[q + 2] = n2;
-#else
                 d2u8 a, b;
                 a.x = nx, a.y = ny_, b.x = n0, b.y = n1;
                 *(d2u8 *)(prep.pos_out + q) = a;
                 prep.pos_out[q + 2] = nz;
                 *(d2u8 *)(prep.mom_out + q) = b;
                 prep.mom_out[q + 2] = n2;
-#endif
             }
-#elif defined(CG_GK_RUNSTORE)   // (NOSTORE: timing probe only)
-            gk_store_run(prep.pos_out, (i64)first, rs, rl, lane, valid, nx, ny_, nz);
-            gk_store_run(prep.mom_out, (i64)first, rs, rl, lane, valid, n0, n1, n2);
-#endif
             if (valid && prep.ids_in) prep.ids_out[(i64)first + (lane - rs)] = prep.ids_in[p];
             if (valid && prep.aux_in) prep.aux_out[(i64)first + (lane - rs)] = prep.aux_in[p];
             if (prep.emig_rows && pvalid && next_key == kNoTile) {
@@ -1009,24 +917,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
                     atomicOr(prep.err_flags, (unsigned)CG_ERR_BUCKET_OVERFLOW);
                 }
             }
-            GK_T(4);  // stores
+            if (prep.mom2_out) {
+                // analysis.measure(component, 'v_rms') (analysis.py:3902-3910) of the momenta
+                // this pass leaves: the sum of a batch's |mom|^2 over the wave's lanes, carried
+                // on in scalar registers (the values are dead by now: no register of the
+                // pass's 80 is held for it — a per-lane accumulator cost the third workgroup
+                // per CU its place)
+                const double e = pvalid ? (n0 * n0 + n1 * n1) + n2 * n2 : 0.0;
+                const double t = gk_wave_sum(e);
+                const double acc = __hiloint2double(m2_hi, m2_lo) +
+                                   __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), 63),
+                                                    __builtin_amdgcn_readlane(__double2loint(t), 63));
+                m2_lo = __builtin_amdgcn_readfirstlane(__double2loint(acc));
+                m2_hi = __builtin_amdgcn_readfirstlane(__double2hiint(acc));
+            }
         }
     }
-#ifdef CG_GK_TIMING
-    if (FUSED && threadIdx.x == 0) {
-        for (int i = 0; i < 5; i++) atomicAdd(&cg_gk_timing[i], gk_t[i]);
-        atomicAdd(&cg_gk_timing[8], 1ull);
+    if (FUSED && prep.mom2_out && (threadIdx.x & 63) == 0)
+        prep.mom2_out[8 * (i64)blockIdx.x + (threadIdx.x >> 6)] = __hiloint2double(m2_hi, m2_lo);
+}
+
+// the wavefronts' partial sums added in a fixed order (1024 strided sums, then a tree)
+__global__ __launch_bounds__(1024) void k_sum_partials(const double *__restrict__ part, i64 n,
+                                                       double *__restrict__ out) {
+    __shared__ double red[1024];
+    double s = 0;
+    for (i64 i = threadIdx.x; i < n; i += 1024) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 512; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
     }
-#endif
+    if (threadIdx.x == 0) out[0] = red[0];
 }
 
 template <int ORDER, int T>
 static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsigned *tile_offset,
                          double c1, double c2, double factor, const PrepArgs *prep) {
-    size_t lds = sizeof(double) * GatherLds<ORDER, T>::doubles;
-#ifdef CG_GK_LDS_PROBE  // timing probe only: a smaller LDS allocation (accesses beyond it are dropped)
-    if (const char *e = getenv("CONCEPT_GPU_GK_LDS_PROBE")) lds = (size_t)atol(e);
-#endif
+    const size_t lds = sizeof(double) * GatherLds<ORDER, T>::doubles;
     auto kern = k_gather_kick_tiled<ORDER, T, 0>;
     auto kern_prep = k_gather_kick_tiled<ORDER, T, 1>;
     auto kern_fused = k_gather_kick_tiled<ORDER, T, 2>;
@@ -1082,6 +1011,19 @@ int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
         prep_args.emig_rows_count = c->emig_rows_count;
         prep_args.emig_rows_cap = c->emig_rows_cap;
         if (c->emig_rows) CG_HIP(hipMemsetAsync(c->emig_rows_count, 0, 4, c->stream));
+        if (c->mom2_sum_out) {
+            const size_t need = sizeof(double) * 8 * ((size_t)c->ntiles + (c->ntiles / 8 + 8));
+            if (need > c->mom2_partial_bytes) {
+                CG_HIP(hipStreamSynchronize(c->stream));
+                (void)hipFree(c->mom2_partial);
+                c->mom2_partial = nullptr;
+                c->mom2_partial_bytes = 0;
+                CG_HIP(hipMalloc((void **)&c->mom2_partial, need));
+                c->mom2_partial_bytes = need;
+            }
+            CG_HIP(hipMemsetAsync(c->mom2_partial, 0, need, c->stream));
+            prep_args.mom2_out = c->mom2_partial;
+        }
         prepare = 0;
         CG_HIP(hipMemsetAsync(fs->count_out, 0, 4 * (8 * c->ntiles), c->stream));
     }
@@ -1117,6 +1059,12 @@ int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
 #undef CG_GATHER_CASE
     if (rc) return rc;
     CG_LAUNCH_CHECK();
+    if (fs && c->mom2_sum_out) {
+        const i64 nparts = 8 * ((i64)c->ntiles + (i64)tile_order_args(c).cap);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, c->stream, c->mom2_partial,
+                           nparts, c->mom2_sum_out);
+        CG_LAUNCH_CHECK();
+    }
     c->prep_valid = prepare != 0;
     c->prep_pos = pos;
     c->prep_mom = mom;

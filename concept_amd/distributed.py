@@ -541,15 +541,13 @@ def shortrange_kick(domain, particles, *, scale, range_, tilesize, tablesize, so
         ghosts = list(ship_boundary_positions(m, pos, range_*(1 + 1e-9) + 1e-9*L))
     supp = torch.cat([pos] + ghosts).contiguous()
     ext = L/nt
-    mfma = shortrange.SWEEP == 'mfma'
-    build = m.shortrange_tiles if mfma else m.shortrange_cells
-    cells_r = build(pos.contiguous(), nt, ext)
-    cells_s = build(supp, nt, ext) if ghosts else cells_r
+    cells_r = m.shortrange_cells(pos.contiguous(), nt, ext)
+    cells_s = m.shortrange_cells(supp, nt, ext) if ghosts else cells_r
     table, maxr2 = shortrange.get_shortrange_table(softening, scale, range_, tablesize, kernel,
                                                    pos.device)
     dmom = torch.zeros((n, 3), dtype=torch.float64, device=pos.device)
-    (m.shortrange_sweep_tiles if mfma else m.shortrange_sweep_cells)(
-        cells_r, dmom, cells_s, nt, table, (tablesize - 1)/maxr2, range_**2, factor)
+    m.shortrange_sweep_cells(cells_r, dmom, cells_s, nt, table, (tablesize - 1)/maxr2, range_**2,
+                             factor)
     return dmom
 
 
@@ -648,6 +646,14 @@ class RegionParticles:
         self.meta_event = torch.cuda.Event()
         self.pending = False
         self.emigrants_total = 0
+        # sum of |mom|^2 left by the last fused pass (cg_set_momentum_sum): what the time loop's
+        # v_rms needs after every kick, without a pass over the momenta of its own
+        self.m2 = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.m2_host = torch.zeros(1, dtype=torch.float64)
+        if dev.type == 'cuda':
+            self.m2_host = self.m2_host.pin_memory()
+        self.m2_event = torch.cuda.Event()
+        self.m2_valid = False
 
     # -- A1 -------------------------------------------------------------------------
     def deposit(self, contribution, accumulate=False):
@@ -667,14 +673,19 @@ class RegionParticles:
         if self.multi:
             lib.check(lib.raw().cg_set_emigrant_rows(m._ctx, _vp(self.rows), _vp(self.meta),
                                                      self.rows.shape[0]))
+        lib.check(lib.raw().cg_set_momentum_sum(m._ctx, _vp(self.m2)))
         try:
             m.gather_kick_drift_scatter(self.pos[c], self.mom[c], self.ids[c], self.start, self.count,
                                         self.pos[o], self.mom[o], self.ids[o], start_out,
                                         count_out, diff_order, kick_factor, dt_over_mass,
                                         aux_in=self.aux[c], aux_out=self.aux[o])
         finally:
+            lib.check(lib.raw().cg_set_momentum_sum(m._ctx, None))
             if self.multi:
                 lib.check(lib.raw().cg_set_emigrant_rows(m._ctx, None, None, 0))
+        self.m2_host.copy_(self.m2, non_blocking=True)
+        self.m2_event.record()
+        self.m2_valid = True
         self.start, self.count, self.cur = start_out, count_out, o
         if self.multi:
             # destinations and counts on the device, counts swapped with the peers, copy to
@@ -688,9 +699,15 @@ class RegionParticles:
             self.meta_event.record()
             self.pending = True
 
-    def measure_momentum(self):
-        """(Σ mom², max |mom_i|²) of this rank's live particles (analysis.measure's inputs)"""
+    def measure_momentum(self, want_max=True):
+        """(Σ mom², max |mom_i|²) of this rank's live particles (analysis.measure's inputs).
+        want_max=False: the sum the last fused pass left — over the particles THIS rank
+        kicked, the leavers of its slab included, so that the ranks' sums add up to the
+        box's — with NaN for the maximum: no pass, no kernel."""
         self.finish_exchange()
+        if not want_max and self.m2_valid:
+            self.m2_event.synchronize()
+            return float(self.m2_host[0]), float('nan')
         if self.count is None:
             return self.mesh.measure_momentum(self.mom[self.cur][:self.n_dense])
         return self.mesh.measure_momentum_regions(self.mom[self.cur], self.start, self.count)
@@ -731,6 +748,7 @@ class RegionParticles:
     def restore(self, snap):
         self.cur, self.start, self.count = snap
         self.pending = False  # (the leavers of the undone pass are dropped with it)
+        self.m2_valid = False
 
     # -- bookkeeping ------------------------------------------------------------------
     @property

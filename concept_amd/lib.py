@@ -82,19 +82,14 @@ SYMBOLS = {
     'cg_sort_particles': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'cg_drift_sort': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _vp]),
     'cg_tile_info': (_int, [_vp, ctypes.POINTER(ctypes.c_int64*3)]),
-    'cg_shortrange_build': (_int, [_vp, _vp, _i64, _i64, _dbl, _vp, _vp]),
-    'cg_shortrange_sweep': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _i64,
-                                   _dbl, _dbl, _dbl]),
-    'cg_shortrange_sweep_rungs': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp,
-                                         _i64, _dbl, _dbl, _vp, _vp, _vp, _int]),
     'cg_shortrange_cells': (_int, [_vp, _vp, _i64, _i64, _dbl, _vp, _vp, _vp]),
     'cg_shortrange_sweep_cells': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _dbl,
                                          _dbl, _dbl]),
     'cg_shortrange_sweep_cells_rungs': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64,
                                                _dbl, _dbl, _vp, _vp, _vp, _int]),
-    'cg_shortrange_tiles': (_int, [_vp, _vp, _i64, _i64, _dbl, _vp, _int, _vp, _vp, _vp, _vp]),
-    'cg_shortrange_sweep_tiles': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64,
-                                         _dbl, _dbl, _dbl, _vp, _vp]),
+    'cg_shortrange_tiles': (_int, [_vp, _vp, _i64, _i64, _dbl, _vp, _int, _vp, _vp, _vp]),
+    'cg_shortrange_stats': (_int, [_vp, _int, _vp]),
+    'cg_set_momentum_sum': (_int, [_vp, _vp]),
     'cg_dmom_nullify': (_int, [_vp, _vp, _vp, _i64, _int]),
     'cg_dmom_apply': (_int, [_vp, _vp, _vp, _vp, _i64, _int]),
     'cg_dmom_to_acc': (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp, _int]),

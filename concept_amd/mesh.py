@@ -647,36 +647,6 @@ class PotentialMesh:
 
     # -- debug / parity -----------------------------------------------------
     # -- P3M short range -----------------------------------------------------------
-    def shortrange_build(self, pos, nt, tile_extent):
-        n = self._check_particles(pos)
-        order = torch.empty(max(n, 1), dtype=torch.int32, device=pos.device)
-        offset = torch.empty(nt**3 + 1, dtype=torch.int32, device=pos.device)
-        check(_L.cg_shortrange_build(self._ctx, _ptr(pos), n, int(nt), float(tile_extent),
-                                     _ptr(order), _ptr(offset)))
-        return order, offset
-
-    def shortrange_sweep(self, pos_r, cells_r, dmom_r, pos_s, cells_s, nt, same, table,
-                         r2_index_scaling, r2_max, factor, rungs=None):
-        """`rungs` = (factors[3*N_rungs-1] CUDA float64, rung int8, rung_jumped int8,
-        lowest_active_rung) selects the adaptive-rung form (then `factor` is unused)."""
-        n = self._check_particles(pos_r, dmom_r)
-        self._check_particles(pos_s)
-        if table.dtype != torch.float64 or not table.is_cuda:
-            raise lib.ConceptGPUError('short-range table must be a float64 CUDA tensor')
-        if rungs is None:
-            check(_L.cg_shortrange_sweep(
-                self._ctx, _ptr(pos_r), _ptr(cells_r[0]), _ptr(cells_r[1]), _ptr(dmom_r),
-                _ptr(pos_s), _ptr(cells_s[0]), _ptr(cells_s[1]), int(nt), int(same), _ptr(table),
-                table.numel(), float(r2_index_scaling), float(r2_max), float(factor)))
-            return
-        factors, rung, rung_jumped, lowest = rungs
-        self._check_rungs(n, rung, rung_jumped)
-        check(_L.cg_shortrange_sweep_rungs(
-            self._ctx, _ptr(pos_r), _ptr(cells_r[0]), _ptr(cells_r[1]), _ptr(dmom_r), _ptr(pos_s),
-            _ptr(cells_s[0]), _ptr(cells_s[1]), int(nt), int(same), _ptr(table), table.numel(),
-            float(r2_index_scaling), float(r2_max), _ptr(factors), _ptr(rung), _ptr(rung_jumped),
-            int(lowest)))
-
     def shortrange_cells(self, pos, nt, tile_extent):
         """Cell list at half-tile granularity with the positions copied in cell order
         (cg_shortrange_cells): (order, offset, pos_sorted)."""
@@ -690,8 +660,9 @@ class PotentialMesh:
 
     def shortrange_sweep_cells(self, cells_r, dmom_r, cells_s, nt, table, r2_index_scaling,
                                r2_max, factor, rungs=None):
-        """The sweep over half-tile cells; cells_* from shortrange_cells().  `rungs` as in
-        shortrange_sweep."""
+        """The sweep over half-tile cells; cells_* from shortrange_cells().  `rungs` =
+        (factors[3*N_rungs-1] CUDA float64, rung int8, rung_jumped int8, lowest_active_rung)
+        selects the adaptive-rung form (then `factor` is unused)."""
         n = self._check_particles(dmom_r)
         if table.dtype != torch.float64 or not table.is_cuda:
             raise lib.ConceptGPUError('short-range table must be a float64 CUDA tensor')
@@ -711,51 +682,31 @@ class PotentialMesh:
             float(r2_max), _ptr(factors), _ptr(rung), _ptr(rung_jumped), int(lowest)))
 
     def shortrange_tiles(self, pos, nt, tile_extent, active=None):
-        """The particles listed by tile (z fastest) with their positions copied in that order
-        (cg_shortrange_tiles): (order, offset, pos_sorted, operand).  active = (rung int8,
-        lowest_active_rung) lists the particles on active rungs only (a sub-step's receivers:
-        no operand rows); the tensors keep room for all n, offset[-1] says how many are
-        listed."""
+        """The particles listed by tile (z fastest; cg_shortrange_tiles — the reference's
+        `tiles[tile]` lists): (order, offset, pos_sorted).  active = (rung int8,
+        lowest_active_rung) lists the particles on active rungs only; the tensors keep room for
+        all n, offset[-1] says how many are listed."""
         n = self._check_particles(pos)
         order = torch.empty(max(n, 1), dtype=torch.int32, device=pos.device)
         offset = torch.empty(nt**3 + 1, dtype=torch.int32, device=pos.device)
         pos_sorted = torch.empty((max(n, 1), 3), dtype=torch.float64, device=pos.device)
         rung, lowest = (None, 0) if active is None else active
-        operand = None
         if rung is not None:
             self._check_rungs(n, rung)
-        else:
-            # operand rows (16 rows of padding: the last 16-row block of the list is read
-            # whole), then the bounding boxes of the 16-row blocks (2 x 4 floats each)
-            operand = torch.empty(4*(n + 16) + 8*(n//16 + 2), dtype=torch.float32,
-                                  device=pos.device)
         check(_L.cg_shortrange_tiles(self._ctx, _ptr(pos), n, int(nt), float(tile_extent),
                                      _ptr(rung) if rung is not None else None, int(lowest),
-                                     _ptr(order), _ptr(offset), _ptr(pos_sorted),
-                                     _ptr(operand) if operand is not None else None))
-        return order, offset, pos_sorted, operand
+                                     _ptr(order), _ptr(offset), _ptr(pos_sorted)))
+        return order, offset, pos_sorted
 
-    def shortrange_sweep_tiles(self, tiles_r, dmom_r, tiles_s, nt, table, r2_index_scaling,
-                               r2_max, factor, rungs=None):
-        """The sweep with the matrix-core pre-filter over the lists of shortrange_tiles().
-        rungs = (factors, rung_jumped int8): dmom += factors[rung_jumped] * sum per receiver
-        (the receiver list then holds the active receivers only), else `factor`."""
-        n = self._check_particles(dmom_r)
-        if table.dtype != torch.float64 or not table.is_cuda:
-            raise lib.ConceptGPUError('short-range table must be a float64 CUDA tensor')
-        order_r, off_r, pos_r = tiles_r[:3]
-        _, off_s, pos_s, op_s = tiles_s
-        if op_s is None:
-            raise lib.ConceptGPUError('the supplier list was built for receivers only')
-        factors, rung_jumped = (None, None) if rungs is None else rungs
-        if rung_jumped is not None:
-            self._check_rungs(n, rung_jumped)
-        check(_L.cg_shortrange_sweep_tiles(
-            self._ctx, _ptr(pos_r), _ptr(order_r), _ptr(off_r), _ptr(dmom_r), _ptr(pos_s),
-            _ptr(off_s), _ptr(op_s), pos_s.shape[0], int(nt), _ptr(table), table.numel(),
-            float(r2_index_scaling), float(r2_max), float(factor),
-            _ptr(factors) if factors is not None else None,
-            _ptr(rung_jumped) if rung_jumped is not None else None))
+    def shortrange_stats(self, enable):
+        """cg_shortrange_stats: switch the sweeps' counters on (True), or off (False) and return
+        {'cells': (tests, hits, trips), 'dense': (tests, hits, trips)} of the sweeps since."""
+        if enable:
+            check(_L.cg_shortrange_stats(self._ctx, 1, None))
+            return None
+        out = (ctypes.c_uint64*8)()
+        check(_L.cg_shortrange_stats(self._ctx, 0, out))
+        return {'cells': tuple(int(v) for v in out[0:3]), 'dense': tuple(int(v) for v in out[3:6])}
 
     SHORTRANGE_SPARSE_MAX = 8
 

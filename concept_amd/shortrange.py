@@ -90,10 +90,6 @@ def _pair_integrals(ᔑdt_rungs, rec, sup):
 
 
 sparse_sweeps = 0   # sweeps taken without a cell list (a handful of active receivers)
-# which tile sweep runs: 'cells' = the half-tile cell list (cg_shortrange_sweep_cells), the
-# faster of the two on MI355X; 'mfma' = lists by tile + matrix-core range pre-filter
-# (cg_shortrange_sweep_tiles, round 4: same sums; DESIGN.md §16 has the measurements)
-SWEEP = os.environ.get('CONCEPT_GPU_SR_SWEEP', 'cells')
 
 
 def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
@@ -132,9 +128,7 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
         slack = max(c._store.mesh.boxsize/c._store.mesh.gridsize for c in involved)
         for c in involved:
             check_shortrange_fits(c._store.mesh, sr['range'] + slack)
-    if SWEEP not in ('mfma', 'cells'):
-        raise ConceptGPUError(f'CONCEPT_GPU_SR_SWEEP={SWEEP!r}: "mfma" or "cells"')
-    build = mesh.shortrange_tiles if SWEEP == 'mfma' else mesh.shortrange_cells
+    build = mesh.shortrange_cells
     def get_cells(c):
         """the component's cell list (built when a sweep first asks for it: a sub-step that
         kicks a handful of particles needs none, see sweep() below)"""
@@ -142,15 +136,6 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
             cells[id(c)] = build(c.pos, nt, tile_extent)
             supp_cells.setdefault(id(c), cells[id(c)])
         return cells[id(c)]
-    active_lists = {}
-    def get_active(c):
-        """the component's particles on active rungs, by tile: the receivers of a sub-step
-        (main.py:1347-1624 visits the tiles' active rungs only)"""
-        key_ = (id(c), c.lowest_active_rung)
-        if key_ not in active_lists:
-            active_lists[key_] = mesh.shortrange_tiles(
-                c.pos, nt, tile_extent, active=(c.rung_indices, c.lowest_active_rung))
-        return active_lists[key_]
     for c in involved:
         supp_pos[id(c)] = c.pos
         # every involved component can act as supplier: s of sweep(r, s), and r of the
@@ -214,12 +199,6 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
                                                    (factors, rec.rung_indices_jumped))
                         return
                     get_cells(sup)
-                    if SWEEP == 'mfma':
-                        rc = get_active(rec) if rec.lowest_active_rung > 0 else get_cells(rec)
-                        mesh.shortrange_sweep_tiles(rc, rec.Δmom, supp_cells[id(sup)], nt, table,
-                                                    scaling, r2_max, 0.0,
-                                                    (factors, rec.rung_indices_jumped))
-                        return
                     rungs = (factors, rec.rung_indices, rec.rung_indices_jumped,
                              rec.lowest_active_rung)
                     rc = get_cells(rec)
@@ -228,10 +207,9 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
                 else:
                     rc = get_cells(rec)
                     get_cells(sup)
-                    sweep_ = (mesh.shortrange_sweep_tiles if SWEEP == 'mfma'
-                              else mesh.shortrange_sweep_cells)
-                    sweep_(rc, rec.Δmom, supp_cells[id(sup)], nt, table, scaling,
-                           r2_max, p.G_Newton*rec.mass*sup.mass*float(integrals[0]))
+                    mesh.shortrange_sweep_cells(
+                        rc, rec.Δmom, supp_cells[id(sup)], nt, table, scaling, r2_max,
+                        p.G_Newton*rec.mass*sup.mass*float(integrals[0]))
             sweep(r, s, same)
             if not same and s in receivers:
                 # the reference kicks both partners of a pair (Δmom_s -= ..., gravity.py:341-349)

@@ -408,7 +408,7 @@ def measure(component, quantity, a, regions=None):
         raise ConceptGPUError('measure(): particle components only (the fluid solvers are '
                               'outside this path)')
     if regions is not None:
-        mom2_sum, mom2_max = regions.measure_momentum()
+        mom2_sum, mom2_max = regions.measure_momentum(want_max=quantity == 'v_max')
     else:
         mom2_sum, mom2_max = component._store.mesh.measure_momentum(component.mom)
     if component.comm is not None and component.nprocs > 1:

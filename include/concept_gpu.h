@@ -208,6 +208,13 @@ int cg_tile_order_read(cg_ctx *ctx, uint32_t *heavy_out /*HOST*/, int64_t capaci
 /* (ids and aux: two 64-bit columns that travel with the particles — a Component's `ids` and
  * the row numbers its host() uses to restore the populated order) */
 
+/* analysis.measure(component, 'v_rms') (analysis.py:3902-3910, what get_base_timestep_size asks
+ * for after every kick, main.py:697-916) without a pass of its own: with sum_out set,
+ * cg_gather_kick_drift_scatter also leaves the sum of |mom|^2 over the particles it kicked —
+ * leavers of a slab included — in sum_out[0] (per-wavefront partials added in a fixed order:
+ * reproducible).  NULL switches it off.  cg_measure_momentum[_regions] stays the stand-alone form. */
+int cg_set_momentum_sum(cg_ctx *ctx, double *sum_out /*DEV 1, or NULL*/);
+
 /* The same on x-slab domains: a particle whose drift takes it out of the slab has no place in
  * this domain's next order; the kernel appends it — kicked and drifted — to a caller-owned row
  * buffer (8 doubles: pos 3, mom 3, id bits, aux bits), exchange() (communication.py:135-517)
@@ -284,70 +291,49 @@ int cg_drift_sort(cg_ctx *ctx, const double *pos_in, const double *mom_in,
 int cg_tile_info(const cg_ctx *ctx, int64_t info[3]);
 
 /* --- A13..A15: P3M short-range tile sweep -------------------------------------
- * cg_shortrange_build: Tiling.sort (species.py:707-823) for the 'gravity (tiles)'
- * tiling of nt^3 tiles (init_tiling, species.py:3943-3983: nt = int(boxsize/tilesize*
- * (1+eps)), at least 4) as a cell list: order_out[n] = particle indices grouped by
- * tile, offset_out[nt^3+1] = first entry of each tile.
- * cg_shortrange_sweep: particle_particle (interactions.py:1563-1791) +
- * gravity_pairwise_shortrange (gravity.py:263-354), all particles on rung 0:
+ * Tiling.sort (species.py:707-823) for the 'gravity (tiles)' tiling of nt^3 tiles (init_tiling,
+ * species.py:3943-3983: nt = int(boxsize/tilesize*(1+eps)), at least 4), particle_particle
+ * (interactions.py:1563-1791) and gravity_pairwise_shortrange (gravity.py:263-354):
  *   dmom_r[i] += sum_j ((xi - xj) + periodic_offset) * factor * table[int(r2*scaling)]
- * over all supplier particles j != i of the 27 neighbouring tiles with r2 <= r2_max.
- * One-sided: to kick both components of a pair call it twice with the roles swapped
- * (for one component on itself once, same_component = 1).
+ * over all supplier particles j of the tiles around i's own with r2 <= r2_max.
+ * One-sided: to kick both components of a pair call the sweep twice with the roles swapped.
  *   table            get_shortrange_table (gravity.py:373-424), DEV double[tablesize]
  *   r2_index_scaling (tablesize - 1)/shortrange_table_maxr2      (gravity.py:288)
  *   r2_max           shortrange_range**2                          (gravity.py:286)
- *   factor           G_Newton*mass_r*mass_s*dt_rungs[...][0]      (gravity.py:51-64) */
-int cg_shortrange_build(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, int64_t nt,
-                        double tile_extent, uint32_t *order_out /*DEV n*/,
-                        uint32_t *offset_out /*DEV nt^3+1*/);
-int cg_shortrange_sweep(cg_ctx *ctx, const double *pos_r, const uint32_t *order_r,
-                        const uint32_t *offset_r, double *dmom_r /*DEV 3n_r, accumulated*/,
-                        const double *pos_s, const uint32_t *order_s, const uint32_t *offset_s,
-                        int64_t nt, int same_component, const double *table /*DEV*/,
-                        int64_t tablesize, double r2_index_scaling, double r2_max, double factor);
-
-/* The sweep with adaptive rungs (interactions.py:1688-1761, gravity.py:318-349): a receiver
- * on an active rung (rung_r[i] >= lowest_active_rung) is kicked with
- * factors[rung_jumped_r[i]], factors[k] = G*m_r*m_s*dt_rungs[...][k], k < 3*N_rungs-1
- * (DEV); receivers on inactive rungs are left alone. */
-int cg_shortrange_sweep_rungs(cg_ctx *ctx, const double *pos_r, const uint32_t *order_r,
-                              const uint32_t *offset_r, double *dmom_r, const double *pos_s,
-                              const uint32_t *order_s, const uint32_t *offset_s, int64_t nt,
-                              int same_component, const double *table /*DEV*/, int64_t tablesize,
-                              double r2_index_scaling, double r2_max,
-                              const double *factors /*DEV 3*N_rungs-1*/,
-                              const int8_t *rung_r /*DEV*/, const int8_t *rung_jumped_r /*DEV*/,
-                              int lowest_active_rung);
-
-/* The production form of the sweep: a cell list at HALF-tile granularity (the reference prunes
- * below the tile level with subtiles, interactions.py:1141-1278, species.py:4031-4142).
+ *   factor           G_Newton*mass_r*mass_s*dt_rungs[...][0]      (gravity.py:51-64)
+ * With adaptive rungs (interactions.py:1688-1761, gravity.py:318-349; the _rungs entry): a
+ * receiver on an active rung (rung_r[i] >= lowest_active_rung) is kicked with
+ * factors[rung_jumped_r[i]], factors[k] = G*m_r*m_s*dt_rungs[...][k], k < 3*N_rungs-1 (DEV);
+ * receivers on inactive rungs are left alone.
+ *
+ * The list: a cell list at HALF-tile granularity (the reference prunes below the tile level
+ * with subtiles, interactions.py:1141-1278, species.py:4031-4142).
  * cg_shortrange_cells bins the particles into (2 nt)^3 cells — tile index exactly as
  * Tiling.sort (species.py:775-780), then which half of the tile in each dimension — and
  * writes, in cell order (z fastest): order_out[n] = particle indices, pos_sorted_out[3n] =
  * their positions (the sweep stages supplier runs with plain coalesced loads), offset_out[
- * (2 nt)^3 + 1] = first entry of each cell.
- * cg_shortrange_sweep_cells[_rungs]: same sums as cg_shortrange_sweep[_rungs] (x_ji, r2 and the
- * table index bit-identical; the order of partners differs), a receiver only meeting supplier
- * cells at most two away: dmom_r[order_r[q]] += ... for every receiver row q.  The force range
+ * (2 nt)^3 + 1] = first entry of each cell.  tile_extent must be boxsize/nt (species.py:607-609).
+ * cg_shortrange_sweep_cells[_rungs]: x_ji, r2 and the table index bit-identical to the
+ * reference's, a receiver only meeting supplier cells at most two away:
+ * dmom_r[order_r[q]] += ... for every receiver row q.  The force range
  * must not exceed the tile extent (the reference requires tilesize >= range,
  * species.py:3943-3983).  Receivers and suppliers may be different particle sets (two
  * components, or a component extended by the neighbour domains' boundary particles): there is
  * no self-pair test because a particle paired with itself contributes x_ji * f = 0 * f.
- * Density-adaptive (round 4; csrc/cg_shortrange_dense.hip — the counterpart of the reference's
+ * Density-adaptive (csrc/cg_shortrange_dense.hip — the counterpart of the reference's
  * automatic subtile refinement, species.py:4031-4142, interactions.py:145-329, :1236-1251): the
  * receivers of tiles holding 64 particles or more are taken off the cells and swept from a list by
  * tile whose rows follow a Hilbert curve through 8^3 sub-cells — 16 consecutive receivers per
  * wavefront against supplier rows in groups of four, a group whose bounding box is out of the
  * 16 receivers' reach is skipped (2.1-2.6 pair tests per pair in range instead of 4.2-4.4) —
  * with the same pair arithmetic; nothing changes for the caller (the lists are built inside the
- * call, only when such tiles exist and hold enough of the pair work to pay for the lists: one
- * 24-byte read-back per call decides — the call waits for the context's stream once).  With
- * rungs: where every rung is active, as above; in a sub-step for the rungs >= lowest_active_rung
- * the tiles that hold 64 and more ACTIVE receivers (a second look, at the histogram of the active
- * receivers' tiles: the upper rungs live where the particles are dense).  Environment:
- * CONCEPT_GPU_SR_DENSE=0 switches it off, CONCEPT_GPU_SR_DENSE_MIN=<particles per tile> moves
- * the threshold. */
+ * call, only when such tiles exist and hold enough of the pair work to pay for the lists; what
+ * decides is counted when cg_shortrange_cells builds the list and read from pinned memory: a
+ * sweep waits for that list to be complete, no more).  With rungs: where every rung is active,
+ * as above; in a sub-step for the rungs >= lowest_active_rung the tiles that hold 64 and more
+ * ACTIVE receivers (a second look, at the histogram of the active receivers' tiles: the upper
+ * rungs live where the particles are dense).  Environment:
+ * CONCEPT_GPU_SR_DENSE_MIN=<particles per tile> moves the threshold (0: no dense tiles' sweep). */
 int cg_shortrange_cells(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, int64_t nt,
                         double tile_extent, uint32_t *order_out /*DEV n*/,
                         uint32_t *offset_out /*DEV (2nt)^3+1*/,
@@ -368,41 +354,24 @@ int cg_shortrange_sweep_cells_rungs(cg_ctx *ctx, const double *pos_r_sorted,
                                     const int8_t *rung_r /*DEV*/,
                                     const int8_t *rung_jumped_r /*DEV*/, int lowest_active_rung);
 
-/* The sweep with a matrix-core range pre-filter (round 4; csrc/cg_shortrange_mfma.hip): the
- * counterpart of the reference's automatic subtile refinement (species.py:4031-4142,
- * interactions.py:145-329, :1141-1278) — the pairs out of range are discarded by single-precision
- * 16 x 16 distance products on the matrix cores instead of by ever finer subtiles, and the units
- * of work are counts of particles (16 receivers per wavefront wherever the tile borders fall),
- * so a dense tile and a void cost what their pairs cost.  Every pair that passes is evaluated
- * in FP64 exactly as in cg_shortrange_sweep_cells (x_ji, r2, the table index bit-identical).
- * cg_shortrange_tiles lists the particles by tile (Tiling.sort, species.py:775-780), z fastest:
- * order_out[m], pos_sorted_out[3m], offset_out[nt^3 + 1] and, for a list that will supply,
- * operand_out[4(n + 16) + 8(n/16 + 2)] (single precision: first (-2v, |v|^2) of the particle's
- * coordinates v inside its tile, the A operand of the products — 4m floats written, the sweep
- * reads whole 16-row blocks, hence 16 rows of room — then, from float 4(n + 16) on, the
- * bounding boxes (min xyz 0, max xyz 0, in tiles) of the blocks of 16 consecutive rows; null
- * for a list of receivers only).  Tiles of kSubMin = 48 or more particles have their rows
- * ordered by sub-cell (8^3 sub-cells along a Hilbert curve), so that blocks and the
- * receivers of a wavefront are compact where the particles are many.  With `rung` only the
- * m particles on rungs >= lowest_active_rung are listed (the receivers of a sub-step),
- * otherwise m = n.
- * cg_shortrange_sweep_tiles: dmom_r[order_r[q]] += factor * sum over the suppliers in range, or
- * factors[rung_jumped_r[order_r[q]]] * sum when factors is given (gravity.py:318-349); n_s = rows
- * of the supplier list. */
+/* The particles listed by TILE (Tiling.sort, species.py:775-780; z fastest) — the reference's
+ * `tiles[tile]` lists, what the parity tests compare tile by tile: order_out[m],
+ * offset_out[nt^3 + 1] and, unless null, pos_sorted_out[3m].  With `rung` only the m particles
+ * on rungs >= lowest_active_rung are listed (the receivers of a sub-step), otherwise m = n. */
 int cg_shortrange_tiles(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, int64_t nt,
                         double tile_extent, const int8_t *rung /*DEV n or null*/,
                         int lowest_active_rung, uint32_t *order_out /*DEV n*/,
-                        uint32_t *offset_out /*DEV nt^3+1*/, double *pos_sorted_out /*DEV 3n*/,
-                        float *operand_out /*DEV 4(n+16)+8(n/16+2) or null*/);
-int cg_shortrange_sweep_tiles(cg_ctx *ctx, const double *pos_r_sorted /*DEV*/,
-                              const uint32_t *order_r /*DEV*/, const uint32_t *offset_r /*DEV*/,
-                              double *dmom_r /*DEV, accumulated*/,
-                              const double *pos_s_sorted /*DEV*/, const uint32_t *offset_s /*DEV*/,
-                              const float *operand_s /*DEV, as written by cg_shortrange_tiles*/, int64_t n_s, int64_t nt,
-                              const double *table /*DEV*/, int64_t tablesize,
-                              double r2_index_scaling, double r2_max, double factor,
-                              const double *factors /*DEV 3*N_rungs-1 or null*/,
-                              const int8_t *rung_jumped_r /*DEV or null*/);
+                        uint32_t *offset_out /*DEV nt^3+1*/,
+                        double *pos_sorted_out /*DEV 3n or null*/);
+
+/* What the sweeps do per call, for the measurement (bench.py's roofline of the P3M step): with
+ * enable = 1 the counters are zeroed and the following cg_shortrange_sweep_cells[_rungs] calls
+ * run counting instantiations of their kernels; enable = 0 waits for the stream, copies the
+ * counters out and switches back.  out[0..2]: the half-tile cells sweep — pair tests executed
+ * (a lane that holds a receiver against a supplier of its range), of them in range (r2 <=
+ * r2_max), wavefront trips (64 lane slots each); out[3..5]: the same for the dense tiles'
+ * sweep; out[6..7] unused. */
+int cg_shortrange_stats(cg_ctx *ctx, int enable, uint64_t *out /*HOST 8, or null*/);
 
 /* The same sums for k <= 8 receivers (rows active[0..k) of pos_r / dmom_r) against ALL n_s
  * suppliers, without a cell list: the sub-steps of driftkick_short (main.py:1347-1624) that kick
@@ -622,7 +591,7 @@ int cg_fluid_kick(cg_ctx *ctx, double *J_dim /*DEV N^3*/, const double *rho /*DE
  *   visits a pair once and updates both).  same = 1: the first n_r suppliers ARE the
  *   receivers, in the same order (pair i, i skipped); n_s > n_r: the rest of the component, on
  *   other domains (domain_domain pairing of interactions.py:398-590 in one-sided form).  kernel: 0 none, 1 plummer, 2 spline.  With rungs
- *   (factors/rung/rung_jumped DEV, as cg_shortrange_sweep_rungs): receivers below
+ *   (factors/rung/rung_jumped DEV, as cg_shortrange_sweep_cells_rungs): receivers below
  *   lowest_active are skipped, the factor is factors[rung_jumped[i]]. */
 int cg_ewald_tabulate(cg_ctx *ctx, int gridsize, double *grid /*DEV 3 g^3*/);
 int cg_pp_kick(cg_ctx *ctx, const double *pos_r /*DEV 3 n_r*/, int64_t n_r,

@@ -36,7 +36,7 @@ def run(*flags, env=None):
     (), ('--no-fused',), ('--no-sort',), ('--no-prepare',), ('--split-poisson',),
     ('--dist', 'lattice'), ('--dist', 'clustered'), ('--dist', 'zeldovich', '--seed', '2'),
     ('--thermal', '0'), ('--p3m',),
-    ('--p3m', '--sr-tiles'), ('--p3m', '--dist', 'clustered')])
+    ('--p3m', '--dist', 'clustered')])
 def test_bench_flags(flags):
     d = run('--no-cpu-baseline', *flags)
     assert d['n_gpus'] == 1 and 'workload' in d['config']
@@ -75,8 +75,24 @@ def test_bench_eight_ranks_at_config2_size():
     """First contact of `bench.py --gpus 8` with a real workload: the
     ACTUAL command at BASELINE configs[1]'s size — 256^3 particles / 512^3 mesh on 8 x-slab
     domains, here as 8 self-spawned ranks sharing the one GPU over gloo — runs to its JSON
-    line, keeps every particle, reports the stages and carries the link model."""
+    line, keeps every particle, reports the stages and carries the link model.  And it is
+    self-verifying: the box is a function of (seed, identifier), the 1-rank
+    run of the same command leaves the id-keyed sample the 8-rank run compares its own with —
+    positions to 1e-12 of the box, momenta to 1e-12 of their rms."""
+    one = run_workload('c2_256c_512')
+    v1 = one['verify']
+    assert v1['ok'] and v1['particles'] == 256**3 and v1['timed_vs_replay_rel'] <= 1e-12
+    assert os.path.exists(os.path.join(REPO, v1['written_to']))
     d = run_workload('c2_256c_512', '--gpus', '8')
+    v = d['verify']
+    assert v['ok'] is True, v
+    assert v['reference'] == v1['written_to'] and v['sample'] == 512
+    assert v['max_pos_err_over_boxsize'] <= 1e-12 and v['max_mom_err_over_rms'] <= 1e-12
+    assert v['particles'] == 256**3 and v['sum_mom2_rel_err'] <= 1e-12
+    assert d['ranks_seen']['world'] == 8 and \
+        sorted(r for r, _ in d['ranks_seen']['rank_device']) == list(range(8))
+    ppr = d['particles_per_rank']
+    assert sum(ppr['counts']) == 256**3 and 1.0 <= ppr['max_over_mean'] < 1.01
     assert d['n_gpus'] == 8 and d['config']['particles'] == 256**3
     assert d['config']['parallelism'] == 'xslab8' and d['scaling'] == 'strong'
     lm = d['link_model']

@@ -39,10 +39,9 @@ def single_domain(N, n_side, steps, p3m=False, cells_per_step=0.0):
             nt = int(L/rng_*(1 + commons.machine_ϵ))
             table, maxr2 = shortrange.get_shortrange_table(0.05*L/n_side, scale, rng_, 4096,
                                                            'spline', pos.device)
-            cells = mesh.shortrange_build(pos, nt, L/nt)
+            cells = mesh.shortrange_cells(pos, nt, L/nt)
             dm = torch.zeros_like(mom)
-            mesh.shortrange_sweep(pos, cells, dm, pos, cells, nt, True, table, 4095/maxr2,
-                                  rng_**2, 3e-4)
+            mesh.shortrange_sweep_cells(cells, dm, cells, nt, table, 4095/maxr2, rng_**2, 3e-4)
             mom += dm
         mesh.zero()
         mesh.deposit(pos, contribution)
@@ -126,11 +125,10 @@ def test_slab_domains_match_single_domain(world, N, p3m, n_side=20, steps=None):
 @pytest.mark.parametrize('world,N,mode', [(2, 64, 'regions'), (4, 128, 'regions'), (2, 64, False)])
 def test_slab_domains_with_the_tile_order(world, N, mode, monkeypatch):
     """The same with the tile kernels walking their tiles in cgk_tile_order's order on boxes this
-    small too (CONCEPT_GPU_TILE_ORDER=2) and every tile above 1.5 times the mean population
+    small too (CONCEPT_GPU_TILE_ORDER_MIN=-1) and every tile above 1.5 times the mean population
     counted as heavy: the slab deposit's ghost row behind the ordered tiles, the gather-kick and
     the fused pass of every domain."""
-    monkeypatch.setenv('CONCEPT_GPU_TILE_ORDER', '2')
-    monkeypatch.setenv('CONCEPT_GPU_TILE_ORDER_MIN', '1')
+    monkeypatch.setenv('CONCEPT_GPU_TILE_ORDER_MIN', '-1')
     test_slab_domains_match_single_domain(world, N, mode)
 
 

@@ -36,21 +36,18 @@ def dense_everywhere(monkeypatch):
     """The cells sweep hands every tile of 3 particles and more to the dense tiles' sweep
     (cg_shortrange_dense.hip; the default threshold is 64)"""
     monkeypatch.setenv('CONCEPT_GPU_SR_DENSE_MIN', '3')
-    return 'cells'
 
 
-@pytest.mark.parametrize('sweep', ['cells', 'dense', 'mfma'])
+@pytest.mark.parametrize('sweep', ['cells', 'dense'])
 @pytest.mark.parametrize('name', CASES)
 def test_shortrange_vs_golden_and_oracle(golden, name, sweep, monkeypatch):
-    """(the tile sweeps: the half-tile cells, the same with the dense tiles' sweep taking every
-    populated tile, and the lists by tile with the matrix-core pre-filter, shortrange.SWEEP;
-    sweep None — tests/dist_component_worker.py, on several domains — runs the configured one)"""
+    """(the sweep: the half-tile cells, and the same with the dense tiles' sweep taking every
+    populated tile; sweep None — tests/dist_component_worker.py, on several domains — runs
+    the default)"""
     from concept_amd import interactions, shortrange
     from oracle import oracle
     if sweep == 'dense':
-        sweep = dense_everywhere(monkeypatch)
-    if sweep is not None:
-        monkeypatch.setattr(shortrange, 'SWEEP', sweep)
+        dense_everywhere(monkeypatch)
     g = golden(name)
     torch, c = setup(g)
     c.populate(g['pos_after_short'], 'pos')
@@ -99,7 +96,7 @@ def test_table_and_tiles(golden, name):
     L, nt = float(g['boxsize']), int(g['tiling_shape'][0])
     mesh = PotentialMesh(int(g['gridsize']), L)
     pos = torch.tensor(g['pos_after_short'], device='cuda')
-    order, offset = mesh.shortrange_build(pos, nt, L/nt)
+    order, offset, _ = mesh.shortrange_tiles(pos, nt, L/nt)
     order, offset = order.cpu().numpy(), offset.cpu().numpy()
     eps = np.finfo(float).eps
     idx = ((g['pos_after_short'] - 0.0)*((1/(L/nt))*(1 - 2*eps))).astype(np.int64)
@@ -234,9 +231,8 @@ def test_config3_size_shortrange_properties(dist):
     (cg_shortrange_cells + cg_shortrange_sweep_cells: half-tile cells), for the uniform and
     the clustered box of the bench: the one-sided sweep conserves momentum (Newton's third
     law holds pair by pair because both directions of a pair evaluate bit-identical r2 and
-    table entries), is invariant under a permutation of the particle memory, and equals the
-    round-1 sweep (one wavefront per tile, cg_shortrange_build + cg_shortrange_sweep: A/B of
-    two independent pair enumerations) to summation order."""
+    table entries) and is invariant under a permutation of the particle memory.  (Against an
+    independent pair enumeration: test_config3_size_shortrange_vs_oracle_sample.)"""
     import torch
     from concept_amd import commons, shortrange
     from concept_amd.mesh import PotentialMesh
@@ -255,13 +251,6 @@ def test_config3_size_shortrange_properties(dist):
     scale_f = float(dm.abs().max())
     assert scale_f > 0
     assert float(dm.sum(0).abs().max()) <= 1e-9*float(dm.abs().sum(0).max())
-    # A/B: the round-1 sweep
-    dm1 = torch.zeros_like(pos)
-    cells1 = mesh.shortrange_build(pos, nt, L/nt)
-    mesh.shortrange_sweep(pos, cells1, dm1, pos, cells1, nt, True, table, 4095/maxr2, rng_**2,
-                          1.0)
-    assert float((dm1 - dm).abs().max()) <= 1e-11*scale_f
-    del dm1, cells1
     perm = torch.randperm(n, device='cuda', generator=gen)
     pos2 = pos[perm].contiguous()
     dm2 = torch.zeros_like(pos2)
@@ -271,16 +260,15 @@ def test_config3_size_shortrange_properties(dist):
     mesh.close()
 
 
-@pytest.mark.parametrize('sweep', ['cells', 'tiles'])
 @pytest.mark.parametrize('dist', ['uniform', 'clustered'])
-def test_config3_size_shortrange_vs_oracle_sample(dist, sweep):
+def test_config3_size_shortrange_vs_oracle_sample(dist):
     """BASELINE configs[2]'s own size (256^3 particles, 512^3 mesh, default short-range
     parameters, test/concept_vs_gadget_p3m/param:10-46) against the ORACLE, uniform and
     clustered (where tile populations reach the staging limits): the receivers of every 97th
     tile plus those of the 32 most populated tiles (at most 64 of each), summed by the oracle
-    over the 27 tiles around their own (orc_shortrange_sample: O(sample x 600) pairs).  Both
-    sweeps: the half-tile cells (the default) and the lists by tile with the matrix-core
-    pre-filter.  Tile index of EVERY particle bit-exact; Δmom <= 1e-12 of the rms kick."""
+    over the 27 tiles around their own (orc_shortrange_sample: O(sample x 600) pairs).  Tile
+    index of EVERY particle bit-exact (cg_shortrange_tiles against the oracle's tiling); Δmom <=
+    1e-12 of the rms kick."""
     import torch
     from concept_amd import commons, shortrange
     from concept_amd.mesh import PotentialMesh
@@ -295,12 +283,9 @@ def test_config3_size_shortrange_vs_oracle_sample(dist, sweep):
     soft = 0.025*L/256
     table, maxr2 = shortrange.get_shortrange_table(soft, scale, rng_, 4096, 'spline', pos.device)
     dm = torch.zeros_like(pos)
-    if sweep == 'cells':
-        lst = mesh.shortrange_cells(pos, nt, L/nt)
-        mesh.shortrange_sweep_cells(lst, dm, lst, nt, table, 4095/maxr2, rng_**2, 1.0)
-    else:
-        lst = mesh.shortrange_tiles(pos, nt, L/nt)
-        mesh.shortrange_sweep_tiles(lst, dm, lst, nt, table, 4095/maxr2, rng_**2, 1.0)
+    lst = mesh.shortrange_cells(pos, nt, L/nt)
+    mesh.shortrange_sweep_cells(lst, dm, lst, nt, table, 4095/maxr2, rng_**2, 1.0)
+    del lst
     pos_h = pos.cpu().numpy()
     dm_h = dm.cpu().numpy()
     # the sample: by the oracle's own tile indices
@@ -316,20 +301,22 @@ def test_config3_size_shortrange_vs_oracle_sample(dist, sweep):
                                            tilesize=rng_, tablesize=4096, softening=soft,
                                            factor=1.0)
     assert np.array_equal(tile_o, tile)
-    if sweep == 'tiles':   # the list by tile IS the oracle's tiling, particle by particle
-        off = lst[1].cpu().numpy().astype(np.int64)
-        assert np.array_equal(off, start)
-        o = lst[0].cpu().numpy().astype(np.int64)[:n]
-        assert np.array_equal(tile[o], np.repeat(np.arange(nt**3), counts))
+    # the list by tile IS the oracle's tiling, particle by particle
+    lst = mesh.shortrange_tiles(pos, nt, L/nt)
+    off = lst[1].cpu().numpy().astype(np.int64)
+    assert np.array_equal(off, start)
+    o = lst[0].cpu().numpy().astype(np.int64)[:n]
+    assert np.array_equal(tile[o], np.repeat(np.arange(nt**3), counts))
+    del lst
     rms = np.sqrt((dm_h**2).mean())
     assert rms > 0 and len(sample) > 50000
     assert counts.max() >= (1000 if dist == 'clustered' else 40)
     err = np.abs(dm_h[sample] - ref).max()
-    assert err <= 1e-12*rms, (err/rms, dist, sweep)
+    assert err <= 1e-12*rms, (err/rms, dist)
     mesh.close()
 
 
-@pytest.mark.parametrize('sweep', ['cells', 'dense', 'mfma'])
+@pytest.mark.parametrize('sweep', ['cells', 'dense'])
 def test_adaptive_rungs_vs_reference(golden, sweep, monkeypatch):
     """A14/A16 with adaptive rungs on the GPU: RungStepper (initialize_rung_populations,
     kick_long, kick_short, driftkick_short with rung jumps; N_rungs = 4) against the
@@ -338,9 +325,7 @@ def test_adaptive_rungs_vs_reference(golden, sweep, monkeypatch):
     from concept_amd import commons, shortrange, stepper
     from concept_amd.species import Component
     if sweep == 'dense':
-        sweep = dense_everywhere(monkeypatch)
-    if sweep is not None:
-        monkeypatch.setattr(shortrange, 'SWEEP', sweep)
+        dense_everywhere(monkeypatch)
     g = golden('rungs_p3m_n8_g32')
     commons.load_params({
         'boxsize': float(g['boxsize']),
@@ -628,27 +613,6 @@ def test_populate_after_sort_lands_on_the_right_particles():
         assert np.array_equal(c.host('mom'), want)
 
 
-def test_shortrange_pre32_variant_vs_oracle():
-    """The sweep with the single-precision pre-test (CONCEPT_GPU_SR_PRE32=1; not the default:
-    measured slower, cg_shortrange.hip) stays a correct alternative: the same golden and random
-    cases in a fresh process with the switch set (it is read once per process)."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    code = ("import sys; sys.path[:0] = [%r, %r]\n"
-            "import numpy as np, os\n"
-            "import test_gpu_p3m as t\n"
-            "golden = lambda name: np.load(os.path.join(%r, 'golden', name + '.npz'))\n"
-            "for name in t.CASES: t.test_shortrange_vs_golden_and_oracle(golden, name, None, None)\n"
-            "for seed in range(6): t.test_random_shortrange_vs_oracle(seed)\n"
-            "t.test_adaptive_rungs_vs_reference(golden, None, None)\n"
-            "print('PRE32-OK')\n") % (here, os.path.dirname(here), here)
-    p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, CONCEPT_GPU_SR_PRE32='1'),
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    assert p.returncode == 0 and b'PRE32-OK' in p.stdout, p.stdout.decode()[-3000:]
-
-
 @pytest.mark.parametrize('n,N_rungs', [(0, 8), (5, 8), (4096, 1), (1000003, 8), (300007, 10)])
 def test_rung_populations(n, N_rungs):
     """cg_rung_populations (Component.set_rungs_N, species.py:2560-2587) against numpy.bincount;
@@ -759,8 +723,8 @@ def test_dense_sweep_on_the_randomised_and_multi_component_cases(monkeypatch):
     table, maxr2 = shortrange.get_shortrange_table(0.01, scale, rng_, 4096, 'spline', pos.device)
     cells = mesh.shortrange_cells(pos, nt, N/nt)
     out = []
-    for dense in ('0', '1'):
-        monkeypatch.setenv('CONCEPT_GPU_SR_DENSE', dense)
+    for dense in ('0', '64'):
+        monkeypatch.setenv('CONCEPT_GPU_SR_DENSE_MIN', dense)
         dm = torch.zeros_like(pos)
         mesh.shortrange_sweep_cells(cells, dm, cells, nt, table, 4095/maxr2, rng_**2, 1.0)
         out.append(dm)
@@ -770,23 +734,6 @@ def test_dense_sweep_on_the_randomised_and_multi_component_cases(monkeypatch):
     mesh.close()
 
 
-def test_tile_sweep_on_the_randomised_and_multi_component_cases(monkeypatch):
-    """The second tile sweep (lists by tile, sub-cell order, block boxes, matrix-core range
-    pre-filter; shortrange.SWEEP = 'mfma') through the cases the default one is fuzzed with:
-    the random parameter draws (tile size above the range, small tables, the three softening
-    kernels, blobs), two components with receivers that are not suppliers, the knot with
-    adaptive rungs, whole random P³M time loops with rungs."""
-    from concept_amd import shortrange
-    monkeypatch.setattr(shortrange, 'SWEEP', 'mfma')
-    for seed in range(16):
-        test_random_shortrange_vs_oracle(seed)
-    for cell_centered in (True, False):
-        test_shortrange_two_components_receivers_not_suppliers(cell_centered)
-    test_adaptive_rungs_knot_across_domains()
-    for seed in range(2):
-        test_random_p3m_timeloops_across_domains(seed)
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize('lowest', [0, 1, 3])
 def test_dense_sweep_with_active_rungs_equals_the_cells_sweep(lowest, monkeypatch):
@@ -794,7 +741,7 @@ def test_dense_sweep_with_active_rungs_equals_the_cells_sweep(lowest, monkeypatc
     tile; rungs assigned so that the upper ones sit in the blobs, some flagged to jump; receivers
     and suppliers two different components): the sub-step for the rungs >= lowest with the
     dense tiles' sweep — tiles dense with ACTIVE receivers, by the default threshold and cost
-    model — against the half-tile cells everywhere (CONCEPT_GPU_SR_DENSE=0).  Same sums; the
+    model — against the half-tile cells everywhere (CONCEPT_GPU_SR_DENSE_MIN=0).  Same sums; the
     inactive receivers untouched."""
     import torch
     from concept_amd import commons, shortrange
@@ -829,8 +776,8 @@ def test_dense_sweep_with_active_rungs_equals_the_cells_sweep(lowest, monkeypatc
     cs = mesh.shortrange_cells(pos_s_t, nt, L/nt)
     base = torch.as_tensor(rng.normal(0, 1e-3, (n_r, 3)), device='cuda')
     out = []
-    for dense in ('0', '1'):
-        monkeypatch.setenv('CONCEPT_GPU_SR_DENSE', dense)
+    for dense in ('0', '64'):
+        monkeypatch.setenv('CONCEPT_GPU_SR_DENSE_MIN', dense)
         dm = base.clone()
         mesh.shortrange_sweep_cells(cr, dm, cs, nt, table, 4095/maxr2, rng_**2, 0.0,
                                     (factors, rung_t, jumped_t, lowest))

@@ -254,18 +254,13 @@ def test_p3m_kick_vs_oracle(npart, N):
                                                  torch.device('cuda'))
     ref = dmom_o[perm]
     big = max(np.abs(ref).max(), factor/scale**2)
-    # the production sweep (half-tile cells) and the one-wavefront-per-tile form
+    # the production sweep (half-tile cells)
     cells = mesh.shortrange_cells(p1, nt, L/nt)
     dmom = torch.zeros_like(p1)
     mesh.shortrange_sweep_cells(cells, dmom, cells, nt, tab, 4095/maxr2, range_**2, factor)
     out = dmom.cpu().numpy()
     assert np.abs(out - ref).max() <= 1e-12*big
     assert np.abs(out.sum(0)).max() <= 1e-10*big
-    tiles = mesh.shortrange_build(p1, nt, L/nt)
-    dmom_t = torch.zeros_like(p1)
-    mesh.shortrange_sweep(p1, tiles, dmom_t, p1, tiles, nt, True, tab, 4095/maxr2, range_**2,
-                          factor)
-    assert np.abs(dmom_t.cpu().numpy() - ref).max() <= 1e-12*big
     # cell list: a permutation, positions copied in cell order, every particle in its cell
     order, offset, pos_sorted = cells
     o = order.long()
@@ -288,10 +283,13 @@ def test_shortrange_cells_dense_and_two_components():
     """The half-tile sweep where its staging rounds and receiver chunks are exercised: a blob
     with thousands of particles per tile (several staging windows, > 64 receivers per cell
     column), a box face (periodic images), and receivers != suppliers (two components),
-    against the one-wavefront-per-tile sweep."""
+    against the oracle: the sums of a receiver set over another supplier set are those of the
+    union on itself minus those of the receivers on themselves (the sweep is linear in the
+    suppliers)."""
     import torch
     from concept_amd import shortrange
     from concept_amd.mesh import PotentialMesh
+    from oracle import oracle
     L, N = 64.0, 64
     rng = np.random.default_rng(12)
     scale = 1.25*L/N
@@ -305,15 +303,21 @@ def test_shortrange_cells_dense_and_two_components():
     tab, maxr2 = shortrange.get_shortrange_table(0.03, scale, range_, 4096, 'spline',
                                                  torch.device('cuda'))
     sc, r2 = 4095/maxr2, range_**2
-    for rec, sup, same in ((pos_a, pos_a, True), (pos_a, pos_b, False), (pos_b, pos_a, False)):
+    def orc(pos):
+        return oracle.shortrange_kick(pos.cpu().numpy(), boxsize=L, scale=scale, range_=range_,
+                                      tilesize=range_, tablesize=4096, softening=0.03,
+                                      factor=0.7)[0]
+    self_a, self_b = orc(pos_a), orc(pos_b)
+    both = orc(torch.cat([pos_a, pos_b]))
+    na = pos_a.shape[0]
+    for rec, sup, ref, own in ((pos_a, pos_a, self_a, None), (pos_a, pos_b, both[:na], self_a),
+                               (pos_b, pos_a, both[na:], self_b)):
         cr, cs = mesh.shortrange_cells(rec, nt, L/nt), mesh.shortrange_cells(sup, nt, L/nt)
         got = torch.zeros_like(rec)
         mesh.shortrange_sweep_cells(cr, got, cs, nt, tab, sc, r2, 0.7)
-        tr, ts = mesh.shortrange_build(rec, nt, L/nt), mesh.shortrange_build(sup, nt, L/nt)
-        ref = torch.zeros_like(rec)
-        mesh.shortrange_sweep(rec, tr, ref, sup, ts, nt, same, tab, sc, r2, 0.7)
-        big = float(ref.abs().max())
-        assert big > 0 and float((got - ref).abs().max()) <= 1e-12*big, (same, big)
+        big = float(np.abs(ref).max())
+        want = ref if own is None else ref - own
+        assert big > 0 and np.abs(got.cpu().numpy() - want).max() <= 1e-12*big, big
     mesh.close()
 
 

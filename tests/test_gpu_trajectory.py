@@ -535,7 +535,7 @@ def test_p3m_timeloop_with_dense_tiles_equals_the_cells_sweep(monkeypatch):
     """A clustered box (80 % of 64^3 particles in 8 Gaussian blobs: tiles of several hundred
     particles) through the P³M time loop with 8 rungs, twice: with the dense tiles' sweep
     (cg_shortrange_dense.hip, the default from 64 particles per tile on) and with the half-tile
-    cells everywhere (CONCEPT_GPU_SR_DENSE=0).  The two differ in the order of the additions
+    cells everywhere (CONCEPT_GPU_SR_DENSE_MIN=0).  The two differ in the order of the additions
     only: same steps, same rungs, positions equal to 1e-9 of the box after the run."""
     import torch
     from concept_amd import commons, stepper
@@ -543,7 +543,10 @@ def test_p3m_timeloop_with_dense_tiles_equals_the_cells_sweep(monkeypatch):
     n, N, L = 64**3, 128, 128.0
 
     def run(dense):
-        monkeypatch.setenv('CONCEPT_GPU_SR_DENSE', dense)
+        if dense == '0':
+            monkeypatch.setenv('CONCEPT_GPU_SR_DENSE_MIN', '0')
+        else:
+            monkeypatch.delenv('CONCEPT_GPU_SR_DENSE_MIN', raising=False)
         p = commons.load_params({
             'boxsize': L, 'H0': 0.07, 'Ωb': 0.05, 'Ωcdm': 0.25, 'a_begin': 0.1,
             'output_times': {'a': (0.105,)},

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the workgroup -> tile order (cgk_tile_order, CONCEPT_GPU_TILE_ORDER) in ONE process:
+"""A/B of the workgroup -> tile order (cgk_tile_order, CONCEPT_GPU_TILE_ORDER_MIN) in ONE process:
 the same particle arrays, a context per setting, alternating — deposit and fused pass of the
 bench's north-star box, uniform and clustered.  (Process-to-process the fused pass moves by
 +-2 % with the placement of its pages, which is more than what the table costs a uniform box.)
@@ -54,11 +54,8 @@ for dist in (sys.argv[1:] or ['uniform', 'clustered']):
     mins = [m for m in os.environ.get('PROBE_MINS', '').split(',') if m]
     for rep in range(3 if mins else 2):
         for mode in (mins or ('0', '1')):
-            if mins:
-                os.environ['CONCEPT_GPU_TILE_ORDER'] = '1'
-                os.environ['CONCEPT_GPU_TILE_ORDER_MIN'] = mode
-            else:
-                os.environ['CONCEPT_GPU_TILE_ORDER'] = mode
+            # (off against on: thresholds 0 = the plain walk and 1536 = the default)
+            os.environ['CONCEPT_GPU_TILE_ORDER_MIN'] = mode if mins else ('0', '1536')[int(mode)]
             mesh = PotentialMesh(N, L)
             # (each deposit makes the order anew: its cost is inside these times)
             dep = timed(lambda: mesh.deposit_tiled(pa[:n_p], table, 1.0/N**3))

@@ -42,20 +42,11 @@ python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_
 python bench.py --workload ns_256M_1024 --p3m --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_p3m_ns_256M_1024.json
 python bench.py --weak --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_weak_1gpu.json
 python bench.py --workload c2_256c_512 --gpus 8 --dry-links --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_c2_8ranks_gloo_dry_links.json
-# 5. the tile sweep with the matrix-core pre-filter beside the cells sweep (round 4)
-python tools/sr_mfma_check.py big time > $OUT/${TAG}_sr_tiles_vs_cells.txt 2>&1
-(cd /tmp && SR_DIST=uniform $R/tools/pmc_sr.sh > $OUT/${TAG}_pmc_sr_tiles.txt 2>&1)
-python tools/variant.py tools/_variants/srm_count.so cg_shortrange_mfma.hip -DSRM_PROBE_COUNT > /dev/null 2>&1
-python tools/variant.py tools/_variants/srm_nocand.so cg_shortrange_mfma.hip -DSRM_PROBE_NOCAND > /dev/null 2>&1
-python tools/variant.py tools/_variants/srm_nomfma.so cg_shortrange_mfma.hip -DSRM_PROBE_NOMFMA > /dev/null 2>&1
-for v in "" tools/_variants/srm_nocand.so tools/_variants/srm_nomfma.so tools/_variants/srm_count.so; do CONCEPT_GPU_LIB=$v python tools/sr_mfma_time.py; done 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_sr_tiles_phases_and_counts.txt
 # 6. the dense tiles' sweep (round 4): against the cells sweep by itself, its counters, its phases
 python tools/sr_dense_check.py scan big time 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_sr_dense_vs_cells.txt
 (SR_DIST=clustered $R/tools/pmc_srd.sh 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_pmc_sr_dense.txt)
-python tools/variant.py tools/_variants/srd_nopairs.so cg_shortrange_dense.hip -DSRD_PROBE_NOPAIRS > /dev/null 2>&1
-python tools/variant.py tools/_variants/srd_nocull.so cg_shortrange_dense.hip -DSRD_PROBE_NOCULL > /dev/null 2>&1
-for v in "" tools/_variants/srd_nopairs.so tools/_variants/srd_nocull.so; do CONCEPT_GPU_LIB=$v python tools/sr_dense_time.py clustered; done 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_sr_dense_phases.txt
-CONCEPT_GPU_SR_DENSE=0 python tools/sr_dense_time.py clustered 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_sr_dense_phases.txt
+python tools/sr_dense_time.py clustered 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_sr_dense_phases.txt
+CONCEPT_GPU_SR_DENSE_MIN=0 python tools/sr_dense_time.py clustered 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_sr_dense_phases.txt
 # (the stand-alone probes are built here when the tree does not hold them: a fresh clone)
 mkdir -p tools/_variants
 [ -x tools/mall_probe ] || hipcc --offload-arch=gfx950 -O3 -o tools/mall_probe tools/mall_probe.cpp

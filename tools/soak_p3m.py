@@ -27,7 +27,7 @@ gen = torch.Generator(device='cuda').manual_seed(13)
 torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=gen, out=c.pos)
 c.pos.mul_(p.boxsize*(1 - 1e-13))
 if os.environ.get('SOAK_DIST') == 'clustered':
-    from tools.sr_mfma_check import positions
+    from tools.sr_positions import positions
     c.pos.copy_(positions('clustered', n, p.boxsize, gen))
 c.mom.zero_()
 stamps = []

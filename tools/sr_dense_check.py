@@ -1,4 +1,4 @@
-"""The cells sweep by itself (CONCEPT_GPU_SR_DENSE=0) against the cells sweep that hands its
+"""The cells sweep by itself (CONCEPT_GPU_SR_DENSE_MIN=0) against the cells sweep that hands its
 densely populated tiles to cg_shortrange_dense.hip (the default), on the same particles: the
 largest difference of the kicks relative to the largest kick, and the time of each.
 `python tools/sr_dense_check.py [small] [scan] [big] [time]`"""
@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from concept_amd import commons, shortrange  # noqa: E402
 from concept_amd.mesh import PotentialMesh  # noqa: E402
-from tools.sr_mfma_check import positions  # noqa: E402
+from tools.sr_positions import positions  # noqa: E402
 
 
 def run(N, npart, dist, seed=3, reps=0, min_pops=(96,), L=None):
@@ -39,7 +39,7 @@ def run(N, npart, dist, seed=3, reps=0, min_pops=(96,), L=None):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0)/max(reps, 1)*1e3
 
-    os.environ['CONCEPT_GPU_SR_DENSE'] = '0'
+    os.environ['CONCEPT_GPU_SR_DENSE_MIN'] = '0'
     ref = torch.zeros_like(pos)
     sweep(ref)
     torch.cuda.synchronize()
@@ -48,7 +48,6 @@ def run(N, npart, dist, seed=3, reps=0, min_pops=(96,), L=None):
     if reps:
         line += f' cells only {timed():.2f} ms;'
     ok = True
-    os.environ['CONCEPT_GPU_SR_DENSE'] = '1'
     for mp in min_pops:
         os.environ['CONCEPT_GPU_SR_DENSE_MIN'] = str(mp)
         dm = torch.zeros_like(pos)

@@ -1,6 +1,6 @@
 """Time cg_shortrange_sweep_cells (cells sweep + the dense tiles' sweep) alone, 256^3 particles /
 512^3 mesh: `python tools/sr_dense_time.py [uniform] [clustered]`; CONCEPT_GPU_LIB selects a
-variant build, CONCEPT_GPU_SR_DENSE=0 the cells sweep by itself."""
+variant build, CONCEPT_GPU_SR_DENSE_MIN=0 the cells sweep by itself."""
 import os
 import sys
 import time
@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from concept_amd import commons, shortrange  # noqa: E402
 from concept_amd.mesh import PotentialMesh  # noqa: E402
-from tools.sr_mfma_check import positions  # noqa: E402
+from tools.sr_positions import positions  # noqa: E402
 
 N = int(os.environ.get('SR_N', '512'))
 L, n = float(N), int(os.environ.get('SR_NP', str(256**3)))
