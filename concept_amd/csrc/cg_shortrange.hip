@@ -623,6 +623,195 @@ k_sr_sweep_cells(
 }
 
 // ===========================================================================
+// The interior of the box, 2 x 2 tiles per workgroup (round 5).
+//
+// What the sweep above costs apart from its pair tests was measured with a build whose pair
+// loop is empty (256^3 / 512^3, 22 particles per tile): 3.2 of 8.1 ms — the chain a tile's
+// workgroup goes through before its first pair (offsets of its 36 columns -> their rows ->
+// barrier), ~0.3 us of arithmetic in ~3 us of memory round trips, paid 750,000 times, which the
+// eight workgroups of a CU do not hide.  Tiles that are neighbours in x and y share most of what
+// they stage: a block of 2 x 2 tiles needs the 8 x 8 columns around it (6 cells along z each,
+// the same window for all of them, so that a receiver's five columns of one x stay ONE range of
+// the staged array) — 1056 suppliers on average instead of 4 x 594 — and ONE chain.  Eight
+// wavefronts, two receiver groups (a cell column of a tile: 2 cells, ~5.5 receivers) each;
+// the pair loop is the one above.  The tiles on the box faces (periodic images) keep the
+// one-tile kernel.  An odd number of interior tiles per dimension: the last block starts one
+// tile early and leaves the tile it shares with its neighbour out.
+// ===========================================================================
+constexpr int kSbCap = 1344;     // suppliers staged per window (mean 1056 at 22 per tile; more
+                                 // take further windows): with the slack 35.3 KB of LDS -> four
+                                 // workgroups of eight wavefronts per CU
+template <bool RUNGS, bool STATS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(CG_SR_WAVES, 8))) void
+k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
+                  const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
+                  const double *__restrict__ pos_s, const unsigned *__restrict__ off_s,
+                  const double *__restrict__ table, SrParams P) {
+    constexpr int kLen = kSbCap + kSrSlack;
+    __shared__ double sx[kLen], sy[kLen], sz[kLen];
+    __shared__ unsigned p_beg[64], p_cnt[64], p_off[64];
+    __shared__ unsigned wave_any[8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = P.nt, nc = 2 * nt, m = nt - 2;
+    // blocks per dimension (m + 1) / 2; the last one of an odd m overlaps its neighbour
+    const int nb = (m + 1) >> 1;
+    const int bx = blockIdx.z, by = blockIdx.y, tc = (int)blockIdx.x + 1;
+    const bool lastx = bx == nb - 1, lasty = by == nb - 1;
+    const int ta0 = lastx ? nt - 3 : 1 + 2 * bx, tb0 = lasty ? nt - 3 : 1 + 2 * by;
+    const bool skipx = lastx && (m & 1) && nb > 1, skipy = lasty && (m & 1) && nb > 1;
+    // this wave's two receiver groups: cell columns (gx, gy) of the block's 4 x 4, cells 2 tc and
+    // 2 tc + 1.  A group whose tile is left out (shared with the neighbour block, no active
+    // receiver, taken by the dense tiles' sweep) has no receivers.
+    unsigned rbeg[2], rend[2];
+    int gxs[2], gys[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int g = wave + 8 * h, gx = g >> 2, gy = g & 3;
+        gxs[h] = gx, gys[h] = gy;
+        const int ta = ta0 + (gx >> 1), tb = tb0 + (gy >> 1);
+        bool take = !((gx < 2 && skipx) || (gy < 2 && skipy));
+        if (take && P.tile_active)
+            take = P.tile_active[((unsigned)ta * nt + (unsigned)tb) * nt + (unsigned)tc] != 0;
+        const unsigned rcell =
+            ((unsigned)(2 * ta0 + gx) * nc + (unsigned)(2 * tb0 + gy)) * nc + 2 * tc;
+        rbeg[h] = rend[h] = 0;
+        if (take) {
+            rbeg[h] = __builtin_amdgcn_readfirstlane(off_r[rcell]);
+            rend[h] = __builtin_amdgcn_readfirstlane(off_r[rcell + 2]);
+        }
+    }
+    if (lane == 0) wave_any[wave] = (rend[0] - rbeg[0]) + (rend[1] - rbeg[1]);
+    // supplier pieces: column (cx, cy) of the 8 x 8 around the block, cells 2 tc - 2 .. 2 tc + 3
+    // (the block is in the interior: no column wraps around the box)
+    if (tid < 64) {
+        const int cx = tid >> 3, cy = tid & 7;
+        const unsigned base =
+            ((unsigned)(2 * ta0 - 2 + cx) * nc + (unsigned)(2 * tb0 - 2 + cy)) * nc + 2 * tc - 2;
+        const unsigned beg = off_s[base];
+        p_beg[tid] = beg;
+        p_cnt[tid] = off_s[base + 6] - beg;
+    }
+    // the first group's first chunk does not depend on the staging: its loads (and the Δmom it
+    // will be added to) are in flight while the suppliers are staged
+    SrChunk ch = {};
+    double d0 = 0, d1 = 0, d2 = 0;
+    if (rend[0] > rbeg[0]) {
+        ch = sr_chunk_load<RUNGS>(rbeg[0], rend[0], lane, pos_r, order_r, P);
+        if (ch.active && ch.sub == 0) {
+            d0 = dmom_r[3 * (i64)ch.pi];
+            d1 = dmom_r[3 * (i64)ch.pi + 1];
+            d2 = dmom_r[3 * (i64)ch.pi + 2];
+        }
+    }
+    __syncthreads();
+    {
+        unsigned any = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) any |= wave_any[w];
+        if (any == 0) return;  // no receivers in the block
+    }
+    // exclusive prefix of the 64 column sizes by every wave for itself: lane l keeps the bounds
+    // of column l in registers, the range bounds below are v_readlane's
+    const unsigned c0 = p_cnt[lane];
+    const unsigned i0 = sr_wave_scan(c0);   // inclusive
+    const unsigned e0 = i0 - c0;            // exclusive
+    p_off[lane] = e0;  // (identical values from every wave: a wave reads what it wrote itself)
+    const unsigned total = __builtin_amdgcn_readlane(i0, 63);
+    const bool one_window = total <= (unsigned)kSbCap;
+    SrCount cnt;
+    for (unsigned w0 = 0; w0 < total; w0 += kSbCap) {
+        const unsigned w1 = min(total, w0 + (unsigned)kSbCap);
+        const int sw0 = __builtin_amdgcn_readfirstlane((int)w0),
+                  sw1 = __builtin_amdgcn_readfirstlane((int)w1);
+        if (w0) __syncthreads();  // everybody is done with the previous window
+        // staging: 16 lanes per piece, a wave takes 4 pieces at a time.  (All of a lane's
+        // rows loaded before the first is stored — every entry's piece found by bisection of the
+        // prefix sums, one round trip to memory instead of a turn per 16 rows of a piece —
+        // measured no faster: 7.6 against 7.5 ms, and 70 registers.)
+        for (int p0 = wave * 4; p0 < 64; p0 += 32) {
+            const int p = p0 + (lane >> 4);
+            const unsigned beg = p_beg[p], o0 = p_off[p], o1 = o0 + p_cnt[p];
+            const unsigned lo = max(o0, w0), hi = min(o1, w1);  // the part inside this window
+            for (unsigned tn = 0; __any(lo + 16u * tn < hi); tn++) {
+                const unsigned q = lo + (lane & 15) + 16u * tn;
+                if (q < hi) {
+                    const i64 g = (i64)beg + (q - o0);
+                    sx[q - w0] = pos_s[3 * g];
+                    sy[q - w0] = pos_s[3 * g + 1];
+                    sz[q - w0] = pos_s[3 * g + 2];
+                }
+            }
+        }
+        if (tid < kSrSlack) {  // the slack read by masked lanes: finite values
+            sx[w1 - w0 + tid] = 0;
+            sy[w1 - w0 + tid] = 0;
+            sz[w1 - w0 + tid] = 0;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const int gx = gxs[h], gy = gys[h];
+            const bool simple = one_window && rend[h] - rbeg[h] <= 64;  // one chunk, one window
+            for (unsigned base = rbeg[h]; base < rend[h]; base += 64) {
+                if (h || base != rbeg[0] || w0) {
+                    ch = sr_chunk_load<RUNGS>(base, rend[h], lane, pos_r, order_r, P);
+                    if (simple && ch.active && ch.sub == 0) {
+                        d0 = dmom_r[3 * (i64)ch.pi];
+                        d1 = dmom_r[3 * (i64)ch.pi + 1];
+                        d2 = dmom_r[3 * (i64)ch.pi + 2];
+                    }
+                }
+                const int R = ch.R, S = ch.S, sub = ch.sub;
+                const bool active = ch.active;
+                if (!__any(active)) continue;
+                const double xi = ch.xi, yi = ch.yi, zi = ch.zi;
+                double ax = 0, ay = 0, az = 0;
+                // (every lane walks the ranges, active or not: the bounds are v_readlane's of
+                // registers whose 64 lanes must be live, i.e. uniform control flow)
+                for (int xg = 0; xg < 5; xg++) {
+                    const int col = (gx + xg) * 8 + gy;  // first of the 5 columns of this x
+                    const int a = max(__builtin_amdgcn_readlane((int)e0, col), sw0) - sw0;
+                    const int b = min(__builtin_amdgcn_readlane((int)i0, col + 4), sw1) - sw0;
+                    if (b > a)
+                        sr_cell_pairs<false, STATS>(a, b, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
+                                                    P.r2_index_scaling, table, ax, ay, az, active,
+                                                    cnt);
+                }
+                // fold the S partial sums of each receiver (see k_sr_sweep_cells)
+                if (sub >= S) ax = ay = az = 0;
+                for (int d = 1; d < S; d <<= 1) {  // S is wave-uniform
+                    const int src = sub + d < S ? lane + d * R : 63;
+                    ax += __shfl(ax, src);
+                    ay += __shfl(ay, src);
+                    az += __shfl(az, src);
+                }
+                ax *= ch.factor;  // gravity.py:321 (total_factor = factors[rung] * table[...])
+                ay *= ch.factor;
+                az *= ch.factor;
+                if (active && sub == 0) {
+                    const i64 o = 3 * (i64)ch.pi;
+                    if (simple) {  // the Δmom read with the chunk
+                        dmom_r[o] = d0 + ax;
+                        dmom_r[o + 1] = d1 + ay;
+                        dmom_r[o + 2] = d2 + az;
+                    } else {
+                        dmom_r[o] += ax;
+                        dmom_r[o + 1] += ay;
+                        dmom_r[o + 2] += az;
+                    }
+                }
+            }
+        }
+    }
+    if (STATS && lane == 0) {
+        atomicAdd(&P.stats[0], (unsigned long long)cnt.tests);
+        atomicAdd(&P.stats[1], (unsigned long long)cnt.hits);
+        atomicAdd(&P.stats[2], (unsigned long long)cnt.trips);
+    }
+}
+
+// ===========================================================================
 // A handful of active receivers (the top rungs of a base step's sub-steps: sixteen of the 32
 // sub-steps of a run with six rungs kick the few particles of the highest one): no cell list at
 // all.  Every workgroup takes a slice of the suppliers, tests each against the K <= 8 receivers
@@ -784,8 +973,16 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
         CG_LAUNCH_CHECK();
         CG_HIP(hipEventRecord(c->sr_join[slab], c->sr_streams[slab]));
     }
-    hipLaunchKernelGGL(inner, dim3(m, m, m), dim3(256), 0, c->stream, pos_r_sorted, order_r, off_r,
-                       dmom_r, pos_s_sorted, off_s, table, P, 0);
+    if (m >= 2) {
+        const unsigned nb = (m + 1) / 2;
+        auto blocks = rungs ? (P.stats ? k_sr_sweep_blocks<true, true> : k_sr_sweep_blocks<true, false>)
+                            : (P.stats ? k_sr_sweep_blocks<false, true> : k_sr_sweep_blocks<false, false>);
+        hipLaunchKernelGGL(blocks, dim3(m, nb, nb), dim3(512), 0, c->stream, pos_r_sorted, order_r,
+                           off_r, dmom_r, pos_s_sorted, off_s, table, P);
+    } else {
+        hipLaunchKernelGGL(inner, dim3(m, m, m), dim3(256), 0, c->stream, pos_r_sorted, order_r,
+                           off_r, dmom_r, pos_s_sorted, off_s, table, P, 0);
+    }
     CG_LAUNCH_CHECK();
     for (int slab = 0; slab < 3; slab++) CG_HIP(hipStreamWaitEvent(c->stream, c->sr_join[slab], 0));
     if (take && cgk_shortrange_dense_join(c)) return 1;
