@@ -909,6 +909,13 @@ def main():
         else:
             dist.init_process_group(backend, timeout=limit)
 
+    if args.workload in C4_SIZES:
+        if world > 1:
+            sys.exit('bench.py: the c4 workloads run on one GPU (tests/test_gpu_distributed.py '
+                     'steps the shape over domains)')
+        result = run_c4(args, torch, torch.device('cuda', local_rank), C4_SIZES[args.workload])
+        print(json.dumps(result))
+        return
     name = args.workload or ('c2_256c_512' if args.p3m else 'ns_256M_1024')
     if args.weak:
         if world not in WEAK:
@@ -958,12 +965,175 @@ def main():
             if r2['roofline'].get('receivers_in_dense_tiles') is not None:
                 result['configs'][cname]['receivers_in_dense_tiles'] = \
                     r2['roofline']['receivers_in_dense_tiles']
+        r4 = run_c4(args, torch, dev, 512, steps=5, warmup=2)
+        result['configs']['c4_nonlinnu_1gpu'] = {
+            'ms_per_step': round(r4['ms_per_step'], 4), 'steps': r4['steps'],
+            'particle_updates_per_s': r4['value'], 'dominant_kernel': r4['dominant_phase'],
+            'dominant_kernel_ms': r4['roofline']['kernel_ms'], 'bound': r4['roofline']['bound'],
+            'frac': r4['roofline']['frac'], 'interactions': r4['interactions'],
+            'phases': r4['phases'], 'phases_ms': {k: v['ms'] for k, v in r4['phases'].items()},
+            'workload': r4['config']['workload']}
         # the same workload through the drop-in API
         result['timeloop'] = timeloop_leg(torch, dev, result['ms_per_step'])
         result['timeloop_ms_per_step'] = result['timeloop']['ms_per_base_step']
     if not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(name)
     print(json.dumps(result))
+
+
+C4_SIZES = {'c4_nonlinnu_1gpu': 512, 'c4_nonlinnu_small': 128, 'c4_nonlinnu_tiny': 32}
+
+
+def run_c4(args, torch, dev, size=512, steps=None, warmup=None):
+    """BASELINE configs[4]'s shape on ONE GPU: param/example_nonlinnu:36-45
+    with _size = 512 — 512^3 matter particles (P3M on a 1024^3 mesh, spline-softened short range
+    with the default r_s = 1.25 cells, range 4.5 r_s) + a fluid component with non-linear energy
+    and momentum density on a 256^3 grid (the neutrino's place; species 'matter' here, the
+    reference's test/fluid_gravity stand-in, CLASS being out of reach), global PM grid 256.
+    find_interactions() makes three mesh solves of a long kick: (p3m: particles <- particles) on
+    1024^3, (pm: particles <- fluid) and (pm: fluid <- particles, fluid) on 256^3
+    (interactions.py:2456-2636).  A step here is the loop body of main.timeloop() for that
+    configuration, driven through the drop-in API itself — Component.drift_sort, gravity(...,
+    'short-range') + apply_Δmom, then gravity(..., 'long-range') per interaction — with fixed
+    step integrals; the fluid's own evolution (fluid.py) is outside the path.  Phases are timed
+    by HIP events around each call; `moved` bytes per phase below."""
+    import numpy as np
+    from concept_amd import commons, interactions
+    from concept_amd.mesh import get_mesh
+    from concept_amd.species import Component
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    n_side, N3, N1 = size, 2*size, size//2
+    n = n_side**3
+    L = float(N3)
+    p = commons.load_params({
+        'boxsize': L,
+        'potential_options': {'gridsize': {'global': {'gravity': {'pm': N1, 'p3m': N3}}}},
+        'select_forces': {'particles': {'gravity': 'p3m'}, 'fluid': {'gravity': 'pm'}},
+        'select_softening_length': {'particles': '0.025*boxsize/cbrt(N)'}})
+    mass, dt = 1.0, 1e-4
+    part = Component('matter', 'matter', N=n, mass=mass)
+    gen = torch.Generator(device=dev).manual_seed(args.seed)
+    torch.rand((n, 3), dtype=torch.float64, device=dev, generator=gen, out=part.pos)
+    part.pos.mul_(L*(1 - 1e-13))
+    torch.randn((n, 3), dtype=torch.float64, device=dev, generator=gen, out=part.mom)
+    part.mom.mul_(args.thermal/3**0.5*(L/N3)*mass/dt)
+    fluid = Component('neutrino', 'matter', gridsize=N1, boltzmann_order=1)
+    # a smooth density contrast of 10 % and a matching momentum density
+    x = (torch.arange(N1, dtype=torch.float64, device=dev) + 0.5)*(2*np.pi/N1)
+    wave = torch.sin(x)[:, None, None]*torch.cos(2*x)[None, :, None]*torch.sin(3*x)[None, None, :]
+    mean = 0.02*n*mass/N1**3   # a few per cent of the matter's mass in the fluid
+    fluid.ϱ.copy_(mean*(1 + 0.1*wave))
+    fluid.𝒫.copy_(1e-3*fluid.ϱ)
+    for d in range(3):
+        fluid.J[d].copy_(1e-2*mean*wave)
+    del x, wave
+    comps = [part, fluid]
+    sdt = {'1': dt, 'a**(-2)': dt}
+    for c in comps:
+        sdt['a**(-3*w_eff)', c.name] = dt
+        sdt['a**(-3*w_eff-1)', c.name] = dt
+    # (one integral per rung index, main.py:1203-1215; every particle sits on rung 0)
+    sdt_rungs = {('a**(-3*w_eff₀-3*w_eff₁-1)', part.name, part.name):
+                 np.full(3*getattr(part, 'N_rungs', 8) - 1, dt)}
+    mesh3 = get_mesh(N3, L, p.nghosts, p.cell_centered, 2, dev)
+    long_range = interactions.find_interactions(comps, 'long-range')
+    short_range = interactions.find_interactions(comps, 'short-range')
+    describe = lambda it: (f"{it.method}: {', '.join(c.name for c in it.receivers)} <- "
+                           f"{', '.join(c.name for c in it.suppliers)}")
+    PH = ['drift_sort', 'short_range'] + ['long: ' + describe(it) for it in long_range]
+    part.tile_sort(mesh=mesh3)
+    events = []
+
+    def step(record):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(PH) + 1)] if record else None
+        k = 0
+
+        def mark():
+            nonlocal k
+            if ev is not None:
+                ev[k].record()
+                k += 1
+        mark()
+        part.drift_sort(sdt, mesh=mesh3)
+        mark()
+        part.nullify_Δ('mom')
+        for it in short_range:
+            getattr(interactions, it.force)(it.method, it.receivers, it.suppliers, sdt_rungs,
+                                            'short-range', False)
+        part.apply_Δmom()
+        mark()
+        for it in long_range:
+            getattr(interactions, it.force)(it.method, it.receivers, it.suppliers, sdt,
+                                            'long-range', False)
+            mark()
+        if record:
+            events.append(ev)
+    for _ in range(warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    mesh3.check_errors()
+    ms = {ph: sum(ev[k].elapsed_time(ev[k + 1]) for ev in events)/len(events)
+          for k, ph in enumerate(PH)}
+    # bytes each phase must move (DESIGN.md §4, §10): N_p particles, G3 = 1024^3-type mesh of the
+    # P3M interaction, G1 = 256^3-type mesh of the PM interactions and the fluid's grids
+    Np, G3, G1 = n, N3**3, N1**3
+    moved = {'drift_sort': 96*Np + 16*Np,                         # pos + mom read and written, ids
+             'short_range': 2*24*Np + 8*Np + 72*Np + 72*Np}       # cell list, sweep, Δmom apply
+    for ph, it in zip(PH[2:], long_range):
+        rec_p = [c for c in it.receivers if c.representation == 'particles']
+        rec_f = [c for c in it.receivers if c.representation == 'fluid']
+        sup_p = [c for c in it.suppliers if c.representation == 'particles']
+        sup_f = [c for c in it.suppliers if c.representation == 'fluid']
+        G = G3 if it.method == 'p3m' else G1
+        b = 80*G                                                  # five in-place passes
+        b += len(sup_p)*(24*Np + 8*G) + len(sup_f)*16*G           # deposit; ϱ read, mesh written
+        if sup_p and sup_f:
+            b += 32*G                                             # a second forward transform
+        b += len(rec_p)*(72*Np + 8*G)                             # gather-kick
+        b += len(rec_f)*3*(8*G + 16*G + 16*G)                     # fluid kick per dimension:
+        #                                           potential, J read + written, ϱ and 𝒫 read
+        moved[ph] = b
+    phases = {ph: {'ms': round(ms[ph], 4), 'moved_GB': round(moved[ph]/1e9, 3),
+                   'GBps': round(moved[ph]/(ms[ph]*1e-3)/1e9, 1),
+                   'frac_hbm': round(moved[ph]/(ms[ph]*1e-3)/1e9/HBM_PEAK_GBS, 4)}
+              for ph in PH}
+    ms_per_step = elapsed/steps*1e3
+    dom = max(PH, key=lambda ph: ms[ph])
+    out = {
+        'metric': 'P3M + PM (particles + fluid) particle-updates/sec', 'value': n*steps/elapsed,
+        'unit': 'particle-updates/s', 'steps_per_sec': steps/elapsed, 'n_gpus': 1, 'steps': steps,
+        'warmup': warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': f'c4 (param/example_nonlinnu with _size = {size}): {n} matter '
+                               f'particles, P3M mesh {N3}^3, fluid grid and global PM grid '
+                               f'{N1}^3, three mesh solves per long kick; through '
+                               'Component.drift_sort / gravity() / apply_Δmom',
+                   'particles': n, 'gridsize': N3, 'fluid_gridsize': N1,
+                   'parallelism': 'domains1'},
+        'interactions': [describe(it) for it in long_range],
+        'phases': phases, 'dominant_phase': dom,
+        'roofline': ({'bound': 'hbm', 'kernel': dom, 'achieved': phases[dom]['GBps'],
+                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': phases[dom]['frac_hbm'],
+                      'traffic': None, 'kernel_ms': phases[dom]['ms']}
+                     if dom != 'short_range' else
+                     {'bound': 'valu_fp64', 'kernel': 'short_range', 'unit': 'GB/s',
+                      'achieved': phases[dom]['GBps'], 'peak': HBM_PEAK_GBS,
+                      'frac': phases[dom]['frac_hbm'], 'traffic': None,
+                      'kernel_ms': phases[dom]['ms'],
+                      'note': 'the pair sweep is FP64-VALU bound (see the c2 P3M line): its '
+                              'fraction of the HBM rate says only that it is not memory-bound'}),
+    }
+    del part, fluid, comps
+    from concept_amd import mesh as mesh_module
+    mesh_module.free_meshes()
+    torch.cuda.empty_cache()
+    return out
 
 
 def timeloop_leg(torch, dev, raw_ms, n=2**28, N=1024, base_steps=24):
@@ -1028,6 +1198,8 @@ def timeloop_leg(torch, dev, raw_ms, n=2**28, N=1024, base_steps=24):
                     'sum of mom^2 for v_rms + host), torch.cuda.synchronize() in the step '
                     'callback')}
     del c, loop
+    from concept_amd import mesh as mesh_module
+    mesh_module.free_meshes()
     torch.cuda.empty_cache()
     return out
 

@@ -40,45 +40,148 @@ __device__ __forceinline__ i64 wrap(i64 a, i64 n) {
 }
 
 // ---------------------------------------------------------------------------
-// A1/A2 deposit, direct form: one lane per particle, 8 device-scope FP64
-// atomic adds onto the periodic padded mesh.  Index and weight arithmetic is
-// the reference's; only the summation order across particles differs.
+// A1/A2 deposit, direct form (cg_deposit_cic: particles in any order).  Index and weight
+// arithmetic is the reference's; only the summation order across particles differs.
+// Made for particles whose memory order is compact in space but is not THIS mesh's tile
+// order — BASELINE configs[4]: 512^3 particles, sorted by the tiles of their own 1024^3
+// P3M mesh, deposited onto the 256^3 PM mesh of the (fluid <- particles, fluid) interaction
+// (interactions.py:1985-2335; param/example_nonlinnu:36-45).  Device-scope FP64 atomics execute
+// memory-side on MI355X (8 per particle: 31.7 ms for 2^27 particles).  Here a workgroup takes
+// 2048 consecutive particles, finds the box of their lower cells (relative to the first one's:
+// the periodic seam is no seam), and — when the box with its CIC overhang fits 4096 cells of LDS —
+// accumulates there (ds_add_f64) and adds the box to the mesh once: one device atomic per
+// touched cell instead of eight per particle.  A chunk that is spread out (unsorted particles)
+// takes the direct atomics: 8 device-scope FP64 atomic adds per particle.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_deposit_cic_direct(const double *__restrict__ pos, i64 n,
-                                                            double *__restrict__ mesh, i64 N,
-                                                            i64 ny, i64 pad, int g, XMap xm,
-                                                            CicGeom geo, double contribution) {
-    i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
-        Cic1 cx = cic1(pos[3 * p + 0], geo.off[0], geo.scale);
-        Cic1 cy = cic1(pos[3 * p + 1], geo.off[1], geo.scale);
-        Cic1 cz = cic1(pos[3 * p + 2], geo.off[2], geo.scale);
-        i64 i0 = cg_xlayer(xm, cx.index - g, N), i1 = cg_xlayer(xm, cx.index - g + 1, N);
-        i64 j0 = wrap(cy.index - g, N), j1 = wrap(cy.index - g + 1, N);
-        i64 k0 = wrap(cz.index - g, N), k1 = wrap(cz.index - g + 1, N);
+constexpr int kDcPer = 4, kDcLanes = 512, kDcCells = 4096;
+__global__ __launch_bounds__(kDcLanes) void k_deposit_cic_chunks(
+    const double *__restrict__ pos, i64 n, double *__restrict__ mesh, i64 N, i64 ny, i64 pad,
+    int g, XMap xm, CicGeom geo, double contribution) {
+    __shared__ double blk[kDcCells];
+    __shared__ int s_ref[3], s_lo[3], s_hi[3];
+    const int tid = threadIdx.x;
+    const i64 base = (i64)blockIdx.x * (kDcLanes * kDcPer);
+    const int Ni = (int)N;
+    double px[kDcPer], py[kDcPer], pz[kDcPer];
+    bool valid[kDcPer];
+#pragma unroll
+    for (int u = 0; u < kDcPer; u++) {
+        const i64 p = base + tid + (i64)kDcLanes * u;
+        valid[u] = p < n;
+        px[u] = py[u] = pz[u] = 0;
+        if (valid[u]) px[u] = pos[3 * p], py[u] = pos[3 * p + 1], pz[u] = pos[3 * p + 2];
+    }
+    auto cells = [&](int u, int (&cell)[3]) {
+        cell[0] = (int)wrap(cic1(px[u], geo.off[0], geo.scale).index - g, N);
+        cell[1] = (int)wrap(cic1(py[u], geo.off[1], geo.scale).index - g, N);
+        cell[2] = (int)wrap(cic1(pz[u], geo.off[2], geo.scale).index - g, N);
+    };
+    if (tid == 0) {  // (the chunk's first particle exists: base < n)
+        int c0[3];
+        cells(0, c0);
+        for (int d = 0; d < 3; d++) {
+            s_ref[d] = c0[d];
+            s_lo[d] = 0;
+            s_hi[d] = 0;
+        }
+    }
+    __syncthreads();
+    const int r0 = s_ref[0], r1 = s_ref[1], r2 = s_ref[2];
+    // lower cells relative to the first particle's, through the periodic seam: in [-N/2, N/2)
+    auto rel = [&](int cell, int ref) {
+        int d = cell - ref;
+        d += d < -(Ni / 2) ? Ni : 0;
+        d -= d >= Ni - Ni / 2 ? Ni : 0;
+        return d;
+    };
+    int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < kDcPer; u++) {
+        if (!valid[u]) continue;
+        int cell[3];
+        cells(u, cell);
+        const int d[3] = {rel(cell[0], r0), rel(cell[1], r1), rel(cell[2], r2)};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            lo[k] = min(lo[k], d[k]);
+            hi[k] = max(hi[k], d[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            lo[k] = min(lo[k], __shfl_xor(lo[k], m));
+            hi[k] = max(hi[k], __shfl_xor(hi[k], m));
+        }
+        if ((tid & 63) == 0) {
+            atomicMin(&s_lo[k], lo[k]);
+            atomicMax(&s_hi[k], hi[k]);
+        }
+    }
+    __syncthreads();
+    const int l0 = s_lo[0], l1 = s_lo[1], l2 = s_lo[2];
+    const int e0 = s_hi[0] - l0 + 2, e1 = s_hi[1] - l1 + 2, e2 = s_hi[2] - l2 + 2;
+    const bool fits = (i64)e0 * e1 * e2 <= kDcCells && e0 <= Ni && e1 <= Ni && e2 <= Ni;
+    const int ncells = fits ? e0 * e1 * e2 : 0;
+    for (int i = tid; i < ncells; i += kDcLanes) blk[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kDcPer; u++) {
+        if (!valid[u]) continue;
+        const Cic1 cx = cic1(px[u], geo.off[0], geo.scale), cy = cic1(py[u], geo.off[1], geo.scale),
+                   cz = cic1(pz[u], geo.off[2], geo.scale);
         // mesh.py:5142-5155: ((w_x*contribution)*w_y)*w_z
-        double wi0 = cx.w0 * contribution, wi1 = cx.w1 * contribution;
-        double w00 = wi0 * cy.w0, w01 = wi0 * cy.w1, w10 = wi1 * cy.w0, w11 = wi1 * cy.w1;
-        double *r00 = mesh + (i0 * ny + j0) * pad, *r01 = mesh + (i0 * ny + j1) * pad;
-        double *r10 = mesh + (i1 * ny + j0) * pad, *r11 = mesh + (i1 * ny + j1) * pad;
-        unsafeAtomicAdd(r00 + k0, w00 * cz.w0);
-        unsafeAtomicAdd(r00 + k1, w00 * cz.w1);
-        unsafeAtomicAdd(r01 + k0, w01 * cz.w0);
-        unsafeAtomicAdd(r01 + k1, w01 * cz.w1);
-        unsafeAtomicAdd(r10 + k0, w10 * cz.w0);
-        unsafeAtomicAdd(r10 + k1, w10 * cz.w1);
-        unsafeAtomicAdd(r11 + k0, w11 * cz.w0);
-        unsafeAtomicAdd(r11 + k1, w11 * cz.w1);
+        const double wi0 = cx.w0 * contribution, wi1 = cx.w1 * contribution;
+        const double w00 = wi0 * cy.w0, w01 = wi0 * cy.w1, w10 = wi1 * cy.w0, w11 = wi1 * cy.w1;
+        if (fits) {
+            const int a = rel((int)wrap(cx.index - g, N), r0) - l0,
+                      b = rel((int)wrap(cy.index - g, N), r1) - l1,
+                      c = rel((int)wrap(cz.index - g, N), r2) - l2;
+            double *q = blk + (a * e1 + b) * e2 + c;
+            unsafeAtomicAdd(q, w00 * cz.w0);
+            unsafeAtomicAdd(q + 1, w00 * cz.w1);
+            unsafeAtomicAdd(q + e2, w01 * cz.w0);
+            unsafeAtomicAdd(q + e2 + 1, w01 * cz.w1);
+            unsafeAtomicAdd(q + e1 * e2, w10 * cz.w0);
+            unsafeAtomicAdd(q + e1 * e2 + 1, w10 * cz.w1);
+            unsafeAtomicAdd(q + e1 * e2 + e2, w11 * cz.w0);
+            unsafeAtomicAdd(q + e1 * e2 + e2 + 1, w11 * cz.w1);
+        } else {
+            const i64 i0 = cg_xlayer(xm, cx.index - g, N), i1 = cg_xlayer(xm, cx.index - g + 1, N);
+            const i64 j0 = wrap(cy.index - g, N), j1 = wrap(cy.index - g + 1, N);
+            const i64 k0 = wrap(cz.index - g, N), k1 = wrap(cz.index - g + 1, N);
+            double *r00 = mesh + (i0 * ny + j0) * pad, *r01 = mesh + (i0 * ny + j1) * pad;
+            double *r10 = mesh + (i1 * ny + j0) * pad, *r11 = mesh + (i1 * ny + j1) * pad;
+            unsafeAtomicAdd(r00 + k0, w00 * cz.w0);
+            unsafeAtomicAdd(r00 + k1, w00 * cz.w1);
+            unsafeAtomicAdd(r01 + k0, w01 * cz.w0);
+            unsafeAtomicAdd(r01 + k1, w01 * cz.w1);
+            unsafeAtomicAdd(r10 + k0, w10 * cz.w0);
+            unsafeAtomicAdd(r10 + k1, w10 * cz.w1);
+            unsafeAtomicAdd(r11 + k0, w11 * cz.w0);
+            unsafeAtomicAdd(r11 + k1, w11 * cz.w1);
+        }
+    }
+    if (!fits) return;  // (uniform)
+    __syncthreads();
+    for (int i = tid; i < ncells; i += kDcLanes) {
+        const double v = blk[i];
+        if (v == 0) continue;
+        const int c = i % e2, b = (i / e2) % e1, a = i / (e2 * e1);
+        // the cell's index on the mesh: in [-N, 2N) before the wrap (|rel| <= N/2, e <= N)
+        const i64 gi = cg_xlayer(xm, wrap((i64)r0 + l0 + a, N), N), gj = wrap((i64)r1 + l1 + b, N),
+                  gk = wrap((i64)r2 + l2 + c, N);
+        unsafeAtomicAdd(mesh + (gi * ny + gj) * pad + gk, v);
     }
 }
 
 int cgk_deposit_cic(cg_ctx *c, const double *pos, i64 n, double contribution) {
-    int block = 256;
-    i64 blocks = (n + block - 1) / block;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k_deposit_cic_direct, dim3((unsigned)blocks), dim3(block), 0, c->stream, pos,
-                       n, c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->xmap, c->geom_deposit,
-                       contribution);
+    if (n <= 0) return 0;
+    const i64 blocks = (n + kDcLanes * kDcPer - 1) / (kDcLanes * kDcPer);
+    hipLaunchKernelGGL(k_deposit_cic_chunks, dim3((unsigned)blocks), dim3(kDcLanes), 0, c->stream,
+                       pos, n, c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->xmap,
+                       c->geom_deposit, contribution);
     CG_LAUNCH_CHECK();
     return 0;
 }

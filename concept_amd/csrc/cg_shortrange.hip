@@ -637,6 +637,12 @@ k_sr_sweep_cells(
 // the pair loop is the one above.  The tiles on the box faces (periodic images) keep the
 // one-tile kernel.  An odd number of interior tiles per dimension: the last block starts one
 // tile early and leaves the tile it shares with its neighbour out.
+// Measured at 256^3 / 512^3 on one box: 8.05 ms one tile per workgroup, 7.5 ms this.  Also
+// built and measured here: two receivers per lane, so that a supplier read from LDS serves two
+// pair tests (the loop issues three 8-byte LDS reads per test, ~70 % of what a CU's LDS
+// delivers while its SIMDs do the arithmetic): 9.3 ms — a chunk's ~5.5 receivers become 3
+// lane rows x 21 supplier groups, a range of ~82 suppliers is four trips of which the last is
+// mostly empty, and the fold over 21 groups of six sums costs what the reads saved.
 // ===========================================================================
 constexpr int kSbCap = 1344;     // suppliers staged per window (mean 1056 at 22 per tile; more
                                  // take further windows): with the slack 35.3 KB of LDS -> four

@@ -826,7 +826,19 @@ class Timeloop(RungStepper):
                     for v in p.snapshot_times[dump_time.time_param]):
                 return
             name = f'{output_dir}/{output_base}{sep}{dump_time.time_param}={value:.{ndigits}f}'
-            fn = snapshot.save(loop.components, name, a=loop.cosmo.a,
+            # GADGET snapshots hold particles: fluid components (riding along through
+            # fluid_drift) are left out, as the reference's writer leaves them out
+            # (snapshot.py: GadgetSnapshot.populate keeps the particle components)
+            particles = [c for c in loop.components if c.representation == 'particles']
+            left_out = [c.name for c in loop.components if c.representation != 'particles']
+            if left_out and not getattr(loop, '_warned_fluid_snapshot', False):
+                import warnings
+                warnings.warn('GADGET snapshots hold particle components only: '
+                              f'{", ".join(left_out)} not written')
+                loop._warned_fluid_snapshot = True
+            if not particles:
+                return
+            fn = snapshot.save(particles, name, a=loop.cosmo.a,
                                **{'output_base': output_base or 'snapshot', **save_options})
             loop.snapshots_written.append(fn)
         return on_dump

@@ -196,6 +196,17 @@ CASES = {
               "'range': '3.1*scale', 'subtiling': 2}}\n")),
     'traj_pm_n8_g16': dict(method='pm', n=8, gridsize=16, boxsize=8.0, seed=54, traj=dict(
         a_begin=0.05, outputs=(0.2, 1))),
+    # a larger P3M run with adaptive rungs on a CLUSTERED box: the shape of
+    # test/concept_vs_gadget_p3m/param:9-46 — box 8 Mpc, P3M mesh 32, CIC, differentiation
+    # order 4, range 4.5 scale, softening 0.03 boxsize/cbrt(N) — with 16^3 particles, 60 % of
+    # them in three Gaussian clumps (tiles of several hundred particles, rungs that differ)
+    'traj_p3m_n16_g32_clustered': dict(method='p3m', n=16, gridsize=32, boxsize=8.0, seed=55,
+                                       traj=dict(
+        a_begin=0.1, outputs=(0.14, 0.2), clustered=0.6,
+        extra="shortrange_params = {'gravity': {'scale': '1.25*boxsize/gridsize', "
+              "'range': '4.5*scale'}}\n"
+              "potential_options['differentiation'] = {'matter': {'gravity': {'p3m': 4}}}\n"
+              "select_softening_length = {'matter': '0.03*boxsize/cbrt(N)'}\n")),
     # the same P3M run without adaptive rungs (N_rungs = 1)
     'traj_p3m_n8_g24_r1': dict(method='p3m', n=8, gridsize=24, boxsize=4.0, seed=52, traj=dict(
         a_begin=0.1, outputs=(0.3, 0.5, 1),
@@ -765,6 +776,12 @@ def child_traj(name):
     lat = (np.stack(np.meshgrid(*[np.arange(n)]*3, indexing='ij'), -1).reshape(-1, 3) + 0.5)*(L/n)
     psi = rng.normal(0, 0.08*L/n, (N, 3))
     pos = np.ascontiguousarray((lat + psi) % L)
+    if cfg['traj'].get('clustered'):
+        # that fraction of the particles in three Gaussian clumps of sigma = L/25
+        k = int(cfg['traj']['clustered']*N)
+        which = rng.permutation(N)[:k]
+        centres = rng.uniform(0, L, (3, 3))
+        pos[which] = (centres[rng.integers(0, 3, k)] + rng.normal(0, L/25, (k, 3))) % L
     pos[pos >= L] = 0.0
     mass = commons.ρ_mbar*L**3/N
     integration.init_time()

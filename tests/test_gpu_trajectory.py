@@ -531,6 +531,31 @@ def test_timeloop_with_a_fluid_component(golden):
     assert np.abs(mom_f - comps0[0].host('mom')).max() <= 1e-8*kick
 
 
+def test_timeloop_with_a_fluid_component_dumps_snapshots(golden, tmp_path):
+    """a fluid riding along (fluid_drift) and snapshot times together — the GADGET
+    writer holds particle components only, the dumper leaves the fluid out (with a warning, once)
+    instead of failing at the first dump."""
+    from concept_amd import commons, snapshot, stepper
+    from concept_amd.species import Component
+    g = golden('traj_pm_n8_g16')
+    text = (str(g['param_text']) + '\nstatic_timestepping = lambda a: 0.05 + 0*a\n'
+            + "select_forces = {'all': {'gravity': 'pm'}}\n")
+    commons.load_params(text)
+    c = Component('matter', 'matter', N=int(g['N']), mass=float(g['mass']))
+    c.populate(g['pos_in'], 'pos')
+    c.populate(g['mom_in'], 'mom')
+    gs = 16
+    fl = Component('neutrinos', 'neutrino', gridsize=gs, boltzmann_order=1)
+    fl.populate(np.full((gs, gs, gs), 1e-3*c.ϱ_bar), 'ϱ')
+    loop = stepper.Timeloop([c, fl], fluid_drift=lambda comp, ᔑdt, a_end: None)
+    loop.on_dump = loop.snapshot_dumper(str(tmp_path), 'snap')
+    with pytest.warns(UserWarning, match='particle components only'):
+        loop.run()
+    assert len(loop.snapshots_written) == len(g['dump_a']) >= 1
+    (comp,) = snapshot.load(loop.snapshots_written[-1]).components
+    assert comp['N'] == int(g['N'])
+
+
 def test_p3m_timeloop_with_dense_tiles_equals_the_cells_sweep(monkeypatch):
     """A clustered box (80 % of 64^3 particles in 8 Gaussian blobs: tiles of several hundred
     particles) through the P³M time loop with 8 rungs, twice: with the dense tiles' sweep
