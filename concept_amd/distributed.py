@@ -600,10 +600,13 @@ class RegionParticles:
     them and seats the arrivals, after the step's single wait for the GPU (the message sizes).
     Built from a tile-sorted ParticleStore; dense() converts back."""
 
-    def __init__(self, store, slack=1.25, drop_order=False):
+    def __init__(self, store, slack=1.25, drop_order=False, drop_ids=False):
         """drop_order: the `order` column is known to equal `ids` (a Component whose
         identifiers are its running row numbers): one 64-bit column travels instead of two
-        (8.6 GB less traffic per pass at 2^28 particles), columns() returns no 'order'."""
+        (8.6 GB less traffic per pass at 2^28 particles), columns() returns no 'order'.
+        drop_ids: no 64-bit column travels at all — the reference's particles without
+        identifiers (species.py:2040-2064: `ids` only where the run uses them), whose memory
+        order the time loop is free to change; columns() returns neither."""
         if not store.sorted:
             raise lib.ConceptGPUError('RegionParticles: the store must be tile-sorted')
         m = self.mesh = store.mesh
@@ -615,8 +618,9 @@ class RegionParticles:
         self.cap = cap
         # two 64-bit columns may travel with the particles: `ids` and `order` (a Component's
         # identifiers and the row numbers its host() restores the populated order with)
-        self.has_ids = 'ids' in store.cols
-        self.has_aux = 'order' in store.cols and not (drop_order and self.has_ids)
+        self.has_ids = 'ids' in store.cols and not drop_ids
+        self.has_aux = 'order' in store.cols and not (drop_order and self.has_ids) \
+            and not drop_ids
         mk = lambda w: torch.empty((cap, w), dtype=torch.float64, device=dev)
         mi = lambda have: [torch.empty(cap, dtype=torch.int64, device=dev) for _ in range(2)] \
             if have else [None, None]

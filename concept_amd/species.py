@@ -79,6 +79,11 @@ class Component:
         self.tile_mesh = None
         self.tiles_exact = False
         self.use_ids = False  # identifiers are the running row numbers until some are populated
+        # host() returns the particles in the order they were populated in (an `order` column
+        # travels with them).  keep_order = False gives that up where it costs — the streaming
+        # time loop then moves no 64-bit column with particles that have no identifiers, as the
+        # reference moves none (its particle order is whatever the last tile sort left)
+        self.keep_order = True
         if (N is None) == (gridsize is None):
             raise ConceptGPUError(
                 f'{self.name}: give N (particle component) or gridsize (fluid component)')
@@ -146,7 +151,8 @@ class Component:
         from .distributed import RegionParticles
         self.tile_sort(mesh)
         # identifiers that are the running row numbers equal `order`: one column travels
-        return RegionParticles(self._store, drop_order=not self.use_ids)
+        return RegionParticles(self._store, drop_order=not self.use_ids,
+                               drop_ids=not self.use_ids and not self.keep_order)
 
     def from_regions(self, rp, collective=True):
         """Take the particles back from their streaming form (pos, mom, ids, order; Δmom and
@@ -158,6 +164,13 @@ class Component:
             rp.pending = False
         cols = rp.columns()
         old = self._store
+        if 'ids' not in cols:   # (keep_order = False: the rows are renumbered as they lie)
+            first = 0
+            if self.comm is not None and self.nprocs > 1 and collective:
+                counts = self.comm.all_gather_ints([cols['pos'].shape[0]])[:, 0].tolist()
+                first = int(sum(counts[:self.rank]))
+            cols['ids'] = torch.arange(first, first + cols['pos'].shape[0], dtype=torch.int64,
+                                       device=self.device)
         self._store = ParticleStore(old.mesh, cols['pos'], cols['mom'], None, slack=1.4,
                                     extra={'ids': cols['ids'],
                                            'order': cols['order'] if 'order' in cols

@@ -202,7 +202,7 @@ CASES = {
     # them in three Gaussian clumps (tiles of several hundred particles, rungs that differ)
     'traj_p3m_n16_g32_clustered': dict(method='p3m', n=16, gridsize=32, boxsize=8.0, seed=55,
                                        traj=dict(
-        a_begin=0.1, outputs=(0.14, 0.2), clustered=0.6,
+        a_begin=0.1, outputs=(0.11, 0.122), clustered=0.6,
         extra="shortrange_params = {'gravity': {'scale': '1.25*boxsize/gridsize', "
               "'range': '4.5*scale'}}\n"
               "potential_options['differentiation'] = {'matter': {'gravity': {'p3m': 4}}}\n"

@@ -179,6 +179,31 @@ def test_timeloop_wrong_guess_is_undone(golden):
     assert np.abs(m0 - m1).max() <= 1e-10*np.abs(m1).max()
 
 
+def test_streaming_timeloop_without_the_order_column(golden):
+    """Component.keep_order = False: particles without identifiers whose memory order the loop
+    may change (the reference's own contract) — no 64-bit column rides through the fused
+    passes.  Same step sequence, and the same particles as a SET: the rows of (pos, mom),
+    sorted, equal those of the ordered run."""
+    from concept_amd import stepper
+    g = golden('traj_pm_n8_g16')
+    out = []
+    for keep in (True, False):
+        p, c = _component(g)
+        c.keep_order = keep
+        loop = stepper.Timeloop([c])
+        loop.run()
+        assert loop.stream_passes > 0
+        rows = np.concatenate([c.host('pos', original_order=keep),
+                               c.host('mom', original_order=keep)], 1)
+        out.append((np.array(loop.history), rows[np.lexsort(rows.T[::-1])]))
+    (h0, r0), (h1, r1) = out
+    assert h0.shape == h1.shape and np.abs(h0/np.where(h1 == 0, 1, h1) - 1)[:, 1:].max() <= 1e-12
+    L = float(g['boxsize'])
+    assert r0.shape == r1.shape == (int(g['N']), 6)
+    assert np.abs(r0[:, :3] - r1[:, :3]).max() <= 1e-11*L
+    assert np.abs(r0[:, 3:] - r1[:, 3:]).max() <= 1e-10*np.abs(r1[:, 3:]).max()
+
+
 def test_timeloop_overflow_of_the_speculative_pass(golden):
     """The speculative pass (kick + guessed drift after an init kick) overflows AND its guess
     turns out wrong: the replay on the exact path replaces the region objects, so the guess
