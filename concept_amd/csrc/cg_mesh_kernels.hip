@@ -240,62 +240,162 @@ int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst) {
 }
 
 // ---------------------------------------------------------------------------
-// A9/A10 gather + finite difference + kick, direct form: one lane per
-// particle reads the potential stencil straight from the periodic mesh.
-// For each dim the 8 force-cell values are formed exactly as diff_domaingrid
-// forms them (mesh.py:4966-4981) and accumulated in the order of
-// mesh.py:5142-5155 / :445, then value *= factor, mom += value (:456-459).
+// A9/A10 gather + finite difference + kick, direct form (cg_gather_kick: particles in any
+// order).  For each dim the 8 force-cell values are formed exactly as diff_domaingrid forms
+// them (mesh.py:4966-4981) and accumulated in the order of mesh.py:5142-5155 / :445, then
+// value *= factor, mom += value (:456-459).
+// Like the deposit above, a workgroup takes 2048 consecutive particles and, when the box of
+// their cells with the stencil's reach fits 4096 cells, copies that box of the potential into
+// LDS first: particles that are compact in space but not in THIS mesh's tile order (configs[4]:
+// the matter particles, sorted by the tiles of their 1024^3 mesh, kicked by the fluid's
+// potential on the 256^3 mesh) then read the mesh once per box instead of 48 scattered values
+// per particle (5.5 -> 2.x ms for 2^27 particles).  A chunk that is spread out reads the mesh
+// directly.
 // ---------------------------------------------------------------------------
+template <int ORDER, class Phi>
+__device__ __forceinline__ void gather_force(const Phi &phi, const double (&wx)[2],
+                                             const double (&wy)[2], const double (&wz)[2],
+                                             double c1, double c2, double (&val)[3]) {
+    constexpr int H = ORDER / 2;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const double wij = wx[i] * wy[j];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const double w = wij * wz[k];
+                const int a = H + i, b = H + j, cc = H + k;
+                double fx, fy, fz;
+                if (ORDER == 2) {
+                    fx = c1 * (phi(a + 1, b, cc) - phi(a - 1, b, cc));
+                    fy = c1 * (phi(a, b + 1, cc) - phi(a, b - 1, cc));
+                    fz = c1 * (phi(a, b, cc + 1) - phi(a, b, cc - 1));
+                } else {
+                    fx = c1 * (phi(a + 1, b, cc) - phi(a - 1, b, cc)) -
+                         c2 * (phi(a + 2, b, cc) - phi(a - 2, b, cc));
+                    fy = c1 * (phi(a, b + 1, cc) - phi(a, b - 1, cc)) -
+                         c2 * (phi(a, b + 2, cc) - phi(a, b - 2, cc));
+                    fz = c1 * (phi(a, b, cc + 1) - phi(a, b, cc - 1)) -
+                         c2 * (phi(a, b, cc + 2) - phi(a, b, cc - 2));
+                }
+                val[0] += fx * w;
+                val[1] += fy * w;
+                val[2] += fz * w;
+            }
+        }
+}
+
 template <int ORDER>
-__global__ __launch_bounds__(256) void k_gather_kick_direct(const double *__restrict__ pos,
-                                                            double *__restrict__ mom, i64 n,
-                                                            const double *__restrict__ mesh, i64 N,
-                                                            i64 ny, i64 pad, int g, XMap xm,
-                                                            CicGeom geo, double c1, double c2,
-                                                            double factor) {
+__global__ __launch_bounds__(kDcLanes) void k_gather_kick_chunks(
+    const double *__restrict__ pos, double *__restrict__ mom, i64 n,
+    const double *__restrict__ mesh, i64 N, i64 ny, i64 pad, int g, XMap xm, CicGeom geo,
+    double c1, double c2, double factor) {
     constexpr int H = ORDER / 2;      // stencil half width
     constexpr int W = 2 + 2 * H;      // cells needed per dimension
-    i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
-        Cic1 cx = cic1(pos[3 * p + 0], geo.off[0], geo.scale);
-        Cic1 cy = cic1(pos[3 * p + 1], geo.off[1], geo.scale);
-        Cic1 cz = cic1(pos[3 * p + 2], geo.off[2], geo.scale);
-        i64 ix[W], iy[W], iz[W];
+    __shared__ double blk[kDcCells];
+    __shared__ int s_ref[3], s_lo[3], s_hi[3];
+    const int tid = threadIdx.x;
+    const i64 base = (i64)blockIdx.x * (kDcLanes * kDcPer);
+    const int Ni = (int)N;
+    double px[kDcPer], py[kDcPer], pz[kDcPer];
+    bool valid[kDcPer];
 #pragma unroll
-        for (int s = 0; s < W; s++) {
-            ix[s] = cg_xlayer(xm, cx.index - g - H + s, N) * ny * pad;
-            iy[s] = wrap(cy.index - g - H + s, N) * pad;
-            iz[s] = wrap(cz.index - g - H + s, N);
+    for (int u = 0; u < kDcPer; u++) {
+        const i64 p = base + tid + (i64)kDcLanes * u;
+        valid[u] = p < n;
+        px[u] = py[u] = pz[u] = 0;
+        if (valid[u]) px[u] = pos[3 * p], py[u] = pos[3 * p + 1], pz[u] = pos[3 * p + 2];
+    }
+    auto cells = [&](int u, int (&cell)[3]) {
+        cell[0] = (int)wrap(cic1(px[u], geo.off[0], geo.scale).index - g, N);
+        cell[1] = (int)wrap(cic1(py[u], geo.off[1], geo.scale).index - g, N);
+        cell[2] = (int)wrap(cic1(pz[u], geo.off[2], geo.scale).index - g, N);
+    };
+    if (tid == 0) {
+        int c0[3];
+        cells(0, c0);
+        for (int d = 0; d < 3; d++) {
+            s_ref[d] = c0[d];
+            s_lo[d] = 0;
+            s_hi[d] = 0;
         }
-        double wx[2] = {cx.w0, cx.w1}, wy[2] = {cy.w0, cy.w1}, wz[2] = {cz.w0, cz.w1};
+    }
+    __syncthreads();
+    const int r0 = s_ref[0], r1 = s_ref[1], r2 = s_ref[2];
+    auto rel = [&](int cell, int ref) {
+        int d = cell - ref;
+        d += d < -(Ni / 2) ? Ni : 0;
+        d -= d >= Ni - Ni / 2 ? Ni : 0;
+        return d;
+    };
+    int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < kDcPer; u++) {
+        if (!valid[u]) continue;
+        int cell[3];
+        cells(u, cell);
+        const int d[3] = {rel(cell[0], r0), rel(cell[1], r1), rel(cell[2], r2)};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            lo[k] = min(lo[k], d[k]);
+            hi[k] = max(hi[k], d[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            lo[k] = min(lo[k], __shfl_xor(lo[k], m));
+            hi[k] = max(hi[k], __shfl_xor(hi[k], m));
+        }
+        if ((tid & 63) == 0) {
+            atomicMin(&s_lo[k], lo[k]);
+            atomicMax(&s_hi[k], hi[k]);
+        }
+    }
+    __syncthreads();
+    // the box: cells lo - H .. hi + 1 + H of every dimension
+    const int l0 = s_lo[0] - H, l1 = s_lo[1] - H, l2 = s_lo[2] - H;
+    const int e0 = s_hi[0] - s_lo[0] + W, e1 = s_hi[1] - s_lo[1] + W, e2 = s_hi[2] - s_lo[2] + W;
+    const bool fits = (i64)e0 * e1 * e2 <= kDcCells && e0 <= Ni && e1 <= Ni && e2 <= Ni;
+    if (fits) {
+        const int ncells = e0 * e1 * e2;
+        for (int i = tid; i < ncells; i += kDcLanes) {
+            const int c = i % e2, b = (i / e2) % e1, a = i / (e2 * e1);
+            const i64 gi = cg_xlayer(xm, wrap((i64)r0 + l0 + a, N), N),
+                      gj = wrap((i64)r1 + l1 + b, N), gk = wrap((i64)r2 + l2 + c, N);
+            blk[i] = mesh[(gi * ny + gj) * pad + gk];
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int u = 0; u < kDcPer; u++) {
+        const i64 p = base + tid + (i64)kDcLanes * u;
+        if (p >= n) continue;
+        const Cic1 cx = cic1(px[u], geo.off[0], geo.scale), cy = cic1(py[u], geo.off[1], geo.scale),
+                   cz = cic1(pz[u], geo.off[2], geo.scale);
+        const double wx[2] = {cx.w0, cx.w1}, wy[2] = {cy.w0, cy.w1}, wz[2] = {cz.w0, cz.w1};
         double val[3] = {0, 0, 0};
+        if (fits) {
+            // entry (s_a, s_b, s_c) of the particle's W^3 cells = cell index - g - H + s
+            const double *q = blk +
+                ((rel((int)wrap(cx.index - g, N), r0) - H - l0) * e1 +
+                 (rel((int)wrap(cy.index - g, N), r1) - H - l1)) * e2 +
+                (rel((int)wrap(cz.index - g, N), r2) - H - l2);
+            gather_force<ORDER>([&](int a, int b, int c) { return q[(a * e1 + b) * e2 + c]; }, wx,
+                                wy, wz, c1, c2, val);
+        } else {
+            i64 ix[W], iy[W], iz[W];
 #pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                double wij = wx[i] * wy[j];
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    double w = wij * wz[k];
-                    int a = H + i, b = H + j, cc = H + k;
-                    double fx, fy, fz;
-                    if (ORDER == 2) {
-                        fx = c1 * (mesh[ix[a + 1] + iy[b] + iz[cc]] - mesh[ix[a - 1] + iy[b] + iz[cc]]);
-                        fy = c1 * (mesh[ix[a] + iy[b + 1] + iz[cc]] - mesh[ix[a] + iy[b - 1] + iz[cc]]);
-                        fz = c1 * (mesh[ix[a] + iy[b] + iz[cc + 1]] - mesh[ix[a] + iy[b] + iz[cc - 1]]);
-                    } else {
-                        fx = c1 * (mesh[ix[a + 1] + iy[b] + iz[cc]] - mesh[ix[a - 1] + iy[b] + iz[cc]]) -
-                             c2 * (mesh[ix[a + 2] + iy[b] + iz[cc]] - mesh[ix[a - 2] + iy[b] + iz[cc]]);
-                        fy = c1 * (mesh[ix[a] + iy[b + 1] + iz[cc]] - mesh[ix[a] + iy[b - 1] + iz[cc]]) -
-                             c2 * (mesh[ix[a] + iy[b + 2] + iz[cc]] - mesh[ix[a] + iy[b - 2] + iz[cc]]);
-                        fz = c1 * (mesh[ix[a] + iy[b] + iz[cc + 1]] - mesh[ix[a] + iy[b] + iz[cc - 1]]) -
-                             c2 * (mesh[ix[a] + iy[b] + iz[cc + 2]] - mesh[ix[a] + iy[b] + iz[cc - 2]]);
-                    }
-                    val[0] += fx * w;
-                    val[1] += fy * w;
-                    val[2] += fz * w;
-                }
+            for (int s = 0; s < W; s++) {
+                ix[s] = cg_xlayer(xm, cx.index - g - H + s, N) * ny * pad;
+                iy[s] = wrap(cy.index - g - H + s, N) * pad;
+                iz[s] = wrap(cz.index - g - H + s, N);
             }
+            gather_force<ORDER>([&](int a, int b, int c) { return mesh[ix[a] + iy[b] + iz[c]]; },
+                                wx, wy, wz, c1, c2, val);
+        }
         if (factor != 1) {
             val[0] *= factor;
             val[1] *= factor;
@@ -309,18 +409,17 @@ __global__ __launch_bounds__(256) void k_gather_kick_direct(const double *__rest
 
 int cgk_gather_kick(cg_ctx *c, const double *pos, double *mom, i64 n, int diff_order,
                     double factor) {
-    int block = 256;
-    i64 blocks = (n + block - 1) / block;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (n <= 0) return 0;
+    const i64 blocks = (n + kDcLanes * kDcPer - 1) / (kDcLanes * kDcPer);
     double dx = c->p.boxsize / (double)c->N;  // interactions.py:2133
     if (diff_order == 2) {
         double c1 = (1.0 / 2) / dx;  // mesh.py:4967
-        hipLaunchKernelGGL(k_gather_kick_direct<2>, dim3((unsigned)blocks), dim3(block), 0,
+        hipLaunchKernelGGL(k_gather_kick_chunks<2>, dim3((unsigned)blocks), dim3(kDcLanes), 0,
                            c->stream, pos, mom, n, c->mesh, c->N, c->ny, c->pad, c->p.nghosts,
                            c->xmap, c->geom_gather, c1, 0.0, factor);
     } else {
         double c1 = (2.0 / 3) / dx, c2 = (1.0 / 12) / dx;  // mesh.py:4973-4977
-        hipLaunchKernelGGL(k_gather_kick_direct<4>, dim3((unsigned)blocks), dim3(block), 0,
+        hipLaunchKernelGGL(k_gather_kick_chunks<4>, dim3((unsigned)blocks), dim3(kDcLanes), 0,
                            c->stream, pos, mom, n, c->mesh, c->N, c->ny, c->pad, c->p.nghosts,
                            c->xmap, c->geom_gather, c1, c2, factor);
     }
