@@ -38,7 +38,7 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 XGMI_LINK_GBS_DIR = 76.8     # one xGMI link, one direction (153.6 GB/s bidirectional; 7 links)
-PMC_FILE = 'profiles/r04_pmc_hbm_traffic.json'
+PMC_FILE = 'profiles/r05_pmc_hbm_traffic.json'
 
 WORKLOADS = {
     # name: (particles, gridsize)

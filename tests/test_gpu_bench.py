@@ -105,6 +105,18 @@ def test_bench_eight_ranks_at_config2_size():
     assert d['per_gpu']['particles'] == 256**3//8
 
 
+def test_bench_config4_shape_on_one_gpu():
+    """--workload c4_nonlinnu_*: BASELINE configs[4]'s shape (param/example_nonlinnu:36-45) through
+    Component.drift_sort / gravity() / apply_Δmom on one GPU — three mesh solves per long kick,
+    a phase with its moved bytes per interaction."""
+    d = run_workload('c4_nonlinnu_tiny')
+    assert d['interactions'] == ['p3m: matter <- matter', 'pm: matter <- neutrino',
+                                 'pm: neutrino <- matter, neutrino']
+    assert set(d['phases']) == {'drift_sort', 'short_range'} | {'long: ' + s for s in d['interactions']}
+    assert all(v['ms'] > 0 and v['moved_GB'] > 0 for v in d['phases'].values())
+    assert d['config']['particles'] == 32**3 and d['config']['fluid_gridsize'] == 16
+
+
 def test_bench_weak_and_dry_links():
     """--weak: the per-GPU work fixed (2^25 particles, ~1.3e8 cells per GPU); --dry-links: the
     transposes replaced by device sleeps at one xGMI link's rate, the pipelined schedule of the

@@ -251,6 +251,8 @@ COMPONENT_CASES = [
     # whole runs of the time loop (a_begin -> 1, ~140 base steps) against the reference's
     # (power-of-two meshes: the transposing FFT's sizes)
     ('traj', 'traj_pm_n8_g16'), ('traj', 'traj_p3m_n8_g32'),
+    # the clustered box with five rungs populated: a slab holds most of a clump
+    ('traj', 'traj_p3m_n16_g32_clustered'),
 ]
 
 

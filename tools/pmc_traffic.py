@@ -27,7 +27,7 @@ BENCH_KEYS = {  # bench.py kernel names -> demangled prefixes of the device kern
     'gather_kick': ['k_gather_kick_tiled<2, 16, 1>', 'k_gather_kick_tiled<2, 16, 0>'],
     'deposit': ['k_deposit_cic_pull<16, false>'],
     'fft_x_fused_kspace': ['k_fft_strided_h<10, 256, 2>', 'k_fft_strided_p<10, 512, 2, 8>'],
-    'sr_sweep': ['k_sr_sweep_cells'],
+    'sr_sweep': ['k_sr_sweep_blocks', 'k_sr_sweep_cells'],
 }
 
 

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Records the round's measurements on the GPU box into gpurun_out/profiles_new/ (copied into
-# profiles/ afterwards):  tools/record_profiles.sh r04 <commit>
+# profiles/ afterwards):  tools/record_profiles.sh r05 <commit>
 # One-liners a driver can reproduce are listed in profiles/README.md.
 set -u
-TAG=${1:-r04}; COMMIT=${2:-unknown}; MODE=${3:-full}   # quick: kernel statistics, HBM traffic and the default line only
+TAG=${1:-r05}; COMMIT=${2:-unknown}; MODE=${3:-full}   # quick: kernel statistics, HBM traffic and the default line only
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_new; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -47,18 +47,34 @@ python tools/sr_dense_check.py scan big time 2>&1 | grep -v amdgpu.ids > $OUT/${
 (SR_DIST=clustered $R/tools/pmc_srd.sh 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_pmc_sr_dense.txt)
 python tools/sr_dense_time.py clustered 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_sr_dense_phases.txt
 CONCEPT_GPU_SR_DENSE_MIN=0 python tools/sr_dense_time.py clustered 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_sr_dense_phases.txt
-# (the stand-alone probes are built here when the tree does not hold them: a fresh clone)
-mkdir -p tools/_variants
-[ -x tools/mall_probe ] || hipcc --offload-arch=gfx950 -O3 -o tools/mall_probe tools/mall_probe.cpp
-[ -x tools/xcd_handover_probe ] || hipcc --offload-arch=gfx950 -O3 -o tools/xcd_handover_probe tools/xcd_handover_probe.cpp
-./tools/mall_probe > $OUT/${TAG}_mall_probe.txt 2>&1
-# a layer handed from the z pass to the y pass inside an XCD (data movement only): times and HBM-side counters
-(for r in 8 4 2; do ./tools/xcd_handover_probe 1024 $r 2; done; ./tools/xcd_handover_probe 1024 4 1; ./tools/xcd_handover_probe 1024 4 0; bash tools/pmc_handover.sh 2
- for a in 16 8 4; do
-   hipcc --offload-arch=gfx950 -O3 -DCOL_A=$a -o tools/_variants/xcd_col$a tools/xcd_handover_probe.cpp
-   echo "--- column question, COL_A=$a"; ./tools/_variants/xcd_col$a column 2
-   for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && rm -rf /tmp/hc && rocprofv3 --kernel-trace --pmc $c -d /tmp/hc -- $R/tools/_variants/xcd_col$a column 2 > /tmp/hc.log 2>&1; python $R/tools/rocprof_summary.py --pmc /tmp/hc | grep -A1 "k_column\|k_tiles\|k_rows" | grep -v "^--"); done
- done) 2>&1 | grep -v amdgpu.ids | cut -c1-160 > $OUT/${TAG}_xcd_handover_probe.txt
+# 7. configs[4]'s shape on one GPU (round 5): the line and its kernel statistics
+python bench.py --workload c4_nonlinnu_1gpu --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/${TAG}_bench_c4_nonlinnu_1gpu.json
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/stats_c4 -- python $R/bench.py --workload c4_nonlinnu_1gpu --steps 3 --warmup 1 > $OUT/stats_c4.log 2>&1)
+python tools/rocprof_summary.py $OUT/stats_c4 $OUT/${TAG}_rocprof_kernel_stats_c4.txt > /dev/null; rm -rf $OUT/stats_c4
+# 8. the short-range sweep: 2 x 2 tiles per workgroup against one tile per workgroup, and what
+# the sweep costs apart from its pair tests (a build whose pair loop is empty), one box
+python tools/variant_patch.py sr_tiles '    if (m >= 2) {
+        const unsigned nb = (m + 1) / 2;' '    if (false) {
+        const unsigned nb = (m + 1) / 2;' > /dev/null 2>&1
+python tools/variant_patch.py sr_nopairs '    int row = a;
+    for (; row + 2 * S <= b; row += 2 * S)' '    int row = a;
+    ax += 1e-300 * (double)(b - a); return;
+    for (; row + 2 * S <= b; row += 2 * S)' > /dev/null 2>&1
+python tools/variant_patch.py sr_tiles_nopairs '    if (m >= 2) {
+        const unsigned nb = (m + 1) / 2;' '    if (false) {
+        const unsigned nb = (m + 1) / 2;' '    int row = a;
+    for (; row + 2 * S <= b; row += 2 * S)' '    int row = a;
+    ax += 1e-300 * (double)(b - a); return;
+    for (; row + 2 * S <= b; row += 2 * S)' > /dev/null 2>&1
+(for rep in 1 2; do for v in "" sr_tiles sr_nopairs sr_tiles_nopairs; do
+   if [ -n "$v" ]; then export CONCEPT_GPU_LIB=$R/tools/_variants/$v.so; else unset CONCEPT_GPU_LIB; fi
+   python tools/sr_dense_time.py uniform 2>&1 | grep -v amdgpu.ids
+ done; done; unset CONCEPT_GPU_LIB) > $OUT/${TAG}_sr_blocks_ab.txt
+(SR_DIST=uniform $R/tools/pmc_srd.sh 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_pmc_sr_blocks.txt)
+# 9. the 1-rank values an N-rank run of the driver's command compares its sample with
+cp .bench_verify/ns_256M_1024_seed1_thermal0.2_steps25.json $OUT/${TAG}_bench_verify_ns_256M_1024_seed1_thermal0.2_steps25.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
+cp .bench_verify/ns_256M_1024_seed1_thermal0.2_steps7.json $OUT/${TAG}_bench_verify_ns_256M_1024_seed1_thermal0.2_steps7.json 2>/dev/null
 # heavy tiles first (cgk_tile_order) against the plain walk, one process
 python tools/fused_order_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_tile_order_ab.txt
 rm -rf $OUT/stats $OUT/pmc_f $OUT/pmc_w $OUT/stats_p3m $OUT/pmc_sr
