@@ -399,34 +399,60 @@ VERIFY_DIR = os.path.join(REPO, '.bench_verify')
 VERIFY_COMMITTED = 'profiles/r05_bench_verify_{key}.json'
 
 
-def global_particles(torch, args, n_p, L, cell, mass, dt, dev, rank=0, world=1):
-    """(pos, mom, ids) of the particles whose identifiers lie in the chunks rank, rank + world,
-    ... of ID_CHUNK identifiers: uniform positions, Maxwellian momenta (--thermal), each chunk
-    from a generator seeded by (seed, chunk).  Who generates a particle does not matter: the
-    owner gets it through exchange()."""
+def global_particles(torch, args, n_p, L, cell, mass, dt, dev, rank=0, world=1, mesh=None):
+    """(pos, mom, ids) of this rank's share of the box: uniform positions, Maxwellian momenta
+    (--thermal), each chunk of ID_CHUNK identifiers from a generator seeded by (seed, chunk) —
+    the same particles whatever the number of ranks.  With a slab `mesh` (N > 1 ranks) every
+    rank walks ALL chunks and keeps the particles its slab owns (cg_owner_rank, the exchange's own
+    rule): nobody has to be shipped at set-up; without one, the chunks rank, rank + world, ..."""
     sigma = args.thermal/3**0.5*cell*mass/dt if args.thermal > 0 else 0.0
     top = float(torch.nextafter(torch.tensor(L, dtype=torch.float64),
                                 torch.tensor(0.0, dtype=torch.float64)))
     nchunks = (n_p + ID_CHUNK - 1)//ID_CHUNK
-    mine = list(range(rank, nchunks, world))
-    m_total = sum(min(ID_CHUNK, n_p - c*ID_CHUNK) for c in mine)
-    pos = torch.empty((m_total, 3), dtype=torch.float64, device=dev)
-    mom = torch.zeros((m_total, 3), dtype=torch.float64, device=dev)
-    ids = torch.empty(m_total, dtype=torch.int64, device=dev)
-    at = 0
+    by_owner = mesh is not None and world > 1
+    mine = range(nchunks) if by_owner else range(rank, nchunks, world)
+    if not by_owner:
+        # the count is known: write the chunks in place (2^30 particles leave no room for a copy)
+        m_total = sum(min(ID_CHUNK, n_p - c*ID_CHUNK) for c in mine)
+        pos = torch.empty((m_total, 3), dtype=torch.float64, device=dev)
+        mom = torch.zeros((m_total, 3), dtype=torch.float64, device=dev)
+        ids = torch.empty(m_total, dtype=torch.int64, device=dev)
+        at = 0
+        for c in mine:
+            m = min(ID_CHUNK, n_p - c*ID_CHUNK)
+            gen = torch.Generator(device=dev).manual_seed(1000003*args.seed + c)
+            x = torch.rand((ID_CHUNK, 3), dtype=torch.float64, device=dev, generator=gen)
+            pos[at:at + m] = x[:m].mul_(L).clamp_(min=0.0, max=top)
+            if sigma:
+                v = torch.randn((ID_CHUNK, 3), dtype=torch.float64, device=dev, generator=gen)
+                mom[at:at + m] = v[:m].mul_(sigma)
+            ids[at:at + m] = torch.arange(c*ID_CHUNK, c*ID_CHUNK + m, device=dev)
+            at += m
+        return pos, mom, ids
+    P, M, I = [], [], []
     for c in mine:
         m = min(ID_CHUNK, n_p - c*ID_CHUNK)
         gen = torch.Generator(device=dev).manual_seed(1000003*args.seed + c)
         # (always a whole chunk: how a generator's stream maps onto the elements may depend on
         # the tensor's size)
         x = torch.rand((ID_CHUNK, 3), dtype=torch.float64, device=dev, generator=gen)
-        pos[at:at + m] = x[:m].mul_(L).clamp_(min=0.0, max=top)
+        x = x[:m].mul_(L).clamp_(min=0.0, max=top)
+        v = None
         if sigma:
             v = torch.randn((ID_CHUNK, 3), dtype=torch.float64, device=dev, generator=gen)
-            mom[at:at + m] = v[:m].mul_(sigma)
-        ids[at:at + m] = torch.arange(c*ID_CHUNK, c*ID_CHUNK + m, device=dev)
-        at += m
-    return pos, mom, ids
+            v = v[:m].mul_(sigma)
+        ids = torch.arange(c*ID_CHUNK, c*ID_CHUNK + m, device=dev)
+        if by_owner:
+            keep = mesh.owner_rank(x.contiguous()) == rank
+            x, ids = x[keep], ids[keep]
+            v = v[keep] if v is not None else None
+        P.append(x)
+        M.append(v if v is not None else torch.zeros_like(x))
+        I.append(ids)
+    if not P:
+        z = torch.zeros((0, 3), dtype=torch.float64, device=dev)
+        return z, z.clone(), torch.zeros(0, dtype=torch.int64, device=dev)
+    return torch.cat(P).contiguous(), torch.cat(M).contiguous(), torch.cat(I).contiguous()
 
 
 def verify_key(args, name, steps_total):
@@ -441,7 +467,8 @@ def verify_replay(torch, args, domain, name, n_p, N, L, dev, rank, world, steps_
     identifiers are multiples of n_p / VERIFY_SAMPLES.  Untimed."""
     from concept_amd.distributed import ParticleStore, RegionParticles, pm_step_regions
     mass, G, dt = 1.0, 1.0, 1e-4
-    pos, mom, ids = global_particles(torch, args, n_p, L, L/N, mass, dt, dev, rank, world)
+    pos, mom, ids = global_particles(torch, args, n_p, L, L/N, mass, dt, dev, rank, world,
+                                     mesh=domain.mesh)
     parts = ParticleStore(domain, pos, mom, ids, slack=1.15)
     del pos, mom, ids
     parts.exchange()
@@ -505,10 +532,11 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
                                          pm_kick, pm_step_regions)
     dom = SlabDomain(N, L, device=dev)
     # the box is a function of (seed, global identifier): the same particles on any number of
-    # ranks (each rank makes every world-th chunk of identifiers, exchange() takes them home)
+    # ranks (every rank walks all chunks of identifiers and keeps what its slab owns)
     cell = L/N
     mass, G, dt = 1.0, 1.0, 1e-4
-    pos, mom, _ = global_particles(torch, args, n_p, L, cell, mass, dt, dev, rank, world)
+    pos, mom, _ = global_particles(torch, args, n_p, L, cell, mass, dt, dev, rank, world,
+                                   mesh=dom.mesh)
     parts = DistributedParticles(dom, pos, mom, None, slack=1.15)
     del pos, mom
     parts.exchange()
@@ -632,7 +660,7 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
     # The check this line carries: the same step sequence once more, untimed,
     # with the identifiers travelling, and its id-keyed sample against the 1-rank values
     verify = None
-    if not args.no_verify and not args.weak and fused:
+    if not args.no_verify and not args.weak and fused and not args.dry_links:
         import numpy as np
         del parts
         torch.cuda.empty_cache()
@@ -1083,7 +1111,9 @@ def run_c4(args, torch, dev, size=512, steps=None, warmup=None):
     # bytes each phase must move: N_p particles, G3 = 1024^3-type mesh of the
     # P3M interaction, G1 = 256^3-type mesh of the PM interactions and the fluid's grids
     Np, G3, G1 = n, N3**3, N1**3
-    moved = {'drift_sort': 96*Np + 16*Np,                         # pos + mom read and written, ids
+    # (drift_sort: pos + mom read and written, and the Component's other columns — identifiers,
+    # populated order, Δmom, the two rung arrays — read and written at their new places)
+    moved = {'drift_sort': 96*Np + (16 + 16 + 48 + 4)*Np,
              'short_range': 2*24*Np + 8*Np + 72*Np + 72*Np}       # cell list, sweep, Δmom apply
     for ph, it in zip(PH[2:], long_range):
         rec_p = [c for c in it.receivers if c.representation == 'particles']
@@ -1521,7 +1551,8 @@ def run_single(args, torch, dev, rank=0):
             'survey_8d_GB': round(credit/1e9, 2)}
     result['phases'] = phases
     del pos, mom, pos2, mom2
-    if fused and args.dist == 'uniform' and not args.no_verify and not args.weak:
+    if fused and args.dist == 'uniform' and not args.no_verify and not args.weak \
+            and n_p <= 2**29:   # (the replay keeps the identifiers in two stores: ~300 B per particle)
         # the values an N-rank run of this command is checked against (its `verify` block):
         # the same step sequence once more, untimed, with the identifiers travelling
         import types

@@ -937,19 +937,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
         prep.mom2_out[8 * (i64)blockIdx.x + (threadIdx.x >> 6)] = __hiloint2double(m2_hi, m2_lo);
 }
 
-// the wavefronts' partial sums added in a fixed order (1024 strided sums, then a tree)
-__global__ __launch_bounds__(1024) void k_sum_partials(const double *__restrict__ part, i64 n,
-                                                       double *__restrict__ out) {
-    __shared__ double red[1024];
+// the wavefronts' partial sums added in a fixed order: 256 workgroups each sum a slice (256 strided
+// sums, then a tree), one workgroup sums the 256 results the same way
+__global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__ part, i64 n,
+                                                      double *__restrict__ out) {
+    __shared__ double red[256];
+    const i64 per = (n + gridDim.x - 1) / gridDim.x;
+    const i64 lo = (i64)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
     double s = 0;
-    for (i64 i = threadIdx.x; i < n; i += 1024) s += part[i];
+    for (i64 i = lo + threadIdx.x; i < hi; i += 256) s += part[i];
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int h = 512; h > 0; h >>= 1) {
+    for (int h = 128; h > 0; h >>= 1) {
         if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = red[0];
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
 template <int ORDER, int T>
@@ -1012,7 +1015,7 @@ int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
         prep_args.emig_rows_cap = c->emig_rows_cap;
         if (c->emig_rows) CG_HIP(hipMemsetAsync(c->emig_rows_count, 0, 4, c->stream));
         if (c->mom2_sum_out) {
-            const size_t need = sizeof(double) * 8 * ((size_t)c->ntiles + (c->ntiles / 8 + 8));
+            const size_t need = sizeof(double) * (8 * ((size_t)c->ntiles + (c->ntiles / 8 + 8)) + 256);
             if (need > c->mom2_partial_bytes) {
                 CG_HIP(hipStreamSynchronize(c->stream));
                 (void)hipFree(c->mom2_partial);
@@ -1061,8 +1064,13 @@ int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
     CG_LAUNCH_CHECK();
     if (fs && c->mom2_sum_out) {
         const i64 nparts = 8 * ((i64)c->ntiles + (i64)tile_order_args(c).cap);
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, c->stream, c->mom2_partial,
-                           nparts, c->mom2_sum_out);
+        // (the first 256 doubles of the partials' buffer past its nparts entries take stage one)
+        double *stage = c->mom2_partial + nparts;
+        hipLaunchKernelGGL(k_sum_partials, dim3(256), dim3(256), 0, c->stream, c->mom2_partial,
+                           nparts, stage);
+        CG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, stage, (i64)256,
+                           c->mom2_sum_out);
         CG_LAUNCH_CHECK();
     }
     c->prep_valid = prepare != 0;
