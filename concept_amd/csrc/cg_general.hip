@@ -362,59 +362,209 @@ __device__ __forceinline__ int wrap32(int a, int n) {
     return a >= n ? a - n : a;
 }
 
+// ---------------------------------------------------------------------------
+// Deposit and scalar gather of order 1-4 with lattice shifts (mesh.py:1512-1636, :376-459),
+// round 5: through LDS boxes, like cg_deposit_cic / cg_gather_kick (cg_mesh_kernels.hip).  A
+// workgroup takes 2048 consecutive particles, finds the box of their stencils' first cells
+// relative to the first particle's (the periodic seam is no seam) and, when the box with the
+// stencil's width fits 4096 cells of LDS, accumulates there and adds the box to the mesh once — one
+// device-scope FP64 atomic (memory-side on MI355X) per touched cell instead of ORDER^3 per
+// particle — or copies the box of the field in before the gather.  Particles in tile order of
+// ANY mesh are compact enough; a chunk that is spread out takes the direct accesses.  Index and
+// weight arithmetic unchanged (the reference's expressions, set_weights above).
+// ---------------------------------------------------------------------------
+constexpr int kGcPer = 4, kGcLanes = 512, kGcCells = 4096;
+
+// the box of a chunk: s_ref = first particle's first cell, s_lo / s_hi = extremes of the others'
+// first cells relative to it (in [-N/2, N/2) through the seam); called by all lanes
 template <int ORDER>
-__global__ __launch_bounds__(256) void k_deposit_general(const double *__restrict__ pos, i64 n,
-                                                         double *__restrict__ mesh, int N, i64 ny,
-                                                         i64 pad, int g, XMap xm, CicGeom geo,
-                                                         double contribution) {
+struct GcBox {
+    int r[3], l[3], e[3];
+    bool fits;
+};
+__device__ __forceinline__ int gc_rel(int cell, int ref, int N) {
+    int d = cell - ref;
+    d += d < -(N / 2) ? N : 0;
+    d -= d >= N - N / 2 ? N : 0;
+    return d;
+}
+template <int ORDER>
+__device__ __forceinline__ GcBox<ORDER> gc_box(const int (&cell)[kGcPer][3],
+                                               const bool (&valid)[kGcPer], int N, int *s_ref,
+                                               int *s_lo, int *s_hi) {
+    const int tid = threadIdx.x;
+    if (tid == 0) {  // (the chunk's first particle exists)
+        for (int d = 0; d < 3; d++) {
+            s_ref[d] = cell[0][d];
+            s_lo[d] = 0;
+            s_hi[d] = 0;
+        }
+    }
+    __syncthreads();
+    GcBox<ORDER> B;
+    for (int d = 0; d < 3; d++) B.r[d] = s_ref[d];
+    int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < kGcPer; u++) {
+        if (!valid[u]) continue;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const int v = gc_rel(cell[u][d], B.r[d], N);
+            lo[d] = min(lo[d], v);
+            hi[d] = max(hi[d], v);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            lo[d] = min(lo[d], __shfl_xor(lo[d], m));
+            hi[d] = max(hi[d], __shfl_xor(hi[d], m));
+        }
+        if ((tid & 63) == 0) {
+            atomicMin(&s_lo[d], lo[d]);
+            atomicMax(&s_hi[d], hi[d]);
+        }
+    }
+    __syncthreads();
+    for (int d = 0; d < 3; d++) {
+        B.l[d] = s_lo[d];
+        B.e[d] = s_hi[d] - s_lo[d] + ORDER;
+    }
+    B.fits = (i64)B.e[0] * B.e[1] * B.e[2] <= kGcCells && B.e[0] <= N && B.e[1] <= N && B.e[2] <= N;
+    return B;
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(kGcLanes) void k_deposit_general(const double *__restrict__ pos, i64 n,
+                                                              double *__restrict__ mesh, int N,
+                                                              i64 ny, i64 pad, int g, XMap xm,
+                                                              CicGeom geo, double contribution) {
 #pragma clang fp contract(off)
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    __shared__ double blk[kGcCells];
+    __shared__ int s_ref[3], s_lo[3], s_hi[3];
+    const int tid = threadIdx.x;
+    const i64 base = (i64)blockIdx.x * (kGcLanes * kGcPer);
+    double px[kGcPer][3];
+    int cell[kGcPer][3];
+    bool valid[kGcPer];
+#pragma unroll
+    for (int u = 0; u < kGcPer; u++) {
+        const i64 p = base + tid + (i64)kGcLanes * u;
+        valid[u] = p < n;
+        double w[4];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            px[u][d] = valid[u] ? pos[3 * p + d] : 0.0;
+            cell[u][d] = wrap32(set_weights<ORDER>((px[u][d] - geo.off[d]) * geo.scale, w) - g, N);
+        }
+    }
+    const GcBox<ORDER> B = gc_box<ORDER>(cell, valid, N, s_ref, s_lo, s_hi);
+    const int ncells = B.fits ? B.e[0] * B.e[1] * B.e[2] : 0;
+    for (int i = tid; i < ncells; i += kGcLanes) blk[i] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int u = 0; u < kGcPer; u++) {
+        if (!valid[u]) continue;
         double wx[4], wy[4], wz[4];
-        int ii = set_weights<ORDER>((pos[3 * p + 0] - geo.off[0]) * geo.scale, wx) - g;
-        int jj = set_weights<ORDER>((pos[3 * p + 1] - geo.off[1]) * geo.scale, wy) - g;
-        int kk = set_weights<ORDER>((pos[3 * p + 2] - geo.off[2]) * geo.scale, wz) - g;
+        const int ii = set_weights<ORDER>((px[u][0] - geo.off[0]) * geo.scale, wx) - g;
+        const int jj = set_weights<ORDER>((px[u][1] - geo.off[1]) * geo.scale, wy) - g;
+        const int kk = set_weights<ORDER>((px[u][2] - geo.off[2]) * geo.scale, wz) - g;
+        const int a0 = gc_rel(cell[u][0], B.r[0], N) - B.l[0],
+                  b0 = gc_rel(cell[u][1], B.r[1], N) - B.l[1],
+                  c0 = gc_rel(cell[u][2], B.r[2], N) - B.l[2];
 #pragma unroll
         for (int i = 0; i < ORDER; i++) {
             double weight_i = wx[i];
             weight_i *= contribution;  // apply_factor = True
-            const i64 ri = cg_xlayer(xm, (i64)(ii + i), N) * ny;
+            const i64 ri = B.fits ? 0 : cg_xlayer(xm, (i64)(ii + i), N) * ny;
 #pragma unroll
             for (int j = 0; j < ORDER; j++) {
-                double wij = weight_i * wy[j];
-                double *row = mesh + (ri + wrap32(jj + j, N)) * pad;
+                const double wij = weight_i * wy[j];
+                double *row = B.fits ? blk + ((a0 + i) * B.e[1] + (b0 + j)) * B.e[2] + c0
+                                     : mesh + (ri + wrap32(jj + j, N)) * pad;
 #pragma unroll
                 for (int k = 0; k < ORDER; k++)
-                    unsafeAtomicAdd(row + wrap32(kk + k, N), ORDER == 1 ? weight_i : wij * wz[k]);
+                    unsafeAtomicAdd(row + (B.fits ? k : wrap32(kk + k, N)),
+                                    ORDER == 1 ? weight_i : wij * wz[k]);
             }
         }
+    }
+    if (!B.fits) return;  // (uniform)
+    __syncthreads();
+    for (int i = tid; i < ncells; i += kGcLanes) {
+        const double v = blk[i];
+        if (v == 0) continue;
+        const int c = i % B.e[2], b = (i / B.e[2]) % B.e[1], a = i / (B.e[2] * B.e[1]);
+        // (cell index before the wrap in [-N, 2N): |rel| <= N/2, extent <= N)
+        const i64 gi = cg_xlayer(xm, (i64)wrap32(wrap32(B.r[0] + B.l[0], N) + a, N), N);
+        const int gj = wrap32(wrap32(B.r[1] + B.l[1], N) + b, N),
+                  gk = wrap32(wrap32(B.r[2] + B.l[2], N) + c, N);
+        unsafeAtomicAdd(mesh + (gi * ny + gj) * pad + gk, v);
     }
 }
 
 template <int ORDER>
-__global__ __launch_bounds__(256) void k_gather_scalar(const double *__restrict__ pos,
-                                                       double *__restrict__ mom, i64 n, int dim,
-                                                       const double *__restrict__ mesh, int N,
-                                                       i64 ny, i64 pad, int g, XMap xm,
-                                                       CicGeom geo, double factor) {
+__global__ __launch_bounds__(kGcLanes) void k_gather_scalar(const double *__restrict__ pos,
+                                                            double *__restrict__ mom, i64 n,
+                                                            int dim,
+                                                            const double *__restrict__ mesh, int N,
+                                                            i64 ny, i64 pad, int g, XMap xm,
+                                                            CicGeom geo, double factor) {
 #pragma clang fp contract(off)
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    __shared__ double blk[kGcCells];
+    __shared__ int s_ref[3], s_lo[3], s_hi[3];
+    const int tid = threadIdx.x;
+    const i64 base = (i64)blockIdx.x * (kGcLanes * kGcPer);
+    double px[kGcPer][3];
+    int cell[kGcPer][3];
+    bool valid[kGcPer];
+#pragma unroll
+    for (int u = 0; u < kGcPer; u++) {
+        const i64 p = base + tid + (i64)kGcLanes * u;
+        valid[u] = p < n;
+        double w[4];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            px[u][d] = valid[u] ? pos[3 * p + d] : 0.0;
+            cell[u][d] = wrap32(set_weights<ORDER>((px[u][d] - geo.off[d]) * geo.scale, w) - g, N);
+        }
+    }
+    const GcBox<ORDER> B = gc_box<ORDER>(cell, valid, N, s_ref, s_lo, s_hi);
+    if (B.fits) {
+        const int ncells = B.e[0] * B.e[1] * B.e[2];
+        for (int i = tid; i < ncells; i += kGcLanes) {
+            const int c = i % B.e[2], b = (i / B.e[2]) % B.e[1], a = i / (B.e[2] * B.e[1]);
+            const i64 gi = cg_xlayer(xm, (i64)wrap32(wrap32(B.r[0] + B.l[0], N) + a, N), N);
+            const int gj = wrap32(wrap32(B.r[1] + B.l[1], N) + b, N),
+                      gk = wrap32(wrap32(B.r[2] + B.l[2], N) + c, N);
+            blk[i] = mesh[(gi * ny + gj) * pad + gk];
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int u = 0; u < kGcPer; u++) {
+        const i64 p = base + tid + (i64)kGcLanes * u;
+        if (p >= n) continue;
         double wx[4], wy[4], wz[4];
-        int ii = set_weights<ORDER>((pos[3 * p + 0] - geo.off[0]) * geo.scale, wx) - g;
-        int jj = set_weights<ORDER>((pos[3 * p + 1] - geo.off[1]) * geo.scale, wy) - g;
-        int kk = set_weights<ORDER>((pos[3 * p + 2] - geo.off[2]) * geo.scale, wz) - g;
+        const int ii = set_weights<ORDER>((px[u][0] - geo.off[0]) * geo.scale, wx) - g;
+        const int jj = set_weights<ORDER>((px[u][1] - geo.off[1]) * geo.scale, wy) - g;
+        const int kk = set_weights<ORDER>((px[u][2] - geo.off[2]) * geo.scale, wz) - g;
+        const int a0 = gc_rel(cell[u][0], B.r[0], N) - B.l[0],
+                  b0 = gc_rel(cell[u][1], B.r[1], N) - B.l[1],
+                  c0 = gc_rel(cell[u][2], B.r[2], N) - B.l[2];
         double value = 0;
 #pragma unroll
         for (int i = 0; i < ORDER; i++) {
-            const i64 ri = cg_xlayer(xm, (i64)(ii + i), N) * ny;
+            const i64 ri = B.fits ? 0 : cg_xlayer(xm, (i64)(ii + i), N) * ny;
 #pragma unroll
             for (int j = 0; j < ORDER; j++) {
-                double wij = wx[i] * wy[j];
-                const double *row = mesh + (ri + wrap32(jj + j, N)) * pad;
+                const double wij = wx[i] * wy[j];
+                const double *row = B.fits ? blk + ((a0 + i) * B.e[1] + (b0 + j)) * B.e[2] + c0
+                                           : mesh + (ri + wrap32(jj + j, N)) * pad;
 #pragma unroll
                 for (int k = 0; k < ORDER; k++)
-                    value += row[wrap32(kk + k, N)] * (ORDER == 1 ? 1.0 : wij * wz[k]);
+                    value += row[B.fits ? k : wrap32(kk + k, N)] * (ORDER == 1 ? 1.0 : wij * wz[k]);
             }
         }
         if (factor != 1) value *= factor;  // mesh.py:456-458
@@ -575,9 +725,10 @@ int cgk_fluid_kick(cg_ctx *c, double *J, const double *rho, const double *P, int
 int cgk_deposit_general(cg_ctx *c, const double *pos, i64 n, double contribution, int order,
                         const CicGeom &geo) {
     if (n == 0) return 0;
-    CG_ORDER_SWITCH(order, k_deposit_general, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream,
-                    pos, n, c->mesh, (int)c->N, c->ny, c->pad, c->p.nghosts, c->xmap, geo,
-                    contribution)
+    CG_ORDER_SWITCH(order, k_deposit_general,
+                    dim3((unsigned)((n + kGcLanes * kGcPer - 1) / (kGcLanes * kGcPer))),
+                    dim3(kGcLanes), 0, c->stream, pos, n, c->mesh, (int)c->N, c->ny, c->pad,
+                    c->p.nghosts, c->xmap, geo, contribution)
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -585,9 +736,10 @@ int cgk_deposit_general(cg_ctx *c, const double *pos, i64 n, double contribution
 int cgk_gather_scalar(cg_ctx *c, const double *pos, double *mom, i64 n, int dim, int order,
                       const CicGeom &geo, double factor) {
     if (n == 0) return 0;
-    CG_ORDER_SWITCH(order, k_gather_scalar, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream,
-                    pos, mom, n, dim, c->mesh, (int)c->N, c->ny, c->pad, c->p.nghosts, c->xmap, geo,
-                    factor)
+    CG_ORDER_SWITCH(order, k_gather_scalar,
+                    dim3((unsigned)((n + kGcLanes * kGcPer - 1) / (kGcLanes * kGcPer))),
+                    dim3(kGcLanes), 0, c->stream, pos, mom, n, dim, c->mesh, (int)c->N, c->ny,
+                    c->pad, c->p.nghosts, c->xmap, geo, factor)
     CG_LAUNCH_CHECK();
     return 0;
 }
