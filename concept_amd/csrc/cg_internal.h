@@ -142,8 +142,8 @@ struct cg_ctx {
     unsigned tile_order_cap = 0;
     unsigned *tile_order_seen = nullptr;  // pinned: length of the list of the last build done
     bool tile_order_on = false;          // list and bytes of one build are there
-    int tile_order_mode = -1;            // CONCEPT_GPU_TILE_ORDER: 0 off, 1 on (default)
-    unsigned tile_order_floor = 1536;    // CONCEPT_GPU_TILE_ORDER_MIN
+    int tile_order_mode = -1;            // from CONCEPT_GPU_TILE_ORDER_MIN: 0 off, 1 on, 2 also on small boxes
+    unsigned tile_order_floor = 1536;    // |CONCEPT_GPU_TILE_ORDER_MIN|
     const void *tile_order_src[2] = {nullptr, nullptr};  // (start, count) it was made from
     size_t scan_tmp_bytes = 0;
     void *sr_tmp = nullptr;  // short-range cell-list counters

@@ -199,7 +199,7 @@ int cg_gather_kick_drift_scatter(cg_ctx *ctx, const double *pos_in, const double
  * mean) particles; at most an eighth of the tiles) of the populations they are given by falling
  * population (in 61 classes); the tile kernels run those first, dealt out to the XCDs in turn,
  * and the walk behind them skips them; the gather-kick of the same tables takes the list over.
- * Results do not depend on it.  CONCEPT_GPU_TILE_ORDER=0 keeps the plain walk.
+ * Results do not depend on it.  CONCEPT_GPU_TILE_ORDER_MIN=0 keeps the plain walk.
  * cg_tile_order_read copies the present list to the host (at most `capacity` tiles) and
  * reports its length; *n_heavy = -1 when no list is in use (switched off, or fewer than 4096
  * tiles). */

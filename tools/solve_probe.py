@@ -1,5 +1,6 @@
-"""Time cg_poisson_solve by itself at 1024^3 (HIP events around 10 solves), for A/B runs with the
-environment switches of cg_fft.hip (CONCEPT_GPU_FFT_CHUNK, CONCEPT_GPU_FFT_STREAMS, ...)."""
+"""Time cg_poisson_solve by itself at 1024^3 (HIP events around 10 solves), for A/B runs of
+variant builds (tools/variant_patch.py with VAR_SRC=cg_fft.hip, loaded through CONCEPT_GPU_LIB)
+or of CONCEPT_GPU_FFT / CONCEPT_GPU_FFT_SPLIT."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from concept_amd.mesh import PotentialMesh
