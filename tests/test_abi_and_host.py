@@ -286,3 +286,43 @@ initial_conditions = '/tmp/ic'
         commons.load_params({'gadget_snapshot_params': {'snapformat': 3}})
     p = commons.load_params({})
     assert p.output_dirs == {} and p.snapshot_times == {'a': (), 't': ()}
+
+
+def test_bench_box_is_a_function_of_seed_and_identifier(tmp_path, monkeypatch):
+    """bench.py's particles: whichever ranks make the chunks of identifiers,
+    the union is the 1-rank box, row by row; and the 1-rank values an N-rank run compares its
+    sample with survive the round trip through their file bit for bit."""
+    import argparse
+    import sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    monkeypatch.setattr(bench, 'ID_CHUNK', 4096)
+    args = argparse.Namespace(seed=3, thermal=0.2)
+    n_p, L = 5*4096 + 17, 64.0
+    dev = torch.device('cpu')
+    one = bench.global_particles(torch, args, n_p, L, 1.0, 1.0, 1e-4, dev)
+    assert one[0].shape == (n_p, 3) and torch.equal(one[2], torch.arange(n_p))
+    assert float(one[0].min()) >= 0 and float(one[0].max()) < L and float(one[1].abs().max()) > 0
+    for world in (2, 3, 8):
+        parts = [bench.global_particles(torch, args, n_p, L, 1.0, 1.0, 1e-4, dev, r, world)
+                 for r in range(world)]
+        ids = torch.cat([p[2] for p in parts])
+        order = torch.argsort(ids)
+        assert torch.equal(ids[order], one[2])
+        assert torch.equal(torch.cat([p[0] for p in parts])[order], one[0])
+        assert torch.equal(torch.cat([p[1] for p in parts])[order], one[1])
+    other = bench.global_particles(torch, argparse.Namespace(seed=4, thermal=0.2), n_p, L, 1.0, 1.0,
+                                   1e-4, dev)
+    assert not torch.equal(other[0], one[0])
+    monkeypatch.setattr(bench, 'VERIFY_DIR', str(tmp_path))
+    sel = slice(0, n_p, 41)
+    path = bench.verify_save('k', one[2][sel].numpy(), one[0][sel].numpy(), one[1][sel].numpy(),
+                             n_p, 1.25, {'made_by': 'test'})
+    got = bench.verify_load('k')
+    assert os.path.exists(path) and got['particles'] == n_p and got['sum_mom2'] == 1.25
+    assert np.array_equal(got['ids'], one[2][sel].numpy())
+    assert np.array_equal(got['pos'], one[0][sel].numpy())
+    assert np.array_equal(got['mom'], one[1][sel].numpy())
+    assert bench.verify_load('no such key') is None
