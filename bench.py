@@ -1012,6 +1012,50 @@ def main():
 C4_SIZES = {'c4_nonlinnu_1gpu': 512, 'c4_nonlinnu_small': 128, 'c4_nonlinnu_tiny': 32}
 
 
+def c4_components(torch, dev, size, seed=1, thermal=0.2, mass=1.0, dt=1e-4):
+    """The components of BASELINE configs[4]'s shape (param/example_nonlinnu:36-45 with
+    _size = size): size^3 matter particles on P3M (mesh 2 size), a fluid with non-linear energy and
+    momentum density on a (size/2)^3 grid, global PM grid size/2; fixed step integrals.
+    Returns (params, particles, fluid, ᔑdt, ᔑdt_rungs, the particles' P3M mesh)."""
+    import numpy as np
+    from concept_amd import commons
+    from concept_amd.mesh import get_mesh
+    from concept_amd.species import Component
+    n_side, N3, N1 = size, 2*size, size//2
+    n = n_side**3
+    L = float(N3)
+    p = commons.load_params({
+        'boxsize': L,
+        'potential_options': {'gridsize': {'global': {'gravity': {'pm': N1, 'p3m': N3}}}},
+        'select_forces': {'particles': {'gravity': 'p3m'}, 'fluid': {'gravity': 'pm'}},
+        'select_softening_length': {'particles': '0.025*boxsize/cbrt(N)'}})
+    part = Component('matter', 'matter', N=n, mass=mass)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    torch.rand((n, 3), dtype=torch.float64, device=dev, generator=gen, out=part.pos)
+    part.pos.mul_(L*(1 - 1e-13))
+    torch.randn((n, 3), dtype=torch.float64, device=dev, generator=gen, out=part.mom)
+    part.mom.mul_(thermal/3**0.5*(L/N3)*mass/dt)
+    fluid = Component('neutrino', 'matter', gridsize=N1, boltzmann_order=1)
+    # a smooth density contrast of 10 % and a matching momentum density
+    x = (torch.arange(N1, dtype=torch.float64, device=dev) + 0.5)*(2*np.pi/N1)
+    wave = torch.sin(x)[:, None, None]*torch.cos(2*x)[None, :, None]*torch.sin(3*x)[None, None, :]
+    mean = 0.02*n*mass/N1**3   # a few per cent of the matter's mass in the fluid
+    fluid.ϱ.copy_(mean*(1 + 0.1*wave))
+    fluid.𝒫.copy_(1e-3*fluid.ϱ)
+    for d in range(3):
+        fluid.J[d].copy_(1e-2*mean*wave)
+    del x, wave
+    sdt = {'1': dt, 'a**(-2)': dt}
+    for c in (part, fluid):
+        sdt['a**(-3*w_eff)', c.name] = dt
+        sdt['a**(-3*w_eff-1)', c.name] = dt
+    # (one integral per rung index, main.py:1203-1215; every particle sits on rung 0)
+    sdt_rungs = {('a**(-3*w_eff₀-3*w_eff₁-1)', part.name, part.name):
+                 np.full(3*getattr(part, 'N_rungs', 8) - 1, dt)}
+    mesh3 = get_mesh(N3, L, p.nghosts, p.cell_centered, 2, dev)
+    return p, part, fluid, sdt, sdt_rungs, mesh3
+
+
 def run_c4(args, torch, dev, size=512, steps=None, warmup=None):
     """BASELINE configs[4]'s shape on ONE GPU: param/example_nonlinnu:36-45
     with _size = 512 — 512^3 matter particles (P3M on a 1024^3 mesh, spline-softened short range
@@ -1025,46 +1069,12 @@ def run_c4(args, torch, dev, size=512, steps=None, warmup=None):
     'short-range') + apply_Δmom, then gravity(..., 'long-range') per interaction — with fixed
     step integrals; the fluid's own evolution (fluid.py) is outside the path.  Phases are timed
     by HIP events around each call; `moved` bytes per phase below."""
-    import numpy as np
-    from concept_amd import commons, interactions
-    from concept_amd.mesh import get_mesh
-    from concept_amd.species import Component
+    from concept_amd import interactions
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
-    n_side, N3, N1 = size, 2*size, size//2
-    n = n_side**3
-    L = float(N3)
-    p = commons.load_params({
-        'boxsize': L,
-        'potential_options': {'gridsize': {'global': {'gravity': {'pm': N1, 'p3m': N3}}}},
-        'select_forces': {'particles': {'gravity': 'p3m'}, 'fluid': {'gravity': 'pm'}},
-        'select_softening_length': {'particles': '0.025*boxsize/cbrt(N)'}})
-    mass, dt = 1.0, 1e-4
-    part = Component('matter', 'matter', N=n, mass=mass)
-    gen = torch.Generator(device=dev).manual_seed(args.seed)
-    torch.rand((n, 3), dtype=torch.float64, device=dev, generator=gen, out=part.pos)
-    part.pos.mul_(L*(1 - 1e-13))
-    torch.randn((n, 3), dtype=torch.float64, device=dev, generator=gen, out=part.mom)
-    part.mom.mul_(args.thermal/3**0.5*(L/N3)*mass/dt)
-    fluid = Component('neutrino', 'matter', gridsize=N1, boltzmann_order=1)
-    # a smooth density contrast of 10 % and a matching momentum density
-    x = (torch.arange(N1, dtype=torch.float64, device=dev) + 0.5)*(2*np.pi/N1)
-    wave = torch.sin(x)[:, None, None]*torch.cos(2*x)[None, :, None]*torch.sin(3*x)[None, None, :]
-    mean = 0.02*n*mass/N1**3   # a few per cent of the matter's mass in the fluid
-    fluid.ϱ.copy_(mean*(1 + 0.1*wave))
-    fluid.𝒫.copy_(1e-3*fluid.ϱ)
-    for d in range(3):
-        fluid.J[d].copy_(1e-2*mean*wave)
-    del x, wave
+    p, part, fluid, sdt, sdt_rungs, mesh3 = c4_components(torch, dev, size, args.seed, args.thermal)
     comps = [part, fluid]
-    sdt = {'1': dt, 'a**(-2)': dt}
-    for c in comps:
-        sdt['a**(-3*w_eff)', c.name] = dt
-        sdt['a**(-3*w_eff-1)', c.name] = dt
-    # (one integral per rung index, main.py:1203-1215; every particle sits on rung 0)
-    sdt_rungs = {('a**(-3*w_eff₀-3*w_eff₁-1)', part.name, part.name):
-                 np.full(3*getattr(part, 'N_rungs', 8) - 1, dt)}
-    mesh3 = get_mesh(N3, L, p.nghosts, p.cell_centered, 2, dev)
+    n, N3, N1, L, dt = part.N, 2*size, size//2, p.boxsize, sdt['1']
     long_range = interactions.find_interactions(comps, 'long-range')
     short_range = interactions.find_interactions(comps, 'short-range')
     describe = lambda it: (f"{it.method}: {', '.join(c.name for c in it.receivers)} <- "
