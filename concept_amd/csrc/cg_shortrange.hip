@@ -50,6 +50,8 @@ struct SrParams {
     // the range), [1] of them in range, [2] wavefront trips (64 lane slots each) — counted by the
     // STATS instantiations only, which run while the statistics are switched on
     unsigned long long *stats;
+    // the table entries a pair in range can ask for: 0 .. (int)(r2_max * r2_index_scaling)
+    int table_n;
 };
 struct SrCount {
     unsigned tests = 0, hits = 0, trips = 0;
@@ -623,75 +625,93 @@ k_sr_sweep_cells(
 }
 
 // ===========================================================================
-// The interior of the box, 2 x 2 tiles per workgroup (round 5).
+// The interior of the box, 4 x 2 tiles per workgroup, the look-up table in LDS (round 5).
 //
 // What the sweep above costs apart from its pair tests was measured with a build whose pair
 // loop is empty (256^3 / 512^3, 22 particles per tile): 3.2 of 8.1 ms — the chain a tile's
 // workgroup goes through before its first pair (offsets of its 36 columns -> their rows ->
 // barrier), ~0.3 us of arithmetic in ~3 us of memory round trips, paid 750,000 times, which the
 // eight workgroups of a CU do not hide.  Tiles that are neighbours in x and y share most of what
-// they stage: a block of 2 x 2 tiles needs the 8 x 8 columns around it (6 cells along z each,
+// they stage: a block of 4 x 2 tiles needs the 12 x 8 columns around it (6 cells along z each,
 // the same window for all of them, so that a receiver's five columns of one x stay ONE range of
-// the staged array) — 1056 suppliers on average instead of 4 x 594 — and ONE chain.  Eight
+// the staged array) — 1584 suppliers on average instead of 8 x 594 — and ONE chain.  Sixteen
 // wavefronts, two receiver groups (a cell column of a tile: 2 cells, ~5.5 receivers) each;
 // the pair loop is the one above.  The tiles on the box faces (periodic images) keep the
-// one-tile kernel.  An odd number of interior tiles per dimension: the last block starts one
-// tile early and leaves the tile it shares with its neighbour out.
-// Measured at 256^3 / 512^3 on one box: 8.05 ms one tile per workgroup, 7.5 ms this.  Also
-// built and measured here: two receivers per lane, so that a supplier read from LDS serves two
-// pair tests (the loop issues three 8-byte LDS reads per test, ~70 % of what a CU's LDS
-// delivers while its SIMDs do the arithmetic): 9.3 ms — a chunk's ~5.5 receivers become 3
-// lane rows x 21 supplier groups, a range of ~82 suppliers is four trips of which the last is
-// mostly empty, and the fold over 21 groups of six sums costs what the reads saved.
+// one-tile kernel.  An interior that is not a multiple of the block: the last block of a
+// dimension ends with the last interior tile and leaves the tiles it shares with its neighbour
+// out.
+// The table (gravity.py:416-437; 4096 entries by default) is copied into LDS by every workgroup:
+// what the look-up costs as a global load was measured with variant builds
+// (profiles/r05_sr_lookup_ab.txt) — 7.3 ms as it was, 6.3 without it, 6.3 with a look-up in LDS —
+// and 32 KB of table beside the staged window are what sets the block's size: two workgroups of
+// 80 KB and sixteen wavefronts per CU.  A longer table stays in global memory (TABLDS = false).
+// Measured at 256^3 / 512^3 on one box: 8.05 ms one tile per workgroup, 7.3 ms with blocks of
+// 2 x 2 tiles and the table in global memory.  Also built and measured there: two receivers per
+// lane, so that a supplier read from LDS serves two pair tests: 9.3 ms — a chunk's ~5.5 receivers
+// become 3 lane rows x 21 supplier groups, a range of ~82 suppliers is four trips of which the
+// last is mostly empty, and the fold over 21 groups of six sums costs what the reads saved.
 // ===========================================================================
-constexpr int kSbCap = 1344;     // suppliers staged per window (mean 1056 at 22 per tile; more
-                                 // take further windows): with the slack 35.3 KB of LDS -> four
-                                 // workgroups of eight wavefronts per CU
-template <bool RUNGS, bool STATS>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(CG_SR_WAVES, 8))) void
+constexpr int kSbX = 4, kSbY = 2;                        // tiles per block
+constexpr int kSbColsY = 2 * kSbY + 4;                   // staged columns along y: 8
+constexpr int kSbCols = (2 * kSbX + 4) * kSbColsY;       // 12 x 8 = 96
+constexpr int kSbWaves = (2 * kSbX) * (2 * kSbY) / 2;    // 32 receiver groups, two per wavefront
+constexpr int kSbCap = 1856;     // suppliers staged per window (mean 1584 at 22 per tile; more
+                                 // take further windows)
+constexpr int kSbTable = 4096;   // table entries that fit beside it
+constexpr size_t kSbLds = sizeof(double) * (3 * (kSbCap + kSrSlack) + kSbTable) +
+                          sizeof(unsigned) * (3 * kSbCols + 4 * kSbWaves);
+static_assert(kSbCols <= 96 && kSbWaves == 16, "the prefix below is written for 64 + 32 columns");
+template <bool RUNGS, bool STATS, bool TABLDS>
+__global__ __launch_bounds__(64 * kSbWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
                   const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
                   const double *__restrict__ pos_s, const unsigned *__restrict__ off_s,
                   const double *__restrict__ table, SrParams P) {
     constexpr int kLen = kSbCap + kSrSlack;
-    __shared__ double sx[kLen], sy[kLen], sz[kLen];
-    __shared__ unsigned p_beg[64], p_cnt[64], p_off[64];
-    __shared__ unsigned wave_any[8];
+    extern __shared__ double sb_lds[];
+    double *sx = sb_lds, *sy = sx + kLen, *sz = sy + kLen, *stab = sz + kLen;
+    unsigned *p_beg = (unsigned *)(stab + kSbTable), *p_cnt = p_beg + kSbCols,
+             *p_off = p_cnt + kSbCols, *grp_n = p_off + kSbCols, *grp_b = grp_n + 2 * kSbWaves;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = P.nt, nc = 2 * nt, m = nt - 2;
-    // blocks per dimension (m + 1) / 2; the last one of an odd m overlaps its neighbour
-    const int nb = (m + 1) >> 1;
+    const int nbx = (m + kSbX - 1) / kSbX, nby = (m + kSbY - 1) / kSbY;
     const int bx = blockIdx.z, by = blockIdx.y, tc = (int)blockIdx.x + 1;
-    const bool lastx = bx == nb - 1, lasty = by == nb - 1;
-    const int ta0 = lastx ? nt - 3 : 1 + 2 * bx, tb0 = lasty ? nt - 3 : 1 + 2 * by;
-    const bool skipx = lastx && (m & 1) && nb > 1, skipy = lasty && (m & 1) && nb > 1;
-    // this wave's two receiver groups: cell columns (gx, gy) of the block's 4 x 4, cells 2 tc and
+    const bool lastx = bx == nbx - 1, lasty = by == nby - 1;
+    const int ta0 = lastx ? nt - 1 - kSbX : 1 + kSbX * bx, tb0 = lasty ? nt - 1 - kSbY : 1 + kSbY * by;
+    // tiles at the low side of a last block that its neighbour has
+    const int skipx = lastx ? kSbX * nbx - m : 0, skipy = lasty ? kSbY * nby - m : 0;
+    // this wave's two receiver groups: cell columns (gx, gy) of the block's 8 x 4, cells 2 tc and
     // 2 tc + 1.  A group whose tile is left out (shared with the neighbour block, no active
     // receiver, taken by the dense tiles' sweep) has no receivers.
-    unsigned rbeg[2], rend[2];
-    int gxs[2], gys[2];
+    // (scalars selected by the group number, not arrays indexed by it: those end up in scratch
+    // memory and take the wave-uniformity of everything derived from them with them)
+    unsigned rbeg0 = 0, rend0 = 0, rbeg1 = 0, rend1 = 0;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        const int g = wave + 8 * h, gx = g >> 2, gy = g & 3;
-        gxs[h] = gx, gys[h] = gy;
+        const int g = wave + kSbWaves * h, gx = g / (2 * kSbY), gy = g % (2 * kSbY);
         const int ta = ta0 + (gx >> 1), tb = tb0 + (gy >> 1);
-        bool take = !((gx < 2 && skipx) || (gy < 2 && skipy));
+        bool take = (gx >> 1) >= skipx && (gy >> 1) >= skipy;
         if (take && P.tile_active)
             take = P.tile_active[((unsigned)ta * nt + (unsigned)tb) * nt + (unsigned)tc] != 0;
         const unsigned rcell =
             ((unsigned)(2 * ta0 + gx) * nc + (unsigned)(2 * tb0 + gy)) * nc + 2 * tc;
-        rbeg[h] = rend[h] = 0;
         if (take) {
-            rbeg[h] = __builtin_amdgcn_readfirstlane(off_r[rcell]);
-            rend[h] = __builtin_amdgcn_readfirstlane(off_r[rcell + 2]);
+            const unsigned rb = __builtin_amdgcn_readfirstlane(off_r[rcell]),
+                           re = __builtin_amdgcn_readfirstlane(off_r[rcell + 2]);
+            if (h == 0) rbeg0 = rb, rend0 = re; else rbeg1 = rb, rend1 = re;
         }
     }
-    if (lane == 0) wave_any[wave] = (rend[0] - rbeg[0]) + (rend[1] - rbeg[1]);
-    // supplier pieces: column (cx, cy) of the 8 x 8 around the block, cells 2 tc - 2 .. 2 tc + 3
+    if (lane == 0) {
+        grp_n[wave] = rend0 - rbeg0;
+        grp_n[wave + kSbWaves] = rend1 - rbeg1;
+        grp_b[wave] = rbeg0;
+        grp_b[wave + kSbWaves] = rbeg1;
+    }
+    // supplier pieces: column (cx, cy) of the 12 x 8 around the block, cells 2 tc - 2 .. 2 tc + 3
     // (the block is in the interior: no column wraps around the box)
-    if (tid < 64) {
-        const int cx = tid >> 3, cy = tid & 7;
+    if (tid < kSbCols) {
+        const int cx = tid / kSbColsY, cy = tid % kSbColsY;
         const unsigned base =
             ((unsigned)(2 * ta0 - 2 + cx) * nc + (unsigned)(2 * tb0 - 2 + cy)) * nc + 2 * tc - 2;
         const unsigned beg = off_s[base];
@@ -702,8 +722,8 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
     // will be added to) are in flight while the suppliers are staged
     SrChunk ch = {};
     double d0 = 0, d1 = 0, d2 = 0;
-    if (rend[0] > rbeg[0]) {
-        ch = sr_chunk_load<RUNGS>(rbeg[0], rend[0], lane, pos_r, order_r, P);
+    if (rend0 > rbeg0) {
+        ch = sr_chunk_load<RUNGS>(rbeg0, rend0, lane, pos_r, order_r, P);
         if (ch.active && ch.sub == 0) {
             d0 = dmom_r[3 * (i64)ch.pi];
             d1 = dmom_r[3 * (i64)ch.pi + 1];
@@ -711,19 +731,71 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
         }
     }
     __syncthreads();
+    // which of the 32 groups have receivers (bit g): none -> nothing to do; some -> only the
+    // columns within reach of one of them are staged (a block at the edge of the dense tiles,
+    // or with few tiles on an active rung, would otherwise stage its neighbours' thousands of
+    // suppliers for nobody)
+    const unsigned gm = (unsigned)__ballot(grp_n[lane & (2 * kSbWaves - 1)] != 0);
+    if (gm == 0) return;
+    // The groups that have receivers are dealt out again, the k-th of them to wave k % 16: in a
+    // block of which only a part takes part, its wavefronts share what there is instead of
+    // keeping the two groups of their places.  (All 32 present: wave w keeps w and w + 16, and
+    // the chunk it has loaded.)
+    const int g_first = wave;
+    int g0 = -1, g1 = -1;
     {
-        unsigned any = 0;
-#pragma unroll
-        for (int w = 0; w < 8; w++) any |= wave_any[w];
-        if (any == 0) return;  // no receivers in the block
+        const int n = __popc(gm);
+        unsigned t = gm;
+        if (wave < n) {
+            for (int i = 0; i < wave; i++) t &= t - 1;
+            g0 = __builtin_ctz(t);
+            if (wave + kSbWaves < n) {
+                for (int i = 0; i < kSbWaves; i++) t &= t - 1;
+                g1 = __builtin_ctz(t);
+            }
+        }
+        rbeg0 = rend0 = rbeg1 = rend1 = 0;
+        if (g0 >= 0) {
+            rbeg0 = __builtin_amdgcn_readfirstlane(grp_b[g0]);
+            rend0 = rbeg0 + __builtin_amdgcn_readfirstlane(grp_n[g0]);
+        }
+        if (g1 >= 0) {
+            rbeg1 = __builtin_amdgcn_readfirstlane(grp_b[g1]);
+            rend1 = rbeg1 + __builtin_amdgcn_readfirstlane(grp_n[g1]);
+        }
     }
-    // exclusive prefix of the 64 column sizes by every wave for itself: lane l keeps the bounds
-    // of column l in registers, the range bounds below are v_readlane's
-    const unsigned c0 = p_cnt[lane];
-    const unsigned i0 = sr_wave_scan(c0);   // inclusive
-    const unsigned e0 = i0 - c0;            // exclusive
+    auto reach = [gm](int col) {  // column (cx, cy) is within reach of groups gx in [cx - 4, cx],
+        const int cx = col / kSbColsY, cy = col % kSbColsY;  // gy in [cy - 4, cy]
+        unsigned rows = 0;
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+            const int gx = cx - d;
+            if (gx >= 0 && gx < 2 * kSbX) rows |= gm >> (2 * kSbY * gx);
+        }
+        const unsigned ymask = ((2u << cy) - 1u) & ~((1u << max(cy - 4, 0)) - 1u) & ((1u << (2 * kSbY)) - 1u);
+        return (rows & ymask) != 0;
+    };
+    // the table: its loads travel with those of the staging below (the barrier behind the
+    // staging is the one the look-ups wait for)
+    // (a block with few receivers — the edge of the dense tiles, the upper rungs — would pay
+    // more for the copy than its look-ups gain: it reads the table where it is)
+    const bool tab_lds = TABLDS && __popc(gm) >= kSbWaves / 2;
+    if (tab_lds)
+        for (int i = tid; i < P.table_n; i += 64 * kSbWaves) stab[i] = table[i];
+    // exclusive prefix of the 96 column sizes by every wave for itself: lane l keeps the bounds
+    // of columns l and 64 + l in registers, the range bounds below are v_readlane's
+    // (the counts that are not needed are zeroed in place, by every wave with the same result:
+    // a wave that reads another's zero would have made it one itself)
+    const unsigned c0 = reach(lane) ? p_cnt[lane] : 0u,
+                   c1 = lane < kSbCols - 64 && reach(64 + lane) ? p_cnt[64 + lane] : 0u;
+    p_cnt[lane] = c0;
+    if (lane < kSbCols - 64) p_cnt[64 + lane] = c1;
+    const unsigned i0 = sr_wave_scan(c0);                                   // inclusive
+    const unsigned i1 = sr_wave_scan(c1) + __builtin_amdgcn_readlane(i0, 63);
+    const unsigned e0 = i0 - c0, e1 = i1 - c1;                              // exclusive
     p_off[lane] = e0;  // (identical values from every wave: a wave reads what it wrote itself)
-    const unsigned total = __builtin_amdgcn_readlane(i0, 63);
+    if (lane < kSbCols - 64) p_off[64 + lane] = e1;
+    const unsigned total = __builtin_amdgcn_readlane(i1, 63);
     const bool one_window = total <= (unsigned)kSbCap;
     SrCount cnt;
     for (unsigned w0 = 0; w0 < total; w0 += kSbCap) {
@@ -734,8 +806,8 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
         // staging: 16 lanes per piece, a wave takes 4 pieces at a time.  (All of a lane's
         // rows loaded before the first is stored — every entry's piece found by bisection of the
         // prefix sums, one round trip to memory instead of a turn per 16 rows of a piece —
-        // measured no faster: 7.6 against 7.5 ms, and 70 registers.)
-        for (int p0 = wave * 4; p0 < 64; p0 += 32) {
+        // measured no faster with 2 x 2 tiles: 7.6 against 7.5 ms, and 70 registers.)
+        for (int p0 = wave * 4; p0 < kSbCols; p0 += 4 * kSbWaves) {
             const int p = p0 + (lane >> 4);
             const unsigned beg = p_beg[p], o0 = p_off[p], o1 = o0 + p_cnt[p];
             const unsigned lo = max(o0, w0), hi = min(o1, w1);  // the part inside this window
@@ -757,11 +829,12 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
         __syncthreads();
 #pragma unroll 1
         for (int h = 0; h < 2; h++) {
-            const int gx = gxs[h], gy = gys[h];
-            const bool simple = one_window && rend[h] - rbeg[h] <= 64;  // one chunk, one window
-            for (unsigned base = rbeg[h]; base < rend[h]; base += 64) {
-                if (h || base != rbeg[0] || w0) {
-                    ch = sr_chunk_load<RUNGS>(base, rend[h], lane, pos_r, order_r, P);
+            const int g = h ? g1 : g0, gx = g / (2 * kSbY), gy = g % (2 * kSbY);
+            const unsigned rbeg = h ? rbeg1 : rbeg0, rend = h ? rend1 : rend0;
+            const bool simple = one_window && rend - rbeg <= 64;  // one chunk, one window
+            for (unsigned base = rbeg; base < rend; base += 64) {
+                if (h || base != rbeg0 || w0 || g0 != g_first) {
+                    ch = sr_chunk_load<RUNGS>(base, rend, lane, pos_r, order_r, P);
                     if (simple && ch.active && ch.sub == 0) {
                         d0 = dmom_r[3 * (i64)ch.pi];
                         d1 = dmom_r[3 * (i64)ch.pi + 1];
@@ -776,10 +849,19 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
                 // (every lane walks the ranges, active or not: the bounds are v_readlane's of
                 // registers whose 64 lanes must be live, i.e. uniform control flow)
                 for (int xg = 0; xg < 5; xg++) {
-                    const int col = (gx + xg) * 8 + gy;  // first of the 5 columns of this x
-                    const int a = max(__builtin_amdgcn_readlane((int)e0, col), sw0) - sw0;
-                    const int b = min(__builtin_amdgcn_readlane((int)i0, col + 4), sw1) - sw0;
-                    if (b > a)
+                    // first and last of the 5 columns of this x (one staged range)
+                    const int ca = (gx + xg) * kSbColsY + gy, cb = ca + 4;
+                    const int ea = ca < 64 ? __builtin_amdgcn_readlane((int)e0, ca)
+                                           : __builtin_amdgcn_readlane((int)e1, ca - 64);
+                    const int ib = cb < 64 ? __builtin_amdgcn_readlane((int)i0, cb)
+                                           : __builtin_amdgcn_readlane((int)i1, cb - 64);
+                    const int a = max(ea, sw0) - sw0, b = min(ib, sw1) - sw0;
+                    if (b <= a) continue;
+                    if (tab_lds)
+                        sr_cell_pairs<false, STATS>(a, b, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
+                                                    P.r2_index_scaling, stab, ax, ay, az, active,
+                                                    cnt);
+                    else
                         sr_cell_pairs<false, STATS>(a, b, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
                                                     P.r2_index_scaling, table, ax, ay, az, active,
                                                     cnt);
@@ -904,7 +986,7 @@ int cgk_shortrange_sparse(cg_ctx *c, const double *pos_r, const i64 *active, int
     if (n_s == 0) return 0;
     SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, 0,
                factors,      rung_jumped /* non-null = rungs in use */, rung_jumped, 0, nullptr,
-               nullptr};
+               nullptr,      0};
     if (!factors) P.rung = nullptr;
     if (!c->sr_sparse_partial)
         CG_HIP(hipMalloc((void **)&c->sr_sparse_partial,
@@ -927,7 +1009,8 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                                const double *factors, const signed char *rung,
                                const signed char *rung_jumped, int lowest_active) {
     SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt,
-               factors,      rung,             rung_jumped, lowest_active, nullptr, nullptr};
+               factors,      rung,             rung_jumped, lowest_active, nullptr, nullptr,
+               (int)(r2_max * r2_index_scaling) + 1};
     if (rung && lowest_active > 0) {
         // which tiles have a receiver on an active rung (the others leave at once)
         const size_t ntl = (size_t)nt * nt * nt;
@@ -979,12 +1062,20 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
         CG_LAUNCH_CHECK();
         CG_HIP(hipEventRecord(c->sr_join[slab], c->sr_streams[slab]));
     }
-    if (m >= 2) {
-        const unsigned nb = (m + 1) / 2;
-        auto blocks = rungs ? (P.stats ? k_sr_sweep_blocks<true, true> : k_sr_sweep_blocks<true, false>)
-                            : (P.stats ? k_sr_sweep_blocks<false, true> : k_sr_sweep_blocks<false, false>);
-        hipLaunchKernelGGL(blocks, dim3(m, nb, nb), dim3(512), 0, c->stream, pos_r_sorted, order_r,
-                           off_r, dmom_r, pos_s_sorted, off_s, table, P);
+    if (m >= (unsigned)kSbX) {
+        const unsigned nbx = (m + kSbX - 1) / kSbX, nby = (m + kSbY - 1) / kSbY;
+        const bool lds = P.table_n <= kSbTable;
+        auto blocks =
+            rungs ? (P.stats ? (lds ? k_sr_sweep_blocks<true, true, true> : k_sr_sweep_blocks<true, true, false>)
+                             : (lds ? k_sr_sweep_blocks<true, false, true> : k_sr_sweep_blocks<true, false, false>))
+                  : (P.stats ? (lds ? k_sr_sweep_blocks<false, true, true> : k_sr_sweep_blocks<false, true, false>)
+                             : (lds ? k_sr_sweep_blocks<false, false, true> : k_sr_sweep_blocks<false, false, false>));
+        // (the attribute belongs to the function ON A DEVICE; setting it again costs nothing
+        // next to a sweep)
+        CG_HIP(hipFuncSetAttribute((const void *)blocks, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kSbLds));
+        hipLaunchKernelGGL(blocks, dim3(m, nby, nbx), dim3(64 * kSbWaves), kSbLds, c->stream,
+                           pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P);
     } else {
         hipLaunchKernelGGL(inner, dim3(m, m, m), dim3(256), 0, c->stream, pos_r_sorted, order_r,
                            off_r, dmom_r, pos_s_sorted, off_s, table, P, 0);
