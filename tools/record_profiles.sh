@@ -51,18 +51,14 @@ CONCEPT_GPU_SR_DENSE_MIN=0 python tools/sr_dense_time.py clustered 2>&1 | grep -
 python bench.py --workload c4_nonlinnu_1gpu --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/${TAG}_bench_c4_nonlinnu_1gpu.json
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/stats_c4 -- python $R/bench.py --workload c4_nonlinnu_1gpu --steps 3 --warmup 1 > $OUT/stats_c4.log 2>&1)
 python tools/rocprof_summary.py $OUT/stats_c4 $OUT/${TAG}_rocprof_kernel_stats_c4.txt > /dev/null; rm -rf $OUT/stats_c4
-# 8. the short-range sweep: 2 x 2 tiles per workgroup against one tile per workgroup, and what
+# 8. the short-range sweep: blocks of 4 x 2 tiles per workgroup against one tile per workgroup, and what
 # the sweep costs apart from its pair tests (a build whose pair loop is empty), one box
-python tools/variant_patch.py sr_tiles '    if (m >= 2) {
-        const unsigned nb = (m + 1) / 2;' '    if (false) {
-        const unsigned nb = (m + 1) / 2;' > /dev/null 2>&1
+python tools/variant_patch.py sr_tiles '    if (m >= (unsigned)kSbX) {' '    if (false) {' > /dev/null 2>&1
 python tools/variant_patch.py sr_nopairs '    int row = a;
     for (; row + 2 * S <= b; row += 2 * S)' '    int row = a;
     ax += 1e-300 * (double)(b - a); return;
     for (; row + 2 * S <= b; row += 2 * S)' > /dev/null 2>&1
-python tools/variant_patch.py sr_tiles_nopairs '    if (m >= 2) {
-        const unsigned nb = (m + 1) / 2;' '    if (false) {
-        const unsigned nb = (m + 1) / 2;' '    int row = a;
+python tools/variant_patch.py sr_tiles_nopairs '    if (m >= (unsigned)kSbX) {' '    if (false) {' '    int row = a;
     for (; row + 2 * S <= b; row += 2 * S)' '    int row = a;
     ax += 1e-300 * (double)(b - a); return;
     for (; row + 2 * S <= b; row += 2 * S)' > /dev/null 2>&1
