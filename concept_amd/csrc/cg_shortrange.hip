@@ -742,8 +742,10 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
     // keeping the two groups of their places.  (All 32 present: wave w keeps w and w + 16, and
     // the chunk it has loaded.)
     const int g_first = wave;
-    int g0 = -1, g1 = -1;
-    {
+    const bool all_groups = gm == 0xffffffffu;  // (the usual case: nothing to deal out or leave out)
+    int g0 = wave, g1 = wave + kSbWaves;
+    if (!all_groups) {
+        g0 = g1 = -1;
         const int n = __popc(gm);
         unsigned t = gm;
         if (wave < n) {
@@ -764,8 +766,9 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
             rend1 = rbeg1 + __builtin_amdgcn_readfirstlane(grp_n[g1]);
         }
     }
-    auto reach = [gm](int col) {  // column (cx, cy) is within reach of groups gx in [cx - 4, cx],
-        const int cx = col / kSbColsY, cy = col % kSbColsY;  // gy in [cy - 4, cy]
+    auto reach = [gm, all_groups](int col) {  // column (cx, cy) is within reach of groups gx in
+        if (all_groups) return true;          // [cx - 4, cx], gy in [cy - 4, cy]
+        const int cx = col / kSbColsY, cy = col % kSbColsY;
         unsigned rows = 0;
 #pragma unroll
         for (int d = 0; d < 5; d++) {
