@@ -310,6 +310,96 @@ __device__ __forceinline__ void sr_cell_pairs(int a, int b, int sub, int S, doub
                                              r2_index_scaling, table, ax, ay, az, counted, cnt);
 }
 
+// One trip over the end of a range and the start of the next: the lanes whose turn i = sub + j S
+// comes after the `rem` suppliers left at `pos` take theirs from the next range [na, nb) instead
+// of idling — the five ranges of a receiver chunk (~82 suppliers each, 7.5 rows of its S lanes)
+// would otherwise end in a mostly empty trip each.
+template <bool SHIFT, bool STATS>
+__device__ __forceinline__ void sr_cell_straddle(int pos, int rem, int na, int nb, int sub, int S,
+                                                 double xi, double yi, double zi, const double *sx,
+                                                 const double *sy, const double *sz, double r2_max,
+                                                 double r2_index_scaling,
+                                                 const double *__restrict__ table, double &ax,
+                                                 double &ay, double &az, bool counted,
+                                                 SrCount &cnt) {
+    double xj[2], yj[2], zj[2], r2[2], t[2];
+    bool hit[2];
+    const int nxt = na - rem;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int i = sub + j * S;
+        const bool here = i < rem;
+        const int kj = (here ? pos : nxt) + i;
+        const bool valid = here || kj < nb;
+        xj[j] = xi - sx[kj];
+        yj[j] = yi - sy[kj];
+        zj[j] = zi - sz[kj];
+        if (SHIFT) {
+            xj[j] += sx[kSrFaceStride + kj];
+            yj[j] += sy[kSrFaceStride + kj];
+            zj[j] += sz[kSrFaceStride + kj];
+        }
+        r2[j] = xj[j] * xj[j] + yj[j] * yj[j] + zj[j] * zj[j];
+        hit[j] = r2[j] <= r2_max && valid;
+        if (STATS) {
+            cnt.tests += (unsigned)__popcll(__ballot(counted && valid));
+            cnt.hits += (unsigned)__popcll(__ballot(counted && hit[j]));
+            cnt.trips++;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        t[j] = 0.0;
+        if (hit[j]) t[j] = table[(unsigned)(int)(r2[j] * r2_index_scaling)];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        ax = __builtin_fma(xj[j], t[j], ax);
+        ay = __builtin_fma(yj[j], t[j], ay);
+        az = __builtin_fma(zj[j], t[j], az);
+    }
+}
+
+// The NSEG ranges [sa[s], sb[s]) of the staged window as ONE sequence of suppliers: full trips
+// inside a range, one trip across each boundary, a masked end.
+template <bool SHIFT, bool STATS, int NSEG>
+__device__ __forceinline__ void sr_cell_ranges(const int (&sa)[NSEG], const int (&sb)[NSEG],
+                                               int sub, int S, double xi, double yi, double zi,
+                                               const double *sx, const double *sy,
+                                               const double *sz, double r2_max,
+                                               double r2_index_scaling,
+                                               const double *__restrict__ table, double &ax,
+                                               double &ay, double &az, bool counted,
+                                               SrCount &cnt) {
+    int pos = sa[0];
+#pragma unroll
+    for (int s = 0; s < NSEG; s++) {
+        const int b = sb[s];
+        for (; pos + 2 * S <= b; pos += 2 * S)
+            sr_cell_batch<SHIFT, false, 2, STATS>(pos + sub, S, b, xi, yi, zi, sx, sy, sz, r2_max,
+                                                  r2_index_scaling, table, ax, ay, az, counted,
+                                                  cnt);
+        const int rem = b - pos;  // < 2 S
+        if (s == NSEG - 1) {
+            if (rem > S)
+                sr_cell_batch<SHIFT, true, 2, STATS>(pos + sub, S, b, xi, yi, zi, sx, sy, sz,
+                                                     r2_max, r2_index_scaling, table, ax, ay, az,
+                                                     counted, cnt);
+            else if (rem > 0)
+                sr_cell_batch<SHIFT, true, 1, STATS>(pos + sub, S, b, xi, yi, zi, sx, sy, sz,
+                                                     r2_max, r2_index_scaling, table, ax, ay, az,
+                                                     counted, cnt);
+        } else if (rem <= 0) {  // nothing left here (an empty range, or one the trip before used up)
+            pos = sa[s + 1];
+        } else {
+            sr_cell_straddle<SHIFT, STATS>(pos, rem, sa[s + 1], sb[s + 1], sub, S, xi, yi, zi, sx,
+                                           sy, sz, r2_max, r2_index_scaling, table, ax, ay, az,
+                                           counted, cnt);
+            pos = sa[s + 1] + (2 * S - rem);
+        }
+    }
+}
+
 // inclusive scan over the 64 lanes of a wave in DPP adds (no LDS round trips): row_shr 1, 2, 4,
 // 8 inside the rows of 16 lanes, then the row totals are broadcast forward (row_bcast 15, 31)
 __device__ __forceinline__ unsigned sr_wave_scan(unsigned v) {
@@ -580,15 +670,17 @@ k_sr_sweep_cells(
             // (every lane walks the ranges, active or not: the bounds are v_readlane's of
             // registers whose lanes 0..35 must be live, i.e. uniform control flow; an idle
             // lane tests pairs against (0, 0, 0) and its sums are never read)
+            int ra[5], rb[5];
+#pragma unroll
             for (int xg = 0; xg < 5; xg++) {
                 const int col = (wx + xg) * 6 + wy;  // first of the 5 columns of this x
                 // the 5 columns of this x are one staged range
-                const int a = max(__builtin_amdgcn_readlane((int)e0, col), sw0) - sw0;
-                const int b = min(__builtin_amdgcn_readlane((int)i0, col + 4), sw1) - sw0;
-                if (b > a)
-                    sr_cell_pairs<FACE, STATS>(a, b, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
-                                               P.r2_index_scaling, table, ax, ay, az, active, cnt);
+                // (a range of another window: empty, and where this window's rows end)
+                ra[xg] = min(max(__builtin_amdgcn_readlane((int)e0, col), sw0), sw1) - sw0;
+                rb[xg] = max(min(__builtin_amdgcn_readlane((int)i0, col + 4), sw1) - sw0, ra[xg]);
             }
+            sr_cell_ranges<FACE, STATS, 5>(ra, rb, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
+                                           P.r2_index_scaling, table, ax, ay, az, active, cnt);
             // fold the S partial sums of each receiver (lanes rl, rl + R, ...) into lane rl: a
             // tree over the groups, ceil(log2 S) shuffle steps.  A node whose partner group does
             // not exist (sub + d >= S) reads lane 63 instead, which holds zeros whenever such a
@@ -851,6 +943,8 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
                 double ax = 0, ay = 0, az = 0;
                 // (every lane walks the ranges, active or not: the bounds are v_readlane's of
                 // registers whose 64 lanes must be live, i.e. uniform control flow)
+                int ra[5], rb[5];
+#pragma unroll
                 for (int xg = 0; xg < 5; xg++) {
                     // first and last of the 5 columns of this x (one staged range)
                     const int ca = (gx + xg) * kSbColsY + gy, cb = ca + 4;
@@ -858,17 +952,18 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
                                            : __builtin_amdgcn_readlane((int)e1, ca - 64);
                     const int ib = cb < 64 ? __builtin_amdgcn_readlane((int)i0, cb)
                                            : __builtin_amdgcn_readlane((int)i1, cb - 64);
-                    const int a = max(ea, sw0) - sw0, b = min(ib, sw1) - sw0;
-                    if (b <= a) continue;
-                    if (tab_lds)
-                        sr_cell_pairs<false, STATS>(a, b, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
+                    // (a range of another window: empty, and where this window's rows end)
+                    ra[xg] = min(max(ea, sw0), sw1) - sw0;
+                    rb[xg] = max(min(ib, sw1) - sw0, ra[xg]);
+                }
+                if (tab_lds)
+                    sr_cell_ranges<false, STATS, 5>(ra, rb, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
                                                     P.r2_index_scaling, stab, ax, ay, az, active,
                                                     cnt);
-                    else
-                        sr_cell_pairs<false, STATS>(a, b, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
+                else
+                    sr_cell_ranges<false, STATS, 5>(ra, rb, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
                                                     P.r2_index_scaling, table, ax, ay, az, active,
                                                     cnt);
-                }
                 // fold the S partial sums of each receiver (see k_sr_sweep_cells)
                 if (sub >= S) ax = ay = az = 0;
                 for (int d = 1; d < S; d <<= 1) {  // S is wave-uniform
