@@ -743,26 +743,34 @@ k_sr_sweep_cells(
 // become 3 lane rows x 21 supplier groups, a range of ~82 suppliers is four trips of which the
 // last is mostly empty, and the fold over 21 groups of six sums costs what the reads saved.
 // ===========================================================================
-constexpr int kSbX = 4, kSbY = 2;                        // tiles per block
+// Two shapes: BX = 4 (4 x 2 tiles, 1024 lanes, the table in LDS) and BX = 2 (2 x 2 tiles, 512
+// lanes, 8 x 8 columns, 1056 suppliers on average, 35 KB of LDS, the table where it is) — the
+// latter for the sub-steps that kick the upper rungs only, where most tiles have no receiver on an
+// active rung and what a block costs before its first pair decides (tools/soak_p3m.py, 50 base
+// steps of the P3M loop with 8 rungs at 256^3 / 512^3: 5.0 s with 4 x 2 blocks, 4.6 s with 2 x 2).
+constexpr int kSbY = 2;                                  // tiles per block along y
 constexpr int kSbColsY = 2 * kSbY + 4;                   // staged columns along y: 8
-constexpr int kSbCols = (2 * kSbX + 4) * kSbColsY;       // 12 x 8 = 96
-constexpr int kSbWaves = (2 * kSbX) * (2 * kSbY) / 2;    // 32 receiver groups, two per wavefront
-constexpr int kSbCap = 1856;     // suppliers staged per window (mean 1584 at 22 per tile; more
-                                 // take further windows)
-constexpr int kSbTable = 4096;   // table entries that fit beside it
-constexpr size_t kSbLds = sizeof(double) * (3 * (kSbCap + kSrSlack) + kSbTable) +
-                          sizeof(unsigned) * (3 * kSbCols + 4 * kSbWaves);
-static_assert(kSbCols <= 96 && kSbWaves == 16, "the prefix below is written for 64 + 32 columns");
-template <bool RUNGS, bool STATS, bool TABLDS>
-__global__ __launch_bounds__(64 * kSbWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void
+constexpr int kSbTable = 4096;                           // table entries that fit into LDS
+constexpr int sb_cols(int bx) { return (2 * bx + 4) * kSbColsY; }   // 12 x 8 = 96 | 8 x 8 = 64
+constexpr int sb_waves(int bx) { return (2 * bx) * (2 * kSbY) / 2; }  // groups / 2: 16 | 8
+// suppliers staged per window (mean 1584 | 1056 at 22 per tile; more take further windows)
+constexpr int sb_cap(int bx) { return bx == 4 ? 1856 : 1344; }
+constexpr size_t sb_lds_bytes(int bx, bool tab) {
+    return sizeof(double) * (3 * (sb_cap(bx) + kSrSlack) + (tab ? kSbTable : 0)) +
+           sizeof(unsigned) * (3 * sb_cols(bx) + 4 * sb_waves(bx));
+}
+template <int BX, bool RUNGS, bool STATS, bool TABLDS>
+__global__ __launch_bounds__(64 * sb_waves(BX)) __attribute__((amdgpu_waves_per_eu(BX == 4 ? 8 : 4, 8))) void
 k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
                   const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
                   const double *__restrict__ pos_s, const unsigned *__restrict__ off_s,
                   const double *__restrict__ table, SrParams P) {
+    constexpr int kSbX = BX, kSbCols = sb_cols(BX), kSbWaves = sb_waves(BX), kSbCap = sb_cap(BX);
+    static_assert(kSbCols <= 96 && 2 * kSbWaves <= 32, "the prefix below: 64 + 32 columns; the groups: 32 bits");
     constexpr int kLen = kSbCap + kSrSlack;
     extern __shared__ double sb_lds[];
     double *sx = sb_lds, *sy = sx + kLen, *sz = sy + kLen, *stab = sz + kLen;
-    unsigned *p_beg = (unsigned *)(stab + kSbTable), *p_cnt = p_beg + kSbCols,
+    unsigned *p_beg = (unsigned *)(stab + (TABLDS ? kSbTable : 0)), *p_cnt = p_beg + kSbCols,
              *p_off = p_cnt + kSbCols, *grp_n = p_off + kSbCols, *grp_b = grp_n + 2 * kSbWaves;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -827,14 +835,15 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
     // columns within reach of one of them are staged (a block at the edge of the dense tiles,
     // or with few tiles on an active rung, would otherwise stage its neighbours' thousands of
     // suppliers for nobody)
-    const unsigned gm = (unsigned)__ballot(grp_n[lane & (2 * kSbWaves - 1)] != 0);
+    constexpr unsigned kAll = (unsigned)((1ull << (2 * kSbWaves)) - 1ull);
+    const unsigned gm = (unsigned)__ballot(grp_n[lane & (2 * kSbWaves - 1)] != 0) & kAll;
     if (gm == 0) return;
     // The groups that have receivers are dealt out again, the k-th of them to wave k % 16: in a
     // block of which only a part takes part, its wavefronts share what there is instead of
     // keeping the two groups of their places.  (All 32 present: wave w keeps w and w + 16, and
     // the chunk it has loaded.)
     const int g_first = wave;
-    const bool all_groups = gm == 0xffffffffu;  // (the usual case: nothing to deal out or leave out)
+    const bool all_groups = gm == kAll;  // (the usual case: nothing to deal out or leave out)
     int g0 = wave, g1 = wave + kSbWaves;
     if (!all_groups) {
         g0 = g1 = -1;
@@ -948,10 +957,11 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
                 for (int xg = 0; xg < 5; xg++) {
                     // first and last of the 5 columns of this x (one staged range)
                     const int ca = (gx + xg) * kSbColsY + gy, cb = ca + 4;
-                    const int ea = ca < 64 ? __builtin_amdgcn_readlane((int)e0, ca)
-                                           : __builtin_amdgcn_readlane((int)e1, ca - 64);
-                    const int ib = cb < 64 ? __builtin_amdgcn_readlane((int)i0, cb)
-                                           : __builtin_amdgcn_readlane((int)i1, cb - 64);
+                    int ea, ib;
+                    if (kSbCols <= 64 || ca < 64) ea = __builtin_amdgcn_readlane((int)e0, ca);
+                    else ea = __builtin_amdgcn_readlane((int)e1, ca - 64);
+                    if (kSbCols <= 64 || cb < 64) ib = __builtin_amdgcn_readlane((int)i0, cb);
+                    else ib = __builtin_amdgcn_readlane((int)i1, cb - 64);
                     // (a range of another window: empty, and where this window's rows end)
                     ra[xg] = min(max(ea, sw0), sw1) - sw0;
                     rb[xg] = max(min(ib, sw1) - sw0, ra[xg]);
@@ -1160,19 +1170,27 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
         CG_LAUNCH_CHECK();
         CG_HIP(hipEventRecord(c->sr_join[slab], c->sr_streams[slab]));
     }
-    if (m >= (unsigned)kSbX) {
-        const unsigned nbx = (m + kSbX - 1) / kSbX, nby = (m + kSbY - 1) / kSbY;
-        const bool lds = P.table_n <= kSbTable;
+    if (m >= 2) {
+        // 4 x 2 tiles per workgroup; 2 x 2 for the sub-steps of the upper rungs and for boxes of
+        // fewer than 6 tiles a side
+        const bool small = m < 4 || rungs;
+        const bool lds = !small && P.table_n <= kSbTable;
+        const int bx = small ? 2 : 4;
+        const unsigned nbx = (m + bx - 1) / bx, nby = (m + kSbY - 1) / kSbY;
         auto blocks =
-            rungs ? (P.stats ? (lds ? k_sr_sweep_blocks<true, true, true> : k_sr_sweep_blocks<true, true, false>)
-                             : (lds ? k_sr_sweep_blocks<true, false, true> : k_sr_sweep_blocks<true, false, false>))
-                  : (P.stats ? (lds ? k_sr_sweep_blocks<false, true, true> : k_sr_sweep_blocks<false, true, false>)
-                             : (lds ? k_sr_sweep_blocks<false, false, true> : k_sr_sweep_blocks<false, false, false>));
+            small ? (rungs ? (P.stats ? k_sr_sweep_blocks<2, true, true, false> : k_sr_sweep_blocks<2, true, false, false>)
+                           : (P.stats ? k_sr_sweep_blocks<2, false, true, false> : k_sr_sweep_blocks<2, false, false, false>))
+            : rungs ? (P.stats ? (lds ? k_sr_sweep_blocks<4, true, true, true> : k_sr_sweep_blocks<4, true, true, false>)
+                               : (lds ? k_sr_sweep_blocks<4, true, false, true> : k_sr_sweep_blocks<4, true, false, false>))
+                    : (P.stats ? (lds ? k_sr_sweep_blocks<4, false, true, true> : k_sr_sweep_blocks<4, false, true, false>)
+                               : (lds ? k_sr_sweep_blocks<4, false, false, true> : k_sr_sweep_blocks<4, false, false, false>));
+        const size_t bytes = sb_lds_bytes(bx, lds);
         // (the attribute belongs to the function ON A DEVICE; setting it again costs nothing
         // next to a sweep)
-        CG_HIP(hipFuncSetAttribute((const void *)blocks, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)kSbLds));
-        hipLaunchKernelGGL(blocks, dim3(m, nby, nbx), dim3(64 * kSbWaves), kSbLds, c->stream,
+        if (bytes > 64 * 1024)
+            CG_HIP(hipFuncSetAttribute((const void *)blocks,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(blocks, dim3(m, nby, nbx), dim3(64 * sb_waves(bx)), bytes, c->stream,
                            pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P);
     } else {
         hipLaunchKernelGGL(inner, dim3(m, m, m), dim3(256), 0, c->stream, pos_r_sorted, order_r,

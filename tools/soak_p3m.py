@@ -40,7 +40,7 @@ loop.run()
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 d = np.diff(np.array(stamps))
-print(f'a {a0} -> {loop.cosmo.a}: {loop.time_step} base steps in {wall:.1f} s; s per step: first 5 '
+print(f'a {a0} -> {loop.cosmo.a}: {loop.time_step} base steps in {wall:.2f} s; s per step: first 5 '
       + ' '.join(f'{v:.2f}' for v in d[:5]) + ' | last 5 ' + ' '.join(f'{v:.2f}' for v in d[-5:]))
 from concept_amd import shortrange  # noqa: E402
 print('sweeps without a cell list:', shortrange.sparse_sweeps)
