@@ -288,28 +288,6 @@ __device__ __forceinline__ void sr_cell_batch(int k, int S, int b, double xi, do
     }
 }
 
-// the range [a, b) of the staged window: rows of S suppliers, two rows per trip
-template <bool SHIFT, bool STATS>
-__device__ __forceinline__ void sr_cell_pairs(int a, int b, int sub, int S, double xi, double yi,
-                                              double zi, const double *sx, const double *sy,
-                                              const double *sz, double r2_max,
-                                              double r2_index_scaling,
-                                              const double *__restrict__ table, double &ax,
-                                              double &ay, double &az, bool counted, SrCount &cnt) {
-    // a, b, S are wave-uniform (scalar registers): rows of S suppliers walked with scalar adds
-    // and compares only (no division); the last one or two rows may stick out of the range
-    int row = a;
-    for (; row + 2 * S <= b; row += 2 * S)
-        sr_cell_batch<SHIFT, false, 2, STATS>(row + sub, S, b, xi, yi, zi, sx, sy, sz, r2_max,
-                                              r2_index_scaling, table, ax, ay, az, counted, cnt);
-    if (row + S < b)
-        sr_cell_batch<SHIFT, true, 2, STATS>(row + sub, S, b, xi, yi, zi, sx, sy, sz, r2_max,
-                                             r2_index_scaling, table, ax, ay, az, counted, cnt);
-    else if (row < b)
-        sr_cell_batch<SHIFT, true, 1, STATS>(row + sub, S, b, xi, yi, zi, sx, sy, sz, r2_max,
-                                             r2_index_scaling, table, ax, ay, az, counted, cnt);
-}
-
 // One trip over the end of a range and the start of the next: the lanes whose turn i = sub + j S
 // comes after the `rem` suppliers left at `pos` take theirs from the next range [na, nb) instead
 // of idling — the five ranges of a receiver chunk (~82 suppliers each, 7.5 rows of its S lanes)
@@ -1173,7 +1151,7 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
     if (m >= 2) {
         // 4 x 2 tiles per workgroup; 2 x 2 for the sub-steps of the upper rungs and for boxes of
         // fewer than 6 tiles a side
-        const bool small = m < 4 || rungs;
+        const bool small = m < 4 || (rungs && lowest_active > 0);
         const bool lds = !small && P.table_n <= kSbTable;
         const int bx = small ? 2 : 4;
         const unsigned nbx = (m + bx - 1) / bx, nby = (m + kSbY - 1) / kSbY;

@@ -54,14 +54,14 @@ python tools/rocprof_summary.py $OUT/stats_c4 $OUT/${TAG}_rocprof_kernel_stats_c
 # 8. the short-range sweep: blocks of 4 x 2 tiles per workgroup against one tile per workgroup, and what
 # the sweep costs apart from its pair tests (a build whose pair loop is empty), one box
 python tools/variant_patch.py sr_tiles '    if (m >= (unsigned)kSbX) {' '    if (false) {' > /dev/null 2>&1
-python tools/variant_patch.py sr_nopairs '    int row = a;
-    for (; row + 2 * S <= b; row += 2 * S)' '    int row = a;
-    ax += 1e-300 * (double)(b - a); return;
-    for (; row + 2 * S <= b; row += 2 * S)' > /dev/null 2>&1
-python tools/variant_patch.py sr_tiles_nopairs '    if (m >= (unsigned)kSbX) {' '    if (false) {' '    int row = a;
-    for (; row + 2 * S <= b; row += 2 * S)' '    int row = a;
-    ax += 1e-300 * (double)(b - a); return;
-    for (; row + 2 * S <= b; row += 2 * S)' > /dev/null 2>&1
+python tools/variant_patch.py sr_nopairs '    int pos = sa[0];
+#pragma unroll' '    int pos = sa[0];
+    ax += 1e-300 * (double)(sb[0] - pos); return;
+#pragma unroll' > /dev/null 2>&1
+python tools/variant_patch.py sr_tiles_nopairs '    if (m >= (unsigned)kSbX) {' '    if (false) {' '    int pos = sa[0];
+#pragma unroll' '    int pos = sa[0];
+    ax += 1e-300 * (double)(sb[0] - pos); return;
+#pragma unroll' > /dev/null 2>&1
 (for rep in 1 2; do for v in "" sr_tiles sr_nopairs sr_tiles_nopairs; do
    if [ -n "$v" ]; then export CONCEPT_GPU_LIB=$R/tools/_variants/$v.so; else unset CONCEPT_GPU_LIB; fi
    python tools/sr_dense_time.py uniform 2>&1 | grep -v amdgpu.ids
