@@ -53,12 +53,12 @@ python bench.py --workload c4_nonlinnu_1gpu --steps 5 --warmup 2 2>/dev/null | t
 python tools/rocprof_summary.py $OUT/stats_c4 $OUT/${TAG}_rocprof_kernel_stats_c4.txt > /dev/null; rm -rf $OUT/stats_c4
 # 8. the short-range sweep: blocks of 4 x 2 tiles per workgroup against one tile per workgroup, and what
 # the sweep costs apart from its pair tests (a build whose pair loop is empty), one box
-python tools/variant_patch.py sr_tiles '    if (m >= (unsigned)kSbX) {' '    if (false) {' > /dev/null 2>&1
+python tools/variant_patch.py sr_tiles '    if (m >= 2) {' '    if (false) {' > /dev/null 2>&1
 python tools/variant_patch.py sr_nopairs '    int pos = sa[0];
 #pragma unroll' '    int pos = sa[0];
     ax += 1e-300 * (double)(sb[0] - pos); return;
 #pragma unroll' > /dev/null 2>&1
-python tools/variant_patch.py sr_tiles_nopairs '    if (m >= (unsigned)kSbX) {' '    if (false) {' '    int pos = sa[0];
+python tools/variant_patch.py sr_tiles_nopairs '    if (m >= 2) {' '    if (false) {' '    int pos = sa[0];
 #pragma unroll' '    int pos = sa[0];
     ax += 1e-300 * (double)(sb[0] - pos); return;
 #pragma unroll' > /dev/null 2>&1
