@@ -419,6 +419,19 @@ def test_adaptive_rungs_knot_across_domains():
 
 @pytest.mark.parametrize('seed', range(16))
 def test_random_shortrange_vs_oracle(seed):
+    _random_shortrange_vs_oracle(seed)
+
+
+@pytest.mark.parametrize('tablesize', [4095, 4097, 2**13])
+def test_shortrange_table_beside_and_beyond_the_lds_copy(tablesize):
+    """The sweep's blocks of 4 x 2 tiles keep a copy of the look-up table in LDS when it has at
+    most 4096 entries (cg_shortrange.hip: kSbTable); a longer one is read where it is.  Both
+    sides of that limit against the oracle, on a box of 9 tiles a side (an interior of 7: blocks
+    of four tiles, the last one leaving out the three it shares)."""
+    _random_shortrange_vs_oracle(3, tablesize=tablesize, tiles=9)
+
+
+def _random_shortrange_vs_oracle(seed, tablesize=None, tiles=None):
     """Differential test of the short-range part of gravity('p3m') over its parameters (force
     split scale, range, tile size, table size, softening kernel and length, particle number and
     clustering) against the CPU oracle.  Also run over 2 and 4 domains."""
@@ -431,7 +444,12 @@ def test_random_shortrange_vs_oracle(seed):
     scale = float(rng.uniform(1.0, 1.5))*L/gs
     range_ = float(rng.uniform(3.5, 5.0))*scale
     tilesize = range_*float(rng.choice([1.0, 1.2]))
-    tablesize = int(rng.choice([1024, 4096]))
+    tablesize = int(rng.choice([1024, 4096])) if tablesize is None else tablesize
+    if tiles is not None:
+        L, gs = 50.0, 64
+        range_ = L/tiles/1.0001
+        scale = range_/4.5
+        tilesize = range_
     kernel = str(rng.choice(['spline', 'plummer', 'none']))
     N = int(rng.integers(500, 4000))
     pos = rng.uniform(0, L, (N, 3))
