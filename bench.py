@@ -116,6 +116,13 @@ def cpu_baseline(workload):
     env.setdefault('OMP_PROC_BIND', 'spread')
     env.setdefault('OMP_PLACES', 'threads')
     env['OMP_DYNAMIC'] = 'false'
+    # the host threads this process may use, counted HERE: in the child the OpenMP runtime binds
+    # the initial thread to its first place when the library is loaded (OMP_PROC_BIND), after
+    # which sched_getaffinity() there answers 1
+    try:
+        env['CONCEPT_BENCH_HOST_THREADS'] = str(len(os.sched_getaffinity(0)))
+    except AttributeError:
+        env['CONCEPT_BENCH_HOST_THREADS'] = str(os.cpu_count() or 1)
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child',
                             workload], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -138,12 +145,22 @@ def cpu_baseline_child(workload):
     workers (the reference's FFTW-MPI is not available here).  Single-thread and 256^3 / 512^3
     figures are kept as extras."""
     import numpy as np
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = None
     from oracle import oracle
     oracle.build()
     n_p, N = WORKLOADS[workload]
 
     import ctypes
     omp_lib = oracle.lib('omp')
+    # Loading the OpenMP runtime has bound THIS thread to its first place (OMP_PROC_BIND): the
+    # worker threads scipy.fft starts later inherit the caller's mask and would all share that one
+    # hardware thread (the transforms then take as long with 32 workers as with one).  The
+    # OpenMP workers keep their places; the initial thread gets the process's mask back.
+    if allowed:
+        os.sched_setaffinity(0, allowed)
     _dp = ctypes.POINTER(ctypes.c_double)
     omp_lib.orc_fill_tiled.argtypes = [_dp, ctypes.c_int64, _dp, ctypes.c_int64, ctypes.c_double,
                                        ctypes.c_double]
@@ -195,10 +212,12 @@ def cpu_baseline_child(workload):
             out[k] = e
         return out
 
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
+    avail = int(os.environ.get('CONCEPT_BENCH_HOST_THREADS', '0'))
+    if avail < 1:  # (called by hand: the count may already be the one thread OpenMP left)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
     mem_gb = 0.0
     try:
         with open('/proc/meminfo') as f:
