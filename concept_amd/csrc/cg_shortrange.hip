@@ -723,9 +723,12 @@ k_sr_sweep_cells(
 // ===========================================================================
 // Two shapes: BX = 4 (4 x 2 tiles, 1024 lanes, the table in LDS) and BX = 2 (2 x 2 tiles, 512
 // lanes, 8 x 8 columns, 1056 suppliers on average, 35 KB of LDS, the table where it is) — the
-// latter for the sub-steps that kick the upper rungs only, where most tiles have no receiver on an
-// active rung and what a block costs before its first pair decides (tools/soak_p3m.py, 50 base
-// steps of the P3M loop with 8 rungs at 256^3 / 512^3: 5.0 s with 4 x 2 blocks, 4.6 s with 2 x 2).
+// latter for the sub-steps that kick the upper rungs only (lowest_active > 0), where most tiles
+// have no receiver on an active rung and what a block costs before its first pair decides
+// (tools/soak_p3m.py, 30 base steps of the P3M loop with 8 rungs at 256^3 / 512^3: 2.95 s with
+// 4 x 2 blocks for every sweep, 2.76 s with 2 x 2 for the sub-steps — provided its instantiation
+// with rungs stays within 64 registers: at 67, seven wavefronts per SIMD, it took 2.95 s too), and
+// for boxes of fewer than six tiles a side.
 constexpr int kSbY = 2;                                  // tiles per block along y
 constexpr int kSbColsY = 2 * kSbY + 4;                   // staged columns along y: 8
 constexpr int kSbTable = 4096;                           // table entries that fit into LDS
