@@ -70,29 +70,21 @@ struct SrCount {
 //  * particles are SORTED by cell (z fastest), positions copied in that order: a column of
 //    cells along z is one contiguous run, staged with plain coalesced loads (no index
 //    indirection, no dependent loads);
-//  * one 256-lane workgroup per tile stages the 6 x 6 columns x 6 cells around it ONCE, its
-//    four wavefronts take the tile's four (x, y) cell columns (2 cells along z, ~5.5
-//    receivers): wave (wx, wy) needs columns [wx, wx+4] x [wy, wy+4] over all 6 cells — per
-//    x that is one contiguous range of the staged array — 25/36 of the staged suppliers,
-//    412 tests per receiver instead of 594, with R x floor(64/R) ~ 60 of 64 lanes busy;
+//  * one workgroup per BLOCK of tiles (4 x 2, or 2 x 2) stages the columns around the block
+//    ONCE (6 cells along z each), a wavefront takes cell columns of the block (2 cells along z,
+//    ~5.5 receivers): a receiver group needs the 5 x 5 columns around its own over all 6 cells
+//    — per x that is one contiguous range of the staged array — 412 tests per receiver instead
+//    of 594, with R x floor(64/R) ~ 60 of 64 lanes busy (k_sr_sweep_blocks below);
 //  * no self test: a particle paired with itself has x_ji = 0 exactly and contributes
 //    0 * table[0] = 0, as would two distinct particles at one position (the reference skips
 //    i == j by index, interactions.py:1722; the sums are the same);
 //  * the accumulation a += x_ji * f is a fused multiply-add (the order of partners already
 //    differs from the reference's, Δmom is compared to 1e-12); x_ji, r2 and the table index
 //    keep the reference's operation order and are bit-identical.
-// Periodic images: only tiles on the box faces see pieces with an offset; those are swept
-// piece by piece with the (uniform) offset added as the reference does, (xi - xj) + offset.
+// Periodic images: the tiles on the box faces are swept in blocks that reach across the face,
+// the offset added as the reference does, (xi - xj) + offset (SrWrapSeg below).
 // ===========================================================================
-#ifndef CG_SR_WAVES
-#define CG_SR_WAVES 4  // lower bound of wavefronts per SIMD for the register allocator
-#endif
-constexpr int kSrCap = 624;   // suppliers staged per round: the default tiling stages ~594 per
-                              // tile, more take further rounds; with the slack 18.4 KB of LDS
-                              // -> 8 workgroups (32 wavefronts) per CU
-constexpr int kSrFaceStride = kSrCap + 128;  // (box-face tiles: offsets behind the positions)
 constexpr int kSrSlack = 128; // masked lanes read up to 2*S - 1 < 128 entries past a range
-constexpr int kSrPieces = 72; // 6 x 6 columns x 2 (a column that wraps around the box in z)
 
 __device__ __forceinline__ unsigned sr_cell(const double *__restrict__ pos, i64 p, double inv,
                                             double ext, unsigned nt) {
@@ -239,18 +231,42 @@ int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
     return cgk_shortrange_dense_look(c, offset, nt);
 }
 
+// The periodic images of a block that reaches across a face of the box (WRAP).  The reference
+// adds the image's offset to the pair vector, (xi - xj) + offset (gravity.py:299-302,
+// interactions.py:1615-1621); for a staged block the offset of a pair is
+// (the receiver column's box shift - the supplier column's) * boxsize per dimension:
+//  x: a range is the five columns of ONE x — the offset is the same for the whole range;
+//  y: the five columns of a range cross the face at most once — the staged rows before `ys`
+//     take oyA, the others oyB;
+//  z: a column may come in two pieces (below and above the face): one staged double per
+//     supplier, `soz` (0 for most).
+// Off the faces the three are (+0, +0, +0): the same sums as the plain loop's.
+struct SrWrapSeg {
+    double ox;   // (uniform over the range)
+    int ys;      // first staged row (window-relative) of the columns beyond the y face
+};
+// d box lengths, d in {-1, 0, 1}, by selects: wave-uniform d and L stay in scalar registers (a
+// conversion and a product would go through the vector unit and keep registers there)
+__device__ __forceinline__ double sr_image(int d, double L) {
+    const double v = d == 0 ? 0.0 : (d > 0 ? L : -L);
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // pair tests of this lane's receiver against the staged suppliers [a, b), lane group `sub` of S
-// taking every S-th; SHIFT: the range is a periodic image, offset (ox, oy, oz).  Accumulates
-// sum x_ji * table[...] — the receiver's factor is applied once at the end.  NB pairs per trip:
-// their table loads (hits only) are all issued before the first is used (two: 64 VGPRs, 8
-// wavefronts per SIMD, 8.6 ms at 256^3 / 512^3; four: 80 VGPRs, 9.4 ms; eight: 11.8 ms).
-template <bool SHIFT, bool MASK, int NB, bool STATS>
+// taking every S-th.  Accumulates sum x_ji * table[...] — the receiver's factor is applied once
+// at the end.  NB pairs per trip: their table loads (hits only) are all issued before the first
+// is used (two: 64 VGPRs, 8 wavefronts per SIMD, 8.6 ms at 256^3 / 512^3; four: 80 VGPRs, 9.4 ms;
+// eight: 11.8 ms).
+template <bool WRAP, bool MASK, int NB, bool STATS>
 __device__ __forceinline__ void sr_cell_batch(int k, int S, int b, double xi, double yi, double zi,
                                               const double *sx, const double *sy,
                                               const double *sz, double r2_max,
                                               double r2_index_scaling,
                                               const double *__restrict__ table, double &ax,
-                                              double &ay, double &az, bool counted, SrCount &cnt) {
+                                              double &ay, double &az, bool counted, SrCount &cnt,
+                                              SrWrapSeg w, double oyA, double oyB,
+                                              const double *soz) {
     // NB pairs of this lane: their table loads (hits only) are all issued before the first use
     double xj[NB], yj[NB], zj[NB], r2[NB], t[NB];
     bool hit[NB];
@@ -260,10 +276,10 @@ __device__ __forceinline__ void sr_cell_batch(int k, int S, int b, double xi, do
         xj[j] = xi - sx[kj];                             // interactions.py:1787-1789
         yj[j] = yi - sy[kj];
         zj[j] = zi - sz[kj];
-        if (SHIFT) {                                     // gravity.py:299-302: the periodic
-            xj[j] += sx[kSrFaceStride + kj];             // image's offset, staged per supplier
-            yj[j] += sy[kSrFaceStride + kj];             // behind the positions (0 for most)
-            zj[j] += sz[kSrFaceStride + kj];
+        if (WRAP) {                                      // gravity.py:299-302
+            xj[j] += w.ox;
+            yj[j] += kj < w.ys ? oyA : oyB;
+            zj[j] += soz[kj];
         }
         r2[j] = xj[j] * xj[j] + yj[j] * yj[j] + zj[j] * zj[j];  // gravity.py:306
         hit[j] = r2[j] <= r2_max;                        // gravity.py:311: skip r2 > r2_max
@@ -292,14 +308,15 @@ __device__ __forceinline__ void sr_cell_batch(int k, int S, int b, double xi, do
 // comes after the `rem` suppliers left at `pos` take theirs from the next range [na, nb) instead
 // of idling — the five ranges of a receiver chunk (~82 suppliers each, 7.5 rows of its S lanes)
 // would otherwise end in a mostly empty trip each.
-template <bool SHIFT, bool STATS>
+template <bool WRAP, bool STATS>
 __device__ __forceinline__ void sr_cell_straddle(int pos, int rem, int na, int nb, int sub, int S,
                                                  double xi, double yi, double zi, const double *sx,
                                                  const double *sy, const double *sz, double r2_max,
                                                  double r2_index_scaling,
                                                  const double *__restrict__ table, double &ax,
                                                  double &ay, double &az, bool counted,
-                                                 SrCount &cnt) {
+                                                 SrCount &cnt, SrWrapSeg w, SrWrapSeg wn,
+                                                 double oyA, double oyB, const double *soz) {
     double xj[2], yj[2], zj[2], r2[2], t[2];
     bool hit[2];
     const int nxt = na - rem;
@@ -312,10 +329,10 @@ __device__ __forceinline__ void sr_cell_straddle(int pos, int rem, int na, int n
         xj[j] = xi - sx[kj];
         yj[j] = yi - sy[kj];
         zj[j] = zi - sz[kj];
-        if (SHIFT) {
-            xj[j] += sx[kSrFaceStride + kj];
-            yj[j] += sy[kSrFaceStride + kj];
-            zj[j] += sz[kSrFaceStride + kj];
+        if (WRAP) {
+            xj[j] += here ? w.ox : wn.ox;
+            yj[j] += kj < (here ? w.ys : wn.ys) ? oyA : oyB;
+            zj[j] += soz[kj];
         }
         r2[j] = xj[j] * xj[j] + yj[j] * yj[j] + zj[j] * zj[j];
         hit[j] = r2[j] <= r2_max && valid;
@@ -340,7 +357,7 @@ __device__ __forceinline__ void sr_cell_straddle(int pos, int rem, int na, int n
 
 // The NSEG ranges [sa[s], sb[s]) of the staged window as ONE sequence of suppliers: full trips
 // inside a range, one trip across each boundary, a masked end.
-template <bool SHIFT, bool STATS, int NSEG>
+template <bool WRAP, bool STATS, int NSEG>
 __device__ __forceinline__ void sr_cell_ranges(const int (&sa)[NSEG], const int (&sb)[NSEG],
                                                int sub, int S, double xi, double yi, double zi,
                                                const double *sx, const double *sy,
@@ -348,31 +365,32 @@ __device__ __forceinline__ void sr_cell_ranges(const int (&sa)[NSEG], const int 
                                                double r2_index_scaling,
                                                const double *__restrict__ table, double &ax,
                                                double &ay, double &az, bool counted,
-                                               SrCount &cnt) {
+                                               SrCount &cnt, const SrWrapSeg (&ws)[NSEG],
+                                               double oyA, double oyB, const double *soz) {
     int pos = sa[0];
 #pragma unroll
     for (int s = 0; s < NSEG; s++) {
         const int b = sb[s];
         for (; pos + 2 * S <= b; pos += 2 * S)
-            sr_cell_batch<SHIFT, false, 2, STATS>(pos + sub, S, b, xi, yi, zi, sx, sy, sz, r2_max,
-                                                  r2_index_scaling, table, ax, ay, az, counted,
-                                                  cnt);
+            sr_cell_batch<WRAP, false, 2, STATS>(pos + sub, S, b, xi, yi, zi, sx, sy, sz, r2_max,
+                                                 r2_index_scaling, table, ax, ay, az, counted,
+                                                 cnt, ws[s], oyA, oyB, soz);
         const int rem = b - pos;  // < 2 S
         if (s == NSEG - 1) {
             if (rem > S)
-                sr_cell_batch<SHIFT, true, 2, STATS>(pos + sub, S, b, xi, yi, zi, sx, sy, sz,
-                                                     r2_max, r2_index_scaling, table, ax, ay, az,
-                                                     counted, cnt);
+                sr_cell_batch<WRAP, true, 2, STATS>(pos + sub, S, b, xi, yi, zi, sx, sy, sz,
+                                                    r2_max, r2_index_scaling, table, ax, ay, az,
+                                                    counted, cnt, ws[s], oyA, oyB, soz);
             else if (rem > 0)
-                sr_cell_batch<SHIFT, true, 1, STATS>(pos + sub, S, b, xi, yi, zi, sx, sy, sz,
-                                                     r2_max, r2_index_scaling, table, ax, ay, az,
-                                                     counted, cnt);
+                sr_cell_batch<WRAP, true, 1, STATS>(pos + sub, S, b, xi, yi, zi, sx, sy, sz,
+                                                    r2_max, r2_index_scaling, table, ax, ay, az,
+                                                    counted, cnt, ws[s], oyA, oyB, soz);
         } else if (rem <= 0) {  // nothing left here (an empty range, or one the trip before used up)
             pos = sa[s + 1];
         } else {
-            sr_cell_straddle<SHIFT, STATS>(pos, rem, sa[s + 1], sb[s + 1], sub, S, xi, yi, zi, sx,
-                                           sy, sz, r2_max, r2_index_scaling, table, ax, ay, az,
-                                           counted, cnt);
+            sr_cell_straddle<WRAP, STATS>(pos, rem, sa[s + 1], sb[s + 1], sub, S, xi, yi, zi, sx,
+                                          sy, sz, r2_max, r2_index_scaling, table, ax, ay, az,
+                                          counted, cnt, ws[s], ws[s + 1], oyA, oyB, soz);
             pos = sa[s + 1] + (2 * S - rem);
         }
     }
@@ -488,212 +506,6 @@ __global__ __launch_bounds__(256) void k_sr_tile_activity(const unsigned *__rest
     tile_active[t] = any ? 1 : 0;
 }
 
-// FACE: the tiles on a face of the box, whose suppliers include periodic images.  Same sweep;
-// every staged supplier carries the offset of its image ((xi - xj) + offset in the reference's
-// order, gravity.py:299-302; + 0.0 for the others changes nothing), so a receiver's five
-// columns stay ONE range there too.  (Walking such tiles piece by piece — 10 short ranges per x
-// with a wave-uniform offset each — made these 6 % of the tiles 16 % of the sweep.)
-// (An XCD-contiguous walk of the interior tiles — so that a tile's supplier columns were staged
-// into the same L2 just before — measured 8.17 against 8.08 ms: the 3-D grid stays.)
-template <bool FACE, bool RUNGS, bool STATS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CG_SR_WAVES, 8))) void
-k_sr_sweep_cells(
-    const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
-    const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
-    const double *__restrict__ pos_s, const unsigned *__restrict__ off_s,
-    const double *__restrict__ table, SrParams P, int slab) {
-    constexpr int kLen = (FACE ? 2 : 1) * (kSrCap + kSrSlack);
-    static_assert(kSrFaceStride == kSrCap + kSrSlack, "offsets follow the positions");
-    __shared__ double sx[kLen], sy[kLen], sz[kLen];
-    __shared__ unsigned p_beg[kSrPieces], p_cnt[kSrPieces], p_off[kSrPieces];
-    __shared__ signed char p_shift[kSrPieces][4];  // periodic image: -1, 0, +1 box lengths
-    __shared__ unsigned wave_any[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = P.nt, nc = 2 * nt;
-    // one workgroup per tile: a 3-D grid (no index division; tiles adjacent along z, whose
-    // supplier columns overlap most, are dispatched together)
-    // Launches (nt >= 4): the interior tiles as one (nt-2)^3 grid; the face tiles as three
-    // slabs — slab 0: ta on a face, 1: tb on a face (ta inside), 2: tc on a face (ta, tb inside).
-    int ta = blockIdx.z, tb = blockIdx.y, tc = blockIdx.x;
-    if (!FACE) {
-        ta++, tb++, tc++;
-    } else if (slab == 0) {
-        ta = ta ? nt - 1 : 0;
-    } else if (slab == 1) {
-        tb = tb ? nt - 1 : 0;
-        ta++;
-    } else {
-        tc = tc ? nt - 1 : 0;
-        ta++, tb++;
-    }
-    // With rungs, most sub-steps of a base step kick the highest rungs only (main.py:1347-1624
-    // visits the tiles' active rungs only, species.py tiles_rungs_N): a tile none of whose
-    // receivers is active is gone after one byte
-    if (P.tile_active && !P.tile_active[((unsigned)ta * nt + (unsigned)tb) * nt + (unsigned)tc]) return;
-    // receivers of this wave: cell column (2 ta + wx, 2 tb + wy), cells 2 tc and 2 tc + 1
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int wx = wave_u >> 1, wy = wave_u & 1;
-    const unsigned rcell = ((unsigned)(2 * ta + wx) * nc + (unsigned)(2 * tb + wy)) * nc + 2 * tc;
-    const unsigned rbeg = __builtin_amdgcn_readfirstlane(off_r[rcell]),
-                   rend = __builtin_amdgcn_readfirstlane(off_r[rcell + 2]);
-    if (lane == 0) wave_any[wave] = rend - rbeg;
-    // supplier pieces: column (cx, cy) of the 6 x 6 around the tile, cells 2 tc - 2 .. 2 tc + 3,
-    // cut in two where the column wraps around the box in z
-    if (tid < kSrPieces) {
-        // piece number = half * 36 + column: a tile that does not touch a z face has all its
-        // suppliers in the first 36 pieces, in (cx, cy) order
-        const int half = tid >= 36, col = tid - 36 * half;
-        const int cx = col / 6, cy = col - 6 * cx;
-        int gx = 2 * ta - 2 + cx, gy = 2 * tb - 2 + cy;
-        int ox = 0, oy = 0, oz = 0;
-        if (gx < 0) { gx += nc; ox = 1; } else if (gx >= nc) { gx -= nc; ox = -1; }
-        if (gy < 0) { gy += nc; oy = 1; } else if (gy >= nc) { gy -= nc; oy = -1; }
-        int z0 = 2 * tc - 2, z1 = 2 * tc + 3;  // inclusive
-        int a = 0, b = -1;                      // this piece's cells [a, b]
-        if (z0 < 0) {
-            if (half == 0) { a = z0 + nc; b = nc - 1; oz = 1; } else { a = 0; b = z1; }
-        } else if (z1 >= nc) {
-            if (half == 0) { a = z0; b = nc - 1; } else { a = 0; b = z1 - nc; oz = -1; }
-        } else if (half == 0) {
-            a = z0;
-            b = z1;
-        }
-        const unsigned base = ((unsigned)gx * nc + (unsigned)gy) * nc;
-        unsigned beg = 0, cnt = 0;
-        if (b >= a) {
-            beg = off_s[base + a];
-            cnt = off_s[base + b + 1] - beg;
-        }
-        p_beg[tid] = beg;
-        p_cnt[tid] = cnt;
-        p_shift[tid][0] = (signed char)ox;
-        p_shift[tid][1] = (signed char)oy;
-        p_shift[tid][2] = (signed char)oz;
-    }
-    // the first receiver chunk does not depend on the staging: its loads (and the Δmom it will
-    // be added to) are in flight while the suppliers are staged
-    SrChunk ch = {};
-    double d0 = 0, d1 = 0, d2 = 0;
-    if (rend > rbeg) {
-        ch = sr_chunk_load<RUNGS>(rbeg, rend, lane, pos_r, order_r, P);
-        if (ch.active && ch.sub == 0) {
-            d0 = dmom_r[3 * (i64)ch.pi];
-            d1 = dmom_r[3 * (i64)ch.pi + 1];
-            d2 = dmom_r[3 * (i64)ch.pi + 2];
-        }
-    }
-    __syncthreads();
-    if (wave_any[0] + wave_any[1] + wave_any[2] + wave_any[3] == 0) return;  // empty tile
-    // Staged order: column by column (cx, cy), inside a column its cells in ascending relative z
-    // — where a column wraps around the box in z, its first piece (half 0) then its second.
-    // Exclusive prefix of the 36 column sizes by every wave for itself (identical values into
-    // p_off: a wave reads what it wrote itself, no barrier).  Lane l keeps the bounds of column
-    // l in registers: the range bounds below are v_readlane's.
-    const unsigned c0 = lane < 36 ? p_cnt[lane] : 0u, c1 = lane < 36 ? p_cnt[36 + lane] : 0u;
-    const unsigned i0 = sr_wave_scan(c0 + c1);             // inclusive, whole columns
-    const unsigned e0 = i0 - (c0 + c1);                    // exclusive
-    if (lane < 36) {
-        p_off[lane] = e0;
-        p_off[36 + lane] = e0 + c0;
-    }
-    const unsigned total = __builtin_amdgcn_readlane(i0, 63);
-    const int npieces = FACE ? kSrPieces : 36;  // (half 1 is empty off the z faces)
-    const bool simple = rend - rbeg <= 64 && total <= (unsigned)kSrCap;  // one chunk, one window
-    SrCount cnt;
-    for (unsigned w0 = 0; w0 < total; w0 += kSrCap) {
-        const unsigned w1 = min(total, w0 + (unsigned)kSrCap);
-        // (window bounds as scalar ints: the range bounds below are scalar integer min / max)
-        const int sw0 = __builtin_amdgcn_readfirstlane((int)w0),
-                  sw1 = __builtin_amdgcn_readfirstlane((int)w1);
-        if (w0) __syncthreads();  // everybody is done with the previous window
-        // staging: 16 lanes per piece, a wave takes 4 pieces at a time (pieces are short runs of
-        // ~16 suppliers; a longer one takes more turns) — no search for the piece of an entry
-        for (int p0 = wave_u * 4; p0 < npieces; p0 += 16) {
-            const int p = p0 + (lane >> 4);
-            const unsigned beg = p_beg[p], o0 = p_off[p], o1 = o0 + p_cnt[p];
-            const unsigned lo = max(o0, w0), hi = min(o1, w1);  // the part inside this window
-            for (unsigned tn = 0; __any(lo + 16u * tn < hi); tn++) {
-                const unsigned q = lo + (lane & 15) + 16u * tn;
-                if (q < hi) {
-                    const i64 g = (i64)beg + (q - o0);
-                    sx[q - w0] = pos_s[3 * g];
-                    sy[q - w0] = pos_s[3 * g + 1];
-                    sz[q - w0] = pos_s[3 * g + 2];
-                    if (FACE) {
-                        sx[kSrFaceStride + q - w0] = (double)p_shift[p][0] * P.boxsize;
-                        sy[kSrFaceStride + q - w0] = (double)p_shift[p][1] * P.boxsize;
-                        sz[kSrFaceStride + q - w0] = (double)p_shift[p][2] * P.boxsize;
-                    }
-                }
-            }
-        }
-        if (tid < kSrSlack) {  // the slack read by masked lanes: finite values
-            sx[w1 - w0 + tid] = 0;
-            sy[w1 - w0 + tid] = 0;
-            sz[w1 - w0 + tid] = 0;
-            if (FACE) {
-                sx[kSrFaceStride + w1 - w0 + tid] = 0;
-                sy[kSrFaceStride + w1 - w0 + tid] = 0;
-                sz[kSrFaceStride + w1 - w0 + tid] = 0;
-            }
-        }
-        __syncthreads();
-        for (unsigned base = rbeg; base < rend; base += 64) {
-            if (base != rbeg || w0) ch = sr_chunk_load<RUNGS>(base, rend, lane, pos_r, order_r, P);
-            const int R = ch.R, S = ch.S, sub = ch.sub;
-            const bool active = ch.active;
-            if (!__any(active)) continue;
-            const double xi = ch.xi, yi = ch.yi, zi = ch.zi;
-            double ax = 0, ay = 0, az = 0;
-            // (every lane walks the ranges, active or not: the bounds are v_readlane's of
-            // registers whose lanes 0..35 must be live, i.e. uniform control flow; an idle
-            // lane tests pairs against (0, 0, 0) and its sums are never read)
-            int ra[5], rb[5];
-#pragma unroll
-            for (int xg = 0; xg < 5; xg++) {
-                const int col = (wx + xg) * 6 + wy;  // first of the 5 columns of this x
-                // the 5 columns of this x are one staged range
-                // (a range of another window: empty, and where this window's rows end)
-                ra[xg] = min(max(__builtin_amdgcn_readlane((int)e0, col), sw0), sw1) - sw0;
-                rb[xg] = max(min(__builtin_amdgcn_readlane((int)i0, col + 4), sw1) - sw0, ra[xg]);
-            }
-            sr_cell_ranges<FACE, STATS, 5>(ra, rb, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
-                                           P.r2_index_scaling, table, ax, ay, az, active, cnt);
-            // fold the S partial sums of each receiver (lanes rl, rl + R, ...) into lane rl: a
-            // tree over the groups, ceil(log2 S) shuffle steps.  A node whose partner group does
-            // not exist (sub + d >= S) reads lane 63 instead, which holds zeros whenever such a
-            // node exists: R*S = 64 only for powers of two, where every partner exists.
-            if (sub >= S) ax = ay = az = 0;
-            for (int d = 1; d < S; d <<= 1) {  // S is wave-uniform
-                const int src = sub + d < S ? lane + d * R : 63;
-                ax += __shfl(ax, src);
-                ay += __shfl(ay, src);
-                az += __shfl(az, src);
-            }
-            ax *= ch.factor;  // gravity.py:321 (total_factor = factors[rung] * table[...])
-            ay *= ch.factor;
-            az *= ch.factor;
-            if (active && sub == 0) {
-                const i64 o = 3 * (i64)ch.pi;
-                if (simple) {  // the Δmom read at the top
-                    dmom_r[o] = d0 + ax;
-                    dmom_r[o + 1] = d1 + ay;
-                    dmom_r[o + 2] = d2 + az;
-                } else {
-                    dmom_r[o] += ax;
-                    dmom_r[o + 1] += ay;
-                    dmom_r[o + 2] += az;
-                }
-            }
-        }
-    }
-    if (STATS && lane == 0) {
-        atomicAdd(&P.stats[0], (unsigned long long)cnt.tests);
-        atomicAdd(&P.stats[1], (unsigned long long)cnt.hits);
-        atomicAdd(&P.stats[2], (unsigned long long)cnt.trips);
-    }
-}
-
 // ===========================================================================
 // The interior of the box, 4 x 2 tiles per workgroup, the look-up table in LDS (round 5).
 //
@@ -706,10 +518,12 @@ k_sr_sweep_cells(
 // the same window for all of them, so that a receiver's five columns of one x stay ONE range of
 // the staged array) — 1584 suppliers on average instead of 8 x 594 — and ONE chain.  Sixteen
 // wavefronts, two receiver groups (a cell column of a tile: 2 cells, ~5.5 receivers) each;
-// the pair loop is the one above.  The tiles on the box faces (periodic images) keep the
-// one-tile kernel.  An interior that is not a multiple of the block: the last block of a
-// dimension ends with the last interior tile and leaves the tiles it shares with its neighbour
-// out.
+// the pair loop is the one above.  The tiles on the box faces go to the WRAP instantiation: blocks
+// of 2 x 2 tiles that reach across the face (round 6; before, one tile per workgroup with a
+// staged offset per supplier and dimension: 6.4 % of the tiles cost 11 % of the uniform sweep and a
+// quarter of the rung loop's kernel time).  An interior that is not a multiple of the block: the
+// last block of a dimension ends with the last interior tile and leaves the tiles it shares with
+// its neighbour out.
 // The table (gravity.py:416-437; 4096 entries by default) is copied into LDS by every workgroup:
 // what the look-up costs as a global load was measured with variant builds
 // (profiles/r05_sr_lookup_ab.txt) — 7.3 ms as it was, 6.3 without it, 6.3 with a look-up in LDS —
@@ -736,11 +550,68 @@ constexpr int sb_cols(int bx) { return (2 * bx + 4) * kSbColsY; }   // 12 x 8 = 
 constexpr int sb_waves(int bx) { return (2 * bx) * (2 * kSbY) / 2; }  // groups / 2: 16 | 8
 // suppliers staged per window (mean 1584 | 1056 at 22 per tile; more take further windows)
 constexpr int sb_cap(int bx) { return bx == 4 ? 1856 : 1344; }
-constexpr size_t sb_lds_bytes(int bx, bool tab) {
-    return sizeof(double) * (3 * (sb_cap(bx) + kSrSlack) + (tab ? kSbTable : 0)) +
-           sizeof(unsigned) * (3 * sb_cols(bx) + 4 * sb_waves(bx));
+// (WRAP: one more staged double per supplier, and every column in two pieces)
+constexpr size_t sb_lds_bytes(int bx, bool tab, bool wrap) {
+    return sizeof(double) * ((wrap ? 4 : 3) * (sb_cap(bx) + kSrSlack) + (tab ? kSbTable : 0)) +
+           sizeof(unsigned) * ((wrap ? 8 : 3) * sb_cols(bx) + 4 * sb_waves(bx));
 }
-template <int BX, bool RUNGS, bool STATS, bool TABLDS>
+// Which tiles a workgroup takes.  Plain: the block (bx, by) of the interior's (nt - 2)^2 tiles
+// in x and y, tile tc of its nt - 2 in z.  WRAP: the tiles on the faces of the box in blocks of
+// 2 x 2 that reach ACROSS the face (tile nt - 1 and tile 0 are neighbours), as a 1-D grid of
+// three slabs — 0: x tiles {nt - 1, 0}, every y and z; 1: y tiles {nt - 1, 0}, x inside, every
+// z; 2: z tile 0 or nt - 1, x and y inside.  ta0, tb0: the block's first tile (its tiles are
+// (ta0 + i) mod nt); skipx, skipy: tiles at the low side of a last block that its neighbour has.
+struct SbBlock {
+    int ta0, tb0, tc, skipx, skipy;
+};
+template <int BX, bool WRAP>
+__device__ __forceinline__ SbBlock sb_block(int nt) {
+    const int m = nt - 2;
+    const int nbx = (m + BX - 1) / BX, nby = (m + kSbY - 1) / kSbY;
+    SbBlock B;
+    int jx, jy;
+    bool inx = true, iny = true;  // the interior's blocks in this dimension
+    if (!WRAP) {
+        jx = blockIdx.z, jy = blockIdx.y, B.tc = (int)blockIdx.x + 1;
+    } else {
+        const unsigned nyb = (unsigned)(nt + kSbY - 1) / kSbY;
+        const unsigned n0 = (unsigned)nt * nyb, n1 = (unsigned)nt * (unsigned)nbx;
+        unsigned b = blockIdx.x;
+        if (b < n0) {
+            B.tc = (int)(b % (unsigned)nt), jy = (int)(b / (unsigned)nt), jx = 0;
+            inx = iny = false;
+            B.ta0 = nt - 1, B.skipx = 0;
+            B.tb0 = min(kSbY * jy, nt - kSbY), B.skipy = kSbY * jy - B.tb0;
+        } else if (b < n0 + n1) {
+            b -= n0;
+            B.tc = (int)(b % (unsigned)nt), jx = (int)(b / (unsigned)nt), jy = 0;
+            iny = false;
+            B.tb0 = nt - 1, B.skipy = 0;
+        } else {
+            b -= n0 + n1;
+            B.tc = (b & 1u) ? nt - 1 : 0;
+            b >>= 1;
+            jy = (int)(b % (unsigned)nby), jx = (int)(b / (unsigned)nby);
+        }
+    }
+    if (inx) {
+        const bool last = jx == nbx - 1;
+        B.ta0 = last ? nt - 1 - BX : 1 + BX * jx;
+        B.skipx = last ? BX * nbx - m : 0;
+    }
+    if (iny) {
+        const bool last = jy == nby - 1;
+        B.tb0 = last ? nt - 1 - kSbY : 1 + kSbY * jy;
+        B.skipy = last ? kSbY * nby - m : 0;
+    }
+    return B;
+}
+static unsigned sb_wrap_blocks(unsigned nt) {
+    const unsigned m = nt - 2, nbx = (m + 1) / 2, nby = (m + kSbY - 1) / kSbY;
+    return nt * ((nt + kSbY - 1) / kSbY) + nt * nbx + 2 * nbx * nby;
+}
+
+template <int BX, bool RUNGS, bool STATS, bool TABLDS, bool WRAP>
 __global__ __launch_bounds__(64 * sb_waves(BX)) __attribute__((amdgpu_waves_per_eu(BX == 4 ? 8 : 4, 8))) void
 k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
                   const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
@@ -748,20 +619,24 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
                   const double *__restrict__ table, SrParams P) {
     constexpr int kSbX = BX, kSbCols = sb_cols(BX), kSbWaves = sb_waves(BX), kSbCap = sb_cap(BX);
     static_assert(kSbCols <= 96 && 2 * kSbWaves <= 32, "the prefix below: 64 + 32 columns; the groups: 32 bits");
+    static_assert(!WRAP || (BX == 2 && !TABLDS), "the blocks across the faces: 2 x 2 tiles, 64 columns");
     constexpr int kLen = kSbCap + kSrSlack;
+    constexpr int kPieces = (WRAP ? 2 : 1) * kSbCols;  // (WRAP: a column may wrap around in z)
     extern __shared__ double sb_lds[];
-    double *sx = sb_lds, *sy = sx + kLen, *sz = sy + kLen, *stab = sz + kLen;
-    unsigned *p_beg = (unsigned *)(stab + (TABLDS ? kSbTable : 0)), *p_cnt = p_beg + kSbCols,
-             *p_off = p_cnt + kSbCols, *grp_n = p_off + kSbCols, *grp_b = grp_n + 2 * kSbWaves;
+    double *sx = sb_lds, *sy = sx + kLen, *sz = sy + kLen, *soz = sz + kLen,
+           *stab = soz + (WRAP ? kLen : 0);
+    unsigned *p_beg = (unsigned *)(stab + (TABLDS ? kSbTable : 0)), *p_cnt = p_beg + kPieces,
+             *p_off = p_cnt + kPieces, *grp_n = p_off + kPieces, *grp_b = grp_n + 2 * kSbWaves;
+    int *p_oz = (int *)(grp_b + 2 * kSbWaves);  // (WRAP) a piece's image in z: -1, 0, +1 boxes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = P.nt, nc = 2 * nt, m = nt - 2;
-    const int nbx = (m + kSbX - 1) / kSbX, nby = (m + kSbY - 1) / kSbY;
-    const int bx = blockIdx.z, by = blockIdx.y, tc = (int)blockIdx.x + 1;
-    const bool lastx = bx == nbx - 1, lasty = by == nby - 1;
-    const int ta0 = lastx ? nt - 1 - kSbX : 1 + kSbX * bx, tb0 = lasty ? nt - 1 - kSbY : 1 + kSbY * by;
-    // tiles at the low side of a last block that its neighbour has
-    const int skipx = lastx ? kSbX * nbx - m : 0, skipy = lasty ? kSbY * nby - m : 0;
+    const int nt = P.nt, nc = 2 * nt;
+    const SbBlock B = sb_block<BX, WRAP>(nt);
+    const int ta0 = B.ta0, tb0 = B.tb0, tc = B.tc;
+    // a cell index of the block's frame (it may lie beyond a face) -> the cell of the box, and
+    // how many box lengths lie between them
+    auto wrapc = [nc](int u) { return !WRAP ? u : (u < 0 ? u + nc : (u >= nc ? u - nc : u)); };
+    auto shiftc = [nc](int u) { return !WRAP ? 0 : (u < 0 ? -1 : (u >= nc ? 1 : 0)); };
     // this wave's two receiver groups: cell columns (gx, gy) of the block's 8 x 4, cells 2 tc and
     // 2 tc + 1.  A group whose tile is left out (shared with the neighbour block, no active
     // receiver, taken by the dense tiles' sweep) has no receivers.
@@ -771,12 +646,13 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int g = wave + kSbWaves * h, gx = g / (2 * kSbY), gy = g % (2 * kSbY);
-        const int ta = ta0 + (gx >> 1), tb = tb0 + (gy >> 1);
-        bool take = (gx >> 1) >= skipx && (gy >> 1) >= skipy;
+        int ta = ta0 + (gx >> 1), tb = tb0 + (gy >> 1);
+        if (WRAP) ta -= ta >= nt ? nt : 0, tb -= tb >= nt ? nt : 0;
+        bool take = (gx >> 1) >= B.skipx && (gy >> 1) >= B.skipy;
         if (take && P.tile_active)
             take = P.tile_active[((unsigned)ta * nt + (unsigned)tb) * nt + (unsigned)tc] != 0;
         const unsigned rcell =
-            ((unsigned)(2 * ta0 + gx) * nc + (unsigned)(2 * tb0 + gy)) * nc + 2 * tc;
+            ((unsigned)wrapc(2 * ta0 + gx) * nc + (unsigned)wrapc(2 * tb0 + gy)) * nc + 2 * tc;
         if (take) {
             const unsigned rb = __builtin_amdgcn_readfirstlane(off_r[rcell]),
                            re = __builtin_amdgcn_readfirstlane(off_r[rcell + 2]);
@@ -790,14 +666,32 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
         grp_b[wave + kSbWaves] = rbeg1;
     }
     // supplier pieces: column (cx, cy) of the 12 x 8 around the block, cells 2 tc - 2 .. 2 tc + 3
-    // (the block is in the interior: no column wraps around the box)
-    if (tid < kSbCols) {
-        const int cx = tid / kSbColsY, cy = tid % kSbColsY;
+    // (WRAP: cut in two where the column wraps around the box in z — piece kSbCols + column is
+    // the part beyond the face, staged behind the first)
+    if (tid < kPieces) {
+        const int half = WRAP && tid >= kSbCols, col = tid - (half ? kSbCols : 0);
+        const int cx = col / kSbColsY, cy = col % kSbColsY;
         const unsigned base =
-            ((unsigned)(2 * ta0 - 2 + cx) * nc + (unsigned)(2 * tb0 - 2 + cy)) * nc + 2 * tc - 2;
-        const unsigned beg = off_s[base];
+            ((unsigned)wrapc(2 * ta0 - 2 + cx) * nc + (unsigned)wrapc(2 * tb0 - 2 + cy)) * nc;
+        const int z0 = 2 * tc - 2, z1 = 2 * tc + 3;  // inclusive
+        int a = z0, b = z1, oz = 0;                  // this piece's cells [a, b]
+        if (WRAP) {
+            if (z0 < 0) {
+                if (half == 0) { a = z0 + nc; b = nc - 1; oz = 1; } else { a = 0; }
+            } else if (z1 >= nc) {
+                if (half == 0) { b = nc - 1; } else { a = 0; b = z1 - nc; oz = -1; }
+            } else if (half) {
+                b = a - 1;
+            }
+            p_oz[tid] = oz;
+        }
+        unsigned beg = 0, cnt = 0;
+        if (b >= a) {
+            beg = off_s[base + a];
+            cnt = off_s[base + b + 1] - beg;
+        }
         p_beg[tid] = beg;
-        p_cnt[tid] = off_s[base + 6] - beg;
+        p_cnt[tid] = cnt;
     }
     // the first group's first chunk does not depend on the staging: its loads (and the Δmom it
     // will be added to) are in flight while the suppliers are staged
@@ -871,17 +765,26 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
     // of columns l and 64 + l in registers, the range bounds below are v_readlane's
     // (the counts that are not needed are zeroed in place, by every wave with the same result:
     // a wave that reads another's zero would have made it one itself)
-    const unsigned c0 = reach(lane) ? p_cnt[lane] : 0u,
-                   c1 = lane < kSbCols - 64 && reach(64 + lane) ? p_cnt[64 + lane] : 0u;
-    p_cnt[lane] = c0;
-    if (lane < kSbCols - 64) p_cnt[64 + lane] = c1;
+    const bool want0 = reach(lane), want1 = !WRAP && lane < kSbCols - 64 && reach(64 + lane);
+    // (WRAP: 64 columns; the second count is the column's piece beyond the z face)
+    const unsigned ca_ = want0 ? p_cnt[lane] : 0u,
+                   cb_ = WRAP ? (want0 ? p_cnt[kSbCols + lane] : 0u) : (want1 ? p_cnt[64 + lane] : 0u);
+    const unsigned c0 = WRAP ? ca_ + cb_ : ca_, c1 = WRAP ? 0u : cb_;
+    p_cnt[lane] = ca_;
+    if (WRAP) p_cnt[kSbCols + lane] = cb_;
+    else if (lane < kSbCols - 64) p_cnt[64 + lane] = cb_;
     const unsigned i0 = sr_wave_scan(c0);                                   // inclusive
-    const unsigned i1 = sr_wave_scan(c1) + __builtin_amdgcn_readlane(i0, 63);
+    const unsigned i1 = WRAP ? i0 : sr_wave_scan(c1) + __builtin_amdgcn_readlane(i0, 63);
     const unsigned e0 = i0 - c0, e1 = i1 - c1;                              // exclusive
     p_off[lane] = e0;  // (identical values from every wave: a wave reads what it wrote itself)
-    if (lane < kSbCols - 64) p_off[64 + lane] = e1;
+    if (WRAP) p_off[kSbCols + lane] = e0 + ca_;
+    else if (lane < kSbCols - 64) p_off[64 + lane] = e1;
     const unsigned total = __builtin_amdgcn_readlane(i1, 63);
     const bool one_window = total <= (unsigned)kSbCap;
+    // WRAP, y: the staged columns cy >= cyb lie one box length beyond those below (8 or more:
+    // the block's columns do not cross a y face)
+    const int shA_y = shiftc(2 * tb0 - 2);
+    const int cyb = WRAP ? (shA_y + 1) * nc - (2 * tb0 - 2) : 99;
     SrCount cnt;
     for (unsigned w0 = 0; w0 < total; w0 += kSbCap) {
         const unsigned w1 = min(total, w0 + (unsigned)kSbCap);
@@ -892,10 +795,11 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
         // rows loaded before the first is stored — every entry's piece found by bisection of the
         // prefix sums, one round trip to memory instead of a turn per 16 rows of a piece —
         // measured no faster with 2 x 2 tiles: 7.6 against 7.5 ms, and 70 registers.)
-        for (int p0 = wave * 4; p0 < kSbCols; p0 += 4 * kSbWaves) {
+        for (int p0 = wave * 4; p0 < kPieces; p0 += 4 * kSbWaves) {
             const int p = p0 + (lane >> 4);
             const unsigned beg = p_beg[p], o0 = p_off[p], o1 = o0 + p_cnt[p];
             const unsigned lo = max(o0, w0), hi = min(o1, w1);  // the part inside this window
+            const double oz = WRAP ? sr_image(p_oz[p], P.boxsize) : 0.0;
             for (unsigned tn = 0; __any(lo + 16u * tn < hi); tn++) {
                 const unsigned q = lo + (lane & 15) + 16u * tn;
                 if (q < hi) {
@@ -903,6 +807,7 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
                     sx[q - w0] = pos_s[3 * g];
                     sy[q - w0] = pos_s[3 * g + 1];
                     sz[q - w0] = pos_s[3 * g + 2];
+                    if (WRAP) soz[q - w0] = oz;
                 }
             }
         }
@@ -910,6 +815,7 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
             sx[w1 - w0 + tid] = 0;
             sy[w1 - w0 + tid] = 0;
             sz[w1 - w0 + tid] = 0;
+            if (WRAP) soz[w1 - w0 + tid] = 0;
         }
         __syncthreads();
 #pragma unroll 1
@@ -934,6 +840,12 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
                 // (every lane walks the ranges, active or not: the bounds are v_readlane's of
                 // registers whose 64 lanes must be live, i.e. uniform control flow)
                 int ra[5], rb[5];
+                SrWrapSeg ws[5];
+                // the receivers' own box shifts (a group of tile 0 in a block that starts at
+                // tile nt - 1 lies one box length up in the block's frame)
+                const int shr_x = shiftc(2 * ta0 + gx), shr_y = shiftc(2 * tb0 + gy);
+                const double oyA = sr_image(shr_y - shA_y, P.boxsize),
+                             oyB = sr_image(shr_y - shA_y - 1, P.boxsize);
 #pragma unroll
                 for (int xg = 0; xg < 5; xg++) {
                     // first and last of the 5 columns of this x (one staged range)
@@ -946,16 +858,28 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
                     // (a range of another window: empty, and where this window's rows end)
                     ra[xg] = min(max(ea, sw0), sw1) - sw0;
                     rb[xg] = max(min(ib, sw1) - sw0, ra[xg]);
+                    ws[xg].ox = 0.0, ws[xg].ys = 0;
+                    if (WRAP) {
+                        ws[xg].ox = sr_image(shr_x - shiftc(2 * ta0 - 2 + gx + xg), P.boxsize);
+                        ws[xg].ys = __builtin_amdgcn_readfirstlane(
+                            cyb <= gy ? -0x7fffffff
+                            : cyb > gy + 4
+                                ? 0x7fffffff
+                                : __builtin_amdgcn_readlane((int)e0, (gx + xg) * kSbColsY + min(cyb, kSbColsY - 1)) - sw0);
+                    }
                 }
                 if (tab_lds)
-                    sr_cell_ranges<false, STATS, 5>(ra, rb, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
-                                                    P.r2_index_scaling, stab, ax, ay, az, active,
-                                                    cnt);
+                    sr_cell_ranges<WRAP, STATS, 5>(ra, rb, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
+                                                   P.r2_index_scaling, stab, ax, ay, az, active,
+                                                   cnt, ws, oyA, oyB, soz);
                 else
-                    sr_cell_ranges<false, STATS, 5>(ra, rb, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
-                                                    P.r2_index_scaling, table, ax, ay, az, active,
-                                                    cnt);
-                // fold the S partial sums of each receiver (see k_sr_sweep_cells)
+                    sr_cell_ranges<WRAP, STATS, 5>(ra, rb, sub, S, xi, yi, zi, sx, sy, sz, P.r2_max,
+                                                   P.r2_index_scaling, table, ax, ay, az, active,
+                                                   cnt, ws, oyA, oyB, soz);
+                // fold the S partial sums of each receiver (lanes rl, rl + R, ...) into lane rl: a
+                // tree over the groups, ceil(log2 S) shuffle steps.  A node whose partner group
+                // does not exist (sub + d >= S) reads lane 63 instead, which holds zeros whenever
+                // such a node exists: R*S = 64 only for powers of two, where every partner exists.
                 if (sub >= S) ax = ay = az = 0;
                 for (int d = 1; d < S; d <<= 1) {  // S is wave-uniform
                     const int src = sub + d < S ? lane + d * R : 63;
@@ -1126,32 +1050,29 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                              rung ? lowest_active : 0, P.tile_active, &take))
         return 1;
     if (take) P.tile_active = take;
-    const unsigned n = (unsigned)nt, m = (unsigned)(nt - 2);  // (nt >= 4: checked by the caller)
-    // The four launches touch different receivers: the face slabs go to side streams (forked
-    // from and joined back into the context's stream) and run beside the interior grid.
+    const unsigned m = (unsigned)(nt - 2);  // (nt >= 4: checked by the caller)
+    // Two launches that touch different receivers: the blocks across the box faces go to a side
+    // stream (forked from and joined back into the context's stream) and run beside the
+    // interior's.
     if (!c->sr_fork) {
         CG_HIP(hipEventCreateWithFlags(&c->sr_fork, hipEventDisableTiming));
-        for (int i = 0; i < 3; i++) {
-            CG_HIP(hipStreamCreateWithFlags(&c->sr_streams[i], hipStreamNonBlocking));
-            CG_HIP(hipEventCreateWithFlags(&c->sr_join[i], hipEventDisableTiming));
-        }
+        CG_HIP(hipStreamCreateWithFlags(&c->sr_streams[0], hipStreamNonBlocking));
+        CG_HIP(hipEventCreateWithFlags(&c->sr_join[0], hipEventDisableTiming));
     }
-    CG_HIP(hipEventRecord(c->sr_fork, c->stream));
-    const dim3 slabs[3] = {dim3(n, n, 2), dim3(n, 2, m), dim3(2, m, m)};
     const bool rungs = rung != nullptr;
     P.stats = c->sr_stats;
-    auto face = rungs ? (P.stats ? k_sr_sweep_cells<true, true, true> : k_sr_sweep_cells<true, true, false>)
-                      : (P.stats ? k_sr_sweep_cells<true, false, true> : k_sr_sweep_cells<true, false, false>);
-    auto inner = rungs ? (P.stats ? k_sr_sweep_cells<false, true, true> : k_sr_sweep_cells<false, true, false>)
-                       : (P.stats ? k_sr_sweep_cells<false, false, true> : k_sr_sweep_cells<false, false, false>);
-    for (int slab = 0; slab < 3; slab++) {
-        CG_HIP(hipStreamWaitEvent(c->sr_streams[slab], c->sr_fork, 0));
-        hipLaunchKernelGGL(face, slabs[slab], dim3(256), 0, c->sr_streams[slab], pos_r_sorted,
-                           order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P, slab);
+    {
+        CG_HIP(hipEventRecord(c->sr_fork, c->stream));
+        CG_HIP(hipStreamWaitEvent(c->sr_streams[0], c->sr_fork, 0));
+        auto faces = rungs ? (P.stats ? k_sr_sweep_blocks<2, true, true, false, true> : k_sr_sweep_blocks<2, true, false, false, true>)
+                           : (P.stats ? k_sr_sweep_blocks<2, false, true, false, true> : k_sr_sweep_blocks<2, false, false, false, true>);
+        hipLaunchKernelGGL(faces, dim3(sb_wrap_blocks((unsigned)nt)), dim3(64 * sb_waves(2)),
+                           sb_lds_bytes(2, false, true), c->sr_streams[0], pos_r_sorted, order_r,
+                           off_r, dmom_r, pos_s_sorted, off_s, table, P);
         CG_LAUNCH_CHECK();
-        CG_HIP(hipEventRecord(c->sr_join[slab], c->sr_streams[slab]));
+        CG_HIP(hipEventRecord(c->sr_join[0], c->sr_streams[0]));
     }
-    if (m >= 2) {
+    {
         // 4 x 2 tiles per workgroup; 2 x 2 for the sub-steps of the upper rungs and for boxes of
         // fewer than 6 tiles a side
         const bool small = m < 4 || (rungs && lowest_active > 0);
@@ -1159,13 +1080,13 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
         const int bx = small ? 2 : 4;
         const unsigned nbx = (m + bx - 1) / bx, nby = (m + kSbY - 1) / kSbY;
         auto blocks =
-            small ? (rungs ? (P.stats ? k_sr_sweep_blocks<2, true, true, false> : k_sr_sweep_blocks<2, true, false, false>)
-                           : (P.stats ? k_sr_sweep_blocks<2, false, true, false> : k_sr_sweep_blocks<2, false, false, false>))
-            : rungs ? (P.stats ? (lds ? k_sr_sweep_blocks<4, true, true, true> : k_sr_sweep_blocks<4, true, true, false>)
-                               : (lds ? k_sr_sweep_blocks<4, true, false, true> : k_sr_sweep_blocks<4, true, false, false>))
-                    : (P.stats ? (lds ? k_sr_sweep_blocks<4, false, true, true> : k_sr_sweep_blocks<4, false, true, false>)
-                               : (lds ? k_sr_sweep_blocks<4, false, false, true> : k_sr_sweep_blocks<4, false, false, false>));
-        const size_t bytes = sb_lds_bytes(bx, lds);
+            small ? (rungs ? (P.stats ? k_sr_sweep_blocks<2, true, true, false, false> : k_sr_sweep_blocks<2, true, false, false, false>)
+                           : (P.stats ? k_sr_sweep_blocks<2, false, true, false, false> : k_sr_sweep_blocks<2, false, false, false, false>))
+            : rungs ? (P.stats ? (lds ? k_sr_sweep_blocks<4, true, true, true, false> : k_sr_sweep_blocks<4, true, true, false, false>)
+                               : (lds ? k_sr_sweep_blocks<4, true, false, true, false> : k_sr_sweep_blocks<4, true, false, false, false>))
+                    : (P.stats ? (lds ? k_sr_sweep_blocks<4, false, true, true, false> : k_sr_sweep_blocks<4, false, true, false, false>)
+                               : (lds ? k_sr_sweep_blocks<4, false, false, true, false> : k_sr_sweep_blocks<4, false, false, false, false>));
+        const size_t bytes = sb_lds_bytes(bx, lds, false);
         // (the attribute belongs to the function ON A DEVICE; setting it again costs nothing
         // next to a sweep)
         if (bytes > 64 * 1024)
@@ -1173,12 +1094,9 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         hipLaunchKernelGGL(blocks, dim3(m, nby, nbx), dim3(64 * sb_waves(bx)), bytes, c->stream,
                            pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P);
-    } else {
-        hipLaunchKernelGGL(inner, dim3(m, m, m), dim3(256), 0, c->stream, pos_r_sorted, order_r,
-                           off_r, dmom_r, pos_s_sorted, off_s, table, P, 0);
     }
     CG_LAUNCH_CHECK();
-    for (int slab = 0; slab < 3; slab++) CG_HIP(hipStreamWaitEvent(c->stream, c->sr_join[slab], 0));
+    CG_HIP(hipStreamWaitEvent(c->stream, c->sr_join[0], 0));
     if (take && cgk_shortrange_dense_join(c)) return 1;
     return 0;
 }

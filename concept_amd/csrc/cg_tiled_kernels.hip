@@ -558,7 +558,9 @@ constexpr int gk_waves() {
 
 // MODE 0: gather + kick in place.  1: also histogram the tile keys after the next drift (PREP).
 // 2: kick, drift and scatter into the next tile order in one pass (nothing written in place).
-template <int ORDER, int T, int MODE>
+// MOM2 (MODE 2 only): the pass also leaves the sum of |mom|^2 (prep.mom2_out) — its own
+// instantiation, so that the pass without the sum is the code it was before the sum existed.
+template <int ORDER, int T, int MODE, bool MOM2 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
     gk_waves<ORDER, T, MODE>(), 8))) void k_gather_kick_tiled(
     const double *__restrict__ pos, double *__restrict__ mom,
@@ -809,24 +811,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
             // 24 more registers that this variant does without, 9.9 -> 9.6 ms).
             atomicOr(prep.err_flags, (unsigned)CG_ERR_NOT_IN_TILE);
         } else {
-            // outside its tile (array drifted since the sort): read the mesh directly
-            constexpr int W = 2 + 2 * H;
-            i64 ix[W], iy[W], iz[W];
-#pragma unroll
-            for (int s = 0; s < W; s++) {
-                ix[s] = cg_xlayer(xm, (i64)(ga - H + s), N) * ny * pad;
-                iy[s] = (i64)wrap(gb - H + s, Ni) * pad;
-                iz[s] = wrap(gc - H + s, Ni);
-            }
-#pragma unroll
+            // outside its tile (array drifted since the sort): read the mesh directly.  Rare:
+            // the addresses are formed per read and the loops stay loops, so that this branch
+            // holds no registers beside the staged path's (index tables per dimension cost the
+            // order-4 kernel 12 B of scratch per lane)
+#pragma unroll 1
             for (int i = 0; i < 2; i++)
-#pragma unroll
+#pragma unroll 1
                 for (int j = 0; j < 2; j++) {
                     double wij = wx[i] * wy[j];
-#pragma unroll
+#pragma unroll 1
                     for (int k = 0; k < 2; k++) {
                         auto phi = [&](int da, int db, int dc) {
-                            return mesh[ix[H + i + da] + iy[H + j + db] + iz[H + k + dc]];
+                            return mesh[cg_xlayer(xm, (i64)(ga + i + da), N) * ny * pad +
+                                        (i64)wrap(gb + j + db, Ni) * pad + wrap(gc + k + dc, Ni)];
                         };
                         double fx, fy, fz;
                         force_cell<ORDER>(phi, c1, c2, fx, fy, fz);
@@ -917,7 +915,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
                     atomicOr(prep.err_flags, (unsigned)CG_ERR_BUCKET_OVERFLOW);
                 }
             }
-            if (prep.mom2_out) {
+            if (MOM2) {
                 // analysis.measure(component, 'v_rms') (analysis.py:3902-3910) of the momenta
                 // this pass leaves: the sum of a batch's |mom|^2 over the wave's lanes, carried
                 // on in scalar registers (the values are dead by now: no register of the
@@ -933,8 +931,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(
             }
         }
     }
-    if (FUSED && prep.mom2_out && (threadIdx.x & 63) == 0)
-        prep.mom2_out[8 * (i64)blockIdx.x + (threadIdx.x >> 6)] = __hiloint2double(m2_hi, m2_lo);
+    // (the wave's index from a scalar read of the lane index: kept in a vector register across
+    // the loop it was the pass's one spilled value)
+    if (FUSED && MOM2 && (threadIdx.x & 63) == 0)
+        prep.mom2_out[8 * (i64)blockIdx.x + (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6)] =
+            __hiloint2double(m2_hi, m2_lo);
 }
 
 // the wavefronts' partial sums added in a fixed order: 256 workgroups each sum a slice (256 strided
@@ -962,6 +963,7 @@ static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsign
     auto kern = k_gather_kick_tiled<ORDER, T, 0>;
     auto kern_prep = k_gather_kick_tiled<ORDER, T, 1>;
     auto kern_fused = k_gather_kick_tiled<ORDER, T, 2>;
+    auto kern_fused_m2 = k_gather_kick_tiled<ORDER, T, 2, true>;
     // the attribute belongs to the function ON A DEVICE: once per device of this process
     static bool attr_set[64] = {};
     const int dev = c->p.device & 63;
@@ -972,6 +974,8 @@ static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsign
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CG_HIP(hipFuncSetAttribute((const void *)kern_fused,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CG_HIP(hipFuncSetAttribute((const void *)kern_fused_m2,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev] = true;
     }
     unsigned nt = (unsigned)c->ntiles;
@@ -979,7 +983,7 @@ static int launch_gather(cg_ctx *c, const double *pos, double *mom, const unsign
     plain.order = prep ? prep->order : tile_order_args(c);
     const unsigned nblocks = nt + plain.order.cap;
     if (prep && prep->start_out)
-        hipLaunchKernelGGL(kern_fused, dim3(nblocks), dim3(512), lds, c->stream, pos, mom, tile_offset,
+        hipLaunchKernelGGL(prep->mom2_out ? kern_fused_m2 : kern_fused, dim3(nblocks), dim3(512), lds, c->stream, pos, mom, tile_offset,
                            c->mesh, c->N, c->ny, c->pad, c->p.nghosts, c->tiles.nty, nt, c->xmap,
                            c->geom_gather, c1, c2, factor, *prep);
     else if (prep)
@@ -1063,7 +1067,8 @@ int cgk_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i64 n,
     if (rc) return rc;
     CG_LAUNCH_CHECK();
     if (fs && c->mom2_sum_out) {
-        const i64 nparts = 8 * ((i64)c->ntiles + (i64)tile_order_args(c).cap);
+        // (the cap the pass was LAUNCHED with: tile_order_args() reads a word the device updates)
+        const i64 nparts = 8 * ((i64)c->ntiles + (i64)prep_args.order.cap);
         // (the first 256 doubles of the partials' buffer past its nparts entries take stage one)
         double *stage = c->mom2_partial + nparts;
         hipLaunchKernelGGL(k_sum_partials, dim3(256), dim3(256), 0, c->stream, c->mom2_partial,
