@@ -976,21 +976,48 @@ extern "C" int cg_cic_indices(cg_ctx *c, const double *pos, int64_t n, int for_g
     return cgk_cic_indices(c, pos, n, for_gather, idx_out);
 }
 
-extern "C" int cg_shortrange_cells(cg_ctx *c, const double *pos, int64_t n, int64_t nt,
-                                   double tile_extent, uint32_t *order_out,
-                                   uint32_t *offset_out, double *pos_sorted_out) {
+static int shortrange_cells_checks(cg_ctx *c, const void *pos, int64_t n, int64_t nt,
+                                   double tile_extent, const void *order_out,
+                                   const void *offset_out, const void *pos_sorted_out) {
     CG_CHECK(c && offset_out && (n == 0 || (pos && order_out && pos_sorted_out)),
              "cg_shortrange_cells: null argument");
     CG_CHECK(nt >= 4, "The global gravity tiling needs to have at least 4 tiles across the box in "
                       "every direction (species.py:3971); got %lld", (long long)nt);
     CG_CHECK(nt <= 512 && n < (1ll << 32), "cg_shortrange_cells: size out of range");
     // the sweeps take the tile extent from the box (species.py:607-609): a list made with another
-    // one would put a particle on a tile border into one tile here and into its neighbour there
-    CG_CHECK(tile_extent == c->p.boxsize / (double)nt,
-             "cg_shortrange_cells: tile_extent must be boxsize/nt (%.17g), got %.17g",
-             c->p.boxsize / (double)nt, tile_extent);
-    return cgk_shortrange_cells(c, pos, n, nt, tile_extent, order_out, offset_out,
-                                pos_sorted_out);
+    // one would put a particle on a tile border into one tile here and into its neighbour there.
+    // The list is made with boxsize/nt itself; the argument only has to agree with it (4 ulp: a
+    // caller may have formed it as boxsize*(1/nt)).
+    const double ext = c->p.boxsize / (double)nt;
+    CG_CHECK(fabs(tile_extent - ext) <= 4 * 2.220446049250313e-16 * ext,
+             "cg_shortrange_cells: tile_extent must be boxsize/nt (%.17g), got %.17g", ext,
+             tile_extent);
+    return 0;
+}
+
+extern "C" int cg_shortrange_cells(cg_ctx *c, const double *pos, int64_t n, int64_t nt,
+                                   double tile_extent, uint32_t *order_out,
+                                   uint32_t *offset_out, double *pos_sorted_out) {
+    if (shortrange_cells_checks(c, pos, n, nt, tile_extent, order_out, offset_out, pos_sorted_out))
+        return 1;
+    return cgk_shortrange_cells(c, pos, n, nt, c->p.boxsize / (double)nt, order_out, offset_out,
+                                pos_sorted_out, nullptr, nullptr, 0, nullptr, nullptr);
+}
+
+extern "C" int cg_shortrange_cells_rungs(cg_ctx *c, const double *pos, int64_t n, int64_t nt,
+                                         double tile_extent, const int8_t *rung,
+                                         const int8_t *rung_jumped, int lowest_active_rung,
+                                         uint32_t *order_out, uint32_t *offset_out,
+                                         double *pos_sorted_out, uint32_t *nact_out,
+                                         int8_t *rung_jumped_sorted_out) {
+    if (shortrange_cells_checks(c, pos, n, nt, tile_extent, order_out, offset_out, pos_sorted_out))
+        return 1;
+    CG_CHECK(nact_out && (n == 0 || (rung && rung_jumped && rung_jumped_sorted_out)),
+             "cg_shortrange_cells_rungs: null argument");
+    return cgk_shortrange_cells(c, pos, n, nt, c->p.boxsize / (double)nt, order_out, offset_out,
+                                pos_sorted_out, (const signed char *)rung,
+                                (const signed char *)rung_jumped, lowest_active_rung, nact_out,
+                                (signed char *)rung_jumped_sorted_out);
 }
 
 static int sweep_cells_checks(cg_ctx *c, const void *a, const void *b, const void *d,
@@ -1023,7 +1050,7 @@ extern "C" int cg_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted,
         return 1;
     return cgk_shortrange_sweep_cells(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted,
                                       offset_s, nt, table, r2_index_scaling, r2_max, factor,
-                                      nullptr, nullptr, nullptr, 0);
+                                      nullptr, nullptr, nullptr, 0, nullptr, nullptr);
 }
 
 extern "C" int cg_shortrange_sweep_cells_rungs(
@@ -1040,7 +1067,25 @@ extern "C" int cg_shortrange_sweep_cells_rungs(
     return cgk_shortrange_sweep_cells(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted,
                                       offset_s, nt, table, r2_index_scaling, r2_max, 0.0, factors,
                                       (const signed char *)rung_r,
-                                      (const signed char *)rung_jumped_r, lowest_active_rung);
+                                      (const signed char *)rung_jumped_r, lowest_active_rung,
+                                      nullptr, nullptr);
+}
+
+extern "C" int cg_shortrange_sweep_cells_active(
+    cg_ctx *c, const double *pos_r_sorted, const uint32_t *order_r, const uint32_t *offset_r,
+    const uint32_t *nact_r, const int8_t *rung_jumped_sorted_r, double *dmom_r,
+    const double *pos_s_sorted, const uint32_t *offset_s, int64_t nt, const double *table,
+    int64_t tablesize, double r2_index_scaling, double r2_max, const double *factors,
+    const int8_t *rung_r, const int8_t *rung_jumped_r, int lowest_active_rung) {
+    if (sweep_cells_checks(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted, offset_s,
+                           table, nt, tablesize, r2_index_scaling, r2_max))
+        return 1;
+    CG_CHECK(factors && nact_r, "cg_shortrange_sweep_cells_active: null argument");
+    return cgk_shortrange_sweep_cells(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted,
+                                      offset_s, nt, table, r2_index_scaling, r2_max, 0.0, factors,
+                                      (const signed char *)rung_r,
+                                      (const signed char *)rung_jumped_r, lowest_active_rung,
+                                      nact_r, (const signed char *)rung_jumped_sorted_r);
 }
 
 extern "C" int cg_shortrange_stats(cg_ctx *c, int enable, uint64_t *out) {
@@ -1070,9 +1115,11 @@ extern "C" int cg_shortrange_tiles(cg_ctx *c, const double *pos, int64_t n, int6
     CG_CHECK(nt >= 4, "The global gravity tiling needs to have at least 4 tiles across the box in "
                       "every direction (species.py:3971); got %lld", (long long)nt);
     CG_CHECK(nt <= 1024 && n < (1ll << 32), "cg_shortrange_tiles: size out of range");
-    CG_CHECK(tile_extent == c->p.boxsize / (double)nt,
+    CG_CHECK(fabs(tile_extent - c->p.boxsize / (double)nt) <=
+                 4 * 2.220446049250313e-16 * (c->p.boxsize / (double)nt),
              "cg_shortrange_tiles: tile_extent must be boxsize/nt (%.17g), got %.17g",
              c->p.boxsize / (double)nt, tile_extent);
+    tile_extent = c->p.boxsize / (double)nt;
     return cgk_shortrange_tiles(c, pos, n, nt, tile_extent, (const signed char *)rung,
                                 lowest_active_rung, order_out, offset_out, pos_sorted_out);
 }

@@ -204,7 +204,9 @@ int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *i
              double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out,
              int drift, double dt_over_mass, int use_prepared);
 int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
-                         unsigned *order, unsigned *offset, double *pos_sorted);
+                         unsigned *order, unsigned *offset, double *pos_sorted,
+                         const signed char *rung, const signed char *rung_jumped,
+                         int lowest_active, unsigned *nact, signed char *rj_sorted);
 int cgk_shortrange_sparse(cg_ctx *c, const double *pos_r, const i64 *active, int K, double *dmom_r,
                           const double *pos_s, i64 n_s, const double *table,
                           double r2_index_scaling, double r2_max, double factor,
@@ -214,7 +216,8 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                                const unsigned *off_s, i64 nt, const double *table,
                                double r2_index_scaling, double r2_max, double factor,
                                const double *factors, const signed char *rung,
-                               const signed char *rung_jumped, int lowest_active);
+                               const signed char *rung_jumped, int lowest_active,
+                               const unsigned *nact_r, const signed char *rj_sorted_r);
 int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
                          const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
                          const unsigned *off_s, i64 nt, const double *table,

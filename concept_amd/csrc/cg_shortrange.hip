@@ -19,6 +19,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "cg_internal.h"
 
@@ -52,6 +53,10 @@ struct SrParams {
     unsigned long long *stats;
     // the table entries a pair in range can ask for: 0 .. (int)(r2_max * r2_index_scaling)
     int table_n;
+    // receivers' list with the active particles first in every cell (cgk_shortrange_cells with
+    // rungs): nact[cell] of them, rj_sorted[row] = their jumped rung index (null = plain list)
+    const unsigned *nact;
+    const signed char *rj_sorted;
 };
 struct SrCount {
     unsigned tests = 0, hits = 0, trips = 0;
@@ -112,30 +117,48 @@ __device__ __forceinline__ unsigned sr_cell(const double *__restrict__ pos, i64 
 // workgroup then issues ONE device atomic per cell it met.  Particles in any other order still
 // sort correctly (up to 1024 distinct cells fit the table: one per particle).
 constexpr int kSrHashSlots = 2048, kSrPerThread = 4;
+// ACT (a sub-step of the rung loop, main.py:1347-1624, that kicks the rungs >= lowest_active
+// only): inside every cell the particles on active rungs come FIRST, nact[cell] of them — the
+// list by tile AND rung of the reference (species.py tiles_rungs_N) in the sweep's layout.  A
+// receiver group is then the first nact rows of its two cells, known from two words per cell:
+// no pass over the tiles' rungs, no gathers of rung[order[row]] in front of every chunk.  The
+// rows' jumped rung indices (what selects a receiver's factor, gravity.py:318-349) are written
+// in list order beside the positions.
 struct SrHash {
     unsigned key[kSrHashSlots], cnt[kSrHashSlots];
 };
-__device__ __forceinline__ void sr_hash_clear(SrHash &H) {
+struct SrHashAct : SrHash {
+    unsigned act[kSrHashSlots];
+};
+template <class H_>
+__device__ __forceinline__ void sr_hash_clear(H_ &H) {
+    constexpr bool ACT = sizeof(H_) > sizeof(SrHash);
     for (int i = threadIdx.x; i < kSrHashSlots; i += 256) {
         H.key[i] = 0xffffffffu;
         H.cnt[i] = 0;
+        if constexpr (ACT) H.act[i] = 0;
     }
 }
-// returns the slot of `key`; rank = how many of the workgroup's particles took it before
-__device__ __forceinline__ unsigned sr_hash_insert(SrHash &H, unsigned key, unsigned &rank) {
+// returns the slot of `key`
+__device__ __forceinline__ unsigned sr_hash_slot(SrHash &H, unsigned key) {
     unsigned slot = (key * 2654435761u) >> (32 - 11);
     for (;;) {
         const unsigned old = atomicCAS(&H.key[slot], 0xffffffffu, key);
         if (old == 0xffffffffu || old == key) break;
         slot = (slot + 1) & (kSrHashSlots - 1);
     }
-    rank = atomicAdd(&H.cnt[slot], 1u);
     return slot;
 }
+struct SrActive {  // (ACT) which particles are receivers of this sub-step
+    const signed char *rung, *rung_jumped;
+    int lowest;
+};
+template <bool ACT>
 __global__ __launch_bounds__(256) void k_sr_cell_histogram(const double *__restrict__ pos, i64 n,
                                                            double inv, double ext, unsigned nt,
-                                                           unsigned *__restrict__ count) {
-    __shared__ SrHash H;
+                                                           unsigned *__restrict__ count,
+                                                           SrActive A, unsigned *__restrict__ nact) {
+    __shared__ std::conditional_t<ACT, SrHashAct, SrHash> H;
     sr_hash_clear(H);
     __syncthreads();
     const i64 base = (i64)blockIdx.x * (256 * kSrPerThread);
@@ -143,71 +166,110 @@ __global__ __launch_bounds__(256) void k_sr_cell_histogram(const double *__restr
     for (int u = 0; u < kSrPerThread; u++) {
         const i64 p = base + threadIdx.x + 256 * u;
         if (p < n) {
-            unsigned rank;
-            sr_hash_insert(H, sr_cell(pos, p, inv, ext, nt), rank);
+            const unsigned slot = sr_hash_slot(H, sr_cell(pos, p, inv, ext, nt));
+            atomicAdd(&H.cnt[slot], 1u);
+            if constexpr (ACT)
+                if (A.rung[p] >= A.lowest) atomicAdd(&H.act[slot], 1u);
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kSrHashSlots; i += 256)
-        if (H.cnt[i]) atomicAdd(&count[H.key[i]], H.cnt[i]);
+        if (H.cnt[i]) {
+            atomicAdd(&count[H.key[i]], H.cnt[i]);
+            if constexpr (ACT)
+                if (H.act[i]) atomicAdd(&nact[H.key[i]], H.act[i]);
+        }
 }
+// cursor: rows handed out so far per cell (ACT: to the active particles; cursor_i: to the others,
+// whose rows follow the cell's nact active ones)
+template <bool ACT>
 __global__ __launch_bounds__(256) void k_sr_cell_scatter(const double *__restrict__ pos, i64 n,
                                                          double inv, double ext, unsigned nt,
                                                          const unsigned *__restrict__ offset,
                                                          unsigned *__restrict__ cursor,
                                                          unsigned *__restrict__ order,
-                                                         double *__restrict__ pos_sorted) {
-    __shared__ SrHash H;
+                                                         double *__restrict__ pos_sorted,
+                                                         SrActive A, const unsigned *__restrict__ nact,
+                                                         unsigned *__restrict__ cursor_i,
+                                                         signed char *__restrict__ rj_sorted) {
+    __shared__ std::conditional_t<ACT, SrHashAct, SrHash> H;
     sr_hash_clear(H);
     __syncthreads();
     const i64 base = (i64)blockIdx.x * (256 * kSrPerThread);
     unsigned slot[kSrPerThread], rank[kSrPerThread];
+    bool act[kSrPerThread];
     double x[kSrPerThread], y[kSrPerThread], z[kSrPerThread];
 #pragma unroll
     for (int u = 0; u < kSrPerThread; u++) {
         const i64 p = base + threadIdx.x + 256 * u;
-        slot[u] = 0, rank[u] = 0;
+        slot[u] = 0, rank[u] = 0, act[u] = false;
         if (p < n) {
             x[u] = pos[3 * p], y[u] = pos[3 * p + 1], z[u] = pos[3 * p + 2];
-            slot[u] = sr_hash_insert(H, sr_cell(pos, p, inv, ext, nt), rank[u]);
+            slot[u] = sr_hash_slot(H, sr_cell(pos, p, inv, ext, nt));
+            if constexpr (ACT) act[u] = A.rung[p] >= A.lowest;
+            // the particle's rank among the workgroup's (active | other) particles of its cell
+            bool taken = false;
+            if constexpr (ACT)
+                if (act[u]) rank[u] = atomicAdd(&H.act[slot[u]], 1u), taken = true;
+            if (!taken) rank[u] = atomicAdd(&H.cnt[slot[u]], 1u);
         }
     }
     __syncthreads();
     // a slot's first row in the list: the cell's offset + what earlier workgroups reserved
-    for (int i = threadIdx.x; i < kSrHashSlots; i += 256)
-        if (H.cnt[i]) H.cnt[i] = offset[H.key[i]] + atomicAdd(&cursor[H.key[i]], H.cnt[i]);
+    for (int i = threadIdx.x; i < kSrHashSlots; i += 256) {
+        const unsigned key = H.key[i];
+        if constexpr (ACT) {
+            if (H.act[i]) H.act[i] = offset[key] + atomicAdd(&cursor[key], H.act[i]);
+            if (H.cnt[i]) H.cnt[i] = offset[key] + nact[key] + atomicAdd(&cursor_i[key], H.cnt[i]);
+        } else {
+            if (H.cnt[i]) H.cnt[i] = offset[key] + atomicAdd(&cursor[key], H.cnt[i]);
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < kSrPerThread; u++) {
         const i64 p = base + threadIdx.x + 256 * u;
         if (p < n) {
-            const i64 q = (i64)H.cnt[slot[u]] + rank[u];
+            unsigned first = H.cnt[slot[u]];
+            if constexpr (ACT)
+                if (act[u]) first = H.act[slot[u]];
+            const i64 q = (i64)first + rank[u];
             order[q] = (unsigned)p;
             pos_sorted[3 * q] = x[u];
             pos_sorted[3 * q + 1] = y[u];
             pos_sorted[3 * q + 2] = z[u];
+            if constexpr (ACT) rj_sorted[q] = A.rung_jumped[p];
         }
     }
 }
 
 int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
-                         unsigned *order, unsigned *offset, double *pos_sorted) {
+                         unsigned *order, unsigned *offset, double *pos_sorted,
+                         const signed char *rung, const signed char *rung_jumped,
+                         int lowest_active, unsigned *nact, signed char *rj_sorted) {
     const double eps = 2.220446049250313e-16;
     double inv = (1 / tile_extent) * (1 - 2 * eps);
     i64 ncells = 8 * nt * nt * nt;
-    if ((size_t)(8 * (ncells + 1)) > c->sr_tmp_bytes) {
+    const bool act = nact != nullptr;
+    const size_t words = (size_t)(ncells + 1) * (act ? 3 : 2);
+    if (4 * words > c->sr_tmp_bytes) {
         CG_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(c->sr_tmp);
         c->sr_tmp = nullptr;
-        CG_HIP(hipMalloc(&c->sr_tmp, 8 * (ncells + 1)));
-        c->sr_tmp_bytes = 8 * (ncells + 1);
+        c->sr_tmp_bytes = 0;
+        CG_HIP(hipMalloc(&c->sr_tmp, 4 * words));
+        c->sr_tmp_bytes = 4 * words;
     }
-    unsigned *count = (unsigned *)c->sr_tmp, *cursor = count + (ncells + 1);
-    CG_HIP(hipMemsetAsync(c->sr_tmp, 0, 8 * (ncells + 1), c->stream));
+    unsigned *count = (unsigned *)c->sr_tmp, *cursor = count + (ncells + 1),
+             *cursor_i = cursor + (ncells + 1);
+    CG_HIP(hipMemsetAsync(c->sr_tmp, 0, 4 * words, c->stream));
+    if (act) CG_HIP(hipMemsetAsync(nact, 0, 4 * (size_t)ncells, c->stream));
+    const SrActive A{rung, rung_jumped, lowest_active};
     i64 blocks = (n + 256 * kSrPerThread - 1) / (256 * kSrPerThread);
     if (n > 0) {
-        hipLaunchKernelGGL(k_sr_cell_histogram, dim3((unsigned)blocks), dim3(256), 0, c->stream,
-                           pos, n, inv, tile_extent, (unsigned)nt, count);
+        hipLaunchKernelGGL(act ? k_sr_cell_histogram<true> : k_sr_cell_histogram<false>,
+                           dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n, inv,
+                           tile_extent, (unsigned)nt, count, A, nact);
         CG_LAUNCH_CHECK();
     }
     size_t need = 0;
@@ -223,8 +285,10 @@ int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
     CG_HIP(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp, need, count, offset, (int)(ncells + 1),
                                             c->stream));
     if (n > 0) {
-        hipLaunchKernelGGL(k_sr_cell_scatter, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos,
-                           n, inv, tile_extent, (unsigned)nt, offset, cursor, order, pos_sorted);
+        hipLaunchKernelGGL(act ? k_sr_cell_scatter<true> : k_sr_cell_scatter<false>,
+                           dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n, inv,
+                           tile_extent, (unsigned)nt, offset, cursor, order, pos_sorted, A, nact,
+                           cursor_i, rj_sorted);
         CG_LAUNCH_CHECK();
     }
     // what the dense tiles' sweep wants to know about this list, while it is being made
@@ -417,18 +481,25 @@ struct SrChunk {
 };
 // (RUNGS: the instantiation for particles on adaptive rungs — the plain sweep carries none of it:
 // with the packing below in one kernel the single-rung sweep measured 7.84 against 7.62 ms)
-template <bool RUNGS>
+// RUNGS 2 (ACT): the list has the active particles first in each of the group's two cells — the
+// group's receivers are the rows rbeg + k (k < n0) and rbeg + gap + k (the second cell's), `base`
+// and `rend` count k from rbeg; nothing of the per-particle rung arrays is read.
+// PACK: a plain list swept for a subset of the rungs (RUNGS 1, lowest_active > 0) — the 2 x 2
+// blocks' instantiation only; the 4 x 2 blocks are launched for sweeps in which every rung is
+// active and carry none of it (with it they spilled 12 B per lane at their 64 registers).
+template <int RUNGS, bool PACK>
 __device__ __forceinline__ SrChunk sr_chunk_load(unsigned base, unsigned rend, int lane,
                                                  const double *__restrict__ pos_r,
                                                  const unsigned *__restrict__ order_r,
-                                                 const SrParams &P) {
+                                                 const SrParams &P, unsigned rbeg = 0,
+                                                 unsigned n0 = 0, unsigned gap = 0) {
     SrChunk c;
     c.pi = 0;
     c.factor = P.factor;
     c.xi = c.yi = c.zi = 0;
     const unsigned cand = min(64u, rend - base);  // this chunk's rows of the sorted order
     unsigned qi = base;
-    if (RUNGS && P.lowest_active > 0) {
+    if (RUNGS == 1 && PACK && P.lowest_active > 0) {
         // With rungs only the receivers on an active rung take part (gravity.py:318-349 through
         // the tiles' active rungs): they are packed to the front — lane l of the active ones
         // hands its row to lane rank(l) — so that R counts them alone and every one of them
@@ -476,12 +547,14 @@ __device__ __forceinline__ SrChunk sr_chunk_load(unsigned base, unsigned rend, i
     c.rl = lane - c.sub * c.R;
     c.active = c.sub < c.S;
     qi = base + c.rl;  // receiver's row in the sorted order
+    if (RUNGS == 2) qi += qi - rbeg >= n0 ? gap : 0u;
     if (c.active) {
         c.pi = order_r[qi];
         c.xi = pos_r[3 * (i64)qi];
         c.yi = pos_r[3 * (i64)qi + 1];
         c.zi = pos_r[3 * (i64)qi + 2];
-        if (RUNGS) c.factor = P.factors[P.rung_jumped[c.pi]];  // (every rung is active)
+        if (RUNGS == 1) c.factor = P.factors[P.rung_jumped[c.pi]];  // (every rung is active)
+        if (RUNGS == 2) c.factor = P.factors[P.rj_sorted[qi]];
     }
     return c;
 }
@@ -553,7 +626,9 @@ constexpr int sb_cap(int bx) { return bx == 4 ? 1856 : 1344; }
 // (WRAP: one more staged double per supplier, and every column in two pieces)
 constexpr size_t sb_lds_bytes(int bx, bool tab, bool wrap) {
     return sizeof(double) * ((wrap ? 4 : 3) * (sb_cap(bx) + kSrSlack) + (tab ? kSbTable : 0)) +
-           sizeof(unsigned) * ((wrap ? 8 : 3) * sb_cols(bx) + 4 * sb_waves(bx));
+           // (the 4 x 2 blocks with the table: 81,792 B — two workgroups fill a CU's 160 KB to
+           // within 256 B; the sub-steps' group tables are the 2 x 2 blocks' alone)
+           sizeof(unsigned) * ((wrap ? 8 : 3) * sb_cols(bx) + (bx == 2 ? 8 : 4) * sb_waves(bx));
 }
 // Which tiles a workgroup takes.  Plain: the block (bx, by) of the interior's (nt - 2)^2 tiles
 // in x and y, tile tc of its nt - 2 in z.  WRAP: the tiles on the faces of the box in blocks of
@@ -611,7 +686,7 @@ static unsigned sb_wrap_blocks(unsigned nt) {
     return nt * ((nt + kSbY - 1) / kSbY) + nt * nbx + 2 * nbx * nby;
 }
 
-template <int BX, bool RUNGS, bool STATS, bool TABLDS, bool WRAP>
+template <int BX, int RUNGS, bool STATS, bool TABLDS, bool WRAP>
 __global__ __launch_bounds__(64 * sb_waves(BX)) __attribute__((amdgpu_waves_per_eu(BX == 4 ? 8 : 4, 8))) void
 k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
                   const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
@@ -626,8 +701,11 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
     double *sx = sb_lds, *sy = sx + kLen, *sz = sy + kLen, *soz = sz + kLen,
            *stab = soz + (WRAP ? kLen : 0);
     unsigned *p_beg = (unsigned *)(stab + (TABLDS ? kSbTable : 0)), *p_cnt = p_beg + kPieces,
-             *p_off = p_cnt + kPieces, *grp_n = p_off + kPieces, *grp_b = grp_n + 2 * kSbWaves;
-    int *p_oz = (int *)(grp_b + 2 * kSbWaves);  // (WRAP) a piece's image in z: -1, 0, +1 boxes
+             *p_off = p_cnt + kPieces, *grp_n = p_off + kPieces, *grp_b = grp_n + 2 * kSbWaves,
+             *grp_n0 = grp_b + 2 * kSbWaves, *grp_gap = grp_n0 + 2 * kSbWaves;  // (ACT: BX = 2)
+    int *p_oz = (int *)(grp_gap + 2 * kSbWaves);  // (WRAP) a piece's image in z: -1, 0, +1 boxes
+    static_assert(RUNGS != 2 || BX == 2, "the active-first lists are swept in 2 x 2 blocks");
+    constexpr bool ACT = RUNGS == 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = P.nt, nc = 2 * nt;
@@ -642,7 +720,10 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
     // receiver, taken by the dense tiles' sweep) has no receivers.
     // (scalars selected by the group number, not arrays indexed by it: those end up in scratch
     // memory and take the wave-uniformity of everything derived from them with them)
+    // (ACT: the active rows of the group's two cells — n0 of the first, then `gap` rows of its
+    // inactive particles, then the second cell's; rend counts the active ones from rbeg)
     unsigned rbeg0 = 0, rend0 = 0, rbeg1 = 0, rend1 = 0;
+    unsigned n00 = 0, gap0 = 0, n01 = 0, gap1 = 0;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int g = wave + kSbWaves * h, gx = g / (2 * kSbY), gy = g % (2 * kSbY);
@@ -654,9 +735,18 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
         const unsigned rcell =
             ((unsigned)wrapc(2 * ta0 + gx) * nc + (unsigned)wrapc(2 * tb0 + gy)) * nc + 2 * tc;
         if (take) {
-            const unsigned rb = __builtin_amdgcn_readfirstlane(off_r[rcell]),
-                           re = __builtin_amdgcn_readfirstlane(off_r[rcell + 2]);
-            if (h == 0) rbeg0 = rb, rend0 = re; else rbeg1 = rb, rend1 = re;
+            const unsigned rb = __builtin_amdgcn_readfirstlane(off_r[rcell]);
+            unsigned re, n0 = 0, gap = 0;
+            if (ACT) {
+                const unsigned b1 = __builtin_amdgcn_readfirstlane(off_r[rcell + 1]);
+                n0 = __builtin_amdgcn_readfirstlane(P.nact[rcell]);
+                gap = b1 - rb - n0;
+                re = rb + n0 + __builtin_amdgcn_readfirstlane(P.nact[rcell + 1]);
+            } else {
+                re = __builtin_amdgcn_readfirstlane(off_r[rcell + 2]);
+            }
+            if (h == 0) rbeg0 = rb, rend0 = re, n00 = n0, gap0 = gap;
+            else rbeg1 = rb, rend1 = re, n01 = n0, gap1 = gap;
         }
     }
     if (lane == 0) {
@@ -664,6 +754,10 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
         grp_n[wave + kSbWaves] = rend1 - rbeg1;
         grp_b[wave] = rbeg0;
         grp_b[wave + kSbWaves] = rbeg1;
+        if (ACT) {
+            grp_n0[wave] = n00, grp_n0[wave + kSbWaves] = n01;
+            grp_gap[wave] = gap0, grp_gap[wave + kSbWaves] = gap1;
+        }
     }
     // supplier pieces: column (cx, cy) of the 12 x 8 around the block, cells 2 tc - 2 .. 2 tc + 3
     // (WRAP: cut in two where the column wraps around the box in z — piece kSbCols + column is
@@ -698,7 +792,7 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
     SrChunk ch = {};
     double d0 = 0, d1 = 0, d2 = 0;
     if (rend0 > rbeg0) {
-        ch = sr_chunk_load<RUNGS>(rbeg0, rend0, lane, pos_r, order_r, P);
+        ch = sr_chunk_load<RUNGS, BX == 2>(rbeg0, rend0, lane, pos_r, order_r, P, rbeg0, n00, gap0);
         if (ch.active && ch.sub == 0) {
             d0 = dmom_r[3 * (i64)ch.pi];
             d1 = dmom_r[3 * (i64)ch.pi + 1];
@@ -736,10 +830,14 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
         if (g0 >= 0) {
             rbeg0 = __builtin_amdgcn_readfirstlane(grp_b[g0]);
             rend0 = rbeg0 + __builtin_amdgcn_readfirstlane(grp_n[g0]);
+            if (ACT) n00 = __builtin_amdgcn_readfirstlane(grp_n0[g0]),
+                     gap0 = __builtin_amdgcn_readfirstlane(grp_gap[g0]);
         }
         if (g1 >= 0) {
             rbeg1 = __builtin_amdgcn_readfirstlane(grp_b[g1]);
             rend1 = rbeg1 + __builtin_amdgcn_readfirstlane(grp_n[g1]);
+            if (ACT) n01 = __builtin_amdgcn_readfirstlane(grp_n0[g1]),
+                     gap1 = __builtin_amdgcn_readfirstlane(grp_gap[g1]);
         }
     }
     auto reach = [gm, all_groups](int col) {  // column (cx, cy) is within reach of groups gx in
@@ -822,10 +920,11 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
         for (int h = 0; h < 2; h++) {
             const int g = h ? g1 : g0, gx = g / (2 * kSbY), gy = g % (2 * kSbY);
             const unsigned rbeg = h ? rbeg1 : rbeg0, rend = h ? rend1 : rend0;
+            const unsigned n0 = h ? n01 : n00, gap = h ? gap1 : gap0;
             const bool simple = one_window && rend - rbeg <= 64;  // one chunk, one window
             for (unsigned base = rbeg; base < rend; base += 64) {
                 if (h || base != rbeg0 || w0 || g0 != g_first) {
-                    ch = sr_chunk_load<RUNGS>(base, rend, lane, pos_r, order_r, P);
+                    ch = sr_chunk_load<RUNGS, BX == 2>(base, rend, lane, pos_r, order_r, P, rbeg, n0, gap);
                     if (simple && ch.active && ch.sub == 0) {
                         d0 = dmom_r[3 * (i64)ch.pi];
                         d1 = dmom_r[3 * (i64)ch.pi + 1];
@@ -1015,16 +1114,38 @@ int cgk_shortrange_sparse(cg_ctx *c, const double *pos_r, const i64 *active, int
     return 0;
 }
 
+// the instantiation for (shape, rungs mode, statistics, table in LDS, across the faces)
+typedef void (*SbKernel)(const double *, const unsigned *, const unsigned *, double *,
+                         const double *, const unsigned *, const double *, SrParams);
+template <int BX, bool TABLDS, bool WRAP>
+static SbKernel sb_kernel(int mode, bool stats) {
+    switch (mode) {
+        case 0: return stats ? k_sr_sweep_blocks<BX, 0, true, TABLDS, WRAP> : k_sr_sweep_blocks<BX, 0, false, TABLDS, WRAP>;
+        case 1: return stats ? k_sr_sweep_blocks<BX, 1, true, TABLDS, WRAP> : k_sr_sweep_blocks<BX, 1, false, TABLDS, WRAP>;
+        default:
+            if constexpr (BX == 2)  // (the sub-steps' shape)
+                return stats ? k_sr_sweep_blocks<BX, 2, true, TABLDS, WRAP> : k_sr_sweep_blocks<BX, 2, false, TABLDS, WRAP>;
+            else
+                return nullptr;
+    }
+}
+
+// nact_r, rj_sorted_r: the receivers' list was made with the active particles first
+// (cgk_shortrange_cells with this rung array and this lowest active rung); null: a plain list
 int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
                                const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
                                const unsigned *off_s, i64 nt, const double *table,
                                double r2_index_scaling, double r2_max, double factor,
                                const double *factors, const signed char *rung,
-                               const signed char *rung_jumped, int lowest_active) {
+                               const signed char *rung_jumped, int lowest_active,
+                               const unsigned *nact_r, const signed char *rj_sorted_r) {
     SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt,
                factors,      rung,             rung_jumped, lowest_active, nullptr, nullptr,
-               (int)(r2_max * r2_index_scaling) + 1};
-    if (rung && lowest_active > 0) {
+               (int)(r2_max * r2_index_scaling) + 1, nullptr, nullptr};
+    const bool partial = rung && lowest_active > 0;
+    const bool act = partial && nact_r && rj_sorted_r;
+    if (act) P.nact = nact_r, P.rj_sorted = rj_sorted_r;
+    if (partial && !act) {
         // which tiles have a receiver on an active rung (the others leave at once)
         const size_t ntl = (size_t)nt * nt * nt;
         if (c->sr_tile_active_cap < ntl) {
@@ -1059,13 +1180,12 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
         CG_HIP(hipStreamCreateWithFlags(&c->sr_streams[0], hipStreamNonBlocking));
         CG_HIP(hipEventCreateWithFlags(&c->sr_join[0], hipEventDisableTiming));
     }
-    const bool rungs = rung != nullptr;
+    const int mode = !rung ? 0 : (act ? 2 : 1);
     P.stats = c->sr_stats;
     {
         CG_HIP(hipEventRecord(c->sr_fork, c->stream));
         CG_HIP(hipStreamWaitEvent(c->sr_streams[0], c->sr_fork, 0));
-        auto faces = rungs ? (P.stats ? k_sr_sweep_blocks<2, true, true, false, true> : k_sr_sweep_blocks<2, true, false, false, true>)
-                           : (P.stats ? k_sr_sweep_blocks<2, false, true, false, true> : k_sr_sweep_blocks<2, false, false, false, true>);
+        SbKernel faces = sb_kernel<2, false, true>(mode, P.stats != nullptr);
         hipLaunchKernelGGL(faces, dim3(sb_wrap_blocks((unsigned)nt)), dim3(64 * sb_waves(2)),
                            sb_lds_bytes(2, false, true), c->sr_streams[0], pos_r_sorted, order_r,
                            off_r, dmom_r, pos_s_sorted, off_s, table, P);
@@ -1075,17 +1195,13 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
     {
         // 4 x 2 tiles per workgroup; 2 x 2 for the sub-steps of the upper rungs and for boxes of
         // fewer than 6 tiles a side
-        const bool small = m < 4 || (rungs && lowest_active > 0);
+        const bool small = m < 4 || partial;
         const bool lds = !small && P.table_n <= kSbTable;
         const int bx = small ? 2 : 4;
         const unsigned nbx = (m + bx - 1) / bx, nby = (m + kSbY - 1) / kSbY;
-        auto blocks =
-            small ? (rungs ? (P.stats ? k_sr_sweep_blocks<2, true, true, false, false> : k_sr_sweep_blocks<2, true, false, false, false>)
-                           : (P.stats ? k_sr_sweep_blocks<2, false, true, false, false> : k_sr_sweep_blocks<2, false, false, false, false>))
-            : rungs ? (P.stats ? (lds ? k_sr_sweep_blocks<4, true, true, true, false> : k_sr_sweep_blocks<4, true, true, false, false>)
-                               : (lds ? k_sr_sweep_blocks<4, true, false, true, false> : k_sr_sweep_blocks<4, true, false, false, false>))
-                    : (P.stats ? (lds ? k_sr_sweep_blocks<4, false, true, true, false> : k_sr_sweep_blocks<4, false, true, false, false>)
-                               : (lds ? k_sr_sweep_blocks<4, false, false, true, false> : k_sr_sweep_blocks<4, false, false, false, false>));
+        SbKernel blocks = small ? sb_kernel<2, false, false>(mode, P.stats != nullptr)
+                          : lds ? sb_kernel<4, true, false>(mode, P.stats != nullptr)
+                                : sb_kernel<4, false, false>(mode, P.stats != nullptr);
         const size_t bytes = sb_lds_bytes(bx, lds, false);
         // (the attribute belongs to the function ON A DEVICE; setting it again costs nothing
         // next to a sweep)

@@ -647,13 +647,27 @@ class PotentialMesh:
 
     # -- debug / parity -----------------------------------------------------
     # -- P3M short range -----------------------------------------------------------
-    def shortrange_cells(self, pos, nt, tile_extent):
+    def shortrange_cells(self, pos, nt, tile_extent, rungs=None):
         """Cell list at half-tile granularity with the positions copied in cell order
-        (cg_shortrange_cells): (order, offset, pos_sorted)."""
+        (cg_shortrange_cells): (order, offset, pos_sorted).  rungs = (rung int8, rung_jumped
+        int8, lowest_active_rung) with lowest_active_rung > 0 makes the list of a sub-step
+        (cg_shortrange_cells_rungs): the particles on active rungs first in every cell, and the
+        tuple continues with (nact, rung_jumped_sorted, rung, lowest_active_rung) — what
+        shortrange_sweep_cells() needs to take the active rows as its receivers."""
         n = self._check_particles(pos)
         order = torch.empty(max(n, 1), dtype=torch.int32, device=pos.device)
         offset = torch.empty(8*nt**3 + 1, dtype=torch.int32, device=pos.device)
         pos_sorted = torch.empty((max(n, 1), 3), dtype=torch.float64, device=pos.device)
+        if rungs is not None and rungs[2] > 0:
+            rung, rung_jumped, lowest = rungs
+            self._check_rungs(n, rung, rung_jumped)
+            nact = torch.empty(8*nt**3, dtype=torch.int32, device=pos.device)
+            rj_sorted = torch.empty(max(n, 1), dtype=torch.int8, device=pos.device)
+            check(_L.cg_shortrange_cells_rungs(
+                self._ctx, _ptr(pos), n, int(nt), float(tile_extent), _ptr(rung),
+                _ptr(rung_jumped), int(lowest), _ptr(order), _ptr(offset), _ptr(pos_sorted),
+                _ptr(nact), _ptr(rj_sorted)))
+            return order, offset, pos_sorted, nact, rj_sorted, rung, int(lowest)
         check(_L.cg_shortrange_cells(self._ctx, _ptr(pos), n, int(nt), float(tile_extent),
                                      _ptr(order), _ptr(offset), _ptr(pos_sorted)))
         return order, offset, pos_sorted
@@ -662,12 +676,13 @@ class PotentialMesh:
                                r2_max, factor, rungs=None):
         """The sweep over half-tile cells; cells_* from shortrange_cells().  `rungs` =
         (factors[3*N_rungs-1] CUDA float64, rung int8, rung_jumped int8, lowest_active_rung)
-        selects the adaptive-rung form (then `factor` is unused)."""
+        selects the adaptive-rung form (then `factor` is unused); a receivers' list made with
+        the active particles first (for these rungs) is swept by its active rows."""
         n = self._check_particles(dmom_r)
         if table.dtype != torch.float64 or not table.is_cuda:
             raise lib.ConceptGPUError('short-range table must be a float64 CUDA tensor')
-        order_r, off_r, pos_r = cells_r
-        _, off_s, pos_s = cells_s
+        order_r, off_r, pos_r = cells_r[:3]
+        _, off_s, pos_s = cells_s[:3]
         if rungs is None:
             check(_L.cg_shortrange_sweep_cells(
                 self._ctx, _ptr(pos_r), _ptr(order_r), _ptr(off_r), _ptr(dmom_r), _ptr(pos_s),
@@ -676,6 +691,17 @@ class PotentialMesh:
             return
         factors, rung, rung_jumped, lowest = rungs
         self._check_rungs(n, rung, rung_jumped)
+        if len(cells_r) > 3:
+            nact, rj_sorted, rung_list, lowest_list = cells_r[3:]
+            if rung_list.data_ptr() != rung.data_ptr() or lowest_list != int(lowest):
+                raise lib.ConceptGPUError(
+                    'shortrange_sweep_cells: the receivers\' list was made for other rungs')
+            check(_L.cg_shortrange_sweep_cells_active(
+                self._ctx, _ptr(pos_r), _ptr(order_r), _ptr(off_r), _ptr(nact), _ptr(rj_sorted),
+                _ptr(dmom_r), _ptr(pos_s), _ptr(off_s), int(nt), _ptr(table), table.numel(),
+                float(r2_index_scaling), float(r2_max), _ptr(factors), _ptr(rung),
+                _ptr(rung_jumped), int(lowest)))
+            return
         check(_L.cg_shortrange_sweep_cells_rungs(
             self._ctx, _ptr(pos_r), _ptr(order_r), _ptr(off_r), _ptr(dmom_r), _ptr(pos_s),
             _ptr(off_s), int(nt), _ptr(table), table.numel(), float(r2_index_scaling),

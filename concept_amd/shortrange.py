@@ -133,7 +133,11 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
         """the component's cell list (built when a sweep first asks for it: a sub-step that
         kicks a handful of particles needs none, see sweep() below)"""
         if id(c) not in cells:
-            cells[id(c)] = build(c.pos, nt, tile_extent)
+            # a sub-step (lowest active rung > 0): the particles on active rungs first in every
+            # cell, so that the sweep takes its receivers without looking at the rungs again
+            rungs = ((c.rung_indices, c.rung_indices_jumped, c.lowest_active_rung)
+                     if c.use_rungs and c in receivers else None)
+            cells[id(c)] = build(c.pos, nt, tile_extent, rungs)
             supp_cells.setdefault(id(c), cells[id(c)])
         return cells[id(c)]
     for c in involved:

@@ -312,7 +312,8 @@ int cg_tile_info(const cg_ctx *ctx, int64_t info[3]);
  * Tiling.sort (species.py:775-780), then which half of the tile in each dimension — and
  * writes, in cell order (z fastest): order_out[n] = particle indices, pos_sorted_out[3n] =
  * their positions (the sweep stages supplier runs with plain coalesced loads), offset_out[
- * (2 nt)^3 + 1] = first entry of each cell.  tile_extent must be boxsize/nt (species.py:607-609).
+ * (2 nt)^3 + 1] = first entry of each cell.  tile_extent must be boxsize/nt (species.py:607-609)
+ * to within 4 ulp (the sweeps take boxsize/nt themselves; any other extent is refused).
  * cg_shortrange_sweep_cells[_rungs]: x_ji, r2 and the table index bit-identical to the
  * reference's, a receiver only meeting supplier cells at most two away:
  * dmom_r[order_r[q]] += ... for every receiver row q.  The force range
@@ -353,6 +354,34 @@ int cg_shortrange_sweep_cells_rungs(cg_ctx *ctx, const double *pos_r_sorted,
                                     const double *factors /*DEV 3*N_rungs-1*/,
                                     const int8_t *rung_r /*DEV*/,
                                     const int8_t *rung_jumped_r /*DEV*/, int lowest_active_rung);
+
+/* The list for a SUB-STEP of the rung loop (driftkick_short, main.py:1347-1624: the rungs >=
+ * lowest_active_rung are kicked, the others only supply): as cg_shortrange_cells, with the
+ * particles on active rungs FIRST inside every cell — the reference's lists by tile and rung
+ * (species.py tiles_rungs_N, interactions.py:1688-1761) in the sweep's layout.  nact_out[cell] =
+ * how many of the cell's rows are active, rung_jumped_sorted_out[row] = rung_jumped[order[row]]
+ * (what selects the row's factor).  cg_shortrange_sweep_cells_active is
+ * cg_shortrange_sweep_cells_rungs for a receivers' list made this way WITH THE SAME rung array
+ * and lowest active rung: its receiver groups are the first nact rows of their cells — no pass
+ * over the tiles' rungs, no gathers through order_r in front of the pair loop.  The sums are
+ * those of the _rungs entry up to the order of the additions.  (As a suppliers' list it is a
+ * plain list: the order of the rows inside a cell does not matter there.) */
+int cg_shortrange_cells_rungs(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, int64_t nt,
+                              double tile_extent, const int8_t *rung /*DEV n*/,
+                              const int8_t *rung_jumped /*DEV n*/, int lowest_active_rung,
+                              uint32_t *order_out /*DEV n*/, uint32_t *offset_out /*DEV (2nt)^3+1*/,
+                              double *pos_sorted_out /*DEV 3n*/, uint32_t *nact_out /*DEV (2nt)^3*/,
+                              int8_t *rung_jumped_sorted_out /*DEV n*/);
+int cg_shortrange_sweep_cells_active(cg_ctx *ctx, const double *pos_r_sorted,
+                                     const uint32_t *order_r, const uint32_t *offset_r,
+                                     const uint32_t *nact_r /*DEV*/,
+                                     const int8_t *rung_jumped_sorted_r /*DEV*/, double *dmom_r,
+                                     const double *pos_s_sorted, const uint32_t *offset_s,
+                                     int64_t nt, const double *table /*DEV*/, int64_t tablesize,
+                                     double r2_index_scaling, double r2_max,
+                                     const double *factors /*DEV 3*N_rungs-1*/,
+                                     const int8_t *rung_r /*DEV*/,
+                                     const int8_t *rung_jumped_r /*DEV*/, int lowest_active_rung);
 
 /* The particles listed by TILE (Tiling.sort, species.py:775-780; z fastest) — the reference's
  * `tiles[tile]` lists, what the parity tests compare tile by tile: order_out[m],

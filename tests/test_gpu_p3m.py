@@ -713,6 +713,87 @@ def test_sparse_shortrange_equals_the_cells_sweep(k):
     mesh.close()
 
 
+@pytest.mark.parametrize('nt_box', [(64, 64.0), (24, 24.0)])
+def test_active_first_cell_list_and_its_sweep(nt_box):
+    """cg_shortrange_cells_rungs / cg_shortrange_sweep_cells_active (the list of a sub-step:
+    the particles on active rungs first in every cell — the reference's lists by tile and rung,
+    species.py tiles_rungs_N, interactions.py:1688-1761): the list's invariants, and its sweep
+    against cg_shortrange_sweep_cells_rungs on a plain list for every lowest active rung —
+    receivers that are not the suppliers, receivers on the box faces and corners (the blocks
+    that reach across the faces), a box of 4 tiles a side (every tile on a face), factors by
+    the jumped rung index, momentum buffers accumulated, inactive particles untouched."""
+    import torch
+    from concept_amd import commons, shortrange
+    from concept_amd.lib import ConceptGPUError
+    from concept_amd.mesh import PotentialMesh
+    N, L = nt_box
+    mesh = PotentialMesh(N, L)
+    rng = np.random.default_rng(606)
+    n_r, n_s = 30000 if N == 64 else 4000, 41003 if N == 64 else 5003
+    pos_r = rng.uniform(0, L, (n_r, 3))
+    pos_s = rng.uniform(0, L, (n_s, 3))
+    pos_s[:3000] = np.mod(L - 0.5 + rng.normal(0, 0.7, (3000, 3)), L)   # a clump on the corner
+    pos_r[:6] = [[1e-9, L - 1e-9, 0.3], [L - 0.2, 0.1, L/2], [L/3, L/2, L - 1e-7],
+                 [L - 1e-9, L - 1e-9, L - 1e-9], [0.0, 0.0, 0.0], [L/2, 1e-8, L - 1e-8]]
+    pos_r_t = torch.as_tensor(pos_r, device='cuda')
+    pos_s_t = torch.as_tensor(pos_s, device='cuda')
+    scale = 1.25*L/N
+    rng_ = 4.5*scale
+    nt = int(L/rng_*(1 + commons.machine_ϵ))
+    table, maxr2 = shortrange.get_shortrange_table(0.03*L/27, scale, rng_, 4096, 'spline',
+                                                   pos_r_t.device)
+    N_rungs = 8
+    rung = rng.choice(5, n_r, p=[0.5, 0.25, 0.13, 0.1, 0.02]).astype(np.int8)
+    rung[:6] = 4
+    jumped = rung.copy()
+    flag = rng.random(n_r) < 0.05
+    jumped[flag & (rung < 4)] += 2*N_rungs       # up
+    jumped[flag & (rung == 4)] += N_rungs        # down
+    factors = torch.as_tensor(rng.uniform(0.5, 2.0, 3*N_rungs - 1), device='cuda')
+    rung_t, jumped_t = torch.as_tensor(rung, device='cuda'), torch.as_tensor(jumped, device='cuda')
+    base = torch.as_tensor(rng.normal(0, 1e-3, (n_r, 3)), device='cuda')
+    plain_r = mesh.shortrange_cells(pos_r_t, nt, L/nt)
+    cs = mesh.shortrange_cells(pos_s_t, nt, L/nt)
+    assert len(mesh.shortrange_cells(pos_r_t, nt, L/nt, (rung_t, jumped_t, 0))) == 3
+    for la in (1, 2, 3, 4, 5):
+        act_r = mesh.shortrange_cells(pos_r_t, nt, L/nt, (rung_t, jumped_t, la))
+        order, offset, pos_sorted, nact, rj_sorted = (t.cpu().numpy() for t in act_r[:5])
+        # the same cells with the same members as the plain list
+        assert np.array_equal(offset, plain_r[1].cpu().numpy())
+        assert np.array_equal(np.sort(order[:n_r]), np.arange(n_r))
+        assert np.array_equal(pos_sorted[:n_r], pos_r[order[:n_r]])
+        assert np.array_equal(rj_sorted[:n_r], jumped[order[:n_r]])
+        cell_of_row = np.repeat(np.arange(offset.size - 1), np.diff(offset))
+        rank = np.arange(n_r) - offset[cell_of_row]
+        active_row = rung[order[:n_r]] >= la
+        assert np.array_equal(active_row, rank < nact[cell_of_row])   # the active ones first
+        assert nact.sum() == (rung >= la).sum()
+        ref, got = base.clone(), base.clone()
+        mesh.shortrange_sweep_cells(plain_r, ref, cs, nt, table, 4095/maxr2, rng_**2, 0.0,
+                                    (factors, rung_t, jumped_t, la))
+        mesh.shortrange_sweep_cells(act_r, got, cs, nt, table, 4095/maxr2, rng_**2, 0.0,
+                                    (factors, rung_t, jumped_t, la))
+        inactive = rung_t < la
+        assert bool((got[inactive] == base[inactive]).all())
+        if la == 5:
+            assert bool((got == base).all())
+            continue
+        kick = (ref - base)[~inactive]
+        assert float(kick.abs().max()) > 0
+        assert float((got - ref).abs().max()) <= 1e-12*float(kick.pow(2).mean().sqrt())
+        # as a suppliers' list it is a plain list
+        got2 = base.clone()
+        mesh.shortrange_sweep_cells(plain_r, got2, act_r, nt, table, 4095/maxr2, rng_**2, 1.3)
+        ref2 = base.clone()
+        mesh.shortrange_sweep_cells(plain_r, ref2, plain_r, nt, table, 4095/maxr2, rng_**2, 1.3)
+        assert float((got2 - ref2).abs().max()) <= 1e-12*float((ref2 - base).pow(2).mean().sqrt())
+        # a list made for other rungs is refused
+        with pytest.raises(ConceptGPUError, match='other rungs'):
+            mesh.shortrange_sweep_cells(act_r, got, cs, nt, table, 4095/maxr2, rng_**2, 0.0,
+                                        (factors, rung_t, jumped_t, la + 1))
+    mesh.close()
+
+
 def test_dense_sweep_on_the_randomised_and_multi_component_cases(monkeypatch):
     """The dense tiles' sweep (Hilbert sub-cell order, supplier quads culled by their boxes;
     here from 3 particles per tile on instead of 64) through the cases the cells sweep is fuzzed

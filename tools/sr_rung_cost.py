@@ -41,18 +41,30 @@ def timed(f, reps=5):
     return (time.perf_counter() - t0)/reps*1e3
 
 
+# (particle memory in the order of the mesh tiles, as the time loop keeps it)
+key = (pos/16).floor().long()
+pos = pos[torch.argsort((key[:, 0]*64 + key[:, 1])*64 + key[:, 2])].contiguous()
 lst = mesh.shortrange_cells(pos, nt, L/nt)
 print(f'{dist}: cell list {timed(lambda: mesh.shortrange_cells(pos, nt, L/nt)):.3f} ms', flush=True)
 for la in range(5):
     act = int((rung >= la).sum())
-    f = lambda: mesh.shortrange_sweep_cells(lst, dm, lst, nt, table, 4095/maxr2, rng_**2, 0.0,  # noqa: E731
-                                            (factors, rung, rung, la))
-    t = timed(f)
-    mesh.shortrange_stats(True)
-    f()
-    torch.cuda.synchronize()
-    st = mesh.shortrange_stats(False)
-    tests, hits, trips = (a + b for a, b in zip(st['cells'], st['dense']))
-    print(f'{dist}: lowest active rung {la}: {act} receivers, sweep {t:.3f} ms; {tests:.3e} tests '
-          f'({tests/max(act, 1):.0f} per receiver), {trips:.3e} trips, lane use '
-          f'{tests/max(64*trips, 1):.3f}', flush=True)
+    for kind in ('plain', 'active first'):
+        if kind == 'active first':
+            if la == 0:
+                continue
+            t_l = timed(lambda: mesh.shortrange_cells(pos, nt, L/nt, (rung, rung, la)))
+            rl = mesh.shortrange_cells(pos, nt, L/nt, (rung, rung, la))
+        else:
+            t_l, rl = float('nan'), lst
+        f = lambda: mesh.shortrange_sweep_cells(rl, dm, lst, nt, table, 4095/maxr2, rng_**2, 0.0,  # noqa: E731
+                                                (factors, rung, rung, la))
+        t = timed(f)
+        mesh.shortrange_stats(True)
+        f()
+        torch.cuda.synchronize()
+        st = mesh.shortrange_stats(False)
+        tests, hits, trips = (a + b for a, b in zip(st['cells'], st['dense']))
+        print(f'{dist}: lowest active rung {la} ({kind} list{"" if t_l != t_l else f", made in {t_l:.3f} ms"}): '
+              f'{act} receivers, sweep {t:.3f} ms; {tests:.3e} tests '
+              f'({tests/max(act, 1):.0f} per receiver), {trips:.3e} trips, lane use '
+              f'{tests/max(64*trips, 1):.3f}', flush=True)
