@@ -453,6 +453,7 @@ extern "C" int cg_destroy(cg_ctx *c) {
         if (c->sr_join[i]) (void)hipEventDestroy(c->sr_join[i]);
     }
     if (c->sr_fork) (void)hipEventDestroy(c->sr_fork);
+    (void)hipFree(c->sr_active);
     delete c;
     return 0;
 }
@@ -1050,7 +1051,7 @@ extern "C" int cg_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted,
         return 1;
     return cgk_shortrange_sweep_cells(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted,
                                       offset_s, nt, table, r2_index_scaling, r2_max, factor,
-                                      nullptr, nullptr, nullptr, 0, nullptr, nullptr);
+                                      nullptr, nullptr, nullptr, 0, nullptr, nullptr, -1);
 }
 
 extern "C" int cg_shortrange_sweep_cells_rungs(
@@ -1068,7 +1069,7 @@ extern "C" int cg_shortrange_sweep_cells_rungs(
                                       offset_s, nt, table, r2_index_scaling, r2_max, 0.0, factors,
                                       (const signed char *)rung_r,
                                       (const signed char *)rung_jumped_r, lowest_active_rung,
-                                      nullptr, nullptr);
+                                      nullptr, nullptr, -1);
 }
 
 extern "C" int cg_shortrange_sweep_cells_active(
@@ -1076,16 +1077,19 @@ extern "C" int cg_shortrange_sweep_cells_active(
     const uint32_t *nact_r, const int8_t *rung_jumped_sorted_r, double *dmom_r,
     const double *pos_s_sorted, const uint32_t *offset_s, int64_t nt, const double *table,
     int64_t tablesize, double r2_index_scaling, double r2_max, const double *factors,
-    const int8_t *rung_r, const int8_t *rung_jumped_r, int lowest_active_rung) {
+    const int8_t *rung_r, const int8_t *rung_jumped_r, int lowest_active_rung,
+    int64_t n_active_max) {
     if (sweep_cells_checks(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted, offset_s,
                            table, nt, tablesize, r2_index_scaling, r2_max))
         return 1;
     CG_CHECK(factors && nact_r, "cg_shortrange_sweep_cells_active: null argument");
+    CG_CHECK(n_active_max < (1ll << 31), "cg_shortrange_sweep_cells_active: n_active_max");
     return cgk_shortrange_sweep_cells(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted,
                                       offset_s, nt, table, r2_index_scaling, r2_max, 0.0, factors,
                                       (const signed char *)rung_r,
                                       (const signed char *)rung_jumped_r, lowest_active_rung,
-                                      nact_r, (const signed char *)rung_jumped_sorted_r);
+                                      nact_r, (const signed char *)rung_jumped_sorted_r,
+                                      lowest_active_rung > 0 ? n_active_max : -1);
 }
 
 extern "C" int cg_shortrange_stats(cg_ctx *c, int enable, uint64_t *out) {

@@ -123,6 +123,8 @@ struct cg_ctx {
     // side streams of the short-range sweep (its interior and face launches are independent and
     // run side by side: a clustered box otherwise waits for the few dense tiles of each launch
     // in turn), created at the first sweep
+    unsigned *sr_active = nullptr;   // [0] count, [64..] the cells that hold an active receiver
+    size_t sr_active_bytes = 0;
     hipStream_t sr_streams[3] = {nullptr, nullptr, nullptr};
     hipEvent_t sr_fork = nullptr, sr_join[3] = {nullptr, nullptr, nullptr};
     unsigned long long *sr_stats = nullptr;   // cg_shortrange_stats: device counters while on
@@ -217,7 +219,8 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                                double r2_index_scaling, double r2_max, double factor,
                                const double *factors, const signed char *rung,
                                const signed char *rung_jumped, int lowest_active,
-                               const unsigned *nact_r, const signed char *rj_sorted_r);
+                               const unsigned *nact_r, const signed char *rj_sorted_r,
+                               i64 n_active_max);
 int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
                          const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
                          const unsigned *off_s, i64 nt, const double *table,

@@ -1114,6 +1114,178 @@ int cgk_shortrange_sparse(cg_ctx *c, const double *pos_r, const i64 *active, int
     return 0;
 }
 
+// ===========================================================================
+// A sub-step with FEW active receivers (the upper rungs of a base step's sub-steps: at 256^3 the
+// eight sub-steps that kick the highest of five rungs have 1 % of the particles active): the
+// blocks above stage ~1000 suppliers for a receiver or two and wait for a table look-up per
+// trip with nobody to hide it (1.2 ms for 6e7 pair tests).  Here the cells that hold an active
+// receiver are listed (k_sr_active_cells, from the nact words of the active-first list) and each
+// gets ONE wavefront: the 5 x 5 columns x 5 cells around the cell are 25 runs of the suppliers'
+// list (50 where the z range wraps around the box) read where they are — 16 lanes per run, four
+// runs per trip, nothing staged, no barrier.  Same pair arithmetic ((xi - xj) + offset, r2, table
+// index bit-identical to the reference's); a receiver's sum is reduced over the wave in a fixed
+// order.
+// ===========================================================================
+constexpr int kSaRuns = 52;  // 25 columns x 2 pieces, rounded up to whole trips of 4
+// (one atomic on the list's counter per 4096 cells: an atomic per wavefront — 94,000 of them on
+// ONE address at 256^3 — took 0.9 ms, three times the sweep it feeds)
+constexpr int kSaPerThread = 16;
+__global__ __launch_bounds__(256) void k_sr_active_cells(const unsigned *__restrict__ nact,
+                                                         unsigned ncells,
+                                                         unsigned *__restrict__ list,
+                                                         unsigned *__restrict__ count,
+                                                         unsigned cap) {
+    __shared__ unsigned w_tot[4], w_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave w of the workgroup takes 1024 consecutive cells, 64 at a time
+    const unsigned first = (blockIdx.x * 4u + (unsigned)wave) * (64u * kSaPerThread);
+    unsigned flags = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < kSaPerThread; i++) {
+        const unsigned c = first + 64u * i + lane;
+        const bool any = c < ncells && nact[c] != 0;
+        flags |= (unsigned)any << i;
+        total += (unsigned)__popcll(__ballot(any));
+    }
+    if (lane == 0) w_tot[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) w_base = atomicAdd(count, w_tot[0] + w_tot[1] + w_tot[2] + w_tot[3]);
+    __syncthreads();
+    unsigned off = w_base;
+    for (int w = 0; w < wave; w++) off += w_tot[w];
+#pragma unroll
+    for (int i = 0; i < kSaPerThread; i++) {
+        const bool any = flags >> i & 1u;
+        const unsigned long long m = __ballot(any);
+        const unsigned slot = off + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (any && slot < cap) list[slot] = first + 64u * i + lane;
+        off += (unsigned)__popcll(m);
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_sr_sweep_active_cells(
+    const double *__restrict__ pos_r, const unsigned *__restrict__ order_r,
+    const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
+    const double *__restrict__ pos_s, const unsigned *__restrict__ off_s,
+    const double *__restrict__ table, SrParams P, const unsigned *__restrict__ list,
+    const unsigned *__restrict__ nlist) {
+    __shared__ unsigned r_beg[4][kSaRuns], r_cnt[4][kSaRuns];
+    __shared__ int r_img[4][kSaRuns];  // the run's image: (ox + 1) | (oy + 1) << 2 | (oz + 1) << 4
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned idx = blockIdx.x * 4u + (unsigned)wave;
+    if (idx >= __builtin_amdgcn_readfirstlane((int)*nlist)) return;  // (no barrier below)
+    const unsigned cell = (unsigned)__builtin_amdgcn_readfirstlane((int)list[idx]);
+    const int nt = P.nt, nc = 2 * nt;
+    const int Z = (int)(cell % (unsigned)nc), Y = (int)((cell / (unsigned)nc) % (unsigned)nc),
+              X = (int)(cell / ((unsigned)nc * (unsigned)nc));
+    // (the dense tiles' sweep has taken the tile)
+    if (P.tile_active &&
+        !P.tile_active[((unsigned)(X >> 1) * nt + (unsigned)(Y >> 1)) * nt + (unsigned)(Z >> 1)])
+        return;
+    // the runs: slot = column (dx, dy) of the 5 x 5, + 25 for the piece beyond a z face
+    const bool zwrap = Z < 2 || Z + 2 >= nc;  // (uniform)
+    if (lane < kSaRuns) {
+        const int half = lane >= 25, col = lane - 25 * half;
+        unsigned beg = 0, cnt = 0;
+        int img = 1 | 1 << 2 | 1 << 4;
+        if (lane < 50 && (half == 0 || zwrap)) {
+            int gx = X + col / 5 - 2, gy = Y + col % 5 - 2;
+            int ox = 0, oy = 0, oz = 0;
+            if (gx < 0) { gx += nc; ox = 1; } else if (gx >= nc) { gx -= nc; ox = -1; }
+            if (gy < 0) { gy += nc; oy = 1; } else if (gy >= nc) { gy -= nc; oy = -1; }
+            const int z0 = Z - 2, z1 = Z + 2;  // inclusive
+            int a = z0, b = z1;
+            if (z0 < 0) {
+                if (half == 0) { a = z0 + nc; b = nc - 1; oz = 1; } else { a = 0; }
+            } else if (z1 >= nc) {
+                if (half == 0) { b = nc - 1; } else { a = 0; b = z1 - nc; oz = -1; }
+            }
+            const unsigned base = ((unsigned)gx * nc + (unsigned)gy) * nc;
+            beg = off_s[base + a];
+            cnt = off_s[base + b + 1] - beg;
+            img = (ox + 1) | (oy + 1) << 2 | (oz + 1) << 4;
+        }
+        r_beg[wave][lane] = beg;
+        r_cnt[wave][lane] = cnt;
+        r_img[wave][lane] = img;
+    }
+    const unsigned rb = (unsigned)__builtin_amdgcn_readfirstlane((int)off_r[cell]);
+    const int R = __builtin_amdgcn_readfirstlane((int)P.nact[cell]);
+    const int ntrips = zwrap ? kSaRuns / 4 : 7;  // (25 runs: 7 trips of 4)
+    const int slot0 = lane >> 4, k0 = lane & 15;
+    const double L = P.boxsize;
+    SrCount cnt;
+    for (int r = 0; r < R; r++) {
+        const i64 row = (i64)rb + r;
+        const double xi = pos_r[3 * row], yi = pos_r[3 * row + 1], zi = pos_r[3 * row + 2];
+        double ax = 0, ay = 0, az = 0;
+        // (a lane's loads of seven trips issued together before the first is used — 126 registers,
+        // four wavefronts per SIMD — measured slower than a trip at a time at eight: 6.5 against
+        // 4.4 ms for the 2 million receivers of the upper two rungs at 256^3)
+        for (int q = 0; q < ntrips; q++) {
+            const int slot = 4 * q + slot0;
+            const unsigned beg = r_beg[wave][slot], n = r_cnt[wave][slot];
+            const int img = r_img[wave][slot];
+            const double ox = (double)((img & 3) - 1) * L, oy = (double)((img >> 2 & 3) - 1) * L,
+                         oz = (double)((img >> 4 & 3) - 1) * L;
+            for (unsigned k = (unsigned)k0; __any(k < n); k += 16) {
+                const bool valid = k < n;
+                double t = 0.0, x = 0, y = 0, z = 0;
+                bool hit = false;
+                if (valid) {
+                    const i64 g = (i64)beg + k;
+                    x = (xi - pos_s[3 * g]) + ox;          // interactions.py:1787-1789,
+                    y = (yi - pos_s[3 * g + 1]) + oy;      // gravity.py:299-302
+                    z = (zi - pos_s[3 * g + 2]) + oz;
+                    const double r2 = x * x + y * y + z * z;   // gravity.py:306
+                    hit = r2 <= P.r2_max;                      // gravity.py:311
+                    if (hit) t = table[(unsigned)(int)(r2 * P.r2_index_scaling)];
+                }
+                if (STATS) {
+                    cnt.tests += (unsigned)__popcll(__ballot(valid));
+                    cnt.hits += (unsigned)__popcll(__ballot(hit));
+                    cnt.trips++;
+                }
+                ax = __builtin_fma(x, t, ax);
+                ay = __builtin_fma(y, t, ay);
+                az = __builtin_fma(z, t, az);
+            }
+        }
+        // the wave's lanes added in a fixed order (DPP: rows of 16, then the row totals)
+        auto wave_sum = [](double v) {
+#define SA_DPP_ADD(ctrl, rows)                                                                    \
+    do {                                                                                          \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rows, 0xf, false); \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rows, 0xf, false); \
+        v += __hiloint2double(hi_, lo_);                                                          \
+    } while (0)
+            SA_DPP_ADD(0x111, 0xf);
+            SA_DPP_ADD(0x112, 0xf);
+            SA_DPP_ADD(0x114, 0xf);
+            SA_DPP_ADD(0x118, 0xf);
+            SA_DPP_ADD(0x142, 0xa);
+            SA_DPP_ADD(0x143, 0xc);
+#undef SA_DPP_ADD
+            return v;  // (the total in lane 63)
+        };
+        ax = wave_sum(ax), ay = wave_sum(ay), az = wave_sum(az);
+        if (lane == 63) {
+            const i64 o = 3 * (i64)order_r[row];
+            const double f = P.factors[P.rj_sorted[row]];  // gravity.py:318-349
+            dmom_r[o] += ax * f;
+            dmom_r[o + 1] += ay * f;
+            dmom_r[o + 2] += az * f;
+        }
+    }
+    if (STATS && lane == 0) {
+        atomicAdd(&P.stats[0], (unsigned long long)cnt.tests);
+        atomicAdd(&P.stats[1], (unsigned long long)cnt.hits);
+        atomicAdd(&P.stats[2], (unsigned long long)cnt.trips);
+    }
+}
+
 // the instantiation for (shape, rungs mode, statistics, table in LDS, across the faces)
 typedef void (*SbKernel)(const double *, const unsigned *, const unsigned *, double *,
                          const double *, const unsigned *, const double *, SrParams);
@@ -1131,14 +1303,17 @@ static SbKernel sb_kernel(int mode, bool stats) {
 }
 
 // nact_r, rj_sorted_r: the receivers' list was made with the active particles first
-// (cgk_shortrange_cells with this rung array and this lowest active rung); null: a plain list
+// (cgk_shortrange_cells with this rung array and this lowest active rung); null: a plain list.
+// n_active_max >= 0: no more than that many receivers are active and the caller wants them swept
+// cell by cell (k_sr_sweep_active_cells) instead of in blocks of tiles
 int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsigned *order_r,
                                const unsigned *off_r, double *dmom_r, const double *pos_s_sorted,
                                const unsigned *off_s, i64 nt, const double *table,
                                double r2_index_scaling, double r2_max, double factor,
                                const double *factors, const signed char *rung,
                                const signed char *rung_jumped, int lowest_active,
-                               const unsigned *nact_r, const signed char *rj_sorted_r) {
+                               const unsigned *nact_r, const signed char *rj_sorted_r,
+                               i64 n_active_max) {
     SrParams P{c->p.boxsize, r2_index_scaling, r2_max, factor, (int)nt,
                factors,      rung,             rung_jumped, lowest_active, nullptr, nullptr,
                (int)(r2_max * r2_index_scaling) + 1, nullptr, nullptr};
@@ -1182,6 +1357,35 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
     }
     const int mode = !rung ? 0 : (act ? 2 : 1);
     P.stats = c->sr_stats;
+    if (act && n_active_max >= 0) {
+        // few active receivers: one wavefront per cell that holds one
+        const i64 ncells = 8 * nt * nt * nt;
+        const size_t need = 4 * ((size_t)n_active_max + 64);
+        if (need > c->sr_active_bytes) {
+            CG_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->sr_active);
+            c->sr_active = nullptr;
+            c->sr_active_bytes = 0;
+            CG_HIP(hipMalloc((void **)&c->sr_active, need));
+            c->sr_active_bytes = need;
+        }
+        unsigned *count = c->sr_active, *list = c->sr_active + 64;
+        CG_HIP(hipMemsetAsync(count, 0, 4, c->stream));
+        if (n_active_max > 0) {
+            hipLaunchKernelGGL(k_sr_active_cells,
+                               dim3((unsigned)((ncells + 256 * kSaPerThread - 1) / (256 * kSaPerThread))), dim3(256),
+                               0, c->stream, nact_r, (unsigned)ncells, list, count,
+                               (unsigned)n_active_max);
+            CG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(P.stats ? k_sr_sweep_active_cells<true> : k_sr_sweep_active_cells<false>,
+                               dim3((unsigned)((n_active_max + 3) / 4)), dim3(256), 0, c->stream,
+                               pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P,
+                               list, count);
+            CG_LAUNCH_CHECK();
+        }
+        if (take && cgk_shortrange_dense_join(c)) return 1;
+        return 0;
+    }
     {
         CG_HIP(hipEventRecord(c->sr_fork, c->stream));
         CG_HIP(hipStreamWaitEvent(c->sr_streams[0], c->sr_fork, 0));

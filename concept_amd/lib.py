@@ -90,7 +90,7 @@ SYMBOLS = {
     'cg_shortrange_cells_rungs': (_int, [_vp, _vp, _i64, _i64, _dbl, _vp, _vp, _int, _vp, _vp, _vp,
                                          _vp, _vp]),
     'cg_shortrange_sweep_cells_active': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                                                _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _int]),
+                                                _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _int, _i64]),
     'cg_shortrange_tiles': (_int, [_vp, _vp, _i64, _i64, _dbl, _vp, _int, _vp, _vp, _vp]),
     'cg_shortrange_stats': (_int, [_vp, _int, _vp]),
     'cg_set_momentum_sum': (_int, [_vp, _vp]),

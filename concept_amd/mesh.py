@@ -673,11 +673,13 @@ class PotentialMesh:
         return order, offset, pos_sorted
 
     def shortrange_sweep_cells(self, cells_r, dmom_r, cells_s, nt, table, r2_index_scaling,
-                               r2_max, factor, rungs=None):
+                               r2_max, factor, rungs=None, n_active=None):
         """The sweep over half-tile cells; cells_* from shortrange_cells().  `rungs` =
         (factors[3*N_rungs-1] CUDA float64, rung int8, rung_jumped int8, lowest_active_rung)
         selects the adaptive-rung form (then `factor` is unused); a receivers' list made with
-        the active particles first (for these rungs) is swept by its active rows."""
+        the active particles first (for these rungs) is swept by its active rows — cell by
+        cell instead of in blocks of tiles when `n_active` (an upper bound of the number of
+        active receivers) is given."""
         n = self._check_particles(dmom_r)
         if table.dtype != torch.float64 or not table.is_cuda:
             raise lib.ConceptGPUError('short-range table must be a float64 CUDA tensor')
@@ -700,7 +702,7 @@ class PotentialMesh:
                 self._ctx, _ptr(pos_r), _ptr(order_r), _ptr(off_r), _ptr(nact), _ptr(rj_sorted),
                 _ptr(dmom_r), _ptr(pos_s), _ptr(off_s), int(nt), _ptr(table), table.numel(),
                 float(r2_index_scaling), float(r2_max), _ptr(factors), _ptr(rung),
-                _ptr(rung_jumped), int(lowest)))
+                _ptr(rung_jumped), int(lowest), -1 if n_active is None else int(n_active)))
             return
         check(_L.cg_shortrange_sweep_cells_rungs(
             self._ctx, _ptr(pos_r), _ptr(order_r), _ptr(off_r), _ptr(dmom_r), _ptr(pos_s),
@@ -735,6 +737,10 @@ class PotentialMesh:
         return {'cells': tuple(int(v) for v in out[0:3]), 'dense': tuple(int(v) for v in out[3:6])}
 
     SHORTRANGE_SPARSE_MAX = 8
+    # the sweep by active cell is taken up to this fraction of the receivers on active rungs
+    # (tools/sr_rung_cost.py, 256^3 / 512^3: 0.35 against 1.23 ms at 0.9 %, 3.5 against 3.0 ms at
+    # 12 %; the two cross near 8 %)
+    SHORTRANGE_BY_CELL_MAX = 0.06
 
     def shortrange_sparse(self, pos_r, active, dmom_r, pos_s, table, r2_index_scaling, r2_max,
                           factor, rungs=None):

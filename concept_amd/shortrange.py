@@ -206,8 +206,15 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
                     rungs = (factors, rec.rung_indices, rec.rung_indices_jumped,
                              rec.lowest_active_rung)
                     rc = get_cells(rec)
+                    # few receivers on active rungs (one domain: rungs_N counts them): the
+                    # sweep by active cell
+                    n_active = None
+                    if not multi and rec.lowest_active_rung > 0:
+                        n_active = int(sum(rec.rungs_N[rec.lowest_active_rung:]))
+                        if n_active > mesh.SHORTRANGE_BY_CELL_MAX*rec.N_local:
+                            n_active = None
                     mesh.shortrange_sweep_cells(rc, rec.Δmom, supp_cells[id(sup)], nt, table,
-                                                scaling, r2_max, 0.0, rungs)
+                                                scaling, r2_max, 0.0, rungs, n_active)
                 else:
                     rc = get_cells(rec)
                     get_cells(sup)

@@ -365,7 +365,11 @@ int cg_shortrange_sweep_cells_rungs(cg_ctx *ctx, const double *pos_r_sorted,
  * and lowest active rung: its receiver groups are the first nact rows of their cells — no pass
  * over the tiles' rungs, no gathers through order_r in front of the pair loop.  The sums are
  * those of the _rungs entry up to the order of the additions.  (As a suppliers' list it is a
- * plain list: the order of the rows inside a cell does not matter there.) */
+ * plain list: the order of the rows inside a cell does not matter there.)
+ * n_active_max: -1, or an upper bound of the number of active receivers (the time loop knows
+ * the rung populations) with which the caller asks for the sweep by active CELL — one wavefront
+ * per cell that holds an active receiver, its 25 supplier columns read where they are — which is
+ * the faster one while a few per cent of the particles are active. */
 int cg_shortrange_cells_rungs(cg_ctx *ctx, const double *pos /*DEV 3n*/, int64_t n, int64_t nt,
                               double tile_extent, const int8_t *rung /*DEV n*/,
                               const int8_t *rung_jumped /*DEV n*/, int lowest_active_rung,
@@ -381,7 +385,8 @@ int cg_shortrange_sweep_cells_active(cg_ctx *ctx, const double *pos_r_sorted,
                                      double r2_index_scaling, double r2_max,
                                      const double *factors /*DEV 3*N_rungs-1*/,
                                      const int8_t *rung_r /*DEV*/,
-                                     const int8_t *rung_jumped_r /*DEV*/, int lowest_active_rung);
+                                     const int8_t *rung_jumped_r /*DEV*/, int lowest_active_rung,
+                                     int64_t n_active_max);
 
 /* The particles listed by TILE (Tiling.sort, species.py:775-780; z fastest) — the reference's
  * `tiles[tile]` lists, what the parity tests compare tile by tile: order_out[m],

@@ -773,14 +773,20 @@ def test_active_first_cell_list_and_its_sweep(nt_box):
                                     (factors, rung_t, jumped_t, la))
         mesh.shortrange_sweep_cells(act_r, got, cs, nt, table, 4095/maxr2, rng_**2, 0.0,
                                     (factors, rung_t, jumped_t, la))
+        # ... and cell by cell (one wavefront per cell that holds an active receiver)
+        got_c = base.clone()
+        mesh.shortrange_sweep_cells(act_r, got_c, cs, nt, table, 4095/maxr2, rng_**2, 0.0,
+                                    (factors, rung_t, jumped_t, la), int((rung >= la).sum()))
         inactive = rung_t < la
         assert bool((got[inactive] == base[inactive]).all())
+        assert bool((got_c[inactive] == base[inactive]).all())
         if la == 5:
-            assert bool((got == base).all())
+            assert bool((got == base).all()) and bool((got_c == base).all())
             continue
         kick = (ref - base)[~inactive]
         assert float(kick.abs().max()) > 0
         assert float((got - ref).abs().max()) <= 1e-12*float(kick.pow(2).mean().sqrt())
+        assert float((got_c - ref).abs().max()) <= 1e-12*float(kick.pow(2).mean().sqrt())
         # as a suppliers' list it is a plain list
         got2 = base.clone()
         mesh.shortrange_sweep_cells(plain_r, got2, act_r, nt, table, 4095/maxr2, rng_**2, 1.3)

@@ -1,5 +1,15 @@
 cd /root/repo
-for v in "" tools/_variants/noface.so tools/_variants/nointerior.so; do
-echo "== $v"
-CONCEPT_GPU_LIB=$v python tools/sr_rung_cost.py uniform 2>&1 | grep -v 'plain list' | tail -5 | cut -c1-110
-done
+python - <<'PY' 2>&1 | tail -45
+import cProfile, pstats, sys, io, runpy
+sys.argv = ['tools/soak_p3m.py', '0.04']
+pr = cProfile.Profile()
+pr.enable()
+try:
+    runpy.run_path('tools/soak_p3m.py', run_name='__main__')
+finally:
+    pr.disable()
+s = io.StringIO()
+ps = pstats.Stats(pr, stream=s).sort_stats('tottime')
+ps.print_stats(28)
+print(s.getvalue()[-5500:])
+PY

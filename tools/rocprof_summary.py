@@ -22,6 +22,23 @@ def main(path, out=None):
     for r in rows:
         lines.append('%-100s %6d %11.3f %10.4f %10.4f %10.4f %6.2f' % (
             r[0][:100], r[1], r[2], r[3], r[4], r[5], 100*r[2]/tot))
+    # how much of the trace's span the GPU had a kernel running (union of the kernels' intervals)
+    for db in dbs:
+        iv = sqlite3.connect(db).execute('select start, end from kernels order by start').fetchall()
+        if not iv:
+            continue
+        busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+        for a, b in iv[1:]:
+            if a > cur_e:
+                busy += cur_e - cur_s
+                cur_s, cur_e = a, b
+            else:
+                cur_e = max(cur_e, b)
+        busy += cur_e - cur_s
+        span = max(b for _, b in iv) - iv[0][0]
+        lines.append('# %s: kernels running %.1f ms of the %.1f ms between the first kernel\'s start '
+                     'and the last one\'s end (%.0f %%); summed kernel durations %.1f ms' % (
+                         os.path.basename(db), busy/1e6, span/1e6, 100.0*busy/span, tot))
     text = '\n'.join(lines)
     print(text)
     if out:

@@ -48,8 +48,8 @@ lst = mesh.shortrange_cells(pos, nt, L/nt)
 print(f'{dist}: cell list {timed(lambda: mesh.shortrange_cells(pos, nt, L/nt)):.3f} ms', flush=True)
 for la in range(5):
     act = int((rung >= la).sum())
-    for kind in ('plain', 'active first'):
-        if kind == 'active first':
+    for kind in ('plain', 'active first', 'by cell'):
+        if kind != 'plain':
             if la == 0:
                 continue
             t_l = timed(lambda: mesh.shortrange_cells(pos, nt, L/nt, (rung, rung, la)))
@@ -57,7 +57,8 @@ for la in range(5):
         else:
             t_l, rl = float('nan'), lst
         f = lambda: mesh.shortrange_sweep_cells(rl, dm, lst, nt, table, 4095/maxr2, rng_**2, 0.0,  # noqa: E731
-                                                (factors, rung, rung, la))
+                                                (factors, rung, rung, la),
+                                                act if kind == 'by cell' else None)
         t = timed(f)
         mesh.shortrange_stats(True)
         f()
