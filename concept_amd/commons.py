@@ -440,3 +440,16 @@ def softening_length(p, species, N):
 
 
 params = None
+
+
+def upload(values, device, dtype=None):
+    """a small host array as a CUDA tensor without waiting for the GPU: through pinned memory
+    (torch's caching host allocator hands the block out again only after the copy has run) —
+    torch.tensor(..., device='cuda') copies from pageable memory, which waits for everything
+    queued on the stream before it"""
+    import numpy as np
+    import torch
+    h = torch.from_numpy(np.ascontiguousarray(values, dtype=dtype or np.float64))
+    if torch.device(device).type != 'cuda':
+        return h.clone()
+    return h.pin_memory().to(device, non_blocking=True)

@@ -1172,6 +1172,36 @@ extern "C" int cg_apply_rung_jumps(cg_ctx *c, int8_t *rung, int8_t *rung_jumped,
     return cgk_apply_rung_jumps(c, (signed char *)rung, (signed char *)rung_jumped, n, N_rungs);
 }
 
+extern "C" int cg_substep_begin(cg_ctx *c, double *pos, const double *mom, double *dmom,
+                                const int8_t *rung, int8_t *rung_jumped, int64_t n, int do_drift,
+                                double dt_over_mass, int do_flag, int lowest_active_rung,
+                                const double *integrals_1, double rung_factor_up,
+                                double rung_factor_down, int N_rungs, int32_t *any_out) {
+    CG_CHECK(c && (n == 0 || ((!do_drift || (pos && mom)) &&
+                              (!do_flag || (dmom && rung && rung_jumped)))) &&
+                 (!do_flag || (integrals_1 && any_out)),
+             "cg_substep_begin: null argument");
+    CG_CHECK(N_rungs >= 1 && 3 * N_rungs - 1 <= CG_RUNG_TABLE_MAX, "cg_substep_begin: N_rungs = %d",
+             N_rungs);
+    return cgk_substep_begin(c, pos, mom, dmom, (const signed char *)rung,
+                             (signed char *)rung_jumped, n, do_drift, dt_over_mass, do_flag,
+                             lowest_active_rung, integrals_1, rung_factor_up, rung_factor_down,
+                             N_rungs, any_out);
+}
+extern "C" int cg_substep_end(cg_ctx *c, double *mom, double *dmom, int8_t *rung,
+                              int8_t *rung_jumped, int64_t n, int do_apply,
+                              int lowest_active_rung, const double *conversion_factors,
+                              int N_rungs, int64_t *counts) {
+    CG_CHECK(c && counts && (n == 0 || (rung && rung_jumped && (!do_apply || (mom && dmom)))) &&
+                 (!do_apply || conversion_factors),
+             "cg_substep_end: null argument");
+    CG_CHECK(N_rungs >= 1 && 3 * N_rungs - 1 <= CG_RUNG_TABLE_MAX, "cg_substep_end: N_rungs = %d",
+             N_rungs);
+    return cgk_substep_end(c, mom, dmom, (signed char *)rung, (signed char *)rung_jumped, n,
+                           do_apply, lowest_active_rung, conversion_factors, N_rungs,
+                           (long long *)counts);
+}
+
 extern "C" int cg_shortrange_sparse(cg_ctx *c, const double *pos_r, const int64_t *active, int k,
                                    double *dmom_r, const double *pos_s, int64_t n_s,
                                    const double *table, int64_t tablesize,

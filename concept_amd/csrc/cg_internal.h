@@ -250,6 +250,16 @@ int cgk_flag_rung_jumps(cg_ctx *c, const double *dmom, const signed char *rung,
                         int *any_out);
 int cgk_apply_rung_jumps(cg_ctx *c, signed char *rung, signed char *rung_jumped, i64 n,
                          int N_rungs);
+// (3 N_rungs - 1 entries of a rung table passed to a kernel by value)
+#define CG_RUNG_TABLE_MAX 64
+int cgk_substep_begin(cg_ctx *c, double *pos, const double *mom, double *dmom,
+                      const signed char *rung, signed char *rung_jumped, i64 n, int do_drift,
+                      double dt_over_mass, int do_flag, int lowest_active,
+                      const double *integrals_1, double rf_up, double rf_down, int N_rungs,
+                      int *any_out);
+int cgk_substep_end(cg_ctx *c, double *mom, double *dmom, signed char *rung,
+                    signed char *rung_jumped, i64 n, int do_apply, int lowest_active,
+                    const double *conversion_factors, int N_rungs, long long *counts);
 int cgk_rung_populations(cg_ctx *c, const signed char *rung, i64 n, int N_rungs, long long *counts);
 bool cgk_fft_supported(i64 N);
 int cgk_fft_dist_forward(cg_ctx *c, double *send_buf, i64 layer0, i64 nlayers);

@@ -7,6 +7,7 @@
 // All are streaming, one lane per particle; rung indices are the reference's
 // `signed char` arrays (int8), jumped indices carry +N_rungs (down) / +2 N_rungs (up).
 #include "cg_internal.h"
+#include "cg_tiles.h"
 
 #define CG_LAUNCH_CHECK()                                                                     \
     do {                                                                                      \
@@ -186,6 +187,140 @@ int cgk_apply_rung_jumps(cg_ctx *c, i8 *rung, i8 *rung_jumped, i64 n, int N_rung
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_apply_rung_jumps, dim3(nblocks(n)), dim3(256), 0, c->stream, rung,
                        rung_jumped, n, N_rungs);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// A sub-step of driftkick_short (main.py:1347-1624) in two passes over the particles instead of
+// seven.  Every kernel above is one lane per particle and touches only that particle's rows, so
+// running them back to back per particle gives the same values:
+//   begin: Component.drift (species.py:2179-2199) -> flag_rung_jumps -> nullify_Δ('mom')
+//   end:   apply_Δmom -> convert_Δmom_to_acc -> apply_rung_jumps -> set_rungs_N
+// The rung tables (3 N_rungs - 1 doubles) travel as kernel arguments: no upload, no wait.
+// ---------------------------------------------------------------------------
+struct RungTable {
+    double v[CG_RUNG_TABLE_MAX];
+};
+
+template <bool DRIFT, bool FLAG>
+__global__ __launch_bounds__(256) void k_substep_begin(double *__restrict__ pos,
+                                                       const double *__restrict__ mom,
+                                                       double *__restrict__ dmom,
+                                                       const i8 *__restrict__ rung,
+                                                       i8 *__restrict__ rung_jumped, i64 n,
+                                                       double dtm, double L, int lowest_active,
+                                                       RungTable integrals, double rf_up,
+                                                       double rf_down, int N_rungs,
+                                                       int *__restrict__ any_out) {
+    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (DRIFT) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) pos[3 * p + d] = ref_mod(pos[3 * p + d] + mom[3 * p + d] * dtm, L);
+    }
+    if (!FLAG) return;
+    const int r = rung[p];
+    if (r < lowest_active) return;  // (flag_rung_jumps and nullify_Δ: active rungs only)
+    // flag_rung_jumps, species.py:2476-2512 (k_flag_rung_jumps)
+    if (integrals.v[r] != 0) {
+        int ought = get_rung(dmom, p, r, rf_up, N_rungs);
+        if (ought > r) {
+            rung_jumped[p] = (i8)(r + 2 * N_rungs);
+            *any_out = 1;
+        } else if (integrals.v[r + N_rungs] != -1) {
+            ought = get_rung(dmom, p, r, rf_down, N_rungs);
+            if (ought < r) {
+                rung_jumped[p] = (i8)(r + N_rungs);
+                *any_out = 1;
+            }
+        }
+    }
+    // nullify_Δ('mom'), species.py:3717-3741
+    dmom[3 * p] = 0;
+    dmom[3 * p + 1] = 0;
+    dmom[3 * p + 2] = 0;
+}
+
+// (a fixed number of workgroups, every thread a strided share: the populations cost 8 atomics
+// per workgroup on 8 addresses, which one workgroup per 256 particles would turn into 65,000
+// per address at 256^3)
+constexpr int kSubstepEndBlocks = 2048;
+template <bool APPLY>
+__global__ __launch_bounds__(256) void k_substep_end(double *__restrict__ mom,
+                                                     double *__restrict__ dmom,
+                                                     i8 *__restrict__ rung,
+                                                     i8 *__restrict__ rung_jumped, i64 n,
+                                                     int lowest_active, RungTable conv,
+                                                     int N_rungs,
+                                                     unsigned long long *__restrict__ counts) {
+    __shared__ unsigned s_cnt[64];
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 p0 = (i64)blockIdx.x * blockDim.x; p0 < n; p0 += stride) {
+        const i64 p = p0 + threadIdx.x;
+        int r = 255;
+        if (p < n) {
+            r = rung[p];
+            const int j = rung_jumped[p];
+            if (APPLY && r >= lowest_active) {
+                const double f = conv.v[j];  // species.py:2311-2325 (no jump: j == r)
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const double dm = dmom[3 * p + d];
+                    mom[3 * p + d] += dm;      // apply_Δmom, species.py:2253-2266
+                    dmom[3 * p + d] = dm * f;  // convert_Δmom_to_acc
+                }
+            }
+            if (j >= N_rungs) {  // apply_rung_jumps, species.py:2536-2547
+                r += 2 * (j >= 2 * N_rungs) - 1;
+                rung[p] = (i8)r;
+                rung_jumped[p] = (i8)r;
+            }
+        }
+        // set_rungs_N, species.py:2560-2587
+        for (int q = 0; q < N_rungs && q < 64; q++) {
+            const unsigned c = (unsigned)__popcll(__ballot(r == q));
+            if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt[q], c);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)N_rungs && threadIdx.x < 64 && s_cnt[threadIdx.x])
+        atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
+int cgk_substep_begin(cg_ctx *c, double *pos, const double *mom, double *dmom, const i8 *rung,
+                      i8 *rung_jumped, i64 n, int do_drift, double dt_over_mass, int do_flag,
+                      int lowest_active, const double *integrals_1, double rf_up, double rf_down,
+                      int N_rungs, int *any_out) {
+    if (do_flag) CG_HIP(hipMemsetAsync(any_out, 0, sizeof(int), c->stream));
+    if (n == 0 || (!do_drift && !do_flag)) return 0;
+    RungTable T{};
+    if (do_flag)
+        for (int i = 0; i < 3 * N_rungs - 1; i++) T.v[i] = integrals_1[i];
+    auto kern = do_drift ? (do_flag ? k_substep_begin<true, true> : k_substep_begin<true, false>)
+                         : k_substep_begin<false, true>;
+    hipLaunchKernelGGL(kern, dim3(nblocks(n)), dim3(256), 0, c->stream, pos, mom, dmom, rung,
+                       rung_jumped, n, dt_over_mass, c->p.boxsize, lowest_active, T, rf_up, rf_down,
+                       N_rungs, any_out);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cgk_substep_end(cg_ctx *c, double *mom, double *dmom, i8 *rung, i8 *rung_jumped, i64 n,
+                    int do_apply, int lowest_active, const double *conversion_factors, int N_rungs,
+                    long long *counts) {
+    CG_HIP(hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)N_rungs, c->stream));
+    if (n == 0) return 0;
+    RungTable T{};
+    if (do_apply)
+        for (int i = 0; i < 3 * N_rungs - 1; i++) T.v[i] = conversion_factors[i];
+    const i64 want = (n + 255) / 256;
+    const unsigned blocks = (unsigned)(want < kSubstepEndBlocks ? want : kSubstepEndBlocks);
+    hipLaunchKernelGGL(do_apply ? k_substep_end<true> : k_substep_end<false>, dim3(blocks),
+                       dim3(256), 0, c->stream, mom, dmom, rung, rung_jumped, n, lowest_active, T,
+                       N_rungs, (unsigned long long *)counts);
     CG_LAUNCH_CHECK();
     return 0;
 }

@@ -801,6 +801,33 @@ class PotentialMesh:
                                     float(rf_down), int(N_rungs), _ptr(flag)))
         return bool(flag.item())
 
+    def substep_begin(self, pos, mom, dmom, rung, rung_jumped, dt_over_mass, flag, lowest_active_rung,
+                      integrals_1, rf_up, rf_down, N_rungs, any_out):
+        """cg_substep_begin: drift (dt_over_mass not None), then flag_rung_jumps + nullify_Δ
+        (flag) in one pass; integrals_1 a host array, any_out an int32 CUDA tensor read later."""
+        n = self._check_particles(pos)
+        self._check_rungs(n, rung, rung_jumped)
+        tab = (ctypes.c_double*(3*N_rungs - 1))(*[float(v) for v in integrals_1]) if flag else None
+        check(_L.cg_substep_begin(
+            self._ctx, _ptr(pos), _ptr(mom), _ptr(dmom) if dmom is not None else None, _ptr(rung),
+            _ptr(rung_jumped), n, int(dt_over_mass is not None), float(dt_over_mass or 0.0),
+            int(bool(flag)), int(lowest_active_rung), tab, float(rf_up), float(rf_down),
+            int(N_rungs), _ptr(any_out)))
+
+    def substep_end(self, mom, dmom, rung, rung_jumped, apply, lowest_active_rung,
+                    conversion_factors, N_rungs, counts):
+        """cg_substep_end: apply_Δmom + convert_Δmom_to_acc (apply), apply_rung_jumps and the
+        rung populations in one pass; conversion_factors a host array, counts an int64 CUDA
+        tensor [N_rungs] read later."""
+        n = self._check_particles(mom)
+        self._check_rungs(n, rung, rung_jumped)
+        tab = ((ctypes.c_double*(3*N_rungs - 1))(*[float(v) for v in conversion_factors])
+               if apply else None)
+        check(_L.cg_substep_end(
+            self._ctx, _ptr(mom), _ptr(dmom) if dmom is not None else None, _ptr(rung),
+            _ptr(rung_jumped), n, int(bool(apply)), int(lowest_active_rung), tab, int(N_rungs),
+            _ptr(counts)))
+
     def apply_rung_jumps(self, rung, rung_jumped, N_rungs):
         n = rung.numel()
         self._check_rungs(n, rung, rung_jumped)

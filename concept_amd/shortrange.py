@@ -189,8 +189,7 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
                 # compute_factors (gravity.py:51-64): G*m_r*m_s*ᔑdt_rungs[...][k] per rung k
                 integrals = _pair_integrals(ᔑdt_rungs, rec, sup)
                 if rec.use_rungs:
-                    factors = torch.tensor(p.G_Newton*rec.mass*sup.mass*integrals,
-                                           dtype=torch.float64, device=rec.device)
+                    factors = commons.upload(p.G_Newton*rec.mass*sup.mass*integrals, rec.device)
                     rows = active_rows(rec)
                     if rows is not None:
                         # the sub-steps for the highest rungs (main.py:1347-1624): a handful
@@ -286,8 +285,7 @@ def component_component_pp(force, receivers, suppliers, ᔑdt_rungs, periodic):
                 integrals = _pair_integrals(ᔑdt_rungs, rec, sup)
                 rungs, factor = None, p.G_Newton*rec.mass*sup.mass*float(integrals[0])
                 if rec.use_rungs:
-                    factors = torch.tensor(p.G_Newton*rec.mass*sup.mass*integrals,
-                                           dtype=torch.float64, device=rec.device)
+                    factors = commons.upload(p.G_Newton*rec.mass*sup.mass*integrals, rec.device)
                     rungs = (factors, rec.rung_indices, rec.rung_indices_jumped,
                              rec.lowest_active_rung)
                     factor = 0.0

@@ -76,6 +76,7 @@ class Component:
         self.nprocs = self.comm.world if self.comm is not None else 1
         self.rank = self.comm.rank if self.comm is not None else 0
         self._store = None
+        self._sub_dev = None   # (substep_begin/_end: device words read back by substep_finish)
         self.tile_mesh = None
         self.tiles_exact = False
         self.use_ids = False  # identifiers are the running row numbers until some are populated
@@ -482,7 +483,7 @@ class Component:
         w_eff = self.w_eff(a=a)
         conversion_factors = a**(3*w_eff)/(self.mass*(commons.machine_ϵ
                                                       + np.asarray(ᔑdt_rungs['a**2'])))
-        conv = torch.tensor(conversion_factors, dtype=torch.float64, device=self.device)
+        conv = commons.upload(conversion_factors, self.device)
         self._mesh().dmom_to_acc(self.Δmom, self.rung_indices, self.rung_indices_jumped,
                                  self.lowest_active_rung, conv, any_rung_jumps)
 
@@ -504,8 +505,7 @@ class Component:
         """species.py:2463-2513; returns whether any particle (of any domain) was flagged."""
         if not self.use_rungs:
             return False
-        integrals = torch.tensor(np.asarray(ᔑdt_rungs['1']), dtype=torch.float64,
-                                 device=self.device)
+        integrals = commons.upload(np.asarray(ᔑdt_rungs['1']), self.device)
         flagged = self._mesh().flag_rung_jumps(
             self.Δmom, self.rung_indices, self.rung_indices_jumped, self.lowest_active_rung,
             integrals, self.get_rung_factor(Δt*Δt_jump_fac, fac_softening),
@@ -520,6 +520,71 @@ class Component:
             return
         self._mesh().apply_rung_jumps(self.rung_indices, self.rung_indices_jumped, self.N_rungs)
         self.set_rungs_N()
+
+    # -- a sub-step of driftkick_short in two passes (one domain) -------------------------
+    def substep_begin(self, ᔑdt_drift, flag, Δt=None, Δt_jump_fac=None, fac_softening=None,
+                      ᔑdt_rungs=None, a=1.0):
+        """drift(ᔑdt_drift) (unless None), then — `flag` — flag_rung_jumps() and
+        nullify_Δ('mom') as one pass over the particles (cg_substep_begin); what
+        flag_rung_jumps() returns is read by substep_finish().  For components with rungs in
+        use (the time loop takes the separate calls otherwise)."""
+        if not self.use_rungs:
+            raise ConceptGPUError(f'{self.name}: substep_begin() is for components with rungs')
+        mesh = self._mesh()
+        if self._sub_dev is None:
+            self._sub_dev = (torch.zeros(self.N_rungs, dtype=torch.int64, device=self.device),
+                             torch.zeros(1, dtype=torch.int32, device=self.device))
+            self._sub_host = (torch.zeros(self.N_rungs, dtype=torch.int64).pin_memory(),
+                              torch.zeros(1, dtype=torch.int32).pin_memory())
+            self._sub_event = torch.cuda.Event()
+        dtm = None
+        if ᔑdt_drift is not None:
+            dtm = ᔑdt_drift['a**(-2)']*a**(3*self.w_eff(a=a))/self.mass
+            self._store.sorted = False
+            self._store._emig_for = None
+            self.tiles_exact = False
+        if flag and self.Δmom is None:
+            self._store.add_column('Δmom', dtype=torch.float64, width=3)
+        flag = bool(flag and self.use_rungs)
+        if flag:
+            args = (ᔑdt_rungs['1'], self.get_rung_factor(Δt*Δt_jump_fac, fac_softening),
+                    self.get_rung_factor(Δt/Δt_jump_fac, fac_softening))
+        else:
+            args = (None, 0.0, 0.0)
+        self._sub_flag_pending = flag
+        if dtm is None and not flag:
+            return
+        mesh.substep_begin(self.pos, self.mom, self.Δmom, self.rung_indices,
+                           self.rung_indices_jumped, dtm, flag, self.lowest_active_rung, args[0],
+                           args[1], args[2], self.N_rungs, self._sub_dev[1])
+
+    def substep_end(self, apply, ᔑdt_rungs, a=1.0):
+        """apply_Δmom() + convert_Δmom_to_acc() (`apply`: the component received a kick),
+        apply_rung_jumps() and set_rungs_N() as one pass (cg_substep_end); the populations
+        arrive with substep_finish()."""
+        if apply:
+            self._store.touch_mom()
+        conv = None
+        if apply:
+            w_eff = self.w_eff(a=a)
+            conv = a**(3*w_eff)/(self.mass*(commons.machine_ϵ + np.asarray(ᔑdt_rungs['a**2'])))
+        self._mesh().substep_end(self.mom, self.Δmom, self.rung_indices, self.rung_indices_jumped,
+                                 apply, self.lowest_active_rung, conv, self.N_rungs,
+                                 self._sub_dev[0])
+        self._sub_host[0].copy_(self._sub_dev[0], non_blocking=True)
+        self._sub_host[1].copy_(self._sub_dev[1], non_blocking=True)
+        self._sub_event.record()
+
+    def substep_finish(self):
+        """wait for the sub-step's passes; the rung populations (set_rungs_N) are set, and
+        whether any particle was flagged to jump is returned"""
+        self._sub_event.synchronize()
+        counts = self._sub_host[0].tolist()
+        self.rungs_N = counts[:self.N_rungs]
+        populated = [r for r, c in enumerate(self.rungs_N) if c > 0]
+        self.lowest_populated_rung = populated[0] if populated else self.N_rungs - 1
+        self.highest_populated_rung = populated[-1] if populated else 0
+        return bool(self._sub_flag_pending and int(self._sub_host[1][0]))
 
     def set_rungs_N(self):
         """species.py:2560-2587 (set_rungs_N + set_lowest_highest_populated_rung): the

@@ -199,6 +199,28 @@ def static_integrals(components):
     return integrals
 
 
+class _CachedIntegrals:
+    """get_time_step_integrals() behind a small cache: the rung loop asks for a sub-step's
+    integrals while the GPU is still busy with the sub-step before it (prefetch), and again
+    when it needs them."""
+
+    def __init__(self, func):
+        self.func = func
+        self.cache = {}
+
+    def __call__(self, t_start, t_end):
+        key = (t_start, t_end)
+        out = self.cache.pop(key, None)
+        return out if out is not None else self.func(t_start, t_end)
+
+    def prefetch(self, t_start, t_end):
+        key = (t_start, t_end)
+        if key not in self.cache:
+            if len(self.cache) > 256:
+                self.cache.clear()
+            self.cache[key] = self.func(t_start, t_end)
+
+
 class RungStepper:
     """kick_long / kick_short / driftkick_short / initialize_rung_populations of main.py
     for particle components with a P3M short-range force and N_rungs > 1.
@@ -210,7 +232,7 @@ class RungStepper:
         # the short-range machinery (rungs, sub-steps, drifts) is the particles' alone
         # (main.py's particle_components); fluids take part in kick_long()
         self.particles = [c for c in self.components if c.representation == 'particles']
-        self.integrals = integrals
+        self.integrals = _CachedIntegrals(integrals)
         self.t = float(t)
         p = self.components[0].params
         self.N_rungs = p.N_rungs
@@ -312,6 +334,10 @@ class RungStepper:
             for c in comps:
                 c.drift_sort(ᔑdt)
             return
+        # One domain, rungs in use: a sub-step's per-particle calls run as two passes
+        # (Component.substep_begin / substep_end) and the host waits once per sub-step
+        # (substep_finish), after it has worked out the next sub-step's integrals.
+        fused = all(c.nprocs == 1 and c.use_rungs for c in comps)
         any_kicks = True
         index_start = 0
         for driftkick_index in range(2**(nr - 1)):
@@ -331,41 +357,37 @@ class RungStepper:
             index_end = 2*driftkick_index + 2
             t_start = self._clip(self.t + Δt*(float(index_start)/2**nr), Δt, sync_time)
             t_end = self._clip(self.t + Δt*(float(index_end)/2**nr), Δt, sync_time)
-            if t_end > t_start:
-                ᔑdt = self.integrals(t_start, t_end)
+            ᔑdt_drift = self.integrals(t_start, t_end) if t_end > t_start else None
+            if ᔑdt_drift is not None and not fused:
                 for c in comps:
                     # (one domain: nothing to exchange, and the short-range cell list does not
                     # need the mesh-tile order — kick_long sorts once before the mesh kernels;
                     # several domains: the fused drift + exchange + sort)
                     if c.nprocs == 1:
-                        c.drift(ᔑdt)
+                        c.drift(ᔑdt_drift)
                     else:
-                        c.drift_sort(ᔑdt)
+                        c.drift_sort(ᔑdt_drift)
                     c.lowest_active_rung = max(lowest_active_rung, c.lowest_populated_rung)
             highest_populated_rung = max(c.highest_populated_rung for c in comps)
-            for rung_index in range(lowest_active_rung, highest_populated_rung + 1):
-                i0 = (2**(nr - 1 - rung_index)
-                      + (driftkick_index//2**(nr - 1 - rung_index))*2**(nr - rung_index))
-                i1 = i0 + 2**(nr - rung_index)
-                ts = self._clip(self.t + Δt*(float(i0)/2**nr), Δt, sync_time)
-                te = self._clip(self.t + Δt*(float(i1)/2**nr), Δt, sync_time)
-                self._store(self.integrals(ts, te), rung_index)
-                # integral for jumping down a rung: only every second kick, else -1
-                if rung_index > 0 and (
-                        (driftkick_index + 1) - 2**(nr - 1 - rung_index)) % 2**(nr - rung_index) == 0:
-                    te = self._clip(self.t + Δt*(float(i0 + 2**(nr - 1 - rung_index))/2**nr), Δt,
-                                    sync_time)
-                    self._store(self.integrals(ts, te), rung_index + nr)
-                else:
-                    for arr in self.ᔑdt_rungs.values():
-                        arr[rung_index + nr] = -1
-                # integral for jumping up a rung
-                if rung_index < nr - 1:
-                    te = self._clip(self.t + Δt*(float(i0 + 3*2**(nr - 2 - rung_index))/2**nr), Δt,
-                                    sync_time)
-                    self._store(self.integrals(ts, te), rung_index + 2*nr)
+            self._store_rung_integrals(driftkick_index, lowest_active_rung,
+                                       highest_populated_rung, Δt, sync_time)
             integrals_1 = self.ᔑdt_rungs['1']
-            if sum(integrals_1[lowest_active_rung:highest_populated_rung + 1]) == 0:
+            kick = sum(integrals_1[lowest_active_rung:highest_populated_rung + 1]) != 0
+            if fused:
+                for c in comps:
+                    c.substep_begin(ᔑdt_drift, kick, Δt, self.Δt_jump_fac, self.fac_softening,
+                                    self.ᔑdt_rungs)
+                if not kick:
+                    continue
+                receivers_all = self._gravity_short()
+                for c in comps:
+                    c.substep_end(c in receivers_all, self.ᔑdt_rungs)
+                # (the GPU is busy with the sweep: the next sub-step's integrals meanwhile)
+                self._prefetch_integrals(driftkick_index + 1, Δt, sync_time)
+                for c in comps:
+                    c.substep_finish()
+                continue
+            if not kick:
                 continue
             any_rung_jumps = [c.flag_rung_jumps(Δt, self.Δt_jump_fac, self.fac_softening,
                                                 self.ᔑdt_rungs) for c in comps]
@@ -379,6 +401,63 @@ class RungStepper:
             for c, jumps in zip(comps, any_rung_jumps):
                 if jumps:
                     c.apply_rung_jumps()
+
+    def _rung_integral_times(self, driftkick_index, rung_index, Δt, sync_time):
+        """(index into ᔑdt_rungs, t_start, t_end) of the integrals rung `rung_index` needs in
+        sub-step `driftkick_index`, t_end None where the entry is -1 (main.py:1480-1552)"""
+        nr = self.N_rungs
+        i0 = (2**(nr - 1 - rung_index)
+              + (driftkick_index//2**(nr - 1 - rung_index))*2**(nr - rung_index))
+        i1 = i0 + 2**(nr - rung_index)
+        ts = self._clip(self.t + Δt*(float(i0)/2**nr), Δt, sync_time)
+        out = [(rung_index, ts, self._clip(self.t + Δt*(float(i1)/2**nr), Δt, sync_time))]
+        # integral for jumping down a rung: only every second kick, else -1
+        if rung_index > 0 and (
+                (driftkick_index + 1) - 2**(nr - 1 - rung_index)) % 2**(nr - rung_index) == 0:
+            out.append((rung_index + nr, ts,
+                        self._clip(self.t + Δt*(float(i0 + 2**(nr - 1 - rung_index))/2**nr), Δt,
+                                   sync_time)))
+        else:
+            out.append((rung_index + nr, ts, None))
+        # integral for jumping up a rung
+        if rung_index < nr - 1:
+            out.append((rung_index + 2*nr, ts,
+                        self._clip(self.t + Δt*(float(i0 + 3*2**(nr - 2 - rung_index))/2**nr), Δt,
+                                   sync_time)))
+        return out
+
+    def _store_rung_integrals(self, driftkick_index, lowest_active_rung, highest_populated_rung,
+                              Δt, sync_time):
+        for rung_index in range(lowest_active_rung, highest_populated_rung + 1):
+            for index, ts, te in self._rung_integral_times(driftkick_index, rung_index, Δt,
+                                                           sync_time):
+                if te is None:
+                    for arr in self.ᔑdt_rungs.values():
+                        arr[index] = -1
+                else:
+                    self._store(self.integrals(ts, te), index)
+
+    def _prefetch_integrals(self, driftkick_index, Δt, sync_time):
+        """the integrals the sub-step `driftkick_index` will ask for, worked out now (they land
+        in the integrals' cache; which rungs are populated by then is not known yet: all from
+        the lowest active one)"""
+        nr = self.N_rungs
+        if driftkick_index >= 2**(nr - 1) or not hasattr(self.integrals, 'prefetch'):
+            return
+        for rung_index in range(nr):
+            if (driftkick_index + 1) % 2**(nr - 1 - rung_index) == 0:
+                lowest_active_rung = rung_index
+                break
+        t_start = self._clip(self.t + Δt*(float(2*driftkick_index)/2**nr), Δt, sync_time)
+        t_end = self._clip(self.t + Δt*(float(2*driftkick_index + 2)/2**nr), Δt, sync_time)
+        if t_end > t_start:
+            self.integrals.prefetch(t_start, t_end)
+        highest = max(c.highest_populated_rung for c in self.particles)
+        for rung_index in range(lowest_active_rung, min(nr, highest + 2)):
+            for index, ts, te in self._rung_integral_times(driftkick_index, rung_index, Δt,
+                                                           sync_time):
+                if te is not None:
+                    self.integrals.prefetch(ts, te)
 
     # -- one base step of main.timeloop (main.py:335-361) ----------------------
     def base_step(self, Δt, sync_time=float('inf')):

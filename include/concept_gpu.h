@@ -450,6 +450,28 @@ int cg_flag_rung_jumps(cg_ctx *ctx, const double *acc, const int8_t *rung, int8_
 int cg_apply_rung_jumps(cg_ctx *ctx, int8_t *rung, int8_t *rung_jumped, int64_t n, int N_rungs);
 int cg_rung_populations(cg_ctx *ctx, const int8_t *rung, int64_t n, int N_rungs, int64_t *counts);
 
+/* A sub-step of driftkick_short (main.py:1347-1624, one domain) in two passes over the particles:
+ *   cg_substep_begin = [Component.drift, species.py:2179-2199, if do_drift] ->
+ *                      [flag_rung_jumps -> nullify_Δ('mom') for the rungs >= lowest_active_rung,
+ *                       if do_flag]
+ *   cg_substep_end   = [apply_Δmom -> convert_Δmom_to_acc, if do_apply] -> apply_rung_jumps ->
+ *                      set_rungs_N (counts[N_rungs], DEV int64)
+ * per particle the calls above in that order (each of them touches only the particle's own
+ * rows: the values are the same).  integrals_1 = dt_rungs['1'] and conversion_factors
+ * (species.py:2311-2315) are HOST arrays of 3*N_rungs-1 doubles — they travel as kernel
+ * arguments, nothing is uploaded and nothing waited for; *any_out (DEV int32) as in
+ * cg_flag_rung_jumps.  convert_Δmom_to_acc indexes the factors by the jumped rung index, which
+ * IS the rung index of a particle that is not flagged. */
+int cg_substep_begin(cg_ctx *ctx, double *pos /*DEV 3n*/, const double *mom /*DEV 3n*/,
+                     double *dmom /*DEV 3n*/, const int8_t *rung, int8_t *rung_jumped, int64_t n,
+                     int do_drift, double dt_over_mass, int do_flag, int lowest_active_rung,
+                     const double *integrals_1 /*HOST*/, double rung_factor_up,
+                     double rung_factor_down, int N_rungs, int32_t *any_out /*DEV*/);
+int cg_substep_end(cg_ctx *ctx, double *mom, double *dmom, int8_t *rung, int8_t *rung_jumped,
+                   int64_t n, int do_apply, int lowest_active_rung,
+                   const double *conversion_factors /*HOST*/, int N_rungs,
+                   int64_t *counts /*DEV N_rungs*/);
+
 /* --- multi-GPU: x-slab domains ----------------------------------------------
  * One context per GPU with params.nprocs = P, rank = r, subdiv = (P,1,1):
  * domain r owns mesh layers x in [r*N/P, (r+1)*N/P) and the particles whose

@@ -1,0 +1,72 @@
+"""The two fused passes of a rung sub-step (cg_substep_begin / cg_substep_end) against the calls
+they stand for (Component.drift, flag_rung_jumps, nullify_Δ | apply_Δmom, convert_Δmom_to_acc,
+apply_rung_jumps, set_rungs_N; species.py:2179-2587, main.py:1347-1624): bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('lowest', [0, 2, 4])
+@pytest.mark.parametrize('n', [1, 1000, 700001])
+def test_substep_passes_equal_the_separate_calls(n, lowest):
+    import torch
+    from concept_amd.mesh import PotentialMesh
+    L, N_rungs = 37.0, 8
+    mesh = PotentialMesh(16, L)
+    g = torch.Generator(device='cuda').manual_seed(n + lowest)
+    pos = torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=g)*L*(1 - 1e-13)
+    mom = torch.randn((n, 3), dtype=torch.float64, device='cuda', generator=g)
+    acc = torch.randn((n, 3), dtype=torch.float64, device='cuda', generator=g) \
+        * torch.exp(4*torch.randn((n, 1), dtype=torch.float64, device='cuda', generator=g))
+    acc[::7] = 0
+    rung = torch.randint(0, 6, (n,), device='cuda', generator=g).to(torch.int8)
+    rng = np.random.default_rng(5)
+    integrals = rng.uniform(0.1, 1.0, 3*N_rungs - 1)
+    integrals[3] = 0.0                       # a rung whose kick is empty
+    integrals[N_rungs:2*N_rungs:2] = -1      # no downward jump this sub-step
+    conv = rng.uniform(0.5, 2.0, 3*N_rungs - 1)
+    rf_up, rf_down, dtm = 1.3, 2.1, 0.37
+    up = lambda a: torch.as_tensor(a, device='cuda')   # noqa: E731
+    # the separate calls
+    p0, m0, d0, r0, j0 = pos.clone(), mom.clone(), acc.clone(), rung.clone(), rung.clone()
+    mesh.drift(p0, m0, dtm)
+    flagged0 = mesh.flag_rung_jumps(d0, r0, j0, lowest, up(integrals), rf_up, rf_down, N_rungs)
+    mesh.dmom_nullify(d0, r0, lowest)
+    # the pass
+    p1, m1, d1, r1, j1 = pos.clone(), mom.clone(), acc.clone(), rung.clone(), rung.clone()
+    any_out = torch.zeros(1, dtype=torch.int32, device='cuda')
+    mesh.substep_begin(p1, m1, d1, r1, j1, dtm, True, lowest, integrals, rf_up, rf_down, N_rungs,
+                       any_out)
+    assert torch.equal(p0, p1) and torch.equal(d0, d1) and torch.equal(j0, j1)
+    assert bool(any_out.item()) == flagged0
+    assert n < 1000 or (flagged0 and bool((j1 >= N_rungs).any()) and bool((j1 >= 2*N_rungs).any()))
+    # drift alone, flag alone
+    p2 = pos.clone()
+    mesh.substep_begin(p2, m1, None, r1, j1.clone(), dtm, False, lowest, None, 0.0, 0.0, N_rungs,
+                       any_out)
+    assert torch.equal(p2, p0)
+    d3, j3 = acc.clone(), rung.clone()
+    mesh.substep_begin(pos.clone(), m1, d3, rung, j3, None, True, lowest, integrals, rf_up,
+                       rf_down, N_rungs, any_out)
+    assert torch.equal(d3, d0) and torch.equal(j3, j0)
+    # a kick arrives in Δmom
+    kick = torch.randn((n, 3), dtype=torch.float64, device='cuda', generator=g)
+    d0 += kick
+    d1 += kick
+    mesh.dmom_apply(m0, d0, r0, lowest)
+    mesh.dmom_to_acc(d0, r0, j0, lowest, up(conv), flagged0)
+    mesh.apply_rung_jumps(r0, j0, N_rungs)
+    counts0 = mesh.rung_populations(r0, N_rungs)
+    counts1 = torch.zeros(N_rungs, dtype=torch.int64, device='cuda')
+    mesh.substep_end(m1, d1, r1, j1, True, lowest, conv, N_rungs, counts1)
+    assert torch.equal(m0, m1) and torch.equal(d0, d1)
+    assert torch.equal(r0, r1) and torch.equal(j0, j1) and torch.equal(r1, j1)
+    assert torch.equal(counts0, counts1) and int(counts1.sum()) == n
+    # a component that received nothing: the jumps and the populations only
+    r4, j4 = rung.clone(), j3.clone()
+    m4, d4 = mom.clone(), acc.clone()
+    mesh.substep_end(m4, d4, r4, j4, False, lowest, None, N_rungs, counts1)
+    assert torch.equal(m4, mom) and torch.equal(d4, acc) and torch.equal(r4, r1)
+    assert torch.equal(counts0, counts1)
+    mesh.close()
