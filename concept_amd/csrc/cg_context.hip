@@ -1013,7 +1013,7 @@ extern "C" int cg_shortrange_cells_rungs(cg_ctx *c, const double *pos, int64_t n
                                          int8_t *rung_jumped_sorted_out) {
     if (shortrange_cells_checks(c, pos, n, nt, tile_extent, order_out, offset_out, pos_sorted_out))
         return 1;
-    CG_CHECK(nact_out && (n == 0 || (rung && rung_jumped && rung_jumped_sorted_out)),
+    CG_CHECK(nact_out && (n == 0 || (rung && (rung_jumped || !rung_jumped_sorted_out))),
              "cg_shortrange_cells_rungs: null argument");
     return cgk_shortrange_cells(c, pos, n, nt, c->p.boxsize / (double)nt, order_out, offset_out,
                                 pos_sorted_out, (const signed char *)rung,

@@ -157,8 +157,10 @@ struct cg_ctx {
         i64 nt = 0;
         int min_pop = 0;
         hipEvent_t ev = nullptr;
+        bool harvested = true;   // its result has been counted in srd_quiet
     } srd_look[4];
     int srd_look_next = 0, srd_idle = 0;
+    int srd_quiet = 0;   // completed looks in a row that found no dense tile
     bool srd_hilbert_done = false;
     unsigned *srd_host = nullptr;
     void *srd_small = nullptr, *srd_buf = nullptr, *srd_rung = nullptr;

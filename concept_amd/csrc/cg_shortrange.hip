@@ -238,7 +238,8 @@ __global__ __launch_bounds__(256) void k_sr_cell_scatter(const double *__restric
             pos_sorted[3 * q] = x[u];
             pos_sorted[3 * q + 1] = y[u];
             pos_sorted[3 * q + 2] = z[u];
-            if constexpr (ACT) rj_sorted[q] = A.rung_jumped[p];
+            if constexpr (ACT)
+                if (rj_sorted) rj_sorted[q] = A.rung_jumped[p];
         }
     }
 }
@@ -554,7 +555,7 @@ __device__ __forceinline__ SrChunk sr_chunk_load(unsigned base, unsigned rend, i
         c.yi = pos_r[3 * (i64)qi + 1];
         c.zi = pos_r[3 * (i64)qi + 2];
         if (RUNGS == 1) c.factor = P.factors[P.rung_jumped[c.pi]];  // (every rung is active)
-        if (RUNGS == 2) c.factor = P.factors[P.rj_sorted[qi]];
+        if (RUNGS == 2) c.factor = P.factors[P.rj_sorted ? P.rj_sorted[qi] : P.rung_jumped[c.pi]];
     }
     return c;
 }
@@ -1118,11 +1119,12 @@ int cgk_shortrange_sparse(cg_ctx *c, const double *pos_r, const i64 *active, int
 // A sub-step with FEW active receivers (the upper rungs of a base step's sub-steps: at 256^3 the
 // eight sub-steps that kick the highest of five rungs have 1 % of the particles active): the
 // blocks above stage ~1000 suppliers for a receiver or two and wait for a table look-up per
-// trip with nobody to hide it (1.2 ms for 6e7 pair tests).  Here the cells that hold an active
-// receiver are listed (k_sr_active_cells, from the nact words of the active-first list) and each
-// gets ONE wavefront: the 5 x 5 columns x 5 cells around the cell are 25 runs of the suppliers'
-// list (50 where the z range wraps around the box) read where they are — 16 lanes per run, four
-// runs per trip, nothing staged, no barrier.  Same pair arithmetic ((xi - xj) + offset, r2, table
+// trip with nobody to hide it (1.2 ms for 6e7 pair tests).  Here the active receivers are listed
+// (k_sr_active_cells, from the nact words of the active-first list: cell and row of each) and
+// every one gets a wavefront of its own — a cell in a clump may hold hundreds of them: the 5 x 5
+// columns x 5 cells around the cell are 25 runs of the suppliers' list (50 where the z range
+// wraps around the box) read where they are — 16 lanes per run, four runs per trip, nothing
+// staged, no barrier.  Same pair arithmetic ((xi - xj) + offset, r2, table
 // index bit-identical to the reference's); a receiver's sum is reduced over the wave in a fixed
 // order.
 // ===========================================================================
@@ -1130,23 +1132,27 @@ constexpr int kSaRuns = 52;  // 25 columns x 2 pieces, rounded up to whole trips
 // (one atomic on the list's counter per 4096 cells: an atomic per wavefront — 94,000 of them on
 // ONE address at 256^3 — took 0.9 ms, three times the sweep it feeds)
 constexpr int kSaPerThread = 16;
+// list[i] = the cell of the i-th active receiver, rows[i] = its row in the receivers' list
+// (a cell's nact active rows are its first ones)
 __global__ __launch_bounds__(256) void k_sr_active_cells(const unsigned *__restrict__ nact,
+                                                         const unsigned *__restrict__ off_r,
                                                          unsigned ncells,
                                                          unsigned *__restrict__ list,
+                                                         unsigned *__restrict__ rows,
                                                          unsigned *__restrict__ count,
                                                          unsigned cap) {
     __shared__ unsigned w_tot[4], w_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // wave w of the workgroup takes 1024 consecutive cells, 64 at a time
     const unsigned first = (blockIdx.x * 4u + (unsigned)wave) * (64u * kSaPerThread);
-    unsigned flags = 0, total = 0;
+    unsigned mine[kSaPerThread], total = 0;
 #pragma unroll
     for (int i = 0; i < kSaPerThread; i++) {
         const unsigned c = first + 64u * i + lane;
-        const bool any = c < ncells && nact[c] != 0;
-        flags |= (unsigned)any << i;
-        total += (unsigned)__popcll(__ballot(any));
+        mine[i] = c < ncells ? nact[c] : 0u;
+        total += mine[i];
     }
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
     if (lane == 0) w_tot[wave] = total;
     __syncthreads();
     if (threadIdx.x == 0) w_base = atomicAdd(count, w_tot[0] + w_tot[1] + w_tot[2] + w_tot[3]);
@@ -1155,11 +1161,17 @@ __global__ __launch_bounds__(256) void k_sr_active_cells(const unsigned *__restr
     for (int w = 0; w < wave; w++) off += w_tot[w];
 #pragma unroll
     for (int i = 0; i < kSaPerThread; i++) {
-        const bool any = flags >> i & 1u;
-        const unsigned long long m = __ballot(any);
-        const unsigned slot = off + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-        if (any && slot < cap) list[slot] = first + 64u * i + lane;
-        off += (unsigned)__popcll(m);
+        const unsigned n = mine[i];
+        const unsigned incl = sr_wave_scan(n);
+        if (n) {
+            const unsigned c = first + 64u * i + lane, r0 = off_r[c];
+            unsigned slot = off + incl - n;
+            for (unsigned k = 0; k < n && slot < cap; k++, slot++) {
+                list[slot] = c;
+                rows[slot] = r0 + k;
+            }
+        }
+        off += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
     }
 }
 
@@ -1169,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_sr_sweep_active_cells(
     const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
     const double *__restrict__ pos_s, const unsigned *__restrict__ off_s,
     const double *__restrict__ table, SrParams P, const unsigned *__restrict__ list,
-    const unsigned *__restrict__ nlist) {
+    const unsigned *__restrict__ rows, const unsigned *__restrict__ nlist) {
     __shared__ unsigned r_beg[4][kSaRuns], r_cnt[4][kSaRuns];
     __shared__ int r_img[4][kSaRuns];  // the run's image: (ox + 1) | (oy + 1) << 2 | (oz + 1) << 4
     const int lane = threadIdx.x & 63;
@@ -1211,14 +1223,12 @@ __global__ __launch_bounds__(256) void k_sr_sweep_active_cells(
         r_cnt[wave][lane] = cnt;
         r_img[wave][lane] = img;
     }
-    const unsigned rb = (unsigned)__builtin_amdgcn_readfirstlane((int)off_r[cell]);
-    const int R = __builtin_amdgcn_readfirstlane((int)P.nact[cell]);
     const int ntrips = zwrap ? kSaRuns / 4 : 7;  // (25 runs: 7 trips of 4)
     const int slot0 = lane >> 4, k0 = lane & 15;
     const double L = P.boxsize;
     SrCount cnt;
-    for (int r = 0; r < R; r++) {
-        const i64 row = (i64)rb + r;
+    {
+        const i64 row = (i64)(unsigned)__builtin_amdgcn_readfirstlane((int)rows[idx]);
         const double xi = pos_r[3 * row], yi = pos_r[3 * row + 1], zi = pos_r[3 * row + 2];
         double ax = 0, ay = 0, az = 0;
         // (a lane's loads of seven trips issued together before the first is used — 126 registers,
@@ -1273,7 +1283,7 @@ __global__ __launch_bounds__(256) void k_sr_sweep_active_cells(
         ax = wave_sum(ax), ay = wave_sum(ay), az = wave_sum(az);
         if (lane == 63) {
             const i64 o = 3 * (i64)order_r[row];
-            const double f = P.factors[P.rj_sorted[row]];  // gravity.py:318-349
+            const double f = P.factors[P.rj_sorted ? P.rj_sorted[row] : P.rung_jumped[o / 3]];  // gravity.py:318-349
             dmom_r[o] += ax * f;
             dmom_r[o + 1] += ay * f;
             dmom_r[o + 2] += az * f;
@@ -1318,7 +1328,7 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                factors,      rung,             rung_jumped, lowest_active, nullptr, nullptr,
                (int)(r2_max * r2_index_scaling) + 1, nullptr, nullptr};
     const bool partial = rung && lowest_active > 0;
-    const bool act = partial && nact_r && rj_sorted_r;
+    const bool act = partial && nact_r;
     if (act) P.nact = nact_r, P.rj_sorted = rj_sorted_r;
     if (partial && !act) {
         // which tiles have a receiver on an active rung (the others leave at once)
@@ -1360,7 +1370,7 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
     if (act && n_active_max >= 0) {
         // few active receivers: one wavefront per cell that holds one
         const i64 ncells = 8 * nt * nt * nt;
-        const size_t need = 4 * ((size_t)n_active_max + 64);
+        const size_t need = 4 * (2 * (size_t)n_active_max + 64);
         if (need > c->sr_active_bytes) {
             CG_HIP(hipStreamSynchronize(c->stream));
             (void)hipFree(c->sr_active);
@@ -1369,18 +1379,18 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
             CG_HIP(hipMalloc((void **)&c->sr_active, need));
             c->sr_active_bytes = need;
         }
-        unsigned *count = c->sr_active, *list = c->sr_active + 64;
+        unsigned *count = c->sr_active, *list = c->sr_active + 64, *rows = list + n_active_max;
         CG_HIP(hipMemsetAsync(count, 0, 4, c->stream));
         if (n_active_max > 0) {
             hipLaunchKernelGGL(k_sr_active_cells,
                                dim3((unsigned)((ncells + 256 * kSaPerThread - 1) / (256 * kSaPerThread))), dim3(256),
-                               0, c->stream, nact_r, (unsigned)ncells, list, count,
+                               0, c->stream, nact_r, off_r, (unsigned)ncells, list, rows, count,
                                (unsigned)n_active_max);
             CG_LAUNCH_CHECK();
             hipLaunchKernelGGL(P.stats ? k_sr_sweep_active_cells<true> : k_sr_sweep_active_cells<false>,
                                dim3((unsigned)((n_active_max + 3) / 4)), dim3(256), 0, c->stream,
                                pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P,
-                               list, count);
+                               list, rows, count);
             CG_LAUNCH_CHECK();
         }
         if (take && cgk_shortrange_dense_join(c)) return 1;

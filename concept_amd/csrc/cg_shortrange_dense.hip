@@ -795,6 +795,7 @@ int cgk_shortrange_dense_look(cg_ctx *c, const unsigned *off_cells, i64 nt) {
     L.off = off_cells;
     L.nt = nt;
     L.min_pop = min_pop;
+    L.harvested = false;
     return 0;
 }
 
@@ -826,9 +827,29 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
         if (cgk_shortrange_dense_look(c, off_r, nt)) return 1;
         lr = srd_look_slot(c, off_r, nt, min_pop);
     }
-    CG_HIP(hipEventSynchronize(c->srd_look[lr].ev));
+    // The looks that have completed since the last call: how many in a row found nothing dense.
+    // While that has been so for a while (a box without clumps: every sub-step of a rung loop)
+    // a look that is still on its way is not waited for — its sweep goes without the dense
+    // tiles' form, which is a matter of speed alone, and the host keeps queueing (the wait had
+    // the GPU idle once per sub-step until the sweep's launch arrived).  A look that finds
+    // dense tiles ends the streak; the sweeps after it wait again.
+    for (int i = 0; i < kdLooks; i++) {
+        cg_ctx::SrdLook &K = c->srd_look[i];
+        if (K.ev && !K.harvested && hipEventQuery(K.ev) == hipSuccess) {
+            K.harvested = true;
+            c->srd_quiet = c->srd_host[16 + 8 * i] == 0 ? c->srd_quiet + 1 : 0;
+        }
+    }
+    if (!c->srd_look[lr].harvested) {
+        if (c->srd_quiet >= 2 * kdLooks && !by_threshold) return 0;
+        CG_HIP(hipEventSynchronize(c->srd_look[lr].ev));
+        c->srd_look[lr].harvested = true;
+        c->srd_quiet = c->srd_host[16 + 8 * lr] == 0 ? c->srd_quiet + 1 : 0;
+    }
     const unsigned *hr = c->srd_host + 16 + 8 * lr;
     const i64 ndense = hr[0], tdense = hr[1], n_r = hr[2];
+    unsigned long long sq;   // (with them: a look for the suppliers below may take this slot)
+    memcpy(&sq, hr + 4, 8);
     // buffers nobody has used for a while go back (a run whose clumps dissolve, a test)
     if (ndense == 0) {
         if (++c->srd_idle >= 16 && c->srd_buf_bytes + c->sr_sub_bytes > ((size_t)256 << 20)) {
@@ -851,6 +872,7 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
             ls = srd_look_slot(c, off_s, nt, min_pop);
         }
         CG_HIP(hipEventSynchronize(c->srd_look[ls].ev));
+        c->srd_look[ls].harvested = true;
         n_s = c->srd_host[16 + 8 * ls + 2];
         sdense = c->srd_host[16 + 8 * ls];
     }
@@ -860,8 +882,6 @@ int cgk_shortrange_dense(cg_ctx *c, const double *pos_r_sorted, const unsigned *
     // particles at 44 per tile has 0.3 % of its tiles above the threshold and 17 ms of lists to
     // pay: not worth it.  (With CONCEPT_GPU_SR_DENSE_MIN set the threshold alone decides.)
     const double cost = 5e-5 + 1e-10 * (double)(n_r + (same ? 0 : n_s));
-    unsigned long long sq;
-    memcpy(&sq, hr + 4, 8);
     if (!by_threshold && 0.45 * 18.75 * (double)sq / 0.9e12 < 2 * cost) return 0;
     c->srd_idle = 0;
     // [2] items, [6] active receivers in tiles dense with them, [7] such tiles, [8..9] sum of

@@ -662,12 +662,14 @@ class PotentialMesh:
             rung, rung_jumped, lowest = rungs
             self._check_rungs(n, rung, rung_jumped)
             nact = torch.empty(8*nt**3, dtype=torch.int32, device=pos.device)
-            rj_sorted = torch.empty(max(n, 1), dtype=torch.int8, device=pos.device)
+            # (the rows' jumped rung indices are not copied into list order: the sweep reads
+            # them through `order` for its active receivers — the copy cost the list 0.1 ms
+            # per build at 256^3, a scattered byte per particle)
             check(_L.cg_shortrange_cells_rungs(
                 self._ctx, _ptr(pos), n, int(nt), float(tile_extent), _ptr(rung),
                 _ptr(rung_jumped), int(lowest), _ptr(order), _ptr(offset), _ptr(pos_sorted),
-                _ptr(nact), _ptr(rj_sorted)))
-            return order, offset, pos_sorted, nact, rj_sorted, rung, int(lowest)
+                _ptr(nact), None))
+            return order, offset, pos_sorted, nact, None, rung, int(lowest)
         check(_L.cg_shortrange_cells(self._ctx, _ptr(pos), n, int(nt), float(tile_extent),
                                      _ptr(order), _ptr(offset), _ptr(pos_sorted)))
         return order, offset, pos_sorted
@@ -699,7 +701,8 @@ class PotentialMesh:
                 raise lib.ConceptGPUError(
                     'shortrange_sweep_cells: the receivers\' list was made for other rungs')
             check(_L.cg_shortrange_sweep_cells_active(
-                self._ctx, _ptr(pos_r), _ptr(order_r), _ptr(off_r), _ptr(nact), _ptr(rj_sorted),
+                self._ctx, _ptr(pos_r), _ptr(order_r), _ptr(off_r), _ptr(nact),
+                _ptr(rj_sorted) if rj_sorted is not None else None,
                 _ptr(dmom_r), _ptr(pos_s), _ptr(off_s), int(nt), _ptr(table), table.numel(),
                 float(r2_index_scaling), float(r2_max), _ptr(factors), _ptr(rung),
                 _ptr(rung_jumped), int(lowest), -1 if n_active is None else int(n_active)))

@@ -209,9 +209,8 @@ class _CachedIntegrals:
         self.cache = {}
 
     def __call__(self, t_start, t_end):
-        key = (t_start, t_end)
-        out = self.cache.pop(key, None)
-        return out if out is not None else self.func(t_start, t_end)
+        out = self.cache.get((t_start, t_end))
+        return dict(out) if out is not None else self.func(t_start, t_end)
 
     def prefetch(self, t_start, t_end):
         key = (t_start, t_end)
@@ -383,7 +382,7 @@ class RungStepper:
                 for c in comps:
                     c.substep_end(c in receivers_all, self.ᔑdt_rungs)
                 # (the GPU is busy with the sweep: the next sub-step's integrals meanwhile)
-                self._prefetch_integrals(driftkick_index + 1, Δt, sync_time)
+                self._prefetch_integrals(driftkick_index, Δt, sync_time)
                 for c in comps:
                     c.substep_finish()
                 continue
@@ -438,24 +437,30 @@ class RungStepper:
                     self._store(self.integrals(ts, te), index)
 
     def _prefetch_integrals(self, driftkick_index, Δt, sync_time):
-        """the integrals the sub-step `driftkick_index` will ask for, worked out now (they land
-        in the integrals' cache; which rungs are populated by then is not known yet: all from
-        the lowest active one)"""
+        """the integrals of the sub-step that follows `driftkick_index`, worked out now (they
+        land in the integrals' cache).  Which rungs are populated by then is not known yet: the
+        next sub-step is taken to be the next one whose lowest active rung is no higher than
+        the highest rung populated now, plus one (a wrong guess costs nothing but the work)."""
         nr = self.N_rungs
-        if driftkick_index >= 2**(nr - 1) or not hasattr(self.integrals, 'prefetch'):
+        if not hasattr(self.integrals, 'prefetch'):
             return
-        for rung_index in range(nr):
-            if (driftkick_index + 1) % 2**(nr - 1 - rung_index) == 0:
-                lowest_active_rung = rung_index
+        highest = min(nr - 1, max(c.highest_populated_rung for c in self.particles) + 1)
+        for nxt in range(driftkick_index + 1, 2**(nr - 1)):
+            for rung_index in range(nr):
+                if (nxt + 1) % 2**(nr - 1 - rung_index) == 0:
+                    lowest_active_rung = rung_index
+                    break
+            if lowest_active_rung <= highest:
                 break
-        t_start = self._clip(self.t + Δt*(float(2*driftkick_index)/2**nr), Δt, sync_time)
-        t_end = self._clip(self.t + Δt*(float(2*driftkick_index + 2)/2**nr), Δt, sync_time)
+        else:
+            return
+        # (the drift runs from the end of this sub-step to the end of that one)
+        t_start = self._clip(self.t + Δt*(float(2*driftkick_index + 2)/2**nr), Δt, sync_time)
+        t_end = self._clip(self.t + Δt*(float(2*nxt + 2)/2**nr), Δt, sync_time)
         if t_end > t_start:
             self.integrals.prefetch(t_start, t_end)
-        highest = max(c.highest_populated_rung for c in self.particles)
-        for rung_index in range(lowest_active_rung, min(nr, highest + 2)):
-            for index, ts, te in self._rung_integral_times(driftkick_index, rung_index, Δt,
-                                                           sync_time):
+        for rung_index in range(lowest_active_rung, highest + 1):
+            for index, ts, te in self._rung_integral_times(nxt, rung_index, Δt, sync_time):
                 if te is not None:
                     self.integrals.prefetch(ts, te)
 
