@@ -872,6 +872,9 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default=None)
+    ap.add_argument('--rung-loop', default=None, choices=['uniform', 'clustered'],
+                    help='only the P3M time loop with 8 rungs at 256^3 / 512^3 '
+                         '(configs.c2_p3m_rungs of the default line), --steps base steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-configs', action='store_true',
                     help='default run only: skip the other configurations timed after the '
@@ -956,6 +959,12 @@ def main():
         else:
             dist.init_process_group(backend, timeout=limit)
 
+    if args.rung_loop:
+        n_p, N = WORKLOADS[args.workload or 'c2_256c_512']
+        print(json.dumps(rung_loop_leg(torch, torch.device('cuda', local_rank), args.rung_loop,
+                                       base_steps=max(args.steps, 3), n_side=round(n_p**(1/3)),
+                                       N=N)))
+        return
     if args.workload in C4_SIZES:
         if world > 1:
             sys.exit('bench.py: the c4 workloads run on one GPU (tests/test_gpu_distributed.py '
@@ -1020,6 +1029,24 @@ def main():
             'frac': r4['roofline']['frac'], 'interactions': r4['interactions'],
             'phases': r4['phases'], 'phases_ms': {k: v['ms'] for k, v in r4['phases'].items()},
             'workload': r4['config']['workload']}
+        # BASELINE configs[3] at its own size on one GPU: 1024^3 particles /
+        # 2048^3 mesh — 3 steps
+        a3 = copy.copy(args)
+        a3.steps, a3.warmup, a3.workload = 3, 1, 'c3_1024c_2048'
+        r3 = run_single(a3, torch, dev, rank)
+        torch.cuda.empty_cache()
+        result['configs']['c3_1024c_2048'] = {
+            'ms_per_step': round(r3['ms_per_step'], 4), 'steps': a3.steps,
+            'particle_updates_per_s': r3['value'],
+            'dominant_kernel': r3['roofline']['kernel'],
+            'dominant_kernel_ms': r3['roofline']['kernel_ms'],
+            'bound': r3['roofline']['bound'], 'frac': r3['roofline']['frac'],
+            'phases_ms': {k: v['ms'] for k, v in r3['phases'].items()},
+            'workload': r3['config']['workload']}
+        # the reference's default run mode: the P3M time loop with 8 rungs
+        result['configs']['c2_p3m_rungs'] = {
+            'uniform': rung_loop_leg(torch, dev, 'uniform', base_steps=12),
+            'clustered': rung_loop_leg(torch, dev, 'clustered', base_steps=10)}
         # the same workload through the drop-in API
         result['timeloop'] = timeloop_leg(torch, dev, result['ms_per_step'])
         result['timeloop_ms_per_step'] = result['timeloop']['ms_per_base_step']
@@ -1162,6 +1189,22 @@ def run_c4(args, torch, dev, size=512, steps=None, warmup=None):
                    'GBps': round(moved[ph]/(ms[ph]*1e-3)/1e9, 1),
                    'frac_hbm': round(moved[ph]/(ms[ph]*1e-3)/1e9/HBM_PEAK_GBS, 4)}
               for ph in PH}
+    # The short-range phase is the pair sweep (FP64 issue bound) with the cell list in front of
+    # it: its fraction of the HBM rate says nothing, executed pair tests per second against the
+    # FP64 issue rate do (counted by one more pass through the short-range interactions after
+    # the timed region, on a scratch Δmom; `kernel_ms` is the whole phase, list included)
+    del phases['short_range']['frac_hbm']
+    part.nullify_Δ('mom')
+    mesh3.shortrange_stats(True)
+    for it in short_range:
+        getattr(interactions, it.force)(it.method, it.receivers, it.suppliers, sdt_rungs,
+                                        'short-range', False)
+    sweep_roofline = pair_sweep_roofline(mesh3.shortrange_stats(False), ms['short_range'],
+                                         'short_range')
+    part.nullify_Δ('mom')
+    phases['short_range'].update(
+        bound='valu_fp64', frac_valu_fp64=sweep_roofline['frac'],
+        tests_per_hit=sweep_roofline['tests_per_hit'], lane_use=sweep_roofline['lane_use'])
     ms_per_step = elapsed/steps*1e3
     dom = max(PH, key=lambda ph: ms[ph])
     out = {
@@ -1180,13 +1223,7 @@ def run_c4(args, torch, dev, size=512, steps=None, warmup=None):
         'roofline': ({'bound': 'hbm', 'kernel': dom, 'achieved': phases[dom]['GBps'],
                       'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': phases[dom]['frac_hbm'],
                       'traffic': None, 'kernel_ms': phases[dom]['ms']}
-                     if dom != 'short_range' else
-                     {'bound': 'valu_fp64', 'kernel': 'short_range', 'unit': 'GB/s',
-                      'achieved': phases[dom]['GBps'], 'peak': HBM_PEAK_GBS,
-                      'frac': phases[dom]['frac_hbm'], 'traffic': None,
-                      'kernel_ms': phases[dom]['ms'],
-                      'note': 'the pair sweep is FP64-VALU bound (see the c2 P3M line): its '
-                              'fraction of the HBM rate says only that it is not memory-bound'}),
+                     if dom != 'short_range' else sweep_roofline),
     }
     del part, fluid, comps
     from concept_amd import mesh as mesh_module
@@ -1205,6 +1242,102 @@ def timeloop_leg(torch, dev, raw_ms, n=2**28, N=1024, base_steps=24):
     out['with_order_column'] = {k: ordered[k] for k in (
         'ms_per_base_step', 'ratio_to_raw_step', 'ms_per_synchronisation_step',
         'mean_ms_over_all_steps', 'one_pass_steps', 'particles_kept')}
+    # both contracts side by side: the API's default (host() restores the populated
+    # order) and the reference's own (no identifiers, order free), which README.md quotes
+    out['ms_per_base_step_default'] = ordered['ms_per_base_step']
+    out['ms_per_base_step_no_order'] = out['ms_per_base_step']
+    return out
+
+
+def rung_loop_leg(torch, dev, dist, base_steps=12, n_side=256, N=512):
+    """The reference's default run mode under the bench's clock: BASELINE
+    configs[2]'s size — 256^3 particles, P3M on a 512^3 mesh — through stepper.Timeloop with
+    N_rungs = 8: a white-noise field at rest (`uniform`) or bench.py's clustered box from
+    a = 0.02, every base step the rung loop of driftkick_short (main.py:1347-1624: a drift, the
+    short-range kick of the active rungs and the rung bookkeeping per sub-step) + the long-range
+    kick.  Wall time between the beginnings of consecutive base steps; the loop's calls grouped
+    by HIP events around them."""
+    import statistics
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from concept_amd import commons, shortrange, species, stepper
+    from concept_amd.mesh import PotentialMesh
+    from tools.sr_positions import positions
+    n = n_side**3
+    p = commons.load_params({
+        'boxsize': float(N), 'H0': 0.07, 'Ωb': 0.05, 'Ωcdm': 0.25, 'a_begin': 0.02,
+        'output_times': {'a': (0.5,)},
+        'potential_options': {'gridsize': {'gravity': {'p3m': N}}},
+        'select_forces': {'all': {'gravity': 'p3m'}}})
+    c = species.Component('matter', 'matter', N=n, mass=p.ρ_mbar*p.boxsize**3/n)
+    gen = torch.Generator(device=dev).manual_seed(13)
+    c.pos.copy_(positions(dist, n, p.boxsize, gen))
+    c.mom.zero_()
+    # the loop's calls, grouped: an event pair around each
+    groups = {}
+
+    def timed(obj, attr, group):
+        f = getattr(obj, attr)
+
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            try:
+                return f(*a, **k)
+            finally:
+                e1.record()
+                groups.setdefault(group, []).append((e0, e1))
+        setattr(obj, attr, wrapper)
+        return lambda: setattr(obj, attr, f)
+    undo = [timed(species.Component, 'substep_begin', 'drift_flag_nullify'),
+            timed(species.Component, 'substep_end', 'apply_convert_jumps_populations'),
+            timed(PotentialMesh, 'shortrange_cells', 'cell_list'),
+            timed(PotentialMesh, 'shortrange_sweep_cells', 'sweep'),
+            timed(PotentialMesh, 'shortrange_sparse', 'sweep_without_list'),
+            timed(stepper.RungStepper, 'kick_long', 'long_range_kick')]
+
+    class Enough(Exception):
+        pass
+    stamps, marks, sparse0 = [], [], shortrange.sparse_sweeps
+
+    def on_step(lp):
+        torch.cuda.synchronize()
+        stamps.append(time.perf_counter())
+        marks.append({g: len(v) for g, v in groups.items()})
+        if len(stamps) > base_steps + 2:
+            raise Enough
+    loop = stepper.Timeloop([c], on_step=on_step)
+    try:
+        loop.run()
+    except Enough:
+        pass
+    torch.cuda.synchronize()
+    for u in undo:
+        u()
+    # the first two base steps out (the loop's set-up, the lists' first allocations)
+    dts = [(b - a)*1e3 for a, b in zip(stamps[2:-1], stamps[3:])]
+    lo = marks[2]
+    per_group = {g: round(sum(e0.elapsed_time(e1) for e0, e1 in v[lo.get(g, 0):])/len(dts), 3)
+                 for g, v in groups.items()}
+    sweeps = len(groups.get('sweep', [])) - lo.get('sweep', 0)
+    out = {'ms_per_base_step': round(statistics.median(dts), 3),
+           'ms_per_base_step_min_max': [round(min(dts), 3), round(max(dts), 3)],
+           'base_steps_timed': len(dts),
+           'sub_steps_per_base_step': round(
+               (len(groups.get('drift_flag_nullify', [])) - lo.get('drift_flag_nullify', 0))/len(dts), 2),
+           'sweeps_per_base_step': round(sweeps/len(dts), 2),
+           'gpu_ms_per_base_step_by_call': per_group,
+           'gpu_ms_per_base_step_in_calls': round(sum(per_group.values()), 3),
+           'rung_populations_at_the_end': [int(v) for v in c.rungs_N],
+           'a_reached': loop.cosmo.a, 'particles_kept': int(c.N_local) == n,
+           'what': (f'stepper.Timeloop (= main.timeloop(), main.py:102-471), P3M, N_rungs = '
+                    f'{p.N_rungs}, {n_side}^3 particles / {N}^3 mesh, {dist} box at rest from '
+                    'a = 0.02; median wall time between the beginnings of consecutive base '
+                    'steps (torch.cuda.synchronize() in the step callback); by_call = GPU time '
+                    'between HIP events around the calls of the loop, per base step')}
+    del c, loop
+    from concept_amd import mesh as mesh_module
+    mesh_module.free_meshes()
+    torch.cuda.empty_cache()
     return out
 
 
@@ -1274,6 +1407,45 @@ def timeloop_run(torch, dev, raw_ms, n, N, base_steps, keep_order):
     mesh_module.free_meshes()
     torch.cuda.empty_cache()
     return out
+
+
+def pair_sweep_roofline(st, ms, kernel, cell_offsets=None, nt=None):
+    """the short-range sweep's roofline entry from the counters of cg_shortrange_stats (`st`)
+    and the sweep's time: EXECUTED pair tests per second against the FP64 vector issue rate"""
+    tests = st['cells'][0] + st['dense'][0]
+    hits = st['cells'][1] + st['dense'][1]
+    trips = st['cells'][2] + st['dense'][2]
+    per_test = 12   # 3 sub, 3 mul, 2 add, 1 cmp, 3 fma (DESIGN.md §7)
+    dense_tiles = dense_receivers = None
+    if cell_offsets is not None:
+        # the receivers the dense tiles' sweep took: populations of the tiles from the cell list
+        nc = 2*nt
+        off = cell_offsets.long()
+        pop = (off[1:] - off[:-1]).reshape(nc//2, 2, nc//2, 2, nc//2, 2).sum((1, 3, 5))
+        dense_min = int(os.environ.get('CONCEPT_GPU_SR_DENSE_MIN', '64'))
+        took = st['dense'][0] > 0 and dense_min > 0
+        dense_tiles = int((pop >= dense_min).sum()) if took else 0
+        dense_receivers = int(pop[pop >= dense_min].sum()) if took else 0
+    # 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2.4 GHz: one FP64 VALU op per lane slot
+    valu_peak = 256*4*16*2.4e9
+    return {
+        'bound': 'valu_fp64', 'kernel': kernel, 'unit': 'pair-tests/s',
+        'achieved': round(tests/(ms*1e-3), 1), 'peak': round(valu_peak/per_test, 1),
+        'frac': round(tests/(ms*1e-3)/(valu_peak/per_test), 4), 'traffic': None,
+        'kernel_ms': round(ms, 4), 'pair_tests_per_launch': int(tests),
+        'pairs_in_range_per_launch': int(hits),
+        'tests_per_hit': round(tests/max(hits, 1), 3),
+        'lane_slots_per_launch': int(64*trips),
+        'lane_use': round(tests/max(64*trips, 1), 4),
+        'by_kernel': {k: {'pair_tests': v[0], 'in_range': v[1], 'wave_trips': v[2]}
+                      for k, v in st.items()},
+        'dense_tiles': dense_tiles, 'receivers_in_dense_tiles': dense_receivers,
+        'note': ('the sweep is not HBM-bound (72 B per particle against hundreds of pair '
+                 f'tests); peak = FP64 vector issue rate {valu_peak:.3g} lane-ops/s / '
+                 f'{per_test} FP64 VALU instructions per pair test; pair tests = EXECUTED '
+                 'tests counted on the device (half-tile cells sweep + dense tiles\' sweep), '
+                 'tests_per_hit = executed tests per pair inside the force range, lane_use = '
+                 'tests per lane slot of the pair loops')}
 
 
 def run_single(args, torch, dev, rank=0):
@@ -1453,6 +1625,11 @@ def run_single(args, torch, dev, rank=0):
     for ph in PHASES:
         phase_ms[ph] /= len(events)
 
+    # every timed step by itself (HIP events: a step's first mark to the next step's; the last
+    # one to its own last mark): a cold first configuration shows as such
+    step_ms = [events[i][0].elapsed_time(events[i + 1][0]) for i in range(len(events) - 1)]
+    step_ms.append(events[-1][0].elapsed_time(events[-1][len(PHASES)]))
+
     def entry(key, ms):
         gbs = mv[key]/(ms*1e-3)/1e9 if ms > 0 else 0.0
         e = {'ms': round(ms, 4), 'moved_GB': round(mv[key]/1e9, 3), 'GBps': round(gbs, 1),
@@ -1491,6 +1668,9 @@ def run_single(args, torch, dev, rank=0):
         'unit': 'particle-updates/s', 'steps_per_sec': args.steps/elapsed,
         'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'timed_region_s': round(elapsed, 4),
+        'ms_per_step_min_median_max': [round(min(step_ms), 4),
+                                       round(sorted(step_ms)[len(step_ms)//2], 4),
+                                       round(max(step_ms), 4)],
         'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': f'{name}: {n_p} particles ({args.dist}, seed {args.seed}, thermal rms '
@@ -1516,39 +1696,7 @@ def run_single(args, torch, dev, rank=0):
                                     sr['scaling'], sr['r2_max'], sr['factor'])
         st = mesh.shortrange_stats(False)
         del scratch
-        tests = st['cells'][0] + st['dense'][0]
-        hits = st['cells'][1] + st['dense'][1]
-        trips = st['cells'][2] + st['dense'][2]
-        per_test = 12   # 3 sub, 3 mul, 2 add, 1 cmp, 3 fma
-        # the receivers the dense tiles' sweep took: populations of the tiles from the cell list
-        nc = 2*sr['nt']
-        off = sr['cells'][1].long()
-        pop = (off[1:] - off[:-1]).reshape(nc//2, 2, nc//2, 2, nc//2, 2).sum((1, 3, 5))
-        dense_min = int(os.environ.get('CONCEPT_GPU_SR_DENSE_MIN', '64'))
-        took = st['dense'][0] > 0 and dense_min > 0
-        dense_tiles = int((pop >= dense_min).sum()) if took else 0
-        dense_receivers = int(pop[pop >= dense_min].sum()) if took else 0
-        ms = kernels[dom]
-        # 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2.4 GHz: one FP64 VALU op per lane slot
-        valu_peak = 256*4*16*2.4e9
-        result['roofline'] = {
-            'bound': 'valu_fp64', 'kernel': dom, 'unit': 'pair-tests/s',
-            'achieved': round(tests/(ms*1e-3), 1), 'peak': round(valu_peak/per_test, 1),
-            'frac': round(tests/(ms*1e-3)/(valu_peak/per_test), 4), 'traffic': None,
-            'kernel_ms': round(ms, 4), 'pair_tests_per_launch': int(tests),
-            'pairs_in_range_per_launch': int(hits),
-            'tests_per_hit': round(tests/max(hits, 1), 3),
-            'lane_slots_per_launch': int(64*trips),
-            'lane_use': round(tests/max(64*trips, 1), 4),
-            'by_kernel': {k: {'pair_tests': v[0], 'in_range': v[1], 'wave_trips': v[2]}
-                          for k, v in st.items()},
-            'dense_tiles': dense_tiles, 'receivers_in_dense_tiles': dense_receivers,
-            'note': ('the sweep is not HBM-bound (72 B per particle against hundreds of pair '
-                     f'tests); peak = FP64 vector issue rate {valu_peak:.3g} lane-ops/s / '
-                     f'{per_test} FP64 VALU instructions per pair test; pair tests = EXECUTED '
-                     'tests counted on the device (half-tile cells sweep + dense tiles\' sweep), '
-                     'tests_per_hit = executed tests per pair inside the force range, lane_use = '
-                     'tests per lane slot of the pair loops')}
+        result['roofline'] = pair_sweep_roofline(st, kernels[dom], dom, sr['cells'][1], sr['nt'])
     else:
         ach = mv[dom]/(kernels[dom]*1e-3)/1e9
         traffic, traffic_source = pmc_traffic(dom, name)

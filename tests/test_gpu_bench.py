@@ -115,6 +115,16 @@ def test_bench_config4_shape_on_one_gpu():
     assert set(d['phases']) == {'drift_sort', 'short_range'} | {'long: ' + s for s in d['interactions']}
     assert all(v['ms'] > 0 and v['moved_GB'] > 0 for v in d['phases'].values())
     assert d['config']['particles'] == 32**3 and d['config']['fluid_gridsize'] == 16
+    # fractions in the phase's own unit: the pair sweep against the FP64 issue rate (executed
+    # tests counted on the device), the others against the HBM rate
+    sr = d['phases']['short_range']
+    assert 'frac_hbm' not in sr and sr['bound'] == 'valu_fp64' and 0 < sr['frac_valu_fp64'] <= 1
+    assert sr['tests_per_hit'] >= 1 and 0 < sr['lane_use'] <= 1
+    assert all(0 < v['frac_hbm'] <= 1 for k, v in d['phases'].items() if k != 'short_range')
+    r = d['roofline']
+    assert 0 < r['frac'] <= 1
+    assert (r['unit'], r['bound']) in {('pair-tests/s', 'valu_fp64'), ('GB/s', 'hbm')}
+    assert (r['kernel'] == 'short_range') == (r['bound'] == 'valu_fp64')
 
 
 def test_bench_weak_and_dry_links():
@@ -138,3 +148,19 @@ def test_bench_weak_and_dry_links():
     # (with the ranks sharing one GPU the hand-offs between the streams of eight processes
     # cost more than the sleeps: the fraction is reported, not asserted)
     assert 'overlap_fraction' in dl and dl['solve_ms'] > 0
+
+
+def test_bench_rung_loop_leg():
+    """--rung-loop: the P3M time loop with 8 rungs (configs.c2_p3m_rungs of the default line) —
+    base steps timed between their beginnings, the loop's calls grouped by HIP events."""
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--workload', 'tiny',
+                        '--rung-loop', 'clustered', '--steps', '4'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.strip()][-1])
+    assert d['base_steps_timed'] == 4 and d['ms_per_base_step'] > 0 and d['particles_kept']
+    assert d['sub_steps_per_base_step'] >= 1 and d['sweeps_per_base_step'] >= 0
+    g = d['gpu_ms_per_base_step_by_call']
+    assert {'drift_flag_nullify', 'apply_convert_jumps_populations', 'long_range_kick'} <= set(g)
+    assert sum(d['rung_populations_at_the_end']) == 32**3
+    assert d['gpu_ms_per_base_step_in_calls'] <= 1.05*d['ms_per_base_step_min_max'][1]

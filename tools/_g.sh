@@ -1,5 +1,4 @@
 cd /root/repo
-timeout 1200 python -m pytest tests/test_gpu_trajectory.py tests/test_gpu_p3m.py -x -q -m gpu 2>&1 | tail -2
-python tools/sr_rung_cost.py uniform 2>&1 | grep 'by cell' | cut -c1-150
-timeout 600 python tools/soak_p3m.py 0.04 2>&1 | tail -4 | head -1
-SOAK_DIST=clustered timeout 900 python tools/soak_p3m.py 0.025 2>&1 | tail -4 | head -2
+timeout 900 python -m pytest tests/test_gpu_bench.py -x -q -m gpu -k "rung_loop or config4" 2>&1 | tail -5
+timeout 600 python bench.py --rung-loop uniform --steps 12 2>&1 | tail -1
+timeout 600 python bench.py --rung-loop clustered --steps 10 2>&1 | tail -1
