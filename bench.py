@@ -1272,23 +1272,26 @@ def rung_loop_leg(torch, dev, dist, base_steps=12, n_side=256, N=512):
     gen = torch.Generator(device=dev).manual_seed(13)
     c.pos.copy_(positions(dist, n, p.boxsize, gen))
     c.mom.zero_()
-    # the loop's calls, grouped: an event pair around each
-    groups = {}
+    # the loop's calls, grouped: an event pair around each (and the host's clock at both ends)
+    groups, host = {}, []
 
     def timed(obj, attr, group):
         f = getattr(obj, attr)
 
         def wrapper(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
             e0.record()
             try:
                 return f(*a, **k)
             finally:
                 e1.record()
                 groups.setdefault(group, []).append((e0, e1))
+                host.append((group, t0, time.perf_counter()))
         setattr(obj, attr, wrapper)
         return lambda: setattr(obj, attr, f)
-    undo = [timed(species.Component, 'substep_begin', 'drift_flag_nullify'),
+    undo = [timed(species.Component, 'substep_finish', 'wait_for_the_sub_step'),
+            timed(species.Component, 'substep_begin', 'drift_flag_nullify'),
             timed(species.Component, 'substep_end', 'apply_convert_jumps_populations'),
             timed(PotentialMesh, 'shortrange_cells', 'cell_list'),
             timed(PotentialMesh, 'shortrange_sweep_cells', 'sweep'),
@@ -1318,6 +1321,20 @@ def rung_loop_leg(torch, dev, dist, base_steps=12, n_side=256, N=512):
     lo = marks[2]
     per_group = {g: round(sum(e0.elapsed_time(e1) for e0, e1 in v[lo.get(g, 0):])/len(dts), 3)
                  for g, v in groups.items()}
+    per_group.pop('wait_for_the_sub_step', None)
+    # the host between the end of a sub-step's wait and the first call that launches work for
+    # the next one (the GPU has nothing queued then), per base step
+    t_first = stamps[2]
+    idle, inside = 0.0, {}
+    prev = None
+    for g, t0, t1 in host:
+        if t0 < t_first:
+            prev = (g, t1)
+            continue
+        inside[g] = inside.get(g, 0.0) + (t1 - t0)
+        if prev is not None and prev[0] == 'wait_for_the_sub_step' and t0 <= stamps[-1]:
+            idle += t0 - prev[1]
+        prev = (g, t1)
     sweeps = len(groups.get('sweep', [])) - lo.get('sweep', 0)
     out = {'ms_per_base_step': round(statistics.median(dts), 3),
            'ms_per_base_step_min_max': [round(min(dts), 3), round(max(dts), 3)],
@@ -1327,6 +1344,9 @@ def rung_loop_leg(torch, dev, dist, base_steps=12, n_side=256, N=512):
            'sweeps_per_base_step': round(sweeps/len(dts), 2),
            'gpu_ms_per_base_step_by_call': per_group,
            'gpu_ms_per_base_step_in_calls': round(sum(per_group.values()), 3),
+           'host_ms_per_base_step_between_wait_and_next_call': round(idle*1e3/len(dts), 3),
+           'host_ms_per_base_step_inside_calls': {g: round(v*1e3/len(dts), 3)
+                                                  for g, v in inside.items()},
            'rung_populations_at_the_end': [int(v) for v in c.rungs_N],
            'a_reached': loop.cosmo.a, 'particles_kept': int(c.N_local) == n,
            'what': (f'stepper.Timeloop (= main.timeloop(), main.py:102-471), P3M, N_rungs = '

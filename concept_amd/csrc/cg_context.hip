@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "cg_internal.h"
+#include "cg_substep.h"
 
 static thread_local std::string g_err;
 
@@ -305,6 +306,7 @@ extern "C" int cg_create(const cg_params *p, cg_ctx **out) {
         g_rocfft_ready = true;
     }
     cg_ctx *c = new cg_ctx();
+    c->sub_begin = new SubstepBegin();
     c->p = *p;
     c->N = p->gridsize;
     c->pad = (c->N % 16 == 0) ? c->N + 16 : c->N + 2;
@@ -454,17 +456,21 @@ extern "C" int cg_destroy(cg_ctx *c) {
     }
     if (c->sr_fork) (void)hipEventDestroy(c->sr_fork);
     (void)hipFree(c->sr_active);
+    delete c->sub_begin;
+    (void)hipFree(c->sub_partial);
     delete c;
     return 0;
 }
 
 extern "C" int cg_set_stream(cg_ctx *c, void *s) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c, "cg_set_stream: null context");
     c->stream = (hipStream_t)s;
     return 0;
 }
 
 extern "C" int cg_synchronize(cg_ctx *c) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c, "cg_synchronize: null context");
     CG_HIP(hipStreamSynchronize(c->stream));
     return 0;
@@ -493,6 +499,7 @@ extern "C" int cg_mesh_zero(cg_ctx *c) {
 }
 
 extern "C" int cg_deposit_cic(cg_ctx *c, const double *pos, int64_t n, double contribution) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && (pos || n == 0), "cg_deposit_cic: null argument");
     CG_CHECK(n >= 0, "cg_deposit_cic: negative particle count");
     if (n == 0) return 0;
@@ -586,6 +593,7 @@ extern "C" int cg_copy_modes_unpack(cg_ctx *onto, cg_ctx *from, int64_t n_small,
 
 extern "C" int cg_deposit(cg_ctx *c, const double *pos, int64_t n, double contribution, int order,
                           const double *shift) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && (pos || n == 0), "cg_deposit: null argument");
     CG_CHECK(order >= 1 && order <= 4,
              "interpolate_particles() called with order = %d not in {1 (NGP), 2 (CIC), 3 (TSC), 4 (PCS)}",
@@ -597,6 +605,7 @@ extern "C" int cg_deposit(cg_ctx *c, const double *pos, int64_t n, double contri
 
 extern "C" int cg_gather_scalar(cg_ctx *c, const double *pos, double *mom, int64_t n, int dim,
                                 int order, const double *shift, double factor) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && ((pos && mom) || n == 0), "cg_gather_scalar: null argument");
     CG_CHECK(order >= 1 && order <= 4,
              "interpolate_domaingrid_to_particles() called with order = %d not in {1, 2, 3, 4}",
@@ -636,6 +645,7 @@ extern "C" int cg_pp_kick(cg_ctx *c, const double *pos_r, int64_t n_r, double *d
                           int ewald_gridsize, double softening, int kernel, double factor,
                           const double *factors, const signed char *rung,
                           const signed char *rung_jumped, int lowest_active) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && ((pos_r && dmom_r) || n_r == 0) && (pos_s || n_s == 0),
              "cg_pp_kick: null argument");
     CG_CHECK(kernel >= 0 && kernel <= 2, "Softening kernel %d not understood", kernel);
@@ -740,6 +750,7 @@ extern "C" int cg_poisson_solve_timed(cg_ctx *c, int deconv_order, double C, int
 
 extern "C" int cg_gather_kick(cg_ctx *c, const double *pos, double *mom, int64_t n, int diff_order,
                               double factor) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && ((pos && mom) || n == 0), "cg_gather_kick: null argument");
     CG_CHECK(diff_order == 2 || diff_order == 4,
              "cg_gather_kick: differentiation order %d not built (2 and 4 are)", diff_order);
@@ -753,6 +764,7 @@ extern "C" int cg_gather_kick(cg_ctx *c, const double *pos, double *mom, int64_t
 
 extern "C" int cg_drift(cg_ctx *c, double *pos, const double *mom, int64_t n,
                         double dt_over_mass) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && ((pos && mom) || n == 0), "cg_drift: null argument");
     if (n == 0) return 0;
     c->prep_valid = false;
@@ -761,6 +773,7 @@ extern "C" int cg_drift(cg_ctx *c, double *pos, const double *mom, int64_t n,
 
 extern "C" int cg_measure_momentum(cg_ctx *c, const double *mom, int64_t n, double *out,
                                    double *scratch) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && out && scratch && (mom || n == 0), "cg_measure_momentum: null argument");
     CG_CHECK(n >= 0, "cg_measure_momentum: n out of range");
     return cgk_measure_mom(c, mom, n, out, scratch);
@@ -783,6 +796,7 @@ extern "C" int cg_tile_info(const cg_ctx *c, int64_t info[3]) {
 extern "C" int cg_deposit_cic_tiled(cg_ctx *c, const double *pos, int64_t n,
                                     const uint32_t *tile_offset, double contribution,
                                     int accumulate) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && tile_offset && (pos || n == 0), "cg_deposit_cic_tiled: null argument");
     CG_CHECK(n >= 0 && n < (1ll << 32), "cg_deposit_cic_tiled: n out of range");
     return cgk_deposit_cic_tiled(c, pos, n, tile_offset, nullptr, contribution, accumulate);
@@ -851,6 +865,7 @@ extern "C" int cg_gather_kick_drift_scatter(
 
 extern "C" int cg_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, int64_t n,
                                     const uint32_t *tile_offset, int diff_order, double factor) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && tile_offset && ((pos && mom) || n == 0), "cg_gather_kick_tiled: null argument");
     CG_CHECK(diff_order == 2 || diff_order == 4,
              "cg_gather_kick_tiled: differentiation order %d not built (2 and 4 are)", diff_order);
@@ -864,6 +879,7 @@ extern "C" int cg_gather_kick_tiled(cg_ctx *c, const double *pos, double *mom, i
 extern "C" int cg_gather_kick_tiled_prepare(cg_ctx *c, const double *pos, double *mom, int64_t n,
                                             const uint32_t *tile_offset, int diff_order,
                                             double factor, double next_dt_over_mass) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && tile_offset && ((pos && mom) || n == 0),
              "cg_gather_kick_tiled_prepare: null argument");
     CG_CHECK(diff_order == 2 || diff_order == 4,
@@ -922,6 +938,7 @@ extern "C" int cg_region_insert(cg_ctx *c, const double *rows, int64_t m, const 
 extern "C" int cg_sort_particles(cg_ctx *c, const double *pos_in, const double *mom_in,
                                  const int64_t *ids_in, double *pos_out, double *mom_out,
                                  int64_t *ids_out, int64_t n, uint32_t *tile_offset_out) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     // (an empty set — a domain without particles — may come with null arrays)
     CG_CHECK(c && tile_offset_out && (n == 0 || (pos_in && mom_in && pos_out && mom_out)),
              "cg_sort_particles: null argument");
@@ -938,6 +955,7 @@ extern "C" int cg_drift_sort(cg_ctx *c, const double *pos_in, const double *mom_
                              const int64_t *ids_in, double *pos_out, double *mom_out,
                              int64_t *ids_out, int64_t n, double dt_over_mass,
                              uint32_t *tile_offset_out) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && tile_offset_out && (n == 0 || (pos_in && mom_in && pos_out && mom_out)),
              "cg_drift_sort: null argument");
     CG_CHECK(n == 0 || (pos_in != pos_out && mom_in != mom_out),
@@ -958,6 +976,7 @@ extern "C" int cg_drift_sort(cg_ctx *c, const double *pos_in, const double *mom_
 
 extern "C" int cg_owner_rank_drifted(cg_ctx *c, const double *pos, const double *mom, int64_t n,
                                      double dt_over_mass, int32_t *owner) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && (n == 0 || (pos && mom && owner)), "cg_owner_rank_drifted: null argument");
     return cgk_owner_rank_drifted(c, pos, mom, n, dt_over_mass, owner);
 }
@@ -972,6 +991,7 @@ extern "C" int cg_prepare_rebind(cg_ctx *c, const double *pos, const double *mom
 
 extern "C" int cg_cic_indices(cg_ctx *c, const double *pos, int64_t n, int for_gather,
                               int64_t *idx_out) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && (n == 0 || (pos && idx_out)), "cg_cic_indices: null argument");
     if (n == 0) return 0;
     return cgk_cic_indices(c, pos, n, for_gather, idx_out);
@@ -1046,6 +1066,7 @@ extern "C" int cg_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted,
                                          const uint32_t *offset_s, int64_t nt,
                                          const double *table, int64_t tablesize,
                                          double r2_index_scaling, double r2_max, double factor) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     if (sweep_cells_checks(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted, offset_s,
                            table, nt, tablesize, r2_index_scaling, r2_max))
         return 1;
@@ -1060,6 +1081,7 @@ extern "C" int cg_shortrange_sweep_cells_rungs(
     const double *table, int64_t tablesize, double r2_index_scaling, double r2_max,
     const double *factors, const int8_t *rung_r, const int8_t *rung_jumped_r,
     int lowest_active_rung) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     if (sweep_cells_checks(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted, offset_s,
                            table, nt, tablesize, r2_index_scaling, r2_max))
         return 1;
@@ -1079,6 +1101,7 @@ extern "C" int cg_shortrange_sweep_cells_active(
     int64_t tablesize, double r2_index_scaling, double r2_max, const double *factors,
     const int8_t *rung_r, const int8_t *rung_jumped_r, int lowest_active_rung,
     int64_t n_active_max) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     if (sweep_cells_checks(c, pos_r_sorted, order_r, offset_r, dmom_r, pos_s_sorted, offset_s,
                            table, nt, tablesize, r2_index_scaling, r2_max))
         return 1;
@@ -1114,6 +1137,7 @@ extern "C" int cg_shortrange_tiles(cg_ctx *c, const double *pos, int64_t n, int6
                                    double tile_extent, const int8_t *rung,
                                    int lowest_active_rung, uint32_t *order_out,
                                    uint32_t *offset_out, double *pos_sorted_out) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && offset_out && (n == 0 || (pos && order_out)),
              "cg_shortrange_tiles: null argument");
     CG_CHECK(nt >= 4, "The global gravity tiling needs to have at least 4 tiles across the box in "
@@ -1130,11 +1154,13 @@ extern "C" int cg_shortrange_tiles(cg_ctx *c, const double *pos, int64_t n, int6
 
 extern "C" int cg_dmom_nullify(cg_ctx *c, double *dmom, const int8_t *rung, int64_t n,
                                int lowest_active_rung) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && (dmom || n == 0), "cg_dmom_nullify: null argument");
     return cgk_dmom_active(c, nullptr, dmom, (const signed char *)rung, n, lowest_active_rung, 0);
 }
 extern "C" int cg_dmom_apply(cg_ctx *c, double *mom, const double *dmom, const int8_t *rung,
                              int64_t n, int lowest_active_rung) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && ((mom && dmom) || n == 0), "cg_dmom_apply: null argument");
     c->prep_valid = false;  // mom changes: a prepared drift histogram no longer describes it
     return cgk_dmom_active(c, mom, (double *)dmom, (const signed char *)rung, n,
@@ -1143,6 +1169,7 @@ extern "C" int cg_dmom_apply(cg_ctx *c, double *mom, const double *dmom, const i
 extern "C" int cg_dmom_to_acc(cg_ctx *c, double *dmom, const int8_t *rung,
                               const int8_t *rung_jumped, int64_t n, int lowest_active_rung,
                               const double *conversion_factors, int any_rung_jumps) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && conversion_factors && ((dmom && rung && rung_jumped) || n == 0),
              "cg_dmom_to_acc: null argument");
     return cgk_dmom_to_acc(c, dmom, (const signed char *)rung, (const signed char *)rung_jumped, n,
@@ -1150,6 +1177,7 @@ extern "C" int cg_dmom_to_acc(cg_ctx *c, double *dmom, const int8_t *rung,
 }
 extern "C" int cg_assign_rungs(cg_ctx *c, const double *acc, int8_t *rung, int8_t *rung_jumped,
                                int64_t n, double rung_factor, int N_rungs) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && ((acc && rung && rung_jumped) || n == 0), "cg_assign_rungs: null argument");
     CG_CHECK(N_rungs >= 1 && N_rungs <= 42, "cg_assign_rungs: N_rungs = %d", N_rungs);
     return cgk_assign_rungs(c, acc, (signed char *)rung, (signed char *)rung_jumped, n, rung_factor,
@@ -1159,6 +1187,7 @@ extern "C" int cg_flag_rung_jumps(cg_ctx *c, const double *acc, const int8_t *ru
                                   int8_t *rung_jumped, int64_t n, int lowest_active_rung,
                                   const double *integrals_1, double rung_factor_up,
                                   double rung_factor_down, int N_rungs, int32_t *any_out) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && integrals_1 && any_out && ((acc && rung && rung_jumped) || n == 0),
              "cg_flag_rung_jumps: null argument");
     CG_CHECK(N_rungs >= 1 && N_rungs <= 42, "cg_flag_rung_jumps: N_rungs = %d", N_rungs);
@@ -1168,6 +1197,7 @@ extern "C" int cg_flag_rung_jumps(cg_ctx *c, const double *acc, const int8_t *ru
 }
 extern "C" int cg_apply_rung_jumps(cg_ctx *c, int8_t *rung, int8_t *rung_jumped, int64_t n,
                                    int N_rungs) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && ((rung && rung_jumped) || n == 0), "cg_apply_rung_jumps: null argument");
     return cgk_apply_rung_jumps(c, (signed char *)rung, (signed char *)rung_jumped, n, N_rungs);
 }
@@ -1176,7 +1206,8 @@ extern "C" int cg_substep_begin(cg_ctx *c, double *pos, const double *mom, doubl
                                 const int8_t *rung, int8_t *rung_jumped, int64_t n, int do_drift,
                                 double dt_over_mass, int do_flag, int lowest_active_rung,
                                 const double *integrals_1, double rung_factor_up,
-                                double rung_factor_down, int N_rungs, int32_t *any_out) {
+                                double rung_factor_down, int N_rungs, int32_t *any_out,
+                                int64_t *counts_after, int defer) {
     CG_CHECK(c && (n == 0 || ((!do_drift || (pos && mom)) &&
                               (!do_flag || (dmom && rung && rung_jumped)))) &&
                  (!do_flag || (integrals_1 && any_out)),
@@ -1186,13 +1217,18 @@ extern "C" int cg_substep_begin(cg_ctx *c, double *pos, const double *mom, doubl
     return cgk_substep_begin(c, pos, mom, dmom, (const signed char *)rung,
                              (signed char *)rung_jumped, n, do_drift, dt_over_mass, do_flag,
                              lowest_active_rung, integrals_1, rung_factor_up, rung_factor_down,
-                             N_rungs, any_out);
+                             N_rungs, any_out, (long long *)counts_after, defer);
+}
+extern "C" int cg_substep_flush(cg_ctx *c) {
+    CG_CHECK(c, "cg_substep_flush: null context");
+    return cgk_substep_flush(c);
 }
 extern "C" int cg_substep_end(cg_ctx *c, double *mom, double *dmom, int8_t *rung,
                               int8_t *rung_jumped, int64_t n, int do_apply,
                               int lowest_active_rung, const double *conversion_factors,
                               int N_rungs, int64_t *counts) {
-    CG_CHECK(c && counts && (n == 0 || (rung && rung_jumped && (!do_apply || (mom && dmom)))) &&
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
+    CG_CHECK(c && (n == 0 || (rung && rung_jumped && (!do_apply || (mom && dmom)))) &&
                  (!do_apply || conversion_factors),
              "cg_substep_end: null argument");
     CG_CHECK(N_rungs >= 1 && 3 * N_rungs - 1 <= CG_RUNG_TABLE_MAX, "cg_substep_end: N_rungs = %d",
@@ -1207,6 +1243,7 @@ extern "C" int cg_shortrange_sparse(cg_ctx *c, const double *pos_r, const int64_
                                    const double *table, int64_t tablesize,
                                    double r2_index_scaling, double r2_max, double factor,
                                    const double *factors, const int8_t *rung_jumped) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && pos_r && active && dmom_r && table && (pos_s || n_s == 0),
              "cg_shortrange_sparse: null argument");
     CG_CHECK(tablesize >= 2 && (double)(tablesize - 1) >= r2_max * r2_index_scaling,
@@ -1222,6 +1259,7 @@ extern "C" int cg_shortrange_sparse(cg_ctx *c, const double *pos_r, const int64_
 
 extern "C" int cg_rung_populations(cg_ctx *c, const int8_t *rung, int64_t n, int N_rungs,
                                    int64_t *counts) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && counts && (rung || n == 0), "cg_rung_populations: null argument");
     CG_CHECK(N_rungs >= 1 && N_rungs <= 64, "cg_rung_populations: N_rungs out of range");
     return cgk_rung_populations(c, (const signed char *)rung, n, N_rungs, (long long *)counts);
@@ -1334,6 +1372,7 @@ extern "C" int cg_dist_fft_backward_layers(cg_ctx *c, const double *recv_buf, in
     return cgk_fft_dist_backward(c, recv_buf, layer0, nlayers);
 }
 extern "C" int cg_owner_rank(cg_ctx *c, const double *pos, int64_t n, int32_t *owner_out) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
     CG_CHECK(c && (n == 0 || (pos && owner_out)), "cg_owner_rank: null argument");
     return cgk_owner_rank(c, pos, n, owner_out);
 }

@@ -123,6 +123,12 @@ struct cg_ctx {
     // side streams of the short-range sweep (its interior and face launches are independent and
     // run side by side: a clustered box otherwise waits for the few dense tiles of each launch
     // in turn), created at the first sweep
+    // a sub-step's first pass, deferred to the cell list that follows it (cg_substep.h)
+    struct SubstepBegin *sub_begin = nullptr;
+    bool sub_pending = false;
+    long long *sub_counts = nullptr;     // where the pending pass leaves the populations (DEV)
+    unsigned *sub_partial = nullptr;     // ... per workgroup first
+    size_t sub_partial_bytes = 0;
     unsigned *sr_active = nullptr;   // [0] count, [64..] the cells that hold an active receiver
     size_t sr_active_bytes = 0;
     hipStream_t sr_streams[3] = {nullptr, nullptr, nullptr};
@@ -258,7 +264,10 @@ int cgk_substep_begin(cg_ctx *c, double *pos, const double *mom, double *dmom,
                       const signed char *rung, signed char *rung_jumped, i64 n, int do_drift,
                       double dt_over_mass, int do_flag, int lowest_active,
                       const double *integrals_1, double rf_up, double rf_down, int N_rungs,
-                      int *any_out);
+                      int *any_out, long long *counts_after, int defer);
+int cgk_substep_flush(cg_ctx *c);
+int cgk_substep_partial(cg_ctx *c, i64 n, i64 per, int N_rungs, i64 *nwg_out);
+int cgk_substep_populations(cg_ctx *c, i64 nwg, int N_rungs, long long *counts);
 int cgk_substep_end(cg_ctx *c, double *mom, double *dmom, signed char *rung,
                     signed char *rung_jumped, i64 n, int do_apply, int lowest_active,
                     const double *conversion_factors, int N_rungs, long long *counts);

@@ -7,7 +7,7 @@
 // All are streaming, one lane per particle; rung indices are the reference's
 // `signed char` arrays (int8), jumped indices carry +N_rungs (down) / +2 N_rungs (up).
 #include "cg_internal.h"
-#include "cg_tiles.h"
+#include "cg_substep.h"
 
 #define CG_LAUNCH_CHECK()                                                                     \
     do {                                                                                      \
@@ -54,17 +54,8 @@ __global__ void k_dmom_to_acc(double *__restrict__ dmom, const i8 *__restrict__ 
     dmom[3 * p + 2] *= f;
 }
 
-// get_rung, species.py:2341-2363
-__device__ __forceinline__ int get_rung(const double *__restrict__ dmom, i64 p, int current,
-                                        double rung_factor, int N_rungs) {
-    double ax = dmom[3 * p], ay = dmom[3 * p + 1], az = dmom[3 * p + 2];
-    double acc2 = ax * ax + ay * ay + az * az;
-    if (acc2 == 0) return current;
-    double f = rung_factor + 0.25 * log2(acc2);
-    if (f < 0) return 0;
-    if (f > N_rungs - 1) return N_rungs - 1;
-    return 1 + (int)(i8)f;
-}
+// get_rung (species.py:2341-2363): cg_substep.h
+#define get_rung cg_get_rung
 
 __global__ void k_assign_rungs(const double *__restrict__ dmom, i8 *__restrict__ rung,
                                i8 *__restrict__ rung_jumped, i64 n, double rung_factor,
@@ -199,47 +190,58 @@ int cgk_apply_rung_jumps(cg_ctx *c, i8 *rung, i8 *rung_jumped, i64 n, int N_rung
 //   end:   apply_Δmom -> convert_Δmom_to_acc -> apply_rung_jumps -> set_rungs_N
 // The rung tables (3 N_rungs - 1 doubles) travel as kernel arguments: no upload, no wait.
 // ---------------------------------------------------------------------------
-struct RungTable {
-    double v[CG_RUNG_TABLE_MAX];
-};
-
-template <bool DRIFT, bool FLAG>
-__global__ __launch_bounds__(256) void k_substep_begin(double *__restrict__ pos,
-                                                       const double *__restrict__ mom,
-                                                       double *__restrict__ dmom,
-                                                       const i8 *__restrict__ rung,
-                                                       i8 *__restrict__ rung_jumped, i64 n,
-                                                       double dtm, double L, int lowest_active,
-                                                       RungTable integrals, double rf_up,
-                                                       double rf_down, int N_rungs,
-                                                       int *__restrict__ any_out) {
+__global__ __launch_bounds__(256) void k_substep_begin(SubstepBegin B) {
+    __shared__ unsigned s_cnt[64];
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    if (DRIFT) {
-#pragma unroll
-        for (int d = 0; d < 3; d++) pos[3 * p + d] = ref_mod(pos[3 * p + d] + mom[3 * p + d] * dtm, L);
+    int r = 255;
+    if (p < B.n) {
+        double x, y, z;
+        r = cg_substep_begin_particle(B, p, x, y, z);
     }
-    if (!FLAG) return;
-    const int r = rung[p];
-    if (r < lowest_active) return;  // (flag_rung_jumps and nullify_Δ: active rungs only)
-    // flag_rung_jumps, species.py:2476-2512 (k_flag_rung_jumps)
-    if (integrals.v[r] != 0) {
-        int ought = get_rung(dmom, p, r, rf_up, N_rungs);
-        if (ought > r) {
-            rung_jumped[p] = (i8)(r + 2 * N_rungs);
-            *any_out = 1;
-        } else if (integrals.v[r + N_rungs] != -1) {
-            ought = get_rung(dmom, p, r, rf_down, N_rungs);
-            if (ought < r) {
-                rung_jumped[p] = (i8)(r + N_rungs);
-                *any_out = 1;
-            }
-        }
+    if (!B.partial) return;
+    cg_count_rungs(r, B.N_rungs, s_cnt);
+    __syncthreads();
+    if (threadIdx.x < (unsigned)B.N_rungs)
+        B.partial[(i64)B.N_rungs * blockIdx.x + threadIdx.x] = s_cnt[threadIdx.x];
+}
+// counts[r] = sum over the workgroups' partial[N_rungs * w + r]: a workgroup per rung, fixed order
+__global__ __launch_bounds__(1024) void k_substep_populations(const unsigned *__restrict__ partial,
+                                                              i64 nwg, int N_rungs,
+                                                              unsigned long long *__restrict__ counts) {
+    __shared__ unsigned long long red[1024];
+    const int r = blockIdx.x;
+    unsigned long long s = 0;
+    for (i64 w = threadIdx.x; w < nwg; w += 1024) s += partial[(i64)N_rungs * w + r];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 512; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
     }
-    // nullify_Δ('mom'), species.py:3717-3741
-    dmom[3 * p] = 0;
-    dmom[3 * p + 1] = 0;
-    dmom[3 * p + 2] = 0;
+    if (threadIdx.x == 0) counts[r] = red[0];
+}
+int cgk_substep_populations(cg_ctx *c, i64 nwg, int N_rungs, long long *counts) {
+    hipLaunchKernelGGL(k_substep_populations, dim3(N_rungs), dim3(1024), 0, c->stream, c->sub_partial,
+                       nwg, N_rungs, (unsigned long long *)counts);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+// room for the per-workgroup populations of a pass over n particles in workgroups of `per`
+int cgk_substep_partial(cg_ctx *c, i64 n, i64 per, int N_rungs, i64 *nwg_out) {
+    const i64 nwg = (n + per - 1) / per;
+    const size_t need = sizeof(unsigned) * (size_t)N_rungs * (size_t)(nwg + 1);
+    if (need > c->sub_partial_bytes) {
+        CG_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->sub_partial);
+        c->sub_partial = nullptr;
+        c->sub_partial_bytes = 0;
+        CG_HIP(hipMalloc((void **)&c->sub_partial, need));
+        c->sub_partial_bytes = need;
+    }
+    *nwg_out = nwg;
+    return 0;
 }
 
 // (a fixed number of workgroups, every thread a strided share: the populations cost 8 atomics
@@ -279,39 +281,53 @@ __global__ __launch_bounds__(256) void k_substep_end(double *__restrict__ mom,
                 rung_jumped[p] = (i8)r;
             }
         }
-        // set_rungs_N, species.py:2560-2587
-        for (int q = 0; q < N_rungs && q < 64; q++) {
-            const unsigned c = (unsigned)__popcll(__ballot(r == q));
-            if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt[q], c);
-        }
+        // set_rungs_N, species.py:2560-2587 (null: the sub-step's first pass has counted)
+        if (counts) cg_count_rungs(r, N_rungs, s_cnt);
     }
     __syncthreads();
-    if (threadIdx.x < (unsigned)N_rungs && threadIdx.x < 64 && s_cnt[threadIdx.x])
+    if (counts && threadIdx.x < (unsigned)N_rungs && threadIdx.x < 64 && s_cnt[threadIdx.x])
         atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 }
 
+// defer: nothing is launched — the cell list the sub-step's sweep asks for next (cg_shortrange_cells
+// [_rungs] on the same positions) runs the pass on every particle it bins, cgk_substep_flush
+// (any other use of the particles) launches it by itself
 int cgk_substep_begin(cg_ctx *c, double *pos, const double *mom, double *dmom, const i8 *rung,
                       i8 *rung_jumped, i64 n, int do_drift, double dt_over_mass, int do_flag,
                       int lowest_active, const double *integrals_1, double rf_up, double rf_down,
-                      int N_rungs, int *any_out) {
+                      int N_rungs, int *any_out, long long *counts_after, int defer) {
+    if (cgk_substep_flush(c)) return 1;
     if (do_flag) CG_HIP(hipMemsetAsync(any_out, 0, sizeof(int), c->stream));
     if (n == 0 || (!do_drift && !do_flag)) return 0;
-    RungTable T{};
+    SubstepBegin &B = *c->sub_begin;
+    B = SubstepBegin{pos, mom, dmom, rung, rung_jumped, n, do_drift, do_flag, dt_over_mass,
+                     c->p.boxsize, lowest_active, RungTable{}, rf_up, rf_down, N_rungs, any_out,
+                     nullptr};
     if (do_flag)
-        for (int i = 0; i < 3 * N_rungs - 1; i++) T.v[i] = integrals_1[i];
-    auto kern = do_drift ? (do_flag ? k_substep_begin<true, true> : k_substep_begin<true, false>)
-                         : k_substep_begin<false, true>;
-    hipLaunchKernelGGL(kern, dim3(nblocks(n)), dim3(256), 0, c->stream, pos, mom, dmom, rung,
-                       rung_jumped, n, dt_over_mass, c->p.boxsize, lowest_active, T, rf_up, rf_down,
-                       N_rungs, any_out);
+        for (int i = 0; i < 3 * N_rungs - 1; i++) B.integrals.v[i] = integrals_1[i];
+    c->sub_counts = do_flag ? counts_after : nullptr;
+    c->sub_pending = true;
+    return defer ? 0 : cgk_substep_flush(c);
+}
+int cgk_substep_flush(cg_ctx *c) {
+    if (!c->sub_pending) return 0;
+    c->sub_pending = false;
+    SubstepBegin &B = *c->sub_begin;
+    i64 nwg = 0;
+    if (c->sub_counts) {
+        if (cgk_substep_partial(c, B.n, 256, B.N_rungs, &nwg)) return 1;
+        B.partial = c->sub_partial;
+    }
+    hipLaunchKernelGGL(k_substep_begin, dim3(nblocks(B.n)), dim3(256), 0, c->stream, B);
     CG_LAUNCH_CHECK();
+    if (c->sub_counts && cgk_substep_populations(c, nwg, B.N_rungs, c->sub_counts)) return 1;
     return 0;
 }
 
 int cgk_substep_end(cg_ctx *c, double *mom, double *dmom, i8 *rung, i8 *rung_jumped, i64 n,
                     int do_apply, int lowest_active, const double *conversion_factors, int N_rungs,
                     long long *counts) {
-    CG_HIP(hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)N_rungs, c->stream));
+    if (counts) CG_HIP(hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)N_rungs, c->stream));
     if (n == 0) return 0;
     RungTable T{};
     if (do_apply)

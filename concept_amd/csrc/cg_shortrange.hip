@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "cg_internal.h"
+#include "cg_substep.h"
 
 #define CG_LAUNCH_CHECK()                                                                     \
     do {                                                                                      \
@@ -91,14 +92,15 @@ struct SrCount {
 // ===========================================================================
 constexpr int kSrSlack = 128; // masked lanes read up to 2*S - 1 < 128 entries past a range
 
-__device__ __forceinline__ unsigned sr_cell(const double *__restrict__ pos, i64 p, double inv,
-                                            double ext, unsigned nt) {
+__device__ __forceinline__ unsigned sr_cell_of(double x0, double x1, double x2, double inv,
+                                               double ext, unsigned nt) {
     // tile index exactly as Tiling.sort (species.py:775-780); the half inside the tile from
     // the distance to the tile's lower face
     unsigned c[3];
+    const double xs[3] = {x0, x1, x2};
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        const double x = pos[3 * p + d];
+        const double x = xs[d];
         unsigned t = (unsigned)(i64)((x - 0.0) * inv);
         t = t >= nt ? nt - 1 : t;
         const unsigned half = (x - (double)t * ext) >= 0.5 * ext ? 1u : 0u;
@@ -153,77 +155,59 @@ struct SrActive {  // (ACT) which particles are receivers of this sub-step
     const signed char *rung, *rung_jumped;
     int lowest;
 };
-template <bool ACT>
-__global__ __launch_bounds__(256) void k_sr_cell_histogram(const double *__restrict__ pos, i64 n,
-                                                           double inv, double ext, unsigned nt,
-                                                           unsigned *__restrict__ count,
-                                                           SrActive A, unsigned *__restrict__ nact) {
+// Pass 1, counting.  The workgroup's particles are counted per cell in the LDS table (a slot's
+// counter hands every particle its rank among the workgroup's particles of that cell); then ONE
+// device atomic per cell the workgroup met adds its count to the cell's — and what the atomic
+// returns is where the workgroup's particles start INSIDE the cell.  cellrel[p] = (cell, that
+// start + the particle's rank): the second pass has nothing left to count — no table, no atomic
+// (it had one per cell and workgroup too: the two passes' 13 million device atomics at 256^3
+// were most of their time; the memory-side atomic units take 28e9 a second).
+// ACT: count[] takes the inactive particles, nact[] the active ones; bit 31 of the second word
+// marks an active particle.
+// BEGIN: the particle's sub-step pass first (cg_substep.h: drift, flag_rung_jumps, nullify_Δ — the
+// time loop deferred it to this list): the drifted position is binned without being read again.
+template <bool ACT, bool BEGIN>
+__global__ __launch_bounds__(256) void k_sr_cell_count(const double *__restrict__ pos, i64 n,
+                                                       double inv, double ext, unsigned nt,
+                                                       unsigned *__restrict__ count, SrActive A,
+                                                       unsigned *__restrict__ nact,
+                                                       uint2 *__restrict__ cellrel,
+                                                       SubstepBegin B) {
     __shared__ std::conditional_t<ACT, SrHashAct, SrHash> H;
+    __shared__ unsigned s_cnt[64];  // (BEGIN: the workgroup's particles per rung after the sub-step)
     sr_hash_clear(H);
+    if (BEGIN && threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const i64 base = (i64)blockIdx.x * (256 * kSrPerThread);
-#pragma unroll
-    for (int u = 0; u < kSrPerThread; u++) {
-        const i64 p = base + threadIdx.x + 256 * u;
-        if (p < n) {
-            const unsigned slot = sr_hash_slot(H, sr_cell(pos, p, inv, ext, nt));
-            atomicAdd(&H.cnt[slot], 1u);
-            if constexpr (ACT)
-                if (A.rung[p] >= A.lowest) atomicAdd(&H.act[slot], 1u);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kSrHashSlots; i += 256)
-        if (H.cnt[i]) {
-            atomicAdd(&count[H.key[i]], H.cnt[i]);
-            if constexpr (ACT)
-                if (H.act[i]) atomicAdd(&nact[H.key[i]], H.act[i]);
-        }
-}
-// cursor: rows handed out so far per cell (ACT: to the active particles; cursor_i: to the others,
-// whose rows follow the cell's nact active ones)
-template <bool ACT>
-__global__ __launch_bounds__(256) void k_sr_cell_scatter(const double *__restrict__ pos, i64 n,
-                                                         double inv, double ext, unsigned nt,
-                                                         const unsigned *__restrict__ offset,
-                                                         unsigned *__restrict__ cursor,
-                                                         unsigned *__restrict__ order,
-                                                         double *__restrict__ pos_sorted,
-                                                         SrActive A, const unsigned *__restrict__ nact,
-                                                         unsigned *__restrict__ cursor_i,
-                                                         signed char *__restrict__ rj_sorted) {
-    __shared__ std::conditional_t<ACT, SrHashAct, SrHash> H;
-    sr_hash_clear(H);
-    __syncthreads();
-    const i64 base = (i64)blockIdx.x * (256 * kSrPerThread);
-    unsigned slot[kSrPerThread], rank[kSrPerThread];
+    unsigned slot[kSrPerThread], rank[kSrPerThread], cell[kSrPerThread];
     bool act[kSrPerThread];
-    double x[kSrPerThread], y[kSrPerThread], z[kSrPerThread];
 #pragma unroll
     for (int u = 0; u < kSrPerThread; u++) {
         const i64 p = base + threadIdx.x + 256 * u;
-        slot[u] = 0, rank[u] = 0, act[u] = false;
+        slot[u] = rank[u] = cell[u] = 0, act[u] = false;
+        int r_after = 255;
         if (p < n) {
-            x[u] = pos[3 * p], y[u] = pos[3 * p + 1], z[u] = pos[3 * p + 2];
-            slot[u] = sr_hash_slot(H, sr_cell(pos, p, inv, ext, nt));
+            double x, y, z;
+            if (BEGIN) r_after = cg_substep_begin_particle(B, p, x, y, z);
+            else x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+            cell[u] = sr_cell_of(x, y, z, inv, ext, nt);
+            slot[u] = sr_hash_slot(H, cell[u]);
             if constexpr (ACT) act[u] = A.rung[p] >= A.lowest;
-            // the particle's rank among the workgroup's (active | other) particles of its cell
             bool taken = false;
             if constexpr (ACT)
                 if (act[u]) rank[u] = atomicAdd(&H.act[slot[u]], 1u), taken = true;
             if (!taken) rank[u] = atomicAdd(&H.cnt[slot[u]], 1u);
         }
+        if (BEGIN && B.partial) cg_count_rungs(r_after, B.N_rungs, s_cnt);
     }
     __syncthreads();
-    // a slot's first row in the list: the cell's offset + what earlier workgroups reserved
+    if (BEGIN && B.partial && threadIdx.x < (unsigned)B.N_rungs)
+        B.partial[(i64)B.N_rungs * blockIdx.x + threadIdx.x] = s_cnt[threadIdx.x];
     for (int i = threadIdx.x; i < kSrHashSlots; i += 256) {
         const unsigned key = H.key[i];
-        if constexpr (ACT) {
-            if (H.act[i]) H.act[i] = offset[key] + atomicAdd(&cursor[key], H.act[i]);
-            if (H.cnt[i]) H.cnt[i] = offset[key] + nact[key] + atomicAdd(&cursor_i[key], H.cnt[i]);
-        } else {
-            if (H.cnt[i]) H.cnt[i] = offset[key] + atomicAdd(&cursor[key], H.cnt[i]);
-        }
+        if (H.cnt[i]) H.cnt[i] = atomicAdd(&count[key], H.cnt[i]);
+        if constexpr (ACT)
+            if (H.act[i]) H.act[i] = atomicAdd(&nact[key], H.act[i]);
     }
     __syncthreads();
 #pragma unroll
@@ -233,15 +217,38 @@ __global__ __launch_bounds__(256) void k_sr_cell_scatter(const double *__restric
             unsigned first = H.cnt[slot[u]];
             if constexpr (ACT)
                 if (act[u]) first = H.act[slot[u]];
-            const i64 q = (i64)first + rank[u];
-            order[q] = (unsigned)p;
-            pos_sorted[3 * q] = x[u];
-            pos_sorted[3 * q + 1] = y[u];
-            pos_sorted[3 * q + 2] = z[u];
-            if constexpr (ACT)
-                if (rj_sorted) rj_sorted[q] = A.rung_jumped[p];
+            cellrel[p] = make_uint2(cell[u], (first + rank[u]) | (act[u] ? 0x80000000u : 0u));
         }
     }
+}
+// (ACT) the cells' populations for the scan: the inactive + the active
+__global__ __launch_bounds__(256) void k_sr_cell_total(unsigned *__restrict__ count,
+                                                       const unsigned *__restrict__ nact,
+                                                       unsigned ncells) {
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ncells) count[c] += nact[c];
+}
+// Pass 2, placing: row = the cell's offset + the particle's place inside the cell (ACT: the active
+// ones first, then the others)
+template <bool ACT>
+__global__ __launch_bounds__(256) void k_sr_cell_place(const double *__restrict__ pos, i64 n,
+                                                       const unsigned *__restrict__ offset,
+                                                       const uint2 *__restrict__ cellrel,
+                                                       unsigned *__restrict__ order,
+                                                       double *__restrict__ pos_sorted,
+                                                       SrActive A, const unsigned *__restrict__ nact,
+                                                       signed char *__restrict__ rj_sorted) {
+    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint2 cr = cellrel[p];
+    i64 q = (i64)offset[cr.x] + (cr.y & 0x7fffffffu);
+    if (ACT && !(cr.y >> 31)) q += nact[cr.x];
+    order[q] = (unsigned)p;
+    pos_sorted[3 * q] = pos[3 * p];
+    pos_sorted[3 * q + 1] = pos[3 * p + 1];
+    pos_sorted[3 * q + 2] = pos[3 * p + 2];
+    if constexpr (ACT)
+        if (rj_sorted) rj_sorted[q] = A.rung_jumped[p];
 }
 
 int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
@@ -252,7 +259,10 @@ int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
     double inv = (1 / tile_extent) * (1 - 2 * eps);
     i64 ncells = 8 * nt * nt * nt;
     const bool act = nact != nullptr;
-    const size_t words = (size_t)(ncells + 1) * (act ? 3 : 2);
+    // the sub-step's first pass, if the time loop left it to this list (same particles)
+    const bool begin = c->sub_pending && c->sub_begin->pos == pos && c->sub_begin->n == n && n > 0;
+    if (!begin && cgk_substep_flush(c)) return 1;
+    const size_t words = (size_t)(ncells + 4) + 2 * (size_t)(n + 1);  // counts | (cell, place)
     if (4 * words > c->sr_tmp_bytes) {
         CG_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(c->sr_tmp);
@@ -261,17 +271,33 @@ int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
         CG_HIP(hipMalloc(&c->sr_tmp, 4 * words));
         c->sr_tmp_bytes = 4 * words;
     }
-    unsigned *count = (unsigned *)c->sr_tmp, *cursor = count + (ncells + 1),
-             *cursor_i = cursor + (ncells + 1);
-    CG_HIP(hipMemsetAsync(c->sr_tmp, 0, 4 * words, c->stream));
+    unsigned *count = (unsigned *)c->sr_tmp;
+    uint2 *cellrel = (uint2 *)(count + ((ncells + 2) & ~(i64)1));
+    CG_HIP(hipMemsetAsync(count, 0, 4 * (size_t)(ncells + 1), c->stream));
     if (act) CG_HIP(hipMemsetAsync(nact, 0, 4 * (size_t)ncells, c->stream));
     const SrActive A{rung, rung_jumped, lowest_active};
     i64 blocks = (n + 256 * kSrPerThread - 1) / (256 * kSrPerThread);
     if (n > 0) {
-        hipLaunchKernelGGL(act ? k_sr_cell_histogram<true> : k_sr_cell_histogram<false>,
-                           dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n, inv,
-                           tile_extent, (unsigned)nt, count, A, nact);
+        auto kern = act ? (begin ? k_sr_cell_count<true, true> : k_sr_cell_count<true, false>)
+                        : (begin ? k_sr_cell_count<false, true> : k_sr_cell_count<false, false>);
+        c->sub_pending = false;
+        i64 nwg = 0;
+        c->sub_begin->partial = nullptr;
+        if (begin && c->sub_counts) {
+            if (cgk_substep_partial(c, n, 256 * kSrPerThread, c->sub_begin->N_rungs, &nwg)) return 1;
+            c->sub_begin->partial = c->sub_partial;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n, inv,
+                           tile_extent, (unsigned)nt, count, A, nact, cellrel, *c->sub_begin);
         CG_LAUNCH_CHECK();
+        if (begin && c->sub_counts &&
+            cgk_substep_populations(c, nwg, c->sub_begin->N_rungs, c->sub_counts))
+            return 1;
+        if (act) {
+            hipLaunchKernelGGL(k_sr_cell_total, dim3((unsigned)((ncells + 255) / 256)), dim3(256),
+                               0, c->stream, count, nact, (unsigned)ncells);
+            CG_LAUNCH_CHECK();
+        }
     }
     size_t need = 0;
     CG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, count, offset, (int)(ncells + 1),
@@ -286,10 +312,9 @@ int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
     CG_HIP(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp, need, count, offset, (int)(ncells + 1),
                                             c->stream));
     if (n > 0) {
-        hipLaunchKernelGGL(act ? k_sr_cell_scatter<true> : k_sr_cell_scatter<false>,
-                           dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n, inv,
-                           tile_extent, (unsigned)nt, offset, cursor, order, pos_sorted, A, nact,
-                           cursor_i, rj_sorted);
+        hipLaunchKernelGGL(act ? k_sr_cell_place<true> : k_sr_cell_place<false>,
+                           dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, pos, n,
+                           offset, cellrel, order, pos_sorted, A, nact, rj_sorted);
         CG_LAUNCH_CHECK();
     }
     // what the dense tiles' sweep wants to know about this list, while it is being made

@@ -88,7 +88,8 @@ SYMBOLS = {
     'cg_shortrange_sweep_cells_rungs': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64,
                                                _dbl, _dbl, _vp, _vp, _vp, _int]),
     'cg_substep_begin': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _dbl, _int, _int, _vp, _dbl,
-                                _dbl, _int, _vp]),
+                                _dbl, _int, _vp, _vp, _int]),
+    'cg_substep_flush': (_int, [_vp]),
     'cg_substep_end': (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _int, _vp]),
     'cg_shortrange_cells_rungs': (_int, [_vp, _vp, _i64, _i64, _dbl, _vp, _vp, _int, _vp, _vp, _vp,
                                          _vp, _vp]),

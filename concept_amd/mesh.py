@@ -805,9 +805,13 @@ class PotentialMesh:
         return bool(flag.item())
 
     def substep_begin(self, pos, mom, dmom, rung, rung_jumped, dt_over_mass, flag, lowest_active_rung,
-                      integrals_1, rf_up, rf_down, N_rungs, any_out):
+                      integrals_1, rf_up, rf_down, N_rungs, any_out, counts_after=None,
+                      defer=False):
         """cg_substep_begin: drift (dt_over_mass not None), then flag_rung_jumps + nullify_Δ
-        (flag) in one pass; integrals_1 a host array, any_out an int32 CUDA tensor read later."""
+        (flag) in one pass; integrals_1 a host array, any_out an int32 CUDA tensor read later.
+        counts_after (int64 CUDA tensor [N_rungs]): the rung populations after the sub-step's
+        jumps.  defer: the pass is left to the next shortrange_cells() on these positions (or
+        to substep_flush(), or to any other call that touches particles)."""
         n = self._check_particles(pos)
         self._check_rungs(n, rung, rung_jumped)
         tab = (ctypes.c_double*(3*N_rungs - 1))(*[float(v) for v in integrals_1]) if flag else None
@@ -815,7 +819,11 @@ class PotentialMesh:
             self._ctx, _ptr(pos), _ptr(mom), _ptr(dmom) if dmom is not None else None, _ptr(rung),
             _ptr(rung_jumped), n, int(dt_over_mass is not None), float(dt_over_mass or 0.0),
             int(bool(flag)), int(lowest_active_rung), tab, float(rf_up), float(rf_down),
-            int(N_rungs), _ptr(any_out)))
+            int(N_rungs), _ptr(any_out),
+            _ptr(counts_after) if counts_after is not None else None, int(bool(defer))))
+
+    def substep_flush(self):
+        check(_L.cg_substep_flush(self._ctx))
 
     def substep_end(self, mom, dmom, rung, rung_jumped, apply, lowest_active_rung,
                     conversion_factors, N_rungs, counts):
@@ -829,7 +837,7 @@ class PotentialMesh:
         check(_L.cg_substep_end(
             self._ctx, _ptr(mom), _ptr(dmom) if dmom is not None else None, _ptr(rung),
             _ptr(rung_jumped), n, int(bool(apply)), int(lowest_active_rung), tab, int(N_rungs),
-            _ptr(counts)))
+            _ptr(counts) if counts is not None else None))
 
     def apply_rung_jumps(self, rung, rung_jumped, N_rungs):
         n = rung.numel()

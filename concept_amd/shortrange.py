@@ -112,7 +112,9 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
     for c in involved:
         if c.representation != 'particles':
             raise ConceptGPUError(f'{c.name}: only particle components have short-range forces')
-        if c.Δmom is None:
+        # (asked of the store, not through the attribute: reading c.Δmom would run a sub-step
+        # pass the time loop has left to this call's cell list)
+        if 'Δmom' not in c._store.cols:
             c.Δmom = torch.zeros_like(c.mom)
     # On several domains every supplier component is extended by the neighbour ranks'
     # particles within the force range of this rank's slab (sendrecv_component,
@@ -135,13 +137,17 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
         if id(c) not in cells:
             # a sub-step (lowest active rung > 0): the particles on active rungs first in every
             # cell, so that the sweep takes its receivers without looking at the rungs again
+            # (the sub-step's first pass over the particles, if the time loop left it to this
+            # list: run by the list's counting pass on the particles it bins)
+            taken = c.take_begin(mesh)
             rungs = ((c.rung_indices, c.rung_indices_jumped, c.lowest_active_rung)
                      if c.use_rungs and c in receivers else None)
             cells[id(c)] = build(c.pos, nt, tile_extent, rungs)
+            if taken:
+                c.begin_queued()
             supp_cells.setdefault(id(c), cells[id(c)])
         return cells[id(c)]
     for c in involved:
-        supp_pos[id(c)] = c.pos
         # every involved component can act as supplier: s of sweep(r, s), and r of the
         # reciprocal sweep(s, r) when s is also a receiver
         if multi:
@@ -163,8 +169,14 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
             return None
         key_ = (id(rec), rec.lowest_active_rung)
         if key_ not in sparse_rows:
-            sparse_rows[key_] = torch.nonzero(
-                rec.rung_indices >= rec.lowest_active_rung).flatten()
+            # (the populations say how many there are: the rows are found without the host
+            # waiting for their number — torch.nonzero() would drain the stream, the sweep of
+            # the sub-step before included, once per such sub-step)
+            mask = rec.rung_indices >= rec.lowest_active_rung
+            if hasattr(torch, 'nonzero_static'):
+                sparse_rows[key_] = torch.nonzero_static(mask, size=n_active).flatten()
+            else:
+                sparse_rows[key_] = torch.nonzero(mask).flatten()
         rows_ = sparse_rows[key_]
         # (the populations are bookkeeping of the time loop: should they lag behind the rung
         # array, the cells sweep takes over)
@@ -197,14 +209,17 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
                         global sparse_sweeps
                         sparse_sweeps += 1
                         if rows.numel():
-                            mesh.shortrange_sparse(rec.pos, rows, rec.Δmom, supp_pos[id(sup)],
+                            rec.flush_begin()
+                            sup.flush_begin()
+                            mesh.shortrange_sparse(rec.pos, rows, rec.Δmom,
+                                                   supp_pos[id(sup)] if multi else sup.pos,
                                                    table, scaling, r2_max, 0.0,
                                                    (factors, rec.rung_indices_jumped))
                         return
                     get_cells(sup)
+                    rc = get_cells(rec)
                     rungs = (factors, rec.rung_indices, rec.rung_indices_jumped,
                              rec.lowest_active_rung)
-                    rc = get_cells(rec)
                     # few receivers on active rungs (one domain: rungs_N counts them): the
                     # sweep by active cell
                     n_active = None

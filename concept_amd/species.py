@@ -27,12 +27,19 @@ from .mesh import get_mesh
 PotentialGridsizes = collections.namedtuple('PotentialGridsizes', ('upstream', 'downstream'))
 
 
+_BEGIN_WRITES = ('pos', 'Δmom', 'rung_indices_jumped')
+
+
 def _store_column(name):
     """Component attribute backed by a column of its ParticleStore: the live rows"""
     def get(self):
         st = self.__dict__.get('_store')
         if st is None or name not in st.cols:
             return None
+        # (a sub-step pass left to the next cell list, substep_begin(defer=True), runs before
+        # anybody else looks at the rows it changes)
+        if self.__dict__.get('_begin_args') is not None and name in _BEGIN_WRITES:
+            self.flush_begin()
         return st.cols[name][:st.n]
 
     def set_(self, value):
@@ -77,6 +84,8 @@ class Component:
         self.rank = self.comm.rank if self.comm is not None else 0
         self._store = None
         self._sub_dev = None   # (substep_begin/_end: device words read back by substep_finish)
+        self._begin_args = None   # (a substep_begin() left to the next short-range cell list)
+        self._sub_counted = False
         self.tile_mesh = None
         self.tiles_exact = False
         self.use_ids = False  # identifiers are the running row numbers until some are populated
@@ -523,11 +532,13 @@ class Component:
 
     # -- a sub-step of driftkick_short in two passes (one domain) -------------------------
     def substep_begin(self, ᔑdt_drift, flag, Δt=None, Δt_jump_fac=None, fac_softening=None,
-                      ᔑdt_rungs=None, a=1.0):
+                      ᔑdt_rungs=None, a=1.0, defer=False):
         """drift(ᔑdt_drift) (unless None), then — `flag` — flag_rung_jumps() and
         nullify_Δ('mom') as one pass over the particles (cg_substep_begin); what
         flag_rung_jumps() returns is read by substep_finish().  For components with rungs in
-        use (the time loop takes the separate calls otherwise)."""
+        use (the time loop takes the separate calls otherwise).  defer: the pass is left to the
+        short-range cell list built next from these positions, which runs it on every particle
+        as it bins it."""
         if not self.use_rungs:
             raise ConceptGPUError(f'{self.name}: substep_begin() is for components with rungs')
         mesh = self._mesh()
@@ -554,14 +565,45 @@ class Component:
         self._sub_flag_pending = flag
         if dtm is None and not flag:
             return
-        mesh.substep_begin(self.pos, self.mom, self.Δmom, self.rung_indices,
-                           self.rung_indices_jumped, dtm, flag, self.lowest_active_rung, args[0],
-                           args[1], args[2], self.N_rungs, self._sub_dev[1])
+        self._begin_args = (dtm, flag, self.lowest_active_rung, args[0], args[1], args[2])
+        if not defer:
+            self.flush_begin()
+
+    def take_begin(self, mesh):
+        """hand a deferred substep_begin() to `mesh`, whose next shortrange_cells() on this
+        component's positions runs it with its counting pass; True if there was one (the caller
+        then reports the list queued: begin_queued())"""
+        if self._begin_args is None:
+            return False
+        self.flush_begin(mesh, defer=True)
+        return True
+
+    def flush_begin(self, mesh=None, defer=False):
+        """run a deferred substep_begin() now"""
+        args, self._begin_args = self._begin_args, None
+        if args is None:
+            return
+        dtm, flag, lowest, integrals_1, rf_up, rf_down = args
+        (mesh or self._mesh()).substep_begin(
+            self.pos, self.mom, self.Δmom, self.rung_indices, self.rung_indices_jumped, dtm, flag,
+            lowest, integrals_1, rf_up, rf_down, self.N_rungs, self._sub_dev[1],
+            self._sub_dev[0] if flag else None, defer)
+        if not defer:
+            self.begin_queued()
+
+    def begin_queued(self):
+        """the pass is on the stream: its populations and its flag follow it to the host"""
+        if self._sub_flag_pending:
+            self._sub_host[0].copy_(self._sub_dev[0], non_blocking=True)
+            self._sub_host[1].copy_(self._sub_dev[1], non_blocking=True)
+            self._sub_event.record()
+            self._sub_counted = True
 
     def substep_end(self, apply, ᔑdt_rungs, a=1.0):
-        """apply_Δmom() + convert_Δmom_to_acc() (`apply`: the component received a kick),
-        apply_rung_jumps() and set_rungs_N() as one pass (cg_substep_end); the populations
-        arrive with substep_finish()."""
+        """apply_Δmom() + convert_Δmom_to_acc() (`apply`: the component received a kick) and
+        apply_rung_jumps() as one pass (cg_substep_end).  The populations the jumps leave were
+        counted by the sub-step's first pass: substep_finish() has them."""
+        self.flush_begin()
         if apply:
             self._store.touch_mom()
         conv = None
@@ -569,22 +611,22 @@ class Component:
             w_eff = self.w_eff(a=a)
             conv = a**(3*w_eff)/(self.mass*(commons.machine_ϵ + np.asarray(ᔑdt_rungs['a**2'])))
         self._mesh().substep_end(self.mom, self.Δmom, self.rung_indices, self.rung_indices_jumped,
-                                 apply, self.lowest_active_rung, conv, self.N_rungs,
-                                 self._sub_dev[0])
-        self._sub_host[0].copy_(self._sub_dev[0], non_blocking=True)
-        self._sub_host[1].copy_(self._sub_dev[1], non_blocking=True)
-        self._sub_event.record()
+                                 apply, self.lowest_active_rung, conv, self.N_rungs, None)
 
     def substep_finish(self):
-        """wait for the sub-step's passes; the rung populations (set_rungs_N) are set, and
-        whether any particle was flagged to jump is returned"""
+        """wait for the sub-step's FIRST pass (the sweep may still be running): the rung
+        populations as the sub-step leaves them (set_rungs_N after apply_rung_jumps) are set,
+        and whether any particle was flagged to jump is returned"""
+        if not self._sub_counted:
+            return False
+        self._sub_counted = False
         self._sub_event.synchronize()
         counts = self._sub_host[0].tolist()
         self.rungs_N = counts[:self.N_rungs]
         populated = [r for r, c in enumerate(self.rungs_N) if c > 0]
         self.lowest_populated_rung = populated[0] if populated else self.N_rungs - 1
         self.highest_populated_rung = populated[-1] if populated else 0
-        return bool(self._sub_flag_pending and int(self._sub_host[1][0]))
+        return bool(int(self._sub_host[1][0]))
 
     def set_rungs_N(self):
         """species.py:2560-2587 (set_rungs_N + set_lowest_highest_populated_rung): the

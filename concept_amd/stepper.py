@@ -199,6 +199,97 @@ def static_integrals(components):
     return integrals
 
 
+class _LazyIntegrals(dict):
+    """{integrand: integral over (t_start, t_end)} whose values are worked out when they are
+    asked for: a sub-step of the rung loop reads four of the run's eleven integrands ('1',
+    'a**2', 'a**(-2)' and the pair integrand of its components), and there are three such
+    dictionaries per populated rung and sub-step (get_time_step_integrals, main.py:998-1073,
+    evaluates them all: the values are the same, the unread ones are not missed)."""
+
+    def __init__(self, one, keys, t_start, t_end):
+        super().__init__()
+        self.one, self.all_keys, self.t = one, keys, (t_start, t_end)
+
+    def __missing__(self, key):
+        if key not in self.all_keys:
+            raise KeyError(key)
+        value = self[key] = self.one(key, *self.t)
+        return value
+
+    def __contains__(self, key):
+        return key in self.all_keys
+
+    def __iter__(self):
+        return iter(self.all_keys)
+
+    def __len__(self):
+        return len(self.all_keys)
+
+    def keys(self):
+        return list(self.all_keys)
+
+    def items(self):
+        return [(k, self[k]) for k in self.all_keys]
+
+    def values(self):
+        return [self[k] for k in self.all_keys]
+
+    def get(self, key, default=None):
+        return self[key] if key in self.all_keys else default
+
+
+class _RungIntegrals(dict):
+    """ᔑdt_rungs: {integrand: array of 3 N_rungs - 1 integrals}.  Entries set from lazy step
+    integrals are filled in when the integrand's array is read."""
+
+    def __init__(self, size):
+        super().__init__()
+        self.size, self.pending = size, {}
+
+    def set(self, source, index):
+        """arr[index] = source[integrand] for every integrand of `source` (a number: for every
+        integrand known so far)"""
+        if isinstance(source, _LazyIntegrals):
+            for key in source.all_keys:
+                self.pending.setdefault(key, {})[index] = source
+        elif isinstance(source, dict):
+            for key, value in source.items():
+                self.pending.setdefault(key, {})[index] = value
+        else:
+            for key in set(self.pending) | set(dict.keys(self)):
+                self.pending.setdefault(key, {})[index] = source
+
+    def __missing__(self, key):
+        if key not in self.pending:
+            raise KeyError(key)
+        arr = self[key] = np.zeros(self.size)
+        return arr
+
+    def __getitem__(self, key):
+        arr = dict.__getitem__(self, key) if dict.__contains__(self, key) else self.__missing__(key)
+        todo = self.pending.get(key)
+        if todo:
+            for index, source in todo.items():
+                arr[index] = source[key] if isinstance(source, dict) else source
+            todo.clear()
+        return arr
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self.pending
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return list(set(dict.keys(self)) | set(self.pending))
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+
 class _CachedIntegrals:
     """get_time_step_integrals() behind a small cache: the rung loop asks for a sub-step's
     integrals while the GPU is still busy with the sub-step before it (prefetch), and again
@@ -210,7 +301,7 @@ class _CachedIntegrals:
 
     def __call__(self, t_start, t_end):
         out = self.cache.get((t_start, t_end))
-        return dict(out) if out is not None else self.func(t_start, t_end)
+        return out if out is not None else self.func(t_start, t_end)
 
     def prefetch(self, t_start, t_end):
         key = (t_start, t_end)
@@ -239,15 +330,11 @@ class RungStepper:
         self.fac_softening = 0.025 if fac_softening is None else fac_softening
         self.Δt_jump_fac = Δt_jump_fac
         self.Δt_reltol = Δt_reltol
-        self.ᔑdt_rungs = {}
+        self.ᔑdt_rungs = _RungIntegrals(3*self.N_rungs - 1)
 
     # -- helpers --------------------------------------------------------------
     def _store(self, ᔑdt_rung, index):
-        for integrand, integral in ᔑdt_rung.items():
-            arr = self.ᔑdt_rungs.get(integrand)
-            if arr is None:
-                arr = self.ᔑdt_rungs[integrand] = np.zeros(3*self.N_rungs - 1)
-            arr[index] = integral
+        self.ᔑdt_rungs.set(ᔑdt_rung, index)
 
     def _clip(self, t, Δt, sync_time):
         return sync_time if t + self.Δt_reltol*Δt + 2*commons.machine_ϵ > sync_time else t
@@ -374,8 +461,10 @@ class RungStepper:
             kick = sum(integrals_1[lowest_active_rung:highest_populated_rung + 1]) != 0
             if fused:
                 for c in comps:
+                    # (a kick follows: the pass is left to the cell list of the component's
+                    # short-range sweep, which bins the particles it has just drifted)
                     c.substep_begin(ᔑdt_drift, kick, Δt, self.Δt_jump_fac, self.fac_softening,
-                                    self.ᔑdt_rungs)
+                                    self.ᔑdt_rungs, defer=kick)
                 if not kick:
                     continue
                 receivers_all = self._gravity_short()
@@ -431,8 +520,7 @@ class RungStepper:
             for index, ts, te in self._rung_integral_times(driftkick_index, rung_index, Δt,
                                                            sync_time):
                 if te is None:
-                    for arr in self.ᔑdt_rungs.values():
-                        arr[index] = -1
+                    self.ᔑdt_rungs.set(-1, index)
                 else:
                     self._store(self.integrals(ts, te), index)
 
@@ -607,7 +695,15 @@ class Timeloop(RungStepper):
     t = property(lambda self: self.cosmo.t, lambda self, v: setattr(self.cosmo, 't', float(v)))
 
     def _integrals(self, t_start, t_end):
-        return self.cosmo.get_time_step_integrals(t_start, t_end, self.components, self.keys)
+        """get_time_step_integrals(t_start, t_end) (main.py:998-1073), every integrand worked
+        out when it is read (the values are those of
+        cosmo.get_time_step_integrals(t_start, t_end, components, keys))"""
+        if self.keys is None:
+            return self.cosmo.get_time_step_integrals(t_start, t_end, self.components, self.keys)
+        return _LazyIntegrals(self._one_integral, self.keys, t_start, t_end)
+
+    def _one_integral(self, key, t_start, t_end):
+        return self.cosmo.get_time_step_integrals(t_start, t_end, self.components, (key,))[key]
 
     # -- the streaming form of the loop ----------------------------------------------------
     def _stream_begin(self):

@@ -463,12 +463,22 @@ int cg_rung_populations(cg_ctx *ctx, const int8_t *rung, int64_t n, int N_rungs,
  * (species.py:2311-2315) are HOST arrays of 3*N_rungs-1 doubles — they travel as kernel
  * arguments, nothing is uploaded and nothing waited for; *any_out (DEV int32) as in
  * cg_flag_rung_jumps.  convert_Δmom_to_acc indexes the factors by the jumped rung index, which
- * IS the rung index of a particle that is not flagged. */
+ * IS the rung index of a particle that is not flagged.
+ * counts_after (with do_flag): the rung populations as they will be AFTER this sub-step's jumps —
+ * a flagged particle counted on the rung it jumps to, which is all apply_rung_jumps does at the
+ * sub-step's end: the time loop learns them while the sub-step's sweep is still running and
+ * queues the next sub-step behind it (cg_substep_end's counts may then be null). */
 int cg_substep_begin(cg_ctx *ctx, double *pos /*DEV 3n*/, const double *mom /*DEV 3n*/,
                      double *dmom /*DEV 3n*/, const int8_t *rung, int8_t *rung_jumped, int64_t n,
                      int do_drift, double dt_over_mass, int do_flag, int lowest_active_rung,
                      const double *integrals_1 /*HOST*/, double rung_factor_up,
-                     double rung_factor_down, int N_rungs, int32_t *any_out /*DEV*/);
+                     double rung_factor_down, int N_rungs, int32_t *any_out /*DEV*/,
+                     int64_t *counts_after /*DEV N_rungs, or null*/, int defer);
+/* defer = 1: cg_substep_begin launches nothing; the cell list the sub-step's sweep asks for next
+ * (cg_shortrange_cells[_rungs] on the same pos, n) runs the pass on every particle as it bins it
+ * — the drifted positions are not read a second time.  Any other entry that touches particles
+ * runs a pass still pending first, as does cg_substep_flush. */
+int cg_substep_flush(cg_ctx *ctx);
 int cg_substep_end(cg_ctx *ctx, double *mom, double *dmom, int8_t *rung, int8_t *rung_jumped,
                    int64_t n, int do_apply, int lowest_active_rung,
                    const double *conversion_factors /*HOST*/, int N_rungs,

@@ -36,8 +36,9 @@ def test_substep_passes_equal_the_separate_calls(n, lowest):
     # the pass
     p1, m1, d1, r1, j1 = pos.clone(), mom.clone(), acc.clone(), rung.clone(), rung.clone()
     any_out = torch.zeros(1, dtype=torch.int32, device='cuda')
+    after = torch.full((N_rungs,), -1, dtype=torch.int64, device='cuda')
     mesh.substep_begin(p1, m1, d1, r1, j1, dtm, True, lowest, integrals, rf_up, rf_down, N_rungs,
-                       any_out)
+                       any_out, after)
     assert torch.equal(p0, p1) and torch.equal(d0, d1) and torch.equal(j0, j1)
     assert bool(any_out.item()) == flagged0
     assert n < 1000 or (flagged0 and bool((j1 >= N_rungs).any()) and bool((j1 >= 2*N_rungs).any()))
@@ -63,10 +64,83 @@ def test_substep_passes_equal_the_separate_calls(n, lowest):
     assert torch.equal(m0, m1) and torch.equal(d0, d1)
     assert torch.equal(r0, r1) and torch.equal(j0, j1) and torch.equal(r1, j1)
     assert torch.equal(counts0, counts1) and int(counts1.sum()) == n
+    # ... which the first pass had counted before the jumps were applied
+    assert torch.equal(after, counts0)
+    mesh.substep_end(m1.clone(), d1.clone(), r1.clone(), j1.clone(), True, lowest, conv, N_rungs,
+                     None)
     # a component that received nothing: the jumps and the populations only
     r4, j4 = rung.clone(), j3.clone()
     m4, d4 = mom.clone(), acc.clone()
     mesh.substep_end(m4, d4, r4, j4, False, lowest, None, N_rungs, counts1)
     assert torch.equal(m4, mom) and torch.equal(d4, acc) and torch.equal(r4, r1)
     assert torch.equal(counts0, counts1)
+    mesh.close()
+
+
+@pytest.mark.parametrize('lowest', [0, 3])
+def test_deferred_pass_runs_with_the_cell_list(lowest):
+    """substep_begin(defer=True): nothing happens until the next shortrange_cells() on the same
+    positions, whose counting pass drifts, flags and nullifies every particle as it bins it — the
+    arrays and the list equal those of the pass followed by the list; a pass still pending is
+    run by any other call that touches particles."""
+    import torch
+    from concept_amd import commons
+    from concept_amd.mesh import PotentialMesh
+    N, L, N_rungs, n = 64, 64.0, 8, 50021
+    mesh = PotentialMesh(N, L)
+    g = torch.Generator(device='cuda').manual_seed(77 + lowest)
+    pos = torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=g)*L*(1 - 1e-13)
+    mom = torch.randn((n, 3), dtype=torch.float64, device='cuda', generator=g)
+    acc = torch.randn((n, 3), dtype=torch.float64, device='cuda', generator=g) \
+        * torch.exp(4*torch.randn((n, 1), dtype=torch.float64, device='cuda', generator=g))
+    rung = torch.randint(0, 6, (n,), device='cuda', generator=g).to(torch.int8)
+    integrals = np.random.default_rng(3).uniform(0.1, 1.0, 3*N_rungs - 1)
+    rf_up, rf_down, dtm = 1.3, 2.1, 0.41
+    nt = int(L/(4.5*1.25*L/N)*(1 + commons.machine_ϵ))
+    any0 = torch.zeros(1, dtype=torch.int32, device='cuda')
+    any1 = torch.zeros(1, dtype=torch.int32, device='cuda')
+    p0, d0, j0 = pos.clone(), acc.clone(), rung.clone()
+    mesh.substep_begin(p0, mom, d0, rung, j0, dtm, True, lowest, integrals, rf_up, rf_down,
+                       N_rungs, any0)
+    list0 = mesh.shortrange_cells(p0, nt, L/nt, (rung, j0, lowest))
+    p1, d1, j1 = pos.clone(), acc.clone(), rung.clone()
+    after0 = torch.zeros(N_rungs, dtype=torch.int64, device='cuda')
+    after1 = torch.zeros(N_rungs, dtype=torch.int64, device='cuda')
+    mesh.substep_begin(pos.clone(), mom, acc.clone(), rung, rung.clone(), dtm, True, lowest,
+                       integrals, rf_up, rf_down, N_rungs, any0, after0)
+    mesh.substep_begin(p1, mom, d1, rung, j1, dtm, True, lowest, integrals, rf_up, rf_down,
+                       N_rungs, any1, after1, defer=True)
+    torch.cuda.synchronize()
+    assert torch.equal(p1, pos) and torch.equal(d1, acc)      # nothing yet
+    list1 = mesh.shortrange_cells(p1, nt, L/nt, (rung, j1, lowest))
+    assert torch.equal(p1, p0) and torch.equal(d1, d0) and torch.equal(j1, j0)
+    assert torch.equal(after0, after1) and int(after1.sum()) == n
+    rr, jj = rung.clone(), j1.clone()
+    mesh.apply_rung_jumps(rr, jj, N_rungs)
+    assert torch.equal(after1, mesh.rung_populations(rr, N_rungs))
+    assert int(any0.item()) == int(any1.item()) == 1
+    assert torch.equal(list0[1], list1[1])                     # the cells' offsets
+    if lowest:
+        assert torch.equal(list0[3], list1[3])                 # active rows per cell
+    # the same members in every cell (the order inside a cell is the atomics')
+    cell = torch.repeat_interleave(torch.arange(8*nt**3, device='cuda'),
+                                   (list0[1][1:] - list0[1][:-1]).long())
+    for lst in (list0, list1):
+        assert torch.equal(lst[2][:n], p0[lst[0][:n].long()])
+    key0 = torch.sort(cell*n + list0[0][:n].long()).values
+    key1 = torch.sort(cell*n + list1[0][:n].long()).values
+    assert torch.equal(key0, key1)
+    # a pending pass and another list (other positions): the pass runs by itself first
+    p2, d2, j2 = pos.clone(), acc.clone(), rung.clone()
+    mesh.substep_begin(p2, mom, d2, rung, j2, dtm, True, lowest, integrals, rf_up, rf_down,
+                       N_rungs, any1, after1, defer=True)
+    other = mesh.shortrange_cells(pos, nt, L/nt)
+    assert torch.equal(p2, p0) and torch.equal(d2, d0) and torch.equal(j2, j0)
+    assert torch.equal(other[2][:n], pos[other[0][:n].long()])
+    # ... or by a flush
+    p3, d3, j3 = pos.clone(), acc.clone(), rung.clone()
+    mesh.substep_begin(p3, mom, d3, rung, j3, dtm, True, lowest, integrals, rf_up, rf_down,
+                       N_rungs, any1, None, defer=True)
+    mesh.substep_flush()
+    assert torch.equal(p3, p0) and torch.equal(d3, d0) and torch.equal(j3, j0)
     mesh.close()

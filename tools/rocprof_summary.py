@@ -39,6 +39,25 @@ def main(path, out=None):
         lines.append('# %s: kernels running %.1f ms of the %.1f ms between the first kernel\'s start '
                      'and the last one\'s end (%.0f %%); summed kernel durations %.1f ms' % (
                          os.path.basename(db), busy/1e6, span/1e6, 100.0*busy/span, tot))
+    if os.environ.get('ROCPROF_GAPS'):
+        # where the GPU waits: idle time between consecutive kernels, by (kernel before, after)
+        import collections
+        for db in dbs:
+            iv = sqlite3.connect(db).execute(
+                'select start, end, name from kernels order by start').fetchall()
+            gaps = collections.defaultdict(lambda: [0, 0.0])
+            cur_e, cur_n = iv[0][1], iv[0][2]
+            for a, b, nm in iv[1:]:
+                if a > cur_e:
+                    if a - cur_e < 50e6:   # (not the pauses between the run's phases)
+                        g = gaps[(cur_n[:48], nm[:48])]
+                        g[0] += 1
+                        g[1] += (a - cur_e)/1e6
+                if b > cur_e:
+                    cur_e, cur_n = b, nm
+            lines.append('# idle between kernels (count, total ms): before -> after')
+            for (k0, k1), (cnt, ms) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:16]:
+                lines.append('#   %5d %9.2f  %s -> %s' % (cnt, ms, k0, k1))
     text = '\n'.join(lines)
     print(text)
     if out:
