@@ -255,7 +255,27 @@ def cpu_baseline_child(workload):
               'sample': f'128^3 particles / 256^3 mesh (BASELINE configs[0]), {steps_one} PM '
                         f'steps, oracle C port built {flags} + numpy pocketfft, '
                         f'{dt_one:.1f} s wall'}
-    extras = {'thread_trials_s_per_step_256c_512': {str(k): round(v, 3) for k, v in trial.items()},
+    # what this host's memory gives those thread counts: STREAM triad (a = b + s c, 3 x 2^27
+    # doubles touched first by the threads that sweep them, best of 3) — the ceiling beside
+    # which the port's phases and its scaling with threads are to be read
+    omp.orc_stream_triad.restype = ctypes.c_double
+    omp.orc_stream_triad.argtypes = [_dp, _dp, _dp, ctypes.c_int64, ctypes.c_int]
+    triad = {}
+    nt_ = 1 << 27
+    for threads in sorted({min(avail, t) for t in (1, 32, 128, avail)} - {0}):
+        omp.orc_threads(threads)
+        arrs = [np.empty(nt_, dtype=np.float64) for _ in range(3)]
+        dt_ = omp.orc_stream_triad(*(a_.ctypes.data_as(_dp) for a_ in arrs), nt_, 3)
+        triad[str(threads)] = round(24*nt_/dt_/1e9, 1)
+        del arrs
+    extras = {'host_stream_triad_GBps_by_threads': triad,
+              'thread_scaling_note': (
+                  'the fastest trial is the one reported; where more threads are slower the port '
+                  'is held by the host\'s memory system, not by its loops: compare the phases\' '
+                  'GB/s (SURVEY.md §8(d) bytes) with the triad figures — a thread count beyond '
+                  'the one that saturates the triad adds contention (scattered 8-byte updates of '
+                  'the deposit and gather across NUMA domains), no bandwidth'),
+              'thread_trials_s_per_step_256c_512': {str(k): round(v, 3) for k, v in trial.items()},
               'c2_256c_512': c2, 'single_thread': single, 'host_threads': avail,
               'host_mem_available_GB': round(mem_gb, 1), 'binding': binding,
               'fft_backend': 'scipy.fft (pocketfft), workers = OpenMP threads'}
@@ -540,6 +560,39 @@ def verify_load(key):
 # ---------------------------------------------------------------------------
 # N > 1: x-slab domains
 # ---------------------------------------------------------------------------
+# one GPU, 2^28 particles / 1024^3 (profiles/r05_bench_ns_full_default.json), ms
+LINK_MODEL_SINGLE = {'deposit': 3.1, 'fft_zy_pairs': 11.6, 'fft_x_fused': 4.0,
+                     'kick_drift_sort': 9.0}
+
+
+def link_model_predict(N, total, world, transform_bytes=None):
+    """The link model of DESIGN.md §6: local kernels at 1/P of their single-GPU times, each
+    transpose at (local transform)/P bytes per peer over that peer's own xGMI link, the z / y
+    transforms hidden under the links when those are slower (the transposes are pipelined with
+    them), the x pass not.  transform_bytes: a rank's transform buffer (default: its slab's
+    N/P x N x (N + 2) doubles)."""
+    if transform_bytes is None:
+        transform_bytes = N*N*(N + 2)*8//world
+    scale = (N/1024.0)**3/world
+    local = {k: v*scale*((total/2.0**28)/(N/1024.0)**3 if k in ('deposit', 'kick_drift_sort')
+                         else 1.0) for k, v in LINK_MODEL_SINGLE.items()}
+    per_peer = transform_bytes/world
+    t_transpose = per_peer/(XGMI_LINK_GBS_DIR*1e9)*1e3 if world > 1 else 0.0
+    poisson_pred = max(2*t_transpose, local['fft_zy_pairs']) + local['fft_x_fused']
+    pred = local['deposit'] + poisson_pred + local['kick_drift_sort']
+    return {
+        'single_gpu_kernel_ms': dict(LINK_MODEL_SINGLE),
+        'local_kernel_ms_at_this_P': {k: round(v, 3) for k, v in local.items()},
+        'bytes_per_peer_per_transpose': int(per_peer),
+        'transpose_ms_at_link_rate': round(t_transpose, 3),
+        'predicted_poisson_stage_ms': round(poisson_pred, 3),
+        'predicted_step_ms': round(pred, 3),
+        'predicted_particle_updates_per_s': round(total/(pred*1e-3), 1),
+        'note': ('prediction = deposit/P + max(2 transposes at one xGMI link per peer '
+                 f'({XGMI_LINK_GBS_DIR} GB/s one way), z/y transforms/P) + x pass/P + fused '
+                 'particle pass/P; exchange of leavers and halo layers not priced (MBs)')}
+
+
 def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
     """Strong scaling: the same total workload on `world` x-slab domains, one per GPU
     (concept_amd/distributed.py).  A step = drift + particle exchange + tile sort (fused:
@@ -779,27 +832,9 @@ def main_distributed(args, name, n_p, N, L, dev, rank, world, backend):
     # the links when those are slower (the transposes are pipelined with them), the x pass not.
     link_model = None
     if world > 1:
-        scale = (N/1024.0)**3/world
-        single = {'deposit': 3.1, 'fft_zy_pairs': 11.6, 'fft_x_fused': 4.0,
-                  'kick_drift_sort': 9.0}   # ms, one GPU, 2^28 particles / 1024^3
-        local = {k: v*scale*((total/2.0**28)/(N/1024.0)**3 if k in ('deposit', 'kick_drift_sort')
-                             else 1.0) for k, v in single.items()}
-        per_peer = dom.tbuf_a.numel()*8/world
-        t_transpose = per_peer/(XGMI_LINK_GBS_DIR*1e9)*1e3
-        poisson_pred = max(2*t_transpose, local['fft_zy_pairs']) + local['fft_x_fused']
-        pred = local['deposit'] + poisson_pred + local['kick_drift_sort']
-        link_model = {
-            'single_gpu_kernel_ms': single,
-            'local_kernel_ms_at_this_P': {k: round(v, 3) for k, v in local.items()},
-            'bytes_per_peer_per_transpose': int(per_peer),
-            'transpose_ms_at_link_rate': round(t_transpose, 3),
-            'predicted_poisson_stage_ms': round(poisson_pred, 3),
-            'predicted_step_ms': round(pred, 3),
-            'measured_step_ms': round(elapsed/args.steps*1e3, 3),
-            'measured_poisson_stage_ms': round(ps_ms, 3),
-            'note': ('prediction = deposit/P + max(2 transposes at one xGMI link per peer '
-                     f'({XGMI_LINK_GBS_DIR} GB/s one way), z/y transforms/P) + x pass/P + fused '
-                     'particle pass/P; exchange of leavers and halo layers not priced (MBs)')}
+        link_model = link_model_predict(N, total, world, dom.tbuf_a.numel()*8)
+        link_model.update(measured_step_ms=round(elapsed/args.steps*1e3, 3),
+                          measured_poisson_stage_ms=round(ps_ms, 3))
     print(json.dumps({
         'metric': 'PM particle-updates/sec', 'value': total*args.steps/elapsed,
         'unit': 'particle-updates/s', 'steps_per_sec': args.steps/elapsed, 'n_gpus': world,
@@ -872,6 +907,9 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default=None)
+    ap.add_argument('--link-model', action='store_true',
+                    help='print the link model\'s prediction for the headline size on 1, 2, 4 '
+                         'and 8 GPUs (no GPU needed) and exit')
     ap.add_argument('--rung-loop', default=None, choices=['uniform', 'clustered'],
                     help='only the P3M time loop with 8 rungs at 256^3 / 512^3 '
                          '(configs.c2_p3m_rungs of the default line), --steps base steps')
@@ -914,6 +952,17 @@ def main():
                     help='direct (untiled) kernels on unsorted particles, for A/B')
     args = ap.parse_args()
 
+    if args.link_model:
+        n_p, N = WORKLOADS[args.workload or 'ns_256M_1024']
+        rows = {str(P): link_model_predict(N, n_p, P) for P in (1, 2, 4, 8)}
+        one = rows['1']['predicted_step_ms']
+        for P, r in rows.items():
+            r['predicted_speedup'] = round(one/r['predicted_step_ms'], 3)
+            r['predicted_efficiency'] = round(one/r['predicted_step_ms']/int(P), 3)
+        print(json.dumps({'workload': args.workload or 'ns_256M_1024', 'particles': n_p,
+                          'gridsize': N, 'xgmi_GBps_per_link_one_way': XGMI_LINK_GBS_DIR,
+                          'by_gpus': rows}, indent=1))
+        return
     if args.dry_links:
         os.environ['CONCEPT_GPU_DRY_LINKS'] = str(args.dry_links)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:

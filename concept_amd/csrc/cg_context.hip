@@ -1202,6 +1202,21 @@ extern "C" int cg_apply_rung_jumps(cg_ctx *c, int8_t *rung, int8_t *rung_jumped,
     return cgk_apply_rung_jumps(c, (signed char *)rung, (signed char *)rung_jumped, n, N_rungs);
 }
 
+extern "C" int cg_permute_rows(cg_ctx *c, const int64_t *perm, int64_t n, int ncols,
+                               const void *const *src, void *const *dst, const int *row_bytes) {
+    if (c && cgk_substep_flush(c)) return 1;  // (a deferred sub-step pass first)
+    CG_CHECK(c && ncols >= 0 && (n == 0 || ncols == 0 || (perm && src && dst && row_bytes)),
+             "cg_permute_rows: null argument");
+    for (int k = 0; k < ncols && n > 0; k++) {
+        CG_CHECK(src[k] && dst[k] && src[k] != dst[k] && row_bytes[k] > 0,
+                 "cg_permute_rows: column %d (source, destination — not in place — and row size)", k);
+        const int b = row_bytes[k], al = b % 8 == 0 ? 8 : (b == 4 ? 4 : 1);
+        CG_CHECK((uintptr_t)src[k] % al == 0 && (uintptr_t)dst[k] % al == 0,
+                 "cg_permute_rows: column %d is not aligned to %d bytes", k, al);
+    }
+    return cgk_permute_rows(c, (const i64 *)perm, n, ncols, src, dst, row_bytes);
+}
+
 extern "C" int cg_substep_begin(cg_ctx *c, double *pos, const double *mom, double *dmom,
                                 const int8_t *rung, int8_t *rung_jumped, int64_t n, int do_drift,
                                 double dt_over_mass, int do_flag, int lowest_active_rung,

@@ -213,6 +213,8 @@ int cgk_transpose_fourier(cg_ctx *c, const double *src, double *dst);
 int cgk_sort(cg_ctx *c, const double *pos_in, const double *mom_in, const i64 *ids_in,
              double *pos_out, double *mom_out, i64 *ids_out, i64 n, unsigned *tile_offset_out,
              int drift, double dt_over_mass, int use_prepared);
+int cgk_permute_rows(cg_ctx *c, const i64 *perm, i64 n, int ncols, const void *const *src,
+                     void *const *dst, const int *row_bytes);
 int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
                          unsigned *order, unsigned *offset, double *pos_sorted,
                          const signed char *rung, const signed char *rung_jumped,

@@ -475,3 +475,65 @@ int cgk_region_insert(cg_ctx *c, const double *rows, i64 m, const unsigned *star
     CG_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// The columns that follow a sort (Δmom, identifiers, the populated order, the two rung arrays of a
+// Component: species.py:955-996 keeps them in step with pos and mom through every reordering):
+// dst[c][q] = src[c][perm[q]] for all columns in one pass — the permutation is read once per row,
+// the stores are contiguous per column.  (One torch.index_select per column: five launches that
+// read the permutation five times, 5.7 of the 8.0 ms of BASELINE configs[4]'s drift + sort.)
+// ---------------------------------------------------------------------------
+constexpr int kPermuteCols = 8;
+struct PermuteCols {
+    const char *src[kPermuteCols];
+    char *dst[kPermuteCols];
+    int bytes[kPermuteCols];  // of a row
+    int n;
+};
+__global__ __launch_bounds__(256) void k_permute_rows(const i64 *__restrict__ perm, i64 n,
+                                                      PermuteCols C) {
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const i64 p = perm[q];
+#pragma unroll
+    for (int c = 0; c < kPermuteCols; c++) {
+        if (c >= C.n) break;
+        const int b = C.bytes[c];
+        const char *s = C.src[c] + p * b;
+        char *d = C.dst[c] + q * b;
+        if (b == 24) {  // three doubles
+            const double *s8 = (const double *)s;
+            double *d8 = (double *)d;
+            const double v0 = s8[0], v1 = s8[1], v2 = s8[2];
+            d8[0] = v0, d8[1] = v1, d8[2] = v2;
+        } else if (b == 8) {
+            *(unsigned long long *)d = *(const unsigned long long *)s;
+        } else if (b == 4) {
+            *(unsigned *)d = *(const unsigned *)s;
+        } else if (b == 1) {
+            *d = *s;
+        } else if (b % 8 == 0) {
+            for (int k = 0; k < b; k += 8)
+                *(unsigned long long *)(d + k) = *(const unsigned long long *)(s + k);
+        } else {
+            for (int k = 0; k < b; k++) d[k] = s[k];
+        }
+    }
+}
+int cgk_permute_rows(cg_ctx *c, const i64 *perm, i64 n, int ncols, const void *const *src,
+                     void *const *dst, const int *row_bytes) {
+    if (n == 0 || ncols == 0) return 0;
+    for (int c0 = 0; c0 < ncols; c0 += kPermuteCols) {
+        PermuteCols C{};
+        C.n = ncols - c0 < kPermuteCols ? ncols - c0 : kPermuteCols;
+        for (int k = 0; k < C.n; k++) {
+            C.src[k] = (const char *)src[c0 + k];
+            C.dst[k] = (char *)dst[c0 + k];
+            C.bytes[k] = row_bytes[c0 + k];
+        }
+        hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           c->stream, perm, n, C);
+        CG_LAUNCH_CHECK();
+    }
+    return 0;
+}

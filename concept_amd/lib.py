@@ -87,6 +87,7 @@ SYMBOLS = {
                                          _dbl, _dbl]),
     'cg_shortrange_sweep_cells_rungs': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64,
                                                _dbl, _dbl, _vp, _vp, _vp, _int]),
+    'cg_permute_rows': (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp]),
     'cg_substep_begin': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _dbl, _int, _int, _vp, _dbl,
                                 _dbl, _int, _vp, _vp, _int]),
     'cg_substep_flush': (_int, [_vp]),

@@ -632,6 +632,24 @@ class PotentialMesh:
             _ptr(tile_offset)))
         return tile_offset
 
+    def permute_rows(self, perm, pairs):
+        """dst[q] = src[perm[q]] for every (src, dst) of `pairs` in one pass (cg_permute_rows):
+        the columns that follow a sort."""
+        k = len(pairs)
+        if k == 0 or perm.numel() == 0:
+            return
+        n = perm.numel()
+        for s_, d_ in pairs:
+            if (s_.dtype != d_.dtype or s_.shape[1:] != d_.shape[1:] or s_.shape[0] < n
+                    or d_.shape[0] < n or not s_.is_contiguous() or not d_.is_contiguous()):
+                raise lib.ConceptGPUError('permute_rows: columns must be contiguous, of one '
+                                          'type and shape, with a row per entry of perm')
+        src = (ctypes.c_void_p*k)(*[s_.data_ptr() for s_, _ in pairs])
+        dst = (ctypes.c_void_p*k)(*[d_.data_ptr() for _, d_ in pairs])
+        rb = (ctypes.c_int*k)(*[s_.element_size()*int(np.prod(s_.shape[1:], dtype=np.int64))
+                                for s_, _ in pairs])
+        check(_L.cg_permute_rows(self._ctx, _ptr(perm), n, k, src, dst, rb))
+
     def drift_sort(self, pos, mom, ids, pos_out, mom_out, ids_out, dt_over_mass,
                    tile_offset=None):
         """Fused drift + tile sort: the outputs hold the drifted particles in tile order."""

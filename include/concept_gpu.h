@@ -452,6 +452,13 @@ int cg_flag_rung_jumps(cg_ctx *ctx, const double *acc, const int8_t *rung, int8_
 int cg_apply_rung_jumps(cg_ctx *ctx, int8_t *rung, int8_t *rung_jumped, int64_t n, int N_rungs);
 int cg_rung_populations(cg_ctx *ctx, const int8_t *rung, int64_t n, int N_rungs, int64_t *counts);
 
+/* The other columns of a Component follow a sort (species.py:955-996: Δmom, ids, the rung arrays
+ * stay in step with pos and mom through every reordering): dst[k][q] = src[k][perm[q]] for ncols
+ * columns of row_bytes[k] bytes per row in ONE pass.  src, dst, row_bytes: HOST arrays of ncols
+ * entries (the pointers in them DEV); not in place. */
+int cg_permute_rows(cg_ctx *ctx, const int64_t *perm /*DEV n*/, int64_t n, int ncols,
+                    const void *const *src, void *const *dst, const int *row_bytes);
+
 /* A sub-step of driftkick_short (main.py:1347-1624, one domain) in two passes over the particles:
  *   cg_substep_begin = [Component.drift, species.py:2179-2199, if do_drift] ->
  *                      [flag_rung_jumps -> nullify_Δ('mom') for the rungs >= lowest_active_rung,

@@ -18,6 +18,7 @@
  * reference's pure-Python fft() does (mesh.py:4035-4143).
  */
 #include <math.h>
+#include <time.h>
 #include <stdint.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -423,6 +424,34 @@ void orc_fill_tiled(double *dst, i64 n, const double *block, i64 nb, double shif
         }
         dst[i] = v;
     }
+}
+/* STREAM triad a = b + s c on arrays of n doubles touched first by the threads that sweep
+ * them (static schedule): what this host's memory gives the thread count in use — the ceiling
+ * bench.py prints beside the port's phases.  Returns the best of `reps` sweeps in seconds. */
+double orc_stream_triad(double *a, double *b, double *c, i64 n, int reps) {
+    double best = 1e300;
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; i++) {
+        a[i] = 0.0;
+        b[i] = 1.0;
+        c[i] = 2.0;
+    }
+    for (int r = 0; r < reps; r++) {
+#ifdef _OPENMP
+        const double t0 = omp_get_wtime();
+#else
+        const clock_t c0 = clock();
+#endif
+#pragma omp parallel for schedule(static)
+        for (i64 i = 0; i < n; i++) a[i] = b[i] + 3.0 * c[i];
+#ifdef _OPENMP
+        const double dt = omp_get_wtime() - t0;
+#else
+        const double dt = (double)(clock() - c0) / (double)CLOCKS_PER_SEC;
+#endif
+        if (dt < best) best = dt;
+    }
+    return best;
 }
 void orc_zero(double *dst, i64 n) {
 #pragma omp parallel for schedule(static)

@@ -203,9 +203,23 @@ def test_fused_pass_north_star_size_properties(torch_cuda):
     positions and momenta are BIT-EQUAL to cg_gather_kick_tiled + cg_drift on the same
     potential; the mesh force transfers no net momentum; the region deposit conserves mass
     (first step from the dense tile order, then from regions with gaps)."""
+    _fused_pass_size_properties(torch_cuda, 1024, 2**28, 97)
+
+
+def test_fused_pass_config3_size_properties(torch_cuda):
+    """The same at BASELINE configs[3]'s own size on one GPU — 1024^3 = 2^30 particles on a
+    2048^3 mesh (meant for 8 GPUs; ~200 GB here) — : the step bench.py times as
+    configs.c3_1024c_2048."""
     torch = torch_cuda
+    free, _ = torch.cuda.mem_get_info()
+    if free < 230e9:
+        pytest.skip(f'needs ~230 GB of device memory, {free/1e9:.0f} GB are free')
+    _fused_pass_size_properties(torch_cuda, 2048, 2**30, 389)
+
+
+def _fused_pass_size_properties(torch, N, n, stride):
     from concept_amd.mesh import PotentialMesh
-    N, L, n = 1024, 1024.0, 2**28
+    L = float(N)
     dt, mass = 1e-4, 1.0
     dtm, kick = dt/mass, mass*(-dt)
     mesh = PotentialMesh(N, L)
@@ -254,7 +268,7 @@ def test_fused_pass_north_star_size_properties(torch_cuda):
         st_in = start.long()
         ct_in = (st_in[1:] - st_in[:-1]) if count is None else count.long()
         nreg = ct_in.numel()
-        pick = torch.arange(0, nreg, 97, device='cuda')
+        pick = torch.arange(0, nreg, stride, device='cuda')
         lens = ct_in[pick]
         tot_s = int(lens.sum())
         offs = torch.cumsum(lens, 0) - lens

@@ -144,3 +144,35 @@ def test_deferred_pass_runs_with_the_cell_list(lowest):
     mesh.substep_flush()
     assert torch.equal(p3, p0) and torch.equal(d3, d0) and torch.equal(j3, j0)
     mesh.close()
+
+
+def test_permute_rows_carries_every_column_in_one_pass():
+    """cg_permute_rows: dst[k][q] = src[k][perm[q]] for a Component's other columns (Δmom,
+    identifiers, the order column, the rung arrays) — against torch.index_select per column;
+    more columns than one launch takes; what the store does with them after a tile sort."""
+    import torch
+    from concept_amd.lib import ConceptGPUError
+    from concept_amd.mesh import PotentialMesh
+    mesh = PotentialMesh(16, 16.0)
+    g = torch.Generator(device='cuda').manual_seed(9)
+    n, cap = 100003, 100100
+    perm = torch.randperm(n, device='cuda', generator=g)
+    cols = [torch.randn((cap, 3), dtype=torch.float64, device='cuda', generator=g),
+            torch.randint(0, 2**40, (cap,), device='cuda', generator=g),
+            torch.randint(0, 2**40, (cap,), device='cuda', generator=g),
+            torch.randint(-8, 8, (cap,), device='cuda', generator=g).to(torch.int8),
+            torch.randint(-8, 8, (cap,), device='cuda', generator=g).to(torch.int8),
+            torch.randn((cap, 5), dtype=torch.float32, device='cuda', generator=g),
+            torch.randint(0, 2**30, (cap,), device='cuda', generator=g).to(torch.int32),
+            torch.randn((cap, 2), dtype=torch.float64, device='cuda', generator=g),
+            torch.randn((cap, 7), dtype=torch.float64, device='cuda', generator=g),
+            torch.randint(0, 255, (cap, 3), device='cuda', generator=g).to(torch.uint8)]
+    outs = [torch.zeros_like(c) for c in cols]
+    mesh.permute_rows(perm, list(zip(cols, outs)))
+    for c, o in zip(cols, outs):
+        assert torch.equal(o[:n], torch.index_select(c[:n], 0, perm))
+        assert bool((o[n:] == 0).all())
+    mesh.permute_rows(perm[:0], list(zip(cols, outs)))       # nothing to do
+    with pytest.raises(ConceptGPUError, match='permute_rows'):
+        mesh.permute_rows(perm, [(cols[0], outs[1])])
+    mesh.close()
