@@ -38,7 +38,14 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 XGMI_LINK_GBS_DIR = 76.8     # one xGMI link, one direction (153.6 GB/s bidirectional; 7 links)
-PMC_FILE = 'profiles/r05_pmc_hbm_traffic.json'
+def _latest(pattern):
+    """the newest round's committed recording of that name (profiles/rNN_...)"""
+    import glob
+    found = sorted(glob.glob(os.path.join(REPO, 'profiles', pattern)))
+    return os.path.relpath(found[-1], REPO) if found else os.path.join('profiles', pattern)
+
+
+PMC_FILE = _latest('r??_pmc_hbm_traffic.json')
 
 WORKLOADS = {
     # name: (particles, gridsize)
@@ -435,7 +442,7 @@ def pmc_traffic(dom_kernel, workload):
 ID_CHUNK = 1 << 20
 VERIFY_SAMPLES = 512
 VERIFY_DIR = os.path.join(REPO, '.bench_verify')
-VERIFY_COMMITTED = 'profiles/r05_bench_verify_{key}.json'
+VERIFY_COMMITTED = 'profiles/r??_bench_verify_{key}.json'   # (the newest round's)
 
 
 def global_particles(torch, args, n_p, L, cell, mass, dt, dev, rank=0, world=1, mesh=None):
@@ -546,7 +553,7 @@ def verify_save(key, ids, pos, mom, n, sum_mom2, extra):
 def verify_load(key):
     import numpy as np
     for path in (os.path.join(VERIFY_DIR, key + '.json'),
-                 os.path.join(REPO, VERIFY_COMMITTED.format(key=key))):
+                 os.path.join(REPO, _latest(os.path.basename(VERIFY_COMMITTED.format(key=key))))):
         if os.path.exists(path):
             d = json.load(open(path))
             unhex = lambda rows: np.array([[float.fromhex(v) for v in row] for row in rows])

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libconcept_gpu.so')
 SOURCES = ['cg_context.hip', 'cg_mesh_kernels.hip', 'cg_tiled_kernels.hip', 'cg_fft.hip', 'cg_shortrange.hip', 'cg_shortrange_dense.hip', 'cg_rungs.hip',
            'cg_particles.hip', 'cg_general.hip', 'cg_pp.hip']
-HEADERS = [os.path.join(CSRC, 'cg_internal.h'), os.path.join(CSRC, 'cg_kspace.h'), os.path.join(CSRC, 'cg_tiles.h'), os.path.join(REPO, 'include', 'concept_gpu.h')]
+HEADERS = [os.path.join(CSRC, 'cg_internal.h'), os.path.join(CSRC, 'cg_kspace.h'), os.path.join(CSRC, 'cg_tiles.h'), os.path.join(CSRC, 'cg_substep.h'), os.path.join(REPO, 'include', 'concept_gpu.h')]
 
 FLAGS = [
     '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
@@ -51,7 +51,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
@@ -64,8 +64,11 @@ def build(force=False, verbose=True):
             cmd = [hipcc] + flags + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            jobs.append((cmd, subprocess.Popen(cmd)))   # (the sources compile side by side)
         objs.append(o)
+    for cmd, job in jobs:
+        if job.wait():
+            raise subprocess.CalledProcessError(job.returncode, cmd)
     if force or _stale(LIB, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + [
             '-L/opt/rocm/lib', '-lrocfft', '-Wl,-rpath,/opt/rocm/lib']

@@ -3,7 +3,7 @@
 # profiles/ afterwards):  tools/record_profiles.sh r05 <commit>
 # One-liners a driver can reproduce are listed in profiles/README.md.
 set -u
-TAG=${1:-r05}; COMMIT=${2:-unknown}; MODE=${3:-full}   # quick: kernel statistics, HBM traffic and the default line only
+TAG=${1:-r06}; COMMIT=${2:-unknown}; MODE=${3:-full}   # quick: kernel statistics, HBM traffic and the default line only
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_new; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -51,21 +51,14 @@ CONCEPT_GPU_SR_DENSE_MIN=0 python tools/sr_dense_time.py clustered 2>&1 | grep -
 python bench.py --workload c4_nonlinnu_1gpu --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/${TAG}_bench_c4_nonlinnu_1gpu.json
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/stats_c4 -- python $R/bench.py --workload c4_nonlinnu_1gpu --steps 3 --warmup 1 > $OUT/stats_c4.log 2>&1)
 python tools/rocprof_summary.py $OUT/stats_c4 $OUT/${TAG}_rocprof_kernel_stats_c4.txt > /dev/null; rm -rf $OUT/stats_c4
-# 8. the short-range sweep: blocks of 4 x 2 tiles per workgroup against one tile per workgroup, and what
-# the sweep costs apart from its pair tests (a build whose pair loop is empty), one box
-python tools/variant_patch.py sr_tiles '    if (m >= 2) {' '    if (false) {' > /dev/null 2>&1
-python tools/variant_patch.py sr_nopairs '    int pos = sa[0];
-#pragma unroll' '    int pos = sa[0];
-    ax += 1e-300 * (double)(sb[0] - pos); return;
-#pragma unroll' > /dev/null 2>&1
-python tools/variant_patch.py sr_tiles_nopairs '    if (m >= 2) {' '    if (false) {' '    int pos = sa[0];
-#pragma unroll' '    int pos = sa[0];
-    ax += 1e-300 * (double)(sb[0] - pos); return;
-#pragma unroll' > /dev/null 2>&1
-(for rep in 1 2; do for v in "" sr_tiles sr_nopairs sr_tiles_nopairs; do
-   if [ -n "$v" ]; then export CONCEPT_GPU_LIB=$R/tools/_variants/$v.so; else unset CONCEPT_GPU_LIB; fi
-   python tools/sr_dense_time.py uniform 2>&1 | grep -v amdgpu.ids
- done; done; unset CONCEPT_GPU_LIB) > $OUT/${TAG}_sr_blocks_ab.txt
+# 8. the rung loop (round 6): kernel statistics of the P3M time loop with 8 rungs, what a sub-step's
+# sweep and list cost by lowest active rung, the bench's leg for both boxes
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/stats_soak -- python $R/tools/soak_p3m.py 0.04 > $OUT/stats_soak.log 2>&1)
+(echo "# rocprofv3 --kernel-trace --stats -- python tools/soak_p3m.py 0.04  (the P3M time loop with 8 rungs, 256^3 / 512^3, a = 0.02 -> 0.04)"; grep 'base steps' $OUT/stats_soak.log; ROCPROF_GAPS=1 python tools/rocprof_summary.py $OUT/stats_soak) > $OUT/${TAG}_rocprof_kernel_stats_soak_p3m.txt; rm -rf $OUT/stats_soak
+python tools/sr_rung_cost.py uniform 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_sr_rung_cost.txt
+python bench.py --rung-loop uniform --steps 12 2>/dev/null | tail -1 > $OUT/${TAG}_bench_rung_loop_uniform.json
+python bench.py --rung-loop clustered --steps 10 2>/dev/null | tail -1 > $OUT/${TAG}_bench_rung_loop_clustered.json
+(python tools/soak_p3m.py 0.04 2>&1 | grep 'base steps'; SOAK_DIST=clustered python tools/soak_p3m.py 0.025 2>&1 | grep 'base steps') > $OUT/${TAG}_soak_p3m.txt
 (SR_DIST=uniform $R/tools/pmc_srd.sh 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_pmc_sr_blocks.txt)
 # 9. the 1-rank values an N-rank run of the driver's command compares its sample with
 cp .bench_verify/ns_256M_1024_seed1_thermal0.2_steps25.json $OUT/${TAG}_bench_verify_ns_256M_1024_seed1_thermal0.2_steps25.json 2>/dev/null
