@@ -23,7 +23,7 @@
 //    table[int(r2*scaling)], three multiply-adds in FP64 — every contribution bit-identical to the
 //    cells sweep's, only the order of the additions differs.  All 64 lanes work in every trip:
 //    no per-lane candidate lists.
-// Measured on a Gaussian blob of the bench's clustered box (tools: DESIGN.md §16b): 2.1-2.6 pair
+// Measured on a Gaussian blob of the bench's clustered box (profiles/HISTORY_design_r1_r5.md §16b): 2.1-2.6 pair
 // tests per pair in range in tiles of 256 particles and more, 3.2 at 128-256, 4.1 at 64-128
 // (the cells sweep: 4.1-4.7), worse below — so cg_shortrange_sweep_cells hands the tiles above a
 // population threshold to this kernel and keeps the others.

@@ -80,7 +80,7 @@ force_replays = 0   # test hook: that many of the next streaming passes are repl
 
 
 def _streaming_pass(plan, components, rps, ᔑdt_kick, ᔑdt_drift, label='', drift_on_replay=True):
-    """One pass of the streaming form (DESIGN.md §4a) over particles kept in tile regions: every
+    """One pass of the streaming form (DESIGN.md §4) over particles kept in tile regions: every
     component deposited from its regions (mesh.py:1512-1636), one Poisson solve
     (interactions.py:2092-2118), then per component cg_gather_kick_drift_scatter with the kick's
     ᔑdt['a**(-3*w_eff)', name] and the following drift's ᔑdt['a**(-2)'].  ᔑdt_drift None: a kick
@@ -151,7 +151,7 @@ def _streaming_pass(plan, components, rps, ᔑdt_kick, ᔑdt_drift, label='', dr
 
 def _timeloop_streaming(components, n_steps, integrals, plan):
     """timeloop() for the default PM configuration with the kick of one step and the drift of
-    the next fused (DESIGN.md §4a): K½ D K D ... K as n_steps + 1 passes of _streaming_pass."""
+    the next fused (DESIGN.md §4): K½ D K D ... K as n_steps + 1 passes of _streaming_pass."""
     mesh = plan['mesh']
     rps = [c.to_regions(mesh) for c in components]
     try:
