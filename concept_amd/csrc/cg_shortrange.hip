@@ -1209,6 +1209,7 @@ __global__ __launch_bounds__(256) void k_sr_sweep_active_cells(
     const unsigned *__restrict__ rows, const unsigned *__restrict__ nlist) {
     __shared__ unsigned r_beg[4][kSaRuns], r_cnt[4][kSaRuns];
     __shared__ int r_img[4][kSaRuns];  // the run's image: (ox + 1) | (oy + 1) << 2 | (oz + 1) << 4
+    __shared__ unsigned r_pre[4][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned idx = blockIdx.x * 4u + (unsigned)wave;
@@ -1248,45 +1249,56 @@ __global__ __launch_bounds__(256) void k_sr_sweep_active_cells(
         r_cnt[wave][lane] = cnt;
         r_img[wave][lane] = img;
     }
-    const int ntrips = zwrap ? kSaRuns / 4 : 7;  // (25 runs: 7 trips of 4)
-    const int slot0 = lane >> 4, k0 = lane & 15;
+    // The runs as ONE sequence of suppliers: r_pre[s] = suppliers in the runs before s (the
+    // wave's own scan of the counts it has just written: lanes 0..51 hold them).  A lane takes
+    // supplier t = trip * 64 + lane and finds its run by bisection of the 64 prefix sums (six
+    // LDS reads) — 6 trips of 64 for the ~350 suppliers of a receiver instead of 11 trips of
+    // 4 runs x 16 lanes, most of them half empty (0.48 of the lane slots used).
+    {
+        const unsigned mine = lane < kSaRuns ? r_cnt[wave][lane] : 0u;
+        const unsigned incl = sr_wave_scan(mine);
+        r_pre[wave][lane] = incl - mine;   // (lanes >= 52: the total)
+    }
+    const unsigned total = r_pre[wave][63];
     const double L = P.boxsize;
     SrCount cnt;
     {
         const i64 row = (i64)(unsigned)__builtin_amdgcn_readfirstlane((int)rows[idx]);
         const double xi = pos_r[3 * row], yi = pos_r[3 * row + 1], zi = pos_r[3 * row + 2];
         double ax = 0, ay = 0, az = 0;
-        // (a lane's loads of seven trips issued together before the first is used — 126 registers,
-        // four wavefronts per SIMD — measured slower than a trip at a time at eight: 6.5 against
-        // 4.4 ms for the 2 million receivers of the upper two rungs at 256^3)
-        for (int q = 0; q < ntrips; q++) {
-            const int slot = 4 * q + slot0;
-            const unsigned beg = r_beg[wave][slot], n = r_cnt[wave][slot];
-            const int img = r_img[wave][slot];
-            const double ox = (double)((img & 3) - 1) * L, oy = (double)((img >> 2 & 3) - 1) * L,
-                         oz = (double)((img >> 4 & 3) - 1) * L;
-            for (unsigned k = (unsigned)k0; __any(k < n); k += 16) {
-                const bool valid = k < n;
-                double t = 0.0, x = 0, y = 0, z = 0;
-                bool hit = false;
-                if (valid) {
-                    const i64 g = (i64)beg + k;
-                    x = (xi - pos_s[3 * g]) + ox;          // interactions.py:1787-1789,
-                    y = (yi - pos_s[3 * g + 1]) + oy;      // gravity.py:299-302
-                    z = (zi - pos_s[3 * g + 2]) + oz;
-                    const double r2 = x * x + y * y + z * z;   // gravity.py:306
-                    hit = r2 <= P.r2_max;                      // gravity.py:311
-                    if (hit) t = table[(unsigned)(int)(r2 * P.r2_index_scaling)];
-                }
-                if (STATS) {
-                    cnt.tests += (unsigned)__popcll(__ballot(valid));
-                    cnt.hits += (unsigned)__popcll(__ballot(hit));
-                    cnt.trips++;
-                }
-                ax = __builtin_fma(x, t, ax);
-                ay = __builtin_fma(y, t, ay);
-                az = __builtin_fma(z, t, az);
+        // (a lane's loads of several trips issued together before the first is used — 126
+        // registers, four wavefronts per SIMD — measured slower than a trip at a time at eight)
+        for (unsigned t0 = 0; t0 < total; t0 += 64) {
+            const unsigned t = t0 + (unsigned)lane;
+            const bool valid = t < total;
+            // the run of supplier t: the last s with r_pre[s] <= t
+            int sl = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+                if (r_pre[wave][sl + step] <= t) sl += step;   // (entries beyond the runs hold the total)
+            sl = min(sl, kSaRuns - 1);
+            double tv = 0.0, x = 0, y = 0, z = 0;
+            bool hit = false;
+            if (valid) {
+                const i64 g = (i64)r_beg[wave][sl] + (t - r_pre[wave][sl]);
+                const int img = r_img[wave][sl];
+                const double ox = (double)((img & 3) - 1) * L, oy = (double)((img >> 2 & 3) - 1) * L,
+                             oz = (double)((img >> 4 & 3) - 1) * L;
+                x = (xi - pos_s[3 * g]) + ox;          // interactions.py:1787-1789,
+                y = (yi - pos_s[3 * g + 1]) + oy;      // gravity.py:299-302
+                z = (zi - pos_s[3 * g + 2]) + oz;
+                const double r2 = x * x + y * y + z * z;   // gravity.py:306
+                hit = r2 <= P.r2_max;                      // gravity.py:311
+                if (hit) tv = table[(unsigned)(int)(r2 * P.r2_index_scaling)];
             }
+            if (STATS) {
+                cnt.tests += (unsigned)__popcll(__ballot(valid));
+                cnt.hits += (unsigned)__popcll(__ballot(hit));
+                cnt.trips++;
+            }
+            ax = __builtin_fma(x, tv, ax);
+            ay = __builtin_fma(y, tv, ay);
+            az = __builtin_fma(z, tv, az);
         }
         // the wave's lanes added in a fixed order (DPP: rows of 16, then the row totals)
         auto wave_sum = [](double v) {

@@ -758,10 +758,10 @@ class PotentialMesh:
         return {'cells': tuple(int(v) for v in out[0:3]), 'dense': tuple(int(v) for v in out[3:6])}
 
     SHORTRANGE_SPARSE_MAX = 8
-    # the sweep by active cell is taken up to this fraction of the receivers on active rungs
-    # (tools/sr_rung_cost.py, 256^3 / 512^3: 0.35 against 1.23 ms at 0.9 %, 3.5 against 3.0 ms at
-    # 12 %; the two cross near 8 %)
-    SHORTRANGE_BY_CELL_MAX = 0.06
+    # the sweep by active receiver is taken up to this fraction of the receivers on active rungs
+    # (tools/sr_rung_cost.py, 256^3 / 512^3: 0.32 against 1.39 ms in blocks at 0.9 %, 2.5 against
+    # 3.5 ms at 12 %, 4.9 against 4.6 ms at 25 %)
+    SHORTRANGE_BY_CELL_MAX = 0.16
 
     def shortrange_sparse(self, pos_r, active, dmom_r, pos_s, table, r2_index_scaling, r2_max,
                           factor, rungs=None):
