@@ -220,12 +220,13 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
                     rc = get_cells(rec)
                     rungs = (factors, rec.rung_indices, rec.rung_indices_jumped,
                              rec.lowest_active_rung)
-                    # few receivers on active rungs (one domain: rungs_N counts them): the
-                    # sweep by active cell
+                    # few receivers on active rungs (rungs_N counts them — over all domains: an
+                    # upper bound of this domain's, which is all the sweep asks for): the sweep
+                    # by active receiver
                     n_active = None
-                    if not multi and rec.lowest_active_rung > 0:
+                    if rec.lowest_active_rung > 0:
                         n_active = int(sum(rec.rungs_N[rec.lowest_active_rung:]))
-                        if n_active > mesh.SHORTRANGE_BY_CELL_MAX*rec.N_local:
+                        if n_active > mesh.SHORTRANGE_BY_CELL_MAX*rec.N:
                             n_active = None
                     mesh.shortrange_sweep_cells(rc, rec.Δmom, supp_cells[id(sup)], nt, table,
                                                 scaling, r2_max, 0.0, rungs, n_active)

@@ -211,6 +211,13 @@ def test_fused_pass_config3_size_properties(torch_cuda):
     2048^3 mesh (meant for 8 GPUs; ~200 GB here) — : the step bench.py times as
     configs.c3_1024c_2048."""
     torch = torch_cuda
+    # (what the tests before this one left in torch's allocator and in the mesh cache goes back
+    # to the device first)
+    import gc
+    from concept_amd import mesh as mesh_module
+    gc.collect()
+    mesh_module.free_meshes()
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     if free < 230e9:
         pytest.skip(f'needs ~230 GB of device memory, {free/1e9:.0f} GB are free')
