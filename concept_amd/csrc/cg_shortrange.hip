@@ -238,17 +238,39 @@ __global__ __launch_bounds__(256) void k_sr_cell_place(const double *__restrict_
                                                        double *__restrict__ pos_sorted,
                                                        SrActive A, const unsigned *__restrict__ nact,
                                                        signed char *__restrict__ rj_sorted) {
-    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const uint2 cr = cellrel[p];
-    i64 q = (i64)offset[cr.x] + (cr.y & 0x7fffffffu);
-    if (ACT && !(cr.y >> 31)) q += nact[cr.x];
-    order[q] = (unsigned)p;
-    pos_sorted[3 * q] = pos[3 * p];
-    pos_sorted[3 * q + 1] = pos[3 * p + 1];
-    pos_sorted[3 * q + 2] = pos[3 * p + 2];
-    if constexpr (ACT)
-        if (rj_sorted) rj_sorted[q] = A.rung_jumped[p];
+    // (four particles per thread, every load of the four issued before the first store: the
+    // chain cell -> the cell's offset -> the row's address is waited for once, not four times)
+    const i64 base = (i64)blockIdx.x * (256 * kSrPerThread);
+    uint2 cr[kSrPerThread];
+    double x[kSrPerThread], y[kSrPerThread], z[kSrPerThread];
+    i64 q[kSrPerThread];
+#pragma unroll
+    for (int u = 0; u < kSrPerThread; u++) {
+        const i64 p = base + threadIdx.x + 256 * u;
+        cr[u] = p < n ? cellrel[p] : make_uint2(0u, 0u);
+        if (p < n) x[u] = pos[3 * p], y[u] = pos[3 * p + 1], z[u] = pos[3 * p + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < kSrPerThread; u++) {
+        const i64 p = base + threadIdx.x + 256 * u;
+        q[u] = 0;
+        if (p < n) {
+            q[u] = (i64)offset[cr[u].x] + (cr[u].y & 0x7fffffffu);
+            if (ACT && !(cr[u].y >> 31)) q[u] += nact[cr[u].x];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kSrPerThread; u++) {
+        const i64 p = base + threadIdx.x + 256 * u;
+        if (p < n) {
+            order[q[u]] = (unsigned)p;
+            pos_sorted[3 * q[u]] = x[u];
+            pos_sorted[3 * q[u] + 1] = y[u];
+            pos_sorted[3 * q[u] + 2] = z[u];
+            if constexpr (ACT)
+                if (rj_sorted) rj_sorted[q[u]] = A.rung_jumped[p];
+        }
+    }
 }
 
 int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double tile_extent,
@@ -313,7 +335,7 @@ int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
                                             c->stream));
     if (n > 0) {
         hipLaunchKernelGGL(act ? k_sr_cell_place<true> : k_sr_cell_place<false>,
-                           dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, pos, n,
+                           dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n,
                            offset, cellrel, order, pos_sorted, A, nact, rj_sorted);
         CG_LAUNCH_CHECK();
     }
