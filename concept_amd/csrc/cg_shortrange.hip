@@ -602,7 +602,10 @@ __device__ __forceinline__ SrChunk sr_chunk_load(unsigned base, unsigned rend, i
         c.yi = pos_r[3 * (i64)qi + 1];
         c.zi = pos_r[3 * (i64)qi + 2];
         if (RUNGS == 1) c.factor = P.factors[P.rung_jumped[c.pi]];  // (every rung is active)
-        if (RUNGS == 2) c.factor = P.factors[P.rj_sorted ? P.rj_sorted[qi] : P.rung_jumped[c.pi]];
+        // (the rows' jumped rung indices in list order: a load beside the others — read through
+        // order_r it would wait for that load first, 0.5 ms of a sweep with half the receivers
+        // active)
+        if (RUNGS == 2) c.factor = P.factors[P.rj_sorted[qi]];
     }
     return c;
 }
@@ -1287,6 +1290,10 @@ __global__ __launch_bounds__(256) void k_sr_sweep_active_cells(
     {
         const i64 row = (i64)(unsigned)__builtin_amdgcn_readfirstlane((int)rows[idx]);
         const double xi = pos_r[3 * row], yi = pos_r[3 * row + 1], zi = pos_r[3 * row + 2];
+        // (the receiver's particle index and its factor: asked for now, needed after the loop —
+        // as a chain behind the loop they were three round trips at the end of every wavefront)
+        const i64 o = 3 * (i64)order_r[row];
+        const double f = P.factors[P.rj_sorted ? P.rj_sorted[row] : P.rung_jumped[o / 3]];  // gravity.py:318-349
         double ax = 0, ay = 0, az = 0;
         // (a lane's loads of several trips issued together before the first is used — 126
         // registers, four wavefronts per SIMD — measured slower than a trip at a time at eight)
@@ -1341,8 +1348,6 @@ __global__ __launch_bounds__(256) void k_sr_sweep_active_cells(
         };
         ax = wave_sum(ax), ay = wave_sum(ay), az = wave_sum(az);
         if (lane == 63) {
-            const i64 o = 3 * (i64)order_r[row];
-            const double f = P.factors[P.rj_sorted ? P.rj_sorted[row] : P.rung_jumped[o / 3]];  // gravity.py:318-349
             dmom_r[o] += ax * f;
             dmom_r[o + 1] += ay * f;
             dmom_r[o + 2] += az * f;
@@ -1387,7 +1392,10 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                factors,      rung,             rung_jumped, lowest_active, nullptr, nullptr,
                (int)(r2_max * r2_index_scaling) + 1, nullptr, nullptr};
     const bool partial = rung && lowest_active > 0;
-    const bool act = partial && nact_r;
+    // (the blocks take the active-first form only with the jumped rung indices in list order; a
+    // list without them is swept as a plain list — its order inside the cells does not matter
+    // there — unless the caller asks for the sweep by active receiver)
+    const bool act = partial && nact_r && (rj_sorted_r || n_active_max >= 0);
     if (act) P.nact = nact_r, P.rj_sorted = rj_sorted_r;
     if (partial && !act) {
         // which tiles have a receiver on an active rung (the others leave at once)

@@ -665,7 +665,7 @@ class PotentialMesh:
 
     # -- debug / parity -----------------------------------------------------
     # -- P3M short range -----------------------------------------------------------
-    def shortrange_cells(self, pos, nt, tile_extent, rungs=None):
+    def shortrange_cells(self, pos, nt, tile_extent, rungs=None, sorted_jumps=False):
         """Cell list at half-tile granularity with the positions copied in cell order
         (cg_shortrange_cells): (order, offset, pos_sorted).  rungs = (rung int8, rung_jumped
         int8, lowest_active_rung) with lowest_active_rung > 0 makes the list of a sub-step
@@ -680,14 +680,17 @@ class PotentialMesh:
             rung, rung_jumped, lowest = rungs
             self._check_rungs(n, rung, rung_jumped)
             nact = torch.empty(8*nt**3, dtype=torch.int32, device=pos.device)
-            # (the rows' jumped rung indices are not copied into list order: the sweep reads
-            # them through `order` for its active receivers — the copy cost the list 0.1 ms
-            # per build at 256^3, a scattered byte per particle)
+            # sorted_jumps: the rows' jumped rung indices copied into list order too — worth
+            # its scattered byte per particle (0.1 ms per list at 256^3) where many receivers
+            # are active and the sweep goes in blocks (5.2 against 5.8 ms with half of them
+            # active); the sweep by active receiver reads them through `order`
+            rj_sorted = (torch.empty(max(n, 1), dtype=torch.int8, device=pos.device)
+                         if sorted_jumps else None)
             check(_L.cg_shortrange_cells_rungs(
                 self._ctx, _ptr(pos), n, int(nt), float(tile_extent), _ptr(rung),
                 _ptr(rung_jumped), int(lowest), _ptr(order), _ptr(offset), _ptr(pos_sorted),
-                _ptr(nact), None))
-            return order, offset, pos_sorted, nact, None, rung, int(lowest)
+                _ptr(nact), _ptr(rj_sorted) if rj_sorted is not None else None))
+            return order, offset, pos_sorted, nact, rj_sorted, rung, int(lowest)
         check(_L.cg_shortrange_cells(self._ctx, _ptr(pos), n, int(nt), float(tile_extent),
                                      _ptr(order), _ptr(offset), _ptr(pos_sorted)))
         return order, offset, pos_sorted

@@ -142,7 +142,11 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
             taken = c.take_begin(mesh)
             rungs = ((c.rung_indices, c.rung_indices_jumped, c.lowest_active_rung)
                      if c.use_rungs and c in receivers else None)
-            cells[id(c)] = build(c.pos, nt, tile_extent, rungs)
+            # (many active receivers: the sweep goes in blocks and wants the jumped rung
+            # indices in list order)
+            in_blocks = (rungs is not None and c.lowest_active_rung > 0 and
+                         sum(c.rungs_N[c.lowest_active_rung:]) > mesh.SHORTRANGE_BY_CELL_MAX*c.N)
+            cells[id(c)] = build(c.pos, nt, tile_extent, rungs, in_blocks)
             if taken:
                 c.begin_queued()
             supp_cells.setdefault(id(c), cells[id(c)])

@@ -360,9 +360,9 @@ int cg_shortrange_sweep_cells_rungs(cg_ctx *ctx, const double *pos_r_sorted,
  * particles on active rungs FIRST inside every cell — the reference's lists by tile and rung
  * (species.py tiles_rungs_N, interactions.py:1688-1761) in the sweep's layout.  nact_out[cell] =
  * how many of the cell's rows are active, rung_jumped_sorted_out[row] = rung_jumped[order[row]]
- * (what selects the row's factor; may be null, as may rung_jumped_sorted_r of the sweep, which
- * then reads rung_jumped_r through order_r — one scattered byte per particle less to write, one
- * gather per active receiver more).  cg_shortrange_sweep_cells_active is
+ * (what selects the row's factor; may be null, as may rung_jumped_sorted_r of the sweep: the
+ * sweep by active receiver reads rung_jumped_r through order_r — one scattered byte per particle
+ * less to write — while a sweep in blocks of a list without them takes it as a plain list).  cg_shortrange_sweep_cells_active is
  * cg_shortrange_sweep_cells_rungs for a receivers' list made this way WITH THE SAME rung array
  * and lowest active rung: its receiver groups are the first nact rows of their cells — no pass
  * over the tiles' rungs, no gathers through order_r in front of the pair loop.  The sums are

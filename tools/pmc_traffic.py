@@ -22,12 +22,12 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 BENCH_KEYS = {  # bench.py kernel names -> demangled prefixes of the device kernels
-    'kick_drift_sort': ['k_gather_kick_tiled<2, 16, 2>'],
+    'kick_drift_sort': ['k_gather_kick_tiled<2, 16, 2, false>'],
     'fft_zy_forward_chunked': [], 'fft_yz_backward_chunked': [],
-    'gather_kick': ['k_gather_kick_tiled<2, 16, 1>', 'k_gather_kick_tiled<2, 16, 0>'],
+    'gather_kick': ['k_gather_kick_tiled<2, 16, 1, false>', 'k_gather_kick_tiled<2, 16, 0, false>'],
     'deposit': ['k_deposit_cic_pull<16, false>'],
-    'fft_x_fused_kspace': ['k_fft_strided_h<10, 256, 2>', 'k_fft_strided_p<10, 512, 2, 8>'],
-    'sr_sweep': ['k_sr_sweep_blocks', 'k_sr_sweep_cells'],
+    'fft_x_fused_kspace': ['k_fft_strided_h<10, 256, 2,', 'k_fft_strided_p<10, 512, 2, 8>'],
+    'sr_sweep': ['k_sr_sweep_blocks'],
 }
 
 

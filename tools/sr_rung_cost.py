@@ -52,8 +52,9 @@ for la in range(5):
         if kind != 'plain':
             if la == 0:
                 continue
-            t_l = timed(lambda: mesh.shortrange_cells(pos, nt, L/nt, (rung, rung, la)))
-            rl = mesh.shortrange_cells(pos, nt, L/nt, (rung, rung, la))
+            blocks = kind == 'active first'
+            t_l = timed(lambda: mesh.shortrange_cells(pos, nt, L/nt, (rung, rung, la), blocks))
+            rl = mesh.shortrange_cells(pos, nt, L/nt, (rung, rung, la), blocks)
         else:
             t_l, rl = float('nan'), lst
         f = lambda: mesh.shortrange_sweep_cells(rl, dm, lst, nt, table, 4095/maxr2, rng_**2, 0.0,  # noqa: E731
