@@ -503,7 +503,11 @@ __attribute__((amdgpu_waves_per_eu(8, 8))) void k_sr_sweep_dense(
     // the pieces: column (ta + dx, tb + dy), tiles tc - 1 .. tc + 1 — one run of the list (z is
     // fastest), two where the column wraps around the box in z
     if (tid < kdPieces) {
-        const int c9 = tid >> 1, half = tid & 1;
+        // (worked out per item: hoisted out of the item loop, the column's coordinates were the
+        // two registers this kernel spilled at its 64)
+        int c9 = tid >> 1;
+        asm volatile("" : "+v"(c9));
+        const int half = tid & 1;
         int gx = ta + c9 / 3 - 1, gy = tb + c9 % 3 - 1;
         // periodic offset from the tile separation (interactions.py:1615-1621): code 2 = +L
         unsigned ix = 1, iy = 1, iz = 1;
