@@ -316,6 +316,10 @@ class RungStepper:
     for particle components with a P3M short-range force and N_rungs > 1.
     `integrals(t_start, t_end)` plays get_time_step_integrals(); `t` is universals.t."""
 
+    # (False: the separate calls of the reference's loop — what several domains take, and what
+    # the tests compare the two-pass form of a sub-step with)
+    fuse_substeps = True
+
     def __init__(self, components, integrals, t=0.0, fac_softening=None, Δt_jump_fac=0.95,
                  Δt_reltol=1e-9):
         self.components = list(components)
@@ -423,7 +427,7 @@ class RungStepper:
         # One domain, rungs in use: a sub-step's per-particle calls run as two passes
         # (Component.substep_begin / substep_end) and the host waits once per sub-step
         # (substep_finish), after it has worked out the next sub-step's integrals.
-        fused = all(c.nprocs == 1 and c.use_rungs for c in comps)
+        fused = self.fuse_substeps and all(c.nprocs == 1 and c.use_rungs for c in comps)
         any_kicks = True
         index_start = 0
         for driftkick_index in range(2**(nr - 1)):

@@ -630,3 +630,63 @@ def test_p3m_timeloop_with_dense_tiles_equals_the_cells_sweep(monkeypatch):
     assert float(d.max()) <= 1e-9*L, float(d.max())
     assert float((rungs0 != rungs1).double().mean()) <= 1e-4   # (a particle on a rung's border)
     assert int(rungs0.max()) >= 2
+
+
+def test_rung_loop_in_two_passes_equals_the_separate_calls(monkeypatch):
+    """The rung loop's production form (a sub-step as two passes over the particles, the first
+    inside the cell list's counting pass, populations counted before the jumps are applied, the
+    sweeps by active receiver / by active-first blocks) against the reference's call sequence
+    (drift, flag_rung_jumps, nullify_Δ, sweep with rung gathers, apply_Δmom,
+    convert_Δmom_to_acc, apply_rung_jumps, set_rungs_N: main.py:1347-1624) on a clustered box of
+    48^3 particles with several rungs populated, base step by base step."""
+    import torch
+    from concept_amd import commons, stepper
+    from concept_amd.mesh import PotentialMesh
+    from concept_amd.species import Component
+    n_side, N = 48, 96
+    n = n_side**3
+
+    def run(fuse):
+        monkeypatch.setattr(stepper.RungStepper, 'fuse_substeps', fuse)
+        # (the separate calls with the plain lists of the reference's loop)
+        monkeypatch.setattr(PotentialMesh, 'SHORTRANGE_BY_CELL_MAX', 0.16 if fuse else -1.0)
+        p = commons.load_params({
+            'boxsize': float(N), 'H0': 0.07, 'Ωb': 0.05, 'Ωcdm': 0.25, 'a_begin': 0.02,
+            'output_times': {'a': (0.5,)},
+            'potential_options': {'gridsize': {'gravity': {'p3m': N}}},
+            'select_forces': {'all': {'gravity': 'p3m'}}})
+        c = Component('matter', 'matter', N=n, mass=p.ρ_mbar*p.boxsize**3/n)
+        g = torch.Generator(device='cuda').manual_seed(4)
+        pos = torch.rand((n, 3), dtype=torch.float64, device='cuda', generator=g)*N
+        blob = N/2 + torch.randn((n, 3), dtype=torch.float64, device='cuda', generator=g)*(N/30)
+        pick = torch.rand(n, device='cuda', generator=g) < 0.5
+        pos = torch.where(pick[:, None], torch.remainder(blob, N), pos).clamp_(0, N*(1 - 1e-13))
+        c.populate(pos.cpu().numpy(), 'pos')
+        c.populate(np.zeros((n, 3)), 'mom')
+        snaps = []
+
+        class Enough(Exception):
+            pass
+
+        def on_step(lp):
+            snaps.append((lp.cosmo.t, lp.Δt, list(c.rungs_N), c.host('pos'), c.host('mom')))
+            if len(snaps) > 6:
+                raise Enough
+        loop = stepper.Timeloop([c], on_step=on_step)
+        try:
+            loop.run()
+        except Enough:
+            pass
+        return snaps
+    a, b = run(False), run(True)
+    assert len(a) == len(b) == 7
+    assert max(len([v for v in s[2] if v]) for s in a) >= 3      # several rungs populated
+    kick = np.abs(a[-1][4]).max()
+    for i, (x, y) in enumerate(zip(a, b)):
+        # the same clock (the base step follows v_rms: sums of momenta that agree to rounding)
+        assert abs(x[0]/y[0] - 1) <= 1e-12 and abs(x[1]/y[1] - 1) <= 1e-10, i
+        d = np.abs(x[3] - y[3])
+        assert np.minimum(d, N - d).max() <= 1e-10*N, i
+        assert np.abs(x[4] - y[4]).max() <= 1e-9*kick, i
+        # (a rung assignment can differ where an acceleration sits on a rung's edge to rounding)
+        assert sum(abs(u - v) for u, v in zip(x[2], y[2])) <= 2e-4*n, (i, x[2], y[2])
