@@ -1190,7 +1190,8 @@ __global__ __launch_bounds__(256) void k_sr_active_cells(const unsigned *__restr
                                                          unsigned *__restrict__ list,
                                                          unsigned *__restrict__ rows,
                                                          unsigned *__restrict__ count,
-                                                         unsigned cap) {
+                                                         unsigned cap,
+                                                         unsigned *__restrict__ err_flags) {
     __shared__ unsigned w_tot[4], w_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // wave w of the workgroup takes 1024 consecutive cells, 64 at a time
@@ -1220,6 +1221,8 @@ __global__ __launch_bounds__(256) void k_sr_active_cells(const unsigned *__restr
                 list[slot] = c;
                 rows[slot] = r0 + k;
             }
+            // (more active receivers than the caller's bound: they are not swept, and it shows)
+            if (off + incl > cap) atomicOr(err_flags, (unsigned)CG_ERR_ACTIVE_OVERFLOW);
         }
         off += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
     }
@@ -1452,7 +1455,7 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
             hipLaunchKernelGGL(k_sr_active_cells,
                                dim3((unsigned)((ncells + 256 * kSaPerThread - 1) / (256 * kSaPerThread))), dim3(256),
                                0, c->stream, nact_r, off_r, (unsigned)ncells, list, rows, count,
-                               (unsigned)n_active_max);
+                               (unsigned)n_active_max, c->err_flags);
             CG_LAUNCH_CHECK();
             hipLaunchKernelGGL(P.stats ? k_sr_sweep_active_cells<true> : k_sr_sweep_active_cells<false>,
                                dim3((unsigned)((n_active_max + 3) / 4)), dim3(256), 0, c->stream,

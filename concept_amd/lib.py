@@ -42,6 +42,7 @@ CG_FETCH_MESH_FOURIER = 1
 CG_ERR_STALE_HISTOGRAM = 1
 CG_ERR_BUCKET_OVERFLOW = 2
 CG_ERR_NOT_IN_TILE = 4
+CG_ERR_ACTIVE_OVERFLOW = 8
 
 _vp, _i64, _dbl, _int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int
 

@@ -578,6 +578,11 @@ class PotentialMesh:
                 'cg_gather_kick_drift_scatter: a particle was not in the tile it is stored under '
                 '(positions changed since the order was made) and got no kick — repeat the step '
                 'on the exact path')
+        if flags & lib.CG_ERR_ACTIVE_OVERFLOW:
+            raise lib.ConceptGPUError(
+                'cg_shortrange_sweep_cells_active: more receivers on active rungs than the bound '
+                'it was given (the rung populations lag behind the rung array); the receivers '
+                'beyond it got no short-range kick')
         if flags & lib.CG_ERR_BUCKET_OVERFLOW:
             raise lib.ConceptGPUError(
                 'cg_gather_kick_drift_scatter: a (tile, bucket) outgrew its predicted region; '

@@ -90,6 +90,7 @@ def _pair_integrals(ᔑdt_rungs, rec, sup):
 
 
 sparse_sweeps = 0   # sweeps taken without a cell list (a handful of active receivers)
+by_receiver_meshes = {}   # meshes that took a sweep by active receiver since the time loop looked
 
 
 def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
@@ -232,6 +233,8 @@ def component_component(force, receivers, suppliers, ᔑdt_rungs, gridsize):
                         n_active = int(sum(rec.rungs_N[rec.lowest_active_rung:]))
                         if n_active > mesh.SHORTRANGE_BY_CELL_MAX*rec.N:
                             n_active = None
+                    if n_active is not None:
+                        by_receiver_meshes[id(mesh)] = mesh
                     mesh.shortrange_sweep_cells(rc, rec.Δmom, supp_cells[id(sup)], nt, table,
                                                 scaling, r2_max, 0.0, rungs, n_active)
                 else:

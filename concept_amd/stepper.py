@@ -493,6 +493,15 @@ class RungStepper:
             for c, jumps in zip(comps, any_rung_jumps):
                 if jumps:
                     c.apply_rung_jumps()
+        self._check_sweeps()
+
+    def _check_sweeps(self):
+        """once per base step: did a sweep by active receiver meet more of them than the rung
+        populations said (cg_error_flags of the meshes that took such sweeps)?"""
+        from . import shortrange
+        for mesh in list(shortrange.by_receiver_meshes.values()):
+            mesh.check_errors()
+        shortrange.by_receiver_meshes.clear()
 
     def _rung_integral_times(self, driftkick_index, rung_index, Δt, sync_time):
         """(index into ᔑdt_rungs, t_start, t_end) of the integrals rung `rung_index` needs in

@@ -175,6 +175,8 @@ int cg_gather_kick_tiled_prepare(cg_ctx *ctx, const double *pos /*DEV 3n*/,
  *                        outside the tile it is stored under is not kicked and sets
  *                        CG_ERR_NOT_IN_TILE.  On x-slab domains see below. */
 #define CG_ERR_BUCKET_OVERFLOW 2u
+#define CG_ERR_ACTIVE_OVERFLOW 8u /* cg_shortrange_sweep_cells_active: more active receivers than
+                                   * n_active_max; those beyond it were not swept */
 #define CG_ERR_NOT_IN_TILE 4u /* cg_gather_kick_drift_scatter met a particle outside the tile it
                                  is stored under (positions changed since the order was made):
                                  not kicked; repeat the step on the exact path */

@@ -792,6 +792,14 @@ def test_active_first_cell_list_and_its_sweep(nt_box):
         ref2 = base.clone()
         mesh.shortrange_sweep_cells(plain_r, ref2, plain_r, nt, table, 4095/maxr2, rng_**2, 1.3)
         assert float((got2 - ref2).abs().max()) <= 1e-12*float((ref2 - base).pow(2).mean().sqrt())
+        # a bound below the number of active receivers: the flag is raised, not a silent loss
+        if la == 1:
+            short = base.clone()
+            mesh.shortrange_sweep_cells(act_r, short, cs, nt, table, 4095/maxr2, rng_**2, 0.0,
+                                        (factors, rung_t, jumped_t, la), int((rung >= la).sum()) - 5)
+            with pytest.raises(ConceptGPUError, match='more receivers on active rungs'):
+                mesh.check_errors()
+            assert mesh.error_flags() == 0          # (read and cleared)
         # a list made for other rungs is refused
         with pytest.raises(ConceptGPUError, match='other rungs'):
             mesh.shortrange_sweep_cells(act_r, got, cs, nt, table, 4095/maxr2, rng_**2, 0.0,
