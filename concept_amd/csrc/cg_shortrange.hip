@@ -181,24 +181,33 @@ __global__ __launch_bounds__(256) void k_sr_cell_count(const double *__restrict_
     const i64 base = (i64)blockIdx.x * (256 * kSrPerThread);
     unsigned slot[kSrPerThread], rank[kSrPerThread], cell[kSrPerThread];
     bool act[kSrPerThread];
+    int r_after[kSrPerThread];
+    // (first the four particles' own work — their loads are in flight together — then the table:
+    // its compare-and-swap loops would otherwise stand between one particle's loads and the next's)
 #pragma unroll
     for (int u = 0; u < kSrPerThread; u++) {
         const i64 p = base + threadIdx.x + 256 * u;
         slot[u] = rank[u] = cell[u] = 0, act[u] = false;
-        int r_after = 255;
+        r_after[u] = 255;
         if (p < n) {
             double x, y, z;
-            if (BEGIN) r_after = cg_substep_begin_particle(B, p, x, y, z);
+            if (BEGIN) r_after[u] = cg_substep_begin_particle(B, p, x, y, z);
             else x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
             cell[u] = sr_cell_of(x, y, z, inv, ext, nt);
-            slot[u] = sr_hash_slot(H, cell[u]);
             if constexpr (ACT) act[u] = A.rung[p] >= A.lowest;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kSrPerThread; u++) {
+        const i64 p = base + threadIdx.x + 256 * u;
+        if (p < n) {
+            slot[u] = sr_hash_slot(H, cell[u]);
             bool taken = false;
             if constexpr (ACT)
                 if (act[u]) rank[u] = atomicAdd(&H.act[slot[u]], 1u), taken = true;
             if (!taken) rank[u] = atomicAdd(&H.cnt[slot[u]], 1u);
         }
-        if (BEGIN && B.partial) cg_count_rungs(r_after, B.N_rungs, s_cnt);
+        if (BEGIN && B.partial) cg_count_rungs(r_after[u], B.N_rungs, s_cnt);
     }
     __syncthreads();
     if (BEGIN && B.partial && threadIdx.x < (unsigned)B.N_rungs)
@@ -1234,14 +1243,16 @@ __global__ __launch_bounds__(256) void k_sr_sweep_active_cells(
     const unsigned *__restrict__ off_r, double *__restrict__ dmom_r,
     const double *__restrict__ pos_s, const unsigned *__restrict__ off_s,
     const double *__restrict__ table, SrParams P, const unsigned *__restrict__ list,
-    const unsigned *__restrict__ rows, const unsigned *__restrict__ nlist) {
+    const unsigned *__restrict__ rows, const unsigned *__restrict__ nlist, unsigned cap) {
     __shared__ unsigned r_beg[4][kSaRuns], r_cnt[4][kSaRuns];
     __shared__ int r_img[4][kSaRuns];  // the run's image: (ox + 1) | (oy + 1) << 2 | (oz + 1) << 4
     __shared__ unsigned r_pre[4][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned idx = blockIdx.x * 4u + (unsigned)wave;
-    if (idx >= __builtin_amdgcn_readfirstlane((int)*nlist)) return;  // (no barrier below)
+    // (no barrier below; the count may exceed the list's room — CG_ERR_ACTIVE_OVERFLOW — the list
+    // holds the first `cap`)
+    if (idx >= min((unsigned)__builtin_amdgcn_readfirstlane((int)*nlist), cap)) return;
     const unsigned cell = (unsigned)__builtin_amdgcn_readfirstlane((int)list[idx]);
     const int nt = P.nt, nc = 2 * nt;
     const int Z = (int)(cell % (unsigned)nc), Y = (int)((cell / (unsigned)nc) % (unsigned)nc),
@@ -1460,7 +1471,7 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
             hipLaunchKernelGGL(P.stats ? k_sr_sweep_active_cells<true> : k_sr_sweep_active_cells<false>,
                                dim3((unsigned)((n_active_max + 3) / 4)), dim3(256), 0, c->stream,
                                pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P,
-                               list, rows, count);
+                               list, rows, count, (unsigned)n_active_max);
             CG_LAUNCH_CHECK();
         }
         if (take && cgk_shortrange_dense_join(c)) return 1;
