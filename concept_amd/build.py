@@ -25,19 +25,28 @@ FLAGS = [
 ]
 
 
+def _code_only(text):
+    """the source text without comments and with white space collapsed: what the compiler sees"""
+    import re
+    pattern = r'("(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])*\')|//[^\n]*|/\*.*?\*/'
+    text = re.sub(pattern, lambda m: m.group(1) or ' ', text, flags=re.S)
+    return ' '.join(text.split())
+
+
 def source_hash():
-    """sha256 over the sources libconcept_gpu.so is built from (csrc/*.hip, *.h, the C ABI header
-    and the compiler flags): written beside the library at build time (libconcept_gpu.so.srchash)
-    and stamped into profiles/*_pmc_hbm_traffic.json by tools/pmc_traffic.py, so that bench.py
-    can tell whether a committed counter run describes the kernels it is timing."""
+    """sha256 over the CODE libconcept_gpu.so is built from (csrc/*.hip, *.h and the C ABI header
+    without their comments, and the compiler flags): written beside the library at build time
+    (libconcept_gpu.so.srchash) and stamped into profiles/*_pmc_hbm_traffic.json by
+    tools/pmc_traffic.py, so that bench.py can tell whether a committed counter run describes the
+    kernels it is timing (a reworded comment does not make it a different library)."""
     import hashlib
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
                    if f.endswith(('.hip', '.h'))) + [HEADERS[-1]]
     for f in files:
         h.update(os.path.basename(f).encode())
-        with open(f, 'rb') as fh:
-            h.update(fh.read())
+        with open(f, 'r', encoding='utf-8') as fh:
+            h.update(_code_only(fh.read()).encode())
     h.update(' '.join(FLAGS[:7]).encode())
     return h.hexdigest()[:16]
 

@@ -8,8 +8,8 @@
 // Form: one-sided.  The reference visits every unordered pair once and updates
 // both partners (Δmom_r += r*f, Δmom_s -= r*f); here every receiver particle
 // sums over all its partners itself — twice the arithmetic, but no atomics, no
-// write conflicts (the order of partners inside a cell follows the cell-list
-// scatter, so sums are reproducible to rounding, not bit for bit).  The pair
+// write conflicts (the order of partners inside a cell follows the cell list's
+// atomics, so sums are reproducible to rounding, not bit for bit).  The pair
 // vector, r2 and the table index are evaluated with the reference's expression
 // and operation order ((xi - xj) + offset; x*x + y*y + z*z; int(r2*scaling)):
 // exact negation symmetry makes the two directions of a pair bit-consistent.
@@ -110,9 +110,9 @@ __device__ __forceinline__ unsigned sr_cell_of(double x0, double x1, double x2, 
     return (c[0] * nc + c[1]) * nc + c[2];
 }
 
-// The cell list is a counting sort by cell: a histogram, a scan, a scatter.  Device-scope
-// atomics execute memory-side on MI355X (2^31 of them take 77 ms): one per particle, twice, was
-// most of the list's time.  Particle memory is in mesh-tile order (16^3 mesh cells), so the 1024
+// The cell list is a counting sort by cell: a counting pass, a scan, a placing pass.  Device-scope
+// atomics execute memory-side on MI355X (2^31 of them take 77 ms): one per particle was most of
+// the list's time.  Particle memory is in mesh-tile order (16^3 mesh cells), so the 1024
 // consecutive particles a workgroup takes fall into a few hundred short-range cells at most:
 // they are counted in an LDS hash table first (key -> slot by open addressing, the slot's counter
 // hands every particle its rank among the workgroup's particles of that cell), and the
