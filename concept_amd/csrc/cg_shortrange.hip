@@ -670,8 +670,9 @@ __global__ __launch_bounds__(256) void k_sr_tile_activity(const unsigned *__rest
 // ===========================================================================
 // Two shapes: BX = 4 (4 x 2 tiles, 1024 lanes, the table in LDS) and BX = 2 (2 x 2 tiles, 512
 // lanes, 8 x 8 columns, 1056 suppliers on average, 35 KB of LDS, the table where it is) — the
-// latter for the sub-steps that kick the upper rungs only (lowest_active > 0), where most tiles
-// have no receiver on an active rung and what a block costs before its first pair decides
+// latter for the sub-steps that kick the upper rungs only (lowest_active > 0) from the plain list,
+// where most tiles have no receiver on an active rung and what a block costs before its first pair
+// decides
 // (tools/soak_p3m.py, 30 base steps of the P3M loop with 8 rungs at 256^3 / 512^3: 2.95 s with
 // 4 x 2 blocks for every sweep, 2.76 s with 2 x 2 for the sub-steps — provided its instantiation
 // with rungs stays within 64 registers: at 67, seven wavefronts per SIMD, it took 2.95 s too), and
@@ -681,14 +682,14 @@ constexpr int kSbColsY = 2 * kSbY + 4;                   // staged columns along
 constexpr int kSbTable = 4096;                           // table entries that fit into LDS
 constexpr int sb_cols(int bx) { return (2 * bx + 4) * kSbColsY; }   // 12 x 8 = 96 | 8 x 8 = 64
 constexpr int sb_waves(int bx) { return (2 * bx) * (2 * kSbY) / 2; }  // groups / 2: 16 | 8
-// suppliers staged per window (mean 1584 | 1056 at 22 per tile; more take further windows)
-constexpr int sb_cap(int bx) { return bx == 4 ? 1856 : 1344; }
+// suppliers staged per window (mean 1584 | 1056 at 22 per tile; more take further windows; 1824:
+// with the group tables of the active-first form two workgroups still fit a CU's 160 KB)
+constexpr int sb_cap(int bx) { return bx == 4 ? 1824 : 1344; }
 // (WRAP: one more staged double per supplier, and every column in two pieces)
 constexpr size_t sb_lds_bytes(int bx, bool tab, bool wrap) {
     return sizeof(double) * ((wrap ? 4 : 3) * (sb_cap(bx) + kSrSlack) + (tab ? kSbTable : 0)) +
-           // (the 4 x 2 blocks with the table: 81,792 B — two workgroups fill a CU's 160 KB to
-           // within 256 B; the sub-steps' group tables are the 2 x 2 blocks' alone)
-           sizeof(unsigned) * ((wrap ? 8 : 3) * sb_cols(bx) + (bx == 2 ? 8 : 4) * sb_waves(bx));
+           // (the 4 x 2 blocks with the table: 81,280 B — two workgroups per CU)
+           sizeof(unsigned) * ((wrap ? 8 : 3) * sb_cols(bx) + 8 * sb_waves(bx));
 }
 // Which tiles a workgroup takes.  Plain: the block (bx, by) of the interior's (nt - 2)^2 tiles
 // in x and y, tile tc of its nt - 2 in z.  WRAP: the tiles on the faces of the box in blocks of
@@ -762,9 +763,8 @@ k_sr_sweep_blocks(const double *__restrict__ pos_r, const unsigned *__restrict__
            *stab = soz + (WRAP ? kLen : 0);
     unsigned *p_beg = (unsigned *)(stab + (TABLDS ? kSbTable : 0)), *p_cnt = p_beg + kPieces,
              *p_off = p_cnt + kPieces, *grp_n = p_off + kPieces, *grp_b = grp_n + 2 * kSbWaves,
-             *grp_n0 = grp_b + 2 * kSbWaves, *grp_gap = grp_n0 + 2 * kSbWaves;  // (ACT: BX = 2)
+             *grp_n0 = grp_b + 2 * kSbWaves, *grp_gap = grp_n0 + 2 * kSbWaves;  // (ACT)
     int *p_oz = (int *)(grp_gap + 2 * kSbWaves);  // (WRAP) a piece's image in z: -1, 0, +1 boxes
-    static_assert(RUNGS != 2 || BX == 2, "the active-first lists are swept in 2 x 2 blocks");
     constexpr bool ACT = RUNGS == 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1383,10 +1383,7 @@ static SbKernel sb_kernel(int mode, bool stats) {
         case 0: return stats ? k_sr_sweep_blocks<BX, 0, true, TABLDS, WRAP> : k_sr_sweep_blocks<BX, 0, false, TABLDS, WRAP>;
         case 1: return stats ? k_sr_sweep_blocks<BX, 1, true, TABLDS, WRAP> : k_sr_sweep_blocks<BX, 1, false, TABLDS, WRAP>;
         default:
-            if constexpr (BX == 2)  // (the sub-steps' shape)
-                return stats ? k_sr_sweep_blocks<BX, 2, true, TABLDS, WRAP> : k_sr_sweep_blocks<BX, 2, false, TABLDS, WRAP>;
-            else
-                return nullptr;
+            return stats ? k_sr_sweep_blocks<BX, 2, true, TABLDS, WRAP> : k_sr_sweep_blocks<BX, 2, false, TABLDS, WRAP>;
     }
 }
 
@@ -1490,7 +1487,11 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
     {
         // 4 x 2 tiles per workgroup; 2 x 2 for the sub-steps of the upper rungs and for boxes of
         // fewer than 6 tiles a side
-        const bool small = m < 4 || partial;
+        // (an active-first list is swept in blocks only when many receivers are active — the
+        // sparse sub-steps go receiver by receiver — and then the 4 x 2 shape wins as it does for a
+        // full sweep: 4.7 against 5.2 ms with half the receivers active, 3.8 against 4.1 with a
+        // quarter)
+        const bool small = m < 4 || (partial && !act);
         const bool lds = !small && P.table_n <= kSbTable;
         const int bx = small ? 2 : 4;
         const unsigned nbx = (m + bx - 1) / bx, nby = (m + kSbY - 1) / kSbY;
