@@ -402,7 +402,7 @@ __device__ __forceinline__ void sr_cell_batch(int k, int S, int b, double xi, do
             yj[j] += kj < w.ys ? oyA : oyB;
             zj[j] += soz[kj];
         }
-        r2[j] = xj[j] * xj[j] + yj[j] * yj[j] + zj[j] * zj[j];  // gravity.py:306
+        r2[j] = sr_r2(xj[j], yj[j], zj[j]);  // gravity.py:306
         hit[j] = r2[j] <= r2_max;                        // gravity.py:311: skip r2 > r2_max
         if (MASK) hit[j] &= kj < b;                      // (read past the range: staged slack)
         if (STATS) {
@@ -455,7 +455,7 @@ __device__ __forceinline__ void sr_cell_straddle(int pos, int rem, int na, int n
             yj[j] += kj < (here ? w.ys : wn.ys) ? oyA : oyB;
             zj[j] += soz[kj];
         }
-        r2[j] = xj[j] * xj[j] + yj[j] * yj[j] + zj[j] * zj[j];
+        r2[j] = sr_r2(xj[j], yj[j], zj[j]);
         hit[j] = r2[j] <= r2_max && valid;
         if (STATS) {
             cnt.tests += (unsigned)__popcll(__ballot(counted && valid));
@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_sr_sparse(const double *__restrict__ po
             x = x + (x > half ? -L : (x < -half ? L : 0.0));       // + the image's offset
             y = y + (y > half ? -L : (y < -half ? L : 0.0));
             z = z + (z > half ? -L : (z < -half ? L : 0.0));
-            const double r2 = x * x + y * y + z * z;               // gravity.py:306
+            const double r2 = sr_r2(x, y, z);               // gravity.py:306
             if (r2 <= P.r2_max) {                                   // gravity.py:311
                 const double t = table[(unsigned)(int)(r2 * P.r2_index_scaling)];
                 acc[r][0] = __builtin_fma(x, t, acc[r][0]);
@@ -1330,7 +1330,7 @@ __global__ __launch_bounds__(256) void k_sr_sweep_active_cells(
                 x = (xi - pos_s[3 * g]) + ox;          // interactions.py:1787-1789,
                 y = (yi - pos_s[3 * g + 1]) + oy;      // gravity.py:299-302
                 z = (zi - pos_s[3 * g + 2]) + oz;
-                const double r2 = x * x + y * y + z * z;   // gravity.py:306
+                const double r2 = sr_r2(x, y, z);   // gravity.py:306
                 hit = r2 <= P.r2_max;                      // gravity.py:311
                 if (hit) tv = table[(unsigned)(int)(r2 * P.r2_index_scaling)];
             }

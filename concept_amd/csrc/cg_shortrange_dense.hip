@@ -33,6 +33,7 @@
 #include <cstring>
 
 #include "cg_internal.h"
+#include "cg_tiles.h"
 
 #define CG_LAUNCH_CHECK()                                                                     \
     do {                                                                                      \
@@ -428,7 +429,7 @@ __device__ __forceinline__ void srd_quads(const SrdShared &S, const int (&q)[NB]
             yj[k] += (double)((int)((im >> 2) & 3) - 1) * boxsize;
             zj[k] += (double)((int)((im >> 4) & 3) - 1) * boxsize;
         }
-        r2[k] = xj[k] * xj[k] + yj[k] * yj[k] + zj[k] * zj[k];  // gravity.py:306
+        r2[k] = sr_r2(xj[k], yj[k], zj[k]);  // gravity.py:306
         hit[k] = r2[k] <= r2_max;                        // gravity.py:311
         if (STATS) {
             // a row of padding (the rest of a last quad, the far quad) sits at 1e300
