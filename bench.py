@@ -1491,7 +1491,7 @@ def pair_sweep_roofline(st, ms, kernel, cell_offsets=None, nt=None):
     tests = st['cells'][0] + st['dense'][0]
     hits = st['cells'][1] + st['dense'][1]
     trips = st['cells'][2] + st['dense'][2]
-    per_test = 12   # 3 sub, 3 mul, 2 add, 1 cmp, 3 fma
+    per_test = 10   # 3 sub, 1 mul + 2 fma (r2), 1 cmp, 3 fma
     dense_tiles = dense_receivers = None
     if cell_offsets is not None:
         # the receivers the dense tiles' sweep took: populations of the tiles from the cell list
