@@ -249,7 +249,12 @@ __global__ __launch_bounds__(256) void k_sr_cell_place(const double *__restrict_
                                                        signed char *__restrict__ rj_sorted) {
     // (four particles per thread, every load of the four issued before the first store: the
     // chain cell -> the cell's offset -> the row's address is waited for once, not four times)
-    const i64 base = (i64)blockIdx.x * (256 * kSrPerThread);
+    // Workgroups are handed to the eight XCDs in turn; the rows of consecutive stretches of
+    // particles share lines of the sorted arrays (a cell's particles sit together in the store's
+    // tile order), and a line written from two L2s goes out twice, partially: an XCD takes a
+    // contiguous eighth of the particles (grid: a multiple of 8).
+    const unsigned per_xcd = gridDim.x >> 3;
+    const i64 base = (i64)((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * (256 * kSrPerThread);
     uint2 cr[kSrPerThread];
     double x[kSrPerThread], y[kSrPerThread], z[kSrPerThread];
     i64 q[kSrPerThread];
@@ -344,7 +349,7 @@ int cgk_shortrange_cells(cg_ctx *c, const double *pos, i64 n, i64 nt, double til
                                             c->stream));
     if (n > 0) {
         hipLaunchKernelGGL(act ? k_sr_cell_place<true> : k_sr_cell_place<false>,
-                           dim3((unsigned)blocks), dim3(256), 0, c->stream, pos, n,
+                           dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, c->stream, pos, n,
                            offset, cellrel, order, pos_sorted, A, nact, rj_sorted);
         CG_LAUNCH_CHECK();
     }
@@ -1249,10 +1254,16 @@ __global__ __launch_bounds__(256) void k_sr_sweep_active_cells(
     __shared__ unsigned r_pre[4][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned idx = blockIdx.x * 4u + (unsigned)wave;
     // (no barrier below; the count may exceed the list's room — CG_ERR_ACTIVE_OVERFLOW — the list
     // holds the first `cap`)
-    if (idx >= min((unsigned)__builtin_amdgcn_readfirstlane((int)*nlist), cap)) return;
+    const unsigned nrec = min((unsigned)__builtin_amdgcn_readfirstlane((int)*nlist), cap);
+    // Neighbours on the list read the same supplier runs: an XCD (workgroup b runs on XCD b % 8)
+    // takes a contiguous eighth of the receivers, so that its L2 serves them — dealt out in turn,
+    // each of the eight L2s fetched every run
+    const unsigned per_xcd = ((nrec + 3u) / 4u + 7u) / 8u;
+    if ((blockIdx.x >> 3) >= per_xcd) return;
+    const unsigned idx = ((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * 4u + (unsigned)wave;
+    if (idx >= nrec) return;
     const unsigned cell = (unsigned)__builtin_amdgcn_readfirstlane((int)list[idx]);
     const int nt = P.nt, nc = 2 * nt;
     const int Z = (int)(cell % (unsigned)nc), Y = (int)((cell / (unsigned)nc) % (unsigned)nc),
@@ -1263,6 +1274,9 @@ __global__ __launch_bounds__(256) void k_sr_sweep_active_cells(
         return;
     // the runs: slot = column (dx, dy) of the 5 x 5, + 25 for the piece beyond a z face
     const bool zwrap = Z < 2 || Z + 2 >= nc;  // (uniform)
+    // (uniform) does any of the receiver's runs lie beyond a face of the box?  (17 of a trip's
+    // ~70 vector instructions turn the image bits into offsets; 6 % of the cells need them)
+    const bool faces = zwrap || X < 2 || X + 2 >= nc || Y < 2 || Y + 2 >= nc;
     if (lane < kSaRuns) {
         const int half = lane >= 25, col = lane - 25 * half;
         unsigned beg = 0, cnt = 0;
@@ -1309,39 +1323,75 @@ __global__ __launch_bounds__(256) void k_sr_sweep_active_cells(
         const i64 o = 3 * (i64)order_r[row];
         const double f = P.factors[P.rj_sorted ? P.rj_sorted[row] : P.rung_jumped[o / 3]];  // gravity.py:318-349
         double ax = 0, ay = 0, az = 0;
-        // (a lane's loads of several trips issued together before the first is used — 126
-        // registers, four wavefronts per SIMD — measured slower than a trip at a time at eight)
-        for (unsigned t0 = 0; t0 < total; t0 += 64) {
-            const unsigned t = t0 + (unsigned)lane;
-            const bool valid = t < total;
-            // the run of supplier t: the last s with r_pre[s] <= t
-            int sl = 0;
+        // One trip = 64 suppliers: the lane's run (six LDS reads one behind the other), its
+        // supplier's row (a round trip to memory), the look-up of a pair in range (another) — a
+        // wavefront spent its time waiting for them in turn.  Two trips go together (their chains
+        // side by side), and the rows of the NEXT two are asked for before this pair's look-ups
+        // are waited for; a lane beyond the end reads the last supplier and counts for nothing.
+        // (All trips' loads issued together — 126 registers, four wavefronts per SIMD — measured
+        // slower than a trip at a time at eight.)
+        struct Row { double x, y, z; int sl; bool valid; };
+        auto ask = [&](unsigned t0, Row &ra, Row &rb) {
+            const unsigned ta = t0 + (unsigned)lane, tb = ta + 64u;
+            ra.valid = ta < total, rb.valid = tb < total;
+            const unsigned ua = min(ta, total - 1u), ub = min(tb, total - 1u);
+            // the runs of the two suppliers: the last s with r_pre[s] <= t (side by side)
+            int sa = 0, sb = 0;
 #pragma unroll
-            for (int step = 32; step > 0; step >>= 1)
-                if (r_pre[wave][sl + step] <= t) sl += step;   // (entries beyond the runs hold the total)
-            sl = min(sl, kSaRuns - 1);
-            double tv = 0.0, x = 0, y = 0, z = 0;
-            bool hit = false;
-            if (valid) {
-                const i64 g = (i64)r_beg[wave][sl] + (t - r_pre[wave][sl]);
-                const int img = r_img[wave][sl];
-                const double ox = (double)((img & 3) - 1) * L, oy = (double)((img >> 2 & 3) - 1) * L,
-                             oz = (double)((img >> 4 & 3) - 1) * L;
-                x = (xi - pos_s[3 * g]) + ox;          // interactions.py:1787-1789,
-                y = (yi - pos_s[3 * g + 1]) + oy;      // gravity.py:299-302
-                z = (zi - pos_s[3 * g + 2]) + oz;
-                const double r2 = sr_r2(x, y, z);   // gravity.py:306
-                hit = r2 <= P.r2_max;                      // gravity.py:311
-                if (hit) tv = table[(unsigned)(int)(r2 * P.r2_index_scaling)];
+            for (int step = 32; step > 0; step >>= 1) {
+                const unsigned pa = r_pre[wave][sa + step], pb = r_pre[wave][sb + step];
+                if (pa <= ua) sa += step;   // (entries beyond the runs hold the total)
+                if (pb <= ub) sb += step;
             }
-            if (STATS) {
-                cnt.tests += (unsigned)__popcll(__ballot(valid));
-                cnt.hits += (unsigned)__popcll(__ballot(hit));
-                cnt.trips++;
+            sa = min(sa, kSaRuns - 1), sb = min(sb, kSaRuns - 1);
+            const i64 ga = (i64)r_beg[wave][sa] + (ua - r_pre[wave][sa]),
+                      gb = (i64)r_beg[wave][sb] + (ub - r_pre[wave][sb]);
+            ra.x = pos_s[3 * ga], ra.y = pos_s[3 * ga + 1], ra.z = pos_s[3 * ga + 2];
+            rb.x = pos_s[3 * gb], rb.y = pos_s[3 * gb + 1], rb.z = pos_s[3 * gb + 2];
+            ra.sl = sa, rb.sl = sb;
+        };
+        if (total) {
+            Row c0, c1;
+            ask(0, c0, c1);
+            for (unsigned t0 = 0; t0 < total; t0 += 128) {
+                Row n0, n1;
+                ask(t0 + 128, n0, n1);
+                double x[2], y[2], z[2], r2[2], tv[2];
+                bool hit[2];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const Row &c = j ? c1 : c0;
+                    x[j] = xi - c.x;                   // interactions.py:1787-1789
+                    y[j] = yi - c.y;
+                    z[j] = zi - c.z;
+                    if (faces) {                       // gravity.py:299-302 (elsewhere: + 0)
+                        const int img = r_img[wave][c.sl];
+                        x[j] += (double)((img & 3) - 1) * L;
+                        y[j] += (double)((img >> 2 & 3) - 1) * L;
+                        z[j] += (double)((img >> 4 & 3) - 1) * L;
+                    }
+                    r2[j] = sr_r2(x[j], y[j], z[j]);       // gravity.py:306
+                    hit[j] = c.valid && r2[j] <= P.r2_max; // gravity.py:311
+                    if (STATS) {
+                        const bool any = __builtin_amdgcn_readfirstlane((int)(t0 + 64u * j < total));
+                        cnt.tests += (unsigned)__popcll(__ballot(c.valid));
+                        cnt.hits += (unsigned)__popcll(__ballot(hit[j]));
+                        cnt.trips += any ? 1u : 0u;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    tv[j] = 0.0;
+                    if (hit[j]) tv[j] = table[(unsigned)(int)(r2[j] * P.r2_index_scaling)];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    ax = __builtin_fma(x[j], tv[j], ax);
+                    ay = __builtin_fma(y[j], tv[j], ay);
+                    az = __builtin_fma(z[j], tv[j], az);
+                }
+                c0 = n0, c1 = n1;
             }
-            ax = __builtin_fma(x, tv, ax);
-            ay = __builtin_fma(y, tv, ay);
-            az = __builtin_fma(z, tv, az);
         }
         // the wave's lanes added in a fixed order (DPP: rows of 16, then the row totals)
         auto wave_sum = [](double v) {
@@ -1466,8 +1516,8 @@ int cgk_shortrange_sweep_cells(cg_ctx *c, const double *pos_r_sorted, const unsi
                                (unsigned)n_active_max, c->err_flags);
             CG_LAUNCH_CHECK();
             hipLaunchKernelGGL(P.stats ? k_sr_sweep_active_cells<true> : k_sr_sweep_active_cells<false>,
-                               dim3((unsigned)((n_active_max + 3) / 4)), dim3(256), 0, c->stream,
-                               pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P,
+                               dim3((unsigned)(((n_active_max + 3) / 4 + 7) / 8 * 8)), dim3(256), 0,
+                               c->stream, pos_r_sorted, order_r, off_r, dmom_r, pos_s_sorted, off_s, table, P,
                                list, rows, count, (unsigned)n_active_max);
             CG_LAUNCH_CHECK();
         }
